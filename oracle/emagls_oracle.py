@@ -1,0 +1,482 @@
+"""CPU oracle: literal FP64 NumPy restatement of the eMagLS reference hot path.
+
+THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import it; the product (emagls_amd/) never does and fails loudly without its HIP library.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).
+The reference is MATLAB and cannot run in this container or on the GPU box (no matlab/octave), so
+the oracle is pinned against the reference's own shipped golden filter sets
+(resources/HRIR_L2702_512samples_32channels_sh4_*.mat -> tests/golden/ref_fixtures.npz) through
+the fixture-internal known-answer tests in tests/test_oracle_kats.py.  Their input
+(resources/HRIR_L2702.mat, Zenodo 3928297) is not shipped, therefore END-TO-END PARITY TO 1e-6 IS
+UNPINNED: the KATs pin the SH convention, ACN order, Condon-Shortley phase, the real<->complex
+relation, getShFreqDomainConjugate's semantics, window end points, delay bookkeeping and (to
+discrimination level, ~5 %) the rigid-sphere modal coefficients -- not the tap values.
+
+Third-party arithmetic that is NOT under /root/reference (empty git submodules, .gitmodules:1-9,
+pinned SHAs unrecoverable) is restated from the published algorithms:
+  * getSH                     polarch/Spherical-Harmonic-Transform  (orthonormal SH, ACN, [azi zen])
+  * sphModalCoeffs            polarch/Array-Response-Simulator      (b_n(kr), rigid sphere)
+  * getShFreqDomainConjugate  thomasdeppisch/sh-symmetries
+and MathWorks built-ins (pinv, svd, grpdelay, hann, fftfilt, median, angle) from their documented
+behaviour.  Array layout follows MATLAB: hL is [numSamples x numDirections], filters [len x C].
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import scipy.special as sps
+
+C_SOUND = 343.0  # dependencies/getSMAIRMatrix.m:86
+NFFT_MAX_LEN = 2048  # lib/getEMagLsFilters.m:35
+F_CUT_MIN_FREQ = 1e3  # lib/getEMagLsFilters.m:36
+SVD_REGUL_CONST = 0.01  # lib/getEMagLsFilters.m:39
+
+
+# --------------------------------------------------------------------------------------------
+# third-party restatements
+# --------------------------------------------------------------------------------------------
+def getSH(N, dirs, basisType="real"):
+    """Orthonormal spherical harmonics, rows = directions, columns = ACN (n^2+n+m).
+
+    Restates polarch getSH (call sites lib/getLsFilters.m:30, lib/getEMagLsFilters.m:68,
+    dependencies/getSMAIRMatrix.m:101).  dirs = [azimuth, zenith] in radians.  Convention is the
+    one stated in-tree by dependencies/getNnm.m:20-28 + dependencies/getCH.m:22-27:
+      complex: Y_n^m = N_n^m P_n^m(cos zen) e^{i m azi}, Condon-Shortley inside P (MATLAB legendre),
+               Y_n^{-m} = (-1)^m conj(Y_n^m);
+      real:    Condon-Shortley cancelled; m<0 -> sqrt2 N P^{|m|} sin(|m| azi), m>0 -> sqrt2 N P^m cos(m azi).
+    """
+    dirs = np.asarray(dirs, dtype=np.float64)
+    azi = dirs[:, 0]
+    zen = dirs[:, 1]
+    D = dirs.shape[0]
+    x = np.cos(zen)
+    cplx = basisType == "complex"
+    if not cplx and basisType != "real":
+        raise ValueError("basisType must be 'real' or 'complex'")
+    Y = np.zeros((D, (N + 1) ** 2), dtype=np.complex128 if cplx else np.float64)
+    for n in range(N + 1):
+        m = np.arange(0, n + 1)
+        # MATLAB legendre(n, x): unnormalised P_n^m with Condon-Shortley phase == scipy lpmv
+        Lnm = sps.lpmv(m[:, None], n, x[None, :])  # (n+1) x D
+        lg = sps.gammaln(n - m + 1) - sps.gammaln(n + m + 1)
+        norm = np.sqrt((2 * n + 1) / (4 * np.pi) * np.exp(lg))  # sqrt((2n+1)(n-m)!/(4pi (n+m)!))
+        if cplx:
+            Ypos = (norm[:, None] * Lnm) * np.exp(1j * m[:, None] * azi[None, :])
+            for mm in range(0, n + 1):
+                Y[:, n * n + n + mm] = Ypos[mm]
+                if mm > 0:
+                    Y[:, n * n + n - mm] = (-1) ** mm * np.conj(Ypos[mm])
+        else:
+            for mm in range(0, n + 1):
+                base = norm[mm] * ((-1) ** mm) * Lnm[mm]  # cancel Condon-Shortley
+                if mm == 0:
+                    Y[:, n * n + n] = base
+                else:
+                    Y[:, n * n + n + mm] = base * (math.sqrt(2.0) * np.cos(mm * azi))
+                    Y[:, n * n + n - mm] = base * (math.sqrt(2.0) * np.sin(mm * azi))
+    return Y
+
+
+def _sph_besselj(n, x):
+    return sps.spherical_jn(n, x)
+
+
+def _dsph_besselj(n, x):
+    return sps.spherical_jn(n, x, derivative=True)
+
+
+def _sph_hankel2(n, x):
+    return sps.spherical_jn(n, x) - 1j * sps.spherical_yn(n, x)
+
+
+def _dsph_hankel2(n, x):
+    return sps.spherical_jn(n, x, derivative=True) - 1j * sps.spherical_yn(n, x, derivative=True)
+
+
+def sphModalCoeffs(N, kr, arrayType="rigid", dirCoeff=0.0):
+    """Modal coefficients b_n(kr), [len(kr) x (N+1)] (polarch sphModalCoeffs; call site
+    dependencies/getSMAIRMatrix.m:107).  rigid: 4 pi i^n (j_n - j_n'/h_n^(2)' h_n^(2)),
+    open: 4 pi i^n j_n.  kr == 0 -> [4 pi, 0, 0, ...]; NaN (huge orders) -> 0.
+    Sign / conjugation / scale are pinned (to ~5 %) by the cross-fixture physics KAT."""
+    kr = np.asarray(kr, dtype=np.float64).ravel()
+    b = np.zeros((kr.size, N + 1), dtype=np.complex128)
+    nz = kr != 0
+    x = kr[nz]
+    for n in range(N + 1):
+        if arrayType == "open":
+            t = 4 * np.pi * (1j ** n) * _sph_besselj(n, x)
+        elif arrayType == "rigid":
+            with np.errstate(all="ignore"):
+                jn = _sph_besselj(n, x)
+                jnp_ = _dsph_besselj(n, x)
+                hn = _sph_hankel2(n, x)
+                hnp = _dsph_hankel2(n, x)
+                t = 4 * np.pi * (1j ** n) * (jn - (jnp_ / hnp) * hn)
+        else:
+            raise ValueError("arrayType must be 'rigid' or 'open'")
+        b[nz, n] = t
+        b[~nz, n] = 4 * np.pi if n == 0 else 0.0
+    b[np.isnan(b)] = 0
+    return b
+
+
+def getShFreqDomainConjugate(Wpos):
+    """Positive-frequency half [P x C] (complex-SH filters) -> full spectrum [nfft x C],
+    nfft = 2(P-1), such that the time-domain filters obey w_{n,-m} = (-1)^m conj(w_{n,m}):
+    W(nfft-k,(n,m)) = (-1)^m conj(W(k,(n,-m))), k = 1..P-2 (call sites lib/getMagLsFilters.m:78-79,
+    lib/getEMagLsFilters.m:118-119; semantics pinned by the fixture symmetry KAT)."""
+    Wpos = np.asarray(Wpos)
+    P, C = Wpos.shape
+    N = int(round(math.sqrt(C))) - 1
+    assert (N + 1) ** 2 == C
+    neg = np.empty((P - 2, C), dtype=np.complex128)
+    for n in range(N + 1):
+        for m in range(-n, n + 1):
+            neg[:, n * n + n + m] = (-1) ** m * np.conj(Wpos[1 : P - 1, n * n + n - m])
+    return np.vstack([Wpos, neg[::-1]])
+
+
+# --------------------------------------------------------------------------------------------
+# MathWorks built-ins
+# --------------------------------------------------------------------------------------------
+def pinv(A):
+    """MATLAB pinv: SVD, tol = max(size(A)) * eps(norm(A))."""
+    U, s, Vh = np.linalg.svd(A, full_matrices=False)
+    tol = max(A.shape) * np.spacing(s[0])
+    r = int(np.sum(s > tol))
+    return (Vh[:r].conj().T / s[:r]) @ U[:, :r].conj().T
+
+
+def hann(N):
+    """MATLAB hann(N) (symmetric): 0.5 (1 - cos(2 pi n/(N-1)))."""
+    if N == 1:
+        return np.ones(1)
+    n = np.arange(N)
+    return 0.5 * (1 - np.cos(2 * np.pi * n / (N - 1)))
+
+
+def grpdelay_fir(b, nfft_half_plus1):
+    """grpdelay(b,1,f,fs) for FIR b at f = linspace(0, fs/2, P): Re{sum n b[n] z^-n / sum b[n] z^-n},
+    bins with |den| < 10 eps -> 0 (call site lib/getEMagLsFilters.m:74-75)."""
+    b = np.asarray(b, dtype=np.float64).ravel()
+    P = nfft_half_plus1
+    w = np.pi * np.arange(P) / (P - 1)
+    n = np.arange(b.size)
+    E = np.exp(-1j * np.outer(w, n))
+    den = E @ b
+    num = E @ (n * b)
+    bad = np.abs(den) < 10 * np.finfo(float).eps
+    num[bad] = 0
+    den[bad] = 1
+    return np.real(num / den)
+
+
+def fftfilt(b, x):
+    """fftfilt(b,x): first len(x) samples of the linear convolution, per column
+    (call site dependencies/binauralDecode.m:40-41)."""
+    b = np.asarray(b)
+    x = np.asarray(x)
+    n = x.shape[0]
+    L = n + b.shape[0] - 1
+    nf = 1 << (L - 1).bit_length()
+    y = np.fft.ifft(np.fft.fft(b, nf, axis=0) * np.fft.fft(x, nf, axis=0), axis=0)[:n]
+    if np.isrealobj(b) and np.isrealobj(x):
+        y = y.real
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# dependencies/*.m
+# --------------------------------------------------------------------------------------------
+def sh_repToOrder(v):
+    """dependencies/sh_repToOrder.m:15-20: (n+1) per-order weights -> (n+1)^2 ACN channels."""
+    v = np.asarray(v)
+    n = v.shape[0] - 1
+    out = np.zeros(((n + 1) ** 2,) + v.shape[1:], dtype=v.dtype)
+    for nn in range(n + 1):
+        out[nn * nn : (nn + 1) ** 2] = v[nn]
+    return out
+
+
+def getFadeWindow(irLen, relFadeLen=0.15):
+    """dependencies/getFadeWindow.m:9-16.  MATLAB round() = half away from zero."""
+    nf = int(math.floor(relFadeLen * irLen + 0.5))
+    h = hann(2 * nf)
+    return np.concatenate([h[:nf], np.ones(irLen - 2 * nf), h[nf:]])
+
+
+def applySubsampleDelay(sig, delay_samples):
+    """dependencies/applySubsampleDelay.m:10-18.  sig [n x ...]; delay scalar or broadcastable
+    over the trailing dims."""
+    sig = np.asarray(sig)
+    n = sig.shape[0]
+    omega = np.linspace(0, 0.5, n // 2 + 1)
+    delay = np.asarray(delay_samples, dtype=np.float64)
+    shp = (omega.size,) + (1,) * (sig.ndim - 1)
+    e = np.exp(-1j * 2 * np.pi * omega.reshape(shp) * delay)
+    e = np.broadcast_to(e, (omega.size,) + np.broadcast_shapes(e.shape[1:], sig.shape[1:])).copy()
+    e[-1] = np.real(e[-1])
+    e = np.concatenate([e, np.conj(e[-2:0:-1])], axis=0)
+    return np.fft.ifft(np.fft.fft(sig, axis=0) * e, axis=0)
+
+
+def simulation_order(order, fs, radius):
+    """dependencies/getSMAIRMatrix.m:95"""
+    return max(int(order), int(math.ceil(fs * math.pi * radius / C_SOUND)))
+
+
+def getSMAIRMatrix(order, fs, irLen, smaRadius, smaDesignAziZenRad, shDefinition="real",
+                   returnRawMicSigs=False, arrayType="rigid"):
+    """dependencies/getSMAIRMatrix.m:86-127 with oversamplingFactor=1, radialFilter='none',
+    planeWave (the only configuration the five entry points use, lib/getEMagLsFilters.m:51-63).
+    Returns [C x S x P] like the reference."""
+    nfft = irLen
+    assert nfft % 2 == 0
+    f = np.linspace(0, fs / 2, nfft // 2 + 1)
+    simOrder = simulation_order(order, fs, smaRadius)
+    S = (simOrder + 1) ** 2
+    nOut = (order + 1) ** 2
+    P = f.size
+    M = smaDesignAziZenRad.shape[0]
+    Y_Hi = getSH(simOrder, smaDesignAziZenRad, shDefinition)
+    Y_Lo_pinv = pinv(Y_Hi[:, :nOut])
+    bnAll = -sphModalCoeffs(simOrder, 2 * np.pi * f / C_SOUND * smaRadius, arrayType).T  # (simOrder+1) x P
+    rows = M if returnRawMicSigs else nOut
+    out = np.zeros((rows, S, P), dtype=np.complex128)
+    for k in range(P):
+        Bn = sh_repToOrder(bnAll[:, k])
+        if k == P - 1:
+            Bn = np.real(Bn)  # :115-117
+        pM = Y_Hi * Bn[None, :]
+        out[:, :, k] = pM if returnRawMicSigs else Y_Lo_pinv @ pM
+    return out, simOrder
+
+
+# --------------------------------------------------------------------------------------------
+# lib/*.m
+# --------------------------------------------------------------------------------------------
+def getLsFilters(hL, hR, aziRad, zenRad, order, shDefinition="real"):
+    """lib/getLsFilters.m:30-34"""
+    Y_conj = getSH(order, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
+    Y_pinv = pinv(Y_conj)
+    return hL @ Y_pinv, hR @ Y_pinv
+
+
+def _design_consts(fs, length, f_trans):
+    nfft = min(NFFT_MAX_LEN, 2 * length)
+    f = np.linspace(0, fs / 2, nfft // 2 + 1)
+    k_cut = int(math.ceil(f_trans / f[1]))  # 1-based MATLAB index
+    return nfft, f, f.size, k_cut
+
+
+def _pad(h, nfft):
+    out = np.zeros((nfft, h.shape[1]), dtype=h.dtype)
+    out[: h.shape[0]] = h
+    return out
+
+
+def _grp_delay(h_padded, P):
+    return float(np.median(grpdelay_fir(h_padded.sum(axis=1), P)))
+
+
+def _finish(W_l, W_r, P, nfft, length, is_real_basis, delayL, delayR, integer_shift=False):
+    """DC rule, spectrum completion, ifft, shift, truncate, fade
+    (lib/getEMagLsFilters.m:110-142; lib/getEMagLsFiltersFromAtf.m:125-151)."""
+    out = []
+    for W, dly in ((W_l, delayL), (W_r, delayR)):
+        if is_real_basis:
+            Wf = np.vstack([W[:P], np.conj(W[P - 2 : 0 : -1])])
+        else:
+            Wf = getShFreqDomainConjugate(W[:P])
+        w = np.fft.ifft(Wf, axis=0)
+        if integer_shift:
+            w = np.roll(w, int(dly), axis=0)
+        else:
+            w = applySubsampleDelay(w, dly)
+        n_shift = nfft // 2
+        w = w[n_shift - length // 2 : n_shift + length // 2]
+        w = w * getFadeWindow(length)[:, None]
+        out.append(w)
+    return out
+
+
+def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="real"):
+    """lib/getMagLsFilters.m:30-98"""
+    assert length >= hL.shape[0], "HRIR len too short"
+    nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
+    Y_conj = getSH(order, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
+    Y_pinv = pinv(Y_conj)
+    is_real = np.isrealobj(Y_conj)
+    hL = _pad(hL, nfft)
+    hR = _pad(hR, nfft)
+    grpD = (_grp_delay(hL, P), _grp_delay(hR, P))
+    W = []
+    for h, g in ((hL, grpD[0]), (hR, grpD[1])):
+        h = applySubsampleDelay(h, -g)
+        w_LS = h @ Y_pinv
+        H = np.fft.fft(h, axis=0)
+        Wm = np.fft.fft(w_LS, axis=0).astype(np.complex128)
+        for k in range(k_cut, P + 1):  # 1-based
+            phi = np.angle(Wm[k - 2] @ Y_conj)
+            t = np.abs(H[k - 1]) * np.exp(1j * phi)
+            if k == P:
+                t = np.real(t)
+            Wm[k - 1] = t @ Y_pinv
+        W.append(Wm)
+    n_shift = nfft // 2
+    wL, wR = _finish(W[0], W[1], P, nfft, length, is_real, n_shift, n_shift + (grpD[1] - grpD[0]))
+    if is_real:
+        wL, wR = wL.real, wR.real
+    return wL, wR
+
+
+def _emagls_core(HL, HR, pwGrid_of_k, P, k_cut, C, collect=None):
+    """The per-bin loop shared by lib/getEMagLsFilters.m:85-106, lib/getEMagLs2Filters.m:85-105 and
+    lib/getEMagLsFiltersFromAtf.m:100-120.  HL/HR are [>=P x D]; pwGrid_of_k(k) -> [C x D] (k 1-based)."""
+    W_l = np.zeros((P, C), dtype=np.complex128)
+    W_r = np.zeros((P, C), dtype=np.complex128)
+    for k in range(2, P + 1):
+        pw = pwGrid_of_k(k)
+        U, s, Vh = np.linalg.svd(pw.T, full_matrices=False)  # svd(pwGrid.','econ','vector')
+        s_reg = 1.0 / np.maximum(s, SVD_REGUL_CONST * s.max())
+        Y_reg_inv = np.conj(U) @ (s_reg[:, None] * Vh.conj())  # conj(U) * (s .* V.')
+        if collect is not None:
+            collect(k, pw, s, Y_reg_inv)
+        if k < k_cut:
+            W_l[k - 1] = HL[k - 1] @ Y_reg_inv
+            W_r[k - 1] = HR[k - 1] @ Y_reg_inv
+        else:
+            phi_l = np.angle(W_l[k - 2] @ pw)
+            phi_r = np.angle(W_r[k - 2] @ pw)
+            tl = np.abs(HL[k - 1]) * np.exp(1j * phi_l)
+            tr = np.abs(HR[k - 1]) * np.exp(1j * phi_r)
+            if k == P:
+                tl, tr = np.real(tl), np.real(tr)
+            W_l[k - 1] = tl @ Y_reg_inv
+            W_r[k - 1] = tr @ Y_reg_inv
+    W_l[0] = np.real(W_l[1])  # :110-111
+    W_r[0] = np.real(W_r[1])
+    return W_l, W_r
+
+
+def _hrir_prologue(hL, hR, nfft, P):
+    """lib/getEMagLsFilters.m:72-81"""
+    hL = _pad(hL, nfft)
+    hR = _pad(hR, nfft)
+    gL = _grp_delay(hL, P)
+    gR = _grp_delay(hR, P)
+    HL = np.fft.fft(applySubsampleDelay(hL, -gL), axis=0)
+    HR = np.fft.fft(applySubsampleDelay(hR, -gR), axis=0)
+    return HL, HR, gL, gR
+
+
+def _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
+                    shDefinition, raw, collect=None):
+    assert length >= hL.shape[0], "len too short"
+    nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
+    smair, simOrder = getSMAIRMatrix(order, fs, nfft, micRadius, np.column_stack([micAzi, micZen]),
+                                     shDefinition, returnRawMicSigs=raw)
+    Y_Hi_conj = getSH(simOrder, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
+    HL, HR, gL, gR = _hrir_prologue(hL, hR, nfft, P)
+    C = smair.shape[0]
+    W_l, W_r = _emagls_core(HL, HR, lambda k: smair[:, :, k - 1] @ Y_Hi_conj, P, k_cut, C, collect)
+    is_real = np.isrealobj(Y_Hi_conj) or raw  # eMagLS2 always mirrors (lib/getEMagLs2Filters.m:113-114)
+    n_shift = nfft // 2
+    wL, wR = _finish(W_l, W_r, P, nfft, length, is_real, n_shift, n_shift + gR - gL)
+    if np.isrealobj(Y_Hi_conj):
+        wL, wR = wL.real, wR.real
+    return wL, wR
+
+
+def getEMagLsFilters(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
+                     shDefinition="real", collect=None):
+    """lib/getEMagLsFilters.m:32-142"""
+    return _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
+                           shDefinition, raw=False, collect=collect)
+
+
+def getEMagLs2Filters(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
+                      shDefinition="real", collect=None):
+    """lib/getEMagLs2Filters.m:32-135"""
+    return _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
+                           shDefinition, raw=True, collect=collect)
+
+
+def _sph2cart_unit(aziZen):
+    azi, zen = aziZen[:, 0], aziZen[:, 1]
+    ele = np.pi / 2 - zen
+    return np.column_stack([np.cos(ele) * np.cos(azi), np.cos(ele) * np.sin(azi), np.sin(ele)])
+
+
+def getEMagLsFiltersFromAtf(hL, hR, hrirGridAziZenRad, atfIrs, atfGridAziZenRad, fs, filterLen, fTrans):
+    """lib/getEMagLsFiltersFromAtf.m:29-151.  atfIrs [taps x numMics x numAtfDirs].
+    Returns (wL, wR, meanGridDeviationDeg) -- the third value is what :96 prints."""
+    assert filterLen >= hL.shape[0], "len too short"
+    nfft, f, P, kTrans = _design_consts(fs, filterLen, fTrans)
+    M = atfIrs.shape[1]
+    hL = _pad(hL, nfft)
+    hR = _pad(hR, nfft)
+    gL = _grp_delay(hL, P)
+    gR = _grp_delay(hR, P)
+    rnd = lambda v: int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)  # MATLAB round
+    HL = np.fft.fft(np.roll(hL, -rnd(gL), axis=0), axis=0)
+    HR = np.fft.fft(np.roll(hR, -rnd(gR), axis=0), axis=0)
+    atfs = np.fft.fft(atfIrs, nfft, axis=0)
+    hc = _sph2cart_unit(hrirGridAziZenRad)
+    ac = _sph2cart_unit(atfGridAziZenRad)
+    hrir_smaller = hL.shape[1] <= atfIrs.shape[2]  # min() returns the first index on ties (:62)
+    if hrir_smaller:
+        dirC, matchC = hc, ac
+    else:
+        dirC, matchC = ac, hc
+    D = dirC.shape[0]
+    idx = np.empty(D, dtype=np.int64)
+    dev = np.empty(D)
+    for ii in range(D):
+        d = np.sqrt(np.sum((matchC - dirC[ii]) ** 2, axis=1))
+        idx[ii] = int(np.argmin(d))
+        dev[ii] = np.degrees(np.arccos(np.clip(dirC[ii] @ matchC[idx[ii]], -1, 1)))
+    if hrir_smaller:
+        HLm, HRm = HL, HR
+        atfM = atfs[:P][:, :, idx]  # P x M x D
+    else:
+        HLm, HRm = HL[:P][:, idx], HR[:P][:, idx]
+        atfM = atfs[:P]
+    W_l, W_r = _emagls_core(HLm, HRm, lambda k: atfM[k - 1], P, kTrans, M)
+    n_shift = int(math.floor(nfft / 2 + 0.5))
+    wL, wR = _finish(W_l, W_r, P, nfft, filterLen, True, n_shift, n_shift, integer_shift=True)
+    return wL.real, wR.real, float(dev.mean())
+
+
+def binauralDecode(sig, wL, wR, compensateDelay=False):
+    """dependencies/binauralDecode.m:33-64 (core loop; resample / rotation / extra convolution are
+    out of scope).  sig [numSamples x C], filters [len x C] -> [numSamples x 2] real."""
+    n, C = sig.shape
+    left = np.zeros(n, dtype=np.complex128)
+    right = np.zeros(n, dtype=np.complex128)
+    for ii in range(C):
+        left += fftfilt(wL[:, ii], sig[:, ii])
+        right += fftfilt(wR[:, ii], sig[:, ii])
+    out = np.column_stack([left, right])
+    if compensateDelay:
+        d = wL.shape[0] // 2
+        out = out[d - 1 :]
+    return out.real
+
+
+# --------------------------------------------------------------------------------------------
+# harness rule
+# --------------------------------------------------------------------------------------------
+def assert_all_close_metrics(x1, x2):
+    """verifyEMagLs.m:370-395.  Returns (norm_diff, signed max dB over bins>=1 of |fft(x1)/fft(x2)|,
+    max |dB|)."""
+    x1 = np.asarray(x1)
+    x2 = np.asarray(x2)
+    norm_diff = float(np.max(np.abs(x1 - x2)) / max(np.max(np.abs(x1)), np.max(np.abs(x2))))
+    with np.errstate(all="ignore"):
+        r = np.abs(np.fft.fft(x1, axis=0) / np.fft.fft(x2, axis=0))[1:]
+        db = 20 * np.log10(r)
+    db = db[np.isfinite(db)]
+    return norm_diff, float(db.max()), float(np.abs(db).max())

@@ -1,0 +1,266 @@
+"""T0: pin the CPU oracle against the reference's own golden filter sets.
+
+The fixtures' input (HRIR_L2702.mat) is not shipped, so these are fixture-internal known-answer
+tests: each pins one convention of the restated third-party / built-in arithmetic.
+"""
+import math
+
+import mpmath as mp
+import numpy as np
+import pytest
+import scipy.special as sps
+
+from oracle import emagls_oracle as O
+
+
+def real_to_complex_T(N):
+    """Unitary T with Y_complex = Y_real @ T (ACN, Condon-Shortley in the complex basis)."""
+    C = (N + 1) ** 2
+    T = np.zeros((C, C), complex)
+    for n in range(N + 1):
+        T[n * n + n, n * n + n] = 1
+        for m in range(1, n + 1):
+            p, q = n * n + n + m, n * n + n - m
+            T[p, p] = (-1) ** m / math.sqrt(2)
+            T[q, p] = 1j * (-1) ** m / math.sqrt(2)
+            T[p, q] = 1 / math.sqrt(2)
+            T[q, q] = -1j / math.sqrt(2)
+    return T
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+# ---------------------------------------------------------------- getSH
+def test_sh_real_complex_relation(grids):
+    d = np.column_stack([grids["azi"], grids["zen"]])
+    for N in (4, 19):
+        Yr = O.getSH(N, d, "real")
+        Yc = O.getSH(N, d, "complex")
+        assert np.abs(Yr @ real_to_complex_T(N) - Yc).max() < 5e-15
+
+
+def test_sh_against_mpmath(grids):
+    idx = [1, 7, 100, 1000, 2000, 2700]
+    d = np.column_stack([grids["azi"][idx], grids["zen"][idx]])
+    Y = O.getSH(19, d, "complex")
+    mp.mp.dps = 40
+    for ii in range(len(idx)):
+        for n in (0, 1, 4, 11, 19):
+            for m in sorted({-n, -1 if n else 0, 0, n // 2, n}):
+                ref = complex(mp.spherharm(n, m, mp.mpf(float(d[ii, 1])), mp.mpf(float(d[ii, 0]))))
+                assert abs(Y[ii, n * n + n + m] - ref) < 5e-15
+
+
+def test_sh_orthonormal_on_quadrature_like_grid(grids):
+    d = np.column_stack([grids["azi"], grids["zen"]])
+    Y = O.getSH(4, d, "real")
+    G = Y.T @ Y * (4 * np.pi / d.shape[0])
+    assert np.abs(G - np.eye(25)).max() < 0.2  # Lebedev grid without its weights: roughly unit-norm SH
+
+
+def test_golden_ls_real_vs_complex(golden):
+    """real_LS . T == complex_LS  (pins ACN, CS phase, sign of i; conj(T) gives O(1) error)."""
+    T = real_to_complex_T(4)
+    for ear in "LR":
+        a, b = golden[f"real_LS/wLs{ear}"], golden[f"complex_LS/wLs{ear}"]
+        assert rel(a @ T, b) < 1e-13
+        assert rel(a @ np.conj(T), b) > 0.5
+
+
+def test_golden_magls_real_vs_complex(golden):
+    T = real_to_complex_T(4)
+    for ear in "LR":
+        a, b = golden[f"real_MagLS_woDC/wMls{ear}"], golden[f"complex_MagLS_woDC/wMls{ear}"]
+        assert rel(a @ T, b) < 2e-12
+
+
+def test_golden_complex_time_domain_symmetry(golden):
+    """w[:, (n,-m)] == (-1)^m conj(w[:, (n,m)])  <=> getShFreqDomainConjugate's rule."""
+    w = golden["complex_MagLS_woDC/wMlsL"]
+    for n in range(5):
+        for m in range(1, n + 1):
+            a = w[:, n * n + n - m]
+            b = (-1) ** m * np.conj(w[:, n * n + n + m])
+            assert np.abs(a - b).max() < 1e-14
+    # and the oracle's implementation produces exactly that symmetry
+    rng = np.random.default_rng(0)
+    Wpos = rng.standard_normal((9, 9)) + 1j * rng.standard_normal((9, 9))
+    for n in range(3):  # make DC / Nyquist rows consistent with the symmetry
+        for m in range(0, n + 1):
+            for r in (0, 8):
+                Wpos[r, n * n + n - m] = (-1) ** m * np.conj(Wpos[r, n * n + n + m])
+    w = np.fft.ifft(O.getShFreqDomainConjugate(Wpos), axis=0)
+    for n in range(3):
+        for m in range(1, n + 1):
+            assert np.abs(w[:, n * n + n - m] - (-1) ** m * np.conj(w[:, n * n + n + m])).max() < 1e-15
+
+
+def test_golden_emagls2_is_basis_free(golden):
+    a, b = golden["real_eMagLS2_woDC/wEMls2L"], golden["complex_eMagLS2_woDC/wEMls2L"]
+    assert rel(a, b) < 1e-7  # the reference's own noise floor (ill-conditioned low bins): 1.5e-8
+    assert np.abs(b.imag).max() < 1e-15
+
+
+def test_golden_window_endpoints(golden):
+    for key in ("real_MagLS_woDC/wMlsL", "real_eMagLS_woDC/wEMlsL", "real_eMagLS2_woDC/wEMls2R"):
+        w = golden[key]
+        assert np.all(w[0] == 0) and np.all(w[-1] == 0)
+    win = O.getFadeWindow(512)
+    assert win[0] == 0 and win[-1] == 0 and win[77] == 1 and win[511 - 77] == 1
+    assert abs(win[1] - 0.5 * (1 - math.cos(2 * math.pi / 153))) < 1e-16
+
+
+def test_golden_emagls_real_vs_complex_quirk(golden):
+    """The per-coefficient real() rules at DC / Nyquist are NOT basis-equivariant (reference quirk,
+    lib/getEMagLsFilters.m:98-100,110-111): difference is 4e-3, zero for m = 0 columns."""
+    T = real_to_complex_T(4)
+    a, b = golden["real_eMagLS_woDC/wEMlsL"] @ T, golden["complex_eMagLS_woDC/wEMlsL"]
+    d = np.abs(a - b).max(axis=0) / np.abs(b).max()
+    assert 1e-3 < d.max() < 1e-2
+    m0 = [n * n + n for n in range(5)]
+    assert d[m0].max() < 1e-6
+
+
+# ---------------------------------------------------------------- LS path with a surrogate input
+def test_ls_surrogate_roundtrip(golden, grids):
+    """h_sur = wLs . Y^H has the golden LS filter as its exact LS solution: the oracle must
+    reproduce the fixture from it (pins pinv + the transpose conventions of getLsFilters)."""
+    d = np.column_stack([grids["azi"], grids["zen"]])
+    for basis in ("real", "complex"):
+        Yc = O.getSH(4, d, basis).conj().T
+        wL, wR = golden[f"{basis}_LS/wLsL"], golden[f"{basis}_LS/wLsR"]
+        oL, oR = O.getLsFilters(wL @ Yc, wR @ Yc, grids["azi"], grids["zen"], 4, basis)
+        assert rel(oL, wL) < 1e-12 and rel(oR, wR) < 1e-12
+
+
+# ---------------------------------------------------------------- sphModalCoeffs
+def test_modal_coeffs_against_mpmath():
+    mp.mp.dps = 50
+    for x in (0.05, 0.9, 7.3, 18.4):
+        b = O.sphModalCoeffs(19, np.array([x]), "rigid")[0]
+        for n in (0, 1, 4, 12, 19):
+            X = mp.mpf(x)
+            jn = lambda nu, z: mp.sqrt(mp.pi / (2 * z)) * mp.besselj(nu + 0.5, z)
+            yn = lambda nu, z: mp.sqrt(mp.pi / (2 * z)) * mp.bessely(nu + 0.5, z)
+            h2 = lambda nu, z: jn(nu, z) - 1j * yn(nu, z)
+            dj = mp.diff(lambda z: jn(n, z), X)
+            dh = mp.diff(lambda z: h2(n, z), X)
+            ref = complex(4 * mp.pi * (1j ** n) * (jn(n, X) - dj / dh * h2(n, X)))
+            assert abs(b[n] - ref) < 1e-10 * abs(ref) + 1e-300, (x, n, b[n], ref)
+    b0 = O.sphModalCoeffs(3, np.array([0.0]), "rigid")[0]
+    assert b0[0] == 4 * np.pi and np.all(b0[1:] == 0)
+
+
+def _simulate_render(golden, grids, key, raw, variant):
+    """|W_fixture(k) . pwGrid_k| rendered HRTF for a few low bins, using the oracle's SMA model."""
+    fs, nfft, P = 48000.0, 1024, 513
+    w = golden[key]
+    wp = np.zeros((nfft, w.shape[1]))
+    wp[256:768] = w
+    W = np.fft.fft(wp, axis=0)
+    micd = np.column_stack([grids["mic_azi"], grids["mic_zen"]])
+    smair, simOrder = O.getSMAIRMatrix(4, fs, nfft, grids["mic_radius"], micd, "real", returnRawMicSigs=raw)
+    if variant == "nominus":
+        smair = -smair
+    elif variant == "conj":
+        smair = np.conj(smair)
+    Yh = O.getSH(simOrder, np.column_stack([grids["azi"], grids["zen"]]), "real").T
+    bins = np.arange(4, 40)
+    return bins, np.stack([W[k] @ (smair[:, :, k] @ Yh) for k in bins])
+
+
+@pytest.mark.parametrize("key,raw", [("real_eMagLS_woDC/wEMlsL", False), ("real_eMagLS2_woDC/wEMls2L", True)])
+def test_cross_fixture_physics_pins_modal_convention(golden, grids, key, raw):
+    """Below f_cut the eMagLS/eMagLS2 filters, rendered through the simulated array, must
+    reproduce the LS-filter HRTF (same delay bookkeeping): pins b_n's formula, 4 pi scale, i^n,
+    Hankel kind and the reference's leading minus (dependencies/getSMAIRMatrix.m:104-108)."""
+    nfft = 1024
+    wls = golden["real_LS/wLsL"]
+    Y4 = O.getSH(4, np.column_stack([grids["azi"], grids["zen"]]), "real")
+    Wls = np.fft.fft(np.vstack([wls, np.zeros((nfft - wls.shape[0], 25))]), axis=0)
+    res = {}
+    for variant in ("ref", "nominus", "conj"):
+        bins, R = _simulate_render(golden, grids, key, raw, variant)
+        best = None
+        for delay in np.arange(495.5, 498.0, 0.05):
+            T = np.stack([(Wls[k] @ Y4.T) * np.exp(-2j * np.pi * k * delay / nfft) for k in bins])
+            e = np.linalg.norm(R - T, axis=1) / np.linalg.norm(T, axis=1)
+            if best is None or np.median(e) < np.median(best[1]):
+                best = (delay, e)
+        res[variant] = best
+    d, e = res["ref"]
+    assert abs(d - 496.63) < 0.3          # 512 - grpD(L2702) ~ 512 - 15.37
+    assert np.median(e) < 0.07 and e.max() < 0.12
+    assert np.median(res["nominus"][1]) > 1.0 and np.median(res["conj"][1]) > 1.0
+
+
+# ---------------------------------------------------------------- built-ins
+def test_pinv_hann_fftfilt_grpdelay():
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((25, 300)) + 1j * rng.standard_normal((25, 300))
+    assert np.abs(O.pinv(A) - np.linalg.pinv(A)).max() < 1e-13
+    assert np.allclose(O.hann(8), [0, 0.1882550990706332, 0.6112604669781572, 0.9504844339512095,
+                                   0.9504844339512095, 0.6112604669781572, 0.1882550990706332, 0])
+    b, x = rng.standard_normal(37), rng.standard_normal(500)
+    assert np.abs(O.fftfilt(b, x) - np.convolve(b, x)[:500]).max() < 1e-12
+    # group delay of a pure (fractional) delay is that delay
+    n = np.arange(64)
+    h = np.sinc(n - 20.3) * np.hanning(64 + 2)[1:-1].repeat(1)[:64] ** 0  # plain shifted sinc
+    gd = O.grpdelay_fir(h, 257)
+    assert abs(np.median(gd) - 20.3) < 0.05
+    # numerical phase derivative agrees
+    H = np.fft.rfft(h, 512)
+    ph = np.unwrap(np.angle(H))
+    num = -np.gradient(ph, 2 * np.pi / 512)
+    assert np.abs(num[20:200] - gd[20:200]).max() < 0.05
+
+
+def test_apply_subsample_delay_integer_is_roll():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((64, 3))
+    y = O.applySubsampleDelay(x, 5)
+    assert np.abs(y - np.roll(x, 5, axis=0)).max() < 1e-13
+    z = O.applySubsampleDelay(O.applySubsampleDelay(x, 0.37), -0.37)
+    # Nyquist bin is forced real in both passes, so only that component may change
+    Z, X = np.fft.fft(z, axis=0), np.fft.fft(x, axis=0)
+    assert np.abs(Z[:32] - X[:32]).max() < 1e-12
+
+
+def test_sh_rep_to_order():
+    out = O.sh_repToOrder(np.array([1.0, 2.0, 3.0]))
+    assert out.tolist() == [1, 2, 2, 2, 3, 3, 3, 3, 3]
+
+
+def test_simulation_order():
+    assert O.simulation_order(4, 48000, 0.042) == 19
+    assert O.simulation_order(4, 48000, 0.02) == 9 and O.simulation_order(4, 48000, 0.10) == 44
+
+
+# ---------------------------------------------------------------- end-to-end sanity on synthetic input
+def test_magls_equals_ls_below_cut(grids, hrirs):
+    """MagLS bins below k_cut are the LS solution (delayed): restates the fixture KAT on our own data."""
+    hL, hR = hrirs
+    wL, _ = O.getMagLsFilters(hL, hR, grids["azi"], grids["zen"], 4, 48000.0, 512)
+    lsL, _ = O.getLsFilters(hL, hR, grids["azi"], grids["zen"], 4)
+    assert wL.shape == (512, 25) and np.isrealobj(wL)
+    nfft = 1024
+    wp = np.zeros((nfft, 25)); wp[256:768] = wL
+    W = np.fft.fft(wp, axis=0)
+    Wls = np.fft.fft(np.vstack([lsL, np.zeros((nfft - lsL.shape[0], 25))]), axis=0)
+    gd = np.median(O.grpdelay_fir(hL.sum(axis=1), 513))
+    k = np.arange(3, 40)
+    T = Wls[k] * np.exp(-2j * np.pi * k * (512 - gd) / nfft)[:, None]
+    assert np.linalg.norm(W[k] - T) / np.linalg.norm(T) < 2e-2
+
+
+def test_emagls_real_vs_complex_equivariance_below_nyquist(grids, hrirs):
+    """eMagLS2 is basis-free: real- and complex-SH simulations must give the same raw-mic filters."""
+    hL, hR = hrirs
+    sub = slice(0, 2702, 6)  # keep the CPU suite fast: 451 directions
+    a = O.getEMagLs2Filters(hL[:, sub], hR[:, sub], grids["azi"][sub], grids["zen"][sub], 0.02,
+                            grids["mic_azi"], grids["mic_zen"], 2, 48000.0, 128, "real")
+    b = O.getEMagLs2Filters(hL[:, sub], hR[:, sub], grids["azi"][sub], grids["zen"][sub], 0.02,
+                            grids["mic_azi"], grids["mic_zen"], 2, 48000.0, 128, "complex")
+    assert rel(a[0], b[0].real) < 1e-6 and np.abs(b[0].imag).max() < 1e-12
