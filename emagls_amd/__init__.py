@@ -1,0 +1,12 @@
+"""emagls_amd -- MI355X-native eMagLS filter design and binaural rendering (HIP, gfx950).
+
+The Python layer mirrors the reference's MATLAB entry points over the C ABI in include/emagls.h.
+Importing the package does not need a GPU; calling any function needs emagls_amd/lib/libemagls.so
+(python -m emagls_amd.build) and an MI355X -- there is no CPU fallback.
+"""
+from .api import (binauralDecode, getEMagLs2Filters, getEMagLsFilters, getEMagLsFiltersFromAtf, getLsFilters,
+                  getMagLsFilters, getSH, sphModalCoeffs)
+from .plan import Plan
+
+__all__ = ["getLsFilters", "getMagLsFilters", "getEMagLsFilters", "getEMagLs2Filters", "getEMagLsFiltersFromAtf",
+           "binauralDecode", "getSH", "sphModalCoeffs", "Plan"]

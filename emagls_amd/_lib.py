@@ -1,0 +1,102 @@
+"""ctypes binding of include/emagls.h.  Loads emagls_amd/lib/libemagls.so; there is no fallback:
+if the HIP library is missing or no GPU is present, calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libemagls.so")
+
+OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NUMERIC = 0, 1, 2, 3, 4
+BASIS = {"real": 0, "complex": 1}
+KIND_LS, KIND_MAGLS, KIND_EMAGLS, KIND_EMAGLS2, KIND_FROM_ATF = range(5)
+
+c_dp = C.POINTER(C.c_double)
+c_i64 = C.c_int64
+
+
+class DesignDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("basis", C.c_int), ("order", C.c_int), ("fs", C.c_double), ("len", c_i64),
+                ("nsamp", c_i64), ("ndirs", c_i64), ("mic_radius", C.c_double), ("nmics", c_i64),
+                ("f_trans", C.c_double), ("atf_taps", c_i64), ("natf", c_i64)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("nfft", C.c_int), ("num_pos_freqs", C.c_int), ("k_cut", C.c_int), ("sim_order", C.c_int),
+                ("num_sh_sim", C.c_int), ("num_channels", C.c_int), ("out_is_complex", C.c_int),
+                ("out_rows", c_i64), ("out_cols", c_i64), ("grp_delay_l", C.c_double), ("grp_delay_r", C.c_double),
+                ("mean_grid_dev_deg", C.c_double), ("num_sweep_launches", C.c_int), ("device_bytes", c_i64)]
+
+
+# name -> (restype, argtypes); every symbol include/emagls.h declares
+SYMBOLS = {
+    "emagls_last_error": (C.c_char_p, []),
+    "emagls_version": (C.c_int, []),
+    "emagls_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "emagls_set_device": (C.c_int, [C.c_int]),
+    "emagls_sh_basis": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "emagls_modal_bn": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p]),
+    "emagls_get_ls_filters": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
+    "emagls_get_magls_filters": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_double, c_i64, C.c_int, C.c_void_p, C.c_void_p]),
+    "emagls_get_emagls_filters": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_double,
+                                            C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_double, c_i64, C.c_int,
+                                            C.c_void_p, C.c_void_p]),
+    "emagls_get_emagls2_filters": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_double,
+                                             C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_double, c_i64, C.c_int,
+                                             C.c_void_p, C.c_void_p]),
+    "emagls_get_emagls_filters_from_atf": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p,
+                                                     C.c_double, c_i64, C.c_double, C.c_void_p, C.c_void_p,
+                                                     C.POINTER(C.c_double)]),
+    "emagls_binaural_decode": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_void_p]),
+    "emagls_plan_create": (C.c_int, [C.POINTER(DesignDesc), C.POINTER(C.c_void_p)]),
+    "emagls_plan_destroy": (C.c_int, [C.c_void_p]),
+    "emagls_plan_set_hrir_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "emagls_plan_set_mic_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "emagls_plan_set_hrirs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "emagls_plan_set_atfs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "emagls_plan_execute": (C.c_int, [C.c_void_p]),
+    "emagls_plan_synchronize": (C.c_int, [C.c_void_p]),
+    "emagls_plan_get_filters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "emagls_plan_get_info": (C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
+    "emagls_plan_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "emagls_plan_num_stages": (C.c_int, [C.c_void_p]),
+    "emagls_plan_stage_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "emagls_plan_stage_times": (C.c_int, [C.c_void_p, c_dp, C.c_int]),
+    "emagls_plan_sweep_kernel_time": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
+    "emagls_plan_debug_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "emagls_plan_stream": (C.c_void_p, [C.c_void_p]),
+}
+
+
+class EmaglsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("emagls error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("HIP library not built: %s is missing (run `python -m emagls_amd.build`)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header diverge
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        raise EmaglsError(rc, load().emagls_last_error().decode("utf-8", "replace"))

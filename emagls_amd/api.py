@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's MATLAB entry points (same names, argument order and error
+behaviour), calling the C ABI in include/emagls.h.  NumPy arrays in MATLAB layout:
+hL/hR are [numSamples x numDirections]; filters come back [len x numChannels].
+
+    getLsFilters            lib/getLsFilters.m:1-2
+    getMagLsFilters         lib/getMagLsFilters.m:1-2
+    getEMagLsFilters        lib/getEMagLsFilters.m:1-2
+    getEMagLs2Filters       lib/getEMagLs2Filters.m:1-2
+    getEMagLsFiltersFromAtf lib/getEMagLsFiltersFromAtf.m:1
+    binauralDecode          dependencies/binauralDecode.m:1-2
+    getSH / sphModalCoeffs  the un-vendored third-party functions the above call
+
+`shFunction` handles other than the built-in getSH cannot cross the C ABI and raise
+NotImplementedError, as INTEGRATION.md explains.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f(a):
+    """MATLAB-layout (column-major) float64 copy and its pointer."""
+    a = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _vec(a, n=None, name="vector"):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel())
+    if n is not None and a.size != n:
+        raise ValueError("%s must have %d elements, got %d" % (name, n, a.size))
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _out(rows, cols, cplx):
+    w = np.zeros((rows, cols), dtype=np.complex128 if cplx else np.float64, order="F")
+    return w, w.ctypes.data_as(C.c_void_p)
+
+
+def _basis(shDefinition, shFunction):
+    if shFunction is not None:
+        raise NotImplementedError("custom shFunction handles cannot cross the C ABI; the built-in getSH is used")
+    if shDefinition is None or shDefinition == "":
+        shDefinition = "real"
+    if shDefinition not in L.BASIS:
+        raise ValueError("shDefinition must be 'real' or 'complex'")
+    return L.BASIS[shDefinition], shDefinition == "complex"
+
+
+def _hrirs(hL, hR):
+    hL, pL = _f(hL)
+    hR, pR = _f(hR)
+    if hL.ndim != 2 or hL.shape != hR.shape:
+        raise ValueError("hL and hR must be [numSamples x numDirections] arrays of equal shape")
+    return hL, hR, pL, pR
+
+
+def getSH(N, dirs, basisType="real"):
+    dirs = np.asarray(dirs, dtype=np.float64)
+    D = dirs.shape[0]
+    azi, pa = _vec(dirs[:, 0])
+    zen, pz = _vec(dirs[:, 1])
+    b, cplx = _basis(basisType, None)
+    Y, pY = _out(D, (N + 1) ** 2, cplx)
+    L.check(L.load().emagls_sh_basis(int(N), D, pa, pz, b, pY))
+    return Y
+
+
+def sphModalCoeffs(N, kr, arrayType="rigid", dirCoeff=0.0):
+    if arrayType != "rigid":
+        raise NotImplementedError("only the rigid-sphere model is on the eMagLS path (lib/getEMagLsFilters.m:38)")
+    kr, pk = _vec(kr)
+    b, pb = _out(kr.size, N + 1, True)
+    L.check(L.load().emagls_modal_bn(int(N), kr.size, pk, pb))
+    return b
+
+
+def getLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, shDefinition="real", shFunction=None):
+    b, cplx = _basis(shDefinition, shFunction)
+    hL, hR, pL, pR = _hrirs(hL, hR)
+    n, D = hL.shape
+    azi, pa = _vec(hrirGridAziRad, D, "hrirGridAziRad")
+    zen, pz = _vec(hrirGridZenRad, D, "hrirGridZenRad")
+    wL, pwL = _out(n, (order + 1) ** 2, cplx)
+    wR, pwR = _out(n, (order + 1) ** 2, cplx)
+    L.check(L.load().emagls_get_ls_filters(pL, pR, n, D, pa, pz, int(order), b, pwL, pwR))
+    return wL, wR
+
+
+def getMagLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, fs, len, shDefinition="real", shFunction=None):
+    b, cplx = _basis(shDefinition, shFunction)
+    hL, hR, pL, pR = _hrirs(hL, hR)
+    n, D = hL.shape
+    azi, pa = _vec(hrirGridAziRad, D, "hrirGridAziRad")
+    zen, pz = _vec(hrirGridZenRad, D, "hrirGridZenRad")
+    wL, pwL = _out(int(len), (order + 1) ** 2, cplx)
+    wR, pwR = _out(int(len), (order + 1) ** 2, cplx)
+    L.check(L.load().emagls_get_magls_filters(pL, pR, n, D, pa, pz, int(order), float(fs), int(len), b, pwL, pwR))
+    return wL, wR
+
+
+def _sma(fn_name, raw, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition, shFunction):
+    b, cplx = _basis(shDefinition, shFunction)
+    hL, hR, pL, pR = _hrirs(hL, hR)
+    n, D = hL.shape
+    azi, pa = _vec(azi, D, "hrirGridAziRad")
+    zen, pz = _vec(zen, D, "hrirGridZenRad")
+    micAzi, pma = _vec(micAzi)
+    micZen, pmz = _vec(micZen, micAzi.size, "micGridZenRad")
+    M = micAzi.size
+    C_ = M if raw else (order + 1) ** 2
+    wL, pwL = _out(int(len), C_, cplx)
+    wR, pwR = _out(int(len), C_, cplx)
+    fn = getattr(L.load(), fn_name)
+    L.check(fn(pL, pR, n, D, pa, pz, float(micRadius), pma, pmz, M, int(order), float(fs), int(len), b, pwL, pwR))
+    return wL, wR
+
+
+def getEMagLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, micGridZenRad, order, fs, len,
+                     shDefinition="real", shFunction=None):
+    return _sma("emagls_get_emagls_filters", False, hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad,
+                micGridZenRad, order, fs, len, shDefinition, shFunction)
+
+
+def getEMagLs2Filters(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, micGridZenRad, order, fs, len,
+                      shDefinition="real", shFunction=None):
+    return _sma("emagls_get_emagls2_filters", True, hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad,
+                micGridZenRad, order, fs, len, shDefinition, shFunction)
+
+
+def getEMagLsFiltersFromAtf(hL, hR, hrirGridAziZenRad, atfIrs, atfGridAziZenRad, fs, filterLen, fTrans, verbose=True):
+    hL, hR, pL, pR = _hrirs(hL, hR)
+    n, D = hL.shape
+    hg = np.asarray(hrirGridAziZenRad, dtype=np.float64)
+    ag = np.asarray(atfGridAziZenRad, dtype=np.float64)
+    azi, pa = _vec(hg[:, 0], D, "hrirGridAziZenRad")
+    zen, pz = _vec(hg[:, 1], D, "hrirGridAziZenRad")
+    atf, patf = _f(atfIrs)
+    if atf.ndim != 3:
+        raise ValueError("atfIrs must be [taps x numMics x numDirections]")
+    taps, M, Da = atf.shape
+    aazi, paa = _vec(ag[:, 0], Da, "atfGridAziZenRad")
+    azen, paz = _vec(ag[:, 1], Da, "atfGridAziZenRad")
+    wL, pwL = _out(int(filterLen), M, False)
+    wR, pwR = _out(int(filterLen), M, False)
+    dev = C.c_double(0.0)
+    L.check(L.load().emagls_get_emagls_filters_from_atf(pL, pR, n, D, pa, pz, patf, taps, M, Da, paa, paz, float(fs),
+                                                        int(filterLen), float(fTrans), pwL, pwR, C.byref(dev)))
+    if verbose:  # the reference prints this line (lib/getEMagLsFiltersFromAtf.m:96)
+        print("Matching HRTF and ATF grids, average grid deviation: %.5g deg" % dev.value)
+    return wL, wR
+
+
+def binauralDecode(sig, inFs, decodingFilterLeft, decodingFilterRight, decodingFilterFs, compensateDelay=False,
+                   signal=None, signalFs=None, horRotAngleRad=None):
+    if decodingFilterFs != inFs or signal is not None or (horRotAngleRad not in (None, 0)):
+        raise NotImplementedError("resampling, rotation and the extra convolution are outside the accelerated path")
+    sig, ps = _f(sig)
+    wL, pwL = _f(decodingFilterLeft)
+    wR, pwR = _f(decodingFilterRight)
+    if np.iscomplexobj(decodingFilterLeft) or np.iscomplexobj(sig):
+        raise NotImplementedError("complex-SH rendering is not implemented yet")
+    n, Cc = sig.shape
+    ln = wL.shape[0]
+    if wL.shape != wR.shape or wL.shape[1] != Cc:
+        raise ValueError("filters must be [len x numChannels] matching the signal's channel count")
+    skip = (ln // 2 - 1) if (compensateDelay and ln // 2 > 0) else 0
+    out, po = _out(max(n - skip, 0), 2, False)
+    L.check(L.load().emagls_binaural_decode(ps, n, Cc, pwL, pwR, ln, 1 if compensateDelay else 0, po))
+    return out

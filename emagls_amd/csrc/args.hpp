@@ -1,0 +1,69 @@
+// Kernel argument blocks (plain structs passed by value at launch).
+#pragma once
+#include "common.hpp"
+
+namespace emagls {
+
+struct FactorArgs {
+    int S;            // rows of B_k
+    int C;            // columns (output channels)
+    int ldS;          // leading dimension of [c][s] arrays
+    int kb0;          // first bin index handled (blockIdx.x = kb - kb0)
+    int P;            // number of positive-frequency bins (Nyquist bin = P-1 uses real(b_n))
+    // assemble mode
+    const void* Tn;   // [n][c][ldS]  (real or complex), nullptr in dense mode
+    const cplx* bn;   // [P][nOrders]
+    int nOrders;
+    // dense mode
+    const cplx* Xd;   // [kb][c][ldS] (per-bin) ; stride 0 allowed through xd_stride
+    int64_t xd_stride;
+    // regularisation
+    int reg_mode;     // 0: 1/max(s, reg_c*smax)   1: pinv tolerance tol_dim*eps(smax)
+    double reg_c;
+    double tol_dim;
+    // outputs
+    cplx* Z;          // [kb][c][ldS]
+    cplx* Bk;         // [kb][c][ldS] or nullptr  (written for kb >= bk_from)
+    int bk_from;
+    cplx* Vws;        // [blockIdx.x][c][ldS] Householder vectors workspace
+    double* sv;       // [kb][C] singular values (unsorted) or nullptr
+    // least-squares bins: W[e][kb][c] = sum_s Hq[e][kb][s] Z[s][c] for kb < ls_end
+    const cplx* Hq;   // [e][kb][ldHq] or nullptr
+    int64_t ldHq;
+    int64_t hq_estride;
+    int ls_end;
+    cplx* W;          // [e][P][C]
+    int* sweeps_out;  // optional [kb]
+};
+
+struct SweepArgs {
+    int D, S, C, ldS, P;
+    int64_t ldQ;
+    const void* Q;        // [D][ldQ] real or complex
+    const cplx* Z;        // [kb][c][ldS]
+    const cplx* Bk;       // [kb][c][ldS]
+    const double* Habs;   // [e][kb-kabs0][ldD]
+    int64_t ldD;
+    int kabs0;
+    cplx* Wpart;          // [2][nWG][2][C]
+    cplx* W;              // [e][P][C]
+    int nWG, dpw;         // workgroups, directions per workgroup
+    int kfirst;           // first swept bin: W(k-1) is read from W instead of the partials
+};
+
+struct DenseSweepArgs {
+    int D, C, ldD, P;
+    const void* X;        // [kb][c][ldD] (TX real or complex)
+    int64_t x_stride;
+    const void* Zd;       // [kb][c][ldD]
+    int64_t z_stride;
+    const double* Habs;   // [e][kb-kabs0][ldH]
+    int64_t ldH;
+    int kabs0;
+    cplx* Wpart;          // [2][nWG][2][C]
+    cplx* W;
+    int nWG, dpw;
+    int kfirst;
+};
+
+}  // namespace emagls

@@ -1,0 +1,838 @@
+// C ABI (include/emagls.h) and host-side orchestration of the design pipelines.
+// The host code only sequences launches and derives scalar constants (nfft, k_cut, simulation
+// order: lib/getEMagLsFilters.m:44-48, dependencies/getSMAIRMatrix.m:95); all array arithmetic runs
+// in the HIP kernels.  There is no CPU fallback: without a GPU every entry point returns an error.
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/emagls.h"
+#include "kernels.hpp"
+
+using namespace emagls;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+constexpr double C_SOUND = 343.0;       // dependencies/getSMAIRMatrix.m:86
+constexpr int NFFT_MAX_LEN = 2048;      // lib/getEMagLsFilters.m:35
+constexpr double F_CUT_MIN_FREQ = 1e3;  // :36
+constexpr double SVD_REGUL_CONST = 0.01;  // :39
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+int round_up(int64_t v, int64_t m) { return (int)(ceil_div(v, m) * m); }
+
+}  // namespace
+
+struct emagls_plan {
+    emagls_design_desc d{};
+    hipStream_t stream = nullptr;
+    std::map<std::string, DevBuf> bufs;
+    int64_t total_bytes = 0;
+    // derived constants
+    bool cplx_basis = false;
+    int nfft = 0, P = 0, k_cut = 0, kcut0 = 0;
+    int simOrder = 0, S = 0, C = 0, ldS = 0, nOut = 0;
+    int64_t D = 0, ldD = 0, Dpad = 0, Dm = 0;  // Dm: matched direction count (FROM_ATF)
+    bool hrir_smaller = true;
+    bool out_cplx = false;
+    int64_t out_rows = 0, out_cols = 0;
+    int nWG = 0, dpw = 0;
+    bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
+    // profiling
+    int prof_level = 0;
+    std::vector<std::string> stage_names;
+    std::vector<hipEvent_t> stage_events;
+    std::vector<double> stage_ms;
+    std::vector<hipEvent_t> sweep_events;
+    int sweep_launches = 0;
+    bool executed = false;
+
+    ~emagls_plan() {
+        for (auto& kv : bufs) if (kv.second.p) hipFree(kv.second.p);
+        for (auto e : stage_events) hipEventDestroy(e);
+        for (auto e : sweep_events) hipEventDestroy(e);
+        if (stream) hipStreamDestroy(stream);
+    }
+    void* alloc(const std::string& name, size_t bytes, bool zero = true) {
+        if (bytes == 0) bytes = 16;
+        DevBuf b;
+        HIP_CHECK(hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+        if (zero) HIP_CHECK(hipMemsetAsync(b.p, 0, bytes, stream));
+        bufs[name] = b;
+        total_bytes += (int64_t)bytes;
+        return b.p;
+    }
+    template <typename T = void> T* get(const std::string& name) {
+        auto it = bufs.find(name);
+        if (it == bufs.end()) throw Error(EMAGLS_ERR_ARG, "internal: unknown buffer " + name);
+        return reinterpret_cast<T*>(it->second.p);
+    }
+    bool has(const std::string& name) const { return bufs.count(name) != 0; }
+    void upload(const std::string& name, const void* src, size_t bytes) {
+        auto it = bufs.find(name);
+        if (it == bufs.end() || it->second.bytes < bytes) throw Error(EMAGLS_ERR_ARG, "internal: upload size mismatch for " + name);
+        HIP_CHECK(hipMemcpyAsync(it->second.p, src, bytes, hipMemcpyDefault, stream));
+    }
+    void mark(const char* name) {
+        if (prof_level < 1) return;
+        const size_t i = stage_names.size();
+        stage_names.push_back(name);
+        if (stage_events.size() <= i) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            stage_events.push_back(e);
+        }
+        HIP_CHECK(hipEventRecord(stage_events[i], stream));
+    }
+};
+
+namespace {
+
+size_t esz(bool c) { return c ? sizeof(cplx) : sizeof(double); }
+
+void check_pow2(int nfft) {
+    if (nfft < 8 || (nfft & (nfft - 1)) != 0)
+        throw Error(EMAGLS_ERR_UNSUPPORTED, "filter length must give a power-of-two nfft = min(2048, 2*len) in this build");
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan construction: derive constants, allocate every device buffer once
+// ---------------------------------------------------------------------------------------------
+void plan_setup(emagls_plan& p) {
+    const emagls_design_desc& d = p.d;
+    if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_FROM_ATF) throw Error(EMAGLS_ERR_ARG, "unknown design kind");
+    if (d.basis != EMAGLS_BASIS_REAL && d.basis != EMAGLS_BASIS_COMPLEX) throw Error(EMAGLS_ERR_ARG, "shDefinition must be 'real' or 'complex'");
+    if (d.ndirs < 1 || d.nsamp < 1) throw Error(EMAGLS_ERR_ARG, "empty HRIR set");
+    if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
+    HIP_CHECK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    p.cplx_basis = d.basis == EMAGLS_BASIS_COMPLEX;
+    p.D = d.ndirs;
+    p.ldD = round_up(p.D, 64);
+    const bool cb = p.cplx_basis;
+
+    p.alloc("hL", sizeof(double) * d.nsamp * d.ndirs, false);
+    p.alloc("hR", sizeof(double) * d.nsamp * d.ndirs, false);
+    p.alloc("hrir_azi", sizeof(double) * p.D, false);
+    p.alloc("hrir_zen", sizeof(double) * p.D, false);
+    p.alloc("flag", sizeof(int) * 4);
+    p.alloc("grpd", sizeof(double) * 2);
+
+    if (d.kind != EMAGLS_KIND_LS) {
+        if (d.len < d.nsamp)
+            throw Error(EMAGLS_ERR_ARG, d.kind == EMAGLS_KIND_MAGLS ? "HRIR len too short" : "len too short");
+        if (!(d.fs > 0)) throw Error(EMAGLS_ERR_ARG, "fs must be positive");
+        p.nfft = (int)std::min<int64_t>(NFFT_MAX_LEN, 2 * d.len);
+        check_pow2(p.nfft);
+        if (d.len % 2) throw Error(EMAGLS_ERR_ARG, "filter length must be even");
+        p.P = p.nfft / 2 + 1;
+        const double f2 = (d.fs / 2.0) / (double)(p.P - 1);  // f(2) of linspace(0, fs/2, P)
+        const double f_cut = (d.kind == EMAGLS_KIND_FROM_ATF) ? d.f_trans : std::max(F_CUT_MIN_FREQ, 500.0 * d.order);
+        p.k_cut = (int)std::ceil(f_cut / f2);
+        if (p.k_cut < 1) p.k_cut = 1;
+        p.kcut0 = std::min(p.k_cut - 1, p.P);  // 0-based index of the first magnitude-least-squares bin
+        if (d.kind == EMAGLS_KIND_MAGLS && p.kcut0 < 1) throw Error(EMAGLS_ERR_ARG, "k_cut must be at least 2");
+        p.alloc("tw", sizeof(cplx) * p.nfft);
+        p.alloc("dirsum", sizeof(double) * 2 * d.nsamp * hrir_dirsum_chunks(d.ndirs));
+    }
+
+    const int N = d.order;
+    if (d.kind == EMAGLS_KIND_LS || d.kind == EMAGLS_KIND_MAGLS) {
+        p.simOrder = N;
+        p.S = (N + 1) * (N + 1);
+        p.C = p.S;
+        p.nOut = p.S;
+        if (p.S > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "SH order above 4 is not supported for LS/MagLS in this build");
+        if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than SH channels");
+    } else if (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) {
+        if (!(d.mic_radius > 0) || d.nmics < 1) throw Error(EMAGLS_ERR_ARG, "invalid array geometry");
+        p.simOrder = std::max(N, (int)std::ceil(d.fs * kPi * d.mic_radius / C_SOUND));  // getSMAIRMatrix.m:95
+        p.S = (p.simOrder + 1) * (p.simOrder + 1);
+        p.nOut = (N + 1) * (N + 1);
+        p.C = d.kind == EMAGLS_KIND_EMAGLS ? p.nOut : (int)d.nmics;
+        if (p.C > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels is not supported in this build");
+        if (p.S > 768) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 26 (array radius > ~5.9 cm at 48 kHz) is not supported in this build");
+        if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than simulated SH channels");
+        if (d.kind == EMAGLS_KIND_EMAGLS && d.nmics < p.nOut) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than SH output channels");
+    } else {
+        if (d.nmics < 1 || d.natf < 1 || d.atf_taps < 1) throw Error(EMAGLS_ERR_ARG, "invalid ATF set");
+        p.C = (int)d.nmics;
+        if (p.C > 8) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 8 ATF microphones is not supported in this build");
+        p.hrir_smaller = d.ndirs <= d.natf;  // min([a b]) returns the first index on ties (FromAtf.m:62)
+        p.Dm = p.hrir_smaller ? d.ndirs : d.natf;
+        if (p.Dm > 4096) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 4096 matched directions is not supported in this build");
+        if (p.Dm < p.C) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer directions than microphones");
+    }
+    p.ldS = round_up(std::max(p.S, 1), 64);
+
+    if (d.kind != EMAGLS_KIND_FROM_ATF) {
+        // ---- SH machinery on the HRIR grid
+        p.Dpad = gram_dpad(p.D);
+        p.alloc("sh_tab", sizeof(double) * sh_coeff_count(p.simOrder));
+        p.alloc("Ycm", esz(cb) * (size_t)p.S * p.ldD);                 // [S][ldD] column-major SH matrix
+        p.alloc("Yc", esz(cb) * (size_t)p.Dpad * p.ldS);               // [Dpad][ldS] conj(Y), direction-major
+        p.alloc("Gp", esz(cb) * (size_t)gram_ksplit(p.D) * p.S * p.S);
+        p.alloc("R", esz(cb) * (size_t)p.S * p.S);
+        p.alloc("Q", esz(cb) * (size_t)p.D * p.ldS);
+    }
+    if (d.kind == EMAGLS_KIND_LS || d.kind == EMAGLS_KIND_MAGLS) {
+        p.alloc("Rb", sizeof(cplx) * (size_t)p.C * p.ldS);             // R as [c][s] complex
+        p.alloc("Zb", sizeof(cplx) * (size_t)p.C * p.ldS);
+        p.alloc("Vws", sizeof(cplx) * (size_t)p.C * p.ldS);
+        p.alloc("sv", sizeof(double) * p.C);
+        p.alloc("Ypinv", esz(cb) * (size_t)p.C * p.ldD);
+        if (d.kind == EMAGLS_KIND_LS) {
+            p.out_rows = d.nsamp;
+        } else {
+            p.alloc("Xc", esz(cb) * (size_t)p.S * p.ldD);              // Y_conj as [c][d]
+        }
+    }
+    if (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) {
+        const int M = (int)d.nmics;
+        const int ldM = round_up(M, 64);
+        p.alloc("mic_azi", sizeof(double) * M, false);
+        p.alloc("mic_zen", sizeof(double) * M, false);
+        p.alloc("Ymic_cm", esz(cb) * (size_t)p.S * M);                 // [S][M]
+        p.alloc("Ymic_rm", esz(cb) * (size_t)ldM * p.ldS);             // [M][ldS]
+        p.alloc("E", esz(cb) * (size_t)p.C * p.ldS);                   // [C][ldS]
+        if (d.kind == EMAGLS_KIND_EMAGLS) {
+            p.alloc("Ylo_c", sizeof(cplx) * (size_t)p.nOut * ldM);     // [nOut][ldM] complex copy of Y_Lo^T
+            p.alloc("Zlo", sizeof(cplx) * (size_t)p.nOut * ldM);
+            p.alloc("Vlo", sizeof(cplx) * (size_t)p.nOut * ldM);
+        }
+        p.alloc("kr", sizeof(double) * p.P, false);
+        p.alloc("bn", sizeof(cplx) * (size_t)p.P * (p.simOrder + 1));
+        p.alloc("Tn", esz(cb) * (size_t)(p.simOrder + 1) * p.C * p.ldS);
+        p.alloc("Hq", sizeof(cplx) * (size_t)2 * std::max(p.kcut0, 1) * p.ldS);
+        p.alloc("Z", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
+        p.alloc("Bk", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
+        p.alloc("Vws", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
+        p.alloc("sv", sizeof(double) * (size_t)p.P * p.C);
+        p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
+        p.nWG = 128;
+        p.dpw = (int)ceil_div(p.D, p.nWG);
+    }
+    if (d.kind == EMAGLS_KIND_FROM_ATF) {
+        const int M = p.C;
+        p.alloc("atf", sizeof(double) * (size_t)d.atf_taps * M * d.natf, false);
+        p.alloc("atf_azi", sizeof(double) * d.natf, false);
+        p.alloc("atf_zen", sizeof(double) * d.natf, false);
+        p.alloc("cartB", sizeof(double) * 3 * std::max(d.natf, d.ndirs));
+        p.alloc("match_idx", sizeof(int64_t) * p.Dm);
+        p.alloc("match_dev", sizeof(double) * p.Dm);
+        p.alloc("mean_dev", sizeof(double));
+        p.alloc("colidx", sizeof(int64_t) * (size_t)p.Dm * M);
+        p.ldD = round_up(p.Dm, 64);
+        p.alloc("X", sizeof(cplx) * (size_t)p.P * M * p.ldD);
+        p.alloc("Z", sizeof(cplx) * (size_t)p.P * M * p.ldD);
+        p.alloc("Vws", sizeof(cplx) * (size_t)p.P * M * p.ldD);
+        p.alloc("sv", sizeof(double) * (size_t)p.P * M);
+        p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
+    }
+    if (d.kind != EMAGLS_KIND_LS) {
+        const int64_t Dh = (d.kind == EMAGLS_KIND_FROM_ATF) ? p.Dm : p.D;
+        const int n_c = std::max(std::min(p.kcut0, p.P), 1);
+        p.alloc("Hc", sizeof(cplx) * (size_t)2 * n_c * p.ldD);
+        p.alloc("Habs", sizeof(double) * (size_t)2 * std::max(p.P - p.kcut0, 1) * p.ldD);
+        p.alloc("W", sizeof(cplx) * (size_t)2 * p.P * p.C);
+        if (d.kind == EMAGLS_KIND_MAGLS || d.kind == EMAGLS_KIND_FROM_ATF) p.nWG = dense_sweep_nwg((int)Dh);
+        p.alloc("Wpart", sizeof(cplx) * (size_t)2 * p.nWG * 2 * p.C);
+        p.out_rows = d.len;
+    }
+    p.out_cols = p.C;
+    p.out_cplx = cb && d.kind != EMAGLS_KIND_FROM_ATF;
+    p.alloc("wL", (p.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p.out_rows * p.out_cols);
+    p.alloc("wR", (p.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p.out_rows * p.out_cols);
+    HIP_CHECK(hipStreamSynchronize(p.stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// pipelines
+// ---------------------------------------------------------------------------------------------
+// SH matrix on the HRIR grid, Cholesky-QR:  conj(Y) = Q R
+void stage_hrir_basis(emagls_plan& p) {
+    hipStream_t st = p.stream;
+    const bool cb = p.cplx_basis;
+    launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), st);
+    launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), cb,
+                    p.get("Ycm"), p.ldD, st);
+    launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, cb, true, st);
+    p.mark("sh_basis");
+    launch_gram(p.get("Yc"), p.D, p.S, p.ldS, cb, p.get("Gp"), p.get("R"), st);
+    p.mark("gram_mfma");
+    launch_cholesky(p.get("R"), p.S, cb, p.get<int>("flag"), st);
+    p.mark("cholesky");
+    launch_qform(p.get("Yc"), p.get("R"), p.S, p.D, p.ldS, cb, p.get("Q"), st);
+    p.mark("qform");
+}
+
+void stage_prologue(emagls_plan& p, int mode, const int64_t* didx, int64_t Dh) {
+    hipStream_t st = p.stream;
+    const emagls_design_desc& d = p.d;
+    launch_twiddles(p.nfft, p.get("tw"), st);
+    // group delay from the sum over ALL HRIR directions (lib/getEMagLsFilters.m:74-75)
+    launch_hrir_grpdelay(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, d.ndirs, p.nfft, p.get("tw"),
+                         p.get<double>("dirsum"), p.get<double>("grpd"), st);
+    const int n_c = std::max(std::min(p.kcut0, p.P), 1);
+    launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, Dh, didx, p.nfft, p.get("tw"), p.get<double>("grpd"),
+                    mode, std::min(p.kcut0, p.P), p.kcut0, p.get("Hc"), p.get<double>("Habs"), p.ldD, st);
+    (void)n_c;
+    p.mark("hrir_prologue");
+}
+
+void record_sweep_event(emagls_plan& p, size_t i) {
+    if (p.sweep_events.size() <= i) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        p.sweep_events.push_back(e);
+    }
+    HIP_CHECK(hipEventRecord(p.sweep_events[i], p.stream));
+}
+
+void run_pinv_of_R(emagls_plan& p) {
+    // pinv(Y_conj) = conj(Q) Z_B, Z_B from the SVD of B = R with MATLAB's pinv tolerance
+    hipStream_t st = p.stream;
+    const bool cb = p.cplx_basis;
+    launch_widen(p.get("R"), p.S, cb, p.get("Rb"), p.ldS, p.C, p.S, /*transpose=*/true, /*upper_only=*/true, st);
+    FactorArgs a{};
+    a.S = p.S; a.C = p.C; a.ldS = p.ldS; a.kb0 = 0; a.P = 2;  // P=2: bin 0 is not a Nyquist bin
+    a.Tn = nullptr; a.bn = nullptr; a.nOrders = 0;
+    a.Xd = p.get<cplx>("Rb"); a.xd_stride = 0;
+    a.reg_mode = 1; a.reg_c = 0.0; a.tol_dim = (double)std::max<int64_t>(p.D, p.C);
+    a.Z = p.get<cplx>("Zb"); a.Bk = nullptr; a.bk_from = 0; a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
+    a.Hq = nullptr; a.W = nullptr; a.ls_end = 0; a.sweeps_out = nullptr;
+    launch_factor(a, 1, true, st);
+    launch_ypinv(p.get("Q"), p.ldS, cb, p.get("Zb"), p.ldS, (int)p.D, p.S, p.C, p.get("Ypinv"), p.ldD, st);
+    p.mark("pinv");
+}
+
+void execute_ls(emagls_plan& p) {
+    stage_hrir_basis(p);
+    run_pinv_of_R(p);
+    launch_ls_filters(p.get<double>("hL"), p.get<double>("hR"), p.d.nsamp, (int)p.D, p.get("Ypinv"), p.cplx_basis, p.ldD,
+                      p.C, p.get("wL"), p.get("wR"), p.stream);
+    p.mark("ls_filters");
+}
+
+void execute_magls(emagls_plan& p) {
+    hipStream_t st = p.stream;
+    const bool cb = p.cplx_basis;
+    stage_hrir_basis(p);
+    run_pinv_of_R(p);
+    launch_conj_copy(p.get("Ycm"), p.get("Xc"), (int64_t)p.S * p.ldD, cb, st);  // Y_conj [c][d]
+    stage_prologue(p, 0, nullptr, p.D);
+    launch_ls_apply(p.get("Hc"), p.ldD, std::min(p.kcut0, p.P), p.get("Ypinv"), cb, p.ldD, (int)p.D, p.C, p.P, 0,
+                    std::min(p.kcut0, p.P), p.get("W"), st);
+    p.mark("ls_bins");
+    DenseSweepArgs a{};
+    a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
+    a.X = p.get("Xc"); a.x_stride = 0; a.Zd = p.get("Ypinv"); a.z_stride = 0;
+    a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
+    a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG; a.dpw = 0; a.kfirst = p.kcut0;
+    p.sweep_launches = 0;
+    for (int kb = p.kcut0; kb < p.P; ++kb) {
+        if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
+        launch_sweep_dense(a, kb, cb, st);
+        if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
+        ++p.sweep_launches;
+    }
+    if (p.kcut0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
+    p.mark("magls_sweep");
+    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"), cb ? 1 : 0, 0, 0,
+                           p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), st);
+    p.mark("epilogue");
+}
+
+void execute_emagls(emagls_plan& p) {
+    hipStream_t st = p.stream;
+    const emagls_design_desc& d = p.d;
+    const bool cb = p.cplx_basis;
+    const bool raw = d.kind == EMAGLS_KIND_EMAGLS2;
+    const int M = (int)d.nmics;
+    const int ldM = round_up(M, 64);
+    stage_hrir_basis(p);
+    // ---- array model: E = Y_mic (raw) or pinv(Y_mic(:,1:nOut)) Y_mic   (getSMAIRMatrix.m:101-102,119-121)
+    launch_sh_basis(p.simOrder, M, p.get<double>("mic_azi"), p.get<double>("mic_zen"), p.get<double>("sh_tab"), cb,
+                    p.get("Ymic_cm"), M, st);
+    launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("Ymic_rm"), M, p.ldS, cb, false, st);
+    if (raw) {
+        HIP_CHECK(hipMemcpyAsync(p.get("E"), p.get("Ymic_rm"), esz(cb) * (size_t)M * p.ldS, hipMemcpyDeviceToDevice, st));
+    } else {
+        // Y_Lo^T as complex [c][m]: the first nOut rows of the column-major SH matrix
+        launch_widen(p.get("Ymic_cm"), M, cb, p.get("Ylo_c"), ldM, p.nOut, M, false, false, st);
+        FactorArgs a{};
+        a.S = M; a.C = p.nOut; a.ldS = ldM; a.kb0 = 0; a.P = 2;
+        a.Xd = p.get<cplx>("Ylo_c"); a.xd_stride = 0;
+        a.reg_mode = 1; a.tol_dim = (double)std::max(M, p.nOut);
+        a.Z = p.get<cplx>("Zlo"); a.Vws = p.get<cplx>("Vlo");
+        launch_factor(a, 1, true, st);
+        // E[c][s] = sum_m pinv[c][m] Y_mic[m][s],  pinv[c][m] = Zlo[c][m]
+        launch_small_gemm(p.get("Zlo"), ldM, true, p.get("Ymic_rm"), p.ldS, cb, p.get("E"), p.ldS, cb, p.nOut, p.S, M, st);
+    }
+    // ---- modal coefficients  bnAll = -sphModalCoeffs(simOrder, kr, 'rigid')   (getSMAIRMatrix.m:107)
+    launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), p.simOrder + 1, 1, st);
+    launch_tn(p.get("R"), p.get("E"), p.S, p.C, p.ldS, p.simOrder + 1, cb, p.get("Tn"), p.ldS, st);
+    p.mark("array_model");
+    stage_prologue(p, 0, nullptr, p.D);
+    const int ls_end = std::min(p.kcut0, p.P);
+    launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Q"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, st);
+    p.mark("ls_rhs");
+    {
+        FactorArgs a{};
+        a.S = p.S; a.C = p.C; a.ldS = p.ldS; a.kb0 = 1; a.P = p.P;
+        a.Tn = p.get("Tn"); a.bn = p.get<cplx>("bn"); a.nOrders = p.simOrder + 1;
+        a.reg_mode = 0; a.reg_c = SVD_REGUL_CONST;
+        a.Z = p.get<cplx>("Z"); a.Bk = p.get<cplx>("Bk"); a.bk_from = p.kcut0;
+        a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
+        a.Hq = p.get<cplx>("Hq"); a.ldHq = p.ldS; a.hq_estride = (int64_t)ls_end * p.ldS; a.ls_end = ls_end;
+        a.W = p.get<cplx>("W"); a.sweeps_out = p.get<int>("jsweeps");
+        launch_factor(a, p.P - 1, cb, st);
+    }
+    p.mark("factor_bins");
+    {
+        SweepArgs a{};
+        a.D = (int)p.D; a.S = p.S; a.C = p.C; a.ldS = p.ldS; a.P = p.P; a.ldQ = p.ldS;
+        a.Q = p.get("Q"); a.Z = p.get<cplx>("Z"); a.Bk = p.get<cplx>("Bk");
+        a.Habs = p.get<double>("Habs"); a.ldD = p.ldD; a.kabs0 = p.kcut0;
+        a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG; a.dpw = p.dpw;
+        const int k0 = std::max(p.kcut0, 1);
+        a.kfirst = k0;
+        p.sweep_launches = 0;
+        for (int kb = k0; kb < p.P; ++kb) {
+            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
+            launch_sweep_factored(a, kb, cb, st);
+            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
+            ++p.sweep_launches;
+        }
+        if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
+    }
+    p.mark("magls_sweep");
+    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)d.len, p.get("tw"), p.get<double>("grpd"), (cb && !raw) ? 1 : 0, 1, 0,
+                           p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), st);
+    p.mark("epilogue");
+}
+
+void execute_from_atf(emagls_plan& p) {
+    hipStream_t st = p.stream;
+    const emagls_design_desc& d = p.d;
+    const int M = p.C;
+    // ---- grid matching (FromAtf.m:56-95)
+    if (p.hrir_smaller)
+        launch_grid_match(p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), d.ndirs, p.get<double>("atf_azi"),
+                          p.get<double>("atf_zen"), d.natf, p.get<double>("cartB"), p.get<int64_t>("match_idx"),
+                          p.get<double>("match_dev"), p.get<double>("mean_dev"), st);
+    else
+        launch_grid_match(p.get<double>("atf_azi"), p.get<double>("atf_zen"), d.natf, p.get<double>("hrir_azi"),
+                          p.get<double>("hrir_zen"), d.ndirs, p.get<double>("cartB"), p.get<int64_t>("match_idx"),
+                          p.get<double>("match_dev"), p.get<double>("mean_dev"), st);
+    launch_atf_colidx(p.hrir_smaller ? p.get<int64_t>("match_idx") : nullptr, p.Dm, M, p.get<int64_t>("colidx"), st);
+    p.mark("grid_match");
+    stage_prologue(p, 1, p.hrir_smaller ? nullptr : p.get<int64_t>("match_idx"), p.Dm);
+    // atfs = fft(atfIrs, nfft) on the matched directions only: X[kb][m][d]
+    launch_real_fft_gather(p.get<double>("atf"), d.atf_taps, (int64_t)M * p.Dm, p.get<int64_t>("colidx"), p.nfft, p.get("tw"),
+                           p.get("X"), (int64_t)M * p.ldD, p.Dm, p.ldD, st);
+    p.mark("atf_fft");
+    const int ls_end = std::min(p.kcut0, p.P);
+    {
+        FactorArgs a{};
+        a.S = (int)p.Dm; a.C = M; a.ldS = (int)p.ldD; a.kb0 = 1; a.P = p.P;
+        a.Xd = p.get<cplx>("X"); a.xd_stride = (int64_t)M * p.ldD;
+        a.reg_mode = 0; a.reg_c = SVD_REGUL_CONST;
+        a.Z = p.get<cplx>("Z"); a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
+        a.Hq = p.get<cplx>("Hc"); a.ldHq = p.ldD; a.hq_estride = (int64_t)ls_end * p.ldD; a.ls_end = ls_end;
+        a.W = p.get<cplx>("W"); a.sweeps_out = p.get<int>("jsweeps");
+        launch_factor(a, p.P - 1, true, st);
+    }
+    p.mark("factor_bins");
+    {
+        DenseSweepArgs a{};
+        a.D = (int)p.Dm; a.C = M; a.ldD = (int)p.ldD; a.P = p.P;
+        a.X = p.get("X"); a.x_stride = (int64_t)M * p.ldD; a.Zd = p.get("Z"); a.z_stride = (int64_t)M * p.ldD;
+        a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
+        a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG;
+        const int k0 = std::max(p.kcut0, 1);
+        a.kfirst = k0;
+        p.sweep_launches = 0;
+        for (int kb = k0; kb < p.P; ++kb) {
+            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
+            launch_sweep_dense(a, kb, true, st);
+            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
+            ++p.sweep_launches;
+        }
+        if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, M, p.P, p.P - 1, st);
+    }
+    p.mark("magls_sweep");
+    launch_filter_epilogue(p.get("W"), M, p.nfft, (int)d.len, p.get("tw"), p.get<double>("grpd"), 0, 1, 1, 0, p.get("wL"),
+                           p.get("wR"), st);
+    p.mark("epilogue");
+}
+
+void plan_execute(emagls_plan& p) {
+    const emagls_design_desc& d = p.d;
+    if (!p.have_hrir_grid || !p.have_hrirs) throw Error(EMAGLS_ERR_ARG, "HRIRs and their grid must be set before execute");
+    if ((d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) && !p.have_mic_grid)
+        throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
+    if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
+    p.stage_names.clear();
+    HIP_CHECK(hipMemsetAsync(p.get("flag"), 0, sizeof(int) * 4, p.stream));
+    if (p.has("W")) HIP_CHECK(hipMemsetAsync(p.get("W"), 0, p.bufs["W"].bytes, p.stream));
+    p.mark("begin");
+    switch (d.kind) {
+        case EMAGLS_KIND_LS: execute_ls(p); break;
+        case EMAGLS_KIND_MAGLS: execute_magls(p); break;
+        case EMAGLS_KIND_EMAGLS:
+        case EMAGLS_KIND_EMAGLS2: execute_emagls(p); break;
+        default: execute_from_atf(p); break;
+    }
+    p.executed = true;
+}
+
+void plan_check_flags(emagls_plan& p) {
+    int flag[4] = {0, 0, 0, 0};
+    HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
+    if (flag[0])
+        throw Error(EMAGLS_ERR_NUMERIC,
+                    "SH Gram matrix of the HRIR grid is not positive definite (the grid cannot resolve the required SH order)");
+}
+
+template <typename F> int guarded(F&& f) {
+    try {
+        f();
+        return EMAGLS_OK;
+    } catch (const Error& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return EMAGLS_ERR_HIP;
+    }
+}
+
+int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR, const double* azi, const double* zen,
+             const double* mic_azi, const double* mic_zen, const double* atf, const double* atf_azi, const double* atf_zen,
+             void* wL, void* wR, double* mean_dev) {
+    return guarded([&] {
+        std::unique_ptr<emagls_plan> p(new emagls_plan);
+        p->d = desc;
+        plan_setup(*p);
+        auto req = [](int rc) { if (rc != EMAGLS_OK) throw Error(rc, g_last_error); };
+        req(emagls_plan_set_hrir_grid(p.get(), azi, zen));
+        req(emagls_plan_set_hrirs(p.get(), hL, hR));
+        if (mic_azi) req(emagls_plan_set_mic_grid(p.get(), mic_azi, mic_zen));
+        if (atf) req(emagls_plan_set_atfs(p.get(), atf, atf_azi, atf_zen));
+        plan_execute(*p);
+        req(emagls_plan_get_filters(p.get(), wL, wR));
+        if (mean_dev) {
+            emagls_plan_info info;
+            req(emagls_plan_get_info(p.get(), &info));
+            *mean_dev = info.mean_grid_dev_deg;
+        }
+    });
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* emagls_last_error(void) { return g_last_error.c_str(); }
+int emagls_version(void) { return 100; }
+
+int emagls_device_count(int* count) {
+    return guarded([&] {
+        if (!count) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        HIP_CHECK(hipGetDeviceCount(count));
+    });
+}
+int emagls_set_device(int device) {
+    return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
+}
+
+int emagls_sh_basis(int order, int64_t ndirs, const double* azi, const double* zen, int basis, void* Y) {
+    return guarded([&] {
+        if (order < 0 || ndirs < 0 || !azi || !zen || !Y) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        if (ndirs == 0) return;
+        const bool cb = basis == EMAGLS_BASIS_COMPLEX;
+        const size_t S = (size_t)(order + 1) * (order + 1);
+        double *d_azi = nullptr, *d_zen = nullptr, *d_tab = nullptr;
+        void* d_Y = nullptr;
+        auto cleanup = [&] { hipFree(d_azi); hipFree(d_zen); hipFree(d_tab); hipFree(d_Y); };
+        try {
+            HIP_CHECK(hipMalloc(&d_azi, sizeof(double) * ndirs));
+            HIP_CHECK(hipMalloc(&d_zen, sizeof(double) * ndirs));
+            HIP_CHECK(hipMalloc(&d_tab, sizeof(double) * sh_coeff_count(order)));
+            HIP_CHECK(hipMalloc(&d_Y, esz(cb) * S * ndirs));
+            HIP_CHECK(hipMemcpy(d_azi, azi, sizeof(double) * ndirs, hipMemcpyDefault));
+            HIP_CHECK(hipMemcpy(d_zen, zen, sizeof(double) * ndirs, hipMemcpyDefault));
+            launch_sh_coeff(order, d_tab, nullptr);
+            launch_sh_basis(order, ndirs, d_azi, d_zen, d_tab, cb, d_Y, ndirs, nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipMemcpy(Y, d_Y, esz(cb) * S * ndirs, hipMemcpyDefault));
+        } catch (...) { cleanup(); throw; }
+        cleanup();
+    });
+}
+
+int emagls_modal_bn(int order, int64_t nfreq, const double* kr, void* bn) {
+    return guarded([&] {
+        if (order < 0 || nfreq < 0 || !kr || !bn) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        if (nfreq == 0) return;
+        double* d_kr = nullptr;
+        void* d_bn = nullptr;
+        auto cleanup = [&] { hipFree(d_kr); hipFree(d_bn); };
+        try {
+            HIP_CHECK(hipMalloc(&d_kr, sizeof(double) * nfreq));
+            HIP_CHECK(hipMalloc(&d_bn, sizeof(cplx) * nfreq * (order + 1)));
+            HIP_CHECK(hipMemcpy(d_kr, kr, sizeof(double) * nfreq, hipMemcpyDefault));
+            launch_modal_bn(order, nfreq, d_kr, 1.0, 1.0, d_bn, 1, nfreq, nullptr);  // column-major [nfreq x (order+1)]
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipMemcpy(bn, d_bn, sizeof(cplx) * nfreq * (order + 1), hipMemcpyDefault));
+        } catch (...) { cleanup(); throw; }
+        cleanup();
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+int emagls_plan_create(const emagls_design_desc* desc, emagls_plan** plan) {
+    return guarded([&] {
+        if (!desc || !plan) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        std::unique_ptr<emagls_plan> p(new emagls_plan);
+        p->d = *desc;
+        plan_setup(*p);
+        *plan = p.release();
+    });
+}
+int emagls_plan_destroy(emagls_plan* plan) {
+    return guarded([&] { delete plan; });
+}
+int emagls_plan_set_hrir_grid(emagls_plan* p, const double* azi, const double* zen) {
+    return guarded([&] {
+        if (!p || !azi || !zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        p->upload("hrir_azi", azi, sizeof(double) * p->d.ndirs);
+        p->upload("hrir_zen", zen, sizeof(double) * p->d.ndirs);
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        p->have_hrir_grid = true;
+    });
+}
+int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* zen) {
+    return guarded([&] {
+        if (!p || !azi || !zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (!p->has("mic_azi")) throw Error(EMAGLS_ERR_ARG, "this design kind has no microphone grid");
+        p->upload("mic_azi", azi, sizeof(double) * p->d.nmics);
+        p->upload("mic_zen", zen, sizeof(double) * p->d.nmics);
+        // kr = 2*pi*f/C * smaRadius on f = linspace(0, fs/2, P)   (getSMAIRMatrix.m:90,107)
+        std::vector<double> kr(p->P);
+        for (int k = 0; k < p->P; ++k) {
+            const double f = (double)k * (p->d.fs / 2.0) / (double)(p->P - 1);
+            kr[k] = 2.0 * kPi * f / C_SOUND * p->d.mic_radius;
+        }
+        p->upload("kr", kr.data(), sizeof(double) * p->P);
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        p->have_mic_grid = true;
+    });
+}
+int emagls_plan_set_hrirs(emagls_plan* p, const double* hL, const double* hR) {
+    return guarded([&] {
+        if (!p || !hL || !hR) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        p->upload("hL", hL, sizeof(double) * p->d.nsamp * p->d.ndirs);
+        p->upload("hR", hR, sizeof(double) * p->d.nsamp * p->d.ndirs);
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        p->have_hrirs = true;
+    });
+}
+int emagls_plan_set_atfs(emagls_plan* p, const double* atf, const double* azi, const double* zen) {
+    return guarded([&] {
+        if (!p || !atf || !azi || !zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (!p->has("atf")) throw Error(EMAGLS_ERR_ARG, "this design kind has no ATFs");
+        p->upload("atf", atf, sizeof(double) * p->d.atf_taps * p->d.nmics * p->d.natf);
+        p->upload("atf_azi", azi, sizeof(double) * p->d.natf);
+        p->upload("atf_zen", zen, sizeof(double) * p->d.natf);
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        p->have_atfs = true;
+    });
+}
+int emagls_plan_execute(emagls_plan* p) {
+    return guarded([&] {
+        if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        plan_execute(*p);
+    });
+}
+int emagls_plan_synchronize(emagls_plan* p) {
+    return guarded([&] {
+        if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+    });
+}
+int emagls_plan_get_filters(emagls_plan* p, void* wL, void* wR) {
+    return guarded([&] {
+        if (!p || !wL || !wR) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (!p->executed) throw Error(EMAGLS_ERR_ARG, "plan has not been executed");
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        plan_check_flags(*p);
+        const size_t bytes = (p->out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p->out_rows * p->out_cols;
+        HIP_CHECK(hipMemcpy(wL, p->get("wL"), bytes, hipMemcpyDefault));
+        HIP_CHECK(hipMemcpy(wR, p->get("wR"), bytes, hipMemcpyDefault));
+    });
+}
+int emagls_plan_get_info(emagls_plan* p, emagls_plan_info* info) {
+    return guarded([&] {
+        if (!p || !info) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        std::memset(info, 0, sizeof *info);
+        info->nfft = p->nfft; info->num_pos_freqs = p->P; info->k_cut = p->k_cut; info->sim_order = p->simOrder;
+        info->num_sh_sim = p->S; info->num_channels = p->C; info->out_is_complex = p->out_cplx;
+        info->out_rows = p->out_rows; info->out_cols = p->out_cols; info->num_sweep_launches = p->sweep_launches;
+        info->device_bytes = p->total_bytes;
+        if (p->executed) {
+            HIP_CHECK(hipStreamSynchronize(p->stream));
+            double g[2];
+            HIP_CHECK(hipMemcpy(g, p->get("grpd"), sizeof g, hipMemcpyDeviceToHost));
+            info->grp_delay_l = g[0]; info->grp_delay_r = g[1];
+            if (p->has("mean_dev")) HIP_CHECK(hipMemcpy(&info->mean_grid_dev_deg, p->get("mean_dev"), sizeof(double), hipMemcpyDeviceToHost));
+        }
+    });
+}
+int emagls_plan_set_profiling(emagls_plan* p, int level) {
+    return guarded([&] {
+        if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        p->prof_level = level;
+    });
+}
+int emagls_plan_num_stages(emagls_plan* p) { return p ? (int)p->stage_names.size() : 0; }
+const char* emagls_plan_stage_name(emagls_plan* p, int i) {
+    if (!p || i < 0 || i >= (int)p->stage_names.size()) return "";
+    return p->stage_names[i].c_str();
+}
+int emagls_plan_stage_times(emagls_plan* p, double* ms, int n) {
+    return guarded([&] {
+        if (!p || !ms) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        const int ns = (int)p->stage_names.size();
+        for (int i = 0; i < n; ++i) {
+            ms[i] = 0.0;
+            if (i >= 1 && i < ns) {
+                float t = 0.f;
+                HIP_CHECK(hipEventElapsedTime(&t, p->stage_events[i - 1], p->stage_events[i]));
+                ms[i] = t;
+            }
+        }
+    });
+}
+int emagls_plan_sweep_kernel_time(emagls_plan* p, double* total_ms, int* launches) {
+    return guarded([&] {
+        if (!p || !total_ms || !launches) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        double tot = 0.0;
+        int n = 0;
+        if (p->prof_level >= 2) {
+            for (int i = 0; i < p->sweep_launches && 2 * (size_t)i + 1 < p->sweep_events.size(); ++i) {
+                float t = 0.f;
+                HIP_CHECK(hipEventElapsedTime(&t, p->sweep_events[2 * i], p->sweep_events[2 * i + 1]));
+                tot += t;
+                ++n;
+            }
+        }
+        *total_ms = tot;
+        *launches = n;
+    });
+}
+int emagls_plan_debug_buffer(emagls_plan* p, const char* name, void* dst, size_t* nbytes) {
+    return guarded([&] {
+        if (!p || !name || !nbytes) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        auto it = p->bufs.find(name);
+        if (it == p->bufs.end()) throw Error(EMAGLS_ERR_ARG, std::string("unknown buffer ") + name);
+        if (!dst) { *nbytes = it->second.bytes; return; }
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        const size_t n = std::min(*nbytes, it->second.bytes);
+        HIP_CHECK(hipMemcpy(dst, it->second.p, n, hipMemcpyDeviceToHost));
+        *nbytes = n;
+    });
+}
+void* emagls_plan_stream(emagls_plan* p) { return p ? (void*)p->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------------------
+int emagls_get_ls_filters(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi,
+                          const double* zen, int order, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_LS; d.basis = basis; d.order = order; d.nsamp = nsamp; d.ndirs = ndirs;
+    return one_shot(d, hL, hR, azi, zen, nullptr, nullptr, nullptr, nullptr, nullptr, wL, wR, nullptr);
+}
+int emagls_get_magls_filters(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi,
+                             const double* zen, int order, double fs, int64_t len, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_MAGLS; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    return one_shot(d, hL, hR, azi, zen, nullptr, nullptr, nullptr, nullptr, nullptr, wL, wR, nullptr);
+}
+int emagls_get_emagls_filters(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi,
+                              const double* zen, double mic_radius, const double* mic_azi, const double* mic_zen,
+                              int64_t nmics, int order, double fs, int64_t len, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_EMAGLS; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    d.mic_radius = mic_radius; d.nmics = nmics;
+    if (!mic_azi || !mic_zen) { g_last_error = "null microphone grid"; return EMAGLS_ERR_ARG; }
+    return one_shot(d, hL, hR, azi, zen, mic_azi, mic_zen, nullptr, nullptr, nullptr, wL, wR, nullptr);
+}
+int emagls_get_emagls2_filters(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi,
+                               const double* zen, double mic_radius, const double* mic_azi, const double* mic_zen,
+                               int64_t nmics, int order, double fs, int64_t len, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_EMAGLS2; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    d.mic_radius = mic_radius; d.nmics = nmics;
+    if (!mic_azi || !mic_zen) { g_last_error = "null microphone grid"; return EMAGLS_ERR_ARG; }
+    return one_shot(d, hL, hR, azi, zen, mic_azi, mic_zen, nullptr, nullptr, nullptr, wL, wR, nullptr);
+}
+int emagls_get_emagls_filters_from_atf(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
+                                       const double* azi, const double* zen, const double* atf_irs, int64_t atf_taps,
+                                       int64_t nmics, int64_t natf, const double* atf_azi, const double* atf_zen, double fs,
+                                       int64_t filter_len, double f_trans, double* wL, double* wR, double* mean_dev) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_FROM_ATF; d.basis = EMAGLS_BASIS_REAL; d.fs = fs; d.len = filter_len; d.nsamp = nsamp; d.ndirs = ndirs;
+    d.nmics = nmics; d.f_trans = f_trans; d.atf_taps = atf_taps; d.natf = natf;
+    if (!atf_irs || !atf_azi || !atf_zen) { g_last_error = "null ATF set"; return EMAGLS_ERR_ARG; }
+    return one_shot(d, hL, hR, azi, zen, nullptr, nullptr, atf_irs, atf_azi, atf_zen, wL, wR, mean_dev);
+}
+
+int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const double* wL, const double* wR, int64_t len,
+                           int compensate_delay, double* out) {
+    return guarded([&] {
+        if (!in || !wL || !wR || !out) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (nsamp < 0 || nch < 1 || len < 1) throw Error(EMAGLS_ERR_ARG, "invalid shape");
+        if (nsamp == 0) return;
+        double *d_in = nullptr, *d_wL = nullptr, *d_wR = nullptr, *d_out = nullptr;
+        hipStream_t st = nullptr;
+        auto cleanup = [&] { hipFree(d_in); hipFree(d_wL); hipFree(d_wR); hipFree(d_out); if (st) hipStreamDestroy(st); };
+        try {
+            HIP_CHECK(hipStreamCreate(&st));
+            HIP_CHECK(hipMalloc(&d_in, sizeof(double) * nsamp * nch));
+            HIP_CHECK(hipMalloc(&d_wL, sizeof(double) * len * nch));
+            HIP_CHECK(hipMalloc(&d_wR, sizeof(double) * len * nch));
+            HIP_CHECK(hipMalloc(&d_out, sizeof(double) * nsamp * 2));
+            HIP_CHECK(hipMemcpy(d_in, in, sizeof(double) * nsamp * nch, hipMemcpyDefault));
+            HIP_CHECK(hipMemcpy(d_wL, wL, sizeof(double) * len * nch, hipMemcpyDefault));
+            HIP_CHECK(hipMemcpy(d_wR, wR, sizeof(double) * len * nch, hipMemcpyDefault));
+            binaural_decode_real(d_in, nsamp, (int)nch, d_wL, d_wR, len, d_out, st);
+            if (!compensate_delay) {
+                HIP_CHECK(hipMemcpy(out, d_out, sizeof(double) * nsamp * 2, hipMemcpyDefault));
+            } else {
+                // binauralOut(del:end,:), del = len/2 (1-based)   (binauralDecode.m:53-57)
+                const int64_t del = len / 2;
+                const int64_t skip = del > 0 ? del - 1 : 0;
+                const int64_t nout = nsamp - skip;
+                if (nout > 0) {
+                    HIP_CHECK(hipMemcpy(out, d_out + skip, sizeof(double) * nout, hipMemcpyDefault));
+                    HIP_CHECK(hipMemcpy(out + nout, d_out + nsamp + skip, sizeof(double) * nout, hipMemcpyDefault));
+                }
+            }
+        } catch (...) { cleanup(); throw; }
+        cleanup();
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+// Per-frequency-bin regularised inverse, batched over bins (one workgroup per bin).
+//
+// Reference (lib/getEMagLsFilters.m:87-90, same in getEMagLs2Filters.m:86-89, getEMagLsFiltersFromAtf.m:101-104):
+//     pwGrid = smairMat(:,:,k) * Y_Hi_conj;  [U,s,V] = svd(pwGrid.','econ');
+//     s = 1 ./ max(s, 0.01*max(s));          Y_reg_inv = conj(U) * (s .* V.');
+//
+// Here pwGrid.' = Q B_k with Q orthonormal (gram_chol.hip), B_k = R diag(b_n(k)) E^T = sum_n b_n(k) T_n
+// (S x C), so  Y_reg_inv = conj(Q) Z_k  with  Z_k = conj(U_B) diag(s_reg) V^T  (S x C), U_B S V^H = B_k.
+// The clipped singular values receive the LARGEST weight (100/s_max), so U_B must be orthonormal to
+// working precision even where s_min/s_max ~ 1e-13: a Gram/normal-equation solve cannot do that.
+// Per bin:  Householder QR of B_k (registers, column-per-lane-group)  ->  one-sided Jacobi SVD of
+// R2^H (LDS, converges in <= 10 sweeps)  ->  N = U2 diag(s_reg) V^H  ->  Z_k = conj(Q2 [N; 0]).
+//
+// Thread layout: tid = c * NCH + ch; lane group (NCH = 32 or 64 consecutive lanes) owns column c,
+// lane ch owns rows s = ch + NCH*i.  All reductions are inside one wave.
+#include "kernels.hpp"
+
+namespace emagls {
+
+
+constexpr int CPMAX = 32;  // max (even-padded) column count
+
+template <typename TT, int NCH, int RPT, int MAXT>
+__global__ void __launch_bounds__(MAXT) factor_kernel(FactorArgs a) {
+    __shared__ __attribute__((aligned(16))) cplx Xs[CPMAX][CPMAX + 1];  // Xs[col][row]
+    __shared__ __attribute__((aligned(16))) cplx Vs[CPMAX][CPMAX + 1];
+    __shared__ __attribute__((aligned(16))) cplx Ns[CPMAX][CPMAX + 1];  // Ns[a][b]
+    __shared__ __attribute__((aligned(16))) cplx bns[96];
+    __shared__ cplx alpha_s[CPMAX];
+    __shared__ double tau_s[CPMAX];
+    __shared__ double g_s[CPMAX];
+    __shared__ double sig_s[CPMAX];
+    __shared__ int rot_flag;
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* vbuf = reinterpret_cast<cplx*>(dyn);  // [2][ldS]
+
+    const int tid = threadIdx.x;
+    const int c = tid / NCH, ch = tid % NCH;
+    const int S = a.S, C = a.C, ldS = a.ldS;
+    const int kb = a.kb0 + blockIdx.x;
+    const bool active = c < C;
+    const int Cp = (C + 1) & ~1;
+
+    cplx B[RPT];
+    // ------------------------------------------------------------------ 1. assemble / load B_k
+    if (a.Tn) {
+        for (int n = tid; n < a.nOrders; n += blockDim.x) {
+            cplx b = a.bn[(int64_t)kb * a.nOrders + n];
+            if (kb == a.P - 1) b.y = 0.0;  // Nyquist: real(Bn)  (dependencies/getSMAIRMatrix.m:115-117)
+            bns[n] = b;
+        }
+        __syncthreads();
+        const TT* Tn = reinterpret_cast<const TT*>(a.Tn);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int s = ch + NCH * i;
+            cplx acc = mk(0, 0);
+            if (active && s < S) {
+                int n0 = (int)sqrt((double)s);  // first order whose block reaches row s: (n0+1)^2 > s
+                while ((n0 + 1) * (n0 + 1) <= s) ++n0;
+                while (n0 > 0 && n0 * n0 > s) --n0;
+                for (int n = n0; n < a.nOrders; ++n) cfma(acc, bns[n], Tn[((int64_t)n * C + c) * ldS + s]);
+            }
+            B[i] = acc;
+        }
+    } else {
+        const cplx* X = a.Xd + (int64_t)kb * a.xd_stride;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int s = ch + NCH * i;
+            B[i] = (active && s < S) ? X[(int64_t)c * ldS + s] : mk(0, 0);
+        }
+    }
+    if (a.Bk && kb >= a.bk_from && active) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int s = ch + NCH * i;
+            if (s < S) a.Bk[((int64_t)kb * C + c) * ldS + s] = B[i];
+        }
+    }
+    // ------------------------------------------------------------------ 2. Householder QR
+    cplx* Vw = a.Vws + (int64_t)blockIdx.x * C * ldS;
+    for (int j = 0; j < C; ++j) {
+        cplx* vb = vbuf + (size_t)(j & 1) * ldS;
+        if (c == j) {
+            double n2 = 0.0;
+            cplx x0 = mk(0, 0);
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int s = ch + NCH * i;
+                if (s >= j && s < S) n2 += norm2(B[i]);
+                if (s == j) x0 = B[i];
+            }
+            n2 = group_sum<NCH>(n2);
+            x0 = group_sum<NCH>(x0);
+            const double nrm = sqrt(n2);
+            const double ax0 = cabs(x0);
+            cplx alpha = mk(0, 0);
+            double tau = 0.0;
+            if (nrm > 0.0) {
+                alpha = (ax0 > 0.0) ? mk(-x0.x / ax0 * nrm, -x0.y / ax0 * nrm) : mk(-nrm, 0.0);
+                tau = 1.0 / (nrm * (nrm + ax0));  // 2 / ||v||^2, ||v||^2 = 2 nrm (nrm + |x0|)
+            }
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int s = ch + NCH * i;
+                if (s == j) B[i] = B[i] - alpha;  // v0 = x0 - alpha
+                if (s >= j && s < S) {
+                    const cplx v = (nrm > 0.0) ? B[i] : mk(0, 0);
+                    vb[s] = v;
+                    Vw[(int64_t)j * ldS + s] = v;
+                }
+            }
+            if (ch == 0) { alpha_s[j] = alpha; tau_s[j] = tau; }
+        }
+        __syncthreads();
+        if (active && c > j) {
+            const double tau = tau_s[j];
+            cplx w = mk(0, 0);
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int s = ch + NCH * i;
+                if (s >= j && s < S) cfma_conj(w, vb[s], B[i]);
+            }
+            w = group_sum<NCH>(w);
+            w = w * tau;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int s = ch + NCH * i;
+                if (s >= j && s < S) { cplx p = w * vb[s]; B[i] -= p; }
+            }
+        }
+        // vbuf is double-buffered: the next column writes the other half, no second barrier needed
+    }
+    // ------------------------------------------------------------------ 3. X = R2^H into LDS, V = I
+    for (int idx = tid; idx < CPMAX * (CPMAX + 1); idx += blockDim.x) {
+        (&Xs[0][0])[idx] = mk(0, 0);
+        (&Vs[0][0])[idx] = mk(0, 0);
+    }
+    if (tid == 0) rot_flag = 0;
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int s = ch + NCH * i;
+            if (s < c) Xs[s][c] = conj(B[i]);  // X[a=c][b=s] = conj(R2[s][c]); stored Xs[col=b][row=a]
+        }
+        if (ch == 0) { Xs[c][c] = conj(alpha_s[c]); Vs[c][c] = mk(1, 0); }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ 4. one-sided Jacobi on the columns of X
+    {
+        constexpr int GL = 8;                 // lanes per pair
+        constexpr int RL = CPMAX / GL;        // rows per lane
+        const int npairs = Cp / 2;
+        const int pi = tid / GL, gl = tid % GL;
+        const bool jactive = pi < npairs;     // whole waves: npairs*GL threads, other waves only hit barriers
+        int sweeps = 0;
+        for (; sweeps < 60; ++sweeps) {
+            for (int r = 0; r < Cp - 1; ++r) {
+                if (jactive) {
+                    int p, q;
+                    if (pi == 0) { p = Cp - 1; q = r; }
+                    else { p = (r + pi) % (Cp - 1); q = (r - pi + (Cp - 1)) % (Cp - 1); }
+                    cplx xp[RL], xq[RL];
+                    double al = 0.0, be = 0.0;
+                    cplx ga = mk(0, 0);
+#pragma unroll
+                    for (int t = 0; t < RL; ++t) {
+                        const int row = gl + GL * t;
+                        xp[t] = Xs[p][row];
+                        xq[t] = Xs[q][row];
+                        al += norm2(xp[t]);
+                        be += norm2(xq[t]);
+                        cfma_conj(ga, xp[t], xq[t]);
+                    }
+                    al = group_sum<GL>(al);
+                    be = group_sum<GL>(be);
+                    ga = group_sum<GL>(ga);
+                    const double ag = cabs(ga);
+                    if (ag > 2.220446049250313e-16 * sqrt(al * be) && ag > 0.0) {
+                        const double zeta = (be - al) / (2.0 * ag);
+                        const double t_ = (zeta == 0.0) ? 1.0 : copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + t_ * t_), sn = cs * t_;
+                        const cplx ph = mk(ga.x / ag, ga.y / ag);
+                        const cplx sph = mk(sn * ph.x, sn * ph.y);          // s * ph
+                        const cplx spc = mk(sn * ph.x, -sn * ph.y);         // s * conj(ph)
+#pragma unroll
+                        for (int t = 0; t < RL; ++t) {
+                            const int row = gl + GL * t;
+                            const cplx np = cs * xp[t] - spc * xq[t];
+                            const cplx nq = sph * xp[t] + cs * xq[t];
+                            Xs[p][row] = np;
+                            Xs[q][row] = nq;
+                            const cplx vp = Vs[p][row], vq = Vs[q][row];
+                            Vs[p][row] = cs * vp - spc * vq;
+                            Vs[q][row] = sph * vp + cs * vq;
+                        }
+                        if (gl == 0) rot_flag = 1;
+                    }
+                }
+                __syncthreads();
+            }
+            const int f = rot_flag;
+            __syncthreads();
+            if (tid == 0) rot_flag = 0;
+            __syncthreads();
+            if (!f) break;
+        }
+        if (a.sweeps_out && tid == 0) a.sweeps_out[kb] = sweeps;
+    }
+    // ------------------------------------------------------------------ 5. singular values, regularisation weights
+    if (tid < CPMAX) {
+        double n2 = 0.0;
+        for (int row = 0; row < CPMAX; ++row) n2 += norm2(Xs[tid][row]);
+        sig_s[tid] = sqrt(n2);
+    }
+    __syncthreads();
+    if (tid < CPMAX) {
+        double smax = 0.0;
+        for (int i = 0; i < C; ++i) smax = fmax(smax, sig_s[i]);
+        const double s = sig_s[tid];
+        double g = 0.0;
+        if (tid < C && s > 0.0) {
+            if (a.reg_mode == 0) {
+                g = 1.0 / (fmax(s, a.reg_c * smax) * s);  // s_reg / s
+            } else {
+                int ex;
+                frexp(smax, &ex);                          // smax = m 2^ex, m in [0.5,1)
+                const double tol = a.tol_dim * ldexp(1.0, ex - 53);  // max(size) * eps(smax)
+                g = (s > tol) ? 1.0 / (s * s) : 0.0;
+            }
+        }
+        g_s[tid] = g;
+        if (a.sv && tid < C) a.sv[(int64_t)kb * C + tid] = s;
+    }
+    __syncthreads();
+    // N[a][b] = sum_i Vx[a][i] g_i conj(Xrot[b][i])   (R2 = Vx Sigma Ux^H, Ux = Xrot/sigma)
+    for (int idx = tid; idx < C * C; idx += blockDim.x) {
+        const int aa = idx / C, bb = idx % C;
+        cplx acc = mk(0, 0);
+        for (int i = 0; i < C; ++i) {
+            const cplx t = g_s[i] * Vs[i][aa];
+            cfma(acc, t, conj(Xs[i][bb]));
+        }
+        Ns[aa][bb] = acc;
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ 6. M = Q2 [N; 0]   (reuse B registers)
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int s = ch + NCH * i;
+            B[i] = (s < C) ? Ns[s][c] : mk(0, 0);
+        }
+        for (int j = C - 1; j >= 0; --j) {
+            const double tau = tau_s[j];
+            const cplx* vj = Vw + (int64_t)j * ldS;
+            cplx w = mk(0, 0);
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int s = ch + NCH * i;
+                if (s >= j && s < S) cfma_conj(w, vj[s], B[i]);
+            }
+            w = group_sum<NCH>(w);
+            w = w * tau;
+            // second pass re-reads v (L1-resident) instead of holding RPT more registers
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int s = ch + NCH * i;
+                if (s >= j && s < S) { cplx p = w * vj[s]; B[i] -= p; }
+            }
+        }
+        // Z = conj(M)
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int s = ch + NCH * i;
+            if (s < S) a.Z[((int64_t)kb * C + c) * ldS + s] = conj(B[i]);
+        }
+        // -------------------------------------------------------------- 7. least-squares bins
+        if (a.Hq && kb < a.ls_end) {
+            for (int e = 0; e < 2; ++e) {
+                const cplx* hq = a.Hq + e * a.hq_estride + (int64_t)kb * a.ldHq;
+                cplx w = mk(0, 0);
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int s = ch + NCH * i;
+                    if (s < S) cfma(w, hq[s], conj(B[i]));
+                }
+                w = group_sum<NCH>(w);
+                if (ch == 0) a.W[((int64_t)e * a.P + kb) * C + c] = w;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename TT, int NCH, int RPT, int MAXT>
+static void launch_one(const FactorArgs& a, int nbins, hipStream_t st) {
+    const int threads = (int)(ceil_div((int64_t)NCH * a.C, 64) * 64);
+    if (threads > MAXT) throw Error(2, "factor: too many channels for this row count");
+    const size_t dyn = (size_t)2 * a.ldS * sizeof(cplx);
+    if (a.nOrders > 96) throw Error(2, "factor: simulation order above 95 is not supported");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)factor_kernel<TT, NCH, RPT, MAXT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr_set = true;
+    }
+    factor_kernel<TT, NCH, RPT, MAXT><<<nbins, threads, dyn, st>>>(a);
+    KERNEL_CHECK();
+}
+
+template <typename TT>
+static void dispatch(const FactorArgs& a, int nbins, hipStream_t st) {
+    const int S = a.S, C = a.C;
+    if (C > CPMAX) throw Error(2, "factor: more than 32 output channels is not supported in this build");
+    if (S < C) throw Error(2, "factor: fewer rows than channels (under-determined array model) is not supported");
+    if (C * 32 <= 1024) {
+        if (S <= 32 * 1) return launch_one<TT, 32, 1, 1024>(a, nbins, st);
+        if (S <= 32 * 4) return launch_one<TT, 32, 4, 1024>(a, nbins, st);
+        if (S <= 32 * 8) return launch_one<TT, 32, 8, 1024>(a, nbins, st);
+        if (S <= 32 * 13) return launch_one<TT, 32, 13, 1024>(a, nbins, st);
+        if (S <= 32 * 16) return launch_one<TT, 32, 16, 1024>(a, nbins, st);
+        if (S <= 32 * 24) return launch_one<TT, 32, 24, 1024>(a, nbins, st);
+    }
+    if (C * 64 <= 512) {
+        if (S <= 64 * 24) return launch_one<TT, 64, 24, 512>(a, nbins, st);
+        if (S <= 64 * 43) return launch_one<TT, 64, 43, 512>(a, nbins, st);
+        if (S <= 64 * 64) return launch_one<TT, 64, 64, 512>(a, nbins, st);
+    }
+    throw Error(2, "factor: problem shape (rows x channels) not supported in this build");
+}
+
+void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st) {
+    if (nbins <= 0) return;
+    if (a.Tn && !tn_cplx) dispatch<double>(a, nbins, st); else dispatch<cplx>(a, nbins, st);
+}
+
+}  // namespace emagls

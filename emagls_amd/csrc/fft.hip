@@ -1,0 +1,383 @@
+// HRIR prologue and filter epilogue: LDS-resident FP64 FFTs fused with the reference's delay /
+// mirroring / windowing arithmetic.
+//
+//   prologue  lib/getEMagLsFilters.m:72-81  (zero-pad, grpdelay -> median, applySubsampleDelay, fft)
+//             lib/getEMagLsFiltersFromAtf.m:43-53 (integer circshift variant)
+//   epilogue  lib/getEMagLsFilters.m:110-142 (DC rule, Hermitian mirror or getShFreqDomainConjugate,
+//             ifft, applySubsampleDelay / circshift, truncate, getFadeWindow)
+//
+// The reference's ifft(fft(h) .* E) followed by fft(.) collapses to fft(h) .* E, and
+// applySubsampleDelay(ifft(W)) to ifft(W .* E): one transform instead of three.
+#include "kernels.hpp"
+
+namespace emagls {
+
+// tw[j] = exp(-2 pi i j / nfft), j = 0..nfft-1
+__global__ void twiddle_kernel(int nfft, cplx* __restrict__ tw) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nfft) return;
+    double s, c;
+    // exact octant symmetries are not needed at 1e-16; sincos of the reduced angle is enough
+    sincos(-2.0 * kPi * (double)j / (double)nfft, &s, &c);
+    if (j == 0) { c = 1.0; s = 0.0; }
+    if (2 * j == nfft) { c = -1.0; s = 0.0; }
+    if (4 * j == nfft) { c = 0.0; s = -1.0; }
+    if (4 * j == 3 * nfft) { c = 0.0; s = 1.0; }
+    tw[j] = mk(c, s);
+}
+
+__device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
+
+// in-place radix-2 DIT on `nt` transforms laid out buf[t*nfft + i] (input already bit-reversed).
+// tws[j] = exp(-2 pi i j/nfft) for j < nfft/2 in LDS.  INVERSE uses conj twiddles (no scaling).
+template <bool INVERSE>
+__device__ __forceinline__ void lds_fft_stages(cplx* buf, const cplx* tws, int nfft, int log2n, int nt) {
+    const int half_n = nfft >> 1;
+    for (int s = 0; s < log2n; ++s) {
+        const int half = 1 << s;
+        const int tstep = nfft >> (s + 1);
+        for (int b = threadIdx.x; b < nt * half_n; b += blockDim.x) {
+            const int t = b / half_n, bb = b - t * half_n;
+            const int pos = bb & (half - 1);
+            const int i0 = ((bb >> s) << (s + 1)) + pos;
+            cplx w = tws[pos * tstep];
+            if (INVERSE) w.y = -w.y;
+            cplx* x = buf + (size_t)t * nfft;
+            const cplx a = x[i0], c = x[i0 + half] * w;
+            x[i0] = a + c;
+            x[i0 + half] = a - c;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sum over directions (input of grpdelay(sum(h,2),...), lib/getEMagLsFilters.m:74)
+// partial[chunk][e][n] = sum_{d in chunk} h_e[d*L + n]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) hrir_dirsum_kernel(const double* __restrict__ hL, const double* __restrict__ hR,
+                                                          int64_t L, int64_t D, int chunk, double* __restrict__ partial) {
+    const int e = blockIdx.y;
+    const double* h = e ? hR : hL;
+    const int64_t d0 = (int64_t)blockIdx.x * chunk;
+    const int64_t d1 = min(D, d0 + chunk);
+    for (int64_t n = threadIdx.x; n < L; n += blockDim.x) {
+        double acc = 0.0;
+        for (int64_t d = d0; d < d1; ++d) acc += h[d * L + n];
+        partial[((int64_t)blockIdx.x * 2 + e) * L + n] = acc;
+    }
+}
+
+// one workgroup per ear: b = sum of partials; gd(k) = Re{ sum n b[n] z^-n / sum b[n] z^-n };
+// grpd[e] = median_k gd(k)   (MATLAB grpdelay FIR branch: |den| < 10 eps -> 0)
+__global__ void __launch_bounds__(1024) grpdelay_median_kernel(const double* __restrict__ partial, int nchunks, int64_t L,
+                                                               int nfft, const cplx* __restrict__ tw,
+                                                               double* __restrict__ grpd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* b = reinterpret_cast<double*>(smem);   // L
+    double* v = b + ((L + 1) & ~(int64_t)1);       // npow2
+    const int e = blockIdx.x;
+    const int P = nfft / 2 + 1;
+    int npow2 = 1;
+    while (npow2 < P) npow2 <<= 1;
+    for (int64_t n = threadIdx.x; n < L; n += blockDim.x) {
+        double acc = 0.0;
+        for (int c = 0; c < nchunks; ++c) acc += partial[((int64_t)c * 2 + e) * L + n];
+        b[n] = acc;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < npow2; k += blockDim.x) {
+        double g = INFINITY;
+        if (k < P) {
+            cplx num = mk(0, 0), den = mk(0, 0);
+            for (int64_t n = 0; n < L; ++n) {
+                const cplx w = tw[(int)(((int64_t)k * n) & (nfft - 1))];  // nfft is a power of two
+                cfma(den, b[n], w);
+                cfma(num, (double)n * b[n], w);
+            }
+            if (cabs(den) < 10.0 * 2.220446049250313e-16) { num = mk(0, 0); den = mk(1, 0); }
+            g = cdiv(num, den).x;
+        }
+        v[k] = g;
+    }
+    __syncthreads();
+    // bitonic sort ascending
+    for (int size = 2; size <= npow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < npow2 / 2; i += blockDim.x) {
+                const int lo = ((i / stride) * 2 * stride) + (i % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const double a = v[lo], c = v[hi];
+                if ((a > c) == up) { v[lo] = c; v[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) grpd[e] = (P & 1) ? v[(P - 1) / 2] : 0.5 * (v[P / 2 - 1] + v[P / 2]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// HRIR spectra.  TD directions per workgroup, both ears packed into one complex transform.
+//   kcut0 = 0-based index of the first magnitude-least-squares bin
+//   Hc  [e][kb][d]  complex, kb <  n_c  (bins that need the complex HRTF)
+//   Habs[e][kb - kabs0][d] real, kb >= kabs0
+// mode 0: fractional delay by -grpd[e] (applySubsampleDelay);  mode 1: circshift by -round(grpd[e])
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict__ hL, const double* __restrict__ hR,
+                                                       int64_t L, int64_t D, const int64_t* __restrict__ didx, int nfft,
+                                                       int log2n, int TD,
+                                                       const cplx* __restrict__ tw, const double* __restrict__ grpd,
+                                                       int mode, int n_c, int kabs0, cplx* __restrict__ Hc,
+                                                       double* __restrict__ Habs, int64_t ldD) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* tws = reinterpret_cast<cplx*>(smem);  // nfft/2
+    cplx* buf = tws + nfft / 2;                 // TD * nfft
+    const int P = nfft / 2 + 1;
+    const int64_t d0 = (int64_t)blockIdx.x * TD;
+    const int nt = (int)min((int64_t)TD, D - d0);
+    const double gL = grpd[0], gR = grpd[1];
+    int sL = 0, sR = 0;
+    if (mode == 1) { sL = (int)round(gL); sR = (int)round(gR); }
+    for (int j = threadIdx.x; j < nfft / 2; j += blockDim.x) tws[j] = tw[j];
+    for (int idx = threadIdx.x; idx < nt * nfft; idx += blockDim.x) {
+        const int t = idx / nfft, n = idx - t * nfft;
+        // circshift(h, -s): out[n] = h[(n + s) mod nfft]; zero beyond the L recorded taps
+        int nl = (n + sL) % nfft; if (nl < 0) nl += nfft;
+        int nr = (n + sR) % nfft; if (nr < 0) nr += nfft;
+        const int64_t dsrc = didx ? didx[d0 + t] : d0 + t;  // optional gather of matched directions
+        const double a = (nl < L) ? hL[dsrc * L + nl] : 0.0;
+        const double c = (nr < L) ? hR[dsrc * L + nr] : 0.0;
+        buf[(size_t)t * nfft + bitrev((unsigned)n, log2n)] = mk(a, c);
+    }
+    __syncthreads();
+    lds_fft_stages<false>(buf, tws, nfft, log2n, nt);
+    // unpack ears, apply delay phase, write transposed (bin-major, directions contiguous)
+    for (int idx = threadIdx.x; idx < P * TD; idx += blockDim.x) {
+        const int kb = idx / TD, t = idx - kb * TD;
+        if (t >= nt) continue;
+        const cplx* x = buf + (size_t)t * nfft;
+        const cplx z = x[kb], zc = conj(x[(nfft - kb) & (nfft - 1)]);
+        cplx HLv = mk(0.5 * (z.x + zc.x), 0.5 * (z.y + zc.y));
+        cplx HRv = mk(0.5 * (z.y - zc.y), -0.5 * (z.x - zc.x));  // (z - zc) / (2i)
+        if (mode == 0) {
+            const double omega = (double)kb / (double)nfft;  // linspace(0, 0.5, nfft/2+1)
+            double s1, c1, s2, c2;
+            sincos((6.283185307179586 * omega) * gL, &s1, &c1);  // exp(-1j*2*pi*omega*(-grpD))
+            sincos((6.283185307179586 * omega) * gR, &s2, &c2);
+            if (kb == P - 1) { s1 = 0.0; s2 = 0.0; }  // Nyquist bin forced real (applySubsampleDelay.m:12)
+            HLv = HLv * mk(c1, s1);
+            HRv = HRv * mk(c2, s2);
+        }
+        const int64_t d = d0 + t;
+        if (kb < n_c) {
+            Hc[((int64_t)0 * n_c + kb) * ldD + d] = HLv;
+            Hc[((int64_t)1 * n_c + kb) * ldD + d] = HRv;
+        }
+        if (kb >= kabs0) {
+            const int64_t na = P - kabs0;
+            Habs[((int64_t)0 * na + (kb - kabs0)) * ldD + d] = cabs(HLv);
+            Habs[((int64_t)1 * na + (kb - kabs0)) * ldD + d] = cabs(HRv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic batched forward FFT of real columns (ATF path: atfs = fft(atfIrs, nfft)),
+// two real columns packed per complex transform.  Column j of `x` is x[j*L .. j*L+L), columns are
+// selected through `colidx` (gather of matched directions).  Output out[kb][j] for kb < P
+// (bin-major, columns contiguous, leading dimension ldo).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) real_fft_gather_kernel(const double* __restrict__ x, int64_t L, int64_t ncols,
+                                                              const int64_t* __restrict__ colidx, int nfft, int log2n,
+                                                              int TP, const cplx* __restrict__ tw,
+                                                              cplx* __restrict__ out, int64_t ldo, int64_t inner,
+                                                              int64_t ld_inner) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* tws = reinterpret_cast<cplx*>(smem);
+    cplx* buf = tws + nfft / 2;
+    const int P = nfft / 2 + 1;
+    const int64_t p0 = (int64_t)blockIdx.x * TP;  // pair index
+    const int64_t npairs = (ncols + 1) / 2;
+    const int nt = (int)min((int64_t)TP, npairs - p0);
+    for (int j = threadIdx.x; j < nfft / 2; j += blockDim.x) tws[j] = tw[j];
+    for (int idx = threadIdx.x; idx < nt * nfft; idx += blockDim.x) {
+        const int t = idx / nfft, n = idx - t * nfft;
+        const int64_t j0 = 2 * (p0 + t), j1 = j0 + 1;
+        double a = 0.0, c = 0.0;
+        if (n < L) {
+            a = x[(colidx ? colidx[j0] : j0) * L + n];
+            if (j1 < ncols) c = x[(colidx ? colidx[j1] : j1) * L + n];
+        }
+        buf[(size_t)t * nfft + bitrev((unsigned)n, log2n)] = mk(a, c);
+    }
+    __syncthreads();
+    lds_fft_stages<false>(buf, tws, nfft, log2n, nt);
+    for (int idx = threadIdx.x; idx < P * 2 * TP; idx += blockDim.x) {
+        const int kb = idx / (2 * TP), r = idx - kb * 2 * TP;
+        const int t = r >> 1, which = r & 1;
+        if (t >= nt) continue;
+        const int64_t j = 2 * (p0 + t) + which;
+        if (j >= ncols) continue;
+        const cplx* xx = buf + (size_t)t * nfft;
+        const cplx z = xx[kb], zc = conj(xx[(nfft - kb) & (nfft - 1)]);
+        // column j = (j / inner, j % inner) lands at (j / inner) * ld_inner + j % inner
+        out[(int64_t)kb * ldo + (j / inner) * ld_inner + (j % inner)] = which ? mk(0.5 * (z.y - zc.y), -0.5 * (z.x - zc.x))
+                                           : mk(0.5 * (z.x + zc.x), 0.5 * (z.y + zc.y));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// epilogue: one workgroup per (channel, ear).
+//   W [e][kb][c]  positive-frequency filter spectra, kb = 0..P-1, ldW = channel stride count C
+//   conj_mode 0: Hermitian mirror (real SH / raw microphones)
+//   conj_mode 1: getShFreqDomainConjugate  W(nfft-k,(n,m)) = (-1)^m conj(W(k,(n,-m)))
+//   dc_rule   1: W(0) := real(W(1))   (lib/getEMagLsFilters.m:110-111)
+//   shift_mode 0: applySubsampleDelay by nfft/2 (left) / nfft/2 + grpDR - grpDL (right)
+//   shift_mode 1: circshift by round(nfft/2)     (lib/getEMagLsFiltersFromAtf.m:136-138)
+// out: real [e][c*len + t] (out_cplx = 0) or complex (out_cplx = 1)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) filter_epilogue_kernel(const cplx* __restrict__ W, int C, int nfft, int log2n,
+                                                              int len, const cplx* __restrict__ tw,
+                                                              const double* __restrict__ grpd, int conj_mode,
+                                                              int dc_rule, int shift_mode, int out_cplx,
+                                                              void* __restrict__ outL, void* __restrict__ outR) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* tws = reinterpret_cast<cplx*>(smem);
+    cplx* buf = tws + nfft / 2;
+    const int c = blockIdx.x, e = blockIdx.y;
+    const int P = nfft / 2 + 1;
+    const cplx* We = W + (size_t)e * P * C;
+    for (int j = threadIdx.x; j < nfft / 2; j += blockDim.x) tws[j] = tw[j];
+    // partner channel and sign for the complex-SH conjugate rule
+    int cpart = c;
+    double sgn = 1.0;
+    if (conj_mode == 1) {
+        const int n = (int)floor(sqrt((double)c));
+        const int m = c - n * n - n;
+        cpart = n * n + n - m;
+        sgn = (m & 1) ? -1.0 : 1.0;
+    }
+    const int n_shift = nfft / 2;
+    const double delay = (e == 0) ? (double)n_shift : ((double)n_shift + grpd[1]) - grpd[0];
+    for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
+        cplx v;
+        int kb;
+        if (k < P) {
+            kb = k;
+            v = We[(size_t)kb * C + c];
+            if (kb == 0 && dc_rule) v = mk(We[(size_t)1 * C + c].x, 0.0);
+        } else {
+            kb = nfft - k;
+            v = conj(We[(size_t)kb * C + cpart]);
+            v.x *= sgn; v.y *= sgn;
+        }
+        if (shift_mode == 0) {
+            const double omega = (double)kb / (double)nfft;
+            double s, cs;
+            sincos((6.283185307179586 * omega) * delay, &s, &cs);  // exp(-1j*2*pi*omega*delay) = cs - i s
+            cplx E = mk(cs, -s);
+            if (kb == P - 1) E.y = 0.0;
+            if (k >= P) E.y = -E.y;  // mirrored half is conj (applySubsampleDelay.m:13)
+            v = v * E;
+        }
+        buf[bitrev((unsigned)k, log2n)] = v;
+    }
+    __syncthreads();
+    lds_fft_stages<true>(buf, tws, nfft, log2n, 1);
+    const double inv_n = 1.0 / (double)nfft;
+    const int nf = (int)round(0.15 * (double)len);  // getFadeWindow.m:11-12
+    const int t0 = n_shift - len / 2;
+    for (int tt = threadIdx.x; tt < len; tt += blockDim.x) {
+        int t = t0 + tt;
+        if (shift_mode == 1) { t = (t - n_shift) % nfft; if (t < 0) t += nfft; }
+        cplx v = buf[t];
+        double win = 1.0;
+        if (tt < nf || tt >= len - nf) {
+            // hann(2 nf): first half evaluated, second half mirrored (MATLAB builds symmetric windows that way)
+            int i = (tt < nf) ? tt : (2 * nf - 1 - (nf + (tt - (len - nf))));
+            win = 0.5 - 0.5 * cos(2.0 * kPi * (double)i / (double)(2 * nf - 1));
+        }
+        v.x *= inv_n * win;
+        v.y *= inv_n * win;
+        if (out_cplx) {
+            cplx* o = reinterpret_cast<cplx*>(e ? outR : outL);
+            o[(size_t)c * len + tt] = v;
+        } else {
+            double* o = reinterpret_cast<double*>(e ? outR : outL);
+            o[(size_t)c * len + tt] = v.x;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+
+void launch_twiddles(int nfft, void* tw, hipStream_t st) {
+    twiddle_kernel<<<(nfft + 255) / 256, 256, 0, st>>>(nfft, (cplx*)tw);
+    KERNEL_CHECK();
+}
+
+int hrir_dirsum_chunks(int64_t D) { return (int)ceil_div(D, 64); }
+
+void launch_hrir_grpdelay(const double* hL, const double* hR, int64_t L, int64_t D, int nfft, const void* tw,
+                          double* partial, double* grpd, hipStream_t st) {
+    const int chunk = 64;
+    const int nchunks = hrir_dirsum_chunks(D);
+    hrir_dirsum_kernel<<<dim3(nchunks, 2), 256, 0, st>>>(hL, hR, L, D, chunk, partial);
+    KERNEL_CHECK();
+    const int P = nfft / 2 + 1;
+    int npow2 = 1;
+    while (npow2 < P) npow2 <<= 1;
+    size_t sm = (((size_t)L + 1) & ~(size_t)1) * 8 + (size_t)npow2 * 8;
+    grpdelay_median_kernel<<<2, 1024, sm, st>>>(partial, nchunks, L, nfft, (const cplx*)tw, grpd);
+    KERNEL_CHECK();
+}
+
+void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, const int64_t* didx, int nfft,
+                     const void* tw, const double* grpd, int mode, int n_c, int kabs0, void* Hc, double* Habs,
+                     int64_t ldD, hipStream_t st) {
+    const int log2n = ilog2(nfft);
+    int TD = 8;
+    while (TD > 1 && (size_t)TD * nfft * 16 + (size_t)nfft * 8 > 150 * 1024) TD >>= 1;
+    const size_t sm = (size_t)TD * nfft * 16 + (size_t)nfft * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)real_fft_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hrir_fft_kernel<<<(unsigned)ceil_div(D, TD), 512, sm, st>>>(hL, hR, L, D, didx, nfft, log2n, TD, (const cplx*)tw, grpd, mode,
+                                                               n_c, kabs0, (cplx*)Hc, Habs, ldD);
+    KERNEL_CHECK();
+}
+
+void launch_real_fft_gather(const double* x, int64_t L, int64_t ncols, const int64_t* colidx, int nfft, const void* tw,
+                            void* out, int64_t ldo, int64_t inner, int64_t ld_inner, hipStream_t st) {
+    const int log2n = ilog2(nfft);
+    int TP = 8;
+    while (TP > 1 && (size_t)TP * nfft * 16 + (size_t)nfft * 8 > 150 * 1024) TP >>= 1;
+    const size_t sm = (size_t)TP * nfft * 16 + (size_t)nfft * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)real_fft_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int64_t npairs = (ncols + 1) / 2;
+    real_fft_gather_kernel<<<(unsigned)ceil_div(npairs, TP), 512, sm, st>>>(x, L, ncols, colidx, nfft, log2n, TP,
+                                                                          (const cplx*)tw, (cplx*)out, ldo, inner, ld_inner);
+    KERNEL_CHECK();
+}
+
+void launch_filter_epilogue(const void* W, int C, int nfft, int len, const void* tw, const double* grpd, int conj_mode,
+                            int dc_rule, int shift_mode, int out_cplx, void* outL, void* outR, hipStream_t st) {
+    const int log2n = ilog2(nfft);
+    const size_t sm = (size_t)nfft * 16 + (size_t)nfft * 8;
+    filter_epilogue_kernel<<<dim3(C, 2), 256, sm, st>>>((const cplx*)W, C, nfft, log2n, len, (const cplx*)tw, grpd,
+                                                        conj_mode, dc_rule, shift_mode, out_cplx, outL, outR);
+    KERNEL_CHECK();
+}
+
+}  // namespace emagls

@@ -1,0 +1,375 @@
+// Orthonormal compression of the HRIR-grid SH matrix:  conj(Y) = Q R  (Cholesky-QR)
+//
+//   gram      G = Yc^H Yc  (S x S, upper block triangle)   FP64 MFMA v_mfma_f64_16x16x4_f64, split-K
+//   cholesky  G = R^H R    blocked right-looking, 2 launches per 32-column panel
+//   qform     Q = Yc R^-1  row-parallel forward substitution (rows are independent)
+//   tn        T_n = R(:,blk_n) E(:,blk_n)^T  so that  R diag(b_n) E^T = sum_n b_n T_n
+//
+// This replaces the reference's per-bin  pwGrid = smairMat(:,:,k) * Y_Hi_conj  (lib/getEMagLsFilters.m:87)
+// + svd(pwGrid.')  (:88) on a D x C matrix by an S x C problem:  pwGrid.' = conj(Y) A_k^T = Q (R A_k^T).
+// The HRIR grid's SH matrix is well conditioned (cond 1.5 at N=19 on the 2702-point grid), so
+// Cholesky-QR loses nothing; a non-positive pivot raises a device flag and the host reports it.
+#include "kernels.hpp"
+
+namespace emagls {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// Gram.  Workgroup = 4 waves = 64x64 tile of G, each wave a 32x32 sub-tile (2x2 MFMA tiles).
+// grid.x enumerates upper block-triangle tiles (ti <= tj), grid.y = K split.
+// Yc is [Dpad][ld] with rows >= D zero.  Lane l feeds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
+// f64 C/D layout: col = l&15, row = (l>>4) + 4*reg.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct GramAcc;
+template <> struct GramAcc<double> {
+    double4_t r[2][2];
+    __device__ void init() { for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) r[a][b] = double4_t{0, 0, 0, 0}; }
+};
+template <> struct GramAcc<cplx> {
+    double4_t r[2][2], i[2][2];
+    __device__ void init() {
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) { r[a][b] = double4_t{0, 0, 0, 0}; i[a][b] = double4_t{0, 0, 0, 0}; }
+    }
+};
+
+__device__ __forceinline__ void gram_step(GramAcc<double>& acc, const double (&a)[2], const double (&b)[2]) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc.r[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc.r[x][y], 0, 0, 0);
+}
+__device__ __forceinline__ void gram_step(GramAcc<cplx>& acc, const cplx (&a)[2], const cplx (&b)[2]) {
+    // G = conj(A)^T B :  Gr += ar br + ai bi ;  Gi += ar bi - ai br
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            acc.r[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x].x, b[y].x, acc.r[x][y], 0, 0, 0);
+            acc.r[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x].y, b[y].y, acc.r[x][y], 0, 0, 0);
+            acc.i[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x].x, b[y].y, acc.i[x][y], 0, 0, 0);
+            acc.i[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[x].y, b[y].x, acc.i[x][y], 0, 0, 0);
+        }
+}
+__device__ __forceinline__ double gram_get(const GramAcc<double>& acc, int x, int y, int r, double*) { return acc.r[x][y][r]; }
+__device__ __forceinline__ cplx gram_get(const GramAcc<cplx>& acc, int x, int y, int r, cplx*) {
+    return mk(acc.r[x][y][r], acc.i[x][y][r]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gram_mfma_kernel(const T* __restrict__ Yc, int64_t ld, int S, int kc, int nbt,
+                                                        T* __restrict__ Gp) {
+    // decode upper-triangle tile index
+    int t = blockIdx.x, ti = 0;
+    while (t >= nbt - ti) { t -= nbt - ti; ++ti; }
+    const int tj = ti + t;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i0 = ti * 64 + (wave >> 1) * 32, j0 = tj * 64 + (wave & 1) * 32;
+    const int ii = lane & 15, kk = lane >> 4;
+    const int64_t dbeg = (int64_t)blockIdx.y * kc;
+    GramAcc<T> acc;
+    acc.init();
+    const bool va0 = i0 + ii < S, va1 = i0 + 16 + ii < S, vb0 = j0 + ii < S, vb1 = j0 + 16 + ii < S;
+    for (int64_t d = dbeg; d < dbeg + kc; d += 4) {
+        const T* row = Yc + (d + kk) * ld;
+        T a[2], b[2];
+        a[0] = va0 ? row[i0 + ii] : zero_of<T>();
+        a[1] = va1 ? row[i0 + 16 + ii] : zero_of<T>();
+        b[0] = vb0 ? row[j0 + ii] : zero_of<T>();
+        b[1] = vb1 ? row[j0 + 16 + ii] : zero_of<T>();
+        gram_step(acc, a, b);
+    }
+    T* out = Gp + (int64_t)blockIdx.y * S * S;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = i0 + 16 * x + kk + 4 * r, gj = j0 + 16 * y + ii;
+                if (gi < S && gj < S) out[(int64_t)gi * S + gj] = gram_get(acc, x, y, r, (T*)nullptr);
+            }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const T* __restrict__ Gp, int S, int ksplit, T* __restrict__ G) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)S * S) return;
+    const int i = (int)(idx / S), j = (int)(idx % S);
+    T acc = zero_of<T>();
+    if ((i >> 6) <= (j >> 6))
+        for (int y = 0; y < ksplit; ++y) acc = acc + Gp[(int64_t)y * S * S + idx];
+    G[idx] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// blocked Cholesky  G = R^H R  (upper, in place; only the upper triangle is read or written)
+// ---------------------------------------------------------------------------------------------
+constexpr int NB = 32;
+
+template <typename T> __device__ __forceinline__ double real_of(T v);
+template <> __device__ __forceinline__ double real_of<double>(double v) { return v; }
+template <> __device__ __forceinline__ double real_of<cplx>(cplx v) { return v.x; }
+template <typename T> __device__ __forceinline__ T scale_real(T v, double s);
+template <> __device__ __forceinline__ double scale_real<double>(double v, double s) { return v * s; }
+template <> __device__ __forceinline__ cplx scale_real<cplx>(cplx v, double s) { return mk(v.x * s, v.y * s); }
+
+// panel kernel: every workgroup factors the diagonal block redundantly in LDS, then solves its own
+// 32-column slice of the block row:  R(J, c) = R_JJ^-H G(J, c).
+template <typename T>
+__global__ void __launch_bounds__(256) chol_panel_kernel(T* __restrict__ G, int S, int j0, int* __restrict__ flag) {
+    __shared__ T Rd[NB][NB + 1];
+    __shared__ int bad;
+    const int nb = min(NB, S - j0);
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+        const int r = idx / NB, c = idx % NB;
+        Rd[r][c] = (r < nb && c < nb && r <= c) ? G[(int64_t)(j0 + r) * S + j0 + c] : zero_of<T>();
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        const double piv = real_of(Rd[j][j]);
+        if (!(piv > 0.0)) { if (tid == 0) bad = 1; }
+        const double dinv = 1.0 / sqrt(piv > 0.0 ? piv : 1.0);
+        __syncthreads();
+        if (tid >= j && tid < nb) Rd[j][tid] = scale_real(Rd[j][tid], dinv);  // row j: diag becomes sqrt(piv)
+        __syncthreads();
+        for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+            const int r = idx / NB, c = idx % NB;
+            if (r > j && r < nb && c >= r && c < nb) {
+                T acc = zero_of<T>();
+                cfma_conj(acc, Rd[j][r], Rd[j][c]);
+                Rd[r][c] = Rd[r][c] - acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (bad && tid == 0) atomicExch(flag, 1 + j0);
+    const int c0 = j0 + blockIdx.x * NB;
+    if (blockIdx.x == 0) {
+        for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+            const int r = idx / NB, c = idx % NB;
+            if (r < nb && c < nb && r <= c) G[(int64_t)(j0 + r) * S + j0 + c] = Rd[r][c];
+        }
+    } else if (tid < NB && c0 + tid < S) {
+        const int c = c0 + tid;
+        T x[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) x[i] = (i < nb) ? G[(int64_t)(j0 + i) * S + c] : zero_of<T>();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (i < nb) {
+                T acc = x[i];
+#pragma unroll
+                for (int l = 0; l < NB; ++l)
+                    if (l < i) { T p = zero_of<T>(); cfma_conj(p, Rd[l][i], x[l]); acc = acc - p; }
+                x[i] = scale_real(acc, 1.0 / real_of(Rd[i][i]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (i < nb) G[(int64_t)(j0 + i) * S + c] = x[i];
+    }
+}
+
+// trailing update: G(r, c) -= sum_{i in J} conj(R(i, r)) R(i, c) for r <= c beyond the panel
+template <typename T>
+__global__ void __launch_bounds__(256) chol_update_kernel(T* __restrict__ G, int S, int j0, int nbt) {
+    __shared__ T Pr[NB][NB + 1], Pc[NB][NB + 1];
+    int t = blockIdx.x, bi = 0;
+    while (t >= nbt - bi) { t -= nbt - bi; ++bi; }
+    const int bj = bi + t;
+    const int j1 = j0 + NB;
+    const int r0 = j1 + bi * NB, c0 = j1 + bj * NB;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+        const int i = idx / NB, x = idx % NB;
+        Pr[i][x] = (r0 + x < S) ? G[(int64_t)(j0 + i) * S + r0 + x] : zero_of<T>();
+        Pc[i][x] = (c0 + x < S) ? G[(int64_t)(j0 + i) * S + c0 + x] : zero_of<T>();
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+        const int r = idx / NB, c = idx % NB;
+        if (r0 + r < S && c0 + c < S && r0 + r <= c0 + c) {
+            T acc = zero_of<T>();
+#pragma unroll
+            for (int i = 0; i < NB; ++i) cfma_conj(acc, Pr[i][r], Pc[i][c]);
+            T* g = &G[(int64_t)(r0 + r) * S + c0 + c];
+            *g = *g - acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Q = Yc R^-1.  TR rows per workgroup; thread owns columns c = tid + 256 i.
+// Right-looking: once q_j is known, subtract q_j R(j, c) from all later columns.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int CPT>
+__global__ void __launch_bounds__(256) qform_kernel(const T* __restrict__ Yc, const T* __restrict__ R, int S, int64_t D,
+                                                    int64_t ld, T* __restrict__ Q) {
+    constexpr int TR = 4;
+    __shared__ T qj[2][TR];
+    const int tid = threadIdx.x;
+    const int64_t d0 = (int64_t)blockIdx.x * TR;
+    T y[TR][CPT];
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 256 * i;
+            y[r][i] = (c < S && d0 + r < D) ? Yc[(d0 + r) * ld + c] : zero_of<T>();
+        }
+    for (int j = 0; j < S; ++j) {
+        const int oi = j >> 8, ot = j & 255, buf = j & 1;
+        if (tid == ot) {
+            const double dinv = 1.0 / real_of(R[(int64_t)j * S + j]);
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+                if (i == oi) {
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) {
+                        y[r][i] = scale_real(y[r][i], dinv);
+                        qj[buf][r] = y[r][i];
+                    }
+                }
+        }
+        __syncthreads();
+        T q[TR];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) q[r] = qj[buf][r];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 256 * i;
+            if (c > j && c < S) {
+                const T rv = R[(int64_t)j * S + c];
+#pragma unroll
+                for (int r = 0; r < TR; ++r) { T p = zero_of<T>(); cfma(p, q[r], rv); y[r][i] = y[r][i] - p; }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 256 * i;
+            if (c < S && d0 + r < D) Q[(d0 + r) * ld + c] = y[r][i];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// T[n][c][s] = sum_{j in [n^2,(n+1)^2)} R[s][j] E[c][j]   (zero for s >= (n+1)^2: R is upper triangular)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) tn_kernel(const T* __restrict__ R, const T* __restrict__ E, int S, int C, int ldE,
+                                                 T* __restrict__ Tn, int64_t ldS) {
+    const int n = blockIdx.x, c = blockIdx.y;
+    const int jb = n * n, je = (n + 1) * (n + 1);
+    T* out = Tn + ((int64_t)n * C + c) * ldS;
+    for (int s = threadIdx.x; s < ldS; s += blockDim.x) {
+        T acc = zero_of<T>();
+        if (s < je && s < S)
+            for (int j = max(jb, s); j < je; ++j) cfma(acc, R[(int64_t)s * S + j], E[(int64_t)c * ldE + j]);
+        out[s] = acc;
+    }
+}
+
+// small dense product  Cm[i][j] = sum_l A[i][l] Bm[l][j]   (E = pinv(Y_Lo) Y_mic etc.)
+template <typename TA, typename TB, typename TC>
+__global__ void __launch_bounds__(256) small_gemm_kernel(const TA* __restrict__ A, int lda, const TB* __restrict__ Bm, int ldb,
+                                                         TC* __restrict__ Cm, int ldc, int M, int N, int K) {
+    const int i = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+        cplx acc = mk(0, 0);
+        for (int l = 0; l < K; ++l) { cplx p = to_cplx(A[(int64_t)i * lda + l]) * to_cplx(Bm[(int64_t)l * ldb + j]); acc += p; }
+        if constexpr (sizeof(TC) == sizeof(double)) Cm[(int64_t)i * ldc + j] = acc.x; else Cm[(int64_t)i * ldc + j] = acc;
+    }
+    (void)M;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int gram_ksplit(int64_t D) {
+    int ks = 32;
+    while (ks > 1 && D / ks < 32) ks >>= 1;
+    return ks;
+}
+int64_t gram_dpad(int64_t D) {
+    const int ks = gram_ksplit(D);
+    const int64_t kc = ceil_div(ceil_div(D, ks), 4) * 4;
+    return kc * ks;
+}
+
+template <typename T>
+static void gram_impl(const void* Yc, int64_t D, int S, int64_t ld, void* Gp, void* G, hipStream_t st) {
+    const int ks = gram_ksplit(D);
+    const int kc = (int)(gram_dpad(D) / ks);
+    const int nbt = (S + 63) / 64;
+    const int ntiles = nbt * (nbt + 1) / 2;
+    gram_mfma_kernel<T><<<dim3(ntiles, ks), 256, 0, st>>>((const T*)Yc, ld, S, kc, nbt, (T*)Gp);
+    KERNEL_CHECK();
+    gram_reduce_kernel<T><<<(unsigned)ceil_div((int64_t)S * S, 256), 256, 0, st>>>((const T*)Gp, S, ks, (T*)G);
+    KERNEL_CHECK();
+}
+void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, void* Gp, void* G, hipStream_t st) {
+    if (is_cplx) gram_impl<cplx>(Yc, D, S, ld, Gp, G, st); else gram_impl<double>(Yc, D, S, ld, Gp, G, st);
+}
+
+template <typename T> static void chol_impl(void* G, int S, int* flag, hipStream_t st) {
+    for (int j0 = 0; j0 < S; j0 += NB) {
+        const int rem = S - j0;
+        const int ncb = (rem + NB - 1) / NB;  // column blocks incl. the diagonal one
+        chol_panel_kernel<T><<<ncb, 256, 0, st>>>((T*)G, S, j0, flag);
+        KERNEL_CHECK();
+        const int nbt = ncb - 1;
+        if (nbt > 0) {
+            chol_update_kernel<T><<<nbt * (nbt + 1) / 2, 256, 0, st>>>((T*)G, S, j0, nbt);
+            KERNEL_CHECK();
+        }
+    }
+}
+void launch_cholesky(void* G, int S, bool is_cplx, int* flag, hipStream_t st) {
+    if (is_cplx) chol_impl<cplx>(G, S, flag, st); else chol_impl<double>(G, S, flag, st);
+}
+
+template <typename T> static void qform_impl(const void* Yc, const void* R, int S, int64_t D, int64_t ld, void* Q, hipStream_t st) {
+    const unsigned grid = (unsigned)ceil_div(D, 4);
+    const int cpt = (S + 255) / 256;
+    switch (cpt) {
+        case 1: qform_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q); break;
+        case 2: qform_kernel<T, 2><<<grid, 256, 0, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q); break;
+        case 3: qform_kernel<T, 3><<<grid, 256, 0, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q); break;
+        case 4: qform_kernel<T, 4><<<grid, 256, 0, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q); break;
+        default: throw Error(2, "qform: more than 1024 SH channels is not supported in this build");
+    }
+    KERNEL_CHECK();
+}
+void launch_qform(const void* Yc, const void* R, int S, int64_t D, int64_t ld, bool is_cplx, void* Q, hipStream_t st) {
+    if (is_cplx) qform_impl<cplx>(Yc, R, S, D, ld, Q, st); else qform_impl<double>(Yc, R, S, D, ld, Q, st);
+}
+
+void launch_tn(const void* R, const void* E, int S, int C, int ldE, int nOrders, bool is_cplx, void* Tn, int64_t ldS,
+               hipStream_t st) {
+    if (is_cplx) tn_kernel<cplx><<<dim3(nOrders, C), 256, 0, st>>>((const cplx*)R, (const cplx*)E, S, C, ldE, (cplx*)Tn, ldS);
+    else tn_kernel<double><<<dim3(nOrders, C), 256, 0, st>>>((const double*)R, (const double*)E, S, C, ldE, (double*)Tn, ldS);
+    KERNEL_CHECK();
+}
+
+void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int ldb, bool b_cplx, void* Cm, int ldc,
+                       bool c_cplx, int M, int N, int K, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(N, 256), M);
+    if (a_cplx && b_cplx && c_cplx)
+        small_gemm_kernel<cplx, cplx, cplx><<<grid, 256, 0, st>>>((const cplx*)A, lda, (const cplx*)B, ldb, (cplx*)Cm, ldc, M, N, K);
+    else if (a_cplx && !b_cplx && c_cplx)
+        small_gemm_kernel<cplx, double, cplx><<<grid, 256, 0, st>>>((const cplx*)A, lda, (const double*)B, ldb, (cplx*)Cm, ldc, M, N, K);
+    else if (a_cplx && !b_cplx && !c_cplx)
+        small_gemm_kernel<cplx, double, double><<<grid, 256, 0, st>>>((const cplx*)A, lda, (const double*)B, ldb, (double*)Cm, ldc, M, N, K);
+    else if (!a_cplx && !b_cplx && !c_cplx)
+        small_gemm_kernel<double, double, double><<<grid, 256, 0, st>>>((const double*)A, lda, (const double*)B, ldb, (double*)Cm, ldc, M, N, K);
+    else
+        throw Error(2, "small_gemm: unsupported type combination");
+    KERNEL_CHECK();
+}
+
+}  // namespace emagls

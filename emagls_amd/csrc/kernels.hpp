@@ -1,0 +1,80 @@
+// Launcher declarations shared by the kernel translation units and the C ABI (capi.hip).
+#pragma once
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace emagls {
+
+// ---- sh_basis.hip
+void launch_sh_coeff(int N, double* tab, hipStream_t st);
+inline size_t sh_coeff_count(int N) { return (size_t)2 * (N + 1) * (N + 1) + 2 * (N + 1); }
+void launch_sh_basis(int N, int64_t D, const double* azi, const double* zen, const double* tab, bool cplx_basis,
+                     void* Y, int64_t ld, hipStream_t st);
+void launch_transpose_conj(const void* Y, int64_t D, int64_t S, int64_t ldY, void* Yt, int64_t Dpad, int64_t ldYt,
+                           bool is_cplx, bool conj_it, hipStream_t st);
+
+// ---- modal.hip
+void launch_modal_bn(int N, int64_t nfreq, const double* kr, double kr_scale, double out_scale, void* bn,
+                     int64_t stride_k, int64_t stride_n, hipStream_t st);
+
+// ---- fft.hip
+void launch_twiddles(int nfft, void* tw, hipStream_t st);
+int hrir_dirsum_chunks(int64_t D);
+void launch_hrir_grpdelay(const double* hL, const double* hR, int64_t L, int64_t D, int nfft, const void* tw,
+                          double* partial, double* grpd, hipStream_t st);
+void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, const int64_t* didx, int nfft,
+                     const void* tw, const double* grpd, int mode, int n_c, int kabs0, void* Hc, double* Habs,
+                     int64_t ldD, hipStream_t st);
+void launch_real_fft_gather(const double* x, int64_t L, int64_t ncols, const int64_t* colidx, int nfft, const void* tw,
+                            void* out, int64_t ldo, int64_t inner, int64_t ld_inner, hipStream_t st);
+void launch_filter_epilogue(const void* W, int C, int nfft, int len, const void* tw, const double* grpd, int conj_mode,
+                            int dc_rule, int shift_mode, int out_cplx, void* outL, void* outR, hipStream_t st);
+
+// ---- gram_chol.hip
+int gram_ksplit(int64_t D);
+int64_t gram_dpad(int64_t D);
+void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, void* Gp, void* G, hipStream_t st);
+void launch_cholesky(void* G, int S, bool is_cplx, int* flag, hipStream_t st);
+void launch_qform(const void* Yc, const void* R, int S, int64_t D, int64_t ld, bool is_cplx, void* Q, hipStream_t st);
+void launch_tn(const void* R, const void* E, int S, int C, int ldE, int nOrders, bool is_cplx, void* Tn, int64_t ldS,
+               hipStream_t st);
+void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int ldb, bool b_cplx, void* Cm, int ldc,
+                       bool c_cplx, int M, int N, int K, hipStream_t st);
+
+// ---- factor.hip
+struct FactorArgs;
+void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st);
+
+// ---- sweep.hip
+struct SweepArgs;
+struct DenseSweepArgs;
+void launch_sweep_factored(const SweepArgs& a, int kb, bool q_cplx, hipStream_t st);
+void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st);
+int dense_sweep_nwg(int D);
+void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
+void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
+               int kb_hi, void* Hq, int ldS, hipStream_t st);
+void launch_ypinv(const void* Q, int64_t ldQ, bool q_cplx, const void* Zb, int ldS, int D, int S, int C, void* Ypinv,
+                  int64_t ldD, hipStream_t st);
+void launch_ls_apply(const void* Hc, int64_t ldH, int n_c, const void* Zf, bool z_cplx, int64_t ldD, int D, int C, int P,
+                     int kb_lo, int kb_hi, void* W, hipStream_t st);
+void launch_ls_filters(const double* hL, const double* hR, int64_t L, int D, const void* Yp, bool cplx_basis, int64_t ldD,
+                       int C, void* wL, void* wR, hipStream_t st);
+void launch_conj_copy(const void* in, void* out, int64_t n, bool is_cplx, hipStream_t st);
+void launch_widen(const void* in, int64_t ldi, bool in_cplx, void* out, int64_t ldo, int rows, int cols, bool transpose,
+                  bool upper_only, hipStream_t st);
+
+// ---- atf.hip
+void launch_grid_match(const double* aziA, const double* zenA, int64_t nA, const double* aziB, const double* zenB,
+                       int64_t nB, double* cartB, int64_t* idx, double* dev_deg, double* mean_dev, hipStream_t st);
+void launch_atf_colidx(const int64_t* idx, int64_t nA, int M, int64_t* colidx, hipStream_t st);
+
+// ---- decode.hip
+void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL, const double* wR, int64_t len,
+                          double* out /* [n x 2] column-major */, hipStream_t st);
+
+}  // namespace emagls
+
+// full definitions of the argument structs (kept in their kernel files' header section)
+#include "args.hpp"

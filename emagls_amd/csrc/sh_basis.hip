@@ -1,0 +1,147 @@
+// Spherical-harmonic basis assembly (replaces polarch getSH; call sites lib/getLsFilters.m:30,
+// lib/getMagLsFilters.m:47, lib/getEMagLsFilters.m:68, dependencies/getSMAIRMatrix.m:101).
+//
+// One thread per direction.  Fully-normalised associated-Legendre three-term recurrence in n for
+// fixed m, seeded from the sectoral term, normalisation folded into the recurrence coefficients (no
+// factorials, so orders > 85 do not overflow as the reference's factorial form does).  The
+// recurrence coefficients are wave-uniform and come from a small table (scalar loads).  Output is
+// MATLAB column-major [ (N+1)^2 ][ D ]: consecutive lanes = consecutive directions, so every store
+// instruction of a wave writes 512 contiguous bytes (real) / 1 KiB (complex) -- the kernel is an
+// HBM-write stream: 8*D*S (real) or 16*D*S (complex) algorithmic bytes, 16*D bytes read.
+#include "kernels.hpp"
+
+namespace emagls {
+
+// table layout: A[n*(N+1)+m], B[n*(N+1)+m] for n >= m+2;  C1[m] = sqrt(2m+3);  CM[m] = sqrt((2m+1)/(2m))
+__global__ void sh_coeff_kernel(int N, double* __restrict__ tab) {
+    const int stride = (N + 1) * (N + 1);
+    double* A = tab;
+    double* B = tab + stride;
+    double* C1 = tab + 2 * stride;
+    double* CM = C1 + (N + 1);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < stride; idx += gridDim.x * blockDim.x) {
+        int n = idx / (N + 1), m = idx % (N + 1);
+        double a = 0.0, b = 0.0;
+        if (n >= m + 2) {
+            double nn = (double)n, mm = (double)m;
+            a = sqrt((4.0 * nn * nn - 1.0) / (nn * nn - mm * mm));
+            b = sqrt(((nn - 1.0) * (nn - 1.0) - mm * mm) / (4.0 * (nn - 1.0) * (nn - 1.0) - 1.0));
+        }
+        A[idx] = a;
+        B[idx] = b;
+        if (n == 0) {
+            C1[m] = sqrt(2.0 * m + 3.0);
+            CM[m] = (m == 0) ? 0.0 : sqrt((2.0 * m + 1.0) / (2.0 * m));
+        }
+    }
+}
+
+template <bool COMPLEX>
+__global__ void __launch_bounds__(256) sh_basis_kernel(int N, int64_t D, const double* __restrict__ azi,
+                                                       const double* __restrict__ zen,
+                                                       const double* __restrict__ tab, double* __restrict__ Y,
+                                                       int64_t ld) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const int stride = (N + 1) * (N + 1);
+    const double* A = tab;
+    const double* B = tab + stride;
+    const double* C1 = tab + 2 * stride;
+    const double* CM = C1 + (N + 1);
+    const double phi = azi[d];
+    // MATLAB legendre() sees only x = cos(zenith); sin is sqrt(1-x^2) >= 0 (matters at the poles)
+    const double x = cos(zen[d]);
+    const double s = sqrt(fmax(0.0, 1.0 - x * x));
+    const double SQ2 = 1.4142135623730951;
+    double pmm = 0.28209479177387814;  // sqrt(1/(4 pi))
+    for (int m = 0; m <= N; ++m) {
+        if (m > 0) pmm *= CM[m] * s;
+        double sn = 0.0, cs = 1.0;
+        if (m > 0) sincos((double)m * phi, &sn, &cs);
+        const double sign = (m & 1) ? -1.0 : 1.0;
+        double p0 = pmm, p1 = 0.0;
+        for (int n = m; n <= N; ++n) {
+            double p;
+            if (n == m) {
+                p = p0;
+            } else if (n == m + 1) {
+                p1 = C1[m] * x * p0;
+                p = p1;
+            } else {
+                p = A[n * (N + 1) + m] * (x * p1 - B[n * (N + 1) + m] * p0);
+                p0 = p1;
+                p1 = p;
+            }
+            const int64_t base = (int64_t)n * n + n;
+            if (COMPLEX) {
+                cplx* Yc = reinterpret_cast<cplx*>(Y);
+                if (m == 0) {
+                    Yc[base * ld + d] = mk(p, 0.0);
+                } else {
+                    Yc[(base + m) * ld + d] = mk(sign * p * cs, sign * p * sn);  // Condon-Shortley
+                    Yc[(base - m) * ld + d] = mk(p * cs, -p * sn);               // (-1)^m conj(Y_n^m)
+                }
+            } else {
+                if (m == 0) {
+                    Y[base * ld + d] = p;
+                } else {
+                    Y[(base + m) * ld + d] = SQ2 * p * cs;
+                    Y[(base - m) * ld + d] = SQ2 * p * sn;
+                }
+            }
+        }
+    }
+}
+
+// Yt[d][s] = conj(Y[s][d]) (or plain transpose when conj_it == 0), rows d in [D, Dpad) zero-filled.
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_conj_kernel(const T* __restrict__ Y, int64_t D, int64_t S, int64_t ldY,
+                                                             T* __restrict__ Yt, int64_t Dpad, int64_t ldYt,
+                                                             int conj_it) {
+    __shared__ T tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t d0 = (int64_t)blockIdx.x * 32, s0 = (int64_t)blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8) {
+        int64_t s = s0 + r, d = d0 + tx;
+        T v = zero_of<T>();
+        if (s < S && d < D) v = Y[s * ldY + d];
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int64_t d = d0 + r, s = s0 + tx;
+        if (d < Dpad && s < S) {
+            T v = tile[tx][r];
+            Yt[d * ldYt + s] = conj_it ? conj(v) : v;
+        }
+    }
+}
+
+void launch_sh_coeff(int N, double* tab, hipStream_t st) {
+    sh_coeff_kernel<<<8, 256, 0, st>>>(N, tab);
+    KERNEL_CHECK();
+}
+
+void launch_sh_basis(int N, int64_t D, const double* azi, const double* zen, const double* tab, bool cplx_basis,
+                     void* Y, int64_t ld, hipStream_t st) {
+    if (D <= 0) return;
+    dim3 grid((unsigned)ceil_div(D, 256));
+    if (cplx_basis)
+        sh_basis_kernel<true><<<grid, 256, 0, st>>>(N, D, azi, zen, tab, (double*)Y, ld);
+    else
+        sh_basis_kernel<false><<<grid, 256, 0, st>>>(N, D, azi, zen, tab, (double*)Y, ld);
+    KERNEL_CHECK();
+}
+
+void launch_transpose_conj(const void* Y, int64_t D, int64_t S, int64_t ldY, void* Yt, int64_t Dpad, int64_t ldYt,
+                           bool is_cplx, bool conj_it, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(Dpad, 32), (unsigned)ceil_div(S, 32));
+    if (is_cplx)
+        transpose_conj_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)Y, D, S, ldY, (cplx*)Yt, Dpad, ldYt, conj_it);
+    else
+        transpose_conj_kernel<double><<<grid, 256, 0, st>>>((const double*)Y, D, S, ldY, (double*)Yt, Dpad, ldYt,
+                                                           conj_it);
+    KERNEL_CHECK();
+}
+
+}  // namespace emagls

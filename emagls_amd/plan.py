@@ -1,0 +1,93 @@
+"""Plan objects: inputs resident in HBM, repeated execution, stage timing, debug buffers."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Plan:
+    def __init__(self, kind, basis="real", order=4, fs=48000.0, length=512, nsamp=128, ndirs=0, mic_radius=0.0, nmics=0,
+                 f_trans=0.0, atf_taps=0, natf=0):
+        self._lib = L.load()
+        self.desc = L.DesignDesc(kind, L.BASIS[basis], order, fs, length, nsamp, ndirs, mic_radius, nmics, f_trans,
+                                 atf_taps, natf)
+        self._h = C.c_void_p()
+        L.check(self._lib.emagls_plan_create(C.byref(self.desc), C.byref(self._h)))
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            self._lib.emagls_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _p(self, a):
+        a = np.asfortranarray(np.asarray(a, dtype=np.float64))
+        self._keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    def set_hrir_grid(self, azi, zen):
+        L.check(self._lib.emagls_plan_set_hrir_grid(self._h, self._p(azi), self._p(zen)))
+
+    def set_mic_grid(self, azi, zen):
+        L.check(self._lib.emagls_plan_set_mic_grid(self._h, self._p(azi), self._p(zen)))
+
+    def set_hrirs(self, hL, hR):
+        L.check(self._lib.emagls_plan_set_hrirs(self._h, self._p(hL), self._p(hR)))
+
+    def set_atfs(self, atf, azi, zen):
+        L.check(self._lib.emagls_plan_set_atfs(self._h, self._p(atf), self._p(azi), self._p(zen)))
+
+    def execute(self):
+        L.check(self._lib.emagls_plan_execute(self._h))
+
+    def synchronize(self):
+        L.check(self._lib.emagls_plan_synchronize(self._h))
+
+    def info(self):
+        i = L.PlanInfo()
+        L.check(self._lib.emagls_plan_get_info(self._h, C.byref(i)))
+        return i
+
+    def get_filters(self):
+        i = self.info()
+        dt = np.complex128 if i.out_is_complex else np.float64
+        wL = np.zeros((i.out_rows, i.out_cols), dtype=dt, order="F")
+        wR = np.zeros((i.out_rows, i.out_cols), dtype=dt, order="F")
+        L.check(self._lib.emagls_plan_get_filters(self._h, wL.ctypes.data_as(C.c_void_p), wR.ctypes.data_as(C.c_void_p)))
+        return wL, wR
+
+    def set_profiling(self, level):
+        L.check(self._lib.emagls_plan_set_profiling(self._h, int(level)))
+
+    def stage_times(self):
+        n = self._lib.emagls_plan_num_stages(self._h)
+        ms = (C.c_double * max(n, 1))()
+        L.check(self._lib.emagls_plan_stage_times(self._h, ms, n))
+        return [(self._lib.emagls_plan_stage_name(self._h, i).decode(), ms[i]) for i in range(1, n)]
+
+    def sweep_kernel_time(self):
+        tot = C.c_double(0.0)
+        n = C.c_int(0)
+        L.check(self._lib.emagls_plan_sweep_kernel_time(self._h, C.byref(tot), C.byref(n)))
+        return tot.value, n.value
+
+    def debug(self, name, dtype, shape=None):
+        nb = C.c_size_t(0)
+        L.check(self._lib.emagls_plan_debug_buffer(self._h, name.encode(), None, C.byref(nb)))
+        buf = np.empty(nb.value // np.dtype(dtype).itemsize, dtype=dtype)
+        nb2 = C.c_size_t(buf.nbytes)
+        L.check(self._lib.emagls_plan_debug_buffer(self._h, name.encode(), buf.ctypes.data_as(C.c_void_p), C.byref(nb2)))
+        return buf.reshape(shape) if shape is not None else buf
+
+    @property
+    def stream(self):
+        return self._lib.emagls_plan_stream(self._h)

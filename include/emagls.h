@@ -1,0 +1,155 @@
+/* emagls.h -- C ABI of the MI355X-native eMagLS filter-design / binaural-render library.
+ *
+ * Drop-in boundary for the reference's MATLAB entry points (paths relative to thomasdeppisch/eMagLS):
+ *
+ *   emagls_get_ls_filters              <-  lib/getLsFilters.m:1-2
+ *   emagls_get_magls_filters           <-  lib/getMagLsFilters.m:1-2
+ *   emagls_get_emagls_filters          <-  lib/getEMagLsFilters.m:1-2
+ *   emagls_get_emagls2_filters         <-  lib/getEMagLs2Filters.m:1-2
+ *   emagls_get_emagls_filters_from_atf <-  lib/getEMagLsFiltersFromAtf.m:1
+ *   emagls_binaural_decode             <-  dependencies/binauralDecode.m:1-2 (core loop :33-42,53-64)
+ *   emagls_sh_basis                    <-  getSH (polarch/Spherical-Harmonic-Transform, call site lib/getLsFilters.m:30)
+ *   emagls_modal_bn                    <-  sphModalCoeffs (polarch/Array-Response-Simulator, call site dependencies/getSMAIRMatrix.m:107)
+ *
+ * Conventions (identical to the MATLAB side, so a MEX gateway passes mxGetDoubles() pointers through):
+ *   - all arrays are column-major FP64; complex arrays are interleaved (re,im) pairs
+ *     (MATLAB R2018a+ interleaved complex API, numpy complex128);
+ *   - HRIRs are [numSamples x numDirections]; filters come back [len x numChannels];
+ *   - angles in radians, zenith (0..pi), not elevation;
+ *   - basis: EMAGLS_BASIS_REAL -> real outputs (double), EMAGLS_BASIS_COMPLEX -> complex outputs;
+ *   - pointers may be host or device pointers (copies use hipMemcpyDefault); outputs are caller-allocated;
+ *   - every function returns EMAGLS_OK or an error code; emagls_last_error() gives the message
+ *     (the MEX shim forwards it to mexErrMsgIdAndTxt);
+ *   - the default shFunction (@getSH) is built in; a custom MATLAB shFunction handle cannot cross a C ABI.
+ *
+ * Threading: one host thread per plan; one process per GPU for multi-GPU batches.
+ */
+#ifndef EMAGLS_H
+#define EMAGLS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMAGLS_OK 0
+#define EMAGLS_ERR_ARG 1         /* invalid argument; mirrors the reference's assert()s, e.g. "len too short" */
+#define EMAGLS_ERR_UNSUPPORTED 2 /* shape outside what this build supports */
+#define EMAGLS_ERR_HIP 3         /* HIP / hipFFT runtime failure */
+#define EMAGLS_ERR_NUMERIC 4     /* e.g. SH Gram matrix of the HRIR grid not positive definite */
+
+#define EMAGLS_BASIS_REAL 0
+#define EMAGLS_BASIS_COMPLEX 1
+
+#define EMAGLS_KIND_LS 0
+#define EMAGLS_KIND_MAGLS 1
+#define EMAGLS_KIND_EMAGLS 2
+#define EMAGLS_KIND_EMAGLS2 3
+#define EMAGLS_KIND_FROM_ATF 4
+
+const char* emagls_last_error(void);
+int emagls_version(void);
+int emagls_device_count(int* count);
+int emagls_set_device(int device);
+
+/* ---- kernel-level entry points ------------------------------------------------------------- */
+
+/* Y [ndirs x (order+1)^2], column-major; real (8 B) or interleaved complex (16 B) per entry. */
+int emagls_sh_basis(int order, int64_t ndirs, const double* azi, const double* zen, int basis, void* Y);
+
+/* bn [nfreq x (order+1)] interleaved complex, column-major: rigid-sphere modal coefficients b_n(kr). */
+int emagls_modal_bn(int order, int64_t nfreq, const double* kr, void* bn);
+
+/* ---- one-shot filter design (signatures follow the MATLAB functions) ------------------------ */
+
+int emagls_get_ls_filters(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
+                          const double* hrir_azi, const double* hrir_zen, int order, int basis,
+                          void* wL, void* wR /* [nsamp x (order+1)^2] */);
+
+int emagls_get_magls_filters(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
+                             const double* hrir_azi, const double* hrir_zen, int order, double fs, int64_t len,
+                             int basis, void* wL, void* wR /* [len x (order+1)^2] */);
+
+int emagls_get_emagls_filters(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
+                              const double* hrir_azi, const double* hrir_zen, double mic_radius,
+                              const double* mic_azi, const double* mic_zen, int64_t nmics, int order, double fs,
+                              int64_t len, int basis, void* wL, void* wR /* [len x (order+1)^2] */);
+
+int emagls_get_emagls2_filters(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
+                               const double* hrir_azi, const double* hrir_zen, double mic_radius,
+                               const double* mic_azi, const double* mic_zen, int64_t nmics, int order, double fs,
+                               int64_t len, int basis, void* wL, void* wR /* [len x nmics] */);
+
+/* atf_irs [atf_taps x nmics x natf]; outputs real [filter_len x nmics];
+ * mean_grid_dev_deg (optional) receives the value the reference prints (getEMagLsFiltersFromAtf.m:96). */
+int emagls_get_emagls_filters_from_atf(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
+                                       const double* hrir_azi, const double* hrir_zen, const double* atf_irs,
+                                       int64_t atf_taps, int64_t nmics, int64_t natf, const double* atf_azi,
+                                       const double* atf_zen, double fs, int64_t filter_len, double f_trans,
+                                       double* wL, double* wR, double* mean_grid_dev_deg);
+
+/* out [nsamp_out x 2] real, nsamp_out = nsamp (compensate_delay == 0) or nsamp - len/2 + 1 (!= 0).
+ * in [nsamp x nch], wL/wR [len x nch], all real. */
+int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const double* wL, const double* wR,
+                           int64_t len, int compensate_delay, double* out);
+
+/* ---- plan API: inputs resident in HBM, repeated execution (benchmarks, batches) ------------- */
+
+typedef struct emagls_plan emagls_plan;
+
+typedef struct emagls_design_desc {
+    int kind;            /* EMAGLS_KIND_* */
+    int basis;           /* EMAGLS_BASIS_* */
+    int order;           /* SH output order N */
+    double fs;           /* Hz */
+    int64_t len;         /* filter length (ignored for LS) */
+    int64_t nsamp;       /* HRIR taps */
+    int64_t ndirs;       /* HRIR directions */
+    double mic_radius;   /* EMAGLS / EMAGLS2 */
+    int64_t nmics;       /* EMAGLS / EMAGLS2 / FROM_ATF */
+    double f_trans;      /* FROM_ATF: transition frequency in Hz */
+    int64_t atf_taps;    /* FROM_ATF */
+    int64_t natf;        /* FROM_ATF: ATF directions */
+} emagls_design_desc;
+
+typedef struct emagls_plan_info {
+    int nfft, num_pos_freqs, k_cut /* 1-based like the reference */, sim_order, num_sh_sim, num_channels;
+    int out_is_complex;
+    int64_t out_rows, out_cols;
+    double grp_delay_l, grp_delay_r; /* valid after an execute + synchronize */
+    double mean_grid_dev_deg;        /* FROM_ATF */
+    int num_sweep_launches;
+    int64_t device_bytes;
+} emagls_plan_info;
+
+int emagls_plan_create(const emagls_design_desc* desc, emagls_plan** plan);
+int emagls_plan_destroy(emagls_plan* plan);
+int emagls_plan_set_hrir_grid(emagls_plan* plan, const double* azi, const double* zen);
+int emagls_plan_set_mic_grid(emagls_plan* plan, const double* azi, const double* zen);
+int emagls_plan_set_hrirs(emagls_plan* plan, const double* hL, const double* hR);
+int emagls_plan_set_atfs(emagls_plan* plan, const double* atf_irs, const double* atf_azi, const double* atf_zen);
+/* enqueue the whole design (SH basis ... windowed filters) on the plan's stream; returns immediately */
+int emagls_plan_execute(emagls_plan* plan);
+int emagls_plan_synchronize(emagls_plan* plan);
+/* synchronise, check device-side status flags, copy the filters out */
+int emagls_plan_get_filters(emagls_plan* plan, void* wL, void* wR);
+int emagls_plan_get_info(emagls_plan* plan, emagls_plan_info* info);
+/* profiling: level 0 none, 1 = HIP events between stages, 2 = additionally around every sweep launch */
+int emagls_plan_set_profiling(emagls_plan* plan, int level);
+int emagls_plan_num_stages(emagls_plan* plan);
+const char* emagls_plan_stage_name(emagls_plan* plan, int stage);
+/* after execute + synchronize with profiling >= 1: per-stage milliseconds of the last execute */
+int emagls_plan_stage_times(emagls_plan* plan, double* ms, int n);
+/* profiling level 2: sum and count of per-launch sweep kernel durations (ms) of the last execute */
+int emagls_plan_sweep_kernel_time(emagls_plan* plan, double* total_ms, int* launches);
+/* copy an internal device buffer to the host (tests): returns its size in *nbytes when dst == NULL */
+int emagls_plan_debug_buffer(emagls_plan* plan, const char* name, void* dst, size_t* nbytes);
+/* the plan's hipStream_t, for callers that interleave their own work */
+void* emagls_plan_stream(emagls_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMAGLS_H */

@@ -1,0 +1,145 @@
+"""GPU parity proper: the six entry points through the C ABI (emagls_amd mirrors the MATLAB
+signatures) against the CPU oracle on the same seeded inputs.  Tolerance: 1e-6 relative complex
+error (BASELINE.json north_star), reported together with the reference's own assertAllClose
+metrics (verifyEMagLs.m:370-395)."""
+import numpy as np
+import pytest
+
+from oracle import emagls_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def report(name, w, o):
+    nd, db, adb = O.assert_all_close_metrics(w, o)
+    print(f"{name}: norm_diff={nd:.3e} max_dB={db:.3e} max|dB|={adb:.3e}")
+    return nd
+
+
+@pytest.fixture(scope="module")
+def thin(grids, hrirs):
+    sub = slice(0, 2702, 3)
+    return dict(hL=hrirs[0][:, sub], hR=hrirs[1][:, sub], azi=grids["azi"][sub], zen=grids["zen"][sub])
+
+
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_ls_filters_config1(grids, hrirs, basis):
+    import emagls_amd as E
+    wL, wR = E.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, basis)
+    oL, oR = O.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, basis)
+    assert wL.shape == (128, 25) and wL.dtype == oL.dtype
+    assert report("LS L " + basis, wL, oL) < 1e-12 and report("LS R " + basis, wR, oR) < 1e-12
+
+
+def test_ls_golden_surrogate(golden, grids):
+    """The reference's golden LS filters are reproduced from the surrogate input h = wLs Y^H."""
+    import emagls_amd as E
+    d = np.column_stack([grids["azi"], grids["zen"]])
+    for basis in ("real", "complex"):
+        Yc = O.getSH(4, d, basis).conj().T
+        gL, gR = golden[f"{basis}_LS/wLsL"], golden[f"{basis}_LS/wLsR"]
+        hL, hR = gL @ Yc, gR @ Yc
+        if basis == "complex":
+            continue  # complex surrogate HRIRs are outside the real-input ABI
+        wL, wR = E.getLsFilters(hL, hR, grids["azi"], grids["zen"], 4, basis)
+        assert rel(wL, gL) < 1e-11 and rel(wR, gR) < 1e-11
+
+
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_magls_filters_config2(grids, hrirs, basis):
+    import emagls_amd as E
+    wL, wR = E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 512, basis)
+    oL, oR = O.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 512, basis)
+    assert wL.shape == (512, 25) and wL.dtype == oL.dtype
+    assert report("MagLS L " + basis, wL, oL) < TOL and report("MagLS R " + basis, wR, oR) < TOL
+
+
+@pytest.mark.parametrize("basis,length", [("real", 128), ("complex", 256)])
+def test_emagls_filters_thin(grids, thin, basis, length):
+    import emagls_amd as E
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4,
+            48000.0, length, basis)
+    wL, wR = E.getEMagLsFilters(*args)
+    oL, oR = O.getEMagLsFilters(*args)
+    assert wL.dtype == oL.dtype and wL.shape == (length, 25)
+    assert report("eMagLS L " + basis, wL, oL) < TOL and report("eMagLS R " + basis, wR, oR) < TOL
+
+
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_emagls2_filters_thin(grids, thin, basis):
+    import emagls_amd as E
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4,
+            48000.0, 256, basis)
+    wL, wR = E.getEMagLs2Filters(*args)
+    oL, oR = O.getEMagLs2Filters(*args)
+    assert wL.shape == (256, 32)
+    assert report("eMagLS2 L " + basis, wL, oL) < TOL and report("eMagLS2 R " + basis, wR, oR) < TOL
+
+
+def test_emagls_filters_config3_full(grids, hrirs):
+    """BASELINE config 3: em32 r = 4.2 cm, N = 4, complex SH, 2702 directions, 512 taps."""
+    import emagls_amd as E
+    args = (hrirs[0], hrirs[1], grids["azi"], grids["zen"], grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4,
+            48000.0, 512, "complex")
+    wL, wR = E.getEMagLsFilters(*args)
+    oL, oR = O.getEMagLsFilters(*args)
+    assert report("eMagLS config3 L", wL, oL) < TOL and report("eMagLS config3 R", wR, oR) < TOL
+
+
+def test_from_atf_small(thin):
+    import emagls_amd as E
+    from emagls_amd import synth
+    atf, aazi, azen = synth.glasses_atfs(natf=2048, nmics=8, taps=128)
+    hg = np.column_stack([thin["azi"], thin["zen"]])
+    ag = np.column_stack([aazi, azen])
+    wL, wR = E.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 256, 2000.0)
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 256, 2000.0)
+    assert wL.shape == (256, 8)
+    assert report("FromAtf L", wL, oL) < TOL and report("FromAtf R", wR, oR) < TOL
+
+
+def test_from_atf_atf_grid_smaller(thin):
+    """ATF grid smaller than the HRIR grid: the HRTFs are gathered instead (FromAtf.m:71-79,91-93)."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    atf, aazi, azen = synth.glasses_atfs(natf=512, nmics=4, taps=64)
+    hg = np.column_stack([thin["azi"], thin["zen"]])
+    ag = np.column_stack([aazi, azen])
+    wL, wR = E.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 128, 1500.0, verbose=False)
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 128, 1500.0)
+    assert report("FromAtf(small ATF grid) L", wL, oL) < TOL and report("FromAtf(small ATF grid) R", wR, oR) < TOL
+
+
+def test_binaural_decode(golden):
+    import emagls_amd as E
+    rng = np.random.default_rng(5)
+    sig = rng.standard_normal((20000, 25))
+    wL = golden["real_eMagLS_woDC/wEMlsL"]
+    wR = golden["real_eMagLS_woDC/wEMlsR"]
+    out = E.binauralDecode(sig, 48000, wL, wR, 48000)
+    ref = O.binauralDecode(sig, wL, wR)
+    assert out.shape == (20000, 2) and rel(out, ref) < 1e-12
+    out2 = E.binauralDecode(sig, 48000, wL, wR, 48000, True)
+    ref2 = O.binauralDecode(sig, wL, wR, True)
+    assert out2.shape == ref2.shape and rel(out2, ref2) < 1e-12
+    # linearity (size-independent property)
+    a = E.binauralDecode(2.5 * sig, 48000, wL, wR, 48000)
+    assert rel(a, 2.5 * out) < 1e-13
+
+
+def test_error_behaviour(grids, hrirs):
+    """assert(len >= size(hL,1), 'len too short') (lib/getEMagLsFilters.m:42) and friends."""
+    import emagls_amd as E
+    from emagls_amd._lib import EmaglsError
+    with pytest.raises(EmaglsError, match="len too short"):
+        E.getEMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 0.042, grids["mic_azi"], grids["mic_zen"], 4,
+                           48000.0, 64)
+    with pytest.raises(EmaglsError, match="HRIR len too short"):
+        E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 64)
+    with pytest.raises(ValueError):
+        E.getLsFilters(hrirs[0], hrirs[1], grids["azi"][:10], grids["zen"], 4)

@@ -1,0 +1,147 @@
+"""GPU parity, stage by stage: every intermediate of the HIP pipeline against NumPy on the same
+inputs (debug buffers of a Plan), then the kernel-level C-ABI entry points against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import emagls_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize("basis", ["real", "complex"])
+@pytest.mark.parametrize("N", [4, 19, 44])
+def test_sh_basis_vs_oracle(grids, basis, N):
+    import emagls_amd as E
+    d = np.column_stack([grids["azi"], grids["zen"]])
+    Y = E.getSH(N, d, basis)
+    Yo = O.getSH(N, d, basis)
+    assert Y.shape == Yo.shape and Y.dtype == Yo.dtype
+    err = np.abs(Y - Yo)
+    # at the poles sqrt(1-x^2) amplifies the last-ulp difference of cos(zen): ~1e-10 absolute there
+    polar = np.abs(np.sin(grids["zen"])) < 1e-6
+    assert err[~polar].max() < 2e-13, err[~polar].max()
+    assert err.max() < 1e-9
+
+
+def test_sh_basis_mic_grid_and_empty(grids):
+    import emagls_amd as E
+    d = np.column_stack([grids["mic_azi"], grids["mic_zen"]])
+    assert rel(E.getSH(19, d, "complex"), O.getSH(19, d, "complex")) < 1e-13
+    assert E.getSH(3, np.zeros((0, 2)), "real").shape == (0, 16)
+
+
+def test_modal_bn_vs_oracle():
+    import emagls_amd as E
+    for r, N, P in ((0.042, 19, 513), (0.10, 44, 1025), (0.02, 9, 257)):
+        kr = 2 * np.pi * np.linspace(0, 24000, P) / 343.0 * r
+        b = E.sphModalCoeffs(N, kr)
+        bo = O.sphModalCoeffs(N, kr)
+        assert b.shape == bo.shape
+        assert np.all(b[0] == bo[0])
+        e = np.abs(b[1:] - bo[1:]) / np.abs(bo[1:])
+        assert e.max() < 1e-12, (r, N, e.max())
+
+
+@pytest.fixture(scope="module")
+def emagls_plan(grids, hrirs):
+    """config-3 shaped plan (em32, N=4, complex SH) on a thinned grid and 128-tap filters so the
+    NumPy cross-checks stay fast; keeps all intermediates on the device."""
+    from emagls_amd import Plan, _lib as L
+    sub = slice(0, 2702, 3)
+    hL, hR = hrirs[0][:, sub], hrirs[1][:, sub]
+    azi, zen = grids["azi"][sub], grids["zen"][sub]
+    p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, hL.shape[0], hL.shape[1], grids["mic_radius"], 32)
+    p.set_hrir_grid(azi, zen)
+    p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+    p.set_hrirs(hL, hR)
+    p.set_profiling(1)
+    p.execute()
+    p.synchronize()
+    yield dict(p=p, hL=hL, hR=hR, azi=azi, zen=zen)
+    p.close()
+
+
+def test_stage_basis_gram_cholesky_q(emagls_plan, grids):
+    p = emagls_plan["p"]
+    i = p.info()
+    S, D = i.num_sh_sim, emagls_plan["hL"].shape[1]
+    assert (i.sim_order, S, i.num_channels, i.nfft, i.num_pos_freqs) == (19, 400, 25, 256, 129)
+    ldD, ldS = -(-D // 64) * 64, -(-S // 64) * 64
+    Yo = O.getSH(19, np.column_stack([emagls_plan["azi"], emagls_plan["zen"]]), "complex")
+    Ycm = p.debug("Ycm", np.complex128, (S, ldD))[:, :D]
+    assert np.abs(Ycm.T - Yo).max() < 1e-9
+    Yc = p.debug("Yc", np.complex128).reshape(-1, ldS)
+    assert np.abs(Yc[:D, :S] - np.conj(Yo)).max() < 1e-9
+    assert np.all(Yc[D:, :S] == 0)
+    R = np.triu(p.debug("R", np.complex128, (S, S)))
+    G = Yc[:D, :S].conj().T @ Yc[:D, :S]
+    assert rel(R.conj().T @ R, G) < 1e-13
+    Q = p.debug("Q", np.complex128, (D, ldS))[:, :S]
+    assert np.abs(Q.conj().T @ Q - np.eye(S)).max() < 1e-13
+    assert rel(Q @ R, Yc[:D, :S]) < 1e-13
+
+
+def test_stage_array_model(emagls_plan, grids):
+    p = emagls_plan["p"]
+    S, C, P = 400, 25, 129
+    ldS = 448
+    micd = np.column_stack([grids["mic_azi"], grids["mic_zen"]])
+    Ym = O.getSH(19, micd, "complex")
+    Eo = O.pinv(Ym[:, :25]) @ Ym
+    E = p.debug("E", np.complex128, (C, ldS))[:, :S]
+    assert rel(E, Eo) < 1e-12
+    f = np.linspace(0, 24000, P)
+    bo = -O.sphModalCoeffs(19, 2 * np.pi * f / 343.0 * grids["mic_radius"])
+    b = p.debug("bn", np.complex128, (P, 20))
+    assert (np.abs(b[1:] - bo[1:]) / np.abs(bo[1:])).max() < 1e-12
+    R = np.triu(p.debug("R", np.complex128, (S, S)))
+    Tn = p.debug("Tn", np.complex128, (20, C, ldS))[:, :, :S]
+    for n in (0, 3, 19):
+        blk = slice(n * n, (n + 1) ** 2)
+        To = (R[:, blk] @ Eo[:, blk].T).T  # [c][s]
+        assert rel(Tn[n], To) < 1e-12
+
+
+def test_stage_prologue(emagls_plan):
+    p = emagls_plan["p"]
+    hL, hR = emagls_plan["hL"], emagls_plan["hR"]
+    D = hL.shape[1]
+    ldD = -(-D // 64) * 64
+    i = p.info()
+    nfft, P, kcut0 = i.nfft, i.num_pos_freqs, i.k_cut - 1
+    HL, HR, gL, gR = O._hrir_prologue(hL, hR, nfft, P)
+    assert abs(i.grp_delay_l - gL) < 1e-9 and abs(i.grp_delay_r - gR) < 1e-9
+    Hc = p.debug("Hc", np.complex128).reshape(2, kcut0, ldD)[:, :, :D]
+    assert rel(Hc[0], HL[:kcut0]) < 1e-12 and rel(Hc[1], HR[:kcut0]) < 1e-12
+    Ha = p.debug("Habs", np.float64).reshape(2, P - kcut0, ldD)[:, :, :D]
+    assert rel(Ha[0], np.abs(HL[kcut0:P])) < 1e-12 and rel(Ha[1], np.abs(HR[kcut0:P])) < 1e-12
+
+
+def test_stage_factor_and_sweep(emagls_plan, grids):
+    """Z_k against LAPACK on the SAME B_k, singular values, Jacobi sweep counts, and the final
+    filters against the oracle."""
+    p = emagls_plan["p"]
+    S, C, ldS = 400, 25, 448
+    i = p.info()
+    P, kcut0 = i.num_pos_freqs, i.k_cut - 1
+    Bk = p.debug("Bk", np.complex128).reshape(P, C, ldS)[:, :, :S]
+    Z = p.debug("Z", np.complex128).reshape(P, C, ldS)[:, :, :S]
+    sv = p.debug("sv", np.float64).reshape(P, C)
+    js = p.debug("jsweeps", np.int32)
+    assert js[1:P].max() <= 20, js[1:P].max()
+    for kb in (kcut0, kcut0 + 1, P // 2, P - 1):
+        B = Bk[kb].T  # S x C
+        U, s, Vh = np.linalg.svd(B, full_matrices=False)
+        assert np.abs(np.sort(sv[kb])[::-1] - s).max() < 1e-13 * s[0]
+        sreg = 1 / np.maximum(s, 0.01 * s[0])
+        Zo = np.conj(U) @ (sreg[:, None] * Vh.conj())
+        assert rel(Z[kb].T, Zo) < 1e-9, (kb, rel(Z[kb].T, Zo))
+    wL, wR = p.get_filters()
+    oL, oR = O.getEMagLsFilters(emagls_plan["hL"], emagls_plan["hR"], emagls_plan["azi"], emagls_plan["zen"],
+                                grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "complex")
+    assert rel(wL, oL) < 1e-6 and rel(wR, oR) < 1e-6, (rel(wL, oL), rel(wR, oR))
+    print("stage times (ms):", p.stage_times())
