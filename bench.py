@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- eMagLS filter-design throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one complete filter-set design (both ears, all channels) of BASELINE.json config 3:
+getEMagLsFilters, em32 (32 mics, r = 4.2 cm), N = 4, complex SH, 2702 HRIR directions, 512 taps,
+48 kHz -- from the angles and HRIRs resident in HBM to the windowed time-domain filters in HBM.
+Every rank designs its own filter sets (independent jobs, weak scaling); the only collective is
+one RCCL gather of the finished filters to rank 0 inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the per-bin sweep kernel);
+`cpu_baseline` times the NumPy oracle on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def load_inputs(seed_offset=0):
+    from emagls_amd import synth
+    gpath = os.path.join(ROOT, "tests", "golden", "ref_fixtures.npz")
+    if os.path.exists(gpath):
+        g = np.load(gpath)
+        azi, zen = g["grid/hrirGridAziRad"], g["grid/hrirGridZenRad"]
+        maz, mzn = g["grid/micGridAziRad"], g["grid/micGridZenRad"]
+    else:
+        azi, zen = synth.fibonacci_grid(2702)
+        maz, mzn = synth.em32_grid()
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen, seed=20250310 + seed_offset)
+    return azi, zen, maz, mzn, hL, hR
+
+
+def cpu_baseline(azi, zen, maz, mzn, hL, hR, nbins_sample=48):
+    """Oracle (NumPy restatement of lib/getEMagLsFilters.m) on a bounded sample: everything outside the
+    per-bin loop in full, the per-bin loop (lines :85-106) on bins 2..nbins_sample+1 -- which straddle
+    k_cut = 43, so both branches are sampled -- scaled to the 512 bins of the workload."""
+    from oracle import emagls_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    order, fs, length, r = 4, 48000.0, 512, 0.042
+
+    def run():
+        t0 = time.perf_counter()
+        nfft, f, P, k_cut = O._design_consts(fs, length, max(1e3, 500 * order))
+        smair, simOrder = O.getSMAIRMatrix(order, fs, nfft, r, np.column_stack([maz, mzn]), "complex")
+        Yh = O.getSH(simOrder, np.column_stack([azi, zen]), "complex").conj().T
+        HL, HR, gL, gR = O._hrir_prologue(hL, hR, nfft, P)
+        t1 = time.perf_counter()
+        Ps = nbins_sample + 1
+        Wl, Wr = O._emagls_core(HL, HR, lambda k: smair[:, :, k - 1] @ Yh, Ps, k_cut, 25)
+        t2 = time.perf_counter()
+        Wl_full = np.zeros((P, 25), complex); Wl_full[:Ps] = Wl
+        O._finish(Wl_full, Wl_full, P, nfft, length, False, nfft // 2, nfft // 2 + gR - gL)
+        t3 = time.perf_counter()
+        return (t1 - t0) + (t3 - t2) + (t2 - t1) * (P - 1) / nbins_sample
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            t_1 = run()
+    else:
+        t_1 = run()
+    t_all = run()
+    ncores = os.cpu_count() or 1
+    best, cores = (t_1, 1) if t_1 <= t_all else (t_all, ncores)
+    return {"value": 1.0 / best, "unit": "filter sets/s", "cores": cores, "kind": "port",
+            "sample": "NumPy oracle, config 3: SH/modal/HRIR prologue + epilogue in full, per-bin SVD loop on %d of 512 "
+                      "bins (2..%d, straddling k_cut=43) scaled x%.2f; 1 thread %.2f s/set, %d threads %.2f s/set"
+                      % (nbins_sample, nbins_sample + 1, 512.0 / nbins_sample, t_1, ncores, t_all)}
+
+
+def sh_basis_roofline(lib_mod):
+    """SH-basis assembly on a launch big enough to be bandwidth bound (D = 2^20, N = 19, real: 3.36 GB)."""
+    import ctypes as C
+    import torch
+    D, N = 1 << 20, 19
+    S = (N + 1) ** 2
+    from emagls_amd import synth
+    azi, zen = synth.fibonacci_grid(D)
+    t_azi = torch.from_numpy(azi).cuda()
+    t_zen = torch.from_numpy(zen).cuda()
+    out = torch.empty((S, D), dtype=torch.float64, device="cuda")
+    lib = lib_mod.load()
+    # emagls_sh_basis accepts device pointers; it allocates a staging copy, so time only the kernel via events
+    # around a second call path: use the plan-free entry point twice and take the steady-state one.
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = lib.emagls_sh_basis(N, D, C.c_void_p(t_azi.data_ptr()), C.c_void_p(t_zen.data_ptr()), 0,
+                                 C.c_void_p(out.data_ptr()))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            return None
+        best = dt if best is None else min(best, dt)
+    return {"note": "end-to-end call incl. staging copies (kernel-only number: profiles/)", "bytes": 8.0 * D * S,
+            "seconds": best, "GB/s": 8.0 * D * S / best / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-level", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch  # first: the library then shares torch's HIP runtime (same SONAME libamdhip64.so.7)
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from emagls_amd import Plan, _lib as L
+    L.check(L.load().emagls_set_device(local_rank))
+    azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=rank)
+    plan = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 512, hL.shape[0], hL.shape[1], 0.042, 32)
+    plan.set_hrir_grid(azi, zen)
+    plan.set_mic_grid(maz, mzn)
+    plan.set_hrirs(hL, hR)
+    info = plan.info()
+    K, W = args.steps, args.warmup
+    import ctypes as C
+    out = torch.zeros((K, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")  # complex as (re,im)
+    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(W):
+        plan.execute()
+    plan.synchronize()
+    if world > 1:  # warm the collective too
+        dist.gather(out, gathered, dst=0)
+    # ---- timed region: K designs + one gather (hipGraph replay of the captured design, no profiling hooks)
+    plan.set_profiling(0)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(K):
+        plan.execute()
+        L.check(plan._lib.emagls_plan_get_filters(plan._h, C.c_void_p(out[s, 0].data_ptr()), C.c_void_p(out[s, 1].data_ptr())))
+    if world > 1:
+        dist.gather(out, gathered, dst=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    plan.set_profiling(1)  # eager pass with HIP events between stages (includes host launch gaps)
+    plan.execute()
+    plan.synchronize()
+    stages = plan.stage_times()
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- per-launch duration of the dominant kernel (HIP events on the plan's stream), separate pass
+    plan.set_profiling(args.profile_level)
+    plan.execute()
+    plan.synchronize()
+    sweep_ms, sweep_n = plan.sweep_kernel_time()
+    stages2 = plan.stage_times()
+    plan.set_profiling(0)
+
+    if rank == 0:
+        D, S, Cc = hL.shape[1], info.num_sh_sim, info.num_channels
+        # algorithmic bytes one sweep launch must touch: Q (D x S complex) + B_k + Z_k (2 x C x S complex)
+        # + |H| rows (2 x D) + partial W in/out
+        bytes_launch = 16.0 * D * S + 2 * 16.0 * Cc * S + 2 * 8.0 * D + 2 * 128 * 2 * Cc * 16.0
+        roof = None
+        if sweep_n > 0:
+            avg_s = sweep_ms / sweep_n * 1e-3
+            ach = bytes_launch / avg_s / 1e9
+            roof = {"kernel": "sweep_factored_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches_per_step": sweep_n,
+                    "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": bytes_launch,
+                    "note": "operands are L2/Infinity-Cache resident by design (17.7 MB working set); the launch is "
+                            "latency bound, see DESIGN.md"}
+        res = {
+            "metric": "eMagLS filter sets/s (N=4, 2702 dirs, 512 taps)", "value": world * K / dt, "unit": "filter sets/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: getEMagLsFilters em32 r=4.2cm N=4 complex-SH, 2702 dirs, 512 taps, "
+                                   "48 kHz; one filter set per step per GPU, inputs resident in HBM",
+                       "dirs": int(D), "taps": 512, "sim_order": info.sim_order, "bins": info.num_pos_freqs - 1,
+                       "k_cut": info.k_cut, "parallelism": "independent jobs per GPU, one RCCL gather"},
+            "roofline": roof,
+            "stages_ms": {k: round(v, 4) for k, v in stages},
+            "stages_ms_profiled_pass": {k: round(v, 4) for k, v in stages2},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(azi, zen, maz, mzn, hL, hR)
+            res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+            # accuracy half of the metric: GPU result of this run vs the oracle would take minutes at full size;
+            # the parity tests report it (tests/test_gpu_parity.py::test_emagls_filters_config3_full)
+        print(json.dumps(res))
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,10 @@ struct FactorArgs {
     int ls_end;
     cplx* W;          // [e][P][C]
     int* sweeps_out;  // optional [kb]
+    // inter-kernel workspaces, indexed by blockIdx.x (= kb - kb0)
+    double* tauw;     // [bin][C]       Householder scalars
+    cplx* R2w;        // [bin][C][C]    triangular factor (upper)
+    cplx* Nw;         // [bin][C][C]    U2 diag(s_reg) V^H
 };
 
 struct SweepArgs {
@@ -49,6 +53,7 @@ struct SweepArgs {
     cplx* W;              // [e][P][C]
     int nWG, dpw;         // workgroups, directions per workgroup
     int kfirst;           // first swept bin: W(k-1) is read from W instead of the partials
+    long long* timing;    // optional [P][16] clock stamps of workgroup 0 (debug)
 };
 
 struct DenseSweepArgs {

@@ -2,6 +2,7 @@
 // The host code only sequences launches and derives scalar constants (nfft, k_cut, simulation
 // order: lib/getEMagLsFilters.m:44-48, dependencies/getSMAIRMatrix.m:95); all array arithmetic runs
 // in the HIP kernels.  There is no CPU fallback: without a GPU every entry point returns an error.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -54,11 +55,18 @@ struct emagls_plan {
     std::vector<hipEvent_t> sweep_events;
     int sweep_launches = 0;
     bool executed = false;
+    // hipGraph replay of the whole design (launch-bound: ~520 small kernels per execute)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int eager_runs = 0;
+    bool use_graph = true;
 
     ~emagls_plan() {
         for (auto& kv : bufs) if (kv.second.p) hipFree(kv.second.p);
         for (auto e : stage_events) hipEventDestroy(e);
         for (auto e : sweep_events) hipEventDestroy(e);
+        if (graph_exec) hipGraphExecDestroy(graph_exec);
+        if (graph) hipGraphDestroy(graph);
         if (stream) hipStreamDestroy(stream);
     }
     void* alloc(const std::string& name, size_t bytes, bool zero = true) {
@@ -114,6 +122,7 @@ void plan_setup(emagls_plan& p) {
     if (d.ndirs < 1 || d.nsamp < 1) throw Error(EMAGLS_ERR_ARG, "empty HRIR set");
     if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
     HIP_CHECK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    if (const char* ng = getenv("EMAGLS_NO_GRAPH")) p.use_graph = !(ng[0] == '1');
     p.cplx_basis = d.basis == EMAGLS_BASIS_COMPLEX;
     p.D = d.ndirs;
     p.ldD = round_up(p.D, 64);
@@ -188,6 +197,9 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Zb", sizeof(cplx) * (size_t)p.C * p.ldS);
         p.alloc("Vws", sizeof(cplx) * (size_t)p.C * p.ldS);
         p.alloc("sv", sizeof(double) * p.C);
+        p.alloc("tauw", sizeof(double) * p.C);
+        p.alloc("R2w", sizeof(cplx) * (size_t)p.C * p.C);
+        p.alloc("Nw", sizeof(cplx) * (size_t)p.C * p.C);
         p.alloc("Ypinv", esz(cb) * (size_t)p.C * p.ldD);
         if (d.kind == EMAGLS_KIND_LS) {
             p.out_rows = d.nsamp;
@@ -207,6 +219,9 @@ void plan_setup(emagls_plan& p) {
             p.alloc("Ylo_c", sizeof(cplx) * (size_t)p.nOut * ldM);     // [nOut][ldM] complex copy of Y_Lo^T
             p.alloc("Zlo", sizeof(cplx) * (size_t)p.nOut * ldM);
             p.alloc("Vlo", sizeof(cplx) * (size_t)p.nOut * ldM);
+            p.alloc("tau_lo", sizeof(double) * p.nOut);
+            p.alloc("R2_lo", sizeof(cplx) * (size_t)p.nOut * p.nOut);
+            p.alloc("N_lo", sizeof(cplx) * (size_t)p.nOut * p.nOut);
         }
         p.alloc("kr", sizeof(double) * p.P, false);
         p.alloc("bn", sizeof(cplx) * (size_t)p.P * (p.simOrder + 1));
@@ -217,7 +232,12 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Vws", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
         p.alloc("sv", sizeof(double) * (size_t)p.P * p.C);
         p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
+        p.alloc("tauw", sizeof(double) * (size_t)p.P * p.C);
+        p.alloc("R2w", sizeof(cplx) * (size_t)p.P * p.C * p.C);
+        p.alloc("Nw", sizeof(cplx) * (size_t)p.P * p.C * p.C);
+        if (getenv("EMAGLS_SWEEP_TIMING")) p.alloc("sweep_timing", sizeof(long long) * 16 * (size_t)p.P);
         p.nWG = 128;
+        if (const char* e = getenv("EMAGLS_SWEEP_NWG")) p.nWG = std::max(8, std::min(256, atoi(e)));
         p.dpw = (int)ceil_div(p.D, p.nWG);
     }
     if (d.kind == EMAGLS_KIND_FROM_ATF) {
@@ -236,6 +256,9 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Vws", sizeof(cplx) * (size_t)p.P * M * p.ldD);
         p.alloc("sv", sizeof(double) * (size_t)p.P * M);
         p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
+        p.alloc("tauw", sizeof(double) * (size_t)p.P * M);
+        p.alloc("R2w", sizeof(cplx) * (size_t)p.P * M * M);
+        p.alloc("Nw", sizeof(cplx) * (size_t)p.P * M * M);
     }
     if (d.kind != EMAGLS_KIND_LS) {
         const int64_t Dh = (d.kind == EMAGLS_KIND_FROM_ATF) ? p.Dm : p.D;
@@ -309,6 +332,7 @@ void run_pinv_of_R(emagls_plan& p) {
     a.reg_mode = 1; a.reg_c = 0.0; a.tol_dim = (double)std::max<int64_t>(p.D, p.C);
     a.Z = p.get<cplx>("Zb"); a.Bk = nullptr; a.bk_from = 0; a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
     a.Hq = nullptr; a.W = nullptr; a.ls_end = 0; a.sweeps_out = nullptr;
+    a.tauw = p.get<double>("tauw"); a.R2w = p.get<cplx>("R2w"); a.Nw = p.get<cplx>("Nw");
     launch_factor(a, 1, true, st);
     launch_ypinv(p.get("Q"), p.ldS, cb, p.get("Zb"), p.ldS, (int)p.D, p.S, p.C, p.get("Ypinv"), p.ldD, st);
     p.mark("pinv");
@@ -373,6 +397,7 @@ void execute_emagls(emagls_plan& p) {
         a.Xd = p.get<cplx>("Ylo_c"); a.xd_stride = 0;
         a.reg_mode = 1; a.tol_dim = (double)std::max(M, p.nOut);
         a.Z = p.get<cplx>("Zlo"); a.Vws = p.get<cplx>("Vlo");
+        a.tauw = p.get<double>("tau_lo"); a.R2w = p.get<cplx>("R2_lo"); a.Nw = p.get<cplx>("N_lo");
         launch_factor(a, 1, true, st);
         // E[c][s] = sum_m pinv[c][m] Y_mic[m][s],  pinv[c][m] = Zlo[c][m]
         launch_small_gemm(p.get("Zlo"), ldM, true, p.get("Ymic_rm"), p.ldS, cb, p.get("E"), p.ldS, cb, p.nOut, p.S, M, st);
@@ -394,6 +419,7 @@ void execute_emagls(emagls_plan& p) {
         a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
         a.Hq = p.get<cplx>("Hq"); a.ldHq = p.ldS; a.hq_estride = (int64_t)ls_end * p.ldS; a.ls_end = ls_end;
         a.W = p.get<cplx>("W"); a.sweeps_out = p.get<int>("jsweeps");
+        a.tauw = p.get<double>("tauw"); a.R2w = p.get<cplx>("R2w"); a.Nw = p.get<cplx>("Nw");
         launch_factor(a, p.P - 1, cb, st);
     }
     p.mark("factor_bins");
@@ -405,6 +431,7 @@ void execute_emagls(emagls_plan& p) {
         a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG; a.dpw = p.dpw;
         const int k0 = std::max(p.kcut0, 1);
         a.kfirst = k0;
+        a.timing = p.has("sweep_timing") ? p.get<long long>("sweep_timing") : nullptr;
         p.sweep_launches = 0;
         for (int kb = k0; kb < p.P; ++kb) {
             if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
@@ -449,6 +476,7 @@ void execute_from_atf(emagls_plan& p) {
         a.Z = p.get<cplx>("Z"); a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
         a.Hq = p.get<cplx>("Hc"); a.ldHq = p.ldD; a.hq_estride = (int64_t)ls_end * p.ldD; a.ls_end = ls_end;
         a.W = p.get<cplx>("W"); a.sweeps_out = p.get<int>("jsweeps");
+        a.tauw = p.get<double>("tauw"); a.R2w = p.get<cplx>("R2w"); a.Nw = p.get<cplx>("Nw");
         launch_factor(a, p.P - 1, true, st);
     }
     p.mark("factor_bins");
@@ -475,15 +503,11 @@ void execute_from_atf(emagls_plan& p) {
     p.mark("epilogue");
 }
 
-void plan_execute(emagls_plan& p) {
+void run_pipeline(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
-    if (!p.have_hrir_grid || !p.have_hrirs) throw Error(EMAGLS_ERR_ARG, "HRIRs and their grid must be set before execute");
-    if ((d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) && !p.have_mic_grid)
-        throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
-    if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
     p.stage_names.clear();
-    HIP_CHECK(hipMemsetAsync(p.get("flag"), 0, sizeof(int) * 4, p.stream));
-    if (p.has("W")) HIP_CHECK(hipMemsetAsync(p.get("W"), 0, p.bufs["W"].bytes, p.stream));
+    launch_zero(p.get("flag"), sizeof(int) * 4, p.stream);
+    if (p.has("W")) launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
     p.mark("begin");
     switch (d.kind) {
         case EMAGLS_KIND_LS: execute_ls(p); break;
@@ -492,6 +516,37 @@ void plan_execute(emagls_plan& p) {
         case EMAGLS_KIND_EMAGLS2: execute_emagls(p); break;
         default: execute_from_atf(p); break;
     }
+}
+
+void plan_execute(emagls_plan& p) {
+    const emagls_design_desc& d = p.d;
+    if (!p.have_hrir_grid || !p.have_hrirs) throw Error(EMAGLS_ERR_ARG, "HRIRs and their grid must be set before execute");
+    if ((d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) && !p.have_mic_grid)
+        throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
+    if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
+    if (p.prof_level == 0 && p.use_graph) {
+        // first execute runs eagerly (one-time function attributes, lazy module load), the second is captured
+        if (!p.graph_exec && p.eager_runs >= 1) {
+            HIP_CHECK(hipStreamBeginCapture(p.stream, hipStreamCaptureModeThreadLocal));
+            try {
+                run_pipeline(p);
+            } catch (...) {
+                hipGraph_t g = nullptr;
+                hipStreamEndCapture(p.stream, &g);
+                if (g) hipGraphDestroy(g);
+                throw;
+            }
+            HIP_CHECK(hipStreamEndCapture(p.stream, &p.graph));
+            HIP_CHECK(hipGraphInstantiate(&p.graph_exec, p.graph, nullptr, nullptr, 0));
+        }
+        if (p.graph_exec) {
+            HIP_CHECK(hipGraphLaunch(p.graph_exec, p.stream));
+            p.executed = true;
+            return;
+        }
+    }
+    run_pipeline(p);
+    ++p.eager_runs;
     p.executed = true;
 }
 

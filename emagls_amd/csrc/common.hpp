@@ -93,16 +93,49 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xo
 __device__ __forceinline__ cplx shfl_xor_c(cplx v, int m) { return {__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64)}; }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-// all-reduce (sum) over aligned groups of W consecutive lanes, W power of two <= 64
-template <int W> __device__ __forceinline__ double group_sum(double v) {
+// ---- fast FP64 reciprocal / reciprocal square root: hardware seed + Newton steps (~1 ulp), far
+// cheaper than the IEEE division / sqrt expansions on the latency-bound paths (Jacobi, sweep)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
 #pragma unroll
-    for (int m = W / 2; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
+    for (int i = 0; i < 3; ++i) y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double e = fma(-x * y, y, 1.0);        // 1 - x y^2
+        y = fma(y * e, fma(0.375, e, 0.5), y);       // y (1 + e/2 + 3 e^2/8)
+    }
+    return y;
+}
+
+// ---- DPP lane exchange (no LDS crossbar round trip): v from another lane of the same 16-lane row
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i within each 8 lanes
+constexpr int DPP_ROW_MIRROR = 0x140;  // lane i <-> 15-i within each 16 lanes
+
+// all-reduce (sum) over aligned groups of W consecutive lanes, W power of two <= 64.
+// Steps inside a 16-lane row use DPP; the 32/64-lane steps use ds_bpermute.
+template <int W> __device__ __forceinline__ double group_sum(double v) {
+    if (W >= 2) v += dpp_d<DPP_XOR1>(v);
+    if (W >= 4) v += dpp_d<DPP_XOR2>(v);
+    if (W >= 8) v += dpp_d<DPP_HALF_MIRROR>(v);   // both quads already hold their sums
+    if (W >= 16) v += dpp_d<DPP_ROW_MIRROR>(v);
+    if (W >= 32) v += shfl_xor_d(v, 16);
+    if (W >= 64) v += shfl_xor_d(v, 32);
     return v;
 }
 template <int W> __device__ __forceinline__ cplx group_sum(cplx v) {
-#pragma unroll
-    for (int m = W / 2; m >= 1; m >>= 1) { v.x += shfl_xor_d(v.x, m); v.y += shfl_xor_d(v.y, m); }
-    return v;
+    return {group_sum<W>(v.x), group_sum<W>(v.y)};
 }
 template <int W> __device__ __forceinline__ double group_max(double v) {
 #pragma unroll

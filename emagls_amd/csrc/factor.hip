@@ -20,17 +20,14 @@ namespace emagls {
 
 constexpr int CPMAX = 32;  // max (even-padded) column count
 
+// =============================================================================================
+// kernel 1: assemble B_k, Householder QR.  Leaves v_j in Vws, tau_j in tauw, R2 (upper) in R2w.
+// =============================================================================================
 template <typename TT, int NCH, int RPT, int MAXT>
-__global__ void __launch_bounds__(MAXT) factor_kernel(FactorArgs a) {
-    __shared__ __attribute__((aligned(16))) cplx Xs[CPMAX][CPMAX + 1];  // Xs[col][row]
-    __shared__ __attribute__((aligned(16))) cplx Vs[CPMAX][CPMAX + 1];
-    __shared__ __attribute__((aligned(16))) cplx Ns[CPMAX][CPMAX + 1];  // Ns[a][b]
+__global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a) {
     __shared__ __attribute__((aligned(16))) cplx bns[96];
     __shared__ cplx alpha_s[CPMAX];
     __shared__ double tau_s[CPMAX];
-    __shared__ double g_s[CPMAX];
-    __shared__ double sig_s[CPMAX];
-    __shared__ int rot_flag;
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     cplx* vbuf = reinterpret_cast<cplx*>(dyn);  // [2][ldS]
 
@@ -39,7 +36,6 @@ __global__ void __launch_bounds__(MAXT) factor_kernel(FactorArgs a) {
     const int S = a.S, C = a.C, ldS = a.ldS;
     const int kb = a.kb0 + blockIdx.x;
     const bool active = c < C;
-    const int Cp = (C + 1) & ~1;
 
     cplx B[RPT];
     // ------------------------------------------------------------------ 1. assemble / load B_k
@@ -132,31 +128,52 @@ __global__ void __launch_bounds__(MAXT) factor_kernel(FactorArgs a) {
         }
         // vbuf is double-buffered: the next column writes the other half, no second barrier needed
     }
-    // ------------------------------------------------------------------ 3. X = R2^H into LDS, V = I
-    for (int idx = tid; idx < CPMAX * (CPMAX + 1); idx += blockDim.x) {
-        (&Xs[0][0])[idx] = mk(0, 0);
-        (&Vs[0][0])[idx] = mk(0, 0);
-    }
-    if (tid == 0) rot_flag = 0;
-    __syncthreads();
+    // ------------------------------------------------------------------ 3. hand R2 and tau to the SVD kernel
     if (active) {
+        cplx* R2 = a.R2w + (int64_t)blockIdx.x * C * C;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int s = ch + NCH * i;
-            if (s < c) Xs[s][c] = conj(B[i]);  // X[a=c][b=s] = conj(R2[s][c]); stored Xs[col=b][row=a]
+            if (s < c) R2[(int64_t)s * C + c] = B[i];
         }
-        if (ch == 0) { Xs[c][c] = conj(alpha_s[c]); Vs[c][c] = mk(1, 0); }
+        if (ch == 0) {
+            R2[(int64_t)c * C + c] = alpha_s[c];
+            a.tauw[(int64_t)blockIdx.x * C + c] = tau_s[c];
+        }
+    }
+}
+
+// =============================================================================================
+// kernel 2: one-sided Jacobi SVD of X = R2^H (C x C) in LDS, 256 threads = 16 column pairs x 16 lanes.
+//   R2 = Vx Sigma Ux^H;  N = Vx diag(g) Xrot^H with g = s_reg / s   (U2 diag(s_reg) V^H)
+// =============================================================================================
+__global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a) {
+    __shared__ __attribute__((aligned(16))) cplx Xs[CPMAX][CPMAX + 1];  // Xs[col][row]
+    __shared__ __attribute__((aligned(16))) cplx Vs[CPMAX][CPMAX + 1];
+    __shared__ double g_s[CPMAX];
+    __shared__ double sig_s[CPMAX];
+    const int tid = threadIdx.x;
+    const int C = a.C;
+    const int Cp = (C + 1) & ~1;
+    const int kb = a.kb0 + blockIdx.x;
+    const cplx* R2 = a.R2w + (int64_t)blockIdx.x * C * C;
+    for (int idx = tid; idx < CPMAX * CPMAX; idx += 256) {
+        const int col = idx / CPMAX, row = idx % CPMAX;  // X[row][col] = conj(R2[col][row]) for col <= row
+        cplx v = mk(0, 0);
+        if (row < C && col <= row) v = conj(R2[(int64_t)col * C + row]);
+        Xs[col][row] = v;
+        Vs[col][row] = (col == row && col < C) ? mk(1, 0) : mk(0, 0);
     }
     __syncthreads();
-    // ------------------------------------------------------------------ 4. one-sided Jacobi on the columns of X
     {
-        constexpr int GL = 8;                 // lanes per pair
-        constexpr int RL = CPMAX / GL;        // rows per lane
+        constexpr int GL = 16;                // lanes per pair
+        constexpr int RL = CPMAX / GL;        // rows per lane (2)
         const int npairs = Cp / 2;
         const int pi = tid / GL, gl = tid % GL;
-        const bool jactive = pi < npairs;     // whole waves: npairs*GL threads, other waves only hit barriers
+        const bool jactive = pi < npairs;
         int sweeps = 0;
         for (; sweeps < 60; ++sweeps) {
+            int rotated = 0;
             for (int r = 0; r < Cp - 1; ++r) {
                 if (jactive) {
                     int p, q;
@@ -177,39 +194,37 @@ __global__ void __launch_bounds__(MAXT) factor_kernel(FactorArgs a) {
                     al = group_sum<GL>(al);
                     be = group_sum<GL>(be);
                     ga = group_sum<GL>(ga);
-                    const double ag = cabs(ga);
-                    if (ag > 2.220446049250313e-16 * sqrt(al * be) && ag > 0.0) {
-                        const double zeta = (be - al) / (2.0 * ag);
-                        const double t_ = (zeta == 0.0) ? 1.0 : copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        const double cs = 1.0 / sqrt(1.0 + t_ * t_), sn = cs * t_;
-                        const cplx ph = mk(ga.x / ag, ga.y / ag);
+                    const double ag2 = norm2(ga);
+                    // rotate when |gamma| > eps sqrt(alpha beta)
+                    if (ag2 > (2.220446049250313e-16 * 2.220446049250313e-16) * (al * be) && ag2 > 0.0) {
+                        const double iag = fast_rsqrt(ag2);           // 1/|gamma|
+                        const double zeta = 0.5 * (be - al) * iag;
+                        const double z2 = fma(zeta, zeta, 1.0);
+                        const double sq = z2 * fast_rsqrt(z2);        // sqrt(1 + zeta^2)
+                        const double t_ = (zeta == 0.0) ? 1.0 : copysign(fast_rcp(fabs(zeta) + sq), zeta);
+                        const double cs = fast_rsqrt(fma(t_, t_, 1.0)), sn = cs * t_;
+                        const cplx ph = mk(ga.x * iag, ga.y * iag);
                         const cplx sph = mk(sn * ph.x, sn * ph.y);          // s * ph
                         const cplx spc = mk(sn * ph.x, -sn * ph.y);         // s * conj(ph)
 #pragma unroll
                         for (int t = 0; t < RL; ++t) {
                             const int row = gl + GL * t;
-                            const cplx np = cs * xp[t] - spc * xq[t];
-                            const cplx nq = sph * xp[t] + cs * xq[t];
-                            Xs[p][row] = np;
-                            Xs[q][row] = nq;
+                            Xs[p][row] = cs * xp[t] - spc * xq[t];
+                            Xs[q][row] = sph * xp[t] + cs * xq[t];
                             const cplx vp = Vs[p][row], vq = Vs[q][row];
                             Vs[p][row] = cs * vp - spc * vq;
                             Vs[q][row] = sph * vp + cs * vq;
                         }
-                        if (gl == 0) rot_flag = 1;
+                        rotated = 1;
                     }
                 }
                 __syncthreads();
             }
-            const int f = rot_flag;
-            __syncthreads();
-            if (tid == 0) rot_flag = 0;
-            __syncthreads();
-            if (!f) break;
+            if (!__syncthreads_or(rotated)) { ++sweeps; break; }
         }
         if (a.sweeps_out && tid == 0) a.sweeps_out[kb] = sweeps;
     }
-    // ------------------------------------------------------------------ 5. singular values, regularisation weights
+    // ---- singular values, regularisation weights
     if (tid < CPMAX) {
         double n2 = 0.0;
         for (int row = 0; row < CPMAX; ++row) n2 += norm2(Xs[tid][row]);
@@ -223,11 +238,11 @@ __global__ void __launch_bounds__(MAXT) factor_kernel(FactorArgs a) {
         double g = 0.0;
         if (tid < C && s > 0.0) {
             if (a.reg_mode == 0) {
-                g = 1.0 / (fmax(s, a.reg_c * smax) * s);  // s_reg / s
+                g = 1.0 / (fmax(s, a.reg_c * smax) * s);  // s_reg / s,  s_reg = 1/max(s, c smax)
             } else {
                 int ex;
-                frexp(smax, &ex);                          // smax = m 2^ex, m in [0.5,1)
-                const double tol = a.tol_dim * ldexp(1.0, ex - 53);  // max(size) * eps(smax)
+                frexp(smax, &ex);                                      // smax = m 2^ex, m in [0.5,1)
+                const double tol = a.tol_dim * ldexp(1.0, ex - 53);   // max(size) * eps(smax)  (MATLAB pinv)
                 g = (s > tol) ? 1.0 / (s * s) : 0.0;
             }
         }
@@ -235,27 +250,56 @@ __global__ void __launch_bounds__(MAXT) factor_kernel(FactorArgs a) {
         if (a.sv && tid < C) a.sv[(int64_t)kb * C + tid] = s;
     }
     __syncthreads();
-    // N[a][b] = sum_i Vx[a][i] g_i conj(Xrot[b][i])   (R2 = Vx Sigma Ux^H, Ux = Xrot/sigma)
-    for (int idx = tid; idx < C * C; idx += blockDim.x) {
+    // N[a][b] = sum_i Vx[a][i] g_i conj(Xrot[b][i])
+    cplx* N = a.Nw + (int64_t)blockIdx.x * C * C;
+    for (int idx = tid; idx < C * C; idx += 256) {
         const int aa = idx / C, bb = idx % C;
         cplx acc = mk(0, 0);
         for (int i = 0; i < C; ++i) {
             const cplx t = g_s[i] * Vs[i][aa];
             cfma(acc, t, conj(Xs[i][bb]));
         }
-        Ns[aa][bb] = acc;
+        N[idx] = acc;
     }
-    __syncthreads();
-    // ------------------------------------------------------------------ 6. M = Q2 [N; 0]   (reuse B registers)
-    if (active) {
+}
+
+// =============================================================================================
+// kernel 3: Z_k = conj(Q2 [N; 0]) by applying the stored reflectors backwards; least-squares bins.
+// =============================================================================================
+template <int NCH, int RPT, int MAXT>
+__global__ void __launch_bounds__(MAXT) factor_back_kernel(FactorArgs a) {
+    const int tid = threadIdx.x;
+    const int c = tid / NCH, ch = tid % NCH;
+    const int S = a.S, C = a.C, ldS = a.ldS;
+    const int kb = a.kb0 + blockIdx.x;
+    if (c >= C) return;
+    const cplx* Vw = a.Vws + (int64_t)blockIdx.x * C * ldS;
+    const cplx* N = a.Nw + (int64_t)blockIdx.x * C * C;
+    const double* tauw = a.tauw + (int64_t)blockIdx.x * C;
+    cplx B[RPT];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int s = ch + NCH * i;
-            B[i] = (s < C) ? Ns[s][c] : mk(0, 0);
-        }
-        for (int j = C - 1; j >= 0; --j) {
-            const double tau = tau_s[j];
-            const cplx* vj = Vw + (int64_t)j * ldS;
+    for (int i = 0; i < RPT; ++i) {
+        const int s = ch + NCH * i;
+        B[i] = (s < C) ? N[(int64_t)s * C + c] : mk(0, 0);
+    }
+    for (int j = C - 1; j >= 0; --j) {
+        const double tau = tauw[j];
+        const cplx* vj = Vw + (int64_t)j * ldS;
+        if constexpr (RPT <= 16) {
+            cplx v[RPT];
+            cplx w = mk(0, 0);
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int s = ch + NCH * i;
+                v[i] = (s >= j && s < S) ? vj[s] : mk(0, 0);
+                cfma_conj(w, v[i], B[i]);
+            }
+            w = group_sum<NCH>(w);
+            w = w * tau;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) { cplx p = w * v[i]; B[i] -= p; }
+        } else {
+            // tall problems: re-read v (L1/L2 resident) in the update pass instead of holding RPT more registers
             cplx w = mk(0, 0);
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
@@ -264,32 +308,29 @@ __global__ void __launch_bounds__(MAXT) factor_kernel(FactorArgs a) {
             }
             w = group_sum<NCH>(w);
             w = w * tau;
-            // second pass re-reads v (L1-resident) instead of holding RPT more registers
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
                 const int s = ch + NCH * i;
                 if (s >= j && s < S) { cplx p = w * vj[s]; B[i] -= p; }
             }
         }
-        // Z = conj(M)
+    }
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int s = ch + NCH * i;
-            if (s < S) a.Z[((int64_t)kb * C + c) * ldS + s] = conj(B[i]);
-        }
-        // -------------------------------------------------------------- 7. least-squares bins
-        if (a.Hq && kb < a.ls_end) {
-            for (int e = 0; e < 2; ++e) {
-                const cplx* hq = a.Hq + e * a.hq_estride + (int64_t)kb * a.ldHq;
-                cplx w = mk(0, 0);
+    for (int i = 0; i < RPT; ++i) {
+        const int s = ch + NCH * i;
+        if (s < S) a.Z[((int64_t)kb * C + c) * ldS + s] = conj(B[i]);
+    }
+    if (a.Hq && kb < a.ls_end) {
+        for (int e = 0; e < 2; ++e) {
+            const cplx* hq = a.Hq + e * a.hq_estride + (int64_t)kb * a.ldHq;
+            cplx w = mk(0, 0);
 #pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const int s = ch + NCH * i;
-                    if (s < S) cfma(w, hq[s], conj(B[i]));
-                }
-                w = group_sum<NCH>(w);
-                if (ch == 0) a.W[((int64_t)e * a.P + kb) * C + c] = w;
+            for (int i = 0; i < RPT; ++i) {
+                const int s = ch + NCH * i;
+                if (s < S) cfma(w, hq[s], conj(B[i]));
             }
+            w = group_sum<NCH>(w);
+            if (ch == 0) a.W[((int64_t)e * a.P + kb) * C + c] = w;
         }
     }
 }
@@ -303,11 +344,15 @@ static void launch_one(const FactorArgs& a, int nbins, hipStream_t st) {
     if (a.nOrders > 96) throw Error(2, "factor: simulation order above 95 is not supported");
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)factor_kernel<TT, NCH, RPT, MAXT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)factor_qr_kernel<TT, NCH, RPT, MAXT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         attr_set = true;
     }
-    factor_kernel<TT, NCH, RPT, MAXT><<<nbins, threads, dyn, st>>>(a);
+    factor_qr_kernel<TT, NCH, RPT, MAXT><<<nbins, threads, dyn, st>>>(a);
+    KERNEL_CHECK();
+    factor_jacobi_kernel<<<nbins, 256, 0, st>>>(a);
+    KERNEL_CHECK();
+    factor_back_kernel<NCH, RPT, MAXT><<<nbins, threads, 0, st>>>(a);
     KERNEL_CHECK();
 }
 
@@ -316,6 +361,7 @@ static void dispatch(const FactorArgs& a, int nbins, hipStream_t st) {
     const int S = a.S, C = a.C;
     if (C > CPMAX) throw Error(2, "factor: more than 32 output channels is not supported in this build");
     if (S < C) throw Error(2, "factor: fewer rows than channels (under-determined array model) is not supported");
+    if (!a.tauw || !a.R2w || !a.Nw || !a.Vws) throw Error(2, "factor: workspaces missing");
     if (C * 32 <= 1024) {
         if (S <= 32 * 1) return launch_one<TT, 32, 1, 1024>(a, nbins, st);
         if (S <= 32 * 4) return launch_one<TT, 32, 4, 1024>(a, nbins, st);

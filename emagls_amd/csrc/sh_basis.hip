@@ -117,6 +117,18 @@ __global__ void __launch_bounds__(256) transpose_conj_kernel(const T* __restrict
     }
 }
 
+// zero fill with a plain kernel (hipMemsetAsync nodes misbehave under graph replay on older runtimes)
+__global__ void zero_fill_kernel(unsigned long long* __restrict__ p, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0ull;
+}
+void launch_zero(void* p, size_t bytes, hipStream_t st) {
+    const int64_t n8 = (int64_t)(bytes / 8);
+    if (n8 == 0) return;
+    const unsigned grid = (unsigned)std::min<int64_t>(2048, ceil_div(n8, 256));
+    zero_fill_kernel<<<grid, 256, 0, st>>>((unsigned long long*)p, n8);
+    KERNEL_CHECK();
+}
+
 void launch_sh_coeff(int N, double* tab, hipStream_t st) {
     sh_coeff_kernel<<<8, 256, 0, st>>>(N, tab);
     KERNEL_CHECK();

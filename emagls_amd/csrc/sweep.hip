@@ -16,34 +16,49 @@ constexpr int SW_NT = 512;  // threads per workgroup (8 waves)
 
 
 __device__ __forceinline__ cplx unit_phase_times(double h, cplx p, bool nyquist) {
-    const double ap = cabs(p);
-    cplx t = (ap > 0.0) ? mk(h * (p.x / ap), h * (p.y / ap)) : mk(h, 0.0);
+    // |H| exp(1i*angle(p)) = |H| p/|p|;  angle(0) = 0 -> 1.  p is O(1e-3..1e3): |p|^2 cannot over/underflow
+    const double a2 = norm2(p);
+    cplx t = mk(h, 0.0);
+    if (a2 > 0.0) {
+        const double ia = h * fast_rsqrt(a2);
+        t = mk(p.x * ia, p.y * ia);
+    }
     if (nyquist) t.y = 0.0;
     return t;
 }
 
-// sum the previous launch's partials into Wp[e*C+c] (LDS); workgroup 0 publishes W(kb-1,:)
+// Partial sums live in Wpart[parity][pair][nWG] (pair = e*C + c): every (ear, channel) pair's nWG values are
+// contiguous, so one wave sums a pair with a few coalesced loads per lane and one wave reduction.
+// Sums the previous launch's partials into Wp[pair] (LDS); workgroup 0 publishes W(kb-1,:).
 __device__ __forceinline__ void gather_prev(cplx* Wp, const cplx* Wpart_prev, cplx* W, int nWG, int C, int P, int kb,
                                             bool first) {
-    const int tid = threadIdx.x;
-    const int pair = tid >> 3, part = tid & 7;
-    if (pair < 2 * C) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    for (int pair = wave; pair < 2 * C; pair += nwaves) {
         const int e = pair / C, c = pair % C;
         cplx acc = mk(0, 0);
         if (first) {
-            if (part == 0) acc = W[((int64_t)e * P + (kb - 1)) * C + c];
+            if (lane == 0) acc = W[((int64_t)e * P + (kb - 1)) * C + c];
         } else {
-            for (int w = part; w < nWG; w += 8) acc += Wpart_prev[((int64_t)w * 2 + e) * C + c];
+            const cplx* src = Wpart_prev + (int64_t)pair * nWG;
+            cplx v0 = mk(0, 0), v1 = mk(0, 0), v2 = mk(0, 0), v3 = mk(0, 0);
+            if (lane < nWG) v0 = src[lane];
+            if (lane + 64 < nWG) v1 = src[lane + 64];
+            if (lane + 128 < nWG) v2 = src[lane + 128];
+            if (lane + 192 < nWG) v3 = src[lane + 192];
+            acc = (v0 + v1) + (v2 + v3);
+            for (int w = lane + 256; w < nWG; w += 64) acc += src[w];
         }
-        acc = group_sum<8>(acc);
-        if (part == 0) {
+        acc = group_sum<64>(acc);
+        if (lane == 0) {
             Wp[pair] = acc;
             if (blockIdx.x == 0 && !first) W[((int64_t)e * P + (kb - 1)) * C + c] = acc;
         }
     }
 }
 
-template <typename TQ, int RS>
+constexpr int SW_CMAX = 32;
+
+template <typename TQ, int RS, int NL>
 __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int kb) {
     __shared__ __attribute__((aligned(16))) cplx Wp[64];
     extern __shared__ __attribute__((aligned(16))) char dyn[];
@@ -54,24 +69,91 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
     const bool nyq = (kb == a.P - 1);
     const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * a.nWG * 2 * C;
     cplx* Wout = a.Wpart + (int64_t)(kb & 1) * a.nWG * 2 * C;
+    const TQ* Q = reinterpret_cast<const TQ*>(a.Q);
+    const int64_t d0 = (int64_t)blockIdx.x * a.dpw;
+    const int64_t na = a.P - a.kabs0;
+    const double* HaL = a.Habs + ((int64_t)0 * na + (kb - a.kabs0)) * a.ldD;
+    const double* HaR = a.Habs + ((int64_t)1 * na + (kb - a.kabs0)) * a.ldD;
 
-    gather_prev(Wp, Wprev, a.W, a.nWG, C, a.P, kb, kb == a.kfirst);
-    __syncthreads();
-    // z[e][s] = sum_c W(k-1)[e][c] B_k[c][s]
-    {
-        const cplx* Bk = a.Bk + (int64_t)kb * C * ldS;
-        for (int s = tid; s < S; s += SW_NT) {
-            cplx z0 = mk(0, 0), z1 = mk(0, 0);
-            for (int c = 0; c < C; ++c) {
-                const cplx b = Bk[(int64_t)c * ldS + s];
-                cfma(z0, Wp[c], b);
-                cfma(z1, Wp[C + c], b);
-            }
-            zs[s] = z0;
-            zs[ldS + s] = z1;
+#define STAMP(i) do { if (a.timing && blockIdx.x == 7 && tid == 0) a.timing[(int64_t)kb * 16 + (i)] = (i) == 15 ? (long long)wall_clock64() : (long long)clock64(); } while (0)
+    STAMP(0);
+    STAMP(15);
+    if (a.nWG > 64 * NL) return;  // host guarantees nWG <= 64*NL (NL partials per lane)
+    // ---- the partial sums of the previous launch are the head of the dependency chain: their loads
+    //      go out first (memory returns in order), the W-independent operands right behind them
+    constexpr int NPW = (2 * SW_CMAX) / (SW_NT / 64);  // pairs per wave (8)
+    const bool first = (kb == a.kfirst);
+    cplx pv[NPW][NL];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int pair = wave + (SW_NT / 64) * j;
+        const cplx* src = Wprev + (int64_t)pair * a.nWG;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int w = lane + 64 * l;
+            pv[j][l] = (!first && pair < 2 * C && w < a.nWG) ? src[w] : mk(0, 0);
         }
     }
+    const cplx* Bk = a.Bk + (int64_t)kb * C * ldS;
+    cplx breg[SW_CMAX];
+    const int sz = tid;  // this thread's row of B_k (S <= 512 handled here, the rest in the loop below)
+#pragma unroll
+    for (int c = 0; c < SW_CMAX; ++c) breg[c] = (c < C && sz < S) ? Bk[(int64_t)c * ldS + sz] : mk(0, 0);
+    TQ q[RS];
+    double h0 = 0.0, h1 = 0.0;
+    {
+        const int64_t d = d0 + wave;
+        const bool ok = wave < a.dpw && d < a.D;
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            const int s = lane + 64 * i;
+            q[i] = (ok && s < S) ? Q[d * a.ldQ + s] : zero_of<TQ>();
+        }
+        if (ok) { h0 = HaL[d]; h1 = HaR[d]; }
+    }
+    STAMP(1);
+    // W(k-1)[pair] = sum over workgroups; workgroup 0 publishes it
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int pair = wave + (SW_NT / 64) * j;
+        if (pair < 2 * C) {
+            const int e = pair / C, c = pair % C;
+            cplx acc = pv[j][0];
+#pragma unroll
+            for (int l = 1; l < NL; ++l) acc += pv[j][l];
+            if (first) acc = (lane == 0) ? a.W[((int64_t)e * a.P + (kb - 1)) * C + c] : mk(0, 0);
+            acc = group_sum<64>(acc);
+            if (lane == 0) {
+                Wp[pair] = acc;
+                if (blockIdx.x == 0 && !first) a.W[((int64_t)e * a.P + (kb - 1)) * C + c] = acc;
+            }
+        }
+    }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
+    // ---- z[e][s] = sum_c W(k-1)[e][c] B_k[c][s]
+    if (sz < S) {
+        cplx z0 = mk(0, 0), z1 = mk(0, 0);
+#pragma unroll
+        for (int c = 0; c < SW_CMAX; ++c)
+            if (c < C) { cfma(z0, Wp[c], breg[c]); cfma(z1, Wp[C + c], breg[c]); }
+        zs[sz] = z0;
+        zs[ldS + sz] = z1;
+    }
+    for (int s = tid + SW_NT; s < S; s += SW_NT) {
+        cplx z0 = mk(0, 0), z1 = mk(0, 0);
+        for (int c = 0; c < C; ++c) {
+            const cplx b = Bk[(int64_t)c * ldS + s];
+            cfma(z0, Wp[c], b);
+            cfma(z1, Wp[C + c], b);
+        }
+        zs[s] = z0;
+        zs[ldS + s] = z1;
+    }
+    STAMP(4);
+    __syncthreads();
+    STAMP(5);
     cplx z0[RS], z1[RS], u0[RS], u1[RS];
 #pragma unroll
     for (int i = 0; i < RS; ++i) {
@@ -81,72 +163,95 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
         u0[i] = mk(0, 0);
         u1[i] = mk(0, 0);
     }
-    const TQ* Q = reinterpret_cast<const TQ*>(a.Q);
-    const int64_t d0 = (int64_t)blockIdx.x * a.dpw;
-    const int64_t na = a.P - a.kabs0;
-    const double* HaL = a.Habs + ((int64_t)0 * na + (kb - a.kabs0)) * a.ldD;
-    const double* HaR = a.Habs + ((int64_t)1 * na + (kb - a.kabs0)) * a.ldD;
+    // ---- this wave's directions: p = Q z, t = |H| p/|p|, u += t conj(q); next direction prefetched
     for (int dd = wave; dd < a.dpw; dd += SW_NT / 64) {
         const int64_t d = d0 + dd;
         if (d >= a.D) break;
-        TQ q[RS];
+        TQ qn[RS];
+        double hn0 = 0.0, hn1 = 0.0;
+        {
+            const int64_t dn = d + SW_NT / 64;
+            const bool ok = dd + SW_NT / 64 < a.dpw && dn < a.D;
+#pragma unroll
+            for (int i = 0; i < RS; ++i) {
+                const int s = lane + 64 * i;
+                qn[i] = (ok && s < S) ? Q[dn * a.ldQ + s] : zero_of<TQ>();
+            }
+            if (ok) { hn0 = HaL[dn]; hn1 = HaR[dn]; }
+        }
         cplx p0 = mk(0, 0), p1 = mk(0, 0);
 #pragma unroll
-        for (int i = 0; i < RS; ++i) {
-            const int s = lane + 64 * i;
-            q[i] = (s < S) ? Q[d * a.ldQ + s] : zero_of<TQ>();
-            cfma(p0, z0[i], q[i]);
-            cfma(p1, z1[i], q[i]);
-        }
+        for (int i = 0; i < RS; ++i) { cfma(p0, z0[i], q[i]); cfma(p1, z1[i], q[i]); }
         p0 = group_sum<64>(p0);
         p1 = group_sum<64>(p1);
-        const cplx t0 = unit_phase_times(HaL[d], p0, nyq);
-        const cplx t1 = unit_phase_times(HaR[d], p1, nyq);
+        const cplx t0 = unit_phase_times(h0, p0, nyq);
+        const cplx t1 = unit_phase_times(h1, p1, nyq);
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             const TQ qc = conj(q[i]);
             cfma(u0[i], t0, qc);
             cfma(u1[i], t1, qc);
+            q[i] = qn[i];
         }
+        h0 = hn0; h1 = hn1;
     }
-    // deterministic cross-wave accumulation of u into LDS
-    for (int w = 0; w < SW_NT / 64; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int i = 0; i < RS; ++i) {
-                const int s = lane + 64 * i;
-                if (s < S) {
-                    if (w == 0) { us[s] = u0[i]; us[ldS + s] = u1[i]; }
-                    else { us[s] += u0[i]; us[ldS + s] += u1[i]; }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // partial W(k,:) = u Z_k
-#pragma unroll
-    for (int i = 0; i < RS; ++i) {
-        const int s = lane + 64 * i;
-        u0[i] = (s < S) ? us[s] : mk(0, 0);
-        u1[i] = (s < S) ? us[ldS + s] : mk(0, 0);
-    }
+    STAMP(6);
+    // ---- Z_k loads for this wave's channels go out before the cross-wave reduction of u
+    constexpr int NCW = SW_CMAX / (SW_NT / 64);  // channels per wave (4)
     const cplx* Zk = a.Z + (int64_t)kb * C * ldS;
-    for (int c = wave; c < C; c += SW_NT / 64) {
-        cplx w0 = mk(0, 0), w1 = mk(0, 0);
+    cplx zv[NCW][RS];
+#pragma unroll
+    for (int j = 0; j < NCW; ++j) {
+        const int c = wave + (SW_NT / 64) * j;
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             const int s = lane + 64 * i;
-            const cplx zv = (s < S) ? Zk[(int64_t)c * ldS + s] : mk(0, 0);
-            cfma(w0, u0[i], zv);
-            cfma(w1, u1[i], zv);
-        }
-        w0 = group_sum<64>(w0);
-        w1 = group_sum<64>(w1);
-        if (lane == 0) {
-            Wout[((int64_t)blockIdx.x * 2 + 0) * C + c] = w0;
-            Wout[((int64_t)blockIdx.x * 2 + 1) * C + c] = w1;
+            zv[j][i] = (c < C && s < S) ? Zk[(int64_t)c * ldS + s] : mk(0, 0);
         }
     }
+    STAMP(7);
+    // deterministic cross-wave reduction of u: every wave stores its slab, one barrier, fixed-order sum
+    {
+        cplx* slab = us + (size_t)wave * 2 * ldS;
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            const int s = lane + 64 * i;
+            if (s < S) { slab[s] = u0[i]; slab[ldS + s] = u1[i]; }
+        }
+    }
+    __syncthreads();
+    STAMP(8);
+#pragma unroll
+    for (int i = 0; i < RS; ++i) {
+        const int s = lane + 64 * i;
+        cplx a0 = mk(0, 0), a1 = mk(0, 0);
+        if (s < S) {
+#pragma unroll
+            for (int w = 0; w < SW_NT / 64; ++w) {
+                a0 += us[(size_t)w * 2 * ldS + s];
+                a1 += us[(size_t)w * 2 * ldS + ldS + s];
+            }
+        }
+        u0[i] = a0;
+        u1[i] = a1;
+    }
+    // ---- partial W(k,:) = u Z_k
+#pragma unroll
+    for (int j = 0; j < NCW; ++j) {
+        const int c = wave + (SW_NT / 64) * j;
+        cplx w0 = mk(0, 0), w1 = mk(0, 0);
+#pragma unroll
+        for (int i = 0; i < RS; ++i) { cfma(w0, u0[i], zv[j][i]); cfma(w1, u1[i], zv[j][i]); }
+        w0 = group_sum<64>(w0);
+        w1 = group_sum<64>(w1);
+        if (lane == 0 && c < C) {
+            Wout[((int64_t)0 * C + c) * a.nWG + blockIdx.x] = w0;
+            Wout[((int64_t)1 * C + c) * a.nWG + blockIdx.x] = w1;
+        }
+    }
+    STAMP(9);
+    if (a.timing && blockIdx.x == 7 && tid == 0) a.timing[(int64_t)kb * 16 + 14] = (long long)wall_clock64();
+#undef STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,7 +299,7 @@ __global__ void __launch_bounds__(DS_NT) sweep_dense_kernel(DenseSweepArgs a, in
             if (d < a.D) cfma(acc, ts[e][dd], Zd[(int64_t)c * a.ldD + d]);
         }
         acc = group_sum<4>(acc);
-        if (part == 0) Wout[((int64_t)blockIdx.x * 2 + e) * C + c] = acc;
+        if (part == 0) Wout[((int64_t)e * C + c) * a.nWG + blockIdx.x] = acc;
     }
 }
 
@@ -212,11 +317,29 @@ __global__ void __launch_bounds__(SW_NT) sweep_finalize_kernel(const cplx* __res
 template <typename TQ>
 __global__ void __launch_bounds__(256) hq_kernel(const cplx* __restrict__ Hc, int64_t ldD, int n_c, const TQ* __restrict__ Q,
                                                  int64_t ldQ, int D, int S, int kb_lo, cplx* __restrict__ Hq, int ldS) {
+    // 32 SH channels x 8 direction slices per workgroup; slices reduced through LDS
+    __shared__ __attribute__((aligned(16))) cplx red[8][33];
     const int kb = kb_lo + blockIdx.x, e = blockIdx.y;
     const cplx* h = Hc + ((int64_t)e * n_c + kb) * ldD;
-    for (int s = blockIdx.z * blockDim.x + threadIdx.x; s < S; s += gridDim.z * blockDim.x) {
-        cplx acc = mk(0, 0);
-        for (int d = 0; d < D; ++d) cfma(acc, h[d], conj(Q[(int64_t)d * ldQ + s]));
+    const int sl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int s = blockIdx.z * 32 + sl;
+    cplx a0 = mk(0, 0), a1 = mk(0, 0), a2 = mk(0, 0), a3 = mk(0, 0);
+    if (s < S) {
+        int d = part;
+        for (; d + 24 < D; d += 32) {
+            cfma(a0, h[d], conj(Q[(int64_t)d * ldQ + s]));
+            cfma(a1, h[d + 8], conj(Q[(int64_t)(d + 8) * ldQ + s]));
+            cfma(a2, h[d + 16], conj(Q[(int64_t)(d + 16) * ldQ + s]));
+            cfma(a3, h[d + 24], conj(Q[(int64_t)(d + 24) * ldQ + s]));
+        }
+        for (; d < D; d += 8) cfma(a0, h[d], conj(Q[(int64_t)d * ldQ + s]));
+    }
+    red[part][sl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (part == 0 && s < S) {
+        cplx acc = red[0][sl];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) acc += red[j][sl];
         Hq[((int64_t)e * n_c + kb) * ldS + s] = acc;
     }
 }
@@ -289,10 +412,22 @@ __global__ void widen_kernel(const T* __restrict__ in, int64_t ldi, cplx* __rest
 // ---------------------------------------------------------------------------------------------
 template <typename TQ>
 static void sweep_factored_dispatch(const SweepArgs& a, int kb, hipStream_t st) {
-    const size_t dyn = (size_t)4 * a.ldS * sizeof(cplx);
+    const size_t dyn = (size_t)(2 + 2 * (SW_NT / 64)) * a.ldS * sizeof(cplx);
+    if (dyn > 150 * 1024) throw Error(2, "sweep: SH channel count too large for the LDS-resident reduction");
     const int rs = (a.S + 63) / 64;
 #define EMAGLS_SWEEP_CASE(R)                                                                         \
-    sweep_factored_kernel<TQ, R><<<a.nWG, SW_NT, dyn, st>>>(a, kb)
+    do {                                                                                             \
+        static bool attr_set = false;                                                                \
+        if (!attr_set) {                                                                             \
+            HIP_CHECK(hipFuncSetAttribute((const void*)sweep_factored_kernel<TQ, R, 2>,              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+            HIP_CHECK(hipFuncSetAttribute((const void*)sweep_factored_kernel<TQ, R, 4>,              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+            attr_set = true;                                                                         \
+        }                                                                                            \
+        if (a.nWG <= 128) sweep_factored_kernel<TQ, R, 2><<<a.nWG, SW_NT, dyn, st>>>(a, kb);         \
+        else sweep_factored_kernel<TQ, R, 4><<<a.nWG, SW_NT, dyn, st>>>(a, kb);                      \
+    } while (0)
     if (rs <= 2) EMAGLS_SWEEP_CASE(2);
     else if (rs <= 4) EMAGLS_SWEEP_CASE(4);
     else if (rs <= 7) EMAGLS_SWEEP_CASE(7);
@@ -322,7 +457,7 @@ void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, in
 void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
                int kb_hi, void* Hq, int ldS, hipStream_t st) {
     if (kb_hi <= kb_lo) return;
-    dim3 grid(kb_hi - kb_lo, 2, (unsigned)ceil_div(S, 256));
+    dim3 grid(kb_hi - kb_lo, 2, (unsigned)ceil_div(S, 32));
     if (q_cplx) hq_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const cplx*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS);
     else hq_kernel<double><<<grid, 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const double*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS);
     KERNEL_CHECK();
