@@ -38,6 +38,7 @@ struct FactorArgs {
     double* tauw;     // [bin][C]       Householder scalars
     cplx* R2w;        // [bin][C][C]    triangular factor (upper)
     cplx* Nw;         // [bin][C][C]    U2 diag(s_reg) V^H
+    cplx* Mw;         // [bin][C][C]    V diag(s_reg/s) V^H (optional, for the direction-space sweep operands)
 };
 
 struct SweepArgs {

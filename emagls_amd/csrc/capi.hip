@@ -45,7 +45,7 @@ struct emagls_plan {
     bool hrir_smaller = true;
     bool out_cplx = false;
     int64_t out_rows = 0, out_cols = 0;
-    int nWG = 0, dpw = 0;
+    int nWG = 0, dpw = 0, nWG_dense = 0;
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
     // profiling
     int prof_level = 0;
@@ -60,6 +60,7 @@ struct emagls_plan {
     hipGraphExec_t graph_exec = nullptr;
     int eager_runs = 0;
     bool use_graph = true;
+    bool sweep_factored = false;  // legacy S-space sweep (kept for comparison)
 
     ~emagls_plan() {
         for (auto& kv : bufs) if (kv.second.p) hipFree(kv.second.p);
@@ -235,6 +236,15 @@ void plan_setup(emagls_plan& p) {
         p.alloc("tauw", sizeof(double) * (size_t)p.P * p.C);
         p.alloc("R2w", sizeof(cplx) * (size_t)p.P * p.C * p.C);
         p.alloc("Nw", sizeof(cplx) * (size_t)p.P * p.C * p.C);
+        p.alloc("Mw", sizeof(cplx) * (size_t)p.P * p.C * p.C);
+        p.alloc("cond_ok", sizeof(double) * (size_t)p.P);
+        p.alloc("QT", esz(cb) * (size_t)(p.simOrder + 1) * p.C * p.ldD);
+        {
+            const size_t nsw = (size_t)std::max(p.P - std::max(p.kcut0, 1), 1);
+            p.alloc("G", sizeof(cplx) * nsw * p.C * p.ldD, false);
+            p.alloc("Yri", sizeof(cplx) * nsw * p.C * p.ldD, false);
+        }
+        p.sweep_factored = getenv("EMAGLS_SWEEP") && std::string(getenv("EMAGLS_SWEEP")) == "factored";
         if (getenv("EMAGLS_SWEEP_TIMING")) p.alloc("sweep_timing", sizeof(long long) * 16 * (size_t)p.P);
         p.nWG = 128;
         if (const char* e = getenv("EMAGLS_SWEEP_NWG")) p.nWG = std::max(8, std::min(256, atoi(e)));
@@ -267,7 +277,8 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Habs", sizeof(double) * (size_t)2 * std::max(p.P - p.kcut0, 1) * p.ldD);
         p.alloc("W", sizeof(cplx) * (size_t)2 * p.P * p.C);
         if (d.kind == EMAGLS_KIND_MAGLS || d.kind == EMAGLS_KIND_FROM_ATF) p.nWG = dense_sweep_nwg((int)Dh);
-        p.alloc("Wpart", sizeof(cplx) * (size_t)2 * p.nWG * 2 * p.C);
+        p.nWG_dense = dense_sweep_nwg((int)Dh);
+        p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(p.nWG, p.nWG_dense) * 2 * p.C);
         p.out_rows = d.len;
     }
     p.out_cols = p.C;
@@ -415,7 +426,8 @@ void execute_emagls(emagls_plan& p) {
         a.S = p.S; a.C = p.C; a.ldS = p.ldS; a.kb0 = 1; a.P = p.P;
         a.Tn = p.get("Tn"); a.bn = p.get<cplx>("bn"); a.nOrders = p.simOrder + 1;
         a.reg_mode = 0; a.reg_c = SVD_REGUL_CONST;
-        a.Z = p.get<cplx>("Z"); a.Bk = p.get<cplx>("Bk"); a.bk_from = p.kcut0;
+        a.Z = p.get<cplx>("Z"); a.Bk = p.sweep_factored ? p.get<cplx>("Bk") : nullptr; a.bk_from = p.kcut0;
+        a.Mw = p.get<cplx>("Mw");
         a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
         a.Hq = p.get<cplx>("Hq"); a.ldHq = p.ldS; a.hq_estride = (int64_t)ls_end * p.ldS; a.ls_end = ls_end;
         a.W = p.get<cplx>("W"); a.sweeps_out = p.get<int>("jsweeps");
@@ -423,13 +435,13 @@ void execute_emagls(emagls_plan& p) {
         launch_factor(a, p.P - 1, cb, st);
     }
     p.mark("factor_bins");
-    {
+    const int k0 = std::max(p.kcut0, 1);
+    if (p.sweep_factored) {
         SweepArgs a{};
         a.D = (int)p.D; a.S = p.S; a.C = p.C; a.ldS = p.ldS; a.P = p.P; a.ldQ = p.ldS;
         a.Q = p.get("Q"); a.Z = p.get<cplx>("Z"); a.Bk = p.get<cplx>("Bk");
         a.Habs = p.get<double>("Habs"); a.ldD = p.ldD; a.kabs0 = p.kcut0;
         a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG; a.dpw = p.dpw;
-        const int k0 = std::max(p.kcut0, 1);
         a.kfirst = k0;
         a.timing = p.has("sweep_timing") ? p.get<long long>("sweep_timing") : nullptr;
         p.sweep_launches = 0;
@@ -440,6 +452,29 @@ void execute_emagls(emagls_plan& p) {
             ++p.sweep_launches;
         }
         if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
+    } else {
+        // direction-space operands of every swept bin (parallel over bins), then the light sequential sweep
+        launch_qt(p.get("Q"), p.ldS, p.get("Tn"), p.ldS, (int)p.D, p.S, p.C, p.simOrder + 1, cb, p.get("QT"), p.ldD, st);
+        launch_dspace(p.get("QT"), p.ldD, cb, p.get("bn"), p.simOrder + 1, p.get("Mw"), 1, p.get<double>("sv"),
+                      p.get<double>("cond_ok"), (int)p.D, p.C, p.P, k0, p.get("G"), p.get("Yri"), st);
+        launch_yri_accurate(p.get("Q"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
+                            p.get("Yri"), p.ldD, st);
+        p.mark("dspace_operands");
+        DenseSweepArgs a{};
+        a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
+        // the operand arrays start at bin k0: shift the base so that the kernels can index by kb
+        a.X = p.get<cplx>("G") - (int64_t)k0 * p.C * p.ldD; a.x_stride = (int64_t)p.C * p.ldD;
+        a.Zd = p.get<cplx>("Yri") - (int64_t)k0 * p.C * p.ldD; a.z_stride = (int64_t)p.C * p.ldD;
+        a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
+        a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG_dense; a.kfirst = k0;
+        p.sweep_launches = 0;
+        for (int kb = k0; kb < p.P; ++kb) {
+            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
+            launch_sweep_dense(a, kb, true, st);
+            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
+            ++p.sweep_launches;
+        }
+        if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG_dense, p.C, p.P, p.P - 1, st);
     }
     p.mark("magls_sweep");
     launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)d.len, p.get("tw"), p.get<double>("grpd"), (cb && !raw) ? 1 : 0, 1, 0,

@@ -134,6 +134,21 @@ template <int W> __device__ __forceinline__ double group_sum(double v) {
     if (W >= 64) v += shfl_xor_d(v, 32);
     return v;
 }
+// full-wave all-reduce: DPP inside the four 16-lane rows, then four scalar lane reads (no LDS crossbar)
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_d<DPP_XOR1>(v);
+    v += dpp_d<DPP_XOR2>(v);
+    v += dpp_d<DPP_HALF_MIRROR>(v);
+    v += dpp_d<DPP_ROW_MIRROR>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ cplx wave_sum(cplx v) { return {wave_sum(v.x), wave_sum(v.y)}; }
+
 template <int W> __device__ __forceinline__ cplx group_sum(cplx v) {
     return {group_sum<W>(v.x), group_sum<W>(v.y)};
 }

@@ -1,0 +1,181 @@
+// Direction-space operands of the magnitude-least-squares sweep, built once per design for all
+// swept bins (bins are independent here; only the sweep itself is sequential).
+//
+//   G_k   = pwGrid_k.' = Q B_k = sum_n b_n(k) (Q T_n)            [D x C]   -- exact, 20 cMAC per entry
+//   Yri_k = Y_reg_inv_k = conj(U_k) diag(s_reg) V^T
+//         = conj(G_k) conj(M_k),  M_k = V diag(s_reg/s) V^H       [D x C]   -- U_k = G_k V S^-1
+//
+// The second identity forms U_k from G_k V S^-1, which is only as orthonormal as eps*cond(G_k).  That is
+// harmless for the swept bins (k >= k_cut, f >= 1 kHz: cond ~ 1e2..1e3, error ~ eps*100*cond), and the
+// least-squares bins below k_cut -- where cond reaches 1e13 -- never take this route (factor.hip).
+// Bins whose condition number exceeds COND_LIMIT are recomputed from the orthonormal S-space factor
+// (Yri_k = conj(Q) Z_k) by yri_accurate_kernel.
+//
+// Why direction space: a launch starts with cold L2 (kernel boundaries invalidate it), so the per-launch
+// cost of the sweep is set by the bytes EVERY workgroup must fetch; S-space operands (B_k, Z_k: 2 x 160 KB)
+// are needed whole by every workgroup, direction-space slabs are disjoint (2 x 1.08 MB / nWG).
+#include "kernels.hpp"
+
+namespace emagls {
+
+constexpr double COND_LIMIT = 1.0e4;
+constexpr int SW_CMAX_ = 32;
+
+// QT[n][c][d] = sum_{s < (n+1)^2} Q[d][s] T[n][c][s]      thread = (direction, channel)
+template <typename T>
+__global__ void __launch_bounds__(256) qt_kernel(const T* __restrict__ Q, int64_t ldQ, const T* __restrict__ Tn, int ldS,
+                                                 int D, int S, int C, int nOrders, T* __restrict__ QT, int64_t ldD) {
+    const int c = threadIdx.x >> 3, dl = threadIdx.x & 7;  // direction fastest: full-line stores
+    const int d = blockIdx.x * 8 + dl;
+    const int n = blockIdx.y;
+    if (c >= C || d >= D) return;
+    const int se = min(S, (n + 1) * (n + 1));
+    const T* q = Q + (int64_t)d * ldQ;
+    const T* t = Tn + ((int64_t)n * C + c) * ldS;
+    T a0 = zero_of<T>(), a1 = zero_of<T>();
+    int s = 0;
+    for (; s + 1 < se; s += 2) { cfma(a0, q[s], t[s]); cfma(a1, q[s + 1], t[s + 1]); }
+    if (s < se) cfma(a0, q[s], t[s]);
+    QT[((int64_t)n * C + c) * ldD + d] = a0 + a1;
+}
+
+// G kernel: one workgroup = 8 directions x a chunk of swept bins; thread = (channel, direction).  The
+// thread's order terms QT[n][c][d] stay in registers for the whole chunk and the chunk's b_n(k) table is
+// staged in LDS once, so a bin costs 20 LDS broadcasts, 20 complex FMAs and one coalesced store -- no barrier.
+//   G [kb - k0][c][d]
+constexpr int DSP_TD = 8;
+constexpr int DSP_NMAX = 32;  // orders held in registers (simulation order <= 31)
+
+template <typename T>
+__global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT, int64_t ldD, const cplx* __restrict__ bn,
+                                                       int nOrders, int D, int C, int P, int k0, int bins_per_chunk,
+                                                       cplx* __restrict__ G) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* bs = reinterpret_cast<cplx*>(dyn);  // [bins_per_chunk][nOrders]
+    const int c = threadIdx.x >> 3, dl = threadIdx.x & 7;  // direction fastest: full-line stores
+    const int d = blockIdx.x * DSP_TD + dl;
+    const bool act = c < C && d < D;
+    const int kb_begin = k0 + blockIdx.y * bins_per_chunk;
+    const int kb_end = min(P, kb_begin + bins_per_chunk);
+    for (int idx = threadIdx.x; idx < (kb_end - kb_begin) * nOrders; idx += 256) {
+        const int kb = kb_begin + idx / nOrders;
+        cplx b = bn[(int64_t)kb_begin * nOrders + idx];
+        if (kb == P - 1) b.y = 0.0;  // Nyquist: real(Bn)
+        bs[idx] = b;
+    }
+    T qt[DSP_NMAX];
+#pragma unroll
+    for (int n = 0; n < DSP_NMAX; ++n) qt[n] = (act && n < nOrders) ? QT[((int64_t)n * C + c) * ldD + d] : zero_of<T>();
+    __syncthreads();
+    if (!act) return;
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+        const cplx* b = bs + (size_t)(kb - kb_begin) * nOrders;
+        cplx g0 = mk(0, 0), g1 = mk(0, 0);
+#pragma unroll
+        for (int n = 0; n < DSP_NMAX; n += 2) {
+            if (n < nOrders) cfma(g0, b[n], qt[n]);
+            if (n + 1 < nOrders) cfma(g1, b[n + 1], qt[n + 1]);
+        }
+        G[((int64_t)(kb - k0) * C + c) * ldD + d] = g0 + g1;
+    }
+}
+
+// Yri kernel: one workgroup = one swept bin x 256 directions; thread = direction.
+//   Yri[c][d] = conj( sum_c' G[c'][d] M[c'][c] )      M_k staged in LDS (broadcast reads)
+__global__ void __launch_bounds__(256) dspace_yri_kernel(const cplx* __restrict__ G, int64_t ldD, const cplx* __restrict__ Mw,
+                                                         int kb0_factor, const double* __restrict__ cond_ok, int D, int C,
+                                                         int k0, cplx* __restrict__ Yri) {
+    __shared__ __attribute__((aligned(16))) cplx ms[SW_CMAX_ * SW_CMAX_];
+    const int kb = k0 + blockIdx.y;
+    if (cond_ok[kb] == 0.0) return;  // ill-conditioned bin: yri_accurate_kernel handles it
+    const cplx* M = Mw + (int64_t)(kb - kb0_factor) * C * C;
+    for (int idx = threadIdx.x; idx < C * C; idx += 256) ms[idx] = M[idx];
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    cplx g[SW_CMAX_];
+#pragma unroll
+    for (int c = 0; c < SW_CMAX_; ++c) g[c] = (c < C && d < D) ? G[((int64_t)(kb - k0) * C + c) * ldD + d] : mk(0, 0);
+    __syncthreads();
+    if (d >= D) return;
+    for (int c = 0; c < C; ++c) {
+        cplx a0 = mk(0, 0), a1 = mk(0, 0);
+#pragma unroll
+        for (int cc = 0; cc < SW_CMAX_; cc += 2) {
+            if (cc < C) cfma(a0, g[cc], ms[cc * C + c]);
+            if (cc + 1 < C) cfma(a1, g[cc + 1], ms[(cc + 1) * C + c]);
+        }
+        Yri[((int64_t)(kb - k0) * C + c) * ldD + d] = conj(a0 + a1);
+    }
+}
+
+// cond_ok[kb] = 1 when smax <= COND_LIMIT * smin for bin kb (the cheap identity is accurate), else 0
+__global__ void cond_flag_kernel(const double* __restrict__ sv, int C, int P, double* __restrict__ cond_ok) {
+    const int kb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kb >= P) return;
+    double smax = 0.0, smin = INFINITY;
+    for (int i = 0; i < C; ++i) { const double s = sv[(int64_t)kb * C + i]; smax = fmax(smax, s); smin = fmin(smin, s); }
+    cond_ok[kb] = (smax <= COND_LIMIT * smin) ? 1.0 : 0.0;
+}
+
+// ill-conditioned swept bins: Yri[c][d] = sum_s conj(Q[d][s]) Z_k[c][s]  (orthonormal S-space factor)
+template <typename T>
+__global__ void __launch_bounds__(256) yri_accurate_kernel(const T* __restrict__ Q, int64_t ldQ, const cplx* __restrict__ Z,
+                                                           int ldS, const double* __restrict__ cond_ok, int D, int S, int C, int k0,
+                                                           cplx* __restrict__ Yri, int64_t ldD) {
+    const int kb = k0 + blockIdx.y;
+    if (cond_ok[kb] != 0.0) return;
+    const int c = threadIdx.x >> 3, dl = threadIdx.x & 7;
+    if (c >= C) return;
+    for (int d = blockIdx.x * 8 + dl; d < D; d += gridDim.x * 8) {
+        const T* q = Q + (int64_t)d * ldQ;
+        const cplx* z = Z + ((int64_t)kb * C + c) * ldS;
+        cplx a0 = mk(0, 0), a1 = mk(0, 0);
+        int s = 0;
+        for (; s + 1 < S; s += 2) { cfma(a0, conj(q[s]), z[s]); cfma(a1, conj(q[s + 1]), z[s + 1]); }
+        if (s < S) cfma(a0, conj(q[s]), z[s]);
+        Yri[((int64_t)(kb - k0) * C + c) * ldD + d] = a0 + a1;
+    }
+}
+
+void launch_qt(const void* Q, int64_t ldQ, const void* Tn, int ldS, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
+               int64_t ldD, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(D, 8), nOrders);
+    if (is_cplx) qt_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)Q, ldQ, (const cplx*)Tn, ldS, D, S, C, nOrders, (cplx*)QT, ldD);
+    else qt_kernel<double><<<grid, 256, 0, st>>>((const double*)Q, ldQ, (const double*)Tn, ldS, D, S, C, nOrders, (double*)QT, ldD);
+    KERNEL_CHECK();
+}
+
+template <typename T>
+static void dspace_impl(const void* QT, int64_t ldD, const void* bn, int nOrders, const void* Mw, int kb0_factor,
+                        const double* sv, double* cond_ok, int D, int C, int P, int k0, void* G, void* Yri, hipStream_t st) {
+    const int nbins = P - k0;
+    if (nbins <= 0) return;
+    if (nOrders > DSP_NMAX) throw Error(2, "dspace: simulation order above 31 is not supported in this build");
+    cond_flag_kernel<<<(P + 255) / 256, 256, 0, st>>>(sv, C, P, cond_ok);
+    KERNEL_CHECK();
+    const int chunks = 4;
+    const int bpc = (nbins + chunks - 1) / chunks;
+    const size_t dyn = sizeof(cplx) * (size_t)bpc * nOrders;
+    if (dyn > 60 * 1024) throw Error(2, "dspace: too many bins per chunk");
+    dspace_g_kernel<T><<<dim3((unsigned)ceil_div(D, DSP_TD), chunks), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D,
+                                                                                     C, P, k0, bpc, (cplx*)G);
+    KERNEL_CHECK();
+    dspace_yri_kernel<<<dim3((unsigned)ceil_div(D, 256), nbins), 256, 0, st>>>((const cplx*)G, ldD, (const cplx*)Mw, kb0_factor,
+                                                                              cond_ok, D, C, k0, (cplx*)Yri);
+    KERNEL_CHECK();
+}
+void launch_dspace(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, const void* Mw, int kb0_factor,
+                   const double* sv, double* cond_ok, int D, int C, int P, int k0, void* G, void* Yri, hipStream_t st) {
+    if (is_cplx) dspace_impl<cplx>(QT, ldD, bn, nOrders, Mw, kb0_factor, sv, cond_ok, D, C, P, k0, G, Yri, st);
+    else dspace_impl<double>(QT, ldD, bn, nOrders, Mw, kb0_factor, sv, cond_ok, D, C, P, k0, G, Yri, st);
+}
+
+void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S, int C,
+                         int P, int k0, void* Yri, int64_t ldD, hipStream_t st) {
+    if (P - k0 <= 0) return;
+    dim3 grid(32, P - k0);  // flagged bins are rare: workgroups of well-conditioned bins exit at once
+    if (is_cplx) yri_accurate_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)Q, ldQ, (const cplx*)Z, ldS, cond_ok, D, S, C, k0, (cplx*)Yri, ldD);
+    else yri_accurate_kernel<double><<<grid, 256, 0, st>>>((const double*)Q, ldQ, (const cplx*)Z, ldS, cond_ok, D, S, C, k0, (cplx*)Yri, ldD);
+    KERNEL_CHECK();
+}
+
+}  // namespace emagls

@@ -261,6 +261,21 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a) {
         }
         N[idx] = acc;
     }
+    // M = V diag(g) V^H with V = Xrot / sigma:  M[a][b] = sum_i Xrot[a][i] (g_i / sigma_i^2) conj(Xrot[b][i])
+    if (a.Mw) {
+        cplx* M = a.Mw + (int64_t)blockIdx.x * C * C;
+        for (int idx = tid; idx < C * C; idx += 256) {
+            const int aa = idx / C, bb = idx % C;
+            cplx acc = mk(0, 0);
+            for (int i = 0; i < C; ++i) {
+                const double sg = sig_s[i];
+                const double w = (sg > 0.0) ? g_s[i] / (sg * sg) : 0.0;
+                const cplx t = w * Xs[i][aa];
+                cfma(acc, t, conj(Xs[i][bb]));
+            }
+            M[idx] = acc;
+        }
+    }
 }
 
 // =============================================================================================

@@ -66,6 +66,14 @@ void launch_conj_copy(const void* in, void* out, int64_t n, bool is_cplx, hipStr
 void launch_widen(const void* in, int64_t ldi, bool in_cplx, void* out, int64_t ldo, int rows, int cols, bool transpose,
                   bool upper_only, hipStream_t st);
 
+// ---- dspace.hip
+void launch_qt(const void* Q, int64_t ldQ, const void* Tn, int ldS, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
+               int64_t ldD, hipStream_t st);
+void launch_dspace(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, const void* Mw, int kb0_factor,
+                   const double* sv, double* cond_ok, int D, int C, int P, int k0, void* G, void* Yri, hipStream_t st);
+void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S,
+                         int C, int P, int k0, void* Yri, int64_t ldD, hipStream_t st);
+
 // ---- atf.hip
 void launch_grid_match(const double* aziA, const double* zenA, int64_t nA, const double* aziB, const double* zenB,
                        int64_t nB, double* cartB, int64_t* idx, double* dev_deg, double* mean_dev, hipStream_t st);

@@ -58,47 +58,53 @@ __device__ __forceinline__ void gather_prev(cplx* Wp, const cplx* Wpart_prev, cp
 
 constexpr int SW_CMAX = 32;
 
+// LDS plan of the factored sweep kernel (complex elements):
+//   zu   [2][ldS]                       z, later the reduced u
+//   big  max(2C*(nWG+1), 8*2*ldS)       staged partial sums of the previous launch, later the per-wave u slabs
+__host__ __device__ inline size_t sweep_lds_elems(int ldS, int C, int nWG) {
+    const size_t g = (size_t)2 * C * (nWG + 1), sl = (size_t)(SW_NT / 64) * 2 * ldS;
+    return (size_t)2 * ldS + (g > sl ? g : sl);
+}
+
 template <typename TQ, int RS, int NL>
 __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int kb) {
     __shared__ __attribute__((aligned(16))) cplx Wp[64];
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    cplx* zs = reinterpret_cast<cplx*>(dyn);  // [2][ldS]
-    cplx* us = zs + 2 * a.ldS;                // [2][ldS]
+    cplx* zu = reinterpret_cast<cplx*>(dyn);  // [2][ldS]
+    cplx* big = zu + 2 * a.ldS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int S = a.S, C = a.C, ldS = a.ldS;
+    const int S = a.S, C = a.C, ldS = a.ldS, nWG = a.nWG;
     const bool nyq = (kb == a.P - 1);
-    const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * a.nWG * 2 * C;
-    cplx* Wout = a.Wpart + (int64_t)(kb & 1) * a.nWG * 2 * C;
+    const bool first = (kb == a.kfirst);
+    const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * nWG * 2 * C;
+    cplx* Wout = a.Wpart + (int64_t)(kb & 1) * nWG * 2 * C;
     const TQ* Q = reinterpret_cast<const TQ*>(a.Q);
     const int64_t d0 = (int64_t)blockIdx.x * a.dpw;
     const int64_t na = a.P - a.kabs0;
     const double* HaL = a.Habs + ((int64_t)0 * na + (kb - a.kabs0)) * a.ldD;
     const double* HaR = a.Habs + ((int64_t)1 * na + (kb - a.kabs0)) * a.ldD;
-
 #define STAMP(i) do { if (a.timing && blockIdx.x == 7 && tid == 0) a.timing[(int64_t)kb * 16 + (i)] = (i) == 15 ? (long long)wall_clock64() : (long long)clock64(); } while (0)
     STAMP(0);
     STAMP(15);
-    if (a.nWG > 64 * NL) return;  // host guarantees nWG <= 64*NL (NL partials per lane)
-    // ---- the partial sums of the previous launch are the head of the dependency chain: their loads
-    //      go out first (memory returns in order), the W-independent operands right behind them
-    constexpr int NPW = (2 * SW_CMAX) / (SW_NT / 64);  // pairs per wave (8)
-    const bool first = (kb == a.kfirst);
-    cplx pv[NPW][NL];
+    if (nWG > 64 * NL) return;  // host guarantees nWG <= 64*NL
+
+    // ---- 0. issue every load of this launch's head: the previous launch's partial sums first (they gate
+    //         everything; memory returns in order), then the operands that do not depend on W(k-1)
+    constexpr int NGV = (2 * SW_CMAX * 64 * NL) / SW_NT;  // staged partials per thread
+    const int npart = 2 * C * nWG;
+    cplx gv[NGV];
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-        const int pair = wave + (SW_NT / 64) * j;
-        const cplx* src = Wprev + (int64_t)pair * a.nWG;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const int w = lane + 64 * l;
-            pv[j][l] = (!first && pair < 2 * C && w < a.nWG) ? src[w] : mk(0, 0);
-        }
+    for (int i = 0; i < NGV; ++i) {
+        const int f = tid + SW_NT * i;
+        gv[i] = (!first && f < npart) ? Wprev[f] : mk(0, 0);
     }
+    if (a.timing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(10); }
     const cplx* Bk = a.Bk + (int64_t)kb * C * ldS;
     cplx breg[SW_CMAX];
-    const int sz = tid;  // this thread's row of B_k (S <= 512 handled here, the rest in the loop below)
+    const int sz = tid;  // this thread's row of B_k (S <= 512 handled here, the rest in a loop below)
 #pragma unroll
     for (int c = 0; c < SW_CMAX; ++c) breg[c] = (c < C && sz < S) ? Bk[(int64_t)c * ldS + sz] : mk(0, 0);
+    if (a.timing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(11); }
     TQ q[RS];
     double h0 = 0.0, h1 = 0.0;
     {
@@ -111,19 +117,33 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
         }
         if (ok) { h0 = HaL[d]; h1 = HaR[d]; }
     }
+    if (a.timing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(12); }
     STAMP(1);
-    // W(k-1)[pair] = sum over workgroups; workgroup 0 publishes it
+    // ---- 1. W(k-1)[pair] = sum over workgroups of the staged partials (row stride nWG+1 against bank conflicts)
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-        const int pair = wave + (SW_NT / 64) * j;
+    for (int i = 0; i < NGV; ++i) {
+        const int f = tid + SW_NT * i;
+        if (f < npart) big[f + f / nWG] = gv[i];
+    }
+    __syncthreads();
+    {
+        const int pair = tid >> 3, part = tid & 7;
         if (pair < 2 * C) {
             const int e = pair / C, c = pair % C;
-            cplx acc = pv[j][0];
-#pragma unroll
-            for (int l = 1; l < NL; ++l) acc += pv[j][l];
-            if (first) acc = (lane == 0) ? a.W[((int64_t)e * a.P + (kb - 1)) * C + c] : mk(0, 0);
-            acc = group_sum<64>(acc);
-            if (lane == 0) {
+            cplx acc = mk(0, 0);
+            if (first) {
+                if (part == 0) acc = a.W[((int64_t)e * a.P + (kb - 1)) * C + c];
+            } else {
+                const cplx* row = big + (size_t)pair * (nWG + 1);
+                cplx a0 = mk(0, 0), a1 = mk(0, 0);
+                for (int w = part; w < nWG; w += 16) {
+                    a0 += row[w];
+                    if (w + 8 < nWG) a1 += row[w + 8];
+                }
+                acc = a0 + a1;
+            }
+            acc = group_sum<8>(acc);
+            if (part == 0) {
                 Wp[pair] = acc;
                 if (blockIdx.x == 0 && !first) a.W[((int64_t)e * a.P + (kb - 1)) * C + c] = acc;
             }
@@ -132,14 +152,16 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
     STAMP(2);
     __syncthreads();
     STAMP(3);
-    // ---- z[e][s] = sum_c W(k-1)[e][c] B_k[c][s]
+    // ---- 2. z[e][s] = sum_c W(k-1)[e][c] B_k[c][s]
     if (sz < S) {
-        cplx z0 = mk(0, 0), z1 = mk(0, 0);
+        cplx z0a = mk(0, 0), z0b = mk(0, 0), z1a = mk(0, 0), z1b = mk(0, 0);
 #pragma unroll
-        for (int c = 0; c < SW_CMAX; ++c)
-            if (c < C) { cfma(z0, Wp[c], breg[c]); cfma(z1, Wp[C + c], breg[c]); }
-        zs[sz] = z0;
-        zs[ldS + sz] = z1;
+        for (int c = 0; c < SW_CMAX; c += 2) {
+            if (c < C) { cfma(z0a, Wp[c], breg[c]); cfma(z1a, Wp[C + c], breg[c]); }
+            if (c + 1 < C) { cfma(z0b, Wp[c + 1], breg[c + 1]); cfma(z1b, Wp[C + c + 1], breg[c + 1]); }
+        }
+        zu[sz] = z0a + z0b;
+        zu[ldS + sz] = z1a + z1b;
     }
     for (int s = tid + SW_NT; s < S; s += SW_NT) {
         cplx z0 = mk(0, 0), z1 = mk(0, 0);
@@ -148,8 +170,8 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
             cfma(z0, Wp[c], b);
             cfma(z1, Wp[C + c], b);
         }
-        zs[s] = z0;
-        zs[ldS + s] = z1;
+        zu[s] = z0;
+        zu[ldS + s] = z1;
     }
     STAMP(4);
     __syncthreads();
@@ -158,12 +180,12 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
 #pragma unroll
     for (int i = 0; i < RS; ++i) {
         const int s = lane + 64 * i;
-        z0[i] = (s < S) ? zs[s] : mk(0, 0);
-        z1[i] = (s < S) ? zs[ldS + s] : mk(0, 0);
+        z0[i] = (s < S) ? zu[s] : mk(0, 0);
+        z1[i] = (s < S) ? zu[ldS + s] : mk(0, 0);
         u0[i] = mk(0, 0);
         u1[i] = mk(0, 0);
     }
-    // ---- this wave's directions: p = Q z, t = |H| p/|p|, u += t conj(q); next direction prefetched
+    // ---- 3. this wave's directions: p = Q z, t = |H| p/|p|, u += t conj(q); next direction prefetched
     for (int dd = wave; dd < a.dpw; dd += SW_NT / 64) {
         const int64_t d = d0 + dd;
         if (d >= a.D) break;
@@ -182,8 +204,8 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
         cplx p0 = mk(0, 0), p1 = mk(0, 0);
 #pragma unroll
         for (int i = 0; i < RS; ++i) { cfma(p0, z0[i], q[i]); cfma(p1, z1[i], q[i]); }
-        p0 = group_sum<64>(p0);
-        p1 = group_sum<64>(p1);
+        p0 = wave_sum(p0);
+        p1 = wave_sum(p1);
         const cplx t0 = unit_phase_times(h0, p0, nyq);
         const cplx t1 = unit_phase_times(h1, p1, nyq);
 #pragma unroll
@@ -196,7 +218,7 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
         h0 = hn0; h1 = hn1;
     }
     STAMP(6);
-    // ---- Z_k loads for this wave's channels go out before the cross-wave reduction of u
+    // ---- 4. Z_k loads for this wave's channels go out before the cross-wave reduction of u
     constexpr int NCW = SW_CMAX / (SW_NT / 64);  // channels per wave (4)
     const cplx* Zk = a.Z + (int64_t)kb * C * ldS;
     cplx zv[NCW][RS];
@@ -210,9 +232,9 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
         }
     }
     STAMP(7);
-    // deterministic cross-wave reduction of u: every wave stores its slab, one barrier, fixed-order sum
+    // deterministic cross-wave reduction of u: per-wave slabs, barrier, fixed-order column sums, barrier
     {
-        cplx* slab = us + (size_t)wave * 2 * ldS;
+        cplx* slab = big + (size_t)wave * 2 * ldS;
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             const int s = lane + 64 * i;
@@ -220,33 +242,36 @@ __global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int 
         }
     }
     __syncthreads();
+    for (int s = tid; s < S; s += SW_NT) {
+        cplx a0 = mk(0, 0), a1 = mk(0, 0);
+#pragma unroll
+        for (int w = 0; w < SW_NT / 64; ++w) {
+            a0 += big[(size_t)w * 2 * ldS + s];
+            a1 += big[(size_t)w * 2 * ldS + ldS + s];
+        }
+        zu[s] = a0;
+        zu[ldS + s] = a1;
+    }
+    __syncthreads();
     STAMP(8);
 #pragma unroll
     for (int i = 0; i < RS; ++i) {
         const int s = lane + 64 * i;
-        cplx a0 = mk(0, 0), a1 = mk(0, 0);
-        if (s < S) {
-#pragma unroll
-            for (int w = 0; w < SW_NT / 64; ++w) {
-                a0 += us[(size_t)w * 2 * ldS + s];
-                a1 += us[(size_t)w * 2 * ldS + ldS + s];
-            }
-        }
-        u0[i] = a0;
-        u1[i] = a1;
+        u0[i] = (s < S) ? zu[s] : mk(0, 0);
+        u1[i] = (s < S) ? zu[ldS + s] : mk(0, 0);
     }
-    // ---- partial W(k,:) = u Z_k
+    // ---- 5. partial W(k,:) = u Z_k
 #pragma unroll
     for (int j = 0; j < NCW; ++j) {
         const int c = wave + (SW_NT / 64) * j;
         cplx w0 = mk(0, 0), w1 = mk(0, 0);
 #pragma unroll
         for (int i = 0; i < RS; ++i) { cfma(w0, u0[i], zv[j][i]); cfma(w1, u1[i], zv[j][i]); }
-        w0 = group_sum<64>(w0);
-        w1 = group_sum<64>(w1);
+        w0 = wave_sum(w0);
+        w1 = wave_sum(w1);
         if (lane == 0 && c < C) {
-            Wout[((int64_t)0 * C + c) * a.nWG + blockIdx.x] = w0;
-            Wout[((int64_t)1 * C + c) * a.nWG + blockIdx.x] = w1;
+            Wout[((int64_t)0 * C + c) * nWG + blockIdx.x] = w0;
+            Wout[((int64_t)1 * C + c) * nWG + blockIdx.x] = w1;
         }
     }
     STAMP(9);
@@ -266,40 +291,95 @@ template <typename TX>
 __global__ void __launch_bounds__(DS_NT) sweep_dense_kernel(DenseSweepArgs a, int kb) {
     __shared__ __attribute__((aligned(16))) cplx Wp[64];
     __shared__ __attribute__((aligned(16))) cplx ts[2][DS_DPW];
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* stage = reinterpret_cast<cplx*>(dyn);  // [2C][nWG+1] partial sums of the previous launch
     const int tid = threadIdx.x;
-    const int C = a.C;
+    const int C = a.C, nWG = a.nWG;
     const bool nyq = (kb == a.P - 1);
-    const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * a.nWG * 2 * C;
-    cplx* Wout = a.Wpart + (int64_t)(kb & 1) * a.nWG * 2 * C;
-    gather_prev(Wp, Wprev, a.W, a.nWG, C, a.P, kb, kb == a.kfirst);
-    __syncthreads();
+    const bool first = (kb == a.kfirst);
+    const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * nWG * 2 * C;
+    cplx* Wout = a.Wpart + (int64_t)(kb & 1) * nWG * 2 * C;
     const TX* X = reinterpret_cast<const TX*>(a.X) + (int64_t)kb * a.x_stride;
     const TX* Zd = reinterpret_cast<const TX*>(a.Zd) + (int64_t)kb * a.z_stride;
     const int64_t d0 = (int64_t)blockIdx.x * DS_DPW;
     const int64_t na = a.P - a.kabs0;
-    if (tid < 2 * DS_DPW) {
-        const int e = tid / DS_DPW, dd = tid % DS_DPW;
-        const int64_t d = d0 + dd;
-        cplx t = mk(0, 0);
-        if (d < a.D) {
-            cplx p = mk(0, 0);
-            for (int c = 0; c < C; ++c) cfma(p, Wp[e * C + c], X[(int64_t)c * a.ldD + d]);
-            t = unit_phase_times(a.Habs[((int64_t)e * na + (kb - a.kabs0)) * a.ldH + d], p, nyq);
-        }
-        ts[e][dd] = t;
+    // ---- 0. every load of the launch goes out up front; the previous launch's partial sums first
+    //         (they gate the chain and memory returns in order), then this slab's operands
+    constexpr int NGV = 16;  // staged partials per thread: 2C*nWG <= 64*64
+    const int npart = 2 * C * nWG;
+    cplx gv[NGV];
+#pragma unroll
+    for (int i = 0; i < NGV; ++i) {
+        const int f = tid + DS_NT * i;
+        gv[i] = (!first && f < npart) ? Wprev[f] : mk(0, 0);
+    }
+    const int e_ = tid / DS_DPW, dd_ = tid % DS_DPW;       // phase-1 role: (ear, direction)
+    const int64_t d_ = d0 + dd_;
+    const bool p1 = tid < 2 * DS_DPW && d_ < a.D;
+    TX xr[SW_CMAX];
+#pragma unroll
+    for (int c = 0; c < SW_CMAX; ++c) xr[c] = (p1 && c < C) ? X[(int64_t)c * a.ldD + d_] : zero_of<TX>();
+    const double habs = p1 ? a.Habs[((int64_t)e_ * na + (kb - a.kabs0)) * a.ldH + d_] : 0.0;
+    const int pair2 = tid >> 2, part2 = tid & 3;             // phase-2 role: (ear, channel) x 4 lanes
+    constexpr int NZ = DS_DPW / 4;
+    TX zr[NZ];
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) {
+        const int64_t d = d0 + part2 + 4 * j;
+        zr[j] = (pair2 < 2 * C && d < a.D) ? Zd[(int64_t)(pair2 % C) * a.ldD + d] : zero_of<TX>();
+    }
+    // ---- 1. W(k-1) = sum of the staged partials
+#pragma unroll
+    for (int i = 0; i < NGV; ++i) {
+        const int f = tid + DS_NT * i;
+        if (f < npart) stage[f + f / nWG] = gv[i];
     }
     __syncthreads();
-    // partial W(k,:)[e][c] = sum_{d in slab} t[e][d] Zd[c][d] ; 4 lanes per (e,c)
-    const int pair = tid >> 2, part = tid & 3;
-    if (pair < 2 * C) {
+    for (int pair = tid >> 2; pair < 2 * C; pair += DS_NT >> 2) {
+        const int part = tid & 3;
         const int e = pair / C, c = pair % C;
         cplx acc = mk(0, 0);
-        for (int dd = part; dd < DS_DPW; dd += 4) {
-            const int64_t d = d0 + dd;
-            if (d < a.D) cfma(acc, ts[e][dd], Zd[(int64_t)c * a.ldD + d]);
+        if (first) {
+            if (part == 0) acc = a.W[((int64_t)e * a.P + (kb - 1)) * C + c];
+        } else {
+            const cplx* row = stage + (size_t)pair * (nWG + 1);
+            cplx a0 = mk(0, 0), a1 = mk(0, 0);
+            for (int w = part; w < nWG; w += 8) {
+                a0 += row[w];
+                if (w + 4 < nWG) a1 += row[w + 4];
+            }
+            acc = a0 + a1;
         }
         acc = group_sum<4>(acc);
-        if (part == 0) Wout[((int64_t)e * C + c) * a.nWG + blockIdx.x] = acc;
+        if (part == 0) {
+            Wp[pair] = acc;
+            if (blockIdx.x == 0 && !first) a.W[((int64_t)e * a.P + (kb - 1)) * C + c] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- 2. p = W(k-1) pwGrid ;  t = |H| p/|p|
+    if (tid < 2 * DS_DPW) {
+        cplx t = mk(0, 0);
+        if (p1) {
+            cplx pa = mk(0, 0), pb = mk(0, 0);
+#pragma unroll
+            for (int c = 0; c < SW_CMAX; c += 2) {
+                if (c < C) cfma(pa, Wp[e_ * C + c], xr[c]);
+                if (c + 1 < C) cfma(pb, Wp[e_ * C + c + 1], xr[c + 1]);
+            }
+            t = unit_phase_times(habs, pa + pb, nyq);
+        }
+        ts[e_][dd_] = t;
+    }
+    __syncthreads();
+    // ---- 3. partial W(k,:)[e][c] = sum_{d in slab} t[e][d] Y_reg_inv[d][c] ; 4 lanes per (e,c)
+    if (pair2 < 2 * C) {
+        const int e = pair2 / C, c = pair2 % C;
+        cplx acc = mk(0, 0);
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) cfma(acc, ts[e][part2 + 4 * j], zr[j]);
+        acc = group_sum<4>(acc);
+        if (part2 == 0) Wout[((int64_t)e * C + c) * nWG + blockIdx.x] = acc;
     }
 }
 
@@ -412,7 +492,7 @@ __global__ void widen_kernel(const T* __restrict__ in, int64_t ldi, cplx* __rest
 // ---------------------------------------------------------------------------------------------
 template <typename TQ>
 static void sweep_factored_dispatch(const SweepArgs& a, int kb, hipStream_t st) {
-    const size_t dyn = (size_t)(2 + 2 * (SW_NT / 64)) * a.ldS * sizeof(cplx);
+    const size_t dyn = sweep_lds_elems(a.ldS, a.C, a.nWG) * sizeof(cplx);
     if (dyn > 150 * 1024) throw Error(2, "sweep: SH channel count too large for the LDS-resident reduction");
     const int rs = (a.S + 63) / 64;
 #define EMAGLS_SWEEP_CASE(R)                                                                         \
@@ -443,8 +523,10 @@ void launch_sweep_factored(const SweepArgs& a, int kb, bool q_cplx, hipStream_t 
 }
 
 void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st) {
-    if (x_cplx) sweep_dense_kernel<cplx><<<a.nWG, DS_NT, 0, st>>>(a, kb);
-    else sweep_dense_kernel<double><<<a.nWG, DS_NT, 0, st>>>(a, kb);
+    if (2 * a.C * a.nWG > 16 * DS_NT) throw Error(2, "dense sweep: too many workgroup partials");
+    const size_t dyn = sizeof(cplx) * (size_t)2 * a.C * (a.nWG + 1);
+    if (x_cplx) sweep_dense_kernel<cplx><<<a.nWG, DS_NT, dyn, st>>>(a, kb);
+    else sweep_dense_kernel<double><<<a.nWG, DS_NT, dyn, st>>>(a, kb);
     KERNEL_CHECK();
 }
 int dense_sweep_nwg(int D) { return (D + DS_DPW - 1) / DS_DPW; }

@@ -18,4 +18,5 @@ for k in ks:
 tot=(t[60:500,9]-t[60:500,0]); wall=(t[60:500,14]-t[60:500,15])
 print('mean cycles', tot.mean(), 'mean wall us', wall.mean()/100.0, '=> clock GHz', tot.mean()/ (wall.mean()/100.0)/1e3)
 print('mean phases', np.diff(t[60:500,:10],axis=1).mean(axis=0).round(0).tolist())
+m=t[60:500]; print('gather loads', (m[:,10]-m[:,0]).mean(), 'B loads', (m[:,11]-m[:,10]).mean(), 'q loads', (m[:,12]-m[:,11]).mean())
 print('launch-to-launch wall us', np.diff(t[60:500,15]).mean()/100.0)

@@ -122,24 +122,42 @@ def test_stage_prologue(emagls_plan):
 
 
 def test_stage_factor_and_sweep(emagls_plan, grids):
-    """Z_k against LAPACK on the SAME B_k, singular values, Jacobi sweep counts, and the final
-    filters against the oracle."""
+    """Per-bin factors against LAPACK on the SAME B_k: singular values, Jacobi sweep counts, the
+    S-space inverse Z_k of the least-squares bins, the direction-space operands G_k / Yri_k of the swept
+    bins, and the final filters against the oracle."""
     p = emagls_plan["p"]
     S, C, ldS = 400, 25, 448
+    D = emagls_plan["hL"].shape[1]
+    ldD = -(-D // 64) * 64
     i = p.info()
     P, kcut0 = i.num_pos_freqs, i.k_cut - 1
-    Bk = p.debug("Bk", np.complex128).reshape(P, C, ldS)[:, :, :S]
+    Tn = p.debug("Tn", np.complex128, (20, C, ldS))[:, :, :S]
+    bn = p.debug("bn", np.complex128, (P, 20))
+    Q = p.debug("Q", np.complex128, (D, ldS))[:, :S]
     Z = p.debug("Z", np.complex128).reshape(P, C, ldS)[:, :, :S]
     sv = p.debug("sv", np.float64).reshape(P, C)
     js = p.debug("jsweeps", np.int32)
-    assert js[1:P].max() <= 20, js[1:P].max()
-    for kb in (kcut0, kcut0 + 1, P // 2, P - 1):
-        B = Bk[kb].T  # S x C
+    assert 1 <= js[1:P].min() and js[1:P].max() <= 20, (js[1:P].min(), js[1:P].max())
+    G = p.debug("G", np.complex128).reshape(-1, C, ldD)[:, :, :D]
+    Yri = p.debug("Yri", np.complex128).reshape(-1, C, ldD)[:, :, :D]
+
+    def Bk(kb):
+        b = bn[kb].copy()
+        if kb == P - 1:
+            b = b.real
+        return np.tensordot(b, Tn, axes=(0, 0)).T  # S x C
+
+    for kb in (1, 2, kcut0 - 1, kcut0, kcut0 + 1, P // 2, P - 1):
+        B = Bk(kb)
         U, s, Vh = np.linalg.svd(B, full_matrices=False)
         assert np.abs(np.sort(sv[kb])[::-1] - s).max() < 1e-13 * s[0]
         sreg = 1 / np.maximum(s, 0.01 * s[0])
         Zo = np.conj(U) @ (sreg[:, None] * Vh.conj())
-        assert rel(Z[kb].T, Zo) < 1e-9, (kb, rel(Z[kb].T, Zo))
+        assert rel(Z[kb].T, Zo) < 1e-8, (kb, rel(Z[kb].T, Zo))
+        if kb >= kcut0:
+            X = Q @ B  # pwGrid.'  (D x C)
+            assert rel(G[kb - kcut0].T, X) < 1e-12
+            assert rel(Yri[kb - kcut0].T, np.conj(Q) @ Zo) < 1e-9, (kb, rel(Yri[kb - kcut0].T, np.conj(Q) @ Zo))
     wL, wR = p.get_filters()
     oL, oR = O.getEMagLsFilters(emagls_plan["hL"], emagls_plan["hR"], emagls_plan["azi"], emagls_plan["zen"],
                                 grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "complex")
