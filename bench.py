@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- eMagLS filter-design throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--concurrent J]
 
 One "step" = one complete filter-set design (both ears, all channels) of BASELINE.json config 3:
 getEMagLsFilters, em32 (32 mics, r = 4.2 cm), N = 4, complex SH, 2702 HRIR directions, 512 taps,
 48 kHz -- from the angles and HRIRs resident in HBM to the windowed time-domain filters in HBM.
 Every rank designs its own filter sets (independent jobs, weak scaling); the only collective is
-one RCCL gather of the finished filters to rank 0 inside the timed region.
+one RCCL gather of the finished filters to rank 0 inside the timed region.  With --concurrent J
+each rank keeps J independent designs (different HRIR sets) in flight on J HIP streams.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the per-bin sweep kernel);
 `cpu_baseline` times the NumPy oracle on this host on a bounded sample of the same workload.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -61,7 +63,8 @@ def cpu_baseline(azi, zen, maz, mzn, hL, hR, nbins_sample=48):
         Ps = nbins_sample + 1
         Wl, Wr = O._emagls_core(HL, HR, lambda k: smair[:, :, k - 1] @ Yh, Ps, k_cut, 25)
         t2 = time.perf_counter()
-        Wl_full = np.zeros((P, 25), complex); Wl_full[:Ps] = Wl
+        Wl_full = np.zeros((P, 25), complex)
+        Wl_full[:Ps] = Wl
         O._finish(Wl_full, Wl_full, P, nfft, length, False, nfft // 2, nfft // 2 + gR - gL)
         t3 = time.perf_counter()
         return (t1 - t0) + (t3 - t2) + (t2 - t1) * (P - 1) / nbins_sample
@@ -75,47 +78,54 @@ def cpu_baseline(azi, zen, maz, mzn, hL, hR, nbins_sample=48):
     ncores = os.cpu_count() or 1
     best, cores = (t_1, 1) if t_1 <= t_all else (t_all, ncores)
     return {"value": 1.0 / best, "unit": "filter sets/s", "cores": cores, "kind": "port",
-            "sample": "NumPy oracle, config 3: SH/modal/HRIR prologue + epilogue in full, per-bin SVD loop on %d of 512 "
-                      "bins (2..%d, straddling k_cut=43) scaled x%.2f; 1 thread %.2f s/set, %d threads %.2f s/set"
-                      % (nbins_sample, nbins_sample + 1, 512.0 / nbins_sample, t_1, ncores, t_all)}
+            "sample": "NumPy oracle (CPU restatement of the MATLAB path, not MATLAB), config 3: SH/modal/HRIR prologue + "
+                      "epilogue in full, per-bin SVD loop on %d of 512 bins (2..%d, straddling k_cut=43) scaled x%.2f; "
+                      "1 thread %.2f s/set, %d threads %.2f s/set" % (nbins_sample, nbins_sample + 1, 512.0 / nbins_sample,
+                                                                   t_1, ncores, t_all)}
 
 
-def sh_basis_roofline(lib_mod):
-    """SH-basis assembly on a launch big enough to be bandwidth bound (D = 2^20, N = 19, real: 3.36 GB)."""
-    import ctypes as C
+def sh_basis_roofline(lib):
+    """SH-basis assembly on a launch big enough to be bandwidth bound: D = 2^20 directions, N = 19, real
+    basis -> 8*D*S = 3.36 GB written, 16*D bytes read.  Kernel time from HIP events on the
+    default stream, inputs and output resident in HBM."""
     import torch
+    from emagls_amd import synth
     D, N = 1 << 20, 19
     S = (N + 1) ** 2
-    from emagls_amd import synth
     azi, zen = synth.fibonacci_grid(D)
     t_azi = torch.from_numpy(azi).cuda()
     t_zen = torch.from_numpy(zen).cuda()
     out = torch.empty((S, D), dtype=torch.float64, device="cuda")
-    lib = lib_mod.load()
-    # emagls_sh_basis accepts device pointers; it allocates a staging copy, so time only the kernel via events
-    # around a second call path: use the plan-free entry point twice and take the steady-state one.
+    st = torch.cuda.current_stream().cuda_stream
+    call = lambda: lib.emagls_sh_basis_device(N, D, C.c_void_p(t_azi.data_ptr()), C.c_void_p(t_zen.data_ptr()), 0,
+                                              C.c_void_p(out.data_ptr()), C.c_void_p(st))
+    if call() != 0:
+        return None
+    torch.cuda.synchronize()
     best = None
-    for _ in range(3):
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call()
+        e1.record()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        rc = lib.emagls_sh_basis(N, D, C.c_void_p(t_azi.data_ptr()), C.c_void_p(t_zen.data_ptr()), 0,
-                                 C.c_void_p(out.data_ptr()))
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if rc != 0:
-            return None
-        best = dt if best is None else min(best, dt)
-    return {"note": "end-to-end call incl. staging copies (kernel-only number: profiles/)", "bytes": 8.0 * D * S,
-            "seconds": best, "GB/s": 8.0 * D * S / best / 1e9}
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    nbytes = 8.0 * D * S + 16.0 * D
+    ach = nbytes / (best * 1e-3) / 1e9
+    return {"kernel": "sh_basis_kernel<real>", "bound": "hbm", "dirs": D, "order": N, "algorithmic_bytes": nbytes,
+            "ms": best, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--concurrent", type=int, default=int(os.environ.get("EMAGLS_BENCH_CONCURRENT", "4")),
+                    help="independent designs in flight per GPU (steps are processed in groups of this size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-level", type=int, default=2)
+    ap.add_argument("--no-sh-roofline", action="store_true")
     args = ap.parse_args()
 
     import torch  # first: the library then shares torch's HIP runtime (same SONAME libamdhip64.so.7)
@@ -131,15 +141,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from emagls_amd import Plan, _lib as L
-    L.check(L.load().emagls_set_device(local_rank))
-    azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=rank)
-    plan = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 512, hL.shape[0], hL.shape[1], 0.042, 32)
-    plan.set_hrir_grid(azi, zen)
-    plan.set_mic_grid(maz, mzn)
-    plan.set_hrirs(hL, hR)
-    info = plan.info()
+    lib = L.load()
+    L.check(lib.emagls_set_device(local_rank))
+    J = max(1, args.concurrent)
     K, W = args.steps, args.warmup
-    import ctypes as C
+    plans, inputs = [], None
+    for j in range(J):
+        azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=rank * 100 + j)
+        if inputs is None:
+            inputs = (azi, zen, maz, mzn, hL, hR)
+        p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 512, hL.shape[0], hL.shape[1], 0.042, 32)
+        p.set_hrir_grid(azi, zen)
+        p.set_mic_grid(maz, mzn)
+        p.set_hrirs(hL, hR)
+        plans.append(p)
+    info = plans[0].info()
     out = torch.zeros((K, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")  # complex as (re,im)
     gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
 
@@ -148,72 +164,95 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(W):
-        plan.execute()
-    plan.synchronize()
+    def run_steps(nsteps, store):
+        s = 0
+        while s < nsteps:
+            g = min(J, nsteps - s)
+            for j in range(g):
+                plans[j].execute()
+            for j in range(g):
+                if store:
+                    L.check(lib.emagls_plan_get_filters(plans[j]._h, C.c_void_p(out[s + j, 0].data_ptr()),
+                                                        C.c_void_p(out[s + j, 1].data_ptr())))
+                else:
+                    plans[j].synchronize()
+            s += g
+
+    run_steps(max(W, 2 * J), False)  # first execute of a plan is eager, the second captures the hipGraph
     if world > 1:  # warm the collective too
         dist.gather(out, gathered, dst=0)
+    # ---- latency of ONE design with nothing else in flight (not the headline: that is the throughput below)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        plans[0].execute()
+        plans[0].synchronize()
+    single_ms = (time.perf_counter() - t0) / 8 * 1e3
     # ---- timed region: K designs + one gather (hipGraph replay of the captured design, no profiling hooks)
-    plan.set_profiling(0)
     barrier()
     t0 = time.perf_counter()
-    for s in range(K):
-        plan.execute()
-        L.check(plan._lib.emagls_plan_get_filters(plan._h, C.c_void_p(out[s, 0].data_ptr()), C.c_void_p(out[s, 1].data_ptr())))
+    run_steps(K, True)
     if world > 1:
         dist.gather(out, gathered, dst=0)
     barrier()
     dt = time.perf_counter() - t0
-    plan.set_profiling(1)  # eager pass with HIP events between stages (includes host launch gaps)
-    plan.execute()
-    plan.synchronize()
-    stages = plan.stage_times()
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # ---- per-launch duration of the dominant kernel (HIP events on the plan's stream), separate pass
-    plan.set_profiling(args.profile_level)
-    plan.execute()
-    plan.synchronize()
-    sweep_ms, sweep_n = plan.sweep_kernel_time()
-    stages2 = plan.stage_times()
-    plan.set_profiling(0)
+    # ---- separate eager passes with HIP events on the plan's stream: per-stage times (level 1) and the
+    #      per-launch duration of the dominant kernel (level 2)
+    p0 = plans[0]
+    p0.set_profiling(1)
+    p0.execute()
+    p0.synchronize()
+    stages = p0.stage_times()
+    p0.set_profiling(2)
+    p0.execute()
+    p0.synchronize()
+    sweep_ms, sweep_n = p0.sweep_kernel_time()
+    p0.set_profiling(0)
 
     if rank == 0:
-        D, S, Cc = hL.shape[1], info.num_sh_sim, info.num_channels
-        # algorithmic bytes one sweep launch must touch: Q (D x S complex) + B_k + Z_k (2 x C x S complex)
-        # + |H| rows (2 x D) + partial W in/out
-        bytes_launch = 16.0 * D * S + 2 * 16.0 * Cc * S + 2 * 8.0 * D + 2 * 128 * 2 * Cc * 16.0
+        D, Cc = inputs[4].shape[1], info.num_channels
+        # algorithmic bytes of one sweep launch (one frequency bin, both ears): the bin's pwGrid and Y_reg_inv
+        # (D x C complex each), |H| of both ears, W(k-1) in and W(k) out
+        bytes_launch = 2 * 16.0 * D * Cc + 2 * 8.0 * D + 2 * 2 * Cc * 16.0
         roof = None
         if sweep_n > 0:
             avg_s = sweep_ms / sweep_n * 1e-3
             ach = bytes_launch / avg_s / 1e9
-            roof = {"kernel": "sweep_factored_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"kernel": "sweep_dense_kernel<cplx>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches_per_step": sweep_n,
                     "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": bytes_launch,
-                    "note": "operands are L2/Infinity-Cache resident by design (17.7 MB working set); the launch is "
-                            "latency bound, see DESIGN.md"}
+                    "note": "sequential recurrence: one launch per frequency bin, 2.2 MB of operands per launch; every "
+                            "launch starts with cold L2 (kernel boundaries invalidate it), so it is bound by L2-miss "
+                            "latency and per-CU miss bandwidth, not by HBM bandwidth -- see DESIGN.md section 5"}
         res = {
             "metric": "eMagLS filter sets/s (N=4, 2702 dirs, 512 taps)", "value": world * K / dt, "unit": "filter sets/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: getEMagLsFilters em32 r=4.2cm N=4 complex-SH, 2702 dirs, 512 taps, "
-                                   "48 kHz; one filter set per step per GPU, inputs resident in HBM",
+                                   "48 kHz; one filter set per step, inputs resident in HBM",
                        "dirs": int(D), "taps": 512, "sim_order": info.sim_order, "bins": info.num_pos_freqs - 1,
-                       "k_cut": info.k_cut, "parallelism": "independent jobs per GPU, one RCCL gather"},
+                       "k_cut": info.k_cut, "designs_in_flight_per_gpu": J,
+                       "parallelism": "independent jobs per GPU, one RCCL gather"},
             "roofline": roof,
+            "single_design_latency_ms": round(single_ms, 4),
             "stages_ms": {k: round(v, 4) for k, v in stages},
-            "stages_ms_profiled_pass": {k: round(v, 4) for k, v in stages2},
         }
+        if not args.no_sh_roofline and world == 1:
+            try:
+                res["sh_basis_roofline"] = sh_basis_roofline(lib)
+            except Exception as e:  # the large launch needs ~3.5 GB; never fail the bench on it
+                res["sh_basis_roofline"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(azi, zen, maz, mzn, hL, hR)
+            res["cpu_baseline"] = cpu_baseline(*inputs)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
-            # accuracy half of the metric: GPU result of this run vs the oracle would take minutes at full size;
-            # the parity tests report it (tests/test_gpu_parity.py::test_emagls_filters_config3_full)
         print(json.dumps(res))
-    plan.close()
+    for p in plans:
+        p.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -36,6 +36,7 @@ SYMBOLS = {
     "emagls_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "emagls_set_device": (C.c_int, [C.c_int]),
     "emagls_sh_basis": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "emagls_sh_basis_device": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "emagls_modal_bn": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p]),
     "emagls_get_ls_filters": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p]),

@@ -671,6 +671,25 @@ int emagls_sh_basis(int order, int64_t ndirs, const double* azi, const double* z
     });
 }
 
+int emagls_sh_basis_device(int order, int64_t ndirs, const double* d_azi, const double* d_zen, int basis, void* d_Y,
+                           void* stream) {
+    return guarded([&] {
+        if (order < 0 || ndirs < 0 || !d_azi || !d_zen || !d_Y) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        if (ndirs == 0) return;
+        // the recurrence table is tiny and depends only on the order: cached per (thread, order)
+        thread_local int tab_order = -1;
+        thread_local double* tab = nullptr;
+        hipStream_t st = (hipStream_t)stream;
+        if (tab_order != order) {
+            if (tab) { HIP_CHECK(hipFree(tab)); tab = nullptr; }
+            HIP_CHECK(hipMalloc(&tab, sizeof(double) * sh_coeff_count(order)));
+            tab_order = order;
+            launch_sh_coeff(order, tab, st);
+        }
+        launch_sh_basis(order, ndirs, d_azi, d_zen, tab, basis == EMAGLS_BASIS_COMPLEX, d_Y, ndirs, st);
+    });
+}
+
 int emagls_modal_bn(int order, int64_t nfreq, const double* kr, void* bn) {
     return guarded([&] {
         if (order < 0 || nfreq < 0 || !kr || !bn) throw Error(EMAGLS_ERR_ARG, "invalid argument");

@@ -59,6 +59,12 @@ int emagls_set_device(int device);
 /* Y [ndirs x (order+1)^2], column-major; real (8 B) or interleaved complex (16 B) per entry. */
 int emagls_sh_basis(int order, int64_t ndirs, const double* azi, const double* zen, int basis, void* Y);
 
+/* Same kernel on buffers that are already in HBM, enqueued on `stream` (a hipStream_t, NULL = default
+ * stream) without any staging copy or synchronisation: used for the bandwidth measurement of the
+ * SH-basis assembly and by callers that keep their data on the device. */
+int emagls_sh_basis_device(int order, int64_t ndirs, const double* d_azi, const double* d_zen, int basis, void* d_Y,
+                           void* stream);
+
 /* bn [nfreq x (order+1)] interleaved complex, column-major: rigid-sphere modal coefficients b_n(kr). */
 int emagls_modal_bn(int order, int64_t nfreq, const double* kr, void* bn);
 

@@ -1,0 +1,75 @@
+"""The N > 1 path on CPU: job sharding and the single gather, world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from emagls_amd.batch import run_batch, shard_jobs
+
+
+def _design(job):
+    """Stand-in for a filter design (the HIP library needs a GPU): deterministic in the job parameters."""
+    r, cplx = job
+    rng = np.random.default_rng(int(r * 1e6))
+    w = rng.standard_normal((16, 5))
+    if cplx:
+        w = w + 1j * rng.standard_normal((16, 5))
+    return w, -w
+
+
+def _worker(rank, world, port, cplx, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    radii = np.linspace(0.02, 0.10, 7)
+    jobs = [(float(r), cplx) for r in radii]
+    costs = [(max(4, int(np.ceil(439.6 * r))) + 1) ** 2 for r in radii]  # (simOrder+1)^2 at 48 kHz
+    out = run_batch(jobs, _design, costs)
+    if rank == 0:
+        ok = all(np.array_equal(out[j][0], _design(jobs[j])[0]) and np.array_equal(out[j][1], _design(jobs[j])[1])
+                 for j in range(len(jobs)))
+        q.put(("ok" if ok else "mismatch", len(out)))
+    else:
+        assert out is None
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_two_ranks_gather(cplx):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cplx, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == ("ok", 7)
+
+
+def test_shard_jobs_balanced():
+    costs = [(n + 1) ** 2 for n in range(9, 45)]
+    shards = shard_jobs(costs, 8)
+    assert sorted(j for s in shards for j in s) == list(range(len(costs)))
+    loads = [sum(costs[j] for j in s) for s in shards]
+    assert max(loads) / min(loads) < 1.15
+    assert shard_jobs([1.0] * 5, 8)[5:] == [[], [], []]
+
+
+def test_single_process_batch():
+    jobs = [(0.03, False), (0.05, False)]
+    out = run_batch(jobs, _design)
+    assert len(out) == 2 and np.array_equal(out[1][0], _design(jobs[1])[0])
