@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--concurrent", type=int, default=int(os.environ.get("EMAGLS_BENCH_CONCURRENT", "4")),
                     help="independent designs in flight per GPU (steps are processed in groups of this size)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", "4")),
+                    help="designs per batch: the sequential sweep is launched once per bin for the whole batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sh-roofline", action="store_true")
     args = ap.parse_args()
@@ -140,22 +142,53 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from emagls_amd import Plan, _lib as L
+    from emagls_amd import Batch, Plan, _lib as L
     lib = L.load()
     L.check(lib.emagls_set_device(local_rank))
     J = max(1, args.concurrent)
+    Bsz = max(1, min(args.batch, J, 8))
+    nbatch = max(1, J // Bsz)
+    J = nbatch * Bsz
     K, W = args.steps, args.warmup
-    plans, inputs = [], None
-    for j in range(J):
-        azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=rank * 100 + j)
-        if inputs is None:
-            inputs = (azi, zen, maz, mzn, hL, hR)
+
+    def make_plan(seed_offset, streams=1):
+        azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=seed_offset)
         p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 512, hL.shape[0], hL.shape[1], 0.042, 32)
+        p.set_streams(streams)
         p.set_hrir_grid(azi, zen)
         p.set_mic_grid(maz, mzn)
         p.set_hrirs(hL, hR)
-        plans.append(p)
-    info = plans[0].info()
+        return p, (azi, zen, maz, mzn, hL, hR)
+
+    # ---- latency of ONE design with nothing else in flight (3 streams: independent branches fork)
+    p0, inputs = make_plan(rank * 100, streams=3)
+    for _ in range(3):
+        p0.execute()
+    p0.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        p0.execute()
+        p0.synchronize()
+    single_ms = (time.perf_counter() - t0) / 8 * 1e3
+    # per-stage times and the per-launch duration of the dominant kernel: eager passes with HIP events
+    p0.set_streams(1)
+    p0.set_profiling(1)
+    p0.execute()
+    p0.synchronize()
+    stages = p0.stage_times()
+    p0.set_profiling(2)
+    p0.execute()
+    p0.synchronize()
+    sweep_ms, sweep_n = p0.sweep_kernel_time()
+    info = p0.info()
+    p0.close()
+
+    # ---- throughput: nbatch batches of Bsz designs each, every batch on its own stream / hardware queue
+    plans, batches = [], []
+    for b in range(nbatch):
+        ps = [make_plan(rank * 100 + b * Bsz + j)[0] for j in range(Bsz)]
+        plans.append(ps)
+        batches.append(Batch(ps) if Bsz > 1 else None)
     out = torch.zeros((K, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")  # complex as (re,im)
     gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
 
@@ -167,28 +200,30 @@ def main():
     def run_steps(nsteps, store):
         s = 0
         while s < nsteps:
-            g = min(J, nsteps - s)
-            for j in range(g):
-                plans[j].execute()
-            for j in range(g):
-                if store:
-                    L.check(lib.emagls_plan_get_filters(plans[j]._h, C.c_void_p(out[s + j, 0].data_ptr()),
-                                                        C.c_void_p(out[s + j, 1].data_ptr())))
+            started = []
+            for b in range(nbatch):
+                if s + len(started) * Bsz >= nsteps:
+                    break
+                if batches[b] is not None:
+                    batches[b].execute()
                 else:
-                    plans[j].synchronize()
-            s += g
+                    plans[b][0].execute()
+                started.append(b)
+            for b in started:
+                for j, p in enumerate(plans[b]):
+                    if s < nsteps and store:
+                        L.check(lib.emagls_plan_get_filters(p._h, C.c_void_p(out[s, 0].data_ptr()),
+                                                            C.c_void_p(out[s, 1].data_ptr())))
+                    elif batches[b] is not None:
+                        batches[b].synchronize()
+                    else:
+                        p.synchronize()
+                    s += 1
 
-    run_steps(max(W, 2 * J), False)  # first execute of a plan is eager, the second captures the hipGraph
+    run_steps(3 * J, False)  # first execute is eager, the second captures the hipGraph, the third replays it
     if world > 1:  # warm the collective too
         dist.gather(out, gathered, dst=0)
-    # ---- latency of ONE design with nothing else in flight (not the headline: that is the throughput below)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(8):
-        plans[0].execute()
-        plans[0].synchronize()
-    single_ms = (time.perf_counter() - t0) / 8 * 1e3
-    # ---- timed region: K designs + one gather (hipGraph replay of the captured design, no profiling hooks)
+    # ---- timed region: K designs + one gather (hipGraph replays, no profiling hooks)
     barrier()
     t0 = time.perf_counter()
     run_steps(K, True)
@@ -200,19 +235,6 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-
-    # ---- separate eager passes with HIP events on the plan's stream: per-stage times (level 1) and the
-    #      per-launch duration of the dominant kernel (level 2)
-    p0 = plans[0]
-    p0.set_profiling(1)
-    p0.execute()
-    p0.synchronize()
-    stages = p0.stage_times()
-    p0.set_profiling(2)
-    p0.execute()
-    p0.synchronize()
-    sweep_ms, sweep_n = p0.sweep_kernel_time()
-    p0.set_profiling(0)
 
     if rank == 0:
         D, Cc = inputs[4].shape[1], info.num_channels
@@ -236,7 +258,7 @@ def main():
             "config": {"workload": "BASELINE config 3: getEMagLsFilters em32 r=4.2cm N=4 complex-SH, 2702 dirs, 512 taps, "
                                    "48 kHz; one filter set per step, inputs resident in HBM",
                        "dirs": int(D), "taps": 512, "sim_order": info.sim_order, "bins": info.num_pos_freqs - 1,
-                       "k_cut": info.k_cut, "designs_in_flight_per_gpu": J,
+                       "k_cut": info.k_cut, "designs_in_flight_per_gpu": J, "designs_per_batch": Bsz, "batches_in_flight": nbatch,
                        "parallelism": "independent jobs per GPU, one RCCL gather"},
             "roofline": roof,
             "single_design_latency_ms": round(single_ms, 4),
@@ -251,8 +273,12 @@ def main():
             res["cpu_baseline"] = cpu_baseline(*inputs)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
-    for p in plans:
-        p.close()
+    for b in batches:
+        if b is not None:
+            b.close()
+    for ps in plans:
+        for p in ps:
+            p.close()
     if world > 1:
         dist.destroy_process_group()
 

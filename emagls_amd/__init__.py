@@ -6,7 +6,7 @@ Importing the package does not need a GPU; calling any function needs emagls_amd
 """
 from .api import (binauralDecode, getEMagLs2Filters, getEMagLsFilters, getEMagLsFiltersFromAtf, getLsFilters,
                   getMagLsFilters, getSH, sphModalCoeffs)
-from .plan import Plan
+from .plan import Batch, Plan
 
 __all__ = ["getLsFilters", "getMagLsFilters", "getEMagLsFilters", "getEMagLs2Filters", "getEMagLsFiltersFromAtf",
-           "binauralDecode", "getSH", "sphModalCoeffs", "Plan"]
+           "binauralDecode", "getSH", "sphModalCoeffs", "Plan", "Batch"]

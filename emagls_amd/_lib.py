@@ -64,12 +64,17 @@ SYMBOLS = {
     "emagls_plan_get_filters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "emagls_plan_get_info": (C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
     "emagls_plan_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "emagls_plan_set_streams": (C.c_int, [C.c_void_p, C.c_int]),
     "emagls_plan_num_stages": (C.c_int, [C.c_void_p]),
     "emagls_plan_stage_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "emagls_plan_stage_times": (C.c_int, [C.c_void_p, c_dp, C.c_int]),
     "emagls_plan_sweep_kernel_time": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
     "emagls_plan_debug_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_size_t)]),
     "emagls_plan_stream": (C.c_void_p, [C.c_void_p]),
+    "emagls_batch_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "emagls_batch_execute": (C.c_int, [C.c_void_p]),
+    "emagls_batch_synchronize": (C.c_int, [C.c_void_p]),
+    "emagls_batch_destroy": (C.c_int, [C.c_void_p]),
 }
 
 

@@ -72,4 +72,10 @@ struct DenseSweepArgs {
     int kfirst;
 };
 
+constexpr int SWEEP_MULTI_MAX = 8;
+struct DenseSweepMulti {
+    int n;
+    DenseSweepArgs a[SWEEP_MULTI_MAX];
+};
+
 }  // namespace emagls

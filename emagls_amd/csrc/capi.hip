@@ -45,7 +45,10 @@ struct emagls_plan {
     bool hrir_smaller = true;
     bool out_cplx = false;
     int64_t out_rows = 0, out_cols = 0;
-    int nWG = 0, dpw = 0, nWG_dense = 0;
+    int nWG = 0, dpw = 0, nWG_dense = 0, nWG_split = 0;
+    // two tiny kernels per bin (slab + reduce) instead of one with a redundant gather: slower for ONE design
+    // (two launch floors per bin), faster when a batch shares the launches; batches switch it on
+    bool sweep_split = false;
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
     // profiling
     int prof_level = 0;
@@ -60,14 +63,41 @@ struct emagls_plan {
     hipGraphExec_t graph_exec = nullptr;
     int eager_runs = 0;
     bool use_graph = true;
+    hipGraph_t pre_graph = nullptr;          // batches: stages before the sweep, captured on the plan's own stream
+    hipGraphExec_t pre_exec = nullptr;
     bool sweep_factored = false;  // legacy S-space sweep (kept for comparison)
+    int nstreams = 1;
+    hipStream_t sync_stream = nullptr;  // stream whose completion means this plan's results are ready
+    // fork/join inside one design: independent branches run on side streams (captured into the same graph)
+    hipStream_t side[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> sync_events;
+    size_t sync_used = 0;
+    hipEvent_t next_sync_event() {
+        if (sync_used == sync_events.size()) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            sync_events.push_back(e);
+        }
+        return sync_events[sync_used++];
+    }
+    // make `waiter` wait for everything enqueued so far on `signaller`
+    void depend(hipStream_t waiter, hipStream_t signaller) {
+        if (waiter == signaller) return;  // same stream: already ordered
+        hipEvent_t e = next_sync_event();
+        HIP_CHECK(hipEventRecord(e, signaller));
+        HIP_CHECK(hipStreamWaitEvent(waiter, e, 0));
+    }
 
     ~emagls_plan() {
         for (auto& kv : bufs) if (kv.second.p) hipFree(kv.second.p);
         for (auto e : stage_events) hipEventDestroy(e);
         for (auto e : sweep_events) hipEventDestroy(e);
+        for (auto e : sync_events) hipEventDestroy(e);
+        for (auto st : side) if (st) hipStreamDestroy(st);
         if (graph_exec) hipGraphExecDestroy(graph_exec);
         if (graph) hipGraphDestroy(graph);
+        if (pre_exec) hipGraphExecDestroy(pre_exec);
+        if (pre_graph) hipGraphDestroy(pre_graph);
         if (stream) hipStreamDestroy(stream);
     }
     void* alloc(const std::string& name, size_t bytes, bool zero = true) {
@@ -104,6 +134,37 @@ struct emagls_plan {
     }
 };
 
+struct emagls_batch {
+    std::vector<emagls_plan*> plans;
+    hipStream_t stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int eager_runs = 0;
+    bool use_graph = true;
+    std::vector<hipEvent_t> events;
+    size_t used = 0;
+    hipEvent_t next_event() {
+        if (used == events.size()) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            events.push_back(e);
+        }
+        return events[used++];
+    }
+    void depend(hipStream_t waiter, hipStream_t signaller) {
+        hipEvent_t e = next_event();
+        HIP_CHECK(hipEventRecord(e, signaller));
+        HIP_CHECK(hipStreamWaitEvent(waiter, e, 0));
+    }
+    ~emagls_batch() {
+        for (auto e : events) hipEventDestroy(e);
+        if (graph_exec) hipGraphExecDestroy(graph_exec);
+        if (graph) hipGraphDestroy(graph);
+        if (stream) hipStreamDestroy(stream);
+        for (auto* p : plans) p->sync_stream = nullptr;
+    }
+};
+
 namespace {
 
 size_t esz(bool c) { return c ? sizeof(cplx) : sizeof(double); }
@@ -124,6 +185,8 @@ void plan_setup(emagls_plan& p) {
     if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
     HIP_CHECK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     if (const char* ng = getenv("EMAGLS_NO_GRAPH")) p.use_graph = !(ng[0] == '1');
+    for (auto& st : p.side) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (const char* ns = getenv("EMAGLS_STREAMS")) p.nstreams = std::max(1, std::min(3, atoi(ns)));
     p.cplx_basis = d.basis == EMAGLS_BASIS_COMPLEX;
     p.D = d.ndirs;
     p.ldD = round_up(p.D, 64);
@@ -278,7 +341,10 @@ void plan_setup(emagls_plan& p) {
         p.alloc("W", sizeof(cplx) * (size_t)2 * p.P * p.C);
         if (d.kind == EMAGLS_KIND_MAGLS || d.kind == EMAGLS_KIND_FROM_ATF) p.nWG = dense_sweep_nwg((int)Dh);
         p.nWG_dense = dense_sweep_nwg((int)Dh);
-        p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(p.nWG, p.nWG_dense) * 2 * p.C);
+        p.nWG_split = slab_sweep_nwg((int)Dh);
+        if (const char* e = getenv("EMAGLS_SWEEP_SPLIT")) p.sweep_split = e[0] == '1';
+        if (p.nWG_split > 256 || 2 * p.C > 64) p.sweep_split = false;
+        p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(std::max(p.nWG, p.nWG_dense), p.nWG_split) * 2 * p.C);
         p.out_rows = d.len;
     }
     p.out_cols = p.C;
@@ -386,55 +452,127 @@ void execute_magls(emagls_plan& p) {
     p.mark("epilogue");
 }
 
-void execute_emagls(emagls_plan& p) {
-    hipStream_t st = p.stream;
+void emagls_pre_sweep(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     const bool cb = p.cplx_basis;
     const bool raw = d.kind == EMAGLS_KIND_EMAGLS2;
     const int M = (int)d.nmics;
     const int ldM = round_up(M, 64);
-    stage_hrir_basis(p);
-    // ---- array model: E = Y_mic (raw) or pinv(Y_mic(:,1:nOut)) Y_mic   (getSMAIRMatrix.m:101-102,119-121)
+    // side streams shorten one design's critical path; with several designs in flight they only add queue
+    // contention, so a plan can be restricted to its main stream (emagls_plan_set_streams / EMAGLS_STREAMS=1)
+    hipStream_t s0 = p.stream, s1 = p.nstreams >= 2 ? p.side[0] : s0, s2 = p.nstreams >= 3 ? p.side[1] : s0;
+    const int nOrd = p.simOrder + 1;
+    const int ls_end = std::min(p.kcut0, p.P);
+    const int k0 = std::max(p.kcut0, 1);
+    p.sync_used = 0;
+
+    // ---- fork: three independent branches
+    launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), s0);
+    p.depend(s1, s0);
+    p.depend(s2, s0);
+
+    // s1: array model  E = Y_mic (raw) or pinv(Y_mic(:,1:nOut)) Y_mic   (getSMAIRMatrix.m:101-102,119-121), b_n(kr)
     launch_sh_basis(p.simOrder, M, p.get<double>("mic_azi"), p.get<double>("mic_zen"), p.get<double>("sh_tab"), cb,
-                    p.get("Ymic_cm"), M, st);
-    launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("Ymic_rm"), M, p.ldS, cb, false, st);
+                    p.get("Ymic_cm"), M, s1);
+    launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("Ymic_rm"), M, p.ldS, cb, false, s1);
     if (raw) {
-        HIP_CHECK(hipMemcpyAsync(p.get("E"), p.get("Ymic_rm"), esz(cb) * (size_t)M * p.ldS, hipMemcpyDeviceToDevice, st));
+        launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("E"), M, p.ldS, cb, false, s1);  // E = Y_mic
     } else {
-        // Y_Lo^T as complex [c][m]: the first nOut rows of the column-major SH matrix
-        launch_widen(p.get("Ymic_cm"), M, cb, p.get("Ylo_c"), ldM, p.nOut, M, false, false, st);
+        launch_widen(p.get("Ymic_cm"), M, cb, p.get("Ylo_c"), ldM, p.nOut, M, false, false, s1);
         FactorArgs a{};
         a.S = M; a.C = p.nOut; a.ldS = ldM; a.kb0 = 0; a.P = 2;
         a.Xd = p.get<cplx>("Ylo_c"); a.xd_stride = 0;
         a.reg_mode = 1; a.tol_dim = (double)std::max(M, p.nOut);
         a.Z = p.get<cplx>("Zlo"); a.Vws = p.get<cplx>("Vlo");
         a.tauw = p.get<double>("tau_lo"); a.R2w = p.get<cplx>("R2_lo"); a.Nw = p.get<cplx>("N_lo");
-        launch_factor(a, 1, true, st);
-        // E[c][s] = sum_m pinv[c][m] Y_mic[m][s],  pinv[c][m] = Zlo[c][m]
-        launch_small_gemm(p.get("Zlo"), ldM, true, p.get("Ymic_rm"), p.ldS, cb, p.get("E"), p.ldS, cb, p.nOut, p.S, M, st);
+        launch_factor(a, 1, true, s1);
+        launch_small_gemm(p.get("Zlo"), ldM, true, p.get("Ymic_rm"), p.ldS, cb, p.get("E"), p.ldS, cb, p.nOut, p.S, M, s1);
     }
-    // ---- modal coefficients  bnAll = -sphModalCoeffs(simOrder, kr, 'rigid')   (getSMAIRMatrix.m:107)
-    launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), p.simOrder + 1, 1, st);
-    launch_tn(p.get("R"), p.get("E"), p.S, p.C, p.ldS, p.simOrder + 1, cb, p.get("Tn"), p.ldS, st);
-    p.mark("array_model");
-    stage_prologue(p, 0, nullptr, p.D);
-    const int ls_end = std::min(p.kcut0, p.P);
-    launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Q"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, st);
-    p.mark("ls_rhs");
+    // bnAll = -sphModalCoeffs(simOrder, kr, 'rigid')   (getSMAIRMatrix.m:107)
+    launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, s1);
+    hipEvent_t e_E = p.next_sync_event();
+    if (s1 != s0) HIP_CHECK(hipEventRecord(e_E, s1));
+
+    // s2: HRIR prologue
     {
-        FactorArgs a{};
-        a.S = p.S; a.C = p.C; a.ldS = p.ldS; a.kb0 = 1; a.P = p.P;
-        a.Tn = p.get("Tn"); a.bn = p.get<cplx>("bn"); a.nOrders = p.simOrder + 1;
-        a.reg_mode = 0; a.reg_c = SVD_REGUL_CONST;
-        a.Z = p.get<cplx>("Z"); a.Bk = p.sweep_factored ? p.get<cplx>("Bk") : nullptr; a.bk_from = p.kcut0;
-        a.Mw = p.get<cplx>("Mw");
-        a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
-        a.Hq = p.get<cplx>("Hq"); a.ldHq = p.ldS; a.hq_estride = (int64_t)ls_end * p.ldS; a.ls_end = ls_end;
-        a.W = p.get<cplx>("W"); a.sweeps_out = p.get<int>("jsweeps");
-        a.tauw = p.get<double>("tauw"); a.R2w = p.get<cplx>("R2w"); a.Nw = p.get<cplx>("Nw");
-        launch_factor(a, p.P - 1, cb, st);
+        launch_twiddles(p.nfft, p.get("tw"), s2);
+        launch_hrir_grpdelay(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, d.ndirs, p.nfft, p.get("tw"),
+                             p.get<double>("dirsum"), p.get<double>("grpd"), s2);
+        launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"),
+                        p.get<double>("grpd"), 0, ls_end, p.kcut0, p.get("Hc"), p.get<double>("Habs"), p.ldD, s2);
     }
-    p.mark("factor_bins");
+
+    // s0: SH matrix of the HRIR grid, Gram, Cholesky
+    launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), cb,
+                    p.get("Ycm"), p.ldD, s0);
+    launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, cb, true, s0);
+    p.mark("sh_basis");
+    hipEvent_t e_Yc = p.next_sync_event();
+    if (s1 != s0) HIP_CHECK(hipEventRecord(e_Yc, s0));
+    launch_gram(p.get("Yc"), p.D, p.S, p.ldS, cb, p.get("Gp"), p.get("R"), s0);
+    p.mark("gram_mfma");
+    launch_cholesky(p.get("R"), p.S, cb, p.get<int>("flag"), s0);
+    p.mark("cholesky");
+    hipEvent_t e_R = p.next_sync_event();
+    if (s2 != s0) HIP_CHECK(hipEventRecord(e_R, s0));
+
+    // s1 (after the array model): order terms of pwGrid.' and G_k of every swept bin -- needs only conj(Y) and E
+    if (!p.sweep_factored) {
+        if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s1, e_Yc, 0));
+        launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, cb, p.get("QT"), p.ldD, s1);
+        launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, k0, p.get("G"), s1);
+    }
+    // s2 (after the prologue): Q = conj(Y) R^-1 and the least-squares right-hand sides H conj(Q)
+    if (s2 != s0) HIP_CHECK(hipStreamWaitEvent(s2, e_R, 0));
+    launch_qform(p.get("Yc"), p.get("R"), p.S, p.D, p.ldS, cb, p.get("Q"), s2);
+    launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Q"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, s2);
+
+    // s0: T_n, per-bin QR + Jacobi
+    if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s0, e_E, 0));
+    launch_tn(p.get("R"), p.get("E"), p.S, p.C, p.ldS, nOrd, cb, p.get("Tn"), p.ldS, s0);
+    p.mark("array_model+tn");
+    FactorArgs fa{};
+    fa.S = p.S; fa.C = p.C; fa.ldS = p.ldS; fa.kb0 = 1; fa.P = p.P;
+    fa.Tn = p.get("Tn"); fa.bn = p.get<cplx>("bn"); fa.nOrders = nOrd;
+    fa.reg_mode = 0; fa.reg_c = SVD_REGUL_CONST;
+    fa.Z = p.get<cplx>("Z"); fa.Bk = p.sweep_factored ? p.get<cplx>("Bk") : nullptr; fa.bk_from = p.kcut0;
+    fa.Mw = p.get<cplx>("Mw");
+    fa.Vws = p.get<cplx>("Vws"); fa.sv = p.get<double>("sv");
+    fa.Hq = p.get<cplx>("Hq"); fa.ldHq = p.ldS; fa.hq_estride = (int64_t)ls_end * p.ldS; fa.ls_end = ls_end;
+    fa.W = p.get<cplx>("W"); fa.sweeps_out = p.get<int>("jsweeps");
+    fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
+    launch_factor(fa, p.P - 1, cb, s0, 1);
+    p.mark("factor_qr_jacobi");
+    // join s2 (Q, Hq, spectra, group delays): back-transform + least-squares bins
+    p.depend(s0, s2);
+    launch_factor(fa, p.P - 1, cb, s0, 2);
+    p.mark("factor_back+ls_bins");
+    // join s1 (G)
+    p.depend(s0, s1);
+    if (!p.sweep_factored) {
+        launch_dspace_yri(p.get("G"), p.ldD, p.get("Mw"), 1, p.get<double>("sv"), p.get<double>("cond_ok"), (int)p.D, p.C, p.P, k0,
+                          p.get("Yri"), s0);
+        launch_yri_accurate(p.get("Q"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
+                            p.get("Yri"), p.ldD, s0);
+        p.mark("yri_operands");
+    }
+}
+
+DenseSweepArgs emagls_dense_args(emagls_plan& p) {
+    const int k0 = std::max(p.kcut0, 1);
+    DenseSweepArgs a{};
+    a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
+    // the operand arrays start at bin k0: shift the base so that the kernels can index by kb
+    a.X = p.get<cplx>("G") - (int64_t)k0 * p.C * p.ldD; a.x_stride = (int64_t)p.C * p.ldD;
+    a.Zd = p.get<cplx>("Yri") - (int64_t)k0 * p.C * p.ldD; a.z_stride = (int64_t)p.C * p.ldD;
+    a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
+    a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.sweep_split ? p.nWG_split : p.nWG_dense; a.kfirst = k0;
+    return a;
+}
+
+void emagls_run_sweep(emagls_plan& p) {
+    const bool cb = p.cplx_basis;
+    hipStream_t s0 = p.stream;
     const int k0 = std::max(p.kcut0, 1);
     if (p.sweep_factored) {
         SweepArgs a{};
@@ -447,39 +585,40 @@ void execute_emagls(emagls_plan& p) {
         p.sweep_launches = 0;
         for (int kb = k0; kb < p.P; ++kb) {
             if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
-            launch_sweep_factored(a, kb, cb, st);
+            launch_sweep_factored(a, kb, cb, s0);
             if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
             ++p.sweep_launches;
         }
-        if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
+        if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, s0);
     } else {
-        // direction-space operands of every swept bin (parallel over bins), then the light sequential sweep
-        launch_qt(p.get("Q"), p.ldS, p.get("Tn"), p.ldS, (int)p.D, p.S, p.C, p.simOrder + 1, cb, p.get("QT"), p.ldD, st);
-        launch_dspace(p.get("QT"), p.ldD, cb, p.get("bn"), p.simOrder + 1, p.get("Mw"), 1, p.get<double>("sv"),
-                      p.get<double>("cond_ok"), (int)p.D, p.C, p.P, k0, p.get("G"), p.get("Yri"), st);
-        launch_yri_accurate(p.get("Q"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
-                            p.get("Yri"), p.ldD, st);
-        p.mark("dspace_operands");
-        DenseSweepArgs a{};
-        a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
-        // the operand arrays start at bin k0: shift the base so that the kernels can index by kb
-        a.X = p.get<cplx>("G") - (int64_t)k0 * p.C * p.ldD; a.x_stride = (int64_t)p.C * p.ldD;
-        a.Zd = p.get<cplx>("Yri") - (int64_t)k0 * p.C * p.ldD; a.z_stride = (int64_t)p.C * p.ldD;
-        a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
-        a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG_dense; a.kfirst = k0;
+        const DenseSweepArgs a = emagls_dense_args(p);
+        DenseSweepMulti m{};
+        m.n = 1;
+        m.a[0] = a;
         p.sweep_launches = 0;
         for (int kb = k0; kb < p.P; ++kb) {
             if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
-            launch_sweep_dense(a, kb, true, st);
+            if (p.sweep_split) launch_sweep_split(m, kb, s0); else launch_sweep_dense(a, kb, true, s0);
             if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
             ++p.sweep_launches;
         }
-        if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG_dense, p.C, p.P, p.P - 1, st);
+        if (k0 < p.P && !p.sweep_split) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG_dense, p.C, p.P, p.P - 1, s0);
     }
     p.mark("magls_sweep");
-    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)d.len, p.get("tw"), p.get<double>("grpd"), (cb && !raw) ? 1 : 0, 1, 0,
-                           p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), st);
+}
+
+void emagls_post_sweep(emagls_plan& p) {
+    const bool cb = p.cplx_basis;
+    const bool raw = p.d.kind == EMAGLS_KIND_EMAGLS2;
+    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"), (cb && !raw) ? 1 : 0, 1, 0,
+                           p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), p.stream);
     p.mark("epilogue");
+}
+
+void execute_emagls(emagls_plan& p) {
+    emagls_pre_sweep(p);
+    emagls_run_sweep(p);
+    emagls_post_sweep(p);
 }
 
 void execute_from_atf(emagls_plan& p) {
@@ -583,6 +722,72 @@ void plan_execute(emagls_plan& p) {
     run_pipeline(p);
     ++p.eager_runs;
     p.executed = true;
+}
+
+void emagls_pre_sweep(emagls_plan& p);
+void emagls_post_sweep(emagls_plan& p);
+DenseSweepArgs emagls_dense_args(emagls_plan& p);
+// A batch runs as separate graphs on separate streams (one hipGraph executes its nodes in order, so
+// parallel branches inside ONE graph would serialize): per-plan "pre" graphs on the plans' own streams,
+// the shared sweep graph on the batch stream, ordered by events outside the graphs.
+void plan_pre_stage(emagls_plan& p) {
+    p.stage_names.clear();
+    launch_zero(p.get("flag"), sizeof(int) * 4, p.stream);
+    launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
+    emagls_pre_sweep(p);
+}
+void batch_sweep_stage(emagls_batch& b) {
+    DenseSweepMulti m{};
+    m.n = (int)b.plans.size();
+    for (int j = 0; j < m.n; ++j) m.a[j] = emagls_dense_args(*b.plans[j]);
+    emagls_plan& p0 = *b.plans[0];
+    const int k0 = std::max(p0.kcut0, 1);
+    if (p0.sweep_split) {
+        for (int kb = k0; kb < p0.P; ++kb) launch_sweep_split(m, kb, b.stream);
+    } else {
+        for (int kb = k0; kb < p0.P; ++kb) launch_sweep_dense_multi(m, kb, b.stream);
+        if (k0 < p0.P) launch_sweep_finalize_multi(m, p0.P - 1, b.stream);
+    }
+}
+template <typename F> void capture_into(hipStream_t st, hipGraph_t* g, hipGraphExec_t* ge, F&& body) {
+    HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    try {
+        body();
+    } catch (...) {
+        hipGraph_t tmp = nullptr;
+        hipStreamEndCapture(st, &tmp);
+        if (tmp) hipGraphDestroy(tmp);
+        throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(st, g));
+    HIP_CHECK(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+}
+
+void batch_execute(emagls_batch& b) {
+    for (auto* p : b.plans)
+        if (!p->have_hrir_grid || !p->have_hrirs || !p->have_mic_grid) throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grids and HRIRs");
+    const bool replay = b.use_graph && b.eager_runs >= 1;
+    if (replay && !b.graph_exec) {
+        for (auto* p : b.plans) capture_into(p->stream, &p->pre_graph, &p->pre_exec, [&] { plan_pre_stage(*p); });
+        capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_sweep_stage(b); });
+    }
+    b.used = 0;
+    // the previous sweep of this batch must be done before a plan's buffers are rewritten
+    for (auto* p : b.plans) b.depend(p->stream, b.stream);
+    for (auto* p : b.plans) {
+        if (replay) HIP_CHECK(hipGraphLaunch(p->pre_exec, p->stream)); else plan_pre_stage(*p);
+        b.depend(b.stream, p->stream);
+    }
+    if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_sweep_stage(b);
+    emagls_plan& p0 = *b.plans[0];
+    for (auto* p : b.plans) {
+        b.depend(p->stream, b.stream);
+        emagls_post_sweep(*p);
+        b.depend(b.stream, p->stream);  // batch stream completion == all results ready
+        p->executed = true;
+        p->sweep_launches = p0.P - std::max(p0.kcut0, 1);
+    }
+    if (!replay) ++b.eager_runs;
 }
 
 void plan_check_flags(emagls_plan& p) {
@@ -777,14 +982,14 @@ int emagls_plan_execute(emagls_plan* p) {
 int emagls_plan_synchronize(emagls_plan* p) {
     return guarded([&] {
         if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
-        HIP_CHECK(hipStreamSynchronize(p->stream));
+        HIP_CHECK(hipStreamSynchronize(p->sync_stream ? p->sync_stream : p->stream));
     });
 }
 int emagls_plan_get_filters(emagls_plan* p, void* wL, void* wR) {
     return guarded([&] {
         if (!p || !wL || !wR) throw Error(EMAGLS_ERR_ARG, "null pointer");
         if (!p->executed) throw Error(EMAGLS_ERR_ARG, "plan has not been executed");
-        HIP_CHECK(hipStreamSynchronize(p->stream));
+        HIP_CHECK(hipStreamSynchronize(p->sync_stream ? p->sync_stream : p->stream));
         plan_check_flags(*p);
         const size_t bytes = (p->out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p->out_rows * p->out_cols;
         HIP_CHECK(hipMemcpy(wL, p->get("wL"), bytes, hipMemcpyDefault));
@@ -812,6 +1017,16 @@ int emagls_plan_set_profiling(emagls_plan* p, int level) {
     return guarded([&] {
         if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
         p->prof_level = level;
+    });
+}
+int emagls_plan_set_streams(emagls_plan* p, int nstreams) {
+    return guarded([&] {
+        if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (nstreams < 1 || nstreams > 3) throw Error(EMAGLS_ERR_ARG, "nstreams must be 1..3");
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        if (p->graph_exec) { HIP_CHECK(hipGraphExecDestroy(p->graph_exec)); p->graph_exec = nullptr; }
+        if (p->graph) { HIP_CHECK(hipGraphDestroy(p->graph)); p->graph = nullptr; }
+        p->nstreams = nstreams;
     });
 }
 int emagls_plan_num_stages(emagls_plan* p) { return p ? (int)p->stage_names.size() : 0; }
@@ -865,6 +1080,52 @@ int emagls_plan_debug_buffer(emagls_plan* p, const char* name, void* dst, size_t
     });
 }
 void* emagls_plan_stream(emagls_plan* p) { return p ? (void*)p->stream : nullptr; }
+
+int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
+    return guarded([&] {
+        if (!plans || !batch || nplans < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        if (nplans > SWEEP_MULTI_MAX) throw Error(EMAGLS_ERR_UNSUPPORTED, "at most 8 designs per batch");
+        std::unique_ptr<emagls_batch> b(new emagls_batch);
+        for (int j = 0; j < nplans; ++j) {
+            emagls_plan* p = plans[j];
+            if (!p) throw Error(EMAGLS_ERR_ARG, "null plan");
+            if (p->d.kind != EMAGLS_KIND_EMAGLS && p->d.kind != EMAGLS_KIND_EMAGLS2) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 plans");
+            if (p->sweep_factored) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches need the direction-space sweep");
+            const emagls_plan* q = plans[0];
+            if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_split != q->sweep_split)
+                throw Error(EMAGLS_ERR_ARG, "all designs of a batch must have the same shape (directions, channels, bins, k_cut)");
+            b->plans.push_back(p);
+        }
+        HIP_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        if (const char* ng = getenv("EMAGLS_NO_GRAPH")) b->use_graph = !(ng[0] == '1');
+        bool can_split = true;
+        for (auto* p : b->plans) can_split = can_split && p->nWG_split <= 256 && 2 * p->C <= 64;
+        if (const char* e = getenv("EMAGLS_SWEEP_SPLIT")) can_split = can_split && e[0] != '0';
+        for (auto* p : b->plans) {
+            HIP_CHECK(hipStreamSynchronize(p->stream));
+            p->sweep_split = can_split && b->plans.size() > 1;
+            p->nstreams = 1;
+            p->prof_level = 0;
+            p->sync_stream = b->stream;
+        }
+        *batch = b.release();
+    });
+}
+int emagls_batch_execute(emagls_batch* b) {
+    return guarded([&] {
+        if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        batch_execute(*b);
+    });
+}
+int emagls_batch_synchronize(emagls_batch* b) {
+    return guarded([&] {
+        if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        HIP_CHECK(hipStreamSynchronize(b->stream));
+    });
+}
+int emagls_batch_destroy(emagls_batch* b) {
+    return guarded([&] { delete b; });
+}
 
 // ---------------------------------------------------------------------------------------------
 int emagls_get_ls_filters(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi,

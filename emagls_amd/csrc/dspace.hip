@@ -21,22 +21,37 @@ namespace emagls {
 constexpr double COND_LIMIT = 1.0e4;
 constexpr int SW_CMAX_ = 32;
 
-// QT[n][c][d] = sum_{s < (n+1)^2} Q[d][s] T[n][c][s]      thread = (direction, channel)
+// Order terms of pwGrid.':  G_k = conj(Y) diag(b_n(k)) E^T = sum_n b_n(k) QT_n  with
+//   QT[n][c][d] = sum_{s in [n^2,(n+1)^2)} Yc[d][s] E[c][s]
+// (equal to Q T_n, but needs neither Q nor R: the order blocks of conj(Y) and of the array matrix E suffice).
+// One workgroup = 16 directions, all orders; the 16 rows of Yc sit in LDS, thread = (channel c, direction dl)
+// with dl fastest: the 16 lanes of a channel share every E load and store a contiguous 256-byte run.
+constexpr int QT_TD = 16;
+
 template <typename T>
-__global__ void __launch_bounds__(256) qt_kernel(const T* __restrict__ Q, int64_t ldQ, const T* __restrict__ Tn, int ldS,
+__global__ void __launch_bounds__(512) qt_kernel(const T* __restrict__ Yc, int64_t ldY, const T* __restrict__ E, int ldE,
                                                  int D, int S, int C, int nOrders, T* __restrict__ QT, int64_t ldD) {
-    const int c = threadIdx.x >> 3, dl = threadIdx.x & 7;  // direction fastest: full-line stores
-    const int d = blockIdx.x * 8 + dl;
-    const int n = blockIdx.y;
-    if (c >= C || d >= D) return;
-    const int se = min(S, (n + 1) * (n + 1));
-    const T* q = Q + (int64_t)d * ldQ;
-    const T* t = Tn + ((int64_t)n * C + c) * ldS;
-    T a0 = zero_of<T>(), a1 = zero_of<T>();
-    int s = 0;
-    for (; s + 1 < se; s += 2) { cfma(a0, q[s], t[s]); cfma(a1, q[s + 1], t[s + 1]); }
-    if (s < se) cfma(a0, q[s], t[s]);
-    QT[((int64_t)n * C + c) * ldD + d] = a0 + a1;
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    T* ys = reinterpret_cast<T*>(dyn);  // [QT_TD][S+1]
+    const int ldq = S + 1;
+    const int d0 = blockIdx.x * QT_TD;
+    for (int idx = threadIdx.x; idx < QT_TD * S; idx += blockDim.x) {
+        const int dl = idx / S, s = idx % S;
+        ys[(size_t)dl * ldq + s] = (d0 + dl < D) ? Yc[(int64_t)(d0 + dl) * ldY + s] : zero_of<T>();
+    }
+    __syncthreads();
+    const int c = threadIdx.x >> 4, dl = threadIdx.x & 15;
+    if (c >= C) return;
+    const T* y = ys + (size_t)dl * ldq;
+    const T* e = E + (int64_t)c * ldE;
+    for (int n = 0; n < nOrders; ++n) {
+        const int sb = n * n, se = min(S, (n + 1) * (n + 1));
+        T a0 = zero_of<T>(), a1 = zero_of<T>();
+        int s = sb;
+        for (; s + 1 < se; s += 2) { cfma(a0, y[s], e[s]); cfma(a1, y[s + 1], e[s + 1]); }
+        if (s < se) cfma(a0, y[s], e[s]);
+        if (d0 + dl < D) QT[((int64_t)n * C + c) * ldD + d0 + dl] = a0 + a1;
+    }
 }
 
 // G kernel: one workgroup = 8 directions x a chunk of swept bins; thread = (channel, direction).  The
@@ -136,22 +151,31 @@ __global__ void __launch_bounds__(256) yri_accurate_kernel(const T* __restrict__
     }
 }
 
-void launch_qt(const void* Q, int64_t ldQ, const void* Tn, int ldS, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
-               int64_t ldD, hipStream_t st) {
-    dim3 grid((unsigned)ceil_div(D, 8), nOrders);
-    if (is_cplx) qt_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)Q, ldQ, (const cplx*)Tn, ldS, D, S, C, nOrders, (cplx*)QT, ldD);
-    else qt_kernel<double><<<grid, 256, 0, st>>>((const double*)Q, ldQ, (const double*)Tn, ldS, D, S, C, nOrders, (double*)QT, ldD);
+template <typename T>
+static void qt_impl(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, void* QT, int64_t ldD,
+                    hipStream_t st) {
+    const size_t dyn = sizeof(T) * (size_t)QT_TD * (S + 1);
+    if (dyn > 150 * 1024) throw Error(2, "qt: simulation order too large for the LDS-resident tile");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)qt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    qt_kernel<T><<<(unsigned)ceil_div(D, QT_TD), 512, dyn, st>>>((const T*)Yc, ldY, (const T*)E, ldE, D, S, C, nOrders, (T*)QT, ldD);
     KERNEL_CHECK();
+}
+void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
+               int64_t ldD, hipStream_t st) {
+    if (is_cplx) qt_impl<cplx>(Yc, ldY, E, ldE, D, S, C, nOrders, QT, ldD, st);
+    else qt_impl<double>(Yc, ldY, E, ldE, D, S, C, nOrders, QT, ldD, st);
 }
 
 template <typename T>
-static void dspace_impl(const void* QT, int64_t ldD, const void* bn, int nOrders, const void* Mw, int kb0_factor,
-                        const double* sv, double* cond_ok, int D, int C, int P, int k0, void* G, void* Yri, hipStream_t st) {
+static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
+                          hipStream_t st) {
     const int nbins = P - k0;
     if (nbins <= 0) return;
     if (nOrders > DSP_NMAX) throw Error(2, "dspace: simulation order above 31 is not supported in this build");
-    cond_flag_kernel<<<(P + 255) / 256, 256, 0, st>>>(sv, C, P, cond_ok);
-    KERNEL_CHECK();
     const int chunks = 4;
     const int bpc = (nbins + chunks - 1) / chunks;
     const size_t dyn = sizeof(cplx) * (size_t)bpc * nOrders;
@@ -159,14 +183,21 @@ static void dspace_impl(const void* QT, int64_t ldD, const void* bn, int nOrders
     dspace_g_kernel<T><<<dim3((unsigned)ceil_div(D, DSP_TD), chunks), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D,
                                                                                      C, P, k0, bpc, (cplx*)G);
     KERNEL_CHECK();
+}
+void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
+                     hipStream_t st) {
+    if (is_cplx) dspace_g_impl<cplx>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
+    else dspace_g_impl<double>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
+}
+void launch_dspace_yri(const void* G, int64_t ldD, const void* Mw, int kb0_factor, const double* sv, double* cond_ok, int D, int C,
+                       int P, int k0, void* Yri, hipStream_t st) {
+    const int nbins = P - k0;
+    if (nbins <= 0) return;
+    cond_flag_kernel<<<(P + 255) / 256, 256, 0, st>>>(sv, C, P, cond_ok);
+    KERNEL_CHECK();
     dspace_yri_kernel<<<dim3((unsigned)ceil_div(D, 256), nbins), 256, 0, st>>>((const cplx*)G, ldD, (const cplx*)Mw, kb0_factor,
                                                                               cond_ok, D, C, k0, (cplx*)Yri);
     KERNEL_CHECK();
-}
-void launch_dspace(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, const void* Mw, int kb0_factor,
-                   const double* sv, double* cond_ok, int D, int C, int P, int k0, void* G, void* Yri, hipStream_t st) {
-    if (is_cplx) dspace_impl<cplx>(QT, ldD, bn, nOrders, Mw, kb0_factor, sv, cond_ok, D, C, P, k0, G, Yri, st);
-    else dspace_impl<double>(QT, ldD, bn, nOrders, Mw, kb0_factor, sv, cond_ok, D, C, P, k0, G, Yri, st);
 }
 
 void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S, int C,

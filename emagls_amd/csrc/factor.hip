@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(MAXT) factor_back_kernel(FactorArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 template <typename TT, int NCH, int RPT, int MAXT>
-static void launch_one(const FactorArgs& a, int nbins, hipStream_t st) {
+static void launch_one(const FactorArgs& a, int nbins, hipStream_t st, int phases) {
     const int threads = (int)(ceil_div((int64_t)NCH * a.C, 64) * 64);
     if (threads > MAXT) throw Error(2, "factor: too many channels for this row count");
     const size_t dyn = (size_t)2 * a.ldS * sizeof(cplx);
@@ -363,39 +363,44 @@ static void launch_one(const FactorArgs& a, int nbins, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         attr_set = true;
     }
-    factor_qr_kernel<TT, NCH, RPT, MAXT><<<nbins, threads, dyn, st>>>(a);
-    KERNEL_CHECK();
-    factor_jacobi_kernel<<<nbins, 256, 0, st>>>(a);
-    KERNEL_CHECK();
-    factor_back_kernel<NCH, RPT, MAXT><<<nbins, threads, 0, st>>>(a);
-    KERNEL_CHECK();
+    if (phases & 1) {
+        factor_qr_kernel<TT, NCH, RPT, MAXT><<<nbins, threads, dyn, st>>>(a);
+        KERNEL_CHECK();
+        factor_jacobi_kernel<<<nbins, 256, 0, st>>>(a);
+        KERNEL_CHECK();
+    }
+    if (phases & 2) {
+        factor_back_kernel<NCH, RPT, MAXT><<<nbins, threads, 0, st>>>(a);
+        KERNEL_CHECK();
+    }
 }
 
 template <typename TT>
-static void dispatch(const FactorArgs& a, int nbins, hipStream_t st) {
+static void dispatch(const FactorArgs& a, int nbins, hipStream_t st, int phases) {
     const int S = a.S, C = a.C;
     if (C > CPMAX) throw Error(2, "factor: more than 32 output channels is not supported in this build");
     if (S < C) throw Error(2, "factor: fewer rows than channels (under-determined array model) is not supported");
     if (!a.tauw || !a.R2w || !a.Nw || !a.Vws) throw Error(2, "factor: workspaces missing");
     if (C * 32 <= 1024) {
-        if (S <= 32 * 1) return launch_one<TT, 32, 1, 1024>(a, nbins, st);
-        if (S <= 32 * 4) return launch_one<TT, 32, 4, 1024>(a, nbins, st);
-        if (S <= 32 * 8) return launch_one<TT, 32, 8, 1024>(a, nbins, st);
-        if (S <= 32 * 13) return launch_one<TT, 32, 13, 1024>(a, nbins, st);
-        if (S <= 32 * 16) return launch_one<TT, 32, 16, 1024>(a, nbins, st);
-        if (S <= 32 * 24) return launch_one<TT, 32, 24, 1024>(a, nbins, st);
+        if (S <= 32 * 1) return launch_one<TT, 32, 1, 1024>(a, nbins, st, phases);
+        if (S <= 32 * 4) return launch_one<TT, 32, 4, 1024>(a, nbins, st, phases);
+        if (S <= 32 * 8) return launch_one<TT, 32, 8, 1024>(a, nbins, st, phases);
+        if (S <= 32 * 13) return launch_one<TT, 32, 13, 1024>(a, nbins, st, phases);
+        if (S <= 32 * 16) return launch_one<TT, 32, 16, 1024>(a, nbins, st, phases);
+        if (S <= 32 * 24) return launch_one<TT, 32, 24, 1024>(a, nbins, st, phases);
     }
     if (C * 64 <= 512) {
-        if (S <= 64 * 24) return launch_one<TT, 64, 24, 512>(a, nbins, st);
-        if (S <= 64 * 43) return launch_one<TT, 64, 43, 512>(a, nbins, st);
-        if (S <= 64 * 64) return launch_one<TT, 64, 64, 512>(a, nbins, st);
+        if (S <= 64 * 24) return launch_one<TT, 64, 24, 512>(a, nbins, st, phases);
+        if (S <= 64 * 43) return launch_one<TT, 64, 43, 512>(a, nbins, st, phases);
+        if (S <= 64 * 64) return launch_one<TT, 64, 64, 512>(a, nbins, st, phases);
     }
     throw Error(2, "factor: problem shape (rows x channels) not supported in this build");
 }
 
-void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st) {
+// phases: 1 = QR + Jacobi, 2 = back-transform (+ least-squares bins), 3 = both
+void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st, int phases) {
     if (nbins <= 0) return;
-    if (a.Tn && !tn_cplx) dispatch<double>(a, nbins, st); else dispatch<cplx>(a, nbins, st);
+    if (a.Tn && !tn_cplx) dispatch<double>(a, nbins, st, phases); else dispatch<cplx>(a, nbins, st, phases);
 }
 
 }  // namespace emagls

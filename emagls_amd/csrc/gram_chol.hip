@@ -110,66 +110,85 @@ constexpr int NB = 32;
 template <typename T> __device__ __forceinline__ double real_of(T v);
 template <> __device__ __forceinline__ double real_of<double>(double v) { return v; }
 template <> __device__ __forceinline__ double real_of<cplx>(cplx v) { return v.x; }
+template <typename T> __device__ __forceinline__ T to_T(double v);
+template <> __device__ __forceinline__ double to_T<double>(double v) { return v; }
+template <> __device__ __forceinline__ cplx to_T<cplx>(double v) { return mk(v, 0.0); }
 template <typename T> __device__ __forceinline__ T scale_real(T v, double s);
 template <> __device__ __forceinline__ double scale_real<double>(double v, double s) { return v * s; }
 template <> __device__ __forceinline__ cplx scale_real<cplx>(cplx v, double s) { return mk(v.x * s, v.y * s); }
 
-// panel kernel: every workgroup factors the diagonal block redundantly in LDS, then solves its own
-// 32-column slice of the block row:  R(J, c) = R_JJ^-H G(J, c).
+// panel kernel: every workgroup factors the diagonal block redundantly (wave 0, wave-synchronous LDS: no
+// workgroup barrier inside the 32-step elimination), inverts L = R_JJ^H once, then forms its own 32-column
+// slice of the block row as a small product:  R(J, c) = L^-1 G(J, c).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) chol_panel_kernel(T* __restrict__ G, int S, int j0, int* __restrict__ flag) {
-    __shared__ T Rd[NB][NB + 1];
-    __shared__ int bad;
+    __shared__ T Rd[NB][NB + 1];   // upper factor of the diagonal block
+    __shared__ T Li[NB][NB + 1];   // (R_JJ^H)^-1, lower triangular
+    __shared__ T Gs[NB][NB + 1];   // this workgroup's slice G(J, c0..c0+32)
     const int nb = min(NB, S - j0);
     const int tid = threadIdx.x;
-    if (tid == 0) bad = 0;
+    const int c0 = j0 + blockIdx.x * NB;
     for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
         const int r = idx / NB, c = idx % NB;
         Rd[r][c] = (r < nb && c < nb && r <= c) ? G[(int64_t)(j0 + r) * S + j0 + c] : zero_of<T>();
+        Li[r][c] = zero_of<T>();
+        Gs[r][c] = (blockIdx.x > 0 && r < nb && c0 + c < S) ? G[(int64_t)(j0 + r) * S + c0 + c] : zero_of<T>();
     }
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        const double piv = real_of(Rd[j][j]);
-        if (!(piv > 0.0)) { if (tid == 0) bad = 1; }
-        const double dinv = 1.0 / sqrt(piv > 0.0 ? piv : 1.0);
-        __syncthreads();
-        if (tid >= j && tid < nb) Rd[j][tid] = scale_real(Rd[j][tid], dinv);  // row j: diag becomes sqrt(piv)
-        __syncthreads();
-        for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
-            const int r = idx / NB, c = idx % NB;
-            if (r > j && r < nb && c >= r && c < nb) {
+    if (tid < 64) {
+        const int c = tid & 31, half = tid >> 5;  // two lanes per column
+        bool bad = false;
+        for (int j = 0; j < nb; ++j) {
+            const double piv = real_of(Rd[j][j]);
+            if (!(piv > 0.0)) bad = true;
+            const double dinv = 1.0 / sqrt(piv > 0.0 ? piv : 1.0);
+            wave_lds_fence();
+            if (half == 0 && c >= j && c < nb) Rd[j][c] = scale_real(Rd[j][c], dinv);  // diag becomes sqrt(piv)
+            wave_lds_fence();
+            if (c > j && c < nb) {
+                const T rjc = Rd[j][c];
+                for (int r = j + 1 + half; r <= c; r += 2) {
+                    T acc = zero_of<T>();
+                    cfma_conj(acc, Rd[j][r], rjc);
+                    Rd[r][c] = Rd[r][c] - acc;
+                }
+            }
+            wave_lds_fence();
+        }
+        if (bad && tid == 0) atomicExch(flag, 1 + j0);
+        // Li = L^-1, L[i][l] = conj(Rd[l][i]); lane c builds column c by forward substitution
+        if (half == 0 && c < nb) {
+            Li[c][c] = scale_real(to_T<T>(1.0), 1.0 / real_of(Rd[c][c]));
+            for (int i = c + 1; i < nb; ++i) {
                 T acc = zero_of<T>();
-                cfma_conj(acc, Rd[j][r], Rd[j][c]);
-                Rd[r][c] = Rd[r][c] - acc;
+                for (int l = c; l < i; ++l) cfma_conj(acc, Rd[l][i], Li[l][c]);
+                Li[i][c] = scale_real(zero_of<T>() - acc, 1.0 / real_of(Rd[i][i]));
             }
         }
-        __syncthreads();
     }
-    if (bad && tid == 0) atomicExch(flag, 1 + j0);
-    const int c0 = j0 + blockIdx.x * NB;
+    __syncthreads();
     if (blockIdx.x == 0) {
         for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
             const int r = idx / NB, c = idx % NB;
             if (r < nb && c < nb && r <= c) G[(int64_t)(j0 + r) * S + j0 + c] = Rd[r][c];
         }
-    } else if (tid < NB && c0 + tid < S) {
-        const int c = c0 + tid;
-        T x[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) x[i] = (i < nb) ? G[(int64_t)(j0 + i) * S + c] : zero_of<T>();
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            if (i < nb) {
-                T acc = x[i];
-#pragma unroll
-                for (int l = 0; l < NB; ++l)
-                    if (l < i) { T p = zero_of<T>(); cfma_conj(p, Rd[l][i], x[l]); acc = acc - p; }
-                x[i] = scale_real(acc, 1.0 / real_of(Rd[i][i]));
+    } else {
+        for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+            const int i = idx / NB, c = idx % NB;
+            if (i < nb && c0 + c < S) {
+                T a0 = zero_of<T>(), a1 = zero_of<T>();
+                int l = 0;
+                for (; l + 1 <= i; l += 2) { cfma(a0, Li[i][l], Gs[l][c]); cfma(a1, Li[i][l + 1], Gs[l + 1][c]); }
+                if (l <= i) cfma(a0, Li[i][l], Gs[l][c]);
+                G[(int64_t)(j0 + i) * S + c0 + c] = a0 + a1;
             }
         }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            if (i < nb) G[(int64_t)(j0 + i) * S + c] = x[i];
     }
 }
 
@@ -202,59 +221,59 @@ __global__ void __launch_bounds__(256) chol_update_kernel(T* __restrict__ G, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Q = Yc R^-1.  TR rows per workgroup; thread owns columns c = tid + 256 i.
-// Right-looking: once q_j is known, subtract q_j R(j, c) from all later columns.
+// Q = Yc R^-1, blocked by 32 columns.  A workgroup owns 8 rows (directions) and keeps their finished Q
+// entries in LDS; thread = (row r = tid/32, column-in-block c = tid%32).  Per block J:
+//   acc(r,c) = Yc(r, j0+c) - sum_{i < j0} Q(r,i) R(i, j0+c)         (Q from LDS, R streamed from L2)
+//   x = acc R_JJ^-1 by forward substitution inside the 32-lane half wave (shuffles, no barrier)
+// Rows are independent, so there is no inter-workgroup dependency and one barrier per block.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int CPT>
+template <typename T> __device__ __forceinline__ T shfl_T(T v, int src);
+template <> __device__ __forceinline__ double shfl_T<double>(double v, int src) { return __shfl(v, src, 64); }
+template <> __device__ __forceinline__ cplx shfl_T<cplx>(cplx v, int src) { return {__shfl(v.x, src, 64), __shfl(v.y, src, 64)}; }
+
+template <typename T>
 __global__ void __launch_bounds__(256) qform_kernel(const T* __restrict__ Yc, const T* __restrict__ R, int S, int64_t D,
                                                     int64_t ld, T* __restrict__ Q) {
-    constexpr int TR = 4;
-    __shared__ T qj[2][TR];
-    const int tid = threadIdx.x;
-    const int64_t d0 = (int64_t)blockIdx.x * TR;
-    T y[TR][CPT];
-#pragma unroll
-    for (int r = 0; r < TR; ++r)
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 256 * i;
-            y[r][i] = (c < S && d0 + r < D) ? Yc[(d0 + r) * ld + c] : zero_of<T>();
+    constexpr int TR = 8;
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    T* qs = reinterpret_cast<T*>(dyn);  // [TR][ldq]
+    const int ldq = S + 1;
+    const int tid = threadIdx.x, r = tid >> 5, c = tid & 31;
+    const int64_t d = (int64_t)blockIdx.x * TR + r;
+    const bool rowok = d < D;
+    const int lane_base = (tid & 32);  // first lane of this half wave inside its wave
+    for (int j0 = 0; j0 < S; j0 += 32) {
+        const int col = j0 + c;
+        const bool colok = col < S;
+        T acc0 = (rowok && colok) ? Yc[d * ld + col] : zero_of<T>();
+        T acc1 = zero_of<T>();
+        if (colok) {
+            const T* qrow = qs + (size_t)r * ldq;
+            int i = 0;
+            for (; i + 1 < j0; i += 2) {
+                T p0 = zero_of<T>(), p1 = zero_of<T>();
+                cfma(p0, qrow[i], R[(int64_t)i * S + col]);
+                cfma(p1, qrow[i + 1], R[(int64_t)(i + 1) * S + col]);
+                acc0 = acc0 - p0;
+                acc1 = acc1 - p1;
+            }
+            if (i < j0) { T p0 = zero_of<T>(); cfma(p0, qrow[i], R[(int64_t)i * S + col]); acc0 = acc0 - p0; }
         }
-    for (int j = 0; j < S; ++j) {
-        const int oi = j >> 8, ot = j & 255, buf = j & 1;
-        if (tid == ot) {
-            const double dinv = 1.0 / real_of(R[(int64_t)j * S + j]);
-#pragma unroll
-            for (int i = 0; i < CPT; ++i)
-                if (i == oi) {
-#pragma unroll
-                    for (int r = 0; r < TR; ++r) {
-                        y[r][i] = scale_real(y[r][i], dinv);
-                        qj[buf][r] = y[r][i];
-                    }
-                }
+        T x = acc0 + acc1;
+        // forward substitution across the 32 columns of the block: x_j final once columns < j are eliminated
+        const int nb = min(32, S - j0);
+        for (int j = 0; j < nb; ++j) {
+            const double dinv = 1.0 / real_of(R[(int64_t)(j0 + j) * S + j0 + j]);
+            if (c == j) x = scale_real(x, dinv);
+            const T xj = shfl_T<T>(x, lane_base + j);
+            if (c > j && colok) { T p = zero_of<T>(); cfma(p, xj, R[(int64_t)(j0 + j) * S + col]); x = x - p; }
+        }
+        if (colok) {
+            qs[(size_t)r * ldq + col] = x;
+            if (rowok) Q[d * ld + col] = x;
         }
         __syncthreads();
-        T q[TR];
-#pragma unroll
-        for (int r = 0; r < TR; ++r) q[r] = qj[buf][r];
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 256 * i;
-            if (c > j && c < S) {
-                const T rv = R[(int64_t)j * S + c];
-#pragma unroll
-                for (int r = 0; r < TR; ++r) { T p = zero_of<T>(); cfma(p, q[r], rv); y[r][i] = y[r][i] - p; }
-            }
-        }
     }
-#pragma unroll
-    for (int r = 0; r < TR; ++r)
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int c = tid + 256 * i;
-            if (c < S && d0 + r < D) Q[(d0 + r) * ld + c] = y[r][i];
-        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,15 +353,15 @@ void launch_cholesky(void* G, int S, bool is_cplx, int* flag, hipStream_t st) {
 }
 
 template <typename T> static void qform_impl(const void* Yc, const void* R, int S, int64_t D, int64_t ld, void* Q, hipStream_t st) {
-    const unsigned grid = (unsigned)ceil_div(D, 4);
-    const int cpt = (S + 255) / 256;
-    switch (cpt) {
-        case 1: qform_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q); break;
-        case 2: qform_kernel<T, 2><<<grid, 256, 0, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q); break;
-        case 3: qform_kernel<T, 3><<<grid, 256, 0, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q); break;
-        case 4: qform_kernel<T, 4><<<grid, 256, 0, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q); break;
-        default: throw Error(2, "qform: more than 1024 SH channels is not supported in this build");
+    const unsigned grid = (unsigned)ceil_div(D, 8);
+    const size_t dyn = sizeof(T) * (size_t)8 * (S + 1);
+    if (dyn > 150 * 1024) throw Error(2, "qform: more than 1024 SH channels is not supported in this build");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
     }
+    qform_kernel<T><<<grid, 256, dyn, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q);
     KERNEL_CHECK();
 }
 void launch_qform(const void* Yc, const void* R, int S, int64_t D, int64_t ld, bool is_cplx, void* Q, hipStream_t st) {

@@ -45,14 +45,19 @@ void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int l
 
 // ---- factor.hip
 struct FactorArgs;
-void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st);
+void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st, int phases = 3);
 
 // ---- sweep.hip
 struct SweepArgs;
 struct DenseSweepArgs;
+struct DenseSweepMulti;
 void launch_sweep_factored(const SweepArgs& a, int kb, bool q_cplx, hipStream_t st);
 void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st);
 int dense_sweep_nwg(int D);
+int slab_sweep_nwg(int D);
+void launch_sweep_split(const DenseSweepMulti& m, int kb, hipStream_t st);
+void launch_sweep_dense_multi(const DenseSweepMulti& m, int kb, hipStream_t st);
+void launch_sweep_finalize_multi(const DenseSweepMulti& m, int kb_last, hipStream_t st);
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
 void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
                int kb_hi, void* Hq, int ldS, hipStream_t st);
@@ -67,10 +72,12 @@ void launch_widen(const void* in, int64_t ldi, bool in_cplx, void* out, int64_t 
                   bool upper_only, hipStream_t st);
 
 // ---- dspace.hip
-void launch_qt(const void* Q, int64_t ldQ, const void* Tn, int ldS, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
+void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
                int64_t ldD, hipStream_t st);
-void launch_dspace(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, const void* Mw, int kb0_factor,
-                   const double* sv, double* cond_ok, int D, int C, int P, int k0, void* G, void* Yri, hipStream_t st);
+void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
+                     hipStream_t st);
+void launch_dspace_yri(const void* G, int64_t ldD, const void* Mw, int kb0_factor, const double* sv, double* cond_ok, int D, int C,
+                       int P, int k0, void* Yri, hipStream_t st);
 void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S,
                          int C, int P, int k0, void* Yri, int64_t ldD, hipStream_t st);
 

@@ -288,11 +288,7 @@ constexpr int DS_NT = 256;
 constexpr int DS_DPW = 64;
 
 template <typename TX>
-__global__ void __launch_bounds__(DS_NT) sweep_dense_kernel(DenseSweepArgs a, int kb) {
-    __shared__ __attribute__((aligned(16))) cplx Wp[64];
-    __shared__ __attribute__((aligned(16))) cplx ts[2][DS_DPW];
-    extern __shared__ __attribute__((aligned(16))) char dyn[];
-    cplx* stage = reinterpret_cast<cplx*>(dyn);  // [2C][nWG+1] partial sums of the previous launch
+__device__ __forceinline__ void sweep_dense_body(const DenseSweepArgs& a, int kb, cplx* Wp, cplx (*ts)[DS_DPW], cplx* stage) {
     const int tid = threadIdx.x;
     const int C = a.C, nWG = a.nWG;
     const bool nyq = (kb == a.P - 1);
@@ -381,6 +377,123 @@ __global__ void __launch_bounds__(DS_NT) sweep_dense_kernel(DenseSweepArgs a, in
         acc = group_sum<4>(acc);
         if (part2 == 0) Wout[((int64_t)e * C + c) * nWG + blockIdx.x] = acc;
     }
+}
+
+template <typename TX>
+__global__ void __launch_bounds__(DS_NT) sweep_dense_kernel(DenseSweepArgs a, int kb) {
+    __shared__ __attribute__((aligned(16))) cplx Wp[64];
+    __shared__ __attribute__((aligned(16))) cplx ts[2][DS_DPW];
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    sweep_dense_body<TX>(a, kb, Wp, ts, reinterpret_cast<cplx*>(dyn));
+}
+
+// several independent designs of identical shape in one launch: blockIdx.y selects the design
+template <typename TX>
+__global__ void __launch_bounds__(DS_NT) sweep_dense_multi_kernel(DenseSweepMulti m, int kb) {
+    __shared__ __attribute__((aligned(16))) cplx Wp[64];
+    __shared__ __attribute__((aligned(16))) cplx ts[2][DS_DPW];
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    sweep_dense_body<TX>(m.a[blockIdx.y], kb, Wp, ts, reinterpret_cast<cplx*>(dyn));
+}
+__global__ void __launch_bounds__(SW_NT) sweep_finalize_multi_kernel(DenseSweepMulti m, int kb_last) {
+    const DenseSweepArgs& a = m.a[blockIdx.x];  // blockIdx.x is the design
+    const cplx* Wprev = a.Wpart + (int64_t)(kb_last & 1) * a.nWG * 2 * a.C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    for (int pair = wave; pair < 2 * a.C; pair += nwaves) {
+        const int e = pair / a.C, c = pair % a.C;
+        const cplx* src = Wprev + (int64_t)pair * a.nWG;
+        cplx acc = mk(0, 0);
+        for (int w = lane; w < a.nWG; w += 64) acc += src[w];
+        acc = group_sum<64>(acc);
+        if (lane == 0) a.W[((int64_t)e * a.P + kb_last) * a.C + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split sweep: two tiny kernels per bin instead of one kernel in which every workgroup re-reads all
+// partial sums (a launch starts with cold L2, so per-launch time is set by the bytes each workgroup fetches).
+//   slab kernel   (nWG x designs workgroups of one wave): reads W(k-1) (800 B), its 22-direction slabs of
+//                 pwGrid_k and Y_reg_inv_k, writes its partial W(k)          -> Wpart[pair][wg]
+//   reduce kernel (2C x designs workgroups of one wave):  W(k)[pair] = sum_wg Wpart[pair][wg]
+// ---------------------------------------------------------------------------------------------
+constexpr int SL_TD = 22;  // directions per workgroup (44 of the 64 lanes form p, 2C <= 64 lanes form the partial)
+
+__global__ void __launch_bounds__(64) sweep_slab_kernel(DenseSweepMulti m, int kb) {
+    const DenseSweepArgs& a = m.a[blockIdx.y];
+    __shared__ __attribute__((aligned(16))) cplx Wp[64];
+    __shared__ __attribute__((aligned(16))) cplx ts[2][SL_TD];
+    const int lane = threadIdx.x;
+    const int C = a.C;
+    const bool nyq = (kb == a.P - 1);
+    const cplx* X = reinterpret_cast<const cplx*>(a.X) + (int64_t)kb * a.x_stride;
+    const cplx* Zd = reinterpret_cast<const cplx*>(a.Zd) + (int64_t)kb * a.z_stride;
+    const int64_t d0 = (int64_t)blockIdx.x * SL_TD;
+    const int64_t na = a.P - a.kabs0;
+    // W(k-1): the only load that depends on the previous launch goes out first
+    cplx wprev = mk(0, 0);
+    if (lane < 2 * C) wprev = a.W[((int64_t)(lane / C) * a.P + (kb - 1)) * C + lane % C];
+    const int e_ = lane / SL_TD, dd_ = lane % SL_TD;
+    const int64_t d_ = d0 + dd_;
+    const bool p1 = lane < 2 * SL_TD && d_ < a.D;
+    cplx xr[SW_CMAX];
+#pragma unroll
+    for (int c = 0; c < SW_CMAX; ++c) xr[c] = (p1 && c < C) ? X[(int64_t)c * a.ldD + d_] : mk(0, 0);
+    const double habs = p1 ? a.Habs[((int64_t)e_ * na + (kb - a.kabs0)) * a.ldH + d_] : 0.0;
+    const int e2 = lane / C, c2 = lane % C;
+    const bool p2 = lane < 2 * C;
+    cplx zr[SL_TD];
+#pragma unroll
+    for (int j = 0; j < SL_TD; ++j) zr[j] = (p2 && d0 + j < a.D) ? Zd[(int64_t)c2 * a.ldD + d0 + j] : mk(0, 0);
+    if (p2) Wp[lane] = wprev;
+    __syncthreads();
+    if (lane < 2 * SL_TD) {
+        cplx t = mk(0, 0);
+        if (p1) {
+            cplx pa = mk(0, 0), pb = mk(0, 0);
+#pragma unroll
+            for (int c = 0; c < SW_CMAX; c += 2) {
+                if (c < C) cfma(pa, Wp[e_ * C + c], xr[c]);
+                if (c + 1 < C) cfma(pb, Wp[e_ * C + c + 1], xr[c + 1]);
+            }
+            t = unit_phase_times(habs, pa + pb, nyq);
+        }
+        ts[e_][dd_] = t;
+    }
+    __syncthreads();
+    if (p2) {
+        cplx a0 = mk(0, 0), a1 = mk(0, 0);
+#pragma unroll
+        for (int j = 0; j < SL_TD; j += 2) {
+            cfma(a0, ts[e2][j], zr[j]);
+            if (j + 1 < SL_TD) cfma(a1, ts[e2][j + 1], zr[j + 1]);
+        }
+        a.Wpart[(int64_t)lane * a.nWG + blockIdx.x] = a0 + a1;
+    }
+}
+
+__global__ void __launch_bounds__(64) sweep_reduce_kernel(DenseSweepMulti m, int kb) {
+    const DenseSweepArgs& a = m.a[blockIdx.y];
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const cplx* src = a.Wpart + (int64_t)pair * a.nWG;
+    cplx v0 = mk(0, 0), v1 = mk(0, 0), v2 = mk(0, 0), v3 = mk(0, 0);
+    if (lane < a.nWG) v0 = src[lane];
+    if (lane + 64 < a.nWG) v1 = src[lane + 64];
+    if (lane + 128 < a.nWG) v2 = src[lane + 128];
+    if (lane + 192 < a.nWG) v3 = src[lane + 192];
+    cplx acc = (v0 + v1) + (v2 + v3);
+    acc = wave_sum(acc);
+    if (lane == 0) a.W[((int64_t)(pair / a.C) * a.P + kb) * a.C + pair % a.C] = acc;
+}
+
+int slab_sweep_nwg(int D) { return (D + SL_TD - 1) / SL_TD; }
+
+void launch_sweep_split(const DenseSweepMulti& m, int kb, hipStream_t st) {
+    const DenseSweepArgs& a = m.a[0];
+    if (a.nWG > 256 || 2 * a.C > 64) throw Error(2, "split sweep: shape not supported");
+    sweep_slab_kernel<<<dim3(a.nWG, m.n), 64, 0, st>>>(m, kb);
+    KERNEL_CHECK();
+    sweep_reduce_kernel<<<dim3(2 * a.C, m.n), 64, 0, st>>>(m, kb);
+    KERNEL_CHECK();
 }
 
 // after the last swept bin: W(P-1,:) = sum of partials
@@ -527,6 +640,17 @@ void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_
     const size_t dyn = sizeof(cplx) * (size_t)2 * a.C * (a.nWG + 1);
     if (x_cplx) sweep_dense_kernel<cplx><<<a.nWG, DS_NT, dyn, st>>>(a, kb);
     else sweep_dense_kernel<double><<<a.nWG, DS_NT, dyn, st>>>(a, kb);
+    KERNEL_CHECK();
+}
+void launch_sweep_dense_multi(const DenseSweepMulti& m, int kb, hipStream_t st) {
+    const DenseSweepArgs& a = m.a[0];
+    if (2 * a.C * a.nWG > 16 * DS_NT) throw Error(2, "dense sweep: too many workgroup partials");
+    const size_t dyn = sizeof(cplx) * (size_t)2 * a.C * (a.nWG + 1);
+    sweep_dense_multi_kernel<cplx><<<dim3(a.nWG, m.n), DS_NT, dyn, st>>>(m, kb);
+    KERNEL_CHECK();
+}
+void launch_sweep_finalize_multi(const DenseSweepMulti& m, int kb_last, hipStream_t st) {
+    sweep_finalize_multi_kernel<<<m.n, SW_NT, 0, st>>>(m, kb_last);
     KERNEL_CHECK();
 }
 int dense_sweep_nwg(int D) { return (D + DS_DPW - 1) / DS_DPW; }

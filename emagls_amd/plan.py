@@ -68,6 +68,9 @@ class Plan:
     def set_profiling(self, level):
         L.check(self._lib.emagls_plan_set_profiling(self._h, int(level)))
 
+    def set_streams(self, n):
+        L.check(self._lib.emagls_plan_set_streams(self._h, int(n)))
+
     def stage_times(self):
         n = self._lib.emagls_plan_num_stages(self._h)
         ms = (C.c_double * max(n, 1))()
@@ -91,3 +94,35 @@ class Plan:
     @property
     def stream(self):
         return self._lib.emagls_plan_stream(self._h)
+
+
+class Batch:
+    """Several eMagLS / eMagLS2 plans of identical shape executed together: per-design stages on the plans' own
+    streams, one sweep launch per frequency bin for all of them."""
+
+    def __init__(self, plans):
+        self._lib = L.load()
+        self.plans = list(plans)
+        arr = (C.c_void_p * len(self.plans))(*[p._h for p in self.plans])
+        self._h = C.c_void_p()
+        L.check(self._lib.emagls_batch_create(arr, len(self.plans), C.byref(self._h)))
+
+    def execute(self):
+        L.check(self._lib.emagls_batch_execute(self._h))
+
+    def synchronize(self):
+        L.check(self._lib.emagls_batch_synchronize(self._h))
+
+    def get_filters(self):
+        return [p.get_filters() for p in self.plans]
+
+    def close(self):
+        if self._h:
+            self._lib.emagls_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -142,6 +142,9 @@ int emagls_plan_synchronize(emagls_plan* plan);
 /* synchronise, check device-side status flags, copy the filters out */
 int emagls_plan_get_filters(emagls_plan* plan, void* wL, void* wR);
 int emagls_plan_get_info(emagls_plan* plan, emagls_plan_info* info);
+/* 1..3: number of HIP streams one design may use (independent branches fork onto side streams; default 3,
+ * best for the latency of ONE design; use 1 when several plans are in flight). Drops the captured graph. */
+int emagls_plan_set_streams(emagls_plan* plan, int nstreams);
 /* profiling: level 0 none, 1 = HIP events between stages, 2 = additionally around every sweep launch */
 int emagls_plan_set_profiling(emagls_plan* plan, int level);
 int emagls_plan_num_stages(emagls_plan* plan);
@@ -154,6 +157,16 @@ int emagls_plan_sweep_kernel_time(emagls_plan* plan, double* total_ms, int* laun
 int emagls_plan_debug_buffer(emagls_plan* plan, const char* name, void* dst, size_t* nbytes);
 /* the plan's hipStream_t, for callers that interleave their own work */
 void* emagls_plan_stream(emagls_plan* plan);
+
+/* ---- batches: several eMagLS / eMagLS2 designs of identical shape (different arrays / HRIR sets) ---------
+ * The per-design stages run on the plans' own streams; the sequential sweep is issued ONCE per frequency
+ * bin for all designs of the batch (the launch-bound part of a design).  At most 8 plans; the plans stay
+ * owned by the caller and must outlive the batch.  Results: emagls_plan_get_filters on each plan. */
+typedef struct emagls_batch emagls_batch;
+int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch);
+int emagls_batch_execute(emagls_batch* batch);
+int emagls_batch_synchronize(emagls_batch* batch);
+int emagls_batch_destroy(emagls_batch* batch);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,39 @@ def test_emagls_filters_config3_full(grids, hrirs):
     assert report("eMagLS config3 L", wL, oL) < TOL and report("eMagLS config3 R", wR, oR) < TOL
 
 
+def test_batch_of_designs_matches_single_designs(grids, thin):
+    """Four designs of the same shape (two array radii x two HRIR sets) executed as one batch -- one sweep launch
+    per bin for all of them -- give bit-identical filters to four separate designs, also under graph replay."""
+    from emagls_amd import Batch, Plan, _lib as L, synth
+    hL2, hR2 = synth.rigid_sphere_hrirs(thin["azi"], thin["zen"], seed=99)
+    jobs = [(0.042, thin["hL"], thin["hR"]), (0.040, thin["hL"], thin["hR"]), (0.042, hL2, hR2), (0.040, hL2, hR2)]
+    plans, singles = [], []
+    for r, hL, hR in jobs:
+        def mk():
+            p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, hL.shape[0], hL.shape[1], r, 32)
+            p.set_hrir_grid(thin["azi"], thin["zen"])
+            p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+            p.set_hrirs(hL, hR)
+            return p
+        q = mk()
+        q.execute()
+        singles.append(q.get_filters())
+        q.close()
+        plans.append(mk())
+    b = Batch(plans)
+    for it in range(3):  # eager, captured, replayed
+        b.execute()
+        res = b.get_filters()
+        for (wL, wR), (sL, sR) in zip(res, singles):
+            assert np.array_equal(wL, sL) and np.array_equal(wR, sR), it
+    oL, oR = O.getEMagLsFilters(jobs[3][1], jobs[3][2], thin["azi"], thin["zen"], 0.040, grids["mic_azi"], grids["mic_zen"], 4,
+                                48000.0, 128, "complex")
+    assert rel(res[3][0], oL) < TOL and rel(res[3][1], oR) < TOL
+    b.close()
+    for p in plans:
+        p.close()
+
+
 def test_from_atf_small(thin):
     import emagls_amd as E
     from emagls_amd import synth
