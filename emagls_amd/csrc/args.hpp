@@ -72,6 +72,28 @@ struct DenseSweepArgs {
     int kfirst;
 };
 
+// sweep on ONE direction-space operand per bin: Y_reg_inv_k = conj(G_k) conj(M_k) is applied as
+//   v = t conj(G_k) (per workgroup partial)  ->  W(k,:) = (sum of partials) conj(M_k)  at the start of the next launch
+struct HalfSweepArgs {
+    int D, C, ldD, P;
+    const cplx* G;          // [kb][c][ldD], base shifted so that it is indexed by kb
+    int64_t g_stride;
+    const cplx* Yri;        // same indexing; only ill-conditioned bins (cond_ok == 0) are filled and used
+    const cplx* Mw;         // [kb][C][C], base shifted so that it is indexed by kb
+    const double* cond_ok;  // [P]
+    const double* Habs;     // [e][kb-kabs0][ldH]
+    int64_t ldH;
+    int kabs0;
+    cplx* Wpart;            // [2][pair][nWG]
+    cplx* W;                // [e][P][C]
+    int nWG;
+    int kfirst;
+};
+struct HalfSweepMulti {
+    int n;
+    HalfSweepArgs a[8];
+};
+
 constexpr int SWEEP_MULTI_MAX = 8;
 struct DenseSweepMulti {
     int n;

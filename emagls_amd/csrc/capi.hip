@@ -49,6 +49,8 @@ struct emagls_plan {
     // two tiny kernels per bin (slab + reduce) instead of one with a redundant gather: slower for ONE design
     // (two launch floors per bin), faster when a batch shares the launches; batches switch it on
     bool sweep_split = false;
+    // one direction-space operand per bin (G_k; M_k applied after the cross-workgroup sum): default
+    bool sweep_half = true;
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
     // profiling
     int prof_level = 0;
@@ -343,6 +345,8 @@ void plan_setup(emagls_plan& p) {
         p.nWG_dense = dense_sweep_nwg((int)Dh);
         p.nWG_split = slab_sweep_nwg((int)Dh);
         if (const char* e = getenv("EMAGLS_SWEEP_SPLIT")) p.sweep_split = e[0] == '1';
+        if (const char* e = getenv("EMAGLS_SWEEP_HALF")) p.sweep_half = e[0] != '0';
+        if (p.sweep_split || p.sweep_factored) p.sweep_half = false;
         if (p.nWG_split > 256 || 2 * p.C > 64) p.sweep_split = false;
         p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(std::max(p.nWG, p.nWG_dense), p.nWG_split) * 2 * p.C);
         p.out_rows = d.len;
@@ -550,8 +554,11 @@ void emagls_pre_sweep(emagls_plan& p) {
     // join s1 (G)
     p.depend(s0, s1);
     if (!p.sweep_factored) {
-        launch_dspace_yri(p.get("G"), p.ldD, p.get("Mw"), 1, p.get<double>("sv"), p.get<double>("cond_ok"), (int)p.D, p.C, p.P, k0,
-                          p.get("Yri"), s0);
+        if (p.sweep_half)
+            launch_cond_flags(p.get<double>("sv"), p.C, p.P, p.get<double>("cond_ok"), s0);
+        else
+            launch_dspace_yri(p.get("G"), p.ldD, p.get("Mw"), 1, p.get<double>("sv"), p.get<double>("cond_ok"), (int)p.D, p.C, p.P,
+                              k0, p.get("Yri"), s0);
         launch_yri_accurate(p.get("Q"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
                             p.get("Yri"), p.ldD, s0);
         p.mark("yri_operands");
@@ -567,6 +574,20 @@ DenseSweepArgs emagls_dense_args(emagls_plan& p) {
     a.Zd = p.get<cplx>("Yri") - (int64_t)k0 * p.C * p.ldD; a.z_stride = (int64_t)p.C * p.ldD;
     a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
     a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.sweep_split ? p.nWG_split : p.nWG_dense; a.kfirst = k0;
+    return a;
+}
+
+HalfSweepArgs emagls_half_args(emagls_plan& p) {
+    const int k0 = std::max(p.kcut0, 1);
+    HalfSweepArgs a{};
+    a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
+    a.g_stride = (int64_t)p.C * p.ldD;
+    a.G = p.get<cplx>("G") - (int64_t)k0 * a.g_stride;      // indexed by kb
+    a.Yri = p.get<cplx>("Yri") - (int64_t)k0 * a.g_stride;
+    a.Mw = p.get<cplx>("Mw") - (int64_t)1 * p.C * p.C;      // factor stage stores bin kb at slot kb-1
+    a.cond_ok = p.get<double>("cond_ok");
+    a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
+    a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG_dense; a.kfirst = k0;
     return a;
 }
 
@@ -590,6 +611,18 @@ void emagls_run_sweep(emagls_plan& p) {
             ++p.sweep_launches;
         }
         if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, s0);
+    } else if (p.sweep_half) {
+        HalfSweepMulti m{};
+        m.n = 1;
+        m.a[0] = emagls_half_args(p);
+        p.sweep_launches = 0;
+        for (int kb = k0; kb < p.P; ++kb) {
+            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
+            launch_sweep_half(m, kb, s0);
+            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
+            ++p.sweep_launches;
+        }
+        if (k0 < p.P) launch_sweep_half_finalize(m, p.P - 1, s0);
     } else {
         const DenseSweepArgs a = emagls_dense_args(p);
         DenseSweepMulti m{};
@@ -737,6 +770,16 @@ void plan_pre_stage(emagls_plan& p) {
     emagls_pre_sweep(p);
 }
 void batch_sweep_stage(emagls_batch& b) {
+    if (b.plans[0]->sweep_half) {
+        HalfSweepMulti h{};
+        h.n = (int)b.plans.size();
+        for (int j = 0; j < h.n; ++j) h.a[j] = emagls_half_args(*b.plans[j]);
+        emagls_plan& q0 = *b.plans[0];
+        const int kk0 = std::max(q0.kcut0, 1);
+        for (int kb = kk0; kb < q0.P; ++kb) launch_sweep_half(h, kb, b.stream);
+        if (kk0 < q0.P) launch_sweep_half_finalize(h, q0.P - 1, b.stream);
+        return;
+    }
     DenseSweepMulti m{};
     m.n = (int)b.plans.size();
     for (int j = 0; j < m.n; ++j) m.a[j] = emagls_dense_args(*b.plans[j]);
@@ -1092,7 +1135,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
             if (p->d.kind != EMAGLS_KIND_EMAGLS && p->d.kind != EMAGLS_KIND_EMAGLS2) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 plans");
             if (p->sweep_factored) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches need the direction-space sweep");
             const emagls_plan* q = plans[0];
-            if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_split != q->sweep_split)
+            if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_split != q->sweep_split || p->sweep_half != q->sweep_half)
                 throw Error(EMAGLS_ERR_ARG, "all designs of a batch must have the same shape (directions, channels, bins, k_cut)");
             b->plans.push_back(p);
         }
@@ -1103,7 +1146,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         if (const char* e = getenv("EMAGLS_SWEEP_SPLIT")) can_split = can_split && e[0] != '0';
         for (auto* p : b->plans) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
-            p->sweep_split = can_split && b->plans.size() > 1;
+            p->sweep_split = !p->sweep_half && can_split && b->plans.size() > 1;
             p->nstreams = 1;
             p->prof_level = 0;
             p->sync_stream = b->stream;

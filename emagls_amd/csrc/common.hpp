@@ -98,13 +98,13 @@ __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, s
 __device__ __forceinline__ double fast_rcp(double x) {
     double y = __builtin_amdgcn_rcp(x);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) y = fma(fma(-x, y, 1.0), y, y);
+    for (int i = 0; i < 2; ++i) y = fma(fma(-x, y, 1.0), y, y);
     return y;
 }
 __device__ __forceinline__ double fast_rsqrt(double x) {
     double y = __builtin_amdgcn_rsq(x);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const double e = fma(-x * y, y, 1.0);        // 1 - x y^2
         y = fma(y * e, fma(0.375, e, 0.5), y);       // y (1 + e/2 + 3 e^2/8)
     }

@@ -189,6 +189,10 @@ void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, 
     if (is_cplx) dspace_g_impl<cplx>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
     else dspace_g_impl<double>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
 }
+void launch_cond_flags(const double* sv, int C, int P, double* cond_ok, hipStream_t st) {
+    cond_flag_kernel<<<(P + 255) / 256, 256, 0, st>>>(sv, C, P, cond_ok);
+    KERNEL_CHECK();
+}
 void launch_dspace_yri(const void* G, int64_t ldD, const void* Mw, int kb0_factor, const double* sv, double* cond_ok, int D, int C,
                        int P, int k0, void* Yri, hipStream_t st) {
     const int nbins = P - k0;

@@ -126,69 +126,79 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// diagonal block: one wave factors G(J,J) in place (wave-synchronous LDS, the trailing update of each of the
+// 32 steps spread over the 64 lanes).  A separate launch, so the row-panel workgroups below read a factor
+// that can no longer change (they used to re-factor a block that workgroup 0 was overwriting: a race).
 template <typename T>
-__global__ void __launch_bounds__(256) chol_panel_kernel(T* __restrict__ G, int S, int j0, int* __restrict__ flag) {
-    __shared__ T Rd[NB][NB + 1];   // upper factor of the diagonal block
-    __shared__ T Li[NB][NB + 1];   // (R_JJ^H)^-1, lower triangular
-    __shared__ T Gs[NB][NB + 1];   // this workgroup's slice G(J, c0..c0+32)
+__global__ void __launch_bounds__(64) chol_diag_kernel(T* __restrict__ G, int S, int j0, int* __restrict__ flag) {
+    __shared__ T Rd[NB][NB + 1];
     const int nb = min(NB, S - j0);
-    const int tid = threadIdx.x;
-    const int c0 = j0 + blockIdx.x * NB;
+    const int lane = threadIdx.x;
+    for (int idx = lane; idx < NB * NB; idx += 64) {
+        const int r = idx / NB, c = idx % NB;
+        Rd[r][c] = (r < nb && c < nb && r <= c) ? G[(int64_t)(j0 + r) * S + j0 + c] : zero_of<T>();
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int j = 0; j < nb; ++j) {
+        const double piv = real_of(Rd[j][j]);
+        if (!(piv > 0.0)) bad = true;
+        const double dinv = fast_rsqrt(piv > 0.0 ? piv : 1.0);
+        wave_lds_fence();
+        if (lane >= j && lane < nb) Rd[j][lane] = scale_real(Rd[j][lane], dinv);  // diag becomes sqrt(piv)
+        wave_lds_fence();
+        const int m = nb - j - 1;
+        for (int idx = lane; idx < m * m; idx += 64) {
+            const int r = j + 1 + idx / m, c = j + 1 + idx % m;
+            if (r <= c) {
+                T acc = zero_of<T>();
+                cfma_conj(acc, Rd[j][r], Rd[j][c]);
+                Rd[r][c] = Rd[r][c] - acc;
+            }
+        }
+        wave_lds_fence();
+    }
+    if (bad && lane == 0) atomicExch(flag, 1 + j0);
+    for (int idx = lane; idx < NB * NB; idx += 64) {
+        const int r = idx / NB, c = idx % NB;
+        if (r < nb && c < nb && r <= c) G[(int64_t)(j0 + r) * S + j0 + c] = Rd[r][c];
+    }
+}
+
+// row panel: R(J, c) = L^-1 G(J, c), L = R_JJ^H (already factored): right-looking forward substitution; each wave
+// owns 8 of the workgroup's 32 columns (lane = (column cl, row lane rl)), no workgroup barriers inside
+template <typename T>
+__global__ void __launch_bounds__(256) chol_panel_kernel(T* __restrict__ G, int S, int j0) {
+    __shared__ T Rd[NB][NB + 1];
+    __shared__ T Gs[NB][NB + 1];
+    const int nb = min(NB, S - j0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c0 = j0 + (blockIdx.x + 1) * NB;
     for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
         const int r = idx / NB, c = idx % NB;
         Rd[r][c] = (r < nb && c < nb && r <= c) ? G[(int64_t)(j0 + r) * S + j0 + c] : zero_of<T>();
-        Li[r][c] = zero_of<T>();
-        Gs[r][c] = (blockIdx.x > 0 && r < nb && c0 + c < S) ? G[(int64_t)(j0 + r) * S + c0 + c] : zero_of<T>();
+        Gs[r][c] = (r < nb && c0 + c < S) ? G[(int64_t)(j0 + r) * S + c0 + c] : zero_of<T>();
     }
     __syncthreads();
-    if (tid < 64) {
-        const int c = tid & 31, half = tid >> 5;  // two lanes per column
-        bool bad = false;
-        for (int j = 0; j < nb; ++j) {
-            const double piv = real_of(Rd[j][j]);
-            if (!(piv > 0.0)) bad = true;
-            const double dinv = 1.0 / sqrt(piv > 0.0 ? piv : 1.0);
+    {
+        const int cl = wave * 8 + (lane & 7), rl = lane >> 3;
+        for (int i = 0; i < nb; ++i) {
+            const double dinv = 1.0 / real_of(Rd[i][i]);
             wave_lds_fence();
-            if (half == 0 && c >= j && c < nb) Rd[j][c] = scale_real(Rd[j][c], dinv);  // diag becomes sqrt(piv)
+            if (rl == 0) Gs[i][cl] = scale_real(Gs[i][cl], dinv);
             wave_lds_fence();
-            if (c > j && c < nb) {
-                const T rjc = Rd[j][c];
-                for (int r = j + 1 + half; r <= c; r += 2) {
-                    T acc = zero_of<T>();
-                    cfma_conj(acc, Rd[j][r], rjc);
-                    Rd[r][c] = Rd[r][c] - acc;
-                }
-            }
-            wave_lds_fence();
-        }
-        if (bad && tid == 0) atomicExch(flag, 1 + j0);
-        // Li = L^-1, L[i][l] = conj(Rd[l][i]); lane c builds column c by forward substitution
-        if (half == 0 && c < nb) {
-            Li[c][c] = scale_real(to_T<T>(1.0), 1.0 / real_of(Rd[c][c]));
-            for (int i = c + 1; i < nb; ++i) {
+            const T xi = Gs[i][cl];
+            for (int r = i + 1 + rl; r < nb; r += 8) {
                 T acc = zero_of<T>();
-                for (int l = c; l < i; ++l) cfma_conj(acc, Rd[l][i], Li[l][c]);
-                Li[i][c] = scale_real(zero_of<T>() - acc, 1.0 / real_of(Rd[i][i]));
+                cfma_conj(acc, Rd[i][r], xi);
+                Gs[r][cl] = Gs[r][cl] - acc;
             }
         }
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
-        for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
-            const int r = idx / NB, c = idx % NB;
-            if (r < nb && c < nb && r <= c) G[(int64_t)(j0 + r) * S + j0 + c] = Rd[r][c];
-        }
-    } else {
-        for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
-            const int i = idx / NB, c = idx % NB;
-            if (i < nb && c0 + c < S) {
-                T a0 = zero_of<T>(), a1 = zero_of<T>();
-                int l = 0;
-                for (; l + 1 <= i; l += 2) { cfma(a0, Li[i][l], Gs[l][c]); cfma(a1, Li[i][l + 1], Gs[l + 1][c]); }
-                if (l <= i) cfma(a0, Li[i][l], Gs[l][c]);
-                G[(int64_t)(j0 + i) * S + c0 + c] = a0 + a1;
-            }
-        }
+    for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+        const int i = idx / NB, c = idx % NB;
+        if (i < nb && c0 + c < S) G[(int64_t)(j0 + i) * S + c0 + c] = Gs[i][c];
     }
 }
 
@@ -236,41 +246,67 @@ __global__ void __launch_bounds__(256) qform_kernel(const T* __restrict__ Yc, co
                                                     int64_t ld, T* __restrict__ Q) {
     constexpr int TR = 8;
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    T* qs = reinterpret_cast<T*>(dyn);  // [TR][ldq]
+    T* qs = reinterpret_cast<T*>(dyn);        // [TR][ldq] finished Q entries of this workgroup's rows
     const int ldq = S + 1;
+    T* rt = qs + (size_t)TR * ldq;            // [2][32][33] staged 32x32 tiles of R (double buffered)
     const int tid = threadIdx.x, r = tid >> 5, c = tid & 31;
     const int64_t d = (int64_t)blockIdx.x * TR + r;
     const bool rowok = d < D;
     const int lane_base = (tid & 32);  // first lane of this half wave inside its wave
+    // cooperative tile load: thread (r, c) fetches rows r, r+8, r+16, r+24 of a 32 x 32 tile
+    auto load_tile = [&](int i0, int j0, T (&v)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + r + 8 * k, j = j0 + c;
+            v[k] = (i < S && j < S) ? R[(int64_t)i * S + j] : zero_of<T>();
+        }
+    };
+    auto store_tile = [&](int buf, const T (&v)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rt[((size_t)buf * 32 + r + 8 * k) * 33 + c] = v[k];
+    };
     for (int j0 = 0; j0 < S; j0 += 32) {
         const int col = j0 + c;
         const bool colok = col < S;
         T acc0 = (rowok && colok) ? Yc[d * ld + col] : zero_of<T>();
         T acc1 = zero_of<T>();
-        if (colok) {
-            const T* qrow = qs + (size_t)r * ldq;
-            int i = 0;
-            for (; i + 1 < j0; i += 2) {
-                T p0 = zero_of<T>(), p1 = zero_of<T>();
-                cfma(p0, qrow[i], R[(int64_t)i * S + col]);
-                cfma(p1, qrow[i + 1], R[(int64_t)(i + 1) * S + col]);
-                acc0 = acc0 - p0;
-                acc1 = acc1 - p1;
+        // tiles (i0, j0) for i0 = 0, 32, ..., j0 (the last one is the diagonal block used by the solve)
+        const int ntiles = j0 / 32 + 1;
+        T v[4];
+        load_tile(0, j0, v);
+        for (int t = 0; t < ntiles; ++t) {
+            const int buf = t & 1;
+            store_tile(buf, v);
+            if (t + 1 < ntiles) load_tile(32 * (t + 1), j0, v);  // next tile in flight while this one is used
+            __syncthreads();
+            const T* tile = rt + (size_t)buf * 32 * 33;
+            if (t + 1 < ntiles) {
+                const T* qrow = qs + (size_t)r * ldq + 32 * t;
+#pragma unroll 8
+                for (int ii = 0; ii < 32; ii += 2) {
+                    T p0 = zero_of<T>(), p1 = zero_of<T>();
+                    cfma(p0, qrow[ii], tile[ii * 33 + c]);
+                    cfma(p1, qrow[ii + 1], tile[(ii + 1) * 33 + c]);
+                    acc0 = acc0 - p0;
+                    acc1 = acc1 - p1;
+                }
+            } else {
+                // diagonal block: forward substitution inside the 32-lane half wave
+                T x = acc0 + acc1;
+                const int nb = min(32, S - j0);
+                for (int j = 0; j < nb; ++j) {
+                    const double dinv = 1.0 / real_of(tile[j * 33 + j]);
+                    if (c == j) x = scale_real(x, dinv);
+                    const T xj = shfl_T<T>(x, lane_base + j);
+                    if (c > j) { T p = zero_of<T>(); cfma(p, xj, tile[j * 33 + c]); x = x - p; }
+                }
+                if (colok) {
+                    qs[(size_t)r * ldq + col] = x;
+                    if (rowok) Q[d * ld + col] = x;
+                }
             }
-            if (i < j0) { T p0 = zero_of<T>(); cfma(p0, qrow[i], R[(int64_t)i * S + col]); acc0 = acc0 - p0; }
-        }
-        T x = acc0 + acc1;
-        // forward substitution across the 32 columns of the block: x_j final once columns < j are eliminated
-        const int nb = min(32, S - j0);
-        for (int j = 0; j < nb; ++j) {
-            const double dinv = 1.0 / real_of(R[(int64_t)(j0 + j) * S + j0 + j]);
-            if (c == j) x = scale_real(x, dinv);
-            const T xj = shfl_T<T>(x, lane_base + j);
-            if (c > j && colok) { T p = zero_of<T>(); cfma(p, xj, R[(int64_t)(j0 + j) * S + col]); x = x - p; }
-        }
-        if (colok) {
-            qs[(size_t)r * ldq + col] = x;
-            if (rowok) Q[d * ld + col] = x;
+            // the buffer written two tiles ago is free again only after everyone has read it: the barrier at
+            // the top of the next iteration (after store_tile into the OTHER buffer) provides that
         }
         __syncthreads();
     }
@@ -339,10 +375,12 @@ template <typename T> static void chol_impl(void* G, int S, int* flag, hipStream
     for (int j0 = 0; j0 < S; j0 += NB) {
         const int rem = S - j0;
         const int ncb = (rem + NB - 1) / NB;  // column blocks incl. the diagonal one
-        chol_panel_kernel<T><<<ncb, 256, 0, st>>>((T*)G, S, j0, flag);
+        chol_diag_kernel<T><<<1, 64, 0, st>>>((T*)G, S, j0, flag);
         KERNEL_CHECK();
         const int nbt = ncb - 1;
         if (nbt > 0) {
+            chol_panel_kernel<T><<<nbt, 256, 0, st>>>((T*)G, S, j0);
+            KERNEL_CHECK();
             chol_update_kernel<T><<<nbt * (nbt + 1) / 2, 256, 0, st>>>((T*)G, S, j0, nbt);
             KERNEL_CHECK();
         }
@@ -354,7 +392,7 @@ void launch_cholesky(void* G, int S, bool is_cplx, int* flag, hipStream_t st) {
 
 template <typename T> static void qform_impl(const void* Yc, const void* R, int S, int64_t D, int64_t ld, void* Q, hipStream_t st) {
     const unsigned grid = (unsigned)ceil_div(D, 8);
-    const size_t dyn = sizeof(T) * (size_t)8 * (S + 1);
+    const size_t dyn = sizeof(T) * ((size_t)8 * (S + 1) + 2 * 32 * 33);
     if (dyn > 150 * 1024) throw Error(2, "qform: more than 1024 SH channels is not supported in this build");
     static bool attr_set = false;
     if (!attr_set) {

@@ -51,10 +51,14 @@ void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st,
 struct SweepArgs;
 struct DenseSweepArgs;
 struct DenseSweepMulti;
+struct HalfSweepArgs;
+struct HalfSweepMulti;
 void launch_sweep_factored(const SweepArgs& a, int kb, bool q_cplx, hipStream_t st);
 void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st);
 int dense_sweep_nwg(int D);
 int slab_sweep_nwg(int D);
+void launch_sweep_half(const HalfSweepMulti& m, int kb, hipStream_t st);
+void launch_sweep_half_finalize(const HalfSweepMulti& m, int kb_last, hipStream_t st);
 void launch_sweep_split(const DenseSweepMulti& m, int kb, hipStream_t st);
 void launch_sweep_dense_multi(const DenseSweepMulti& m, int kb, hipStream_t st);
 void launch_sweep_finalize_multi(const DenseSweepMulti& m, int kb_last, hipStream_t st);
@@ -76,6 +80,7 @@ void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S
                int64_t ldD, hipStream_t st);
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
                      hipStream_t st);
+void launch_cond_flags(const double* sv, int C, int P, double* cond_ok, hipStream_t st);
 void launch_dspace_yri(const void* G, int64_t ldD, const void* Mw, int kb0_factor, const double* sv, double* cond_ok, int D, int C,
                        int P, int k0, void* Yri, hipStream_t st);
 void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S,

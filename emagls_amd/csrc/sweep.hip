@@ -410,6 +410,196 @@ __global__ void __launch_bounds__(SW_NT) sweep_finalize_multi_kernel(DenseSweepM
 }
 
 // ---------------------------------------------------------------------------------------------
+// Halved sweep: one direction-space operand per bin.  With Y_reg_inv_k = conj(G_k) conj(M_k):
+//   launch kb:  W(kb-1,:) = (sum of the previous launch's partials) conj(M_{kb-1})        [C x C, every workgroup]
+//               p = W(kb-1,:) G_kb^T ; t = |H| p/|p| ; partial v = t conj(G_kb) over this workgroup's slab
+// The G slab is fetched once into LDS and used for both products, so a workgroup reads 800 B x nWG of
+// partials + 25.6 KB of G + 10 KB of M instead of two 25.6 KB slabs.  Ill-conditioned bins (cond_ok == 0, rare:
+// tiny arrays) take their accurate Y_reg_inv slab from memory instead and skip the M product.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sweep_half_body(const HalfSweepArgs& a, int kb, char* dyn) {
+    __shared__ __attribute__((aligned(16))) cplx Wp[64];
+    __shared__ __attribute__((aligned(16))) cplx vt[64];
+    __shared__ __attribute__((aligned(16))) cplx ts[2][DS_DPW];
+    const int tid = threadIdx.x;
+    const int C = a.C, nWG = a.nWG;
+    cplx* xs = reinterpret_cast<cplx*>(dyn);                  // [C][DS_DPW+1]   G slab
+    cplx* ms = xs + (size_t)C * (DS_DPW + 1);                 // [C][C]          M of the previous bin
+    cplx* stage = ms + (size_t)C * C;                         // [2C][nWG+1]     partial sums of the previous launch
+    const bool nyq = (kb == a.P - 1);
+    const bool first = (kb == a.kfirst);
+    const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * nWG * 2 * C;
+    cplx* Wout = a.Wpart + (int64_t)(kb & 1) * nWG * 2 * C;
+    const cplx* X = a.G + (int64_t)kb * a.g_stride;
+    const int64_t d0 = (int64_t)blockIdx.x * DS_DPW;
+    const int64_t na = a.P - a.kabs0;
+    // ---- 0. all loads up front; the previous launch's partial sums first (they gate the chain)
+    constexpr int NGV = 16;
+    const int npart = 2 * C * nWG;
+    cplx gv[NGV];
+#pragma unroll
+    for (int i = 0; i < NGV; ++i) {
+        const int f = tid + DS_NT * i;
+        gv[i] = (!first && f < npart) ? Wprev[f] : mk(0, 0);
+    }
+    constexpr int NXV = (SW_CMAX * DS_DPW) / DS_NT;  // 8 slab elements per thread
+    cplx xv[NXV];
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+        const int f = tid + DS_NT * i, c = f / DS_DPW, dd = f % DS_DPW;
+        xv[i] = (c < C && d0 + dd < a.D) ? X[(int64_t)c * a.ldD + d0 + dd] : mk(0, 0);
+    }
+    constexpr int NMV = (SW_CMAX * SW_CMAX) / DS_NT;  // 4 elements of M per thread
+    const cplx* M = a.Mw + (int64_t)(kb - 1) * C * C;
+    cplx mv[NMV];
+#pragma unroll
+    for (int i = 0; i < NMV; ++i) {
+        const int f = tid + DS_NT * i;
+        mv[i] = (!first && f < C * C) ? M[f] : mk(0, 0);
+    }
+    const int e_ = tid / DS_DPW, dd_ = tid % DS_DPW;
+    const int64_t d_ = d0 + dd_;
+    const bool p1 = tid < 2 * DS_DPW && d_ < a.D;
+    const double habs = p1 ? a.Habs[((int64_t)e_ * na + (kb - a.kabs0)) * a.ldH + d_] : 0.0;
+    const bool prev_ok = first ? true : (a.cond_ok[kb - 1] != 0.0);
+    const bool cur_ok = a.cond_ok[kb] != 0.0;
+    // ---- 1. stage everything in LDS
+#pragma unroll
+    for (int i = 0; i < NGV; ++i) {
+        const int f = tid + DS_NT * i;
+        if (f < npart) stage[f + f / nWG] = gv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+        const int f = tid + DS_NT * i, c = f / DS_DPW, dd = f % DS_DPW;
+        if (c < C) xs[(size_t)c * (DS_DPW + 1) + dd] = xv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NMV; ++i) {
+        const int f = tid + DS_NT * i;
+        if (f < C * C) ms[f] = mv[i];
+    }
+    __syncthreads();
+    // ---- 2. v_total[pair] = sum over workgroups
+    for (int pair = tid >> 2; pair < 2 * C; pair += DS_NT >> 2) {
+        const int part = tid & 3;
+        cplx acc = mk(0, 0);
+        if (first) {
+            if (part == 0) acc = a.W[((int64_t)(pair / C) * a.P + (kb - 1)) * C + pair % C];
+        } else {
+            const cplx* row = stage + (size_t)pair * (nWG + 1);
+            cplx a0 = mk(0, 0), a1 = mk(0, 0);
+            for (int w = part; w < nWG; w += 8) {
+                a0 += row[w];
+                if (w + 4 < nWG) a1 += row[w + 4];
+            }
+            acc = a0 + a1;
+        }
+        acc = group_sum<4>(acc);
+        if (part == 0) vt[pair] = acc;
+    }
+    __syncthreads();
+    // ---- 3. W(kb-1,:) = v_total conj(M_{kb-1})   (identity for the first swept bin and for ill-conditioned bins)
+    for (int pair = tid >> 2; pair < 2 * C; pair += DS_NT >> 2) {
+        const int part = tid & 3;
+        const int e = pair / C, c = pair % C;
+        cplx acc = mk(0, 0);
+        if (first || !prev_ok) {
+            if (part == 0) acc = vt[pair];
+        } else {
+            for (int cc = part; cc < C; cc += 4) cfma(acc, vt[e * C + cc], conj(ms[cc * C + c]));
+        }
+        acc = group_sum<4>(acc);
+        if (part == 0) {
+            Wp[pair] = acc;
+            if (blockIdx.x == 0 && !first) a.W[((int64_t)e * a.P + (kb - 1)) * C + c] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- 4. p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
+    if (tid < 2 * DS_DPW) {
+        cplx t = mk(0, 0);
+        if (p1) {
+            cplx pa = mk(0, 0), pb = mk(0, 0);
+            int c = 0;
+            for (; c + 1 < C; c += 2) {
+                cfma(pa, Wp[e_ * C + c], xs[(size_t)c * (DS_DPW + 1) + dd_]);
+                cfma(pb, Wp[e_ * C + c + 1], xs[(size_t)(c + 1) * (DS_DPW + 1) + dd_]);
+            }
+            if (c < C) cfma(pa, Wp[e_ * C + c], xs[(size_t)c * (DS_DPW + 1) + dd_]);
+            t = unit_phase_times(habs, pa + pb, nyq);
+        }
+        ts[e_][dd_] = t;
+    }
+    __syncthreads();
+    // ---- 5. partial of this slab: v = t conj(G)  (or t Y_reg_inv for an ill-conditioned bin); 4 lanes per (e,c)
+    {
+        const int pair = tid >> 2, part = tid & 3;
+        if (pair < 2 * C) {
+            const int e = pair / C, c = pair % C;
+            cplx a0 = mk(0, 0), a1 = mk(0, 0);
+            if (cur_ok) {
+                const cplx* xrow = xs + (size_t)c * (DS_DPW + 1);
+#pragma unroll
+                for (int j = 0; j < DS_DPW / 4; j += 2) {
+                    cfma(a0, ts[e][part + 4 * j], conj(xrow[part + 4 * j]));
+                    cfma(a1, ts[e][part + 4 * (j + 1)], conj(xrow[part + 4 * (j + 1)]));
+                }
+            } else {
+                const cplx* Y = a.Yri + (int64_t)kb * a.g_stride + (int64_t)c * a.ldD;
+                for (int dd = part; dd < DS_DPW; dd += 4)
+                    if (d0 + dd < a.D) cfma(a0, ts[e][dd], Y[d0 + dd]);
+            }
+            cplx acc = group_sum<4>(a0 + a1);
+            if (part == 0) Wout[((int64_t)e * C + c) * nWG + blockIdx.x] = acc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(DS_NT) sweep_half_kernel(HalfSweepMulti m, int kb) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    sweep_half_body(m.a[blockIdx.y], kb, dyn);
+}
+
+// after the last swept bin: W(P-1,:) = (sum of partials) conj(M_{P-1})
+__global__ void __launch_bounds__(256) sweep_half_finalize_kernel(HalfSweepMulti m, int kb_last) {
+    const HalfSweepArgs& a = m.a[blockIdx.x];
+    __shared__ cplx vt[64];
+    const int C = a.C, nWG = a.nWG;
+    const cplx* Wprev = a.Wpart + (int64_t)(kb_last & 1) * nWG * 2 * C;
+    const int tid = threadIdx.x;
+    for (int pair = tid >> 2; pair < 2 * C; pair += 64) {
+        const int part = tid & 3;
+        cplx acc = mk(0, 0);
+        for (int w = part; w < nWG; w += 4) acc += Wprev[(int64_t)pair * nWG + w];
+        acc = group_sum<4>(acc);
+        if (part == 0) vt[pair] = acc;
+    }
+    __syncthreads();
+    const bool ok = a.cond_ok[kb_last] != 0.0;
+    const cplx* M = a.Mw + (int64_t)kb_last * C * C;
+    for (int pair = tid; pair < 2 * C; pair += 256) {
+        const int e = pair / C, c = pair % C;
+        cplx acc = mk(0, 0);
+        if (ok) { for (int cc = 0; cc < C; ++cc) cfma(acc, vt[e * C + cc], conj(M[cc * C + c])); }
+        else acc = vt[pair];
+        a.W[((int64_t)e * a.P + kb_last) * C + c] = acc;
+    }
+}
+
+void launch_sweep_half(const HalfSweepMulti& m, int kb, hipStream_t st) {
+    const HalfSweepArgs& a = m.a[0];
+    if (2 * a.C * a.nWG > 16 * DS_NT || a.C > SW_CMAX) throw Error(2, "halved sweep: shape not supported");
+    const size_t dyn = sizeof(cplx) * ((size_t)a.C * (DS_DPW + 1) + (size_t)a.C * a.C + (size_t)2 * a.C * (a.nWG + 1));
+    sweep_half_kernel<<<dim3(a.nWG, m.n), DS_NT, dyn, st>>>(m, kb);
+    KERNEL_CHECK();
+}
+void launch_sweep_half_finalize(const HalfSweepMulti& m, int kb_last, hipStream_t st) {
+    sweep_half_finalize_kernel<<<m.n, 256, 0, st>>>(m, kb_last);
+    KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Split sweep: two tiny kernels per bin instead of one kernel in which every workgroup re-reads all
 // partial sums (a launch starts with cold L2, so per-launch time is set by the bytes each workgroup fetches).
 //   slab kernel   (nWG x designs workgroups of one wave): reads W(k-1) (800 B), its 22-direction slabs of

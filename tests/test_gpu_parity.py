@@ -111,11 +111,18 @@ def test_batch_of_designs_matches_single_designs(grids, thin):
         q.close()
         plans.append(mk())
     b = Batch(plans)
+    first = None
     for it in range(3):  # eager, captured, replayed
         b.execute()
         res = b.get_filters()
         for (wL, wR), (sL, sR) in zip(res, singles):
-            assert np.array_equal(wL, sL) and np.array_equal(wR, sR), it
+            # the batch sums the per-workgroup partials in a different (fixed) order than a single design
+            assert rel(wL, sL) < 1e-12 and rel(wR, sR) < 1e-12, it
+        if first is None:
+            first = res
+        else:  # deterministic: eager, captured and replayed runs agree to the bit
+            for (wL, wR), (fL, fR) in zip(res, first):
+                assert np.array_equal(wL, fL) and np.array_equal(wR, fR), it
     oL, oR = O.getEMagLsFilters(jobs[3][1], jobs[3][2], thin["azi"], thin["zen"], 0.040, grids["mic_azi"], grids["mic_zen"], 4,
                                 48000.0, 128, "complex")
     assert rel(res[3][0], oL) < TOL and rel(res[3][1], oR) < TOL

@@ -139,7 +139,7 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
     js = p.debug("jsweeps", np.int32)
     assert 1 <= js[1:P].min() and js[1:P].max() <= 20, (js[1:P].min(), js[1:P].max())
     G = p.debug("G", np.complex128).reshape(-1, C, ldD)[:, :, :D]
-    Yri = p.debug("Yri", np.complex128).reshape(-1, C, ldD)[:, :, :D]
+    Mw = p.debug("Mw", np.complex128).reshape(P, C, C)  # bin kb is stored at slot kb-1
 
     def Bk(kb):
         b = bn[kb].copy()
@@ -157,7 +157,9 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
         if kb >= kcut0:
             X = Q @ B  # pwGrid.'  (D x C)
             assert rel(G[kb - kcut0].T, X) < 1e-12
-            assert rel(Yri[kb - kcut0].T, np.conj(Q) @ Zo) < 1e-9, (kb, rel(Yri[kb - kcut0].T, np.conj(Q) @ Zo))
+            # Y_reg_inv_k = conj(G_k) conj(M_k): the sweep applies conj(M_k) after the cross-workgroup sum
+            Yri = np.conj(G[kb - kcut0].T) @ np.conj(Mw[kb - 1])
+            assert rel(Yri, np.conj(Q) @ Zo) < 1e-9, (kb, rel(Yri, np.conj(Q) @ Zo))
     wL, wR = p.get_filters()
     oL, oR = O.getEMagLsFilters(emagls_plan["hL"], emagls_plan["hR"], emagls_plan["azi"], emagls_plan["zen"],
                                 grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "complex")
