@@ -257,6 +257,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Gp", esz(cb) * (size_t)gram_ksplit(p.D) * p.S * p.S);
         p.alloc("R", esz(cb) * (size_t)p.S * p.S);
         p.alloc("Q", esz(cb) * (size_t)p.D * p.ldS);
+        p.alloc("Rinv", esz(cb) * (size_t)ceil_div(p.S, 32) * 32 * 32);
     }
     if (d.kind == EMAGLS_KIND_LS || d.kind == EMAGLS_KIND_MAGLS) {
         p.alloc("Rb", sizeof(cplx) * (size_t)p.C * p.ldS);             // R as [c][s] complex
@@ -374,7 +375,7 @@ void stage_hrir_basis(emagls_plan& p) {
     p.mark("gram_mfma");
     launch_cholesky(p.get("R"), p.S, cb, p.get<int>("flag"), st);
     p.mark("cholesky");
-    launch_qform(p.get("Yc"), p.get("R"), p.S, p.D, p.ldS, cb, p.get("Q"), st);
+    launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, cb, p.get("Q"), st);
     p.mark("qform");
 }
 
@@ -528,7 +529,7 @@ void emagls_pre_sweep(emagls_plan& p) {
     }
     // s2 (after the prologue): Q = conj(Y) R^-1 and the least-squares right-hand sides H conj(Q)
     if (s2 != s0) HIP_CHECK(hipStreamWaitEvent(s2, e_R, 0));
-    launch_qform(p.get("Yc"), p.get("R"), p.S, p.D, p.ldS, cb, p.get("Q"), s2);
+    launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, cb, p.get("Q"), s2);
     launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Q"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, s2);
 
     // s0: T_n, per-bin QR + Jacobi

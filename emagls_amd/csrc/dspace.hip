@@ -176,10 +176,10 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
     const int nbins = P - k0;
     if (nbins <= 0) return;
     if (nOrders > DSP_NMAX) throw Error(2, "dspace: simulation order above 31 is not supported in this build");
-    const int chunks = 4;
+    int chunks = 4;
+    while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nOrders > 56 * 1024) ++chunks;  // b_n table of a chunk in LDS
     const int bpc = (nbins + chunks - 1) / chunks;
     const size_t dyn = sizeof(cplx) * (size_t)bpc * nOrders;
-    if (dyn > 60 * 1024) throw Error(2, "dspace: too many bins per chunk");
     dspace_g_kernel<T><<<dim3((unsigned)ceil_div(D, DSP_TD), chunks), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D,
                                                                                      C, P, k0, bpc, (cplx*)G);
     KERNEL_CHECK();

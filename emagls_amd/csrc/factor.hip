@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a) {
                     int p, q;
                     if (pi == 0) { p = Cp - 1; q = r; }
                     else { p = (r + pi) % (Cp - 1); q = (r - pi + (Cp - 1)) % (Cp - 1); }
-                    cplx xp[RL], xq[RL];
+                    cplx xp[RL], xq[RL], vp[RL], vq[RL];
                     double al = 0.0, be = 0.0;
                     cplx ga = mk(0, 0);
 #pragma unroll
@@ -187,6 +187,8 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a) {
                         const int row = gl + GL * t;
                         xp[t] = Xs[p][row];
                         xq[t] = Xs[q][row];
+                        vp[t] = Vs[p][row];  // fetched with X: the rotation below then has no LDS latency left
+                        vq[t] = Vs[q][row];
                         al += norm2(xp[t]);
                         be += norm2(xq[t]);
                         cfma_conj(ga, xp[t], xq[t]);
@@ -211,9 +213,8 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a) {
                             const int row = gl + GL * t;
                             Xs[p][row] = cs * xp[t] - spc * xq[t];
                             Xs[q][row] = sph * xp[t] + cs * xq[t];
-                            const cplx vp = Vs[p][row], vq = Vs[q][row];
-                            Vs[p][row] = cs * vp - spc * vq;
-                            Vs[q][row] = sph * vp + cs * vq;
+                            Vs[p][row] = cs * vp[t] - spc * vq[t];
+                            Vs[q][row] = sph * vp[t] + cs * vq[t];
                         }
                         rotated = 1;
                     }

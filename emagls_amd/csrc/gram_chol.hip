@@ -147,13 +147,27 @@ __global__ void __launch_bounds__(64) chol_diag_kernel(T* __restrict__ G, int S,
         wave_lds_fence();
         if (lane >= j && lane < nb) Rd[j][lane] = scale_real(Rd[j][lane], dinv);  // diag becomes sqrt(piv)
         wave_lds_fence();
-        const int m = nb - j - 1;
-        for (int idx = lane; idx < m * m; idx += 64) {
-            const int r = j + 1 + idx / m, c = j + 1 + idx % m;
-            if (r <= c) {
-                T acc = zero_of<T>();
-                cfma_conj(acc, Rd[j][r], Rd[j][c]);
-                Rd[r][c] = Rd[r][c] - acc;
+        // trailing update of step j: lane owns column c = lane & 31 and rows r = (lane >> 5) + 2 i.  All LDS
+        // operands of the step are fetched first, then combined, then stored, so the LDS latency is paid once
+        // per step instead of once per element.
+        {
+            const int c = lane & 31, rh = lane >> 5;
+            const T rjc = Rd[j][c];
+            T rjr[NB / 2], cur[NB / 2];
+#pragma unroll
+            for (int i = 0; i < NB / 2; ++i) {
+                const int r = rh + 2 * i;
+                rjr[i] = Rd[j][r];
+                cur[i] = Rd[r][c];
+            }
+#pragma unroll
+            for (int i = 0; i < NB / 2; ++i) {
+                const int r = rh + 2 * i;
+                if (r > j && r <= c && c < nb) {
+                    T acc = zero_of<T>();
+                    cfma_conj(acc, rjr[i], rjc);
+                    Rd[r][c] = cur[i] - acc;
+                }
             }
         }
         wave_lds_fence();
@@ -188,10 +202,21 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(T* __restrict__ G, int 
             if (rl == 0) Gs[i][cl] = scale_real(Gs[i][cl], dinv);
             wave_lds_fence();
             const T xi = Gs[i][cl];
-            for (int r = i + 1 + rl; r < nb; r += 8) {
-                T acc = zero_of<T>();
-                cfma_conj(acc, Rd[i][r], xi);
-                Gs[r][cl] = Gs[r][cl] - acc;
+            T rir[NB / 8], cur[NB / 8];
+#pragma unroll
+            for (int k = 0; k < NB / 8; ++k) {
+                const int r = rl + 8 * k;
+                rir[k] = Rd[i][r];
+                cur[k] = Gs[r][cl];
+            }
+#pragma unroll
+            for (int k = 0; k < NB / 8; ++k) {
+                const int r = rl + 8 * k;
+                if (r > i && r < nb) {
+                    T acc = zero_of<T>();
+                    cfma_conj(acc, rir[k], xi);
+                    Gs[r][cl] = cur[k] - acc;
+                }
             }
         }
     }
@@ -241,72 +266,110 @@ template <typename T> __device__ __forceinline__ T shfl_T(T v, int src);
 template <> __device__ __forceinline__ double shfl_T<double>(double v, int src) { return __shfl(v, src, 64); }
 template <> __device__ __forceinline__ cplx shfl_T<cplx>(cplx v, int src) { return {__shfl(v.x, src, 64), __shfl(v.y, src, 64)}; }
 
+// inverses of the 32 x 32 diagonal blocks of R (upper triangular), one wave per block:
+// lane c builds column c of X = R_JJ^-1 by back substitution.  Rinv[J][k][c]
 template <typename T>
-__global__ void __launch_bounds__(256) qform_kernel(const T* __restrict__ Yc, const T* __restrict__ R, int S, int64_t D,
-                                                    int64_t ld, T* __restrict__ Q) {
-    constexpr int TR = 8;
+__global__ void __launch_bounds__(64) rinv_diag_kernel(const T* __restrict__ R, int S, T* __restrict__ Rinv) {
+    __shared__ T Rd[NB][NB + 1];
+    const int j0 = blockIdx.x * NB, nb = min(NB, S - j0), lane = threadIdx.x;
+    for (int idx = lane; idx < NB * NB; idx += 64) {
+        const int r = idx / NB, c = idx % NB;
+        Rd[r][c] = (r < nb && c < nb && r <= c) ? R[(int64_t)(j0 + r) * S + j0 + c] : zero_of<T>();
+    }
+    __syncthreads();
+    T* out = Rinv + (int64_t)blockIdx.x * NB * NB;
+    if (lane < NB) {
+        const int c = lane;
+        T x[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) x[i] = zero_of<T>();
+        if (c < nb) {
+#pragma unroll
+            for (int i = NB - 1; i >= 0; --i) {
+                if (i <= c) {
+                    T acc = (i == c) ? to_T<T>(1.0) : zero_of<T>();
+#pragma unroll
+                    for (int l = NB - 1; l > i; --l)
+                        if (l <= c) { T p = zero_of<T>(); cfma(p, Rd[i][l], x[l]); acc = acc - p; }
+                    x[i] = scale_real(acc, 1.0 / real_of(Rd[i][i]));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) out[i * NB + c] = x[i];
+    }
+}
+
+// Q = Yc R^-1, blocked by 32 columns.  A workgroup owns 8 rows (directions) and keeps their finished Q entries in
+// LDS; thread = (row r = tid/32, column-in-block c = tid%32).  Per block J:
+//   acc(r,c) = Yc(r, j0+c) - sum_{i < j0} Q(r,i) R(i, j0+c)     R streamed through LDS in 128-row chunks, the next
+//                                                                 chunk's loads in flight while the current one is used
+//   Q(r, j0+c) = sum_k acc(r,k) Rinv_J(k,c)                      no sequential solve
+template <typename T, int CH>
+__global__ void __launch_bounds__(256) qform_kernel(const T* __restrict__ Yc, const T* __restrict__ R,
+                                                    const T* __restrict__ Rinv, int S, int64_t D, int64_t ld,
+                                                    T* __restrict__ Q) {
+    constexpr int TR = 8, NV = CH / TR;  // chunk elements per thread
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    T* qs = reinterpret_cast<T*>(dyn);        // [TR][ldq] finished Q entries of this workgroup's rows
+    T* qs = reinterpret_cast<T*>(dyn);        // [TR][ldq]
     const int ldq = S + 1;
-    T* rt = qs + (size_t)TR * ldq;            // [2][32][33] staged 32x32 tiles of R (double buffered)
+    T* rt = qs + (size_t)TR * ldq;            // [CH][33] chunk of R(:, block J)
+    T* ri = rt + (size_t)CH * 33;             // [32][33] Rinv_J
+    T* as = ri + (size_t)32 * 33;             // [TR][33] acc rows
     const int tid = threadIdx.x, r = tid >> 5, c = tid & 31;
     const int64_t d = (int64_t)blockIdx.x * TR + r;
     const bool rowok = d < D;
-    const int lane_base = (tid & 32);  // first lane of this half wave inside its wave
-    // cooperative tile load: thread (r, c) fetches rows r, r+8, r+16, r+24 of a 32 x 32 tile
-    auto load_tile = [&](int i0, int j0, T (&v)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = i0 + r + 8 * k, j = j0 + c;
-            v[k] = (i < S && j < S) ? R[(int64_t)i * S + j] : zero_of<T>();
-        }
-    };
-    auto store_tile = [&](int buf, const T (&v)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rt[((size_t)buf * 32 + r + 8 * k) * 33 + c] = v[k];
-    };
     for (int j0 = 0; j0 < S; j0 += 32) {
         const int col = j0 + c;
         const bool colok = col < S;
         T acc0 = (rowok && colok) ? Yc[d * ld + col] : zero_of<T>();
         T acc1 = zero_of<T>();
-        // tiles (i0, j0) for i0 = 0, 32, ..., j0 (the last one is the diagonal block used by the solve)
-        const int ntiles = j0 / 32 + 1;
-        T v[4];
-        load_tile(0, j0, v);
-        for (int t = 0; t < ntiles; ++t) {
-            const int buf = t & 1;
-            store_tile(buf, v);
-            if (t + 1 < ntiles) load_tile(32 * (t + 1), j0, v);  // next tile in flight while this one is used
-            __syncthreads();
-            const T* tile = rt + (size_t)buf * 32 * 33;
-            if (t + 1 < ntiles) {
-                const T* qrow = qs + (size_t)r * ldq + 32 * t;
-#pragma unroll 8
-                for (int ii = 0; ii < 32; ii += 2) {
-                    T p0 = zero_of<T>(), p1 = zero_of<T>();
-                    cfma(p0, qrow[ii], tile[ii * 33 + c]);
-                    cfma(p1, qrow[ii + 1], tile[(ii + 1) * 33 + c]);
-                    acc0 = acc0 - p0;
-                    acc1 = acc1 - p1;
-                }
-            } else {
-                // diagonal block: forward substitution inside the 32-lane half wave
-                T x = acc0 + acc1;
-                const int nb = min(32, S - j0);
-                for (int j = 0; j < nb; ++j) {
-                    const double dinv = 1.0 / real_of(tile[j * 33 + j]);
-                    if (c == j) x = scale_real(x, dinv);
-                    const T xj = shfl_T<T>(x, lane_base + j);
-                    if (c > j) { T p = zero_of<T>(); cfma(p, xj, tile[j * 33 + c]); x = x - p; }
-                }
-                if (colok) {
-                    qs[(size_t)r * ldq + col] = x;
-                    if (rowok) Q[d * ld + col] = x;
-                }
+        const int nch = (j0 + CH - 1) / CH;  // chunks covering rows [0, j0)
+        T v[NV];
+        auto load_chunk = [&](int i0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = i0 + r + TR * k;
+                v[k] = (i < j0 && colok) ? R[(int64_t)i * S + col] : zero_of<T>();
             }
-            // the buffer written two tiles ago is free again only after everyone has read it: the barrier at
-            // the top of the next iteration (after store_tile into the OTHER buffer) provides that
+        };
+        // Rinv_J for this block (independent of everything else: goes out first)
+        T rv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rv[k] = Rinv[((int64_t)(j0 / 32) * NB + r + 8 * k) * NB + c];
+        if (nch > 0) load_chunk(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ri[(r + 8 * k) * 33 + c] = rv[k];
+        for (int t = 0; t < nch; ++t) {
+            __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+            for (int k = 0; k < NV; ++k) rt[(r + TR * k) * 33 + c] = v[k];
+            if (t + 1 < nch) load_chunk(CH * (t + 1));
+            __syncthreads();
+            const T* qrow = qs + (size_t)r * ldq + CH * t;
+            const int lim = min(CH, j0 - CH * t);
+            int ii = 0;
+            for (; ii + 1 < lim; ii += 2) {
+                T p0 = zero_of<T>(), p1 = zero_of<T>();
+                cfma(p0, qrow[ii], rt[ii * 33 + c]);
+                cfma(p1, qrow[ii + 1], rt[(ii + 1) * 33 + c]);
+                acc0 = acc0 - p0;
+                acc1 = acc1 - p1;
+            }
+            if (ii < lim) { T p0 = zero_of<T>(); cfma(p0, qrow[ii], rt[ii * 33 + c]); acc0 = acc0 - p0; }
+        }
+        as[r * 33 + c] = acc0 + acc1;
+        __syncthreads();
+        T x0 = zero_of<T>(), x1 = zero_of<T>();
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            cfma(x0, as[r * 33 + k], ri[k * 33 + c]);       // Rinv is upper triangular: entries below the diagonal are 0
+            cfma(x1, as[r * 33 + k + 1], ri[(k + 1) * 33 + c]);
+        }
+        const T x = x0 + x1;
+        if (colok) {
+            qs[(size_t)r * ldq + col] = x;
+            if (rowok) Q[d * ld + col] = x;
         }
         __syncthreads();
     }
@@ -390,20 +453,28 @@ void launch_cholesky(void* G, int S, bool is_cplx, int* flag, hipStream_t st) {
     if (is_cplx) chol_impl<cplx>(G, S, flag, st); else chol_impl<double>(G, S, flag, st);
 }
 
-template <typename T> static void qform_impl(const void* Yc, const void* R, int S, int64_t D, int64_t ld, void* Q, hipStream_t st) {
+template <typename T> static void qform_impl(const void* Yc, const void* R, void* Rinv, int S, int64_t D, int64_t ld, void* Q,
+                                             hipStream_t st) {
     const unsigned grid = (unsigned)ceil_div(D, 8);
-    const size_t dyn = sizeof(T) * ((size_t)8 * (S + 1) + 2 * 32 * 33);
-    if (dyn > 150 * 1024) throw Error(2, "qform: more than 1024 SH channels is not supported in this build");
+    auto lds = [&](int ch) { return sizeof(T) * ((size_t)8 * (S + 1) + (size_t)ch * 33 + 32 * 33 + 8 * 33); };
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    qform_kernel<T><<<grid, 256, dyn, st>>>((const T*)Yc, (const T*)R, S, D, ld, (T*)Q);
+    rinv_diag_kernel<T><<<(unsigned)ceil_div(S, NB), 64, 0, st>>>((const T*)R, S, (T*)Rinv);
+    KERNEL_CHECK();
+    if (lds(128) <= 150 * 1024)
+        qform_kernel<T, 128><<<grid, 256, lds(128), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q);
+    else if (lds(32) <= 150 * 1024)
+        qform_kernel<T, 32><<<grid, 256, lds(32), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q);
+    else
+        throw Error(2, "qform: too many SH channels for the LDS-resident rows");
     KERNEL_CHECK();
 }
-void launch_qform(const void* Yc, const void* R, int S, int64_t D, int64_t ld, bool is_cplx, void* Q, hipStream_t st) {
-    if (is_cplx) qform_impl<cplx>(Yc, R, S, D, ld, Q, st); else qform_impl<double>(Yc, R, S, D, ld, Q, st);
+void launch_qform(const void* Yc, const void* R, void* Rinv, int S, int64_t D, int64_t ld, bool is_cplx, void* Q, hipStream_t st) {
+    if (is_cplx) qform_impl<cplx>(Yc, R, Rinv, S, D, ld, Q, st); else qform_impl<double>(Yc, R, Rinv, S, D, ld, Q, st);
 }
 
 void launch_tn(const void* R, const void* E, int S, int C, int ldE, int nOrders, bool is_cplx, void* Tn, int64_t ldS,

@@ -37,7 +37,7 @@ int gram_ksplit(int64_t D);
 int64_t gram_dpad(int64_t D);
 void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, void* Gp, void* G, hipStream_t st);
 void launch_cholesky(void* G, int S, bool is_cplx, int* flag, hipStream_t st);
-void launch_qform(const void* Yc, const void* R, int S, int64_t D, int64_t ld, bool is_cplx, void* Q, hipStream_t st);
+void launch_qform(const void* Yc, const void* R, void* Rinv, int S, int64_t D, int64_t ld, bool is_cplx, void* Q, hipStream_t st);
 void launch_tn(const void* R, const void* E, int S, int C, int ldE, int nOrders, bool is_cplx, void* Tn, int64_t ldS,
                hipStream_t st);
 void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int ldb, bool b_cplx, void* Cm, int ldc,

@@ -131,6 +131,31 @@ def test_batch_of_designs_matches_single_designs(grids, thin):
         p.close()
 
 
+def test_emagls2_filters_config4_shape(grids, hrirs):
+    """BASELINE config 4, one job of the radius batch: raw 32-mic em32, 2702 directions, 1024 taps (nfft 2048,
+    1024 solved bins, k_cut 86), default real basis."""
+    import emagls_amd as E
+    args = (hrirs[0], hrirs[1], grids["azi"], grids["zen"], 0.05, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 1024, "real")
+    wL, wR = E.getEMagLs2Filters(*args)
+    oL, oR = O.getEMagLs2Filters(*args)
+    assert wL.shape == (1024, 32) and wL.dtype == np.float64
+    assert report("eMagLS2 config4 L", wL, oL) < TOL and report("eMagLS2 config4 R", wR, oR) < TOL
+
+
+def test_from_atf_config5_shape(grids, hrirs):
+    """BASELINE config 5 shape: ATF grid of 16 384 directions x 8 microphones, 2048 taps, fTrans 2 kHz, the full
+    2702-direction HRIR grid.  Checked against the oracle on the same inputs."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    atf, aazi, azen = synth.glasses_atfs(natf=16384, nmics=8, taps=256)
+    hg = np.column_stack([grids["azi"], grids["zen"]])
+    ag = np.column_stack([aazi, azen])
+    wL, wR = E.getEMagLsFiltersFromAtf(hrirs[0], hrirs[1], hg, atf, ag, 48000.0, 2048, 2000.0, verbose=False)
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(hrirs[0], hrirs[1], hg, atf, ag, 48000.0, 2048, 2000.0)
+    assert wL.shape == (2048, 8)
+    assert report("FromAtf config5 L", wL, oL) < TOL and report("FromAtf config5 R", wR, oR) < TOL
+
+
 def test_from_atf_small(thin):
     import emagls_amd as E
     from emagls_amd import synth
