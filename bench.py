@@ -242,6 +242,12 @@ def main():
         # its C x C matrix M_k, |H| of both ears, W(k-1) in and W(k) out
         bytes_launch = 16.0 * D * Cc + 16.0 * Cc * Cc + 2 * 8.0 * D + 2 * 2 * Cc * 16.0
         roof = None
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside the bench)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f)["sweep_half_kernel"]["bytes"]
+        except Exception:
+            traffic = None
         if sweep_n > 0:
             # average launch duration = sweep stage time / launches (launches are back to back: the rocprof kernel
             # average agrees to ~1 %); the per-launch event pairs add ~2 us each and are kept as a cross-check
@@ -249,7 +255,7 @@ def main():
             avg_s = stage_sweep_ms / sweep_n * 1e-3
             ach = bytes_launch / avg_s / 1e9
             roof = {"kernel": "sweep_half_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches_per_step": sweep_n,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launches_per_step": sweep_n,
                     "avg_launch_us": avg_s * 1e6, "avg_launch_us_event_pairs": sweep_ms / sweep_n * 1e3,
                     "algorithmic_bytes_per_launch": bytes_launch,
                     "note": "sequential recurrence: one launch per frequency bin, 1.1 MB of operands per launch; every "
