@@ -88,6 +88,8 @@ struct HalfSweepArgs {
     cplx* W;                // [e][P][C]
     int nWG;
     int kfirst;
+    unsigned long long* ll;  // persistent sweep: [2][nWG_persist][2C][4] granules {payload32, tag32}
+    int* abort_flag;         // persistent sweep: set when a workgroup gave up waiting for its peers
 };
 struct HalfSweepMulti {
     int n;

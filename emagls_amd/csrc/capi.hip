@@ -51,6 +51,7 @@ struct emagls_plan {
     bool sweep_split = false;
     // one direction-space operand per bin (G_k; M_k applied after the cross-workgroup sum): default
     bool sweep_half = true;
+    bool sweep_persist = true;  // one resident launch for all swept bins (sweep_persist.hip); needs sweep_half
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
     // profiling
     int prof_level = 0;
@@ -348,6 +349,9 @@ void plan_setup(emagls_plan& p) {
         if (const char* e = getenv("EMAGLS_SWEEP_SPLIT")) p.sweep_split = e[0] == '1';
         if (const char* e = getenv("EMAGLS_SWEEP_HALF")) p.sweep_half = e[0] != '0';
         if (p.sweep_split || p.sweep_factored) p.sweep_half = false;
+        if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) p.sweep_persist = e[0] != '0';
+        if (!p.sweep_half) p.sweep_persist = false;
+        p.alloc("ll", persist_sweep_ll_bytes((int)Dh, p.C));
         if (p.nWG_split > 256 || 2 * p.C > 64) p.sweep_split = false;
         p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(std::max(p.nWG, p.nWG_dense), p.nWG_split) * 2 * p.C);
         p.out_rows = d.len;
@@ -589,6 +593,8 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     a.cond_ok = p.get<double>("cond_ok");
     a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
     a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG_dense; a.kfirst = k0;
+    a.ll = p.get<unsigned long long>("ll");
+    a.abort_flag = p.get<int>("flag") + 1;
     return a;
 }
 
@@ -612,6 +618,18 @@ void emagls_run_sweep(emagls_plan& p) {
             ++p.sweep_launches;
         }
         if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, s0);
+    } else if (p.sweep_half && p.sweep_persist) {
+        HalfSweepMulti m{};
+        m.n = 1;
+        m.a[0] = emagls_half_args(p);
+        p.sweep_launches = 0;
+        if (k0 < p.P) {
+            launch_zero(p.get("ll"), p.bufs["ll"].bytes, s0);
+            if (p.prof_level >= 2) record_sweep_event(p, 0);
+            launch_sweep_persist(m, s0);
+            if (p.prof_level >= 2) record_sweep_event(p, 1);
+            p.sweep_launches = 1;
+        }
     } else if (p.sweep_half) {
         HalfSweepMulti m{};
         m.n = 1;
@@ -777,6 +795,13 @@ void batch_sweep_stage(emagls_batch& b) {
         for (int j = 0; j < h.n; ++j) h.a[j] = emagls_half_args(*b.plans[j]);
         emagls_plan& q0 = *b.plans[0];
         const int kk0 = std::max(q0.kcut0, 1);
+        if (q0.sweep_persist) {
+            if (kk0 < q0.P) {
+                for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, b.stream);
+                launch_sweep_persist(h, b.stream);
+            }
+            return;
+        }
         for (int kb = kk0; kb < q0.P; ++kb) launch_sweep_half(h, kb, b.stream);
         if (kk0 < q0.P) launch_sweep_half_finalize(h, q0.P - 1, b.stream);
         return;
@@ -837,6 +862,8 @@ void batch_execute(emagls_batch& b) {
 void plan_check_flags(emagls_plan& p) {
     int flag[4] = {0, 0, 0, 0};
     HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
+    if (flag[1])
+        throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");
     if (flag[0])
         throw Error(EMAGLS_ERR_NUMERIC,
                     "SH Gram matrix of the HRIR grid is not positive definite (the grid cannot resolve the required SH order)");
@@ -1136,7 +1163,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
             if (p->d.kind != EMAGLS_KIND_EMAGLS && p->d.kind != EMAGLS_KIND_EMAGLS2) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 plans");
             if (p->sweep_factored) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches need the direction-space sweep");
             const emagls_plan* q = plans[0];
-            if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_split != q->sweep_split || p->sweep_half != q->sweep_half)
+            if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_split != q->sweep_split || p->sweep_half != q->sweep_half || p->sweep_persist != q->sweep_persist)
                 throw Error(EMAGLS_ERR_ARG, "all designs of a batch must have the same shape (directions, channels, bins, k_cut)");
             b->plans.push_back(p);
         }
