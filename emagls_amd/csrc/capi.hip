@@ -51,7 +51,7 @@ struct emagls_plan {
     bool sweep_split = false;
     // one direction-space operand per bin (G_k; M_k applied after the cross-workgroup sum): default
     bool sweep_half = true;
-    bool sweep_persist = true;  // one resident launch for all swept bins (sweep_persist.hip); needs sweep_half
+    bool sweep_persist = false;  // (EMAGLS_SWEEP_PERSIST=1) one resident launch for all swept bins (sweep_persist.hip); needs sweep_half
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
     // profiling
     int prof_level = 0;
@@ -350,7 +350,7 @@ void plan_setup(emagls_plan& p) {
         if (const char* e = getenv("EMAGLS_SWEEP_HALF")) p.sweep_half = e[0] != '0';
         if (p.sweep_split || p.sweep_factored) p.sweep_half = false;
         if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) p.sweep_persist = e[0] != '0';
-        if (!p.sweep_half) p.sweep_persist = false;
+        if (!p.sweep_half || !persist_sweep_supported((int)Dh, p.C)) p.sweep_persist = false;
         p.alloc("ll", persist_sweep_ll_bytes((int)Dh, p.C));
         if (p.nWG_split > 256 || 2 * p.C > 64) p.sweep_split = false;
         p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(std::max(p.nWG, p.nWG_dense), p.nWG_split) * 2 * p.C);
@@ -595,6 +595,9 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG_dense; a.kfirst = k0;
     a.ll = p.get<unsigned long long>("ll");
     a.abort_flag = p.get<int>("flag") + 1;
+    a.timing = p.has("sweep_timing") ? p.get<long long>("sweep_timing") : nullptr;
+    static const int force_global = [] { const char* e = getenv("EMAGLS_PERSIST_GLOBAL"); return (e && e[0] == '1') ? 1 : 0; }();
+    a.force_global = force_global;
     return a;
 }
 

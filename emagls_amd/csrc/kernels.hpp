@@ -61,6 +61,7 @@ void launch_sweep_half(const HalfSweepMulti& m, int kb, hipStream_t st);
 void launch_sweep_half_finalize(const HalfSweepMulti& m, int kb_last, hipStream_t st);
 // ---- sweep_persist.hip
 int persist_sweep_nwg(int D);
+bool persist_sweep_supported(int D, int C);
 size_t persist_sweep_ll_bytes(int D, int C);
 void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st);
 void launch_sweep_split(const DenseSweepMulti& m, int kb, hipStream_t st);

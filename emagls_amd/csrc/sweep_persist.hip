@@ -2,20 +2,31 @@
 //
 // Reference recurrence (lib/getEMagLsFilters.m:95-103): W(k,:) depends on W(k-1,:), so the bins are a chain of
 // P - k_cut dependent steps.  The launch-per-bin kernels (sweep.hip) pay a kernel boundary per step: cold L2s
-// and >= 4.5 us.  Here the workgroups of one design stay resident and exchange their partial sums through
-// memory inside the launch:
+// and >= 4.5 us.  Here the workgroups of one design stay resident and all-reduce their partial sums through
+// memory inside the launch, in two small hops (reduce-scatter, all-gather):
 //
 //   * a design's workgroups are the blocks b with b % 8 == design (the dispatcher is observed to place block b
-//     on XCD b % 8, so a design's exchange stays inside one XCD's L2; this is a speed assumption only);
-//   * the partial W(k,:) of a workgroup (2C complex numbers) is published as 8-byte {payload32, tag32} granules,
-//     each written by ONE relaxed agent-scope store (sc1, write-through) and read by relaxed agent-scope loads
-//     (sc1, bypass L1): a granule is valid as soon as its tag equals the bin number, so no fence, flag or
-//     barrier is needed and the protocol does not depend on where the workgroups run;
-//   * two granule slots (bin parity) suffice: a workgroup can only publish bin k+2 after it has read every
-//     other workgroup's bin k+1, which those publish only after they finished reading bin k;
-//   * the operands of the next bin (G slab, M, |H|) do not depend on the chain; they are fetched into registers
-//     right after a bin's exchange completed and are consumed one bin later;
-//   * a workgroup that waits longer than the spin limit sets a sticky abort flag and everybody leaves:
+//     on XCD b % 8; this is a speed assumption only, the protocol is placement independent);
+//   * every number that crosses workgroups travels as two 8-byte {payload32, tag32} granules, each written by ONE
+//     relaxed agent-scope store (sc1, write-through) and read by relaxed agent-scope loads (sc1, bypass L1).  A
+//     granule is valid as soon as its tag equals the bin number: no fence, flag or barrier is needed;
+//   * hop 1: a workgroup publishes its partial W(k,:) (2C complex numbers); the pair (ear, channel) q is owned
+//     by workgroup q % nWG, whose communication wave collects the nWG partials of q (one per lane), sums them
+//     with a fixed-order wave reduction (bitwise reproducible) and publishes the total;
+//     hop 2: every communication wave collects the 2C totals (1.6 KB) into LDS.
+//     (A single hop in which every workgroup reads every partial costs nWG x 1.6 KB per workgroup and bin:
+//     measured 8.9 us per bin for 43 workgroups, against 7.4 us for the launch-per-bin kernel.)
+//   * at start-up the workgroups of a design exchange their XCC ids with that (placement independent) protocol.
+//     If all of them run on ONE XCD - the observed placement - the granules are afterwards written with plain
+//     stores: the line stays in the XCD's shared L2, where the peers' sc1 loads (which bypass only L1) find it, so
+//     a hop costs an L2 round trip instead of a fabric round trip.  Otherwise the sc1 stores stay: a wrong
+//     placement guess is slower, never wrong;
+//   * two granule slots (bin parity) suffice: a workgroup publishes bin k+2 only after it has read the totals of
+//     bin k+1, which exist only after every owner has read the partials of bin k+1, i.e. is done with bin k;
+//   * waves 0-3 compute, wave 4 communicates: the polls never sit behind the operand loads in a wave's in-order
+//     memory queue.  The operands of the next bin (G slab in two register layouts, M, |H|) do not depend on the
+//     chain; the compute waves fetch them into registers at the end of a bin;
+//   * a communication wave that waits longer than the spin limit sets a sticky abort flag and everybody leaves:
 //     a missing peer (not co-resident, killed) produces an error return, never a hang.
 #include "kernels.hpp"
 
@@ -23,9 +34,13 @@ namespace emagls {
 
 namespace {
 
-constexpr int PS_NT = 256;
+// DPW directions per workgroup; 4 DPW compute threads (p phase: one direction and a quarter of the channels per
+// thread) + one communication wave.  One workgroup per CU (register budget), and a design's workgroups share an
+// XCD (32 CUs), so nWG = ceil(D / DPW) must not exceed 32: DPW = 64 up to 2048 directions, 96 up to 3072.
 constexpr int PS_CMAX = 32;
+constexpr int PS_NI = PS_CMAX / 4;  // channels per lane (p phase), rows of M per lane
 constexpr unsigned PS_SPIN_LIMIT = 1u << 21;
+typedef unsigned long long u64;
 
 __device__ __forceinline__ cplx unit_phase(double h, cplx p, bool nyquist) {
     const double a2 = norm2(p);
@@ -37,256 +52,311 @@ __device__ __forceinline__ cplx unit_phase(double h, cplx p, bool nyquist) {
     if (nyquist) t.y = 0.0;
     return t;
 }
-
-__device__ __forceinline__ void ll_store(unsigned long long* dst, double v, unsigned tag) {
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-    const unsigned long long hi = (unsigned long long)tag << 32;
-    __hip_atomic_store(dst, hi | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(dst + 1, hi | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// HW_REG_XCC_ID (register 20, bits 3:0): the XCD this wave runs on
+__device__ __forceinline__ unsigned read_xcc_id() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
+#else
+    return 0;
+#endif
 }
+__device__ __forceinline__ u64 ll_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// local: every reader shares the writer's XCD L2 -> plain store (stays in L2); otherwise sc1 write-through
+__device__ __forceinline__ void ll_put(u64* dst, u64 word, bool local) {
+    if (local) __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ll_store(u64* lo, u64* hi, double v, unsigned tag, bool local) {
+    const u64 bits = (u64)__double_as_longlong(v), t = (u64)tag << 32;
+    ll_put(lo, t | (bits & 0xffffffffull), local);
+    ll_put(hi, t | (bits >> 32), local);
+}
+__device__ __forceinline__ double ll_value(u64 lo, u64 hi) {
+    return __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+}
+__device__ __forceinline__ bool ll_ok(u64 w, unsigned tag) { return (unsigned)(w >> 32) == tag; }
 
-// DPW: directions per workgroup; NV: granule pairs (doubles) gathered per thread and pass
-template <int DPW, int NV>
-__global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
-    extern __shared__ __attribute__((aligned(16))) char dyn[];
-    __shared__ __attribute__((aligned(16))) cplx Wp[64];
-    __shared__ __attribute__((aligned(16))) cplx vt[64];
-    __shared__ __attribute__((aligned(16))) cplx ts[2][DPW];
-    __shared__ int s_abort;
-    const int design = blockIdx.x & 7, member = blockIdx.x >> 3;
-    if (design >= m.n || member >= nWG) return;
-    const HalfSweepArgs& a = m.a[design];
-    const int tid = threadIdx.x;
-    const int C = a.C;
-    cplx* xs = reinterpret_cast<cplx*>(dyn);           // [C][DPW+1]     G slab of the current bin
-    cplx* ms = xs + (size_t)C * (DPW + 1);             // [C][C]         M of the previous bin
-    cplx* stage = ms + (size_t)C * C;                  // [2C][nWG+1]    partial sums of the previous bin
-    double* stage_d = reinterpret_cast<double*>(stage);
-    const int64_t d0 = (int64_t)member * DPW;
-    const int64_t na = a.P - a.kabs0;
-    const int ndbl = nWG * 4 * C;                      // doubles in one granule slot
-    unsigned long long* ll = a.ll;
-    if (tid == 0) s_abort = 0;
-
-    constexpr int NXV = (PS_CMAX * DPW) / PS_NT;
-    constexpr int NMV = (PS_CMAX * PS_CMAX) / PS_NT;
-    cplx xv[NXV], mv[NMV];
-    double habs = 0.0;
-    const int e_ = tid / DPW, dd_ = tid % DPW;
-    const int64_t d_ = d0 + dd_;
-    const bool p1 = tid < 2 * DPW && d_ < a.D;
-    // operands of bin kb: G_kb slab, M_{kb-1}, |H_kb|
-    auto fetch = [&](int kb) {
-        const bool have_g = kb < a.P;
-        const cplx* X = a.G + (int64_t)kb * a.g_stride;
-#pragma unroll
-        for (int i = 0; i < NXV; ++i) {
-            const int f = tid + PS_NT * i, c = f / DPW, dd = f % DPW;
-            xv[i] = (have_g && c < C && d0 + dd < a.D) ? X[(int64_t)c * a.ldD + d0 + dd] : mk(0, 0);
+// wave-uniform wait: returns false when the wait was abandoned
+template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and_check, int* abort_flag, unsigned* nspins = nullptr, long long* t_first = nullptr) {
+    unsigned spins = 0;
+    for (;;) {
+        const bool ok = load_and_check();
+        if (t_first && spins == 0) *t_first = (long long)wall_clock64();
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) { if (nspins) *nspins += spins; return true; }
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        if ((spins & 255u) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (spins >= PS_SPIN_LIMIT) {
+            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
         }
-        const cplx* M = a.Mw + (int64_t)(kb - 1) * C * C;
-#pragma unroll
-        for (int i = 0; i < NMV; ++i) {
-            const int f = tid + PS_NT * i;
-            mv[i] = (kb > a.kfirst && f < C * C) ? M[f] : mk(0, 0);
-        }
-        habs = (have_g && p1) ? a.Habs[((int64_t)e_ * na + (kb - a.kabs0)) * a.ldH + d_] : 0.0;
-    };
-    fetch(a.kfirst);
-    __syncthreads();
-
-    for (int kb = a.kfirst; kb <= a.P; ++kb) {
-        const bool first = (kb == a.kfirst);
-        const bool last = (kb == a.P);  // only W(P-1,:) is left to form
-        const bool nyq = (kb == a.P - 1);
-        // ---- A. gather the partial sums of bin kb-1 (granules tagged kb-1) into LDS
-        if (!first) {
-            const unsigned tag = (unsigned)(kb - 1);
-            const unsigned long long* src = ll + (size_t)((kb - 1) & 1) * 2 * ndbl;
-            unsigned long long w0[NV], w1[NV];
-            for (int base = 0; base < ndbl; base += NV * PS_NT) {
-                unsigned spins = 0;
-                bool ok;
-                do {
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) {
-                        const int f = base + tid + PS_NT * i;
-                        if (f < ndbl) {
-                            w0[i] = __hip_atomic_load(src + 2 * (size_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            w1[i] = __hip_atomic_load(src + 2 * (size_t)f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                    ok = true;
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) {
-                        const int f = base + tid + PS_NT * i;
-                        if (f < ndbl) ok = ok && (unsigned)(w0[i] >> 32) == tag && (unsigned)(w1[i] >> 32) == tag;
-                    }
-                    if (!ok) {
-                        __builtin_amdgcn_s_sleep(1);
-                        ++spins;
-                        if ((spins & 255u) == 0 &&
-                            __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                            spins = PS_SPIN_LIMIT;
-                        if (spins >= PS_SPIN_LIMIT) {
-                            __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            s_abort = 1;
-                            break;
-                        }
-                    }
-                } while (!ok);
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const int f = base + tid + PS_NT * i;
-                    if (f < ndbl) {
-                        const int wg = f / (4 * C), rem = f - wg * (4 * C);
-                        const unsigned long long bits = (w0[i] & 0xffffffffull) | (w1[i] << 32);
-                        stage_d[((size_t)(rem >> 1) * (nWG + 1) + wg) * 2 + (rem & 1)] = __longlong_as_double((long long)bits);
-                    }
-                }
-            }
-        }
-        // ---- B. stage this bin's operands, then issue the next bin's loads
-#pragma unroll
-        for (int i = 0; i < NXV; ++i) {
-            const int f = tid + PS_NT * i, c = f / DPW, dd = f % DPW;
-            if (c < C) xs[(size_t)c * (DPW + 1) + dd] = xv[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NMV; ++i) {
-            const int f = tid + PS_NT * i;
-            if (f < C * C) ms[f] = mv[i];
-        }
-        const double habs_cur = habs;
-        const bool prev_ok = first ? true : (a.cond_ok[kb - 1] != 0.0);
-        const bool cur_ok = last ? true : (a.cond_ok[kb] != 0.0);
-        __syncthreads();
-        if (s_abort) break;
-        if (!last) fetch(kb + 1);
-        // ---- C. v_total = sum over workgroups;  W(kb-1,:) = v_total conj(M_{kb-1})
-        for (int pair = tid >> 2; pair < 2 * C; pair += PS_NT >> 2) {
-            const int part = tid & 3;
-            cplx acc = mk(0, 0);
-            if (first) {
-                if (part == 0) acc = a.W[((int64_t)(pair / C) * a.P + (kb - 1)) * C + pair % C];
-            } else {
-                const cplx* row = stage + (size_t)pair * (nWG + 1);
-                cplx a0 = mk(0, 0), a1 = mk(0, 0);
-                for (int w = part; w < nWG; w += 8) {
-                    a0 += row[w];
-                    if (w + 4 < nWG) a1 += row[w + 4];
-                }
-                acc = a0 + a1;
-            }
-            acc = group_sum<4>(acc);
-            if (part == 0) vt[pair] = acc;
-        }
-        __syncthreads();
-        for (int pair = tid >> 2; pair < 2 * C; pair += PS_NT >> 2) {
-            const int part = tid & 3;
-            const int e = pair / C, c = pair % C;
-            cplx acc = mk(0, 0);
-            if (first || !prev_ok) {
-                if (part == 0) acc = vt[pair];
-            } else {
-                for (int cc = part; cc < C; cc += 4) cfma(acc, vt[e * C + cc], conj(ms[cc * C + c]));
-            }
-            acc = group_sum<4>(acc);
-            if (part == 0) {
-                Wp[pair] = acc;
-                if (member == 0 && !first) a.W[((int64_t)e * a.P + (kb - 1)) * C + c] = acc;
-            }
-        }
-        if (last) break;
-        __syncthreads();
-        // ---- D. p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
-        if (tid < 2 * DPW) {
-            cplx t = mk(0, 0);
-            if (p1) {
-                cplx pa = mk(0, 0), pb = mk(0, 0);
-                int c = 0;
-                for (; c + 1 < C; c += 2) {
-                    cfma(pa, Wp[e_ * C + c], xs[(size_t)c * (DPW + 1) + dd_]);
-                    cfma(pb, Wp[e_ * C + c + 1], xs[(size_t)(c + 1) * (DPW + 1) + dd_]);
-                }
-                if (c < C) cfma(pa, Wp[e_ * C + c], xs[(size_t)c * (DPW + 1) + dd_]);
-                t = unit_phase(habs_cur, pa + pb, nyq);
-            }
-            ts[e_][dd_] = t;
-        }
-        __syncthreads();
-        // ---- E. this slab's partial v = t conj(G) (or t Y_reg_inv for an ill-conditioned bin), published as granules
-        {
-            const int pair = tid >> 2, part = tid & 3;
-            if (pair < 2 * C) {
-                const int e = pair / C, c = pair % C;
-                cplx a0 = mk(0, 0), a1 = mk(0, 0);
-                if (cur_ok) {
-                    const cplx* xrow = xs + (size_t)c * (DPW + 1);
-#pragma unroll
-                    for (int j = 0; j < DPW / 4; j += 2) {
-                        cfma(a0, ts[e][part + 4 * j], conj(xrow[part + 4 * j]));
-                        cfma(a1, ts[e][part + 4 * (j + 1)], conj(xrow[part + 4 * (j + 1)]));
-                    }
-                } else {
-                    const cplx* Y = a.Yri + (int64_t)kb * a.g_stride + (int64_t)c * a.ldD;
-                    for (int dd = part; dd < DPW; dd += 4)
-                        if (d0 + dd < a.D) cfma(a0, ts[e][dd], Y[d0 + dd]);
-                }
-                const cplx acc = group_sum<4>(a0 + a1);
-                if (part == 0) {
-                    unsigned long long* dst = ll + (size_t)(kb & 1) * 2 * ndbl + 2 * ((size_t)member * 4 * C + 2 * pair);
-                    ll_store(dst, acc.x, (unsigned)kb);
-                    ll_store(dst + 2, acc.y, (unsigned)kb);
-                }
-            }
-        }
-        __syncthreads();  // xs / ts / stage are rewritten by the next bin
     }
 }
 
-template <int DPW, int NV>
-void launch_one(const HalfSweepMulti& m, int nWG, size_t dyn, hipStream_t st) {
-    auto kern = sweep_persist_kernel<DPW, NV>;
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    kern<<<dim3(8 * nWG), PS_NT, dyn, st>>>(m, nWG);
-    KERNEL_CHECK();
-}
+template <int PS_DPW>
+__global__ void __launch_bounds__(4 * PS_DPW + 64) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
+    constexpr int PS_NC = 4 * PS_DPW;   // compute threads
+    constexpr int PS_NJ = PS_DPW / 4;   // directions per lane (partial phase)
+    __shared__ __attribute__((aligned(16))) cplx vt[64];          // totals of the previous bin
+    __shared__ __attribute__((aligned(16))) cplx Wp[64];          // W(kb-1,:)
+    __shared__ __attribute__((aligned(16))) cplx ts[2][PS_DPW];   // t per ear and direction
+    __shared__ int s_abort, s_local;
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* xs = reinterpret_cast<cplx*>(dyn);                      // [C][DPW + 4]  G slab of the current bin
+    constexpr int XLD = PS_DPW + 4;                               // row stride = 16 dwords mod 64: conflict-free quarter-wave reads
+    const int design = blockIdx.x & 7, member = blockIdx.x >> 3;
+    if (design >= m.n || member >= nWG) return;
+    const HalfSweepArgs& a = m.a[design];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool comm = tid >= PS_NC;
+    const int C = a.C, P = a.P, npairs = 2 * a.C;
+    const int64_t d0 = (int64_t)member * PS_DPW;
+    const int64_t na = P - a.kabs0;
+    // totals: granule words of a double x (x = 2 pair + re/im): low halves lo[x], high halves hi[x], each array contiguous
+    u64* part_ll = a.ll;                                    // [2][2C][nWG][re lo, im lo, re hi, im hi]: an owner reads nWG x 32 contiguous bytes
+    u64* tot_ll = a.ll + (size_t)2 * nWG * 4 * npairs;      // [2][lo 4C | hi 4C]
+    const int nd2 = 2 * npairs;                             // doubles per workgroup and bin
+    u64* xcc_ll = tot_ll + (size_t)2 * 2 * nd2;             // [nWG] start-up exchange of the XCC ids
+    if (tid < 64) { vt[tid] = mk(0, 0); Wp[tid] = mk(0, 0); }
+    if (tid == 0) { s_abort = 0; s_local = 0; }
+    // compute-thread roles
+    const int part = tid & 3;
+    const int dloc = comm ? 0 : (tid >> 2);           // p phase: (direction, channel quarter)
+    const int64_t d = d0 + dloc;
+    const bool dvalid = !comm && d < a.D;
+    const int pair = tid >> 2;                        // M / partial phases: (pair, quarter)
+    const bool pvalid = !comm && pair < npairs;
+    const int e = pvalid ? pair / C : 0, c = pvalid ? pair % C : 0;
+    // two register sets: the operands of bin kb+1 are requested when bin kb starts (see below)
+    cplx gDa[PS_NI], mRa[PS_NI], gDb[PS_NI], mRb[PS_NI];
+    double habsa = 0.0, habsb = 0.0;
+#pragma unroll
+    for (int i = 0; i < PS_NI; ++i) { gDa[i] = mk(0, 0); mRa[i] = mk(0, 0); gDb[i] = mk(0, 0); mRb[i] = mk(0, 0); }
+    // operands of bin kb: M_{kb-1}, the G_kb slab in both register layouts, |H_kb|
+    // Loads are unconditional at clamped addresses and are NOT masked here (a select would make the wave wait for
+    // the data on the spot): entries beyond C or D hold finite real data and meet zeros at their use - vt and Wp
+    // are stored [ear][32] with zero padding, and t is zero beyond D.
+    const int c_ld = pvalid ? c : 0;
+    const int64_t d_ld = dvalid ? d : 0;
+    // (also unconditional in kb: M_{kb-1} of the first swept bin and G_P are never used, so the bin index is clamped)
+    auto fetch = [&](int kb, cplx (&gD)[PS_NI], cplx (&mR)[PS_NI], double& habs) {
+        const int kbm = kb - 1 > a.kfirst ? kb - 1 : a.kfirst, kbg = kb < P ? kb : P - 1;
+        const cplx* M = a.Mw + (int64_t)kbm * C * C + c_ld;
+#pragma unroll
+        for (int i = 0; i < PS_NI; ++i) {
+            const int cc = part + 4 * i;
+            mR[i] = M[(cc < C ? cc : 0) * C];
+        }
+        const cplx* X = a.G + (int64_t)kbg * a.g_stride + d_ld;
+#pragma unroll
+        for (int i = 0; i < PS_NI; ++i) {
+            const int cc = part + 4 * i;
+            gD[i] = X[(int64_t)(cc < C ? cc : 0) * a.ldD];
+        }
+        habs = a.Habs[((int64_t)(part & 1) * na + (kbg - a.kabs0)) * a.ldH + d_ld];
+    };
+    if (!comm) fetch(a.kfirst, gDa, mRa, habsa);
+    __syncthreads();
+    if (comm) {  // do all workgroups of this design share an XCD?
+        const unsigned xcc = read_xcc_id();
+        const unsigned tag0 = 0x58434300u;  // 'XCC'
+        if (lane == 0) ll_put(xcc_ll + member, ((u64)tag0 << 32) | xcc, false);
+        u64 w = 0;
+        const bool alive = ll_wait([&] {
+            if (lane >= nWG) return true;
+            w = ll_load(xcc_ll + lane);
+            return ll_ok(w, tag0);
+        }, a.abort_flag);
+        const bool same = lane >= nWG || (unsigned)w == xcc;
+        if (lane == 0) {
+            s_local = alive && __builtin_amdgcn_ballot_w64(!same) == 0 && a.force_global == 0;
+            if (!alive) s_abort = 1;
+            if (a.timing && member == 1) a.timing[15] = s_local;
+        }
+    }
+    __syncthreads();
+    const bool local = s_local != 0;
 
-template <int DPW>
-void launch_dpw(const HalfSweepMulti& m, int nWG, hipStream_t st) {
-    const HalfSweepArgs& a = m.a[0];
-    const size_t dyn = sizeof(cplx) * ((size_t)a.C * (DPW + 1) + (size_t)a.C * a.C + (size_t)2 * a.C * (nWG + 1));
-    if (dyn > 150 * 1024) throw Error(2, "persistent sweep: shape not supported");
-    const int per_thread = ceil_div(nWG * 4 * a.C, PS_NT);
-    if (per_thread <= 12) launch_one<DPW, 12>(m, nWG, dyn, st);
-    else if (per_thread <= 17) launch_one<DPW, 17>(m, nWG, dyn, st);
-    else launch_one<DPW, 32>(m, nWG, dyn, st);  // more than 32 per thread: several passes
+#define PSTAMP(i) do { if (a.timing && member == 1 && lane == 0 && kb < P) a.timing[(int64_t)kb * 16 + (i)] = (long long)wall_clock64(); } while (0)
+    // The communication wave and the compute waves run separate loops that meet at the same three barriers per bin
+    // (B1: vt complete, B2: Wp complete, B3: ts complete); every branch around a barrier is workgroup-uniform.
+    if (comm) {
+        for (int kb = a.kfirst; kb <= P; ++kb) {
+            const bool first = (kb == a.kfirst);
+            PSTAMP(0);
+            if (first) {
+                if (lane < npairs) vt[(lane / C) * PS_CMAX + lane % C] = a.W[((int64_t)(lane / C) * P + (kb - 1)) * C + lane % C];
+            } else {
+                const unsigned tag = (unsigned)(kb - 1);
+                const int slot = (kb - 1) & 1;
+                bool alive = true;
+                unsigned spins1 = 0;
+                // hop 1 (reduce-scatter): the pairs this workgroup owns, two per pass
+                for (int q = member; q < npairs && alive; q += 2 * nWG) {
+                    const int q2 = q + nWG;
+                    const bool two = q2 < npairs;
+                    const u64* src = part_ll + (((size_t)slot * npairs + q) * nWG + lane) * 4;   // lane = producing workgroup
+                    const u64* src2 = src + (size_t)nWG * nWG * 4;
+                    u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+                    alive = ll_wait([&] {
+                        if (lane >= nWG) return true;
+                        w0 = ll_load(src); w1 = ll_load(src + 2); w2 = ll_load(src + 1); w3 = ll_load(src + 3);
+                        bool ok = true;
+                        if (two) {
+                            u0 = ll_load(src2); u1 = ll_load(src2 + 2); u2 = ll_load(src2 + 1); u3 = ll_load(src2 + 3);
+                            ok = ll_ok(u0, tag) && ll_ok(u1, tag) && ll_ok(u2, tag) && ll_ok(u3, tag);
+                        }
+                        return ok && ll_ok(w0, tag) && ll_ok(w1, tag) && ll_ok(w2, tag) && ll_ok(w3, tag);
+                    }, a.abort_flag, &spins1, (a.timing && member == 1 && lane == 0 && q == member) ? &a.timing[(int64_t)kb * 16 + 6] : nullptr);
+                    const double re = wave_sum(lane < nWG ? ll_value(w0, w1) : 0.0);
+                    const double im = wave_sum(lane < nWG ? ll_value(w2, w3) : 0.0);
+                    double re2 = 0.0, im2 = 0.0;
+                    if (two) {
+                        re2 = wave_sum(lane < nWG ? ll_value(u0, u1) : 0.0);
+                        im2 = wave_sum(lane < nWG ? ll_value(u2, u3) : 0.0);
+                    }
+                    if (lane == 0) {
+                        u64* dst = tot_ll + (size_t)slot * 2 * nd2 + 2 * q;
+                        ll_store(dst, dst + nd2, re, tag, local);
+                        ll_store(dst + 1, dst + nd2 + 1, im, tag, local);
+                        if (two) {
+                            ll_store(dst + 2 * nWG, dst + 2 * nWG + nd2, re2, tag, local);
+                            ll_store(dst + 2 * nWG + 1, dst + 2 * nWG + nd2 + 1, im2, tag, local);
+                        }
+                    }
+                }
+                PSTAMP(1);
+                if (a.timing && member == 1 && lane == 0) a.timing[(int64_t)kb * 16 + 9] = spins1;
+                // hop 2 (all-gather): every total; lane l takes the doubles l and l + 64
+                if (alive) {
+                    const u64* src = tot_ll + (size_t)slot * 2 * nd2;
+                    const int x0 = lane, x1 = lane + 64;
+                    u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                    alive = ll_wait([&] {
+                        bool ok = true;
+                        if (x0 < nd2) { w0 = ll_load(src + x0); w1 = ll_load(src + nd2 + x0); ok = ll_ok(w0, tag) && ll_ok(w1, tag); }
+                        if (x1 < nd2) { w2 = ll_load(src + x1); w3 = ll_load(src + nd2 + x1); ok = ok && ll_ok(w2, tag) && ll_ok(w3, tag); }
+                        return ok;
+                    }, a.abort_flag);
+                    double* vd = reinterpret_cast<double*>(vt);
+                    // double x = 2 (e C + c) + re/im  ->  padded slot 2 (32 e + c) + re/im
+                    if (x0 < nd2) vd[x0 + ((x0 >> 1) >= C ? 2 * (PS_CMAX - C) : 0)] = ll_value(w0, w1);
+                    if (x1 < nd2) vd[x1 + ((x1 >> 1) >= C ? 2 * (PS_CMAX - C) : 0)] = ll_value(w2, w3);
+                }
+                if (!alive && lane == 0) s_abort = 1;
+            }
+            PSTAMP(2);
+            __syncthreads();  // B1
+            if (s_abort || kb == P) break;
+            __syncthreads();  // B2
+            __syncthreads();  // B3
+        }
+        return;
+    }
+
+    // ---- compute waves.  One bin; returns false when the sweep is over (or abandoned).
+    // gD/mR/habs: this bin's operands, gDn/mRn/habsn: the other register set (next bin)
+    auto bin = [&](int kb, cplx (&gD)[PS_NI], cplx (&mR)[PS_NI], double& habs, cplx (&gDn)[PS_NI], cplx (&mRn)[PS_NI],
+                   double& habsn) -> bool {
+        const bool first = (kb == a.kfirst);
+        const bool last = (kb == P);  // only W(P-1,:) is left to form
+        const bool nyq = (kb == P - 1);
+        const bool prev_ok = first ? true : (a.cond_ok[kb - 1] != 0.0);
+        const bool cur_ok = last ? true : (a.cond_ok[kb] != 0.0);
+        __syncthreads();  // B1: vt is complete
+        if (s_abort) return false;
+        // The next bin's operands are requested NOW, not at the end of the bin: a CU's vector memory pipeline returns in
+        // order, so loads that miss to HBM (1.2-1.5 us) delay every later poll of the communication wave behind them.
+        // Issued here they drain during the three compute phases, before the communication wave polls again.
+        // (Unconditional: a branch around the loads makes the compiler wait for them at the join.)
+        fetch(kb + 1, gDn, mRn, habsn);
+        if (!last) {  // this bin's G slab for the partial phase (the p phase uses the registers)
+#pragma unroll
+            for (int i = 0; i < PS_NI; ++i) {
+                const int cc = part + 4 * i;
+                if (cc < C) xs[cc * XLD + dloc] = gD[i];
+            }
+        }
+        // ---- W(kb-1,:) = v_total conj(M_{kb-1})  (identity for the first swept bin and after an ill-conditioned bin)
+        if (pvalid) {
+            cplx acc = mk(0, 0);
+            if (first || !prev_ok) {
+                if (part == 0) acc = vt[e * PS_CMAX + c];
+            } else {
+#pragma unroll
+                for (int i = 0; i < PS_NI; ++i) cfma(acc, vt[e * PS_CMAX + part + 4 * i], conj(mR[i]));  // vt is 0 beyond C
+            }
+            acc = group_sum<4>(acc);
+            if (part == 0) {
+                Wp[e * PS_CMAX + c] = acc;
+                if (member == 0 && !first) a.W[((int64_t)e * P + (kb - 1)) * C + c] = acc;
+            }
+        }
+        if (last) return false;
+        __syncthreads();  // B2: Wp is complete
+        // ---- p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
+        {
+            if (tid == 0) PSTAMP(3);
+            cplx p0 = mk(0, 0), p1 = mk(0, 0);
+#pragma unroll
+            for (int i = 0; i < PS_NI; ++i) {  // Wp is 0 beyond C
+                cfma(p0, Wp[part + 4 * i], gD[i]);
+                cfma(p1, Wp[PS_CMAX + part + 4 * i], gD[i]);
+            }
+            p0 = group_sum<4>(p0);
+            p1 = group_sum<4>(p1);
+            if (part < 2) ts[part][dloc] = dvalid ? unit_phase(habs, part ? p1 : p0, nyq) : mk(0, 0);
+        }
+        __syncthreads();  // B3: ts is complete
+        // ---- this slab's partial v = t conj(G) (or t Y_reg_inv for an ill-conditioned bin), published as granules
+        if (tid == 0) PSTAMP(4);
+        if (pvalid) {
+            cplx a0 = mk(0, 0), a1 = mk(0, 0);
+            if (cur_ok) {
+                const cplx* xrow = xs + c * XLD;
+#pragma unroll
+                for (int j = 0; j < PS_NJ; j += 2) {
+                    cfma(a0, ts[e][part + 4 * j], conj(xrow[part + 4 * j]));
+                    cfma(a1, ts[e][part + 4 * (j + 1)], conj(xrow[part + 4 * (j + 1)]));
+                }
+            } else {
+                const cplx* Y = a.Yri + (int64_t)kb * a.g_stride + (int64_t)c * a.ldD;
+                for (int dd = part; dd < PS_DPW; dd += 4)
+                    if (d0 + dd < a.D) cfma(a0, ts[e][dd], Y[d0 + dd]);
+            }
+            const cplx acc = group_sum<4>(a0 + a1);  // all four lanes of the pair hold the sum: each stores one word
+            const u64 bits = (u64)__double_as_longlong((part & 1) ? acc.y : acc.x);
+            const u64 word = ((u64)(unsigned)kb << 32) | ((part & 2) ? (bits >> 32) : (bits & 0xffffffffull));
+            u64* dst = part_ll + (((size_t)(kb & 1) * npairs + pair) * nWG + member) * 4 + part;
+            ll_put(dst, word, local);
+        }
+        if (tid == 0) PSTAMP(5);
+        return true;
+    };
+    for (int kb = a.kfirst;; kb += 2) {
+        if (!bin(kb, gDa, mRa, habsa, gDb, mRb, habsb)) break;
+        if (!bin(kb + 1, gDb, mRb, habsb, gDa, mRa, habsa)) break;
+    }
 }
 
 }  // namespace
 
-int persist_sweep_dpw(int D) {
-    static const int forced = [] {
-        const char* e = getenv("EMAGLS_PERSIST_DPW");
-        return e ? atoi(e) : 0;
-    }();
-    if (forced == 64 || forced == 96 || forced == 128) return forced;
-    (void)D;
-    return 64;
+int persist_sweep_dpw(int D) { return D <= 32 * 64 ? 64 : 96; }
+int persist_sweep_nwg(int D) { return (int)ceil_div(D, persist_sweep_dpw(D)); }
+bool persist_sweep_supported(int D, int C) { return C <= PS_CMAX && persist_sweep_nwg(D) <= 32; }
+size_t persist_sweep_ll_bytes(int D, int C) {
+    return sizeof(u64) * ((size_t)2 * persist_sweep_nwg(D) * 8 * C + (size_t)2 * 8 * C + 64);
 }
-int persist_sweep_nwg(int D) { return ceil_div(D, persist_sweep_dpw(D)); }
-size_t persist_sweep_ll_bytes(int D, int C) { return sizeof(unsigned long long) * 2 * 2 * (size_t)persist_sweep_nwg(D) * 4 * C; }
 
 void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const HalfSweepArgs& a = m.a[0];
-    if (a.C > PS_CMAX || m.n > 8) throw Error(2, "persistent sweep: shape not supported");
-    const int dpw = persist_sweep_dpw(a.D), nWG = ceil_div(a.D, dpw);
-    switch (dpw) {
-        case 64: launch_dpw<64>(m, nWG, st); break;
-        case 96: launch_dpw<96>(m, nWG, st); break;
-        default: launch_dpw<128>(m, nWG, st); break;
-    }
+    const int nWG = persist_sweep_nwg(a.D);
+    if (!persist_sweep_supported(a.D, a.C) || m.n > 8) throw Error(2, "persistent sweep: shape not supported");
+    const int dpw = persist_sweep_dpw(a.D);
+    const size_t dyn = sizeof(cplx) * (size_t)a.C * (dpw + 4);
+    if (dpw == 64) sweep_persist_kernel<64><<<dim3(8 * nWG), 4 * 64 + 64, dyn, st>>>(m, nWG);
+    else sweep_persist_kernel<96><<<dim3(8 * nWG), 4 * 96 + 64, dyn, st>>>(m, nWG);
+    KERNEL_CHECK();
 }
 
 }  // namespace emagls
