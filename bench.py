@@ -240,27 +240,32 @@ def main():
         D, Cc = inputs[4].shape[1], info.num_channels
         # algorithmic bytes of one sweep launch (one frequency bin, both ears): the bin's pwGrid (D x C complex),
         # its C x C matrix M_k, |H| of both ears, W(k-1) in and W(k) out
-        bytes_launch = 16.0 * D * Cc + 16.0 * Cc * Cc + 2 * 8.0 * D + 2 * 2 * Cc * 16.0
+        bytes_bin = 16.0 * D * Cc + 16.0 * Cc * Cc + 2 * 8.0 * D + 2 * 2 * Cc * 16.0
+        nbins_swept = info.num_pos_freqs - max(info.k_cut - 1, 1)
         roof = None
-        traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside the bench)
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["sweep_half_kernel"]["bytes"]
-        except Exception:
-            traffic = None
         if sweep_n > 0:
-            # average launch duration = sweep stage time / launches (launches are back to back: the rocprof kernel
-            # average agrees to ~1 %); the per-launch event pairs add ~2 us each and are kept as a cross-check
+            persistent = sweep_n == 1  # one resident launch walks all swept bins (sweep_persist.hip)
+            kname = "sweep_persist_kernel" if persistent else "sweep_half_kernel"
+            bytes_launch = bytes_bin * nbins_swept / sweep_n
+            traffic = None
+            try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside the bench)
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    traffic = json.load(f)[kname]["bytes"]
+            except Exception:
+                traffic = None
+            # average launch duration = sweep stage time / launches (HIP events around the stage on the plan's stream;
+            # launch-per-bin kernels run back to back, the rocprof kernel average agrees to ~1 %)
             stage_sweep_ms = dict(stages).get("magls_sweep", sweep_ms)
             avg_s = stage_sweep_ms / sweep_n * 1e-3
             ach = bytes_launch / avg_s / 1e9
-            roof = {"kernel": "sweep_half_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launches_per_step": sweep_n,
                     "avg_launch_us": avg_s * 1e6, "avg_launch_us_event_pairs": sweep_ms / sweep_n * 1e3,
-                    "algorithmic_bytes_per_launch": bytes_launch,
-                    "note": "sequential recurrence: one launch per frequency bin, 1.1 MB of operands per launch; every "
-                            "launch starts with cold L2 (kernel boundaries invalidate it), so it is bound by L2-miss "
-                            "latency and per-CU miss bandwidth, not by HBM bandwidth -- see DESIGN.md section 5"}
+                    "algorithmic_bytes_per_launch": bytes_launch, "bins_per_launch": nbins_swept / sweep_n,
+                    "us_per_bin": avg_s * 1e6 * sweep_n / nbins_swept,
+                    "note": "sequential recurrence over the frequency bins (W(k) needs W(k-1)): 1.1 MB of operands per bin; "
+                            "the chain is bound by the per-bin exchange of partial sums between workgroups (two in-launch "
+                            "hops through the XCD's L2) and LDS-bound phases, not by HBM bandwidth -- see DESIGN.md section 5"}
         res = {
             "metric": "eMagLS filter sets/s (N=4, 2702 dirs, 512 taps)", "value": world * K / dt, "unit": "filter sets/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,

@@ -51,7 +51,7 @@ struct emagls_plan {
     bool sweep_split = false;
     // one direction-space operand per bin (G_k; M_k applied after the cross-workgroup sum): default
     bool sweep_half = true;
-    bool sweep_persist = false;  // (EMAGLS_SWEEP_PERSIST=1) one resident launch for all swept bins (sweep_persist.hip); needs sweep_half
+    bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip); needs sweep_half
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
     // profiling
     int prof_level = 0;
@@ -303,12 +303,12 @@ void plan_setup(emagls_plan& p) {
         p.alloc("tauw", sizeof(double) * (size_t)p.P * p.C);
         p.alloc("R2w", sizeof(cplx) * (size_t)p.P * p.C * p.C);
         p.alloc("Nw", sizeof(cplx) * (size_t)p.P * p.C * p.C);
-        p.alloc("Mw", sizeof(cplx) * (size_t)p.P * p.C * p.C);
+        p.alloc("Mw", sizeof(cplx) * ((size_t)p.P * p.C * p.C + 1024));
         p.alloc("cond_ok", sizeof(double) * (size_t)p.P);
         p.alloc("QT", esz(cb) * (size_t)(p.simOrder + 1) * p.C * p.ldD);
         {
             const size_t nsw = (size_t)std::max(p.P - std::max(p.kcut0, 1), 1);
-            p.alloc("G", sizeof(cplx) * nsw * p.C * p.ldD, false);
+            p.alloc("G", sizeof(cplx) * (nsw * p.C + 8) * p.ldD, false);  // + 8 rows: the persistent sweep loads whole row groups
             p.alloc("Yri", sizeof(cplx) * nsw * p.C * p.ldD, false);
         }
         p.sweep_factored = getenv("EMAGLS_SWEEP") && std::string(getenv("EMAGLS_SWEEP")) == "factored";
@@ -596,8 +596,8 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     a.ll = p.get<unsigned long long>("ll");
     a.abort_flag = p.get<int>("flag") + 1;
     a.timing = p.has("sweep_timing") ? p.get<long long>("sweep_timing") : nullptr;
-    static const int force_global = [] { const char* e = getenv("EMAGLS_PERSIST_GLOBAL"); return (e && e[0] == '1') ? 1 : 0; }();
-    a.force_global = force_global;
+    const char* fg = getenv("EMAGLS_PERSIST_GLOBAL");
+    a.force_global = (fg && fg[0] == '1') ? 1 : 0;
     return a;
 }
 

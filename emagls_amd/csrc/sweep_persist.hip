@@ -60,6 +60,9 @@ __device__ __forceinline__ unsigned read_xcc_id() {
     return 0;
 #endif
 }
+// element-wise copy: a whole-struct assignment from global memory becomes a memcpy that pins the destination array
+// in scratch memory
+__device__ __forceinline__ cplx ldc(const cplx* p) { return mk(p->x, p->y); }
 __device__ __forceinline__ u64 ll_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // local: every reader shares the writer's XCD L2 -> plain store (stays in L2); otherwise sc1 write-through
 __device__ __forceinline__ void ll_put(u64* dst, u64 word, bool local) {
@@ -93,22 +96,38 @@ template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and
     }
 }
 
+// Thread roles (PS_NT = 448 threads, 7 waves):
+//   tid < 4 DPW          p phase: (direction, channel quarter)
+//   tid < 256            M and partial phases: (pair, quarter)
+//   256 <= tid < 384     loader: requests the next bin's operands when a bin starts and moves them into the other LDS
+//                        buffer while everybody waits for the exchange (DPW = 96: these two waves also do p-phase work)
+//   tid >= 384           communication wave
+constexpr int PS_NT = 448, PS_LD0 = 256, PS_NL = 128, PS_COMM0 = 384;
+constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
+
 template <int PS_DPW>
-__global__ void __launch_bounds__(4 * PS_DPW + 64) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
-    constexpr int PS_NC = 4 * PS_DPW;   // compute threads
+__global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
+    constexpr int PS_NC = 4 * PS_DPW;   // p-phase threads
     constexpr int PS_NJ = PS_DPW / 4;   // directions per lane (partial phase)
-    __shared__ __attribute__((aligned(16))) cplx vt[64];          // totals of the previous bin
-    __shared__ __attribute__((aligned(16))) cplx Wp[64];          // W(kb-1,:)
+    constexpr int XLD = PS_DPW + 4;     // row stride of the G slab (16 dwords mod 64: conflict-free quarter-wave reads)
+    constexpr int RG = PS_DPW == 96 ? 4 : 2, CH = RG * PS_DPW / PS_NL, NG = PS_CMAX / RG;  // G: NG row groups x CH chunks per loader thread
+    constexpr int NLM = (PS_CMAX * PS_CMAX) / 256;                                         // M: loads per M-phase thread
+    static_assert(PS_NC <= PS_COMM0 && 2 * PS_DPW <= 2 * PS_NL && PS_DPW >= 64, "role layout");
+    __shared__ __attribute__((aligned(16))) cplx vt[64];          // totals of the previous bin, [ear][32] zero padded
+    __shared__ __attribute__((aligned(16))) cplx Wp[64];          // W(kb-1,:), same layout
     __shared__ __attribute__((aligned(16))) cplx ts[2][PS_DPW];   // t per ear and direction
     __shared__ int s_abort, s_local;
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    cplx* xs = reinterpret_cast<cplx*>(dyn);                      // [C][DPW + 4]  G slab of the current bin
-    constexpr int XLD = PS_DPW + 4;                               // row stride = 16 dwords mod 64: conflict-free quarter-wave reads
+    // double-buffered operands (buffer kb & 1 holds bin kb); rows beyond C stay zero
+    cplx* xs_all = reinterpret_cast<cplx*>(dyn);                          // [2][32][XLD]   G_kb slab
+    cplx* ms_all = xs_all + (size_t)2 * PS_CMAX * XLD;                    // [2][32][MLD]   M_{kb-1}
+    double* hs_all = reinterpret_cast<double*>(ms_all + (size_t)2 * PS_CMAX * PS_MLD);  // [2][2][DPW]  |H_kb|
     const int design = blockIdx.x & 7, member = blockIdx.x >> 3;
     if (design >= m.n || member >= nWG) return;
     const HalfSweepArgs& a = m.a[design];
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool comm = tid >= PS_NC;
+    const bool comm = tid >= PS_COMM0;
+    const bool loader = tid >= PS_LD0 && tid < PS_LD0 + PS_NL;
     const int C = a.C, P = a.P, npairs = 2 * a.C;
     const int64_t d0 = (int64_t)member * PS_DPW;
     const int64_t na = P - a.kabs0;
@@ -119,44 +138,86 @@ __global__ void __launch_bounds__(4 * PS_DPW + 64) sweep_persist_kernel(HalfSwee
     u64* xcc_ll = tot_ll + (size_t)2 * 2 * nd2;             // [nWG] start-up exchange of the XCC ids
     if (tid < 64) { vt[tid] = mk(0, 0); Wp[tid] = mk(0, 0); }
     if (tid == 0) { s_abort = 0; s_local = 0; }
-    // compute-thread roles
+    {
+        const size_t ncplx = (size_t)2 * PS_CMAX * XLD + (size_t)2 * PS_CMAX * PS_MLD + PS_DPW * 2;  // hs: 4 DPW doubles
+        for (size_t i = tid; i < ncplx; i += PS_NT) xs_all[i] = mk(0, 0);
+    }
+    // roles
     const int part = tid & 3;
-    const int dloc = comm ? 0 : (tid >> 2);           // p phase: (direction, channel quarter)
-    const int64_t d = d0 + dloc;
-    const bool dvalid = !comm && d < a.D;
+    const bool pth = tid < PS_NC;                     // p phase: (direction, channel quarter)
+    const int dloc = pth ? (tid >> 2) : 0;
+    const bool dvalid = pth && d0 + dloc < a.D;
     const int pair = tid >> 2;                        // M / partial phases: (pair, quarter)
-    const bool pvalid = !comm && pair < npairs;
+    const bool pvalid = pair < npairs;                // (npairs <= 64, so tid < 256)
     const int e = pvalid ? pair / C : 0, c = pvalid ? pair % C : 0;
-    // two register sets: the operands of bin kb+1 are requested when bin kb starts (see below)
-    cplx gDa[PS_NI], mRa[PS_NI], gDb[PS_NI], mRb[PS_NI];
-    double habsa = 0.0, habsb = 0.0;
+    // ---- loaders: operands of bin kb (M_{kb-1}, the G_kb slab, |H_kb|) from memory into registers ...
+    // The loads are unconditional at clamped / padded addresses (a branch or a select around them makes the wave wait on
+    // the spot); what lies beyond C or the bin range is finite or never stored, directions beyond D repeat D-1.
+    // G and |H| are fetched by the two loader waves: RG rows of the slab are CH chunks of 128 consecutive elements.
+    const int lt = tid - PS_LD0;
+    cplx gReg[NG * CH];
+    double hReg = 0.0, hReg2 = 0.0;   // |H|: 2 DPW values, loader thread lt takes lt and lt + 128
+    int goff[CH], xoff[CH], gcc[CH];
 #pragma unroll
-    for (int i = 0; i < PS_NI; ++i) { gDa[i] = mk(0, 0); mRa[i] = mk(0, 0); gDb[i] = mk(0, 0); mRb[i] = mk(0, 0); }
-    // operands of bin kb: M_{kb-1}, the G_kb slab in both register layouts, |H_kb|
-    // Loads are unconditional at clamped addresses and are NOT masked here (a select would make the wave wait for
-    // the data on the spot): entries beyond C or D hold finite real data and meet zeros at their use - vt and Wp
-    // are stored [ear][32] with zero padding, and t is zero beyond D.
-    const int c_ld = pvalid ? c : 0;
-    const int64_t d_ld = dvalid ? d : 0;
-    // (also unconditional in kb: M_{kb-1} of the first swept bin and G_P are never used, so the bin index is clamped)
-    auto fetch = [&](int kb, cplx (&gD)[PS_NI], cplx (&mR)[PS_NI], double& habs) {
-        const int kbm = kb - 1 > a.kfirst ? kb - 1 : a.kfirst, kbg = kb < P ? kb : P - 1;
-        const cplx* M = a.Mw + (int64_t)kbm * C * C + c_ld;
-#pragma unroll
-        for (int i = 0; i < PS_NI; ++i) {
-            const int cc = part + 4 * i;
-            mR[i] = M[(cc < C ? cc : 0) * C];
-        }
-        const cplx* X = a.G + (int64_t)kbg * a.g_stride + d_ld;
-#pragma unroll
-        for (int i = 0; i < PS_NI; ++i) {
-            const int cc = part + 4 * i;
-            gD[i] = X[(int64_t)(cc < C ? cc : 0) * a.ldD];
-        }
-        habs = a.Habs[((int64_t)(part & 1) * na + (kbg - a.kabs0)) * a.ldH + d_ld];
+    for (int j = 0; j < CH; ++j) {
+        const int g = lt + PS_NL * j, cc = g / PS_DPW, dd = g % PS_DPW;
+        const int64_t dg = d0 + dd < a.D ? d0 + dd : a.D - 1;
+        goff[j] = (int)(cc * a.ldD + dg);
+        xoff[j] = cc * XLD + dd;
+        gcc[j] = cc;
+    }
+    auto habs_off = [&](int x) {
+        const int eh = (x / PS_DPW) & 1, dh = x % PS_DPW;
+        return (int)((int64_t)eh * na * a.ldH + (d0 + dh < a.D ? d0 + dh : a.D - 1));
     };
-    if (!comm) fetch(a.kfirst, gDa, mRa, habsa);
-    __syncthreads();
+    const int hoff = habs_off(lt), hoff2 = habs_off(lt + PS_NL);
+    auto fetch_g = [&](int kb, cplx (&gL)[NG * CH], double& hL, double& hL2) __attribute__((always_inline)) {
+        const int kbg = kb < P ? kb : P - 1;
+        const cplx* X = a.G + (int64_t)kbg * a.g_stride;
+#pragma unroll
+        for (int i = 0; i < NG * CH; ++i) {
+            const int r = i / CH, j = i % CH;
+            gL[i] = ldc(X + goff[j] + r * RG * a.ldD);
+        }
+        hL = a.Habs[(int64_t)(kbg - a.kabs0) * a.ldH + hoff];
+        hL2 = a.Habs[(int64_t)(kbg - a.kabs0) * a.ldH + hoff2];
+    };
+    auto stage_g = [&](int kb, const cplx (&gL)[NG * CH], double hL, double hL2) __attribute__((always_inline)) {
+        cplx* xs = xs_all + (size_t)(kb & 1) * PS_CMAX * XLD;
+        double* hs = hs_all + (size_t)(kb & 1) * 2 * PS_DPW;
+#pragma unroll
+        for (int i = 0; i < NG * CH; ++i) {
+            const int r = i / CH, j = i % CH;
+            if (RG * r + gcc[j] < C) xs[xoff[j] + r * RG * XLD] = gL[i];
+        }
+        if (lt < 2 * PS_DPW) hs[lt] = hL;
+        if (lt + PS_NL < 2 * PS_DPW) hs[lt + PS_NL] = hL2;
+    };
+    // M (C x C) is fetched by the threads of the M phase right after they used the previous one
+    cplx mReg[NLM];
+    auto fetch_m = [&](int kb, cplx (&mL)[NLM]) __attribute__((always_inline)) {
+        const int kbm = kb - 1 > a.kfirst ? kb - 1 : a.kfirst;
+        const cplx* M = a.Mw + (int64_t)kbm * C * C;
+#pragma unroll
+        for (int i = 0; i < NLM; ++i) mL[i] = ldc(M + tid + 256 * i);   // (Mw is padded by 1024 elements)
+    };
+    auto stage_m = [&](int kb, const cplx (&mL)[NLM]) __attribute__((always_inline)) {
+        cplx* ms = ms_all + (size_t)(kb & 1) * PS_CMAX * PS_MLD;
+#pragma unroll
+        for (int i = 0; i < NLM; ++i) {
+            const int f = tid + 256 * i;
+            if (f < C * C) ms[(f / C) * PS_MLD + f % C] = mL[i];
+        }
+    };
+    __syncthreads();  // LDS is zeroed
+    if (loader) {
+        fetch_g(a.kfirst, gReg, hReg, hReg2);
+        stage_g(a.kfirst, gReg, hReg, hReg2);
+    }
+    if (tid < 256) {
+        fetch_m(a.kfirst, mReg);
+        stage_m(a.kfirst, mReg);
+    }
     if (comm) {  // do all workgroups of this design share an XCD?
         const unsigned xcc = read_xcc_id();
         const unsigned tag0 = 0x58434300u;  // 'XCC'
@@ -254,29 +315,22 @@ __global__ void __launch_bounds__(4 * PS_DPW + 64) sweep_persist_kernel(HalfSwee
         return;
     }
 
-    // ---- compute waves.  One bin; returns false when the sweep is over (or abandoned).
-    // gD/mR/habs: this bin's operands, gDn/mRn/habsn: the other register set (next bin)
-    auto bin = [&](int kb, cplx (&gD)[PS_NI], cplx (&mR)[PS_NI], double& habs, cplx (&gDn)[PS_NI], cplx (&mRn)[PS_NI],
-                   double& habsn) -> bool {
+    // ---- compute and loader waves
+    for (int kb = a.kfirst; kb <= P; ++kb) {
         const bool first = (kb == a.kfirst);
         const bool last = (kb == P);  // only W(P-1,:) is left to form
         const bool nyq = (kb == P - 1);
         const bool prev_ok = first ? true : (a.cond_ok[kb - 1] != 0.0);
         const bool cur_ok = last ? true : (a.cond_ok[kb] != 0.0);
-        __syncthreads();  // B1: vt is complete
-        if (s_abort) return false;
-        // The next bin's operands are requested NOW, not at the end of the bin: a CU's vector memory pipeline returns in
-        // order, so loads that miss to HBM (1.2-1.5 us) delay every later poll of the communication wave behind them.
-        // Issued here they drain during the three compute phases, before the communication wave polls again.
-        // (Unconditional: a branch around the loads makes the compiler wait for them at the join.)
-        fetch(kb + 1, gDn, mRn, habsn);
-        if (!last) {  // this bin's G slab for the partial phase (the p phase uses the registers)
-#pragma unroll
-            for (int i = 0; i < PS_NI; ++i) {
-                const int cc = part + 4 * i;
-                if (cc < C) xs[cc * XLD + dloc] = gD[i];
-            }
-        }
+        const cplx* xs = xs_all + (size_t)(kb & 1) * PS_CMAX * XLD;
+        const cplx* ms = ms_all + (size_t)(kb & 1) * PS_CMAX * PS_MLD;
+        const double* hs = hs_all + (size_t)(kb & 1) * 2 * PS_DPW;
+        __syncthreads();  // B1: vt is complete (and the loader has staged this bin's operands)
+        if (s_abort) break;
+        // The next bin's operands are requested NOW: a CU's vector memory pipeline returns in order, so loads that miss
+        // to HBM (1.2-1.5 us) delay every later poll of the communication wave behind them.  Issued here they drain
+        // during the three compute phases; the loader waves are idle in the M phase anyway.
+        if (loader) fetch_g(kb + 1, gReg, hReg, hReg2);
         // ---- W(kb-1,:) = v_total conj(M_{kb-1})  (identity for the first swept bin and after an ill-conditioned bin)
         if (pvalid) {
             cplx acc = mk(0, 0);
@@ -284,7 +338,8 @@ __global__ void __launch_bounds__(4 * PS_DPW + 64) sweep_persist_kernel(HalfSwee
                 if (part == 0) acc = vt[e * PS_CMAX + c];
             } else {
 #pragma unroll
-                for (int i = 0; i < PS_NI; ++i) cfma(acc, vt[e * PS_CMAX + part + 4 * i], conj(mR[i]));  // vt is 0 beyond C
+                for (int i = 0; i < PS_NI; ++i)  // vt and ms are 0 beyond C
+                    cfma(acc, vt[e * PS_CMAX + part + 4 * i], conj(ms[(part + 4 * i) * PS_MLD + c]));
             }
             acc = group_sum<4>(acc);
             if (part == 0) {
@@ -292,20 +347,22 @@ __global__ void __launch_bounds__(4 * PS_DPW + 64) sweep_persist_kernel(HalfSwee
                 if (member == 0 && !first) a.W[((int64_t)e * P + (kb - 1)) * C + c] = acc;
             }
         }
-        if (last) return false;
+        if (last) break;
+        if (tid < 256) fetch_m(kb + 1, mReg);
         __syncthreads();  // B2: Wp is complete
         // ---- p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
-        {
+        if (pth) {
             if (tid == 0) PSTAMP(3);
             cplx p0 = mk(0, 0), p1 = mk(0, 0);
 #pragma unroll
-            for (int i = 0; i < PS_NI; ++i) {  // Wp is 0 beyond C
-                cfma(p0, Wp[part + 4 * i], gD[i]);
-                cfma(p1, Wp[PS_CMAX + part + 4 * i], gD[i]);
+            for (int i = 0; i < PS_NI; ++i) {  // Wp and xs are 0 beyond C
+                const cplx g = xs[(part + 4 * i) * XLD + dloc];
+                cfma(p0, Wp[part + 4 * i], g);
+                cfma(p1, Wp[PS_CMAX + part + 4 * i], g);
             }
             p0 = group_sum<4>(p0);
             p1 = group_sum<4>(p1);
-            if (part < 2) ts[part][dloc] = dvalid ? unit_phase(habs, part ? p1 : p0, nyq) : mk(0, 0);
+            if (part < 2) ts[part][dloc] = dvalid ? unit_phase(hs[part * PS_DPW + dloc], part ? p1 : p0, nyq) : mk(0, 0);
         }
         __syncthreads();  // B3: ts is complete
         // ---- this slab's partial v = t conj(G) (or t Y_reg_inv for an ill-conditioned bin), published as granules
@@ -331,11 +388,9 @@ __global__ void __launch_bounds__(4 * PS_DPW + 64) sweep_persist_kernel(HalfSwee
             ll_put(dst, word, local);
         }
         if (tid == 0) PSTAMP(5);
-        return true;
-    };
-    for (int kb = a.kfirst;; kb += 2) {
-        if (!bin(kb, gDa, mRa, habsa, gDb, mRb, habsb)) break;
-        if (!bin(kb + 1, gDb, mRb, habsb, gDa, mRa, habsa)) break;
+        // the other buffer was last read in bin kb-1: fill it while everybody waits for the exchange
+        if (loader) stage_g(kb + 1, gReg, hReg, hReg2);
+        if (tid < 256) stage_m(kb + 1, mReg);
     }
 }
 
@@ -353,9 +408,15 @@ void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const int nWG = persist_sweep_nwg(a.D);
     if (!persist_sweep_supported(a.D, a.C) || m.n > 8) throw Error(2, "persistent sweep: shape not supported");
     const int dpw = persist_sweep_dpw(a.D);
-    const size_t dyn = sizeof(cplx) * (size_t)a.C * (dpw + 4);
-    if (dpw == 64) sweep_persist_kernel<64><<<dim3(8 * nWG), 4 * 64 + 64, dyn, st>>>(m, nWG);
-    else sweep_persist_kernel<96><<<dim3(8 * nWG), 4 * 96 + 64, dyn, st>>>(m, nWG);
+    const size_t dyn = sizeof(cplx) * ((size_t)2 * PS_CMAX * (dpw + 4) + (size_t)2 * PS_CMAX * PS_MLD + 2 * dpw);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    if (dpw == 64) sweep_persist_kernel<64><<<dim3(8 * nWG), PS_NT, dyn, st>>>(m, nWG);
+    else sweep_persist_kernel<96><<<dim3(8 * nWG), PS_NT, dyn, st>>>(m, nWG);
     KERNEL_CHECK();
 }
 

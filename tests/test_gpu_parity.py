@@ -131,6 +131,40 @@ def test_batch_of_designs_matches_single_designs(grids, thin):
         p.close()
 
 
+@pytest.mark.parametrize("mode", ["launch_per_bin", "persistent_write_through"])
+def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
+    """The phase sweep has three forms: the persistent launch with XCD-local granule stores (default when all
+    workgroups of a design share an XCD), the same with write-through stores (any placement), and one launch per
+    bin (shapes the persistent kernel does not cover).  They sum the per-workgroup partials in different fixed
+    orders, so they agree to rounding; each is bitwise reproducible."""
+    from emagls_amd import Plan, _lib as L
+
+    def run():
+        p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], 0.042, 32)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+        p.set_hrirs(thin["hL"], thin["hR"])
+        outs = []
+        for _ in range(3):  # eager, captured, replayed
+            p.execute()
+            outs.append(p.get_filters())
+        launches = p.info().num_sweep_launches
+        p.close()
+        for wL, wR in outs[1:]:
+            assert np.array_equal(wL, outs[0][0]) and np.array_equal(wR, outs[0][1])
+        return outs[0], launches
+
+    (dL, dR), n_default = run()
+    assert n_default == 1  # the persistent kernel is the default
+    if mode == "launch_per_bin":
+        monkeypatch.setenv("EMAGLS_SWEEP_PERSIST", "0")
+    else:
+        monkeypatch.setenv("EMAGLS_PERSIST_GLOBAL", "1")
+    (vL, vR), n_variant = run()
+    assert (n_variant > 1) == (mode == "launch_per_bin")
+    assert rel(vL, dL) < 1e-12 and rel(vR, dR) < 1e-12
+
+
 def test_emagls2_filters_config4_shape(grids, hrirs):
     """BASELINE config 4, one job of the radius batch: raw 32-mic em32, 2702 directions, 1024 taps (nfft 2048,
     1024 solved bins, k_cut 86), default real basis."""

@@ -138,8 +138,9 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
     sv = p.debug("sv", np.float64).reshape(P, C)
     js = p.debug("jsweeps", np.int32)
     assert 1 <= js[1:P].min() and js[1:P].max() <= 20, (js[1:P].min(), js[1:P].max())
-    G = p.debug("G", np.complex128).reshape(-1, C, ldD)[:, :, :D]
-    Mw = p.debug("Mw", np.complex128).reshape(P, C, C)  # bin kb is stored at slot kb-1
+    nsw = P - max(kcut0, 1)  # swept bins; the buffers carry padding for the persistent sweep's whole-row-group loads
+    G = p.debug("G", np.complex128)[:nsw * C * ldD].reshape(nsw, C, ldD)[:, :, :D]
+    Mw = p.debug("Mw", np.complex128)[:P * C * C].reshape(P, C, C)  # bin kb is stored at slot kb-1
 
     def Bk(kb):
         b = bn[kb].copy()
