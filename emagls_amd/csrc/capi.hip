@@ -27,6 +27,11 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
 };
+// one allocation that holds the buffers of all plans of a batch at a constant stride (see emagls_batch)
+struct Arena {
+    void* base = nullptr;
+    ~Arena() { if (base) hipFree(base); }
+};
 
 int round_up(int64_t v, int64_t m) { return (int)(ceil_div(v, m) * m); }
 
@@ -36,6 +41,7 @@ struct emagls_plan {
     emagls_design_desc d{};
     hipStream_t stream = nullptr;
     std::map<std::string, DevBuf> bufs;
+    std::shared_ptr<Arena> arena;  // set when a batch moved the buffers into its arena (they are not freed one by one then)
     int64_t total_bytes = 0;
     // derived constants
     bool cplx_basis = false;
@@ -92,7 +98,7 @@ struct emagls_plan {
     }
 
     ~emagls_plan() {
-        for (auto& kv : bufs) if (kv.second.p) hipFree(kv.second.p);
+        if (!arena) for (auto& kv : bufs) if (kv.second.p) hipFree(kv.second.p);
         for (auto e : stage_events) hipEventDestroy(e);
         for (auto e : sweep_events) hipEventDestroy(e);
         for (auto e : sync_events) hipEventDestroy(e);
@@ -139,6 +145,10 @@ struct emagls_plan {
 
 struct emagls_batch {
     std::vector<emagls_plan*> plans;
+    // lanes: all plans have the same shape and their buffers sit `stride` bytes apart in one arena, so every
+    // launch of the design pipeline covers the whole batch (grid.z = design)
+    bool lanes = false;
+    size_t stride = 0;
     hipStream_t stream = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -785,6 +795,7 @@ DenseSweepArgs emagls_dense_args(emagls_plan& p);
 // A batch runs as separate graphs on separate streams (one hipGraph executes its nodes in order, so
 // parallel branches inside ONE graph would serialize): per-plan "pre" graphs on the plans' own streams,
 // the shared sweep graph on the batch stream, ordered by events outside the graphs.
+void batch_execute_lanes(emagls_batch& b);
 void plan_pre_stage(emagls_plan& p) {
     p.stage_names.clear();
     launch_zero(p.get("flag"), sizeof(int) * 4, p.stream);
@@ -835,9 +846,48 @@ template <typename F> void capture_into(hipStream_t st, hipGraph_t* g, hipGraphE
     HIP_CHECK(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
 }
 
+// lane mode: the pipeline of plan 0 is enqueued once on the batch stream with grid.z = designs
+void batch_lanes_body(emagls_batch& b) {
+    emagls_plan& p0 = *b.plans[0];
+    hipStream_t keep = p0.stream;
+    const int keep_streams = p0.nstreams;
+    p0.stream = b.stream;
+    p0.nstreams = 1;
+    try {
+        {
+            BatchScope sc((int)b.plans.size(), b.stride);
+            plan_pre_stage(p0);
+        }
+        batch_sweep_stage(b);
+        {
+            BatchScope sc((int)b.plans.size(), b.stride);
+            emagls_post_sweep(p0);
+        }
+    } catch (...) {
+        p0.stream = keep; p0.nstreams = keep_streams;
+        throw;
+    }
+    p0.stream = keep; p0.nstreams = keep_streams;
+}
+void batch_execute_lanes(emagls_batch& b) {
+    const bool replay = b.use_graph && b.eager_runs >= 1;
+    if (replay && !b.graph_exec) capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_lanes_body(b); });
+    if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_lanes_body(b);
+    emagls_plan& p0 = *b.plans[0];
+    for (auto* p : b.plans) {
+        p->executed = true;
+        p->sweep_launches = p0.sweep_persist ? 1 : p0.P - std::max(p0.kcut0, 1);
+    }
+    if (!replay) ++b.eager_runs;
+}
+
 void batch_execute(emagls_batch& b) {
     for (auto* p : b.plans)
         if (!p->have_hrir_grid || !p->have_hrirs || !p->have_mic_grid) throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grids and HRIRs");
+    if (b.lanes) {
+        batch_execute_lanes(b);
+        return;
+    }
     const bool replay = b.use_graph && b.eager_runs >= 1;
     if (replay && !b.graph_exec) {
         for (auto* p : b.plans) capture_into(p->stream, &p->pre_graph, &p->pre_exec, [&] { plan_pre_stage(*p); });
@@ -1155,6 +1205,55 @@ int emagls_plan_debug_buffer(emagls_plan* p, const char* name, void* dst, size_t
 }
 void* emagls_plan_stream(emagls_plan* p) { return p ? (void*)p->stream : nullptr; }
 
+// Lane mode needs plans of identical shape (same buffers of the same sizes, same derived constants).  Their
+// buffers are moved into one arena at a constant stride; the plans keep working on their own afterwards.
+void batch_try_lanes(emagls_batch& b) {
+    if (const char* e = getenv("EMAGLS_BATCH_LANES")) if (e[0] == '0') return;
+    emagls_plan& q = *b.plans[0];
+    if (!q.sweep_half || !q.sweep_persist) return;
+    for (auto* p : b.plans) {
+        if (p->S != q.S || p->simOrder != q.simOrder || p->nOut != q.nOut || p->nfft != q.nfft || p->ldS != q.ldS || p->ldD != q.ldD ||
+            p->Dpad != q.Dpad || p->k_cut != q.k_cut || p->cplx_basis != q.cplx_basis || p->out_cplx != q.out_cplx ||
+            p->d.kind != q.d.kind || p->d.nsamp != q.d.nsamp || p->d.nmics != q.d.nmics || p->d.len != q.d.len || p->d.order != q.d.order ||
+            p->bufs.size() != q.bufs.size())
+            return;
+        auto it = q.bufs.begin();
+        for (auto& kv : p->bufs) {
+            if (kv.first != it->first || kv.second.bytes != it->second.bytes) return;
+            ++it;
+        }
+    }
+    size_t stride = 0;
+    std::vector<size_t> off;
+    for (auto& kv : q.bufs) {
+        off.push_back(stride);
+        stride += (kv.second.bytes + 255) / 256 * 256;
+    }
+    stride = (stride + 4095) / 4096 * 4096;
+    auto arena = std::make_shared<Arena>();
+    HIP_CHECK(hipMalloc(&arena->base, stride * b.plans.size()));
+    for (size_t j = 0; j < b.plans.size(); ++j) {
+        emagls_plan& p = *b.plans[j];
+        size_t i = 0;
+        for (auto& kv : p.bufs) {
+            char* dst = static_cast<char*>(arena->base) + j * stride + off[i++];
+            HIP_CHECK(hipMemcpy(dst, kv.second.p, kv.second.bytes, hipMemcpyDeviceToDevice));
+            if (!p.arena) HIP_CHECK(hipFree(kv.second.p));
+            kv.second.p = dst;
+        }
+        p.arena = arena;  // (a previous arena is released when its last plan has moved out)
+        // the captured graphs hold the old addresses
+        if (p.graph_exec) { HIP_CHECK(hipGraphExecDestroy(p.graph_exec)); p.graph_exec = nullptr; }
+        if (p.graph) { HIP_CHECK(hipGraphDestroy(p.graph)); p.graph = nullptr; }
+        if (p.pre_exec) { HIP_CHECK(hipGraphExecDestroy(p.pre_exec)); p.pre_exec = nullptr; }
+        if (p.pre_graph) { HIP_CHECK(hipGraphDestroy(p.pre_graph)); p.pre_graph = nullptr; }
+        p.eager_runs = 0;
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    b.lanes = true;
+    b.stride = stride;
+}
+
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
     return guarded([&] {
         if (!plans || !batch || nplans < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
@@ -1182,6 +1281,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
             p->prof_level = 0;
             p->sync_stream = b->stream;
         }
+        batch_try_lanes(*b);
         *batch = b.release();
     });
 }

@@ -88,7 +88,21 @@ template <> __host__ __device__ __forceinline__ cplx zero_of<cplx>() { return {0
 // ---------------------------------------------------------------------------------------------
 // wave64 helpers
 // ---------------------------------------------------------------------------------------------
+// ---- batches: one launch covers `n` designs of identical shape whose buffers sit `stride` bytes apart
+// (grid.z enumerates the designs; every kernel offsets its pointer arguments by blockIdx.z * stride)
+struct BatchCtx { int n = 1; size_t stride = 0; };
+BatchCtx& batch_ctx();  // thread-local launch context (sh_basis.hip); {1, 0} outside emagls_batch_execute
+struct BatchScope {
+    BatchCtx saved;
+    BatchScope(int n, size_t stride) : saved(batch_ctx()) { batch_ctx() = BatchCtx{n, stride}; }
+    ~BatchScope() { batch_ctx() = saved; }
+};
+
 #ifdef __HIPCC__
+inline dim3 bgrid(dim3 g) { g.z = (unsigned)batch_ctx().n; return g; }
+template <typename T> __device__ __forceinline__ T* boff(T* p, size_t stride) {
+    return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.z * stride) : p;
+}
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ cplx shfl_xor_c(cplx v, int m) { return {__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64)}; }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }

@@ -30,7 +30,8 @@ constexpr int QT_TD = 16;
 
 template <typename T>
 __global__ void __launch_bounds__(512) qt_kernel(const T* __restrict__ Yc, int64_t ldY, const T* __restrict__ E, int ldE,
-                                                 int D, int S, int C, int nOrders, T* __restrict__ QT, int64_t ldD) {
+                                                 int D, int S, int C, int nOrders, T* __restrict__ QT, int64_t ldD, size_t bstride) {
+    Yc = boff(Yc, bstride); E = boff(E, bstride); QT = boff(QT, bstride);
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     T* ys = reinterpret_cast<T*>(dyn);  // [QT_TD][S+1]
     const int ldq = S + 1;
@@ -64,7 +65,8 @@ constexpr int DSP_NMAX = 32;  // orders held in registers (simulation order <= 3
 template <typename T>
 __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT, int64_t ldD, const cplx* __restrict__ bn,
                                                        int nOrders, int D, int C, int P, int k0, int bins_per_chunk,
-                                                       cplx* __restrict__ G) {
+                                                       cplx* __restrict__ G, size_t bstride) {
+    QT = boff(QT, bstride); bn = boff(bn, bstride); G = boff(G, bstride);
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     cplx* bs = reinterpret_cast<cplx*>(dyn);  // [bins_per_chunk][nOrders]
     const int c = threadIdx.x >> 3, dl = threadIdx.x & 7;  // direction fastest: full-line stores
@@ -99,7 +101,8 @@ __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT,
 //   Yri[c][d] = conj( sum_c' G[c'][d] M[c'][c] )      M_k staged in LDS (broadcast reads)
 __global__ void __launch_bounds__(256) dspace_yri_kernel(const cplx* __restrict__ G, int64_t ldD, const cplx* __restrict__ Mw,
                                                          int kb0_factor, const double* __restrict__ cond_ok, int D, int C,
-                                                         int k0, cplx* __restrict__ Yri) {
+                                                         int k0, cplx* __restrict__ Yri, size_t bstride) {
+    G = boff(G, bstride); Mw = boff(Mw, bstride); cond_ok = boff(cond_ok, bstride); Yri = boff(Yri, bstride);
     __shared__ __attribute__((aligned(16))) cplx ms[SW_CMAX_ * SW_CMAX_];
     const int kb = k0 + blockIdx.y;
     if (cond_ok[kb] == 0.0) return;  // ill-conditioned bin: yri_accurate_kernel handles it
@@ -123,7 +126,8 @@ __global__ void __launch_bounds__(256) dspace_yri_kernel(const cplx* __restrict_
 }
 
 // cond_ok[kb] = 1 when smax <= COND_LIMIT * smin for bin kb (the cheap identity is accurate), else 0
-__global__ void cond_flag_kernel(const double* __restrict__ sv, int C, int P, double* __restrict__ cond_ok) {
+__global__ void cond_flag_kernel(const double* __restrict__ sv, int C, int P, double* __restrict__ cond_ok, size_t bstride) {
+    sv = boff(sv, bstride); cond_ok = boff(cond_ok, bstride);
     const int kb = blockIdx.x * blockDim.x + threadIdx.x;
     if (kb >= P) return;
     double smax = 0.0, smin = INFINITY;
@@ -135,7 +139,8 @@ __global__ void cond_flag_kernel(const double* __restrict__ sv, int C, int P, do
 template <typename T>
 __global__ void __launch_bounds__(256) yri_accurate_kernel(const T* __restrict__ Q, int64_t ldQ, const cplx* __restrict__ Z,
                                                            int ldS, const double* __restrict__ cond_ok, int D, int S, int C, int k0,
-                                                           cplx* __restrict__ Yri, int64_t ldD) {
+                                                           cplx* __restrict__ Yri, int64_t ldD, size_t bstride) {
+    Q = boff(Q, bstride); Z = boff(Z, bstride); cond_ok = boff(cond_ok, bstride); Yri = boff(Yri, bstride);
     const int kb = k0 + blockIdx.y;
     if (cond_ok[kb] != 0.0) return;
     const int c = threadIdx.x >> 3, dl = threadIdx.x & 7;
@@ -161,7 +166,7 @@ static void qt_impl(const void* Yc, int64_t ldY, const void* E, int ldE, int D, 
         HIP_CHECK(hipFuncSetAttribute((const void*)qt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    qt_kernel<T><<<(unsigned)ceil_div(D, QT_TD), 512, dyn, st>>>((const T*)Yc, ldY, (const T*)E, ldE, D, S, C, nOrders, (T*)QT, ldD);
+    qt_kernel<T><<<bgrid((unsigned)ceil_div(D, QT_TD)), 512, dyn, st>>>((const T*)Yc, ldY, (const T*)E, ldE, D, S, C, nOrders, (T*)QT, ldD, batch_ctx().stride);
     KERNEL_CHECK();
 }
 void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
@@ -180,8 +185,8 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
     while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nOrders > 56 * 1024) ++chunks;  // b_n table of a chunk in LDS
     const int bpc = (nbins + chunks - 1) / chunks;
     const size_t dyn = sizeof(cplx) * (size_t)bpc * nOrders;
-    dspace_g_kernel<T><<<dim3((unsigned)ceil_div(D, DSP_TD), chunks), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D,
-                                                                                     C, P, k0, bpc, (cplx*)G);
+    dspace_g_kernel<T><<<bgrid(dim3((unsigned)ceil_div(D, DSP_TD), chunks)), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D,
+                                                                                     C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
     KERNEL_CHECK();
 }
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
@@ -190,17 +195,17 @@ void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, 
     else dspace_g_impl<double>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
 }
 void launch_cond_flags(const double* sv, int C, int P, double* cond_ok, hipStream_t st) {
-    cond_flag_kernel<<<(P + 255) / 256, 256, 0, st>>>(sv, C, P, cond_ok);
+    cond_flag_kernel<<<bgrid((P + 255) / 256), 256, 0, st>>>(sv, C, P, cond_ok, batch_ctx().stride);
     KERNEL_CHECK();
 }
 void launch_dspace_yri(const void* G, int64_t ldD, const void* Mw, int kb0_factor, const double* sv, double* cond_ok, int D, int C,
                        int P, int k0, void* Yri, hipStream_t st) {
     const int nbins = P - k0;
     if (nbins <= 0) return;
-    cond_flag_kernel<<<(P + 255) / 256, 256, 0, st>>>(sv, C, P, cond_ok);
+    cond_flag_kernel<<<bgrid((P + 255) / 256), 256, 0, st>>>(sv, C, P, cond_ok, batch_ctx().stride);
     KERNEL_CHECK();
-    dspace_yri_kernel<<<dim3((unsigned)ceil_div(D, 256), nbins), 256, 0, st>>>((const cplx*)G, ldD, (const cplx*)Mw, kb0_factor,
-                                                                              cond_ok, D, C, k0, (cplx*)Yri);
+    dspace_yri_kernel<<<bgrid(dim3((unsigned)ceil_div(D, 256), nbins)), 256, 0, st>>>((const cplx*)G, ldD, (const cplx*)Mw, kb0_factor,
+                                                                              cond_ok, D, C, k0, (cplx*)Yri, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
@@ -208,8 +213,8 @@ void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z
                          int P, int k0, void* Yri, int64_t ldD, hipStream_t st) {
     if (P - k0 <= 0) return;
     dim3 grid(32, P - k0);  // flagged bins are rare: workgroups of well-conditioned bins exit at once
-    if (is_cplx) yri_accurate_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)Q, ldQ, (const cplx*)Z, ldS, cond_ok, D, S, C, k0, (cplx*)Yri, ldD);
-    else yri_accurate_kernel<double><<<grid, 256, 0, st>>>((const double*)Q, ldQ, (const cplx*)Z, ldS, cond_ok, D, S, C, k0, (cplx*)Yri, ldD);
+    if (is_cplx) yri_accurate_kernel<cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)Q, ldQ, (const cplx*)Z, ldS, cond_ok, D, S, C, k0, (cplx*)Yri, ldD, batch_ctx().stride);
+    else yri_accurate_kernel<double><<<bgrid(grid), 256, 0, st>>>((const double*)Q, ldQ, (const cplx*)Z, ldS, cond_ok, D, S, C, k0, (cplx*)Yri, ldD, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

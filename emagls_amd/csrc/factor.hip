@@ -17,6 +17,14 @@
 
 namespace emagls {
 
+// batches: shift every pointer of the argument block to the design blockIdx.z
+__device__ __forceinline__ void batch_offset(FactorArgs& a, size_t bstride) {
+    a.Tn = boff(a.Tn, bstride); a.bn = boff(a.bn, bstride); a.Xd = boff(a.Xd, bstride);
+    a.Z = boff(a.Z, bstride); a.Bk = boff(a.Bk, bstride); a.Vws = boff(a.Vws, bstride); a.sv = boff(a.sv, bstride);
+    a.Hq = boff(a.Hq, bstride); a.W = boff(a.W, bstride); a.sweeps_out = boff(a.sweeps_out, bstride);
+    a.tauw = boff(a.tauw, bstride); a.R2w = boff(a.R2w, bstride); a.Nw = boff(a.Nw, bstride); a.Mw = boff(a.Mw, bstride);
+}
+
 
 constexpr int CPMAX = 32;  // max (even-padded) column count
 
@@ -24,7 +32,8 @@ constexpr int CPMAX = 32;  // max (even-padded) column count
 // kernel 1: assemble B_k, Householder QR.  Leaves v_j in Vws, tau_j in tauw, R2 (upper) in R2w.
 // =============================================================================================
 template <typename TT, int NCH, int RPT, int MAXT>
-__global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a) {
+__global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bstride) {
+    batch_offset(a, bstride);
     __shared__ __attribute__((aligned(16))) cplx bns[96];
     __shared__ cplx alpha_s[CPMAX];
     __shared__ double tau_s[CPMAX];
@@ -147,7 +156,8 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a) {
 // kernel 2: one-sided Jacobi SVD of X = R2^H (C x C) in LDS, 256 threads = 16 column pairs x 16 lanes.
 //   R2 = Vx Sigma Ux^H;  N = Vx diag(g) Xrot^H with g = s_reg / s   (U2 diag(s_reg) V^H)
 // =============================================================================================
-__global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a) {
+__global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t bstride) {
+    batch_offset(a, bstride);
     __shared__ __attribute__((aligned(16))) cplx Xs[CPMAX][CPMAX + 1];  // Xs[col][row]
     __shared__ __attribute__((aligned(16))) cplx Vs[CPMAX][CPMAX + 1];
     __shared__ double g_s[CPMAX];
@@ -283,7 +293,8 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a) {
 // kernel 3: Z_k = conj(Q2 [N; 0]) by applying the stored reflectors backwards; least-squares bins.
 // =============================================================================================
 template <int NCH, int RPT, int MAXT>
-__global__ void __launch_bounds__(MAXT) factor_back_kernel(FactorArgs a) {
+__global__ void __launch_bounds__(MAXT) factor_back_kernel(FactorArgs a, size_t bstride) {
+    batch_offset(a, bstride);
     const int tid = threadIdx.x;
     const int c = tid / NCH, ch = tid % NCH;
     const int S = a.S, C = a.C, ldS = a.ldS;
@@ -365,13 +376,13 @@ static void launch_one(const FactorArgs& a, int nbins, hipStream_t st, int phase
         attr_set = true;
     }
     if (phases & 1) {
-        factor_qr_kernel<TT, NCH, RPT, MAXT><<<nbins, threads, dyn, st>>>(a);
+        factor_qr_kernel<TT, NCH, RPT, MAXT><<<bgrid(nbins), threads, dyn, st>>>(a, batch_ctx().stride);
         KERNEL_CHECK();
-        factor_jacobi_kernel<<<nbins, 256, 0, st>>>(a);
+        factor_jacobi_kernel<<<bgrid(nbins), 256, 0, st>>>(a, batch_ctx().stride);
         KERNEL_CHECK();
     }
     if (phases & 2) {
-        factor_back_kernel<NCH, RPT, MAXT><<<nbins, threads, 0, st>>>(a);
+        factor_back_kernel<NCH, RPT, MAXT><<<bgrid(nbins), threads, 0, st>>>(a, batch_ctx().stride);
         KERNEL_CHECK();
     }
 }

@@ -13,7 +13,8 @@
 namespace emagls {
 
 // tw[j] = exp(-2 pi i j / nfft), j = 0..nfft-1
-__global__ void twiddle_kernel(int nfft, cplx* __restrict__ tw) {
+__global__ void twiddle_kernel(int nfft, cplx* __restrict__ tw, size_t bstride) {
+    tw = boff(tw, bstride);
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nfft) return;
     double s, c;
@@ -56,7 +57,8 @@ __device__ __forceinline__ void lds_fft_stages(cplx* buf, const cplx* tws, int n
 // partial[chunk][e][n] = sum_{d in chunk} h_e[d*L + n]
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) hrir_dirsum_kernel(const double* __restrict__ hL, const double* __restrict__ hR,
-                                                          int64_t L, int64_t D, int chunk, double* __restrict__ partial) {
+                                                          int64_t L, int64_t D, int chunk, double* __restrict__ partial, size_t bstride) {
+    hL = boff(hL, bstride); hR = boff(hR, bstride); partial = boff(partial, bstride);
     const int e = blockIdx.y;
     const double* h = e ? hR : hL;
     const int64_t d0 = (int64_t)blockIdx.x * chunk;
@@ -72,7 +74,8 @@ __global__ void __launch_bounds__(256) hrir_dirsum_kernel(const double* __restri
 // grpd[e] = median_k gd(k)   (MATLAB grpdelay FIR branch: |den| < 10 eps -> 0)
 __global__ void __launch_bounds__(1024) grpdelay_median_kernel(const double* __restrict__ partial, int nchunks, int64_t L,
                                                                int nfft, const cplx* __restrict__ tw,
-                                                               double* __restrict__ grpd) {
+                                                               double* __restrict__ grpd, size_t bstride) {
+    partial = boff(partial, bstride); tw = boff(tw, bstride); grpd = boff(grpd, bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* b = reinterpret_cast<double*>(smem);   // L
     double* v = b + ((L + 1) & ~(int64_t)1);       // npow2
@@ -129,7 +132,8 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
                                                        int log2n, int TD,
                                                        const cplx* __restrict__ tw, const double* __restrict__ grpd,
                                                        int mode, int n_c, int kabs0, cplx* __restrict__ Hc,
-                                                       double* __restrict__ Habs, int64_t ldD) {
+                                                       double* __restrict__ Habs, int64_t ldD, size_t bstride) {
+    hL = boff(hL, bstride); hR = boff(hR, bstride); didx = boff(didx, bstride); tw = boff(tw, bstride); grpd = boff(grpd, bstride); Hc = boff(Hc, bstride); Habs = boff(Habs, bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* tws = reinterpret_cast<cplx*>(smem);  // nfft/2
     cplx* buf = tws + nfft / 2;                 // TD * nfft
@@ -241,7 +245,8 @@ __global__ void __launch_bounds__(256) filter_epilogue_kernel(const cplx* __rest
                                                               int len, const cplx* __restrict__ tw,
                                                               const double* __restrict__ grpd, int conj_mode,
                                                               int dc_rule, int shift_mode, int out_cplx,
-                                                              void* __restrict__ outL, void* __restrict__ outR) {
+                                                              void* __restrict__ outL, void* __restrict__ outR, size_t bstride) {
+    W = boff(W, bstride); tw = boff(tw, bstride); grpd = boff(grpd, bstride); outL = boff(outL, bstride); outR = boff(outR, bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* tws = reinterpret_cast<cplx*>(smem);
     cplx* buf = tws + nfft / 2;
@@ -316,7 +321,7 @@ __global__ void __launch_bounds__(256) filter_epilogue_kernel(const cplx* __rest
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
 void launch_twiddles(int nfft, void* tw, hipStream_t st) {
-    twiddle_kernel<<<(nfft + 255) / 256, 256, 0, st>>>(nfft, (cplx*)tw);
+    twiddle_kernel<<<bgrid((nfft + 255) / 256), 256, 0, st>>>(nfft, (cplx*)tw, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
@@ -326,13 +331,13 @@ void launch_hrir_grpdelay(const double* hL, const double* hR, int64_t L, int64_t
                           double* partial, double* grpd, hipStream_t st) {
     const int chunk = 64;
     const int nchunks = hrir_dirsum_chunks(D);
-    hrir_dirsum_kernel<<<dim3(nchunks, 2), 256, 0, st>>>(hL, hR, L, D, chunk, partial);
+    hrir_dirsum_kernel<<<bgrid(dim3(nchunks, 2)), 256, 0, st>>>(hL, hR, L, D, chunk, partial, batch_ctx().stride);
     KERNEL_CHECK();
     const int P = nfft / 2 + 1;
     int npow2 = 1;
     while (npow2 < P) npow2 <<= 1;
     size_t sm = (((size_t)L + 1) & ~(size_t)1) * 8 + (size_t)npow2 * 8;
-    grpdelay_median_kernel<<<2, 1024, sm, st>>>(partial, nchunks, L, nfft, (const cplx*)tw, grpd);
+    grpdelay_median_kernel<<<bgrid(2), 1024, sm, st>>>(partial, nchunks, L, nfft, (const cplx*)tw, grpd, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
@@ -349,8 +354,8 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
         HIP_CHECK(hipFuncSetAttribute((const void*)real_fft_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hrir_fft_kernel<<<(unsigned)ceil_div(D, TD), 512, sm, st>>>(hL, hR, L, D, didx, nfft, log2n, TD, (const cplx*)tw, grpd, mode,
-                                                               n_c, kabs0, (cplx*)Hc, Habs, ldD);
+    hrir_fft_kernel<<<bgrid((unsigned)ceil_div(D, TD)), 512, sm, st>>>(hL, hR, L, D, didx, nfft, log2n, TD, (const cplx*)tw, grpd, mode,
+                                                               n_c, kabs0, (cplx*)Hc, Habs, ldD, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
@@ -375,8 +380,8 @@ void launch_filter_epilogue(const void* W, int C, int nfft, int len, const void*
                             int dc_rule, int shift_mode, int out_cplx, void* outL, void* outR, hipStream_t st) {
     const int log2n = ilog2(nfft);
     const size_t sm = (size_t)nfft * 16 + (size_t)nfft * 8;
-    filter_epilogue_kernel<<<dim3(C, 2), 256, sm, st>>>((const cplx*)W, C, nfft, log2n, len, (const cplx*)tw, grpd,
-                                                        conj_mode, dc_rule, shift_mode, out_cplx, outL, outR);
+    filter_epilogue_kernel<<<bgrid(dim3(C, 2)), 256, sm, st>>>((const cplx*)W, C, nfft, log2n, len, (const cplx*)tw, grpd,
+                                                        conj_mode, dc_rule, shift_mode, out_cplx, outL, outR, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

@@ -58,7 +58,8 @@ __device__ __forceinline__ cplx gram_get(const GramAcc<cplx>& acc, int x, int y,
 
 template <typename T>
 __global__ void __launch_bounds__(256) gram_mfma_kernel(const T* __restrict__ Yc, int64_t ld, int S, int kc, int nbt,
-                                                        T* __restrict__ Gp) {
+                                                        T* __restrict__ Gp, size_t bstride) {
+    Yc = boff(Yc, bstride); Gp = boff(Gp, bstride);
     // decode upper-triangle tile index
     int t = blockIdx.x, ti = 0;
     while (t >= nbt - ti) { t -= nbt - ti; ++ti; }
@@ -92,7 +93,8 @@ __global__ void __launch_bounds__(256) gram_mfma_kernel(const T* __restrict__ Yc
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) gram_reduce_kernel(const T* __restrict__ Gp, int S, int ksplit, T* __restrict__ G) {
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const T* __restrict__ Gp, int S, int ksplit, T* __restrict__ G, size_t bstride) {
+    Gp = boff(Gp, bstride); G = boff(G, bstride);
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)S * S) return;
     const int i = (int)(idx / S), j = (int)(idx % S);
@@ -130,7 +132,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 // 32 steps spread over the 64 lanes).  A separate launch, so the row-panel workgroups below read a factor
 // that can no longer change (they used to re-factor a block that workgroup 0 was overwriting: a race).
 template <typename T>
-__global__ void __launch_bounds__(64) chol_diag_kernel(T* __restrict__ G, int S, int j0, int* __restrict__ flag) {
+__global__ void __launch_bounds__(64) chol_diag_kernel(T* __restrict__ G, int S, int j0, int* __restrict__ flag, size_t bstride) {
+    G = boff(G, bstride); flag = boff(flag, bstride);
     __shared__ T Rd[NB][NB + 1];
     const int nb = min(NB, S - j0);
     const int lane = threadIdx.x;
@@ -182,7 +185,8 @@ __global__ void __launch_bounds__(64) chol_diag_kernel(T* __restrict__ G, int S,
 // row panel: R(J, c) = L^-1 G(J, c), L = R_JJ^H (already factored): right-looking forward substitution; each wave
 // owns 8 of the workgroup's 32 columns (lane = (column cl, row lane rl)), no workgroup barriers inside
 template <typename T>
-__global__ void __launch_bounds__(256) chol_panel_kernel(T* __restrict__ G, int S, int j0) {
+__global__ void __launch_bounds__(256) chol_panel_kernel(T* __restrict__ G, int S, int j0, size_t bstride) {
+    G = boff(G, bstride);
     __shared__ T Rd[NB][NB + 1];
     __shared__ T Gs[NB][NB + 1];
     const int nb = min(NB, S - j0);
@@ -229,7 +233,8 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(T* __restrict__ G, int 
 
 // trailing update: G(r, c) -= sum_{i in J} conj(R(i, r)) R(i, c) for r <= c beyond the panel
 template <typename T>
-__global__ void __launch_bounds__(256) chol_update_kernel(T* __restrict__ G, int S, int j0, int nbt) {
+__global__ void __launch_bounds__(256) chol_update_kernel(T* __restrict__ G, int S, int j0, int nbt, size_t bstride) {
+    G = boff(G, bstride);
     __shared__ T Pr[NB][NB + 1], Pc[NB][NB + 1];
     int t = blockIdx.x, bi = 0;
     while (t >= nbt - bi) { t -= nbt - bi; ++bi; }
@@ -269,7 +274,8 @@ template <> __device__ __forceinline__ cplx shfl_T<cplx>(cplx v, int src) { retu
 // inverses of the 32 x 32 diagonal blocks of R (upper triangular), one wave per block:
 // lane c builds column c of X = R_JJ^-1 by back substitution.  Rinv[J][k][c]
 template <typename T>
-__global__ void __launch_bounds__(64) rinv_diag_kernel(const T* __restrict__ R, int S, T* __restrict__ Rinv) {
+__global__ void __launch_bounds__(64) rinv_diag_kernel(const T* __restrict__ R, int S, T* __restrict__ Rinv, size_t bstride) {
+    R = boff(R, bstride); Rinv = boff(Rinv, bstride);
     __shared__ T Rd[NB][NB + 1];
     const int j0 = blockIdx.x * NB, nb = min(NB, S - j0), lane = threadIdx.x;
     for (int idx = lane; idx < NB * NB; idx += 64) {
@@ -308,7 +314,8 @@ __global__ void __launch_bounds__(64) rinv_diag_kernel(const T* __restrict__ R, 
 template <typename T, int CH>
 __global__ void __launch_bounds__(256) qform_kernel(const T* __restrict__ Yc, const T* __restrict__ R,
                                                     const T* __restrict__ Rinv, int S, int64_t D, int64_t ld,
-                                                    T* __restrict__ Q) {
+                                                    T* __restrict__ Q, size_t bstride) {
+    Yc = boff(Yc, bstride); R = boff(R, bstride); Rinv = boff(Rinv, bstride); Q = boff(Q, bstride);
     constexpr int TR = 8, NV = CH / TR;  // chunk elements per thread
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     T* qs = reinterpret_cast<T*>(dyn);        // [TR][ldq]
@@ -380,7 +387,8 @@ __global__ void __launch_bounds__(256) qform_kernel(const T* __restrict__ Yc, co
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) tn_kernel(const T* __restrict__ R, const T* __restrict__ E, int S, int C, int ldE,
-                                                 T* __restrict__ Tn, int64_t ldS) {
+                                                 T* __restrict__ Tn, int64_t ldS, size_t bstride) {
+    R = boff(R, bstride); E = boff(E, bstride); Tn = boff(Tn, bstride);
     const int n = blockIdx.x, c = blockIdx.y;
     const int jb = n * n, je = (n + 1) * (n + 1);
     T* out = Tn + ((int64_t)n * C + c) * ldS;
@@ -395,7 +403,8 @@ __global__ void __launch_bounds__(256) tn_kernel(const T* __restrict__ R, const 
 // small dense product  Cm[i][j] = sum_l A[i][l] Bm[l][j]   (E = pinv(Y_Lo) Y_mic etc.)
 template <typename TA, typename TB, typename TC>
 __global__ void __launch_bounds__(256) small_gemm_kernel(const TA* __restrict__ A, int lda, const TB* __restrict__ Bm, int ldb,
-                                                         TC* __restrict__ Cm, int ldc, int M, int N, int K) {
+                                                         TC* __restrict__ Cm, int ldc, int M, int N, int K, size_t bstride) {
+    A = boff(A, bstride); Bm = boff(Bm, bstride); Cm = boff(Cm, bstride);
     const int i = blockIdx.y;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
         cplx acc = mk(0, 0);
@@ -425,9 +434,9 @@ static void gram_impl(const void* Yc, int64_t D, int S, int64_t ld, void* Gp, vo
     const int kc = (int)(gram_dpad(D) / ks);
     const int nbt = (S + 63) / 64;
     const int ntiles = nbt * (nbt + 1) / 2;
-    gram_mfma_kernel<T><<<dim3(ntiles, ks), 256, 0, st>>>((const T*)Yc, ld, S, kc, nbt, (T*)Gp);
+    gram_mfma_kernel<T><<<bgrid(dim3(ntiles, ks)), 256, 0, st>>>((const T*)Yc, ld, S, kc, nbt, (T*)Gp, batch_ctx().stride);
     KERNEL_CHECK();
-    gram_reduce_kernel<T><<<(unsigned)ceil_div((int64_t)S * S, 256), 256, 0, st>>>((const T*)Gp, S, ks, (T*)G);
+    gram_reduce_kernel<T><<<bgrid((unsigned)ceil_div((int64_t)S * S, 256)), 256, 0, st>>>((const T*)Gp, S, ks, (T*)G, batch_ctx().stride);
     KERNEL_CHECK();
 }
 void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, void* Gp, void* G, hipStream_t st) {
@@ -438,13 +447,13 @@ template <typename T> static void chol_impl(void* G, int S, int* flag, hipStream
     for (int j0 = 0; j0 < S; j0 += NB) {
         const int rem = S - j0;
         const int ncb = (rem + NB - 1) / NB;  // column blocks incl. the diagonal one
-        chol_diag_kernel<T><<<1, 64, 0, st>>>((T*)G, S, j0, flag);
+        chol_diag_kernel<T><<<bgrid(1), 64, 0, st>>>((T*)G, S, j0, flag, batch_ctx().stride);
         KERNEL_CHECK();
         const int nbt = ncb - 1;
         if (nbt > 0) {
-            chol_panel_kernel<T><<<nbt, 256, 0, st>>>((T*)G, S, j0);
+            chol_panel_kernel<T><<<bgrid(nbt), 256, 0, st>>>((T*)G, S, j0, batch_ctx().stride);
             KERNEL_CHECK();
-            chol_update_kernel<T><<<nbt * (nbt + 1) / 2, 256, 0, st>>>((T*)G, S, j0, nbt);
+            chol_update_kernel<T><<<bgrid(nbt * (nbt + 1) / 2), 256, 0, st>>>((T*)G, S, j0, nbt, batch_ctx().stride);
             KERNEL_CHECK();
         }
     }
@@ -463,12 +472,12 @@ template <typename T> static void qform_impl(const void* Yc, const void* R, void
         HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    rinv_diag_kernel<T><<<(unsigned)ceil_div(S, NB), 64, 0, st>>>((const T*)R, S, (T*)Rinv);
+    rinv_diag_kernel<T><<<bgrid((unsigned)ceil_div(S, NB)), 64, 0, st>>>((const T*)R, S, (T*)Rinv, batch_ctx().stride);
     KERNEL_CHECK();
     if (lds(128) <= 150 * 1024)
-        qform_kernel<T, 128><<<grid, 256, lds(128), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q);
+        qform_kernel<T, 128><<<bgrid(grid), 256, lds(128), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q, batch_ctx().stride);
     else if (lds(32) <= 150 * 1024)
-        qform_kernel<T, 32><<<grid, 256, lds(32), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q);
+        qform_kernel<T, 32><<<bgrid(grid), 256, lds(32), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q, batch_ctx().stride);
     else
         throw Error(2, "qform: too many SH channels for the LDS-resident rows");
     KERNEL_CHECK();
@@ -479,8 +488,8 @@ void launch_qform(const void* Yc, const void* R, void* Rinv, int S, int64_t D, i
 
 void launch_tn(const void* R, const void* E, int S, int C, int ldE, int nOrders, bool is_cplx, void* Tn, int64_t ldS,
                hipStream_t st) {
-    if (is_cplx) tn_kernel<cplx><<<dim3(nOrders, C), 256, 0, st>>>((const cplx*)R, (const cplx*)E, S, C, ldE, (cplx*)Tn, ldS);
-    else tn_kernel<double><<<dim3(nOrders, C), 256, 0, st>>>((const double*)R, (const double*)E, S, C, ldE, (double*)Tn, ldS);
+    if (is_cplx) tn_kernel<cplx><<<bgrid(dim3(nOrders, C)), 256, 0, st>>>((const cplx*)R, (const cplx*)E, S, C, ldE, (cplx*)Tn, ldS, batch_ctx().stride);
+    else tn_kernel<double><<<bgrid(dim3(nOrders, C)), 256, 0, st>>>((const double*)R, (const double*)E, S, C, ldE, (double*)Tn, ldS, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
@@ -488,13 +497,13 @@ void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int l
                        bool c_cplx, int M, int N, int K, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(N, 256), M);
     if (a_cplx && b_cplx && c_cplx)
-        small_gemm_kernel<cplx, cplx, cplx><<<grid, 256, 0, st>>>((const cplx*)A, lda, (const cplx*)B, ldb, (cplx*)Cm, ldc, M, N, K);
+        small_gemm_kernel<cplx, cplx, cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)A, lda, (const cplx*)B, ldb, (cplx*)Cm, ldc, M, N, K, batch_ctx().stride);
     else if (a_cplx && !b_cplx && c_cplx)
-        small_gemm_kernel<cplx, double, cplx><<<grid, 256, 0, st>>>((const cplx*)A, lda, (const double*)B, ldb, (cplx*)Cm, ldc, M, N, K);
+        small_gemm_kernel<cplx, double, cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)A, lda, (const double*)B, ldb, (cplx*)Cm, ldc, M, N, K, batch_ctx().stride);
     else if (a_cplx && !b_cplx && !c_cplx)
-        small_gemm_kernel<cplx, double, double><<<grid, 256, 0, st>>>((const cplx*)A, lda, (const double*)B, ldb, (double*)Cm, ldc, M, N, K);
+        small_gemm_kernel<cplx, double, double><<<bgrid(grid), 256, 0, st>>>((const cplx*)A, lda, (const double*)B, ldb, (double*)Cm, ldc, M, N, K, batch_ctx().stride);
     else if (!a_cplx && !b_cplx && !c_cplx)
-        small_gemm_kernel<double, double, double><<<grid, 256, 0, st>>>((const double*)A, lda, (const double*)B, ldb, (double*)Cm, ldc, M, N, K);
+        small_gemm_kernel<double, double, double><<<bgrid(grid), 256, 0, st>>>((const double*)A, lda, (const double*)B, ldb, (double*)Cm, ldc, M, N, K, batch_ctx().stride);
     else
         throw Error(2, "small_gemm: unsupported type combination");
     KERNEL_CHECK();

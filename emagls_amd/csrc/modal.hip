@@ -13,7 +13,8 @@ namespace emagls {
 
 __global__ void __launch_bounds__(256) modal_bn_kernel(int N, int64_t nfreq, const double* __restrict__ kr,
                                                        double kr_scale, double out_scale, cplx* __restrict__ bn,
-                                                       int64_t stride_k, int64_t stride_n) {
+                                                       int64_t stride_k, int64_t stride_n, size_t bstride) {
+    kr = boff(kr, bstride); bn = boff(bn, bstride);
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nfreq) return;
     // kr == nullptr: kr_k = k * kr_scale (the FFT-bin grid 2 pi f_k r / c)
@@ -65,8 +66,8 @@ __global__ void __launch_bounds__(256) modal_bn_kernel(int N, int64_t nfreq, con
 void launch_modal_bn(int N, int64_t nfreq, const double* kr, double kr_scale, double out_scale, void* bn,
                      int64_t stride_k, int64_t stride_n, hipStream_t st) {
     if (nfreq <= 0) return;
-    modal_bn_kernel<<<(unsigned)ceil_div(nfreq, 256), 256, 0, st>>>(N, nfreq, kr, kr_scale, out_scale, (cplx*)bn,
-                                                                    stride_k, stride_n);
+    modal_bn_kernel<<<bgrid((unsigned)ceil_div(nfreq, 256)), 256, 0, st>>>(N, nfreq, kr, kr_scale, out_scale, (cplx*)bn,
+                                                                    stride_k, stride_n, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

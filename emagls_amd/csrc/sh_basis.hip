@@ -12,8 +12,14 @@
 
 namespace emagls {
 
+BatchCtx& batch_ctx() {
+    static thread_local BatchCtx ctx;
+    return ctx;
+}
+
 // table layout: A[n*(N+1)+m], B[n*(N+1)+m] for n >= m+2;  C1[m] = sqrt(2m+3);  CM[m] = sqrt((2m+1)/(2m))
-__global__ void sh_coeff_kernel(int N, double* __restrict__ tab) {
+__global__ void sh_coeff_kernel(int N, double* __restrict__ tab, size_t bstride) {
+    tab = boff(tab, bstride);
     const int stride = (N + 1) * (N + 1);
     double* A = tab;
     double* B = tab + stride;
@@ -40,7 +46,8 @@ template <bool COMPLEX>
 __global__ void __launch_bounds__(256) sh_basis_kernel(int N, int64_t D, const double* __restrict__ azi,
                                                        const double* __restrict__ zen,
                                                        const double* __restrict__ tab, double* __restrict__ Y,
-                                                       int64_t ld) {
+                                                       int64_t ld, size_t bstride) {
+    azi = boff(azi, bstride); zen = boff(zen, bstride); tab = boff(tab, bstride); Y = boff(Y, bstride);
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
     const int stride = (N + 1) * (N + 1);
@@ -97,7 +104,8 @@ __global__ void __launch_bounds__(256) sh_basis_kernel(int N, int64_t D, const d
 template <typename T>
 __global__ void __launch_bounds__(256) transpose_conj_kernel(const T* __restrict__ Y, int64_t D, int64_t S, int64_t ldY,
                                                              T* __restrict__ Yt, int64_t Dpad, int64_t ldYt,
-                                                             int conj_it) {
+                                                             int conj_it, size_t bstride) {
+    Y = boff(Y, bstride); Yt = boff(Yt, bstride);
     __shared__ T tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int64_t d0 = (int64_t)blockIdx.x * 32, s0 = (int64_t)blockIdx.y * 32;
@@ -118,19 +126,20 @@ __global__ void __launch_bounds__(256) transpose_conj_kernel(const T* __restrict
 }
 
 // zero fill with a plain kernel (hipMemsetAsync nodes misbehave under graph replay on older runtimes)
-__global__ void zero_fill_kernel(unsigned long long* __restrict__ p, int64_t n8) {
+__global__ void zero_fill_kernel(unsigned long long* __restrict__ p, int64_t n8, size_t bstride) {
+    p = boff(p, bstride);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0ull;
 }
 void launch_zero(void* p, size_t bytes, hipStream_t st) {
     const int64_t n8 = (int64_t)(bytes / 8);
     if (n8 == 0) return;
     const unsigned grid = (unsigned)std::min<int64_t>(2048, ceil_div(n8, 256));
-    zero_fill_kernel<<<grid, 256, 0, st>>>((unsigned long long*)p, n8);
+    zero_fill_kernel<<<bgrid(grid), 256, 0, st>>>((unsigned long long*)p, n8, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
 void launch_sh_coeff(int N, double* tab, hipStream_t st) {
-    sh_coeff_kernel<<<8, 256, 0, st>>>(N, tab);
+    sh_coeff_kernel<<<bgrid(8), 256, 0, st>>>(N, tab, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
@@ -139,9 +148,9 @@ void launch_sh_basis(int N, int64_t D, const double* azi, const double* zen, con
     if (D <= 0) return;
     dim3 grid((unsigned)ceil_div(D, 256));
     if (cplx_basis)
-        sh_basis_kernel<true><<<grid, 256, 0, st>>>(N, D, azi, zen, tab, (double*)Y, ld);
+        sh_basis_kernel<true><<<bgrid(grid), 256, 0, st>>>(N, D, azi, zen, tab, (double*)Y, ld, batch_ctx().stride);
     else
-        sh_basis_kernel<false><<<grid, 256, 0, st>>>(N, D, azi, zen, tab, (double*)Y, ld);
+        sh_basis_kernel<false><<<bgrid(grid), 256, 0, st>>>(N, D, azi, zen, tab, (double*)Y, ld, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
@@ -149,10 +158,10 @@ void launch_transpose_conj(const void* Y, int64_t D, int64_t S, int64_t ldY, voi
                            bool is_cplx, bool conj_it, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(Dpad, 32), (unsigned)ceil_div(S, 32));
     if (is_cplx)
-        transpose_conj_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)Y, D, S, ldY, (cplx*)Yt, Dpad, ldYt, conj_it);
+        transpose_conj_kernel<cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)Y, D, S, ldY, (cplx*)Yt, Dpad, ldYt, conj_it, batch_ctx().stride);
     else
-        transpose_conj_kernel<double><<<grid, 256, 0, st>>>((const double*)Y, D, S, ldY, (double*)Yt, Dpad, ldYt,
-                                                           conj_it);
+        transpose_conj_kernel<double><<<bgrid(grid), 256, 0, st>>>((const double*)Y, D, S, ldY, (double*)Yt, Dpad, ldYt,
+                                                           conj_it, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

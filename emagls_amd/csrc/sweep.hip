@@ -699,13 +699,14 @@ __global__ void __launch_bounds__(SW_NT) sweep_finalize_kernel(const cplx* __res
 // ---------------------------------------------------------------------------------------------
 template <typename TQ>
 __global__ void __launch_bounds__(256) hq_kernel(const cplx* __restrict__ Hc, int64_t ldD, int n_c, const TQ* __restrict__ Q,
-                                                 int64_t ldQ, int D, int S, int kb_lo, cplx* __restrict__ Hq, int ldS) {
+                                                 int64_t ldQ, int D, int S, int kb_lo, cplx* __restrict__ Hq, int ldS, size_t bstride) {
+    Hc = boff(Hc, bstride); Q = boff(Q, bstride); Hq = boff(Hq, bstride);
     // 32 SH channels x 8 direction slices per workgroup; slices reduced through LDS
     __shared__ __attribute__((aligned(16))) cplx red[8][33];
-    const int kb = kb_lo + blockIdx.x, e = blockIdx.y;
+    const int kb = kb_lo + blockIdx.x, e = blockIdx.y & 1;   // grid.y = (SH tile, ear); grid.z = design of a batch
     const cplx* h = Hc + ((int64_t)e * n_c + kb) * ldD;
     const int sl = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int s = blockIdx.z * 32 + sl;
+    const int s = (blockIdx.y >> 1) * 32 + sl;
     cplx a0 = mk(0, 0), a1 = mk(0, 0), a2 = mk(0, 0), a3 = mk(0, 0);
     if (s < S) {
         int d = part;
@@ -773,12 +774,14 @@ __global__ void __launch_bounds__(256) ls_filters_kernel(const double* __restric
 
 // elementwise conj copy (X = conj(Y) for the plain MagLS sweep) and real->complex widening
 template <typename T>
-__global__ void conj_copy_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n) {
+__global__ void conj_copy_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n, size_t bstride) {
+    in = boff(in, bstride); out = boff(out, bstride);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = conj(in[i]);
 }
 template <typename T>
 __global__ void widen_kernel(const T* __restrict__ in, int64_t ldi, cplx* __restrict__ out, int64_t ldo, int rows, int cols,
-                             int transpose, int upper_only) {
+                             int transpose, int upper_only, size_t bstride) {
+    in = boff(in, bstride); out = boff(out, bstride);
     // out[r][c] = in[r][c] (or in[c][r] when transpose) as complex; rows x cols of OUT
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)rows * cols;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -853,9 +856,9 @@ void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, in
 void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
                int kb_hi, void* Hq, int ldS, hipStream_t st) {
     if (kb_hi <= kb_lo) return;
-    dim3 grid(kb_hi - kb_lo, 2, (unsigned)ceil_div(S, 32));
-    if (q_cplx) hq_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const cplx*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS);
-    else hq_kernel<double><<<grid, 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const double*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS);
+    dim3 grid(kb_hi - kb_lo, 2 * (unsigned)ceil_div(S, 32));
+    if (q_cplx) hq_kernel<cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const cplx*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS, batch_ctx().stride);
+    else hq_kernel<double><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const double*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
@@ -886,16 +889,16 @@ void launch_ls_filters(const double* hL, const double* hR, int64_t L, int D, con
 }
 
 void launch_conj_copy(const void* in, void* out, int64_t n, bool is_cplx, hipStream_t st) {
-    if (is_cplx) conj_copy_kernel<cplx><<<1024, 256, 0, st>>>((const cplx*)in, (cplx*)out, n);
-    else conj_copy_kernel<double><<<1024, 256, 0, st>>>((const double*)in, (double*)out, n);
+    if (is_cplx) conj_copy_kernel<cplx><<<bgrid(1024), 256, 0, st>>>((const cplx*)in, (cplx*)out, n, batch_ctx().stride);
+    else conj_copy_kernel<double><<<bgrid(1024), 256, 0, st>>>((const double*)in, (double*)out, n, batch_ctx().stride);
     KERNEL_CHECK();
 }
 
 void launch_widen(const void* in, int64_t ldi, bool in_cplx, void* out, int64_t ldo, int rows, int cols, bool transpose,
                   bool upper_only, hipStream_t st) {
     const unsigned grid = (unsigned)std::min<int64_t>(1024, ceil_div((int64_t)rows * cols, 256));
-    if (in_cplx) widen_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)in, ldi, (cplx*)out, ldo, rows, cols, transpose, upper_only);
-    else widen_kernel<double><<<grid, 256, 0, st>>>((const double*)in, ldi, (cplx*)out, ldo, rows, cols, transpose, upper_only);
+    if (in_cplx) widen_kernel<cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)in, ldi, (cplx*)out, ldo, rows, cols, transpose, upper_only, batch_ctx().stride);
+    else widen_kernel<double><<<bgrid(grid), 256, 0, st>>>((const double*)in, ldi, (cplx*)out, ldo, rows, cols, transpose, upper_only, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

@@ -131,6 +131,56 @@ def test_batch_of_designs_matches_single_designs(grids, thin):
         p.close()
 
 
+def test_lane_batch_matches_single_designs(grids, thin):
+    """Designs of identical shape (same array radius, hence the same simulation order) are executed in lane mode:
+    every launch of the pipeline covers the whole batch.  Each design has its own HRIR grid (rotated), HRIR set and
+    microphone grid, so every per-design stage differs between the lanes."""
+    from emagls_amd import Batch, Plan, _lib as L, synth
+    jobs = []
+    for j in range(3):
+        azi = np.mod(thin["azi"] + 0.37 * j, 2 * np.pi)
+        hL, hR = synth.rigid_sphere_hrirs(azi, thin["zen"], seed=7 + j)
+        jobs.append((azi, hL, hR, np.mod(grids["mic_azi"] + 0.2 * j, 2 * np.pi)))
+
+    def mk(job):
+        azi, hL, hR, maz = job
+        p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, hL.shape[0], hL.shape[1], 0.042, 32)
+        p.set_hrir_grid(azi, thin["zen"])
+        p.set_mic_grid(maz, grids["mic_zen"])
+        p.set_hrirs(hL, hR)
+        return p
+
+    singles = []
+    for job in jobs:
+        q = mk(job)
+        q.execute()
+        singles.append(q.get_filters())
+        q.close()
+    plans = [mk(job) for job in jobs]
+    b = Batch(plans)
+    first = None
+    for it in range(3):  # eager, captured, replayed
+        b.execute()
+        res = b.get_filters()
+        for (wL, wR), (sL, sR) in zip(res, singles):
+            assert rel(wL, sL) < 1e-12 and rel(wR, sR) < 1e-12, it
+        if first is None:
+            first = res
+        else:
+            for (wL, wR), (fL, fR) in zip(res, first):
+                assert np.array_equal(wL, fL) and np.array_equal(wR, fR), it
+    # the plans still work on their own after the batch moved their buffers into its arena
+    plans[1].execute()
+    wL, wR = plans[1].get_filters()
+    assert rel(wL, singles[1][0]) < 1e-12 and rel(wR, singles[1][1]) < 1e-12
+    azi, hL, hR, maz = jobs[2]
+    oL, oR = O.getEMagLsFilters(hL, hR, azi, thin["zen"], 0.042, maz, grids["mic_zen"], 4, 48000.0, 128, "complex")
+    assert rel(res[2][0], oL) < TOL and rel(res[2][1], oR) < TOL
+    b.close()
+    for p in plans:
+        p.close()
+
+
 @pytest.mark.parametrize("mode", ["launch_per_bin", "persistent_write_through"])
 def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
     """The phase sweep has three forms: the persistent launch with XCD-local granule stores (default when all
