@@ -471,6 +471,8 @@ void execute_magls(emagls_plan& p) {
     p.mark("epilogue");
 }
 
+bool emagls_needs_q(const emagls_plan& p) { return !p.cplx_basis || p.sweep_factored; }
+
 void emagls_pre_sweep(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     const bool cb = p.cplx_basis;
@@ -543,8 +545,16 @@ void emagls_pre_sweep(emagls_plan& p) {
     }
     // s2 (after the prologue): Q = conj(Y) R^-1 and the least-squares right-hand sides H conj(Q)
     if (s2 != s0) HIP_CHECK(hipStreamWaitEvent(s2, e_R, 0));
-    launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, cb, p.get("Q"), s2);
-    launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Q"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, s2);
+    // Q itself is only needed by the legacy S-space sweep and by the real-basis path.  Otherwise H conj(Q) is formed as
+    // conj( conj(H conj(Yc)) R^-1 ): one D-long product and a row solve for the 2 (k_cut - 1) least-squares rows.
+    const bool need_q = emagls_needs_q(p);
+    if (need_q) {
+        launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, cb, p.get("Q"), s2);
+        launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Q"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, s2);
+    } else {
+        launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Yc"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, s2, true);
+        launch_qform(p.get("Hq"), p.get("R"), p.get("Rinv"), p.S, 2 * (int64_t)ls_end, p.ldS, cb, p.get("Hq"), s2);
+    }
 
     // s0: T_n, per-bin QR + Jacobi
     if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s0, e_E, 0));
@@ -558,6 +568,7 @@ void emagls_pre_sweep(emagls_plan& p) {
     fa.Mw = p.get<cplx>("Mw");
     fa.Vws = p.get<cplx>("Vws"); fa.sv = p.get<double>("sv");
     fa.Hq = p.get<cplx>("Hq"); fa.ldHq = p.ldS; fa.hq_estride = (int64_t)ls_end * p.ldS; fa.ls_end = ls_end;
+    fa.hq_conj = need_q ? 0 : 1;
     fa.W = p.get<cplx>("W"); fa.sweeps_out = p.get<int>("jsweeps");
     fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
     launch_factor(fa, p.P - 1, cb, s0, 1);
@@ -574,8 +585,14 @@ void emagls_pre_sweep(emagls_plan& p) {
         else
             launch_dspace_yri(p.get("G"), p.ldD, p.get("Mw"), 1, p.get<double>("sv"), p.get<double>("cond_ok"), (int)p.D, p.C, p.P,
                               k0, p.get("Yri"), s0);
-        launch_yri_accurate(p.get("Q"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
-                            p.get("Yri"), p.ldD, s0);
+        if (need_q) {
+            launch_yri_accurate(p.get("Q"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
+                                p.get("Yri"), p.ldD, s0);
+        } else {  // conj(Q) Z_k = conj(Yc) (Z_k R^-H): the flagged bins' Z rows are solved in place first
+            launch_zsolve_flagged(p.get("Z"), p.ldS, p.get("R"), p.get("Rinv"), p.get<double>("cond_ok"), p.S, p.C, p.P, k0, s0);
+            launch_yri_accurate(p.get("Yc"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
+                                p.get("Yri"), p.ldD, s0);
+        }
         p.mark("yri_operands");
     }
 }

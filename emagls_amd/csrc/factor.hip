@@ -354,8 +354,9 @@ __global__ void __launch_bounds__(MAXT) factor_back_kernel(FactorArgs a, size_t 
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
                 const int s = ch + NCH * i;
-                if (s < S) cfma(w, hq[s], conj(B[i]));
+                if (s < S) { if (a.hq_conj) cfma(w, hq[s], B[i]); else cfma(w, hq[s], conj(B[i])); }
             }
+            if (a.hq_conj) w = conj(w);
             w = group_sum<NCH>(w);
             if (ch == 0) a.W[((int64_t)e * a.P + kb) * C + c] = w;
         }

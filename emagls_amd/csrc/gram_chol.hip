@@ -462,6 +462,58 @@ void launch_cholesky(void* G, int S, bool is_cplx, int* flag, hipStream_t st) {
     if (is_cplx) chol_impl<cplx>(G, S, flag, st); else chol_impl<double>(G, S, flag, st);
 }
 
+// Ill-conditioned swept bins when Q is not materialised: Y_reg_inv = conj(Q) Z_k = conj(Yc) (Z_k R^-H), so the rows
+// Z[kb][c][:] of the flagged bins are replaced by zs with zs R^H = z (R upper triangular: columns from the back).
+//   block J (from the last):  acc(c, jj) = z(c, j0+jj) - sum_{i >= j0+32} zs(c, i) conj(R(j0+jj, i))
+//                             zs(c, j0+k) = sum_jj acc(c, jj) conj(Rinv_J(k, jj))
+// One workgroup per flagged bin (rare: tiny arrays); thread = (c, 8 column slices).
+__global__ void __launch_bounds__(256) zsolve_flagged_kernel(cplx* __restrict__ Z, int ldS, const cplx* __restrict__ R,
+                                                             const cplx* __restrict__ Rinv, const double* __restrict__ cond_ok,
+                                                             int S, int C, int k0, size_t bstride) {
+    Z = boff(Z, bstride); R = boff(R, bstride); Rinv = boff(Rinv, bstride); cond_ok = boff(cond_ok, bstride);
+    const int kb = k0 + blockIdx.x;
+    if (cond_ok[kb] != 0.0) return;
+    __shared__ cplx as[32][33];
+    __shared__ cplx ri[32][33];
+    const int c = threadIdx.x >> 3, part = threadIdx.x & 7;
+    cplx* z = Z + ((int64_t)kb * C + (c < C ? c : 0)) * ldS;
+    const int nblk = (S + NB - 1) / NB;
+    for (int J = nblk - 1; J >= 0; --J) {
+        const int j0 = J * NB;
+        for (int idx = threadIdx.x; idx < NB * NB; idx += 256) ri[idx / NB][idx % NB] = Rinv[(int64_t)J * NB * NB + idx];
+        for (int m = 0; m < 4; ++m) {
+            const int jj = part + 8 * m, j = j0 + jj;
+            cplx acc = mk(0, 0);
+            if (c < C && j < S) {
+                acc = z[j];
+                const cplx* rrow = R + (int64_t)j * S;
+                for (int i = j0 + NB; i < S; ++i) { cplx p = mk(0, 0); cfma(p, z[i], conj(rrow[i])); acc = acc - p; }
+            }
+            as[c][jj] = acc;
+        }
+        __syncthreads();
+        for (int m = 0; m < 4; ++m) {
+            const int k = part + 8 * m;
+            if (c < C && j0 + k < S) {
+                cplx x = mk(0, 0);
+                for (int jj = 0; jj < NB; ++jj) cfma(x, as[c][jj], conj(ri[k][jj]));
+                z[j0 + k] = x;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+void launch_zsolve_flagged(void* Z, int ldS, const void* R, const void* Rinv, const double* cond_ok, int S, int C, int P, int k0,
+                           hipStream_t st) {
+    if (P - k0 <= 0) return;
+    if (C > 32) throw Error(2, "zsolve: more than 32 channels");
+    zsolve_flagged_kernel<<<bgrid(P - k0), 256, 0, st>>>((cplx*)Z, ldS, (const cplx*)R, (const cplx*)Rinv, cond_ok, S, C, k0,
+                                                        batch_ctx().stride);
+    KERNEL_CHECK();
+}
+
 template <typename T> static void qform_impl(const void* Yc, const void* R, void* Rinv, int S, int64_t D, int64_t ld, void* Q,
                                              hipStream_t st) {
     const unsigned grid = (unsigned)ceil_div(D, 8);

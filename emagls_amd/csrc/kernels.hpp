@@ -38,6 +38,9 @@ int64_t gram_dpad(int64_t D);
 void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, void* Gp, void* G, hipStream_t st);
 void launch_cholesky(void* G, int S, bool is_cplx, int* flag, hipStream_t st);
 void launch_qform(const void* Yc, const void* R, void* Rinv, int S, int64_t D, int64_t ld, bool is_cplx, void* Q, hipStream_t st);
+// zs R^H = z for the rows Z[kb][c][:] of the flagged bins (cond_ok[kb] == 0), in place (complex basis)
+void launch_zsolve_flagged(void* Z, int ldS, const void* R, const void* Rinv, const double* cond_ok, int S, int C, int P, int k0,
+                           hipStream_t st);
 void launch_tn(const void* R, const void* E, int S, int C, int ldE, int nOrders, bool is_cplx, void* Tn, int64_t ldS,
                hipStream_t st);
 void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int ldb, bool b_cplx, void* Cm, int ldc,
@@ -69,7 +72,7 @@ void launch_sweep_dense_multi(const DenseSweepMulti& m, int kb, hipStream_t st);
 void launch_sweep_finalize_multi(const DenseSweepMulti& m, int kb_last, hipStream_t st);
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
 void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
-               int kb_hi, void* Hq, int ldS, hipStream_t st);
+               int kb_hi, void* Hq, int ldS, hipStream_t st, bool store_conj = false);
 void launch_ypinv(const void* Q, int64_t ldQ, bool q_cplx, const void* Zb, int ldS, int D, int S, int C, void* Ypinv,
                   int64_t ldD, hipStream_t st);
 void launch_ls_apply(const void* Hc, int64_t ldH, int n_c, const void* Zf, bool z_cplx, int64_t ldD, int D, int C, int P,

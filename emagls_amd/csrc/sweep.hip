@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(SW_NT) sweep_finalize_kernel(const cplx* __res
 // ---------------------------------------------------------------------------------------------
 template <typename TQ>
 __global__ void __launch_bounds__(256) hq_kernel(const cplx* __restrict__ Hc, int64_t ldD, int n_c, const TQ* __restrict__ Q,
-                                                 int64_t ldQ, int D, int S, int kb_lo, cplx* __restrict__ Hq, int ldS, size_t bstride) {
+                                                 int64_t ldQ, int D, int S, int kb_lo, cplx* __restrict__ Hq, int ldS, int store_conj, size_t bstride) {
     Hc = boff(Hc, bstride); Q = boff(Q, bstride); Hq = boff(Hq, bstride);
     // 32 SH channels x 8 direction slices per workgroup; slices reduced through LDS
     __shared__ __attribute__((aligned(16))) cplx red[8][33];
@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(256) hq_kernel(const cplx* __restrict__ Hc, in
         cplx acc = red[0][sl];
 #pragma unroll
         for (int j = 1; j < 8; ++j) acc += red[j][sl];
-        Hq[((int64_t)e * n_c + kb) * ldS + s] = acc;
+        Hq[((int64_t)e * n_c + kb) * ldS + s] = store_conj ? conj(acc) : acc;
     }
 }
 
@@ -854,11 +854,11 @@ void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, in
 }
 
 void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
-               int kb_hi, void* Hq, int ldS, hipStream_t st) {
+               int kb_hi, void* Hq, int ldS, hipStream_t st, bool store_conj) {
     if (kb_hi <= kb_lo) return;
     dim3 grid(kb_hi - kb_lo, 2 * (unsigned)ceil_div(S, 32));
-    if (q_cplx) hq_kernel<cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const cplx*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS, batch_ctx().stride);
-    else hq_kernel<double><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const double*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS, batch_ctx().stride);
+    if (q_cplx) hq_kernel<cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const cplx*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS, store_conj ? 1 : 0, batch_ctx().stride);
+    else hq_kernel<double><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const double*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS, store_conj ? 1 : 0, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

@@ -81,6 +81,31 @@ def test_emagls2_filters_thin(grids, thin, basis):
     assert report("eMagLS2 L " + basis, wL, oL) < TOL and report("eMagLS2 R " + basis, wR, oR) < TOL
 
 
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_emagls_tiny_array_ill_conditioned_bins(grids, thin, basis):
+    """A 7 mm array: kr stays below 0.4 up to 3 kHz, the high orders vanish and cond(pwGrid) is far above 1e4 in the
+    first swept bins.  Those bins cannot use Y_reg_inv = conj(G) conj(M); they take the accurate S-space form
+    conj(Q) Z_k (real basis: Q materialised; complex basis: conj(Yc) (Z_k R^-H))."""
+    import emagls_amd as A
+    from emagls_amd import Plan, _lib as L
+    length = 128
+    wL, wR = A.getEMagLsFilters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.007, grids["mic_azi"], grids["mic_zen"], 4,
+                                48000.0, length, basis)
+    oL, oR = O.getEMagLsFilters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.007, grids["mic_azi"], grids["mic_zen"], 4,
+                                48000.0, length, basis)
+    assert rel(wL, oL) < TOL and rel(wR, oR) < TOL, (rel(wL, oL), rel(wR, oR))
+    p = Plan(L.KIND_EMAGLS, basis, 4, 48000.0, length, thin["hL"].shape[0], thin["hL"].shape[1], 0.007, 32)
+    p.set_hrir_grid(thin["azi"], thin["zen"])
+    p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+    p.set_hrirs(thin["hL"], thin["hR"])
+    p.execute()
+    p.synchronize()
+    ok = p.debug("cond_ok", np.float64)
+    k0 = p.info().k_cut - 1
+    assert (ok[k0:] == 0).sum() >= 3, "the test must exercise the ill-conditioned path"
+    p.close()
+
+
 def test_emagls_filters_config3_full(grids, hrirs):
     """BASELINE config 3: em32 r = 4.2 cm, N = 4, complex SH, 2702 directions, 512 taps."""
     import emagls_amd as E

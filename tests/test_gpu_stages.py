@@ -80,9 +80,19 @@ def test_stage_basis_gram_cholesky_q(emagls_plan, grids):
     R = np.triu(p.debug("R", np.complex128, (S, S)))
     G = Yc[:D, :S].conj().T @ Yc[:D, :S]
     assert rel(R.conj().T @ R, G) < 1e-13
-    Q = p.debug("Q", np.complex128, (D, ldS))[:, :S]
+    # Q = conj(Y) R^-1 is not materialised for complex-basis eMagLS designs (only H conj(Q) and, for ill-conditioned
+    # bins, Z_k R^-H are formed): the Cholesky factor must make it orthonormal
+    Q = np.linalg.solve(R.T, Yc[:D, :S].T).T
     assert np.abs(Q.conj().T @ Q - np.eye(S)).max() < 1e-13
-    assert rel(Q @ R, Yc[:D, :S]) < 1e-13
+    Rinv = p.debug("Rinv", np.complex128).reshape(-1, 32, 32)
+    for J in range(S // 32):
+        assert rel(Rinv[J] @ R[32 * J:32 * J + 32, 32 * J:32 * J + 32], np.eye(32)) < 1e-13
+    # least-squares rows: Hq holds conj(H conj(Q)) for the bins below k_cut
+    kcut0 = i.k_cut - 1
+    Hc = p.debug("Hc", np.complex128).reshape(2, kcut0, ldD)[:, :, :D]
+    Hq = p.debug("Hq", np.complex128).reshape(2, kcut0, ldS)[:, :, :S]
+    for e in range(2):
+        assert rel(np.conj(Hq[e, 1:]), Hc[e, 1:] @ np.conj(Q)) < 1e-12
 
 
 def test_stage_array_model(emagls_plan, grids):
@@ -133,7 +143,8 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
     P, kcut0 = i.num_pos_freqs, i.k_cut - 1
     Tn = p.debug("Tn", np.complex128, (20, C, ldS))[:, :, :S]
     bn = p.debug("bn", np.complex128, (P, 20))
-    Q = p.debug("Q", np.complex128, (D, ldS))[:, :S]
+    Yc = p.debug("Yc", np.complex128).reshape(-1, ldS)[:D, :S]
+    Q = np.linalg.solve(np.triu(p.debug("R", np.complex128, (S, S))).T, Yc.T).T  # (not materialised on the GPU)
     Z = p.debug("Z", np.complex128).reshape(P, C, ldS)[:, :, :S]
     sv = p.debug("sv", np.float64).reshape(P, C)
     js = p.debug("jsweeps", np.int32)
