@@ -572,6 +572,12 @@ void emagls_pre_sweep(emagls_plan& p) {
     fa.W = p.get<cplx>("W"); fa.sweeps_out = p.get<int>("jsweeps");
     fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
     launch_factor(fa, p.P - 1, cb, s0, 1);
+    // cond_ok[kb]: the cheap direction-space identity is accurate for this bin.  Only the other swept bins (and the
+    // least-squares bins) need Z_k, i.e. the back-transform
+    if (!p.sweep_factored) {
+        launch_cond_flags(p.get<double>("sv"), p.C, p.P, p.get<double>("cond_ok"), s0);
+        fa.cond_ok = p.get<double>("cond_ok");
+    }
     p.mark("factor_qr_jacobi");
     // join s2 (Q, Hq, spectra, group delays): back-transform + least-squares bins
     p.depend(s0, s2);
@@ -580,9 +586,7 @@ void emagls_pre_sweep(emagls_plan& p) {
     // join s1 (G)
     p.depend(s0, s1);
     if (!p.sweep_factored) {
-        if (p.sweep_half)
-            launch_cond_flags(p.get<double>("sv"), p.C, p.P, p.get<double>("cond_ok"), s0);
-        else
+        if (!p.sweep_half)
             launch_dspace_yri(p.get("G"), p.ldD, p.get("Mw"), 1, p.get<double>("sv"), p.get<double>("cond_ok"), (int)p.D, p.C, p.P,
                               k0, p.get("Yri"), s0);
         if (need_q) {

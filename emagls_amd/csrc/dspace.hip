@@ -55,23 +55,23 @@ __global__ void __launch_bounds__(512) qt_kernel(const T* __restrict__ Yc, int64
     }
 }
 
-// G kernel: one workgroup = 8 directions x a chunk of swept bins; thread = (channel, direction).  The
-// thread's order terms QT[n][c][d] stay in registers for the whole chunk and the chunk's b_n(k) table is
-// staged in LDS once, so a bin costs 20 LDS broadcasts, 20 complex FMAs and one coalesced store -- no barrier.
+// G kernel: one workgroup = 64 directions x a chunk of swept bins; a wave owns one channel pair (c, c + 4) at a time and
+// its 64 lanes are 64 consecutive directions, so every store instruction writes one contiguous 1 KB run (short
+// scattered runs cost HBM page locality).  The thread's order terms QT[n][c][d] stay in registers for the whole chunk,
+// the chunk's b_n(k) table sits in LDS and every LDS broadcast of a b_n feeds two complex FMAs.
 //   G [kb - k0][c][d]
-constexpr int DSP_TD = 8;
+constexpr int DSP_TD = 64;
 constexpr int DSP_NMAX = 32;  // orders held in registers (simulation order <= 31)
 
-template <typename T>
+template <typename T, int NMAX>
 __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT, int64_t ldD, const cplx* __restrict__ bn,
                                                        int nOrders, int D, int C, int P, int k0, int bins_per_chunk,
                                                        cplx* __restrict__ G, size_t bstride) {
     QT = boff(QT, bstride); bn = boff(bn, bstride); G = boff(G, bstride);
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     cplx* bs = reinterpret_cast<cplx*>(dyn);  // [bins_per_chunk][nOrders]
-    const int c = threadIdx.x >> 3, dl = threadIdx.x & 7;  // direction fastest: full-line stores
-    const int d = blockIdx.x * DSP_TD + dl;
-    const bool act = c < C && d < D;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int d = blockIdx.x * DSP_TD + lane;
     const int kb_begin = k0 + blockIdx.y * bins_per_chunk;
     const int kb_end = min(P, kb_begin + bins_per_chunk);
     for (int idx = threadIdx.x; idx < (kb_end - kb_begin) * nOrders; idx += 256) {
@@ -80,20 +80,31 @@ __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT,
         if (kb == P - 1) b.y = 0.0;  // Nyquist: real(Bn)
         bs[idx] = b;
     }
-    T qt[DSP_NMAX];
-#pragma unroll
-    for (int n = 0; n < DSP_NMAX; ++n) qt[n] = (act && n < nOrders) ? QT[((int64_t)n * C + c) * ldD + d] : zero_of<T>();
     __syncthreads();
-    if (!act) return;
-    for (int kb = kb_begin; kb < kb_end; ++kb) {
-        const cplx* b = bs + (size_t)(kb - kb_begin) * nOrders;
-        cplx g0 = mk(0, 0), g1 = mk(0, 0);
+    if (d >= D) return;
+    for (int cbase = 0; cbase < C; cbase += 8) {
+        const int ca = cbase + wave, cb2 = ca + 4;
+        if (ca >= C) break;   // (wave-uniform)
+        const bool two = cb2 < C;
+        T qa[NMAX], qb[NMAX];
 #pragma unroll
-        for (int n = 0; n < DSP_NMAX; n += 2) {
-            if (n < nOrders) cfma(g0, b[n], qt[n]);
-            if (n + 1 < nOrders) cfma(g1, b[n + 1], qt[n + 1]);
+        for (int n = 0; n < NMAX; ++n) {
+            qa[n] = (n < nOrders) ? QT[((int64_t)n * C + ca) * ldD + d] : zero_of<T>();
+            qb[n] = (two && n < nOrders) ? QT[((int64_t)n * C + cb2) * ldD + d] : zero_of<T>();
         }
-        G[((int64_t)(kb - k0) * C + c) * ldD + d] = g0 + g1;
+        cplx* g = G + ((int64_t)(kb_begin - k0) * C + ca) * ldD + d;
+        const int64_t gstep = (int64_t)C * ldD;
+        for (int kb = kb_begin; kb < kb_end; ++kb, g += gstep) {
+            const cplx* b = bs + (size_t)(kb - kb_begin) * nOrders;
+            cplx g0 = mk(0, 0), g1 = mk(0, 0), h0 = mk(0, 0), h1 = mk(0, 0);
+#pragma unroll
+            for (int n = 0; n < NMAX; n += 2) {
+                if (n < nOrders) { const cplx bb = b[n]; cfma(g0, bb, qa[n]); cfma(h0, bb, qb[n]); }
+                if (n + 1 < nOrders) { const cplx bb = b[n + 1]; cfma(g1, bb, qa[n + 1]); cfma(h1, bb, qb[n + 1]); }
+            }
+            g[0] = g0 + g1;
+            if (two) g[4 * ldD] = h0 + h1;
+        }
     }
 }
 
@@ -181,12 +192,15 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
     const int nbins = P - k0;
     if (nbins <= 0) return;
     if (nOrders > DSP_NMAX) throw Error(2, "dspace: simulation order above 31 is not supported in this build");
-    int chunks = 4;
+    int chunks = 8;
     while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nOrders > 56 * 1024) ++chunks;  // b_n table of a chunk in LDS
     const int bpc = (nbins + chunks - 1) / chunks;
     const size_t dyn = sizeof(cplx) * (size_t)bpc * nOrders;
-    dspace_g_kernel<T><<<bgrid(dim3((unsigned)ceil_div(D, DSP_TD), chunks)), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D,
-                                                                                     C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
+    const dim3 grid((unsigned)ceil_div(D, DSP_TD), chunks);
+    if (nOrders <= 20)
+        dspace_g_kernel<T, 20><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
+    else
+        dspace_g_kernel<T, DSP_NMAX><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
     KERNEL_CHECK();
 }
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,

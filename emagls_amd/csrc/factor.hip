@@ -21,7 +21,7 @@ namespace emagls {
 __device__ __forceinline__ void batch_offset(FactorArgs& a, size_t bstride) {
     a.Tn = boff(a.Tn, bstride); a.bn = boff(a.bn, bstride); a.Xd = boff(a.Xd, bstride);
     a.Z = boff(a.Z, bstride); a.Bk = boff(a.Bk, bstride); a.Vws = boff(a.Vws, bstride); a.sv = boff(a.sv, bstride);
-    a.Hq = boff(a.Hq, bstride); a.W = boff(a.W, bstride); a.sweeps_out = boff(a.sweeps_out, bstride);
+    a.Hq = boff(a.Hq, bstride); a.cond_ok = boff(a.cond_ok, bstride); a.W = boff(a.W, bstride); a.sweeps_out = boff(a.sweeps_out, bstride);
     a.tauw = boff(a.tauw, bstride); a.R2w = boff(a.R2w, bstride); a.Nw = boff(a.Nw, bstride); a.Mw = boff(a.Mw, bstride);
 }
 
@@ -84,41 +84,50 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
         }
     }
     // ------------------------------------------------------------------ 2. Householder QR
+    // One barrier per column: while the lane groups c > j apply H_j, the group of column j+1 goes on to form v_{j+1}
+    // from its freshly updated column (look-ahead), so the pivot computation never leaves the other groups waiting.
+    // The pivot arithmetic (norm, phase, tau) uses the reciprocal / rsqrt seeds + Newton steps instead of the
+    // library sqrt, hypot and divisions: it sits on the critical path of all 25 steps.
     cplx* Vw = a.Vws + (int64_t)blockIdx.x * C * ldS;
-    for (int j = 0; j < C; ++j) {
+    auto make_reflector = [&](int j) {  // executed by the lane group c == j on its own column
         cplx* vb = vbuf + (size_t)(j & 1) * ldS;
-        if (c == j) {
-            double n2 = 0.0;
-            cplx x0 = mk(0, 0);
+        double n2 = 0.0;
+        cplx x0 = mk(0, 0);
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const int s = ch + NCH * i;
-                if (s >= j && s < S) n2 += norm2(B[i]);
-                if (s == j) x0 = B[i];
-            }
-            n2 = group_sum<NCH>(n2);
-            x0 = group_sum<NCH>(x0);
-            const double nrm = sqrt(n2);
-            const double ax0 = cabs(x0);
-            cplx alpha = mk(0, 0);
-            double tau = 0.0;
-            if (nrm > 0.0) {
-                alpha = (ax0 > 0.0) ? mk(-x0.x / ax0 * nrm, -x0.y / ax0 * nrm) : mk(-nrm, 0.0);
-                tau = 1.0 / (nrm * (nrm + ax0));  // 2 / ||v||^2, ||v||^2 = 2 nrm (nrm + |x0|)
-            }
-#pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const int s = ch + NCH * i;
-                if (s == j) B[i] = B[i] - alpha;  // v0 = x0 - alpha
-                if (s >= j && s < S) {
-                    const cplx v = (nrm > 0.0) ? B[i] : mk(0, 0);
-                    vb[s] = v;
-                    Vw[(int64_t)j * ldS + s] = v;
-                }
-            }
-            if (ch == 0) { alpha_s[j] = alpha; tau_s[j] = tau; }
+        for (int i = 0; i < RPT; ++i) {
+            const int s = ch + NCH * i;
+            if (s >= j && s < S) n2 += norm2(B[i]);
+            if (s == j) x0 = B[i];
         }
-        __syncthreads();
+        n2 = group_sum<NCH>(n2);
+        x0 = group_sum<NCH>(x0);
+        const bool nz = n2 > 0.0;
+        const double nrm = nz ? n2 * fast_rsqrt(n2) : 0.0;
+        const double a2 = norm2(x0);
+        const double iax0 = a2 > 0.0 ? fast_rsqrt(a2) : 0.0;   // 1 / |x0|
+        const double ax0 = a2 * iax0;
+        cplx alpha = mk(0, 0);
+        double tau = 0.0;
+        if (nz) {
+            alpha = (a2 > 0.0) ? mk(-x0.x * iax0 * nrm, -x0.y * iax0 * nrm) : mk(-nrm, 0.0);
+            tau = fast_rcp(nrm * (nrm + ax0));  // 2 / ||v||^2, ||v||^2 = 2 nrm (nrm + |x0|)
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int s = ch + NCH * i;
+            if (s == j) B[i] = B[i] - alpha;  // v0 = x0 - alpha
+            if (s >= j && s < S) {
+                const cplx v = nz ? B[i] : mk(0, 0);
+                vb[s] = v;
+                Vw[(int64_t)j * ldS + s] = v;
+            }
+        }
+        if (ch == 0) { alpha_s[j] = alpha; tau_s[j] = tau; }
+    };
+    if (c == 0) make_reflector(0);
+    __syncthreads();
+    for (int j = 0; j < C; ++j) {
+        const cplx* vb = vbuf + (size_t)(j & 1) * ldS;
         if (active && c > j) {
             const double tau = tau_s[j];
             cplx w = mk(0, 0);
@@ -134,8 +143,9 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
                 const int s = ch + NCH * i;
                 if (s >= j && s < S) { cplx p = w * vb[s]; B[i] -= p; }
             }
+            if (c == j + 1) make_reflector(j + 1);  // writes the other half of vbuf
         }
-        // vbuf is double-buffered: the next column writes the other half, no second barrier needed
+        __syncthreads();
     }
     // ------------------------------------------------------------------ 3. hand R2 and tau to the SVD kernel
     if (active) {
@@ -161,6 +171,7 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     __shared__ __attribute__((aligned(16))) cplx Xs[CPMAX][CPMAX + 1];  // Xs[col][row]
     __shared__ __attribute__((aligned(16))) cplx Vs[CPMAX][CPMAX + 1];
     __shared__ double g_s[CPMAX];
+    __shared__ double w_s[CPMAX];
     __shared__ double sig_s[CPMAX];
     const int tid = threadIdx.x;
     const int C = a.C;
@@ -258,6 +269,7 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
             }
         }
         g_s[tid] = g;
+        w_s[tid] = (s > 0.0) ? g / (s * s) : 0.0;   // weights of M = V diag(g) V^H with V = Xrot / sigma
         if (a.sv && tid < C) a.sv[(int64_t)kb * C + tid] = s;
     }
     __syncthreads();
@@ -279,9 +291,7 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
             const int aa = idx / C, bb = idx % C;
             cplx acc = mk(0, 0);
             for (int i = 0; i < C; ++i) {
-                const double sg = sig_s[i];
-                const double w = (sg > 0.0) ? g_s[i] / (sg * sg) : 0.0;
-                const cplx t = w * Xs[i][aa];
+                const cplx t = w_s[i] * Xs[i][aa];
                 cfma(acc, t, conj(Xs[i][bb]));
             }
             M[idx] = acc;
@@ -300,6 +310,8 @@ __global__ void __launch_bounds__(MAXT) factor_back_kernel(FactorArgs a, size_t 
     const int S = a.S, C = a.C, ldS = a.ldS;
     const int kb = a.kb0 + blockIdx.x;
     if (c >= C) return;
+    // Z_k feeds the least-squares bins and the ill-conditioned swept bins only (the sweep uses G_k and M_k)
+    if (a.cond_ok && kb >= a.ls_end && a.cond_ok[kb] != 0.0) return;
     const cplx* Vw = a.Vws + (int64_t)blockIdx.x * C * ldS;
     const cplx* N = a.Nw + (int64_t)blockIdx.x * C * C;
     const double* tauw = a.tauw + (int64_t)blockIdx.x * C;
