@@ -210,6 +210,12 @@ def main():
                     plans[b][0].execute()
                 started.append(b)
             for b in started:
+                if batches[b] is not None and store and s + Bsz <= nsteps:
+                    # one synchronisation and one status check for the whole batch; device-to-device copies
+                    batches[b].get_filters_into([out[s + j, 0].data_ptr() for j in range(Bsz)],
+                                                [out[s + j, 1].data_ptr() for j in range(Bsz)])
+                    s += Bsz
+                    continue
                 for j, p in enumerate(plans[b]):
                     if s < nsteps and store:
                         L.check(lib.emagls_plan_get_filters(p._h, C.c_void_p(out[s, 0].data_ptr()),

@@ -74,6 +74,7 @@ SYMBOLS = {
     "emagls_batch_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
     "emagls_batch_execute": (C.c_int, [C.c_void_p]),
     "emagls_batch_synchronize": (C.c_int, [C.c_void_p]),
+    "emagls_batch_get_filters": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "emagls_batch_destroy": (C.c_int, [C.c_void_p]),
 }
 

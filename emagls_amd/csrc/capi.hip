@@ -305,6 +305,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("bn", sizeof(cplx) * (size_t)p.P * (p.simOrder + 1));
         p.alloc("Tn", esz(cb) * (size_t)(p.simOrder + 1) * p.C * p.ldS);
         p.alloc("Hq", sizeof(cplx) * (size_t)2 * std::max(p.kcut0, 1) * p.ldS);
+        p.alloc("Hyp", sizeof(cplx) * hy_workspace_elems(2 * std::max(p.kcut0, 1), p.ldS));
         p.alloc("Z", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
         p.alloc("Bk", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
         p.alloc("Vws", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
@@ -552,7 +553,7 @@ void emagls_pre_sweep(emagls_plan& p) {
         launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, cb, p.get("Q"), s2);
         launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Q"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, s2);
     } else {
-        launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Yc"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, s2, true);
+        launch_hy_conj(p.get("Hc"), p.ldD, 2 * ls_end, p.get("Yc"), p.ldS, (int)p.D, p.S, p.get("Hyp"), p.get("Hq"), p.ldS, s2);
         launch_qform(p.get("Hq"), p.get("R"), p.get("Rinv"), p.S, 2 * (int64_t)ls_end, p.ldS, cb, p.get("Hq"), s2);
     }
 
@@ -1316,6 +1317,37 @@ int emagls_batch_synchronize(emagls_batch* b) {
     return guarded([&] {
         if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
         HIP_CHECK(hipStreamSynchronize(b->stream));
+    });
+}
+int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) {
+    return guarded([&] {
+        if (!b || !wL || !wR) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        const size_t n = b->plans.size();
+        for (size_t j = 0; j < n; ++j) {
+            if (!wL[j] || !wR[j]) throw Error(EMAGLS_ERR_ARG, "null pointer");
+            if (!b->plans[j]->executed) throw Error(EMAGLS_ERR_ARG, "batch has not been executed");
+        }
+        emagls_plan& p0 = *b->plans[0];
+        const size_t bytes = (p0.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p0.out_rows * p0.out_cols;
+        // the copies are ordered behind the batch on its stream; one synchronisation for everything
+        std::vector<int> flags(4 * n, 0);
+        if (b->lanes)
+            HIP_CHECK(hipMemcpy2DAsync(flags.data(), 4 * sizeof(int), p0.get("flag"), b->stride, 4 * sizeof(int), n,
+                                       hipMemcpyDeviceToHost, b->stream));
+        else
+            for (size_t j = 0; j < n; ++j)
+                HIP_CHECK(hipMemcpyAsync(&flags[4 * j], b->plans[j]->get("flag"), 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+        for (size_t j = 0; j < n; ++j) {
+            HIP_CHECK(hipMemcpyAsync(wL[j], b->plans[j]->get("wL"), bytes, hipMemcpyDefault, b->stream));
+            HIP_CHECK(hipMemcpyAsync(wR[j], b->plans[j]->get("wR"), bytes, hipMemcpyDefault, b->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(b->stream));
+        for (size_t j = 0; j < n; ++j) {
+            if (flags[4 * j + 1])
+                throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");
+            if (flags[4 * j])
+                throw Error(EMAGLS_ERR_NUMERIC, "SH Gram matrix of the HRIR grid is not positive definite (the grid cannot resolve the required SH order)");
+        }
     });
 }
 int emagls_batch_destroy(emagls_batch* b) {

@@ -73,6 +73,9 @@ void launch_sweep_finalize_multi(const DenseSweepMulti& m, int kb_last, hipStrea
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
 void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
                int kb_hi, void* Hq, int ldS, hipStream_t st, bool store_conj = false);
+void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, int D, int S, void* Pw, void* out, int ldS,
+                    hipStream_t st);
+size_t hy_workspace_elems(int nrows, int ldS);
 void launch_ypinv(const void* Q, int64_t ldQ, bool q_cplx, const void* Zb, int ldS, int D, int S, int C, void* Ypinv,
                   int64_t ldD, hipStream_t st);
 void launch_ls_apply(const void* Hc, int64_t ldH, int n_c, const void* Zf, bool z_cplx, int64_t ldD, int D, int C, int P,

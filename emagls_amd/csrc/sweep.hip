@@ -728,6 +728,90 @@ __global__ void __launch_bounds__(256) hq_kernel(const cplx* __restrict__ Hc, in
     }
 }
 
+// Least-squares rows without Q:  conj(H conj(Yc)) as a tiled product  P[r][s] = sum_d H[r][d] conj(Yc[d][s])
+// (r = (ear, bin) rows of Hc, 2 n_c of them).  Workgroup tile 96 rows x 32 columns x one K slice of the directions,
+// thread tile 3 x 4: the operands of a 32-direction chunk sit in LDS and every LDS read feeds 3-4 complex FMAs.
+// The K slices are summed in a fixed order by hy_reduce_kernel (bitwise reproducible), which also conjugates.
+constexpr int HY_RT = 96, HY_CT = 32, HY_DC = 32, HY_KS = 8;
+
+__global__ void __launch_bounds__(256) hy_partial_kernel(const cplx* __restrict__ Hc, int64_t ldD, int nrows, const cplx* __restrict__ Yc,
+                                                         int64_t ldY, int D, int S, cplx* __restrict__ Pw, int ldS, size_t bstride) {
+    Hc = boff(Hc, bstride); Yc = boff(Yc, bstride); Pw = boff(Pw, bstride);
+    __shared__ __attribute__((aligned(16))) cplx hs[HY_RT][HY_DC + 1];
+    __shared__ __attribute__((aligned(16))) cplx ys[HY_DC][HY_CT + 1];
+    const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+    const int s0 = blockIdx.x * HY_CT;
+    const int rt = blockIdx.y / HY_KS, ks = blockIdx.y % HY_KS;
+    const int r0 = rt * HY_RT;
+    const int dper = ((D + HY_KS - 1) / HY_KS + HY_DC - 1) / HY_DC * HY_DC;
+    const int dbeg = ks * dper, dend = min(D, dbeg + dper);
+    cplx acc[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mk(0, 0);
+    for (int d0 = dbeg; d0 < dend; d0 += HY_DC) {
+#pragma unroll
+        for (int i = 0; i < (HY_RT * HY_DC) / 256; ++i) {
+            const int idx = tid + 256 * i, r = idx / HY_DC, dd = idx % HY_DC;
+            hs[r][dd] = (r0 + r < nrows && d0 + dd < dend) ? Hc[(int64_t)(r0 + r) * ldD + d0 + dd] : mk(0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < (HY_DC * HY_CT) / 256; ++i) {
+            const int idx = tid + 256 * i, dd = idx / HY_CT, c = idx % HY_CT;
+            ys[dd][c] = (d0 + dd < dend && s0 + c < S) ? Yc[(int64_t)(d0 + dd) * ldY + s0 + c] : mk(0, 0);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int dd = 0; dd < HY_DC; ++dd) {
+            cplx y[4], h[3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = conj(ys[dd][4 * cg + j]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) h[i] = hs[rg + 32 * i][dd];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cfma(acc[i][j], h[i], y[j]);
+        }
+        __syncthreads();
+    }
+    cplx* P = Pw + (int64_t)ks * nrows * ldS;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int r = r0 + rg + 32 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sc = s0 + 4 * cg + j;
+            if (r < nrows && sc < S) P[(int64_t)r * ldS + sc] = acc[i][j];
+        }
+    }
+}
+__global__ void __launch_bounds__(256) hy_reduce_kernel(const cplx* __restrict__ Pw, int nrows, int S, int ldS, cplx* __restrict__ out,
+                                                        size_t bstride) {
+    Pw = boff(Pw, bstride); out = boff(out, bstride);
+    const int r = blockIdx.y;
+    const int sc = blockIdx.x * 256 + threadIdx.x;
+    if (sc >= S) return;
+    cplx acc = mk(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < HY_KS; ++ks) acc += Pw[((int64_t)ks * nrows + r) * ldS + sc];
+    out[(int64_t)r * ldS + sc] = conj(acc);
+}
+// out[r][s] = conj( sum_d Hc[r][d] conj(Yc[d][s]) ), r < nrows;  Pw: workspace [HY_KS][nrows][ldS]
+void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, int D, int S, void* Pw, void* out, int ldS,
+                    hipStream_t st) {
+    if (nrows <= 0) return;
+    const dim3 grid((unsigned)ceil_div(S, HY_CT), (unsigned)(ceil_div(nrows, HY_RT) * HY_KS));
+    hy_partial_kernel<<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, nrows, (const cplx*)Yc, ldY, D, S, (cplx*)Pw, ldS,
+                                                   batch_ctx().stride);
+    KERNEL_CHECK();
+    hy_reduce_kernel<<<bgrid(dim3((unsigned)ceil_div(S, 256), nrows)), 256, 0, st>>>((const cplx*)Pw, nrows, S, ldS, (cplx*)out,
+                                                                                   batch_ctx().stride);
+    KERNEL_CHECK();
+}
+size_t hy_workspace_elems(int nrows, int ldS) { return (size_t)HY_KS * nrows * ldS; }
+
 // Ypinv[c][d] = sum_s conj(Q[d][s]) Zb[c][s]      (pinv(Y_conj) = conj(Q) Z_B, lib/getLsFilters.m:31)
 template <typename TQ>
 __global__ void __launch_bounds__(256) ypinv_kernel(const TQ* __restrict__ Q, int64_t ldQ, const cplx* __restrict__ Zb, int ldS,

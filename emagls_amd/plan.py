@@ -114,7 +114,23 @@ class Batch:
         L.check(self._lib.emagls_batch_synchronize(self._h))
 
     def get_filters(self):
-        return [p.get_filters() for p in self.plans]
+        outs = []
+        i = self.plans[0].info()
+        dt = np.complex128 if i.out_is_complex else np.float64
+        for p in self.plans:
+            outs.append((np.zeros((i.out_rows, i.out_cols), dtype=dt, order="F"), np.zeros((i.out_rows, i.out_cols), dtype=dt, order="F")))
+        n = len(self.plans)
+        pl = (C.c_void_p * n)(*[o[0].ctypes.data for o in outs])
+        pr = (C.c_void_p * n)(*[o[1].ctypes.data for o in outs])
+        L.check(self._lib.emagls_batch_get_filters(self._h, pl, pr))
+        return outs
+
+    def get_filters_into(self, ptrs_l, ptrs_r):
+        """Device (or host) destination addresses, one pair per plan: no host staging."""
+        n = len(self.plans)
+        pl = (C.c_void_p * n)(*ptrs_l)
+        pr = (C.c_void_p * n)(*ptrs_r)
+        L.check(self._lib.emagls_batch_get_filters(self._h, pl, pr))
 
     def close(self):
         if self._h:

@@ -159,13 +159,18 @@ int emagls_plan_debug_buffer(emagls_plan* plan, const char* name, void* dst, siz
 void* emagls_plan_stream(emagls_plan* plan);
 
 /* ---- batches: several eMagLS / eMagLS2 designs of identical shape (different arrays / HRIR sets) ---------
- * The per-design stages run on the plans' own streams; the sequential sweep is issued ONCE per frequency
- * bin for all designs of the batch (the launch-bound part of a design).  At most 8 plans; the plans stay
- * owned by the caller and must outlive the batch.  Results: emagls_plan_get_filters on each plan. */
+ * Plans of identical shape (same simulation order: same array radius class) are executed in lane mode: their buffers
+ * are moved into one arena at a constant stride and every launch of the pipeline covers all designs (grid.z = design);
+ * the sequential sweep is one resident launch in which each design's workgroups occupy one XCD.  Other batches run the
+ * per-design stages on the plans' own streams and share only the sweep.  At most 8 plans; the plans stay owned by the
+ * caller and must outlive the batch.  Results: emagls_batch_get_filters, or emagls_plan_get_filters on each plan. */
 typedef struct emagls_batch emagls_batch;
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch);
 int emagls_batch_execute(emagls_batch* batch);
 int emagls_batch_synchronize(emagls_batch* batch);
+/* synchronise once, check every plan's device-side status flags, copy all filters out: wL[j], wR[j] receive the filters of
+ * plan j (host or device pointers).  Equivalent to emagls_plan_get_filters on every plan, without the per-plan round trips. */
+int emagls_batch_get_filters(emagls_batch* batch, void* const* wL, void* const* wR);
 int emagls_batch_destroy(emagls_batch* batch);
 
 #ifdef __cplusplus
