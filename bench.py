@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--concurrent", type=int, default=int(os.environ.get("EMAGLS_BENCH_CONCURRENT", "8")),
+    ap.add_argument("--concurrent", type=int, default=int(os.environ.get("EMAGLS_BENCH_CONCURRENT", "16")),
                     help="independent designs in flight per GPU (steps are processed in groups of this size)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", "8")),
                     help="designs per batch: the sequential sweep is launched once per bin for the whole batch")

@@ -33,6 +33,8 @@ struct FactorArgs {
     int64_t hq_estride;
     int ls_end;
     const double* cond_ok;  // optional [P]: the back-transform (Z_k) is only needed for kb < ls_end and where cond_ok[kb] == 0
+    int jrun;         // Jacobi: consecutive bins per workgroup (warm start from the neighbour's rotations); 0/1 = independent
+    int nbins;        // set by the launcher
     int hq_conj;      // Hq holds conj(H conj(Q)) (the row-solve form used when Q is not materialised)
     cplx* W;          // [e][P][C]
     int* sweeps_out;  // optional [kb]

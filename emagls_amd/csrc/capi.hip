@@ -570,6 +570,10 @@ void emagls_pre_sweep(emagls_plan& p) {
     fa.Vws = p.get<cplx>("Vws"); fa.sv = p.get<double>("sv");
     fa.Hq = p.get<cplx>("Hq"); fa.ldHq = p.ldS; fa.hq_estride = (int64_t)ls_end * p.ldS; fa.ls_end = ls_end;
     fa.hq_conj = need_q ? 0 : 1;
+    // batches have workgroups to spare: a Jacobi workgroup walks a run of neighbouring bins, each warm-started from the
+    // previous one (a third of the sweeps); a single design keeps one bin per workgroup (shortest critical path)
+    fa.jrun = batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
+    if (const char* e = getenv("EMAGLS_JACOBI_RUN")) fa.jrun = std::max(1, atoi(e));
     fa.W = p.get<cplx>("W"); fa.sweeps_out = p.get<int>("jsweeps");
     fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
     launch_factor(fa, p.P - 1, cb, s0, 1);
