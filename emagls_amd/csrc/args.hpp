@@ -33,6 +33,10 @@ struct FactorArgs {
     int64_t hq_estride;
     int ls_end;
     const double* cond_ok;  // optional [P]: the back-transform (Z_k) is only needed for kb < ls_end and where cond_ok[kb] == 0
+    // Gram route (well-conditioned swept bins): the QR kernel hands A = B^H B instead of R2 and skips the reflectors
+    int gram_from;    // first bin that takes it (0: none); the host derives it from kr so that cond(B) stays below ~3e2
+    int* route;       // [P] 1 where the Gram route was taken (zeroed per execute)
+    int* status;      // plan status flags; [2] is set when a Gram-route bin turns out ill-conditioned (the host re-runs without it)
     int jrun;         // Jacobi: consecutive bins per workgroup (warm start from the neighbour's rotations); 0/1 = independent
     int nbins;        // set by the launcher
     int hq_conj;      // Hq holds conj(H conj(Q)) (the row-solve form used when Q is not materialised)

@@ -57,6 +57,9 @@ struct emagls_plan {
     bool sweep_split = false;
     // one direction-space operand per bin (G_k; M_k applied after the cross-workgroup sum): default
     bool sweep_half = true;
+    // Gram route of the per-bin factorisation for the well-conditioned swept bins (factor.hip); switched off for good
+    // when a run reports that the kr-based conditioning estimate was too optimistic (the plan is then re-executed)
+    bool gram_route = true;
     bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip); needs sweep_half
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
     // profiling
@@ -112,7 +115,7 @@ struct emagls_plan {
     void* alloc(const std::string& name, size_t bytes, bool zero = true) {
         if (bytes == 0) bytes = 16;
         DevBuf b;
-        HIP_CHECK(hipMalloc(&b.p, bytes));
+        HIP_CHECK(hipMalloc(&b.p, (bytes + 15) / 16 * 16));  // (launch_zero works on whole 8-byte words)
         b.bytes = bytes;
         if (zero) HIP_CHECK(hipMemsetAsync(b.p, 0, bytes, stream));
         bufs[name] = b;
@@ -305,6 +308,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("bn", sizeof(cplx) * (size_t)p.P * (p.simOrder + 1));
         p.alloc("Tn", esz(cb) * (size_t)(p.simOrder + 1) * p.C * p.ldS);
         p.alloc("Hq", sizeof(cplx) * (size_t)2 * std::max(p.kcut0, 1) * p.ldS);
+        p.alloc("route", sizeof(int) * (size_t)p.P);
         p.alloc("Hyp", sizeof(cplx) * hy_workspace_elems(2 * std::max(p.kcut0, 1), p.ldS));
         p.alloc("Z", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
         p.alloc("Bk", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
@@ -472,6 +476,25 @@ void execute_magls(emagls_plan& p) {
     p.mark("epilogue");
 }
 
+// First bin of the Gram route: cond(B_k) is governed by the ratio of the lowest to the highest modal coefficient the C
+// output channels can carry, |b_0 / b_n| ~ (2n+1)!! / (kr)^n with n = ceil(sqrt(C)) - 1; the route starts where that
+// estimate falls below 3e2 (the Jacobi kernel verifies cond < 3e3 and asks for a re-run otherwise).
+int emagls_gram_from(const emagls_plan& p) {
+    if (!p.gram_route || p.sweep_factored || p.d.mic_radius <= 0.0) return 0;
+    if (const char* e = getenv("EMAGLS_GRAM_ROUTE")) if (e[0] == '0') return 0;
+    int n = 0;
+    while ((n + 1) * (n + 1) < p.C) ++n;
+    if (n < 1) return 0;
+    double dfact = 1.0;
+    for (int i = 3; i <= 2 * n + 1; i += 2) dfact *= i;
+    double est_limit = 3.0e2;
+    if (const char* e = getenv("EMAGLS_GRAM_COND_EST")) est_limit = atof(e);   // (tests force the re-run path with a huge limit)
+    const double kr_min = std::pow(dfact / est_limit, 1.0 / n);
+    const double df = p.d.fs / p.nfft;
+    const int kb = (int)std::ceil(kr_min * C_SOUND / (2.0 * kPi * p.d.mic_radius) / df);
+    const int from = std::max(std::max(kb, p.kcut0), 1);
+    return from < p.P ? from : 0;
+}
 bool emagls_needs_q(const emagls_plan& p) { return !p.cplx_basis || p.sweep_factored; }
 
 void emagls_pre_sweep(emagls_plan& p) {
@@ -570,6 +593,8 @@ void emagls_pre_sweep(emagls_plan& p) {
     fa.Vws = p.get<cplx>("Vws"); fa.sv = p.get<double>("sv");
     fa.Hq = p.get<cplx>("Hq"); fa.ldHq = p.ldS; fa.hq_estride = (int64_t)ls_end * p.ldS; fa.ls_end = ls_end;
     fa.hq_conj = need_q ? 0 : 1;
+    fa.route = p.get<int>("route"); fa.status = p.get<int>("flag");
+    fa.gram_from = emagls_gram_from(p);
     // batches have workgroups to spare: a Jacobi workgroup walks a run of neighbouring bins, each warm-started from the
     // previous one (a third of the sweeps); a single design keeps one bin per workgroup (shortest critical path)
     fa.jrun = batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
@@ -772,6 +797,7 @@ void run_pipeline(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     p.stage_names.clear();
     launch_zero(p.get("flag"), sizeof(int) * 4, p.stream);
+    if (p.has("route")) launch_zero(p.get("route"), p.bufs["route"].bytes, p.stream);
     if (p.has("W")) launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
     p.mark("begin");
     switch (d.kind) {
@@ -825,6 +851,7 @@ void batch_execute_lanes(emagls_batch& b);
 void plan_pre_stage(emagls_plan& p) {
     p.stage_names.clear();
     launch_zero(p.get("flag"), sizeof(int) * 4, p.stream);
+    launch_zero(p.get("route"), p.bufs["route"].bytes, p.stream);
     launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
     emagls_pre_sweep(p);
 }
@@ -938,9 +965,22 @@ void batch_execute(emagls_batch& b) {
     if (!replay) ++b.eager_runs;
 }
 
+void plan_execute(emagls_plan& p);
 void plan_check_flags(emagls_plan& p) {
     int flag[4] = {0, 0, 0, 0};
     HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
+    if (flag[2] && p.gram_route) {
+        // a Gram-route bin was worse conditioned than the kr estimate promised: redo the design on the Householder route
+        p.gram_route = false;
+        if (p.graph_exec) { HIP_CHECK(hipGraphExecDestroy(p.graph_exec)); p.graph_exec = nullptr; }
+        if (p.graph) { HIP_CHECK(hipGraphDestroy(p.graph)); p.graph = nullptr; }
+        if (p.pre_exec) { HIP_CHECK(hipGraphExecDestroy(p.pre_exec)); p.pre_exec = nullptr; }
+        if (p.pre_graph) { HIP_CHECK(hipGraphDestroy(p.pre_graph)); p.pre_graph = nullptr; }
+        p.eager_runs = 0;
+        plan_execute(p);
+        HIP_CHECK(hipStreamSynchronize(p.stream));
+        HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
+    }
     if (flag[1])
         throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");
     if (flag[0])
@@ -1335,17 +1375,32 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
         const size_t bytes = (p0.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p0.out_rows * p0.out_cols;
         // the copies are ordered behind the batch on its stream; one synchronisation for everything
         std::vector<int> flags(4 * n, 0);
-        if (b->lanes)
-            HIP_CHECK(hipMemcpy2DAsync(flags.data(), 4 * sizeof(int), p0.get("flag"), b->stride, 4 * sizeof(int), n,
-                                       hipMemcpyDeviceToHost, b->stream));
-        else
-            for (size_t j = 0; j < n; ++j)
-                HIP_CHECK(hipMemcpyAsync(&flags[4 * j], b->plans[j]->get("flag"), 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
-        for (size_t j = 0; j < n; ++j) {
-            HIP_CHECK(hipMemcpyAsync(wL[j], b->plans[j]->get("wL"), bytes, hipMemcpyDefault, b->stream));
-            HIP_CHECK(hipMemcpyAsync(wR[j], b->plans[j]->get("wR"), bytes, hipMemcpyDefault, b->stream));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (b->lanes)
+                HIP_CHECK(hipMemcpy2DAsync(flags.data(), 4 * sizeof(int), p0.get("flag"), b->stride, 4 * sizeof(int), n,
+                                           hipMemcpyDeviceToHost, b->stream));
+            else
+                for (size_t j = 0; j < n; ++j)
+                    HIP_CHECK(hipMemcpyAsync(&flags[4 * j], b->plans[j]->get("flag"), 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+            for (size_t j = 0; j < n; ++j) {
+                HIP_CHECK(hipMemcpyAsync(wL[j], b->plans[j]->get("wL"), bytes, hipMemcpyDefault, b->stream));
+                HIP_CHECK(hipMemcpyAsync(wR[j], b->plans[j]->get("wR"), bytes, hipMemcpyDefault, b->stream));
+            }
+            HIP_CHECK(hipStreamSynchronize(b->stream));
+            bool redo = false;
+            for (size_t j = 0; j < n; ++j) redo = redo || (flags[4 * j + 2] && b->plans[j]->gram_route);
+            if (!redo) break;
+            // a Gram-route bin was worse conditioned than the kr estimate promised: redo the batch on the Householder route
+            for (auto* q : b->plans) {
+                q->gram_route = false;
+                if (q->pre_exec) { HIP_CHECK(hipGraphExecDestroy(q->pre_exec)); q->pre_exec = nullptr; }
+                if (q->pre_graph) { HIP_CHECK(hipGraphDestroy(q->pre_graph)); q->pre_graph = nullptr; }
+            }
+            if (b->graph_exec) { HIP_CHECK(hipGraphExecDestroy(b->graph_exec)); b->graph_exec = nullptr; }
+            if (b->graph) { HIP_CHECK(hipGraphDestroy(b->graph)); b->graph = nullptr; }
+            b->eager_runs = 0;
+            batch_execute(*b);
         }
-        HIP_CHECK(hipStreamSynchronize(b->stream));
         for (size_t j = 0; j < n; ++j) {
             if (flags[4 * j + 1])
                 throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");

@@ -22,6 +22,7 @@ __device__ __forceinline__ void batch_offset(FactorArgs& a, size_t bstride) {
     a.Tn = boff(a.Tn, bstride); a.bn = boff(a.bn, bstride); a.Xd = boff(a.Xd, bstride);
     a.Z = boff(a.Z, bstride); a.Bk = boff(a.Bk, bstride); a.Vws = boff(a.Vws, bstride); a.sv = boff(a.sv, bstride);
     a.Hq = boff(a.Hq, bstride); a.cond_ok = boff(a.cond_ok, bstride); a.W = boff(a.W, bstride); a.sweeps_out = boff(a.sweeps_out, bstride);
+    a.route = boff(a.route, bstride); a.status = boff(a.status, bstride);
     a.tauw = boff(a.tauw, bstride); a.R2w = boff(a.R2w, bstride); a.Nw = boff(a.Nw, bstride); a.Mw = boff(a.Mw, bstride);
 }
 
@@ -82,6 +83,71 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
             const int s = ch + NCH * i;
             if (s < S) a.Bk[((int64_t)kb * C + c) * ldS + s] = B[i];
         }
+    }
+    // ------------------------------------------------------------------ 1b. Gram route
+    // Well above k_cut the columns of B_k are well conditioned (cond < ~3e2, decided by the host from kr): the Jacobi
+    // kernel can work on A = B^H B directly (error eps cond^2, here < 1e-11) and the 25 sequential reflector steps,
+    // their workspace traffic and the back-transform disappear.  A is formed from LDS row chunks in 2 x 2 tiles.
+    if (a.gram_from > 0 && kb >= a.gram_from) {
+        constexpr int GR = 4 * NCH;                    // rows per chunk (each lane contributes 4 of its rows)
+        cplx* Bs = vbuf + 2 * (size_t)ldS;             // [CPMAX][GR + 1]
+        constexpr int GLD = GR + 1;
+        for (int idx = tid; idx < CPMAX * GLD; idx += blockDim.x) Bs[idx] = mk(0, 0);
+        const int nblk1 = (C + 1) / 2, ntile = nblk1 * (nblk1 + 1) / 2;
+        const int part = tid & 7, tstep = blockDim.x >> 3;
+        constexpr int TS = 2;   // tile slots per thread: (16 * 17 / 2 = 136 tiles) * 8 lanes <= 2 * 832 threads
+        int tbi[TS], tbj[TS];
+        bool tvalid[TS];
+        cplx g00[TS], g01[TS], g10[TS], g11[TS];
+#pragma unroll
+        for (int u = 0; u < TS; ++u) {
+            int t = (tid >> 3) + u * tstep, bi = 0;
+            tvalid[u] = t < ntile;
+            while (bi < nblk1 && t >= nblk1 - bi) { t -= nblk1 - bi; ++bi; }
+            tbi[u] = tvalid[u] ? bi : 0;
+            tbj[u] = tvalid[u] ? bi + t : 0;
+            g00[u] = g01[u] = g10[u] = g11[u] = mk(0, 0);
+        }
+        __syncthreads();
+        for (int g = 0; g * 4 < RPT; ++g) {
+            if (active) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = 4 * g + ii;
+                    cplx v = mk(0, 0);
+#pragma unroll
+                    for (int i2 = 0; i2 < RPT; ++i2) if (i2 == i) v = B[i2];   // (static register indexing)
+                    Bs[c * GLD + ch + NCH * ii] = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < TS; ++u) {
+                if (!tvalid[u]) continue;
+                const cplx* a0 = Bs + (2 * tbi[u]) * GLD, *a1 = a0 + GLD, *b0 = Bs + (2 * tbj[u]) * GLD, *b1 = b0 + GLD;
+#pragma unroll 4
+                for (int rr = 0; rr < GR / 8; ++rr) {
+                    const int r = rr * 8 + part;
+                    const cplx x0 = a0[r], x1 = a1[r], y0 = b0[r], y1 = b1[r];
+                    cfma_conj(g00[u], x0, y0); cfma_conj(g01[u], x0, y1); cfma_conj(g10[u], x1, y0); cfma_conj(g11[u], x1, y1);
+                }
+            }
+            __syncthreads();
+        }
+        cplx* A = a.R2w + (int64_t)blockIdx.x * C * C;   // full Hermitian matrix, row major
+        auto put = [&](int r, int cc, cplx v) {
+            if (r < C && cc < C) { A[(int64_t)r * C + cc] = v; A[(int64_t)cc * C + r] = conj(v); }
+        };
+#pragma unroll
+        for (int u = 0; u < TS; ++u) {
+            const cplx s00 = group_sum<8>(g00[u]), s01 = group_sum<8>(g01[u]), s10 = group_sum<8>(g10[u]), s11 = group_sum<8>(g11[u]);
+            if (tvalid[u] && part == 0) {
+                const int r0 = 2 * tbi[u], c0 = 2 * tbj[u];
+                put(r0, c0, s00); put(r0, c0 + 1, s01); put(r0 + 1, c0, s10); put(r0 + 1, c0 + 1, s11);
+            }
+        }
+        if (tid == 0) a.route[kb] = 1;
+        return;
     }
     // ------------------------------------------------------------------ 2. Householder QR
     // One barrier per column: while the lane groups c > j apply H_j, the group of column j+1 goes on to form v_{j+1}
@@ -186,11 +252,13 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     if (bi >= a.nbins) break;
     const int kb = a.kb0 + bi;
     const cplx* R2 = a.R2w + (int64_t)bi * C * C;
+    const bool gram = a.route && a.route[kb] != 0;   // R2 holds A = B^H B (full): X = A, Xrot = V Lambda
     if (t == 0) {
         for (int idx = tid; idx < CPMAX * CPMAX; idx += 256) {
             const int col = idx / CPMAX, row = idx % CPMAX;  // X[row][col] = conj(R2[col][row]) for col <= row
             cplx v = mk(0, 0);
-            if (row < C && col <= row) v = conj(R2[(int64_t)col * C + row]);
+            if (gram) { if (row < C && col < C) v = R2[(int64_t)row * C + col]; }
+            else if (row < C && col <= row) v = conj(R2[(int64_t)col * C + row]);
             Xs[col][row] = v;
             Vs[col][row] = (col == row && col < C) ? mk(1, 0) : mk(0, 0);
         }
@@ -198,14 +266,17 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
         // X = R2^H V_prev :  X[row][col] = sum_{m <= row} conj(R2[m][row]) V[m][col]
         for (int idx = tid; idx < CPMAX * CPMAX; idx += 256) {
             const int m = idx / CPMAX, row = idx % CPMAX;
-            Ts[m][row] = (row < C && m <= row) ? conj(R2[(int64_t)m * C + row]) : mk(0, 0);
+            cplx v = mk(0, 0);
+            if (gram) { if (row < C && m < C) v = R2[(int64_t)row * C + m]; }
+            else if (row < C && m <= row) v = conj(R2[(int64_t)m * C + row]);
+            Ts[m][row] = v;
         }
         __syncthreads();
         for (int idx = tid; idx < CPMAX * CPMAX; idx += 256) {
             const int col = idx / CPMAX, row = idx % CPMAX;
             cplx acc = mk(0, 0);
             if (row < C && col < C)
-                for (int m = 0; m <= row; ++m) cfma(acc, Ts[m][row], Vs[col][m]);
+                for (int m = 0; m < C; ++m) cfma(acc, Ts[m][row], Vs[col][m]);   // (Ts is zero above the diagonal in the R2 form)
             Xs[col][row] = acc;
         }
     }
@@ -274,7 +345,7 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     if (tid < CPMAX) {
         double n2 = 0.0;
         for (int row = 0; row < CPMAX; ++row) n2 += norm2(Xs[tid][row]);
-        sig_s[tid] = sqrt(n2);
+        sig_s[tid] = gram ? sqrt(sqrt(n2)) : sqrt(n2);   // Gram form: the column norms are the eigenvalues s^2
     }
     __syncthreads();
     if (tid < CPMAX) {
@@ -293,12 +364,19 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
             }
         }
         g_s[tid] = g;
-        w_s[tid] = (s > 0.0) ? g / (s * s) : 0.0;   // weights of M = V diag(g) V^H with V = Xrot / sigma
+        // weights of M = V diag(g) V^H with V = Xrot / sigma  (Gram form: V = Xrot / s^2)
+        w_s[tid] = (s > 0.0) ? (gram ? g / ((s * s) * (s * s)) : g / (s * s)) : 0.0;
+        if (gram && tid == 0) {
+            double smin = INFINITY;
+            for (int i = 0; i < C; ++i) smin = fmin(smin, sig_s[i]);
+            if (!(smax <= 3.0e3 * smin) && a.status) atomicExch(a.status + 2, 1);  // the kr estimate was too optimistic
+        }
         if (a.sv && tid < C) a.sv[(int64_t)kb * C + tid] = s;
     }
     __syncthreads();
     // N[a][b] = sum_i Vx[a][i] g_i conj(Xrot[b][i])
     cplx* N = a.Nw + (int64_t)bi * C * C;
+    if (!gram)  // (the Gram form has no back-transform)
     for (int idx = tid; idx < C * C; idx += 256) {
         const int aa = idx / C, bb = idx % C;
         cplx acc = mk(0, 0);
@@ -406,8 +484,12 @@ template <typename TT, int NCH, int RPT, int MAXT>
 static void launch_one(const FactorArgs& a, int nbins, hipStream_t st, int phases) {
     const int threads = (int)(ceil_div((int64_t)NCH * a.C, 64) * 64);
     if (threads > MAXT) throw Error(2, "factor: too many channels for this row count");
-    const size_t dyn = (size_t)2 * a.ldS * sizeof(cplx);
+    const size_t dyn = ((size_t)2 * a.ldS + (a.gram_from > 0 ? (size_t)CPMAX * (4 * NCH + 1) : 0)) * sizeof(cplx);
     if (a.nOrders > 96) throw Error(2, "factor: simulation order above 95 is not supported");
+    FactorArgs aq = a;
+    if (dyn > 140 * 1024) {  // no room for the Gram route's row chunks next to the reflector buffers
+        aq.gram_from = 0;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void*)factor_qr_kernel<TT, NCH, RPT, MAXT>,
@@ -415,7 +497,7 @@ static void launch_one(const FactorArgs& a, int nbins, hipStream_t st, int phase
         attr_set = true;
     }
     if (phases & 1) {
-        factor_qr_kernel<TT, NCH, RPT, MAXT><<<bgrid(nbins), threads, dyn, st>>>(a, batch_ctx().stride);
+        factor_qr_kernel<TT, NCH, RPT, MAXT><<<bgrid(nbins), threads, aq.gram_from > 0 ? dyn : (size_t)2 * a.ldS * sizeof(cplx), st>>>(aq, batch_ctx().stride);
         KERNEL_CHECK();
         {
             FactorArgs aj = a;

@@ -131,7 +131,7 @@ __global__ void zero_fill_kernel(unsigned long long* __restrict__ p, int64_t n8,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0ull;
 }
 void launch_zero(void* p, size_t bytes, hipStream_t st) {
-    const int64_t n8 = (int64_t)(bytes / 8);
+    const int64_t n8 = (int64_t)((bytes + 7) / 8);  // (every buffer is allocated in multiples of 16 bytes)
     if (n8 == 0) return;
     const unsigned grid = (unsigned)std::min<int64_t>(2048, ceil_div(n8, 256));
     zero_fill_kernel<<<bgrid(grid), 256, 0, st>>>((unsigned long long*)p, n8, batch_ctx().stride);

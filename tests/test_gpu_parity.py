@@ -106,6 +106,35 @@ def test_emagls_tiny_array_ill_conditioned_bins(grids, thin, basis):
     p.close()
 
 
+def test_gram_route_fallback(grids, thin, monkeypatch):
+    """The well-conditioned swept bins are factorised from the Gram matrix B^H B; which bins qualify is estimated on the
+    host from kr.  The Jacobi kernel verifies the estimate and requests a re-run on the Householder route when a bin is
+    worse conditioned.  A forced, far too optimistic estimate on a 7 mm array must still give the oracle's filters, for a
+    single plan and for a batch."""
+    import emagls_amd as A
+    from emagls_amd import Batch, Plan, _lib as L
+    monkeypatch.setenv("EMAGLS_GRAM_COND_EST", "1e30")
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.007, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "complex")
+    oL, oR = O.getEMagLsFilters(*args)
+    wL, wR = A.getEMagLsFilters(*args)
+    assert rel(wL, oL) < TOL and rel(wR, oR) < TOL, (rel(wL, oL), rel(wR, oR))
+    plans = []
+    for j in range(2):
+        p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], 0.007, 32)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+        p.set_hrirs(thin["hL"], thin["hR"])
+        plans.append(p)
+    b = Batch(plans)
+    for it in range(2):
+        b.execute()
+        for bL, bR in b.get_filters():
+            assert rel(bL, oL) < TOL and rel(bR, oR) < TOL, it
+    b.close()
+    for p in plans:
+        p.close()
+
+
 def test_emagls_filters_config3_full(grids, hrirs):
     """BASELINE config 3: em32 r = 4.2 cm, N = 4, complex SH, 2702 directions, 512 taps."""
     import emagls_amd as E

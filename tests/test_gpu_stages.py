@@ -162,7 +162,8 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
     for kb in (1, 2, kcut0 - 1, kcut0, kcut0 + 1, P // 2, P - 1):
         B = Bk(kb)
         U, s, Vh = np.linalg.svd(B, full_matrices=False)
-        assert np.abs(np.sort(sv[kb])[::-1] - s).max() < 1e-13 * s[0]
+        # (well-conditioned swept bins take the Gram route: error eps cond^2 instead of eps)
+        assert np.abs(np.sort(sv[kb])[::-1] - s).max() < (1e-13 if kb <= kcut0 + 1 else 1e-10) * s[0]
         sreg = 1 / np.maximum(s, 0.01 * s[0])
         Zo = np.conj(U) @ (sreg[:, None] * Vh.conj())
         if kb < kcut0:  # Z_k is only formed for the least-squares bins (and for ill-conditioned swept bins)
