@@ -239,7 +239,6 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     __shared__ double g_s[CPMAX];
     __shared__ double w_s[CPMAX];
     __shared__ double sig_s[CPMAX];
-    __shared__ __attribute__((aligned(16))) cplx Ts[CPMAX][CPMAX + 1];  // R2^H of a warm-started bin
     const int tid = threadIdx.x;
     const int C = a.C;
     const int Cp = (C + 1) & ~1;
@@ -263,21 +262,31 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
             Vs[col][row] = (col == row && col < C) ? mk(1, 0) : mk(0, 0);
         }
     } else {
-        // X = R2^H V_prev :  X[row][col] = sum_{m <= row} conj(R2[m][row]) V[m][col]
+        // X = R2^H V_prev :  X[row][col] = sum_{m <= row} conj(R2[m][row]) V[m][col]   (Gram form: X = A V_prev)
+        // The factor is staged in Xs itself (Ts[m][row]); every thread keeps its four results in registers until all
+        // reads are done, so no third C x C buffer is needed (LDS decides how many bins run per CU).
         for (int idx = tid; idx < CPMAX * CPMAX; idx += 256) {
             const int m = idx / CPMAX, row = idx % CPMAX;
             cplx v = mk(0, 0);
             if (gram) { if (row < C && m < C) v = R2[(int64_t)row * C + m]; }
             else if (row < C && m <= row) v = conj(R2[(int64_t)m * C + row]);
-            Ts[m][row] = v;
+            Xs[m][row] = v;
         }
         __syncthreads();
-        for (int idx = tid; idx < CPMAX * CPMAX; idx += 256) {
-            const int col = idx / CPMAX, row = idx % CPMAX;
+        cplx xnew[CPMAX * CPMAX / 256];
+#pragma unroll
+        for (int u = 0; u < CPMAX * CPMAX / 256; ++u) {
+            const int idx = tid + 256 * u, col = idx / CPMAX, row = idx % CPMAX;
             cplx acc = mk(0, 0);
             if (row < C && col < C)
-                for (int m = 0; m < C; ++m) cfma(acc, Ts[m][row], Vs[col][m]);   // (Ts is zero above the diagonal in the R2 form)
-            Xs[col][row] = acc;
+                for (int m = 0; m < C; ++m) cfma(acc, Xs[m][row], Vs[col][m]);   // (zero above the diagonal in the R2 form)
+            xnew[u] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CPMAX * CPMAX / 256; ++u) {
+            const int idx = tid + 256 * u;
+            Xs[idx / CPMAX][idx % CPMAX] = xnew[u];
         }
     }
     __syncthreads();
