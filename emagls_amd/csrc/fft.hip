@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* tws = reinterpret_cast<cplx*>(smem);  // nfft/2
     cplx* buf = tws + nfft / 2;                 // TD * nfft
+    cplx* phs = buf + (size_t)TD * nfft;        // [2][P] delay phase per ear and bin (mode 0)
     const int P = nfft / 2 + 1;
     const int64_t d0 = (int64_t)blockIdx.x * TD;
     const int nt = (int)min((int64_t)TD, D - d0);
@@ -144,6 +145,16 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
     int sL = 0, sR = 0;
     if (mode == 1) { sL = (int)round(gL); sR = (int)round(gR); }
     for (int j = threadIdx.x; j < nfft / 2; j += blockDim.x) tws[j] = tw[j];
+    if (mode == 0) {
+        // exp(-1j*2*pi*omega*(-grpD)), omega = linspace(0, 0.5, nfft/2+1): once per workgroup, not once per direction
+        for (int j = threadIdx.x; j < 2 * P; j += blockDim.x) {
+            const int e = j / P, kb = j - e * P;
+            double sn, cs;
+            sincos((6.283185307179586 * ((double)kb / (double)nfft)) * (e ? gR : gL), &sn, &cs);
+            if (kb == P - 1) sn = 0.0;  // Nyquist bin forced real (applySubsampleDelay.m:12)
+            phs[j] = mk(cs, sn);
+        }
+    }
     for (int idx = threadIdx.x; idx < nt * nfft; idx += blockDim.x) {
         const int t = idx / nfft, n = idx - t * nfft;
         // circshift(h, -s): out[n] = h[(n + s) mod nfft]; zero beyond the L recorded taps
@@ -165,13 +176,8 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
         cplx HLv = mk(0.5 * (z.x + zc.x), 0.5 * (z.y + zc.y));
         cplx HRv = mk(0.5 * (z.y - zc.y), -0.5 * (z.x - zc.x));  // (z - zc) / (2i)
         if (mode == 0) {
-            const double omega = (double)kb / (double)nfft;  // linspace(0, 0.5, nfft/2+1)
-            double s1, c1, s2, c2;
-            sincos((6.283185307179586 * omega) * gL, &s1, &c1);  // exp(-1j*2*pi*omega*(-grpD))
-            sincos((6.283185307179586 * omega) * gR, &s2, &c2);
-            if (kb == P - 1) { s1 = 0.0; s2 = 0.0; }  // Nyquist bin forced real (applySubsampleDelay.m:12)
-            HLv = HLv * mk(c1, s1);
-            HRv = HRv * mk(c2, s2);
+            HLv = HLv * phs[kb];
+            HRv = HRv * phs[P + kb];
         }
         const int64_t d = d0 + t;
         if (kb < n_c) {
@@ -180,8 +186,10 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
         }
         if (kb >= kabs0) {
             const int64_t na = P - kabs0;
-            Habs[((int64_t)0 * na + (kb - kabs0)) * ldD + d] = cabs(HLv);
-            Habs[((int64_t)1 * na + (kb - kabs0)) * ldD + d] = cabs(HRv);
+            // |H| = n rsqrt(n): spectra are O(1), |H|^2 can neither overflow nor underflow
+            const double nl2 = norm2(HLv), nr2 = norm2(HRv);
+            Habs[((int64_t)0 * na + (kb - kabs0)) * ldD + d] = nl2 > 0.0 ? nl2 * fast_rsqrt(nl2) : 0.0;
+            Habs[((int64_t)1 * na + (kb - kabs0)) * ldD + d] = nr2 > 0.0 ? nr2 * fast_rsqrt(nr2) : 0.0;
         }
     }
 }
@@ -346,8 +354,9 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
                      int64_t ldD, hipStream_t st) {
     const int log2n = ilog2(nfft);
     int TD = 8;
-    while (TD > 1 && (size_t)TD * nfft * 16 + (size_t)nfft * 8 > 150 * 1024) TD >>= 1;
-    const size_t sm = (size_t)TD * nfft * 16 + (size_t)nfft * 8;
+    const size_t ph_bytes = (size_t)(nfft + 2) * 16;
+    while (TD > 1 && (size_t)TD * nfft * 16 + (size_t)nfft * 8 + ph_bytes > 150 * 1024) TD >>= 1;
+    const size_t sm = (size_t)TD * nfft * 16 + (size_t)nfft * 8 + ph_bytes;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -171,16 +171,28 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         return (int)((int64_t)eh * na * a.ldH + (d0 + dh < a.D ? d0 + dh : a.D - 1));
     };
     const int hoff = habs_off(lt), hoff2 = habs_off(lt + PS_NL);
-    auto fetch_g = [&](int kb, cplx (&gL)[NG * CH], double& hL, double& hL2) __attribute__((always_inline)) {
+    // (two halves: the loader waves issue the first while the other waves are in the M phase and the second while they
+    // are in the partial phase, so that their issue time -- 26 KB per CU through a 64 B/clk address path -- never holds
+    // up a barrier of the chain)
+    auto fetch_g = [&](int kb, int half, cplx (&gL)[NG * CH], double& hL, double& hL2) __attribute__((always_inline)) {
         const int kbg = kb < P ? kb : P - 1;
         const cplx* X = a.G + (int64_t)kbg * a.g_stride;
+        constexpr int H0 = (NG * CH) / 2;
+        if (half == 0) {
 #pragma unroll
-        for (int i = 0; i < NG * CH; ++i) {
-            const int r = i / CH, j = i % CH;
-            gL[i] = ldc(X + goff[j] + r * RG * a.ldD);
+            for (int i = 0; i < H0; ++i) {
+                const int r = i / CH, j = i % CH;
+                gL[i] = ldc(X + goff[j] + r * RG * a.ldD);
+            }
+        } else {
+#pragma unroll
+            for (int i = H0; i < NG * CH; ++i) {
+                const int r = i / CH, j = i % CH;
+                gL[i] = ldc(X + goff[j] + r * RG * a.ldD);
+            }
+            hL = a.Habs[(int64_t)(kbg - a.kabs0) * a.ldH + hoff];
+            hL2 = a.Habs[(int64_t)(kbg - a.kabs0) * a.ldH + hoff2];
         }
-        hL = a.Habs[(int64_t)(kbg - a.kabs0) * a.ldH + hoff];
-        hL2 = a.Habs[(int64_t)(kbg - a.kabs0) * a.ldH + hoff2];
     };
     auto stage_g = [&](int kb, const cplx (&gL)[NG * CH], double hL, double hL2) __attribute__((always_inline)) {
         cplx* xs = xs_all + (size_t)(kb & 1) * PS_CMAX * XLD;
@@ -211,7 +223,8 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     };
     __syncthreads();  // LDS is zeroed
     if (loader) {
-        fetch_g(a.kfirst, gReg, hReg, hReg2);
+        fetch_g(a.kfirst, 0, gReg, hReg, hReg2);
+        fetch_g(a.kfirst, 1, gReg, hReg, hReg2);
         stage_g(a.kfirst, gReg, hReg, hReg2);
     }
     if (tid < 256) {
@@ -330,7 +343,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         // The next bin's operands are requested NOW: a CU's vector memory pipeline returns in order, so loads that miss
         // to HBM (1.2-1.5 us) delay every later poll of the communication wave behind them.  Issued here they drain
         // during the three compute phases; the loader waves are idle in the M phase anyway.
-        if (loader) fetch_g(kb + 1, gReg, hReg, hReg2);
+        if (loader) fetch_g(kb + 1, 0, gReg, hReg, hReg2);
         // ---- W(kb-1,:) = v_total conj(M_{kb-1})  (identity for the first swept bin and after an ill-conditioned bin)
         if (pvalid) {
             cplx acc = mk(0, 0);
@@ -365,6 +378,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             if (part < 2) ts[part][dloc] = dvalid ? unit_phase(hs[part * PS_DPW + dloc], part ? p1 : p0, nyq) : mk(0, 0);
         }
         __syncthreads();  // B3: ts is complete
+        if (loader) fetch_g(kb + 1, 1, gReg, hReg, hReg2);
         // ---- this slab's partial v = t conj(G) (or t Y_reg_inv for an ill-conditioned bin), published as granules
         if (tid == 0) PSTAMP(4);
         if (pvalid) {
