@@ -108,7 +108,6 @@ constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 template <int PS_DPW>
 __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
     constexpr int PS_NC = 4 * PS_DPW;   // p-phase threads
-    constexpr int PS_NJ = PS_DPW / 4;   // directions per lane (partial phase)
     constexpr int XLD = PS_DPW + 4;     // row stride of the G slab (16 dwords mod 64: conflict-free quarter-wave reads)
     constexpr int RG = PS_DPW == 96 ? 4 : 2, CH = RG * PS_DPW / PS_NL, NG = PS_CMAX / RG;  // G: NG row groups x CH chunks per loader thread
     constexpr int NLM = (PS_CMAX * PS_CMAX) / 256;                                         // M: loads per M-phase thread
@@ -146,7 +145,6 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     const int part = tid & 3;
     const bool pth = tid < PS_NC;                     // p phase: (direction, channel quarter)
     const int dloc = pth ? (tid >> 2) : 0;
-    const bool dvalid = pth && d0 + dloc < a.D;
     const int pair = tid >> 2;                        // M / partial phases: (pair, quarter)
     const bool pvalid = pair < npairs;                // (npairs <= 64, so tid < 256)
     const int e = pvalid ? pair / C : 0, c = pvalid ? pair % C : 0;
@@ -364,42 +362,63 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         if (tid < 256) fetch_m(kb + 1, mReg);
         __syncthreads();  // B2: Wp is complete
         // ---- p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
-        if (pth) {
-            if (tid == 0) PSTAMP(3);
-            cplx p0 = mk(0, 0), p1 = mk(0, 0);
+        // thread = (direction pair (dA, dA + DPW/2), channel quarter): a W value read from LDS feeds two directions
+        if (tid == 0) PSTAMP(3);
+        if (tid < 2 * PS_DPW) {
+            const int dA = tid >> 2, dB = dA + PS_DPW / 2;
+            cplx pA0 = mk(0, 0), pA1 = mk(0, 0), pB0 = mk(0, 0), pB1 = mk(0, 0);   // p[direction][ear]
 #pragma unroll
             for (int i = 0; i < PS_NI; ++i) {  // Wp and xs are 0 beyond C
-                const cplx g = xs[(part + 4 * i) * XLD + dloc];
-                cfma(p0, Wp[part + 4 * i], g);
-                cfma(p1, Wp[PS_CMAX + part + 4 * i], g);
+                const cplx w0 = Wp[part + 4 * i], w1 = Wp[PS_CMAX + part + 4 * i];
+                const cplx gA = xs[(part + 4 * i) * XLD + dA], gB = xs[(part + 4 * i) * XLD + dB];
+                cfma(pA0, w0, gA); cfma(pA1, w1, gA); cfma(pB0, w0, gB); cfma(pB1, w1, gB);
             }
-            p0 = group_sum<4>(p0);
-            p1 = group_sum<4>(p1);
-            if (part < 2) ts[part][dloc] = dvalid ? unit_phase(hs[part * PS_DPW + dloc], part ? p1 : p0, nyq) : mk(0, 0);
+            pA0 = group_sum<4>(pA0); pA1 = group_sum<4>(pA1); pB0 = group_sum<4>(pB0); pB1 = group_sum<4>(pB1);
+            if (part < 2) {   // lane part = ear
+                ts[part][dA] = (d0 + dA < a.D) ? unit_phase(hs[part * PS_DPW + dA], part ? pA1 : pA0, nyq) : mk(0, 0);
+                ts[part][dB] = (d0 + dB < a.D) ? unit_phase(hs[part * PS_DPW + dB], part ? pB1 : pB0, nyq) : mk(0, 0);
+            }
         }
         __syncthreads();  // B3: ts is complete
         if (loader) fetch_g(kb + 1, 1, gReg, hReg, hReg2);
         // ---- this slab's partial v = t conj(G) (or t Y_reg_inv for an ill-conditioned bin), published as granules
         if (tid == 0) PSTAMP(4);
-        if (pvalid) {
-            cplx a0 = mk(0, 0), a1 = mk(0, 0);
-            if (cur_ok) {
-                const cplx* xrow = xs + c * XLD;
+        // thread = (channel pair cp, 16 direction slices): every t and every G element it reads from LDS feeds two
+        // complex FMAs (2 ears x 2 channels), half the LDS traffic of one (ear, channel) pair per thread
+        {
+            const int cp = tid >> 4, ep = tid & 15;
+            const int c0 = 2 * cp, c1 = c0 + 1;
+            if (tid < 256 && c0 < C) {
+                cplx v00 = mk(0, 0), v01 = mk(0, 0), v10 = mk(0, 0), v11 = mk(0, 0);  // v[ear][channel]
+                if (cur_ok) {
+                    const cplx* x0 = xs + c0 * XLD, *x1 = xs + (c1 < C ? c1 : c0) * XLD;
 #pragma unroll
-                for (int j = 0; j < PS_NJ; j += 2) {
-                    cfma(a0, ts[e][part + 4 * j], conj(xrow[part + 4 * j]));
-                    cfma(a1, ts[e][part + 4 * (j + 1)], conj(xrow[part + 4 * (j + 1)]));
+                    for (int j = 0; j < PS_DPW / 16; ++j) {
+                        const int dd = ep + 16 * j;
+                        const cplx t0 = ts[0][dd], t1 = ts[1][dd], g0 = conj(x0[dd]), g1 = conj(x1[dd]);
+                        cfma(v00, t0, g0); cfma(v01, t0, g1); cfma(v10, t1, g0); cfma(v11, t1, g1);
+                    }
+                } else {
+                    const cplx* Y0 = a.Yri + (int64_t)kb * a.g_stride + (int64_t)c0 * a.ldD;
+                    const cplx* Y1 = a.Yri + (int64_t)kb * a.g_stride + (int64_t)(c1 < C ? c1 : c0) * a.ldD;
+                    for (int dd = ep; dd < PS_DPW; dd += 16)
+                        if (d0 + dd < a.D) {
+                            const cplx t0 = ts[0][dd], t1 = ts[1][dd], g0 = Y0[d0 + dd], g1 = Y1[d0 + dd];
+                            cfma(v00, t0, g0); cfma(v01, t0, g1); cfma(v10, t1, g0); cfma(v11, t1, g1);
+                        }
                 }
-            } else {
-                const cplx* Y = a.Yri + (int64_t)kb * a.g_stride + (int64_t)c * a.ldD;
-                for (int dd = part; dd < PS_DPW; dd += 4)
-                    if (d0 + dd < a.D) cfma(a0, ts[e][dd], Y[d0 + dd]);
+                v00 = group_sum<16>(v00); v01 = group_sum<16>(v01); v10 = group_sum<16>(v10); v11 = group_sum<16>(v11);
+                // all 16 lanes hold the four sums: lane ep stores word ep & 3 of the pair (ear ep >> 3, channel c0 + ((ep >> 2) & 1))
+                const int ee = ep >> 3, ch = (ep >> 2) & 1, wi = ep & 3;
+                const cplx acc = ee ? (ch ? v11 : v10) : (ch ? v01 : v00);
+                const int cc = c0 + ch;
+                if (cc < C) {
+                    const u64 bits = (u64)__double_as_longlong((wi & 1) ? acc.y : acc.x);
+                    const u64 word = ((u64)(unsigned)kb << 32) | ((wi & 2) ? (bits >> 32) : (bits & 0xffffffffull));
+                    u64* dst = part_ll + (((size_t)(kb & 1) * npairs + (ee * C + cc)) * nWG + member) * 4 + wi;
+                    ll_put(dst, word, local);
+                }
             }
-            const cplx acc = group_sum<4>(a0 + a1);  // all four lanes of the pair hold the sum: each stores one word
-            const u64 bits = (u64)__double_as_longlong((part & 1) ? acc.y : acc.x);
-            const u64 word = ((u64)(unsigned)kb << 32) | ((part & 2) ? (bits >> 32) : (bits & 0xffffffffull));
-            u64* dst = part_ll + (((size_t)(kb & 1) * npairs + pair) * nWG + member) * 4 + part;
-            ll_put(dst, word, local);
         }
         if (tid == 0) PSTAMP(5);
         // the other buffer was last read in bin kb-1: fill it while everybody waits for the exchange
