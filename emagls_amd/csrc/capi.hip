@@ -565,7 +565,11 @@ void emagls_pre_sweep(emagls_plan& p) {
     if (!p.sweep_factored) {
         if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s1, e_Yc, 0));
         launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, cb, p.get("QT"), p.ldD, s1);
-        launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, k0, p.get("G"), s1);
+        {
+            static const bool real_terms = [] { const char* e = getenv("EMAGLS_DSPACE_REAL"); return !(e && e[0] == '0'); }();
+            launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, k0, p.get("G"), s1, (cb && real_terms) ? 1 : 0,
+                            raw ? -1 : (int)d.order);
+        }
     }
     // s2 (after the prologue): Q = conj(Y) R^-1 and the least-squares right-hand sides H conj(Q)
     if (s2 != s0) HIP_CHECK(hipStreamWaitEvent(s2, e_R, 0));

@@ -108,6 +108,87 @@ __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT,
     }
 }
 
+// G kernel for the complex SH basis, in real arithmetic on the order terms.  With Y_c = Y_r T (T unitary, block diagonal
+// per order) the array matrix is E_c = T_N^H E_r T and the order terms satisfy QT_c,n = QTr_n conj(T_N) with REAL
+// QTr_n = Y_r,n E_r,n^T, so G_c = (sum_n b_n(k) QTr_n) conj(T_N): a complex-times-real sum (2 FMAs per term instead
+// of 4) followed by the fixed two-term channel transform
+//     G(n,+m) = (-1)^m/sqrt2 (ga - i gb),   G(n,-m) = 1/sqrt2 (ga + i gb),   ga/gb = the real-basis rows (n,+m)/(n,-m),
+// QTr(n,+m) = Re((-1)^m QT(n,+m) + QT(n,-m))/sqrt2,  QTr(n,-m) = -Im((-1)^m QT(n,+m) - QT(n,-m))/sqrt2  (m = 0: unchanged).
+// eMagLS2 (channels = microphones, E = Y_mic): QT_c is real as it stands (sh_order < 0: all channels independent).
+// A wave owns one unit (an SH pair, or two independent channels) at a time; lanes = 64 consecutive directions.
+template <int NMAX>
+__global__ void __launch_bounds__(256) dspace_g_real_kernel(const cplx* __restrict__ QT, int64_t ldD, const cplx* __restrict__ bn,
+                                                            int nOrders, int D, int C, int P, int k0, int bins_per_chunk,
+                                                            cplx* __restrict__ G, int sh_order, size_t bstride) {
+    QT = boff(QT, bstride); bn = boff(bn, bstride); G = boff(G, bstride);
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* bs = reinterpret_cast<cplx*>(dyn);  // [bins_per_chunk][nOrders]
+    __shared__ int u_a[32], u_b[32], u_t[32], u_n;   // unit: channels a, b (b = -1: none), type 0 = SH pair (+m, -m, sign in bit 1)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int d = blockIdx.x * DSP_TD + lane;
+    const int kb_begin = k0 + blockIdx.y * bins_per_chunk;
+    const int kb_end = min(P, kb_begin + bins_per_chunk);
+    for (int idx = threadIdx.x; idx < (kb_end - kb_begin) * nOrders; idx += 256) {
+        const int kb = kb_begin + idx / nOrders;
+        cplx b = bn[(int64_t)kb_begin * nOrders + idx];
+        if (kb == P - 1) b.y = 0.0;  // Nyquist: real(Bn)
+        bs[idx] = b;
+    }
+    if (threadIdx.x == 0) {
+        int nu = 0;
+        if (sh_order >= 0) {
+            for (int n = 0; n <= sh_order; ++n)
+                for (int mm = 1; mm <= n; ++mm) { u_a[nu] = n * n + n + mm; u_b[nu] = n * n + n - mm; u_t[nu] = (mm & 1) ? 2 : 0; ++nu; }
+            for (int n = 0; n <= sh_order; n += 2) { u_a[nu] = n * n + n; u_b[nu] = (n + 1 <= sh_order) ? (n + 1) * (n + 1) + n + 1 : -1; u_t[nu] = 1; ++nu; }
+        } else {
+            for (int ca = 0; ca < C; ca += 2) { u_a[nu] = ca; u_b[nu] = ca + 1 < C ? ca + 1 : -1; u_t[nu] = 1; ++nu; }
+        }
+        u_n = nu;
+    }
+    __syncthreads();
+    if (d >= D) return;
+    const double r2 = 0.70710678118654752440;
+    for (int u = wave; u < u_n; u += 4) {
+        const int ca = u_a[u], cb2 = u_b[u], ty = u_t[u];
+        const bool two = cb2 >= 0;
+        double qa[NMAX], qb[NMAX];
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) {
+            cplx xa = mk(0, 0), xb = mk(0, 0);
+            if (n < nOrders) {
+                xa = QT[((int64_t)n * C + ca) * ldD + d];
+                if (two) xb = QT[((int64_t)n * C + cb2) * ldD + d];
+            }
+            if (ty == 1) { qa[n] = xa.x; qb[n] = xb.x; }
+            else {
+                const double sg = (ty & 2) ? -1.0 : 1.0;
+                qa[n] = (sg * xa.x + xb.x) * r2;
+                qb[n] = -(sg * xa.y - xb.y) * r2;
+            }
+        }
+        cplx* ga_p = G + ((int64_t)(kb_begin - k0) * C + ca) * ldD + d;
+        const int64_t boffs = ((int64_t)cb2 - ca) * ldD, gstep = (int64_t)C * ldD;
+        for (int kb = kb_begin; kb < kb_end; ++kb, ga_p += gstep) {
+            const cplx* b = bs + (size_t)(kb - kb_begin) * nOrders;
+            double gax = 0.0, gay = 0.0, gbx = 0.0, gby = 0.0, hax = 0.0, hay = 0.0, hbx = 0.0, hby = 0.0;
+#pragma unroll
+            for (int n = 0; n < NMAX; n += 2) {
+                if (n < nOrders) { const cplx bb = b[n]; gax = fma(bb.x, qa[n], gax); gay = fma(bb.y, qa[n], gay); gbx = fma(bb.x, qb[n], gbx); gby = fma(bb.y, qb[n], gby); }
+                if (n + 1 < nOrders) { const cplx bb = b[n + 1]; hax = fma(bb.x, qa[n + 1], hax); hay = fma(bb.y, qa[n + 1], hay); hbx = fma(bb.x, qb[n + 1], hbx); hby = fma(bb.y, qb[n + 1], hby); }
+            }
+            const double ax = gax + hax, ay = gay + hay, bx = gbx + hbx, by = gby + hby;
+            if (ty == 1) {
+                ga_p[0] = mk(ax, ay);
+                if (two) ga_p[boffs] = mk(bx, by);
+            } else {
+                const double sg = (ty & 2) ? -r2 : r2;
+                ga_p[0] = mk(sg * (ax + by), sg * (ay - bx));        // (-1)^m/sqrt2 (ga - i gb)
+                ga_p[boffs] = mk(r2 * (ax - by), r2 * (ay + bx));     // 1/sqrt2 (ga + i gb)
+            }
+        }
+    }
+}
+
 // Yri kernel: one workgroup = one swept bin x 256 directions; thread = direction.
 //   Yri[c][d] = conj( sum_c' G[c'][d] M[c'][c] )      M_k staged in LDS (broadcast reads)
 __global__ void __launch_bounds__(256) dspace_yri_kernel(const cplx* __restrict__ G, int64_t ldD, const cplx* __restrict__ Mw,
@@ -204,7 +285,21 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
     KERNEL_CHECK();
 }
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
-                     hipStream_t st) {
+                     hipStream_t st, int real_mode, int sh_order) {
+    if (is_cplx && real_mode && nOrders <= DSP_NMAX && C <= 64 && P - k0 > 0) {
+        int chunks = 8;
+        const int nbins = P - k0;
+        while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nOrders > 56 * 1024) ++chunks;
+        const int bpc = (nbins + chunks - 1) / chunks;
+        const size_t dyn = sizeof(cplx) * (size_t)bpc * nOrders;
+        const dim3 grid((unsigned)ceil_div(D, DSP_TD), chunks);
+        if (nOrders <= 20)
+            dspace_g_real_kernel<20><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
+        else
+            dspace_g_real_kernel<DSP_NMAX><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
+        KERNEL_CHECK();
+        return;
+    }
     if (is_cplx) dspace_g_impl<cplx>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
     else dspace_g_impl<double>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
 }

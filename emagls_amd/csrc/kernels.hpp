@@ -89,8 +89,10 @@ void launch_widen(const void* in, int64_t ldi, bool in_cplx, void* out, int64_t 
 // ---- dspace.hip
 void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
                int64_t ldD, hipStream_t st);
+// real_mode: complex basis evaluated on the real order terms (sh_order >= 0: channels are SH coefficients up to that order;
+// < 0: channels are independent, e.g. microphones)
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
-                     hipStream_t st);
+                     hipStream_t st, int real_mode = 0, int sh_order = -1);
 void launch_cond_flags(const double* sv, int C, int P, double* cond_ok, hipStream_t st);
 void launch_dspace_yri(const void* G, int64_t ldD, const void* Mw, int kb0_factor, const double* sv, double* cond_ok, int D, int C,
                        int P, int k0, void* Yri, hipStream_t st);
