@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT,
 // QTr(n,+m) = Re((-1)^m QT(n,+m) + QT(n,-m))/sqrt2,  QTr(n,-m) = -Im((-1)^m QT(n,+m) - QT(n,-m))/sqrt2  (m = 0: unchanged).
 // eMagLS2 (channels = microphones, E = Y_mic): QT_c is real as it stands (sh_order < 0: all channels independent).
 // A wave owns one unit (an SH pair, or two independent channels) at a time; lanes = 64 consecutive directions.
-template <int NMAX>
+template <int NMAX, bool NT>
 __global__ void __launch_bounds__(256) dspace_g_real_kernel(const cplx* __restrict__ QT, int64_t ldD, const cplx* __restrict__ bn,
                                                             int nOrders, int D, int C, int P, int k0, int bins_per_chunk,
                                                             cplx* __restrict__ G, int sh_order, size_t bstride) {
@@ -177,13 +177,20 @@ __global__ void __launch_bounds__(256) dspace_g_real_kernel(const cplx* __restri
                 if (n + 1 < nOrders) { const cplx bb = b[n + 1]; hax = fma(bb.x, qa[n + 1], hax); hay = fma(bb.y, qa[n + 1], hay); hbx = fma(bb.x, qb[n + 1], hbx); hby = fma(bb.y, qb[n + 1], hby); }
             }
             const double ax = gax + hax, ay = gay + hay, bx = gbx + hbx, by = gby + hby;
-            if (ty == 1) {
-                ga_p[0] = mk(ax, ay);
-                if (two) ga_p[boffs] = mk(bx, by);
-            } else {
+            cplx o0, o1;
+            if (ty == 1) { o0 = mk(ax, ay); o1 = mk(bx, by); }
+            else {
                 const double sg = (ty & 2) ? -r2 : r2;
-                ga_p[0] = mk(sg * (ax + by), sg * (ay - bx));        // (-1)^m/sqrt2 (ga - i gb)
-                ga_p[boffs] = mk(r2 * (ax - by), r2 * (ay + bx));     // 1/sqrt2 (ga + i gb)
+                o0 = mk(sg * (ax + by), sg * (ay - bx));        // (-1)^m/sqrt2 (ga - i gb)
+                o1 = mk(r2 * (ax - by), r2 * (ay + bx));        // 1/sqrt2 (ga + i gb)
+            }
+            if (NT) {
+                double* q0 = reinterpret_cast<double*>(ga_p);
+                __builtin_nontemporal_store(o0.x, q0); __builtin_nontemporal_store(o0.y, q0 + 1);
+                if (two) { double* q1 = reinterpret_cast<double*>(ga_p + boffs); __builtin_nontemporal_store(o1.x, q1); __builtin_nontemporal_store(o1.y, q1 + 1); }
+            } else {
+                ga_p[0] = o0;
+                if (two) ga_p[boffs] = o1;
             }
         }
     }
@@ -287,16 +294,20 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
                      hipStream_t st, int real_mode, int sh_order) {
     if (is_cplx && real_mode && nOrders <= DSP_NMAX && C <= 64 && P - k0 > 0) {
-        int chunks = 8;
+        int chunks = 16;   // measured: 4 -> 780, 8 -> 610, 16 -> 560, 32 -> 690 us (mean over single and batched launches)
+        if (const char* e = getenv("EMAGLS_DSP_CHUNKS")) chunks = std::max(1, atoi(e));
+        static const bool nt = [] { const char* e = getenv("EMAGLS_DSP_NT"); return !(e && e[0] == '0'); }();  // streaming stores
         const int nbins = P - k0;
         while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nOrders > 56 * 1024) ++chunks;
         const int bpc = (nbins + chunks - 1) / chunks;
         const size_t dyn = sizeof(cplx) * (size_t)bpc * nOrders;
         const dim3 grid((unsigned)ceil_div(D, DSP_TD), chunks);
-        if (nOrders <= 20)
-            dspace_g_real_kernel<20><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
+        if (nOrders <= 20 && nt)
+            dspace_g_real_kernel<20, true><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
+        else if (nOrders <= 20)
+            dspace_g_real_kernel<20, false><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
         else
-            dspace_g_real_kernel<DSP_NMAX><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
+            dspace_g_real_kernel<DSP_NMAX, false><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
         KERNEL_CHECK();
         return;
     }
