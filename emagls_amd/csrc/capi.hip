@@ -155,6 +155,8 @@ struct emagls_batch {
     hipStream_t stream = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t post_graph = nullptr;           // lane mode: the stages after the sweep (the sweep is launched directly)
+    hipGraphExec_t post_exec = nullptr;
     int eager_runs = 0;
     bool use_graph = true;
     std::vector<hipEvent_t> events;
@@ -176,6 +178,8 @@ struct emagls_batch {
         for (auto e : events) hipEventDestroy(e);
         if (graph_exec) hipGraphExecDestroy(graph_exec);
         if (graph) hipGraphDestroy(graph);
+        if (post_exec) hipGraphExecDestroy(post_exec);
+        if (post_graph) hipGraphDestroy(post_graph);
         if (stream) hipStreamDestroy(stream);
         for (auto* p : plans) p->sync_stream = nullptr;
     }
@@ -904,22 +908,34 @@ template <typename F> void capture_into(hipStream_t st, hipGraph_t* g, hipGraphE
 }
 
 // lane mode: the pipeline of plan 0 is enqueued once on the batch stream with grid.z = designs
-void batch_lanes_body(emagls_batch& b) {
+// A persistent sweep needs all of its workgroups resident.  Two sweeps launched from different streams could each get a
+// part of the CUs and wait for the rest forever (the kernels would give up after their spin limit and report an
+// error), so the sweeps of all batches of a process are chained through one event: a sweep is only launched behind the
+// previous one.  The sweep is therefore not part of a batch's captured graphs.
+hipEvent_t& sweep_chain_event() {
+    static hipEvent_t ev = nullptr;
+    if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return ev;
+}
+void batch_sweep_chained(emagls_batch& b) {
+    static bool recorded = false;
+    if (recorded) HIP_CHECK(hipStreamWaitEvent(b.stream, sweep_chain_event(), 0));
+    batch_sweep_stage(b);
+    HIP_CHECK(hipEventRecord(sweep_chain_event(), b.stream));
+    recorded = true;
+}
+
+// lane mode: the pipeline of plan 0 is enqueued once on the batch stream with grid.z = designs
+// part 0: stages before the sweep, part 2: stages after it
+void batch_lanes_part(emagls_batch& b, int part) {
     emagls_plan& p0 = *b.plans[0];
     hipStream_t keep = p0.stream;
     const int keep_streams = p0.nstreams;
     p0.stream = b.stream;
     p0.nstreams = 1;
     try {
-        {
-            BatchScope sc((int)b.plans.size(), b.stride);
-            plan_pre_stage(p0);
-        }
-        batch_sweep_stage(b);
-        {
-            BatchScope sc((int)b.plans.size(), b.stride);
-            emagls_post_sweep(p0);
-        }
+        BatchScope sc((int)b.plans.size(), b.stride);
+        if (part == 0) plan_pre_stage(p0); else emagls_post_sweep(p0);
     } catch (...) {
         p0.stream = keep; p0.nstreams = keep_streams;
         throw;
@@ -928,8 +944,13 @@ void batch_lanes_body(emagls_batch& b) {
 }
 void batch_execute_lanes(emagls_batch& b) {
     const bool replay = b.use_graph && b.eager_runs >= 1;
-    if (replay && !b.graph_exec) capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_lanes_body(b); });
-    if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_lanes_body(b);
+    if (replay && !b.graph_exec) {
+        capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_lanes_part(b, 0); });
+        capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_lanes_part(b, 2); });
+    }
+    if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_lanes_part(b, 0);
+    batch_sweep_chained(b);
+    if (replay) HIP_CHECK(hipGraphLaunch(b.post_exec, b.stream)); else batch_lanes_part(b, 2);
     emagls_plan& p0 = *b.plans[0];
     for (auto* p : b.plans) {
         p->executed = true;
@@ -946,9 +967,9 @@ void batch_execute(emagls_batch& b) {
         return;
     }
     const bool replay = b.use_graph && b.eager_runs >= 1;
-    if (replay && !b.graph_exec) {
+    if (replay && !b.plans[0]->pre_exec) {
         for (auto* p : b.plans) capture_into(p->stream, &p->pre_graph, &p->pre_exec, [&] { plan_pre_stage(*p); });
-        capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_sweep_stage(b); });
+        if (!b.plans[0]->sweep_persist) capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_sweep_stage(b); });
     }
     b.used = 0;
     // the previous sweep of this batch must be done before a plan's buffers are rewritten
@@ -957,7 +978,8 @@ void batch_execute(emagls_batch& b) {
         if (replay) HIP_CHECK(hipGraphLaunch(p->pre_exec, p->stream)); else plan_pre_stage(*p);
         b.depend(b.stream, p->stream);
     }
-    if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_sweep_stage(b);
+    if (b.plans[0]->sweep_persist) batch_sweep_chained(b);   // (never captured: see batch_sweep_chained)
+    else if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_sweep_stage(b);
     emagls_plan& p0 = *b.plans[0];
     for (auto* p : b.plans) {
         b.depend(p->stream, b.stream);
@@ -1402,6 +1424,8 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
             }
             if (b->graph_exec) { HIP_CHECK(hipGraphExecDestroy(b->graph_exec)); b->graph_exec = nullptr; }
             if (b->graph) { HIP_CHECK(hipGraphDestroy(b->graph)); b->graph = nullptr; }
+            if (b->post_exec) { HIP_CHECK(hipGraphExecDestroy(b->post_exec)); b->post_exec = nullptr; }
+            if (b->post_graph) { HIP_CHECK(hipGraphDestroy(b->post_graph)); b->post_graph = nullptr; }
             b->eager_runs = 0;
             batch_execute(*b);
         }
