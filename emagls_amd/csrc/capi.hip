@@ -670,6 +670,26 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     return a;
 }
 
+// A persistent sweep needs all of its workgroups resident.  Two sweeps launched from different streams could each get a
+// part of the CUs and wait for the rest forever (the kernels would give up after their spin limit and report an
+// error), so all persistent sweeps of a process are chained through one event: a sweep is only launched behind the
+// previous one.  The sweep is therefore never part of a captured graph (plans and batches capture the stages before it).
+struct SweepChain {
+    hipStream_t st;
+    explicit SweepChain(hipStream_t s) : st(s) {
+        if (recorded()) HIP_CHECK(hipStreamWaitEvent(st, event(), 0));
+    }
+    ~SweepChain() {
+        if (hipEventRecord(event(), st) == hipSuccess) recorded() = true;
+    }
+    static hipEvent_t& event() {
+        static hipEvent_t ev = nullptr;
+        if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        return ev;
+    }
+    static bool& recorded() { static bool r = false; return r; }
+};
+
 void emagls_run_sweep(emagls_plan& p) {
     const bool cb = p.cplx_basis;
     hipStream_t s0 = p.stream;
@@ -696,6 +716,7 @@ void emagls_run_sweep(emagls_plan& p) {
         m.a[0] = emagls_half_args(p);
         p.sweep_launches = 0;
         if (k0 < p.P) {
+            SweepChain chain(s0);
             launch_zero(p.get("ll"), p.bufs["ll"].bytes, s0);
             if (p.prof_level >= 2) record_sweep_event(p, 0);
             launch_sweep_persist(m, s0);
@@ -817,12 +838,40 @@ void run_pipeline(emagls_plan& p) {
     }
 }
 
+void plan_pre_stage(emagls_plan& p);
+template <typename F> void capture_into(hipStream_t st, hipGraph_t* g, hipGraphExec_t* ge, F&& body) {
+    HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    try {
+        body();
+    } catch (...) {
+        hipGraph_t tmp = nullptr;
+        hipStreamEndCapture(st, &tmp);
+        if (tmp) hipGraphDestroy(tmp);
+        throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(st, g));
+    HIP_CHECK(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+}
+
 void plan_execute(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     if (!p.have_hrir_grid || !p.have_hrirs) throw Error(EMAGLS_ERR_ARG, "HRIRs and their grid must be set before execute");
     if ((d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) && !p.have_mic_grid)
         throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
     if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
+    const bool persist = (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) && p.sweep_half && p.sweep_persist &&
+                         !p.sweep_factored;
+    if (p.prof_level == 0 && p.use_graph && persist) {
+        // the persistent sweep is launched directly (SweepChain); the stages before it are captured from the second
+        // execute on (the first runs eagerly: one-time function attributes, lazy module load)
+        if (!p.pre_exec && p.eager_runs >= 1) capture_into(p.stream, &p.pre_graph, &p.pre_exec, [&] { plan_pre_stage(p); });
+        if (p.pre_exec) HIP_CHECK(hipGraphLaunch(p.pre_exec, p.stream)); else plan_pre_stage(p);
+        emagls_run_sweep(p);
+        emagls_post_sweep(p);
+        if (!p.pre_exec) ++p.eager_runs;
+        p.executed = true;
+        return;
+    }
     if (p.prof_level == 0 && p.use_graph) {
         // first execute runs eagerly (one-time function attributes, lazy module load), the second is captured
         if (!p.graph_exec && p.eager_runs >= 1) {
@@ -872,6 +921,7 @@ void batch_sweep_stage(emagls_batch& b) {
         const int kk0 = std::max(q0.kcut0, 1);
         if (q0.sweep_persist) {
             if (kk0 < q0.P) {
+                SweepChain chain(b.stream);
                 for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, b.stream);
                 launch_sweep_persist(h, b.stream);
             }
@@ -892,19 +942,6 @@ void batch_sweep_stage(emagls_batch& b) {
         for (int kb = k0; kb < p0.P; ++kb) launch_sweep_dense_multi(m, kb, b.stream);
         if (k0 < p0.P) launch_sweep_finalize_multi(m, p0.P - 1, b.stream);
     }
-}
-template <typename F> void capture_into(hipStream_t st, hipGraph_t* g, hipGraphExec_t* ge, F&& body) {
-    HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    try {
-        body();
-    } catch (...) {
-        hipGraph_t tmp = nullptr;
-        hipStreamEndCapture(st, &tmp);
-        if (tmp) hipGraphDestroy(tmp);
-        throw;
-    }
-    HIP_CHECK(hipStreamEndCapture(st, g));
-    HIP_CHECK(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
 }
 
 // lane mode: the pipeline of plan 0 is enqueued once on the batch stream with grid.z = designs
@@ -949,7 +986,7 @@ void batch_execute_lanes(emagls_batch& b) {
         capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_lanes_part(b, 2); });
     }
     if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_lanes_part(b, 0);
-    batch_sweep_chained(b);
+    batch_sweep_stage(b);   // (never captured: see SweepChain)
     if (replay) HIP_CHECK(hipGraphLaunch(b.post_exec, b.stream)); else batch_lanes_part(b, 2);
     emagls_plan& p0 = *b.plans[0];
     for (auto* p : b.plans) {
@@ -978,7 +1015,7 @@ void batch_execute(emagls_batch& b) {
         if (replay) HIP_CHECK(hipGraphLaunch(p->pre_exec, p->stream)); else plan_pre_stage(*p);
         b.depend(b.stream, p->stream);
     }
-    if (b.plans[0]->sweep_persist) batch_sweep_chained(b);   // (never captured: see batch_sweep_chained)
+    if (b.plans[0]->sweep_persist) batch_sweep_stage(b);   // (never captured: see SweepChain)
     else if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_sweep_stage(b);
     emagls_plan& p0 = *b.plans[0];
     for (auto* p : b.plans) {
