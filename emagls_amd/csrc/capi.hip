@@ -155,6 +155,8 @@ struct emagls_batch {
     hipStream_t stream = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    int prof_level = 0;
+    hipEvent_t sweep_ev[2] = {nullptr, nullptr};
     hipGraph_t post_graph = nullptr;           // lane mode: the stages after the sweep (the sweep is launched directly)
     hipGraphExec_t post_exec = nullptr;
     int eager_runs = 0;
@@ -180,6 +182,7 @@ struct emagls_batch {
         if (graph) hipGraphDestroy(graph);
         if (post_exec) hipGraphExecDestroy(post_exec);
         if (post_graph) hipGraphDestroy(post_graph);
+        for (auto e : sweep_ev) if (e) hipEventDestroy(e);
         if (stream) hipStreamDestroy(stream);
         for (auto* p : plans) p->sync_stream = nullptr;
     }
@@ -923,7 +926,9 @@ void batch_sweep_stage(emagls_batch& b) {
             if (kk0 < q0.P) {
                 SweepChain chain(b.stream);
                 for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, b.stream);
+                if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[0], b.stream));
                 launch_sweep_persist(h, b.stream);
+                if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[1], b.stream));
             }
             return;
         }
@@ -1472,6 +1477,25 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
             if (flags[4 * j])
                 throw Error(EMAGLS_ERR_NUMERIC, "SH Gram matrix of the HRIR grid is not positive definite (the grid cannot resolve the required SH order)");
         }
+    });
+}
+int emagls_batch_set_profiling(emagls_batch* b, int level) {
+    return guarded([&] {
+        if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        HIP_CHECK(hipStreamSynchronize(b->stream));
+        if (level >= 1)
+            for (auto& e : b->sweep_ev) if (!e) HIP_CHECK(hipEventCreate(&e));
+        b->prof_level = level;
+    });
+}
+int emagls_batch_sweep_time(emagls_batch* b, double* ms) {
+    return guarded([&] {
+        if (!b || !ms) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (b->prof_level < 1 || !b->sweep_ev[0]) throw Error(EMAGLS_ERR_ARG, "batch profiling is off");
+        HIP_CHECK(hipStreamSynchronize(b->stream));
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, b->sweep_ev[0], b->sweep_ev[1]));
+        *ms = t;
     });
 }
 int emagls_batch_destroy(emagls_batch* b) {

@@ -125,6 +125,14 @@ class Batch:
         L.check(self._lib.emagls_batch_get_filters(self._h, pl, pr))
         return outs
 
+    def set_profiling(self, level):
+        L.check(self._lib.emagls_batch_set_profiling(self._h, int(level)))
+
+    def sweep_time_ms(self):
+        ms = C.c_double(0.0)
+        L.check(self._lib.emagls_batch_sweep_time(self._h, C.byref(ms)))
+        return ms.value
+
     def get_filters_into(self, ptrs_l, ptrs_r):
         """Device (or host) destination addresses, one pair per plan: no host staging."""
         n = len(self.plans)

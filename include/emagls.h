@@ -171,6 +171,10 @@ int emagls_batch_synchronize(emagls_batch* batch);
 /* synchronise once, check every plan's device-side status flags, copy all filters out: wL[j], wR[j] receive the filters of
  * plan j (host or device pointers).  Equivalent to emagls_plan_get_filters on every plan, without the per-plan round trips. */
 int emagls_batch_get_filters(emagls_batch* batch, void* const* wL, void* const* wR);
+/* profiling: with level >= 1 HIP events bracket the sweep launch of every execute (on the batch stream);
+ * emagls_batch_sweep_time returns the duration in ms of the last execute's sweep (synchronises the batch). */
+int emagls_batch_set_profiling(emagls_batch* batch, int level);
+int emagls_batch_sweep_time(emagls_batch* batch, double* ms);
 int emagls_batch_destroy(emagls_batch* batch);
 
 #ifdef __cplusplus
