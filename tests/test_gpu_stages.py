@@ -148,7 +148,9 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
     Z = p.debug("Z", np.complex128).reshape(P, C, ldS)[:, :, :S]
     sv = p.debug("sv", np.float64).reshape(P, C)
     js = p.debug("jsweeps", np.int32)
-    assert 1 <= js[1:P].min() and js[1:P].max() <= 20, (js[1:P].min(), js[1:P].max())
+    route = p.debug("route", np.int32)   # 0 Householder + Jacobi, 1 Gram + Jacobi, 2 Gram + Cholesky inverse (no SVD)
+    assert js[1:P].max() <= 20 and np.all((js[1:P] >= 1) | (route[1:P] == 2)), (js[1:P].min(), js[1:P].max())
+    assert (route[kcut0:P] == 2).sum() > 0.5 * (P - kcut0)
     nsw = P - max(kcut0, 1)  # swept bins; the buffers carry padding for the persistent sweep's whole-row-group loads
     G = p.debug("G", np.complex128)[:nsw * C * ldD].reshape(nsw, C, ldD)[:, :, :D]
     Mw = p.debug("Mw", np.complex128)[:P * C * C].reshape(P, C, C)  # bin kb is stored at slot kb-1
@@ -162,8 +164,14 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
     for kb in (1, 2, kcut0 - 1, kcut0, kcut0 + 1, P // 2, P - 1):
         B = Bk(kb)
         U, s, Vh = np.linalg.svd(B, full_matrices=False)
-        # (well-conditioned swept bins take the Gram route: error eps cond^2 instead of eps)
-        assert np.abs(np.sort(sv[kb])[::-1] - s).max() < (1e-13 if kb <= kcut0 + 1 else 1e-10) * s[0]
+        if route[kb] == 2:
+            # direct route (no singular value is clipped: M = (B^H B)^-1): sv holds certified bounds, not the values
+            assert sv[kb].max() >= s[0] * (1 - 1e-12) and sv[kb].min() <= s[-1] * (1 + 1e-12)
+            assert sv[kb].max() <= 100 * sv[kb].min()
+            assert rel(Mw[kb - 1], np.linalg.inv(B.conj().T @ B)) < 1e-10
+        else:
+            # (well-conditioned swept bins take the Gram route: error eps cond^2 instead of eps)
+            assert np.abs(np.sort(sv[kb])[::-1] - s).max() < (1e-13 if kb <= kcut0 + 1 else 1e-10) * s[0]
         sreg = 1 / np.maximum(s, 0.01 * s[0])
         Zo = np.conj(U) @ (sreg[:, None] * Vh.conj())
         if kb < kcut0:  # Z_k is only formed for the least-squares bins (and for ill-conditioned swept bins)
