@@ -39,6 +39,7 @@ struct FactorArgs {
     int* status;      // plan status flags; [2] is set when a Gram-route bin turns out ill-conditioned (the host re-runs without it)
     int jrun;         // Jacobi: consecutive bins per workgroup (warm start from the neighbour's rotations); 0/1 = independent
     int nbins;        // set by the launcher
+    int jsplit;       // set by the launcher: the first jsplit bins (Householder route: full Jacobi, the long ones) get one workgroup each
     int hq_conj;      // Hq holds conj(H conj(Q)) (the row-solve form used when Q is not materialised)
     cplx* W;          // [e][P][C]
     int* sweeps_out;  // optional [kb]

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     __shared__ double g_s[CPMAX];
     __shared__ double w_s[CPMAX];
     __shared__ double sig_s[CPMAX];
-    __shared__ __attribute__((aligned(16))) cplx Ws[CPMAX][CPMAX + 1];  // direct route: inverse of the Cholesky factor
+    __shared__ __attribute__((aligned(16))) cplx Ws[2][CPMAX + 1];   // direct route: pivot column and row of a sweep step
     __shared__ double fro_s[2];
     __shared__ int chol_bad;
     const int tid = threadIdx.x;
@@ -249,15 +249,17 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     // a workgroup walks `jrun` consecutive bins: neighbouring bins have nearly the same singular vectors, so the
     // rotations accumulated for one bin are the starting point of the next (X = R2^H V_prev is already almost
     // orthogonal by columns) and the sweeps drop from ~9 to ~3.  jrun = 1 keeps the bins independent.
-    const int jrun = a.jrun > 0 ? a.jrun : 1;
+    const bool solo = (int)blockIdx.x < a.jsplit;   // (workgroup-uniform)
+    const int jrun = solo ? 1 : (a.jrun > 0 ? a.jrun : 1);
+    const int bi0 = solo ? (int)blockIdx.x : a.jsplit + ((int)blockIdx.x - a.jsplit) * jrun;
     for (int t = 0; t < jrun; ++t) {
-    const int bi = blockIdx.x * jrun + t;   // bin slot (workspaces are indexed by it)
+    const int bi = bi0 + t;   // bin slot (workspaces are indexed by it)
     if (bi >= a.nbins) break;
     const int kb = a.kb0 + bi;
     const cplx* R2 = a.R2w + (int64_t)bi * C * C;
     const bool gram = a.route && a.route[kb] != 0;   // R2 holds A = B^H B (full): X = A, Xrot = V Lambda
     // ---- direct route.  The reference clips the singular values at reg_c s_max (1 %).  Where cond(B) <= 1/reg_c nothing
-    // is clipped and M = V diag(1/s^2) V^H = (B^H B)^-1: a Cholesky inverse of the C x C Gram matrix instead of an SVD
+    // is clipped and M = V diag(1/s^2) V^H = (B^H B)^-1: an in-place inverse of the C x C Gram matrix instead of an SVD
     // (all swept bins of BASELINE config 3 qualify: cond 54 at k_cut, < 2 above 5 kHz).  The certificate
     // cond(A) <= ||A||_F ||A^-1||_F <= 1/reg_c^2 is sufficient and rigorous; bins that fail it take the Jacobi route.
     if (gram && a.reg_mode == 0 && a.Mw) {
@@ -275,37 +277,29 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
         fa = wave_sum(fa);
         if ((tid & 63) == 0) atomicAdd(&fro_s[0], fa);
         __syncthreads();
-        // Cholesky A = L L^H in place (lower triangle: Xs[col][row], row >= col)
+        // in-place inversion of the Hermitian positive definite A by C sweep (Gauss-Jordan) steps without pivoting: every
+        // step is one rank-1 update of the whole C x C matrix spread over the 256 threads, two barriers per step
+        // (a Cholesky factorisation + triangular inverse has three times the sequential depth at this size)
+        cplx* colj = &Ws[0][0];          // column j and row j of the current matrix
+        cplx* rowj = &Ws[1][0];
         for (int j = 0; j < C; ++j) {
             const double piv = Xs[j][j].x;
             if (!(piv > 0.0)) { if (tid == 0) chol_bad = 1; }
-            const double dinv = fast_rsqrt(piv > 0.0 ? piv : 1.0);
+            const double ip = fast_rcp(piv > 0.0 ? piv : 1.0);
+            if (tid < C) { colj[tid] = Xs[j][tid]; rowj[tid] = Xs[tid][j]; }   // A[tid][j], A[j][tid]
             __syncthreads();
-            if (tid >= j && tid < C) Xs[j][tid] = (tid == j) ? mk(piv * dinv, 0.0) : mk(Xs[j][tid].x * dinv, Xs[j][tid].y * dinv);
-            __syncthreads();
-            // trailing update A[i][k] -= L[i][j] conj(L[k][j]),  j < k <= i < C
-            const int nrem = C - 1 - j;
-            for (int idx = tid; idx < nrem * nrem; idx += 256) {
-                const int i = j + 1 + idx / nrem, k = j + 1 + idx % nrem;
-                if (k <= i) { cplx pr = mk(0, 0); cfma_conj(pr, Xs[j][k], Xs[j][i]); Xs[k][i] = Xs[k][i] - pr; }   // conj(L[k][j]) L[i][j]
+            for (int idx = tid; idx < C * C; idx += 256) {
+                const int k = idx / C, i = idx - k * C;   // element A[i][k] = Xs[k][i]
+                cplx v;
+                if (i == j && k == j) v = mk(ip, 0.0);
+                else if (i == j) v = mk(rowj[k].x * ip, rowj[k].y * ip);
+                else if (k == j) v = mk(-colj[i].x * ip, -colj[i].y * ip);
+                else { cplx pr = mk(0, 0); cfma(pr, colj[i], rowj[k]); v = Xs[k][i] - mk(pr.x * ip, pr.y * ip); }
+                Xs[k][i] = v;
             }
             __syncthreads();
         }
-        // Linv: thread jc builds column jc of L^-1 by forward substitution -> Ws[jc][row]
-        if (tid < C) {
-            const int jc = tid;
-            for (int i = 0; i < C; ++i) {
-                cplx acc = mk(0, 0);
-                if (i == jc) acc = mk(1.0, 0.0);
-                else if (i > jc) {
-                    for (int k = jc; k < i; ++k) { cplx pr = mk(0, 0); cfma(pr, Xs[k][i], Ws[jc][k]); acc = acc - pr; }   // L[i][k] x_k
-                }
-                const double li = Xs[i][i].x;
-                Ws[jc][i] = (i < jc) ? mk(0, 0) : mk(acc.x / li, acc.y / li);
-            }
-        }
-        __syncthreads();
-        // M = A^-1 = L^-H L^-1:  M[a][b] = sum_{i >= max(a,b)} conj(Linv[i][a]) Linv[i][b]
+        // M = A^-1 (now in Xs); its Frobenius norm for the certificate
         cplx* M = a.Mw + (int64_t)bi * C * C;
         cplx mloc[(CPMAX * CPMAX + 255) / 256];
         double fm = 0.0;
@@ -313,8 +307,7 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
         for (int u = 0; u < (CPMAX * CPMAX + 255) / 256; ++u) {
             const int idx = tid + 256 * u, aa = idx / C, bb = idx % C;
             cplx acc = mk(0, 0);
-            if (idx < C * C)
-                for (int i = (aa > bb ? aa : bb); i < C; ++i) cfma_conj(acc, Ws[aa][i], Ws[bb][i]);
+            if (idx < C * C) acc = Xs[bb][aa];   // M[aa][bb]
             mloc[u] = acc;
             fm += norm2(acc);
         }
@@ -600,7 +593,8 @@ static void launch_one(const FactorArgs& a, int nbins, hipStream_t st, int phase
             FactorArgs aj = a;
             aj.nbins = nbins;
             const int jr = aj.jrun > 0 ? aj.jrun : 1;
-            factor_jacobi_kernel<<<bgrid((nbins + jr - 1) / jr), 256, 0, st>>>(aj, batch_ctx().stride);
+            aj.jsplit = (jr > 1 && aj.gram_from > aj.kb0) ? std::min(nbins, aj.gram_from - aj.kb0) : 0;
+            factor_jacobi_kernel<<<bgrid(aj.jsplit + (nbins - aj.jsplit + jr - 1) / jr), 256, 0, st>>>(aj, batch_ctx().stride);
         }
         KERNEL_CHECK();
     }
