@@ -430,7 +430,10 @@ int64_t gram_dpad(int64_t D) {
 
 template <typename T>
 static void gram_impl(const void* Yc, int64_t D, int S, int64_t ld, void* Gp, void* G, hipStream_t st) {
-    const int ks = gram_ksplit(D);
+    int ks = gram_ksplit(D);
+    // the K split only creates parallelism for ONE design (91 tiles would not fill 256 CUs); the lanes of a batch do that
+    // already, and fewer partial sums mean less traffic for the kernel and for the reduction
+    for (int n = batch_ctx().n; n >= 2 && ks > 4; n >>= 1) ks >>= 1;
     const int kc = (int)(gram_dpad(D) / ks);
     const int nbt = (S + 63) / 64;
     const int ntiles = nbt * (nbt + 1) / 2;

@@ -107,11 +107,10 @@ constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 
 template <int PS_DPW>
 __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
-    constexpr int PS_NC = 4 * PS_DPW;   // p-phase threads
     constexpr int XLD = PS_DPW + 4;     // row stride of the G slab (16 dwords mod 64: conflict-free quarter-wave reads)
     constexpr int RG = PS_DPW == 96 ? 4 : 2, CH = RG * PS_DPW / PS_NL, NG = PS_CMAX / RG;  // G: NG row groups x CH chunks per loader thread
     constexpr int NLM = (PS_CMAX * PS_CMAX) / 256;                                         // M: loads per M-phase thread
-    static_assert(PS_NC <= PS_COMM0 && 2 * PS_DPW <= 2 * PS_NL && PS_DPW >= 64, "role layout");
+    static_assert(4 * PS_DPW <= PS_COMM0 && 2 * PS_DPW <= 2 * PS_NL && PS_DPW >= 64, "role layout");
     __shared__ __attribute__((aligned(16))) cplx vt[64];          // totals of the previous bin, [ear][32] zero padded
     __shared__ __attribute__((aligned(16))) cplx Wp[64];          // W(kb-1,:), same layout
     __shared__ __attribute__((aligned(16))) cplx ts[2][PS_DPW];   // t per ear and direction
@@ -143,8 +142,6 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     }
     // roles
     const int part = tid & 3;
-    const bool pth = tid < PS_NC;                     // p phase: (direction, channel quarter)
-    const int dloc = pth ? (tid >> 2) : 0;
     const int pair = tid >> 2;                        // M / partial phases: (pair, quarter)
     const bool pvalid = pair < npairs;                // (npairs <= 64, so tid < 256)
     const int e = pvalid ? pair / C : 0, c = pvalid ? pair % C : 0;

@@ -145,10 +145,13 @@ def test_emagls_filters_config3_full(grids, hrirs):
     assert report("eMagLS config3 L", wL, oL) < TOL and report("eMagLS config3 R", wR, oR) < TOL
 
 
-def test_batch_of_designs_matches_single_designs(grids, thin):
+@pytest.mark.parametrize("lanes", ["lanes", "streams"])
+def test_batch_of_designs_matches_single_designs(grids, thin, monkeypatch, lanes):
     """Four designs of the same shape (two array radii x two HRIR sets) executed as one batch -- one sweep launch
     per bin for all of them -- give bit-identical filters to four separate designs, also under graph replay."""
     from emagls_amd import Batch, Plan, _lib as L, synth
+    if lanes == "streams":  # per-design stages on the plans' own streams, only the sweep launch is shared
+        monkeypatch.setenv("EMAGLS_BATCH_LANES", "0")
     hL2, hR2 = synth.rigid_sphere_hrirs(thin["azi"], thin["zen"], seed=99)
     jobs = [(0.042, thin["hL"], thin["hR"]), (0.040, thin["hL"], thin["hR"]), (0.042, hL2, hR2), (0.040, hL2, hR2)]
     plans, singles = [], []
