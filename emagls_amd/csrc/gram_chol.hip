@@ -422,10 +422,7 @@ int64_t gram_dpad(int64_t D) {
 
 template <typename T>
 static void gram_impl(const void* Yc, int64_t D, int S, int64_t ld, void* Gp, void* G, hipStream_t st) {
-    int ks = gram_ksplit(D);
-    // the K split only creates parallelism for ONE design (91 tiles would not fill 256 CUs); the lanes of a batch do that
-    // already, and fewer partial sums mean less traffic for the kernel and for the reduction
-    for (int n = batch_ctx().n; n >= 2 && ks > 4; n >>= 1) ks >>= 1;
+    const int ks = gram_ksplit(D);   // (fewer splits in lane mode were measured slower: 595 vs 454 + 104 us per 8 designs)
     const int kc = (int)(gram_dpad(D) / ks);
     const int nbt = (S + 63) / 64;
     const int ntiles = nbt * (nbt + 1) / 2;
