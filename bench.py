@@ -286,6 +286,17 @@ def main():
                             "design; one launch sweeps the designs of a batch, each on its own XCD; the chain is bound by the "
                             "per-bin exchange of partial sums between workgroups (two in-launch hops through the XCD's L2) and "
                             "LDS-bound phases, not by HBM bandwidth -- see DESIGN.md section 5"}
+        # the reference formulation needs F_ref FP64 flop per set (pwGrid GEMM + SVD-equivalent + apply);
+        # the factorised pipeline executes F_exec (per stage in DESIGN.md section 5)
+        Kb, Sx = info.num_pos_freqs - 1, info.num_sh_sim
+        f_ref = (8.0 * Kb * Cc * Sx * D + 8.0 * Kb * D * Cc * Cc + 8.0 * 2 * Kb * 2 * D * Cc + 8.0 * Kb * D * Cc * Cc) / 1e9
+        f_exec = (8.0 * Sx * Sx * D + 8.0 * Sx ** 3 / 3 + 8.0 * D * Cc * Sx + 80.0 * nbins_swept * Cc * D
+                  + 8.0 * 2 * (info.k_cut - 1) * D * Sx + 8.0 * Kb * Sx * Cc * 10 + 8.0 * nbins_swept * Sx * Cc * (Cc + 1) / 2
+                  + 8.0 * nbins_swept * 4 * D * Cc + 5.0 * D * info.nfft * 10) / 1e9
+        flops = {"F_ref_gflop_per_set": f_ref, "F_exec_gflop_per_set": f_exec, "exec_tflops": f_exec * world * K / dt / 1e3,
+                 "ref_equivalent_tflops": f_ref * world * K / dt / 1e3, "fp64_peak_tflops": 78.6,
+                 "note": "F_ref: reference formulation (SURVEY 8d: 126 GFLOP at config 3); F_exec: flops the factorised pipeline "
+                         "executes (Gram on MFMA counted as full tiles); fp64 peak = AMD's public vector/matrix figure"}
         res = {
             "metric": "eMagLS filter sets/s (N=4, 2702 dirs, 512 taps)", "value": world * K / dt, "unit": "filter sets/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
@@ -296,6 +307,7 @@ def main():
                        "k_cut": info.k_cut, "designs_in_flight_per_gpu": J, "designs_per_batch": Bsz, "batches_in_flight": nbatch,
                        "parallelism": "independent jobs per GPU, one RCCL gather"},
             "roofline": roof,
+            "flops": flops,
             "single_design_latency_ms": round(single_ms, 4),
             "stages_ms": {k: round(v, 4) for k, v in stages},
         }
