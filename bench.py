@@ -42,6 +42,25 @@ def load_inputs(seed_offset=0):
     return azi, zen, maz, mzn, hL, hR
 
 
+def parity_check():
+    """Secondary metric: deviation of the GPU filters from the oracle by the reference's own rule
+    (verifyEMagLs.m:370-395: normalised max abs difference, max spectral dB difference), on a case the oracle
+    finishes in seconds (the full-size case is covered by tests/test_gpu_parity.py)."""
+    from oracle import emagls_oracle as O
+    import emagls_amd as E
+    from emagls_amd import synth
+    azi, zen = synth.fibonacci_grid(900)
+    maz, mzn = synth.em32_grid()
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen, taps=64)
+    args = (hL, hR, azi, zen, 0.042, maz, mzn, 4, 48000.0, 128, "complex")
+    wL, wR = E.getEMagLsFilters(*args)
+    oL, oR = O.getEMagLsFilters(*args)
+    nd, db, adb = O.assert_all_close_metrics(np.hstack([wL, wR]), np.hstack([oL, oR]))
+    rel = float(max(np.abs(wL - oL).max() / np.abs(oL).max(), np.abs(wR - oR).max() / np.abs(oR).max()))
+    return {"case": "getEMagLsFilters em32 N=4 complex-SH, 900 dirs, 64-tap HRIRs, 128-tap filters", "rel_complex_error": rel,
+            "norm_max_abs_diff": float(nd), "max_abs_db_diff": float(adb), "tolerance": 1e-6}
+
+
 def cpu_baseline(azi, zen, maz, mzn, hL, hR, nbins_sample=48):
     """Oracle (NumPy restatement of lib/getEMagLsFilters.m) on a bounded sample: everything outside the
     per-bin loop in full, the per-bin loop (lines :85-106) on bins 2..nbins_sample+1 -- which straddle
@@ -319,6 +338,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(*inputs)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+            res["parity"] = parity_check()
         print(json.dumps(res))
     for b in batches:
         if b is not None:
