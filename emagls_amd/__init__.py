@@ -4,9 +4,9 @@ The Python layer mirrors the reference's MATLAB entry points over the C ABI in i
 Importing the package does not need a GPU; calling any function needs emagls_amd/lib/libemagls.so
 (python -m emagls_amd.build) and an MI355X -- there is no CPU fallback.
 """
-from .api import (binauralDecode, getEMagLs2Filters, getEMagLsFilters, getEMagLsFiltersFromAtf, getLsFilters,
+from .api import (binauralDecode, getEMagLs2Filters, getEMagLsFilters, getEMagLsFiltersEMAinCH, getEMagLsFiltersFromAtf, getLsFilters,
                   getMagLsFilters, getSH, sphModalCoeffs)
 from .plan import Batch, Plan
 
-__all__ = ["getLsFilters", "getMagLsFilters", "getEMagLsFilters", "getEMagLs2Filters", "getEMagLsFiltersFromAtf",
+__all__ = ["getLsFilters", "getMagLsFilters", "getEMagLsFilters", "getEMagLs2Filters", "getEMagLsFiltersEMAinCH", "getEMagLsFiltersFromAtf",
            "binauralDecode", "getSH", "sphModalCoeffs", "Plan", "Batch"]

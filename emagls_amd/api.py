@@ -6,6 +6,7 @@ hL/hR are [numSamples x numDirections]; filters come back [len x numChannels].
     getMagLsFilters         lib/getMagLsFilters.m:1-2
     getEMagLsFilters        lib/getEMagLsFilters.m:1-2
     getEMagLs2Filters       lib/getEMagLs2Filters.m:1-2
+    getEMagLsFiltersEMAinCH lib/getEMagLsFiltersEMAinCH.m:1-2
     getEMagLsFiltersFromAtf lib/getEMagLsFiltersFromAtf.m:1
     binauralDecode          dependencies/binauralDecode.m:1-2
     getSH / sphModalCoeffs  the un-vendored third-party functions the above call
@@ -129,6 +130,26 @@ def getEMagLs2Filters(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGrid
                       shDefinition="real", shFunction=None):
     return _sma("emagls_get_emagls2_filters", True, hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad,
                 micGridZenRad, order, fs, len, shDefinition, shFunction)
+
+
+def getEMagLsFiltersEMAinCH(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, order, fs, len,
+                            shDefinition="real", shFunction=None, chFunction=None):
+    """lib/getEMagLsFiltersEMAinCH.m:1-2: eMagLS filters in circular harmonics for an equatorial microphone array;
+    returns [len x (2*order+1)] per ear, channels ordered [C_0, C_-1, C_1, ..., C_-N, C_N] (dependencies/getCH.m)."""
+    if chFunction is not None:
+        raise NotImplementedError("a custom chFunction handle cannot cross the C ABI; the default @getCH is built in")
+    b, cplx = _basis(shDefinition, shFunction)
+    hL, hR, pL, pR = _hrirs(hL, hR)
+    n, D = hL.shape
+    azi, pa = _vec(hrirGridAziRad, D, "hrirGridAziRad")
+    zen, pz = _vec(hrirGridZenRad, D, "hrirGridZenRad")
+    micAzi, pma = _vec(micGridAziRad)
+    C_ = 2 * int(order) + 1
+    wL, pwL = _out(int(len), C_, cplx)
+    wR, pwR = _out(int(len), C_, cplx)
+    L.check(L.load().emagls_get_emagls_filters_ema_in_ch(pL, pR, n, D, pa, pz, float(micRadius), pma, micAzi.size, int(order),
+                                                         float(fs), int(len), b, pwL, pwR))
+    return wL, wR
 
 
 def getEMagLsFiltersFromAtf(hL, hR, hrirGridAziZenRad, atfIrs, atfGridAziZenRad, fs, filterLen, fTrans, verbose=True):

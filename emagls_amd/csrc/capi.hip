@@ -200,9 +200,12 @@ void check_pow2(int nfft) {
 // ---------------------------------------------------------------------------------------------
 // plan construction: derive constants, allocate every device buffer once
 // ---------------------------------------------------------------------------------------------
+// kinds that run the array-model pipeline (simulated array -> per-bin factor -> sweep)
+static inline bool array_kind(int k) { return k == EMAGLS_KIND_EMAGLS || k == EMAGLS_KIND_EMAGLS2 || k == EMAGLS_KIND_EMA_CH; }
+
 void plan_setup(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
-    if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_FROM_ATF) throw Error(EMAGLS_ERR_ARG, "unknown design kind");
+    if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_EMA_CH) throw Error(EMAGLS_ERR_ARG, "unknown design kind");
     if (d.basis != EMAGLS_BASIS_REAL && d.basis != EMAGLS_BASIS_COMPLEX) throw Error(EMAGLS_ERR_ARG, "shDefinition must be 'real' or 'complex'");
     if (d.ndirs < 1 || d.nsamp < 1) throw Error(EMAGLS_ERR_ARG, "empty HRIR set");
     if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
@@ -248,16 +251,16 @@ void plan_setup(emagls_plan& p) {
         p.nOut = p.S;
         if (p.S > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "SH order above 4 is not supported for LS/MagLS in this build");
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than SH channels");
-    } else if (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) {
+    } else if (array_kind(d.kind)) {
         if (!(d.mic_radius > 0) || d.nmics < 1) throw Error(EMAGLS_ERR_ARG, "invalid array geometry");
         p.simOrder = std::max(N, (int)std::ceil(d.fs * kPi * d.mic_radius / C_SOUND));  // getSMAIRMatrix.m:95
         p.S = (p.simOrder + 1) * (p.simOrder + 1);
-        p.nOut = (N + 1) * (N + 1);
-        p.C = d.kind == EMAGLS_KIND_EMAGLS ? p.nOut : (int)d.nmics;
+        p.nOut = d.kind == EMAGLS_KIND_EMA_CH ? 2 * N + 1 : (N + 1) * (N + 1);   // EMAinCH.m:66: numHarmonics = 2*order+1
+        p.C = d.kind == EMAGLS_KIND_EMAGLS2 ? (int)d.nmics : p.nOut;
         if (p.C > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels is not supported in this build");
         if (p.S > 768) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 26 (array radius > ~5.9 cm at 48 kHz) is not supported in this build");
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than simulated SH channels");
-        if (d.kind == EMAGLS_KIND_EMAGLS && d.nmics < p.nOut) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than SH output channels");
+        if (d.kind != EMAGLS_KIND_EMAGLS2 && d.nmics < p.nOut) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than output channels");
     } else {
         if (d.nmics < 1 || d.natf < 1 || d.atf_taps < 1) throw Error(EMAGLS_ERR_ARG, "invalid ATF set");
         p.C = (int)d.nmics;
@@ -295,7 +298,7 @@ void plan_setup(emagls_plan& p) {
             p.alloc("Xc", esz(cb) * (size_t)p.S * p.ldD);              // Y_conj as [c][d]
         }
     }
-    if (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) {
+    if (array_kind(d.kind)) {
         const int M = (int)d.nmics;
         const int ldM = round_up(M, 64);
         p.alloc("mic_azi", sizeof(double) * M, false);
@@ -303,7 +306,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Ymic_cm", esz(cb) * (size_t)p.S * M);                 // [S][M]
         p.alloc("Ymic_rm", esz(cb) * (size_t)ldM * p.ldS);             // [M][ldS]
         p.alloc("E", esz(cb) * (size_t)p.C * p.ldS);                   // [C][ldS]
-        if (d.kind == EMAGLS_KIND_EMAGLS) {
+        if (d.kind != EMAGLS_KIND_EMAGLS2) {
             p.alloc("Ylo_c", sizeof(cplx) * (size_t)p.nOut * ldM);     // [nOut][ldM] complex copy of Y_Lo^T
             p.alloc("Zlo", sizeof(cplx) * (size_t)p.nOut * ldM);
             p.alloc("Vlo", sizeof(cplx) * (size_t)p.nOut * ldM);
@@ -330,7 +333,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("QT", esz(cb) * (size_t)(p.simOrder + 1) * p.C * p.ldD);
         {
             const size_t nsw = (size_t)std::max(p.P - std::max(p.kcut0, 1), 1);
-            p.alloc("G", sizeof(cplx) * (nsw * p.C + 8) * p.ldD, false);  // + 8 rows: the persistent sweep loads whole row groups
+            p.alloc("G", sizeof(cplx) * (nsw * p.C + 32) * p.ldD, false);  // + 32 rows: the persistent sweep loads all 32 slab rows of a bin unconditionally
             p.alloc("Yri", sizeof(cplx) * nsw * p.C * p.ldD, false);
         }
         p.sweep_factored = getenv("EMAGLS_SWEEP") && std::string(getenv("EMAGLS_SWEEP")) == "factored";
@@ -490,7 +493,8 @@ int emagls_gram_from(const emagls_plan& p) {
     if (!p.gram_route || p.sweep_factored || p.d.mic_radius <= 0.0) return 0;
     if (const char* e = getenv("EMAGLS_GRAM_ROUTE")) if (e[0] == '0') return 0;
     int n = 0;
-    while ((n + 1) * (n + 1) < p.C) ++n;
+    if (p.d.kind == EMAGLS_KIND_EMA_CH) n = p.d.order;   // 2N+1 circular harmonics reach order N
+    else while ((n + 1) * (n + 1) < p.C) ++n;
     if (n < 1) return 0;
     double dfact = 1.0;
     for (int i = 3; i <= 2 * n + 1; i += 2) dfact *= i;
@@ -530,7 +534,10 @@ void emagls_pre_sweep(emagls_plan& p) {
     if (raw) {
         launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("E"), M, p.ldS, cb, false, s1);  // E = Y_mic
     } else {
-        launch_widen(p.get("Ymic_cm"), M, cb, p.get("Ylo_c"), ldM, p.nOut, M, false, false, s1);
+        if (d.kind == EMAGLS_KIND_EMA_CH)   // pinv(chFunction(order, micGridAziRad))  (getEMagLsFiltersEMAinCH.m:70)
+            launch_ch_basis(d.order, M, p.get<double>("mic_azi"), cb, p.get("Ylo_c"), ldM, s1);
+        else
+            launch_widen(p.get("Ymic_cm"), M, cb, p.get("Ylo_c"), ldM, p.nOut, M, false, false, s1);
         FactorArgs a{};
         a.S = M; a.C = p.nOut; a.ldS = ldM; a.kb0 = 0; a.P = 2;
         a.Xd = p.get<cplx>("Ylo_c"); a.xd_stride = 0;
@@ -574,8 +581,9 @@ void emagls_pre_sweep(emagls_plan& p) {
         launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, cb, p.get("QT"), p.ldD, s1);
         {
             static const bool real_terms = [] { const char* e = getenv("EMAGLS_DSPACE_REAL"); return !(e && e[0] == '0'); }();
-            launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, k0, p.get("G"), s1, (cb && real_terms) ? 1 : 0,
-                            raw ? -1 : (int)d.order);
+            // (circular-harmonic channels: the real-arithmetic form would need their own channel transform -> complex kernel)
+            launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, k0, p.get("G"), s1,
+                            (cb && real_terms && d.kind != EMAGLS_KIND_EMA_CH) ? 1 : 0, raw ? -1 : (int)d.order);
         }
     }
     // s2 (after the prologue): Q = conj(Y) R^-1 and the least-squares right-hand sides H conj(Q)
@@ -758,7 +766,8 @@ void emagls_run_sweep(emagls_plan& p) {
 void emagls_post_sweep(emagls_plan& p) {
     const bool cb = p.cplx_basis;
     const bool raw = p.d.kind == EMAGLS_KIND_EMAGLS2;
-    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"), (cb && !raw) ? 1 : 0, 1, 0,
+    const int conj_mode = !cb || raw ? 0 : (p.d.kind == EMAGLS_KIND_EMA_CH ? 2 : 1);   // Hermitian mirror / SH rule / CH rule
+    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"), conj_mode, 1, 0,
                            p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), p.stream);
     p.mark("epilogue");
 }
@@ -836,7 +845,8 @@ void run_pipeline(emagls_plan& p) {
         case EMAGLS_KIND_LS: execute_ls(p); break;
         case EMAGLS_KIND_MAGLS: execute_magls(p); break;
         case EMAGLS_KIND_EMAGLS:
-        case EMAGLS_KIND_EMAGLS2: execute_emagls(p); break;
+        case EMAGLS_KIND_EMAGLS2:
+        case EMAGLS_KIND_EMA_CH: execute_emagls(p); break;
         default: execute_from_atf(p); break;
     }
 }
@@ -859,10 +869,10 @@ template <typename F> void capture_into(hipStream_t st, hipGraph_t* g, hipGraphE
 void plan_execute(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     if (!p.have_hrir_grid || !p.have_hrirs) throw Error(EMAGLS_ERR_ARG, "HRIRs and their grid must be set before execute");
-    if ((d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) && !p.have_mic_grid)
+    if (array_kind(d.kind) && !p.have_mic_grid)
         throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
     if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
-    const bool persist = (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) && p.sweep_half && p.sweep_persist &&
+    const bool persist = array_kind(d.kind) && p.sweep_half && p.sweep_persist &&
                          !p.sweep_factored;
     if (p.prof_level == 0 && p.use_graph && persist) {
         // the persistent sweep is launched directly (SweepChain); the stages before it are captured from the second
@@ -1532,6 +1542,16 @@ int emagls_get_emagls2_filters(const double* hL, const double* hR, int64_t nsamp
     d.mic_radius = mic_radius; d.nmics = nmics;
     if (!mic_azi || !mic_zen) { g_last_error = "null microphone grid"; return EMAGLS_ERR_ARG; }
     return one_shot(d, hL, hR, azi, zen, mic_azi, mic_zen, nullptr, nullptr, nullptr, wL, wR, nullptr);
+}
+int emagls_get_emagls_filters_ema_in_ch(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi,
+                                        const double* zen, double mic_radius, const double* mic_azi, int64_t nmics, int order,
+                                        double fs, int64_t len, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_EMA_CH; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    d.mic_radius = mic_radius; d.nmics = nmics;
+    if (!mic_azi || nmics < 1) { g_last_error = "invalid array geometry"; return EMAGLS_ERR_ARG; }
+    std::vector<double> mic_zen((size_t)nmics, kPi / 2.0);   // getEMagLsFiltersEMAinCH.m:60: equatorial array
+    return one_shot(d, hL, hR, azi, zen, mic_azi, mic_zen.data(), nullptr, nullptr, nullptr, wL, wR, nullptr);
 }
 int emagls_get_emagls_filters_from_atf(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
                                        const double* azi, const double* zen, const double* atf_irs, int64_t atf_taps,

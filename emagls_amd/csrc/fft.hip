@@ -244,6 +244,7 @@ __global__ void __launch_bounds__(512) real_fft_gather_kernel(const double* __re
 //   W [e][kb][c]  positive-frequency filter spectra, kb = 0..P-1, ldW = channel stride count C
 //   conj_mode 0: Hermitian mirror (real SH / raw microphones)
 //   conj_mode 1: getShFreqDomainConjugate  W(nfft-k,(n,m)) = (-1)^m conj(W(k,(n,-m)))
+//   conj_mode 2: getChFreqDomainConjugate  W(nfft-k, m) = conj(W(k, -m)), channels [C_0, C_-1, C_1, ..., C_-N, C_N]
 //   dc_rule   1: W(0) := real(W(1))   (lib/getEMagLsFilters.m:110-111)
 //   shift_mode 0: applySubsampleDelay by nfft/2 (left) / nfft/2 + grpDR - grpDL (right)
 //   shift_mode 1: circshift by round(nfft/2)     (lib/getEMagLsFiltersFromAtf.m:136-138)
@@ -270,6 +271,8 @@ __global__ void __launch_bounds__(256) filter_epilogue_kernel(const cplx* __rest
         const int m = c - n * n - n;
         cpart = n * n + n - m;
         sgn = (m & 1) ? -1.0 : 1.0;
+    } else if (conj_mode == 2) {
+        cpart = (c == 0) ? 0 : ((c & 1) ? c + 1 : c - 1);   // (2m-1, 2m) are the pair (-m, +m)
     }
     const int n_shift = nfft / 2;
     const double delay = (e == 0) ? (double)n_shift : ((double)n_shift + grpd[1]) - grpd[0];

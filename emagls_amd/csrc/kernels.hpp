@@ -8,6 +8,7 @@ namespace emagls {
 
 // ---- sh_basis.hip
 void launch_zero(void* p, size_t bytes, hipStream_t st);
+void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out, int ld, hipStream_t st);
 void launch_sh_coeff(int N, double* tab, hipStream_t st);
 inline size_t sh_coeff_count(int N) { return (size_t)2 * (N + 1) * (N + 1) + 2 * (N + 1); }
 void launch_sh_basis(int N, int64_t D, const double* azi, const double* zen, const double* tab, bool cplx_basis,

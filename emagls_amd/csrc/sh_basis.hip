@@ -138,6 +138,31 @@ void launch_zero(void* p, size_t bytes, hipStream_t st) {
     KERNEL_CHECK();
 }
 
+// circular harmonics of an equatorial array (dependencies/getCH.m:17-28), written as the complex [channel][mic] matrix
+// that the pinv factorisation takes:  out[c * ld + m] = C_c(azi_m),  channels [C_0, C_-1, C_1, ..., C_-N, C_N]
+__global__ void ch_basis_kernel(int N, int M, const double* __restrict__ azi, int cplx_basis, cplx* __restrict__ out, int ld,
+                                size_t bstride) {
+    azi = boff(azi, bstride); out = boff(out, bstride);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = 2 * N + 1;
+    if (idx >= C * M) return;
+    const int c = idx / M, m = idx % M;
+    cplx v = mk(1.0, 0.0);
+    if (c > 0) {
+        const int nn = (c + 1) / 2;
+        const bool neg = (c & 1) != 0;   // c = 2 nn - 1: C_-nn, c = 2 nn: C_+nn
+        double sn, cs;
+        sincos((double)nn * azi[m], &sn, &cs);
+        if (cplx_basis) v = neg ? mk(cs, -sn) : mk(cs, sn);
+        else v = mk(1.4142135623730951 * (neg ? sn : cs), 0.0);
+    }
+    out[(size_t)c * ld + m] = v;
+}
+void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out, int ld, hipStream_t st) {
+    ch_basis_kernel<<<bgrid(((2 * N + 1) * M + 255) / 256), 256, 0, st>>>(N, M, azi, cplx_basis ? 1 : 0, (cplx*)out, ld, batch_ctx().stride);
+    KERNEL_CHECK();
+}
+
 void launch_sh_coeff(int N, double* tab, hipStream_t st) {
     sh_coeff_kernel<<<bgrid(8), 256, 0, st>>>(N, tab, batch_ctx().stride);
     KERNEL_CHECK();

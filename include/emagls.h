@@ -7,6 +7,7 @@
  *   emagls_get_emagls_filters          <-  lib/getEMagLsFilters.m:1-2
  *   emagls_get_emagls2_filters         <-  lib/getEMagLs2Filters.m:1-2
  *   emagls_get_emagls_filters_from_atf <-  lib/getEMagLsFiltersFromAtf.m:1
+ *   emagls_get_emagls_filters_ema_in_ch <- lib/getEMagLsFiltersEMAinCH.m:1-2  (default chFunction @getCH, dependencies/getCH.m)
  *   emagls_binaural_decode             <-  dependencies/binauralDecode.m:1-2 (core loop :33-42,53-64)
  *   emagls_sh_basis                    <-  getSH (polarch/Spherical-Harmonic-Transform, call site lib/getLsFilters.m:30)
  *   emagls_modal_bn                    <-  sphModalCoeffs (polarch/Array-Response-Simulator, call site dependencies/getSMAIRMatrix.m:107)
@@ -48,6 +49,7 @@ extern "C" {
 #define EMAGLS_KIND_EMAGLS 2
 #define EMAGLS_KIND_EMAGLS2 3
 #define EMAGLS_KIND_FROM_ATF 4
+#define EMAGLS_KIND_EMA_CH 5   /* equatorial array, output in circular harmonics (2*order+1 channels) */
 
 const char* emagls_last_error(void);
 int emagls_version(void);
@@ -87,6 +89,13 @@ int emagls_get_emagls2_filters(const double* hL, const double* hR, int64_t nsamp
                                const double* hrir_azi, const double* hrir_zen, double mic_radius,
                                const double* mic_azi, const double* mic_zen, int64_t nmics, int order, double fs,
                                int64_t len, int basis, void* wL, void* wR /* [len x nmics] */);
+
+/* Equatorial microphone array (all microphones at zenith pi/2), filters in circular harmonics ordered
+ * [C_0, C_-1, C_1, ..., C_-N, C_N]: wL, wR [len x (2*order+1)], real or complex like the basis. */
+int emagls_get_emagls_filters_ema_in_ch(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
+                                        const double* hrir_azi, const double* hrir_zen, double mic_radius,
+                                        const double* mic_azi, int64_t nmics, int order, double fs, int64_t len, int basis,
+                                        void* wL, void* wR);
 
 /* atf_irs [atf_taps x nmics x natf]; outputs real [filter_len x nmics];
  * mean_grid_dev_deg (optional) receives the value the reference prints (getEMagLsFiltersFromAtf.m:96). */

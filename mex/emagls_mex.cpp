@@ -97,6 +97,20 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         rc = (raw ? emagls_get_emagls2_filters : emagls_get_emagls_filters)(
             hL, hR, nsamp, ndirs, dbl(prhs[3], "azi"), dbl(prhs[4], "zen"), r, dbl(prhs[6], "micAzi"), dbl(prhs[7], "micZen"),
             nmics, order, fs, len, basis, out_ptr(plhs[0]), out_ptr(plhs[1]));
+    } else if (c == "emainch") {   // getEMagLsFiltersEMAinCH(hL, hR, azi, zen, micRadius, micGridAziRad, order, fs, len, shDefinition)
+        if (nrhs < 10) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+        const double r = mxGetScalar(prhs[5]);
+        const mwSize nmics = mxGetNumberOfElements(prhs[6]);
+        const int order = (int)mxGetScalar(prhs[7]);
+        const double fs = mxGetScalar(prhs[8]);
+        const mwSize len = (mwSize)mxGetScalar(prhs[9]);
+        const int basis = basis_of(nrhs > 10 ? prhs[10] : nullptr);
+        const mwSize C = (mwSize)(2 * order + 1);
+        plhs[0] = out_matrix(len, C, basis);
+        plhs[1] = out_matrix(len, C, basis);
+        rc = emagls_get_emagls_filters_ema_in_ch(hL, hR, nsamp, ndirs, dbl(prhs[3], "azi"), dbl(prhs[4], "zen"), r,
+                                                 dbl(prhs[6], "micAzi"), nmics, order, fs, len, basis, out_ptr(plhs[0]),
+                                                 out_ptr(plhs[1]));
     } else if (c == "fromatf") {
         if (nrhs < 9) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
         const double* hg = dbl(prhs[3], "hrirGridAziZenRad");   // [ndirs x 2], column-major: azi then zen

@@ -404,6 +404,68 @@ def getEMagLs2Filters(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, 
                            shDefinition, raw=True, collect=collect)
 
 
+
+# --------------------------------------------------------------------------------------------
+# Equatorial microphone arrays in circular harmonics
+# --------------------------------------------------------------------------------------------
+def getCH(N, aziRad, basisType="real"):
+    """dependencies/getCH.m:17-28: circular harmonics [numDirs x 2N+1], ordered [C_0, C_-1, C_1, ..., C_-N, C_N];
+    real: sqrt(2) sin(m phi) / sqrt(2) cos(m phi); complex: exp(-/+ 1i m phi)."""
+    azi = np.asarray(aziRad, dtype=float).reshape(-1)
+    Y = np.zeros((azi.size, 2 * N + 1), dtype=np.complex128 if basisType == "complex" else np.float64)
+    Y[:, 0] = 1.0
+    for nn in range(1, N + 1):
+        if basisType == "real":
+            Y[:, 2 * nn - 1] = math.sqrt(2.0) * np.sin(nn * azi)
+            Y[:, 2 * nn] = math.sqrt(2.0) * np.cos(nn * azi)
+        else:
+            Y[:, 2 * nn - 1] = np.exp(-1j * nn * azi)
+            Y[:, 2 * nn] = np.exp(1j * nn * azi)
+    return Y
+
+
+def getChFreqDomainConjugate(Wpos):
+    """Positive-frequency half [P x 2N+1] (complex-CH filters) -> full spectrum [nfft x 2N+1] such that the time-domain
+    filters obey w_{-m} = conj(w_m) (C_{-m} = conj(C_m), no Condon-Shortley sign): W(nfft-k, m) = conj(W(k, -m)).
+    Third-party (thomasdeppisch/sh-symmetries, un-vendored; call site lib/getEMagLsFiltersEMAinCH.m:125-126):
+    restated from the symmetry of the basis, no fixture pins it."""
+    Wpos = np.asarray(Wpos)
+    P, C = Wpos.shape
+    N = (C - 1) // 2
+    neg = np.empty((P - 2, C), dtype=np.complex128)
+    neg[:, 0] = np.conj(Wpos[1 : P - 1, 0])
+    for nn in range(1, N + 1):
+        neg[:, 2 * nn - 1] = np.conj(Wpos[1 : P - 1, 2 * nn])
+        neg[:, 2 * nn] = np.conj(Wpos[1 : P - 1, 2 * nn - 1])
+    return np.vstack([Wpos, neg[::-1]])
+
+
+def getEMagLsFiltersEMAinCH(hL, hR, aziRad, zenRad, micRadius, micAzi, order, fs, length, shDefinition="real"):
+    """lib/getEMagLsFiltersEMAinCH.m:32-151: eMagLS for an equatorial array, output in circular harmonics.
+    pwGrid_CH = pinv(CH(order, micAzi)) * (pMics(:,:,k) * Y_hor^H)  (:66-75), same per-bin loop (:93-113), DC rule
+    (:117-118), Hermitian mirror or the CH conjugate rule (:121-127), shift / truncate / fade (:134-147).
+    No fixture pins this function: parity unpinned."""
+    assert length >= hL.shape[0], "len too short"
+    nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
+    micAzi = np.asarray(micAzi, dtype=float).reshape(-1)
+    micGrid = np.column_stack([micAzi, np.full(micAzi.size, np.pi / 2)])
+    smair, simOrder = getSMAIRMatrix(order, fs, nfft, micRadius, micGrid, shDefinition, returnRawMicSigs=True)
+    Y_hor_conj = getSH(simOrder, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
+    Y_CH_Mic_pinv = pinv(getCH(order, micAzi, shDefinition))
+    HL, HR, gL, gR = _hrir_prologue(hL, hR, nfft, P)
+    C = 2 * order + 1
+    W_l, W_r = _emagls_core(HL, HR, lambda k: Y_CH_Mic_pinv @ (smair[:, :, k - 1] @ Y_hor_conj), P, k_cut, C)
+    is_real = np.isrealobj(Y_hor_conj)
+    n_shift = nfft // 2
+    out = []
+    for W, dly in ((W_l, n_shift), (W_r, n_shift + gR - gL)):
+        Wf = np.vstack([W[:P], np.conj(W[P - 2 : 0 : -1])]) if is_real else getChFreqDomainConjugate(W[:P])
+        w = applySubsampleDelay(np.fft.ifft(Wf, axis=0), dly)
+        w = w[n_shift - length // 2 : n_shift + length // 2] * getFadeWindow(length)[:, None]
+        out.append(w.real if is_real else w)
+    return out[0], out[1]
+
+
 def _sph2cart_unit(aziZen):
     azi, zen = aziZen[:, 0], aziZen[:, 1]
     ele = np.pi / 2 - zen

@@ -135,6 +135,36 @@ def test_gram_route_fallback(grids, thin, monkeypatch):
         p.close()
 
 
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_emagls_ema_in_ch(thin, basis):
+    """getEMagLsFiltersEMAinCH: equatorial array of 16 microphones on a 4.2 cm sphere, order 4,
+    filters in the 9 circular harmonics.  Same per-bin kernel as eMagLS with pinv(CH(micAzi)) in front; the complex basis
+    exercises the CH conjugate rule of the epilogue."""
+    import emagls_amd as E
+    mic_azi = np.linspace(0.0, 2 * np.pi, 16, endpoint=False) + 0.1
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, mic_azi, 4, 48000.0, 128, basis)
+    wL, wR = E.getEMagLsFiltersEMAinCH(*args)
+    oL, oR = O.getEMagLsFiltersEMAinCH(*args)
+    assert wL.dtype == oL.dtype and wL.shape == (128, 9)
+    assert report("EMAinCH L " + basis, wL, oL) < TOL and report("EMAinCH R " + basis, wR, oR) < TOL
+    from emagls_amd._lib import EmaglsError
+    with pytest.raises(EmaglsError, match="fewer microphones"):
+        E.getEMagLsFiltersEMAinCH(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, mic_azi[:8], 4, 48000.0, 128, basis)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_emagls_low_orders(grids, thin, order):
+    """Orders below 4 (4, 9, 16 channels): the persistent sweep loads all 32 slab rows of a bin whatever the channel
+    count, so the last bin reads up to 28 rows of padding behind G (regression: the padding once was 8 rows)."""
+    import emagls_amd as E
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], grids["mic_radius"], grids["mic_azi"], grids["mic_zen"],
+            order, 48000.0, 128, "complex" if order == 2 else "real")
+    wL, wR = E.getEMagLsFilters(*args)
+    oL, oR = O.getEMagLsFilters(*args)
+    assert wL.shape == (128, (order + 1) ** 2)
+    assert report(f"eMagLS N={order} L", wL, oL) < TOL and report(f"eMagLS N={order} R", wR, oR) < TOL
+
+
 def test_emagls_filters_config3_full(grids, hrirs):
     """BASELINE config 3: em32 r = 4.2 cm, N = 4, complex SH, 2702 directions, 512 taps."""
     import emagls_amd as E
