@@ -1,0 +1,14 @@
+"""Ragged, minimal and maximal shapes through every entry point, against the oracle (tolerance 1e-6 relative, north_star).
+The full sweep (60 cases, incl. 3000+ directions and 512-tap filters) is scratch/fuzz_shapes.py; measured 2026-10: all < 2e-10."""
+import pytest
+
+from shape_cases import CASES, FAST, run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("idx", FAST, ids=[f"{i}-{CASES[i][0]}-D{CASES[i][1]}" for i in FAST])
+def test_shape_case(idx):
+    err = run(CASES[idx])
+    print(f"case {CASES[idx]}: rel = {err:.2e}")
+    assert err < 1e-6
