@@ -1206,8 +1206,12 @@ int emagls_plan_set_hrir_grid(emagls_plan* p, const double* azi, const double* z
 }
 int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* zen) {
     return guarded([&] {
-        if (!p || !azi || !zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (!p || !azi) throw Error(EMAGLS_ERR_ARG, "null pointer");
         if (!p->has("mic_azi")) throw Error(EMAGLS_ERR_ARG, "this design kind has no microphone grid");
+        // an equatorial array (EMAinCH) has no zenith argument: pi/2 for every microphone (getEMagLsFiltersEMAinCH.m:60)
+        std::vector<double> equator;
+        if (p->d.kind == EMAGLS_KIND_EMA_CH) { equator.assign((size_t)p->d.nmics, kPi / 2.0); zen = equator.data(); }
+        if (!zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
         p->upload("mic_azi", azi, sizeof(double) * p->d.nmics);
         p->upload("mic_zen", zen, sizeof(double) * p->d.nmics);
         // kr = 2*pi*f/C * smaRadius on f = linspace(0, fs/2, P)   (getSMAIRMatrix.m:90,107)
@@ -1406,7 +1410,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         for (int j = 0; j < nplans; ++j) {
             emagls_plan* p = plans[j];
             if (!p) throw Error(EMAGLS_ERR_ARG, "null plan");
-            if (p->d.kind != EMAGLS_KIND_EMAGLS && p->d.kind != EMAGLS_KIND_EMAGLS2) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 plans");
+            if (!array_kind(p->d.kind)) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH plans");
             if (p->sweep_factored) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches need the direction-space sweep");
             const emagls_plan* q = plans[0];
             if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_split != q->sweep_split || p->sweep_half != q->sweep_half || p->sweep_persist != q->sweep_persist)

@@ -37,8 +37,9 @@ class Plan:
     def set_hrir_grid(self, azi, zen):
         L.check(self._lib.emagls_plan_set_hrir_grid(self._h, self._p(azi), self._p(zen)))
 
-    def set_mic_grid(self, azi, zen):
-        L.check(self._lib.emagls_plan_set_mic_grid(self._h, self._p(azi), self._p(zen)))
+    def set_mic_grid(self, azi, zen=None):
+        """zen may be omitted for an equatorial array (KIND_EMA_CH): every microphone sits at pi/2."""
+        L.check(self._lib.emagls_plan_set_mic_grid(self._h, self._p(azi), self._p(zen) if zen is not None else None))
 
     def set_hrirs(self, hL, hR):
         L.check(self._lib.emagls_plan_set_hrirs(self._h, self._p(hL), self._p(hR)))

@@ -142,6 +142,7 @@ typedef struct emagls_plan_info {
 int emagls_plan_create(const emagls_design_desc* desc, emagls_plan** plan);
 int emagls_plan_destroy(emagls_plan* plan);
 int emagls_plan_set_hrir_grid(emagls_plan* plan, const double* azi, const double* zen);
+/* zen is ignored (may be NULL) for EMAGLS_KIND_EMA_CH: an equatorial array, every microphone at pi/2 */
 int emagls_plan_set_mic_grid(emagls_plan* plan, const double* azi, const double* zen);
 int emagls_plan_set_hrirs(emagls_plan* plan, const double* hL, const double* hR);
 int emagls_plan_set_atfs(emagls_plan* plan, const double* atf_irs, const double* atf_azi, const double* atf_zen);

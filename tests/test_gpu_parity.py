@@ -268,6 +268,30 @@ def test_lane_batch_matches_single_designs(grids, thin):
         p.close()
 
 
+def test_batch_of_ema_in_ch_designs(thin):
+    """Equatorial-array designs in a lane batch (odd channel count, 9): equal to the one-shot entry point."""
+    import emagls_amd as E
+    from emagls_amd import Batch, Plan, _lib as L
+    mazs = [np.linspace(0.0, 2 * np.pi, 12, endpoint=False) + 0.1 * (j + 1) for j in range(3)]
+    plans = []
+    for maz in mazs:
+        p = Plan(L.KIND_EMA_CH, "complex", 4, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], 0.042, 12)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(maz)
+        p.set_hrirs(thin["hL"], thin["hR"])
+        plans.append(p)
+    b = Batch(plans)
+    for it in range(2):
+        b.execute()
+        res = b.get_filters()
+    for (wL, wR), maz in zip(res, mazs):
+        sL, sR = E.getEMagLsFiltersEMAinCH(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, 4, 48000.0, 128, "complex")
+        assert wL.shape == (128, 9) and rel(wL, sL) < 1e-12 and rel(wR, sR) < 1e-12
+    b.close()
+    for p in plans:
+        p.close()
+
+
 @pytest.mark.parametrize("mode", ["launch_per_bin", "persistent_write_through"])
 def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
     """The phase sweep has three forms: the persistent launch with XCD-local granule stores (default when all
