@@ -172,7 +172,7 @@ def main():
 
     def make_plan(seed_offset, streams=1):
         azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=seed_offset)
-        p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 512, hL.shape[0], hL.shape[1], 0.042, 32)
+        p = Plan(L.KIND_EMAGLS, os.environ.get("EMAGLS_BENCH_BASIS", "complex"), 4, 48000.0, 512, hL.shape[0], hL.shape[1], 0.042, 32)
         p.set_streams(streams)
         p.set_hrir_grid(azi, zen)
         p.set_mic_grid(maz, mzn)

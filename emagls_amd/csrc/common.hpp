@@ -1,6 +1,7 @@
 // Shared device/host helpers for the eMagLS HIP library (gfx950 / MI355X only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cmath>
 #include <cstdint>
@@ -100,8 +101,17 @@ struct BatchScope {
 
 #ifdef __HIPCC__
 inline dim3 bgrid(dim3 g) { g.z = (unsigned)batch_ctx().n; return g; }
-template <typename T> __device__ __forceinline__ T* boff(T* p, size_t stride) {
-    return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.z * stride) : p;
+// (byte arithmetic on the pointer itself: a round trip through an integer hides the address space from the compiler and
+// every access through the result becomes a flat_* instruction, which also counts on lgkmcnt and so couples with LDS waits)
+template <typename T> __device__ __forceinline__ T* boffz(T* p, size_t stride, unsigned z) {
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type byte_t;
+    return p ? reinterpret_cast<T*>(reinterpret_cast<byte_t*>(p) + (size_t)z * stride) : p;
+}
+template <typename T> __device__ __forceinline__ T* boff(T* p, size_t stride) { return boffz(p, stride, blockIdx.z); }
+// the integer round trip (flat_* accesses): kept for the factor kernels, whose QR kernel the compiler schedules worse
+// with global_* accesses under its 128-VGPR cap (805 -> 901 us per 8-design launch)
+template <typename T> __device__ __forceinline__ T* boff_flat(T* p, size_t stride, unsigned z) {
+    return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)z * stride) : p;
 }
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ cplx shfl_xor_c(cplx v, int m) { return {__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64)}; }

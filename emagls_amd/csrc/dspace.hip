@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(512) qt_kernel(const T* __restrict__ Yc, int64
     if (c >= C) return;
     const T* y = ys + (size_t)dl * ldq;
     const T* e = E + (int64_t)c * ldE;
+    // (tried: eight masked loads of E in flight per pass instead of this two-term loop: 273 -> 313 us per 8-design launch)
     for (int n = 0; n < nOrders; ++n) {
         const int sb = n * n, se = min(S, (n + 1) * (n + 1));
         T a0 = zero_of<T>(), a1 = zero_of<T>();
@@ -69,14 +70,15 @@ __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT,
                                                        cplx* __restrict__ G, size_t bstride) {
     QT = boff(QT, bstride); bn = boff(bn, bstride); G = boff(G, bstride);
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    cplx* bs = reinterpret_cast<cplx*>(dyn);  // [bins_per_chunk][nOrders]
+    cplx* bs = reinterpret_cast<cplx*>(dyn);  // [bins_per_chunk][NMAX], rows zero padded (branch-free inner loop, see below)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int d = blockIdx.x * DSP_TD + lane;
     const int kb_begin = k0 + blockIdx.y * bins_per_chunk;
     const int kb_end = min(P, kb_begin + bins_per_chunk);
-    for (int idx = threadIdx.x; idx < (kb_end - kb_begin) * nOrders; idx += 256) {
-        const int kb = kb_begin + idx / nOrders;
-        cplx b = bn[(int64_t)kb_begin * nOrders + idx];
+    for (int idx = threadIdx.x; idx < (kb_end - kb_begin) * NMAX; idx += 256) {
+        const int kb = kb_begin + idx / NMAX, n = idx % NMAX;
+        cplx b = mk(0, 0);
+        if (n < nOrders) b = bn[(int64_t)kb * nOrders + n];
         if (kb == P - 1) b.y = 0.0;  // Nyquist: real(Bn)
         bs[idx] = b;
     }
@@ -95,13 +97,17 @@ __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT,
         cplx* g = G + ((int64_t)(kb_begin - k0) * C + ca) * ldD + d;
         const int64_t gstep = (int64_t)C * ldD;
         for (int kb = kb_begin; kb < kb_end; ++kb, g += gstep) {
-            const cplx* b = bs + (size_t)(kb - kb_begin) * nOrders;
+            const cplx* b = bs + (size_t)(kb - kb_begin) * NMAX;
+            cplx bb[NMAX];   // all reads of the row before the first use (a test per order serialises read -> wait -> use)
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) bb[n] = b[n];
             cplx g0 = mk(0, 0), g1 = mk(0, 0), h0 = mk(0, 0), h1 = mk(0, 0);
 #pragma unroll
-            for (int n = 0; n < NMAX; n += 2) {
-                if (n < nOrders) { const cplx bb = b[n]; cfma(g0, bb, qa[n]); cfma(h0, bb, qb[n]); }
-                if (n + 1 < nOrders) { const cplx bb = b[n + 1]; cfma(g1, bb, qa[n + 1]); cfma(h1, bb, qb[n + 1]); }
+            for (int n = 0; n + 1 < NMAX; n += 2) {
+                cfma(g0, bb[n], qa[n]); cfma(h0, bb[n], qb[n]);
+                cfma(g1, bb[n + 1], qa[n + 1]); cfma(h1, bb[n + 1], qb[n + 1]);
             }
+            if (NMAX & 1) { cfma(g0, bb[NMAX - 1], qa[NMAX - 1]); cfma(h0, bb[NMAX - 1], qb[NMAX - 1]); }
             g[0] = g0 + g1;
             if (two) g[4 * ldD] = h0 + h1;
         }
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT,
 // eMagLS2 (channels = microphones, E = Y_mic): QT_c is real as it stands (sh_order < 0: all channels independent).
 // A wave owns one unit (an SH pair, or two independent channels) at a time; lanes = 64 consecutive directions.
 template <int NMAX, bool NT>
-__global__ void __launch_bounds__(256) dspace_g_real_kernel(const cplx* __restrict__ QT, int64_t ldD, const cplx* __restrict__ bn,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) dspace_g_real_kernel(const cplx* __restrict__ QT, int64_t ldD, const cplx* __restrict__ bn,
                                                             int nOrders, int D, int C, int P, int k0, int bins_per_chunk,
                                                             cplx* __restrict__ G, int sh_order, size_t bstride) {
     QT = boff(QT, bstride); bn = boff(bn, bstride); G = boff(G, bstride);
@@ -128,9 +134,12 @@ __global__ void __launch_bounds__(256) dspace_g_real_kernel(const cplx* __restri
     const int d = blockIdx.x * DSP_TD + lane;
     const int kb_begin = k0 + blockIdx.y * bins_per_chunk;
     const int kb_end = min(P, kb_begin + bins_per_chunk);
-    for (int idx = threadIdx.x; idx < (kb_end - kb_begin) * nOrders; idx += 256) {
-        const int kb = kb_begin + idx / nOrders;
-        cplx b = bn[(int64_t)kb_begin * nOrders + idx];
+    // rows padded to NMAX orders with zeros: the inner loop below is branch-free (a test per order made every LDS read
+    // wait for its use: 1590 cycles per bin and unit instead of the 320 of its 80 FMAs)
+    for (int idx = threadIdx.x; idx < (kb_end - kb_begin) * NMAX; idx += 256) {
+        const int kb = kb_begin + idx / NMAX, n = idx % NMAX;
+        cplx b = mk(0, 0);
+        if (n < nOrders) b = bn[(int64_t)kb * nOrders + n];
         if (kb == P - 1) b.y = 0.0;  // Nyquist: real(Bn)
         bs[idx] = b;
     }
@@ -169,12 +178,19 @@ __global__ void __launch_bounds__(256) dspace_g_real_kernel(const cplx* __restri
         cplx* ga_p = G + ((int64_t)(kb_begin - k0) * C + ca) * ldD + d;
         const int64_t boffs = ((int64_t)cb2 - ca) * ldD, gstep = (int64_t)C * ldD;
         for (int kb = kb_begin; kb < kb_end; ++kb, ga_p += gstep) {
-            const cplx* b = bs + (size_t)(kb - kb_begin) * nOrders;
+            const cplx* b = bs + (size_t)(kb - kb_begin) * NMAX;
+            cplx bb[NMAX];   // every read of the bin's b_n row is issued before the first use (LDS returns in order)
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) bb[n] = b[n];
             double gax = 0.0, gay = 0.0, gbx = 0.0, gby = 0.0, hax = 0.0, hay = 0.0, hbx = 0.0, hby = 0.0;
 #pragma unroll
-            for (int n = 0; n < NMAX; n += 2) {
-                if (n < nOrders) { const cplx bb = b[n]; gax = fma(bb.x, qa[n], gax); gay = fma(bb.y, qa[n], gay); gbx = fma(bb.x, qb[n], gbx); gby = fma(bb.y, qb[n], gby); }
-                if (n + 1 < nOrders) { const cplx bb = b[n + 1]; hax = fma(bb.x, qa[n + 1], hax); hay = fma(bb.y, qa[n + 1], hay); hbx = fma(bb.x, qb[n + 1], hbx); hby = fma(bb.y, qb[n + 1], hby); }
+            for (int n = 0; n + 1 < NMAX; n += 2) {   // (orders beyond nOrders: b = 0 and q = 0)
+                gax = fma(bb[n].x, qa[n], gax); gay = fma(bb[n].y, qa[n], gay); gbx = fma(bb[n].x, qb[n], gbx); gby = fma(bb[n].y, qb[n], gby);
+                hax = fma(bb[n + 1].x, qa[n + 1], hax); hay = fma(bb[n + 1].y, qa[n + 1], hay); hbx = fma(bb[n + 1].x, qb[n + 1], hbx); hby = fma(bb[n + 1].y, qb[n + 1], hby);
+            }
+            if (NMAX & 1) {
+                gax = fma(bb[NMAX - 1].x, qa[NMAX - 1], gax); gay = fma(bb[NMAX - 1].y, qa[NMAX - 1], gay);
+                gbx = fma(bb[NMAX - 1].x, qb[NMAX - 1], gbx); gby = fma(bb[NMAX - 1].y, qb[NMAX - 1], gby);
             }
             const double ax = gax + hax, ay = gay + hay, bx = gbx + hbx, by = gby + hby;
             cplx o0, o1;
@@ -281,9 +297,10 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
     if (nbins <= 0) return;
     if (nOrders > DSP_NMAX) throw Error(2, "dspace: simulation order above 31 is not supported in this build");
     int chunks = 8;
-    while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nOrders > 56 * 1024) ++chunks;  // b_n table of a chunk in LDS
+    const int nmax = nOrders <= 20 ? 20 : DSP_NMAX;
+    while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nmax > 56 * 1024) ++chunks;  // b_n table of a chunk in LDS
     const int bpc = (nbins + chunks - 1) / chunks;
-    const size_t dyn = sizeof(cplx) * (size_t)bpc * nOrders;
+    const size_t dyn = sizeof(cplx) * (size_t)bpc * nmax;
     const dim3 grid((unsigned)ceil_div(D, DSP_TD), chunks);
     if (nOrders <= 20)
         dspace_g_kernel<T, 20><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
@@ -294,20 +311,20 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
                      hipStream_t st, int real_mode, int sh_order) {
     if (is_cplx && real_mode && nOrders <= DSP_NMAX && C <= 64 && P - k0 > 0) {
-        int chunks = 16;   // measured: 4 -> 780, 8 -> 610, 16 -> 560, 32 -> 690 us (mean over single and batched launches)
+        int chunks = 8;    // 8-design launch: 2 -> 929, 4 -> 896, 8 -> 894, 12 -> 1032, 16 -> 1115, 24 -> 1385 us (every chunk re-reads QT)
         if (const char* e = getenv("EMAGLS_DSP_CHUNKS")) chunks = std::max(1, atoi(e));
         static const bool nt = [] { const char* e = getenv("EMAGLS_DSP_NT"); return !(e && e[0] == '0'); }();  // streaming stores
         const int nbins = P - k0;
-        while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nOrders > 56 * 1024) ++chunks;
+        const int nmax = nOrders <= 12 ? 12 : nOrders <= 20 ? 20 : DSP_NMAX;   // orders held in registers (table rows padded to it)
+        while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nmax > 56 * 1024) ++chunks;
         const int bpc = (nbins + chunks - 1) / chunks;
-        const size_t dyn = sizeof(cplx) * (size_t)bpc * nOrders;
+        const size_t dyn = sizeof(cplx) * (size_t)bpc * nmax;
         const dim3 grid((unsigned)ceil_div(D, DSP_TD), chunks);
-        if (nOrders <= 20 && nt)
-            dspace_g_real_kernel<20, true><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
-        else if (nOrders <= 20)
-            dspace_g_real_kernel<20, false><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
-        else
-            dspace_g_real_kernel<DSP_NMAX, false><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride);
+#define EMAGLS_DSPR(NM, NTS) dspace_g_real_kernel<NM, NTS><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride)
+        if (nmax == 12) { if (nt) EMAGLS_DSPR(12, true); else EMAGLS_DSPR(12, false); }
+        else if (nmax == 20) { if (nt) EMAGLS_DSPR(20, true); else EMAGLS_DSPR(20, false); }
+        else EMAGLS_DSPR(DSP_NMAX, false);
+#undef EMAGLS_DSPR
         KERNEL_CHECK();
         return;
     }

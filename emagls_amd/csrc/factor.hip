@@ -17,15 +17,16 @@
 
 namespace emagls {
 
-// batches: shift every pointer of the argument block to the design blockIdx.z
-__device__ __forceinline__ void batch_offset(FactorArgs& a, size_t bstride) {
-    a.Tn = boff(a.Tn, bstride); a.bn = boff(a.bn, bstride); a.Xd = boff(a.Xd, bstride);
-    a.Z = boff(a.Z, bstride); a.Bk = boff(a.Bk, bstride); a.Vws = boff(a.Vws, bstride); a.sv = boff(a.sv, bstride);
-    a.Hq = boff(a.Hq, bstride); a.cond_ok = boff(a.cond_ok, bstride); a.W = boff(a.W, bstride); a.sweeps_out = boff(a.sweeps_out, bstride);
-    a.route = boff(a.route, bstride); a.status = boff(a.status, bstride);
-    a.tauw = boff(a.tauw, bstride); a.R2w = boff(a.R2w, bstride); a.Nw = boff(a.Nw, bstride); a.Mw = boff(a.Mw, bstride);
+// batches: shift every pointer of the argument block to design z
+__device__ __forceinline__ void batch_offset(FactorArgs& a, size_t bstride, unsigned z) {
+    a.Tn = boff_flat(a.Tn, bstride, z); a.bn = boff_flat(a.bn, bstride, z); a.Xd = boff_flat(a.Xd, bstride, z);
+    a.Z = boff_flat(a.Z, bstride, z); a.Bk = boff_flat(a.Bk, bstride, z); a.Vws = boff_flat(a.Vws, bstride, z); a.sv = boff_flat(a.sv, bstride, z);
+    a.Hq = boff_flat(a.Hq, bstride, z); a.cond_ok = boff_flat(a.cond_ok, bstride, z); a.W = boff_flat(a.W, bstride, z); a.sweeps_out = boff_flat(a.sweeps_out, bstride, z);
+    a.route = boff_flat(a.route, bstride, z); a.status = boff_flat(a.status, bstride, z);
+    a.tauw = boff_flat(a.tauw, bstride, z); a.R2w = boff_flat(a.R2w, bstride, z); a.Nw = boff_flat(a.Nw, bstride, z); a.Mw = boff_flat(a.Mw, bstride, z);
 }
 
+__device__ __forceinline__ void batch_offset(FactorArgs& a, size_t bstride) { batch_offset(a, bstride, blockIdx.z); }
 
 constexpr int CPMAX = 32;  // max (even-padded) column count
 
@@ -34,7 +35,10 @@ constexpr int CPMAX = 32;  // max (even-padded) column count
 // =============================================================================================
 template <typename TT, int NCH, int RPT, int MAXT>
 __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bstride) {
-    batch_offset(a, bstride);
+    // (tried: flattened index split as (design = L mod n, bin = L / n) so that a design's workgroups share one XCD and its
+    // T_n stays in that L2: no measurable change, 859 vs 869 us per 8-design launch with +-40 us between launches)
+    const unsigned bl_z = blockIdx.z, bl_x = blockIdx.x;
+    batch_offset(a, bstride, bl_z);
     __shared__ __attribute__((aligned(16))) cplx bns[96];
     __shared__ cplx alpha_s[CPMAX];
     __shared__ double tau_s[CPMAX];
@@ -44,7 +48,7 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
     const int tid = threadIdx.x;
     const int c = tid / NCH, ch = tid % NCH;
     const int S = a.S, C = a.C, ldS = a.ldS;
-    const int kb = a.kb0 + blockIdx.x;
+    const int kb = a.kb0 + (int)bl_x;
     const bool active = c < C;
 
     cplx B[RPT];
@@ -57,6 +61,9 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
         }
         __syncthreads();
         const TT* Tn = reinterpret_cast<const TT*>(a.Tn);
+        // (tried: a uniform start order per row group with four independent masked loads in flight per pass instead of
+        // this load -> wait -> FMA loop: 960 vs 870 us per 8-design launch -- the kernel sits at its 128-VGPR cap, the wider
+        // loop spills, and lanes masked by their own start order fetch fewer lines of the 1.6 MB T_n stream per workgroup)
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int s = ch + NCH * i;
@@ -134,7 +141,7 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
             }
             __syncthreads();
         }
-        cplx* A = a.R2w + (int64_t)blockIdx.x * C * C;   // full Hermitian matrix, row major
+        cplx* A = a.R2w + (int64_t)bl_x * C * C;   // full Hermitian matrix, row major
         auto put = [&](int r, int cc, cplx v) {
             if (r < C && cc < C) { A[(int64_t)r * C + cc] = v; A[(int64_t)cc * C + r] = conj(v); }
         };
@@ -154,7 +161,7 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
     // from its freshly updated column (look-ahead), so the pivot computation never leaves the other groups waiting.
     // The pivot arithmetic (norm, phase, tau) uses the reciprocal / rsqrt seeds + Newton steps instead of the
     // library sqrt, hypot and divisions: it sits on the critical path of all 25 steps.
-    cplx* Vw = a.Vws + (int64_t)blockIdx.x * C * ldS;
+    cplx* Vw = a.Vws + (int64_t)bl_x * C * ldS;
     auto make_reflector = [&](int j) {  // executed by the lane group c == j on its own column
         cplx* vb = vbuf + (size_t)(j & 1) * ldS;
         double n2 = 0.0;
@@ -215,7 +222,7 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
     }
     // ------------------------------------------------------------------ 3. hand R2 and tau to the SVD kernel
     if (active) {
-        cplx* R2 = a.R2w + (int64_t)blockIdx.x * C * C;
+        cplx* R2 = a.R2w + (int64_t)bl_x * C * C;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int s = ch + NCH * i;
@@ -223,7 +230,7 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
         }
         if (ch == 0) {
             R2[(int64_t)c * C + c] = alpha_s[c];
-            a.tauw[(int64_t)blockIdx.x * C + c] = tau_s[c];
+            a.tauw[(int64_t)bl_x * C + c] = tau_s[c];
         }
     }
 }
@@ -627,8 +634,9 @@ static void dispatch(const FactorArgs& a, int nbins, hipStream_t st, int phases)
 }
 
 // phases: 1 = QR + Jacobi, 2 = back-transform (+ least-squares bins), 3 = both
-void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st, int phases) {
+void launch_factor(const FactorArgs& a0, int nbins, bool tn_cplx, hipStream_t st, int phases) {
     if (nbins <= 0) return;
+    const FactorArgs& a = a0;
     if (a.Tn && !tn_cplx) dispatch<double>(a, nbins, st, phases); else dispatch<cplx>(a, nbins, st, phases);
 }
 
