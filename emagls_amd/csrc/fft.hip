@@ -32,21 +32,35 @@ __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev
 // in-place radix-2 DIT on `nt` transforms laid out buf[t*nfft + i] (input already bit-reversed).
 // tws[j] = exp(-2 pi i j/nfft) for j < nfft/2 in LDS.  INVERSE uses conj twiddles (no scaling).
 template <bool INVERSE>
-__device__ __forceinline__ void lds_fft_stages(cplx* buf, const cplx* tws, int nfft, int log2n, int nt) {
-    const int half_n = nfft >> 1;
-    for (int s = 0; s < log2n; ++s) {
+__device__ __forceinline__ void lds_fft_stages(cplx* buf, const cplx* tws, int nfft, int log2n, int nt, int s_begin = 0) {
+    const int half_n = nfft >> 1, lh = log2n - 1;
+    const int total = nt * half_n;
+    for (int s = s_begin; s < log2n; ++s) {
         const int half = 1 << s;
         const int tstep = nfft >> (s + 1);
-        for (int b = threadIdx.x; b < nt * half_n; b += blockDim.x) {
-            const int t = b / half_n, bb = b - t * half_n;
-            const int pos = bb & (half - 1);
-            const int i0 = ((bb >> s) << (s + 1)) + pos;
-            cplx w = tws[pos * tstep];
-            if (INVERSE) w.y = -w.y;
-            cplx* x = buf + (size_t)t * nfft;
-            const cplx a = x[i0], c = x[i0 + half] * w;
-            x[i0] = a + c;
-            x[i0 + half] = a - c;
+        // four butterflies per pass: their seven LDS reads are issued before the first use
+        for (int b0 = threadIdx.x; b0 < total; b0 += 4 * blockDim.x) {
+            cplx a[4], c[4], w[4];
+            int i0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = min(b0 + u * (int)blockDim.x, total - 1);   // (clamped: the surplus lanes recompute a butterfly, unstored)
+                const int t = b >> lh, bb = b & (half_n - 1);
+                const int pos = bb & (half - 1);
+                i0[u] = (t << log2n) + ((bb >> s) << (s + 1)) + pos;
+                w[u] = tws[pos * tstep];
+                a[u] = buf[i0[u]];
+                c[u] = buf[i0[u] + half];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (b0 + u * (int)blockDim.x < total) {
+                    if (INVERSE) w[u].y = -w[u].y;
+                    const cplx cw = c[u] * w[u];
+                    buf[i0[u]] = a[u] + cw;
+                    buf[i0[u] + half] = a[u] - cw;
+                }
+            }
         }
         __syncthreads();
     }
@@ -155,18 +169,24 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
             phs[j] = mk(cs, sn);
         }
     }
+    // Zero padding (mode 0, no circular shift): with L * 2^z <= nfft only every 2^z-th entry of the bit-reversed input is
+    // non-zero, and the first z radix-2 stages turn each group of 2^z entries into copies of its first one.  The buffer is
+    // filled with that state directly and the transform starts at stage z (3 of 10 stages at 128 taps, nfft 1024).
+    int zskip = 0;
+    if (mode == 0) while (zskip < log2n && (L << (zskip + 1)) <= (int64_t)nfft) ++zskip;
     for (int idx = threadIdx.x; idx < nt * nfft; idx += blockDim.x) {
-        const int t = idx / nfft, n = idx - t * nfft;
+        const int t = idx >> log2n, j = idx & (nfft - 1);
+        const int n = (int)bitrev((unsigned)(j & ~((1 << zskip) - 1)), log2n);
         // circshift(h, -s): out[n] = h[(n + s) mod nfft]; zero beyond the L recorded taps
         int nl = (n + sL) % nfft; if (nl < 0) nl += nfft;
         int nr = (n + sR) % nfft; if (nr < 0) nr += nfft;
         const int64_t dsrc = didx ? didx[d0 + t] : d0 + t;  // optional gather of matched directions
         const double a = (nl < L) ? hL[dsrc * L + nl] : 0.0;
         const double c = (nr < L) ? hR[dsrc * L + nr] : 0.0;
-        buf[(size_t)t * nfft + bitrev((unsigned)n, log2n)] = mk(a, c);
+        buf[(size_t)t * nfft + j] = mk(a, c);
     }
     __syncthreads();
-    lds_fft_stages<false>(buf, tws, nfft, log2n, nt);
+    lds_fft_stages<false>(buf, tws, nfft, log2n, nt, zskip);
     // unpack ears, apply delay phase, write transposed (bin-major, directions contiguous)
     for (int idx = threadIdx.x; idx < P * TD; idx += blockDim.x) {
         const int kb = idx / TD, t = idx - kb * TD;
