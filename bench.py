@@ -139,9 +139,9 @@ def sh_basis_roofline(lib):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--concurrent", type=int, default=int(os.environ.get("EMAGLS_BENCH_CONCURRENT", "16")),
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=96)
+    ap.add_argument("--concurrent", type=int, default=int(os.environ.get("EMAGLS_BENCH_CONCURRENT", "32")),
                     help="independent designs in flight per GPU (steps are processed in groups of this size)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", "8")),
                     help="designs per batch: the sequential sweep is launched once per bin for the whole batch")
@@ -164,11 +164,12 @@ def main():
     from emagls_amd import Batch, Plan, _lib as L
     lib = L.load()
     L.check(lib.emagls_set_device(local_rank))
-    J = max(1, args.concurrent)
+    K, W = args.steps, args.warmup
+    J = max(1, min(args.concurrent, K))   # never more designs in flight than the timed region holds
     Bsz = max(1, min(args.batch, J, 8))
     nbatch = max(1, J // Bsz)
     J = nbatch * Bsz
-    K, W = args.steps, args.warmup
+    W = max(W, 3 * J)   # every batch needs its eager, capturing and first replayed execute before the timed region
 
     def make_plan(seed_offset, streams=1):
         azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=seed_offset)
@@ -245,7 +246,7 @@ def main():
                         p.synchronize()
                     s += 1
 
-    run_steps(3 * J, False)  # first execute is eager, the second captures the hipGraph, the third replays it
+    run_steps(W, False)  # first execute is eager, the second captures the hipGraph, the third replays it
     if world > 1:  # warm the collective too
         dist.gather(out, gathered, dst=0)
     # ---- timed region: K designs + one gather (hipGraph replays; two HIP events bracket each batch's sweep launch)

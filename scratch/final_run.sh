@@ -1,7 +1,8 @@
 #!/bin/bash
 # end-of-round evidence: tests, smoke, bench line, kernel stats (single design and batch), PMC traffic passes
 R=$GRAFT_REPO_ROOT; cd $R
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/final_tests.log
+python -m pytest tests -m gpu -q -rP > gpurun_out/final_tests_full.log 2>&1; tail -3 gpurun_out/final_tests_full.log > gpurun_out/final_tests.log
+grep -h "norm_diff=\|rel = \|^case (" gpurun_out/final_tests_full.log > gpurun_out/final_parity.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 2>&1
 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
 export TMPDIR=/tmp; cd /tmp

@@ -59,3 +59,10 @@ o.append(f"\nSum: {tot:.0f} us per batch of 8 = {tot / 8:.0f} us per design (ker
 open(os.path.join(R, "profiles/r01_d_batch_kernel_stats.md"), "w").write("\n".join(o) + "\n")
 import shutil; shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(R, "profiles/r01_bench.json"))
 print("\n".join(o[6:26])); print(o[-1]); print(j["sweep_persist_kernel"], j["dspace_g_real_kernel"])
+# parity report lines printed by the GPU tests (reference assertAllClose metrics and relative errors)
+pl = os.path.join(G, "final_parity.log")
+if os.path.exists(pl):
+    lines = open(pl).read().strip().splitlines()
+    tests = open(os.path.join(G, "final_tests.log")).read().strip().splitlines()[-1]
+    open(os.path.join(R, "profiles/r01_parity.md"), "w").write(
+        "# Round 1 GPU parity report (python -m pytest tests -m gpu -q -rP on the MI355X box)\n\n" + tests + "\n\n```\n" + "\n".join(lines) + "\n```\n")
