@@ -44,7 +44,9 @@ struct emagls_plan {
     std::shared_ptr<Arena> arena;  // set when a batch moved the buffers into its arena (they are not freed one by one then)
     int64_t total_bytes = 0;
     // derived constants
-    bool cplx_basis = false;
+    bool cplx_basis = false;      // element type of the internal SH machinery
+    bool req_cplx = false;        // shDefinition == 'complex' was requested
+    bool real_internal = false;   // complex request served by the real-arithmetic pipeline + a unitary channel transform
     int nfft = 0, P = 0, k_cut = 0, kcut0 = 0;
     int simOrder = 0, S = 0, C = 0, ldS = 0, nOut = 0;
     int64_t D = 0, ldD = 0, Dpad = 0, Dm = 0;  // Dm: matched direction count (FROM_ATF)
@@ -213,7 +215,15 @@ void plan_setup(emagls_plan& p) {
     if (const char* ng = getenv("EMAGLS_NO_GRAPH")) p.use_graph = !(ng[0] == '1');
     for (auto& st : p.side) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     if (const char* ns = getenv("EMAGLS_STREAMS")) p.nstreams = std::max(1, std::min(3, atoi(ns)));
-    p.cplx_basis = d.basis == EMAGLS_BASIS_COMPLEX;
+    p.req_cplx = d.basis == EMAGLS_BASIS_COMPLEX;
+    // Complex-basis eMagLS / eMagLS2 designs run in real arithmetic.  With Y_c = Y_r T (T unitary, block diagonal per order)
+    // smair_c = T_N^H smair_r T and pwGrid_c = T_N^H pwGrid_r, hence Y_reg_inv_c = Y_reg_inv_r T_N, the angles
+    // W(k-1,:) pwGrid are the same and W_c(k,:) = W_r(k,:) T_N for every solved bin (lib/getEMagLsFilters.m:87-103); the DC
+    // rule and the SH conjugate rule (:109-118) act on W_c and stay in the epilogue.  eMagLS2 is basis free (T cancels).
+    // The real pipeline has a 3x cheaper Gram and half the bytes in T_n and QT: 1460 vs 1295 sets/s at config 3.
+    p.real_internal = p.req_cplx && (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2);
+    if (const char* e = getenv("EMAGLS_REAL_INTERNAL")) if (e[0] == '0') p.real_internal = false;
+    p.cplx_basis = p.req_cplx && !p.real_internal;
     p.D = d.ndirs;
     p.ldD = round_up(p.D, 64);
     const bool cb = p.cplx_basis;
@@ -320,6 +330,10 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Hq", sizeof(cplx) * (size_t)2 * std::max(p.kcut0, 1) * p.ldS);
         p.alloc("route", sizeof(int) * (size_t)p.P);
         p.alloc("Hyp", sizeof(cplx) * hy_workspace_elems(2 * std::max(p.kcut0, 1), p.ldS));
+        if (!cb) {   // complex copies of R and of its diagonal-block inverses (row solves of complex rows in the real basis)
+            p.alloc("Rc", sizeof(cplx) * (size_t)p.S * p.S);
+            p.alloc("Rinvc", sizeof(cplx) * (size_t)ceil_div(p.S, 32) * 32 * 32);
+        }
         p.alloc("Z", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
         p.alloc("Bk", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
         p.alloc("Vws", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
@@ -382,7 +396,7 @@ void plan_setup(emagls_plan& p) {
         p.out_rows = d.len;
     }
     p.out_cols = p.C;
-    p.out_cplx = cb && d.kind != EMAGLS_KIND_FROM_ATF;
+    p.out_cplx = p.req_cplx && d.kind != EMAGLS_KIND_FROM_ATF;
     p.alloc("wL", (p.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p.out_rows * p.out_cols);
     p.alloc("wR", (p.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p.out_rows * p.out_cols);
     HIP_CHECK(hipStreamSynchronize(p.stream));
@@ -506,7 +520,7 @@ int emagls_gram_from(const emagls_plan& p) {
     const int from = std::max(std::max(kb, p.kcut0), 1);
     return from < p.P ? from : 0;
 }
-bool emagls_needs_q(const emagls_plan& p) { return !p.cplx_basis || p.sweep_factored; }
+bool emagls_needs_q(const emagls_plan& p) { return p.sweep_factored; }
 
 void emagls_pre_sweep(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
@@ -595,8 +609,10 @@ void emagls_pre_sweep(emagls_plan& p) {
         launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, cb, p.get("Q"), s2);
         launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Q"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, s2);
     } else {
-        launch_hy_conj(p.get("Hc"), p.ldD, 2 * ls_end, p.get("Yc"), p.ldS, (int)p.D, p.S, p.get("Hyp"), p.get("Hq"), p.ldS, s2);
-        launch_qform(p.get("Hq"), p.get("R"), p.get("Rinv"), p.S, 2 * (int64_t)ls_end, p.ldS, cb, p.get("Hq"), s2);
+        // (real basis: the rows are complex all the same, so R is widened to a complex copy for the row solves)
+        if (!cb) launch_widen(p.get("R"), p.S, false, p.get("Rc"), p.S, p.S, p.S, false, /*upper_only=*/true, s2);
+        launch_hy_conj(p.get("Hc"), p.ldD, 2 * ls_end, p.get("Yc"), p.ldS, cb, (int)p.D, p.S, p.get("Hyp"), p.get("Hq"), p.ldS, s2);
+        launch_qform(p.get("Hq"), p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.S, 2 * (int64_t)ls_end, p.ldS, true, p.get("Hq"), s2);
     }
 
     // s0: T_n, per-bin QR + Jacobi
@@ -642,7 +658,8 @@ void emagls_pre_sweep(emagls_plan& p) {
             launch_yri_accurate(p.get("Q"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
                                 p.get("Yri"), p.ldD, s0);
         } else {  // conj(Q) Z_k = conj(Yc) (Z_k R^-H): the flagged bins' Z rows are solved in place first
-            launch_zsolve_flagged(p.get("Z"), p.ldS, p.get("R"), p.get("Rinv"), p.get<double>("cond_ok"), p.S, p.C, p.P, k0, s0);
+            launch_zsolve_flagged(p.get("Z"), p.ldS, p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.get<double>("cond_ok"), p.S, p.C,
+                                  p.P, k0, s0);
             launch_yri_accurate(p.get("Yc"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
                                 p.get("Yri"), p.ldD, s0);
         }
@@ -766,7 +783,9 @@ void emagls_run_sweep(emagls_plan& p) {
 void emagls_post_sweep(emagls_plan& p) {
     const bool cb = p.cplx_basis;
     const bool raw = p.d.kind == EMAGLS_KIND_EMAGLS2;
-    const int conj_mode = !cb || raw ? 0 : (p.d.kind == EMAGLS_KIND_EMA_CH ? 2 : 1);   // Hermitian mirror / SH rule / CH rule
+    const int conj_mode = !p.req_cplx || raw ? 0 : (p.d.kind == EMAGLS_KIND_EMA_CH ? 2 : 1);   // Hermitian mirror / SH rule / CH rule
+    if (p.real_internal && !raw) launch_sh_rows_to_complex(p.get("W"), p.C, 2 * p.P, (int)p.d.order, p.stream);   // W_c = W_r T_N
+    (void)cb;
     launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"), conj_mode, 1, 0,
                            p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), p.stream);
     p.mark("epilogue");

@@ -74,8 +74,8 @@ void launch_sweep_finalize_multi(const DenseSweepMulti& m, int kb_last, hipStrea
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
 void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
                int kb_hi, void* Hq, int ldS, hipStream_t st, bool store_conj = false);
-void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, int D, int S, void* Pw, void* out, int ldS,
-                    hipStream_t st);
+void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, bool y_cplx, int D, int S, void* Pw, void* out,
+                    int ldS, hipStream_t st);
 size_t hy_workspace_elems(int nrows, int ldS);
 void launch_ypinv(const void* Q, int64_t ldQ, bool q_cplx, const void* Zb, int ldS, int D, int S, int C, void* Ypinv,
                   int64_t ldD, hipStream_t st);
@@ -84,6 +84,8 @@ void launch_ls_apply(const void* Hc, int64_t ldH, int n_c, const void* Zf, bool 
 void launch_ls_filters(const double* hL, const double* hR, int64_t L, int D, const void* Yp, bool cplx_basis, int64_t ldD,
                        int C, void* wL, void* wR, hipStream_t st);
 void launch_conj_copy(const void* in, void* out, int64_t n, bool is_cplx, hipStream_t st);
+// rows of real-SH coefficients -> complex-SH coefficients in place: W_c = W_r T_N (Y_c = Y_r T_N, sh_basis.hip conventions)
+void launch_sh_rows_to_complex(void* W, int C, int nrows, int order, hipStream_t st);
 void launch_widen(const void* in, int64_t ldi, bool in_cplx, void* out, int64_t ldo, int rows, int cols, bool transpose,
                   bool upper_only, hipStream_t st);
 

@@ -163,6 +163,31 @@ void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out
     KERNEL_CHECK();
 }
 
+// Y_c(n,+m) = (-1)^m (Y_r(n,+m) + i Y_r(n,-m)) / sqrt2,  Y_c(n,-m) = (Y_r(n,+m) - i Y_r(n,-m)) / sqrt2  (sh_basis_kernel above),
+// so a row of coefficients transforms the same way: one thread per (row, n, m >= 0), both members of a pair in one thread.
+__global__ void sh_rows_to_complex_kernel(cplx* __restrict__ W, int C, int nrows, int order, size_t bstride) {
+    W = boff(W, bstride);
+    const int S = (order + 1) * (order + 1);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)nrows * S) return;
+    const int r = (int)(idx / S), a = (int)(idx % S);
+    int n = 0;
+    while ((n + 1) * (n + 1) <= a) ++n;
+    const int m = a - n * n - n;
+    if (m <= 0) return;   // m = 0 unchanged; the pair is handled by its +m member
+    cplx* w = W + (int64_t)r * C;
+    const cplx p = w[n * n + n + m], q = w[n * n + n - m];
+    const double r2 = 0.70710678118654752440, sg = (m & 1) ? -r2 : r2;
+    w[n * n + n + m] = mk(sg * (p.x - q.y), sg * (p.y + q.x));   // (-1)^m (p + i q) / sqrt2
+    w[n * n + n - m] = mk(r2 * (p.x + q.y), r2 * (p.y - q.x));   // (p - i q) / sqrt2
+}
+void launch_sh_rows_to_complex(void* W, int C, int nrows, int order, hipStream_t st) {
+    const int64_t n = (int64_t)nrows * (order + 1) * (order + 1);
+    if (n <= 0) return;
+    sh_rows_to_complex_kernel<<<bgrid((unsigned)ceil_div(n, 256)), 256, 0, st>>>((cplx*)W, C, nrows, order, batch_ctx().stride);
+    KERNEL_CHECK();
+}
+
 void launch_sh_coeff(int N, double* tab, hipStream_t st) {
     sh_coeff_kernel<<<bgrid(8), 256, 0, st>>>(N, tab, batch_ctx().stride);
     KERNEL_CHECK();

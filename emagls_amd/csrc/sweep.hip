@@ -734,7 +734,8 @@ __global__ void __launch_bounds__(256) hq_kernel(const cplx* __restrict__ Hc, in
 // The K slices are summed in a fixed order by hy_reduce_kernel (bitwise reproducible), which also conjugates.
 constexpr int HY_RT = 96, HY_CT = 32, HY_DC = 32, HY_KS = 8;
 
-__global__ void __launch_bounds__(256) hy_partial_kernel(const cplx* __restrict__ Hc, int64_t ldD, int nrows, const cplx* __restrict__ Yc,
+template <typename TY>
+__global__ void __launch_bounds__(256) hy_partial_kernel(const cplx* __restrict__ Hc, int64_t ldD, int nrows, const TY* __restrict__ Yc,
                                                          int64_t ldY, int D, int S, cplx* __restrict__ Pw, int ldS, size_t bstride) {
     Hc = boff(Hc, bstride); Yc = boff(Yc, bstride); Pw = boff(Pw, bstride);
     __shared__ __attribute__((aligned(16))) cplx hs[HY_RT][HY_DC + 1];
@@ -759,7 +760,7 @@ __global__ void __launch_bounds__(256) hy_partial_kernel(const cplx* __restrict_
 #pragma unroll
         for (int i = 0; i < (HY_DC * HY_CT) / 256; ++i) {
             const int idx = tid + 256 * i, dd = idx / HY_CT, c = idx % HY_CT;
-            ys[dd][c] = (d0 + dd < dend && s0 + c < S) ? Yc[(int64_t)(d0 + dd) * ldY + s0 + c] : mk(0, 0);
+            ys[dd][c] = (d0 + dd < dend && s0 + c < S) ? to_cplx(Yc[(int64_t)(d0 + dd) * ldY + s0 + c]) : mk(0, 0);
         }
         __syncthreads();
 #pragma unroll 4
@@ -799,12 +800,16 @@ __global__ void __launch_bounds__(256) hy_reduce_kernel(const cplx* __restrict__
     out[(int64_t)r * ldS + sc] = conj(acc);
 }
 // out[r][s] = conj( sum_d Hc[r][d] conj(Yc[d][s]) ), r < nrows;  Pw: workspace [HY_KS][nrows][ldS]
-void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, int D, int S, void* Pw, void* out, int ldS,
-                    hipStream_t st) {
+void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, bool y_cplx, int D, int S, void* Pw, void* out,
+                    int ldS, hipStream_t st) {
     if (nrows <= 0) return;
     const dim3 grid((unsigned)ceil_div(S, HY_CT), (unsigned)(ceil_div(nrows, HY_RT) * HY_KS));
-    hy_partial_kernel<<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, nrows, (const cplx*)Yc, ldY, D, S, (cplx*)Pw, ldS,
-                                                   batch_ctx().stride);
+    if (y_cplx)
+        hy_partial_kernel<cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, nrows, (const cplx*)Yc, ldY, D, S, (cplx*)Pw, ldS,
+                                                             batch_ctx().stride);
+    else
+        hy_partial_kernel<double><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, nrows, (const double*)Yc, ldY, D, S, (cplx*)Pw, ldS,
+                                                               batch_ctx().stride);
     KERNEL_CHECK();
     hy_reduce_kernel<<<bgrid(dim3((unsigned)ceil_div(S, 256), nrows)), 256, 0, st>>>((const cplx*)Pw, nrows, S, ldS, (cplx*)out,
                                                                                    batch_ctx().stride);

@@ -70,6 +70,25 @@ def test_emagls_filters_thin(grids, thin, basis, length):
     assert report("eMagLS L " + basis, wL, oL) < TOL and report("eMagLS R " + basis, wR, oR) < TOL
 
 
+@pytest.mark.parametrize("fn", ["getEMagLsFilters", "getEMagLs2Filters"])
+def test_complex_basis_pipelines_agree(grids, thin, monkeypatch, fn):
+    """A complex-basis design is served by the real-arithmetic pipeline and a unitary channel transform (W_c = W_r T_N;
+    eMagLS2 is basis free).  The complex-arithmetic pipeline (EMAGLS_REAL_INTERNAL=0) must give the same filters, and both
+    must match the oracle's complex-basis computation."""
+    import emagls_amd as E
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4,
+            48000.0, 128, "complex")
+    rL, rR = getattr(E, fn)(*args)
+    monkeypatch.setenv("EMAGLS_REAL_INTERNAL", "0")
+    cL, cR = getattr(E, fn)(*args)
+    monkeypatch.delenv("EMAGLS_REAL_INTERNAL")
+    oL, oR = getattr(O, fn)(*args)
+    assert rL.dtype == np.complex128 and cL.dtype == np.complex128
+    assert report(fn + " real-internal vs complex pipeline", rL, cL) < 1e-9 and rel(rR, cR) < 1e-9
+    assert report(fn + " complex pipeline vs oracle", cL, oL) < TOL and rel(cR, oR) < TOL
+    assert report(fn + " real-internal vs oracle", rL, oL) < TOL and rel(rR, oR) < TOL
+
+
 @pytest.mark.parametrize("basis", ["real", "complex"])
 def test_emagls2_filters_thin(grids, thin, basis):
     import emagls_amd as E

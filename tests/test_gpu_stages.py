@@ -50,11 +50,18 @@ def test_modal_bn_vs_oracle():
 def emagls_plan(grids, hrirs):
     """config-3 shaped plan (em32, N=4, complex SH) on a thinned grid and 128-tap filters so the
     NumPy cross-checks stay fast; keeps all intermediates on the device."""
+    import os
     from emagls_amd import Plan, _lib as L
     sub = slice(0, 2702, 3)
     hL, hR = hrirs[0][:, sub], hrirs[1][:, sub]
     azi, zen = grids["azi"][sub], grids["zen"][sub]
-    p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, hL.shape[0], hL.shape[1], grids["mic_radius"], 32)
+    # complex-basis designs are normally served by the real-arithmetic pipeline plus a channel transform; the stage checks
+    # below look at the complex pipeline itself (still the path of LS / MagLS / EMAinCH in the complex basis)
+    os.environ["EMAGLS_REAL_INTERNAL"] = "0"
+    try:
+        p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, hL.shape[0], hL.shape[1], grids["mic_radius"], 32)
+    finally:
+        del os.environ["EMAGLS_REAL_INTERNAL"]
     p.set_hrir_grid(azi, zen)
     p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
     p.set_hrirs(hL, hR)
