@@ -310,8 +310,10 @@ def main():
         # the factorised pipeline executes F_exec (per stage in DESIGN.md section 5)
         Kb, Sx = info.num_pos_freqs - 1, info.num_sh_sim
         f_ref = (8.0 * Kb * Cc * Sx * D + 8.0 * Kb * D * Cc * Cc + 8.0 * 2 * Kb * 2 * D * Cc + 8.0 * Kb * D * Cc * Cc) / 1e9
-        f_exec = (8.0 * Sx * Sx * D + 8.0 * Sx ** 3 / 3 + 8.0 * D * Cc * Sx + 80.0 * nbins_swept * Cc * D
-                  + 8.0 * 2 * (info.k_cut - 1) * D * Sx + 8.0 * Kb * Sx * Cc * 10 + 8.0 * nbins_swept * Sx * Cc * (Cc + 1) / 2
+        # (the SH machinery of a complex-basis design runs in real arithmetic: real Gram, Cholesky and order terms at 2 flop
+        # per multiply-add, complex-times-real products at 4, complex-times-complex at 8)
+        f_exec = (2.0 * Sx * Sx * D + 2.0 * Sx ** 3 / 3 + 2.0 * D * Cc * Sx + 80.0 * nbins_swept * Cc * D
+                  + 4.0 * 2 * (info.k_cut - 1) * D * Sx + 4.0 * Kb * Sx * Cc * 10 + 8.0 * nbins_swept * Sx * Cc * (Cc + 1) / 2
                   + 8.0 * nbins_swept * 4 * D * Cc + 5.0 * D * info.nfft * 10) / 1e9
         flops = {"F_ref_gflop_per_set": f_ref, "F_exec_gflop_per_set": f_exec, "exec_tflops": f_exec * world * K / dt / 1e3,
                  "ref_equivalent_tflops": f_ref * world * K / dt / 1e3, "fp64_peak_tflops": 78.6,
