@@ -12,10 +12,10 @@ f = pmc(os.path.join(G, "pmc_fetch2/pmc_results.db"), "FETCH_SIZE")
 w = pmc(os.path.join(G, "pmc_write2/pmc_results.db"), "WRITE_SIZE")
 keys = sorted(set(f) | set(w), key=lambda k: -(f.get(k, (0, 0))[1] + w.get(k, (0, 0))[1]))
 rows = [(k, f.get(k, (0, 0))[0], f.get(k, (0, 0))[1], w.get(k, (0, 0))[1]) for k in keys[:12]]
-note = {'sweep_persist': '535 MB (471 bins x 1.14 MB: G_k 1.08 MB + M_k + |H|)', 'dspace_g_real': '518 MB out, 22 MB in',
-        'sh_basis_kernel<false>': '3.37 GB out (D=2^20, N=19)', 'gram_mfma': '17.6 MB in (conj(Y) once per K split), 41 MB of split-K partials out',
-        'factor_qr_kernel<emagls::cplx, 32, 13': 'Tn 3.6 MB in (L2 resident), reflectors 7 MB out (Householder-route bins only)',
-        'hrir_fft': '5.5 MB in, 24 MB out', 'hy_partial': 'Yc 17.6 MB + Hc 3.7 MB in'}
+note = {'sweep_persist': '535 MB (471 bins x 1.14 MB: G_k 1.08 MB + M_k + |H|)', 'dspace_g': '518 MB out, 11 MB of real order terms in (re-read by each of the 8 bin chunks)',
+        'sh_basis_kernel<false>': '3.37 GB out (D=2^20, N=19)', 'gram_mfma': '8.8 MB in (real conj(Y) once per K split), 20 MB of split-K partials out',
+        'factor_qr_kernel<double, 32, 13': 'Tn 1.8 MB in (real), reflectors 7 MB out (Householder-route bins only)',
+        'hrir_fft': '5.5 MB in, 24 MB out', 'hy_partial': 'Yc 8.8 MB (real) + Hc 3.7 MB in'}
 md = ["# Round 1 PMC counters, end-of-round build (separate rocprofv3 --pmc passes: FETCH_SIZE, then WRITE_SIZE)", "",
       "`rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 8 --warmup 2 --concurrent 1 --batch 1 --no-cpu-baseline` (and the same with WRITE_SIZE).",
       "Values are KB per dispatch as reported; per the MI355X guide FETCH_SIZE under-counts wide coalesced streaming reads by 2x on gfx950 (the `x2` column), WRITE_SIZE is uncalibrated.", "",
@@ -24,11 +24,11 @@ for k, n, fk, wk in rows:
     nt = next((v for kk, v in note.items() if kk in k), '')
     md.append(f"| `{k[:70]}` | {n} | {fk:.1f} | {2 * fk:.1f} | {wk:.1f} | {nt} |")
 open(os.path.join(R, "profiles/r01_pmc_traffic.md"), "w").write("\n".join(md) + "\n")
-sp = next(r for r in rows if 'sweep_persist' in r[0]); dg = next(r for r in rows if 'dspace_g_real' in r[0])
+sp = next(r for r in rows if 'sweep_persist' in r[0]); dg = next(r for r in rows if 'dspace_g' in r[0])
 pj = os.path.join(R, "profiles/pmc_traffic.json")
 j = json.load(open(pj))
 j["sweep_persist_kernel"] = {"fetch_kb": sp[2], "write_kb": sp[3], "bytes": int((2 * sp[2] + sp[3]) * 1024)}
-j["dspace_g_real_kernel"] = {"fetch_kb": dg[2], "write_kb": dg[3], "bytes": int((2 * dg[2] + dg[3]) * 1024)}
+j["dspace_g_kernel"] = {"fetch_kb": dg[2], "write_kb": dg[3], "bytes": int((2 * dg[2] + dg[3]) * 1024)}
 json.dump(j, open(pj, "w"), indent=1)
 # single-design kernel stats
 out = subprocess.run([sys.executable, os.path.join(R, "scratch/prof_md.py"), os.path.join(G, "prof_single/bench_results.db"),
@@ -58,7 +58,7 @@ for k, (c, t) in sorted(agg.items(), key=lambda x: -x[1][1]):
 o.append(f"\nSum: {tot:.0f} us per batch of 8 = {tot / 8:.0f} us per design (kernels back to back on one stream).")
 open(os.path.join(R, "profiles/r01_d_batch_kernel_stats.md"), "w").write("\n".join(o) + "\n")
 import shutil; shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(R, "profiles/r01_bench.json"))
-print("\n".join(o[6:26])); print(o[-1]); print(j["sweep_persist_kernel"], j["dspace_g_real_kernel"])
+print("\n".join(o[6:26])); print(o[-1]); print(j["sweep_persist_kernel"], j["dspace_g_kernel"])
 # parity report lines printed by the GPU tests (reference assertAllClose metrics and relative errors)
 pl = os.path.join(G, "final_parity.log")
 if os.path.exists(pl):
