@@ -141,10 +141,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=96)
-    ap.add_argument("--concurrent", type=int, default=int(os.environ.get("EMAGLS_BENCH_CONCURRENT", "32")),
-                    help="independent designs in flight per GPU (steps are processed in groups of this size)")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", "8")),
-                    help="designs per batch: the sequential sweep is launched once per bin for the whole batch")
+    ap.add_argument("--concurrent", type=int, default=int(os.environ.get("EMAGLS_BENCH_CONCURRENT", "0")),
+                    help="independent designs in flight per GPU (default: up to four batches, sized to the step count)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", "0")),
+                    help="designs per batch (<= 8): one persistent sweep launch covers the whole batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sh-roofline", action="store_true")
     args = ap.parse_args()
@@ -165,9 +165,14 @@ def main():
     lib = L.load()
     L.check(lib.emagls_set_device(local_rank))
     K, W = args.steps, args.warmup
-    J = max(1, min(args.concurrent, K))   # never more designs in flight than the timed region holds
-    Bsz = max(1, min(args.batch, J, 8))
-    nbatch = max(1, J // Bsz)
+    if args.concurrent > 0 or args.batch > 0:
+        J = max(1, min(args.concurrent if args.concurrent > 0 else 32, K))   # never more in flight than the timed region holds
+        Bsz = max(1, min(args.batch if args.batch > 0 else 8, J, 8))
+        nbatch = max(1, J // Bsz)
+    else:
+        # up to four batches of up to eight designs, sized so that a short timed region wastes no design of a batch
+        nbatch = max(1, min(4, -(-K // 8)))
+        Bsz = max(1, min(8, -(-K // nbatch)))
     J = nbatch * Bsz
     W = max(W, 3 * J)   # every batch needs its eager, capturing and first replayed execute before the timed region
 
