@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(256) hy_partial_kernel(const cplx* __restrict_
                                                          int64_t ldY, int D, int S, cplx* __restrict__ Pw, int ldS, size_t bstride) {
     Hc = boff(Hc, bstride); Yc = boff(Yc, bstride); Pw = boff(Pw, bstride);
     __shared__ __attribute__((aligned(16))) cplx hs[HY_RT][HY_DC + 1];
-    __shared__ __attribute__((aligned(16))) cplx ys[HY_DC][HY_CT + 1];
+    __shared__ __attribute__((aligned(16))) TY ys[HY_DC][HY_CT + 1];   // real basis: real tile, 2 FMAs per product
     const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
     const int s0 = blockIdx.x * HY_CT;
     const int rt = blockIdx.y / HY_KS, ks = blockIdx.y % HY_KS;
@@ -760,12 +760,13 @@ __global__ void __launch_bounds__(256) hy_partial_kernel(const cplx* __restrict_
 #pragma unroll
         for (int i = 0; i < (HY_DC * HY_CT) / 256; ++i) {
             const int idx = tid + 256 * i, dd = idx / HY_CT, c = idx % HY_CT;
-            ys[dd][c] = (d0 + dd < dend && s0 + c < S) ? to_cplx(Yc[(int64_t)(d0 + dd) * ldY + s0 + c]) : mk(0, 0);
+            ys[dd][c] = (d0 + dd < dend && s0 + c < S) ? Yc[(int64_t)(d0 + dd) * ldY + s0 + c] : zero_of<TY>();
         }
         __syncthreads();
 #pragma unroll 4
         for (int dd = 0; dd < HY_DC; ++dd) {
-            cplx y[4], h[3];
+            TY y[4];
+            cplx h[3];
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = conj(ys[dd][4 * cg + j]);
 #pragma unroll
