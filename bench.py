@@ -136,6 +136,18 @@ def sh_basis_roofline(lib):
             "ms": best, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
 
 
+def plan_batches(steps, concurrent=0, batch=0):
+    """(number of batches in flight, designs per batch) for a timed region of `steps` designs.  Explicit --concurrent /
+    --batch win; otherwise up to four batches of up to eight designs (a persistent sweep launch covers at most eight),
+    sized so that a short timed region wastes no design of a batch."""
+    if concurrent > 0 or batch > 0:
+        j = max(1, min(concurrent if concurrent > 0 else 32, steps))   # never more in flight than the timed region holds
+        bsz = max(1, min(batch if batch > 0 else 8, j, 8))
+        return max(1, j // bsz), bsz
+    nbatch = max(1, min(4, -(-steps // 8)))
+    return nbatch, max(1, min(8, -(-steps // nbatch)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,14 +177,7 @@ def main():
     lib = L.load()
     L.check(lib.emagls_set_device(local_rank))
     K, W = args.steps, args.warmup
-    if args.concurrent > 0 or args.batch > 0:
-        J = max(1, min(args.concurrent if args.concurrent > 0 else 32, K))   # never more in flight than the timed region holds
-        Bsz = max(1, min(args.batch if args.batch > 0 else 8, J, 8))
-        nbatch = max(1, J // Bsz)
-    else:
-        # up to four batches of up to eight designs, sized so that a short timed region wastes no design of a batch
-        nbatch = max(1, min(4, -(-K // 8)))
-        Bsz = max(1, min(8, -(-K // nbatch)))
+    nbatch, Bsz = plan_batches(K, args.concurrent, args.batch)
     J = nbatch * Bsz
     W = max(W, 3 * J)   # every batch needs its eager, capturing and first replayed execute before the timed region
 
