@@ -466,6 +466,98 @@ def getEMagLsFiltersEMAinCH(hL, hR, aziRad, zenRad, micRadius, micAzi, order, fs
     return out[0], out[1]
 
 
+# --------------------------------------------------------------------------------------------
+# Equatorial microphone arrays in spherical harmonics (second half; GPU path: next round)
+# --------------------------------------------------------------------------------------------
+def getNnm(N, zenRad, harmonicsDef="real"):
+    """dependencies/getNnm.m:10-31: the SHs without their azimuth factor, [(N+1)^2].  MATLAB's legendre() and
+    scipy.special.lpmv() both carry the Condon-Shortley phase."""
+    from scipy.special import lpmv
+    out = np.zeros((N + 1) ** 2)
+    x = math.cos(zenRad)
+    for nn in range(N + 1):
+        for mm in range(-nn, nn + 1):
+            am = abs(mm)
+            Pn = float(lpmv(am, nn, x))
+            if harmonicsDef == "complex":
+                Pnm = (-1) ** am * math.factorial(nn - am) / math.factorial(nn + am) * Pn if mm < 0 else Pn
+                v = math.sqrt((2 * nn + 1) * math.factorial(nn - mm) / (4 * math.pi * math.factorial(nn + mm))) * Pnm
+            else:
+                v = (-1) ** mm * math.sqrt((2 * nn + 1) * math.factorial(nn - am) / (4 * math.pi * math.factorial(nn + am))) * Pn
+            out[nn * nn + nn + mm] = v
+    return out
+
+
+def getChToShExpansionMatrix(order, harmonicsDef="real"):
+    """dependencies/getChToShExpansionMatrix.m:11-18: [(N+1)^2 x 2N+1], circular -> equatorial spherical harmonics."""
+    J = np.zeros(((order + 1) ** 2, 2 * order + 1))
+    Nnm = getNnm(order, math.pi / 2, harmonicsDef)
+    for n in range(order + 1):
+        for m in range(-n, n + 1):
+            J[n * n + n + m, 2 * abs(m) - (1 if m < 0 else 0)] = Nnm[n * n + n + m]
+    return J
+
+
+def shRotationForElevation(aziRad, zenRad, order, shDefinition="real"):
+    """The matrix lib/getEMagLsFiltersEMAinSH.m:96-98 multiplies a ROW of SH coefficients with: rotate to the front,
+    tilt to the elevation pi/2 - zen, rotate back to the azimuth -- i.e. the rotation about the horizontal axis
+    perpendicular to the azimuth that carries the direction (azi, pi/2) to (azi, zen).
+    Third party and un-vendored (polarch euler2rotationMatrix + getSHrotMtx): restated from this stated intent, NOT from the
+    library's code, so its sign conventions are pinned only by the physics test in tests/test_oracle_kats.py
+    (the coefficients of a horizontal plane wave become those of the elevated one).  Parity unpinned.
+    With f'(x) = f(R^-1 x) and Y_i(R^-1 x) = sum_j D_ij Y_j(x) the coefficient row transforms as c' = c D; D is obtained by
+    least squares on a point set that resolves order N exactly."""
+    a = float(aziRad)
+    alpha = math.pi / 2 - float(zenRad)                      # elevation
+    ax = np.array([math.sin(a), -math.cos(a), 0.0])         # right-hand rotation about it lifts (azi, pi/2) upwards
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + math.sin(alpha) * K + (1 - math.cos(alpha)) * (K @ K)
+    n = 4 * (order + 1) ** 2 + 8
+    i = np.arange(n) + 0.5
+    zen = np.arccos(1 - 2 * i / n)
+    azi = np.mod(np.pi * (1 + 5 ** 0.5) * i, 2 * np.pi)
+    X = np.column_stack([np.sin(zen) * np.cos(azi), np.sin(zen) * np.sin(azi), np.cos(zen)])
+    Xr = X @ R                                              # rows: R^-1 x_p = R^T x_p
+    azr, znr = np.arctan2(Xr[:, 1], Xr[:, 0]), np.arccos(np.clip(Xr[:, 2], -1, 1))
+    A = getSH(order, np.column_stack([azr, znr]), shDefinition)     # Y_i(R^-1 x_p)
+    B = getSH(order, np.column_stack([azi, zen]), shDefinition)     # Y_j(x_p)
+    return (pinv(B) @ A).T
+
+
+def getEMagLsFiltersEMAinSH(hL, hR, aziRad, zenRad, micRadius, micAzi, order, fs, length, shDefinition="real"):
+    """lib/getEMagLsFiltersEMAinSH.m:32-180: eMagLS for an equatorial array with the output in spherical harmonics
+    (3-DOF head rotation).  Horizontal plane waves on the array (:66-69), circular -> spherical harmonics without radial
+    filters (:77-82), per-direction SH rotation to the HRIR elevation (:85-100), the common per-bin loop (:118-139).
+    See shRotationForElevation for the one un-vendored convention.  Parity unpinned."""
+    assert length >= hL.shape[0], "len too short"
+    nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
+    aziRad = np.asarray(aziRad, dtype=float).reshape(-1)
+    zenRad = np.asarray(zenRad, dtype=float).reshape(-1)
+    micAzi = np.asarray(micAzi, dtype=float).reshape(-1)
+    micGrid = np.column_stack([micAzi, np.full(micAzi.size, np.pi / 2)])
+    ema, simOrder = getSMAIRMatrix(order, fs, nfft, micRadius, micGrid, shDefinition, returnRawMicSigs=True)
+    Y_hor_conj = getSH(simOrder, np.column_stack([aziRad, np.full(aziRad.size, np.pi / 2)]), shDefinition).conj().T
+    C = (order + 1) ** 2
+    D = aziRad.size
+    F = pinv(getCH(order, micAzi, shDefinition).T) @ getChToShExpansionMatrix(order, shDefinition).T   # [M x C]
+    rot = [None if zenRad[d] == np.pi / 2 else shRotationForElevation(aziRad[d], zenRad[d], order, shDefinition) for d in range(D)]
+    is_real = np.isrealobj(Y_hor_conj)
+
+    def pw_of_k(k):
+        emaDir = ema[:, :, k - 1] @ Y_hor_conj            # [M x D]
+        sh = emaDir.T @ F                                  # row d: emaIrDir(k, :, d) * pinv(YCh.') * J.'
+        for d in range(D):
+            if rot[d] is not None:
+                sh[d] = sh[d] @ rot[d]
+        return sh.T                                        # pwGridAll(:, :, k)  [C x D]
+
+    HL, HR, gL, gR = _hrir_prologue(hL, hR, nfft, P)
+    W_l, W_r = _emagls_core(HL, HR, pw_of_k, P, k_cut, C)
+    n_shift = nfft // 2
+    wL, wR = _finish(W_l, W_r, P, nfft, length, is_real, n_shift, n_shift + gR - gL)
+    return (wL.real, wR.real) if is_real else (wL, wR)
+
+
 def _sph2cart_unit(aziZen):
     azi, zen = aziZen[:, 0], aziZen[:, 1]
     ele = np.pi / 2 - zen

@@ -290,3 +290,33 @@ def test_ch_basis_and_ema_in_ch_equivariance(grids, hrirs):
     a = wr @ np.linalg.inv(U)
     d = np.abs(a - wc).max(axis=0) / np.abs(wc).max()
     assert d.max() < 5e-2 and d[0] < 1e-9
+
+
+def test_ema_in_sh_building_blocks(grids, hrirs):
+    """Oracle pieces of getEMagLsFiltersEMAinSH (GPU path: next round).  The circular-to-spherical expansion reproduces the
+    SHs on the equator exactly (dependencies/getChToShExpansionMatrix.m, getNnm.m); the per-direction SH rotation -- the one
+    un-vendored convention -- is pinned by physics: it is unitary and carries the coefficient row of a plane wave from
+    (azi, pi/2) to that of the wave from (azi, zen)."""
+    az = np.array([0.3, 1.1, 4.0, 5.9])
+    eq = np.column_stack([az, np.full(az.size, np.pi / 2)])
+    for basis in ("real", "complex"):
+        J = O.getChToShExpansionMatrix(4, basis)
+        assert np.abs(O.getSH(4, eq, basis) - O.getCH(4, az, basis) @ J.T).max() < 1e-14
+        for azi, zen in ((0.7, 1.0), (2.9, 2.2), (5.5, 0.3)):
+            Dm = O.shRotationForElevation(azi, zen, 4, basis)
+            yh = O.getSH(4, np.array([[azi, np.pi / 2]]), basis)[0]
+            yd = O.getSH(4, np.array([[azi, zen]]), basis)[0]
+            assert np.abs(np.conj(yh) @ Dm - np.conj(yd)).max() < 1e-13
+            assert np.abs(Dm.conj().T @ Dm - np.eye(25)).max() < 1e-13
+    hL, hR = hrirs
+    sub = slice(0, 2702, 12)
+    mic_azi = np.linspace(0, 2 * np.pi, 9, endpoint=False)
+    args = (hL[:, sub], hR[:, sub], grids["azi"][sub], grids["zen"][sub], 0.02, mic_azi, 2, 48000.0, 128)
+    wr = O.getEMagLsFiltersEMAinSH(*args, "real")
+    wc = O.getEMagLsFiltersEMAinSH(*args, "complex")
+    assert wr[0].shape == (128, 9) and wr[0].dtype == np.float64 and wc[0].dtype == np.complex128
+    assert np.isfinite(wr[0]).all() and np.isfinite(wc[1]).all()
+    # the same basis equivariance as the other eMagLS variants (up to the DC quirk, absent in the m = 0 channels)
+    T = real_to_complex_T(2)
+    d = np.abs(wr[0] @ T - wc[0]).max(axis=0) / np.abs(wc[0]).max()
+    assert d.max() < 5e-2 and d[[0, 2, 6]].max() < 1e-9
