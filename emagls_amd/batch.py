@@ -23,6 +23,32 @@ def shard_jobs(costs, world_size):
     return [sorted(s) for s in shards]
 
 
+def lane_groups(shape_keys, max_batch=8):
+    """Group a rank's jobs into lane batches: a `Batch` runs in lane mode (one launch of every kernel for all its designs,
+    one XCD per design in the sweep) only when its plans have identical shapes.  `shape_keys[i]` is any hashable that
+    determines the shape of job i -- for a radius sweep `simulation_order(order, fs, radius)` -- and the result is a list of
+    index lists of at most `max_batch` (<= 8) jobs each, largest classes first, job order kept inside a class."""
+    if not 1 <= max_batch <= 8:
+        raise ValueError("a batch holds 1..8 designs")
+    classes = {}
+    for i, k in enumerate(shape_keys):
+        classes.setdefault(k, []).append(i)
+    groups = []
+    for k in sorted(classes, key=lambda k: (-len(classes[k]), str(k))):
+        idx = classes[k]
+        # equal-sized batches inside a class (e.g. 9 jobs -> 5 + 4, not 8 + 1: the sweep launch costs the same for 1..8 designs)
+        nb = -(-len(idx) // max_batch)
+        size = -(-len(idx) // nb)
+        groups += [idx[i:i + size] for i in range(0, len(idx), size)]
+    return groups
+
+
+def simulation_order(order, fs, radius, c=343.0):
+    """max(N, ceil(fs*pi*r/c)) (dependencies/getSMAIRMatrix.m:95): the shape class of an array-radius job."""
+    import math
+    return max(int(order), int(math.ceil(fs * math.pi * radius / c)))
+
+
 def run_batch(jobs, design_fn, costs=None, group=None, device=None):
     """Run `design_fn(job) -> (wL, wR)` (equal shapes/dtypes for every job) for this rank's share of `jobs`
     and gather everything on rank 0.  Returns the list of (wL, wR) in job order on rank 0, None elsewhere.
