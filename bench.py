@@ -169,8 +169,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # EMAGLS_BENCH_FORCE_PG=1 runs the collective path (barrier, gather, max-reduce over RCCL) with a process group of one
+    # rank too: the N > 1 code is then exercised on a single-GPU box
+    use_pg = world > 1 or os.environ.get("EMAGLS_BENCH_FORCE_PG", "0") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from emagls_amd import Batch, Plan, _lib as L
@@ -220,10 +224,10 @@ def main():
         plans.append(ps)
         batches.append(Batch(ps) if Bsz > 1 else None)
     out = torch.zeros((K, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")  # complex as (re,im)
-    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.zeros_like(out) for _ in range(world)] if (use_pg and rank == 0) else None
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -257,7 +261,7 @@ def main():
                     s += 1
 
     run_steps(W, False)  # first execute is eager, the second captures the hipGraph, the third replays it
-    if world > 1:  # warm the collective too
+    if use_pg:  # warm the collective too
         dist.gather(out, gathered, dst=0)
     # ---- timed region: K designs + one gather (hipGraph replays; two HIP events bracket each batch's sweep launch)
     for b in batches:
@@ -266,12 +270,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_steps(K, True)
-    if world > 1:
+    if use_pg:
         dist.gather(out, gathered, dst=0)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     # duration of the dominant kernel's launches inside the timed region (the last execute of every batch)
@@ -359,7 +363,7 @@ def main():
     for ps in plans:
         for p in ps:
             p.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 
