@@ -467,6 +467,49 @@ def getEMagLsFiltersEMAinCH(hL, hR, aziRad, zenRad, micRadius, micAzi, order, fs
 
 
 # --------------------------------------------------------------------------------------------
+# Render-side neighbours (GPU path: a later round)
+# --------------------------------------------------------------------------------------------
+def getRadialFilter(order, fs, smaRadius, irLen=256, oversamplingFactor=2, radialFilter="tikhonov", arrayType="rigid",
+                    regulConst=1e-2, noiseGainDb=None):
+    """dependencies/getRadialFilter.m:25-71 (plane-wave model): [nfft/2+1 x order+1] with nfft = oversamplingFactor*irLen."""
+    nfft = oversamplingFactor * irLen
+    f = np.linspace(0, fs / 2, nfft // 2 + 1)
+    if radialFilter == "none":
+        return np.ones((nfft // 2 + 1, order + 1))
+    bn = sphModalCoeffs(order, 2 * np.pi * f / C_SOUND * smaRadius, arrayType)[:, : order + 1]
+    with np.errstate(all="ignore"):
+        if radialFilter == "tikhonov":
+            rad = np.conj(bn) / (np.conj(bn) * bn + regulConst)
+        elif radialFilter == "softlimit":
+            g = 10 ** (noiseGainDb / 20)
+            rad = 2 * g / np.pi * np.abs(bn) / bn * np.arctan(np.pi / (2 * g * np.abs(bn)))
+        elif radialFilter == "full":
+            rad = 1.0 / bn
+        else:
+            raise ValueError("unknown radialFilter")
+    if nfft % 2 == 0:
+        rad[-1] = np.abs(rad[-1])  # Nyquist bin (:68-70)
+    return rad
+
+
+def applyRadialFilter(inSig, order, fs, smaRadius, irLen, oversamplingFactor=1, **kw):
+    """dependencies/applyRadialFilter.m:9-31 with params.nfft = oversamplingFactor * irLen as the harness sets it
+    (verifyEMagLs.m:239-250): inSig [numSamples x (order+1)^2] -> filtered, with the filter delay nfft/2 removed."""
+    nfft = oversamplingFactor * irLen
+    rad = getRadialFilter(order, fs, smaRadius, irLen=irLen, oversamplingFactor=oversamplingFactor, **kw)
+    rad = np.where(np.isnan(rad), 0, rad)
+    ir = np.fft.ifft(np.vstack([rad, np.conj(rad[-2:0:-1])]), axis=0)
+    ir = applySubsampleDelay(ir, nfft / 2)
+    ir = ir * getFadeWindow(nfft, 0.05)[:, None]
+    sig = np.asarray(inSig, dtype=np.float64)
+    if sig.shape[0] < nfft:
+        sig = np.vstack([sig, np.zeros((nfft - sig.shape[0], sig.shape[1]))])
+    full = np.column_stack([sh_repToOrder(ir[t]) for t in range(ir.shape[0])]).T   # [nfft x (order+1)^2]
+    out = np.column_stack([fftfilt(full[:, c].real, sig[:, c]) for c in range(sig.shape[1])])
+    return out[nfft // 2:]
+
+
+# --------------------------------------------------------------------------------------------
 # Equatorial microphone arrays in spherical harmonics (SURVEY 8(f) rank 2, second half; GPU path: next round)
 # --------------------------------------------------------------------------------------------
 def getNnm(N, zenRad, harmonicsDef="real"):

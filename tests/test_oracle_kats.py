@@ -320,3 +320,25 @@ def test_ema_in_sh_building_blocks(grids, hrirs):
     T = real_to_complex_T(2)
     d = np.abs(wr[0] @ T - wc[0]).max(axis=0) / np.abs(wc[0]).max()
     assert d.max() < 5e-2 and d[[0, 2, 6]].max() < 1e-9
+
+
+def test_radial_filter_oracle():
+    """Render-side neighbours of the path (dependencies/getRadialFilter.m, applyRadialFilter.m; GPU path in a later round):
+    the Tikhonov filter times b_n is |b_n|^2 / (|b_n|^2 + lambda), 'none' is all ones, the Nyquist row is real, and applying
+    the filters keeps the signal length minus the removed delay."""
+    f = np.linspace(0, 24000.0, 257)
+    bn = O.sphModalCoeffs(4, 2 * np.pi * f / 343.0 * 0.042)
+    rad = O.getRadialFilter(4, 48000.0, 0.042, irLen=512, oversamplingFactor=1)
+    assert rad.shape == (257, 5) and np.isfinite(rad).all()
+    assert np.abs(rad * bn - np.abs(bn) ** 2 / (np.abs(bn) ** 2 + 1e-2))[:-1].max() < 1e-14
+    assert np.abs(rad[-1].imag).max() == 0.0
+    assert np.array_equal(O.getRadialFilter(3, 48000.0, 0.042, irLen=64, radialFilter="none"), np.ones((65, 4)))
+    full = O.getRadialFilter(2, 48000.0, 0.042, irLen=64, oversamplingFactor=1, radialFilter="full")
+    assert np.abs(full[1:-1] * O.sphModalCoeffs(2, 2 * np.pi * np.linspace(0, 24000.0, 33) / 343.0 * 0.042)[1:-1] - 1).max() < 1e-12
+    x = np.random.default_rng(3).standard_normal((2000, 25))
+    y = O.applyRadialFilter(x, 4, 48000.0, 0.042, 512)
+    assert y.shape == (2000 - 256, 25) and np.isfinite(y).all()
+    # channels of one order share a filter: equal inputs in two channels of order 2 give equal outputs
+    x[:, 5] = x[:, 7]
+    y = O.applyRadialFilter(x, 4, 48000.0, 0.042, 512)
+    assert np.array_equal(y[:, 5], y[:, 7])
