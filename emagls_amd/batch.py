@@ -43,10 +43,12 @@ def lane_groups(shape_keys, max_batch=8):
     return groups
 
 
-def simulation_order(order, fs, radius, c=343.0):
-    """max(N, ceil(fs*pi*r/c)) (dependencies/getSMAIRMatrix.m:95): the shape class of an array-radius job."""
+def simulation_order(order, fs, radius, c=343.0, raw=False):
+    """max(N, ceil(fs*pi*r/c)) (dependencies/getSMAIRMatrix.m:95): the shape class of an array-radius job.
+    raw=True is getEMagLs2Filters, which never sets params.order (lib/getEMagLs2Filters.m:51-63), so that
+    getSMAIRMatrix.m:39-41 uses its default 4 in place of `order`."""
     import math
-    return max(int(order), int(math.ceil(fs * math.pi * radius / c)))
+    return max(4 if raw else int(order), int(math.ceil(fs * math.pi * radius / c)))
 
 
 def run_batch(jobs, design_fn, costs=None, group=None, device=None):

@@ -22,6 +22,7 @@ constexpr double C_SOUND = 343.0;       // dependencies/getSMAIRMatrix.m:86
 constexpr int NFFT_MAX_LEN = 2048;      // lib/getEMagLsFilters.m:35
 constexpr double F_CUT_MIN_FREQ = 1e3;  // :36
 constexpr double SVD_REGUL_CONST = 0.01;  // :39
+constexpr int SMAIR_DEFAULT_ORDER = 4;    // dependencies/getSMAIRMatrix.m:39-41 (params.order when the caller leaves it unset)
 
 struct DevBuf {
     void* p = nullptr;
@@ -242,6 +243,10 @@ void plan_setup(emagls_plan& p) {
         p.nfft = (int)std::min<int64_t>(NFFT_MAX_LEN, 2 * d.len);
         check_pow2(p.nfft);
         if (d.len % 2) throw Error(EMAGLS_ERR_ARG, "filter length must be even");
+        // nfft is capped at NFFT_MAX_LEN: a longer filter makes the reference index wMlsL(n_shift-len/2+1 : n_shift+len/2) with a
+        // non-positive start (lib/getEMagLsFilters.m:135-136) and fail; the kernels would read outside their LDS buffers.
+        if (d.len > p.nfft)
+            throw Error(EMAGLS_ERR_ARG, "len exceeds the oversampled FFT length min(2048, 2*len): the reference fails with an index error");
         p.P = p.nfft / 2 + 1;
         const double f2 = (d.fs / 2.0) / (double)(p.P - 1);  // f(2) of linspace(0, fs/2, P)
         const double f_cut = (d.kind == EMAGLS_KIND_FROM_ATF) ? d.f_trans : std::max(F_CUT_MIN_FREQ, 500.0 * d.order);
@@ -263,7 +268,10 @@ void plan_setup(emagls_plan& p) {
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than SH channels");
     } else if (array_kind(d.kind)) {
         if (!(d.mic_radius > 0) || d.nmics < 1) throw Error(EMAGLS_ERR_ARG, "invalid array geometry");
-        p.simOrder = std::max(N, (int)std::ceil(d.fs * kPi * d.mic_radius / C_SOUND));  // getSMAIRMatrix.m:95
+        // getSMAIRMatrix.m:95: max(params.order, ceil(fs*pi*r/C)).  lib/getEMagLs2Filters.m:51-63 leaves params.order unset, so
+        // getSMAIRMatrix.m:39-41 defaults it to 4 there: for eMagLS2 `order` only sets f_cut (:47), never the simulation order.
+        const int smair_order = d.kind == EMAGLS_KIND_EMAGLS2 ? SMAIR_DEFAULT_ORDER : N;
+        p.simOrder = std::max(smair_order, (int)std::ceil(d.fs * kPi * d.mic_radius / C_SOUND));
         p.S = (p.simOrder + 1) * (p.simOrder + 1);
         p.nOut = d.kind == EMAGLS_KIND_EMA_CH ? 2 * N + 1 : (N + 1) * (N + 1);   // EMAinCH.m:66: numHarmonics = 2*order+1
         p.C = d.kind == EMAGLS_KIND_EMAGLS2 ? (int)d.nmics : p.nOut;

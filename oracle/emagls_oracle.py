@@ -32,6 +32,7 @@ C_SOUND = 343.0  # dependencies/getSMAIRMatrix.m:86
 NFFT_MAX_LEN = 2048  # lib/getEMagLsFilters.m:35
 F_CUT_MIN_FREQ = 1e3  # lib/getEMagLsFilters.m:36
 SVD_REGUL_CONST = 0.01  # lib/getEMagLsFilters.m:39
+SMAIR_DEFAULT_ORDER = 4  # dependencies/getSMAIRMatrix.m:39-41 (params.order when the caller leaves it unset)
 
 
 # --------------------------------------------------------------------------------------------
@@ -227,6 +228,11 @@ def simulation_order(order, fs, radius):
     return max(int(order), int(math.ceil(fs * math.pi * radius / C_SOUND)))
 
 
+def emagls2_simulation_order(fs, radius):
+    """Simulation order of getEMagLs2Filters: params.order is left unset there (lib/getEMagLs2Filters.m:51-63), hence 4."""
+    return simulation_order(SMAIR_DEFAULT_ORDER, fs, radius)
+
+
 def getSMAIRMatrix(order, fs, irLen, smaRadius, smaDesignAziZenRad, shDefinition="real",
                    returnRawMicSigs=False, arrayType="rigid"):
     """dependencies/getSMAIRMatrix.m:86-127 with oversamplingFactor=1, radialFilter='none',
@@ -376,7 +382,11 @@ def _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs
                     shDefinition, raw, collect=None):
     assert length >= hL.shape[0], "len too short"
     nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
-    smair, simOrder = getSMAIRMatrix(order, fs, nfft, micRadius, np.column_stack([micAzi, micZen]),
+    # lib/getEMagLs2Filters.m:51-63 never sets params.order, so dependencies/getSMAIRMatrix.m:39-41 defaults it to 4:
+    # the eMagLS2 simulation order is max(4, ceil(fs*pi*r/343)) whatever `order` is (`order` only sets f_cut, :47).
+    # lib/getEMagLsFilters.m:51 (and both EMA variants, :54 / :52) do pass params.order = order.
+    smair_order = SMAIR_DEFAULT_ORDER if raw else order
+    smair, simOrder = getSMAIRMatrix(smair_order, fs, nfft, micRadius, np.column_stack([micAzi, micZen]),
                                      shDefinition, returnRawMicSigs=raw)
     Y_Hi_conj = getSH(simOrder, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
     HL, HR, gL, gR = _hrir_prologue(hL, hR, nfft, P)
@@ -607,6 +617,25 @@ def _sph2cart_unit(aziZen):
     return np.column_stack([np.cos(ele) * np.cos(azi), np.cos(ele) * np.sin(azi), np.sin(ele)])
 
 
+def matchGrids(hrirGridAziZenRad, atfGridAziZenRad):
+    """lib/getEMagLsFiltersFromAtf.m:56-95: the smaller grid picks, per point, its nearest neighbour in the larger one
+    (Euclidean distance of the unit vectors, MATLAB min(): FIRST index on exact ties, :84); equal sizes -> the HRIR grid
+    counts as the smaller one (:62, min([a b]) returns the first).  Returns (hrir_grid_is_smaller, idx (0-based),
+    angular deviation in degrees per point (:85-93))."""
+    hc = _sph2cart_unit(np.asarray(hrirGridAziZenRad, dtype=np.float64))
+    ac = _sph2cart_unit(np.asarray(atfGridAziZenRad, dtype=np.float64))
+    hrir_smaller = hc.shape[0] <= ac.shape[0]
+    dirC, matchC = (hc, ac) if hrir_smaller else (ac, hc)
+    D = dirC.shape[0]
+    idx = np.empty(D, dtype=np.int64)
+    dev = np.empty(D)
+    for ii in range(D):
+        d = np.sqrt(np.sum((matchC - dirC[ii]) ** 2, axis=1))
+        idx[ii] = int(np.argmin(d))   # first minimum, like MATLAB's min
+        dev[ii] = np.degrees(np.arccos(np.clip(dirC[ii] @ matchC[idx[ii]], -1, 1)))
+    return hrir_smaller, idx, dev
+
+
 def getEMagLsFiltersFromAtf(hL, hR, hrirGridAziZenRad, atfIrs, atfGridAziZenRad, fs, filterLen, fTrans):
     """lib/getEMagLsFiltersFromAtf.m:29-151.  atfIrs [taps x numMics x numAtfDirs].
     Returns (wL, wR, meanGridDeviationDeg) -- the third value is what :96 prints."""
@@ -621,20 +650,7 @@ def getEMagLsFiltersFromAtf(hL, hR, hrirGridAziZenRad, atfIrs, atfGridAziZenRad,
     HL = np.fft.fft(np.roll(hL, -rnd(gL), axis=0), axis=0)
     HR = np.fft.fft(np.roll(hR, -rnd(gR), axis=0), axis=0)
     atfs = np.fft.fft(atfIrs, nfft, axis=0)
-    hc = _sph2cart_unit(hrirGridAziZenRad)
-    ac = _sph2cart_unit(atfGridAziZenRad)
-    hrir_smaller = hL.shape[1] <= atfIrs.shape[2]  # min() returns the first index on ties (:62)
-    if hrir_smaller:
-        dirC, matchC = hc, ac
-    else:
-        dirC, matchC = ac, hc
-    D = dirC.shape[0]
-    idx = np.empty(D, dtype=np.int64)
-    dev = np.empty(D)
-    for ii in range(D):
-        d = np.sqrt(np.sum((matchC - dirC[ii]) ** 2, axis=1))
-        idx[ii] = int(np.argmin(d))
-        dev[ii] = np.degrees(np.arccos(np.clip(dirC[ii] @ matchC[idx[ii]], -1, 1)))
+    hrir_smaller, idx, dev = matchGrids(hrirGridAziZenRad, atfGridAziZenRad)
     if hrir_smaller:
         HLm, HRm = HL, HR
         atfM = atfs[:P][:, :, idx]  # P x M x D

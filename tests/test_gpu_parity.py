@@ -356,6 +356,81 @@ def test_emagls2_filters_config4_shape(grids, hrirs):
     assert report("eMagLS2 config4 L", wL, oL) < TOL and report("eMagLS2 config4 R", wR, oR) < TOL
 
 
+@pytest.mark.parametrize("order,radius,sim_order", [(1, 0.005, 4), (6, 0.005, 4), (1, 0.01, 5), (6, 0.01, 5)])
+def test_emagls2_simulation_order_rule(grids, thin, order, radius, sim_order):
+    """eMagLS2 simulates at max(4, ceil(fs*pi*r/343)) whatever `order` is (lib/getEMagLs2Filters.m:51-63 leaves params.order
+    unset -> dependencies/getSMAIRMatrix.m:39-41); `order` only moves f_cut.  Plan constants and filters against the oracle."""
+    import emagls_amd as E
+    from emagls_amd import Plan, _lib as L
+    p = Plan(L.KIND_EMAGLS2, "real", order, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], radius, 12)
+    info = p.info()
+    p.close()
+    assert info.sim_order == sim_order and info.num_sh_sim == (sim_order + 1) ** 2
+    assert info.k_cut == int(np.ceil(max(1e3, 500 * order) / (24000.0 / 128)))
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], radius, grids["mic_azi"][:12], grids["mic_zen"][:12], order, 48000.0, 128, "real")
+    wL, wR = E.getEMagLs2Filters(*args)
+    oL, oR = O.getEMagLs2Filters(*args)
+    assert report(f"eMagLS2 order {order} r {radius} L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
+def _match_idx(hg, ag, nmics=2, taps=16):
+    """match_idx / match_dev of a FROM_ATF plan (the grid matching runs in the first stage of the design)."""
+    from emagls_amd import Plan, _lib as L
+    rng = np.random.default_rng(3)
+    D, Da = hg.shape[0], ag.shape[0]
+    p = Plan(L.KIND_FROM_ATF, "real", 0, 48000.0, 32, nsamp=taps, ndirs=D, nmics=nmics, f_trans=2000.0, atf_taps=taps, natf=Da)
+    p.set_hrir_grid(hg[:, 0], hg[:, 1])
+    p.set_hrirs(rng.standard_normal((taps, D)), rng.standard_normal((taps, D)))
+    p.set_atfs(rng.standard_normal((taps, nmics, Da)), ag[:, 0], ag[:, 1])
+    p.execute()
+    p.synchronize()
+    n = min(D, Da)
+    idx = p.debug("match_idx", np.int64)[:n].copy()
+    dev = p.debug("match_dev", np.float64)[:n].copy()
+    mean = p.info().mean_grid_dev_deg
+    p.close()
+    return idx, dev, mean
+
+
+def test_match_idx_bit_exact(grids):
+    """Index work must be bit-exact: the nearest-neighbour indices of lib/getEMagLsFiltersFromAtf.m:81-95 on config 5's grids
+    (2702 HRIR directions against the 16 384-point ATF lattice), on the reverse case (ATF grid smaller) and on constructed
+    exact ties (duplicate ATF directions, mirror-image pairs: MATLAB's min returns the first index, :84)."""
+    from emagls_amd import synth
+    hg = np.column_stack([grids["azi"], grids["zen"]])
+    aazi, azen = synth.fibonacci_grid(16384)
+    ag = np.column_stack([aazi, azen])
+    smaller, oidx, odev = O.matchGrids(hg, ag)
+    idx, dev, mean = _match_idx(hg, ag)
+    assert smaller and np.array_equal(idx, oidx)
+    assert np.abs(dev - odev).max() < 1e-6 and abs(mean - odev.mean()) < 1e-9   # acos near 1 amplifies the last-bit differences of cos/sin
+    # ATF grid smaller: it picks from the HRIR grid
+    sazi, szen = synth.fibonacci_grid(700)
+    sg = np.column_stack([sazi + 0.01, szen])
+    smaller, oidx, odev = O.matchGrids(hg, sg)
+    idx, dev, mean = _match_idx(hg, sg)
+    assert not smaller and np.array_equal(idx, oidx)
+    # equal sizes: the HRIR grid is the "smaller" one (min([a b]) returns the first index, :62)
+    smaller, oidx, _ = O.matchGrids(sg, sg[::-1].copy())
+    idx, _, _ = _match_idx(sg, sg[::-1].copy())
+    assert smaller and np.array_equal(idx, oidx) and np.array_equal(idx, np.arange(700)[::-1])
+    # exact ties: every ATF direction appears three times (positions j, j + n, j + 2n) -> the first copy wins;
+    # and mirror pairs about azimuth 0 at the equator: (+a) listed before (-a) -> index of (+a)
+    n = 257
+    bazi, bzen = synth.fibonacci_grid(n)
+    tg = np.column_stack([np.tile(bazi, 3), np.tile(bzen, 3)])
+    q = np.column_stack([bazi + 1e-3, bzen])[:64]
+    smaller, oidx, _ = O.matchGrids(q, tg)
+    idx, _, _ = _match_idx(q, tg)
+    assert np.array_equal(idx, oidx) and idx.max() < n
+    a = np.linspace(0.05, 1.0, 40)
+    mg = np.column_stack([np.concatenate([a, -a]), np.full(80, np.pi / 2)])
+    qh = np.column_stack([np.zeros(3), np.full(3, np.pi / 2)])
+    smaller, oidx, _ = O.matchGrids(qh, mg)
+    idx, _, _ = _match_idx(qh, mg)
+    assert oidx.tolist() == [0, 0, 0] and np.array_equal(idx, oidx)
+
+
 def test_from_atf_config5_shape(grids, hrirs):
     """BASELINE config 5 shape: ATF grid of 16 384 directions x 8 microphones, 2048 taps, fTrans 2 kHz, the full
     2702-direction HRIR grid.  Checked against the oracle on the same inputs."""
@@ -422,3 +497,8 @@ def test_error_behaviour(grids, hrirs):
         E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 64)
     with pytest.raises(ValueError):
         E.getLsFilters(hrirs[0], hrirs[1], grids["azi"][:10], grids["zen"], 4)
+    # len > nfft = min(2048, 2*len): the reference fails with an index error (lib/getEMagLsFilters.m:135); here: a clean status
+    with pytest.raises(EmaglsError, match="index error"):
+        E.getEMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 0.042, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 4096)
+    with pytest.raises(EmaglsError, match="index error"):
+        E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 4096)

@@ -238,6 +238,51 @@ def test_simulation_order():
     assert O.simulation_order(4, 48000, 0.02) == 9 and O.simulation_order(4, 48000, 0.10) == 44
 
 
+def test_emagls2_simulation_order_ignores_order(grids):
+    """lib/getEMagLs2Filters.m:51-63 never sets params.order, so dependencies/getSMAIRMatrix.m:39-41 defaults it to 4:
+    the simulation order of eMagLS2 is max(4, ceil(fs*pi*r/343)) for EVERY `order` (which only moves f_cut, :47).
+    r = 5 mm -> 4 (S = 25), r = 1 cm -> 5 (S = 36), for order 1 and order 6 alike; getEMagLsFilters does pass its order."""
+    from emagls_amd import synth
+    from emagls_amd.batch import simulation_order
+    assert O.emagls2_simulation_order(48000.0, 0.005) == 4 and O.emagls2_simulation_order(48000.0, 0.01) == 5
+    assert simulation_order(1, 48000.0, 0.005, raw=True) == 4 and simulation_order(6, 48000.0, 0.01, raw=True) == 5
+    assert simulation_order(1, 48000.0, 0.005) == 3 and simulation_order(6, 48000.0, 0.005) == 6
+    azi, zen = synth.fibonacci_grid(120)
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen, taps=32, centre_delay=8)
+    mic = np.column_stack([grids["mic_azi"], grids["mic_zen"]])[:9]
+    d = np.column_stack([azi, zen])
+    for order, r, so in ((1, 0.005, 4), (6, 0.005, 4), (1, 0.01, 5), (6, 0.01, 5)):
+        seen = {}
+        O.getEMagLs2Filters(hL, hR, azi, zen, r, mic[:, 0], mic[:, 1], order, 48000.0, 32,
+                            collect=lambda k, pw, s, yri: seen.setdefault(k, pw))
+        nfft, P = 64, 33
+        kr = 2 * np.pi * np.linspace(0, 24000.0, P) / 343.0 * r
+        bn = -O.sphModalCoeffs(so, kr)
+        Ymic, Yh = O.getSH(so, mic), O.getSH(so, d)
+        k = 7
+        want = (Ymic * O.sh_repToOrder(bn[k - 1])[None, :]) @ Yh.conj().T
+        assert rel(seen[k], want) < 1e-13, (order, r)
+        # the pre-fix rule (simulation order max(order, ...)) gives a different pwGrid whenever it differs from `so`
+        so_wrong = O.simulation_order(order, 48000.0, r)
+        if so_wrong != so:
+            bw = -O.sphModalCoeffs(so_wrong, kr)
+            wrong = (O.getSH(so_wrong, mic) * O.sh_repToOrder(bw[k - 1])[None, :]) @ O.getSH(so_wrong, d).conj().T
+            assert rel(seen[k], wrong) > 1e-9
+
+
+def test_match_grids_first_index_on_ties():
+    """lib/getEMagLsFiltersFromAtf.m:84: MATLAB min() returns the FIRST index of the minimum; :62 equal sizes -> HRIR grid."""
+    hg = np.array([[0.0, np.pi / 2], [1.0, 1.0], [2.5, 0.3]])
+    # ATF points 1 and 3 are the same direction (duplicate), 0 and 4 mirror images about azimuth 0: exact ties
+    ag = np.array([[0.1, np.pi / 2], [1.0, 1.0], [2.5, 0.31], [1.0, 1.0], [-0.1, np.pi / 2], [2.5, 0.31]])
+    smaller, idx, dev = O.matchGrids(hg, ag)
+    assert smaller and idx.tolist() == [0, 1, 2] and dev[1] < 1e-6
+    smaller, idx, dev = O.matchGrids(ag, hg)       # ATF grid smaller now: it picks from the HRIR grid
+    assert not smaller and idx.tolist() == [0, 1, 2]
+    smaller, idx, dev = O.matchGrids(hg, hg[::-1].copy())
+    assert smaller and idx.tolist() == [2, 1, 0]
+
+
 # ---------------------------------------------------------------- end-to-end sanity on synthetic input
 def test_magls_equals_ls_below_cut(grids, hrirs):
     """MagLS bins below k_cut are the LS solution (delayed): restates the fixture KAT on our own data."""
