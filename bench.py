@@ -1,22 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- eMagLS filter-design throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--concurrent J]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One "step" = one complete filter-set design (both ears, all channels) of BASELINE.json config 3:
 getEMagLsFilters, em32 (32 mics, r = 4.2 cm), N = 4, complex SH, 2702 HRIR directions, 512 taps,
 48 kHz -- from the angles and HRIRs resident in HBM to the windowed time-domain filters in HBM.
 Every rank designs its own filter sets (independent jobs, weak scaling); the only collective is
-one RCCL gather of the finished filters to rank 0 inside the timed region.  With --concurrent J
-each rank keeps J independent designs (different HRIR sets) in flight on J HIP streams.
+one RCCL gather of the finished filters to rank 0 inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the per-bin sweep kernel);
-`cpu_baseline` times the NumPy oracle on this host on a bounded sample of the same workload.
+Launch: `python bench.py --gpus N` starts N fresh child processes itself (one per GPU, env
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) BEFORE torch or HIP are touched and relays rank 0's line;
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE set) it is
+one of the ranks.  A rank that does not find its GPU fails loudly.
+
+Protocol: SETUP builds the resident configuration, which does not depend on --steps: four batches of
+eight designs per GPU (eight designs share every launch of the pipeline, the sweep runs one design
+per XCD), each executed three times (eager, hipGraph capture, first replay).  Then exactly W warm-up
+designs and exactly K timed designs are run through those batches (a last partial batch has its own
+smaller batch object), with a barrier + device synchronisation on both sides of the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the sequential sweep);
+`cpu_baseline` times the NumPy oracle on this host on the same workload (full 512 bins).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,8 +38,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+SLOTS, BSZ = 4, 8      # resident batches per GPU x designs per batch (a persistent sweep launch covers eight designs)
 
 
+# --------------------------------------------------------------------------------------------
+# multi-GPU launch: fresh children, never a re-exec of a process that has touched the GPU
+# --------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv, script=None, timeout=None):
+    """Start `n` fresh interpreters running `script argv...` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set, wait for all of them and return the largest exit code.  The children inherit stdout / stderr (rank 0 prints the
+    result line).  Must be called before this process imports torch or touches HIP.  On the first failure the remaining
+    children are terminated by their exact PIDs."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable] + ([script] if script else []) + list(argv)
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    t_end = None if timeout is None else time.time() + timeout
+    pending = list(procs)
+    terminated = set()
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and p.pid not in terminated:
+                rc = rc or (code if code > 0 else 128 - code)   # the first failure is the launch's exit code
+                for q in pending:      # one rank failed: the others would wait in the rendezvous forever
+                    q.terminate()
+                    terminated.add(q.pid)
+        if t_end is not None and time.time() > t_end:
+            for q in pending:
+                q.kill()
+            return 124
+        time.sleep(0.05)
+    return rc
+
+
+def schedule(n_designs, bsz=BSZ):
+    """Batch sizes that process exactly n_designs: full batches and one partial batch at the end."""
+    full, tail = divmod(int(n_designs), bsz)
+    return [bsz] * full + ([tail] if tail else [])
+
+
+# --------------------------------------------------------------------------------------------
+# inputs, parity, CPU baseline
+# --------------------------------------------------------------------------------------------
 def load_inputs(seed_offset=0):
     from emagls_amd import synth
     gpath = os.path.join(ROOT, "tests", "golden", "ref_fixtures.npz")
@@ -61,46 +130,36 @@ def parity_check():
             "norm_max_abs_diff": float(nd), "max_abs_db_diff": float(adb), "tolerance": 1e-6}
 
 
-def cpu_baseline(azi, zen, maz, mzn, hL, hR, nbins_sample=48):
-    """Oracle (NumPy restatement of lib/getEMagLsFilters.m) on a bounded sample: everything outside the
-    per-bin loop in full, the per-bin loop (lines :85-106) on bins 2..nbins_sample+1 -- which straddle
-    k_cut = 43, so both branches are sampled -- scaled to the 512 bins of the workload."""
+def cpu_baseline(azi, zen, maz, mzn, hL, hR, runs_1t=3, runs_all=1):
+    """The oracle (NumPy restatement of lib/getEMagLsFilters.m) on the whole config-3 workload: all 512 solved bins, no
+    extrapolation.  One thread (median of `runs_1t`) and every core of the host (`runs_all` runs); the faster of the two is
+    the baseline (threads hurt on these tall-skinny SVDs)."""
     from oracle import emagls_oracle as O
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
-    order, fs, length, r = 4, 48000.0, 512, 0.042
 
     def run():
         t0 = time.perf_counter()
-        nfft, f, P, k_cut = O._design_consts(fs, length, max(1e3, 500 * order))
-        smair, simOrder = O.getSMAIRMatrix(order, fs, nfft, r, np.column_stack([maz, mzn]), "complex")
-        Yh = O.getSH(simOrder, np.column_stack([azi, zen]), "complex").conj().T
-        HL, HR, gL, gR = O._hrir_prologue(hL, hR, nfft, P)
-        t1 = time.perf_counter()
-        Ps = nbins_sample + 1
-        Wl, Wr = O._emagls_core(HL, HR, lambda k: smair[:, :, k - 1] @ Yh, Ps, k_cut, 25)
-        t2 = time.perf_counter()
-        Wl_full = np.zeros((P, 25), complex)
-        Wl_full[:Ps] = Wl
-        O._finish(Wl_full, Wl_full, P, nfft, length, False, nfft // 2, nfft // 2 + gR - gL)
-        t3 = time.perf_counter()
-        return (t1 - t0) + (t3 - t2) + (t2 - t1) * (P - 1) / nbins_sample
+        O.getEMagLsFilters(hL, hR, azi, zen, 0.042, maz, mzn, 4, 48000.0, 512, "complex")
+        return time.perf_counter() - t0
 
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
-            t_1 = run()
+            t1 = sorted(run() for _ in range(runs_1t))
     else:
-        t_1 = run()
-    t_all = run()
+        t1 = sorted(run() for _ in range(runs_1t))
+    t_1 = t1[len(t1) // 2]
+    ta = sorted(run() for _ in range(runs_all))
+    t_all = ta[len(ta) // 2]
     ncores = os.cpu_count() or 1
     best, cores = (t_1, 1) if t_1 <= t_all else (t_all, ncores)
     return {"value": 1.0 / best, "unit": "filter sets/s", "cores": cores, "kind": "port",
-            "sample": "NumPy oracle (CPU restatement of the MATLAB path, not MATLAB), config 3: SH/modal/HRIR prologue + "
-                      "epilogue in full, per-bin SVD loop on %d of 512 bins (2..%d, straddling k_cut=43) scaled x%.2f; "
-                      "1 thread %.2f s/set, %d threads %.2f s/set" % (nbins_sample, nbins_sample + 1, 512.0 / nbins_sample,
-                                                                   t_1, ncores, t_all)}
+            "one_thread_s_per_set": t_1, "all_cores_s_per_set": t_all, "host_cores": ncores,
+            "sample": "NumPy oracle (CPU restatement of the MATLAB path, not MATLAB) on the whole workload: config 3, all 512 "
+                      "solved bins, SH / modal / HRIR prologue and epilogue included; 1 thread: median of %d runs = %.2f s/set; "
+                      "%d threads: %d run(s) = %.2f s/set" % (runs_1t, t_1, ncores, runs_all, t_all)}
 
 
 def sh_basis_roofline(lib):
@@ -136,38 +195,63 @@ def sh_basis_roofline(lib):
             "ms": best, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
 
 
-def plan_batches(steps, concurrent=0, batch=0):
-    """(number of batches in flight, designs per batch) for a timed region of `steps` designs.  Explicit --concurrent /
-    --batch win; otherwise up to four batches of up to eight designs (a persistent sweep launch covers at most eight),
-    sized so that a short timed region wastes no design of a batch."""
-    if concurrent > 0 or batch > 0:
-        j = max(1, min(concurrent if concurrent > 0 else 32, steps))   # never more in flight than the timed region holds
-        bsz = max(1, min(batch if batch > 0 else 8, j, 8))
-        return max(1, j // bsz), bsz
-    nbatch = max(1, min(4, -(-steps // 8)))
-    return nbatch, max(1, min(8, -(-steps // nbatch)))
+def pmc_traffic():
+    """HBM bytes from the committed PMC passes (rocprofv3 --pmc cannot run inside the bench): per-kernel bytes of one
+    launch and the sum over one design's kernels (profiles/pmc_traffic.json, written by tools/pmc_summary.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
 
 
+def time_one_shot(lib, inputs, n=3):
+    """The entry point the reference-side caller binds (the MEX shim calls emagls_get_emagls_filters with host arrays):
+    cold = first call of the process for this shape, warm = later calls (plan cache inside the library)."""
+    import emagls_amd as E
+    azi, zen, maz, mzn, hL, hR = inputs
+    ts = []
+    for _ in range(n + 1):
+        t0 = time.perf_counter()
+        E.getEMagLsFilters(hL, hR, azi, zen, 0.042, maz, mzn, 4, 48000.0, 512, "complex")
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return {"cold_ms": round(ts[0], 3), "warm_ms": round(float(np.median(ts[1:])), 3),
+            "note": "emagls_get_emagls_filters with host buffers (H2D of 5.5 MB of HRIRs, D2H of 0.4 MB of filters included)"}
+
+
+# --------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=96)
-    ap.add_argument("--concurrent", type=int, default=int(os.environ.get("EMAGLS_BENCH_CONCURRENT", "0")),
-                    help="independent designs in flight per GPU (default: up to four batches, sized to the step count)")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", "0")),
-                    help="designs per batch (<= 8): one persistent sweep launch covers the whole batch")
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("EMAGLS_BENCH_SLOTS", str(SLOTS))),
+                    help="resident batches per GPU (profiling runs use 1)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", str(BSZ))),
+                    help="designs per batch (<= 8; profiling runs use 1 for the single-design kernel times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sh-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config 4 / config 5 / one-shot secondary figures")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or not 1 <= args.batch <= 8 or args.slots < 1:
+        raise SystemExit("bench.py: invalid arguments")
 
-    import torch  # first: the library then shares torch's HIP runtime (same SONAME libamdhip64.so.7)
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # N fresh children, one per GPU; this parent never imports torch and never touches HIP
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE=%d (launch with `python bench.py --gpus N` or with "
+                         "torch.distributed.run --nproc-per-node N bench.py --gpus N)" % (args.gpus, world))
+    import torch  # first: the library then shares torch's HIP runtime (same SONAME libamdhip64.so.7)
+    import torch.distributed as dist
+    ndev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if ndev <= local_rank:
+        raise SystemExit("bench.py: rank %d of %d needs GPU %d but this box has %d GPU(s); there is no CPU fallback"
+                         % (rank, world, local_rank, ndev))
     torch.cuda.set_device(local_rank)
     # EMAGLS_BENCH_FORCE_PG=1 runs the collective path (barrier, gather, max-reduce over RCCL) with a process group of one
     # rank too: the N > 1 code is then exercised on a single-GPU box
@@ -181,9 +265,7 @@ def main():
     lib = L.load()
     L.check(lib.emagls_set_device(local_rank))
     K, W = args.steps, args.warmup
-    nbatch, Bsz = plan_batches(K, args.concurrent, args.batch)
-    J = nbatch * Bsz
-    W = max(W, 3 * J)   # every batch needs its eager, capturing and first replayed execute before the timed region
+    nslots, Bsz = args.slots, args.batch
 
     def make_plan(seed_offset, streams=1):
         azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=seed_offset)
@@ -217,13 +299,45 @@ def main():
     info = p0.info()
     p0.close()
 
-    # ---- throughput: nbatch batches of Bsz designs each, every batch on its own stream / hardware queue
-    plans, batches = [], []
-    for b in range(nbatch):
-        ps = [make_plan(rank * 100 + b * Bsz + j)[0] for j in range(Bsz)]
-        plans.append(ps)
-        batches.append(Batch(ps) if Bsz > 1 else None)
+    # ---- SETUP: the resident configuration (independent of --steps): nslots batches of Bsz designs, plus one smaller batch
+    # object per distinct tail size of the warm-up and the timed schedule
+    class Unit:
+        def __init__(self, size, seed0):
+            self.plans = [make_plan(seed0 + j)[0] for j in range(size)]
+            self.batch = Batch(self.plans) if size > 1 else None
+            self.size = size
+
+        def execute(self):
+            self.batch.execute() if self.batch is not None else self.plans[0].execute()
+
+        def collect(self, dst_l, dst_r):
+            if self.batch is not None:   # one synchronisation and one status check for the whole batch; device-to-device copies
+                self.batch.get_filters_into(dst_l, dst_r)
+            else:
+                L.check(lib.emagls_plan_get_filters(self.plans[0]._h, C.c_void_p(dst_l[0]), C.c_void_p(dst_r[0])))
+
+        def wait(self):
+            self.batch.synchronize() if self.batch is not None else self.plans[0].synchronize()
+
+        def close(self):
+            if self.batch is not None:
+                self.batch.close()
+            for p in self.plans:
+                p.close()
+
+    units = [Unit(Bsz, rank * 1000 + b * Bsz) for b in range(nslots)]
+    tails = {}
+    for n_designs in (W, K):
+        t = n_designs % Bsz
+        if t and t not in tails:
+            tails[t] = Unit(t, rank * 1000 + 500 + t)
+    for u in units + list(tails.values()):   # eager run, hipGraph capture, first replay
+        for _ in range(3):
+            u.execute()
+        u.wait()
+
     out = torch.zeros((K, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")  # complex as (re,im)
+    scratch = torch.zeros((Bsz, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")
     gathered = [torch.zeros_like(out) for _ in range(world)] if (use_pg and rank == 0) else None
 
     def barrier():
@@ -231,45 +345,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(nsteps, store):
-        s = 0
-        while s < nsteps:
-            started = []
-            for b in range(nbatch):
-                if s + len(started) * Bsz >= nsteps:
-                    break
-                if batches[b] is not None:
-                    batches[b].execute()
+    def run_designs(n_designs, store):
+        """Exactly n_designs designs through the resident batches, at most nslots batches in flight (sliding window: a slot is
+        re-issued as soon as its results have been collected)."""
+        sched = schedule(n_designs, Bsz)
+        free, inflight = list(units), []
+        idx = first = done = 0
+        while idx < len(sched) or inflight:
+            while idx < len(sched) and len(inflight) < nslots:
+                size = sched[idx]
+                if size == Bsz:
+                    if not free:
+                        break
+                    u = free.pop(0)
                 else:
-                    plans[b][0].execute()
-                started.append(b)
-            for b in started:
-                if batches[b] is not None and store and s + Bsz <= nsteps:
-                    # one synchronisation and one status check for the whole batch; device-to-device copies
-                    batches[b].get_filters_into([out[s + j, 0].data_ptr() for j in range(Bsz)],
-                                                [out[s + j, 1].data_ptr() for j in range(Bsz)])
-                    s += Bsz
-                    continue
-                for j, p in enumerate(plans[b]):
-                    if s < nsteps and store:
-                        L.check(lib.emagls_plan_get_filters(p._h, C.c_void_p(out[s, 0].data_ptr()),
-                                                            C.c_void_p(out[s, 1].data_ptr())))
-                    elif batches[b] is not None:
-                        batches[b].synchronize()
-                    else:
-                        p.synchronize()
-                    s += 1
+                    u = tails[size]   # (the partial batch at the end of the schedule)
+                u.execute()
+                inflight.append((u, first))
+                first += size
+                idx += 1
+            u, f0 = inflight.pop(0)
+            dst, base = (out, f0) if store else (scratch, 0)
+            u.collect([dst[base + j, 0].data_ptr() for j in range(u.size)], [dst[base + j, 1].data_ptr() for j in range(u.size)])
+            done += u.size
+            if u.size == Bsz:
+                free.append(u)
+        assert done == n_designs
 
-    run_steps(W, False)  # first execute is eager, the second captures the hipGraph, the third replays it
-    if use_pg:  # warm the collective too
+    # ---- W warm-up designs, untimed (also warms the collective)
+    if W:
+        run_designs(W, False)
+    if use_pg:
         dist.gather(out, gathered, dst=0)
-    # ---- timed region: K designs + one gather (hipGraph replays; two HIP events bracket each batch's sweep launch)
-    for b in batches:
-        if b is not None:
-            b.set_profiling(1)
+    # ---- timed region: exactly K designs + one gather (hipGraph replays; two HIP events bracket each batch's sweep launch)
+    for u in units:
+        if u.batch is not None:
+            u.batch.set_profiling(1)
     barrier()
     t0 = time.perf_counter()
-    run_steps(K, True)
+    run_designs(K, True)
     if use_pg:
         dist.gather(out, gathered, dst=0)
     barrier()
@@ -278,26 +392,22 @@ def main():
     if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    # duration of the dominant kernel's launches inside the timed region (the last execute of every batch)
-    batch_sweep_ms = [b.sweep_time_ms() for b in batches if b is not None]
+    # duration of the dominant kernel's launches inside the timed region (the last execute of every full batch)
+    batch_sweep_ms = [u.batch.sweep_time_ms() for u in units[:min(nslots, K // Bsz)] if u.batch is not None]
 
     if rank == 0:
         D, Cc = inputs[4].shape[1], info.num_channels
-        # algorithmic bytes of one sweep launch (one frequency bin, both ears): the bin's pwGrid (D x C complex),
-        # its C x C matrix M_k, |H| of both ears, W(k-1) in and W(k) out
+        # algorithmic bytes of one swept bin (both ears): the bin's pwGrid (D x C complex), its C x C matrix M_k, |H| of both
+        # ears, W(k-1) in and W(k) out
         bytes_bin = 16.0 * D * Cc + 16.0 * Cc * Cc + 2 * 8.0 * D + 2 * 2 * Cc * 16.0
         nbins_swept = info.num_pos_freqs - max(info.k_cut - 1, 1)
+        pmc = pmc_traffic()
         roof = None
         if sweep_n > 0:
             persistent = sweep_n == 1  # one resident launch walks all swept bins (sweep_persist.hip)
             kname = "sweep_persist_kernel" if persistent else "sweep_half_kernel"
             bytes_launch = bytes_bin * nbins_swept / sweep_n
-            traffic = None
-            try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside the bench)
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    traffic = json.load(f)[kname]["bytes"]
-            except Exception:
-                traffic = None
+            traffic = pmc.get(kname, {}).get("bytes")
             # one design per launch: sweep stage time of the single-design plan (HIP events on the plan's stream)
             stage_sweep_ms = dict(stages).get("magls_sweep", sweep_ms)
             single_s = stage_sweep_ms / sweep_n * 1e-3
@@ -316,10 +426,17 @@ def main():
                     "avg_launch_us_single_design": single_s * 1e6,
                     "algorithmic_bytes_per_launch": bytes_launch, "bins_per_launch": nbins_swept / sweep_n,
                     "us_per_bin": avg_s * 1e6 * sweep_n / nbins_swept,
+                    "compulsory_bytes_per_set": 8.0 * 2 * 128 * D + 2 * 16.0 * 2 * info.num_pos_freqs * D + 16.0 * 2 * 512 * Cc,
+                    "traffic_per_set": pmc.get("per_set", {}).get("bytes"),
                     "note": "sequential recurrence over the frequency bins (W(k) needs W(k-1)): 1.1 MB of operands per bin and "
                             "design; one launch sweeps the designs of a batch, each on its own XCD; the chain is bound by the "
-                            "per-bin exchange of partial sums between workgroups (two in-launch hops through the XCD's L2) and "
-                            "LDS-bound phases, not by HBM bandwidth -- see DESIGN.md section 5"}
+                            "per-bin exchange of partial sums between workgroups and LDS-bound phases, not by HBM bandwidth "
+                            "(DESIGN.md section 5); traffic_per_set = HBM bytes of ALL kernels of one design from the PMC "
+                            "passes, next to SURVEY 8(d)'s compulsory bytes"}
+        # measured FP64 peaks of this device (microbench.hip): matrix pipe and vector pipe
+        peak_mfma, peak_vec = C.c_double(0.0), C.c_double(0.0)
+        lib.emagls_fp64_peak_tflops(0, C.byref(peak_mfma))
+        lib.emagls_fp64_peak_tflops(1, C.byref(peak_vec))
         # the reference formulation needs F_ref FP64 flop per set (pwGrid GEMM + SVD-equivalent + apply);
         # the factorised pipeline executes F_exec (per stage in DESIGN.md section 5)
         Kb, Sx = info.num_pos_freqs - 1, info.num_sh_sim
@@ -330,9 +447,11 @@ def main():
                   + 4.0 * 2 * (info.k_cut - 1) * D * Sx + 4.0 * Kb * Sx * Cc * 10 + 8.0 * nbins_swept * Sx * Cc * (Cc + 1) / 2
                   + 8.0 * nbins_swept * 4 * D * Cc + 5.0 * D * info.nfft * 10) / 1e9
         flops = {"F_ref_gflop_per_set": f_ref, "F_exec_gflop_per_set": f_exec, "exec_tflops": f_exec * world * K / dt / 1e3,
-                 "ref_equivalent_tflops": f_ref * world * K / dt / 1e3, "fp64_peak_tflops": 78.6,
-                 "note": "F_ref: reference formulation (SURVEY 8d: 126 GFLOP at config 3); F_exec: flops the factorised pipeline "
-                         "executes (Gram on MFMA counted as full tiles); fp64 peak = AMD's public vector/matrix figure"}
+                 "fp64_mfma_peak_tflops_measured": round(peak_mfma.value, 2), "fp64_vector_peak_tflops_measured": round(peak_vec.value, 2),
+                 "exec_frac_of_vector_peak": (f_exec * K / dt / 1e3) / peak_vec.value if peak_vec.value > 0 else None,
+                 "note": "F_ref: reference formulation (SURVEY 8d: 126 GFLOP at config 3, 111 of them the pwGrid GEMM the "
+                         "factorised pipeline never executes); F_exec: flops the pipeline executes per set; peaks measured on "
+                         "this device by emagls_fp64_peak_tflops (v_mfma_f64_16x16x4_f64 / v_fma_f64 on every CU)"}
         res = {
             "metric": "eMagLS filter sets/s (N=4, 2702 dirs, 512 taps)", "value": world * K / dt, "unit": "filter sets/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
@@ -340,7 +459,9 @@ def main():
             "config": {"workload": "BASELINE config 3: getEMagLsFilters em32 r=4.2cm N=4 complex-SH, 2702 dirs, 512 taps, "
                                    "48 kHz; one filter set per step, inputs resident in HBM",
                        "dirs": int(D), "taps": 512, "sim_order": info.sim_order, "bins": info.num_pos_freqs - 1,
-                       "k_cut": info.k_cut, "designs_in_flight_per_gpu": J, "designs_per_batch": Bsz, "batches_in_flight": nbatch,
+                       "k_cut": info.k_cut, "designs_resident_per_gpu": nslots * Bsz, "designs_per_batch": Bsz,
+                       "batches_in_flight": nslots, "timed_schedule": "%d full batches of %d + tail %d" % (K // Bsz, Bsz, K % Bsz),
+                       "setup": "each resident batch executed 3x (eager, hipGraph capture, replay) before the warm-up",
                        "parallelism": "independent jobs per GPU, one RCCL gather"},
             "roofline": roof,
             "flops": flops,
@@ -352,17 +473,27 @@ def main():
                 res["sh_basis_roofline"] = sh_basis_roofline(lib)
             except Exception as e:  # the large launch needs ~3.5 GB; never fail the bench on it
                 res["sh_basis_roofline"] = {"error": str(e)}
+        if not args.no_secondary and world == 1:
+            for u in units + list(tails.values()):
+                u.close()
+            units, tails = [], {}
+            try:
+                res["one_shot_ms"] = time_one_shot(lib, inputs)
+            except Exception as e:
+                res["one_shot_ms"] = {"error": str(e)}
+            try:
+                from tools import bench_secondary
+                res["secondary"] = bench_secondary.run()
+            except Exception as e:
+                res["secondary"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(*inputs)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
             res["parity"] = parity_check()
         print(json.dumps(res))
-    for b in batches:
-        if b is not None:
-            b.close()
-    for ps in plans:
-        for p in ps:
-            p.close()
+        sys.stdout.flush()
+    for u in units + list(tails.values()):
+        u.close()
     if use_pg:
         dist.destroy_process_group()
 

@@ -35,6 +35,7 @@ SYMBOLS = {
     "emagls_version": (C.c_int, []),
     "emagls_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "emagls_set_device": (C.c_int, [C.c_int]),
+    "emagls_fp64_peak_tflops": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "emagls_sh_basis": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "emagls_sh_basis_device": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "emagls_modal_bn": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p]),

@@ -23,8 +23,6 @@ struct FactorArgs {
     double tol_dim;
     // outputs
     cplx* Z;          // [kb][c][ldS]
-    cplx* Bk;         // [kb][c][ldS] or nullptr  (written for kb >= bk_from)
-    int bk_from;
     cplx* Vws;        // [blockIdx.x][c][ldS] Householder vectors workspace
     double* sv;       // [kb][C] singular values (unsorted) or nullptr
     // least-squares bins: W[e][kb][c] = sum_s Hq[e][kb][s] Z[s][c] for kb < ls_end
@@ -48,22 +46,6 @@ struct FactorArgs {
     cplx* R2w;        // [bin][C][C]    triangular factor (upper)
     cplx* Nw;         // [bin][C][C]    U2 diag(s_reg) V^H
     cplx* Mw;         // [bin][C][C]    V diag(s_reg/s) V^H (optional, for the direction-space sweep operands)
-};
-
-struct SweepArgs {
-    int D, S, C, ldS, P;
-    int64_t ldQ;
-    const void* Q;        // [D][ldQ] real or complex
-    const cplx* Z;        // [kb][c][ldS]
-    const cplx* Bk;       // [kb][c][ldS]
-    const double* Habs;   // [e][kb-kabs0][ldD]
-    int64_t ldD;
-    int kabs0;
-    cplx* Wpart;          // [2][nWG][2][C]
-    cplx* W;              // [e][P][C]
-    int nWG, dpw;         // workgroups, directions per workgroup
-    int kfirst;           // first swept bin: W(k-1) is read from W instead of the partials
-    long long* timing;    // optional [P][16] clock stamps of workgroup 0 (debug)
 };
 
 struct DenseSweepArgs {
@@ -108,9 +90,5 @@ struct HalfSweepMulti {
 };
 
 constexpr int SWEEP_MULTI_MAX = 8;
-struct DenseSweepMulti {
-    int n;
-    DenseSweepArgs a[SWEEP_MULTI_MAX];
-};
 
 }  // namespace emagls

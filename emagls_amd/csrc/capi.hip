@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,9 @@ int round_up(int64_t v, int64_t m) { return (int)(ceil_div(v, m) * m); }
 
 }  // namespace
 
+struct emagls_batch;
+void emagls_batch_forget(emagls_batch* b, emagls_plan* p);
+
 struct emagls_plan {
     emagls_design_desc d{};
     hipStream_t stream = nullptr;
@@ -54,16 +58,12 @@ struct emagls_plan {
     bool hrir_smaller = true;
     bool out_cplx = false;
     int64_t out_rows = 0, out_cols = 0;
-    int nWG = 0, dpw = 0, nWG_dense = 0, nWG_split = 0;
-    // two tiny kernels per bin (slab + reduce) instead of one with a redundant gather: slower for ONE design
-    // (two launch floors per bin), faster when a batch shares the launches; batches switch it on
-    bool sweep_split = false;
-    // one direction-space operand per bin (G_k; M_k applied after the cross-workgroup sum): default
-    bool sweep_half = true;
+    int nWG = 0, nWG_dense = 0;   // workgroups of the launch-per-bin sweeps (MagLS / FromAtf: nWG; array designs: nWG_dense)
     // Gram route of the per-bin factorisation for the well-conditioned swept bins (factor.hip); switched off for good
     // when a run reports that the kr-based conditioning estimate was too optimistic (the plan is then re-executed)
     bool gram_route = true;
-    bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip); needs sweep_half
+    bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip)
+    emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
     // profiling
     int prof_level = 0;
@@ -80,7 +80,6 @@ struct emagls_plan {
     bool use_graph = true;
     hipGraph_t pre_graph = nullptr;          // batches: stages before the sweep, captured on the plan's own stream
     hipGraphExec_t pre_exec = nullptr;
-    bool sweep_factored = false;  // legacy S-space sweep (kept for comparison)
     int nstreams = 1;
     hipStream_t sync_stream = nullptr;  // stream whose completion means this plan's results are ready
     // fork/join inside one design: independent branches run on side streams (captured into the same graph)
@@ -104,6 +103,7 @@ struct emagls_plan {
     }
 
     ~emagls_plan() {
+        if (owner) emagls_batch_forget(owner, this);
         if (!arena) for (auto& kv : bufs) if (kv.second.p) hipFree(kv.second.p);
         for (auto e : stage_events) hipEventDestroy(e);
         for (auto e : sweep_events) hipEventDestroy(e);
@@ -187,13 +187,32 @@ struct emagls_batch {
         if (post_graph) hipGraphDestroy(post_graph);
         for (auto e : sweep_ev) if (e) hipEventDestroy(e);
         if (stream) hipStreamDestroy(stream);
-        for (auto* p : plans) p->sync_stream = nullptr;
+        for (auto* p : plans) if (p) { p->sync_stream = nullptr; p->owner = nullptr; }
     }
 };
+// a plan of the batch is being destroyed before the batch: the batch must not touch it again
+void emagls_batch_forget(emagls_batch* b, emagls_plan* p) {
+    for (auto& q : b->plans) if (q == p) q = nullptr;
+}
 
 namespace {
 
 size_t esz(bool c) { return c ? sizeof(cplx) : sizeof(double); }
+
+// compute units of the current device (cached per device id)
+int device_cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    int n = 0;
+    HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cache[dev] = n;
+    return n;
+}
 
 void check_pow2(int nfft) {
     if (nfft < 8 || (nfft & (nfft - 1)) != 0)
@@ -298,7 +317,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Yc", esz(cb) * (size_t)p.Dpad * p.ldS);               // [Dpad][ldS] conj(Y), direction-major
         p.alloc("Gp", esz(cb) * (size_t)gram_ksplit(p.D) * p.S * p.S);
         p.alloc("R", esz(cb) * (size_t)p.S * p.S);
-        p.alloc("Q", esz(cb) * (size_t)p.D * p.ldS);
+        if (!array_kind(d.kind)) p.alloc("Q", esz(cb) * (size_t)p.D * p.ldS);   // (the array designs never form Q: section 2.1 of DESIGN.md)
         p.alloc("Rinv", esz(cb) * (size_t)ceil_div(p.S, 32) * 32 * 32);
     }
     if (d.kind == EMAGLS_KIND_LS || d.kind == EMAGLS_KIND_MAGLS) {
@@ -343,7 +362,6 @@ void plan_setup(emagls_plan& p) {
             p.alloc("Rinvc", sizeof(cplx) * (size_t)ceil_div(p.S, 32) * 32 * 32);
         }
         p.alloc("Z", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
-        p.alloc("Bk", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
         p.alloc("Vws", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
         p.alloc("sv", sizeof(double) * (size_t)p.P * p.C);
         p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
@@ -358,11 +376,7 @@ void plan_setup(emagls_plan& p) {
             p.alloc("G", sizeof(cplx) * (nsw * p.C + 32) * p.ldD, false);  // + 32 rows: the persistent sweep loads all 32 slab rows of a bin unconditionally
             p.alloc("Yri", sizeof(cplx) * nsw * p.C * p.ldD, false);
         }
-        p.sweep_factored = getenv("EMAGLS_SWEEP") && std::string(getenv("EMAGLS_SWEEP")) == "factored";
         if (getenv("EMAGLS_SWEEP_TIMING")) p.alloc("sweep_timing", sizeof(long long) * 16 * (size_t)p.P);
-        p.nWG = 128;
-        if (const char* e = getenv("EMAGLS_SWEEP_NWG")) p.nWG = std::max(8, std::min(256, atoi(e)));
-        p.dpw = (int)ceil_div(p.D, p.nWG);
     }
     if (d.kind == EMAGLS_KIND_FROM_ATF) {
         const int M = p.C;
@@ -392,15 +406,13 @@ void plan_setup(emagls_plan& p) {
         p.alloc("W", sizeof(cplx) * (size_t)2 * p.P * p.C);
         if (d.kind == EMAGLS_KIND_MAGLS || d.kind == EMAGLS_KIND_FROM_ATF) p.nWG = dense_sweep_nwg((int)Dh);
         p.nWG_dense = dense_sweep_nwg((int)Dh);
-        p.nWG_split = slab_sweep_nwg((int)Dh);
-        if (const char* e = getenv("EMAGLS_SWEEP_SPLIT")) p.sweep_split = e[0] == '1';
-        if (const char* e = getenv("EMAGLS_SWEEP_HALF")) p.sweep_half = e[0] != '0';
-        if (p.sweep_split || p.sweep_factored) p.sweep_half = false;
         if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) p.sweep_persist = e[0] != '0';
-        if (!p.sweep_half || !persist_sweep_supported((int)Dh, p.C)) p.sweep_persist = false;
+        // the persistent sweep keeps one workgroup per CU resident (142 KB of LDS each): it needs the shape to fit one XCD's
+        // 32 CUs per design AND that many CUs on this device (a partitioned or CU-masked GPU takes the launch-per-bin form)
+        if (!array_kind(d.kind) || !persist_sweep_supported((int)Dh, p.C) || persist_sweep_nwg((int)Dh) > device_cu_count())
+            p.sweep_persist = false;
         p.alloc("ll", persist_sweep_ll_bytes((int)Dh, p.C));
-        if (p.nWG_split > 256 || 2 * p.C > 64) p.sweep_split = false;
-        p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(std::max(p.nWG, p.nWG_dense), p.nWG_split) * 2 * p.C);
+        p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(p.nWG, p.nWG_dense) * 2 * p.C);
         p.out_rows = d.len;
     }
     p.out_cols = p.C;
@@ -463,7 +475,7 @@ void run_pinv_of_R(emagls_plan& p) {
     a.Tn = nullptr; a.bn = nullptr; a.nOrders = 0;
     a.Xd = p.get<cplx>("Rb"); a.xd_stride = 0;
     a.reg_mode = 1; a.reg_c = 0.0; a.tol_dim = (double)std::max<int64_t>(p.D, p.C);
-    a.Z = p.get<cplx>("Zb"); a.Bk = nullptr; a.bk_from = 0; a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
+    a.Z = p.get<cplx>("Zb"); a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
     a.Hq = nullptr; a.W = nullptr; a.ls_end = 0; a.sweeps_out = nullptr;
     a.tauw = p.get<double>("tauw"); a.R2w = p.get<cplx>("R2w"); a.Nw = p.get<cplx>("Nw");
     launch_factor(a, 1, true, st);
@@ -512,7 +524,7 @@ void execute_magls(emagls_plan& p) {
 // output channels can carry, |b_0 / b_n| ~ (2n+1)!! / (kr)^n with n = ceil(sqrt(C)) - 1; the route starts where that
 // estimate falls below 3e2 (the Jacobi kernel verifies cond < 3e3 and asks for a re-run otherwise).
 int emagls_gram_from(const emagls_plan& p) {
-    if (!p.gram_route || p.sweep_factored || p.d.mic_radius <= 0.0) return 0;
+    if (!p.gram_route || p.d.mic_radius <= 0.0) return 0;
     if (const char* e = getenv("EMAGLS_GRAM_ROUTE")) if (e[0] == '0') return 0;
     int n = 0;
     if (p.d.kind == EMAGLS_KIND_EMA_CH) n = p.d.order;   // 2N+1 circular harmonics reach order N
@@ -528,7 +540,6 @@ int emagls_gram_from(const emagls_plan& p) {
     const int from = std::max(std::max(kb, p.kcut0), 1);
     return from < p.P ? from : 0;
 }
-bool emagls_needs_q(const emagls_plan& p) { return p.sweep_factored; }
 
 void emagls_pre_sweep(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
@@ -598,30 +609,19 @@ void emagls_pre_sweep(emagls_plan& p) {
     if (s2 != s0) HIP_CHECK(hipEventRecord(e_R, s0));
 
     // s1 (after the array model): order terms of pwGrid.' and G_k of every swept bin -- needs only conj(Y) and E
-    if (!p.sweep_factored) {
-        if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s1, e_Yc, 0));
-        launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, cb, p.get("QT"), p.ldD, s1);
-        {
-            static const bool real_terms = [] { const char* e = getenv("EMAGLS_DSPACE_REAL"); return !(e && e[0] == '0'); }();
-            // (circular-harmonic channels: the real-arithmetic form would need their own channel transform -> complex kernel)
-            launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, k0, p.get("G"), s1,
-                            (cb && real_terms && d.kind != EMAGLS_KIND_EMA_CH) ? 1 : 0, raw ? -1 : (int)d.order);
-        }
-    }
-    // s2 (after the prologue): Q = conj(Y) R^-1 and the least-squares right-hand sides H conj(Q)
+    if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s1, e_Yc, 0));
+    launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, cb, p.get("QT"), p.ldD, s1);
+    // (complex-arithmetic pipeline: G_k is still evaluated on the real order terms; circular-harmonic
+    // channels would need their own channel transform and take the complex kernel)
+    launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, k0, p.get("G"), s1,
+                    (cb && d.kind != EMAGLS_KIND_EMA_CH) ? 1 : 0, raw ? -1 : (int)d.order);
+    // s2 (after the prologue): the least-squares right-hand sides H conj(Q).  Q itself is never formed: H conj(Q) is
+    // conj( conj(H conj(Yc)) R^-1 ), one D-long product and a row solve for the 2 (k_cut - 1) least-squares rows.
     if (s2 != s0) HIP_CHECK(hipStreamWaitEvent(s2, e_R, 0));
-    // Q itself is only needed by the legacy S-space sweep and by the real-basis path.  Otherwise H conj(Q) is formed as
-    // conj( conj(H conj(Yc)) R^-1 ): one D-long product and a row solve for the 2 (k_cut - 1) least-squares rows.
-    const bool need_q = emagls_needs_q(p);
-    if (need_q) {
-        launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, cb, p.get("Q"), s2);
-        launch_hq(p.get("Hc"), p.ldD, ls_end, p.get("Q"), p.ldS, cb, (int)p.D, p.S, 1, ls_end, p.get("Hq"), p.ldS, s2);
-    } else {
-        // (real basis: the rows are complex all the same, so R is widened to a complex copy for the row solves)
-        if (!cb) launch_widen(p.get("R"), p.S, false, p.get("Rc"), p.S, p.S, p.S, false, /*upper_only=*/true, s2);
-        launch_hy_conj(p.get("Hc"), p.ldD, 2 * ls_end, p.get("Yc"), p.ldS, cb, (int)p.D, p.S, p.get("Hyp"), p.get("Hq"), p.ldS, s2);
-        launch_qform(p.get("Hq"), p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.S, 2 * (int64_t)ls_end, p.ldS, true, p.get("Hq"), s2);
-    }
+    // (real basis: the rows are complex all the same, so R is widened to a complex copy for the row solves)
+    if (!cb) launch_widen(p.get("R"), p.S, false, p.get("Rc"), p.S, p.S, p.S, false, /*upper_only=*/true, s2);
+    launch_hy_conj(p.get("Hc"), p.ldD, 2 * ls_end, p.get("Yc"), p.ldS, cb, (int)p.D, p.S, p.get("Hyp"), p.get("Hq"), p.ldS, s2);
+    launch_qform(p.get("Hq"), p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.S, 2 * (int64_t)ls_end, p.ldS, true, p.get("Hq"), s2);
 
     // s0: T_n, per-bin QR + Jacobi
     if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s0, e_E, 0));
@@ -631,26 +631,23 @@ void emagls_pre_sweep(emagls_plan& p) {
     fa.S = p.S; fa.C = p.C; fa.ldS = p.ldS; fa.kb0 = 1; fa.P = p.P;
     fa.Tn = p.get("Tn"); fa.bn = p.get<cplx>("bn"); fa.nOrders = nOrd;
     fa.reg_mode = 0; fa.reg_c = SVD_REGUL_CONST;
-    fa.Z = p.get<cplx>("Z"); fa.Bk = p.sweep_factored ? p.get<cplx>("Bk") : nullptr; fa.bk_from = p.kcut0;
+    fa.Z = p.get<cplx>("Z");
     fa.Mw = p.get<cplx>("Mw");
     fa.Vws = p.get<cplx>("Vws"); fa.sv = p.get<double>("sv");
     fa.Hq = p.get<cplx>("Hq"); fa.ldHq = p.ldS; fa.hq_estride = (int64_t)ls_end * p.ldS; fa.ls_end = ls_end;
-    fa.hq_conj = need_q ? 0 : 1;
+    fa.hq_conj = 1;
     fa.route = p.get<int>("route"); fa.status = p.get<int>("flag");
     fa.gram_from = emagls_gram_from(p);
     // batches have workgroups to spare: a Jacobi workgroup walks a run of neighbouring bins, each warm-started from the
     // previous one (a third of the sweeps); a single design keeps one bin per workgroup (shortest critical path)
     fa.jrun = batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
-    if (const char* e = getenv("EMAGLS_JACOBI_RUN")) fa.jrun = std::max(1, atoi(e));
     fa.W = p.get<cplx>("W"); fa.sweeps_out = p.get<int>("jsweeps");
     fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
     launch_factor(fa, p.P - 1, cb, s0, 1);
     // cond_ok[kb]: the cheap direction-space identity is accurate for this bin.  Only the other swept bins (and the
     // least-squares bins) need Z_k, i.e. the back-transform
-    if (!p.sweep_factored) {
-        launch_cond_flags(p.get<double>("sv"), p.C, p.P, p.get<double>("cond_ok"), s0);
-        fa.cond_ok = p.get<double>("cond_ok");
-    }
+    launch_cond_flags(p.get<double>("sv"), p.C, p.P, p.get<double>("cond_ok"), s0);
+    fa.cond_ok = p.get<double>("cond_ok");
     p.mark("factor_qr_jacobi");
     // join s2 (Q, Hq, spectra, group delays): back-transform + least-squares bins
     p.depend(s0, s2);
@@ -658,33 +655,12 @@ void emagls_pre_sweep(emagls_plan& p) {
     p.mark("factor_back+ls_bins");
     // join s1 (G)
     p.depend(s0, s1);
-    if (!p.sweep_factored) {
-        if (!p.sweep_half)
-            launch_dspace_yri(p.get("G"), p.ldD, p.get("Mw"), 1, p.get<double>("sv"), p.get<double>("cond_ok"), (int)p.D, p.C, p.P,
-                              k0, p.get("Yri"), s0);
-        if (need_q) {
-            launch_yri_accurate(p.get("Q"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
-                                p.get("Yri"), p.ldD, s0);
-        } else {  // conj(Q) Z_k = conj(Yc) (Z_k R^-H): the flagged bins' Z rows are solved in place first
-            launch_zsolve_flagged(p.get("Z"), p.ldS, p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.get<double>("cond_ok"), p.S, p.C,
-                                  p.P, k0, s0);
-            launch_yri_accurate(p.get("Yc"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
-                                p.get("Yri"), p.ldD, s0);
-        }
-        p.mark("yri_operands");
-    }
-}
-
-DenseSweepArgs emagls_dense_args(emagls_plan& p) {
-    const int k0 = std::max(p.kcut0, 1);
-    DenseSweepArgs a{};
-    a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
-    // the operand arrays start at bin k0: shift the base so that the kernels can index by kb
-    a.X = p.get<cplx>("G") - (int64_t)k0 * p.C * p.ldD; a.x_stride = (int64_t)p.C * p.ldD;
-    a.Zd = p.get<cplx>("Yri") - (int64_t)k0 * p.C * p.ldD; a.z_stride = (int64_t)p.C * p.ldD;
-    a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
-    a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.sweep_split ? p.nWG_split : p.nWG_dense; a.kfirst = k0;
-    return a;
+    // ill-conditioned swept bins: Y_reg_inv_k = conj(Q) Z_k = conj(Yc) (Z_k R^-H); the flagged bins' Z rows are solved in place first
+    launch_zsolve_flagged(p.get("Z"), p.ldS, p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.get<double>("cond_ok"), p.S, p.C,
+                          p.P, k0, s0);
+    launch_yri_accurate(p.get("Yc"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
+                        p.get("Yri"), p.ldD, s0);
+    p.mark("yri_operands");
 }
 
 HalfSweepArgs emagls_half_args(emagls_plan& p) {
@@ -708,82 +684,56 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
 
 // A persistent sweep needs all of its workgroups resident.  Two sweeps launched from different streams could each get a
 // part of the CUs and wait for the rest forever (the kernels would give up after their spin limit and report an
-// error), so all persistent sweeps of a process are chained through one event: a sweep is only launched behind the
+// error), so all persistent sweeps on a device are chained through one event: a sweep is only launched behind the
 // previous one.  The sweep is therefore never part of a captured graph (plans and batches capture the stages before it).
+// The chain state is per device and guarded by a mutex: plans of different host threads may sweep on the same GPU.
 struct SweepChain {
+    struct State { hipEvent_t ev = nullptr; bool recorded = false; };
+    static std::mutex& mutex() { static std::mutex m; return m; }
+    static State& state() {   // (call with the mutex held)
+        static std::map<int, State> per_device;
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        State& st = per_device[dev];
+        if (!st.ev) HIP_CHECK(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+        return st;
+    }
+    std::unique_lock<std::mutex> lock;
     hipStream_t st;
-    explicit SweepChain(hipStream_t s) : st(s) {
-        if (recorded()) HIP_CHECK(hipStreamWaitEvent(st, event(), 0));
+    explicit SweepChain(hipStream_t s) : lock(mutex()), st(s) {
+        State& c = state();
+        if (c.recorded) HIP_CHECK(hipStreamWaitEvent(st, c.ev, 0));
     }
-    ~SweepChain() {
-        if (hipEventRecord(event(), st) == hipSuccess) recorded() = true;
+    ~SweepChain() {   // (the lock is held from the wait to the record: no other sweep can slip in between)
+        try {
+            State& c = state();
+            if (hipEventRecord(c.ev, st) == hipSuccess) c.recorded = true;
+        } catch (...) {}
     }
-    static hipEvent_t& event() {
-        static hipEvent_t ev = nullptr;
-        if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        return ev;
-    }
-    static bool& recorded() { static bool r = false; return r; }
 };
 
 void emagls_run_sweep(emagls_plan& p) {
-    const bool cb = p.cplx_basis;
     hipStream_t s0 = p.stream;
     const int k0 = std::max(p.kcut0, 1);
-    if (p.sweep_factored) {
-        SweepArgs a{};
-        a.D = (int)p.D; a.S = p.S; a.C = p.C; a.ldS = p.ldS; a.P = p.P; a.ldQ = p.ldS;
-        a.Q = p.get("Q"); a.Z = p.get<cplx>("Z"); a.Bk = p.get<cplx>("Bk");
-        a.Habs = p.get<double>("Habs"); a.ldD = p.ldD; a.kabs0 = p.kcut0;
-        a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG; a.dpw = p.dpw;
-        a.kfirst = k0;
-        a.timing = p.has("sweep_timing") ? p.get<long long>("sweep_timing") : nullptr;
-        p.sweep_launches = 0;
-        for (int kb = k0; kb < p.P; ++kb) {
-            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
-            launch_sweep_factored(a, kb, cb, s0);
-            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
-            ++p.sweep_launches;
-        }
-        if (k0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, s0);
-    } else if (p.sweep_half && p.sweep_persist) {
-        HalfSweepMulti m{};
-        m.n = 1;
-        m.a[0] = emagls_half_args(p);
-        p.sweep_launches = 0;
-        if (k0 < p.P) {
-            SweepChain chain(s0);
-            launch_zero(p.get("ll"), p.bufs["ll"].bytes, s0);
-            if (p.prof_level >= 2) record_sweep_event(p, 0);
-            launch_sweep_persist(m, s0);
-            if (p.prof_level >= 2) record_sweep_event(p, 1);
-            p.sweep_launches = 1;
-        }
-    } else if (p.sweep_half) {
-        HalfSweepMulti m{};
-        m.n = 1;
-        m.a[0] = emagls_half_args(p);
-        p.sweep_launches = 0;
+    HalfSweepMulti m{};
+    m.n = 1;
+    m.a[0] = emagls_half_args(p);
+    p.sweep_launches = 0;
+    if (k0 < p.P && p.sweep_persist) {
+        SweepChain chain(s0);
+        launch_zero(p.get("ll"), p.bufs["ll"].bytes, s0);
+        if (p.prof_level >= 2) record_sweep_event(p, 0);
+        launch_sweep_persist(m, s0);
+        if (p.prof_level >= 2) record_sweep_event(p, 1);
+        p.sweep_launches = 1;
+    } else if (k0 < p.P) {
         for (int kb = k0; kb < p.P; ++kb) {
             if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
             launch_sweep_half(m, kb, s0);
             if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
             ++p.sweep_launches;
         }
-        if (k0 < p.P) launch_sweep_half_finalize(m, p.P - 1, s0);
-    } else {
-        const DenseSweepArgs a = emagls_dense_args(p);
-        DenseSweepMulti m{};
-        m.n = 1;
-        m.a[0] = a;
-        p.sweep_launches = 0;
-        for (int kb = k0; kb < p.P; ++kb) {
-            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
-            if (p.sweep_split) launch_sweep_split(m, kb, s0); else launch_sweep_dense(a, kb, true, s0);
-            if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
-            ++p.sweep_launches;
-        }
-        if (k0 < p.P && !p.sweep_split) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG_dense, p.C, p.P, p.P - 1, s0);
+        launch_sweep_half_finalize(m, p.P - 1, s0);
     }
     p.mark("magls_sweep");
 }
@@ -899,8 +849,7 @@ void plan_execute(emagls_plan& p) {
     if (array_kind(d.kind) && !p.have_mic_grid)
         throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
     if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
-    const bool persist = array_kind(d.kind) && p.sweep_half && p.sweep_persist &&
-                         !p.sweep_factored;
+    const bool persist = array_kind(d.kind) && p.sweep_persist;
     if (p.prof_level == 0 && p.use_graph && persist) {
         // the persistent sweep is launched directly (SweepChain); the stages before it are captured from the second
         // execute on (the first runs eagerly: one-time function attributes, lazy module load)
@@ -940,7 +889,6 @@ void plan_execute(emagls_plan& p) {
 
 void emagls_pre_sweep(emagls_plan& p);
 void emagls_post_sweep(emagls_plan& p);
-DenseSweepArgs emagls_dense_args(emagls_plan& p);
 // A batch runs as separate graphs on separate streams (one hipGraph executes its nodes in order, so
 // parallel branches inside ONE graph would serialize): per-plan "pre" graphs on the plans' own streams,
 // the shared sweep graph on the batch stream, ordered by events outside the graphs.
@@ -953,55 +901,22 @@ void plan_pre_stage(emagls_plan& p) {
     emagls_pre_sweep(p);
 }
 void batch_sweep_stage(emagls_batch& b) {
-    if (b.plans[0]->sweep_half) {
-        HalfSweepMulti h{};
-        h.n = (int)b.plans.size();
-        for (int j = 0; j < h.n; ++j) h.a[j] = emagls_half_args(*b.plans[j]);
-        emagls_plan& q0 = *b.plans[0];
-        const int kk0 = std::max(q0.kcut0, 1);
-        if (q0.sweep_persist) {
-            if (kk0 < q0.P) {
-                SweepChain chain(b.stream);
-                for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, b.stream);
-                if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[0], b.stream));
-                launch_sweep_persist(h, b.stream);
-                if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[1], b.stream));
-            }
-            return;
-        }
-        for (int kb = kk0; kb < q0.P; ++kb) launch_sweep_half(h, kb, b.stream);
-        if (kk0 < q0.P) launch_sweep_half_finalize(h, q0.P - 1, b.stream);
+    HalfSweepMulti h{};
+    h.n = (int)b.plans.size();
+    for (int j = 0; j < h.n; ++j) h.a[j] = emagls_half_args(*b.plans[j]);
+    emagls_plan& q0 = *b.plans[0];
+    const int kk0 = std::max(q0.kcut0, 1);
+    if (kk0 >= q0.P) return;
+    if (q0.sweep_persist) {
+        SweepChain chain(b.stream);
+        for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, b.stream);
+        if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[0], b.stream));
+        launch_sweep_persist(h, b.stream);
+        if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[1], b.stream));
         return;
     }
-    DenseSweepMulti m{};
-    m.n = (int)b.plans.size();
-    for (int j = 0; j < m.n; ++j) m.a[j] = emagls_dense_args(*b.plans[j]);
-    emagls_plan& p0 = *b.plans[0];
-    const int k0 = std::max(p0.kcut0, 1);
-    if (p0.sweep_split) {
-        for (int kb = k0; kb < p0.P; ++kb) launch_sweep_split(m, kb, b.stream);
-    } else {
-        for (int kb = k0; kb < p0.P; ++kb) launch_sweep_dense_multi(m, kb, b.stream);
-        if (k0 < p0.P) launch_sweep_finalize_multi(m, p0.P - 1, b.stream);
-    }
-}
-
-// lane mode: the pipeline of plan 0 is enqueued once on the batch stream with grid.z = designs
-// A persistent sweep needs all of its workgroups resident.  Two sweeps launched from different streams could each get a
-// part of the CUs and wait for the rest forever (the kernels would give up after their spin limit and report an
-// error), so the sweeps of all batches of a process are chained through one event: a sweep is only launched behind the
-// previous one.  The sweep is therefore not part of a batch's captured graphs.
-hipEvent_t& sweep_chain_event() {
-    static hipEvent_t ev = nullptr;
-    if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    return ev;
-}
-void batch_sweep_chained(emagls_batch& b) {
-    static bool recorded = false;
-    if (recorded) HIP_CHECK(hipStreamWaitEvent(b.stream, sweep_chain_event(), 0));
-    batch_sweep_stage(b);
-    HIP_CHECK(hipEventRecord(sweep_chain_event(), b.stream));
-    recorded = true;
+    for (int kb = kk0; kb < q0.P; ++kb) launch_sweep_half(h, kb, b.stream);
+    launch_sweep_half_finalize(h, q0.P - 1, b.stream);
 }
 
 // lane mode: the pipeline of plan 0 is enqueued once on the batch stream with grid.z = designs
@@ -1040,6 +955,8 @@ void batch_execute_lanes(emagls_batch& b) {
 
 void batch_execute(emagls_batch& b) {
     for (auto* p : b.plans)
+        if (!p) throw Error(EMAGLS_ERR_ARG, "a plan of this batch has been destroyed");
+    for (auto* p : b.plans)
         if (!p->have_hrir_grid || !p->have_hrirs || !p->have_mic_grid) throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grids and HRIRs");
     if (b.lanes) {
         batch_execute_lanes(b);
@@ -1071,26 +988,88 @@ void batch_execute(emagls_batch& b) {
 }
 
 void plan_execute(emagls_plan& p);
-void plan_check_flags(emagls_plan& p) {
-    int flag[4] = {0, 0, 0, 0};
-    HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
-    if (flag[2] && p.gram_route) {
-        // a Gram-route bin was worse conditioned than the kr estimate promised: redo the design on the Householder route
-        p.gram_route = false;
-        if (p.graph_exec) { HIP_CHECK(hipGraphExecDestroy(p.graph_exec)); p.graph_exec = nullptr; }
-        if (p.graph) { HIP_CHECK(hipGraphDestroy(p.graph)); p.graph = nullptr; }
-        if (p.pre_exec) { HIP_CHECK(hipGraphExecDestroy(p.pre_exec)); p.pre_exec = nullptr; }
-        if (p.pre_graph) { HIP_CHECK(hipGraphDestroy(p.pre_graph)); p.pre_graph = nullptr; }
-        p.eager_runs = 0;
-        plan_execute(p);
-        HIP_CHECK(hipStreamSynchronize(p.stream));
-        HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
+void batch_execute(emagls_batch& b);
+
+void drop_plan_graphs(emagls_plan& p) {
+    if (p.graph_exec) { HIP_CHECK(hipGraphExecDestroy(p.graph_exec)); p.graph_exec = nullptr; }
+    if (p.graph) { HIP_CHECK(hipGraphDestroy(p.graph)); p.graph = nullptr; }
+    if (p.pre_exec) { HIP_CHECK(hipGraphExecDestroy(p.pre_exec)); p.pre_exec = nullptr; }
+    if (p.pre_graph) { HIP_CHECK(hipGraphDestroy(p.pre_graph)); p.pre_graph = nullptr; }
+    p.eager_runs = 0;
+}
+void drop_batch_graphs(emagls_batch& b) {
+    if (b.graph_exec) { HIP_CHECK(hipGraphExecDestroy(b.graph_exec)); b.graph_exec = nullptr; }
+    if (b.graph) { HIP_CHECK(hipGraphDestroy(b.graph)); b.graph = nullptr; }
+    if (b.post_exec) { HIP_CHECK(hipGraphExecDestroy(b.post_exec)); b.post_exec = nullptr; }
+    if (b.post_graph) { HIP_CHECK(hipGraphDestroy(b.post_graph)); b.post_graph = nullptr; }
+    b.eager_runs = 0;
+}
+// Device-side status words of a design: [0] Cholesky pivot, [1] persistent sweep gave up waiting, [2] a Gram-route bin was
+// worse conditioned than the kr estimate promised.  [1] and [2] are recoverable: the design is re-run without the feature.
+// Returns true when the design has to be executed again; throws when a flag cannot be recovered from.
+bool plan_recover(emagls_plan& p, const int* flag, bool apply) {
+    bool redo = false;
+    if (flag[2]) {
+        if (!p.gram_route) throw Error(EMAGLS_ERR_NUMERIC, "internal: Gram-route conditioning flag although the route is off (stale graph)");
+        if (apply) p.gram_route = false;
+        redo = true;
     }
-    if (flag[1])
-        throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");
+    if (flag[1]) {
+        // not every workgroup of the persistent sweep became resident (CUs held by another process, partitioned device):
+        // the launch-per-bin sweep needs no co-residency
+        if (!p.sweep_persist) throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");
+        if (apply) p.sweep_persist = false;
+        redo = true;
+    }
+    return redo;
+}
+void throw_fatal_flags(const int* flag) {
+    if (flag[1]) throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");
+    if (flag[2]) throw Error(EMAGLS_ERR_NUMERIC, "per-bin factorisation: ill-conditioned bin on the Gram route after the re-run");
     if (flag[0])
         throw Error(EMAGLS_ERR_NUMERIC,
                     "SH Gram matrix of the HRIR grid is not positive definite (the grid cannot resolve the required SH order)");
+}
+// re-run a whole batch after one of its designs raised a recoverable flag: in lane mode all designs share the captured
+// graphs, so every plan of the batch changes its configuration together
+void batch_redo(emagls_batch& b, const std::vector<int>& flags) {
+    int any[4] = {0, 0, 0, 0};
+    for (size_t j = 0; j < b.plans.size(); ++j) for (int i = 0; i < 4; ++i) any[i] |= flags[4 * j + i];
+    for (auto* q : b.plans) { plan_recover(*q, any, true); drop_plan_graphs(*q); }
+    drop_batch_graphs(b);
+    batch_execute(b);
+    HIP_CHECK(hipStreamSynchronize(b.stream));
+}
+std::vector<int> batch_read_flags(emagls_batch& b) {
+    const size_t n = b.plans.size();
+    std::vector<int> flags(4 * n, 0);
+    for (size_t j = 0; j < n; ++j)
+        HIP_CHECK(hipMemcpyAsync(&flags[4 * j], b.plans[j]->get("flag"), 4 * sizeof(int), hipMemcpyDeviceToHost, b.stream));
+    HIP_CHECK(hipStreamSynchronize(b.stream));
+    return flags;
+}
+void plan_check_flags(emagls_plan& p) {
+    int flag[4] = {0, 0, 0, 0};
+    HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
+    if (plan_recover(p, flag, false)) {
+        if (p.owner) {   // a member of a batch: the batch re-runs as a whole (its graphs cover every member)
+            emagls_batch& b = *p.owner;
+            for (auto* q : b.plans) if (!q) throw Error(EMAGLS_ERR_ARG, "a plan of this batch has been destroyed");
+            batch_redo(b, batch_read_flags(b));
+        } else {
+            plan_recover(p, flag, true);
+            drop_plan_graphs(p);
+            plan_execute(p);
+            HIP_CHECK(hipStreamSynchronize(p.stream));
+        }
+        HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
+        if (plan_recover(p, flag, false)) {   // e.g. first the Gram route, then the persistent sweep
+            if (p.owner) batch_redo(*p.owner, batch_read_flags(*p.owner));
+            else { plan_recover(p, flag, true); drop_plan_graphs(p); plan_execute(p); HIP_CHECK(hipStreamSynchronize(p.stream)); }
+            HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
+        }
+    }
+    throw_fatal_flags(flag);
 }
 
 template <typename F> int guarded(F&& f) {
@@ -1144,6 +1123,13 @@ int emagls_device_count(int* count) {
 }
 int emagls_set_device(int device) {
     return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
+}
+
+int emagls_fp64_peak_tflops(int which, double* tflops) {
+    return guarded([&] {
+        if (!tflops || which < 0 || which > 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        *tflops = measure_fp64_peak(which, 3);
+    });
 }
 
 int emagls_sh_basis(int order, int64_t ndirs, const double* azi, const double* zen, int basis, void* Y) {
@@ -1325,6 +1311,9 @@ int emagls_plan_set_streams(emagls_plan* p, int nstreams) {
         HIP_CHECK(hipStreamSynchronize(p->stream));
         if (p->graph_exec) { HIP_CHECK(hipGraphExecDestroy(p->graph_exec)); p->graph_exec = nullptr; }
         if (p->graph) { HIP_CHECK(hipGraphDestroy(p->graph)); p->graph = nullptr; }
+        if (p->pre_exec) { HIP_CHECK(hipGraphExecDestroy(p->pre_exec)); p->pre_exec = nullptr; }
+        if (p->pre_graph) { HIP_CHECK(hipGraphDestroy(p->pre_graph)); p->pre_graph = nullptr; }
+        p->eager_runs = 0;   // (the next execute runs eagerly again, the one after it captures with the new stream count)
         p->nstreams = nstreams;
     });
 }
@@ -1385,7 +1374,7 @@ void* emagls_plan_stream(emagls_plan* p) { return p ? (void*)p->stream : nullptr
 void batch_try_lanes(emagls_batch& b) {
     if (const char* e = getenv("EMAGLS_BATCH_LANES")) if (e[0] == '0') return;
     emagls_plan& q = *b.plans[0];
-    if (!q.sweep_half || !q.sweep_persist) return;
+    if (!q.sweep_persist) return;
     for (auto* p : b.plans) {
         if (p->S != q.S || p->simOrder != q.simOrder || p->nOut != q.nOut || p->nfft != q.nfft || p->ldS != q.ldS || p->ldD != q.ldD ||
             p->Dpad != q.Dpad || p->k_cut != q.k_cut || p->cplx_basis != q.cplx_basis || p->out_cplx != q.out_cplx ||
@@ -1438,23 +1427,24 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
             emagls_plan* p = plans[j];
             if (!p) throw Error(EMAGLS_ERR_ARG, "null plan");
             if (!array_kind(p->d.kind)) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH plans");
-            if (p->sweep_factored) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches need the direction-space sweep");
+            if (p->owner) throw Error(EMAGLS_ERR_ARG, "a plan belongs to another batch (destroy that batch first)");
+            for (int i = 0; i < j; ++i) if (plans[i] == p) throw Error(EMAGLS_ERR_ARG, "the same plan appears twice in the batch");
             const emagls_plan* q = plans[0];
-            if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_split != q->sweep_split || p->sweep_half != q->sweep_half || p->sweep_persist != q->sweep_persist)
+            if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_persist != q->sweep_persist)
                 throw Error(EMAGLS_ERR_ARG, "all designs of a batch must have the same shape (directions, channels, bins, k_cut)");
             b->plans.push_back(p);
         }
         HIP_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
         if (const char* ng = getenv("EMAGLS_NO_GRAPH")) b->use_graph = !(ng[0] == '1');
-        bool can_split = true;
-        for (auto* p : b->plans) can_split = can_split && p->nWG_split <= 256 && 2 * p->C <= 64;
-        if (const char* e = getenv("EMAGLS_SWEEP_SPLIT")) can_split = can_split && e[0] != '0';
+        // one persistent sweep launch keeps designs x nWG workgroups resident, one per CU
+        const bool fits = nplans * persist_sweep_nwg((int)b->plans[0]->D) <= device_cu_count();
         for (auto* p : b->plans) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
-            p->sweep_split = !p->sweep_half && can_split && b->plans.size() > 1;
+            if (!fits) p->sweep_persist = false;
             p->nstreams = 1;
             p->prof_level = 0;
             p->sync_stream = b->stream;
+            p->owner = b.get();
         }
         batch_try_lanes(*b);
         *batch = b.release();
@@ -1478,13 +1468,14 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
         const size_t n = b->plans.size();
         for (size_t j = 0; j < n; ++j) {
             if (!wL[j] || !wR[j]) throw Error(EMAGLS_ERR_ARG, "null pointer");
+            if (!b->plans[j]) throw Error(EMAGLS_ERR_ARG, "a plan of this batch has been destroyed");
             if (!b->plans[j]->executed) throw Error(EMAGLS_ERR_ARG, "batch has not been executed");
         }
         emagls_plan& p0 = *b->plans[0];
         const size_t bytes = (p0.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p0.out_rows * p0.out_cols;
         // the copies are ordered behind the batch on its stream; one synchronisation for everything
         std::vector<int> flags(4 * n, 0);
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 3; ++attempt) {
             if (b->lanes)
                 HIP_CHECK(hipMemcpy2DAsync(flags.data(), 4 * sizeof(int), p0.get("flag"), b->stride, 4 * sizeof(int), n,
                                            hipMemcpyDeviceToHost, b->stream));
@@ -1497,27 +1488,12 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
             }
             HIP_CHECK(hipStreamSynchronize(b->stream));
             bool redo = false;
-            for (size_t j = 0; j < n; ++j) redo = redo || (flags[4 * j + 2] && b->plans[j]->gram_route);
+            for (size_t j = 0; j < n; ++j) redo = plan_recover(*b->plans[j], &flags[4 * j], false) || redo;
             if (!redo) break;
-            // a Gram-route bin was worse conditioned than the kr estimate promised: redo the batch on the Householder route
-            for (auto* q : b->plans) {
-                q->gram_route = false;
-                if (q->pre_exec) { HIP_CHECK(hipGraphExecDestroy(q->pre_exec)); q->pre_exec = nullptr; }
-                if (q->pre_graph) { HIP_CHECK(hipGraphDestroy(q->pre_graph)); q->pre_graph = nullptr; }
-            }
-            if (b->graph_exec) { HIP_CHECK(hipGraphExecDestroy(b->graph_exec)); b->graph_exec = nullptr; }
-            if (b->graph) { HIP_CHECK(hipGraphDestroy(b->graph)); b->graph = nullptr; }
-            if (b->post_exec) { HIP_CHECK(hipGraphExecDestroy(b->post_exec)); b->post_exec = nullptr; }
-            if (b->post_graph) { HIP_CHECK(hipGraphDestroy(b->post_graph)); b->post_graph = nullptr; }
-            b->eager_runs = 0;
-            batch_execute(*b);
+            // recoverable: a Gram-route bin worse conditioned than estimated, or a persistent sweep that did not become resident
+            batch_redo(*b, flags);
         }
-        for (size_t j = 0; j < n; ++j) {
-            if (flags[4 * j + 1])
-                throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");
-            if (flags[4 * j])
-                throw Error(EMAGLS_ERR_NUMERIC, "SH Gram matrix of the HRIR grid is not positive definite (the grid cannot resolve the required SH order)");
-        }
+        for (size_t j = 0; j < n; ++j) throw_fatal_flags(&flags[4 * j]);
     });
 }
 int emagls_batch_set_profiling(emagls_batch* b, int level) {

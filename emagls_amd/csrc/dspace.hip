@@ -3,12 +3,12 @@
 //
 //   G_k   = pwGrid_k.' = Q B_k = sum_n b_n(k) (Q T_n)            [D x C]   -- exact, 20 cMAC per entry
 //   Yri_k = Y_reg_inv_k = conj(U_k) diag(s_reg) V^T
-//         = conj(G_k) conj(M_k),  M_k = V diag(s_reg/s) V^H       [D x C]   -- U_k = G_k V S^-1
+//         = conj(G_k) conj(M_k),  M_k = V diag(s_reg/s) V^H       [D x C]   -- U_k = G_k V S^-1 (applied inside the sweep)
 //
 // The second identity forms U_k from G_k V S^-1, which is only as orthonormal as eps*cond(G_k).  That is
 // harmless for the swept bins (k >= k_cut, f >= 1 kHz: cond ~ 1e2..1e3, error ~ eps*100*cond), and the
 // least-squares bins below k_cut -- where cond reaches 1e13 -- never take this route (factor.hip).
-// Bins whose condition number exceeds COND_LIMIT are recomputed from the orthonormal S-space factor
+// Bins whose condition number exceeds COND_LIMIT get their Yri_k from the orthonormal S-space factor
 // (Yri_k = conj(Q) Z_k) by yri_accurate_kernel.
 //
 // Why direction space: a launch starts with cold L2 (kernel boundaries invalidate it), so the per-launch
@@ -212,34 +212,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     }
 }
 
-// Yri kernel: one workgroup = one swept bin x 256 directions; thread = direction.
-//   Yri[c][d] = conj( sum_c' G[c'][d] M[c'][c] )      M_k staged in LDS (broadcast reads)
-__global__ void __launch_bounds__(256) dspace_yri_kernel(const cplx* __restrict__ G, int64_t ldD, const cplx* __restrict__ Mw,
-                                                         int kb0_factor, const double* __restrict__ cond_ok, int D, int C,
-                                                         int k0, cplx* __restrict__ Yri, size_t bstride) {
-    G = boff(G, bstride); Mw = boff(Mw, bstride); cond_ok = boff(cond_ok, bstride); Yri = boff(Yri, bstride);
-    __shared__ __attribute__((aligned(16))) cplx ms[SW_CMAX_ * SW_CMAX_];
-    const int kb = k0 + blockIdx.y;
-    if (cond_ok[kb] == 0.0) return;  // ill-conditioned bin: yri_accurate_kernel handles it
-    const cplx* M = Mw + (int64_t)(kb - kb0_factor) * C * C;
-    for (int idx = threadIdx.x; idx < C * C; idx += 256) ms[idx] = M[idx];
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    cplx g[SW_CMAX_];
-#pragma unroll
-    for (int c = 0; c < SW_CMAX_; ++c) g[c] = (c < C && d < D) ? G[((int64_t)(kb - k0) * C + c) * ldD + d] : mk(0, 0);
-    __syncthreads();
-    if (d >= D) return;
-    for (int c = 0; c < C; ++c) {
-        cplx a0 = mk(0, 0), a1 = mk(0, 0);
-#pragma unroll
-        for (int cc = 0; cc < SW_CMAX_; cc += 2) {
-            if (cc < C) cfma(a0, g[cc], ms[cc * C + c]);
-            if (cc + 1 < C) cfma(a1, g[cc + 1], ms[(cc + 1) * C + c]);
-        }
-        Yri[((int64_t)(kb - k0) * C + c) * ldD + d] = conj(a0 + a1);
-    }
-}
-
 // cond_ok[kb] = 1 when smax <= COND_LIMIT * smin for bin kb (the cheap identity is accurate), else 0
 __global__ void cond_flag_kernel(const double* __restrict__ sv, int C, int P, double* __restrict__ cond_ok, size_t bstride) {
     sv = boff(sv, bstride); cond_ok = boff(cond_ok, bstride);
@@ -312,8 +284,7 @@ void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, 
                      hipStream_t st, int real_mode, int sh_order) {
     if (is_cplx && real_mode && nOrders <= DSP_NMAX && C <= 64 && P - k0 > 0) {
         int chunks = 8;    // 8-design launch: 2 -> 929, 4 -> 896, 8 -> 894, 12 -> 1032, 16 -> 1115, 24 -> 1385 us (every chunk re-reads QT)
-        if (const char* e = getenv("EMAGLS_DSP_CHUNKS")) chunks = std::max(1, atoi(e));
-        static const bool nt = [] { const char* e = getenv("EMAGLS_DSP_NT"); return !(e && e[0] == '0'); }();  // streaming stores
+        const bool nt = true;  // streaming stores: G is written once here and read once by the sweep
         const int nbins = P - k0;
         const int nmax = nOrders <= 12 ? 12 : nOrders <= 20 ? 20 : DSP_NMAX;   // orders held in registers (table rows padded to it)
         while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nmax > 56 * 1024) ++chunks;
@@ -335,17 +306,6 @@ void launch_cond_flags(const double* sv, int C, int P, double* cond_ok, hipStrea
     cond_flag_kernel<<<bgrid((P + 255) / 256), 256, 0, st>>>(sv, C, P, cond_ok, batch_ctx().stride);
     KERNEL_CHECK();
 }
-void launch_dspace_yri(const void* G, int64_t ldD, const void* Mw, int kb0_factor, const double* sv, double* cond_ok, int D, int C,
-                       int P, int k0, void* Yri, hipStream_t st) {
-    const int nbins = P - k0;
-    if (nbins <= 0) return;
-    cond_flag_kernel<<<bgrid((P + 255) / 256), 256, 0, st>>>(sv, C, P, cond_ok, batch_ctx().stride);
-    KERNEL_CHECK();
-    dspace_yri_kernel<<<bgrid(dim3((unsigned)ceil_div(D, 256), nbins)), 256, 0, st>>>((const cplx*)G, ldD, (const cplx*)Mw, kb0_factor,
-                                                                              cond_ok, D, C, k0, (cplx*)Yri, batch_ctx().stride);
-    KERNEL_CHECK();
-}
-
 void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S, int C,
                          int P, int k0, void* Yri, int64_t ldD, hipStream_t st) {
     if (P - k0 <= 0) return;

@@ -20,7 +20,7 @@ namespace emagls {
 // batches: shift every pointer of the argument block to design z
 __device__ __forceinline__ void batch_offset(FactorArgs& a, size_t bstride, unsigned z) {
     a.Tn = boff_flat(a.Tn, bstride, z); a.bn = boff_flat(a.bn, bstride, z); a.Xd = boff_flat(a.Xd, bstride, z);
-    a.Z = boff_flat(a.Z, bstride, z); a.Bk = boff_flat(a.Bk, bstride, z); a.Vws = boff_flat(a.Vws, bstride, z); a.sv = boff_flat(a.sv, bstride, z);
+    a.Z = boff_flat(a.Z, bstride, z); a.Vws = boff_flat(a.Vws, bstride, z); a.sv = boff_flat(a.sv, bstride, z);
     a.Hq = boff_flat(a.Hq, bstride, z); a.cond_ok = boff_flat(a.cond_ok, bstride, z); a.W = boff_flat(a.W, bstride, z); a.sweeps_out = boff_flat(a.sweeps_out, bstride, z);
     a.route = boff_flat(a.route, bstride, z); a.status = boff_flat(a.status, bstride, z);
     a.tauw = boff_flat(a.tauw, bstride, z); a.R2w = boff_flat(a.R2w, bstride, z); a.Nw = boff_flat(a.Nw, bstride, z); a.Mw = boff_flat(a.Mw, bstride, z);
@@ -82,13 +82,6 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
         for (int i = 0; i < RPT; ++i) {
             const int s = ch + NCH * i;
             B[i] = (active && s < S) ? X[(int64_t)c * ldS + s] : mk(0, 0);
-        }
-    }
-    if (a.Bk && kb >= a.bk_from && active) {
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int s = ch + NCH * i;
-            if (s < S) a.Bk[((int64_t)kb * C + c) * ldS + s] = B[i];
         }
     }
     // ------------------------------------------------------------------ 1b. Gram route

@@ -52,15 +52,11 @@ struct FactorArgs;
 void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st, int phases = 3);
 
 // ---- sweep.hip
-struct SweepArgs;
 struct DenseSweepArgs;
-struct DenseSweepMulti;
 struct HalfSweepArgs;
 struct HalfSweepMulti;
-void launch_sweep_factored(const SweepArgs& a, int kb, bool q_cplx, hipStream_t st);
 void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st);
 int dense_sweep_nwg(int D);
-int slab_sweep_nwg(int D);
 void launch_sweep_half(const HalfSweepMulti& m, int kb, hipStream_t st);
 void launch_sweep_half_finalize(const HalfSweepMulti& m, int kb_last, hipStream_t st);
 // ---- sweep_persist.hip
@@ -68,12 +64,7 @@ int persist_sweep_nwg(int D);
 bool persist_sweep_supported(int D, int C);
 size_t persist_sweep_ll_bytes(int D, int C);
 void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st);
-void launch_sweep_split(const DenseSweepMulti& m, int kb, hipStream_t st);
-void launch_sweep_dense_multi(const DenseSweepMulti& m, int kb, hipStream_t st);
-void launch_sweep_finalize_multi(const DenseSweepMulti& m, int kb_last, hipStream_t st);
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
-void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
-               int kb_hi, void* Hq, int ldS, hipStream_t st, bool store_conj = false);
 void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, bool y_cplx, int D, int S, void* Pw, void* out,
                     int ldS, hipStream_t st);
 size_t hy_workspace_elems(int nrows, int ldS);
@@ -97,8 +88,6 @@ void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
                      hipStream_t st, int real_mode = 0, int sh_order = -1);
 void launch_cond_flags(const double* sv, int C, int P, double* cond_ok, hipStream_t st);
-void launch_dspace_yri(const void* G, int64_t ldD, const void* Mw, int kb0_factor, const double* sv, double* cond_ok, int D, int C,
-                       int P, int k0, void* Yri, hipStream_t st);
 void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S,
                          int C, int P, int k0, void* Yri, int64_t ldD, hipStream_t st);
 
@@ -106,6 +95,9 @@ void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z
 void launch_grid_match(const double* aziA, const double* zenA, int64_t nA, const double* aziB, const double* zenB,
                        int64_t nB, double* cartB, int64_t* idx, double* dev_deg, double* mean_dev, hipStream_t st);
 void launch_atf_colidx(const int64_t* idx, int64_t nA, int M, int64_t* colidx, hipStream_t st);
+
+// ---- microbench.hip
+double measure_fp64_peak(int which, int reps);
 
 // ---- decode.hip
 void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL, const double* wR, int64_t len,

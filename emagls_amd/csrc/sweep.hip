@@ -1,12 +1,11 @@
-// The sequential magnitude-least-squares phase sweep (one launch per frequency bin) and the
-// small dense products around it.
+// The sequential magnitude-least-squares phase sweep in its launch-per-bin forms and the small dense products
+// around it.  (The array designs sweep with the persistent kernel of sweep_persist.hip; the kernels here serve
+// MagLS / FromAtf, shapes the persistent kernel does not cover, and EMAGLS_SWEEP_PERSIST=0.)
 //
 // Reference (lib/getEMagLsFilters.m:95-103):
 //     phi = angle(W(k-1,:) * pwGrid);   W(k,:) = (abs(H(k,:)) .* exp(1i*phi)) * Y_reg_inv;
-// With pwGrid.' = Q B_k and Y_reg_inv = conj(Q) Z_k:
-//     z = W(k-1,:) B_k^T (1xS) ; p = Q z ; t = |H| p/|p| ; u = t conj(Q) (1xS) ; W(k,:) = u Z_k.
 // exp(1i*angle(p)) is evaluated as p/|p| (1 when p == 0, as angle(0) = 0); Nyquist takes real(t).
-// Each workgroup owns a slab of directions; its partial W(k,:) goes to a [nWG][2][C] buffer that the
+// Each workgroup owns a slab of directions; its partial W(k,:) goes to a [pair][nWG] buffer that the
 // next launch sums first (the launch boundary is the grid-wide barrier and the release/acquire).
 #include "kernels.hpp"
 
@@ -57,227 +56,6 @@ __device__ __forceinline__ void gather_prev(cplx* Wp, const cplx* Wpart_prev, cp
 }
 
 constexpr int SW_CMAX = 32;
-
-// LDS plan of the factored sweep kernel (complex elements):
-//   zu   [2][ldS]                       z, later the reduced u
-//   big  max(2C*(nWG+1), 8*2*ldS)       staged partial sums of the previous launch, later the per-wave u slabs
-__host__ __device__ inline size_t sweep_lds_elems(int ldS, int C, int nWG) {
-    const size_t g = (size_t)2 * C * (nWG + 1), sl = (size_t)(SW_NT / 64) * 2 * ldS;
-    return (size_t)2 * ldS + (g > sl ? g : sl);
-}
-
-template <typename TQ, int RS, int NL>
-__global__ void __launch_bounds__(SW_NT) sweep_factored_kernel(SweepArgs a, int kb) {
-    __shared__ __attribute__((aligned(16))) cplx Wp[64];
-    extern __shared__ __attribute__((aligned(16))) char dyn[];
-    cplx* zu = reinterpret_cast<cplx*>(dyn);  // [2][ldS]
-    cplx* big = zu + 2 * a.ldS;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int S = a.S, C = a.C, ldS = a.ldS, nWG = a.nWG;
-    const bool nyq = (kb == a.P - 1);
-    const bool first = (kb == a.kfirst);
-    const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * nWG * 2 * C;
-    cplx* Wout = a.Wpart + (int64_t)(kb & 1) * nWG * 2 * C;
-    const TQ* Q = reinterpret_cast<const TQ*>(a.Q);
-    const int64_t d0 = (int64_t)blockIdx.x * a.dpw;
-    const int64_t na = a.P - a.kabs0;
-    const double* HaL = a.Habs + ((int64_t)0 * na + (kb - a.kabs0)) * a.ldD;
-    const double* HaR = a.Habs + ((int64_t)1 * na + (kb - a.kabs0)) * a.ldD;
-#define STAMP(i) do { if (a.timing && blockIdx.x == 7 && tid == 0) a.timing[(int64_t)kb * 16 + (i)] = (i) == 15 ? (long long)wall_clock64() : (long long)clock64(); } while (0)
-    STAMP(0);
-    STAMP(15);
-    if (nWG > 64 * NL) return;  // host guarantees nWG <= 64*NL
-
-    // ---- 0. issue every load of this launch's head: the previous launch's partial sums first (they gate
-    //         everything; memory returns in order), then the operands that do not depend on W(k-1)
-    constexpr int NGV = (2 * SW_CMAX * 64 * NL) / SW_NT;  // staged partials per thread
-    const int npart = 2 * C * nWG;
-    cplx gv[NGV];
-#pragma unroll
-    for (int i = 0; i < NGV; ++i) {
-        const int f = tid + SW_NT * i;
-        gv[i] = (!first && f < npart) ? Wprev[f] : mk(0, 0);
-    }
-    if (a.timing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(10); }
-    const cplx* Bk = a.Bk + (int64_t)kb * C * ldS;
-    cplx breg[SW_CMAX];
-    const int sz = tid;  // this thread's row of B_k (S <= 512 handled here, the rest in a loop below)
-#pragma unroll
-    for (int c = 0; c < SW_CMAX; ++c) breg[c] = (c < C && sz < S) ? Bk[(int64_t)c * ldS + sz] : mk(0, 0);
-    if (a.timing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(11); }
-    TQ q[RS];
-    double h0 = 0.0, h1 = 0.0;
-    {
-        const int64_t d = d0 + wave;
-        const bool ok = wave < a.dpw && d < a.D;
-#pragma unroll
-        for (int i = 0; i < RS; ++i) {
-            const int s = lane + 64 * i;
-            q[i] = (ok && s < S) ? Q[d * a.ldQ + s] : zero_of<TQ>();
-        }
-        if (ok) { h0 = HaL[d]; h1 = HaR[d]; }
-    }
-    if (a.timing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(12); }
-    STAMP(1);
-    // ---- 1. W(k-1)[pair] = sum over workgroups of the staged partials (row stride nWG+1 against bank conflicts)
-#pragma unroll
-    for (int i = 0; i < NGV; ++i) {
-        const int f = tid + SW_NT * i;
-        if (f < npart) big[f + f / nWG] = gv[i];
-    }
-    __syncthreads();
-    {
-        const int pair = tid >> 3, part = tid & 7;
-        if (pair < 2 * C) {
-            const int e = pair / C, c = pair % C;
-            cplx acc = mk(0, 0);
-            if (first) {
-                if (part == 0) acc = a.W[((int64_t)e * a.P + (kb - 1)) * C + c];
-            } else {
-                const cplx* row = big + (size_t)pair * (nWG + 1);
-                cplx a0 = mk(0, 0), a1 = mk(0, 0);
-                for (int w = part; w < nWG; w += 16) {
-                    a0 += row[w];
-                    if (w + 8 < nWG) a1 += row[w + 8];
-                }
-                acc = a0 + a1;
-            }
-            acc = group_sum<8>(acc);
-            if (part == 0) {
-                Wp[pair] = acc;
-                if (blockIdx.x == 0 && !first) a.W[((int64_t)e * a.P + (kb - 1)) * C + c] = acc;
-            }
-        }
-    }
-    STAMP(2);
-    __syncthreads();
-    STAMP(3);
-    // ---- 2. z[e][s] = sum_c W(k-1)[e][c] B_k[c][s]
-    if (sz < S) {
-        cplx z0a = mk(0, 0), z0b = mk(0, 0), z1a = mk(0, 0), z1b = mk(0, 0);
-#pragma unroll
-        for (int c = 0; c < SW_CMAX; c += 2) {
-            if (c < C) { cfma(z0a, Wp[c], breg[c]); cfma(z1a, Wp[C + c], breg[c]); }
-            if (c + 1 < C) { cfma(z0b, Wp[c + 1], breg[c + 1]); cfma(z1b, Wp[C + c + 1], breg[c + 1]); }
-        }
-        zu[sz] = z0a + z0b;
-        zu[ldS + sz] = z1a + z1b;
-    }
-    for (int s = tid + SW_NT; s < S; s += SW_NT) {
-        cplx z0 = mk(0, 0), z1 = mk(0, 0);
-        for (int c = 0; c < C; ++c) {
-            const cplx b = Bk[(int64_t)c * ldS + s];
-            cfma(z0, Wp[c], b);
-            cfma(z1, Wp[C + c], b);
-        }
-        zu[s] = z0;
-        zu[ldS + s] = z1;
-    }
-    STAMP(4);
-    __syncthreads();
-    STAMP(5);
-    cplx z0[RS], z1[RS], u0[RS], u1[RS];
-#pragma unroll
-    for (int i = 0; i < RS; ++i) {
-        const int s = lane + 64 * i;
-        z0[i] = (s < S) ? zu[s] : mk(0, 0);
-        z1[i] = (s < S) ? zu[ldS + s] : mk(0, 0);
-        u0[i] = mk(0, 0);
-        u1[i] = mk(0, 0);
-    }
-    // ---- 3. this wave's directions: p = Q z, t = |H| p/|p|, u += t conj(q); next direction prefetched
-    for (int dd = wave; dd < a.dpw; dd += SW_NT / 64) {
-        const int64_t d = d0 + dd;
-        if (d >= a.D) break;
-        TQ qn[RS];
-        double hn0 = 0.0, hn1 = 0.0;
-        {
-            const int64_t dn = d + SW_NT / 64;
-            const bool ok = dd + SW_NT / 64 < a.dpw && dn < a.D;
-#pragma unroll
-            for (int i = 0; i < RS; ++i) {
-                const int s = lane + 64 * i;
-                qn[i] = (ok && s < S) ? Q[dn * a.ldQ + s] : zero_of<TQ>();
-            }
-            if (ok) { hn0 = HaL[dn]; hn1 = HaR[dn]; }
-        }
-        cplx p0 = mk(0, 0), p1 = mk(0, 0);
-#pragma unroll
-        for (int i = 0; i < RS; ++i) { cfma(p0, z0[i], q[i]); cfma(p1, z1[i], q[i]); }
-        p0 = wave_sum(p0);
-        p1 = wave_sum(p1);
-        const cplx t0 = unit_phase_times(h0, p0, nyq);
-        const cplx t1 = unit_phase_times(h1, p1, nyq);
-#pragma unroll
-        for (int i = 0; i < RS; ++i) {
-            const TQ qc = conj(q[i]);
-            cfma(u0[i], t0, qc);
-            cfma(u1[i], t1, qc);
-            q[i] = qn[i];
-        }
-        h0 = hn0; h1 = hn1;
-    }
-    STAMP(6);
-    // ---- 4. Z_k loads for this wave's channels go out before the cross-wave reduction of u
-    constexpr int NCW = SW_CMAX / (SW_NT / 64);  // channels per wave (4)
-    const cplx* Zk = a.Z + (int64_t)kb * C * ldS;
-    cplx zv[NCW][RS];
-#pragma unroll
-    for (int j = 0; j < NCW; ++j) {
-        const int c = wave + (SW_NT / 64) * j;
-#pragma unroll
-        for (int i = 0; i < RS; ++i) {
-            const int s = lane + 64 * i;
-            zv[j][i] = (c < C && s < S) ? Zk[(int64_t)c * ldS + s] : mk(0, 0);
-        }
-    }
-    STAMP(7);
-    // deterministic cross-wave reduction of u: per-wave slabs, barrier, fixed-order column sums, barrier
-    {
-        cplx* slab = big + (size_t)wave * 2 * ldS;
-#pragma unroll
-        for (int i = 0; i < RS; ++i) {
-            const int s = lane + 64 * i;
-            if (s < S) { slab[s] = u0[i]; slab[ldS + s] = u1[i]; }
-        }
-    }
-    __syncthreads();
-    for (int s = tid; s < S; s += SW_NT) {
-        cplx a0 = mk(0, 0), a1 = mk(0, 0);
-#pragma unroll
-        for (int w = 0; w < SW_NT / 64; ++w) {
-            a0 += big[(size_t)w * 2 * ldS + s];
-            a1 += big[(size_t)w * 2 * ldS + ldS + s];
-        }
-        zu[s] = a0;
-        zu[ldS + s] = a1;
-    }
-    __syncthreads();
-    STAMP(8);
-#pragma unroll
-    for (int i = 0; i < RS; ++i) {
-        const int s = lane + 64 * i;
-        u0[i] = (s < S) ? zu[s] : mk(0, 0);
-        u1[i] = (s < S) ? zu[ldS + s] : mk(0, 0);
-    }
-    // ---- 5. partial W(k,:) = u Z_k
-#pragma unroll
-    for (int j = 0; j < NCW; ++j) {
-        const int c = wave + (SW_NT / 64) * j;
-        cplx w0 = mk(0, 0), w1 = mk(0, 0);
-#pragma unroll
-        for (int i = 0; i < RS; ++i) { cfma(w0, u0[i], zv[j][i]); cfma(w1, u1[i], zv[j][i]); }
-        w0 = wave_sum(w0);
-        w1 = wave_sum(w1);
-        if (lane == 0 && c < C) {
-            Wout[((int64_t)0 * C + c) * nWG + blockIdx.x] = w0;
-            Wout[((int64_t)1 * C + c) * nWG + blockIdx.x] = w1;
-        }
-    }
-    STAMP(9);
-    if (a.timing && blockIdx.x == 7 && tid == 0) a.timing[(int64_t)kb * 16 + 14] = (long long)wall_clock64();
-#undef STAMP
-}
 
 // ---------------------------------------------------------------------------------------------
 // dense sweep: pwGrid_k given directly as X[kb][c][d] and Y_reg_inv_k as Zd[kb][c][d]
@@ -385,28 +163,6 @@ __global__ void __launch_bounds__(DS_NT) sweep_dense_kernel(DenseSweepArgs a, in
     __shared__ __attribute__((aligned(16))) cplx ts[2][DS_DPW];
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     sweep_dense_body<TX>(a, kb, Wp, ts, reinterpret_cast<cplx*>(dyn));
-}
-
-// several independent designs of identical shape in one launch: blockIdx.y selects the design
-template <typename TX>
-__global__ void __launch_bounds__(DS_NT) sweep_dense_multi_kernel(DenseSweepMulti m, int kb) {
-    __shared__ __attribute__((aligned(16))) cplx Wp[64];
-    __shared__ __attribute__((aligned(16))) cplx ts[2][DS_DPW];
-    extern __shared__ __attribute__((aligned(16))) char dyn[];
-    sweep_dense_body<TX>(m.a[blockIdx.y], kb, Wp, ts, reinterpret_cast<cplx*>(dyn));
-}
-__global__ void __launch_bounds__(SW_NT) sweep_finalize_multi_kernel(DenseSweepMulti m, int kb_last) {
-    const DenseSweepArgs& a = m.a[blockIdx.x];  // blockIdx.x is the design
-    const cplx* Wprev = a.Wpart + (int64_t)(kb_last & 1) * a.nWG * 2 * a.C;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    for (int pair = wave; pair < 2 * a.C; pair += nwaves) {
-        const int e = pair / a.C, c = pair % a.C;
-        const cplx* src = Wprev + (int64_t)pair * a.nWG;
-        cplx acc = mk(0, 0);
-        for (int w = lane; w < a.nWG; w += 64) acc += src[w];
-        acc = group_sum<64>(acc);
-        if (lane == 0) a.W[((int64_t)e * a.P + kb_last) * a.C + c] = acc;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -599,133 +355,12 @@ void launch_sweep_half_finalize(const HalfSweepMulti& m, int kb_last, hipStream_
     KERNEL_CHECK();
 }
 
-// ---------------------------------------------------------------------------------------------
-// Split sweep: two tiny kernels per bin instead of one kernel in which every workgroup re-reads all
-// partial sums (a launch starts with cold L2, so per-launch time is set by the bytes each workgroup fetches).
-//   slab kernel   (nWG x designs workgroups of one wave): reads W(k-1) (800 B), its 22-direction slabs of
-//                 pwGrid_k and Y_reg_inv_k, writes its partial W(k)          -> Wpart[pair][wg]
-//   reduce kernel (2C x designs workgroups of one wave):  W(k)[pair] = sum_wg Wpart[pair][wg]
-// ---------------------------------------------------------------------------------------------
-constexpr int SL_TD = 22;  // directions per workgroup (44 of the 64 lanes form p, 2C <= 64 lanes form the partial)
-
-__global__ void __launch_bounds__(64) sweep_slab_kernel(DenseSweepMulti m, int kb) {
-    const DenseSweepArgs& a = m.a[blockIdx.y];
-    __shared__ __attribute__((aligned(16))) cplx Wp[64];
-    __shared__ __attribute__((aligned(16))) cplx ts[2][SL_TD];
-    const int lane = threadIdx.x;
-    const int C = a.C;
-    const bool nyq = (kb == a.P - 1);
-    const cplx* X = reinterpret_cast<const cplx*>(a.X) + (int64_t)kb * a.x_stride;
-    const cplx* Zd = reinterpret_cast<const cplx*>(a.Zd) + (int64_t)kb * a.z_stride;
-    const int64_t d0 = (int64_t)blockIdx.x * SL_TD;
-    const int64_t na = a.P - a.kabs0;
-    // W(k-1): the only load that depends on the previous launch goes out first
-    cplx wprev = mk(0, 0);
-    if (lane < 2 * C) wprev = a.W[((int64_t)(lane / C) * a.P + (kb - 1)) * C + lane % C];
-    const int e_ = lane / SL_TD, dd_ = lane % SL_TD;
-    const int64_t d_ = d0 + dd_;
-    const bool p1 = lane < 2 * SL_TD && d_ < a.D;
-    cplx xr[SW_CMAX];
-#pragma unroll
-    for (int c = 0; c < SW_CMAX; ++c) xr[c] = (p1 && c < C) ? X[(int64_t)c * a.ldD + d_] : mk(0, 0);
-    const double habs = p1 ? a.Habs[((int64_t)e_ * na + (kb - a.kabs0)) * a.ldH + d_] : 0.0;
-    const int e2 = lane / C, c2 = lane % C;
-    const bool p2 = lane < 2 * C;
-    cplx zr[SL_TD];
-#pragma unroll
-    for (int j = 0; j < SL_TD; ++j) zr[j] = (p2 && d0 + j < a.D) ? Zd[(int64_t)c2 * a.ldD + d0 + j] : mk(0, 0);
-    if (p2) Wp[lane] = wprev;
-    __syncthreads();
-    if (lane < 2 * SL_TD) {
-        cplx t = mk(0, 0);
-        if (p1) {
-            cplx pa = mk(0, 0), pb = mk(0, 0);
-#pragma unroll
-            for (int c = 0; c < SW_CMAX; c += 2) {
-                if (c < C) cfma(pa, Wp[e_ * C + c], xr[c]);
-                if (c + 1 < C) cfma(pb, Wp[e_ * C + c + 1], xr[c + 1]);
-            }
-            t = unit_phase_times(habs, pa + pb, nyq);
-        }
-        ts[e_][dd_] = t;
-    }
-    __syncthreads();
-    if (p2) {
-        cplx a0 = mk(0, 0), a1 = mk(0, 0);
-#pragma unroll
-        for (int j = 0; j < SL_TD; j += 2) {
-            cfma(a0, ts[e2][j], zr[j]);
-            if (j + 1 < SL_TD) cfma(a1, ts[e2][j + 1], zr[j + 1]);
-        }
-        a.Wpart[(int64_t)lane * a.nWG + blockIdx.x] = a0 + a1;
-    }
-}
-
-__global__ void __launch_bounds__(64) sweep_reduce_kernel(DenseSweepMulti m, int kb) {
-    const DenseSweepArgs& a = m.a[blockIdx.y];
-    const int pair = blockIdx.x, lane = threadIdx.x;
-    const cplx* src = a.Wpart + (int64_t)pair * a.nWG;
-    cplx v0 = mk(0, 0), v1 = mk(0, 0), v2 = mk(0, 0), v3 = mk(0, 0);
-    if (lane < a.nWG) v0 = src[lane];
-    if (lane + 64 < a.nWG) v1 = src[lane + 64];
-    if (lane + 128 < a.nWG) v2 = src[lane + 128];
-    if (lane + 192 < a.nWG) v3 = src[lane + 192];
-    cplx acc = (v0 + v1) + (v2 + v3);
-    acc = wave_sum(acc);
-    if (lane == 0) a.W[((int64_t)(pair / a.C) * a.P + kb) * a.C + pair % a.C] = acc;
-}
-
-int slab_sweep_nwg(int D) { return (D + SL_TD - 1) / SL_TD; }
-
-void launch_sweep_split(const DenseSweepMulti& m, int kb, hipStream_t st) {
-    const DenseSweepArgs& a = m.a[0];
-    if (a.nWG > 256 || 2 * a.C > 64) throw Error(2, "split sweep: shape not supported");
-    sweep_slab_kernel<<<dim3(a.nWG, m.n), 64, 0, st>>>(m, kb);
-    KERNEL_CHECK();
-    sweep_reduce_kernel<<<dim3(2 * a.C, m.n), 64, 0, st>>>(m, kb);
-    KERNEL_CHECK();
-}
-
 // after the last swept bin: W(P-1,:) = sum of partials
 __global__ void __launch_bounds__(SW_NT) sweep_finalize_kernel(const cplx* __restrict__ Wpart, cplx* __restrict__ W,
                                                                int nWG, int C, int P, int kb_last) {
     __shared__ cplx Wp[64];
     const cplx* Wprev = Wpart + (int64_t)(kb_last & 1) * nWG * 2 * C;
     gather_prev(Wp, Wprev, W, nWG, C, P, kb_last + 1, false);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Hq[e][kb][s] = sum_d Hc[e][kb][d] conj(Q[d][s])   for the least-squares bins
-// ---------------------------------------------------------------------------------------------
-template <typename TQ>
-__global__ void __launch_bounds__(256) hq_kernel(const cplx* __restrict__ Hc, int64_t ldD, int n_c, const TQ* __restrict__ Q,
-                                                 int64_t ldQ, int D, int S, int kb_lo, cplx* __restrict__ Hq, int ldS, int store_conj, size_t bstride) {
-    Hc = boff(Hc, bstride); Q = boff(Q, bstride); Hq = boff(Hq, bstride);
-    // 32 SH channels x 8 direction slices per workgroup; slices reduced through LDS
-    __shared__ __attribute__((aligned(16))) cplx red[8][33];
-    const int kb = kb_lo + blockIdx.x, e = blockIdx.y & 1;   // grid.y = (SH tile, ear); grid.z = design of a batch
-    const cplx* h = Hc + ((int64_t)e * n_c + kb) * ldD;
-    const int sl = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int s = (blockIdx.y >> 1) * 32 + sl;
-    cplx a0 = mk(0, 0), a1 = mk(0, 0), a2 = mk(0, 0), a3 = mk(0, 0);
-    if (s < S) {
-        int d = part;
-        for (; d + 24 < D; d += 32) {
-            cfma(a0, h[d], conj(Q[(int64_t)d * ldQ + s]));
-            cfma(a1, h[d + 8], conj(Q[(int64_t)(d + 8) * ldQ + s]));
-            cfma(a2, h[d + 16], conj(Q[(int64_t)(d + 16) * ldQ + s]));
-            cfma(a3, h[d + 24], conj(Q[(int64_t)(d + 24) * ldQ + s]));
-        }
-        for (; d < D; d += 8) cfma(a0, h[d], conj(Q[(int64_t)d * ldQ + s]));
-    }
-    red[part][sl] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (part == 0 && s < S) {
-        cplx acc = red[0][sl];
-#pragma unroll
-        for (int j = 1; j < 8; ++j) acc += red[j][sl];
-        Hq[((int64_t)e * n_c + kb) * ldS + s] = store_conj ? conj(acc) : acc;
-    }
 }
 
 // Least-squares rows without Q:  conj(H conj(Yc)) as a tiled product  P[r][s] = sum_d H[r][d] conj(Yc[d][s])
@@ -886,38 +521,6 @@ __global__ void widen_kernel(const T* __restrict__ in, int64_t ldi, cplx* __rest
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <typename TQ>
-static void sweep_factored_dispatch(const SweepArgs& a, int kb, hipStream_t st) {
-    const size_t dyn = sweep_lds_elems(a.ldS, a.C, a.nWG) * sizeof(cplx);
-    if (dyn > 150 * 1024) throw Error(2, "sweep: SH channel count too large for the LDS-resident reduction");
-    const int rs = (a.S + 63) / 64;
-#define EMAGLS_SWEEP_CASE(R)                                                                         \
-    do {                                                                                             \
-        static bool attr_set = false;                                                                \
-        if (!attr_set) {                                                                             \
-            HIP_CHECK(hipFuncSetAttribute((const void*)sweep_factored_kernel<TQ, R, 2>,              \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-            HIP_CHECK(hipFuncSetAttribute((const void*)sweep_factored_kernel<TQ, R, 4>,              \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-            attr_set = true;                                                                         \
-        }                                                                                            \
-        if (a.nWG <= 128) sweep_factored_kernel<TQ, R, 2><<<a.nWG, SW_NT, dyn, st>>>(a, kb);         \
-        else sweep_factored_kernel<TQ, R, 4><<<a.nWG, SW_NT, dyn, st>>>(a, kb);                      \
-    } while (0)
-    if (rs <= 2) EMAGLS_SWEEP_CASE(2);
-    else if (rs <= 4) EMAGLS_SWEEP_CASE(4);
-    else if (rs <= 7) EMAGLS_SWEEP_CASE(7);
-    else if (rs <= 8) EMAGLS_SWEEP_CASE(8);
-    else if (rs <= 12) EMAGLS_SWEEP_CASE(12);
-    else throw Error(2, "sweep: more than 768 SH channels is not supported in this build");
-#undef EMAGLS_SWEEP_CASE
-    KERNEL_CHECK();
-}
-
-void launch_sweep_factored(const SweepArgs& a, int kb, bool q_cplx, hipStream_t st) {
-    if (q_cplx) sweep_factored_dispatch<cplx>(a, kb, st); else sweep_factored_dispatch<double>(a, kb, st);
-}
-
 void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st) {
     if (2 * a.C * a.nWG > 16 * DS_NT) throw Error(2, "dense sweep: too many workgroup partials");
     const size_t dyn = sizeof(cplx) * (size_t)2 * a.C * (a.nWG + 1);
@@ -925,30 +528,10 @@ void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_
     else sweep_dense_kernel<double><<<a.nWG, DS_NT, dyn, st>>>(a, kb);
     KERNEL_CHECK();
 }
-void launch_sweep_dense_multi(const DenseSweepMulti& m, int kb, hipStream_t st) {
-    const DenseSweepArgs& a = m.a[0];
-    if (2 * a.C * a.nWG > 16 * DS_NT) throw Error(2, "dense sweep: too many workgroup partials");
-    const size_t dyn = sizeof(cplx) * (size_t)2 * a.C * (a.nWG + 1);
-    sweep_dense_multi_kernel<cplx><<<dim3(a.nWG, m.n), DS_NT, dyn, st>>>(m, kb);
-    KERNEL_CHECK();
-}
-void launch_sweep_finalize_multi(const DenseSweepMulti& m, int kb_last, hipStream_t st) {
-    sweep_finalize_multi_kernel<<<m.n, SW_NT, 0, st>>>(m, kb_last);
-    KERNEL_CHECK();
-}
 int dense_sweep_nwg(int D) { return (D + DS_DPW - 1) / DS_DPW; }
 
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st) {
     sweep_finalize_kernel<<<1, SW_NT, 0, st>>>((const cplx*)Wpart, (cplx*)W, nWG, C, P, kb_last);
-    KERNEL_CHECK();
-}
-
-void launch_hq(const void* Hc, int64_t ldD, int n_c, const void* Q, int64_t ldQ, bool q_cplx, int D, int S, int kb_lo,
-               int kb_hi, void* Hq, int ldS, hipStream_t st, bool store_conj) {
-    if (kb_hi <= kb_lo) return;
-    dim3 grid(kb_hi - kb_lo, 2 * (unsigned)ceil_div(S, 32));
-    if (q_cplx) hq_kernel<cplx><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const cplx*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS, store_conj ? 1 : 0, batch_ctx().stride);
-    else hq_kernel<double><<<bgrid(grid), 256, 0, st>>>((const cplx*)Hc, ldD, n_c, (const double*)Q, ldQ, D, S, kb_lo, (cplx*)Hq, ldS, store_conj ? 1 : 0, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

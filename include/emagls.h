@@ -56,6 +56,10 @@ int emagls_version(void);
 int emagls_device_count(int* count);
 int emagls_set_device(int device);
 
+/* Measured FP64 peak of the current device in TFLOP/s (best of a few launches that keep every CU busy): which = 0 the matrix
+ * pipe (v_mfma_f64_16x16x4_f64), which = 1 the vector pipe (v_fma_f64).  bench.py prices its executed flops against it. */
+int emagls_fp64_peak_tflops(int which, double* tflops);
+
 /* ---- kernel-level entry points ------------------------------------------------------------- */
 
 /* Y [ndirs x (order+1)^2], column-major; real (8 B) or interleaved complex (16 B) per entry. */

@@ -13,6 +13,33 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _have_gpu():
+    """Counting devices does not initialise the GPU; no torch -> ask the library itself (it needs a GPU to answer)."""
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        pass
+    try:
+        import ctypes
+        from emagls_amd import _lib as L
+        n = ctypes.c_int(0)
+        return L.load().emagls_device_count(ctypes.byref(n)) == 0 and n.value > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a box without a GPU skips the gpu-marked tests instead of failing them.  (The product
+    itself never falls back: without a device every entry point returns an error.)"""
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no MI355X in this container (gpu-marked tests run on the GPU box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden():
     """The reference's shipped golden filter sets (tests/golden/make_fixtures.py)."""

@@ -1,5 +1,5 @@
 """Shape sweep: every entry point over ragged / small / large shapes, GPU result against the oracle.
-Used by tests/test_gpu_shapes.py (a subset, FAST) and scratch/fuzz_shapes.py (all cases, crash-resuming driver)."""
+Used by tests/test_gpu_shapes.py (a subset, FAST) and tools/fuzz_shapes.py (all cases)."""
 import numpy as np
 import emagls_amd as E
 from emagls_amd import synth

@@ -12,17 +12,55 @@ def _bench():
     return m
 
 
-def test_plan_batches_covers_the_timed_region_without_waste():
-    pb = _bench().plan_batches
+def test_schedule_processes_exactly_the_requested_designs():
+    """The resident configuration (4 x 8) does not depend on --steps: a region of K designs is K // 8 full batches and one
+    partial batch, never a design more."""
+    sch = _bench().schedule
     for k in range(1, 300):
-        nb, bsz = pb(k)
-        assert 1 <= nb <= 4 and 1 <= bsz <= 8
-        j = nb * bsz
-        if k <= 32:
-            assert k <= j < k + nb       # one round, fewer than one spare design per batch
-        else:
-            assert j == 32
-    assert pb(128, 16, 8) == (2, 8) and pb(8, 1, 1) == (1, 1) and pb(5, 32, 8) == (1, 5) and pb(64, 0, 4) == (8, 4)
+        s = sch(k)
+        assert sum(s) == k and all(x == 8 for x in s[:-1]) and 1 <= s[-1] <= 8
+    assert sch(20) == [8, 8, 4] and sch(128) == [8] * 16 and sch(5, 8) == [5]
+
+
+def test_gpus_flag_spawns_fresh_ranks(tmp_path):
+    """`bench.py --gpus N` without WORLD_SIZE starts N children with the torch.distributed environment (gloo here: the
+    children rendezvous on 127.0.0.1 and all-reduce their ranks), before the parent imports torch or touches HIP."""
+    import sys
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert int(os.environ['LOCAL_RANK']) == r and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "dist.init_process_group('gloo', rank=r, world_size=w)\n"
+        "t = torch.tensor([float(r + 1)]); dist.all_reduce(t)\n"
+        "open(sys.argv[1] + '.%d' % r, 'w').write(str(t.item()))\n"
+        "dist.destroy_process_group()\n")
+    b = _bench()
+    assert "torch" not in b.__dict__                       # the module itself never imports torch at import time
+    rc = b.spawn_ranks(2, [str(tmp_path / "out")], script=str(child), timeout=120)
+    assert rc == 0
+    assert [(tmp_path / ("out.%d" % r)).read_text() for r in range(2)] == ["3.0", "3.0"]
+    # a failing rank fails the launch and takes the others down instead of leaving them in the rendezvous
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\nsys.exit(7) if os.environ['RANK'] == '1' else time.sleep(60)\n")
+    assert b.spawn_ranks(2, [], script=str(bad), timeout=30) == 7
+
+
+def test_gpus_flag_fails_loudly_without_the_gpus():
+    """`--gpus 2` on a box with fewer GPUs must not silently measure one GPU (or none)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this box has the GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout)
+    # WORLD_SIZE that contradicts --gpus is refused as well
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
 
 
 def test_lane_groups_for_a_radius_sweep():

@@ -1,5 +1,5 @@
 """Ragged, minimal and maximal shapes through every entry point, against the oracle (tolerance 1e-6 relative, north_star).
-The full sweep (60 cases, incl. 3000+ directions and 512-tap filters) is scratch/fuzz_shapes.py; measured 2026-10: all < 2e-10."""
+The full sweep (60 cases, incl. 3000+ directions and 512-tap filters): `python tools/fuzz_shapes.py` on the GPU box."""
 import pytest
 
 from shape_cases import CASES, FAST, run

@@ -1,7 +1,9 @@
 """Shape sweep on the GPU box: all cases of tests/shape_cases.py.
-Run:  python scratch/fuzz_shapes.py --driver   (prints one line per case; a crash names the case and the sweep resumes behind it)"""
+Run:  python tools/fuzz_shapes.py --driver   (prints one line per case; a crash names the case and the sweep resumes behind it)"""
 import sys, time, traceback
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from emagls_amd._lib import EmaglsError
 from shape_cases import CASES, run
 
