@@ -12,8 +12,9 @@ struct FactorArgs {
     int P;            // number of positive-frequency bins (Nyquist bin = P-1 uses real(b_n))
     // assemble mode
     const void* Tn;   // [n][c][ldS]  (real or complex), nullptr in dense mode
-    const cplx* bn;   // [P][nOrders]
-    int nOrders;
+    const cplx* bn;   // [P][bn_stride]
+    int nOrders;      // orders assembled (the first nOrders of each row of bn)
+    int bn_stride;    // 0: = nOrders
     // dense mode
     const cplx* Xd;   // [kb][c][ldS] (per-bin) ; stride 0 allowed through xd_stride
     int64_t xd_stride;
@@ -31,10 +32,10 @@ struct FactorArgs {
     int64_t hq_estride;
     int ls_end;
     const double* cond_ok;  // optional [P]: the back-transform (Z_k) is only needed for kb < ls_end and where cond_ok[kb] == 0
-    // Gram route (well-conditioned swept bins): the QR kernel hands A = B^H B instead of R2 and skips the reflectors
-    int gram_from;    // first bin that takes it (0: none); the host derives it from kr so that cond(B) stays below ~3e2
-    int* route;       // [P] 1 where the Gram route was taken (zeroed per execute)
-    int* status;      // plan status flags; [2] is set when a Gram-route bin turns out ill-conditioned (the host re-runs without it)
+    // Gram route (gramroute.hip): route[kb] = 2 where the direct inverse was taken, 1 where R2w holds A = B^H B for the Jacobi kernel
+    int* route;       // [P] (zeroed per execute)
+    int* status;      // plan status flags; [2] is set when a Gram-route bin turns out ill-conditioned, [3] = the highest such bin
+                      // (the host then moves the start of the route behind it and re-runs)
     int jrun;         // Jacobi: consecutive bins per workgroup (warm start from the neighbour's rotations); 0/1 = independent
     int nbins;        // set by the launcher
     int jsplit;       // set by the launcher: the first jsplit bins (Householder route: full Jacobi, the long ones) get one workgroup each

@@ -28,6 +28,7 @@ constexpr int SMAIR_DEFAULT_ORDER = 4;    // dependencies/getSMAIRMatrix.m:39-41
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool owned = false;   // allocated on its own (hipFree when dropped); false once a batch moved it into its arena
 };
 // one allocation that holds the buffers of all plans of a batch at a constant stride (see emagls_batch)
 struct Arena {
@@ -62,6 +63,11 @@ struct emagls_plan {
     // Gram route of the per-bin factorisation for the well-conditioned swept bins (factor.hip); switched off for good
     // when a run reports that the kr-based conditioning estimate was too optimistic (the plan is then re-executed)
     bool gram_route = true;
+    // Routes of the per-bin factorisation (plan_routes): bins [1, hh_end) take the orthonormal S-space route (Householder QR +
+    // Jacobi SVD) on the orders 0..n_h whose modal strength is above 1e-20 of the strongest there (S_h = (n_h+1)^2 rows); bins
+    // [gram_from, P) take the Gram route (gramroute.hip) on all orders.  gram_floor: lower bound of gram_from that a device-side
+    // conditioning check imposed (recovery).  g0: first bin whose direction-space operand G_k exists.
+    int gram_from = 0, gram_floor = 0, hh_end = 0, n_h = 0, S_h = 0, ldS_h = 0, g0 = 0, nb_gram = 0;
     bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip)
     emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
@@ -104,7 +110,7 @@ struct emagls_plan {
 
     ~emagls_plan() {
         if (owner) emagls_batch_forget(owner, this);
-        if (!arena) for (auto& kv : bufs) if (kv.second.p) hipFree(kv.second.p);
+        for (auto& kv : bufs) if (kv.second.p && kv.second.owned) hipFree(kv.second.p);
         for (auto e : stage_events) hipEventDestroy(e);
         for (auto e : sweep_events) hipEventDestroy(e);
         for (auto e : sync_events) hipEventDestroy(e);
@@ -117,9 +123,16 @@ struct emagls_plan {
     }
     void* alloc(const std::string& name, size_t bytes, bool zero = true) {
         if (bytes == 0) bytes = 16;
+        auto it = bufs.find(name);
+        if (it != bufs.end()) {   // re-allocation (a design's routes changed): keep what is large enough
+            if (it->second.bytes >= bytes) return it->second.p;
+            if (it->second.owned) HIP_CHECK(hipFree(it->second.p));
+            total_bytes -= (int64_t)it->second.bytes;
+        }
         DevBuf b;
         HIP_CHECK(hipMalloc(&b.p, (bytes + 15) / 16 * 16));  // (launch_zero works on whole 8-byte words)
         b.bytes = bytes;
+        b.owned = true;
         if (zero) HIP_CHECK(hipMemsetAsync(b.p, 0, bytes, stream));
         bufs[name] = b;
         total_bytes += (int64_t)bytes;
@@ -225,6 +238,67 @@ void check_pow2(int nfft) {
 // kinds that run the array-model pipeline (simulated array -> per-bin factor -> sweep)
 static inline bool array_kind(int k) { return k == EMAGLS_KIND_EMAGLS || k == EMAGLS_KIND_EMAGLS2 || k == EMAGLS_KIND_EMA_CH; }
 
+// Smallest order n such that every order above it contributes less than 1e-20 of the strongest mode to pwGrid at kr = x:
+// |b_n(x)| (2n+1) / |b_0| <= x^n / (2n-1)!! (2n+1) for the rigid sphere (|j_n(x)| <= x^n / (2n+1)!!; the Wronskian form of b_n
+// divides by x^2 |h_n'(x)| >= (n+1) (2n-1)!! / x^n).  Dropping those orders perturbs the bin's matrix by 1e-4 of its own
+// FP64 rounding error: the reference's LAPACK SVD cannot tell the difference.
+int orders_above_noise(double x, int nmax) {
+    double term = 1.0;   // x^n / (2n-1)!!
+    for (int n = 1; n <= nmax; ++n) {
+        term *= x / (double)(2 * n - 1);
+        if ((double)n > x && term * (2 * n + 1) < 1e-20) return n - 1;
+    }
+    return nmax;
+}
+
+int emagls_gram_from(const emagls_plan& p);
+// routes of the per-bin factorisation (see emagls_plan): derived from kr only, so that every rank / replay takes the same
+void plan_routes(emagls_plan& p) {
+    const emagls_design_desc& d = p.d;
+    const int k0 = std::max(p.kcut0, 1);
+    p.gram_from = emagls_gram_from(p);
+    if (p.gram_from > 0 && p.gram_from < p.gram_floor) p.gram_from = p.gram_floor < p.P ? p.gram_floor : 0;
+    p.hh_end = p.gram_from > 0 ? p.gram_from : p.P;
+    const double f_h = (double)(p.hh_end - 1) * (d.fs / 2.0) / (double)(p.P - 1);
+    int n_min = 0;   // the S-space factor needs at least as many rows as channels
+    while ((n_min + 1) * (n_min + 1) < p.C) ++n_min;
+    p.n_h = std::min(p.simOrder, std::max(orders_above_noise(2.0 * kPi * f_h / C_SOUND * d.mic_radius, p.simOrder), n_min));
+    p.S_h = (p.n_h + 1) * (p.n_h + 1);
+    p.ldS_h = round_up(p.S_h, 64);
+    if (p.S_h > 768)
+        throw Error(EMAGLS_ERR_UNSUPPORTED, "the ill-conditioned low bins of this design need more than 27 orders on the orthonormal route "
+                                            "(Gram route off or moved up by a conditioning check): not supported in this build");
+    p.g0 = (p.gram_from > 0 && p.gram_from < k0) ? p.gram_from : k0;
+    p.nb_gram = p.gram_from > 0 ? p.P - p.gram_from : 0;
+}
+// buffers whose size depends on the routes (re-entered when a conditioning check moves the routes: alloc keeps what is large enough)
+void plan_alloc_routes(emagls_plan& p) {
+    const bool cb = p.cplx_basis;
+    const int k0 = std::max(p.kcut0, 1);
+    const int ls_end = std::max(std::min(p.kcut0, p.P), 1);
+    const int nOrd = p.simOrder + 1;
+    p.alloc("R", esz(cb) * (size_t)p.S_h * p.S_h);                     // Cholesky factor of the leading block of Gy
+    p.alloc("Rinv", esz(cb) * (size_t)ceil_div(p.S_h, 32) * 32 * 32);
+    if (!cb) {   // complex copies of R and of its diagonal-block inverses (row solves of complex rows in the real basis)
+        p.alloc("Rc", sizeof(cplx) * (size_t)p.S_h * p.S_h);
+        p.alloc("Rinvc", sizeof(cplx) * (size_t)ceil_div(p.S_h, 32) * 32 * 32);
+    }
+    p.alloc("Tn", esz(cb) * (size_t)(p.n_h + 1) * p.C * p.ldS_h);
+    p.alloc("Hq", sizeof(cplx) * (size_t)2 * ls_end * p.ldS_h);
+    p.alloc("Hyp", sizeof(cplx) * hy_workspace_elems(2 * ls_end, p.ldS_h));
+    p.alloc("Z", sizeof(cplx) * (size_t)p.hh_end * p.C * p.ldS_h);
+    p.alloc("Vws", sizeof(cplx) * (size_t)p.hh_end * p.C * p.ldS_h);
+    p.alloc("G", sizeof(cplx) * ((size_t)std::max(p.P - p.g0, 1) * p.C + 32) * p.ldD, false);  // + 32 rows: the persistent sweep loads all 32 slab rows of a bin unconditionally
+    p.alloc("Yri", sizeof(cplx) * (size_t)std::max(p.hh_end - k0, 1) * p.C * p.ldD, false);    // only Householder-route bins can be flagged ill-conditioned
+    if (p.nb_gram > 0) {
+        const int ldK = round_up(p.C * p.C, 64), Kp = round_up(nOrd * nOrd, 4);
+        p.alloc("Fg", esz(cb) * (size_t)nOrd * p.C * p.ldS);
+        p.alloc("Kmat", sizeof(double) * (size_t)Kp * ldK);                                   // (rows beyond nOrd^2 stay zero)
+        p.alloc("Cf", sizeof(double) * (size_t)Kp * round_up(p.P, 64));                       // (sized for every bin: the routes may move)
+        p.alloc("Apk", sizeof(double) * (size_t)p.P * ldK);
+    }
+}
+
 void plan_setup(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_EMA_CH) throw Error(EMAGLS_ERR_ARG, "unknown design kind");
@@ -295,7 +369,7 @@ void plan_setup(emagls_plan& p) {
         p.nOut = d.kind == EMAGLS_KIND_EMA_CH ? 2 * N + 1 : (N + 1) * (N + 1);   // EMAinCH.m:66: numHarmonics = 2*order+1
         p.C = d.kind == EMAGLS_KIND_EMAGLS2 ? (int)d.nmics : p.nOut;
         if (p.C > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels is not supported in this build");
-        if (p.S > 768) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 26 (array radius > ~5.9 cm at 48 kHz) is not supported in this build");
+        if (p.simOrder > 47) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 47 (array radius > ~10.9 cm at 48 kHz) is not supported in this build");
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than simulated SH channels");
         if (d.kind != EMAGLS_KIND_EMAGLS2 && d.nmics < p.nOut) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than output channels");
     } else {
@@ -311,14 +385,16 @@ void plan_setup(emagls_plan& p) {
 
     if (d.kind != EMAGLS_KIND_FROM_ATF) {
         // ---- SH machinery on the HRIR grid
-        p.Dpad = gram_dpad(p.D);
+        p.Dpad = gram_dpad(p.D, p.S);
         p.alloc("sh_tab", sizeof(double) * sh_coeff_count(p.simOrder));
         p.alloc("Ycm", esz(cb) * (size_t)p.S * p.ldD);                 // [S][ldD] column-major SH matrix
         p.alloc("Yc", esz(cb) * (size_t)p.Dpad * p.ldS);               // [Dpad][ldS] conj(Y), direction-major
-        p.alloc("Gp", esz(cb) * (size_t)gram_ksplit(p.D) * p.S * p.S);
-        p.alloc("R", esz(cb) * (size_t)p.S * p.S);
-        if (!array_kind(d.kind)) p.alloc("Q", esz(cb) * (size_t)p.D * p.ldS);   // (the array designs never form Q: section 2.1 of DESIGN.md)
-        p.alloc("Rinv", esz(cb) * (size_t)ceil_div(p.S, 32) * 32 * 32);
+        p.alloc("Gp", esz(cb) * (size_t)gram_ksplit(p.D, p.S) * p.S * p.S);
+        if (!array_kind(d.kind)) {   // (array designs: R covers the Householder-route orders only, plan_alloc_routes; Q is never formed)
+            p.alloc("R", esz(cb) * (size_t)p.S * p.S);
+            p.alloc("Q", esz(cb) * (size_t)p.D * p.ldS);
+            p.alloc("Rinv", esz(cb) * (size_t)ceil_div(p.S, 32) * 32 * 32);
+        }
     }
     if (d.kind == EMAGLS_KIND_LS || d.kind == EMAGLS_KIND_MAGLS) {
         p.alloc("Rb", sizeof(cplx) * (size_t)p.C * p.ldS);             // R as [c][s] complex
@@ -353,16 +429,10 @@ void plan_setup(emagls_plan& p) {
         }
         p.alloc("kr", sizeof(double) * p.P, false);
         p.alloc("bn", sizeof(cplx) * (size_t)p.P * (p.simOrder + 1));
-        p.alloc("Tn", esz(cb) * (size_t)(p.simOrder + 1) * p.C * p.ldS);
-        p.alloc("Hq", sizeof(cplx) * (size_t)2 * std::max(p.kcut0, 1) * p.ldS);
         p.alloc("route", sizeof(int) * (size_t)p.P);
-        p.alloc("Hyp", sizeof(cplx) * hy_workspace_elems(2 * std::max(p.kcut0, 1), p.ldS));
-        if (!cb) {   // complex copies of R and of its diagonal-block inverses (row solves of complex rows in the real basis)
-            p.alloc("Rc", sizeof(cplx) * (size_t)p.S * p.S);
-            p.alloc("Rinvc", sizeof(cplx) * (size_t)ceil_div(p.S, 32) * 32 * 32);
-        }
-        p.alloc("Z", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
-        p.alloc("Vws", sizeof(cplx) * (size_t)p.P * p.C * p.ldS);
+        p.alloc("Gy", esz(cb) * (size_t)p.S * p.S);                    // Gram matrix of conj(Y) (upper block triangle)
+        plan_routes(p);
+        plan_alloc_routes(p);
         p.alloc("sv", sizeof(double) * (size_t)p.P * p.C);
         p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
         p.alloc("tauw", sizeof(double) * (size_t)p.P * p.C);
@@ -371,11 +441,6 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Mw", sizeof(cplx) * ((size_t)p.P * p.C * p.C + 1024));
         p.alloc("cond_ok", sizeof(double) * (size_t)p.P);
         p.alloc("QT", esz(cb) * (size_t)(p.simOrder + 1) * p.C * p.ldD);
-        {
-            const size_t nsw = (size_t)std::max(p.P - std::max(p.kcut0, 1), 1);
-            p.alloc("G", sizeof(cplx) * (nsw * p.C + 32) * p.ldD, false);  // + 32 rows: the persistent sweep loads all 32 slab rows of a bin unconditionally
-            p.alloc("Yri", sizeof(cplx) * nsw * p.C * p.ldD, false);
-        }
         if (getenv("EMAGLS_SWEEP_TIMING")) p.alloc("sweep_timing", sizeof(long long) * 16 * (size_t)p.P);
     }
     if (d.kind == EMAGLS_KIND_FROM_ATF) {
@@ -434,7 +499,7 @@ void stage_hrir_basis(emagls_plan& p) {
                     p.get("Ycm"), p.ldD, st);
     launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, cb, true, st);
     p.mark("sh_basis");
-    launch_gram(p.get("Yc"), p.D, p.S, p.ldS, cb, p.get("Gp"), p.get("R"), st);
+    launch_gram(p.get("Yc"), p.D, p.S, p.ldS, cb, p.get("Gp"), nullptr, p.get("R"), p.S, st);
     p.mark("gram_mfma");
     launch_cholesky(p.get("R"), p.S, cb, p.get<int>("flag"), st);
     p.mark("cholesky");
@@ -537,7 +602,8 @@ int emagls_gram_from(const emagls_plan& p) {
     const double kr_min = std::pow(dfact / est_limit, 1.0 / n);
     const double df = p.d.fs / p.nfft;
     const int kb = (int)std::ceil(kr_min * C_SOUND / (2.0 * kPi * p.d.mic_radius) / df);
-    const int from = std::max(std::max(kb, p.kcut0), 1);
+    // (least-squares bins above the estimate take the route as well: W(k,:) = (H conj(G_k)) conj(M_k), gramroute.hip)
+    const int from = std::max(kb, 1);
     return from < p.P ? from : 0;
 }
 
@@ -553,6 +619,11 @@ void emagls_pre_sweep(emagls_plan& p) {
     const int nOrd = p.simOrder + 1;
     const int ls_end = std::min(p.kcut0, p.P);
     const int k0 = std::max(p.kcut0, 1);
+    // routes (plan_routes): Householder bins [1, hh_end) on the orders 0..n_h, Gram-route bins [gf, P) on all orders
+    const int gf = p.gram_from, hh_end = p.hh_end, Sh = p.S_h, ldSh = p.ldS_h, nOrdH = p.n_h + 1;
+    const int ls_h = std::min(ls_end, hh_end);     // least-squares bins [1, ls_h) on the Householder route, [ls_h, ls_end) on the Gram route
+    const int64_t g_stride = (int64_t)p.C * p.ldD;
+    cplx* Gk = p.get<cplx>("G") - (int64_t)p.g0 * g_stride;   // indexed by kb
     p.sync_used = 0;
 
     // ---- fork: three independent branches
@@ -594,72 +665,98 @@ void emagls_pre_sweep(emagls_plan& p) {
                         p.get<double>("grpd"), 0, ls_end, p.kcut0, p.get("Hc"), p.get<double>("Habs"), p.ldD, s2);
     }
 
-    // s0: SH matrix of the HRIR grid, Gram, Cholesky
+    // s0: SH matrix of the HRIR grid, its Gram matrix Gy, Cholesky factor R of the leading block (Householder-route orders)
     launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), cb,
                     p.get("Ycm"), p.ldD, s0);
     launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, cb, true, s0);
     p.mark("sh_basis");
     hipEvent_t e_Yc = p.next_sync_event();
     if (s1 != s0) HIP_CHECK(hipEventRecord(e_Yc, s0));
-    launch_gram(p.get("Yc"), p.D, p.S, p.ldS, cb, p.get("Gp"), p.get("R"), s0);
+    launch_gram(p.get("Yc"), p.D, p.S, p.ldS, cb, p.get("Gp"), p.get("Gy"), p.get("R"), Sh, s0);
     p.mark("gram_mfma");
-    launch_cholesky(p.get("R"), p.S, cb, p.get<int>("flag"), s0);
+    launch_cholesky(p.get("R"), Sh, cb, p.get<int>("flag"), s0);
     p.mark("cholesky");
     hipEvent_t e_R = p.next_sync_event();
     if (s2 != s0) HIP_CHECK(hipEventRecord(e_R, s0));
 
-    // s1 (after the array model): order terms of pwGrid.' and G_k of every swept bin -- needs only conj(Y) and E
+    // s1 (after the array model): order terms of pwGrid.' and G_k of every bin from g0 on -- needs only conj(Y) and E
     if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s1, e_Yc, 0));
     launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, cb, p.get("QT"), p.ldD, s1);
     // (complex-arithmetic pipeline: G_k is still evaluated on the real order terms; circular-harmonic
     // channels would need their own channel transform and take the complex kernel)
-    launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, k0, p.get("G"), s1,
+    launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, p.g0, p.get("G"), s1,
                     (cb && d.kind != EMAGLS_KIND_EMA_CH) ? 1 : 0, raw ? -1 : (int)d.order);
-    // s2 (after the prologue): the least-squares right-hand sides H conj(Q).  Q itself is never formed: H conj(Q) is
-    // conj( conj(H conj(Yc)) R^-1 ), one D-long product and a row solve for the 2 (k_cut - 1) least-squares rows.
+    // s2 (after the prologue): the least-squares right-hand sides H conj(Q) of the Householder-route bins.  Q itself is never
+    // formed: H conj(Q) is conj( conj(H conj(Yc)) R^-1 ), one D-long product and a row solve for the least-squares rows.
     if (s2 != s0) HIP_CHECK(hipStreamWaitEvent(s2, e_R, 0));
-    // (real basis: the rows are complex all the same, so R is widened to a complex copy for the row solves)
-    if (!cb) launch_widen(p.get("R"), p.S, false, p.get("Rc"), p.S, p.S, p.S, false, /*upper_only=*/true, s2);
-    launch_hy_conj(p.get("Hc"), p.ldD, 2 * ls_end, p.get("Yc"), p.ldS, cb, (int)p.D, p.S, p.get("Hyp"), p.get("Hq"), p.ldS, s2);
-    launch_qform(p.get("Hq"), p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.S, 2 * (int64_t)ls_end, p.ldS, true, p.get("Hq"), s2);
+    if (hh_end > 1) {
+        // (real basis: the rows are complex all the same, so R is widened to a complex copy for the row solves)
+        if (!cb) launch_widen(p.get("R"), Sh, false, p.get("Rc"), Sh, Sh, Sh, false, /*upper_only=*/true, s2);
+        launch_hy_conj(p.get("Hc"), p.ldD, 2 * ls_end, p.get("Yc"), p.ldS, cb, (int)p.D, Sh, p.get("Hyp"), p.get("Hq"), ldSh, s2);
+        // (also forms the inverses of R's diagonal blocks, which the ill-conditioned swept bins need: at least one row)
+        launch_qform(p.get("Hq"), p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), Sh, 2 * (int64_t)std::max(ls_end, 1), ldSh, true, p.get("Hq"), s2);
+    }
 
-    // s0: T_n, per-bin QR + Jacobi
+    // s0: per-bin factors.  Gram route first (needs E, b_n, Gy): K matrices, one GEMM over the bins, direct inverses
     if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s0, e_E, 0));
-    launch_tn(p.get("R"), p.get("E"), p.S, p.C, p.ldS, nOrd, cb, p.get("Tn"), p.ldS, s0);
-    p.mark("array_model+tn");
     FactorArgs fa{};
-    fa.S = p.S; fa.C = p.C; fa.ldS = p.ldS; fa.kb0 = 1; fa.P = p.P;
-    fa.Tn = p.get("Tn"); fa.bn = p.get<cplx>("bn"); fa.nOrders = nOrd;
+    fa.S = Sh; fa.C = p.C; fa.ldS = ldSh; fa.kb0 = 1; fa.P = p.P;
+    fa.Tn = p.get("Tn"); fa.bn = p.get<cplx>("bn"); fa.nOrders = nOrdH; fa.bn_stride = nOrd;
     fa.reg_mode = 0; fa.reg_c = SVD_REGUL_CONST;
     fa.Z = p.get<cplx>("Z");
     fa.Mw = p.get<cplx>("Mw");
     fa.Vws = p.get<cplx>("Vws"); fa.sv = p.get<double>("sv");
-    fa.Hq = p.get<cplx>("Hq"); fa.ldHq = p.ldS; fa.hq_estride = (int64_t)ls_end * p.ldS; fa.ls_end = ls_end;
+    fa.Hq = p.get<cplx>("Hq"); fa.ldHq = ldSh; fa.hq_estride = (int64_t)ls_end * ldSh; fa.ls_end = ls_h;
     fa.hq_conj = 1;
     fa.route = p.get<int>("route"); fa.status = p.get<int>("flag");
-    fa.gram_from = emagls_gram_from(p);
-    // batches have workgroups to spare: a Jacobi workgroup walks a run of neighbouring bins, each warm-started from the
-    // previous one (a third of the sweeps); a single design keeps one bin per workgroup (shortest critical path)
-    fa.jrun = batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
     fa.W = p.get<cplx>("W"); fa.sweeps_out = p.get<int>("jsweeps");
     fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
-    launch_factor(fa, p.P - 1, cb, s0, 1);
+    if (p.nb_gram > 0) {
+        const int ldK = round_up(p.C * p.C, 64), ldCf = round_up(p.P, 64);
+        launch_gram_kmat(p.get("Gy"), p.get("E"), p.S, p.ldS, p.C, nOrd, cb, p.get("Fg"), p.ldS, p.get<double>("Kmat"), ldK, s0);
+        launch_gram_gemm(p.get("bn"), nOrd, p.P, gf, p.nb_gram, p.get<double>("Cf"), ldCf, p.get<double>("Kmat"), ldK, p.C,
+                         p.get<double>("Apk"), ldK, s0);
+        launch_gram_solve(p.get<double>("Apk"), ldK, p.C, gf, p.nb_gram, SVD_REGUL_CONST, p.get("Mw"), p.get("R2w"), p.get<double>("sv"),
+                          p.get<int>("route"), p.get<int>("jsweeps"), s0);
+        // bins in which the 1 % clipping is active (cond > 100) or the certificate failed: Jacobi SVD of the Gram matrix
+        FactorArgs fg = fa;
+        fg.kb0 = gf;
+        const int64_t off = (int64_t)(gf - 1);
+        fg.R2w = fa.R2w + off * p.C * p.C; fg.Mw = fa.Mw + off * p.C * p.C; fg.Nw = fa.Nw + off * p.C * p.C; fg.tauw = fa.tauw + off * p.C;
+        // batches have workgroups to spare: a Jacobi workgroup walks a run of neighbouring bins, each warm-started from the
+        // previous one (a third of the sweeps); a single design keeps one bin per workgroup (shortest critical path)
+        fg.jrun = batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
+        launch_factor_jacobi_gram(fg, p.nb_gram, s0);
+        p.mark("gram_route");
+    }
+    // Householder route: T_n of the orders 0..n_h, per-bin QR + Jacobi
+    if (hh_end > 1) {
+        launch_tn(p.get("R"), p.get("E"), Sh, p.C, p.ldS, nOrdH, cb, p.get("Tn"), ldSh, s0);
+        p.mark("array_model+tn");
+        launch_factor(fa, hh_end - 1, cb, s0, 1);
+    }
     // cond_ok[kb]: the cheap direction-space identity is accurate for this bin.  Only the other swept bins (and the
     // least-squares bins) need Z_k, i.e. the back-transform
     launch_cond_flags(p.get<double>("sv"), p.C, p.P, p.get<double>("cond_ok"), s0);
     fa.cond_ok = p.get<double>("cond_ok");
     p.mark("factor_qr_jacobi");
-    // join s2 (Q, Hq, spectra, group delays): back-transform + least-squares bins
+    // join s2 (Hq, spectra, group delays): back-transform + least-squares bins of the Householder route
     p.depend(s0, s2);
-    launch_factor(fa, p.P - 1, cb, s0, 2);
+    if (hh_end > 1) launch_factor(fa, hh_end - 1, cb, s0, 2);
     p.mark("factor_back+ls_bins");
     // join s1 (G)
     p.depend(s0, s1);
-    // ill-conditioned swept bins: Y_reg_inv_k = conj(Q) Z_k = conj(Yc) (Z_k R^-H); the flagged bins' Z rows are solved in place first
-    launch_zsolve_flagged(p.get("Z"), p.ldS, p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.get<double>("cond_ok"), p.S, p.C,
-                          p.P, k0, s0);
-    launch_yri_accurate(p.get("Yc"), p.ldS, cb, p.get("Z"), p.ldS, p.get<double>("cond_ok"), (int)p.D, p.S, p.C, p.P, k0,
-                        p.get("Yri"), p.ldD, s0);
+    // least-squares bins on the Gram route
+    if (gf > 0 && gf < ls_end)
+        launch_ls_gram(p.get("Hc"), p.ldD, ls_end, Gk, g_stride, p.ldD, p.get("Mw"), (int)p.D, p.C, p.P, gf, ls_end, p.get("W"), s0);
+    // ill-conditioned swept bins (Householder route only): Y_reg_inv_k = conj(Q) Z_k = conj(Yc) (Z_k R^-H); the flagged bins'
+    // Z rows are solved in place first
+    if (hh_end > k0) {
+        launch_zsolve_flagged(p.get("Z"), ldSh, p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.get<double>("cond_ok"), Sh, p.C,
+                              hh_end, k0, s0);
+        launch_yri_accurate(p.get("Yc"), p.ldS, cb, p.get("Z"), ldSh, p.get<double>("cond_ok"), (int)p.D, Sh, p.C, hh_end, k0,
+                            p.get("Yri"), p.ldD, s0);
+    }
     p.mark("yri_operands");
 }
 
@@ -668,7 +765,7 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     HalfSweepArgs a{};
     a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
     a.g_stride = (int64_t)p.C * p.ldD;
-    a.G = p.get<cplx>("G") - (int64_t)k0 * a.g_stride;      // indexed by kb
+    a.G = p.get<cplx>("G") - (int64_t)p.g0 * a.g_stride;    // indexed by kb (G starts at bin g0 <= k0)
     a.Yri = p.get<cplx>("Yri") - (int64_t)k0 * a.g_stride;
     a.Mw = p.get<cplx>("Mw") - (int64_t)1 * p.C * p.C;      // factor stage stores bin kb at slot kb-1
     a.cond_ok = p.get<double>("cond_ok");
@@ -1010,8 +1107,16 @@ void drop_batch_graphs(emagls_batch& b) {
 bool plan_recover(emagls_plan& p, const int* flag, bool apply) {
     bool redo = false;
     if (flag[2]) {
-        if (!p.gram_route) throw Error(EMAGLS_ERR_NUMERIC, "internal: Gram-route conditioning flag although the route is off (stale graph)");
-        if (apply) p.gram_route = false;
+        // flag[3] = the highest Gram-route bin whose condition number exceeded the limit: the route restarts behind it (the
+        // Householder route then covers more bins and, at their higher kr, more orders: plan_routes refuses beyond its tile)
+        if (p.gram_from == 0 || flag[3] < p.gram_from)
+            throw Error(EMAGLS_ERR_NUMERIC, "internal: Gram-route conditioning flag outside the route (stale graph)");
+        if (apply) {
+            p.gram_floor = std::max(p.gram_floor, flag[3] + 1);
+            plan_routes(p);
+            plan_alloc_routes(p);
+            HIP_CHECK(hipStreamSynchronize(p.stream));
+        }
         redo = true;
     }
     if (flag[1]) {
@@ -1032,11 +1137,71 @@ void throw_fatal_flags(const int* flag) {
 }
 // re-run a whole batch after one of its designs raised a recoverable flag: in lane mode all designs share the captured
 // graphs, so every plan of the batch changes its configuration together
+// Lane mode needs plans of identical shape (same buffers of the same sizes, same derived constants).  Their
+// buffers are moved into one arena at a constant stride; the plans keep working on their own afterwards.
+void batch_try_lanes(emagls_batch& b) {
+    if (const char* e = getenv("EMAGLS_BATCH_LANES")) if (e[0] == '0') return;
+    emagls_plan& q = *b.plans[0];
+    if (!q.sweep_persist) return;
+    for (auto* p : b.plans) {
+        if (p->S != q.S || p->simOrder != q.simOrder || p->nOut != q.nOut || p->nfft != q.nfft || p->ldS != q.ldS || p->ldD != q.ldD ||
+            p->Dpad != q.Dpad || p->k_cut != q.k_cut || p->cplx_basis != q.cplx_basis || p->out_cplx != q.out_cplx ||
+            p->d.kind != q.d.kind || p->d.nsamp != q.d.nsamp || p->d.nmics != q.d.nmics || p->d.len != q.d.len || p->d.order != q.d.order ||
+            p->bufs.size() != q.bufs.size())
+            return;
+        auto it = q.bufs.begin();
+        for (auto& kv : p->bufs) {
+            if (kv.first != it->first || kv.second.bytes != it->second.bytes) return;
+            ++it;
+        }
+    }
+    size_t stride = 0;
+    std::vector<size_t> off;
+    for (auto& kv : q.bufs) {
+        off.push_back(stride);
+        stride += (kv.second.bytes + 255) / 256 * 256;
+    }
+    stride = (stride + 4095) / 4096 * 4096;
+    auto arena = std::make_shared<Arena>();
+    HIP_CHECK(hipMalloc(&arena->base, stride * b.plans.size()));
+    for (size_t j = 0; j < b.plans.size(); ++j) {
+        emagls_plan& p = *b.plans[j];
+        size_t i = 0;
+        for (auto& kv : p.bufs) {
+            char* dst = static_cast<char*>(arena->base) + j * stride + off[i++];
+            HIP_CHECK(hipMemcpy(dst, kv.second.p, kv.second.bytes, hipMemcpyDeviceToDevice));
+            if (kv.second.owned) HIP_CHECK(hipFree(kv.second.p));
+            kv.second.p = dst;
+            kv.second.owned = false;
+        }
+        p.arena = arena;  // (a previous arena is released when its last plan has moved out)
+        // the captured graphs hold the old addresses
+        if (p.graph_exec) { HIP_CHECK(hipGraphExecDestroy(p.graph_exec)); p.graph_exec = nullptr; }
+        if (p.graph) { HIP_CHECK(hipGraphDestroy(p.graph)); p.graph = nullptr; }
+        if (p.pre_exec) { HIP_CHECK(hipGraphExecDestroy(p.pre_exec)); p.pre_exec = nullptr; }
+        if (p.pre_graph) { HIP_CHECK(hipGraphDestroy(p.pre_graph)); p.pre_graph = nullptr; }
+        p.eager_runs = 0;
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    b.lanes = true;
+    b.stride = stride;
+}
+
 void batch_redo(emagls_batch& b, const std::vector<int>& flags) {
     int any[4] = {0, 0, 0, 0};
-    for (size_t j = 0; j < b.plans.size(); ++j) for (int i = 0; i < 4; ++i) any[i] |= flags[4 * j + i];
-    for (auto* q : b.plans) { plan_recover(*q, any, true); drop_plan_graphs(*q); }
+    for (size_t j = 0; j < b.plans.size(); ++j) for (int i = 0; i < 4; ++i) any[i] = std::max(any[i], flags[4 * j + i]);
+    bool moved = false;
+    for (auto* q : b.plans) {
+        const int64_t before = q->total_bytes;
+        plan_recover(*q, any, true);
+        moved = moved || q->total_bytes != before;
+        drop_plan_graphs(*q);
+    }
     drop_batch_graphs(b);
+    if (b.lanes && moved) {   // re-allocated buffers left the arena: lane mode needs them at the common stride again
+        b.lanes = false;
+        batch_try_lanes(b);
+    }
     batch_execute(b);
     HIP_CHECK(hipStreamSynchronize(b.stream));
 }
@@ -1289,6 +1454,7 @@ int emagls_plan_get_info(emagls_plan* p, emagls_plan_info* info) {
         info->num_sh_sim = p->S; info->num_channels = p->C; info->out_is_complex = p->out_cplx;
         info->out_rows = p->out_rows; info->out_cols = p->out_cols; info->num_sweep_launches = p->sweep_launches;
         info->device_bytes = p->total_bytes;
+        info->gram_from = p->gram_from; info->hh_end = p->hh_end; info->hh_orders = p->n_h + 1; info->g_first = p->g0;
         if (p->executed) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
             double g[2];
@@ -1368,55 +1534,6 @@ int emagls_plan_debug_buffer(emagls_plan* p, const char* name, void* dst, size_t
     });
 }
 void* emagls_plan_stream(emagls_plan* p) { return p ? (void*)p->stream : nullptr; }
-
-// Lane mode needs plans of identical shape (same buffers of the same sizes, same derived constants).  Their
-// buffers are moved into one arena at a constant stride; the plans keep working on their own afterwards.
-void batch_try_lanes(emagls_batch& b) {
-    if (const char* e = getenv("EMAGLS_BATCH_LANES")) if (e[0] == '0') return;
-    emagls_plan& q = *b.plans[0];
-    if (!q.sweep_persist) return;
-    for (auto* p : b.plans) {
-        if (p->S != q.S || p->simOrder != q.simOrder || p->nOut != q.nOut || p->nfft != q.nfft || p->ldS != q.ldS || p->ldD != q.ldD ||
-            p->Dpad != q.Dpad || p->k_cut != q.k_cut || p->cplx_basis != q.cplx_basis || p->out_cplx != q.out_cplx ||
-            p->d.kind != q.d.kind || p->d.nsamp != q.d.nsamp || p->d.nmics != q.d.nmics || p->d.len != q.d.len || p->d.order != q.d.order ||
-            p->bufs.size() != q.bufs.size())
-            return;
-        auto it = q.bufs.begin();
-        for (auto& kv : p->bufs) {
-            if (kv.first != it->first || kv.second.bytes != it->second.bytes) return;
-            ++it;
-        }
-    }
-    size_t stride = 0;
-    std::vector<size_t> off;
-    for (auto& kv : q.bufs) {
-        off.push_back(stride);
-        stride += (kv.second.bytes + 255) / 256 * 256;
-    }
-    stride = (stride + 4095) / 4096 * 4096;
-    auto arena = std::make_shared<Arena>();
-    HIP_CHECK(hipMalloc(&arena->base, stride * b.plans.size()));
-    for (size_t j = 0; j < b.plans.size(); ++j) {
-        emagls_plan& p = *b.plans[j];
-        size_t i = 0;
-        for (auto& kv : p.bufs) {
-            char* dst = static_cast<char*>(arena->base) + j * stride + off[i++];
-            HIP_CHECK(hipMemcpy(dst, kv.second.p, kv.second.bytes, hipMemcpyDeviceToDevice));
-            if (!p.arena) HIP_CHECK(hipFree(kv.second.p));
-            kv.second.p = dst;
-        }
-        p.arena = arena;  // (a previous arena is released when its last plan has moved out)
-        // the captured graphs hold the old addresses
-        if (p.graph_exec) { HIP_CHECK(hipGraphExecDestroy(p.graph_exec)); p.graph_exec = nullptr; }
-        if (p.graph) { HIP_CHECK(hipGraphDestroy(p.graph)); p.graph = nullptr; }
-        if (p.pre_exec) { HIP_CHECK(hipGraphExecDestroy(p.pre_exec)); p.pre_exec = nullptr; }
-        if (p.pre_graph) { HIP_CHECK(hipGraphDestroy(p.pre_graph)); p.pre_graph = nullptr; }
-        p.eager_runs = 0;
-    }
-    HIP_CHECK(hipDeviceSynchronize());
-    b.lanes = true;
-    b.stride = stride;
-}
 
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
     return guarded([&] {

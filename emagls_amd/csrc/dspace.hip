@@ -19,16 +19,14 @@
 namespace emagls {
 
 constexpr double COND_LIMIT = 1.0e4;
-constexpr int SW_CMAX_ = 32;
 
 // Order terms of pwGrid.':  G_k = conj(Y) diag(b_n(k)) E^T = sum_n b_n(k) QT_n  with
 //   QT[n][c][d] = sum_{s in [n^2,(n+1)^2)} Yc[d][s] E[c][s]
 // (equal to Q T_n, but needs neither Q nor R: the order blocks of conj(Y) and of the array matrix E suffice).
-// One workgroup = 16 directions, all orders; the 16 rows of Yc sit in LDS, thread = (channel c, direction dl)
-// with dl fastest: the 16 lanes of a channel share every E load and store a contiguous 256-byte run.
-constexpr int QT_TD = 16;
-
-template <typename T>
+// One workgroup = QT_TD directions (16, or fewer when S is large: the rows must fit the LDS), all orders; the rows of Yc
+// sit in LDS, thread = (channel c, direction dl) with dl fastest: the lanes of a channel share every E load and store a
+// contiguous run.
+template <typename T, int QT_TD>
 __global__ void __launch_bounds__(512) qt_kernel(const T* __restrict__ Yc, int64_t ldY, const T* __restrict__ E, int ldE,
                                                  int D, int S, int C, int nOrders, T* __restrict__ QT, int64_t ldD, size_t bstride) {
     Yc = boff(Yc, bstride); E = boff(E, bstride); QT = boff(QT, bstride);
@@ -41,18 +39,19 @@ __global__ void __launch_bounds__(512) qt_kernel(const T* __restrict__ Yc, int64
         ys[(size_t)dl * ldq + s] = (d0 + dl < D) ? Yc[(int64_t)(d0 + dl) * ldY + s] : zero_of<T>();
     }
     __syncthreads();
-    const int c = threadIdx.x >> 4, dl = threadIdx.x & 15;
-    if (c >= C) return;
+    const int dl = threadIdx.x % QT_TD;
     const T* y = ys + (size_t)dl * ldq;
-    const T* e = E + (int64_t)c * ldE;
-    // (tried: eight masked loads of E in flight per pass instead of this two-term loop: 273 -> 313 us per 8-design launch)
-    for (int n = 0; n < nOrders; ++n) {
-        const int sb = n * n, se = min(S, (n + 1) * (n + 1));
-        T a0 = zero_of<T>(), a1 = zero_of<T>();
-        int s = sb;
-        for (; s + 1 < se; s += 2) { cfma(a0, y[s], e[s]); cfma(a1, y[s + 1], e[s + 1]); }
-        if (s < se) cfma(a0, y[s], e[s]);
-        if (d0 + dl < D) QT[((int64_t)n * C + c) * ldD + d0 + dl] = a0 + a1;
+    for (int c = threadIdx.x / QT_TD; c < C; c += 512 / QT_TD) {
+        const T* e = E + (int64_t)c * ldE;
+        // (tried: eight masked loads of E in flight per pass instead of this two-term loop: 273 -> 313 us per 8-design launch)
+        for (int n = 0; n < nOrders; ++n) {
+            const int sb = n * n, se = min(S, (n + 1) * (n + 1));
+            T a0 = zero_of<T>(), a1 = zero_of<T>();
+            int s = sb;
+            for (; s + 1 < se; s += 2) { cfma(a0, y[s], e[s]); cfma(a1, y[s + 1], e[s + 1]); }
+            if (s < se) cfma(a0, y[s], e[s]);
+            if (d0 + dl < D) QT[((int64_t)n * C + c) * ldD + d0 + dl] = a0 + a1;
+        }
     }
 }
 
@@ -62,7 +61,7 @@ __global__ void __launch_bounds__(512) qt_kernel(const T* __restrict__ Yc, int64
 // the chunk's b_n(k) table sits in LDS and every LDS broadcast of a b_n feeds two complex FMAs.
 //   G [kb - k0][c][d]
 constexpr int DSP_TD = 64;
-constexpr int DSP_NMAX = 32;  // orders held in registers (simulation order <= 31)
+constexpr int DSP_NMAX = 48;  // orders held in registers (simulation order <= 47: array radius up to 10.9 cm at 48 kHz)
 
 template <typename T, int NMAX>
 __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT, int64_t ldD, const cplx* __restrict__ bn,
@@ -243,18 +242,26 @@ __global__ void __launch_bounds__(256) yri_accurate_kernel(const T* __restrict__
     }
 }
 
+template <typename T, int TD>
+static void qt_launch(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, void* QT, int64_t ldD,
+                      hipStream_t st) {
+    const size_t dyn = sizeof(T) * (size_t)TD * (S + 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)qt_kernel<T, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    qt_kernel<T, TD><<<bgrid((unsigned)ceil_div(D, TD)), 512, dyn, st>>>((const T*)Yc, ldY, (const T*)E, ldE, D, S, C, nOrders, (T*)QT, ldD, batch_ctx().stride);
+    KERNEL_CHECK();
+}
 template <typename T>
 static void qt_impl(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, void* QT, int64_t ldD,
                     hipStream_t st) {
-    const size_t dyn = sizeof(T) * (size_t)QT_TD * (S + 1);
-    if (dyn > 150 * 1024) throw Error(2, "qt: simulation order too large for the LDS-resident tile");
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)qt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
-    qt_kernel<T><<<bgrid((unsigned)ceil_div(D, QT_TD)), 512, dyn, st>>>((const T*)Yc, ldY, (const T*)E, ldE, D, S, C, nOrders, (T*)QT, ldD, batch_ctx().stride);
-    KERNEL_CHECK();
+    const size_t row = sizeof(T) * (size_t)(S + 1);
+    if (16 * row <= 150 * 1024) qt_launch<T, 16>(Yc, ldY, E, ldE, D, S, C, nOrders, QT, ldD, st);
+    else if (8 * row <= 150 * 1024) qt_launch<T, 8>(Yc, ldY, E, ldE, D, S, C, nOrders, QT, ldD, st);
+    else if (4 * row <= 150 * 1024) qt_launch<T, 4>(Yc, ldY, E, ldE, D, S, C, nOrders, QT, ldD, st);
+    else throw Error(2, "qt: simulation order too large for the LDS-resident tile");
 }
 void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
                int64_t ldD, hipStream_t st) {
@@ -267,26 +274,28 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
                           hipStream_t st) {
     const int nbins = P - k0;
     if (nbins <= 0) return;
-    if (nOrders > DSP_NMAX) throw Error(2, "dspace: simulation order above 31 is not supported in this build");
+    if (nOrders > DSP_NMAX) throw Error(2, "dspace: simulation order above 47 is not supported in this build");
     int chunks = 8;
-    const int nmax = nOrders <= 20 ? 20 : DSP_NMAX;
+    const int nmax = nOrders <= 20 ? 20 : nOrders <= 32 ? 32 : DSP_NMAX;
     while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nmax > 56 * 1024) ++chunks;  // b_n table of a chunk in LDS
     const int bpc = (nbins + chunks - 1) / chunks;
     const size_t dyn = sizeof(cplx) * (size_t)bpc * nmax;
     const dim3 grid((unsigned)ceil_div(D, DSP_TD), chunks);
     if (nOrders <= 20)
         dspace_g_kernel<T, 20><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
+    else if (nOrders <= 32)
+        dspace_g_kernel<T, 32><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
     else
         dspace_g_kernel<T, DSP_NMAX><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
     KERNEL_CHECK();
 }
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
                      hipStream_t st, int real_mode, int sh_order) {
-    if (is_cplx && real_mode && nOrders <= DSP_NMAX && C <= 64 && P - k0 > 0) {
+    if (is_cplx && real_mode && nOrders <= 32 && C <= 64 && P - k0 > 0) {
         int chunks = 8;    // 8-design launch: 2 -> 929, 4 -> 896, 8 -> 894, 12 -> 1032, 16 -> 1115, 24 -> 1385 us (every chunk re-reads QT)
         const bool nt = true;  // streaming stores: G is written once here and read once by the sweep
         const int nbins = P - k0;
-        const int nmax = nOrders <= 12 ? 12 : nOrders <= 20 ? 20 : DSP_NMAX;   // orders held in registers (table rows padded to it)
+        const int nmax = nOrders <= 12 ? 12 : nOrders <= 20 ? 20 : 32;   // orders held in registers (table rows padded to it)
         while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nmax > 56 * 1024) ++chunks;
         const int bpc = (nbins + chunks - 1) / chunks;
         const size_t dyn = sizeof(cplx) * (size_t)bpc * nmax;
@@ -294,7 +303,7 @@ void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, 
 #define EMAGLS_DSPR(NM, NTS) dspace_g_real_kernel<NM, NTS><<<bgrid(grid), 256, dyn, st>>>((const cplx*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, sh_order, batch_ctx().stride)
         if (nmax == 12) { if (nt) EMAGLS_DSPR(12, true); else EMAGLS_DSPR(12, false); }
         else if (nmax == 20) { if (nt) EMAGLS_DSPR(20, true); else EMAGLS_DSPR(20, false); }
-        else EMAGLS_DSPR(DSP_NMAX, false);
+        else EMAGLS_DSPR(32, false);
 #undef EMAGLS_DSPR
         KERNEL_CHECK();
         return;

@@ -54,8 +54,9 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
     cplx B[RPT];
     // ------------------------------------------------------------------ 1. assemble / load B_k
     if (a.Tn) {
+        const int bstr = a.bn_stride > 0 ? a.bn_stride : a.nOrders;
         for (int n = tid; n < a.nOrders; n += blockDim.x) {
-            cplx b = a.bn[(int64_t)kb * a.nOrders + n];
+            cplx b = a.bn[(int64_t)kb * bstr + n];
             if (kb == a.P - 1) b.y = 0.0;  // Nyquist: real(Bn)  (dependencies/getSMAIRMatrix.m:115-117)
             bns[n] = b;
         }
@@ -83,71 +84,6 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
             const int s = ch + NCH * i;
             B[i] = (active && s < S) ? X[(int64_t)c * ldS + s] : mk(0, 0);
         }
-    }
-    // ------------------------------------------------------------------ 1b. Gram route
-    // Well above k_cut the columns of B_k are well conditioned (cond < ~3e2, decided by the host from kr): the Jacobi
-    // kernel can work on A = B^H B directly (error eps cond^2, here < 1e-11) and the 25 sequential reflector steps,
-    // their workspace traffic and the back-transform disappear.  A is formed from LDS row chunks in 2 x 2 tiles.
-    if (a.gram_from > 0 && kb >= a.gram_from) {
-        constexpr int GR = 4 * NCH;                    // rows per chunk (each lane contributes 4 of its rows)
-        cplx* Bs = vbuf + 2 * (size_t)ldS;             // [CPMAX][GR + 1]
-        constexpr int GLD = GR + 1;
-        for (int idx = tid; idx < CPMAX * GLD; idx += blockDim.x) Bs[idx] = mk(0, 0);
-        const int nblk1 = (C + 1) / 2, ntile = nblk1 * (nblk1 + 1) / 2;
-        const int part = tid & 7, tstep = blockDim.x >> 3;
-        constexpr int TS = 2;   // tile slots per thread: (16 * 17 / 2 = 136 tiles) * 8 lanes <= 2 * 832 threads
-        int tbi[TS], tbj[TS];
-        bool tvalid[TS];
-        cplx g00[TS], g01[TS], g10[TS], g11[TS];
-#pragma unroll
-        for (int u = 0; u < TS; ++u) {
-            int t = (tid >> 3) + u * tstep, bi = 0;
-            tvalid[u] = t < ntile;
-            while (bi < nblk1 && t >= nblk1 - bi) { t -= nblk1 - bi; ++bi; }
-            tbi[u] = tvalid[u] ? bi : 0;
-            tbj[u] = tvalid[u] ? bi + t : 0;
-            g00[u] = g01[u] = g10[u] = g11[u] = mk(0, 0);
-        }
-        __syncthreads();
-        for (int g = 0; g * 4 < RPT; ++g) {
-            if (active) {
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int i = 4 * g + ii;
-                    cplx v = mk(0, 0);
-#pragma unroll
-                    for (int i2 = 0; i2 < RPT; ++i2) if (i2 == i) v = B[i2];   // (static register indexing)
-                    Bs[c * GLD + ch + NCH * ii] = v;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < TS; ++u) {
-                if (!tvalid[u]) continue;
-                const cplx* a0 = Bs + (2 * tbi[u]) * GLD, *a1 = a0 + GLD, *b0 = Bs + (2 * tbj[u]) * GLD, *b1 = b0 + GLD;
-#pragma unroll 4
-                for (int rr = 0; rr < GR / 8; ++rr) {
-                    const int r = rr * 8 + part;
-                    const cplx x0 = a0[r], x1 = a1[r], y0 = b0[r], y1 = b1[r];
-                    cfma_conj(g00[u], x0, y0); cfma_conj(g01[u], x0, y1); cfma_conj(g10[u], x1, y0); cfma_conj(g11[u], x1, y1);
-                }
-            }
-            __syncthreads();
-        }
-        cplx* A = a.R2w + (int64_t)bl_x * C * C;   // full Hermitian matrix, row major
-        auto put = [&](int r, int cc, cplx v) {
-            if (r < C && cc < C) { A[(int64_t)r * C + cc] = v; A[(int64_t)cc * C + r] = conj(v); }
-        };
-#pragma unroll
-        for (int u = 0; u < TS; ++u) {
-            const cplx s00 = group_sum<8>(g00[u]), s01 = group_sum<8>(g01[u]), s10 = group_sum<8>(g10[u]), s11 = group_sum<8>(g11[u]);
-            if (tvalid[u] && part == 0) {
-                const int r0 = 2 * tbi[u], c0 = 2 * tbj[u];
-                put(r0, c0, s00); put(r0, c0 + 1, s01); put(r0 + 1, c0, s10); put(r0 + 1, c0 + 1, s11);
-            }
-        }
-        if (tid == 0) a.route[kb] = 1;
-        return;
     }
     // ------------------------------------------------------------------ 2. Householder QR
     // One barrier per column: while the lane groups c > j apply H_j, the group of column j+1 goes on to form v_{j+1}
@@ -239,9 +175,6 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     __shared__ double g_s[CPMAX];
     __shared__ double w_s[CPMAX];
     __shared__ double sig_s[CPMAX];
-    __shared__ __attribute__((aligned(16))) cplx Ws[2][CPMAX + 1];   // direct route: pivot column and row of a sweep step
-    __shared__ double fro_s[2];
-    __shared__ int chol_bad;
     const int tid = threadIdx.x;
     const int C = a.C;
     const int Cp = (C + 1) & ~1;
@@ -257,81 +190,10 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     if (bi >= a.nbins) break;
     const int kb = a.kb0 + bi;
     const cplx* R2 = a.R2w + (int64_t)bi * C * C;
-    const bool gram = a.route && a.route[kb] != 0;   // R2 holds A = B^H B (full): X = A, Xrot = V Lambda
-    // ---- direct route.  The reference clips the singular values at reg_c s_max (1 %).  Where cond(B) <= 1/reg_c nothing
-    // is clipped and M = V diag(1/s^2) V^H = (B^H B)^-1: an in-place inverse of the C x C Gram matrix instead of an SVD
-    // (all swept bins of BASELINE config 3 qualify: cond 54 at k_cut, < 2 above 5 kHz).  The certificate
-    // cond(A) <= ||A||_F ||A^-1||_F <= 1/reg_c^2 is sufficient and rigorous; bins that fail it take the Jacobi route.
-    if (gram && a.reg_mode == 0 && a.Mw) {
-        if (tid < 2) fro_s[tid] = 0.0;
-        if (tid == 0) chol_bad = 0;
-        __syncthreads();
-        double fa = 0.0;
-        for (int idx = tid; idx < CPMAX * CPMAX; idx += 256) {
-            const int col = idx / CPMAX, row = idx % CPMAX;
-            cplx v = mk(0, 0);
-            if (row < C && col < C) v = R2[(int64_t)row * C + col];
-            Xs[col][row] = v;   // A[row][col]
-            fa += norm2(v);
-        }
-        fa = wave_sum(fa);
-        if ((tid & 63) == 0) atomicAdd(&fro_s[0], fa);
-        __syncthreads();
-        // in-place inversion of the Hermitian positive definite A by C sweep (Gauss-Jordan) steps without pivoting: every
-        // step is one rank-1 update of the whole C x C matrix spread over the 256 threads, two barriers per step
-        // (a Cholesky factorisation + triangular inverse has three times the sequential depth at this size)
-        cplx* colj = &Ws[0][0];          // column j and row j of the current matrix
-        cplx* rowj = &Ws[1][0];
-        for (int j = 0; j < C; ++j) {
-            const double piv = Xs[j][j].x;
-            if (!(piv > 0.0)) { if (tid == 0) chol_bad = 1; }
-            const double ip = fast_rcp(piv > 0.0 ? piv : 1.0);
-            if (tid < C) { colj[tid] = Xs[j][tid]; rowj[tid] = Xs[tid][j]; }   // A[tid][j], A[j][tid]
-            __syncthreads();
-            for (int idx = tid; idx < C * C; idx += 256) {
-                const int k = idx / C, i = idx - k * C;   // element A[i][k] = Xs[k][i]
-                cplx v;
-                if (i == j && k == j) v = mk(ip, 0.0);
-                else if (i == j) v = mk(rowj[k].x * ip, rowj[k].y * ip);
-                else if (k == j) v = mk(-colj[i].x * ip, -colj[i].y * ip);
-                else { cplx pr = mk(0, 0); cfma(pr, colj[i], rowj[k]); v = Xs[k][i] - mk(pr.x * ip, pr.y * ip); }
-                Xs[k][i] = v;
-            }
-            __syncthreads();
-        }
-        // M = A^-1 (now in Xs); its Frobenius norm for the certificate
-        cplx* M = a.Mw + (int64_t)bi * C * C;
-        cplx mloc[(CPMAX * CPMAX + 255) / 256];
-        double fm = 0.0;
-#pragma unroll
-        for (int u = 0; u < (CPMAX * CPMAX + 255) / 256; ++u) {
-            const int idx = tid + 256 * u, aa = idx / C, bb = idx % C;
-            cplx acc = mk(0, 0);
-            if (idx < C * C) acc = Xs[bb][aa];   // M[aa][bb]
-            mloc[u] = acc;
-            fm += norm2(acc);
-        }
-        fm = wave_sum(fm);
-        if ((tid & 63) == 0) atomicAdd(&fro_s[1], fm);
-        __syncthreads();
-        const double thr = 1.0 / (a.reg_c * a.reg_c);
-        const bool direct = !chol_bad && fro_s[0] * fro_s[1] <= thr * thr && fro_s[0] > 0.0;   // (||A||_F ||A^-1||_F)^2
-        if (direct) {
-#pragma unroll
-            for (int u = 0; u < (CPMAX * CPMAX + 255) / 256; ++u) {
-                const int idx = tid + 256 * u;
-                if (idx < C * C) M[idx] = mloc[u];
-            }
-            if (a.sv && tid < C) {
-                // bounds instead of singular values: s_max <= ||A||_F^(1/2), s_min >= ||A^-1||_F^(-1/2)
-                a.sv[(int64_t)kb * C + tid] = (tid == 0) ? sqrt(sqrt(fro_s[0])) : 1.0 / sqrt(sqrt(fro_s[1]));
-            }
-            if (tid == 0) { a.route[kb] = 2; if (a.sweeps_out) a.sweeps_out[kb] = 0; }
-            __syncthreads();
-            continue;   // next bin of the run
-        }
-        __syncthreads();
-    }
+    // Gram-route bins: gram_solve_kernel (gramroute.hip) inverted the well-conditioned ones directly (route 2: nothing left to
+    // do) and left A = B^H B (full Hermitian) in R2w for the others (route 1): X = A, Xrot = V Lambda
+    if (a.route && a.route[kb] == 2) continue;   // (workgroup-uniform)
+    const bool gram = a.route && a.route[kb] != 0;
     if (!have_v) {
         for (int idx = tid; idx < CPMAX * CPMAX; idx += 256) {
             const int col = idx / CPMAX, row = idx % CPMAX;  // X[row][col] = conj(R2[col][row]) for col <= row
@@ -459,7 +321,10 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
         if (gram && tid == 0) {
             double smin = INFINITY;
             for (int i = 0; i < C; ++i) smin = fmin(smin, sig_s[i]);
-            if (!(smax <= 3.0e3 * smin) && a.status) atomicExch(a.status + 2, 1);  // the kr estimate was too optimistic
+            if (!(smax <= 3.0e3 * smin) && a.status) {   // the kr estimate was too optimistic: the host moves the start of the route
+                atomicExch(a.status + 2, 1);
+                atomicMax(a.status + 3, kb);
+            }
         }
         if (a.sv && tid < C) a.sv[(int64_t)kb * C + tid] = s;
     }
@@ -574,28 +439,16 @@ template <typename TT, int NCH, int RPT, int MAXT>
 static void launch_one(const FactorArgs& a, int nbins, hipStream_t st, int phases) {
     const int threads = (int)(ceil_div((int64_t)NCH * a.C, 64) * 64);
     if (threads > MAXT) throw Error(2, "factor: too many channels for this row count");
-    const size_t dyn = ((size_t)2 * a.ldS + (a.gram_from > 0 ? (size_t)CPMAX * (4 * NCH + 1) : 0)) * sizeof(cplx);
+    const size_t dyn = (size_t)2 * a.ldS * sizeof(cplx);
     if (a.nOrders > 96) throw Error(2, "factor: simulation order above 95 is not supported");
-    FactorArgs aq = a;
-    if (dyn > 140 * 1024) {  // no room for the Gram route's row chunks next to the reflector buffers
-        aq.gram_from = 0;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)factor_qr_kernel<TT, NCH, RPT, MAXT>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        attr_set = true;
-    }
     if (phases & 1) {
-        factor_qr_kernel<TT, NCH, RPT, MAXT><<<bgrid(nbins), threads, aq.gram_from > 0 ? dyn : (size_t)2 * a.ldS * sizeof(cplx), st>>>(aq, batch_ctx().stride);
+        factor_qr_kernel<TT, NCH, RPT, MAXT><<<bgrid(nbins), threads, dyn, st>>>(a, batch_ctx().stride);
         KERNEL_CHECK();
-        {
-            FactorArgs aj = a;
-            aj.nbins = nbins;
-            const int jr = aj.jrun > 0 ? aj.jrun : 1;
-            aj.jsplit = (jr > 1 && aj.gram_from > aj.kb0) ? std::min(nbins, aj.gram_from - aj.kb0) : 0;
-            factor_jacobi_kernel<<<bgrid(aj.jsplit + (nbins - aj.jsplit + jr - 1) / jr), 256, 0, st>>>(aj, batch_ctx().stride);
-        }
+        FactorArgs aj = a;
+        aj.nbins = nbins;
+        aj.jsplit = nbins;   // one workgroup per bin: the full SVDs of the ill-conditioned bins are the long pole
+        aj.jrun = 1;
+        factor_jacobi_kernel<<<bgrid(nbins), 256, 0, st>>>(aj, batch_ctx().stride);
         KERNEL_CHECK();
     }
     if (phases & 2) {
@@ -624,6 +477,17 @@ static void dispatch(const FactorArgs& a, int nbins, hipStream_t st, int phases)
         if (S <= 64 * 64) return launch_one<TT, 64, 64, 512>(a, nbins, st, phases);
     }
     throw Error(2, "factor: problem shape (rows x channels) not supported in this build");
+}
+
+void launch_factor_jacobi_gram(const FactorArgs& a, int nbins, hipStream_t st) {
+    if (nbins <= 0) return;
+    if (a.C > CPMAX) throw Error(2, "factor: more than 32 output channels is not supported in this build");
+    FactorArgs aj = a;
+    aj.nbins = nbins;
+    const int jr = aj.jrun > 0 ? aj.jrun : 1;
+    aj.jsplit = 0;   // runs of jr neighbouring bins per workgroup (warm start); bins that took the direct route are skipped
+    factor_jacobi_kernel<<<bgrid((nbins + jr - 1) / jr), 256, 0, st>>>(aj, batch_ctx().stride);
+    KERNEL_CHECK();
 }
 
 // phases: 1 = QR + Jacobi, 2 = back-transform (+ least-squares bins), 3 = both

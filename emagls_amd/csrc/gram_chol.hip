@@ -92,16 +92,20 @@ __global__ void __launch_bounds__(256) gram_mfma_kernel(const T* __restrict__ Yc
             }
 }
 
+// sums the K-split partials into the Gram matrix Gy (S x S, upper block triangle) and copies its leading Sh x Sh block to R
+// (compact, leading dimension Sh), which the Cholesky factorisation then overwrites: Gy itself stays intact for the Gram route
 template <typename T>
-__global__ void __launch_bounds__(256) gram_reduce_kernel(const T* __restrict__ Gp, int S, int ksplit, T* __restrict__ G, size_t bstride) {
-    Gp = boff(Gp, bstride); G = boff(G, bstride);
+__global__ void __launch_bounds__(256) gram_reduce_kernel(const T* __restrict__ Gp, int S, int ksplit, T* __restrict__ G, T* __restrict__ R, int Sh,
+                                                          size_t bstride) {
+    Gp = boff(Gp, bstride); G = boff(G, bstride); R = boff(R, bstride);
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)S * S) return;
     const int i = (int)(idx / S), j = (int)(idx % S);
     T acc = zero_of<T>();
     if ((i >> 6) <= (j >> 6))
         for (int y = 0; y < ksplit; ++y) acc = acc + Gp[(int64_t)y * S * S + idx];
-    G[idx] = acc;
+    if (G) G[idx] = acc;
+    if (R && i < Sh && j < Sh) R[(int64_t)i * Sh + j] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -409,30 +413,35 @@ __global__ void __launch_bounds__(256) small_gemm_kernel(const TA* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-int gram_ksplit(int64_t D) {
+// K splits of the Gram product: enough workgroups to fill the chip (about a thousand), never slices shorter than 32 directions.
+// Few tiles (S = 400: 28) take the full 32 splits; many tiles (S = 2025: 528) need only two, which also keeps the partials small.
+int gram_ksplit(int64_t D, int S) {
+    const int nbt = (S + 63) / 64;
+    const int ntiles = nbt * (nbt + 1) / 2;
     int ks = 32;
-    while (ks > 1 && D / ks < 32) ks >>= 1;
+    while (ks > 1 && (D / ks < 32 || (int64_t)ntiles * ks > 1024 + ntiles)) ks >>= 1;
     return ks;
 }
-int64_t gram_dpad(int64_t D) {
-    const int ks = gram_ksplit(D);
+int64_t gram_dpad(int64_t D, int S) {
+    const int ks = gram_ksplit(D, S);
     const int64_t kc = ceil_div(ceil_div(D, ks), 4) * 4;
     return kc * ks;
 }
 
 template <typename T>
-static void gram_impl(const void* Yc, int64_t D, int S, int64_t ld, void* Gp, void* G, hipStream_t st) {
-    const int ks = gram_ksplit(D);   // (fewer splits in lane mode were measured slower: 595 vs 454 + 104 us per 8 designs)
-    const int kc = (int)(gram_dpad(D) / ks);
+static void gram_impl(const void* Yc, int64_t D, int S, int64_t ld, void* Gp, void* G, void* R, int Sh, hipStream_t st) {
+    const int ks = gram_ksplit(D, S);   // (fewer splits in lane mode were measured slower: 595 vs 454 + 104 us per 8 designs)
+    const int kc = (int)(gram_dpad(D, S) / ks);
     const int nbt = (S + 63) / 64;
     const int ntiles = nbt * (nbt + 1) / 2;
     gram_mfma_kernel<T><<<bgrid(dim3(ntiles, ks)), 256, 0, st>>>((const T*)Yc, ld, S, kc, nbt, (T*)Gp, batch_ctx().stride);
     KERNEL_CHECK();
-    gram_reduce_kernel<T><<<bgrid((unsigned)ceil_div((int64_t)S * S, 256)), 256, 0, st>>>((const T*)Gp, S, ks, (T*)G, batch_ctx().stride);
+    gram_reduce_kernel<T><<<bgrid((unsigned)ceil_div((int64_t)S * S, 256)), 256, 0, st>>>((const T*)Gp, S, ks, (T*)G, (T*)R, Sh, batch_ctx().stride);
     KERNEL_CHECK();
 }
-void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, void* Gp, void* G, hipStream_t st) {
-    if (is_cplx) gram_impl<cplx>(Yc, D, S, ld, Gp, G, st); else gram_impl<double>(Yc, D, S, ld, Gp, G, st);
+// Gy = Yc^H Yc (S x S, may be null) and R = its leading Sh x Sh block (compact; may be null), ready for launch_cholesky(R, Sh)
+void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, void* Gp, void* G, void* R, int Sh, hipStream_t st) {
+    if (is_cplx) gram_impl<cplx>(Yc, D, S, ld, Gp, G, R, Sh, st); else gram_impl<double>(Yc, D, S, ld, Gp, G, R, Sh, st);
 }
 
 template <typename T> static void chol_impl(void* G, int S, int* flag, hipStream_t st) {

@@ -34,9 +34,9 @@ void launch_filter_epilogue(const void* W, int C, int nfft, int len, const void*
                             int dc_rule, int shift_mode, int out_cplx, void* outL, void* outR, hipStream_t st);
 
 // ---- gram_chol.hip
-int gram_ksplit(int64_t D);
-int64_t gram_dpad(int64_t D);
-void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, void* Gp, void* G, hipStream_t st);
+int gram_ksplit(int64_t D, int S);
+int64_t gram_dpad(int64_t D, int S);
+void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, void* Gp, void* G, void* R, int Sh, hipStream_t st);
 void launch_cholesky(void* G, int S, bool is_cplx, int* flag, hipStream_t st);
 void launch_qform(const void* Yc, const void* R, void* Rinv, int S, int64_t D, int64_t ld, bool is_cplx, void* Q, hipStream_t st);
 // zs R^H = z for the rows Z[kb][c][:] of the flagged bins (cond_ok[kb] == 0), in place (complex basis)
@@ -50,6 +50,18 @@ void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int l
 // ---- factor.hip
 struct FactorArgs;
 void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st, int phases = 3);
+// Jacobi SVD only, on Gram matrices that gram_solve_kernel handed over (route[kb] == 1); bins with route[kb] == 2 are skipped
+void launch_factor_jacobi_gram(const FactorArgs& a, int nbins, hipStream_t st);
+
+// ---- gramroute.hip
+void launch_gram_kmat(const void* Gy, const void* E, int S, int ldE, int C, int nOrd, bool is_cplx, void* F, int64_t ldF, double* Kmat, int ldK,
+                      hipStream_t st);
+void launch_gram_gemm(const void* bn, int nOrd, int P, int kb0, int nbins, double* Cf, int ldC, const double* Kmat, int ldK, int C, double* Apk,
+                      int ldA, hipStream_t st);
+void launch_gram_solve(const double* Apk, int ldA, int C, int kb0, int nbins, double reg_c, void* Mw, void* R2w, double* sv, int* route,
+                       int* sweeps_out, hipStream_t st);
+void launch_ls_gram(const void* Hc, int64_t ldH, int n_c, const void* G, int64_t g_stride, int64_t ldD, const void* Mw, int D, int C, int P,
+                    int kb_lo, int kb_hi, void* W, hipStream_t st);
 
 // ---- sweep.hip
 struct DenseSweepArgs;

@@ -141,6 +141,10 @@ typedef struct emagls_plan_info {
     double mean_grid_dev_deg;        /* FROM_ATF */
     int num_sweep_launches;
     int64_t device_bytes;
+    /* routes of the per-bin factorisation of the array designs (0 elsewhere), 0-based bins: [1, hh_end) orthonormal route
+     * (Householder QR + Jacobi SVD) on the lowest hh_orders orders, [gram_from, P) Gram route (gram_from == 0: none);
+     * g_first: first bin whose direction-space operand G_k is formed */
+    int gram_from, hh_end, hh_orders, g_first;
 } emagls_plan_info;
 
 int emagls_plan_create(const emagls_design_desc* desc, emagls_plan** plan);

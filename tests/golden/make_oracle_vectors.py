@@ -1,0 +1,34 @@
+"""Expected outputs of the CPU oracle for cases that are too slow to recompute inside the GPU test suite.
+
+    python tests/golden/make_oracle_vectors.py        (about 10 minutes on 8 cores)
+
+Inputs are synthetic and seeded (emagls_amd.synth on the reference's own grids), so the tests regenerate them and only
+the oracle's outputs are stored.  These are vectors of the build's own restatement (oracle/emagls_oracle.py), not of the
+MATLAB reference: they pin the GPU path to the oracle at sizes the oracle needs minutes for.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from emagls_amd import synth  # noqa: E402
+from oracle import emagls_oracle as O  # noqa: E402
+
+
+def main():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_fixtures.npz"))
+    azi, zen = g["grid/hrirGridAziRad"], g["grid/hrirGridZenRad"]
+    maz, mzn = g["grid/micGridAziRad"], g["grid/micGridZenRad"]
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen)
+    out = {}
+    # BASELINE config 4, far end of the radius batch: r = 10 cm, 1024 taps, simulation order 44
+    wL, wR = O.getEMagLs2Filters(hL, hR, azi, zen, 0.10, maz, mzn, 4, 48000.0, 1024, "real")
+    out["config4_r100mm_len1024/wL"], out["config4_r100mm_len1024/wR"] = wL, wR
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz"), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -27,10 +27,24 @@ def test_header_and_binding_agree(lib):
         assert hasattr(lib, name), name
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors have the size and field offsets the C compiler gives the header's structs."""
+    import subprocess
     from emagls_amd import _lib
-    assert C.sizeof(_lib.DesignDesc) == 88
-    assert C.sizeof(_lib.PlanInfo) == 88
+    src = tmp_path / "layout.c"
+    fields_d = [f[0] for f in _lib.DesignDesc._fields_]
+    fields_i = [f[0] for f in _lib.PlanInfo._fields_]
+    body = "".join('printf("%%zu\\n", offsetof(emagls_design_desc, %s));' % f for f in fields_d)
+    body += "".join('printf("%%zu\\n", offsetof(emagls_plan_info, %s));' % f for f in fields_i)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "emagls.h"\nint main(void){printf("%zu %zu\\n", '
+                   'sizeof(emagls_design_desc), sizeof(emagls_plan_info));' + body + 'return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(out[0]), int(out[1])] == [C.sizeof(_lib.DesignDesc), C.sizeof(_lib.PlanInfo)]
+    offs = [int(x) for x in out[2:]]
+    want = [getattr(_lib.DesignDesc, f).offset for f in fields_d] + [getattr(_lib.PlanInfo, f).offset for f in fields_i]
+    assert offs == want
 
 
 def test_no_cpu_fallback(lib):

@@ -1,0 +1,129 @@
+"""BASELINE config 4 as specified: getEMagLs2Filters on the raw 32-microphone em32, 2702 directions, for array radii
+spread over 2..10 cm.  The simulation order max(4, ceil(fs*pi*r/343)) reaches 44 (S = 2025 SH channels) at 10 cm
+(dependencies/getSMAIRMatrix.m:95).  GPU path against the oracle and, for the job batching (emagls_amd.batch.shard_jobs /
+lane_groups + Batch), lane batches against one-shot designs."""
+import numpy as np
+import pytest
+
+from oracle import emagls_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def hrirs64(grids):
+    """64-tap HRIRs: the oracle needs 0.35 s per bin at simulation order 44, so its live comparisons use 64 solved bins."""
+    from emagls_amd import synth
+    return synth.rigid_sphere_hrirs(grids["azi"], grids["zen"], taps=64, centre_delay=16.0)
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def test_every_radius_of_the_config4_batch_is_supported(grids):
+    """No EMAGLS_ERR_UNSUPPORTED anywhere in linspace(0.02, 0.10, 256) at 1024 taps; the routes of the per-bin factorisation
+    keep the orthonormal (Householder) route within its tile: at most 27 orders there, whatever the simulation order."""
+    from emagls_amd import Plan, _lib as L
+    from emagls_amd.batch import simulation_order
+    seen = set()
+    for r in np.linspace(0.02, 0.10, 256):
+        so = simulation_order(4, 48000.0, r, raw=True)
+        if so in seen:
+            continue   # one plan per shape class (a plan allocates its buffers: 36 classes instead of 256 radii)
+        seen.add(so)
+        p = Plan(L.KIND_EMAGLS2, "real", 4, 48000.0, 1024, 128, 2702, float(r), 32)
+        i = p.info()
+        p.close()
+        assert i.sim_order == so and i.num_sh_sim == (so + 1) ** 2
+        assert 1 <= i.gram_from < i.num_pos_freqs and i.hh_orders <= 27 and i.hh_orders <= so + 1
+    assert min(seen) == 9 and max(seen) == 44 and len(seen) == 36
+
+
+@pytest.mark.parametrize("radius,length", [(0.10, 64), (0.0875, 64), (0.062, 128)])
+def test_emagls2_large_radius_vs_oracle(grids, hrirs64, radius, length):
+    """Simulation orders 44 / 39 / 28 (S = 2025 / 1600 / 841): all of them beyond the 768-row tile of the S-space route, served
+    by the Gram route on all orders plus the orthonormal route on the orders that are above rounding noise in the low bins."""
+    import emagls_amd as E
+    hrirs = hrirs64
+    args = (hrirs[0], hrirs[1], grids["azi"], grids["zen"], radius, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, length, "real")
+    wL, wR = E.getEMagLs2Filters(*args)
+    oL, oR = O.getEMagLs2Filters(*args)
+    assert wL.shape == (length, 32) and wL.dtype == np.float64
+    nd = O.assert_all_close_metrics(np.hstack([wL, wR]), np.hstack([oL, oR]))
+    print(f"eMagLS2 r={radius} len={length}: rel L {rel(wL, oL):.3e} R {rel(wR, oR):.3e} norm_diff={nd[0]:.3e} max|dB|={nd[2]:.3e}")
+    assert rel(wL, oL) < TOL and rel(wR, oR) < TOL
+
+
+def test_emagls2_config4_full_size_r10cm(grids, hrirs):
+    """One job of the config-4 batch at the far end of the radius range, full size: r = 10 cm, 1024 taps (nfft 2048, 1024 solved
+    bins, k_cut 86), simulation order 44.  The oracle needs minutes for it: its output is a stored vector
+    (tests/golden/oracle_vectors.npz, written by tests/golden/make_oracle_vectors.py from the same seeded inputs)."""
+    import os
+    import emagls_amd as E
+    vec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
+    args = (hrirs[0], hrirs[1], grids["azi"], grids["zen"], 0.10, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 1024, "real")
+    wL, wR = E.getEMagLs2Filters(*args)
+    oL, oR = vec["config4_r100mm_len1024/wL"], vec["config4_r100mm_len1024/wR"]
+    assert wL.shape == oL.shape == (1024, 32)
+    print(f"eMagLS2 config 4, r = 10 cm, 1024 taps: rel L {rel(wL, oL):.3e} R {rel(wR, oR):.3e}")
+    assert rel(wL, oL) < TOL and rel(wR, oR) < TOL
+
+
+def test_emagls_sh_domain_large_radius(grids, hrirs64):
+    """The SH-domain design (getEMagLsFilters, 25 channels, complex basis) on an 8 cm array: simulation order 36."""
+    import emagls_amd as E
+    hrirs = hrirs64
+    args = (hrirs[0], hrirs[1], grids["azi"], grids["zen"], 0.08, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 64, "complex")
+    wL, wR = E.getEMagLsFilters(*args)
+    oL, oR = O.getEMagLsFilters(*args)
+    print(f"eMagLS r = 8 cm: rel L {rel(wL, oL):.3e} R {rel(wR, oR):.3e}")
+    assert rel(wL, oL) < TOL and rel(wR, oR) < TOL
+
+
+def test_radius_sweep_through_job_batching(grids, hrirs64):
+    """shard_jobs + lane_groups + Batch over 16 radii spanning 2..10 cm (eight shape classes, two radii each, so that every
+    lane batch holds two designs): each job equals its one-shot design."""
+    import emagls_amd as E
+    from emagls_amd import Batch, Plan, _lib as L
+    from emagls_amd.batch import lane_groups, shard_jobs, simulation_order
+    hrirs, length = hrirs64, 64
+    base = np.linspace(0.02, 0.10, 8)
+    radii = np.sort(np.concatenate([base, base - 4e-4]))
+    so = [simulation_order(4, 48000.0, r, raw=True) for r in radii]
+    assert len(set(so)) == 8 and max(so) == 44
+    shards = shard_jobs([(s + 1) ** 2 for s in so], 2)      # two "ranks", run one after the other on this GPU
+    assert sorted(j for s in shards for j in s) == list(range(16))
+    results = {}
+    for mine in shards:
+        for group in lane_groups([so[j] for j in mine]):
+            plans = []
+            for gi in group:
+                r = float(radii[mine[gi]])
+                p = Plan(L.KIND_EMAGLS2, "real", 4, 48000.0, length, 64, 2702, r, 32)
+                p.set_hrir_grid(grids["azi"], grids["zen"])
+                p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+                p.set_hrirs(hrirs[0], hrirs[1])
+                plans.append(p)
+            b = Batch(plans)
+            b.execute()
+            b.execute()     # (second execute: hipGraph capture path)
+            for gi, w in zip(group, b.get_filters()):
+                results[mine[gi]] = w
+            b.close()
+            for p in plans:
+                p.close()
+    assert sorted(results) == list(range(16))
+    worst = 0.0
+    for j in (0, 5, 10, 15):     # one-shot designs of a spread of jobs (each also a different code path: plan of its own)
+        wL, wR = E.getEMagLs2Filters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], float(radii[j]), grids["mic_azi"], grids["mic_zen"],
+                                     4, 48000.0, length, "real")
+        worst = max(worst, rel(results[j][0], wL), rel(results[j][1], wR))
+    print(f"radius sweep: lane batches vs one-shot designs, worst rel = {worst:.3e}")
+    assert worst < 1e-9
+    # and two of them against the oracle (smallest and largest radius)
+    for j in (0, 15):
+        oL, oR = O.getEMagLs2Filters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], float(radii[j]), grids["mic_azi"], grids["mic_zen"],
+                                     4, 48000.0, length, "real")
+        assert rel(results[j][0], oL) < TOL and rel(results[j][1], oR) < TOL

@@ -148,17 +148,21 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
     ldD = -(-D // 64) * 64
     i = p.info()
     P, kcut0 = i.num_pos_freqs, i.k_cut - 1
+    # routes: bins [1, hh_end) Householder QR + Jacobi in S space, bins [gram_from, P) through the Gram matrices; on this
+    # 4.2 cm array no order is negligible at the last Householder bin (hh_orders = 20: R, T_n cover all of S)
+    assert i.hh_orders == 20 and 1 < i.gram_from == i.hh_end <= kcut0 + 1 and i.g_first == min(i.gram_from, kcut0)
+    hh_end, g0 = i.hh_end, i.g_first
     Tn = p.debug("Tn", np.complex128, (20, C, ldS))[:, :, :S]
     bn = p.debug("bn", np.complex128, (P, 20))
     Yc = p.debug("Yc", np.complex128).reshape(-1, ldS)[:D, :S]
     Q = np.linalg.solve(np.triu(p.debug("R", np.complex128, (S, S))).T, Yc.T).T  # (not materialised on the GPU)
-    Z = p.debug("Z", np.complex128).reshape(P, C, ldS)[:, :, :S]
+    Z = p.debug("Z", np.complex128)[:hh_end * C * ldS].reshape(hh_end, C, ldS)[:, :, :S]
     sv = p.debug("sv", np.float64).reshape(P, C)
     js = p.debug("jsweeps", np.int32)
     route = p.debug("route", np.int32)   # 0 Householder + Jacobi, 1 Gram + Jacobi, 2 Gram + Cholesky inverse (no SVD)
     assert js[1:P].max() <= 20 and np.all((js[1:P] >= 1) | (route[1:P] == 2)), (js[1:P].min(), js[1:P].max())
     assert (route[kcut0:P] == 2).sum() > 0.5 * (P - kcut0)
-    nsw = P - max(kcut0, 1)  # swept bins; the buffers carry padding for the persistent sweep's whole-row-group loads
+    nsw = P - g0  # bins with a direction-space operand; the buffers carry padding for the persistent sweep's whole-row-group loads
     G = p.debug("G", np.complex128)[:nsw * C * ldD].reshape(nsw, C, ldD)[:, :, :D]
     Mw = p.debug("Mw", np.complex128)[:P * C * C].reshape(P, C, C)  # bin kb is stored at slot kb-1
 
@@ -181,13 +185,13 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
             assert np.abs(np.sort(sv[kb])[::-1] - s).max() < (1e-13 if kb <= kcut0 + 1 else 1e-10) * s[0]
         sreg = 1 / np.maximum(s, 0.01 * s[0])
         Zo = np.conj(U) @ (sreg[:, None] * Vh.conj())
-        if kb < kcut0:  # Z_k is only formed for the least-squares bins (and for ill-conditioned swept bins)
+        if kb < min(kcut0, hh_end):  # Z_k is only formed for the Householder-route least-squares bins (and for ill-conditioned swept bins)
             assert rel(Z[kb].T, Zo) < 1e-8, (kb, rel(Z[kb].T, Zo))
-        if kb >= kcut0:
+        if kb >= g0:
             X = Q @ B  # pwGrid.'  (D x C)
-            assert rel(G[kb - kcut0].T, X) < 1e-12
+            assert rel(G[kb - g0].T, X) < 1e-12
             # Y_reg_inv_k = conj(G_k) conj(M_k): the sweep applies conj(M_k) after the cross-workgroup sum
-            Yri = np.conj(G[kb - kcut0].T) @ np.conj(Mw[kb - 1])
+            Yri = np.conj(G[kb - g0].T) @ np.conj(Mw[kb - 1])
             assert rel(Yri, np.conj(Q) @ Zo) < 1e-9, (kb, rel(Yri, np.conj(Q) @ Zo))
     wL, wR = p.get_filters()
     oL, oR = O.getEMagLsFilters(emagls_plan["hL"], emagls_plan["hR"], emagls_plan["azi"], emagls_plan["zen"],

@@ -1,0 +1,98 @@
+"""Secondary figures of bench.py (same JSON line, key "secondary"): BASELINE config 4 and config 5 on one GPU.
+
+config 4: getEMagLs2Filters, raw 32-microphone em32, 2702 directions, 1024 taps -- one lane batch of 8 array radii of one
+          simulation-order class (a batch of the 256-radius job list as emagls_amd.batch.lane_groups forms them), at the
+          middle (r = 5 cm, order 22) and at the far end (r = 10 cm, order 44) of the radius range;
+config 5: getEMagLsFiltersFromAtf, 16 384 ATF directions x 8 microphones, 2702 HRIR directions, 2048 taps -- one HRTF subject.
+Inputs resident in HBM, hipGraph replay where the pipeline captures; wall-clock over `reps` executes after three warm ones."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _grids():
+    from emagls_amd import synth
+    gpath = os.path.join(ROOT, "tests", "golden", "ref_fixtures.npz")
+    if os.path.exists(gpath):
+        g = np.load(gpath)
+        return g["grid/hrirGridAziRad"], g["grid/hrirGridZenRad"], g["grid/micGridAziRad"], g["grid/micGridZenRad"]
+    azi, zen = synth.fibonacci_grid(2702)
+    maz, mzn = synth.em32_grid()
+    return azi, zen, maz, mzn
+
+
+def config4(radii, reps=4):
+    from emagls_amd import Batch, Plan, synth, _lib as L
+    azi, zen, maz, mzn = _grids()
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen)
+    plans = []
+    for r in radii:
+        p = Plan(L.KIND_EMAGLS2, "real", 4, 48000.0, 1024, hL.shape[0], hL.shape[1], float(r), 32)
+        p.set_hrir_grid(azi, zen)
+        p.set_mic_grid(maz, mzn)
+        p.set_hrirs(hL, hR)
+        plans.append(p)
+    info = plans[0].info()
+    b = Batch(plans)
+    for _ in range(3):
+        b.execute()
+    b.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b.execute()
+    b.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    b.get_filters()   # (status check of the last execute)
+    b.close()
+    for p in plans:
+        p.close()
+    return {"radii_cm": [round(100 * float(radii[0]), 3), round(100 * float(radii[-1]), 3)], "designs_per_batch": len(radii),
+            "sim_order": info.sim_order, "orthonormal_route_orders": info.hh_orders, "gram_route_from_bin": info.gram_from,
+            "ms_per_batch": round(dt * 1e3, 3), "filter_sets_per_s": round(len(radii) / dt, 1)}
+
+
+def config5(reps=4):
+    from emagls_amd import Plan, synth, _lib as L
+    azi, zen, _, _ = _grids()
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen)
+    atf, aazi, azen = synth.glasses_atfs(natf=16384, nmics=8, taps=256)
+    p = Plan(L.KIND_FROM_ATF, "real", 0, 48000.0, 2048, hL.shape[0], hL.shape[1], nmics=8, f_trans=2000.0, atf_taps=256, natf=16384)
+    p.set_hrir_grid(azi, zen)
+    p.set_hrirs(hL, hR)
+    p.set_atfs(atf, aazi, azen)
+    for _ in range(3):
+        p.execute()
+    p.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        p.execute()
+        p.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    p.get_filters()
+    p.close()
+    return {"atf_dirs": 16384, "mics": 8, "taps": 2048, "ms_per_subject": round(dt * 1e3, 3), "filter_sets_per_s": round(1.0 / dt, 1)}
+
+
+def run():
+    out = {}
+    for name, radii in (("config4_r5cm", np.linspace(0.0480, 0.0500, 8)), ("config4_r10cm", np.linspace(0.0980, 0.1000, 8))):
+        try:
+            out[name] = config4(radii)
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+    try:
+        out["config5"] = config5()
+    except Exception as e:
+        out["config5"] = {"error": repr(e)}
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(run()))
