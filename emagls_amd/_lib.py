@@ -36,6 +36,7 @@ SYMBOLS = {
     "emagls_version": (C.c_int, []),
     "emagls_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "emagls_set_device": (C.c_int, [C.c_int]),
+    "emagls_cache_clear": (C.c_int, []),
     "emagls_fp64_peak_tflops": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "emagls_sh_basis": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "emagls_sh_basis_device": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -57,6 +58,8 @@ SYMBOLS = {
                                                      C.c_double, c_i64, C.c_double, C.c_void_p, C.c_void_p,
                                                      C.POINTER(C.c_double)]),
     "emagls_binaural_decode": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_void_p]),
+    "emagls_binaural_decode_complex": (C.c_int, [C.c_void_p, C.c_int, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int, c_i64, C.c_int,
+                                                 C.c_void_p, C.c_void_p]),
     "emagls_plan_create": (C.c_int, [C.POINTER(DesignDesc), C.POINTER(C.c_void_p)]),
     "emagls_plan_destroy": (C.c_int, [C.c_void_p]),
     "emagls_plan_set_hrir_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

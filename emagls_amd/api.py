@@ -177,18 +177,33 @@ def getEMagLsFiltersFromAtf(hL, hR, hrirGridAziZenRad, atfIrs, atfGridAziZenRad,
 
 def binauralDecode(sig, inFs, decodingFilterLeft, decodingFilterRight, decodingFilterFs, compensateDelay=False,
                    signal=None, signalFs=None, horRotAngleRad=None):
+    """dependencies/binauralDecode.m:1-2.  Real or complex (complex-SH) signals and filters; the output is real: the reference
+    forces it and warns with the absolute sum of the discarded imaginary part (:59-64), and so does this function."""
+    import warnings
     if decodingFilterFs != inFs or signal is not None or (horRotAngleRad not in (None, 0)):
         raise NotImplementedError("resampling, rotation and the extra convolution are outside the accelerated path")
-    sig, ps = _f(sig)
-    wL, pwL = _f(decodingFilterLeft)
-    wR, pwR = _f(decodingFilterRight)
-    if np.iscomplexobj(decodingFilterLeft) or np.iscomplexobj(sig):
-        raise NotImplementedError("complex-SH rendering is not implemented yet")
+    in_c = np.iscomplexobj(sig)
+    w_c = np.iscomplexobj(decodingFilterLeft) or np.iscomplexobj(decodingFilterRight)
+
+    def arr(a, cplx):
+        a = np.asfortranarray(np.asarray(a, dtype=np.complex128 if cplx else np.float64))
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    sig, ps = arr(sig, in_c)
+    wL, pwL = arr(decodingFilterLeft, w_c)
+    wR, pwR = arr(decodingFilterRight, w_c)
     n, Cc = sig.shape
     ln = wL.shape[0]
     if wL.shape != wR.shape or wL.shape[1] != Cc:
         raise ValueError("filters must be [len x numChannels] matching the signal's channel count")
     skip = (ln // 2 - 1) if (compensateDelay and ln // 2 > 0) else 0
     out, po = _out(max(n - skip, 0), 2, False)
-    L.check(L.load().emagls_binaural_decode(ps, n, Cc, pwL, pwR, ln, 1 if compensateDelay else 0, po))
+    if not (in_c or w_c):
+        L.check(L.load().emagls_binaural_decode(ps, n, Cc, pwL, pwR, ln, 1 if compensateDelay else 0, po))
+        return out
+    im = (C.c_double * 2)(0.0, 0.0)
+    L.check(L.load().emagls_binaural_decode_complex(ps, 1 if in_c else 0, n, Cc, pwL, pwR, 1 if w_c else 0, ln,
+                                                    1 if compensateDelay else 0, po, im))
+    if im[0] != 0.0 or im[1] != 0.0:
+        warnings.warn("discarding imaginary part with sum of [%.2g, %.2g] in rendering result." % (im[0], im[1]))
     return out

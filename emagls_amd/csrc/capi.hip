@@ -1250,25 +1250,96 @@ template <typename F> int guarded(F&& f) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-shot entry points (what the MEX shim binds: lib/get*Filters.m signatures, host arrays in, filters out).
+// A shape-keyed cache keeps the plans of recent calls alive -- device buffers, captured graphs, the routes a
+// conditioning check may have moved -- so that a repeated design costs the uploads, one replay and the download instead
+// of ~1.5 GB of hipMalloc and an eager first execute.  emagls_cache_clear() (mexAtExit) releases everything.
+// ---------------------------------------------------------------------------------------------
+struct CachedPlan {
+    std::unique_ptr<emagls_plan> plan;
+    emagls_design_desc desc{};
+    int device = 0;
+    bool busy = false;
+    uint64_t last_use = 0;
+};
+std::mutex g_cache_mu;
+std::vector<CachedPlan> g_cache;
+uint64_t g_cache_tick = 0;
+
+size_t plan_cache_capacity() {
+    static const size_t cap = [] { const char* e = getenv("EMAGLS_PLAN_CACHE"); return e ? (size_t)std::max(0, atoi(e)) : (size_t)4; }();
+    return cap;
+}
+bool same_desc(const emagls_design_desc& a, const emagls_design_desc& b) {
+    return a.kind == b.kind && a.basis == b.basis && a.order == b.order && a.fs == b.fs && a.len == b.len && a.nsamp == b.nsamp &&
+           a.ndirs == b.ndirs && a.mic_radius == b.mic_radius && a.nmics == b.nmics && a.f_trans == b.f_trans &&
+           a.atf_taps == b.atf_taps && a.natf == b.natf;
+}
+
 int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR, const double* azi, const double* zen,
              const double* mic_azi, const double* mic_zen, const double* atf, const double* atf_azi, const double* atf_zen,
              void* wL, void* wR, double* mean_dev) {
     return guarded([&] {
-        std::unique_ptr<emagls_plan> p(new emagls_plan);
-        p->d = desc;
-        plan_setup(*p);
-        auto req = [](int rc) { if (rc != EMAGLS_OK) throw Error(rc, g_last_error); };
-        req(emagls_plan_set_hrir_grid(p.get(), azi, zen));
-        req(emagls_plan_set_hrirs(p.get(), hL, hR));
-        if (mic_azi) req(emagls_plan_set_mic_grid(p.get(), mic_azi, mic_zen));
-        if (atf) req(emagls_plan_set_atfs(p.get(), atf, atf_azi, atf_zen));
-        plan_execute(*p);
-        req(emagls_plan_get_filters(p.get(), wL, wR));
-        if (mean_dev) {
-            emagls_plan_info info;
-            req(emagls_plan_get_info(p.get(), &info));
-            *mean_dev = info.mean_grid_dev_deg;
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        emagls_plan* p = nullptr;
+        std::unique_ptr<emagls_plan> fresh;
+        bool cached = false;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (auto& c : g_cache)
+                if (!c.busy && c.device == dev && same_desc(c.desc, desc)) { c.busy = true; p = c.plan.get(); cached = true; break; }
         }
+        if (!p) {
+            fresh.reset(new emagls_plan);
+            fresh->d = desc;
+            plan_setup(*fresh);
+            if (array_kind(desc.kind)) fresh->nstreams = 3;   // one design at a time: independent branches fork onto side streams
+            p = fresh.get();
+        }
+        auto release = [&](bool ok) {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            if (cached) {
+                for (size_t i = 0; i < g_cache.size(); ++i)
+                    if (g_cache[i].plan.get() == p) {
+                        if (ok) { g_cache[i].busy = false; g_cache[i].last_use = ++g_cache_tick; }
+                        else g_cache.erase(g_cache.begin() + i);   // a failed call leaves the plan in an unknown state: drop it
+                        break;
+                    }
+            } else if (ok && plan_cache_capacity() > 0) {
+                if (g_cache.size() >= plan_cache_capacity()) {   // evict the least recently used idle plan
+                    size_t victim = g_cache.size();
+                    for (size_t i = 0; i < g_cache.size(); ++i)
+                        if (!g_cache[i].busy && (victim == g_cache.size() || g_cache[i].last_use < g_cache[victim].last_use)) victim = i;
+                    if (victim < g_cache.size()) g_cache.erase(g_cache.begin() + victim);
+                }
+                if (g_cache.size() < plan_cache_capacity()) {
+                    CachedPlan c;
+                    c.plan = std::move(fresh);
+                    c.desc = desc; c.device = dev; c.busy = false; c.last_use = ++g_cache_tick;
+                    g_cache.push_back(std::move(c));
+                }
+            }
+        };
+        try {
+            auto req = [](int rc) { if (rc != EMAGLS_OK) throw Error(rc, g_last_error); };
+            req(emagls_plan_set_hrir_grid(p, azi, zen));
+            req(emagls_plan_set_hrirs(p, hL, hR));
+            if (mic_azi) req(emagls_plan_set_mic_grid(p, mic_azi, mic_zen));
+            if (atf) req(emagls_plan_set_atfs(p, atf, atf_azi, atf_zen));
+            plan_execute(*p);
+            req(emagls_plan_get_filters(p, wL, wR));
+            if (mean_dev) {
+                emagls_plan_info info;
+                req(emagls_plan_get_info(p, &info));
+                *mean_dev = info.mean_grid_dev_deg;
+            }
+        } catch (...) {
+            release(false);
+            throw;
+        }
+        release(true);
     });
 }
 
@@ -1288,6 +1359,17 @@ int emagls_device_count(int* count) {
 }
 int emagls_set_device(int device) {
     return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
+}
+
+int emagls_cache_clear(void) {
+    return guarded([&] {
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (size_t i = g_cache.size(); i-- > 0;)
+                if (!g_cache[i].busy) g_cache.erase(g_cache.begin() + i);
+        }
+        decode_cache_clear();
+    });
 }
 
 int emagls_fp64_peak_tflops(int which, double* tflops) {
@@ -1688,25 +1770,42 @@ int emagls_get_emagls_filters_from_atf(const double* hL, const double* hR, int64
     return one_shot(d, hL, hR, azi, zen, nullptr, nullptr, atf_irs, atf_azi, atf_zen, wL, wR, mean_dev);
 }
 
-int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const double* wL, const double* wR, int64_t len,
-                           int compensate_delay, double* out) {
+// common body of the two decode entry points
+static int decode_entry(const void* in, bool in_cplx, int64_t nsamp, int64_t nch, const void* wL, const void* wR, bool w_cplx, int64_t len,
+                        int compensate_delay, double* out, double* imag_abs_sum) {
     return guarded([&] {
         if (!in || !wL || !wR || !out) throw Error(EMAGLS_ERR_ARG, "null pointer");
         if (nsamp < 0 || nch < 1 || len < 1) throw Error(EMAGLS_ERR_ARG, "invalid shape");
+        if (imag_abs_sum) imag_abs_sum[0] = imag_abs_sum[1] = 0.0;
         if (nsamp == 0) return;
-        double *d_in = nullptr, *d_wL = nullptr, *d_wR = nullptr, *d_out = nullptr;
+        const bool any_cplx = in_cplx || w_cplx;
+        const size_t es_in = in_cplx ? sizeof(cplx) : sizeof(double), es_w = w_cplx ? sizeof(cplx) : sizeof(double);
+        void *d_in = nullptr, *d_wL = nullptr, *d_wR = nullptr;
+        double *d_out = nullptr, *d_sig2 = nullptr, *d_w2L = nullptr, *d_w2R = nullptr, *d_tmp = nullptr;
         hipStream_t st = nullptr;
-        auto cleanup = [&] { hipFree(d_in); hipFree(d_wL); hipFree(d_wR); hipFree(d_out); if (st) hipStreamDestroy(st); };
+        auto cleanup = [&] {
+            hipFree(d_in); hipFree(d_wL); hipFree(d_wR); hipFree(d_out); hipFree(d_sig2); hipFree(d_w2L); hipFree(d_w2R); hipFree(d_tmp);
+            if (st) hipStreamDestroy(st);
+        };
         try {
             HIP_CHECK(hipStreamCreate(&st));
-            HIP_CHECK(hipMalloc(&d_in, sizeof(double) * nsamp * nch));
-            HIP_CHECK(hipMalloc(&d_wL, sizeof(double) * len * nch));
-            HIP_CHECK(hipMalloc(&d_wR, sizeof(double) * len * nch));
+            HIP_CHECK(hipMalloc(&d_in, es_in * nsamp * nch));
+            HIP_CHECK(hipMalloc(&d_wL, es_w * len * nch));
+            HIP_CHECK(hipMalloc(&d_wR, es_w * len * nch));
             HIP_CHECK(hipMalloc(&d_out, sizeof(double) * nsamp * 2));
-            HIP_CHECK(hipMemcpy(d_in, in, sizeof(double) * nsamp * nch, hipMemcpyDefault));
-            HIP_CHECK(hipMemcpy(d_wL, wL, sizeof(double) * len * nch, hipMemcpyDefault));
-            HIP_CHECK(hipMemcpy(d_wR, wR, sizeof(double) * len * nch, hipMemcpyDefault));
-            binaural_decode_real(d_in, nsamp, (int)nch, d_wL, d_wR, len, d_out, st);
+            HIP_CHECK(hipMemcpy(d_in, in, es_in * nsamp * nch, hipMemcpyDefault));
+            HIP_CHECK(hipMemcpy(d_wL, wL, es_w * len * nch, hipMemcpyDefault));
+            HIP_CHECK(hipMemcpy(d_wR, wR, es_w * len * nch, hipMemcpyDefault));
+            if (!any_cplx) {
+                binaural_decode_real((const double*)d_in, nsamp, (int)nch, (const double*)d_wL, (const double*)d_wR, len, d_out, st);
+            } else {
+                HIP_CHECK(hipMalloc(&d_sig2, sizeof(double) * 2 * nsamp * nch));
+                HIP_CHECK(hipMalloc(&d_w2L, sizeof(double) * 2 * len * nch));
+                HIP_CHECK(hipMalloc(&d_w2R, sizeof(double) * 2 * len * nch));
+                if (imag_abs_sum) HIP_CHECK(hipMalloc(&d_tmp, sizeof(double) * (2 * nsamp + 2)));
+                binaural_decode_complex(d_in, in_cplx, nsamp, (int)nch, d_wL, d_wR, w_cplx, len, d_sig2, d_w2L, d_w2R, d_out,
+                                        imag_abs_sum, d_tmp, st);
+            }
             if (!compensate_delay) {
                 HIP_CHECK(hipMemcpy(out, d_out, sizeof(double) * nsamp * 2, hipMemcpyDefault));
             } else {
@@ -1722,6 +1821,15 @@ int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const d
         } catch (...) { cleanup(); throw; }
         cleanup();
     });
+}
+
+int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const double* wL, const double* wR, int64_t len,
+                           int compensate_delay, double* out) {
+    return decode_entry(in, false, nsamp, nch, wL, wR, false, len, compensate_delay, out, nullptr);
+}
+int emagls_binaural_decode_complex(const void* in, int in_is_complex, int64_t nsamp, int64_t nch, const void* wL, const void* wR,
+                                   int filters_are_complex, int64_t len, int compensate_delay, double* out, double* imag_abs_sum) {
+    return decode_entry(in, in_is_complex != 0, nsamp, nch, wL, wR, filters_are_complex != 0, len, compensate_delay, out, imag_abs_sum);
 }
 
 }  // extern "C"

@@ -3,6 +3,8 @@
 // accumulated in the frequency domain, so each ear needs ONE inverse transform per block instead of C.
 #include <hipfft/hipfft.h>
 
+#include <mutex>
+
 #include "kernels.hpp"
 
 namespace emagls {
@@ -58,6 +60,85 @@ __global__ void ols_unpack_kernel(const double* __restrict__ y, int64_t n, int64
     }
 }
 
+// [re(x_0..x_C-1), im(x_0..x_C-1)] planes (2C real channels of n samples) from interleaved complex columns; `swap` exchanges
+// the two halves and `neg_im` negates the imaginary planes
+__global__ void split_complex_kernel(const cplx* __restrict__ x, int64_t n, int C, int swap, int neg_im, double* __restrict__ out) {
+    const int64_t total = (int64_t)C * n;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const cplx v = x[idx];
+        const double im = neg_im ? -v.y : v.y;
+        out[(swap ? total : 0) + idx] = v.x;
+        out[(swap ? 0 : total) + idx] = im;
+    }
+}
+__global__ void widen_real_kernel(const double* __restrict__ x, int64_t total, int second_half, double* __restrict__ out) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        out[(second_half ? total : 0) + idx] = x[idx];
+        out[(second_half ? 0 : total) + idx] = 0.0;
+    }
+}
+__global__ void __launch_bounds__(1024) abs_sum_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+    __shared__ double sh[1024];
+    const double* col = x + (int64_t)blockIdx.x * n;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += fabs(col[i]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 512; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) sh[threadIdx.x] += sh[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+// hipFFT plans and work buffers of the last decode shape, kept across calls (creating three plans and six buffers costs
+// more than rendering a short signal); released by emagls_cache_clear().  One render at a time per process.
+namespace {
+struct DecodeWork {
+    int C = 0, Nf = 0, device = -1;
+    int64_t nblocks = 0;
+    double *seg = nullptr, *wpad = nullptr, *y = nullptr;
+    cplx *Xf = nullptr, *Wf = nullptr, *Yf = nullptr;
+    hipfftHandle pf = 0, pw = 0, pi = 0;
+    void release() {
+        if (pf) hipfftDestroy(pf);
+        if (pw) hipfftDestroy(pw);
+        if (pi) hipfftDestroy(pi);
+        pf = pw = pi = 0;
+        hipFree(seg); hipFree(wpad); hipFree(y); hipFree(Xf); hipFree(Wf); hipFree(Yf);
+        seg = wpad = y = nullptr; Xf = Wf = Yf = nullptr;
+        C = Nf = 0; nblocks = 0; device = -1;
+    }
+    void ensure(int C_, int64_t nblocks_, int Nf_) {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        if (C_ == C && nblocks_ == nblocks && Nf_ == Nf && dev == device) return;
+        release();
+        const int Pf = Nf_ / 2 + 1;
+        try {
+            HIP_CHECK(hipMalloc(&seg, sizeof(double) * C_ * nblocks_ * Nf_));
+            HIP_CHECK(hipMalloc(&wpad, sizeof(double) * 2 * C_ * Nf_));
+            HIP_CHECK(hipMalloc(&y, sizeof(double) * 2 * nblocks_ * Nf_));
+            HIP_CHECK(hipMalloc(&Xf, sizeof(cplx) * C_ * nblocks_ * Pf));
+            HIP_CHECK(hipMalloc(&Wf, sizeof(cplx) * 2 * C_ * Pf));
+            HIP_CHECK(hipMalloc(&Yf, sizeof(cplx) * 2 * nblocks_ * Pf));
+            int nn[1] = {Nf_};
+            fft_check(hipfftPlanMany(&pf, 1, nn, nullptr, 1, Nf_, nullptr, 1, Pf, HIPFFT_D2Z, (int)(C_ * nblocks_)), "plan D2Z signal");
+            fft_check(hipfftPlanMany(&pw, 1, nn, nullptr, 1, Nf_, nullptr, 1, Pf, HIPFFT_D2Z, 2 * C_), "plan D2Z filters");
+            fft_check(hipfftPlanMany(&pi, 1, nn, nullptr, 1, Pf, nullptr, 1, Nf_, HIPFFT_Z2D, (int)(2 * nblocks_)), "plan Z2D");
+        } catch (...) { release(); throw; }
+        C = C_; nblocks = nblocks_; Nf = Nf_; device = dev;
+    }
+};
+std::mutex g_decode_mu;
+DecodeWork g_decode;
+}  // namespace
+
+void decode_cache_clear() {
+    std::lock_guard<std::mutex> lk(g_decode_mu);
+    g_decode.release();
+}
+
 void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL, const double* wR, int64_t len,
                           double* out, hipStream_t st) {
     if (n <= 0) return;
@@ -66,46 +147,55 @@ void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL,
     const int64_t B = Nf - (len - 1);
     const int64_t nblocks = ceil_div(n, B);
     const int Pf = Nf / 2 + 1;
-    double *seg = nullptr, *wpad = nullptr, *y = nullptr;
-    cplx *Xf = nullptr, *Wf = nullptr, *Yf = nullptr;
-    hipfftHandle pf = 0, pw = 0, pi = 0;
-    auto cleanup = [&]() {
-        if (pf) hipfftDestroy(pf);
-        if (pw) hipfftDestroy(pw);
-        if (pi) hipfftDestroy(pi);
-        hipFree(seg); hipFree(wpad); hipFree(y); hipFree(Xf); hipFree(Wf); hipFree(Yf);
+    std::lock_guard<std::mutex> lk(g_decode_mu);
+    DecodeWork& w = g_decode;
+    w.ensure(C, nblocks, Nf);
+    fft_check(hipfftSetStream(w.pf, st), "set stream");
+    fft_check(hipfftSetStream(w.pw, st), "set stream");
+    fft_check(hipfftSetStream(w.pi, st), "set stream");
+    ols_pack_kernel<<<2048, 256, 0, st>>>(sig, n, C, nblocks, Nf, B, len, w.seg);
+    KERNEL_CHECK();
+    ols_padfilt_kernel<<<256, 256, 0, st>>>(wL, wR, C, len, Nf, w.wpad);
+    KERNEL_CHECK();
+    fft_check(hipfftExecD2Z(w.pf, w.seg, (hipfftDoubleComplex*)w.Xf), "exec D2Z signal");
+    fft_check(hipfftExecD2Z(w.pw, w.wpad, (hipfftDoubleComplex*)w.Wf), "exec D2Z filters");
+    ols_mac_kernel<<<2048, 256, 0, st>>>(w.Xf, w.Wf, C, nblocks, Pf, w.Yf);
+    KERNEL_CHECK();
+    fft_check(hipfftExecZ2D(w.pi, (hipfftDoubleComplex*)w.Yf, w.y), "exec Z2D");
+    ols_unpack_kernel<<<2048, 256, 0, st>>>(w.y, n, nblocks, Nf, B, len, out);
+    KERNEL_CHECK();
+    HIP_CHECK(hipStreamSynchronize(st));
+}
+
+// Complex-SH rendering (dependencies/binauralDecode.m:39-42,59-64): the reference accumulates complex fftfilt products and
+// keeps real(.) of the sum.  real(w * x) = re(w) * re(x) - im(w) * im(x): the same overlap-save path on 2C real channels
+// [re x; im x] with the filters [re w; -im w].  The discarded imaginary part, whose absolute sum the reference prints in a
+// warning, is re(w) * im(x) + im(w) * re(x): a second pass on [im x; re x] with [re w; im w], only when asked for.
+// sig2 / w2L / w2R: work buffers of 2 C n and 2 C len doubles; sig, wL, wR device pointers (interleaved complex when flagged)
+void binaural_decode_complex(const void* sig, bool sig_cplx, int64_t n, int C, const void* wL, const void* wR, bool w_cplx, int64_t len,
+                             double* sig2, double* w2L, double* w2R, double* out, double* imag_abs, double* d_tmp, hipStream_t st) {
+    if (n <= 0) return;
+    auto planes = [&](const void* x, bool is_cplx, int64_t rows, int swap, int neg_im, double* dst) {
+        const int64_t total = (int64_t)C * rows;
+        const unsigned grid = (unsigned)std::min<int64_t>(2048, ceil_div(total, 256));
+        if (is_cplx) split_complex_kernel<<<grid, 256, 0, st>>>((const cplx*)x, rows, C, swap, neg_im, dst);
+        else widen_real_kernel<<<grid, 256, 0, st>>>((const double*)x, total, swap, dst);
+        KERNEL_CHECK();
     };
-    try {
-        HIP_CHECK(hipMalloc(&seg, sizeof(double) * C * nblocks * Nf));
-        HIP_CHECK(hipMalloc(&wpad, sizeof(double) * 2 * C * Nf));
-        HIP_CHECK(hipMalloc(&y, sizeof(double) * 2 * nblocks * Nf));
-        HIP_CHECK(hipMalloc(&Xf, sizeof(cplx) * C * nblocks * Pf));
-        HIP_CHECK(hipMalloc(&Wf, sizeof(cplx) * 2 * C * Pf));
-        HIP_CHECK(hipMalloc(&Yf, sizeof(cplx) * 2 * nblocks * Pf));
-        int nn[1] = {Nf};
-        fft_check(hipfftPlanMany(&pf, 1, nn, nullptr, 1, Nf, nullptr, 1, Pf, HIPFFT_D2Z, (int)(C * nblocks)), "plan D2Z signal");
-        fft_check(hipfftPlanMany(&pw, 1, nn, nullptr, 1, Nf, nullptr, 1, Pf, HIPFFT_D2Z, 2 * C), "plan D2Z filters");
-        fft_check(hipfftPlanMany(&pi, 1, nn, nullptr, 1, Pf, nullptr, 1, Nf, HIPFFT_Z2D, (int)(2 * nblocks)), "plan Z2D");
-        fft_check(hipfftSetStream(pf, st), "set stream");
-        fft_check(hipfftSetStream(pw, st), "set stream");
-        fft_check(hipfftSetStream(pi, st), "set stream");
-        ols_pack_kernel<<<2048, 256, 0, st>>>(sig, n, C, nblocks, Nf, B, len, seg);
+    planes(sig, sig_cplx, n, 0, 0, sig2);
+    planes(wL, w_cplx, len, 0, 1, w2L);
+    planes(wR, w_cplx, len, 0, 1, w2R);
+    binaural_decode_real(sig2, n, 2 * C, w2L, w2R, len, out, st);
+    if (imag_abs) {
+        planes(sig, sig_cplx, n, 1, 0, sig2);      // [im x; re x]
+        planes(wL, w_cplx, len, 0, 0, w2L);        // [re w; im w]
+        planes(wR, w_cplx, len, 0, 0, w2R);
+        binaural_decode_real(sig2, n, 2 * C, w2L, w2R, len, d_tmp, st);
+        abs_sum_kernel<<<2, 1024, 0, st>>>(d_tmp, n, d_tmp + 2 * n);
         KERNEL_CHECK();
-        ols_padfilt_kernel<<<256, 256, 0, st>>>(wL, wR, C, len, Nf, wpad);
-        KERNEL_CHECK();
-        fft_check(hipfftExecD2Z(pf, seg, (hipfftDoubleComplex*)Xf), "exec D2Z signal");
-        fft_check(hipfftExecD2Z(pw, wpad, (hipfftDoubleComplex*)Wf), "exec D2Z filters");
-        ols_mac_kernel<<<2048, 256, 0, st>>>(Xf, Wf, C, nblocks, Pf, Yf);
-        KERNEL_CHECK();
-        fft_check(hipfftExecZ2D(pi, (hipfftDoubleComplex*)Yf, y), "exec Z2D");
-        ols_unpack_kernel<<<2048, 256, 0, st>>>(y, n, nblocks, Nf, B, len, out);
-        KERNEL_CHECK();
+        HIP_CHECK(hipMemcpyAsync(imag_abs, d_tmp + 2 * n, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-    } catch (...) {
-        cleanup();
-        throw;
     }
-    cleanup();
 }
 
 }  // namespace emagls

@@ -114,6 +114,9 @@ double measure_fp64_peak(int which, int reps);
 // ---- decode.hip
 void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL, const double* wR, int64_t len,
                           double* out /* [n x 2] column-major */, hipStream_t st);
+void binaural_decode_complex(const void* sig, bool sig_cplx, int64_t n, int C, const void* wL, const void* wR, bool w_cplx, int64_t len,
+                             double* sig2, double* w2L, double* w2R, double* out, double* imag_abs, double* d_tmp, hipStream_t st);
+void decode_cache_clear();
 
 }  // namespace emagls
 

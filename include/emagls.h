@@ -8,7 +8,7 @@
  *   emagls_get_emagls2_filters         <-  lib/getEMagLs2Filters.m:1-2
  *   emagls_get_emagls_filters_from_atf <-  lib/getEMagLsFiltersFromAtf.m:1
  *   emagls_get_emagls_filters_ema_in_ch <- lib/getEMagLsFiltersEMAinCH.m:1-2  (default chFunction @getCH, dependencies/getCH.m)
- *   emagls_binaural_decode             <-  dependencies/binauralDecode.m:1-2 (core loop :33-42,53-64)
+ *   emagls_binaural_decode[_complex]   <-  dependencies/binauralDecode.m:1-2 (core loop :33-42,53-64)
  *   emagls_sh_basis                    <-  getSH (polarch/Spherical-Harmonic-Transform, call site lib/getLsFilters.m:30)
  *   emagls_modal_bn                    <-  sphModalCoeffs (polarch/Array-Response-Simulator, call site dependencies/getSMAIRMatrix.m:107)
  *
@@ -55,6 +55,11 @@ const char* emagls_last_error(void);
 int emagls_version(void);
 int emagls_device_count(int* count);
 int emagls_set_device(int device);
+
+/* The one-shot entry points below keep the plans of their most recent shapes alive (device buffers, captured hipGraphs; at most
+ * EMAGLS_PLAN_CACHE plans, default 4, 0 disables), and emagls_binaural_decode its hipFFT plans and work buffers.  This call
+ * releases all of it (a MEX gateway registers it with mexAtExit). */
+int emagls_cache_clear(void);
 
 /* Measured FP64 peak of the current device in TFLOP/s (best of a few launches that keep every CU busy): which = 0 the matrix
  * pipe (v_mfma_f64_16x16x4_f64), which = 1 the vector pipe (v_fma_f64).  bench.py prices its executed flops against it. */
@@ -113,6 +118,13 @@ int emagls_get_emagls_filters_from_atf(const double* hL, const double* hR, int64
  * in [nsamp x nch], wL/wR [len x nch], all real. */
 int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const double* wL, const double* wR,
                            int64_t len, int compensate_delay, double* out);
+
+/* Complex-SH rendering (dependencies/binauralDecode.m:39-42,59-64: complex products accumulated, real part kept).
+ * in [nsamp x nch] and wL / wR [len x nch] are interleaved complex where the flag says so, real otherwise; out as above, real.
+ * imag_abs_sum (optional, [2]) receives sum(abs(imag(.))) of the discarded imaginary part per ear, the two numbers the
+ * reference prints in its warning (:61-62). */
+int emagls_binaural_decode_complex(const void* in, int in_is_complex, int64_t nsamp, int64_t nch, const void* wL, const void* wR,
+                                   int filters_are_complex, int64_t len, int compensate_delay, double* out, double* imag_abs_sum);
 
 /* ---- plan API: inputs resident in HBM, repeated execution (benchmarks, batches) ------------- */
 
