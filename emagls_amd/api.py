@@ -11,8 +11,9 @@ hL/hR are [numSamples x numDirections]; filters come back [len x numChannels].
     binauralDecode          dependencies/binauralDecode.m:1-2
     getSH / sphModalCoeffs  the un-vendored third-party functions the above call
 
-`shFunction` handles other than the built-in getSH cannot cross the C ABI and raise
-NotImplementedError, as INTEGRATION.md explains.
+A custom `shFunction` (a callable with getSH's signature: shFunction(N, [azi zen], shDefinition) -> [dirs x (N+1)^2]) cannot
+cross the C ABI as a handle: it is evaluated here, at the simulation order the library reports, and its matrices go through the
+emagls_*_with_basis entry points -- exactly what the MEX wrappers do with a MATLAB function handle.
 """
 from __future__ import annotations
 
@@ -41,9 +42,7 @@ def _out(rows, cols, cplx):
     return w, w.ctypes.data_as(C.c_void_p)
 
 
-def _basis(shDefinition, shFunction):
-    if shFunction is not None:
-        raise NotImplementedError("custom shFunction handles cannot cross the C ABI; the built-in getSH is used")
+def _basis(shDefinition, shFunction=None):
     if shDefinition is None or shDefinition == "":
         shDefinition = "real"
     if shDefinition not in L.BASIS:
@@ -79,6 +78,17 @@ def sphModalCoeffs(N, kr, arrayType="rigid", dirCoeff=0.0):
     return b
 
 
+def _sh_matrix(shFunction, n, azi, zen, shDefinition, cplx, rows):
+    """Evaluate a custom shFunction and check its result: [rows x (n+1)^2], real or complex like the basis."""
+    Y = np.asarray(shFunction(int(n), np.column_stack([azi, zen]), shDefinition if shDefinition else "real"))
+    if Y.shape != (rows, (n + 1) ** 2):
+        raise ValueError("shFunction returned %s, expected (%d, %d)" % (Y.shape, rows, (n + 1) ** 2))
+    if np.iscomplexobj(Y) != cplx:
+        raise ValueError("shFunction returned a %s matrix for shDefinition=%r" % ("complex" if np.iscomplexobj(Y) else "real", shDefinition))
+    Y = np.asfortranarray(Y, dtype=np.complex128 if cplx else np.float64)
+    return Y, Y.ctypes.data_as(C.c_void_p)
+
+
 def getLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, shDefinition="real", shFunction=None):
     b, cplx = _basis(shDefinition, shFunction)
     hL, hR, pL, pR = _hrirs(hL, hR)
@@ -87,6 +97,10 @@ def getLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, shDefinition="re
     zen, pz = _vec(hrirGridZenRad, D, "hrirGridZenRad")
     wL, pwL = _out(n, (order + 1) ** 2, cplx)
     wR, pwR = _out(n, (order + 1) ** 2, cplx)
+    if shFunction is not None:
+        Y, pY = _sh_matrix(shFunction, order, azi, zen, shDefinition, cplx, D)
+        L.check(L.load().emagls_get_ls_filters_with_basis(pL, pR, n, D, pY, int(order), b, pwL, pwR))
+        return wL, wR
     L.check(L.load().emagls_get_ls_filters(pL, pR, n, D, pa, pz, int(order), b, pwL, pwR))
     return wL, wR
 
@@ -99,6 +113,10 @@ def getMagLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, fs, len, shDe
     zen, pz = _vec(hrirGridZenRad, D, "hrirGridZenRad")
     wL, pwL = _out(int(len), (order + 1) ** 2, cplx)
     wR, pwR = _out(int(len), (order + 1) ** 2, cplx)
+    if shFunction is not None:
+        Y, pY = _sh_matrix(shFunction, order, azi, zen, shDefinition, cplx, D)
+        L.check(L.load().emagls_get_magls_filters_with_basis(pL, pR, n, D, pY, int(order), float(fs), int(len), b, pwL, pwR))
+        return wL, wR
     L.check(L.load().emagls_get_magls_filters(pL, pR, n, D, pa, pz, int(order), float(fs), int(len), b, pwL, pwR))
     return wL, wR
 
@@ -115,6 +133,14 @@ def _sma(fn_name, raw, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, l
     C_ = M if raw else (order + 1) ** 2
     wL, pwL = _out(int(len), C_, cplx)
     wR, pwR = _out(int(len), C_, cplx)
+    if shFunction is not None:
+        # lib/getEMagLsFilters.m:68 and dependencies/getSMAIRMatrix.m:101 call the handle at the simulation order
+        so = L.load().emagls_simulation_order(L.KIND_EMAGLS2 if raw else L.KIND_EMAGLS, int(order), float(fs), float(micRadius))
+        Yh, pYh = _sh_matrix(shFunction, so, azi, zen, shDefinition, cplx, D)
+        Ym, pYm = _sh_matrix(shFunction, so, micAzi, micZen, shDefinition, cplx, M)
+        fn = getattr(L.load(), fn_name + "_with_basis")
+        L.check(fn(pL, pR, n, D, pYh, float(micRadius), pYm, M, int(order), float(fs), int(len), b, pwL, pwR))
+        return wL, wR
     fn = getattr(L.load(), fn_name)
     L.check(fn(pL, pR, n, D, pa, pz, float(micRadius), pma, pmz, M, int(order), float(fs), int(len), b, pwL, pwR))
     return wL, wR
@@ -136,9 +162,10 @@ def getEMagLsFiltersEMAinCH(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, m
                             shDefinition="real", shFunction=None, chFunction=None):
     """lib/getEMagLsFiltersEMAinCH.m:1-2: eMagLS filters in circular harmonics for an equatorial microphone array;
     returns [len x (2*order+1)] per ear, channels ordered [C_0, C_-1, C_1, ..., C_-N, C_N] (dependencies/getCH.m)."""
-    if chFunction is not None:
-        raise NotImplementedError("a custom chFunction handle cannot cross the C ABI; the default @getCH is built in")
-    b, cplx = _basis(shDefinition, shFunction)
+    if chFunction is not None or shFunction is not None:
+        raise NotImplementedError("custom chFunction / shFunction handles are not supported for the EMA variant; the defaults "
+                                  "@getCH / @getSH are built in")
+    b, cplx = _basis(shDefinition)
     hL, hR, pL, pR = _hrirs(hL, hR)
     n, D = hL.shape
     azi, pa = _vec(hrirGridAziRad, D, "hrirGridAziRad")

@@ -70,7 +70,8 @@ struct emagls_plan {
     int gram_from = 0, gram_floor = 0, hh_end = 0, n_h = 0, S_h = 0, ldS_h = 0, g0 = 0, nb_gram = 0;
     bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip)
     emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
-    bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false;
+    bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false, have_basis = false;
+    bool custom_basis = false;    // the SH matrices come from the caller (a custom shFunction evaluated on the MATLAB side)
     // profiling
     int prof_level = 0;
     std::vector<std::string> stage_names;
@@ -315,7 +316,11 @@ void plan_setup(emagls_plan& p) {
     // W(k-1,:) pwGrid are the same and W_c(k,:) = W_r(k,:) T_N for every solved bin (lib/getEMagLsFilters.m:87-103); the DC
     // rule and the SH conjugate rule (:109-118) act on W_c and stay in the epilogue.  eMagLS2 is basis free (T cancels).
     // The real pipeline has a 3x cheaper Gram and half the bytes in T_n and QT: 1460 vs 1295 sets/s at config 3.
-    p.real_internal = p.req_cplx && (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2);
+    p.custom_basis = d.custom_basis != 0;
+    if (p.custom_basis && (d.kind == EMAGLS_KIND_FROM_ATF || d.kind == EMAGLS_KIND_EMA_CH))
+        throw Error(EMAGLS_ERR_UNSUPPORTED, "caller-supplied SH matrices are available for LS, MagLS, eMagLS and eMagLS2 designs");
+    // (a caller-supplied complex basis need not be ours rotated by T: it takes the complex-arithmetic pipeline)
+    p.real_internal = p.req_cplx && !p.custom_basis && (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2);
     if (const char* e = getenv("EMAGLS_REAL_INTERNAL")) if (e[0] == '0') p.real_internal = false;
     p.cplx_basis = p.req_cplx && !p.real_internal;
     p.D = d.ndirs;
@@ -494,9 +499,11 @@ void plan_setup(emagls_plan& p) {
 void stage_hrir_basis(emagls_plan& p) {
     hipStream_t st = p.stream;
     const bool cb = p.cplx_basis;
-    launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), st);
-    launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), cb,
-                    p.get("Ycm"), p.ldD, st);
+    if (!p.custom_basis) {
+        launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), st);
+        launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), cb,
+                        p.get("Ycm"), p.ldD, st);
+    }
     launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, cb, true, st);
     p.mark("sh_basis");
     launch_gram(p.get("Yc"), p.D, p.S, p.ldS, cb, p.get("Gp"), nullptr, p.get("R"), p.S, st);
@@ -632,8 +639,9 @@ void emagls_pre_sweep(emagls_plan& p) {
     p.depend(s2, s0);
 
     // s1: array model  E = Y_mic (raw) or pinv(Y_mic(:,1:nOut)) Y_mic   (getSMAIRMatrix.m:101-102,119-121), b_n(kr)
-    launch_sh_basis(p.simOrder, M, p.get<double>("mic_azi"), p.get<double>("mic_zen"), p.get<double>("sh_tab"), cb,
-                    p.get("Ymic_cm"), M, s1);
+    if (!p.custom_basis)
+        launch_sh_basis(p.simOrder, M, p.get<double>("mic_azi"), p.get<double>("mic_zen"), p.get<double>("sh_tab"), cb,
+                        p.get("Ymic_cm"), M, s1);
     launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("Ymic_rm"), M, p.ldS, cb, false, s1);
     if (raw) {
         launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("E"), M, p.ldS, cb, false, s1);  // E = Y_mic
@@ -666,8 +674,9 @@ void emagls_pre_sweep(emagls_plan& p) {
     }
 
     // s0: SH matrix of the HRIR grid, its Gram matrix Gy, Cholesky factor R of the leading block (Householder-route orders)
-    launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), cb,
-                    p.get("Ycm"), p.ldD, s0);
+    if (!p.custom_basis)
+        launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), cb,
+                        p.get("Ycm"), p.ldD, s0);
     launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, cb, true, s0);
     p.mark("sh_basis");
     hipEvent_t e_Yc = p.next_sync_event();
@@ -685,7 +694,7 @@ void emagls_pre_sweep(emagls_plan& p) {
     // (complex-arithmetic pipeline: G_k is still evaluated on the real order terms; circular-harmonic
     // channels would need their own channel transform and take the complex kernel)
     launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, p.g0, p.get("G"), s1,
-                    (cb && d.kind != EMAGLS_KIND_EMA_CH) ? 1 : 0, raw ? -1 : (int)d.order);
+                    (cb && d.kind != EMAGLS_KIND_EMA_CH && !p.custom_basis) ? 1 : 0, raw ? -1 : (int)d.order);
     // s2 (after the prologue): the least-squares right-hand sides H conj(Q) of the Householder-route bins.  Q itself is never
     // formed: H conj(Q) is conj( conj(H conj(Yc)) R^-1 ), one D-long product and a row solve for the least-squares rows.
     if (s2 != s0) HIP_CHECK(hipStreamWaitEvent(s2, e_R, 0));
@@ -737,7 +746,7 @@ void emagls_pre_sweep(emagls_plan& p) {
     }
     // cond_ok[kb]: the cheap direction-space identity is accurate for this bin.  Only the other swept bins (and the
     // least-squares bins) need Z_k, i.e. the back-transform
-    launch_cond_flags(p.get<double>("sv"), p.C, p.P, p.get<double>("cond_ok"), s0);
+    launch_cond_flags(p.get<double>("sv"), p.C, p.P, hh_end, p.get<double>("cond_ok"), s0);
     fa.cond_ok = p.get<double>("cond_ok");
     p.mark("factor_qr_jacobi");
     // join s2 (Hq, spectra, group delays): back-transform + least-squares bins of the Householder route
@@ -942,9 +951,13 @@ template <typename F> void capture_into(hipStream_t st, hipGraph_t* g, hipGraphE
 
 void plan_execute(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
-    if (!p.have_hrir_grid || !p.have_hrirs) throw Error(EMAGLS_ERR_ARG, "HRIRs and their grid must be set before execute");
-    if (array_kind(d.kind) && !p.have_mic_grid)
-        throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
+    if (p.custom_basis) {
+        if (!p.have_basis || !p.have_hrirs) throw Error(EMAGLS_ERR_ARG, "HRIRs and the SH matrices must be set before execute");
+    } else {
+        if (!p.have_hrir_grid || !p.have_hrirs) throw Error(EMAGLS_ERR_ARG, "HRIRs and their grid must be set before execute");
+        if (array_kind(d.kind) && !p.have_mic_grid)
+            throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
+    }
     if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
     const bool persist = array_kind(d.kind) && p.sweep_persist;
     if (p.prof_level == 0 && p.use_graph && persist) {
@@ -1054,7 +1067,8 @@ void batch_execute(emagls_batch& b) {
     for (auto* p : b.plans)
         if (!p) throw Error(EMAGLS_ERR_ARG, "a plan of this batch has been destroyed");
     for (auto* p : b.plans)
-        if (!p->have_hrir_grid || !p->have_hrirs || !p->have_mic_grid) throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grids and HRIRs");
+        if (!p->have_hrirs || (p->custom_basis ? !p->have_basis : (!p->have_hrir_grid || !p->have_mic_grid)))
+            throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grids (or SH matrices) and HRIRs");
     if (b.lanes) {
         batch_execute_lanes(b);
         return;
@@ -1274,12 +1288,12 @@ size_t plan_cache_capacity() {
 bool same_desc(const emagls_design_desc& a, const emagls_design_desc& b) {
     return a.kind == b.kind && a.basis == b.basis && a.order == b.order && a.fs == b.fs && a.len == b.len && a.nsamp == b.nsamp &&
            a.ndirs == b.ndirs && a.mic_radius == b.mic_radius && a.nmics == b.nmics && a.f_trans == b.f_trans &&
-           a.atf_taps == b.atf_taps && a.natf == b.natf;
+           a.atf_taps == b.atf_taps && a.natf == b.natf && a.custom_basis == b.custom_basis;
 }
 
 int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR, const double* azi, const double* zen,
              const double* mic_azi, const double* mic_zen, const double* atf, const double* atf_azi, const double* atf_zen,
-             void* wL, void* wR, double* mean_dev) {
+             void* wL, void* wR, double* mean_dev, const void* Y_hrir = nullptr, const void* Y_mic = nullptr) {
     return guarded([&] {
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
@@ -1324,9 +1338,13 @@ int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR,
         };
         try {
             auto req = [](int rc) { if (rc != EMAGLS_OK) throw Error(rc, g_last_error); };
-            req(emagls_plan_set_hrir_grid(p, azi, zen));
+            if (desc.custom_basis) {
+                req(emagls_plan_set_basis(p, Y_hrir, Y_mic));
+            } else {
+                req(emagls_plan_set_hrir_grid(p, azi, zen));
+                if (mic_azi) req(emagls_plan_set_mic_grid(p, mic_azi, mic_zen));
+            }
             req(emagls_plan_set_hrirs(p, hL, hR));
-            if (mic_azi) req(emagls_plan_set_mic_grid(p, mic_azi, mic_zen));
             if (atf) req(emagls_plan_set_atfs(p, atf, atf_azi, atf_zen));
             plan_execute(*p);
             req(emagls_plan_get_filters(p, wL, wR));
@@ -1483,6 +1501,25 @@ int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* ze
         p->upload("kr", kr.data(), sizeof(double) * p->P);
         HIP_CHECK(hipStreamSynchronize(p->stream));
         p->have_mic_grid = true;
+    });
+}
+int emagls_plan_set_basis(emagls_plan* p, const void* Y_hrir, const void* Y_mic) {
+    return guarded([&] {
+        if (!p || !Y_hrir) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (!p->custom_basis) throw Error(EMAGLS_ERR_ARG, "the plan was not created with custom_basis = 1");
+        const size_t es = esz(p->cplx_basis);
+        // MATLAB layout [ndirs x S] column-major -> Ycm [S][ldD]
+        HIP_CHECK(hipMemcpy2DAsync(p->get("Ycm"), (size_t)p->ldD * es, Y_hrir, (size_t)p->D * es, (size_t)p->D * es, (size_t)p->S, hipMemcpyDefault,
+                                   p->stream));
+        if (array_kind(p->d.kind)) {
+            if (!Y_mic) throw Error(EMAGLS_ERR_ARG, "the array designs need the SH matrix of the microphone grid too");
+            p->upload("Ymic_cm", Y_mic, es * (size_t)p->S * p->d.nmics);   // [nmics x S] column-major == [S][M]
+            std::vector<double> kr(p->P);
+            for (int k = 0; k < p->P; ++k) kr[k] = 2.0 * kPi * ((double)k * (p->d.fs / 2.0) / (double)(p->P - 1)) / C_SOUND * p->d.mic_radius;
+            p->upload("kr", kr.data(), sizeof(double) * p->P);
+        }
+        HIP_CHECK(hipStreamSynchronize(p->stream));
+        p->have_basis = true;
     });
 }
 int emagls_plan_set_hrirs(emagls_plan* p, const double* hL, const double* hR) {
@@ -1821,6 +1858,46 @@ static int decode_entry(const void* in, bool in_cplx, int64_t nsamp, int64_t nch
         } catch (...) { cleanup(); throw; }
         cleanup();
     });
+}
+
+int emagls_simulation_order(int kind, int order, double fs, double mic_radius) {
+    switch (kind) {
+        case EMAGLS_KIND_EMAGLS: case EMAGLS_KIND_EMA_CH:
+            return std::max(order, (int)std::ceil(fs * kPi * mic_radius / C_SOUND));                   // getSMAIRMatrix.m:95
+        case EMAGLS_KIND_EMAGLS2:
+            return std::max(SMAIR_DEFAULT_ORDER, (int)std::ceil(fs * kPi * mic_radius / C_SOUND));     // params.order unset -> 4
+        default: return order;
+    }
+}
+int emagls_get_ls_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir, int order,
+                                     int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_LS; d.basis = basis; d.order = order; d.nsamp = nsamp; d.ndirs = ndirs; d.custom_basis = 1;
+    return one_shot(d, hL, hR, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, wL, wR, nullptr, Y_hrir, nullptr);
+}
+int emagls_get_magls_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir, int order,
+                                        double fs, int64_t len, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_MAGLS; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs; d.custom_basis = 1;
+    return one_shot(d, hL, hR, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, wL, wR, nullptr, Y_hrir, nullptr);
+}
+int emagls_get_emagls_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir,
+                                         double mic_radius, const void* Y_mic, int64_t nmics, int order, double fs, int64_t len, int basis,
+                                         void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_EMAGLS; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    d.mic_radius = mic_radius; d.nmics = nmics; d.custom_basis = 1;
+    if (!Y_mic) { g_last_error = "null microphone SH matrix"; return EMAGLS_ERR_ARG; }
+    return one_shot(d, hL, hR, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, wL, wR, nullptr, Y_hrir, Y_mic);
+}
+int emagls_get_emagls2_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir,
+                                          double mic_radius, const void* Y_mic, int64_t nmics, int order, double fs, int64_t len, int basis,
+                                          void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_EMAGLS2; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    d.mic_radius = mic_radius; d.nmics = nmics; d.custom_basis = 1;
+    if (!Y_mic) { g_last_error = "null microphone SH matrix"; return EMAGLS_ERR_ARG; }
+    return one_shot(d, hL, hR, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, wL, wR, nullptr, Y_hrir, Y_mic);
 }
 
 int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const double* wL, const double* wR, int64_t len,

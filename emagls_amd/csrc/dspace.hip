@@ -211,14 +211,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     }
 }
 
-// cond_ok[kb] = 1 when smax <= COND_LIMIT * smin for bin kb (the cheap identity is accurate), else 0
-__global__ void cond_flag_kernel(const double* __restrict__ sv, int C, int P, double* __restrict__ cond_ok, size_t bstride) {
+// cond_ok[kb] = 1 when smax <= COND_LIMIT * smin for bin kb (the cheap identity is accurate), else 0.  Only bins of the
+// orthonormal route (kb < hh_end) can be cleared: they alone have the accurate S-space inverse Z_k to fall back on.  A
+// Gram-route bin keeps 1 whatever its singular values say (the conditioning check of that route raises its own flag and the
+// host moves the route's start; the operands of the fallback do not exist for it).
+__global__ void cond_flag_kernel(const double* __restrict__ sv, int C, int P, int hh_end, double* __restrict__ cond_ok, size_t bstride) {
     sv = boff(sv, bstride); cond_ok = boff(cond_ok, bstride);
     const int kb = blockIdx.x * blockDim.x + threadIdx.x;
     if (kb >= P) return;
     double smax = 0.0, smin = INFINITY;
     for (int i = 0; i < C; ++i) { const double s = sv[(int64_t)kb * C + i]; smax = fmax(smax, s); smin = fmin(smin, s); }
-    cond_ok[kb] = (smax <= COND_LIMIT * smin) ? 1.0 : 0.0;
+    cond_ok[kb] = (kb >= hh_end || smax <= COND_LIMIT * smin) ? 1.0 : 0.0;
 }
 
 // ill-conditioned swept bins: Yri[c][d] = sum_s conj(Q[d][s]) Z_k[c][s]  (orthonormal S-space factor)
@@ -311,8 +314,8 @@ void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, 
     if (is_cplx) dspace_g_impl<cplx>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
     else dspace_g_impl<double>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
 }
-void launch_cond_flags(const double* sv, int C, int P, double* cond_ok, hipStream_t st) {
-    cond_flag_kernel<<<bgrid((P + 255) / 256), 256, 0, st>>>(sv, C, P, cond_ok, batch_ctx().stride);
+void launch_cond_flags(const double* sv, int C, int P, int hh_end, double* cond_ok, hipStream_t st) {
+    cond_flag_kernel<<<bgrid((P + 255) / 256), 256, 0, st>>>(sv, C, P, hh_end, cond_ok, batch_ctx().stride);
     KERNEL_CHECK();
 }
 void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S, int C,

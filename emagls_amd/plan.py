@@ -10,10 +10,11 @@ from . import _lib as L
 
 class Plan:
     def __init__(self, kind, basis="real", order=4, fs=48000.0, length=512, nsamp=128, ndirs=0, mic_radius=0.0, nmics=0,
-                 f_trans=0.0, atf_taps=0, natf=0):
+                 f_trans=0.0, atf_taps=0, natf=0, custom_basis=False):
         self._lib = L.load()
         self.desc = L.DesignDesc(kind, L.BASIS[basis], order, fs, length, nsamp, ndirs, mic_radius, nmics, f_trans,
-                                 atf_taps, natf)
+                                 atf_taps, natf, 1 if custom_basis else 0)
+        self._cplx = basis == "complex"
         self._h = C.c_void_p()
         L.check(self._lib.emagls_plan_create(C.byref(self.desc), C.byref(self._h)))
         self._keep = []
@@ -40,6 +41,16 @@ class Plan:
     def set_mic_grid(self, azi, zen=None):
         """zen may be omitted for an equatorial array (KIND_EMA_CH): every microphone sits at pi/2."""
         L.check(self._lib.emagls_plan_set_mic_grid(self._h, self._p(azi), self._p(zen) if zen is not None else None))
+
+    def set_basis(self, Y_hrir, Y_mic=None):
+        """custom_basis plans: the SH matrices a custom shFunction returned ([ndirs x S], [nmics x S]) instead of the grids."""
+        dt = np.complex128 if self._cplx else np.float64
+
+        def ptr(a):
+            a = np.asfortranarray(np.asarray(a, dtype=dt))
+            self._keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+        L.check(self._lib.emagls_plan_set_basis(self._h, ptr(Y_hrir), ptr(Y_mic) if Y_mic is not None else None))
 
     def set_hrirs(self, hL, hR):
         L.check(self._lib.emagls_plan_set_hrirs(self._h, self._p(hL), self._p(hR)))

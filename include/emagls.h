@@ -21,7 +21,8 @@
  *   - pointers may be host or device pointers (copies use hipMemcpyDefault); outputs are caller-allocated;
  *   - every function returns EMAGLS_OK or an error code; emagls_last_error() gives the message
  *     (the MEX shim forwards it to mexErrMsgIdAndTxt);
- *   - the default shFunction (@getSH) is built in; a custom MATLAB shFunction handle cannot cross a C ABI.
+ *   - the default shFunction (@getSH) is built in; a custom MATLAB shFunction handle cannot cross a C ABI: the wrapper
+ *     evaluates it and calls the *_with_basis entry points with the resulting matrices.
  *
  * Threading: one host thread per plan; one process per GPU for multi-GPU batches.
  */
@@ -106,6 +107,22 @@ int emagls_get_emagls_filters_ema_in_ch(const double* hL, const double* hR, int6
                                         const double* mic_azi, int64_t nmics, int order, double fs, int64_t len, int basis,
                                         void* wL, void* wR);
 
+/* The same designs with a custom shFunction (lib/getEMagLsFilters.m:32,68; dependencies/getSMAIRMatrix.m:101): a function handle
+ * cannot cross a C ABI, so the MATLAB-side wrapper evaluates it and passes the matrices -- Y_hrir = shFunction(n, [azi zen],
+ * shDefinition) [ndirs x (n+1)^2] and Y_mic = shFunction(n, micGrid, shDefinition) [nmics x (n+1)^2], column-major, real or
+ * interleaved complex like `basis`, with n = emagls_simulation_order(kind, order, fs, mic_radius) (n = order for LS / MagLS). */
+int emagls_simulation_order(int kind, int order, double fs, double mic_radius);
+int emagls_get_ls_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir, int order,
+                                     int basis, void* wL, void* wR);
+int emagls_get_magls_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir, int order,
+                                        double fs, int64_t len, int basis, void* wL, void* wR);
+int emagls_get_emagls_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir,
+                                         double mic_radius, const void* Y_mic, int64_t nmics, int order, double fs, int64_t len,
+                                         int basis, void* wL, void* wR);
+int emagls_get_emagls2_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir,
+                                          double mic_radius, const void* Y_mic, int64_t nmics, int order, double fs, int64_t len,
+                                          int basis, void* wL, void* wR);
+
 /* atf_irs [atf_taps x nmics x natf]; outputs real [filter_len x nmics];
  * mean_grid_dev_deg (optional) receives the value the reference prints (getEMagLsFiltersFromAtf.m:96). */
 int emagls_get_emagls_filters_from_atf(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
@@ -143,6 +160,7 @@ typedef struct emagls_design_desc {
     double f_trans;      /* FROM_ATF: transition frequency in Hz */
     int64_t atf_taps;    /* FROM_ATF */
     int64_t natf;        /* FROM_ATF: ATF directions */
+    int custom_basis;    /* != 0: the SH matrices are supplied by emagls_plan_set_basis (a custom shFunction, lib/getEMagLsFilters.m:32,68) */
 } emagls_design_desc;
 
 typedef struct emagls_plan_info {
@@ -165,6 +183,9 @@ int emagls_plan_set_hrir_grid(emagls_plan* plan, const double* azi, const double
 /* zen is ignored (may be NULL) for EMAGLS_KIND_EMA_CH: an equatorial array, every microphone at pi/2 */
 int emagls_plan_set_mic_grid(emagls_plan* plan, const double* azi, const double* zen);
 int emagls_plan_set_hrirs(emagls_plan* plan, const double* hL, const double* hR);
+/* custom_basis plans: Y_hrir [ndirs x S] and (array designs) Y_mic [nmics x S], column-major, real or interleaved complex like
+ * the plan's basis, S = (emagls_simulation_order(...) + 1)^2; replaces the two grid setters */
+int emagls_plan_set_basis(emagls_plan* plan, const void* Y_hrir, const void* Y_mic);
 int emagls_plan_set_atfs(emagls_plan* plan, const double* atf_irs, const double* atf_azi, const double* atf_zen);
 /* enqueue the whole design (SH basis ... windowed filters) on the plan's stream; returns immediately */
 int emagls_plan_execute(emagls_plan* plan);

@@ -234,7 +234,7 @@ def emagls2_simulation_order(fs, radius):
 
 
 def getSMAIRMatrix(order, fs, irLen, smaRadius, smaDesignAziZenRad, shDefinition="real",
-                   returnRawMicSigs=False, arrayType="rigid"):
+                   returnRawMicSigs=False, arrayType="rigid", shFunction=None):
     """dependencies/getSMAIRMatrix.m:86-127 with oversamplingFactor=1, radialFilter='none',
     planeWave (the only configuration the five entry points use, lib/getEMagLsFilters.m:51-63).
     Returns [C x S x P] like the reference."""
@@ -246,7 +246,7 @@ def getSMAIRMatrix(order, fs, irLen, smaRadius, smaDesignAziZenRad, shDefinition
     nOut = (order + 1) ** 2
     P = f.size
     M = smaDesignAziZenRad.shape[0]
-    Y_Hi = getSH(simOrder, smaDesignAziZenRad, shDefinition)
+    Y_Hi = (shFunction or getSH)(simOrder, smaDesignAziZenRad, shDefinition)   # params.shFunction (:101)
     Y_Lo_pinv = pinv(Y_Hi[:, :nOut])
     bnAll = -sphModalCoeffs(simOrder, 2 * np.pi * f / C_SOUND * smaRadius, arrayType).T  # (simOrder+1) x P
     rows = M if returnRawMicSigs else nOut
@@ -263,9 +263,9 @@ def getSMAIRMatrix(order, fs, irLen, smaRadius, smaDesignAziZenRad, shDefinition
 # --------------------------------------------------------------------------------------------
 # lib/*.m
 # --------------------------------------------------------------------------------------------
-def getLsFilters(hL, hR, aziRad, zenRad, order, shDefinition="real"):
+def getLsFilters(hL, hR, aziRad, zenRad, order, shDefinition="real", shFunction=None):
     """lib/getLsFilters.m:30-34"""
-    Y_conj = getSH(order, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
+    Y_conj = (shFunction or getSH)(order, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
     Y_pinv = pinv(Y_conj)
     return hL @ Y_pinv, hR @ Y_pinv
 
@@ -308,11 +308,11 @@ def _finish(W_l, W_r, P, nfft, length, is_real_basis, delayL, delayR, integer_sh
     return out
 
 
-def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="real"):
+def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="real", shFunction=None):
     """lib/getMagLsFilters.m:30-98"""
     assert length >= hL.shape[0], "HRIR len too short"
     nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
-    Y_conj = getSH(order, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
+    Y_conj = (shFunction or getSH)(order, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
     Y_pinv = pinv(Y_conj)
     is_real = np.isrealobj(Y_conj)
     hL = _pad(hL, nfft)
@@ -388,7 +388,7 @@ def _matmul(A, B):
 
 
 def _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                    shDefinition, raw, collect=None):
+                    shDefinition, raw, collect=None, shFunction=None):
     assert length >= hL.shape[0], "len too short"
     nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
     # lib/getEMagLs2Filters.m:51-63 never sets params.order, so dependencies/getSMAIRMatrix.m:39-41 defaults it to 4:
@@ -396,8 +396,8 @@ def _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs
     # lib/getEMagLsFilters.m:51 (and both EMA variants, :54 / :52) do pass params.order = order.
     smair_order = SMAIR_DEFAULT_ORDER if raw else order
     smair, simOrder = getSMAIRMatrix(smair_order, fs, nfft, micRadius, np.column_stack([micAzi, micZen]),
-                                     shDefinition, returnRawMicSigs=raw)
-    Y_Hi_conj = getSH(simOrder, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
+                                     shDefinition, returnRawMicSigs=raw, shFunction=shFunction)
+    Y_Hi_conj = (shFunction or getSH)(simOrder, np.column_stack([aziRad, zenRad]), shDefinition).conj().T   # :68
     HL, HR, gL, gR = _hrir_prologue(hL, hR, nfft, P)
     C = smair.shape[0]
     W_l, W_r = _emagls_core(HL, HR, lambda k: _matmul(smair[:, :, k - 1], Y_Hi_conj), P, k_cut, C, collect)
@@ -410,17 +410,17 @@ def _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs
 
 
 def getEMagLsFilters(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                     shDefinition="real", collect=None):
+                     shDefinition="real", collect=None, shFunction=None):
     """lib/getEMagLsFilters.m:32-142"""
     return _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                           shDefinition, raw=False, collect=collect)
+                           shDefinition, raw=False, collect=collect, shFunction=shFunction)
 
 
 def getEMagLs2Filters(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                      shDefinition="real", collect=None):
+                      shDefinition="real", collect=None, shFunction=None):
     """lib/getEMagLs2Filters.m:32-135"""
     return _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                           shDefinition, raw=True, collect=collect)
+                           shDefinition, raw=True, collect=collect, shFunction=shFunction)
 
 
 

@@ -486,6 +486,97 @@ def test_binaural_decode(golden):
     assert rel(a, 2.5 * out) < 1e-13
 
 
+def _sn3d_sh(N, dirs, basisType="real"):
+    """A custom shFunction as a user of the reference would pass it (lib/getEMagLsFilters.m:32): SN3D-weighted harmonics."""
+    Y = O.getSH(N, dirs, basisType)
+    w = np.concatenate([np.full(2 * n + 1, 1.0 / np.sqrt(2 * n + 1)) for n in range(N + 1)])
+    return Y * w[None, :]
+
+
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_custom_sh_function(grids, thin, basis):
+    """shFunction handles (lib/getLsFilters.m:27, getMagLsFilters.m:30, getEMagLsFilters.m:32, getEMagLs2Filters.m:32) are
+    evaluated on the host side and travel as matrices (emagls_*_with_basis).  Passing the default function that way must give
+    the built-in result; a genuinely different basis (SN3D) must give what the oracle computes with the same function."""
+    import emagls_amd as E
+    hL, hR, azi, zen = thin["hL"], thin["hR"], thin["azi"], thin["zen"]
+    mic = (grids["mic_radius"], grids["mic_azi"], grids["mic_zen"])
+    for fn, args in (("getLsFilters", (hL, hR, azi, zen, 3)), ("getMagLsFilters", (hL, hR, azi, zen, 3, 48000.0, 128)),
+                     ("getEMagLsFilters", (hL, hR, azi, zen) + mic + (3, 48000.0, 128)),
+                     ("getEMagLs2Filters", (hL, hR, azi, zen) + mic + (3, 48000.0, 128))):
+        bL, bR = getattr(E, fn)(*args, basis)
+        cL, cR = getattr(E, fn)(*args, basis, O.getSH)
+        assert cL.dtype == bL.dtype and rel(cL, bL) < 1e-9 and rel(cR, bR) < 1e-9, (fn, rel(cL, bL), rel(cR, bR))
+        sL, sR = getattr(E, fn)(*args, basis, _sn3d_sh)
+        oL, oR = getattr(O, fn)(*args, basis, shFunction=_sn3d_sh)
+        assert report(fn + " SN3D shFunction " + basis, sL, oL) < TOL and rel(sR, oR) < TOL
+        if fn != "getEMagLs2Filters":   # (raw-microphone filters do not depend on the basis scaling)
+            assert rel(sL, bL) > 1e-3
+
+
+def test_one_shot_plan_cache(grids, thin):
+    """The one-shot entry points reuse the plan of the previous call of the same shape (buffers, captured graphs): results
+    must follow the inputs, not the cache, and emagls_cache_clear() must leave the library usable."""
+    import emagls_amd as E
+    from emagls_amd import _lib as L
+    args = lambda h: (h[0], h[1], thin["azi"], thin["zen"], grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "complex")
+    h1 = (thin["hL"], thin["hR"])
+    h2 = (thin["hR"][::-1].copy() * 0.5, thin["hL"].copy())
+    a1 = E.getEMagLsFilters(*args(h1))
+    a2 = E.getEMagLsFilters(*args(h2))          # same shape: served by the cached plan (second execute: graph capture)
+    a3 = E.getEMagLsFilters(*args(h1))          # third: graph replay
+    a4 = E.getEMagLsFilters(*args(h2))
+    assert rel(a3[0], a1[0]) < 1e-12 and rel(a3[1], a1[1]) < 1e-12 and rel(a4[0], a2[0]) < 1e-12
+    assert rel(a2[0], a1[0]) > 1e-2
+    o2 = O.getEMagLsFilters(*args(h2))
+    assert rel(a4[0], o2[0]) < TOL and rel(a4[1], o2[1]) < TOL
+    # a different microphone grid under the same shape key
+    g2 = (h1[0], h1[1], thin["azi"], thin["zen"], grids["mic_radius"], grids["mic_azi"] + 0.3, grids["mic_zen"], 4, 48000.0, 128, "complex")
+    b1 = E.getEMagLsFilters(*g2)
+    ob = O.getEMagLsFilters(*g2)
+    assert rel(b1[0], ob[0]) < TOL and rel(b1[0], a1[0]) > 1e-3
+    L.check(L.load().emagls_cache_clear())
+    a5 = E.getEMagLsFilters(*args(h1))
+    assert rel(a5[0], a1[0]) < 1e-12
+
+
+def test_binaural_decode_complex(golden):
+    """Complex-SH rendering (dependencies/binauralDecode.m:39-42,59-64): complex filters (the reference's own complex eMagLS
+    fixture) on a complex-SH signal; the output is the real part of the accumulated products, the discarded imaginary part is
+    reported like the reference's warning does."""
+    import warnings
+    import emagls_amd as E
+    rng = np.random.default_rng(11)
+    wL = golden["complex_eMagLS_woDC/wEMlsL"]
+    wR = golden["complex_eMagLS_woDC/wEMlsR"]
+    assert np.iscomplexobj(wL) and wL.shape == (512, 25)
+    sig = rng.standard_normal((9000, 25)) + 1j * rng.standard_normal((9000, 25))
+    ref = O.binauralDecode(sig, wL, wR)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        out = E.binauralDecode(sig, 48000, wL, wR, 48000)
+    assert out.shape == (9000, 2) and out.dtype == np.float64 and rel(out, ref) < 1e-12
+    assert any("discarding imaginary part" in str(w.message) for w in wlist)
+    out2 = E.binauralDecode(sig, 48000, wL, wR, 48000, True)
+    assert rel(out2, O.binauralDecode(sig, wL, wR, True)) < 1e-12
+    # a real signal through complex filters, and a complex-SH encoded REAL sound field: its rendering has no imaginary part
+    # (w_{n,-m} = (-1)^m conj(w_{n,m}) for the filters, the same symmetry for the coefficients of a real field)
+    sr = rng.standard_normal((4000, 25))
+    assert rel(E.binauralDecode(sr, 48000, wL, wR, 48000), O.binauralDecode(sr, wL, wR)) < 1e-12
+    N = 4
+    T = np.zeros((25, 25), complex)   # Y_c = Y_r T  (tests/test_oracle_kats.py::real_to_complex_T)
+    for n in range(N + 1):
+        T[n * n + n, n * n + n] = 1
+        for m in range(1, n + 1):
+            a, b = n * n + n + m, n * n + n - m
+            T[a, a] = (-1) ** m / np.sqrt(2); T[b, a] = 1j * (-1) ** m / np.sqrt(2)
+            T[a, b] = 1 / np.sqrt(2); T[b, b] = -1j / np.sqrt(2)
+    sc = sr @ np.conj(T)              # complex-SH coefficients of the real field with real-SH coefficients sr
+    oc = E.binauralDecode(sc, 48000, wL, wR, 48000)
+    full = sum(O.fftfilt(wL[:, c], sc[:, c]) for c in range(25))
+    assert np.abs(full.imag).max() < 1e-9 * np.abs(full.real).max() and rel(oc[:, 0], full.real) < 1e-12
+
+
 def test_error_behaviour(grids, hrirs):
     """assert(len >= size(hL,1), 'len too short') (lib/getEMagLsFilters.m:42) and friends."""
     import emagls_amd as E

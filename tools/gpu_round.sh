@@ -1,14 +1,20 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, the bench line, rocprofv3 kernel traces.  Usage (through gpurun):
-#   bash tools/gpu_round.sh <tag> [tests|notests] [pmc]
+#   bash tools/gpu_round.sh <tag> [tests|notests|testsonly] [pmc]      (testsonly: the whole gpu suite without -x, nothing else)
 # Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 tag=${1:-r}; what=${2:-tests}; pmc=${3:-}
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 if [ "$what" = "tests" ]; then
   timeout 1500 python -m pytest tests -m gpu -q -rP -x > gpurun_out/${tag}_tests_full.log 2>&1
   tail -5 gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_tests.log
-  grep -h "norm_diff=\|rel = \|^case (" gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_parity.log
+  grep -h "norm_diff=\|rel = \|^case (\|rel L\|worst rel" gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_parity.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
+fi
+if [ "$what" = "testsonly" ]; then
+  timeout 2400 python -m pytest tests -m gpu -q -rP ${PYTEST_ARGS:-} > gpurun_out/${tag}_tests_full.log 2>&1
+  tail -15 gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_tests.log
+  grep -h "norm_diff=\|rel = \|^case (\|rel L\|worst rel" gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_parity.log
+  cat gpurun_out/${tag}_tests.log; exit 0
 fi
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench20.json 2> gpurun_out/${tag}_bench20.err
 timeout 600 python bench.py --steps 128 --warmup 32 --no-cpu-baseline --no-sh-roofline --no-secondary > gpurun_out/${tag}_bench128.json 2> gpurun_out/${tag}_bench128.err
