@@ -286,7 +286,8 @@ void plan_alloc_routes(emagls_plan& p) {
     }
     p.alloc("Tn", esz(cb) * (size_t)(p.n_h + 1) * p.C * p.ldS_h);
     p.alloc("Hq", sizeof(cplx) * (size_t)2 * ls_end * p.ldS_h);
-    p.alloc("Hyp", sizeof(cplx) * hy_workspace_elems(2 * ls_end, p.ldS_h));
+    p.alloc("Hyp", sizeof(double) * hy_mfma_workspace_doubles(ls_end, p.S_h, cb));
+    p.alloc("HcT", sizeof(double) * (size_t)hy_mfma_kpad((int)p.D) * round_up(4 * ls_end, 64));   // (rows >= D stay zero)
     p.alloc("Z", sizeof(cplx) * (size_t)p.hh_end * p.C * p.ldS_h);
     p.alloc("Vws", sizeof(cplx) * (size_t)p.hh_end * p.C * p.ldS_h);
     p.alloc("G", sizeof(cplx) * ((size_t)std::max(p.P - p.g0, 1) * p.C + 32) * p.ldD, false);  // + 32 rows: the persistent sweep loads all 32 slab rows of a bin unconditionally
@@ -390,7 +391,7 @@ void plan_setup(emagls_plan& p) {
 
     if (d.kind != EMAGLS_KIND_FROM_ATF) {
         // ---- SH machinery on the HRIR grid
-        p.Dpad = gram_dpad(p.D, p.S);
+        p.Dpad = std::max<int64_t>(gram_dpad(p.D, p.S), hy_mfma_kpad((int)p.D));   // (rows D..Dpad of Yc are zero)
         p.alloc("sh_tab", sizeof(double) * sh_coeff_count(p.simOrder));
         p.alloc("Ycm", esz(cb) * (size_t)p.S * p.ldD);                 // [S][ldD] column-major SH matrix
         p.alloc("Yc", esz(cb) * (size_t)p.Dpad * p.ldS);               // [Dpad][ldS] conj(Y), direction-major
@@ -670,7 +671,8 @@ void emagls_pre_sweep(emagls_plan& p) {
         launch_hrir_grpdelay(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, d.ndirs, p.nfft, p.get("tw"),
                              p.get<double>("dirsum"), p.get<double>("grpd"), s2);
         launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"),
-                        p.get<double>("grpd"), 0, ls_end, p.kcut0, p.get("Hc"), p.get<double>("Habs"), p.ldD, s2);
+                        p.get<double>("grpd"), 0, ls_end, p.kcut0, p.get("Hc"), p.get<double>("Habs"), p.ldD, s2,
+                        ls_end > 0 ? p.get<double>("HcT") : nullptr, round_up(4 * std::max(ls_end, 1), 64));
     }
 
     // s0: SH matrix of the HRIR grid, its Gram matrix Gy, Cholesky factor R of the leading block (Householder-route orders)
@@ -701,7 +703,8 @@ void emagls_pre_sweep(emagls_plan& p) {
     if (hh_end > 1) {
         // (real basis: the rows are complex all the same, so R is widened to a complex copy for the row solves)
         if (!cb) launch_widen(p.get("R"), Sh, false, p.get("Rc"), Sh, Sh, Sh, false, /*upper_only=*/true, s2);
-        launch_hy_conj(p.get("Hc"), p.ldD, 2 * ls_end, p.get("Yc"), p.ldS, cb, (int)p.D, Sh, p.get("Hyp"), p.get("Hq"), ldSh, s2);
+        launch_hy_conj_mfma(p.get<double>("HcT"), round_up(4 * std::max(ls_end, 1), 64), ls_end, p.get("Yc"), p.ldS, cb, (int)p.D, Sh,
+                            p.get<double>("Hyp"), p.get("Hq"), ldSh, s2);
         // (also forms the inverses of R's diagonal blocks, which the ill-conditioned swept bins need: at least one row)
         launch_qform(p.get("Hq"), p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), Sh, 2 * (int64_t)std::max(ls_end, 1), ldSh, true, p.get("Hq"), s2);
     }

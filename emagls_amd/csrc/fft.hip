@@ -146,8 +146,10 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
                                                        int log2n, int TD,
                                                        const cplx* __restrict__ tw, const double* __restrict__ grpd,
                                                        int mode, int n_c, int kabs0, cplx* __restrict__ Hc,
-                                                       double* __restrict__ Habs, int64_t ldD, size_t bstride) {
+                                                       double* __restrict__ Habs, int64_t ldD, double* __restrict__ HcT, int ldT,
+                                                       size_t bstride) {
     hL = boff(hL, bstride); hR = boff(hR, bstride); didx = boff(didx, bstride); tw = boff(tw, bstride); grpd = boff(grpd, bstride); Hc = boff(Hc, bstride); Habs = boff(Habs, bstride);
+    HcT = boff(HcT, bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* tws = reinterpret_cast<cplx*>(smem);  // nfft/2
     cplx* buf = tws + nfft / 2;                 // TD * nfft
@@ -210,6 +212,22 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
             const double nl2 = norm2(HLv), nr2 = norm2(HRv);
             Habs[((int64_t)0 * na + (kb - kabs0)) * ldD + d] = nl2 > 0.0 ? nl2 * fast_rsqrt(nl2) : 0.0;
             Habs[((int64_t)1 * na + (kb - kabs0)) * ldD + d] = nr2 > 0.0 ? nr2 * fast_rsqrt(nr2) : 0.0;
+        }
+    }
+    // direction-major copy of the complex rows, HcT[d][2 (e n_c + kb) + re/im]: the K-major operand of the MFMA product
+    // H conj(Yc) of the least-squares rows (launch_hy_conj_mfma)
+    if (HcT) {
+        for (int idx = threadIdx.x; idx < TD * n_c; idx += blockDim.x) {
+            const int t = idx / n_c, kb = idx - t * n_c;
+            if (t >= nt) continue;
+            const cplx* x = buf + (size_t)t * nfft;
+            const cplx z = x[kb], zc = conj(x[(nfft - kb) & (nfft - 1)]);
+            cplx HLv = mk(0.5 * (z.x + zc.x), 0.5 * (z.y + zc.y));
+            cplx HRv = mk(0.5 * (z.y - zc.y), -0.5 * (z.x - zc.x));
+            if (mode == 0) { HLv = HLv * phs[kb]; HRv = HRv * phs[P + kb]; }
+            double* row = HcT + (int64_t)(d0 + t) * ldT;
+            row[2 * kb] = HLv.x; row[2 * kb + 1] = HLv.y;
+            row[2 * (n_c + kb)] = HRv.x; row[2 * (n_c + kb) + 1] = HRv.y;
         }
     }
 }
@@ -374,7 +392,7 @@ void launch_hrir_grpdelay(const double* hL, const double* hR, int64_t L, int64_t
 
 void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, const int64_t* didx, int nfft,
                      const void* tw, const double* grpd, int mode, int n_c, int kabs0, void* Hc, double* Habs,
-                     int64_t ldD, hipStream_t st) {
+                     int64_t ldD, hipStream_t st, double* HcT, int ldT) {
     const int log2n = ilog2(nfft);
     int TD = 8;
     const size_t ph_bytes = (size_t)(nfft + 2) * 16;
@@ -387,7 +405,7 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
         attr_set = true;
     }
     hrir_fft_kernel<<<bgrid((unsigned)ceil_div(D, TD)), 512, sm, st>>>(hL, hR, L, D, didx, nfft, log2n, TD, (const cplx*)tw, grpd, mode,
-                                                               n_c, kabs0, (cplx*)Hc, Habs, ldD, batch_ctx().stride);
+                                                               n_c, kabs0, (cplx*)Hc, Habs, ldD, HcT, ldT, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

@@ -90,28 +90,27 @@ __global__ void __launch_bounds__(256) kfold_kernel(const T* __restrict__ E, int
     }
 }
 
-// coefficients of the GEMM, K-major:  Cf[row][bin - kb0]  (rows as in kfold_kernel); Nyquist bin: real(b_n)
-__global__ void __launch_bounds__(256) gram_coef_kernel(const cplx* __restrict__ bn, int nOrd, int P, int kb0, int nbins, double* __restrict__ Cf,
+// coefficients of the GEMM, K-major:  Cf[row][bin - kb0]  (rows as in kfold_kernel); Nyquist bin: real(b_n).
+// thread = (bin, first order n): lanes are consecutive bins, so every row is written in contiguous runs
+__global__ void __launch_bounds__(128) gram_coef_kernel(const cplx* __restrict__ bn, int nOrd, int P, int kb0, int nbins, double* __restrict__ Cf,
                                                         int ldC, size_t bstride) {
     bn = boff(bn, bstride); Cf = boff(Cf, bstride);
-    const int bi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int bi = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
     if (bi >= nbins) return;
     const int kb = kb0 + bi;
     const cplx* b = bn + (int64_t)kb * nOrd;
     const bool nyq = kb == P - 1;
-    int q = 0;
-    for (int n = 0; n < nOrd; ++n) {
-        cplx x = b[n];
-        if (nyq) x.y = 0.0;
-        Cf[(int64_t)n * ldC + bi] = norm2(x);
-        for (int m = n + 1; m < nOrd; ++m, ++q) {
-            cplx y = b[m];
-            if (nyq) y.y = 0.0;
-            cplx be = mk(0, 0);
-            cfma_conj(be, x, y);   // conj(b_n) b_m
-            Cf[(int64_t)(nOrd + 2 * q) * ldC + bi] = be.x;
-            Cf[(int64_t)(nOrd + 2 * q + 1) * ldC + bi] = be.y;
-        }
+    cplx x = b[n];
+    if (nyq) x.y = 0.0;
+    Cf[(int64_t)n * ldC + bi] = norm2(x);
+    int q = n * nOrd - n * (n + 1) / 2;   // index of the pair (n, n + 1) in lexicographic order
+    for (int m = n + 1; m < nOrd; ++m, ++q) {
+        cplx y = b[m];
+        if (nyq) y.y = 0.0;
+        cplx be = mk(0, 0);
+        cfma_conj(be, x, y);   // conj(b_n) b_m
+        Cf[(int64_t)(nOrd + 2 * q) * ldC + bi] = be.x;
+        Cf[(int64_t)(nOrd + 2 * q + 1) * ldC + bi] = be.y;
     }
 }
 
@@ -119,11 +118,16 @@ __global__ void __launch_bounds__(256) gram_coef_kernel(const cplx* __restrict__
 // Workgroup = 4 waves = 64 x 64 tile, each wave 2 x 2 tiles of v_mfma_f64_16x16x4_f64.  A and B are padded with zeros to
 // multiples of 64 columns and K to a multiple of 4 rows, so the loop carries no bounds test.
 // f64 fragment layout: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; C/D: col = l & 15, row = (l >> 4) + 4 reg.
+// Split-K: blockIdx.x = m tile + mtiles * split; split s covers the rows [s K, (s+1) K) and writes the partial product at
+// Cm + s * cstride (the caller sums the partials in a fixed order).
 __global__ void __launch_bounds__(256) gemm_tn_f64_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, int K,
-                                                          double* __restrict__ Cm, int ldc, int M, int N, size_t bstride) {
+                                                          double* __restrict__ Cm, int ldc, int M, int N, int mtiles, int64_t cstride,
+                                                          size_t bstride) {
     A = boff(A, bstride); B = boff(B, bstride); Cm = boff(Cm, bstride);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m0 = blockIdx.x * 64 + (wave >> 1) * 32, n0 = blockIdx.y * 64 + (wave & 1) * 32;
+    const int split = blockIdx.x / mtiles, mt = blockIdx.x - split * mtiles;
+    A += (int64_t)split * K * lda; B += (int64_t)split * K * ldb; Cm += (int64_t)split * cstride;
+    const int m0 = mt * 64 + (wave >> 1) * 32, n0 = blockIdx.y * 64 + (wave & 1) * 32;
     const int ii = lane & 15, kk = lane >> 4;
     double4_t acc[2][2];
 #pragma unroll
@@ -248,30 +252,35 @@ __global__ void __launch_bounds__(256) gram_solve_kernel(const double* __restric
 }
 
 // least-squares bins on the Gram route:  W(k,:) = H(k,:) Y_reg_inv_k = (H(k,:) conj(G_k)) conj(M_k)
-// one workgroup per bin; thread = (pair (ear, channel), 4 direction slices)
+// one workgroup per bin; a wave takes the channels c = wave, wave + 4, ..., its lanes stride over the directions (1 KB loads)
 __global__ void __launch_bounds__(256) ls_gram_kernel(const cplx* __restrict__ Hc, int64_t ldH, int n_c, const cplx* __restrict__ G, int64_t g_stride,
                                                       int64_t ldD, const cplx* __restrict__ Mw, int D, int C, int P, int kb0, cplx* __restrict__ W,
                                                       size_t bstride) {
     Hc = boff(Hc, bstride); G = boff(G, bstride); Mw = boff(Mw, bstride); W = boff(W, bstride);
     __shared__ __attribute__((aligned(16))) cplx vt[64];
     const int kb = kb0 + blockIdx.x;
-    const int pair = threadIdx.x >> 2, part = threadIdx.x & 3;
-    const int e = pair / C, c = pair % C;
-    if (pair < 2 * C) {
-        const cplx* h = Hc + ((int64_t)e * n_c + kb) * ldH;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const cplx* h0 = Hc + ((int64_t)0 * n_c + kb) * ldH;
+    const cplx* h1 = Hc + ((int64_t)1 * n_c + kb) * ldH;
+    for (int c = wave; c < C; c += 4) {
         const cplx* g = G + (int64_t)kb * g_stride + (int64_t)c * ldD;
-        cplx a0 = mk(0, 0), a1 = mk(0, 0);
-        int d = part;
-        for (; d + 4 < D; d += 8) { cfma(a0, h[d], conj(g[d])); cfma(a1, h[d + 4], conj(g[d + 4])); }
-        if (d < D) cfma(a0, h[d], conj(g[d]));
-        const cplx acc = group_sum<4>(a0 + a1);
-        if (part == 0) vt[pair] = acc;
+        cplx a0 = mk(0, 0), a1 = mk(0, 0), b0 = mk(0, 0), b1 = mk(0, 0);
+        int d = lane;
+        for (; d + 64 < D; d += 128) {
+            const cplx ga = conj(g[d]), gb = conj(g[d + 64]);
+            cfma(a0, h0[d], ga); cfma(a1, h1[d], ga);
+            cfma(b0, h0[d + 64], gb); cfma(b1, h1[d + 64], gb);
+        }
+        if (d < D) { const cplx ga = conj(g[d]); cfma(a0, h0[d], ga); cfma(a1, h1[d], ga); }
+        const cplx s0 = wave_sum(a0 + b0), s1 = wave_sum(a1 + b1);
+        if (lane == 0) { vt[c] = s0; vt[32 + c] = s1; }
     }
     __syncthreads();
-    if (pair < 2 * C && part == 0) {
+    for (int pair = threadIdx.x; pair < 2 * C; pair += blockDim.x) {
+        const int e = pair / C, c = pair % C;
         const cplx* M = Mw + (int64_t)(kb - 1) * C * C;
         cplx acc = mk(0, 0);
-        for (int cc = 0; cc < C; ++cc) cfma(acc, vt[e * C + cc], conj(M[cc * C + c]));
+        for (int cc = 0; cc < C; ++cc) cfma(acc, vt[32 * e + cc], conj(M[cc * C + c]));
         W[((int64_t)e * P + kb) * C + c] = acc;
     }
 }
@@ -300,12 +309,58 @@ void launch_gram_kmat(const void* Gy, const void* E, int S, int ldE, int C, int 
 void launch_gram_gemm(const void* bn, int nOrd, int P, int kb0, int nbins, double* Cf, int ldC, const double* Kmat, int ldK, int C, double* Apk,
                       int ldA, hipStream_t st) {
     if (nbins <= 0) return;
-    gram_coef_kernel<<<bgrid((nbins + 255) / 256), 256, 0, st>>>((const cplx*)bn, nOrd, P, kb0, nbins, Cf, ldC, batch_ctx().stride);
+    gram_coef_kernel<<<bgrid(dim3((nbins + 127) / 128, nOrd)), 128, 0, st>>>((const cplx*)bn, nOrd, P, kb0, nbins, Cf, ldC, batch_ctx().stride);
     KERNEL_CHECK();
     const int K = (nOrd * nOrd + 3) / 4 * 4;
-    gemm_tn_f64_kernel<<<bgrid(dim3((nbins + 63) / 64, (C * C + 63) / 64)), 256, 0, st>>>(Cf, ldC, Kmat, ldK, K, Apk, ldA, nbins, C * C, batch_ctx().stride);
+    const int mtiles = (nbins + 63) / 64;
+    gemm_tn_f64_kernel<<<bgrid(dim3(mtiles, (C * C + 63) / 64)), 256, 0, st>>>(Cf, ldC, Kmat, ldK, K, Apk, ldA, nbins, C * C, mtiles, 0,
+                                                                               batch_ctx().stride);
     KERNEL_CHECK();
 }
+
+// ---- least-squares rows H conj(Yc) on the matrix pipe (the same GEMM kernel, split over the directions)
+namespace {
+constexpr int HYM_KS = 16;   // K splits: 2702 directions -> slices of 172, summed in a fixed order
+// out[r][s] = conj(P[r][s]), P = sum over splits; Pw[split][2 r + re/im of H][s (x2: re/im of Yc when complex)]
+__global__ void __launch_bounds__(256) hy_combine_kernel(const double* __restrict__ Pw, int ldP, int64_t pstride, int nrows, int S, int y_cplx,
+                                                         cplx* __restrict__ out, int ldS, size_t bstride) {
+    Pw = boff(Pw, bstride); out = boff(out, bstride);
+    const int r = blockIdx.y;
+    const int sc = blockIdx.x * 256 + threadIdx.x;
+    if (sc >= S) return;
+    double hr_yr = 0.0, hi_yr = 0.0, hr_yi = 0.0, hi_yi = 0.0;
+    for (int ks = 0; ks < HYM_KS; ++ks) {
+        const double* p0 = Pw + (int64_t)ks * pstride + (int64_t)(2 * r) * ldP;
+        const double* p1 = p0 + ldP;
+        if (y_cplx) { hr_yr += p0[2 * sc]; hr_yi += p0[2 * sc + 1]; hi_yr += p1[2 * sc]; hi_yi += p1[2 * sc + 1]; }
+        else { hr_yr += p0[sc]; hi_yr += p1[sc]; }
+    }
+    // P = (Hr + i Hi)(Yr - i Yi) = (Hr Yr + Hi Yi) + i (Hi Yr - Hr Yi);  out = conj(P)
+    out[(int64_t)r * ldS + sc] = mk(hr_yr + hi_yi, -(hi_yr - hr_yi));
+}
+}  // namespace
+
+static inline int hym_kslice(int D) { return (int)(ceil_div(ceil_div(D, HYM_KS), 4) * 4); }
+size_t hy_mfma_workspace_doubles(int n_c, int S, bool y_cplx) {
+    const int M = 4 * n_c, N = y_cplx ? 2 * S : S;
+    return (size_t)HYM_KS * (size_t)(ceil_div(M, 64) * 64) * (size_t)(ceil_div(N, 64) * 64);
+}
+void launch_hy_conj_mfma(const double* HcT, int ldT, int n_c, const void* Yc, int64_t ldY, bool y_cplx, int D, int S, double* Pw, void* out,
+                         int ldS, hipStream_t st) {
+    if (n_c <= 0) return;
+    const int M = 4 * n_c, N = y_cplx ? 2 * S : S;            // rows: (ear, bin, re/im); columns: s (re/im interleaved when complex)
+    const int ldb = (int)(y_cplx ? 2 * ldY : ldY);
+    const int ldP = (int)(ceil_div(N, 64) * 64), mtiles = (M + 63) / 64;
+    const int64_t pstride = (int64_t)(ceil_div(M, 64) * 64) * ldP;
+    const int kc = hym_kslice(D);                            // rows D .. HYM_KS kc of both operands are zero (padded buffers)
+    gemm_tn_f64_kernel<<<bgrid(dim3(mtiles * HYM_KS, (N + 63) / 64)), 256, 0, st>>>(HcT, ldT, (const double*)Yc, ldb, kc, Pw, ldP, M, N, mtiles,
+                                                                                    pstride, batch_ctx().stride);
+    KERNEL_CHECK();
+    hy_combine_kernel<<<bgrid(dim3((unsigned)ceil_div(S, 256), 2 * n_c)), 256, 0, st>>>(Pw, ldP, pstride, 2 * n_c, S, y_cplx ? 1 : 0, (cplx*)out, ldS,
+                                                                                      batch_ctx().stride);
+    KERNEL_CHECK();
+}
+int hy_mfma_kpad(int D) { return HYM_KS * hym_kslice(D); }
 
 void launch_gram_solve(const double* Apk, int ldA, int C, int kb0, int nbins, double reg_c, void* Mw, void* R2w, double* sv, int* route,
                        int* sweeps_out, hipStream_t st) {

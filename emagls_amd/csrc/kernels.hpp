@@ -25,9 +25,10 @@ void launch_twiddles(int nfft, void* tw, hipStream_t st);
 int hrir_dirsum_chunks(int64_t D);
 void launch_hrir_grpdelay(const double* hL, const double* hR, int64_t L, int64_t D, int nfft, const void* tw,
                           double* partial, double* grpd, hipStream_t st);
+// HcT (optional): direction-major real copy of the complex rows [D][ldT], HcT[d][2 (e n_c + kb) + re/im]
 void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, const int64_t* didx, int nfft,
                      const void* tw, const double* grpd, int mode, int n_c, int kabs0, void* Hc, double* Habs,
-                     int64_t ldD, hipStream_t st);
+                     int64_t ldD, hipStream_t st, double* HcT = nullptr, int ldT = 0);
 void launch_real_fft_gather(const double* x, int64_t L, int64_t ncols, const int64_t* colidx, int nfft, const void* tw,
                             void* out, int64_t ldo, int64_t inner, int64_t ld_inner, hipStream_t st);
 void launch_filter_epilogue(const void* W, int C, int nfft, int len, const void* tw, const double* grpd, int conj_mode,
@@ -60,6 +61,12 @@ void launch_gram_gemm(const void* bn, int nOrd, int P, int kb0, int nbins, doubl
                       int ldA, hipStream_t st);
 void launch_gram_solve(const double* Apk, int ldA, int C, int kb0, int nbins, double reg_c, void* Mw, void* R2w, double* sv, int* route,
                        int* sweeps_out, hipStream_t st);
+// out[r][s] = conj( sum_d H[r][d] conj(Yc[d][s]) ) for the 2 n_c complex rows r = e n_c + kb held direction-major in HcT
+// (launch_hrir_fft); Yc [Dpad][ldY] real or complex, rows >= D zero.  Pw: workspace hy_mfma_workspace_doubles(...)
+size_t hy_mfma_workspace_doubles(int n_c, int S, bool y_cplx);
+int hy_mfma_kpad(int D);   // rows of both operands that the product reads (zero beyond D)
+void launch_hy_conj_mfma(const double* HcT, int ldT, int n_c, const void* Yc, int64_t ldY, bool y_cplx, int D, int S, double* Pw, void* out,
+                         int ldS, hipStream_t st);
 void launch_ls_gram(const void* Hc, int64_t ldH, int n_c, const void* G, int64_t g_stride, int64_t ldD, const void* Mw, int D, int C, int P,
                     int kb_lo, int kb_hi, void* W, hipStream_t st);
 

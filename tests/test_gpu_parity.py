@@ -559,10 +559,13 @@ def test_binaural_decode_complex(golden):
     assert any("discarding imaginary part" in str(w.message) for w in wlist)
     out2 = E.binauralDecode(sig, 48000, wL, wR, 48000, True)
     assert rel(out2, O.binauralDecode(sig, wL, wR, True)) < 1e-12
-    # a real signal through complex filters, and a complex-SH encoded REAL sound field: its rendering has no imaginary part
-    # (w_{n,-m} = (-1)^m conj(w_{n,m}) for the filters, the same symmetry for the coefficients of a real field)
+    # a real signal through complex filters
     sr = rng.standard_normal((4000, 25))
     assert rel(E.binauralDecode(sr, 48000, wL, wR, 48000), O.binauralDecode(sr, wL, wR)) < 1e-12
+    # A complex-SH encoded REAL sound field through filters with the symmetry w_{n,-m} = (-1)^m conj(w_{n,m}) renders without an
+    # imaginary part.  The reference's complex MagLS fixture has that symmetry (test_oracle_kats); its complex eMagLS fixture
+    # does not (DC := real(bin 2) per complex coefficient, lib/getEMagLsFilters.m:110-111) -- which is why the reference warns.
+    mL, mR = golden["complex_MagLS_woDC/wMlsL"], golden["complex_MagLS_woDC/wMlsR"]
     N = 4
     T = np.zeros((25, 25), complex)   # Y_c = Y_r T  (tests/test_oracle_kats.py::real_to_complex_T)
     for n in range(N + 1):
@@ -572,9 +575,13 @@ def test_binaural_decode_complex(golden):
             T[a, a] = (-1) ** m / np.sqrt(2); T[b, a] = 1j * (-1) ** m / np.sqrt(2)
             T[a, b] = 1 / np.sqrt(2); T[b, b] = -1j / np.sqrt(2)
     sc = sr @ np.conj(T)              # complex-SH coefficients of the real field with real-SH coefficients sr
-    oc = E.binauralDecode(sc, 48000, wL, wR, 48000)
-    full = sum(O.fftfilt(wL[:, c], sc[:, c]) for c in range(25))
-    assert np.abs(full.imag).max() < 1e-9 * np.abs(full.real).max() and rel(oc[:, 0], full.real) < 1e-12
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        oc = E.binauralDecode(sc, 48000, mL, mR, 48000)
+    full = sum(O.fftfilt(mL[:, c], sc[:, c]) for c in range(25))
+    assert np.abs(full.imag).max() < 1e-12 * np.abs(full.real).max() and rel(oc[:, 0], full.real) < 1e-12
+    msgs = [str(w.message) for w in wlist if "discarding imaginary part" in str(w.message)]
+    assert all(float(x) < 1e-9 for m_ in msgs for x in m_.split("[")[1].split("]")[0].split(","))
 
 
 def test_error_behaviour(grids, hrirs):
