@@ -252,8 +252,9 @@ __global__ void __launch_bounds__(256) gram_solve_kernel(const double* __restric
 }
 
 // least-squares bins on the Gram route:  W(k,:) = H(k,:) Y_reg_inv_k = (H(k,:) conj(G_k)) conj(M_k)
-// one workgroup per bin; a wave takes the channels c = wave, wave + 4, ..., its lanes stride over the directions (1 KB loads)
-__global__ void __launch_bounds__(256) ls_gram_kernel(const cplx* __restrict__ Hc, int64_t ldH, int n_c, const cplx* __restrict__ G, int64_t g_stride,
+// one workgroup (16 waves) per bin; a wave takes the channels c = wave, wave + 16, ..., its lanes stride over the directions
+// (1 KB loads; the few bins of this kind leave the chip empty, so a bin's channels run side by side)
+__global__ void __launch_bounds__(1024) ls_gram_kernel(const cplx* __restrict__ Hc, int64_t ldH, int n_c, const cplx* __restrict__ G, int64_t g_stride,
                                                       int64_t ldD, const cplx* __restrict__ Mw, int D, int C, int P, int kb0, cplx* __restrict__ W,
                                                       size_t bstride) {
     Hc = boff(Hc, bstride); G = boff(G, bstride); Mw = boff(Mw, bstride); W = boff(W, bstride);
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(256) ls_gram_kernel(const cplx* __restrict__ H
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const cplx* h0 = Hc + ((int64_t)0 * n_c + kb) * ldH;
     const cplx* h1 = Hc + ((int64_t)1 * n_c + kb) * ldH;
-    for (int c = wave; c < C; c += 4) {
+    for (int c = wave; c < C; c += 16) {
         const cplx* g = G + (int64_t)kb * g_stride + (int64_t)c * ldD;
         cplx a0 = mk(0, 0), a1 = mk(0, 0), b0 = mk(0, 0), b1 = mk(0, 0);
         int d = lane;
@@ -375,7 +376,7 @@ void launch_ls_gram(const void* Hc, int64_t ldH, int n_c, const void* G, int64_t
                     int kb_lo, int kb_hi, void* W, hipStream_t st) {
     if (kb_hi <= kb_lo) return;
     if (2 * C > 64) throw Error(2, "gram route: more than 32 channels");
-    ls_gram_kernel<<<bgrid(kb_hi - kb_lo), 256, 0, st>>>((const cplx*)Hc, ldH, n_c, (const cplx*)G, g_stride, ldD, (const cplx*)Mw, D, C, P, kb_lo,
+    ls_gram_kernel<<<bgrid(kb_hi - kb_lo), 1024, 0, st>>>((const cplx*)Hc, ldH, n_c, (const cplx*)G, g_stride, ldD, (const cplx*)Mw, D, C, P, kb_lo,
                                                         (cplx*)W, batch_ctx().stride);
     KERNEL_CHECK();
 }

@@ -1,17 +1,17 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, the bench line, rocprofv3 kernel traces.  Usage (through gpurun):
 #   bash tools/gpu_round.sh <tag> [tests|notests|testsonly] [pmc]      (testsonly: the whole gpu suite without -x, nothing else)
-# Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
+# Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.  PYTEST_K='expr' selects tests (-k).
 tag=${1:-r}; what=${2:-tests}; pmc=${3:-}
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 if [ "$what" = "tests" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q -rP -x > gpurun_out/${tag}_tests_full.log 2>&1
+  timeout 1500 python -m pytest tests -m gpu -q -rP -x ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/${tag}_tests_full.log 2>&1
   tail -5 gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_tests.log
   grep -h "norm_diff=\|rel = \|^case (\|rel L\|worst rel" gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_parity.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
 fi
 if [ "$what" = "testsonly" ]; then
-  timeout 2400 python -m pytest tests -m gpu -q -rP ${PYTEST_ARGS:-} > gpurun_out/${tag}_tests_full.log 2>&1
+  timeout 2400 python -m pytest tests -m gpu -q -rP ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/${tag}_tests_full.log 2>&1
   tail -15 gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_tests.log
   grep -h "norm_diff=\|rel = \|^case (\|rel L\|worst rel" gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_parity.log
   cat gpurun_out/${tag}_tests.log; exit 0
@@ -21,6 +21,7 @@ timeout 600 python bench.py --steps 128 --warmup 32 --no-cpu-baseline --no-sh-ro
 export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_single -o bench -- python3 $R/bench.py --steps 8 --warmup 0 --slots 1 --batch 1 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_single.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_batch -o bench -- python3 $R/bench.py --steps 32 --warmup 0 --slots 1 --batch 8 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_batch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${tag}_prof_slots4 -o bench -- python3 $R/bench.py --steps 128 --warmup 0 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_slots4.log 2>&1
 if [ "$pmc" = "pmc" ]; then
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_pmc_fetch -o pmc -- python3 $R/bench.py --steps 8 --warmup 0 --slots 1 --batch 1 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_pmc_fetch.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_pmc_write -o pmc -- python3 $R/bench.py --steps 8 --warmup 0 --slots 1 --batch 1 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_pmc_write.log 2>&1
@@ -29,6 +30,8 @@ cd $R
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_single 1 > gpurun_out/${tag}_kernels_single.md 2>&1
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch 8 > gpurun_out/${tag}_kernels_batch.md 2>&1
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch > gpurun_out/${tag}_kernels_batch_all.md 2>&1
+python tools/timeline.py gpurun_out/${tag}_prof_slots4 10 > gpurun_out/${tag}_timeline_slots4.md 2>&1
+python tools/timeline.py gpurun_out/${tag}_prof_batch 3 > gpurun_out/${tag}_timeline_slots1.md 2>&1
 # the raw databases are large: keep the summaries
-rm -rf gpurun_out/${tag}_prof_single gpurun_out/${tag}_prof_batch
-cat gpurun_out/${tag}_tests.log gpurun_out/${tag}_smoke.log 2>/dev/null; cut -c1-600 gpurun_out/${tag}_bench20.json; echo; cut -c1-300 gpurun_out/${tag}_bench128.json; echo; tail -3 gpurun_out/${tag}_bench20.err; head -25 gpurun_out/${tag}_kernels_batch.md
+rm -rf gpurun_out/${tag}_prof_single gpurun_out/${tag}_prof_batch gpurun_out/${tag}_prof_slots4
+cat gpurun_out/${tag}_tests.log gpurun_out/${tag}_smoke.log 2>/dev/null; cut -c1-600 gpurun_out/${tag}_bench20.json; echo; cut -c1-300 gpurun_out/${tag}_bench128.json; echo; tail -3 gpurun_out/${tag}_bench20.err; head -32 gpurun_out/${tag}_kernels_batch.md; head -12 gpurun_out/${tag}_timeline_slots4.md

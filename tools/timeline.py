@@ -1,8 +1,9 @@
 """Timeline analysis of a rocprofv3 --kernel-trace run (rocpd sqlite): how busy the GPU is and what overlaps.
 
-    python tools/timeline.py <dir> [skip_fraction]
+    python tools/timeline.py <dir> [n_sweeps]
 
-Prints, for the steady-state part of the run (the first `skip_fraction` of the trace is dropped, default 0.5):
+Prints, for the steady-state part of the run (the window spanned by the last `n_sweeps` sweep launches, default 12,
+i.e. the end of bench.py's timed region):
 wall time, time with >= 1 kernel running, time with the sweep running, time with the sweep running ALONE, and the
 per-kernel busy time (union of its dispatch intervals) as a share of the wall time."""
 import glob
@@ -29,16 +30,17 @@ def union(iv):
 
 def main():
     d = sys.argv[1]
-    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+    nsw = int(float(sys.argv[2])) if len(sys.argv) > 2 else 12
     db = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)[0]
     cur = sqlite3.connect(db).cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = list(cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-    t0, t1 = rows[0][1], max(r[2] for r in rows)
-    cut = t0 + skip * (t1 - t0)
-    rows = [r for r in rows if r[1] >= cut]
+    sw_all = [r for r in rows if "sweep_persist" in r[0]]
+    if len(sw_all) > nsw + 1:   # leave the very last sweep out (drain of the pipeline)
+        t0, t1 = sw_all[-nsw - 1][1], sw_all[-2][2]
+        rows = [r for r in rows if r[1] >= t0 and r[2] <= t1]
     t0, t1 = rows[0][1], max(r[2] for r in rows)
     wall = t1 - t0
     allv = [(s, e) for _, s, e in rows]
