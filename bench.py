@@ -228,12 +228,12 @@ def main():
     ap.add_argument("--slots", type=int, default=int(os.environ.get("EMAGLS_BENCH_SLOTS", str(SLOTS))),
                     help="resident batches per GPU (profiling runs use 1)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", str(BSZ))),
-                    help="designs per batch (<= 8; profiling runs use 1 for the single-design kernel times)")
+                    help="designs per batch (<= 16; profiling runs use 1 for the single-design kernel times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sh-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 4 / config 5 / one-shot secondary figures")
     args = ap.parse_args()
-    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or not 1 <= args.batch <= 8 or args.slots < 1:
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or not 1 <= args.batch <= 16 or args.slots < 1:
         raise SystemExit("bench.py: invalid arguments")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -85,11 +85,11 @@ struct HalfSweepArgs {
     long long* timing;       // optional [P][16] wall-clock stamps (EMAGLS_SWEEP_TIMING), else null
     int force_global;        // persistent sweep: keep the write-through (sc1) stores even on one XCD (EMAGLS_PERSIST_GLOBAL=1)
 };
+constexpr int SWEEP_MULTI_MAX = 16;   // designs per sweep launch: one per XCD up to 8, two per XCD (two workgroups per CU) up to 16
 struct HalfSweepMulti {
     int n;
-    HalfSweepArgs a[8];
+    HalfSweepArgs a[SWEEP_MULTI_MAX];
 };
 
-constexpr int SWEEP_MULTI_MAX = 8;
 
 }  // namespace emagls

@@ -1660,7 +1660,7 @@ void* emagls_plan_stream(emagls_plan* p) { return p ? (void*)p->stream : nullptr
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
     return guarded([&] {
         if (!plans || !batch || nplans < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
-        if (nplans > SWEEP_MULTI_MAX) throw Error(EMAGLS_ERR_UNSUPPORTED, "at most 8 designs per batch");
+        if (nplans > SWEEP_MULTI_MAX) throw Error(EMAGLS_ERR_UNSUPPORTED, "at most 16 designs per batch");
         std::unique_ptr<emagls_batch> b(new emagls_batch);
         for (int j = 0; j < nplans; ++j) {
             emagls_plan* p = plans[j];
@@ -1675,8 +1675,9 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         }
         HIP_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
         if (const char* ng = getenv("EMAGLS_NO_GRAPH")) b->use_graph = !(ng[0] == '1');
-        // one persistent sweep launch keeps designs x nWG workgroups resident, one per CU
-        const bool fits = nplans * persist_sweep_nwg((int)b->plans[0]->D) <= device_cu_count();
+        // one persistent sweep launch keeps designs x nWG workgroups resident: one per CU up to 8 designs (one design per XCD),
+        // two per CU beyond (77 KB of LDS and 5 waves per workgroup)
+        const bool fits = nplans * persist_sweep_nwg((int)b->plans[0]->D) <= device_cu_count() * (nplans > 8 ? 2 : 1);
         for (auto* p : b->plans) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
             if (!fits) p->sweep_persist = false;

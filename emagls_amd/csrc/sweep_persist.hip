@@ -96,31 +96,42 @@ template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and
     }
 }
 
-// Thread roles (PS_NT = 448 threads, 7 waves):
-//   tid < 4 DPW          p phase: (direction, channel quarter)
-//   tid < 256            M and partial phases: (pair, quarter)
-//   256 <= tid < 384     loader: requests the next bin's operands when a bin starts and moves them into the other LDS
-//                        buffer while everybody waits for the exchange (DPW = 96: these two waves also do p-phase work)
-//   tid >= 384           communication wave
-constexpr int PS_NT = 448, PS_LD0 = 256, PS_NL = 128, PS_COMM0 = 384;
+// Thread roles (PS_NT = 320 threads, 5 waves):
+//   tid < 2 DPW          p phase: (direction pair, channel quarter)
+//   tid < 256            M and partial phases: (pair, quarter); the same four waves also load: they request the next bin's
+//                        operands when a bin starts / when its partial phase starts (never while the communication wave
+//                        polls) and move them into the LDS buffer once the bin's partial phase is over
+//   tid >= 256           communication wave
+// Five waves and one LDS buffer (77 KB) let two workgroups share a CU: a launch sweeps up to 16 designs, two per XCD.
+constexpr int PS_NT = 320, PS_LD0 = 0, PS_NL = 256, PS_COMM0 = 256;
 constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 
-template <int PS_DPW>
-__global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
+// NBUF = 2: the G slab and M of the next bin are staged into the other LDS buffer (142 KB per workgroup: nothing else fits on the
+// CU).  NBUF = 1: one buffer, refilled behind a fourth barrier once every wave has finished the bin's partial phase (77 KB:
+// kernels of other batches with up to ~80 KB of LDS share the CU while this workgroup waits for its peers, which is most of
+// the time).
+template <int PS_DPW, int NBUF>
+__global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti m, int nWG) {   // (3 waves per SIMD: two workgroups per CU need <= 168 VGPRs)
     constexpr int XLD = PS_DPW + 4;     // row stride of the G slab (16 dwords mod 64: conflict-free quarter-wave reads)
-    constexpr int RG = PS_DPW == 96 ? 4 : 2, CH = RG * PS_DPW / PS_NL, NG = PS_CMAX / RG;  // G: NG row groups x CH chunks per loader thread
+    constexpr int PUNR = PS_DPW == 96 ? 3 : 4;
+    constexpr int RG = PS_DPW == 96 ? 8 : 4, CH = RG * PS_DPW / PS_NL, NG = PS_CMAX / RG;  // G: NG row groups x CH chunks per loader thread
+    static_assert(CH * PS_NL == RG * PS_DPW && NG * RG == PS_CMAX, "loader layout");
     constexpr int NLM = (PS_CMAX * PS_CMAX) / 256;                                         // M: loads per M-phase thread
-    static_assert(4 * PS_DPW <= PS_COMM0 && 2 * PS_DPW <= 2 * PS_NL && PS_DPW >= 64, "role layout");
+    static_assert(2 * PS_DPW <= PS_COMM0 && 2 * PS_DPW <= PS_NL && PS_DPW >= 64, "role layout");
     __shared__ __attribute__((aligned(16))) cplx vt[64];          // totals of the previous bin, [ear][32] zero padded
     __shared__ __attribute__((aligned(16))) cplx Wp[64];          // W(kb-1,:), same layout
     __shared__ __attribute__((aligned(16))) cplx ts[2][PS_DPW];   // t per ear and direction
     __shared__ int s_abort, s_local;
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    // double-buffered operands (buffer kb & 1 holds bin kb); rows beyond C stay zero
-    cplx* xs_all = reinterpret_cast<cplx*>(dyn);                          // [2][32][XLD]   G_kb slab
-    cplx* ms_all = xs_all + (size_t)2 * PS_CMAX * XLD;                    // [2][32][MLD]   M_{kb-1}
-    double* hs_all = reinterpret_cast<double*>(ms_all + (size_t)2 * PS_CMAX * PS_MLD);  // [2][2][DPW]  |H_kb|
-    const int design = blockIdx.x & 7, member = blockIdx.x >> 3;
+    // operands (NBUF = 2: buffer kb & 1 holds bin kb); rows beyond C stay zero
+    constexpr int BSEL = NBUF - 1;   // buffer index = kb & BSEL
+    cplx* xs_all = reinterpret_cast<cplx*>(dyn);                          // [NBUF][32][XLD]   G_kb slab
+    cplx* ms_all = xs_all + (size_t)NBUF * PS_CMAX * XLD;                 // [NBUF][32][MLD]   M_{kb-1}
+    double* hs_all = reinterpret_cast<double*>(ms_all + (size_t)NBUF * PS_CMAX * PS_MLD);  // [2][2][DPW]  |H_kb| (always two)
+    // up to 8 designs: block b serves design b & 7 (the dispatcher is observed to place block b on XCD b % 8: one design per
+    // XCD); 9 to 16 designs: designs j and j + 8 share XCD j, two workgroups per CU
+    const int two = m.n > 8 ? 1 : 0, rest = blockIdx.x >> 3;
+    const int design = (blockIdx.x & 7) + 8 * (two ? (rest & 1) : 0), member = two ? (rest >> 1) : rest;
     if (design >= m.n || member >= nWG) return;
     const HalfSweepArgs& a = m.a[design];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -137,7 +148,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     if (tid < 64) { vt[tid] = mk(0, 0); Wp[tid] = mk(0, 0); }
     if (tid == 0) { s_abort = 0; s_local = 0; }
     {
-        const size_t ncplx = (size_t)2 * PS_CMAX * XLD + (size_t)2 * PS_CMAX * PS_MLD + PS_DPW * 2;  // hs: 4 DPW doubles
+        const size_t ncplx = (size_t)NBUF * PS_CMAX * XLD + (size_t)NBUF * PS_CMAX * PS_MLD + PS_DPW * 2;  // hs: 4 DPW doubles
         for (size_t i = tid; i < ncplx; i += PS_NT) xs_all[i] = mk(0, 0);
     }
     // roles
@@ -151,7 +162,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     // G and |H| are fetched by the two loader waves: RG rows of the slab are CH chunks of 128 consecutive elements.
     const int lt = tid - PS_LD0;
     cplx gReg[NG * CH];
-    double hReg = 0.0, hReg2 = 0.0;   // |H|: 2 DPW values, loader thread lt takes lt and lt + 128
+    double hReg = 0.0;   // |H|: 2 DPW values, loader thread lt < 2 DPW takes value lt
     int goff[CH], xoff[CH], gcc[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -165,11 +176,11 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         const int eh = (x / PS_DPW) & 1, dh = x % PS_DPW;
         return (int)((int64_t)eh * na * a.ldH + (d0 + dh < a.D ? d0 + dh : a.D - 1));
     };
-    const int hoff = habs_off(lt), hoff2 = habs_off(lt + PS_NL);
+    const int hoff = habs_off(lt < 2 * PS_DPW ? lt : 0);
     // (two halves: the loader waves issue the first while the other waves are in the M phase and the second while they
     // are in the partial phase, so that their issue time -- 26 KB per CU through a 64 B/clk address path -- never holds
     // up a barrier of the chain)
-    auto fetch_g = [&](int kb, int half, cplx (&gL)[NG * CH], double& hL, double& hL2) __attribute__((always_inline)) {
+    auto fetch_g = [&](int kb, int half, cplx (&gL)[NG * CH], double& hL) __attribute__((always_inline)) {
         const int kbg = kb < P ? kb : P - 1;
         const cplx* X = a.G + (int64_t)kbg * a.g_stride;
         constexpr int H0 = (NG * CH) / 2;
@@ -186,11 +197,10 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
                 gL[i] = ldc(X + goff[j] + r * RG * a.ldD);
             }
             hL = a.Habs[(int64_t)(kbg - a.kabs0) * a.ldH + hoff];
-            hL2 = a.Habs[(int64_t)(kbg - a.kabs0) * a.ldH + hoff2];
         }
     };
-    auto stage_g = [&](int kb, const cplx (&gL)[NG * CH], double hL, double hL2) __attribute__((always_inline)) {
-        cplx* xs = xs_all + (size_t)(kb & 1) * PS_CMAX * XLD;
+    auto stage_g = [&](int kb, const cplx (&gL)[NG * CH], double hL) __attribute__((always_inline)) {
+        cplx* xs = xs_all + (size_t)(kb & BSEL) * PS_CMAX * XLD;
         double* hs = hs_all + (size_t)(kb & 1) * 2 * PS_DPW;
 #pragma unroll
         for (int i = 0; i < NG * CH; ++i) {
@@ -198,7 +208,6 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             if (RG * r + gcc[j] < C) xs[xoff[j] + r * RG * XLD] = gL[i];
         }
         if (lt < 2 * PS_DPW) hs[lt] = hL;
-        if (lt + PS_NL < 2 * PS_DPW) hs[lt + PS_NL] = hL2;
     };
     // M (C x C) is fetched by the threads of the M phase right after they used the previous one
     cplx mReg[NLM];
@@ -209,7 +218,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         for (int i = 0; i < NLM; ++i) mL[i] = ldc(M + tid + 256 * i);   // (Mw is padded by 1024 elements)
     };
     auto stage_m = [&](int kb, const cplx (&mL)[NLM]) __attribute__((always_inline)) {
-        cplx* ms = ms_all + (size_t)(kb & 1) * PS_CMAX * PS_MLD;
+        cplx* ms = ms_all + (size_t)(kb & BSEL) * PS_CMAX * PS_MLD;
 #pragma unroll
         for (int i = 0; i < NLM; ++i) {
             const int f = tid + 256 * i;
@@ -218,9 +227,9 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     };
     __syncthreads();  // LDS is zeroed
     if (loader) {
-        fetch_g(a.kfirst, 0, gReg, hReg, hReg2);
-        fetch_g(a.kfirst, 1, gReg, hReg, hReg2);
-        stage_g(a.kfirst, gReg, hReg, hReg2);
+        fetch_g(a.kfirst, 0, gReg, hReg);
+        fetch_g(a.kfirst, 1, gReg, hReg);
+        stage_g(a.kfirst, gReg, hReg);
     }
     if (tid < 256) {
         fetch_m(a.kfirst, mReg);
@@ -319,6 +328,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             if (s_abort || kb == P) break;
             __syncthreads();  // B2
             __syncthreads();  // B3
+            if (NBUF == 1) __syncthreads();  // B4
         }
         return;
     }
@@ -330,15 +340,15 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         const bool nyq = (kb == P - 1);
         const bool prev_ok = first ? true : (a.cond_ok[kb - 1] != 0.0);
         const bool cur_ok = last ? true : (a.cond_ok[kb] != 0.0);
-        const cplx* xs = xs_all + (size_t)(kb & 1) * PS_CMAX * XLD;
-        const cplx* ms = ms_all + (size_t)(kb & 1) * PS_CMAX * PS_MLD;
+        const cplx* xs = xs_all + (size_t)(kb & BSEL) * PS_CMAX * XLD;
+        const cplx* ms = ms_all + (size_t)(kb & BSEL) * PS_CMAX * PS_MLD;
         const double* hs = hs_all + (size_t)(kb & 1) * 2 * PS_DPW;
         __syncthreads();  // B1: vt is complete (and the loader has staged this bin's operands)
         if (s_abort) break;
         // The next bin's operands are requested NOW: a CU's vector memory pipeline returns in order, so loads that miss
         // to HBM (1.2-1.5 us) delay every later poll of the communication wave behind them.  Issued here they drain
         // during the three compute phases; the loader waves are idle in the M phase anyway.
-        if (loader) fetch_g(kb + 1, 0, gReg, hReg, hReg2);
+        if (loader) fetch_g(kb + 1, 0, gReg, hReg);
         // ---- W(kb-1,:) = v_total conj(M_{kb-1})  (identity for the first swept bin and after an ill-conditioned bin)
         if (pvalid) {
             cplx acc = mk(0, 0);
@@ -377,7 +387,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             }
         }
         __syncthreads();  // B3: ts is complete
-        if (loader) fetch_g(kb + 1, 1, gReg, hReg, hReg2);
+        if (loader) fetch_g(kb + 1, 1, gReg, hReg);
         // ---- this slab's partial v = t conj(G) (or t Y_reg_inv for an ill-conditioned bin), published as granules
         if (tid == 0) PSTAMP(4);
         // thread = (channel pair cp, 16 direction slices): every t and every G element it reads from LDS feeds two
@@ -389,7 +399,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
                 cplx v00 = mk(0, 0), v01 = mk(0, 0), v10 = mk(0, 0), v11 = mk(0, 0);  // v[ear][channel]
                 if (cur_ok) {
                     const cplx* x0 = xs + c0 * XLD, *x1 = xs + (c1 < C ? c1 : c0) * XLD;
-#pragma unroll
+#pragma unroll PUNR   // (bounded: the slab prefetch holds 48 registers; all six slices in flight spill)
                     for (int j = 0; j < PS_DPW / 16; ++j) {
                         const int dd = ep + 16 * j;
                         const cplx t0 = ts[0][dd], t1 = ts[1][dd], g0 = conj(x0[dd]), g1 = conj(x1[dd]);
@@ -418,8 +428,10 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             }
         }
         if (tid == 0) PSTAMP(5);
-        // the other buffer was last read in bin kb-1: fill it while everybody waits for the exchange
-        if (loader) stage_g(kb + 1, gReg, hReg, hReg2);
+        // NBUF = 2: the other buffer was last read in bin kb-1: fill it while everybody waits for the exchange.
+        // NBUF = 1: the one buffer is free once every wave has left the partial phase (B4); M was last read before B2
+        if (NBUF == 1) __syncthreads();  // B4
+        if (loader) stage_g(kb + 1, gReg, hReg);
         if (tid < 256) stage_m(kb + 1, mReg);
     }
 }
@@ -436,17 +448,27 @@ size_t persist_sweep_ll_bytes(int D, int C) {
 void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const HalfSweepArgs& a = m.a[0];
     const int nWG = persist_sweep_nwg(a.D);
-    if (!persist_sweep_supported(a.D, a.C) || m.n > 8) throw Error(2, "persistent sweep: shape not supported");
+    if (!persist_sweep_supported(a.D, a.C) || m.n > SWEEP_MULTI_MAX) throw Error(2, "persistent sweep: shape not supported");
+    const unsigned nblocks = 8u * (unsigned)nWG * (m.n > 8 ? 2u : 1u);
     const int dpw = persist_sweep_dpw(a.D);
-    const size_t dyn = sizeof(cplx) * ((size_t)2 * PS_CMAX * (dpw + 4) + (size_t)2 * PS_CMAX * PS_MLD + 2 * dpw);
+    static const int nbuf = [] { const char* e = getenv("EMAGLS_SWEEP_NBUF"); return (e && e[0] == '2') ? 2 : 1; }();
+    if (nbuf == 2 && m.n > 8) throw Error(2, "persistent sweep: more than 8 designs need the single-buffered form");
+    const size_t dyn = sizeof(cplx) * ((size_t)nbuf * PS_CMAX * (dpw + 4) + (size_t)nbuf * PS_CMAX * PS_MLD + 2 * dpw);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<96, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<96, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    if (dpw == 64) sweep_persist_kernel<64><<<dim3(8 * nWG), PS_NT, dyn, st>>>(m, nWG);
-    else sweep_persist_kernel<96><<<dim3(8 * nWG), PS_NT, dyn, st>>>(m, nWG);
+    if (nbuf == 1) {
+        if (dpw == 64) sweep_persist_kernel<64, 1><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
+        else sweep_persist_kernel<96, 1><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
+    } else {
+        if (dpw == 64) sweep_persist_kernel<64, 2><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
+        else sweep_persist_kernel<96, 2><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
+    }
     KERNEL_CHECK();
 }
 

@@ -287,6 +287,40 @@ def test_lane_batch_matches_single_designs(grids, thin):
         p.close()
 
 
+def test_sixteen_design_lane_batch(grids, thin):
+    """9 to 16 designs share one sweep launch with two designs per XCD (two workgroups per CU): a batch of 12 designs (different
+    HRIR sets and microphone grids) equals the single designs; replays are bitwise reproducible."""
+    from emagls_amd import Batch, Plan, _lib as L
+    rng = np.random.default_rng(21)
+    plans, singles = [], []
+    for j in range(12):
+        hL = thin["hL"] * (1.0 + 0.1 * j) + 1e-3 * rng.standard_normal(thin["hL"].shape)
+        hR = thin["hR"] * (1.0 - 0.02 * j)
+        maz = grids["mic_azi"] + 0.05 * j
+        p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, hL.shape[0], hL.shape[1], grids["mic_radius"], 32)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(maz, grids["mic_zen"])
+        p.set_hrirs(hL, hR)
+        p.execute()
+        singles.append(p.get_filters())
+        plans.append(p)
+    b = Batch(plans)
+    outs = []
+    for it in range(3):
+        b.execute()
+        outs.append(b.get_filters())
+    worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(outs[0], singles))
+    print(f"12-design lane batch vs single plans: worst rel = {worst:.3e}")
+    assert worst < 1e-12
+    for it in (1, 2):
+        for a, c in zip(outs[0], outs[it]):
+            assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    assert rel(singles[0][0], singles[5][0]) > 1e-3
+    b.close()
+    for p in plans:
+        p.close()
+
+
 def test_batch_of_ema_in_ch_designs(thin):
     """Equatorial-array designs in a lane batch (odd channel count, 9): equal to the one-shot entry point."""
     import emagls_amd as E
