@@ -21,6 +21,7 @@ struct Error : std::runtime_error {
 
 inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
     if (e != hipSuccess) {
+        (void)hipGetLastError();   // clear the sticky error: a later KERNEL_CHECK must not report this failure as its own
         char buf[512];
         snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
         throw Error(3, buf);

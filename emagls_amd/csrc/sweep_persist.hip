@@ -96,38 +96,35 @@ template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and
     }
 }
 
-// Thread roles (PS_NT = 320 threads, 5 waves):
-//   tid < 2 DPW          p phase: (direction pair, channel quarter)
-//   tid < 256            M and partial phases: (pair, quarter); the same four waves also load: they request the next bin's
+// Thread roles (PS_NT = 256 threads, 4 waves -- one per SIMD, so two workgroups always fit a CU side by side):
+//   tid < 2 DPW          p phase: (direction pair, channel quarter); the same waves load: they request the next bin's
 //                        operands when a bin starts / when its partial phase starts (never while the communication wave
-//                        polls) and move them into the LDS buffer once the bin's partial phase is over
-//   tid >= 256           communication wave
-// Five waves and one LDS buffer (77 KB) let two workgroups share a CU: a launch sweeps up to 16 designs, two per XCD.
-constexpr int PS_NT = 320, PS_LD0 = 0, PS_NL = 256, PS_COMM0 = 256;
+//                        polls) and move them into the LDS buffer once the bin's partial phase is over (barrier B4)
+//   tid < 256            M and partial phases: (pair, quarter); fetch and stage M
+//   tid >= 192 (wave 3)  communication wave: besides its share of the M and partial phases it runs the exchange (it issues
+//                        no operand loads of G, so its polls never queue behind an HBM miss in the wave's in-order memory queue)
+// One LDS buffer (77 KB) and four waves: a launch sweeps up to 16 designs, two per XCD, two workgroups per CU.
+constexpr int PS_NT = 256, PS_COMM0 = 192;
 constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 
-// NBUF = 2: the G slab and M of the next bin are staged into the other LDS buffer (142 KB per workgroup: nothing else fits on the
-// CU).  NBUF = 1: one buffer, refilled behind a fourth barrier once every wave has finished the bin's partial phase (77 KB:
-// kernels of other batches with up to ~80 KB of LDS share the CU while this workgroup waits for its peers, which is most of
-// the time).
-template <int PS_DPW, int NBUF>
-__global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti m, int nWG) {   // (3 waves per SIMD: two workgroups per CU need <= 168 VGPRs)
+template <int PS_DPW>
+__global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
     constexpr int XLD = PS_DPW + 4;     // row stride of the G slab (16 dwords mod 64: conflict-free quarter-wave reads)
     constexpr int PUNR = PS_DPW == 96 ? 3 : 4;
-    constexpr int RG = PS_DPW == 96 ? 8 : 4, CH = RG * PS_DPW / PS_NL, NG = PS_CMAX / RG;  // G: NG row groups x CH chunks per loader thread
+    constexpr int PS_NL = 2 * PS_DPW;   // loader threads = the p-phase threads
+    constexpr int RG = 8, CH = RG * PS_DPW / PS_NL, NG = PS_CMAX / RG;  // G: NG row groups x CH chunks per loader thread
     static_assert(CH * PS_NL == RG * PS_DPW && NG * RG == PS_CMAX, "loader layout");
-    constexpr int NLM = (PS_CMAX * PS_CMAX) / 256;                                         // M: loads per M-phase thread
-    static_assert(2 * PS_DPW <= PS_COMM0 && 2 * PS_DPW <= PS_NL && PS_DPW >= 64, "role layout");
+    constexpr int NLM = (PS_CMAX * PS_CMAX) / 256;                      // M: loads per M-phase thread
+    static_assert(2 * PS_DPW <= PS_COMM0 && PS_DPW >= 64, "role layout");
     __shared__ __attribute__((aligned(16))) cplx vt[64];          // totals of the previous bin, [ear][32] zero padded
     __shared__ __attribute__((aligned(16))) cplx Wp[64];          // W(kb-1,:), same layout
     __shared__ __attribute__((aligned(16))) cplx ts[2][PS_DPW];   // t per ear and direction
     __shared__ int s_abort, s_local;
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    // operands (NBUF = 2: buffer kb & 1 holds bin kb); rows beyond C stay zero
-    constexpr int BSEL = NBUF - 1;   // buffer index = kb & BSEL
-    cplx* xs_all = reinterpret_cast<cplx*>(dyn);                          // [NBUF][32][XLD]   G_kb slab
-    cplx* ms_all = xs_all + (size_t)NBUF * PS_CMAX * XLD;                 // [NBUF][32][MLD]   M_{kb-1}
-    double* hs_all = reinterpret_cast<double*>(ms_all + (size_t)NBUF * PS_CMAX * PS_MLD);  // [2][2][DPW]  |H_kb| (always two)
+    // operands of the current bin; rows beyond C stay zero
+    cplx* xs = reinterpret_cast<cplx*>(dyn);                            // [32][XLD]   G_kb slab
+    cplx* ms = xs + (size_t)PS_CMAX * XLD;                              // [32][MLD]   M_{kb-1}
+    double* hs_all = reinterpret_cast<double*>(ms + (size_t)PS_CMAX * PS_MLD);  // [2][2][DPW]  |H_kb| (two buffers: 3 KB)
     // up to 8 designs: block b serves design b & 7 (the dispatcher is observed to place block b on XCD b % 8: one design per
     // XCD); 9 to 16 designs: designs j and j + 8 share XCD j, two workgroups per CU
     const int two = m.n > 8 ? 1 : 0, rest = blockIdx.x >> 3;
@@ -136,7 +133,7 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
     const HalfSweepArgs& a = m.a[design];
     const int tid = threadIdx.x, lane = tid & 63;
     const bool comm = tid >= PS_COMM0;
-    const bool loader = tid >= PS_LD0 && tid < PS_LD0 + PS_NL;
+    const bool loader = tid < PS_NL;
     const int C = a.C, P = a.P, npairs = 2 * a.C;
     const int64_t d0 = (int64_t)member * PS_DPW;
     const int64_t na = P - a.kabs0;
@@ -148,21 +145,21 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
     if (tid < 64) { vt[tid] = mk(0, 0); Wp[tid] = mk(0, 0); }
     if (tid == 0) { s_abort = 0; s_local = 0; }
     {
-        const size_t ncplx = (size_t)NBUF * PS_CMAX * XLD + (size_t)NBUF * PS_CMAX * PS_MLD + PS_DPW * 2;  // hs: 4 DPW doubles
-        for (size_t i = tid; i < ncplx; i += PS_NT) xs_all[i] = mk(0, 0);
+        const size_t ncplx = (size_t)PS_CMAX * XLD + (size_t)PS_CMAX * PS_MLD + PS_DPW * 2;  // hs: 4 DPW doubles
+        for (size_t i = tid; i < ncplx; i += PS_NT) xs[i] = mk(0, 0);
     }
     // roles
     const int part = tid & 3;
     const int pair = tid >> 2;                        // M / partial phases: (pair, quarter)
-    const bool pvalid = pair < npairs;                // (npairs <= 64, so tid < 256)
+    const bool pvalid = pair < npairs;                // (npairs <= 64)
     const int e = pvalid ? pair / C : 0, c = pvalid ? pair % C : 0;
-    // ---- loaders: operands of bin kb (M_{kb-1}, the G_kb slab, |H_kb|) from memory into registers ...
+    // ---- loaders: operands of bin kb (the G_kb slab, |H_kb|; M_{kb-1} by all threads) from memory into registers ...
     // The loads are unconditional at clamped / padded addresses (a branch or a select around them makes the wave wait on
     // the spot); what lies beyond C or the bin range is finite or never stored, directions beyond D repeat D-1.
-    // G and |H| are fetched by the two loader waves: RG rows of the slab are CH chunks of 128 consecutive elements.
-    const int lt = tid - PS_LD0;
+    // RG rows of the slab are CH chunks of 2 DPW consecutive elements.
+    const int lt = loader ? tid : 0;
     cplx gReg[NG * CH];
-    double hReg = 0.0;   // |H|: 2 DPW values, loader thread lt < 2 DPW takes value lt
+    double hReg = 0.0;   // |H|: 2 DPW values, loader thread lt takes value lt
     int goff[CH], xoff[CH], gcc[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -172,14 +169,9 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
         xoff[j] = cc * XLD + dd;
         gcc[j] = cc;
     }
-    auto habs_off = [&](int x) {
-        const int eh = (x / PS_DPW) & 1, dh = x % PS_DPW;
-        return (int)((int64_t)eh * na * a.ldH + (d0 + dh < a.D ? d0 + dh : a.D - 1));
-    };
-    const int hoff = habs_off(lt < 2 * PS_DPW ? lt : 0);
-    // (two halves: the loader waves issue the first while the other waves are in the M phase and the second while they
-    // are in the partial phase, so that their issue time -- 26 KB per CU through a 64 B/clk address path -- never holds
-    // up a barrier of the chain)
+    const int hoff = (int)((int64_t)((lt / PS_DPW) & 1) * na * a.ldH + (d0 + lt % PS_DPW < a.D ? d0 + lt % PS_DPW : a.D - 1));
+    // (two halves: the first is issued while the waves are in the M phase and the second while they are in the partial
+    // phase, so that the issue time -- 26 KB per CU through a 64 B/clk address path -- never holds up a barrier of the chain)
     auto fetch_g = [&](int kb, int half, cplx (&gL)[NG * CH], double& hL) __attribute__((always_inline)) {
         const int kbg = kb < P ? kb : P - 1;
         const cplx* X = a.G + (int64_t)kbg * a.g_stride;
@@ -200,14 +192,13 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
         }
     };
     auto stage_g = [&](int kb, const cplx (&gL)[NG * CH], double hL) __attribute__((always_inline)) {
-        cplx* xs = xs_all + (size_t)(kb & BSEL) * PS_CMAX * XLD;
         double* hs = hs_all + (size_t)(kb & 1) * 2 * PS_DPW;
 #pragma unroll
         for (int i = 0; i < NG * CH; ++i) {
             const int r = i / CH, j = i % CH;
             if (RG * r + gcc[j] < C) xs[xoff[j] + r * RG * XLD] = gL[i];
         }
-        if (lt < 2 * PS_DPW) hs[lt] = hL;
+        hs[lt] = hL;
     };
     // M (C x C) is fetched by the threads of the M phase right after they used the previous one
     cplx mReg[NLM];
@@ -217,8 +208,7 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
 #pragma unroll
         for (int i = 0; i < NLM; ++i) mL[i] = ldc(M + tid + 256 * i);   // (Mw is padded by 1024 elements)
     };
-    auto stage_m = [&](int kb, const cplx (&mL)[NLM]) __attribute__((always_inline)) {
-        cplx* ms = ms_all + (size_t)(kb & BSEL) * PS_CMAX * PS_MLD;
+    auto stage_m = [&](const cplx (&mL)[NLM]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NLM; ++i) {
             const int f = tid + 256 * i;
@@ -231,10 +221,8 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
         fetch_g(a.kfirst, 1, gReg, hReg);
         stage_g(a.kfirst, gReg, hReg);
     }
-    if (tid < 256) {
-        fetch_m(a.kfirst, mReg);
-        stage_m(a.kfirst, mReg);
-    }
+    fetch_m(a.kfirst, mReg);
+    stage_m(mReg);
     if (comm) {  // do all workgroups of this design share an XCD?
         const unsigned xcc = read_xcc_id();
         const unsigned tag0 = 0x58434300u;  // 'XCC'
@@ -255,13 +243,16 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
     __syncthreads();
     const bool local = s_local != 0;
 
-#define PSTAMP(i) do { if (a.timing && member == 1 && lane == 0 && kb < P) a.timing[(int64_t)kb * 16 + (i)] = (long long)wall_clock64(); } while (0)
-    // The communication wave and the compute waves run separate loops that meet at the same three barriers per bin
-    // (B1: vt complete, B2: Wp complete, B3: ts complete); every branch around a barrier is workgroup-uniform.
-    if (comm) {
-        for (int kb = a.kfirst; kb <= P; ++kb) {
-            const bool first = (kb == a.kfirst);
-            PSTAMP(0);
+#define PSTAMP(i) do { if (a.timing && member == 1 && kb < P) a.timing[(int64_t)kb * 16 + (i)] = (long long)wall_clock64(); } while (0)
+    // Four barriers per bin (B1: vt complete, B2: Wp complete, B3: ts complete, B4: the slab buffer is free); every branch
+    // around a barrier is workgroup-uniform.
+    for (int kb = a.kfirst; kb <= P; ++kb) {
+        const bool first = (kb == a.kfirst);
+        const bool last = (kb == P);  // only W(P-1,:) is left to form
+        const bool nyq = (kb == P - 1);
+        // ================= communication wave: the totals of bin kb-1 into vt =================
+        if (comm) {
+            if (lane == 0) PSTAMP(0);
             if (first) {
                 if (lane < npairs) vt[(lane / C) * PS_CMAX + lane % C] = a.W[((int64_t)(lane / C) * P + (kb - 1)) * C + lane % C];
             } else {
@@ -272,7 +263,7 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
                 // hop 1 (reduce-scatter): the pairs this workgroup owns, two per pass
                 for (int q = member; q < npairs && alive; q += 2 * nWG) {
                     const int q2 = q + nWG;
-                    const bool two = q2 < npairs;
+                    const bool twoq = q2 < npairs;
                     const u64* src = part_ll + (((size_t)slot * npairs + q) * nWG + lane) * 4;   // lane = producing workgroup
                     const u64* src2 = src + (size_t)nWG * nWG * 4;
                     u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
@@ -280,7 +271,7 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
                         if (lane >= nWG) return true;
                         w0 = ll_load(src); w1 = ll_load(src + 2); w2 = ll_load(src + 1); w3 = ll_load(src + 3);
                         bool ok = true;
-                        if (two) {
+                        if (twoq) {
                             u0 = ll_load(src2); u1 = ll_load(src2 + 2); u2 = ll_load(src2 + 1); u3 = ll_load(src2 + 3);
                             ok = ll_ok(u0, tag) && ll_ok(u1, tag) && ll_ok(u2, tag) && ll_ok(u3, tag);
                         }
@@ -289,7 +280,7 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
                     const double re = wave_sum(lane < nWG ? ll_value(w0, w1) : 0.0);
                     const double im = wave_sum(lane < nWG ? ll_value(w2, w3) : 0.0);
                     double re2 = 0.0, im2 = 0.0;
-                    if (two) {
+                    if (twoq) {
                         re2 = wave_sum(lane < nWG ? ll_value(u0, u1) : 0.0);
                         im2 = wave_sum(lane < nWG ? ll_value(u2, u3) : 0.0);
                     }
@@ -297,13 +288,13 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
                         u64* dst = tot_ll + (size_t)slot * 2 * nd2 + 2 * q;
                         ll_store(dst, dst + nd2, re, tag, local);
                         ll_store(dst + 1, dst + nd2 + 1, im, tag, local);
-                        if (two) {
+                        if (twoq) {
                             ll_store(dst + 2 * nWG, dst + 2 * nWG + nd2, re2, tag, local);
                             ll_store(dst + 2 * nWG + 1, dst + 2 * nWG + nd2 + 1, im2, tag, local);
                         }
                     }
                 }
-                PSTAMP(1);
+                if (lane == 0) PSTAMP(1);
                 if (a.timing && member == 1 && lane == 0) a.timing[(int64_t)kb * 16 + 9] = spins1;
                 // hop 2 (all-gather): every total; lane l takes the doubles l and l + 64
                 if (alive) {
@@ -323,31 +314,16 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
                 }
                 if (!alive && lane == 0) s_abort = 1;
             }
-            PSTAMP(2);
-            __syncthreads();  // B1
-            if (s_abort || kb == P) break;
-            __syncthreads();  // B2
-            __syncthreads();  // B3
-            if (NBUF == 1) __syncthreads();  // B4
+            if (lane == 0) PSTAMP(2);
         }
-        return;
-    }
-
-    // ---- compute and loader waves
-    for (int kb = a.kfirst; kb <= P; ++kb) {
-        const bool first = (kb == a.kfirst);
-        const bool last = (kb == P);  // only W(P-1,:) is left to form
-        const bool nyq = (kb == P - 1);
         const bool prev_ok = first ? true : (a.cond_ok[kb - 1] != 0.0);
         const bool cur_ok = last ? true : (a.cond_ok[kb] != 0.0);
-        const cplx* xs = xs_all + (size_t)(kb & BSEL) * PS_CMAX * XLD;
-        const cplx* ms = ms_all + (size_t)(kb & BSEL) * PS_CMAX * PS_MLD;
         const double* hs = hs_all + (size_t)(kb & 1) * 2 * PS_DPW;
-        __syncthreads();  // B1: vt is complete (and the loader has staged this bin's operands)
+        __syncthreads();  // B1: vt is complete (and this bin's operands are staged)
         if (s_abort) break;
-        // The next bin's operands are requested NOW: a CU's vector memory pipeline returns in order, so loads that miss
-        // to HBM (1.2-1.5 us) delay every later poll of the communication wave behind them.  Issued here they drain
-        // during the three compute phases; the loader waves are idle in the M phase anyway.
+        // The next bin's G is requested NOW: a CU's vector memory pipeline returns in order, so loads that miss to HBM
+        // (1.2-1.5 us) delay every later poll of the communication wave behind them.  Issued here they drain during the
+        // three compute phases.
         if (loader) fetch_g(kb + 1, 0, gReg, hReg);
         // ---- W(kb-1,:) = v_total conj(M_{kb-1})  (identity for the first swept bin and after an ill-conditioned bin)
         if (pvalid) {
@@ -366,7 +342,7 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
             }
         }
         if (last) break;
-        if (tid < 256) fetch_m(kb + 1, mReg);
+        fetch_m(kb + 1, mReg);
         __syncthreads();  // B2: Wp is complete
         // ---- p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
         // thread = (direction pair (dA, dA + DPW/2), channel quarter): a W value read from LDS feeds two directions
@@ -395,11 +371,11 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
         {
             const int cp = tid >> 4, ep = tid & 15;
             const int c0 = 2 * cp, c1 = c0 + 1;
-            if (tid < 256 && c0 < C) {
+            if (c0 < C) {
                 cplx v00 = mk(0, 0), v01 = mk(0, 0), v10 = mk(0, 0), v11 = mk(0, 0);  // v[ear][channel]
                 if (cur_ok) {
                     const cplx* x0 = xs + c0 * XLD, *x1 = xs + (c1 < C ? c1 : c0) * XLD;
-#pragma unroll PUNR   // (bounded: the slab prefetch holds 48 registers; all six slices in flight spill)
+#pragma unroll PUNR
                     for (int j = 0; j < PS_DPW / 16; ++j) {
                         const int dd = ep + 16 * j;
                         const cplx t0 = ts[0][dd], t1 = ts[1][dd], g0 = conj(x0[dd]), g1 = conj(x1[dd]);
@@ -428,12 +404,13 @@ __global__ void __launch_bounds__(PS_NT, 3) sweep_persist_kernel(HalfSweepMulti 
             }
         }
         if (tid == 0) PSTAMP(5);
-        // NBUF = 2: the other buffer was last read in bin kb-1: fill it while everybody waits for the exchange.
-        // NBUF = 1: the one buffer is free once every wave has left the partial phase (B4); M was last read before B2
-        if (NBUF == 1) __syncthreads();  // B4
+        // the slab buffer is free once every wave has left the partial phase (M was last read before B2): refill both while
+        // everybody waits for the exchange
+        __syncthreads();  // B4
         if (loader) stage_g(kb + 1, gReg, hReg);
-        if (tid < 256) stage_m(kb + 1, mReg);
+        stage_m(mReg);
     }
+#undef PSTAMP
 }
 
 }  // namespace
@@ -451,24 +428,15 @@ void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     if (!persist_sweep_supported(a.D, a.C) || m.n > SWEEP_MULTI_MAX) throw Error(2, "persistent sweep: shape not supported");
     const unsigned nblocks = 8u * (unsigned)nWG * (m.n > 8 ? 2u : 1u);
     const int dpw = persist_sweep_dpw(a.D);
-    static const int nbuf = [] { const char* e = getenv("EMAGLS_SWEEP_NBUF"); return (e && e[0] == '2') ? 2 : 1; }();
-    if (nbuf == 2 && m.n > 8) throw Error(2, "persistent sweep: more than 8 designs need the single-buffered form");
-    const size_t dyn = sizeof(cplx) * ((size_t)nbuf * PS_CMAX * (dpw + 4) + (size_t)nbuf * PS_CMAX * PS_MLD + 2 * dpw);
+    const size_t dyn = sizeof(cplx) * ((size_t)PS_CMAX * (dpw + 4) + (size_t)PS_CMAX * PS_MLD + 2 * dpw);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<96, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<96, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    if (nbuf == 1) {
-        if (dpw == 64) sweep_persist_kernel<64, 1><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
-        else sweep_persist_kernel<96, 1><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
-    } else {
-        if (dpw == 64) sweep_persist_kernel<64, 2><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
-        else sweep_persist_kernel<96, 2><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
-    }
+    if (dpw == 64) sweep_persist_kernel<64><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
+    else sweep_persist_kernel<96><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
     KERNEL_CHECK();
 }
 
