@@ -307,12 +307,14 @@ __global__ void __launch_bounds__(64) rinv_diag_kernel(const T* __restrict__ R, 
 //   acc(r,c) = Yc(r, j0+c) - sum_{i < j0} Q(r,i) R(i, j0+c)     R streamed through LDS in 128-row chunks, the next
 //                                                                 chunk's loads in flight while the current one is used
 //   Q(r, j0+c) = sum_k acc(r,k) Rinv_J(k,c)                      no sequential solve
-template <typename T, int CH>
-__global__ void __launch_bounds__(256) qform_kernel(const T* __restrict__ Yc, const T* __restrict__ R,
+// TR rows per workgroup (32 TR threads).  TR = 8 for the D rows of Q; TR = 4 with CH = 32 keeps the LDS at 62 KB for the few
+// least-squares rows of an array design, so that the kernel fits on a CU next to a resident sweep workgroup.
+template <typename T, int CH, int TR>
+__global__ void __launch_bounds__(32 * TR) qform_kernel(const T* __restrict__ Yc, const T* __restrict__ R,
                                                     const T* __restrict__ Rinv, int S, int64_t D, int64_t ld,
                                                     T* __restrict__ Q, size_t bstride) {
     Yc = boff(Yc, bstride); R = boff(R, bstride); Rinv = boff(Rinv, bstride); Q = boff(Q, bstride);
-    constexpr int TR = 8, NV = CH / TR;  // chunk elements per thread
+    constexpr int NV = CH / TR;  // chunk elements per thread
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     T* qs = reinterpret_cast<T*>(dyn);        // [TR][ldq]
     const int ldq = S + 1;
@@ -337,12 +339,12 @@ __global__ void __launch_bounds__(256) qform_kernel(const T* __restrict__ Yc, co
             }
         };
         // Rinv_J for this block (independent of everything else: goes out first)
-        T rv[4];
+        T rv[32 / TR];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rv[k] = Rinv[((int64_t)(j0 / 32) * NB + r + 8 * k) * NB + c];
+        for (int k = 0; k < 32 / TR; ++k) rv[k] = Rinv[((int64_t)(j0 / 32) * NB + r + TR * k) * NB + c];
         if (nch > 0) load_chunk(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ri[(r + 8 * k) * 33 + c] = rv[k];
+        for (int k = 0; k < 32 / TR; ++k) ri[(r + TR * k) * 33 + c] = rv[k];
         for (int t = 0; t < nch; ++t) {
             __syncthreads();  // previous chunk fully consumed
 #pragma unroll
@@ -517,20 +519,22 @@ void launch_zsolve_flagged(void* Z, int ldS, const void* R, const void* Rinv, co
 
 template <typename T> static void qform_impl(const void* Yc, const void* R, void* Rinv, int S, int64_t D, int64_t ld, void* Q,
                                              hipStream_t st) {
-    const unsigned grid = (unsigned)ceil_div(D, 8);
-    auto lds = [&](int ch) { return sizeof(T) * ((size_t)8 * (S + 1) + (size_t)ch * 33 + 32 * 33 + 8 * 33); };
+    auto lds = [&](int ch, int tr) { return sizeof(T) * ((size_t)tr * (S + 1) + (size_t)ch * 33 + 32 * 33 + tr * 33); };
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
     rinv_diag_kernel<T><<<bgrid((unsigned)ceil_div(S, NB)), 64, 0, st>>>((const T*)R, S, (T*)Rinv, batch_ctx().stride);
     KERNEL_CHECK();
-    if (lds(128) <= 150 * 1024)
-        qform_kernel<T, 128><<<bgrid(grid), 256, lds(128), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q, batch_ctx().stride);
-    else if (lds(32) <= 150 * 1024)
-        qform_kernel<T, 32><<<bgrid(grid), 256, lds(32), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q, batch_ctx().stride);
+    if (D <= 1024 && lds(32, 4) <= 80 * 1024)   // a few rows (the least-squares rows of an array design): small footprint, more workgroups
+        qform_kernel<T, 32, 4><<<bgrid((unsigned)ceil_div(D, 4)), 128, lds(32, 4), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q, batch_ctx().stride);
+    else if (lds(128, 8) <= 150 * 1024)
+        qform_kernel<T, 128, 8><<<bgrid((unsigned)ceil_div(D, 8)), 256, lds(128, 8), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q, batch_ctx().stride);
+    else if (lds(32, 8) <= 150 * 1024)
+        qform_kernel<T, 32, 8><<<bgrid((unsigned)ceil_div(D, 8)), 256, lds(32, 8), st>>>((const T*)Yc, (const T*)R, (const T*)Rinv, S, D, ld, (T*)Q, batch_ctx().stride);
     else
         throw Error(2, "qform: too many SH channels for the LDS-resident rows");
     KERNEL_CHECK();

@@ -131,6 +131,9 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     const int design = (blockIdx.x & 7) + 8 * (two ? (rest & 1) : 0), member = two ? (rest >> 1) : rest;
     if (design >= m.n || member >= nWG) return;
     const HalfSweepArgs& a = m.a[design];
+    // The chain is latency bound and its waves sleep most of the time; kernels of other batches share the CU.  Highest issue
+    // priority for the chain's waves: when they have work they get the next slot, at no cost to the others while they wait.
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63;
     const bool comm = tid >= PS_COMM0;
     const bool loader = tid < PS_NL;
