@@ -23,7 +23,7 @@ def shard_jobs(costs, world_size):
     return [sorted(s) for s in shards]
 
 
-def lane_groups(shape_keys, max_batch=16):
+def lane_groups(shape_keys, max_batch=8):
     """Group a rank's jobs into lane batches: a `Batch` runs in lane mode (one launch of every kernel for all its designs,
     one XCD per design in the sweep) only when its plans have identical shapes.  `shape_keys[i]` is any hashable that
     determines the shape of job i -- for a radius sweep `simulation_order(order, fs, radius)` -- and the result is a list of
@@ -36,7 +36,7 @@ def lane_groups(shape_keys, max_batch=16):
     groups = []
     for k in sorted(classes, key=lambda k: (-len(classes[k]), str(k))):
         idx = classes[k]
-        # equal-sized batches inside a class (e.g. 9 jobs -> 5 + 4, not 16 + 1: the sweep launch costs about the same for 1..16 designs)
+        # equal-sized batches inside a class (e.g. 9 jobs -> 5 + 4, not 8 + 1: the sweep launch costs the same for 1..8 designs)
         nb = -(-len(idx) // max_batch)
         size = -(-len(idx) // nb)
         groups += [idx[i:i + size] for i in range(0, len(idx), size)]

@@ -1660,7 +1660,15 @@ void* emagls_plan_stream(emagls_plan* p) { return p ? (void*)p->stream : nullptr
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
     return guarded([&] {
         if (!plans || !batch || nplans < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
-        if (nplans > SWEEP_MULTI_MAX) throw Error(EMAGLS_ERR_UNSUPPORTED, "at most 16 designs per batch");
+        // Up to 8 designs per batch by default.  9 to 16 share one sweep launch with two workgroups per CU, which covers EVERY
+        // CU: safe and fastest when nothing else runs on the device, but another stream's kernel that needs a whole CU
+        // (e.g. factor_qr: 1024 threads x 128 registers) makes the dispatcher hold back the sweep's remaining workgroups
+        // while the resident ones wait for them -- observed as a 0.4 s stall until the sweep's own time-out falls back to the
+        // launch-per-bin form.  Hence opt-in: EMAGLS_BATCH_MAX=16.
+        static const int batch_max = [] { const char* e = getenv("EMAGLS_BATCH_MAX"); return e ? std::max(1, std::min(SWEEP_MULTI_MAX, atoi(e))) : 8; }();
+        if (nplans > batch_max)
+            throw Error(EMAGLS_ERR_UNSUPPORTED, batch_max >= SWEEP_MULTI_MAX ? "at most 16 designs per batch"
+                                                                             : "at most 8 designs per batch (EMAGLS_BATCH_MAX=16 allows 16 on an otherwise idle device)");
         std::unique_ptr<emagls_batch> b(new emagls_batch);
         for (int j = 0; j < nplans; ++j) {
             emagls_plan* p = plans[j];
@@ -1677,7 +1685,10 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         if (const char* ng = getenv("EMAGLS_NO_GRAPH")) b->use_graph = !(ng[0] == '1');
         // one persistent sweep launch keeps designs x nWG workgroups resident: one per CU up to 8 designs (one design per XCD),
         // two per CU beyond (77 KB of LDS and 5 waves per workgroup)
-        const bool fits = nplans * persist_sweep_nwg((int)b->plans[0]->D) <= device_cu_count() * (nplans > 8 ? 2 : 1);
+        // (up to 8 designs: 16 CUs stay free of sweep workgroups, so that kernels of other batches which need a whole CU keep
+        // making progress and the dispatcher never has a reason to hold the sweep's own workgroups back)
+        const int nwg_b = persist_sweep_nwg((int)b->plans[0]->D);
+        const bool fits = nplans > 8 ? nplans * nwg_b <= 2 * device_cu_count() : nplans * nwg_b <= device_cu_count() - 16;
         for (auto* p : b->plans) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
             if (!fits) p->sweep_persist = false;

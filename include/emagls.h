@@ -213,8 +213,9 @@ void* emagls_plan_stream(emagls_plan* plan);
  * Plans of identical shape (same simulation order: same array radius class) are executed in lane mode: their buffers
  * are moved into one arena at a constant stride and every launch of the pipeline covers all designs (grid.z = design);
  * the sequential sweep is one resident launch in which each design's workgroups occupy one XCD.  Other batches run the
- * per-design stages on the plans' own streams and share only the sweep.  At most 16 plans (up to 8: one XCD per design in the
- * sweep; 9 to 16: two designs per XCD, two sweep workgroups per CU); the plans stay owned by the
+ * per-design stages on the plans' own streams and share only the sweep.  At most 8 plans (one XCD per design in the sweep);
+ * with EMAGLS_BATCH_MAX=16 in the environment up to 16 (two designs per XCD, two sweep workgroups per CU: for an otherwise
+ * idle device only, see emagls_batch_create in capi.hip); the plans stay owned by the
  * caller and must outlive the batch.  Results: emagls_batch_get_filters, or emagls_plan_get_filters on each plan. */
 typedef struct emagls_batch emagls_batch;
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch);

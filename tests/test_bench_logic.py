@@ -78,6 +78,6 @@ def test_lane_groups_for_a_radius_sweep():
         groups = lane_groups([so[j] for j in s])
         assert sorted(i for g in groups for i in g) == list(range(len(s)))
         for g in groups:
-            assert 1 <= len(g) <= 16 and len({so[s[i]] for i in g}) == 1
-    assert [len(g) for g in lane_groups(["a"] * 9 + ["b"] * 3, max_batch=8)] == [5, 4, 3]
-    assert [len(g) for g in lane_groups(["a"] * 17 + ["b"] * 3)] == [9, 8, 3]
+            assert 1 <= len(g) <= 8 and len({so[s[i]] for i in g}) == 1
+    assert [len(g) for g in lane_groups(["a"] * 9 + ["b"] * 3)] == [5, 4, 3]
+    assert [len(g) for g in lane_groups(["a"] * 17 + ["b"] * 3, max_batch=16)] == [9, 8, 3]

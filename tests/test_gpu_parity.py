@@ -2,6 +2,8 @@
 signatures) against the CPU oracle on the same seeded inputs.  Tolerance: 1e-6 relative complex
 error (BASELINE.json north_star), reported together with the reference's own assertAllClose
 metrics (verifyEMagLs.m:370-395)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -287,10 +289,12 @@ def test_lane_batch_matches_single_designs(grids, thin):
         p.close()
 
 
-def test_sixteen_design_lane_batch(grids, thin):
-    """9 to 16 designs share one sweep launch with two designs per XCD (two workgroups per CU): a batch of 12 designs (different
-    HRIR sets and microphone grids) equals the single designs; replays are bitwise reproducible."""
+def test_sixteen_design_lane_batch(grids, thin, monkeypatch):
+    """9 to 16 designs (opt-in, EMAGLS_BATCH_MAX=16: for an otherwise idle device) share one sweep launch with two designs per
+    XCD (two workgroups per CU): a batch of 12 designs (different HRIR sets and microphone grids) equals the single designs and
+    sweeps with the persistent kernel; replays are bitwise reproducible.  Without the opt-in a batch holds at most 8."""
     from emagls_amd import Batch, Plan, _lib as L
+    from emagls_amd._lib import EmaglsError
     rng = np.random.default_rng(21)
     plans, singles = [], []
     for j in range(12):
@@ -304,11 +308,19 @@ def test_sixteen_design_lane_batch(grids, thin):
         p.execute()
         singles.append(p.get_filters())
         plans.append(p)
+    # (the limit is read once per process: the opt-in must be in the environment before the first batch is created)
+    if os.environ.get("EMAGLS_BATCH_MAX") != "16":
+        with pytest.raises(EmaglsError, match="at most 8 designs"):
+            Batch(plans)
+        for p in plans:
+            p.close()
+        pytest.skip("EMAGLS_BATCH_MAX=16 not set for this process")
     b = Batch(plans)
     outs = []
     for it in range(3):
         b.execute()
         outs.append(b.get_filters())
+    assert plans[0].info().num_sweep_launches == 1     # one persistent launch, not the launch-per-bin fallback
     worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(outs[0], singles))
     print(f"12-design lane batch vs single plans: worst rel = {worst:.3e}")
     assert worst < 1e-12
