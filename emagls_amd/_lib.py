@@ -10,7 +10,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libemagls.so")
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NUMERIC = 0, 1, 2, 3, 4
 BASIS = {"real": 0, "complex": 1}
-KIND_LS, KIND_MAGLS, KIND_EMAGLS, KIND_EMAGLS2, KIND_FROM_ATF, KIND_EMA_CH = range(6)
+KIND_LS, KIND_MAGLS, KIND_EMAGLS, KIND_EMAGLS2, KIND_FROM_ATF, KIND_EMA_CH, KIND_MAGLS_2D = range(7)
+RADIAL = {"tikhonov": 0, "softlimit": 1, "full": 2, "none": 3}
 
 c_dp = C.POINTER(C.c_double)
 c_i64 = C.c_int64
@@ -69,6 +70,17 @@ SYMBOLS = {
     "emagls_binaural_decode": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_void_p]),
     "emagls_binaural_decode_complex": (C.c_int, [C.c_void_p, C.c_int, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int, c_i64, C.c_int,
                                                  C.c_void_p, C.c_void_p]),
+    "emagls_get_magls_filters_2d": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_int, C.c_double, c_i64, C.c_int,
+                                              C.c_void_p, C.c_void_p]),
+    "emagls_get_radial_filter": (C.c_int, [C.c_int, C.c_double, C.c_double, c_i64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "emagls_apply_radial_filter_rows": (c_i64, [c_i64, c_i64, C.c_int]),
+    "emagls_apply_radial_filter": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_double, C.c_double, c_i64, C.c_int, C.c_int, C.c_double,
+                                             C.c_double, C.c_void_p]),
+    "emagls_sh_encode": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "emagls_eq_filter_nfft": (c_i64, [c_i64]),
+    "emagls_get_magls_spherical_head_filter": (C.c_int, [C.c_double, C.c_int, C.c_double, c_i64, C.c_void_p, C.c_void_p]),
+    "emagls_get_magls_array_diffuse_filter": (C.c_int, [C.c_double, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_double, c_i64, C.c_int,
+                                                        C.c_void_p, C.c_void_p]),
     "emagls_plan_create": (C.c_int, [C.POINTER(DesignDesc), C.POINTER(C.c_void_p)]),
     "emagls_plan_destroy": (C.c_int, [C.c_void_p]),
     "emagls_plan_set_hrir_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

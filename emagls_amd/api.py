@@ -9,6 +9,12 @@ hL/hR are [numSamples x numDirections]; filters come back [len x numChannels].
     getEMagLsFiltersEMAinCH lib/getEMagLsFiltersEMAinCH.m:1-2
     getEMagLsFiltersFromAtf lib/getEMagLsFiltersFromAtf.m:1
     binauralDecode          dependencies/binauralDecode.m:1-2
+    getMagLsFilters2D       lib/getMagLsFilters2D.m:1
+    getRadialFilter         dependencies/getRadialFilter.m:1   (params struct -> dict or keywords)
+    applyRadialFilter       dependencies/applyRadialFilter.m:1
+    encodeSH                verifyEMagLs.m:235-236             (smaRecording * pinv(getSH(order, micGrid).'))
+    getMagLsSphericalHeadFilter  lib/getMagLsSphericalHeadFilter.m:1
+    getMagLsArrayDiffuseFilter   lib/getMagLsArrayDiffuseFilter.m:1
     getSH / sphModalCoeffs  the un-vendored third-party functions the above call
 
 A custom `shFunction` (a callable with getSH's signature: shFunction(N, [azi zen], shDefinition) -> [dirs x (N+1)^2]) cannot
@@ -234,3 +240,119 @@ def binauralDecode(sig, inFs, decodingFilterLeft, decodingFilterRight, decodingF
     if im[0] != 0.0 or im[1] != 0.0:
         warnings.warn("discarding imaginary part with sum of [%.2g, %.2g] in rendering result." % (im[0], im[1]))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# render-side neighbours
+# --------------------------------------------------------------------------------------------
+def getMagLsFilters2D(hLHor, hRHor, horHrirGridAziRad, order, fs, len, chDefinition="real"):
+    """lib/getMagLsFilters2D.m:1: MagLS filters in circular harmonics for a horizontal HRIR set; [len x (2*order+1)] per ear,
+    channels [C_0, C_-1, C_1, ..., C_-N, C_N]."""
+    b, cplx = _basis(chDefinition)
+    hL, hR, pL, pR = _hrirs(hLHor, hRHor)
+    n, D = hL.shape
+    azi, pa = _vec(horHrirGridAziRad, D, "horHrirGridAziRad")
+    wL, pwL = _out(int(len), 2 * int(order) + 1, cplx)
+    wR, pwR = _out(int(len), 2 * int(order) + 1, cplx)
+    L.check(L.load().emagls_get_magls_filters_2d(pL, pR, n, D, pa, int(order), float(fs), int(len), b, pwL, pwR))
+    return wL, wR
+
+
+_RADIAL_DEFAULTS = {"radialFilter": "tikhonov", "waveModel": "planeWave", "oversamplingFactor": 2, "irLen": 256, "dirCoeff": 0,
+                    "regulConst": 1e-2}   # dependencies/getRadialFilter.m:27-41,58-60
+
+
+def _radial_params(params, kw):
+    p = dict(_RADIAL_DEFAULTS)
+    p.update(params or {})
+    p.update(kw)
+    for k in ("order", "fs", "smaRadius", "arrayType"):
+        if k not in p:
+            raise KeyError("params.%s is required" % k)       # MATLAB: reference to non-existent field
+    kind = str(p["radialFilter"]).lower()
+    if kind != "none" and str(p["waveModel"]).lower() == "pointsource":
+        raise NotImplementedError('WaveModel parameter "%s" not yet implemented.' % p["waveModel"])    # :50-52
+    if kind not in L.RADIAL:
+        raise ValueError('Unkown radialFilter parameter "%s".' % p["radialFilter"])                   # :76
+    if kind != "none" and (p["arrayType"] != "rigid" or p["dirCoeff"] != 0):
+        raise NotImplementedError("only the rigid-sphere model is built in (the harness's arrayType, verifyEMagLs.m:245)")
+    if kind == "softlimit" and "noiseGainDb" not in p:
+        raise KeyError("params.noiseGainDb is required for the softlimit filter")
+    return p, L.RADIAL[kind]
+
+
+def getRadialFilter(params=None, **kw):
+    """dependencies/getRadialFilter.m:1: radFilts [nfft/2+1 x order+1] complex, nfft = oversamplingFactor * irLen.  `params`
+    is the reference's struct as a dict (order, fs, smaRadius, arrayType, irLen, oversamplingFactor, radialFilter, regulConst,
+    noiseGainDb); keywords override it."""
+    p, kind = _radial_params(params, kw)
+    nfft = int(p["oversamplingFactor"]) * int(p["irLen"])
+    rad, pr = _out(nfft // 2 + 1, int(p["order"]) + 1, True)
+    L.check(L.load().emagls_get_radial_filter(int(p["order"]), float(p["fs"]), float(p["smaRadius"]), int(p["irLen"]),
+                                              int(p["oversamplingFactor"]), kind, float(p["regulConst"]),
+                                              float(p.get("noiseGainDb", float("nan"))), pr))
+    return rad
+
+
+def applyRadialFilter(inSig, params=None, **kw):
+    """dependencies/applyRadialFilter.m:1: inSig [numSamples x (order+1)^2] filtered per SH order with the radial-filter
+    impulse responses, the delay nfft/2 removed.  params.nfft must be oversamplingFactor * irLen (verifyEMagLs.m:250)."""
+    p, kind = _radial_params(params, kw)
+    nfft = int(p["oversamplingFactor"]) * int(p["irLen"])
+    if "nfft" not in p:
+        raise KeyError("params.nfft is required")
+    if int(p["nfft"]) != nfft:
+        raise ValueError("params.nfft must equal oversamplingFactor * irLen (the reference's arrays do not conform otherwise)")
+    sig, ps = _f(inSig)
+    C_ = (int(p["order"]) + 1) ** 2
+    if sig.ndim != 2 or sig.shape[1] != C_:
+        raise ValueError("inSig must be [numSamples x (order+1)^2]")
+    lib = L.load()
+    if sig.shape[0] < nfft:
+        print("applyRadialFilter: short signal, applying zero padding!")      # :21
+    rows = lib.emagls_apply_radial_filter_rows(sig.shape[0], int(p["irLen"]), int(p["oversamplingFactor"]))
+    out, po = _out(rows, C_, False)
+    L.check(lib.emagls_apply_radial_filter(ps, sig.shape[0], int(p["order"]), float(p["fs"]), float(p["smaRadius"]), int(p["irLen"]),
+                                           int(p["oversamplingFactor"]), kind, float(p["regulConst"]),
+                                           float(p.get("noiseGainDb", float("nan"))), po))
+    return out
+
+
+def encodeSH(smaRecording, micGridAziRad, micGridZenRad, order, shDefinition="real"):
+    """verifyEMagLs.m:235-236: shRecording = smaRecording * pinv(getSH(order, micGrid, shDefinition).')."""
+    b, cplx = _basis(shDefinition)
+    sig, ps = _f(smaRecording)
+    if sig.ndim != 2:
+        raise ValueError("smaRecording must be [numSamples x numMics]")
+    n, M = sig.shape
+    azi, pa = _vec(micGridAziRad, M, "micGridAziRad")
+    zen, pz = _vec(micGridZenRad, M, "micGridZenRad")
+    out, po = _out(n, (int(order) + 1) ** 2, cplx)
+    L.check(L.load().emagls_sh_encode(ps, n, M, pa, pz, int(order), b, po))
+    return out
+
+
+def getMagLsSphericalHeadFilter(micRadius, order, fs, len):
+    """lib/getMagLsSphericalHeadFilter.m:1: (wShf [len x 1], W_Shf [nfft x 1])."""
+    lib = L.load()
+    w, pw = _out(int(len), 1, False)
+    W, pW = _out(int(lib.emagls_eq_filter_nfft(int(len))), 1, False)
+    L.check(lib.emagls_get_magls_spherical_head_filter(float(micRadius), int(order), float(fs), int(len), pw, pW))
+    return w, W
+
+
+def getMagLsArrayDiffuseFilter(micRadius, micGridAziRad, micGridZenRad, order, fs, len, shDefinition="real", shFunction=None):
+    """lib/getMagLsArrayDiffuseFilter.m:1: wAdf [len x 1].  A custom shFunction is evaluated here at the simulation order
+    ceil(fs*pi*micRadius/343) (:38) and handed over as a matrix; its low-order matrix is taken as the leading columns."""
+    import math
+    b, cplx = _basis(shDefinition)
+    azi, pa = _vec(micGridAziRad)
+    zen, pz = _vec(micGridZenRad, azi.size, "micGridZenRad")
+    w, pw = _out(int(len), 1, False)
+    pY = None
+    if shFunction is not None:
+        sim = int(math.ceil(float(fs) * math.pi * float(micRadius) / 343.0))
+        Y, pY = _sh_matrix(shFunction, sim, azi, zen, shDefinition, cplx, azi.size)
+    L.check(L.load().emagls_get_magls_array_diffuse_filter(float(micRadius), pa, pz, azi.size, int(order), float(fs), int(len), b,
+                                                           pY, pw))
+    return w

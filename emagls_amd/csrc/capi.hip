@@ -211,7 +211,6 @@ void emagls_batch_forget(emagls_batch* b, emagls_plan* p) {
 
 namespace {
 
-size_t esz(bool c) { return c ? sizeof(cplx) : sizeof(double); }
 
 // compute units of the current device (cached per device id)
 int device_cu_count() {
@@ -237,6 +236,7 @@ void check_pow2(int nfft) {
 // plan construction: derive constants, allocate every device buffer once
 // ---------------------------------------------------------------------------------------------
 // kinds that run the array-model pipeline (simulated array -> per-bin factor -> sweep)
+static inline bool magls_kind(int k) { return k == EMAGLS_KIND_MAGLS || k == EMAGLS_KIND_MAGLS_2D; }
 static inline bool array_kind(int k) { return k == EMAGLS_KIND_EMAGLS || k == EMAGLS_KIND_EMAGLS2 || k == EMAGLS_KIND_EMA_CH; }
 
 // Smallest order n such that every order above it contributes less than 1e-20 of the strongest mode to pwGrid at kr = x:
@@ -303,7 +303,7 @@ void plan_alloc_routes(emagls_plan& p) {
 
 void plan_setup(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
-    if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_EMA_CH) throw Error(EMAGLS_ERR_ARG, "unknown design kind");
+    if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_MAGLS_2D) throw Error(EMAGLS_ERR_ARG, "unknown design kind");
     if (d.basis != EMAGLS_BASIS_REAL && d.basis != EMAGLS_BASIS_COMPLEX) throw Error(EMAGLS_ERR_ARG, "shDefinition must be 'real' or 'complex'");
     if (d.ndirs < 1 || d.nsamp < 1) throw Error(EMAGLS_ERR_ARG, "empty HRIR set");
     if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
@@ -318,7 +318,7 @@ void plan_setup(emagls_plan& p) {
     // rule and the SH conjugate rule (:109-118) act on W_c and stay in the epilogue.  eMagLS2 is basis free (T cancels).
     // The real pipeline has a 3x cheaper Gram and half the bytes in T_n and QT: 1460 vs 1295 sets/s at config 3.
     p.custom_basis = d.custom_basis != 0;
-    if (p.custom_basis && (d.kind == EMAGLS_KIND_FROM_ATF || d.kind == EMAGLS_KIND_EMA_CH))
+    if (p.custom_basis && (d.kind == EMAGLS_KIND_FROM_ATF || d.kind == EMAGLS_KIND_EMA_CH || d.kind == EMAGLS_KIND_MAGLS_2D))
         throw Error(EMAGLS_ERR_UNSUPPORTED, "caller-supplied SH matrices are available for LS, MagLS, eMagLS and eMagLS2 designs");
     // (a caller-supplied complex basis need not be ours rotated by T: it takes the complex-arithmetic pipeline)
     p.real_internal = p.req_cplx && !p.custom_basis && (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2);
@@ -337,7 +337,7 @@ void plan_setup(emagls_plan& p) {
 
     if (d.kind != EMAGLS_KIND_LS) {
         if (d.len < d.nsamp)
-            throw Error(EMAGLS_ERR_ARG, d.kind == EMAGLS_KIND_MAGLS ? "HRIR len too short" : "len too short");
+            throw Error(EMAGLS_ERR_ARG, magls_kind(d.kind) ? "HRIR len too short" : "len too short");
         if (!(d.fs > 0)) throw Error(EMAGLS_ERR_ARG, "fs must be positive");
         p.nfft = (int)std::min<int64_t>(NFFT_MAX_LEN, 2 * d.len);
         check_pow2(p.nfft);
@@ -352,18 +352,20 @@ void plan_setup(emagls_plan& p) {
         p.k_cut = (int)std::ceil(f_cut / f2);
         if (p.k_cut < 1) p.k_cut = 1;
         p.kcut0 = std::min(p.k_cut - 1, p.P);  // 0-based index of the first magnitude-least-squares bin
-        if (d.kind == EMAGLS_KIND_MAGLS && p.kcut0 < 1) throw Error(EMAGLS_ERR_ARG, "k_cut must be at least 2");
+        if (magls_kind(d.kind) && p.kcut0 < 1) throw Error(EMAGLS_ERR_ARG, "k_cut must be at least 2");
         p.alloc("tw", sizeof(cplx) * p.nfft);
         p.alloc("dirsum", sizeof(double) * 2 * d.nsamp * hrir_dirsum_chunks(d.ndirs));
     }
 
     const int N = d.order;
-    if (d.kind == EMAGLS_KIND_LS || d.kind == EMAGLS_KIND_MAGLS) {
+    if (d.kind == EMAGLS_KIND_LS || magls_kind(d.kind)) {
         p.simOrder = N;
-        p.S = (N + 1) * (N + 1);
+        // getMagLsFilters2D.m:49: Y_conj = getCH(order, azi)' has 2*order+1 rows (the numHarmonics of :47 is never used)
+        p.S = d.kind == EMAGLS_KIND_MAGLS_2D ? 2 * N + 1 : (N + 1) * (N + 1);
         p.C = p.S;
         p.nOut = p.S;
-        if (p.S > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "SH order above 4 is not supported for LS/MagLS in this build");
+        if (p.S > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, d.kind == EMAGLS_KIND_MAGLS_2D ? "CH order above 15 is not supported in this build"
+                                                                                           : "SH order above 4 is not supported for LS/MagLS in this build");
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than SH channels");
     } else if (array_kind(d.kind)) {
         if (!(d.mic_radius > 0) || d.nmics < 1) throw Error(EMAGLS_ERR_ARG, "invalid array geometry");
@@ -402,7 +404,7 @@ void plan_setup(emagls_plan& p) {
             p.alloc("Rinv", esz(cb) * (size_t)ceil_div(p.S, 32) * 32 * 32);
         }
     }
-    if (d.kind == EMAGLS_KIND_LS || d.kind == EMAGLS_KIND_MAGLS) {
+    if (d.kind == EMAGLS_KIND_LS || magls_kind(d.kind)) {
         p.alloc("Rb", sizeof(cplx) * (size_t)p.C * p.ldS);             // R as [c][s] complex
         p.alloc("Zb", sizeof(cplx) * (size_t)p.C * p.ldS);
         p.alloc("Vws", sizeof(cplx) * (size_t)p.C * p.ldS);
@@ -475,7 +477,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Hc", sizeof(cplx) * (size_t)2 * n_c * p.ldD);
         p.alloc("Habs", sizeof(double) * (size_t)2 * std::max(p.P - p.kcut0, 1) * p.ldD);
         p.alloc("W", sizeof(cplx) * (size_t)2 * p.P * p.C);
-        if (d.kind == EMAGLS_KIND_MAGLS || d.kind == EMAGLS_KIND_FROM_ATF) p.nWG = dense_sweep_nwg((int)Dh);
+        if (magls_kind(d.kind) || d.kind == EMAGLS_KIND_FROM_ATF) p.nWG = dense_sweep_nwg((int)Dh);
         p.nWG_dense = dense_sweep_nwg((int)Dh);
         if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) p.sweep_persist = e[0] != '0';
         // the persistent sweep keeps one workgroup per CU resident (142 KB of LDS each): it needs the shape to fit one XCD's
@@ -500,7 +502,9 @@ void plan_setup(emagls_plan& p) {
 void stage_hrir_basis(emagls_plan& p) {
     hipStream_t st = p.stream;
     const bool cb = p.cplx_basis;
-    if (!p.custom_basis) {
+    if (p.d.kind == EMAGLS_KIND_MAGLS_2D) {   // circular harmonics of the horizontal HRIR grid (getMagLsFilters2D.m:49)
+        launch_ch_basis(p.d.order, (int)p.D, p.get<double>("hrir_azi"), cb, p.get("Ycm"), (int)p.ldD, st, !cb);
+    } else if (!p.custom_basis) {
         launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), st);
         launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), cb,
                         p.get("Ycm"), p.ldD, st);
@@ -588,7 +592,9 @@ void execute_magls(emagls_plan& p) {
     }
     if (p.kcut0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
     p.mark("magls_sweep");
-    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"), cb ? 1 : 0, 0, 0,
+    // complex basis: getShFreqDomainConjugate (getMagLsFilters.m) / getChFreqDomainConjugate (getMagLsFilters2D.m:82-83)
+    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"),
+                           cb ? (p.d.kind == EMAGLS_KIND_MAGLS_2D ? 2 : 1) : 0, 0, 0,
                            p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), st);
     p.mark("epilogue");
 }
@@ -929,7 +935,8 @@ void run_pipeline(emagls_plan& p) {
     p.mark("begin");
     switch (d.kind) {
         case EMAGLS_KIND_LS: execute_ls(p); break;
-        case EMAGLS_KIND_MAGLS: execute_magls(p); break;
+        case EMAGLS_KIND_MAGLS:
+        case EMAGLS_KIND_MAGLS_2D: execute_magls(p); break;
         case EMAGLS_KIND_EMAGLS:
         case EMAGLS_KIND_EMAGLS2:
         case EMAGLS_KIND_EMA_CH: execute_emagls(p); break;
@@ -1254,6 +1261,20 @@ void plan_check_flags(emagls_plan& p) {
     throw_fatal_flags(flag);
 }
 
+}  // namespace
+int emagls::guarded_call(const std::function<void()>& f) {
+    try {
+        f();
+        return EMAGLS_OK;
+    } catch (const Error& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return EMAGLS_ERR_HIP;
+    }
+}
+namespace {
 template <typename F> int guarded(F&& f) {
     try {
         f();
@@ -1478,7 +1499,11 @@ int emagls_plan_destroy(emagls_plan* plan) {
 }
 int emagls_plan_set_hrir_grid(emagls_plan* p, const double* azi, const double* zen) {
     return guarded([&] {
-        if (!p || !azi || !zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (!p || !azi) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        // a horizontal HRIR set (getMagLsFilters2D) has no zenith argument: pi/2 for every direction
+        std::vector<double> equator;
+        if (p->d.kind == EMAGLS_KIND_MAGLS_2D) { equator.assign((size_t)p->d.ndirs, kPi / 2.0); zen = equator.data(); }
+        if (!zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
         p->upload("hrir_azi", azi, sizeof(double) * p->d.ndirs);
         p->upload("hrir_zen", zen, sizeof(double) * p->d.ndirs);
         HIP_CHECK(hipStreamSynchronize(p->stream));
@@ -1873,6 +1898,13 @@ static int decode_entry(const void* in, bool in_cplx, int64_t nsamp, int64_t nch
         } catch (...) { cleanup(); throw; }
         cleanup();
     });
+}
+
+int emagls_get_magls_filters_2d(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, int order, double fs,
+                                int64_t len, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_MAGLS_2D; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    return one_shot(d, hL, hR, azi, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, wL, wR, nullptr);
 }
 
 int emagls_simulation_order(int kind, int order, double fs, double mic_radius) {

@@ -198,4 +198,87 @@ void binaural_decode_complex(const void* sig, bool sig_cplx, int64_t n, int C, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// applyRadialFilter's convolution (dependencies/applyRadialFilter.m:24-30): out(:,c) = fftfilt(ir(:,order(c)), in(:,c)) with
+// the first `skip` samples dropped (the filter delay nfft/2) -- the same overlap-save blocks as above, but every channel keeps
+// its own output and the filter of channel c is the one of its SH order floor(sqrt(c)).
+// ---------------------------------------------------------------------------------------------
+// wpad[o][i] = ir[o*len + i] for i < len else 0
+__global__ void olsc_padfilt_kernel(const double* __restrict__ ir, int nOrd, int64_t len, int Nf, double* __restrict__ wpad) {
+    const int64_t total = (int64_t)nOrd * Nf;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx % Nf, o = idx / Nf;
+        wpad[idx] = (i < len) ? ir[o * len + i] : 0.0;
+    }
+}
+// Xf[c][b][k] *= Wf[order(c)][k]
+__global__ void olsc_mul_kernel(cplx* __restrict__ Xf, const cplx* __restrict__ Wf, int C, int64_t nblocks, int Pf) {
+    const int64_t total = (int64_t)C * nblocks * Pf;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = idx % Pf, c = idx / ((int64_t)nblocks * Pf);
+        int o = (int)sqrt((double)c);
+        while ((o + 1) * (o + 1) <= c) ++o;
+        while (o * o > c) --o;
+        Xf[idx] = Xf[idx] * Wf[(int64_t)o * Pf + k];
+    }
+}
+// out[c*(n-skip) + t - skip] = y[c][b][len-1+i] / Nf,  t = b*B + i in [skip, n)
+__global__ void olsc_unpack_kernel(const double* __restrict__ y, int64_t n, int C, int64_t nblocks, int Nf, int64_t B, int64_t len,
+                                   int64_t skip, double* __restrict__ out) {
+    const int64_t nout = n - skip, total = (int64_t)C * nout;
+    const double scale = 1.0 / (double)Nf;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = idx % nout + skip, c = idx / nout;
+        const int64_t b = t / B, i = t % B;
+        out[idx] = y[((int64_t)c * nblocks + b) * Nf + (len - 1) + i] * scale;
+    }
+}
+
+// sig holds n_in samples per channel; the signal is taken as zero-padded to n >= n_in samples (applyRadialFilter.m:20-22)
+void filter_channels_by_order(const double* sig, int64_t n_in, int64_t n, int C, const double* ir, int nOrd, int64_t len, int64_t skip,
+                              double* out, hipStream_t st) {
+    if (n <= skip) return;
+    int Nf = 1024;
+    while (Nf < 4 * len) Nf <<= 1;
+    const int64_t B = Nf - (len - 1);
+    const int64_t nblocks = ceil_div(n, B);
+    const int Pf = Nf / 2 + 1;
+    double *seg = nullptr, *wpad = nullptr;
+    cplx *Xf = nullptr, *Wf = nullptr;
+    hipfftHandle pf = 0, pw = 0, pi = 0;
+    auto cleanup = [&] {
+        if (pf) hipfftDestroy(pf);
+        if (pw) hipfftDestroy(pw);
+        if (pi) hipfftDestroy(pi);
+        hipFree(seg); hipFree(wpad); hipFree(Xf); hipFree(Wf);
+    };
+    try {
+        HIP_CHECK(hipMalloc(&seg, sizeof(double) * C * nblocks * Nf));
+        HIP_CHECK(hipMalloc(&wpad, sizeof(double) * nOrd * Nf));
+        HIP_CHECK(hipMalloc(&Xf, sizeof(cplx) * C * nblocks * Pf));
+        HIP_CHECK(hipMalloc(&Wf, sizeof(cplx) * nOrd * Pf));
+        int nn[1] = {Nf};
+        fft_check(hipfftPlanMany(&pf, 1, nn, nullptr, 1, Nf, nullptr, 1, Pf, HIPFFT_D2Z, (int)(C * nblocks)), "plan D2Z signal");
+        fft_check(hipfftPlanMany(&pw, 1, nn, nullptr, 1, Nf, nullptr, 1, Pf, HIPFFT_D2Z, nOrd), "plan D2Z filters");
+        fft_check(hipfftPlanMany(&pi, 1, nn, nullptr, 1, Pf, nullptr, 1, Nf, HIPFFT_Z2D, (int)(C * nblocks)), "plan Z2D");
+        fft_check(hipfftSetStream(pf, st), "set stream");
+        fft_check(hipfftSetStream(pw, st), "set stream");
+        fft_check(hipfftSetStream(pi, st), "set stream");
+        // (ols_pack_kernel reads in[c*n + src] for src < n: the channel stride is the true length, the padding comes from the bound)
+        ols_pack_kernel<<<2048, 256, 0, st>>>(sig, n_in, C, nblocks, Nf, B, len, seg);
+        KERNEL_CHECK();
+        olsc_padfilt_kernel<<<64, 256, 0, st>>>(ir, nOrd, len, Nf, wpad);
+        KERNEL_CHECK();
+        fft_check(hipfftExecD2Z(pf, seg, (hipfftDoubleComplex*)Xf), "exec D2Z signal");
+        fft_check(hipfftExecD2Z(pw, wpad, (hipfftDoubleComplex*)Wf), "exec D2Z filters");
+        olsc_mul_kernel<<<2048, 256, 0, st>>>(Xf, Wf, C, nblocks, Pf);
+        KERNEL_CHECK();
+        fft_check(hipfftExecZ2D(pi, (hipfftDoubleComplex*)Xf, seg), "exec Z2D");
+        olsc_unpack_kernel<<<2048, 256, 0, st>>>(seg, n, C, nblocks, Nf, B, len, skip, out);
+        KERNEL_CHECK();
+        HIP_CHECK(hipStreamSynchronize(st));
+    } catch (...) { cleanup(); throw; }
+    cleanup();
+}
+
 }  // namespace emagls

@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(512) real_fft_gather_kernel(const double* __re
 __global__ void __launch_bounds__(256) filter_epilogue_kernel(const cplx* __restrict__ W, int C, int nfft, int log2n,
                                                               int len, const cplx* __restrict__ tw,
                                                               const double* __restrict__ grpd, int conj_mode,
-                                                              int dc_rule, int shift_mode, int out_cplx,
+                                                              int dc_rule, int shift_mode, int out_cplx, double fade_rel,
                                                               void* __restrict__ outL, void* __restrict__ outR, size_t bstride) {
     W = boff(W, bstride); tw = boff(tw, bstride); grpd = boff(grpd, bstride); outL = boff(outL, bstride); outR = boff(outR, bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256) filter_epilogue_kernel(const cplx* __rest
     __syncthreads();
     lds_fft_stages<true>(buf, tws, nfft, log2n, 1);
     const double inv_n = 1.0 / (double)nfft;
-    const int nf = (int)round(0.15 * (double)len);  // getFadeWindow.m:11-12
+    const int nf = (int)round(fade_rel * (double)len);  // getFadeWindow.m:11-12 (relFadeLen: 0.15 unless the caller says otherwise)
     const int t0 = n_shift - len / 2;
     for (int tt = threadIdx.x; tt < len; tt += blockDim.x) {
         int t = t0 + tt;
@@ -427,11 +427,19 @@ void launch_real_fft_gather(const double* x, int64_t L, int64_t ncols, const int
 }
 
 void launch_filter_epilogue(const void* W, int C, int nfft, int len, const void* tw, const double* grpd, int conj_mode,
-                            int dc_rule, int shift_mode, int out_cplx, void* outL, void* outR, hipStream_t st) {
+                            int dc_rule, int shift_mode, int out_cplx, void* outL, void* outR, hipStream_t st, int n_ears,
+                            double fade_rel) {
     const int log2n = ilog2(nfft);
     const size_t sm = (size_t)nfft * 16 + (size_t)nfft * 8;
-    filter_epilogue_kernel<<<bgrid(dim3(C, 2)), 256, sm, st>>>((const cplx*)W, C, nfft, log2n, len, (const cplx*)tw, grpd,
-                                                        conj_mode, dc_rule, shift_mode, out_cplx, outL, outR, batch_ctx().stride);
+    if (sm > 48 * 1024) {   // (only the radial-filter IRs get here: the designs stop at nfft = 2048)
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)filter_epilogue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+    }
+    filter_epilogue_kernel<<<bgrid(dim3(C, n_ears)), 256, sm, st>>>((const cplx*)W, C, nfft, log2n, len, (const cplx*)tw, grpd,
+                                                        conj_mode, dc_rule, shift_mode, out_cplx, fade_rel, outL, outR, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

@@ -1,6 +1,7 @@
 // Launcher declarations shared by the kernel translation units and the C ABI (capi.hip).
 #pragma once
 #include <algorithm>
+#include <functional>
 
 #include "common.hpp"
 
@@ -8,8 +9,9 @@ namespace emagls {
 
 // ---- sh_basis.hip
 void launch_zero(void* p, size_t bytes, hipStream_t st);
-void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out, int ld, hipStream_t st);
+void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out, int ld, hipStream_t st, bool out_real = false);
 void launch_sh_coeff(int N, double* tab, hipStream_t st);
+inline size_t esz(bool c) { return c ? sizeof(cplx) : sizeof(double); }   // element size of a real / complex basis
 inline size_t sh_coeff_count(int N) { return (size_t)2 * (N + 1) * (N + 1) + 2 * (N + 1); }
 void launch_sh_basis(int N, int64_t D, const double* azi, const double* zen, const double* tab, bool cplx_basis,
                      void* Y, int64_t ld, hipStream_t st);
@@ -32,7 +34,8 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
 void launch_real_fft_gather(const double* x, int64_t L, int64_t ncols, const int64_t* colidx, int nfft, const void* tw,
                             void* out, int64_t ldo, int64_t inner, int64_t ld_inner, hipStream_t st);
 void launch_filter_epilogue(const void* W, int C, int nfft, int len, const void* tw, const double* grpd, int conj_mode,
-                            int dc_rule, int shift_mode, int out_cplx, void* outL, void* outR, hipStream_t st);
+                            int dc_rule, int shift_mode, int out_cplx, void* outL, void* outR, hipStream_t st, int n_ears = 2,
+                            double fade_rel = 0.15);
 
 // ---- gram_chol.hip
 int gram_ksplit(int64_t D, int S);
@@ -124,6 +127,21 @@ void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL,
 void binaural_decode_complex(const void* sig, bool sig_cplx, int64_t n, int C, const void* wL, const void* wR, bool w_cplx, int64_t len,
                              double* sig2, double* w2L, double* w2R, double* out, double* imag_abs, double* d_tmp, hipStream_t st);
 void decode_cache_clear();
+void filter_channels_by_order(const double* sig, int64_t n_in, int64_t n, int C, const double* ir /* [nOrd][len] */, int nOrd, int64_t len,
+                              int64_t skip, double* out /* [C][n-skip] */, hipStream_t st);
+
+// ---- render.hip
+void launch_radial_filter(const void* bn, int nOrd, int P, int type, double regul, double g, bool nyq_abs, bool zero_nan,
+                          void* out_kn, void* out_cm, hipStream_t st);
+void launch_diffuse_field(const void* bn, int nOrd, int n_lo, int P, double* df_hi, double* df_lo, hipStream_t st);
+void launch_array_diffuse(const void* bn, int nOrd, const void* Y, bool y_cplx, int ldY, int S, int M, int nOut, int P,
+                          double* df_lo, hipStream_t st);
+void launch_eq_spectrum(const double* df_hi, const double* df_lo, const double* df_arr, int P, int mode, void* W, double* W_full,
+                        hipStream_t st);
+void launch_sh_encode(const double* sig, int64_t n, int M, const void* Z, int ldZ, int nOut, bool out_cplx, void* out, hipStream_t st);
+
+// ---- capi.hip: runs f, maps exceptions to the C status codes and records the message for emagls_last_error()
+int guarded_call(const std::function<void()>& f);
 
 }  // namespace emagls
 

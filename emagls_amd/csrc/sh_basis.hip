@@ -140,9 +140,10 @@ void launch_zero(void* p, size_t bytes, hipStream_t st) {
 
 // circular harmonics of an equatorial array (dependencies/getCH.m:17-28), written as the complex [channel][mic] matrix
 // that the pinv factorisation takes:  out[c * ld + m] = C_c(azi_m),  channels [C_0, C_-1, C_1, ..., C_-N, C_N]
-__global__ void ch_basis_kernel(int N, int M, const double* __restrict__ azi, int cplx_basis, cplx* __restrict__ out, int ld,
-                                size_t bstride) {
-    azi = boff(azi, bstride); out = boff(out, bstride);
+// (out_real: the real basis as doubles, the layout the HRIR-side pipeline keeps a real basis in)
+__global__ void ch_basis_kernel(int N, int M, const double* __restrict__ azi, int cplx_basis, int out_real, void* __restrict__ out_,
+                                int ld, size_t bstride) {
+    azi = boff(azi, bstride); out_ = boff(out_, bstride);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int C = 2 * N + 1;
     if (idx >= C * M) return;
@@ -156,10 +157,12 @@ __global__ void ch_basis_kernel(int N, int M, const double* __restrict__ azi, in
         if (cplx_basis) v = neg ? mk(cs, -sn) : mk(cs, sn);
         else v = mk(1.4142135623730951 * (neg ? sn : cs), 0.0);
     }
-    out[(size_t)c * ld + m] = v;
+    if (out_real) reinterpret_cast<double*>(out_)[(size_t)c * ld + m] = v.x;
+    else reinterpret_cast<cplx*>(out_)[(size_t)c * ld + m] = v;
 }
-void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out, int ld, hipStream_t st) {
-    ch_basis_kernel<<<bgrid(((2 * N + 1) * M + 255) / 256), 256, 0, st>>>(N, M, azi, cplx_basis ? 1 : 0, (cplx*)out, ld, batch_ctx().stride);
+void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out, int ld, hipStream_t st, bool out_real) {
+    ch_basis_kernel<<<bgrid(((2 * N + 1) * M + 255) / 256), 256, 0, st>>>(N, M, azi, cplx_basis ? 1 : 0, out_real ? 1 : 0, out, ld,
+                                                                          batch_ctx().stride);
     KERNEL_CHECK();
 }
 

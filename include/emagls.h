@@ -51,6 +51,7 @@ extern "C" {
 #define EMAGLS_KIND_EMAGLS2 3
 #define EMAGLS_KIND_FROM_ATF 4
 #define EMAGLS_KIND_EMA_CH 5   /* equatorial array, output in circular harmonics (2*order+1 channels) */
+#define EMAGLS_KIND_MAGLS_2D 6 /* MagLS on a horizontal HRIR set in circular harmonics (2*order+1 channels) */
 
 const char* emagls_last_error(void);
 int emagls_version(void);
@@ -142,6 +143,44 @@ int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const d
  * reference prints in its warning (:61-62). */
 int emagls_binaural_decode_complex(const void* in, int in_is_complex, int64_t nsamp, int64_t nch, const void* wL, const void* wR,
                                    int filters_are_complex, int64_t len, int compensate_delay, double* out, double* imag_abs_sum);
+
+/* ---- render side: what the reference's harness runs between the recording and the decoder ---- */
+
+/* lib/getMagLsFilters2D.m:1 -- [wMlsL, wMlsR] = getMagLsFilters2D(hLHor, hRHor, horHrirGridAziRad, order, fs, len, chDefinition)
+ * hL/hR [nsamp x ndirs]; wL/wR [len x 2*order+1], channels [C_0, C_-1, C_1, ..., C_-N, C_N] (dependencies/getCH.m:17-28),
+ * real, or interleaved complex for basis == EMAGLS_BASIS_COMPLEX. */
+int emagls_get_magls_filters_2d(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* hrir_azi,
+                                int order, double fs, int64_t len, int basis, void* wL, void* wR);
+
+#define EMAGLS_RADIAL_TIKHONOV 0
+#define EMAGLS_RADIAL_SOFTLIMIT 1
+#define EMAGLS_RADIAL_FULL 2
+#define EMAGLS_RADIAL_NONE 3
+/* dependencies/getRadialFilter.m:1 -- radFilts = getRadialFilter(params), plane-wave model, rigid sphere.
+ * nfft = oversampling * ir_len; rad: interleaved complex [nfft/2+1 x order+1] column-major.  regul_const is read by
+ * tikhonov, noise_gain_db by softlimit.  Entries the reference computes as 0/0 or 1/0 (orders > 0 at DC, softlimit / full)
+ * come back as NaN / Inf+NaN i like there. */
+int emagls_get_radial_filter(int order, double fs, double sma_radius, int64_t ir_len, int oversampling, int filter_type,
+                             double regul_const, double noise_gain_db, void* rad);
+/* dependencies/applyRadialFilter.m:1 -- outSig = applyRadialFilter(inSig, params) with params.nfft = oversampling * ir_len
+ * (verifyEMagLs.m:250).  sig [nsamp x (order+1)^2] real; out [emagls_apply_radial_filter_rows(...) x (order+1)^2]:
+ * the signal (zero-padded to nfft if shorter) filtered per SH order, the filter delay nfft/2 removed. */
+int64_t emagls_apply_radial_filter_rows(int64_t nsamp, int64_t ir_len, int oversampling);
+int emagls_apply_radial_filter(const double* sig, int64_t nsamp, int order, double fs, double sma_radius, int64_t ir_len,
+                               int oversampling, int filter_type, double regul_const, double noise_gain_db, double* out);
+/* verifyEMagLs.m:235-236 -- E = getSH(order, micGrid, shDefinition).'; shRecording = smaRecording * pinv(E)
+ * sig [nsamp x nmics] real; out [nsamp x (order+1)^2], real or interleaved complex like the basis. */
+int emagls_sh_encode(const double* sig, int64_t nsamp, int64_t nmics, const double* mic_azi, const double* mic_zen, int order,
+                     int basis, void* out);
+/* lib/getMagLsSphericalHeadFilter.m:1 -- [wShf, W_Shf] = getMagLsSphericalHeadFilter(micRadius, order, fs, len)
+ * w_shf [len]; W_shf (optional) [emagls_eq_filter_nfft(len)] real, the mirrored zero-phase spectrum. */
+int64_t emagls_eq_filter_nfft(int64_t len);
+int emagls_get_magls_spherical_head_filter(double mic_radius, int order, double fs, int64_t len, double* w_shf, double* W_shf);
+/* lib/getMagLsArrayDiffuseFilter.m:1 -- wAdf = getMagLsArrayDiffuseFilter(micRadius, micGridAziRad, micGridZenRad, order, fs,
+ * len, shDefinition, shFunction).  Y_hi (optional) replaces the built-in getSH: the caller's shFunction evaluated at the
+ * simulation order ceil(fs*pi*micRadius/343), [nmics x (simOrder+1)^2] column-major (the grid may then be NULL).  w_adf [len]. */
+int emagls_get_magls_array_diffuse_filter(double mic_radius, const double* mic_azi, const double* mic_zen, int64_t nmics, int order,
+                                          double fs, int64_t len, int basis, const void* Y_hi, double* w_adf);
 
 /* ---- plan API: inputs resident in HBM, repeated execution (benchmarks, batches) ------------- */
 

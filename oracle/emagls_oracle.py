@@ -287,7 +287,7 @@ def _grp_delay(h_padded, P):
     return float(np.median(grpdelay_fir(h_padded.sum(axis=1), P)))
 
 
-def _finish(W_l, W_r, P, nfft, length, is_real_basis, delayL, delayR, integer_shift=False):
+def _finish(W_l, W_r, P, nfft, length, is_real_basis, delayL, delayR, integer_shift=False, conj_fn=None):
     """DC rule, spectrum completion, ifft, shift, truncate, fade
     (lib/getEMagLsFilters.m:110-142; lib/getEMagLsFiltersFromAtf.m:125-151)."""
     out = []
@@ -295,7 +295,7 @@ def _finish(W_l, W_r, P, nfft, length, is_real_basis, delayL, delayR, integer_sh
         if is_real_basis:
             Wf = np.vstack([W[:P], np.conj(W[P - 2 : 0 : -1])])
         else:
-            Wf = getShFreqDomainConjugate(W[:P])
+            Wf = (conj_fn or getShFreqDomainConjugate)(W[:P])
         w = np.fft.ifft(Wf, axis=0)
         if integer_shift:
             w = np.roll(w, int(dly), axis=0)
@@ -308,11 +308,13 @@ def _finish(W_l, W_r, P, nfft, length, is_real_basis, delayL, delayR, integer_sh
     return out
 
 
-def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="real", shFunction=None):
+def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="real", shFunction=None, _Y=None, _conj_fn=None):
     """lib/getMagLsFilters.m:30-98"""
     assert length >= hL.shape[0], "HRIR len too short"
     nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
-    Y_conj = (shFunction or getSH)(order, np.column_stack([aziRad, zenRad]), shDefinition).conj().T
+    if _Y is None:
+        _Y = (shFunction or getSH)(order, np.column_stack([aziRad, zenRad]), shDefinition)
+    Y_conj = _Y.conj().T
     Y_pinv = pinv(Y_conj)
     is_real = np.isrealobj(Y_conj)
     hL = _pad(hL, nfft)
@@ -332,7 +334,7 @@ def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="rea
             Wm[k - 1] = t @ Y_pinv
         W.append(Wm)
     n_shift = nfft // 2
-    wL, wR = _finish(W[0], W[1], P, nfft, length, is_real, n_shift, n_shift + (grpD[1] - grpD[0]))
+    wL, wR = _finish(W[0], W[1], P, nfft, length, is_real, n_shift, n_shift + (grpD[1] - grpD[0]), conj_fn=_conj_fn)
     if is_real:
         wL, wR = wL.real, wR.real
     return wL, wR
@@ -526,6 +528,77 @@ def applyRadialFilter(inSig, order, fs, smaRadius, irLen, oversamplingFactor=1, 
     full = np.column_stack([sh_repToOrder(ir[t]) for t in range(ir.shape[0])]).T   # [nfft x (order+1)^2]
     out = np.column_stack([fftfilt(full[:, c].real, sig[:, c]) for c in range(sig.shape[1])])
     return out[nfft // 2:]
+
+
+# --------------------------------------------------------------------------------------------
+# Render-side neighbours: 2-D MagLS, SH encoding, equalisation filters
+# --------------------------------------------------------------------------------------------
+def getMagLsFilters2D(hLHor, hRHor, horHrirGridAziRad, order, fs, length, chDefinition="real"):
+    """lib/getMagLsFilters2D.m:33-103: the loop of getMagLsFilters with Y_conj = getCH(order, azi)' (:49; 2*order+1 channels,
+    the numHarmonics of :47 is unused) and getChFreqDomainConjugate for a complex basis (:82-83)."""
+    return getMagLsFilters(hLHor, hRHor, None, None, order, fs, length, chDefinition,
+                           _Y=getCH(order, horHrirGridAziRad, chDefinition), _conj_fn=getChFreqDomainConjugate)
+
+
+def encodeSH(smaRecording, micGridAziRad, micGridZenRad, order, shDefinition="real"):
+    """verifyEMagLs.m:235-236: E = getSH(order, micGrid, shDefinition).'; shRecording = smaRecording * pinv(E)."""
+    E = getSH(order, np.column_stack([micGridAziRad, micGridZenRad]), shDefinition).T
+    return np.asarray(smaRecording, dtype=np.float64) @ pinv(E)
+
+
+def _eq_consts(micRadius, fs, length):
+    nfft = min(NFFT_MAX_LEN, 2 * length)
+    f = np.linspace(0, fs / 2, nfft // 2 + 1)
+    kr = 2 * np.pi * f / C_SOUND * micRadius
+    return nfft, kr, int(math.ceil(fs * math.pi * micRadius / C_SOUND))
+
+
+def _eq_finish(W, nfft, length):
+    """:51-67 of lib/getMagLsSphericalHeadFilter.m (same lines in lib/getMagLsArrayDiffuseFilter.m:68-85)"""
+    P = nfft // 2 + 1
+    Wf = np.concatenate([W[:P], np.conj(W[P - 2:0:-1])])
+    w = np.fft.ifft(Wf)
+    n_shift = nfft // 2
+    w = applySubsampleDelay(w[:, None], n_shift)[:, 0]
+    w = w[n_shift - length // 2:n_shift + length // 2]
+    return np.real(w * getFadeWindow(length)), Wf
+
+
+def _df(bn_expanded):
+    """rms(abs(x), 2) * sqrt(size(x, 2)) / (4*pi)"""
+    a = np.abs(bn_expanded)
+    return np.sqrt(np.mean(a * a, axis=1)) * math.sqrt(bn_expanded.shape[1]) / (4 * math.pi)
+
+
+def getMagLsSphericalHeadFilter(micRadius, order, fs, length):
+    """lib/getMagLsSphericalHeadFilter.m:23-67 -> (wShf [len], W_Shf [nfft])."""
+    nfft, kr, simOrder = _eq_consts(micRadius, fs, length)
+    bn_Hi = sphModalCoeffs(simOrder, kr, "rigid")
+    if order > simOrder:
+        raise IndexError("bn_Hi(:, 1:order+1): index exceeds the simulation order")
+    bn_Lo = bn_Hi[:, :order + 1]
+    hi = np.array([sh_repToOrder(r) for r in bn_Hi])
+    lo = np.array([sh_repToOrder(r) for r in bn_Lo])
+    W = 1.0 / (_df(hi) / _df(lo))
+    w, Wf = _eq_finish(W.astype(np.complex128), nfft, length)
+    return w, np.real(Wf)
+
+
+def getMagLsArrayDiffuseFilter(micRadius, micGridAziRad, micGridZenRad, order, fs, length, shDefinition="real", shFunction=None):
+    """lib/getMagLsArrayDiffuseFilter.m:33-85"""
+    sh = shFunction or getSH
+    nfft, kr, simOrder = _eq_consts(micRadius, fs, length)
+    hi = np.array([sh_repToOrder(r) for r in sphModalCoeffs(simOrder, kr, "rigid")])
+    grid = np.column_stack([micGridAziRad, micGridZenRad])
+    Y_Hi_conj = sh(simOrder, grid, shDefinition).conj().T
+    bn_Lo = (hi @ Y_Hi_conj) @ sh(order, grid, shDefinition)
+    hi_df = _df(hi)
+    lo_df = _df(bn_Lo)
+    lo_df = lo_df / lo_df[0]
+    W_Alias = hi_df / lo_df
+    _, W_Shf = getMagLsSphericalHeadFilter(micRadius, order, fs, length)
+    W = W_Shf[:W_Alias.shape[0]] * W_Alias
+    return _eq_finish(W.astype(np.complex128), nfft, length)[0]
 
 
 # --------------------------------------------------------------------------------------------

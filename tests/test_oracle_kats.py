@@ -387,3 +387,76 @@ def test_radial_filter_oracle():
     x[:, 5] = x[:, 7]
     y = O.applyRadialFilter(x, 4, 48000.0, 0.042, 512)
     assert np.array_equal(y[:, 5], y[:, 7])
+
+
+# --------------------------------------------------------------------------------------------
+# render-side neighbours: no reference fixture holds their outputs, so these are known-answer tests
+# --------------------------------------------------------------------------------------------
+def test_spherical_head_filter_is_a_delta_at_the_simulation_order():
+    """lib/getMagLsSphericalHeadFilter.m:31-48: with order == ceil(fs*pi*r/c) the low- and high-order diffuse-field responses
+    coincide, W_Shf == 1 and the filter is a unit impulse at len/2 (zero-phase -> linear-phase shift, :57-58)."""
+    fs, r = 8000.0, 0.042
+    sim = int(np.ceil(fs * np.pi * r / 343.0))
+    w, W = O.getMagLsSphericalHeadFilter(r, sim, fs, 64)
+    assert W.shape == (128,) and np.allclose(W, 1.0, atol=1e-14)
+    d = np.zeros(64)
+    d[32] = 1.0
+    assert np.allclose(w, d, atol=1e-13)
+    # a lower order has less diffuse-field energy at high frequencies: hi/lo >= 1 there, and :48 returns its inverse (1 at DC)
+    w2, W2 = O.getMagLsSphericalHeadFilter(r, 1, fs, 64)
+    assert abs(W2[0] - 1.0) < 1e-14 and np.all(W2[:65] <= 1.0 + 1e-12) and W2[64] < 0.7
+    assert np.allclose(W2[1:64], W2[:64:-1])          # mirrored real spectrum
+    with pytest.raises(IndexError):
+        O.getMagLsSphericalHeadFilter(0.004, 4, 48000.0, 256)
+
+
+def test_array_diffuse_filter_tends_to_a_delta_on_a_dense_array():
+    """lib/getMagLsArrayDiffuseFilter.m:47-66: on an array that samples the sphere densely Y_Hi' Y_Lo tends to a selection of
+    the low orders, the aliasing term cancels the spherical-head term and the filter tends to a unit impulse."""
+    rng = np.random.default_rng(5)
+    M = 40000
+    azi = rng.uniform(0, 2 * np.pi, M)
+    zen = np.arccos(rng.uniform(-1, 1, M))
+    w = O.getMagLsArrayDiffuseFilter(0.042, azi, zen, 2, 8000.0, 64)
+    assert w.shape == (64,) and abs(w[32] - 1.0) < 0.05 and np.abs(np.delete(w, 32)).max() < 0.05
+    # a sparse array does alias: the filter departs from the impulse
+    w4 = O.getMagLsArrayDiffuseFilter(0.042, azi[:9], zen[:9], 2, 8000.0, 64)
+    assert np.abs(w4 - w).max() > 0.05
+
+
+def test_magls_2d_ls_regime_reproduces_ch_limited_hrirs():
+    """lib/getMagLsFilters2D.m: with f_cut = 500*order above fs/2 the magnitude loop (:64-74) never runs and the filters are
+    the least-squares ones; HRIRs that are one impulse times a circular-harmonic pattern come back as that pattern at len/2."""
+    order, fs, length, D = 8, 6000.0, 64, 90
+    azi = np.linspace(0, 2 * np.pi, D, endpoint=False)
+    rng = np.random.default_rng(2)
+    for basis in ("real", "complex"):
+        Y = O.getCH(order, azi, basis)
+        assert Y.shape == (D, 2 * order + 1)
+        a = rng.standard_normal(2 * order + 1)
+        if basis == "complex":      # real HRIRs: a_{-m} = conj(a_m)
+            a = a.astype(complex)
+            for m in range(1, order + 1):
+                a[2 * m - 1] = a[2 * m - 1] + 1j * rng.standard_normal()
+                a[2 * m] = np.conj(a[2 * m - 1])
+        pattern = np.real(a @ Y.conj().T)
+        h = np.zeros((32, D))
+        h[5] = pattern
+        wL, wR = O.getMagLsFilters2D(h, 0.5 * h, azi, order, fs, length, basis)
+        assert wL.shape == (length, 2 * order + 1)
+        assert np.allclose(wL[32], a, atol=1e-10) and np.allclose(wR[32], 0.5 * a, atol=1e-10)
+        assert np.abs(np.delete(wL, 32, axis=0)).max() < 1e-10
+
+
+def test_encode_sh_inverts_plane_wave_sampling(grids):
+    """verifyEMagLs.m:235-236: encoding the array samples of an order-limited field returns its coefficients."""
+    rng = np.random.default_rng(4)
+    for basis in ("real", "complex"):
+        Y = O.getSH(4, np.column_stack([grids["mic_azi"], grids["mic_zen"]]), basis)
+        coef = rng.standard_normal((50, 25))
+        rec = np.real(coef @ Y.T) if basis == "real" else None
+        if basis == "real":
+            assert np.allclose(O.encodeSH(rec, grids["mic_azi"], grids["mic_zen"], 4, basis), coef, atol=1e-10)
+        else:
+            out = O.encodeSH(rng.standard_normal((50, Y.shape[0])), grids["mic_azi"], grids["mic_zen"], 4, basis)
+            assert out.shape == (50, 25) and np.iscomplexobj(out)
