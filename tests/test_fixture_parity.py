@@ -3,7 +3,9 @@
 The fixtures under resources/ were computed from HRIR_L2702.mat, which the reference does not ship
 (.MISSING_LARGE_BLOBS), so these tests are skipped unless the user supplies that HRIR set as plain arrays:
 
-    EMAGLS_HRIR_NPZ=/path/to/hrir_l2702.npz    with  hL, hR  [numSamples x 2702] float64  (48 kHz, the fixture grid order)
+    EMAGLS_HRIR_FILE=/path/to/hrir_l2702.npz | .mat    (emagls_amd.io.load_hrir_set: hL, hR [numSamples x 2702] or the MIRO
+                                                        field names irChOne / irChTwo; 48 kHz, the fixture grid order)
+    (EMAGLS_HRIR_NPZ is still read, for the same thing.)
 
 They then compare, with the reference's own assertAllClose rule (verifyEMagLs.m:370-395), all eight reachable fixture
 sets (real / complex x LS, MagLS_woDC, eMagLS_woDC, eMagLS2_woDC)."""
@@ -14,15 +16,16 @@ import pytest
 
 from oracle import emagls_oracle as O
 
-NPZ = os.environ.get("EMAGLS_HRIR_NPZ", "")
-pytestmark = pytest.mark.skipif(not (NPZ and os.path.exists(NPZ)), reason="HRIR_L2702 not supplied (EMAGLS_HRIR_NPZ)")
+NPZ = os.environ.get("EMAGLS_HRIR_FILE", "") or os.environ.get("EMAGLS_HRIR_NPZ", "")
+pytestmark = pytest.mark.skipif(not (NPZ and os.path.exists(NPZ)), reason="HRIR_L2702 not supplied (EMAGLS_HRIR_FILE)")
 
 CASES = [(b, m) for b in ("real", "complex") for m in ("LS", "MagLS_woDC", "eMagLS_woDC", "eMagLS2_woDC")]
 
 
 def _inputs():
-    d = np.load(NPZ)
-    return np.asarray(d["hL"], dtype=np.float64), np.asarray(d["hR"], dtype=np.float64)
+    from emagls_amd.io import load_hrir_set
+    d = load_hrir_set(NPZ)
+    return d["hL"], d["hR"]
 
 
 def _design(mod, golden, grids, basis, method):
