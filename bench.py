@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--prio", type=int, default=0, help="1: high-priority stream for the first full batch")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("EMAGLS_BENCH_SLOTS", str(SLOTS))),
                     help="resident batches per GPU (profiling runs use 1)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", str(BSZ))),
@@ -266,6 +267,15 @@ def main():
     L.check(lib.emagls_set_device(local_rank))
     K, W = args.steps, args.warmup
     nslots, Bsz = args.slots, args.batch
+    # The HIP runtime multiplexes every stream of the process onto 4 hardware queues, and two batches whose streams share a
+    # queue run strictly one after the other (measured: the third batch of a 20-design run waited 8 ms behind the first one's
+    # sweep).  The streams of the batches that can be in flight together are therefore created here, before the library
+    # creates any stream of its own, and handed to the batches (emagls_batch_set_stream): consecutive streams land on
+    # different queues.  The tail batches come first so that [full, full, tail] never shares a queue.
+    # --prio 1: the first full batch runs on a high-priority stream, so that in a short run (pipeline fill) ONE batch reaches
+    # its sweep early instead of all of them late
+    lane_streams = [torch.cuda.Stream(device=local_rank, priority=(-1 if (args.prio and j == 2) else 0)) for j in range(nslots + 2)]
+    next_stream = iter(lane_streams)
 
     def make_plan(seed_offset, streams=1):
         azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=seed_offset)
@@ -306,6 +316,10 @@ def main():
             self.plans = [make_plan(seed0 + j)[0] for j in range(size)]
             self.batch = Batch(self.plans) if size > 1 else None
             self.size = size
+            if self.batch is not None:
+                st = next(next_stream, None)
+                if st is not None:
+                    self.batch.set_stream(st.cuda_stream)
 
         def execute(self):
             self.batch.execute() if self.batch is not None else self.plans[0].execute()
@@ -325,12 +339,12 @@ def main():
             for p in self.plans:
                 p.close()
 
-    units = [Unit(Bsz, rank * 1000 + b * Bsz) for b in range(nslots)]
     tails = {}
-    for n_designs in (W, K):
+    for n_designs in (K, W):
         t = n_designs % Bsz
         if t and t not in tails:
             tails[t] = Unit(t, rank * 1000 + 500 + t)
+    units = [Unit(Bsz, rank * 1000 + b * Bsz) for b in range(nslots)]
     for u in units + list(tails.values()):   # eager run, hipGraph capture, first replay
         for _ in range(3):
             u.execute()
@@ -345,6 +359,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from concurrent.futures import ThreadPoolExecutor
+    launcher = ThreadPoolExecutor(max_workers=max(nslots, 2))
+
     def run_designs(n_designs, store):
         """Exactly n_designs designs through the resident batches, at most nslots batches in flight (sliding window: a slot is
         re-issued as soon as its results have been collected)."""
@@ -352,6 +369,7 @@ def main():
         free, inflight = list(units), []
         idx = first = done = 0
         while idx < len(sched) or inflight:
+            launch = []
             while idx < len(sched) and len(inflight) < nslots:
                 size = sched[idx]
                 if size == Bsz:
@@ -360,10 +378,16 @@ def main():
                     u = free.pop(0)
                 else:
                     u = tails[size]   # (the partial batch at the end of the schedule)
-                u.execute()
+                launch.append(u)
                 inflight.append((u, first))
                 first += size
                 idx += 1
+            # a batch's execute is ~1 ms of host time (two hipGraphLaunch calls): when several batches start at once (the
+            # fill of the pipeline) their launches are issued from parallel host threads (the C calls release the GIL)
+            if len(launch) > 1:
+                list(launcher.map(lambda x: x.execute(), launch))
+            elif launch:
+                launch[0].execute()
             u, f0 = inflight.pop(0)
             dst, base = (out, f0) if store else (scratch, 0)
             u.collect([dst[base + j, 0].data_ptr() for j in range(u.size)], [dst[base + j, 1].data_ptr() for j in range(u.size)])

@@ -36,6 +36,7 @@ struct FactorArgs {
     int* route;       // [P] (zeroed per execute)
     int* status;      // plan status flags; [2] is set when a Gram-route bin turns out ill-conditioned, [3] = the highest such bin
                       // (the host then moves the start of the route behind it and re-runs)
+    double cond_limit; // Gram form: cond(B_k) above which status[2..3] are raised (10x the host's estimate limit)
     int jrun;         // Jacobi: consecutive bins per workgroup (warm start from the neighbour's rotations); 0/1 = independent
     int nbins;        // set by the launcher
     int jsplit;       // set by the launcher: the first jsplit bins (Householder route: full Jacobi, the long ones) get one workgroup each

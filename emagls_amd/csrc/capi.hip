@@ -170,6 +170,7 @@ struct emagls_batch {
     bool lanes = false;
     size_t stride = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;                    // false once the caller supplied the stream (emagls_batch_set_stream)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int prof_level = 0;
@@ -200,7 +201,7 @@ struct emagls_batch {
         if (post_exec) hipGraphExecDestroy(post_exec);
         if (post_graph) hipGraphDestroy(post_graph);
         for (auto e : sweep_ev) if (e) hipEventDestroy(e);
-        if (stream) hipStreamDestroy(stream);
+        if (stream && own_stream) hipStreamDestroy(stream);
         for (auto* p : plans) if (p) { p->sync_stream = nullptr; p->owner = nullptr; }
     }
 };
@@ -241,13 +242,14 @@ static inline bool array_kind(int k) { return k == EMAGLS_KIND_EMAGLS || k == EM
 
 // Smallest order n such that every order above it contributes less than 1e-20 of the strongest mode to pwGrid at kr = x:
 // |b_n(x)| (2n+1) / |b_0| <= x^n / (2n-1)!! (2n+1) for the rigid sphere (|j_n(x)| <= x^n / (2n+1)!!; the Wronskian form of b_n
-// divides by x^2 |h_n'(x)| >= (n+1) (2n-1)!! / x^n).  Dropping those orders perturbs the bin's matrix by 1e-4 of its own
+// divides by x^2 |h_n'(x)| >= (n+1) (2n-1)!! / x^n).  Dropping those orders perturbs the bin's matrix by 1/200 of its own
 // FP64 rounding error: the reference's LAPACK SVD cannot tell the difference.
+constexpr double ORDER_NOISE = 1e-18;
 int orders_above_noise(double x, int nmax) {
     double term = 1.0;   // x^n / (2n-1)!!
     for (int n = 1; n <= nmax; ++n) {
         term *= x / (double)(2 * n - 1);
-        if ((double)n > x && term * (2 * n + 1) < 1e-20) return n - 1;
+        if ((double)n > x && term * (2 * n + 1) < ORDER_NOISE) return n - 1;
     }
     return nmax;
 }
@@ -601,7 +603,15 @@ void execute_magls(emagls_plan& p) {
 
 // First bin of the Gram route: cond(B_k) is governed by the ratio of the lowest to the highest modal coefficient the C
 // output channels can carry, |b_0 / b_n| ~ (2n+1)!! / (kr)^n with n = ceil(sqrt(C)) - 1; the route starts where that
-// estimate falls below 3e2 (the Jacobi kernel verifies cond < 3e3 and asks for a re-run otherwise).
+// estimate falls below GRAM_COND_EST (the Jacobi kernel verifies cond < 10x that and asks for a re-run otherwise).  The
+// route's error is eps cond^2 <= 2e-7 eps-relative at the verification limit 3e4, i.e. 2e-8 on M_k: two orders inside the
+// 1e-6 parity tolerance.  With 3e3 the Householder route of the em32 design ends at 1 kHz (bin 21 of 513), where 16 orders are
+// above the noise floor: 256 rows, the register tile with which its kernels fit next to a resident sweep workgroup.
+constexpr double GRAM_COND_EST = 3.0e3;
+double gram_cond_est() {
+    if (const char* e = getenv("EMAGLS_GRAM_COND_EST")) return atof(e);   // (tests force the re-run path with a huge limit)
+    return GRAM_COND_EST;
+}
 int emagls_gram_from(const emagls_plan& p) {
     if (!p.gram_route || p.d.mic_radius <= 0.0) return 0;
     if (const char* e = getenv("EMAGLS_GRAM_ROUTE")) if (e[0] == '0') return 0;
@@ -611,8 +621,7 @@ int emagls_gram_from(const emagls_plan& p) {
     if (n < 1) return 0;
     double dfact = 1.0;
     for (int i = 3; i <= 2 * n + 1; i += 2) dfact *= i;
-    double est_limit = 3.0e2;
-    if (const char* e = getenv("EMAGLS_GRAM_COND_EST")) est_limit = atof(e);   // (tests force the re-run path with a huge limit)
+    const double est_limit = gram_cond_est();
     const double kr_min = std::pow(dfact / est_limit, 1.0 / n);
     const double df = p.d.fs / p.nfft;
     const int kb = (int)std::ceil(kr_min * C_SOUND / (2.0 * kPi * p.d.mic_radius) / df);
@@ -727,6 +736,7 @@ void emagls_pre_sweep(emagls_plan& p) {
     fa.Hq = p.get<cplx>("Hq"); fa.ldHq = ldSh; fa.hq_estride = (int64_t)ls_end * ldSh; fa.ls_end = ls_h;
     fa.hq_conj = 1;
     fa.route = p.get<int>("route"); fa.status = p.get<int>("flag");
+    fa.cond_limit = 10.0 * GRAM_COND_EST;   // (not the env override: the forced-estimate test must trip this check)
     fa.W = p.get<cplx>("W"); fa.sweeps_out = p.get<int>("jsweeps");
     fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
     if (p.nb_gram > 0) {
@@ -1770,6 +1780,16 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
             batch_redo(*b, flags);
         }
         for (size_t j = 0; j < n; ++j) throw_fatal_flags(&flags[4 * j]);
+    });
+}
+int emagls_batch_set_stream(emagls_batch* b, void* stream) {
+    return guarded([&] {
+        if (!b || !stream) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        HIP_CHECK(hipStreamSynchronize(b->stream));
+        if (b->own_stream) HIP_CHECK(hipStreamDestroy(b->stream));
+        b->stream = (hipStream_t)stream;      // (captured graphs are not tied to a stream: they replay on the new one)
+        b->own_stream = false;
+        for (auto* p : b->plans) if (p) p->sync_stream = b->stream;
     });
 }
 int emagls_batch_set_profiling(emagls_batch* b, int level) {

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
         if (gram && tid == 0) {
             double smin = INFINITY;
             for (int i = 0; i < C; ++i) smin = fmin(smin, sig_s[i]);
-            if (!(smax <= 3.0e3 * smin) && a.status) {   // the kr estimate was too optimistic: the host moves the start of the route
+            if (!(smax <= a.cond_limit * smin) && a.status) {   // the kr estimate was too optimistic: the host moves the start of the route
                 atomicExch(a.status + 2, 1);
                 atomicMax(a.status + 3, kb);
             }
@@ -362,7 +362,9 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
 // kernel 3: Z_k = conj(Q2 [N; 0]) by applying the stored reflectors backwards; least-squares bins.
 // =============================================================================================
 template <int NCH, int RPT, int MAXT>
-__global__ void __launch_bounds__(MAXT) factor_back_kernel(FactorArgs a, size_t bstride) {
+__global__ void __launch_bounds__(MAXT)
+// (up to 256 rows: at most 72 VGPRs, so that a 16-wave workgroup fits on a CU next to a resident sweep workgroup, 4 x 72 + 224)
+__attribute__((amdgpu_waves_per_eu(RPT <= 8 ? 7 : 4, 8))) factor_back_kernel(FactorArgs a, size_t bstride) {
     batch_offset(a, bstride);
     const int tid = threadIdx.x;
     const int c = tid / NCH, ch = tid % NCH;

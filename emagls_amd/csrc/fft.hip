@@ -135,15 +135,23 @@ __global__ void __launch_bounds__(1024) grpdelay_median_kernel(const double* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// HRIR spectra.  TD directions per workgroup, both ears packed into one complex transform.
+// HRIR spectra.  8 directions per workgroup (the bin-major outputs are written in runs of 8 directions = 64 bytes of |H|),
+// transformed TS directions at a time, both ears packed into one complex transform, so that the LDS footprint stays at
+// TS * nfft * 16 B + one 16 KB region (twiddles during the transform, the delay phases after it): 82 KB at nfft = 1024, TS = 4.
+// That leaves room for a workgroup of another batch's persistent sweep (77 KB, sweep_persist.hip) on the same CU -- a kernel
+// that needs a whole CU only starts once a CU is completely empty, i.e. between two sweeps, and stalls its batch until then.
+// The |H| values of the first sub-tiles wait in registers for the last one.
 //   kcut0 = 0-based index of the first magnitude-least-squares bin
 //   Hc  [e][kb][d]  complex, kb <  n_c  (bins that need the complex HRTF)
 //   Habs[e][kb - kabs0][d] real, kb >= kabs0
 // mode 0: fractional delay by -grpd[e] (applySubsampleDelay);  mode 1: circshift by -round(grpd[e])
 // ---------------------------------------------------------------------------------------------
+constexpr int HF_TD = 8;      // directions per workgroup
+constexpr int HF_MAXS = 3;    // bins per thread: ceil((nfft/2+1) / 512) for nfft <= 2048
+template <int TS>
 __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict__ hL, const double* __restrict__ hR,
                                                        int64_t L, int64_t D, const int64_t* __restrict__ didx, int nfft,
-                                                       int log2n, int TD,
+                                                       int log2n,
                                                        const cplx* __restrict__ tw, const double* __restrict__ grpd,
                                                        int mode, int n_c, int kabs0, cplx* __restrict__ Hc,
                                                        double* __restrict__ Habs, int64_t ldD, double* __restrict__ HcT, int ldT,
@@ -151,83 +159,119 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
     hL = boff(hL, bstride); hR = boff(hR, bstride); didx = boff(didx, bstride); tw = boff(tw, bstride); grpd = boff(grpd, bstride); Hc = boff(Hc, bstride); Habs = boff(Habs, bstride);
     HcT = boff(HcT, bstride);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cplx* tws = reinterpret_cast<cplx*>(smem);  // nfft/2
-    cplx* buf = tws + nfft / 2;                 // TD * nfft
-    cplx* phs = buf + (size_t)TD * nfft;        // [2][P] delay phase per ear and bin (mode 0)
     const int P = nfft / 2 + 1;
-    const int64_t d0 = (int64_t)blockIdx.x * TD;
-    const int nt = (int)min((int64_t)TD, D - d0);
+    cplx* tws = reinterpret_cast<cplx*>(smem);  // nfft/2 twiddles while the stages run ...
+    cplx* phs = tws;                            // ... [2][P] delay phase per ear and bin (mode 0) afterwards
+    cplx* buf = tws + 2 * P;                    // TS * nfft
+    const int64_t d0 = (int64_t)blockIdx.x * HF_TD;
+    const int nt = (int)min((int64_t)HF_TD, D - d0);
     const double gL = grpd[0], gR = grpd[1];
     int sL = 0, sR = 0;
     if (mode == 1) { sL = (int)round(gL); sR = (int)round(gR); }
-    for (int j = threadIdx.x; j < nfft / 2; j += blockDim.x) tws[j] = tw[j];
-    if (mode == 0) {
-        // exp(-1j*2*pi*omega*(-grpD)), omega = linspace(0, 0.5, nfft/2+1): once per workgroup, not once per direction
-        for (int j = threadIdx.x; j < 2 * P; j += blockDim.x) {
-            const int e = j / P, kb = j - e * P;
-            double sn, cs;
-            sincos((6.283185307179586 * ((double)kb / (double)nfft)) * (e ? gR : gL), &sn, &cs);
-            if (kb == P - 1) sn = 0.0;  // Nyquist bin forced real (applySubsampleDelay.m:12)
-            phs[j] = mk(cs, sn);
-        }
-    }
     // Zero padding (mode 0, no circular shift): with L * 2^z <= nfft only every 2^z-th entry of the bit-reversed input is
     // non-zero, and the first z radix-2 stages turn each group of 2^z entries into copies of its first one.  The buffer is
     // filled with that state directly and the transform starts at stage z (3 of 10 stages at 128 taps, nfft 1024).
     int zskip = 0;
     if (mode == 0) while (zskip < log2n && (L << (zskip + 1)) <= (int64_t)nfft) ++zskip;
-    for (int idx = threadIdx.x; idx < nt * nfft; idx += blockDim.x) {
-        const int t = idx >> log2n, j = idx & (nfft - 1);
-        const int n = (int)bitrev((unsigned)(j & ~((1 << zskip) - 1)), log2n);
-        // circshift(h, -s): out[n] = h[(n + s) mod nfft]; zero beyond the L recorded taps
-        int nl = (n + sL) % nfft; if (nl < 0) nl += nfft;
-        int nr = (n + sR) % nfft; if (nr < 0) nr += nfft;
-        const int64_t dsrc = didx ? didx[d0 + t] : d0 + t;  // optional gather of matched directions
-        const double a = (nl < L) ? hL[dsrc * L + nl] : 0.0;
-        const double c = (nr < L) ? hR[dsrc * L + nr] : 0.0;
-        buf[(size_t)t * nfft + j] = mk(a, c);
-    }
-    __syncthreads();
-    lds_fft_stages<false>(buf, tws, nfft, log2n, nt, zskip);
-    // unpack ears, apply delay phase, write transposed (bin-major, directions contiguous)
-    for (int idx = threadIdx.x; idx < P * TD; idx += blockDim.x) {
-        const int kb = idx / TD, t = idx - kb * TD;
-        if (t >= nt) continue;
-        const cplx* x = buf + (size_t)t * nfft;
-        const cplx z = x[kb], zc = conj(x[(nfft - kb) & (nfft - 1)]);
-        cplx HLv = mk(0.5 * (z.x + zc.x), 0.5 * (z.y + zc.y));
-        cplx HRv = mk(0.5 * (z.y - zc.y), -0.5 * (z.x - zc.x));  // (z - zc) / (2i)
+    double habs[HF_MAXS][2][HF_TD];
+#pragma unroll
+    for (int s = 0; s < HF_MAXS; ++s)
+#pragma unroll
+        for (int t = 0; t < HF_TD; ++t) habs[s][0][t] = habs[s][1][t] = 0.0;
+
+#pragma unroll
+    for (int sub = 0; sub < HF_TD / TS; ++sub) {
+        const int t0 = sub * TS;
+        const int nts = min(max(nt - t0, 0), TS);
+        if (sub > 0) __syncthreads();   // (the previous sub-tile's readers of phs / buf are done)
+        for (int j = threadIdx.x; j < nfft / 2; j += blockDim.x) tws[j] = tw[j];
+        for (int idx = threadIdx.x; idx < nts * nfft; idx += blockDim.x) {
+            const int t = idx >> log2n, j = idx & (nfft - 1);
+            const int n = (int)bitrev((unsigned)(j & ~((1 << zskip) - 1)), log2n);
+            // circshift(h, -s): out[n] = h[(n + s) mod nfft]; zero beyond the L recorded taps
+            int nl = (n + sL) % nfft; if (nl < 0) nl += nfft;
+            int nr = (n + sR) % nfft; if (nr < 0) nr += nfft;
+            const int64_t dsrc = didx ? didx[d0 + t0 + t] : d0 + t0 + t;  // optional gather of matched directions
+            const double a = (nl < L) ? hL[dsrc * L + nl] : 0.0;
+            const double c = (nr < L) ? hR[dsrc * L + nr] : 0.0;
+            buf[(size_t)t * nfft + j] = mk(a, c);
+        }
+        __syncthreads();
+        lds_fft_stages<false>(buf, tws, nfft, log2n, nts, zskip);   // (ends with a barrier: the twiddles are free)
         if (mode == 0) {
-            HLv = HLv * phs[kb];
-            HRv = HRv * phs[P + kb];
+            // exp(-1j*2*pi*omega*(-grpD)), omega = linspace(0, 0.5, nfft/2+1): once per sub-tile, not once per direction
+            for (int j = threadIdx.x; j < 2 * P; j += blockDim.x) {
+                const int e = j / P, kb = j - e * P;
+                double sn, cs;
+                sincos((6.283185307179586 * ((double)kb / (double)nfft)) * (e ? gR : gL), &sn, &cs);
+                if (kb == P - 1) sn = 0.0;  // Nyquist bin forced real (applySubsampleDelay.m:12)
+                phs[j] = mk(cs, sn);
+            }
+            __syncthreads();
         }
-        const int64_t d = d0 + t;
-        if (kb < n_c) {
-            Hc[((int64_t)0 * n_c + kb) * ldD + d] = HLv;
-            Hc[((int64_t)1 * n_c + kb) * ldD + d] = HRv;
+        // unpack ears, apply delay phase; complex rows are written now, |H| is kept for the 64-byte runs at the end
+#pragma unroll
+        for (int s = 0; s < HF_MAXS; ++s) {
+            const int kb = threadIdx.x + s * 512;
+            if (kb < P) {
+#pragma unroll
+                for (int t = 0; t < TS; ++t) {
+                    if (t < nts) {
+                        const cplx* x = buf + (size_t)t * nfft;
+                        const cplx z = x[kb], zc = conj(x[(nfft - kb) & (nfft - 1)]);
+                        cplx HLv = mk(0.5 * (z.x + zc.x), 0.5 * (z.y + zc.y));
+                        cplx HRv = mk(0.5 * (z.y - zc.y), -0.5 * (z.x - zc.x));  // (z - zc) / (2i)
+                        if (mode == 0) {
+                            HLv = HLv * phs[kb];
+                            HRv = HRv * phs[P + kb];
+                        }
+                        const int64_t d = d0 + t0 + t;
+                        if (kb < n_c) {
+                            Hc[((int64_t)0 * n_c + kb) * ldD + d] = HLv;
+                            Hc[((int64_t)1 * n_c + kb) * ldD + d] = HRv;
+                        }
+                        // |H| = n rsqrt(n): spectra are O(1), |H|^2 can neither overflow nor underflow
+                        const double nl2 = norm2(HLv), nr2 = norm2(HRv);
+                        habs[s][0][t0 + t] = nl2 > 0.0 ? nl2 * fast_rsqrt(nl2) : 0.0;
+                        habs[s][1][t0 + t] = nr2 > 0.0 ? nr2 * fast_rsqrt(nr2) : 0.0;
+                    }
+                }
+            }
         }
-        if (kb >= kabs0) {
-            const int64_t na = P - kabs0;
-            // |H| = n rsqrt(n): spectra are O(1), |H|^2 can neither overflow nor underflow
-            const double nl2 = norm2(HLv), nr2 = norm2(HRv);
-            Habs[((int64_t)0 * na + (kb - kabs0)) * ldD + d] = nl2 > 0.0 ? nl2 * fast_rsqrt(nl2) : 0.0;
-            Habs[((int64_t)1 * na + (kb - kabs0)) * ldD + d] = nr2 > 0.0 ? nr2 * fast_rsqrt(nr2) : 0.0;
+        // direction-major copy of the complex rows, HcT[d][2 (e n_c + kb) + re/im]: the K-major operand of the MFMA product
+        // H conj(Yc) of the least-squares rows (launch_hy_conj_mfma)
+        if (HcT) {
+            for (int idx = threadIdx.x; idx < TS * n_c; idx += blockDim.x) {
+                const int t = idx / n_c, kb = idx - t * n_c;
+                if (t >= nts) continue;
+                const cplx* x = buf + (size_t)t * nfft;
+                const cplx z = x[kb], zc = conj(x[(nfft - kb) & (nfft - 1)]);
+                cplx HLv = mk(0.5 * (z.x + zc.x), 0.5 * (z.y + zc.y));
+                cplx HRv = mk(0.5 * (z.y - zc.y), -0.5 * (z.x - zc.x));
+                if (mode == 0) { HLv = HLv * phs[kb]; HRv = HRv * phs[P + kb]; }
+                double* row = HcT + (int64_t)(d0 + t0 + t) * ldT;
+                row[2 * kb] = HLv.x; row[2 * kb + 1] = HLv.y;
+                row[2 * (n_c + kb)] = HRv.x; row[2 * (n_c + kb) + 1] = HRv.y;
+            }
         }
     }
-    // direction-major copy of the complex rows, HcT[d][2 (e n_c + kb) + re/im]: the K-major operand of the MFMA product
-    // H conj(Yc) of the least-squares rows (launch_hy_conj_mfma)
-    if (HcT) {
-        for (int idx = threadIdx.x; idx < TD * n_c; idx += blockDim.x) {
-            const int t = idx / n_c, kb = idx - t * n_c;
-            if (t >= nt) continue;
-            const cplx* x = buf + (size_t)t * nfft;
-            const cplx z = x[kb], zc = conj(x[(nfft - kb) & (nfft - 1)]);
-            cplx HLv = mk(0.5 * (z.x + zc.x), 0.5 * (z.y + zc.y));
-            cplx HRv = mk(0.5 * (z.y - zc.y), -0.5 * (z.x - zc.x));
-            if (mode == 0) { HLv = HLv * phs[kb]; HRv = HRv * phs[P + kb]; }
-            double* row = HcT + (int64_t)(d0 + t) * ldT;
-            row[2 * kb] = HLv.x; row[2 * kb + 1] = HLv.y;
-            row[2 * (n_c + kb)] = HRv.x; row[2 * (n_c + kb) + 1] = HRv.y;
+    // |H| rows: 8 consecutive directions per (bin, ear) and thread
+    const int64_t na = P - kabs0;
+#pragma unroll
+    for (int s = 0; s < HF_MAXS; ++s) {
+        const int kb = threadIdx.x + s * 512;
+        if (kb < P && kb >= kabs0) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                double* row = Habs + ((int64_t)e * na + (kb - kabs0)) * ldD + d0;   // (ldD and d0 are multiples of 8: 64-byte aligned)
+                if (nt == HF_TD) {
+#pragma unroll
+                    for (int t = 0; t < HF_TD; t += 2) *reinterpret_cast<double2*>(row + t) = make_double2(habs[s][e][t], habs[s][e][t + 1]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < HF_TD; ++t) if (t < nt) row[t] = habs[s][e][t];
+                }
+            }
         }
     }
 }
@@ -394,18 +438,34 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
                      const void* tw, const double* grpd, int mode, int n_c, int kabs0, void* Hc, double* Habs,
                      int64_t ldD, hipStream_t st, double* HcT, int ldT) {
     const int log2n = ilog2(nfft);
-    int TD = 8;
-    const size_t ph_bytes = (size_t)(nfft + 2) * 16;
-    while (TD > 1 && (size_t)TD * nfft * 16 + (size_t)nfft * 8 + ph_bytes > 150 * 1024) TD >>= 1;
-    const size_t sm = (size_t)TD * nfft * 16 + (size_t)nfft * 8 + ph_bytes;
+    const int P = nfft / 2 + 1;
+    if (P > HF_MAXS * 512) throw Error(2, "HRIR FFT: nfft above 2048 is not supported");
+    // directions per sub-tile: the largest power of two whose buffers stay below the LDS a CU has left next to a resident
+    // sweep workgroup (160 KB - 77 KB)
+    const size_t budget = 83 * 1024, shared = (size_t)2 * P * 16;
+    int TS = HF_TD;
+    while (TS > 1 && (size_t)TS * nfft * 16 + shared > budget) TS >>= 1;
+    const size_t sm = (size_t)TS * nfft * 16 + shared;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void*)real_fft_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hrir_fft_kernel<<<bgrid((unsigned)ceil_div(D, TD)), 512, sm, st>>>(hL, hR, L, D, didx, nfft, log2n, TD, (const cplx*)tw, grpd, mode,
-                                                               n_c, kabs0, (cplx*)Hc, Habs, ldD, HcT, ldT, batch_ctx().stride);
+    const dim3 grid = bgrid((unsigned)ceil_div(D, HF_TD));
+#define EMAGLS_HF(TSV)                                                                                                               \
+    hrir_fft_kernel<TSV><<<grid, 512, sm, st>>>(hL, hR, L, D, didx, nfft, log2n, (const cplx*)tw, grpd, mode, n_c, kabs0, (cplx*)Hc, \
+                                                Habs, ldD, HcT, ldT, batch_ctx().stride)
+    switch (TS) {
+        case 8: EMAGLS_HF(8); break;
+        case 4: EMAGLS_HF(4); break;
+        case 2: EMAGLS_HF(2); break;
+        default: EMAGLS_HF(1); break;
+    }
+#undef EMAGLS_HF
     KERNEL_CHECK();
 }
 

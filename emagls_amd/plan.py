@@ -140,6 +140,10 @@ class Batch:
     def set_profiling(self, level):
         L.check(self._lib.emagls_batch_set_profiling(self._h, int(level)))
 
+    def set_stream(self, hip_stream):
+        """Run on the caller's hipStream_t (an integer handle, e.g. torch.cuda.Stream().cuda_stream); the caller keeps it alive."""
+        L.check(self._lib.emagls_batch_set_stream(self._h, C.c_void_p(int(hip_stream))))
+
     def sweep_time_ms(self):
         ms = C.c_double(0.0)
         L.check(self._lib.emagls_batch_sweep_time(self._h, C.byref(ms)))

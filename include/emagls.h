@@ -266,6 +266,11 @@ int emagls_batch_get_filters(emagls_batch* batch, void* const* wL, void* const* 
 /* profiling: with level >= 1 HIP events bracket the sweep launch of every execute (on the batch stream);
  * emagls_batch_sweep_time returns the duration in ms of the last execute's sweep (synchronises the batch). */
 int emagls_batch_set_profiling(emagls_batch* batch, int level);
+/* Run the batch on the caller's hipStream_t instead of its own (the caller keeps ownership and must not use the stream while a
+ * batch call is in progress).  Why one would: the HIP runtime multiplexes all streams of a process onto 4 hardware queues, and
+ * two batches whose streams land on the same queue execute strictly one after the other; a caller that creates its streams
+ * first and hands one to each batch in flight decides the mapping itself (bench.py does). */
+int emagls_batch_set_stream(emagls_batch* batch, void* hip_stream);
 int emagls_batch_sweep_time(emagls_batch* batch, double* ms);
 int emagls_batch_destroy(emagls_batch* batch);
 

@@ -84,20 +84,25 @@ def test_stage_basis_gram_cholesky_q(emagls_plan, grids):
     Yc = p.debug("Yc", np.complex128).reshape(-1, ldS)
     assert np.abs(Yc[:D, :S] - np.conj(Yo)).max() < 1e-9
     assert np.all(Yc[D:, :S] == 0)
-    R = np.triu(p.debug("R", np.complex128, (S, S)))
-    G = Yc[:D, :S].conj().T @ Yc[:D, :S]
+    # the Cholesky factor covers the orders the Householder-route bins need (hh_orders: the higher ones are below the
+    # noise floor of those low bins): the leading Sh x Sh block of the Gram matrix
+    Sh = i.hh_orders ** 2
+    ldSh = -(-Sh // 64) * 64
+    assert 25 <= Sh <= S
+    R = np.triu(p.debug("R", np.complex128, (Sh, Sh)))
+    G = Yc[:D, :Sh].conj().T @ Yc[:D, :Sh]
     assert rel(R.conj().T @ R, G) < 1e-13
     # Q = conj(Y) R^-1 is not materialised for complex-basis eMagLS designs (only H conj(Q) and, for ill-conditioned
     # bins, Z_k R^-H are formed): the Cholesky factor must make it orthonormal
-    Q = np.linalg.solve(R.T, Yc[:D, :S].T).T
-    assert np.abs(Q.conj().T @ Q - np.eye(S)).max() < 1e-13
+    Q = np.linalg.solve(R.T, Yc[:D, :Sh].T).T
+    assert np.abs(Q.conj().T @ Q - np.eye(Sh)).max() < 1e-13
     Rinv = p.debug("Rinv", np.complex128).reshape(-1, 32, 32)
-    for J in range(S // 32):
+    for J in range(Sh // 32):
         assert rel(Rinv[J] @ R[32 * J:32 * J + 32, 32 * J:32 * J + 32], np.eye(32)) < 1e-13
     # least-squares rows: Hq holds conj(H conj(Q)) for the bins below k_cut
     kcut0 = i.k_cut - 1
     Hc = p.debug("Hc", np.complex128).reshape(2, kcut0, ldD)[:, :, :D]
-    Hq = p.debug("Hq", np.complex128).reshape(2, kcut0, ldS)[:, :, :S]
+    Hq = p.debug("Hq", np.complex128).reshape(2, kcut0, ldSh)[:, :, :Sh]
     for e in range(2):
         assert rel(np.conj(Hq[e, 1:]), Hc[e, 1:] @ np.conj(Q)) < 1e-12
 
@@ -115,9 +120,12 @@ def test_stage_array_model(emagls_plan, grids):
     bo = -O.sphModalCoeffs(19, 2 * np.pi * f / 343.0 * grids["mic_radius"])
     b = p.debug("bn", np.complex128, (P, 20))
     assert (np.abs(b[1:] - bo[1:]) / np.abs(bo[1:])).max() < 1e-12
-    R = np.triu(p.debug("R", np.complex128, (S, S)))
-    Tn = p.debug("Tn", np.complex128, (20, C, ldS))[:, :, :S]
-    for n in (0, 3, 19):
+    nh = p.info().hh_orders
+    Sh = nh * nh
+    ldSh = -(-Sh // 64) * 64
+    R = np.triu(p.debug("R", np.complex128, (Sh, Sh)))
+    Tn = p.debug("Tn", np.complex128)[:nh * C * ldSh].reshape(nh, C, ldSh)[:, :, :Sh]
+    for n in (0, 3, nh - 1):
         blk = slice(n * n, (n + 1) ** 2)
         To = (R[:, blk] @ Eo[:, blk].T).T  # [c][s]
         assert rel(Tn[n], To) < 1e-12
@@ -148,15 +156,18 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
     ldD = -(-D // 64) * 64
     i = p.info()
     P, kcut0 = i.num_pos_freqs, i.k_cut - 1
-    # routes: bins [1, hh_end) Householder QR + Jacobi in S space, bins [gram_from, P) through the Gram matrices; on this
-    # 4.2 cm array no order is negligible at the last Householder bin (hh_orders = 20: R, T_n cover all of S)
-    assert i.hh_orders == 20 and 1 < i.gram_from == i.hh_end <= kcut0 + 1 and i.g_first == min(i.gram_from, kcut0)
-    hh_end, g0 = i.hh_end, i.g_first
-    Tn = p.debug("Tn", np.complex128, (20, C, ldS))[:, :, :S]
+    # routes: bins [1, hh_end) Householder QR + Jacobi in S space on the orders above the noise floor of those bins
+    # (hh_orders: R, T_n, Z cover Sh = hh_orders^2 rows), bins [gram_from, P) through the Gram matrices
+    assert 5 <= i.hh_orders <= 20 and 1 < i.gram_from == i.hh_end <= kcut0 + 1 and i.g_first == min(i.gram_from, kcut0)
+    hh_end, g0, nh = i.hh_end, i.g_first, i.hh_orders
+    Sh = nh * nh
+    ldSh = -(-Sh // 64) * 64
+    Tn = p.debug("Tn", np.complex128)[:nh * C * ldSh].reshape(nh, C, ldSh)[:, :, :Sh]
     bn = p.debug("bn", np.complex128, (P, 20))
     Yc = p.debug("Yc", np.complex128).reshape(-1, ldS)[:D, :S]
-    Q = np.linalg.solve(np.triu(p.debug("R", np.complex128, (S, S))).T, Yc.T).T  # (not materialised on the GPU)
-    Z = p.debug("Z", np.complex128)[:hh_end * C * ldS].reshape(hh_end, C, ldS)[:, :, :S]
+    E = p.debug("E", np.complex128, (C, ldS))[:, :S]
+    Qh = np.linalg.solve(np.triu(p.debug("R", np.complex128, (Sh, Sh))).T, Yc[:, :Sh].T).T  # (not materialised on the GPU)
+    Z = p.debug("Z", np.complex128)[:hh_end * C * ldSh].reshape(hh_end, C, ldSh)[:, :, :Sh]
     sv = p.debug("sv", np.float64).reshape(P, C)
     js = p.debug("jsweeps", np.int32)
     route = p.debug("route", np.int32)   # 0 Householder + Jacobi, 1 Gram + Jacobi, 2 Gram + Cholesky inverse (no SVD)
@@ -166,33 +177,43 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
     G = p.debug("G", np.complex128)[:nsw * C * ldD].reshape(nsw, C, ldD)[:, :, :D]
     Mw = p.debug("Mw", np.complex128)[:P * C * C].reshape(P, C, C)  # bin kb is stored at slot kb-1
 
-    def Bk(kb):
+    rep = np.repeat(np.arange(20), 2 * np.arange(20) + 1)
+
+    def Xk(kb):
+        """pwGrid_k.' = conj(Y) diag(b_n) E^T, D x C, all orders"""
         b = bn[kb].copy()
         if kb == P - 1:
             b = b.real
-        return np.tensordot(b, Tn, axes=(0, 0)).T  # S x C
+        return Yc @ (b[rep][:, None] * E.T)
 
-    for kb in (1, 2, kcut0 - 1, kcut0, kcut0 + 1, P // 2, P - 1):
-        B = Bk(kb)
-        U, s, Vh = np.linalg.svd(B, full_matrices=False)
+    def Bk(kb):
+        """the S-space matrix of a Householder-route bin: sum_n b_n T_n over the orders kept, Sh x C"""
+        return np.tensordot(bn[kb][:nh], Tn, axes=(0, 0)).T
+
+    for kb in sorted({1, 2, hh_end - 1, hh_end, kcut0 - 1, kcut0, kcut0 + 1, P // 2, P - 1}):
+        X = Xk(kb)
+        U, s, Vh = np.linalg.svd(X, full_matrices=False)
+        if kb < hh_end:   # the truncated S-space matrix has the singular values of the full pwGrid_k to rounding
+            B = Bk(kb)
+            assert np.abs(np.linalg.svd(B, compute_uv=False) - s).max() < 1e-13 * s[0]
+        AtA = X.conj().T @ X
         if route[kb] == 2:
             # direct route (no singular value is clipped: M = (B^H B)^-1): sv holds certified bounds, not the values
             assert sv[kb].max() >= s[0] * (1 - 1e-12) and sv[kb].min() <= s[-1] * (1 + 1e-12)
             assert sv[kb].max() <= 100 * sv[kb].min()
-            assert rel(Mw[kb - 1], np.linalg.inv(B.conj().T @ B)) < 1e-10
+            assert rel(Mw[kb - 1], np.linalg.inv(AtA)) < 1e-10
         else:
             # (well-conditioned swept bins take the Gram route: error eps cond^2 instead of eps)
-            assert np.abs(np.sort(sv[kb])[::-1] - s).max() < (1e-13 if kb <= kcut0 + 1 else 1e-10) * s[0]
+            assert np.abs(np.sort(sv[kb])[::-1] - s).max() < (1e-13 if kb < hh_end else 1e-9) * s[0]
         sreg = 1 / np.maximum(s, 0.01 * s[0])
-        Zo = np.conj(U) @ (sreg[:, None] * Vh.conj())
+        Yri_o = np.conj(U) @ (sreg[:, None] * Vh.conj())       # Y_reg_inv_k, D x C  (lib/getEMagLsFilters.m:90)
         if kb < min(kcut0, hh_end):  # Z_k is only formed for the Householder-route least-squares bins (and for ill-conditioned swept bins)
-            assert rel(Z[kb].T, Zo) < 1e-8, (kb, rel(Z[kb].T, Zo))
+            assert rel(np.conj(Qh) @ Z[kb].T, Yri_o) < 1e-8, (kb, rel(np.conj(Qh) @ Z[kb].T, Yri_o))
         if kb >= g0:
-            X = Q @ B  # pwGrid.'  (D x C)
             assert rel(G[kb - g0].T, X) < 1e-12
             # Y_reg_inv_k = conj(G_k) conj(M_k): the sweep applies conj(M_k) after the cross-workgroup sum
             Yri = np.conj(G[kb - g0].T) @ np.conj(Mw[kb - 1])
-            assert rel(Yri, np.conj(Q) @ Zo) < 1e-9, (kb, rel(Yri, np.conj(Q) @ Zo))
+            assert rel(Yri, Yri_o) < 1e-8, (kb, rel(Yri, Yri_o))
     wL, wR = p.get_filters()
     oL, oR = O.getEMagLsFilters(emagls_plan["hL"], emagls_plan["hR"], emagls_plan["azi"], emagls_plan["zen"],
                                 grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "complex")
