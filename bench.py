@@ -225,7 +225,6 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--prio", type=int, default=0, help="1: high-priority stream for the first full batch")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("EMAGLS_BENCH_SLOTS", str(SLOTS))),
                     help="resident batches per GPU (profiling runs use 1)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", str(BSZ))),
@@ -272,9 +271,9 @@ def main():
     # sweep).  The streams of the batches that can be in flight together are therefore created here, before the library
     # creates any stream of its own, and handed to the batches (emagls_batch_set_stream): consecutive streams land on
     # different queues.  The tail batches come first so that [full, full, tail] never shares a queue.
-    # --prio 1: the first full batch runs on a high-priority stream, so that in a short run (pipeline fill) ONE batch reaches
-    # its sweep early instead of all of them late
-    lane_streams = [torch.cuda.Stream(device=local_rank, priority=(-1 if (args.prio and j == 2) else 0)) for j in range(nslots + 2)]
+    # (tried: a high-priority stream for the first batch, so that ONE batch reaches its sweep early in a short run: slower, 1357
+    # vs 1400 sets/s at 20 steps and 1750 vs 1910 at 128)
+    lane_streams = [torch.cuda.Stream(device=local_rank) for _ in range(nslots + 2)]
     next_stream = iter(lane_streams)
 
     def make_plan(seed_offset, streams=1):

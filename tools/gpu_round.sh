@@ -23,8 +23,14 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_single
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_batch -o bench -- python3 $R/bench.py --steps 32 --warmup 0 --slots 1 --batch 8 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_batch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${tag}_prof_slots4 -o bench -- python3 $R/bench.py --steps 128 --warmup 0 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_slots4.log 2>&1
 if [ "$pmc" = "pmc" ]; then
-  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_pmc_fetch -o pmc -- python3 $R/bench.py --steps 8 --warmup 0 --slots 1 --batch 1 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_pmc_fetch.log 2>&1
-  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_pmc_write -o pmc -- python3 $R/bench.py --steps 8 --warmup 0 --slots 1 --batch 1 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_pmc_write.log 2>&1
+  # counters in passes of their own (kernel-trace only next to --pmc); one batch of 8 designs, 4 batches executed
+  PMCCMD="python3 $R/bench.py --steps 32 --warmup 0 --slots 1 --batch 8 --no-cpu-baseline --no-sh-roofline --no-secondary"
+  for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do
+    timeout 400 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/${tag}_pmc_$c -o pmc -- $PMCCMD > $R/gpurun_out/${tag}_pmc_$c.log 2>&1
+  done
+  cd $R
+  python tools/pmc_summary.py gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_pmc.md gpurun_out/${tag}_pmc_* > gpurun_out/${tag}_pmc_summary.log 2>&1
+  rm -rf gpurun_out/${tag}_pmc_FETCH_SIZE gpurun_out/${tag}_pmc_WRITE_SIZE gpurun_out/${tag}_pmc_SQ_*
 fi
 cd $R
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_single 1 > gpurun_out/${tag}_kernels_single.md 2>&1
