@@ -50,16 +50,29 @@ def read(d):
     acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))   # kernel -> counter -> dispatch-less sum
     cnt = defaultdict(lambda: defaultdict(int))
     # one row per (dispatch, counter instance/dimension): sum over instances, then average over dispatches
-    q2 = (f"select s.kernel_name, i.{namecol}, d.id, sum(e.value), d.grid_size_z / d.workgroup_size_z, d.grid_size_x / d.workgroup_size_x "
+    q2 = (f"select s.kernel_name, i.{namecol}, d.id, sum(e.value), d.grid_size_z / d.workgroup_size_z, d.end - d.start "
           f"from {pe} e join {pi} i on e.pmc_id = i.id "
-          f"join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id group by d.id, i.{namecol}")
+          f"join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id group by d.id, i.{namecol} order by d.id")
     out = defaultdict(lambda: defaultdict(list))
-    for kname, cname, _, val, gz, gx in cur.execute(q2):
-        lanes = gz == LANES or ("sweep_persist" in kname and gx >= 25 * LANES)
-        if not lanes:
+    dur = defaultdict(list)
+    sweeps = defaultdict(list)
+    for kname, cname, _, val, gz, ns in cur.execute(q2):
+        if "sweep_persist" in kname:      # (design = blockIdx.x there, not grid.z: the batch launches are the LAST ones of the run)
+            sweeps[(kname, cname)].append((val, ns))
+            continue
+        if gz != LANES:
             continue          # (the single-design plan bench.py also runs: not part of the per-batch figures)
         out[kname][cname].append(val)
-    return {k: {c: (sum(v) / len(v), len(v)) for c, v in cs.items()} for k, cs in out.items()}
+        dur[kname].append(ns)
+    n_exec = max([len(v) for k, cs in out.items() if "dspace_g" in k for v in cs.values()] or [1])
+    for (kname, cname), lst in sweeps.items():
+        lst = lst[-n_exec:]
+        out[kname][cname] = [v for v, _ in lst]
+        dur[kname] = [ns for _, ns in lst]
+    res = {k: {c: (sum(v) / len(v), len(v)) for c, v in cs.items()} for k, cs in out.items()}
+    for k in res:
+        res[k]["avg_us"] = (sum(dur[k]) / len(dur[k]) / 1e3, len(dur[k]))
+    return res
 
 
 def main():
@@ -79,6 +92,10 @@ def main():
         e = {c: v for c, (v, n) in cs.items()}
         nd = max(n for _, n in cs.values())
         e["dispatches"] = nd
+        if e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and e.get("avg_us", 0) > 0:
+            # gfx94x MfmaUtil formula (no gfx950 derived counters ship): busy cycles summed over SIMDs / (cycles x CUs x 4)
+            e["mfma_util_pct"] = 100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["avg_us"] * 1e-6 * 2.4e9 * 256 * 4)
+            e["mfma_f64_tflops"] = e.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) * 512 / (e["avg_us"] * 1e-6) / 1e12
         if "FETCH_SIZE" in e or "WRITE_SIZE" in e:
             e["fetch_kb"] = e.get("FETCH_SIZE", 0.0)
             e["write_kb"] = e.get("WRITE_SIZE", 0.0)
