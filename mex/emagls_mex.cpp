@@ -1,12 +1,15 @@
 // MEX gateway for the MI355X eMagLS library (include/emagls.h).  One gateway, dispatched on a
 // command string, so that the MATLAB wrappers in this directory keep the reference's file names and
 // signatures (lib/getLsFilters.m:1-2, lib/getMagLsFilters.m:1-2, lib/getEMagLsFilters.m:1-2,
-// lib/getEMagLs2Filters.m:1-2, lib/getEMagLsFiltersFromAtf.m:1, dependencies/binauralDecode.m:1-2).
+// lib/getEMagLs2Filters.m:1-2, lib/getEMagLsFiltersFromAtf.m:1, lib/getEMagLsFiltersEMAinCH.m:1-2, lib/getMagLsFilters2D.m:1,
+// lib/getMagLsSphericalHeadFilter.m:1, lib/getMagLsArrayDiffuseFilter.m:1, dependencies/getRadialFilter.m:1,
+// dependencies/applyRadialFilter.m:1, dependencies/binauralDecode.m:1-2).
 //
 // Build on a machine that has MATLAB (R2018a+, interleaved complex) and ROCm:
 //     mex -R2018a emagls_mex.cpp -I../include -L../emagls_amd/lib -lemagls
 // This container has neither mex.h nor MATLAB, so the file is compiled nowhere here; it is a thin
 // adapter: argument checks, pointer hand-over, mxArray allocation, error forwarding.
+#include <cctype>
 #include <cstring>
 #include <string>
 
@@ -34,6 +37,26 @@ mxArray* out_matrix(mwSize rows, mwSize cols, int basis) {
     return mxCreateDoubleMatrix(rows, cols, basis == EMAGLS_BASIS_COMPLEX ? mxCOMPLEX : mxREAL);
 }
 void* out_ptr(mxArray* a) { return mxIsComplex(a) ? (void*)mxGetComplexDoubles(a) : (void*)mxGetDoubles(a); }
+const void* in_ptr(const mxArray* a) { return mxIsComplex(a) ? (const void*)mxGetComplexDoubles(a) : (const void*)mxGetDoubles(a); }
+// a caller-evaluated SH matrix must be real / complex like the basis asked for
+const void* basis_matrix(const mxArray* a, int basis, mwSize rows, mwSize cols, const char* what) {
+    if (!mxIsDouble(a) || mxGetM(a) != rows || mxGetN(a) != cols) mexErrMsgIdAndTxt("eMagLS:arg", "%s must be a %d x %d double matrix", what, (int)rows, (int)cols);
+    if ((basis == EMAGLS_BASIS_COMPLEX) != (bool)mxIsComplex(a)) mexErrMsgIdAndTxt("eMagLS:arg", "%s does not match shDefinition", what);
+    return in_ptr(a);
+}
+int radial_type(const mxArray* a) {
+    char buf[16] = {0};
+    mxGetString(a, buf, sizeof buf);
+    for (char* q = buf; *q; ++q) *q = (char)tolower(*q);     // strcmpi / lower() in getRadialFilter.m:44,56
+    if (!std::strcmp(buf, "tikhonov")) return EMAGLS_RADIAL_TIKHONOV;
+    if (!std::strcmp(buf, "softlimit")) return EMAGLS_RADIAL_SOFTLIMIT;
+    if (!std::strcmp(buf, "full")) return EMAGLS_RADIAL_FULL;
+    if (!std::strcmp(buf, "none")) return EMAGLS_RADIAL_NONE;
+    mexErrMsgIdAndTxt("eMagLS:arg", "Unkown radialFilter parameter \"%s\".", buf);
+    return 0;
+}
+// the plans the one-shot entry points cache (device buffers, captured graphs) are released when the MEX file is cleared
+void at_exit() { emagls_cache_clear(); }
 
 }  // namespace
 
@@ -42,8 +65,21 @@ void* out_ptr(mxArray* a) { return mxIsComplex(a) ? (void*)mxGetComplexDoubles(a
 // emagls_mex('emagls',  hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition)
 // emagls_mex('emagls2', ... same ...)
 // emagls_mex('fromatf', hL, hR, hrirGridAziZen, atfIrs, atfGridAziZen, fs, filterLen, fTrans)
-// emagls_mex('decode',  in, wL, wR, compensateDelay)
+// emagls_mex('emainch', hL, hR, azi, zen, micRadius, micAzi, order, fs, len, shDefinition)
+// emagls_mex('decode',  in, wL, wR, compensateDelay)            real or complex in / filters; [out, imagAbsSum] = ...
+// caller-evaluated shFunction handles (the wrappers evaluate them at emagls_mex('simorder', kind, order, fs, micRadius)):
+// emagls_mex('ls_y', hL, hR, Yhrir, order, shDefinition)        emagls_mex('magls_y', hL, hR, Yhrir, order, fs, len, shDefinition)
+// emagls_mex('emagls_y' | 'emagls2_y', hL, hR, Yhrir, micRadius, Ymic, order, fs, len, shDefinition)
+// render side:
+// emagls_mex('magls2d', hLHor, hRHor, azi, order, fs, len, chDefinition)
+// emagls_mex('radial', order, fs, smaRadius, irLen, oversamplingFactor, radialFilter, regulConst, noiseGainDb)
+// emagls_mex('applyradial', inSig, order, fs, smaRadius, irLen, oversamplingFactor, radialFilter, regulConst, noiseGainDb)
+// emagls_mex('encode', smaRecording, micAzi, micZen, order, shDefinition)
+// emagls_mex('shf', micRadius, order, fs, len)                  [wShf, W_Shf] = ...
+// emagls_mex('adf', micRadius, micAzi, micZen, order, fs, len, shDefinition[, Yhi])
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    static bool registered = false;
+    if (!registered) { mexAtExit(at_exit); registered = true; }
     if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("eMagLS:arg", "first argument must be a command string");
     char cmd[16] = {0};
     mxGetString(prhs[0], cmd, sizeof cmd);
@@ -54,8 +90,75 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const int comp = nrhs > 4 && mxIsLogicalScalarTrue(prhs[4]);
         const mwSize nout = comp ? n - (len / 2 > 0 ? len / 2 - 1 : 0) : n;
         plhs[0] = mxCreateDoubleMatrix(nout, 2, mxREAL);
-        int rc = emagls_binaural_decode(dbl(prhs[1], "in"), n, ch, dbl(prhs[2], "wL"), dbl(prhs[3], "wR"), len, comp,
-                                        mxGetDoubles(plhs[0]));
+        const bool ic = mxIsComplex(prhs[1]), wc = mxIsComplex(prhs[2]);
+        if (wc != (bool)mxIsComplex(prhs[3])) mexErrMsgIdAndTxt("eMagLS:arg", "the two decoding filters must both be real or both complex");
+        int rc;
+        if (!ic && !wc) {
+            rc = emagls_binaural_decode(dbl(prhs[1], "in"), n, ch, dbl(prhs[2], "wL"), dbl(prhs[3], "wR"), len, comp, mxGetDoubles(plhs[0]));
+        } else {   // dependencies/binauralDecode.m:39-42,59-64: complex products accumulated, the real part kept
+            double imag_sum[2] = {0, 0};
+            rc = emagls_binaural_decode_complex(in_ptr(prhs[1]), ic, n, ch, in_ptr(prhs[2]), in_ptr(prhs[3]), wc, len, comp,
+                                                mxGetDoubles(plhs[0]), imag_sum);
+            if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix(1, 2, mxREAL); mxGetDoubles(plhs[1])[0] = imag_sum[0]; mxGetDoubles(plhs[1])[1] = imag_sum[1]; }
+        }
+        if (rc) fail(rc);
+        return;
+    }
+    if (c == "simorder") {   // kind: 'emagls' | 'emagls2'
+        char kind[16] = {0};
+        mxGetString(prhs[1], kind, sizeof kind);
+        plhs[0] = mxCreateDoubleScalar(emagls_simulation_order(!std::strcmp(kind, "emagls2") ? EMAGLS_KIND_EMAGLS2 : EMAGLS_KIND_EMAGLS,
+                                                               (int)mxGetScalar(prhs[2]), mxGetScalar(prhs[3]), mxGetScalar(prhs[4])));
+        return;
+    }
+    if (c == "radial" || c == "applyradial") {
+        const int o = c == "radial" ? 1 : 2;     // index of `order`
+        if (nrhs < o + 8) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+        const int order = (int)mxGetScalar(prhs[o]);
+        const double fs = mxGetScalar(prhs[o + 1]), r = mxGetScalar(prhs[o + 2]);
+        const mwSize irLen = (mwSize)mxGetScalar(prhs[o + 3]);
+        const int ovs = (int)mxGetScalar(prhs[o + 4]), type = radial_type(prhs[o + 5]);
+        const double regul = mxGetScalar(prhs[o + 6]), gain = mxGetScalar(prhs[o + 7]);
+        int rc;
+        if (c == "radial") {
+            plhs[0] = mxCreateDoubleMatrix((irLen * ovs) / 2 + 1, order + 1, mxCOMPLEX);
+            rc = emagls_get_radial_filter(order, fs, r, irLen, ovs, type, regul, gain, mxGetComplexDoubles(plhs[0]));
+        } else {
+            const mwSize n = mxGetM(prhs[1]);
+            plhs[0] = mxCreateDoubleMatrix(emagls_apply_radial_filter_rows(n, irLen, ovs), mxGetN(prhs[1]), mxREAL);
+            if (mxGetN(prhs[1]) != (mwSize)((order + 1) * (order + 1))) mexErrMsgIdAndTxt("eMagLS:arg", "inSig must have (order+1)^2 columns");
+            rc = emagls_apply_radial_filter(dbl(prhs[1], "inSig"), n, order, fs, r, irLen, ovs, type, regul, gain, mxGetDoubles(plhs[0]));
+        }
+        if (rc) fail(rc);
+        return;
+    }
+    if (c == "encode") {
+        if (nrhs < 5) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+        const mwSize n = mxGetM(prhs[1]), M = mxGetN(prhs[1]);
+        const int order = (int)mxGetScalar(prhs[4]), basis = basis_of(nrhs > 5 ? prhs[5] : nullptr);
+        plhs[0] = out_matrix(n, (order + 1) * (order + 1), basis);
+        int rc = emagls_sh_encode(dbl(prhs[1], "smaRecording"), n, M, dbl(prhs[2], "micAzi"), dbl(prhs[3], "micZen"), order, basis, out_ptr(plhs[0]));
+        if (rc) fail(rc);
+        return;
+    }
+    if (c == "shf") {
+        const mwSize len = (mwSize)mxGetScalar(prhs[4]);
+        plhs[0] = mxCreateDoubleMatrix(len, 1, mxREAL);
+        mxArray* W = mxCreateDoubleMatrix(emagls_eq_filter_nfft(len), 1, mxREAL);
+        int rc = emagls_get_magls_spherical_head_filter(mxGetScalar(prhs[1]), (int)mxGetScalar(prhs[2]), mxGetScalar(prhs[3]), len,
+                                                        mxGetDoubles(plhs[0]), mxGetDoubles(W));
+        if (nlhs > 1) plhs[1] = W; else mxDestroyArray(W);
+        if (rc) fail(rc);
+        return;
+    }
+    if (c == "adf") {
+        if (nrhs < 8) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+        const mwSize M = mxGetNumberOfElements(prhs[2]), len = (mwSize)mxGetScalar(prhs[6]);
+        const int basis = basis_of(prhs[7]);
+        plhs[0] = mxCreateDoubleMatrix(len, 1, mxREAL);
+        int rc = emagls_get_magls_array_diffuse_filter(mxGetScalar(prhs[1]), dbl(prhs[2], "micAzi"), dbl(prhs[3], "micZen"), M,
+                                                       (int)mxGetScalar(prhs[4]), mxGetScalar(prhs[5]), len, basis,
+                                                       nrhs > 8 ? in_ptr(prhs[8]) : nullptr, mxGetDoubles(plhs[0]));
         if (rc) fail(rc);
         return;
     }
@@ -97,6 +200,44 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         rc = (raw ? emagls_get_emagls2_filters : emagls_get_emagls_filters)(
             hL, hR, nsamp, ndirs, dbl(prhs[3], "azi"), dbl(prhs[4], "zen"), r, dbl(prhs[6], "micAzi"), dbl(prhs[7], "micZen"),
             nmics, order, fs, len, basis, out_ptr(plhs[0]), out_ptr(plhs[1]));
+    } else if (c == "magls2d") {   // getMagLsFilters2D(hLHor, hRHor, horHrirGridAziRad, order, fs, len, chDefinition)
+        if (nrhs < 7) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+        const int order = (int)mxGetScalar(prhs[4]);
+        const double fs = mxGetScalar(prhs[5]);
+        const mwSize len = (mwSize)mxGetScalar(prhs[6]);
+        const int basis = basis_of(nrhs > 7 ? prhs[7] : nullptr);
+        plhs[0] = out_matrix(len, 2 * order + 1, basis);
+        plhs[1] = out_matrix(len, 2 * order + 1, basis);
+        rc = emagls_get_magls_filters_2d(hL, hR, nsamp, ndirs, dbl(prhs[3], "azi"), order, fs, len, basis, out_ptr(plhs[0]), out_ptr(plhs[1]));
+    } else if (c == "ls_y" || c == "magls_y") {
+        const bool ls = c == "ls_y";
+        const int order = (int)mxGetScalar(prhs[4]);
+        const double fs = ls ? 0.0 : mxGetScalar(prhs[5]);
+        const mwSize len = ls ? nsamp : (mwSize)mxGetScalar(prhs[6]);
+        const int basis = basis_of(nrhs > (ls ? 5 : 7) ? prhs[ls ? 5 : 7] : nullptr);
+        const mwSize C = (order + 1) * (order + 1);
+        const void* Y = basis_matrix(prhs[3], basis, ndirs, C, "shFunction(order, hrirGrid)");
+        plhs[0] = out_matrix(len, C, basis);
+        plhs[1] = out_matrix(len, C, basis);
+        rc = ls ? emagls_get_ls_filters_with_basis(hL, hR, nsamp, ndirs, Y, order, basis, out_ptr(plhs[0]), out_ptr(plhs[1]))
+                : emagls_get_magls_filters_with_basis(hL, hR, nsamp, ndirs, Y, order, fs, len, basis, out_ptr(plhs[0]), out_ptr(plhs[1]));
+    } else if (c == "emagls_y" || c == "emagls2_y") {
+        if (nrhs < 10) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+        const bool raw = c == "emagls2_y";
+        const double r = mxGetScalar(prhs[4]);
+        const mwSize nmics = mxGetM(prhs[5]);
+        const int order = (int)mxGetScalar(prhs[6]);
+        const double fs = mxGetScalar(prhs[7]);
+        const mwSize len = (mwSize)mxGetScalar(prhs[8]);
+        const int basis = basis_of(nrhs > 9 ? prhs[9] : nullptr);
+        const int so = emagls_simulation_order(raw ? EMAGLS_KIND_EMAGLS2 : EMAGLS_KIND_EMAGLS, order, fs, r);
+        const mwSize S = (mwSize)(so + 1) * (so + 1), C = raw ? nmics : (mwSize)((order + 1) * (order + 1));
+        const void* Yh = basis_matrix(prhs[3], basis, ndirs, S, "shFunction(simulationOrder, hrirGrid)");
+        const void* Ym = basis_matrix(prhs[5], basis, nmics, S, "shFunction(simulationOrder, micGrid)");
+        plhs[0] = out_matrix(len, C, basis);
+        plhs[1] = out_matrix(len, C, basis);
+        rc = (raw ? emagls_get_emagls2_filters_with_basis : emagls_get_emagls_filters_with_basis)(
+            hL, hR, nsamp, ndirs, Yh, r, Ym, nmics, order, fs, len, basis, out_ptr(plhs[0]), out_ptr(plhs[1]));
     } else if (c == "emainch") {   // getEMagLsFiltersEMAinCH(hL, hR, azi, zen, micRadius, micGridAziRad, order, fs, len, shDefinition)
         if (nrhs < 10) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
         const double r = mxGetScalar(prhs[5]);

@@ -308,7 +308,8 @@ def _finish(W_l, W_r, P, nfft, length, is_real_basis, delayL, delayR, integer_sh
     return out
 
 
-def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="real", shFunction=None, _Y=None, _conj_fn=None):
+def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="real", shFunction=None, _Y=None, _conj_fn=None,
+                    applyDiffusenessConst=False):
     """lib/getMagLsFilters.m:30-98"""
     assert length >= hL.shape[0], "HRIR len too short"
     nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
@@ -321,10 +322,12 @@ def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="rea
     hR = _pad(hR, nfft)
     grpD = (_grp_delay(hL, P), _grp_delay(hR, P))
     W = []
+    Hs = []
     for h, g in ((hL, grpD[0]), (hR, grpD[1])):
         h = applySubsampleDelay(h, -g)
         w_LS = h @ Y_pinv
         H = np.fft.fft(h, axis=0)
+        Hs.append(H)
         Wm = np.fft.fft(w_LS, axis=0).astype(np.complex128)
         for k in range(k_cut, P + 1):  # 1-based
             phi = np.angle(Wm[k - 2] @ Y_conj)
@@ -333,6 +336,8 @@ def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="rea
                 t = np.real(t)
             Wm[k - 1] = t @ Y_pinv
         W.append(Wm)
+    if applyDiffusenessConst:   # (MagLS keeps its least-squares DC bin: bins 2..P as for the array variants)
+        W[0], W[1] = applyDiffusenessConstraint(W[0], W[1], Hs[0], Hs[1], lambda k: Y_conj, P)
     n_shift = nfft // 2
     wL, wR = _finish(W[0], W[1], P, nfft, length, is_real, n_shift, n_shift + (grpD[1] - grpD[0]), conj_fn=_conj_fn)
     if is_real:
@@ -340,7 +345,7 @@ def getMagLsFilters(hL, hR, aziRad, zenRad, order, fs, length, shDefinition="rea
     return wL, wR
 
 
-def _emagls_core(HL, HR, pwGrid_of_k, P, k_cut, C, collect=None):
+def _emagls_core(HL, HR, pwGrid_of_k, P, k_cut, C, collect=None, diffuseness=False):
     """The per-bin loop shared by lib/getEMagLsFilters.m:85-106, lib/getEMagLs2Filters.m:85-105 and
     lib/getEMagLsFiltersFromAtf.m:100-120.  HL/HR are [>=P x D]; pwGrid_of_k(k) -> [C x D] (k 1-based)."""
     W_l = np.zeros((P, C), dtype=np.complex128)
@@ -364,6 +369,8 @@ def _emagls_core(HL, HR, pwGrid_of_k, P, k_cut, C, collect=None):
                 tl, tr = np.real(tl), np.real(tr)
             W_l[k - 1] = tl @ Y_reg_inv
             W_r[k - 1] = tr @ Y_reg_inv
+    if diffuseness:
+        W_l, W_r = applyDiffusenessConstraint(W_l, W_r, HL, HR, pwGrid_of_k, P)
     W_l[0] = np.real(W_l[1])  # :110-111
     W_r[0] = np.real(W_r[1])
     return W_l, W_r
@@ -390,7 +397,7 @@ def _matmul(A, B):
 
 
 def _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                    shDefinition, raw, collect=None, shFunction=None):
+                    shDefinition, raw, collect=None, shFunction=None, applyDiffusenessConst=False):
     assert length >= hL.shape[0], "len too short"
     nfft, f, P, k_cut = _design_consts(fs, length, max(F_CUT_MIN_FREQ, 500 * order))
     # lib/getEMagLs2Filters.m:51-63 never sets params.order, so dependencies/getSMAIRMatrix.m:39-41 defaults it to 4:
@@ -402,7 +409,8 @@ def _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs
     Y_Hi_conj = (shFunction or getSH)(simOrder, np.column_stack([aziRad, zenRad]), shDefinition).conj().T   # :68
     HL, HR, gL, gR = _hrir_prologue(hL, hR, nfft, P)
     C = smair.shape[0]
-    W_l, W_r = _emagls_core(HL, HR, lambda k: _matmul(smair[:, :, k - 1], Y_Hi_conj), P, k_cut, C, collect)
+    W_l, W_r = _emagls_core(HL, HR, lambda k: _matmul(smair[:, :, k - 1], Y_Hi_conj), P, k_cut, C, collect,
+                            diffuseness=applyDiffusenessConst)
     is_real = np.isrealobj(Y_Hi_conj) or raw  # eMagLS2 always mirrors (lib/getEMagLs2Filters.m:113-114)
     n_shift = nfft // 2
     wL, wR = _finish(W_l, W_r, P, nfft, length, is_real, n_shift, n_shift + gR - gL)
@@ -412,17 +420,17 @@ def _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs
 
 
 def getEMagLsFilters(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                     shDefinition="real", collect=None, shFunction=None):
-    """lib/getEMagLsFilters.m:32-142"""
+                     shDefinition="real", collect=None, shFunction=None, applyDiffusenessConst=False):
+    """lib/getEMagLsFilters.m:32-142 (applyDiffusenessConst: the removed option, see applyDiffusenessConstraint)"""
     return _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                           shDefinition, raw=False, collect=collect, shFunction=shFunction)
+                           shDefinition, raw=False, collect=collect, shFunction=shFunction, applyDiffusenessConst=applyDiffusenessConst)
 
 
 def getEMagLs2Filters(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                      shDefinition="real", collect=None, shFunction=None):
+                      shDefinition="real", collect=None, shFunction=None, applyDiffusenessConst=False):
     """lib/getEMagLs2Filters.m:32-135"""
     return _emagls_generic(hL, hR, aziRad, zenRad, micRadius, micAzi, micZen, order, fs, length,
-                           shDefinition, raw=True, collect=collect, shFunction=shFunction)
+                           shDefinition, raw=True, collect=collect, shFunction=shFunction, applyDiffusenessConst=applyDiffusenessConst)
 
 
 
@@ -599,6 +607,61 @@ def getMagLsArrayDiffuseFilter(micRadius, micGridAziRad, micGridZenRad, order, f
     _, W_Shf = getMagLsSphericalHeadFilter(micRadius, order, fs, length)
     W = W_Shf[:W_Alias.shape[0]] * W_Alias
     return _eq_finish(W.astype(np.complex128), nfft, length)[0]
+
+
+# --------------------------------------------------------------------------------------------
+# Diffuseness (covariance) constraint -- SURVEY 8(f) rank 1.  NOT in the reference snapshot (CHANGELOG.md:10-12 removed it;
+# verifyEMagLs.m:137-145 hard-defaults applyDiffusenessConst to false); only the *_wDC fixtures survive.  Specified here from
+# Zaunschirm, Schoerkhuber, Hoeldrich, "Binaural rendering of Ambisonic signals by head-related impulse response time
+# alignment and a diffuseness constraint", JASA 143(6), 2018, sec. IV.C, and pinned STRUCTURALLY against the fixture pairs
+# (tools/probe_dc_fixtures.py, tests/test_oracle_kats.py::test_diffuseness_*): per bin the two ears' filters are mixed by a
+# 2x2 matrix, W_dc(k,:,[l r]) = W(k,:,[l r]) M(k), that makes the diffuse-field covariance of the rendered ear signals equal
+# the one of the HRTF set.  Among all M with M^H Rhat M = R the paper takes the one closest to the identity (min ||Hhat M -
+# Hhat||_F); its stationarity condition Rhat M (I + Lambda) = Rhat with a Hermitian multiplier makes M Hermitian, i.e. M is
+# the unique Hermitian positive definite solution of  M Rhat M = R  (the fixtures' M(k) are Hermitian to 1e-4 between 1 and
+# 20 kHz).  What the fixtures cannot pin without the HRIR set: the exact definition of R for MagLS (cross term) and
+# the numerics of the nearly singular bins below ~200 Hz, where the reference's own filters deviate from Hermitian by 1e-2.
+# Parity unpinned.
+# --------------------------------------------------------------------------------------------
+def _sqrtm_hpd(A):
+    w, V = np.linalg.eigh(A)
+    return (V * np.sqrt(np.maximum(w, 0.0))) @ V.conj().T
+
+
+def diffuseness_mixing(Rhat, R):
+    """The Hermitian positive definite M with M Rhat M = R (2x2 ear covariances):
+    M = Rhat^-1/2 (Rhat^1/2 R Rhat^1/2)^1/2 Rhat^-1/2."""
+    s = _sqrtm_hpd(Rhat)
+    si = np.linalg.inv(s)
+    return si @ _sqrtm_hpd(s @ R @ s) @ si
+
+
+def ear_covariance(hl, hr):
+    """[2 x 2] covariance of two ear responses over the directions of the grid: E_d[conj(h_i) h_j] (equal weights, like every
+    other sum over the HRIR grid in the reference)."""
+    H = np.column_stack([hl, hr])
+    return H.conj().T @ H / H.shape[0]
+
+
+def applyDiffusenessConstraint(W_l, W_r, HL, HR, pwGrid_of_k, P):
+    """Bins 2..P (1-based; bin 1 is set from bin 2 afterwards, lib/getEMagLsFilters.m:110-111): rendered HRTFs
+    Hhat_e = W_e(k,:) pwGrid_k over the HRIR grid, R from the time-aligned HRTFs HL/HR, W(k,:,[l r]) <- W(k,:,[l r]) M(k)."""
+    W_l, W_r = W_l.copy(), W_r.copy()
+    for k in range(2, P + 1):
+        pw = pwGrid_of_k(k)
+        M = diffuseness_mixing(ear_covariance(W_l[k - 1] @ pw, W_r[k - 1] @ pw), ear_covariance(HL[k - 1], HR[k - 1]))
+        wl, wr = W_l[k - 1].copy(), W_r[k - 1].copy()
+        W_l[k - 1] = wl * M[0, 0] + wr * M[1, 0]
+        W_r[k - 1] = wl * M[0, 1] + wr * M[1, 1]
+    return W_l, W_r
+
+
+def fit_ear_mixing(Wl, Wr, Dl, Dr):
+    """Least-squares 2x2 M with [Dl Dr] = [Wl Wr] M for one bin (columns = ears, rows = channels) and its relative residual."""
+    A = np.column_stack([Wl, Wr])
+    B = np.column_stack([Dl, Dr])
+    M = np.linalg.lstsq(A, B, rcond=None)[0]
+    return M, float(np.linalg.norm(A @ M - B) / max(np.linalg.norm(B), 1e-300))
 
 
 # --------------------------------------------------------------------------------------------

@@ -155,3 +155,10 @@ for k in ks:
     Rp = Mi.conj().T @ Rest["eMagLS"][k] @ Mi
     Rh = Rhat["MagLS"][k]
     print(f"  k={k:3d} needed [{Rp[0,0].real:.4f} {Rp[1,1].real:.4f} {Rp[0,1]:.4f}]  grid-rendered [{Rh[0,0].real:.4f} {Rh[1,1].real:.4f} {Rh[0,1]:.4f}]")
+
+
+print("\n== edge bins (0-based): DC, first solved bin, last bins")
+for m in fits:
+    for k in (0, 1, 2, 510, 511, 512):
+        M = fits[m][0][k]
+        print(f"  {m:8s} k={k:3d} M=[[{M[0,0]:.4f} {M[0,1]:.4f}] [{M[1,0]:.4f} {M[1,1]:.4f}]] res={fits[m][1][k]:.1e}")
