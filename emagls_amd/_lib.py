@@ -20,7 +20,8 @@ c_i64 = C.c_int64
 class DesignDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("basis", C.c_int), ("order", C.c_int), ("fs", C.c_double), ("len", c_i64),
                 ("nsamp", c_i64), ("ndirs", c_i64), ("mic_radius", C.c_double), ("nmics", c_i64),
-                ("f_trans", C.c_double), ("atf_taps", c_i64), ("natf", c_i64), ("custom_basis", C.c_int)]
+                ("f_trans", C.c_double), ("atf_taps", c_i64), ("natf", c_i64), ("custom_basis", C.c_int),
+                ("diffuseness", C.c_int)]
 
 
 class PlanInfo(C.Structure):
@@ -70,6 +71,14 @@ SYMBOLS = {
     "emagls_binaural_decode": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_void_p]),
     "emagls_binaural_decode_complex": (C.c_int, [C.c_void_p, C.c_int, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int, c_i64, C.c_int,
                                                  C.c_void_p, C.c_void_p]),
+    "emagls_get_magls_filters_dc": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_double, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "emagls_get_emagls_filters_dc": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_double,
+                                               C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_double, c_i64, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p]),
+    "emagls_get_emagls2_filters_dc": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_double,
+                                                C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_double, c_i64, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p]),
     "emagls_get_magls_filters_2d": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_int, C.c_double, c_i64, C.c_int,
                                               C.c_void_p, C.c_void_p]),
     "emagls_get_radial_filter": (C.c_int, [C.c_int, C.c_double, C.c_double, c_i64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]),

@@ -111,7 +111,16 @@ def getLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, shDefinition="re
     return wL, wR
 
 
-def getMagLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, fs, len, shDefinition="real", shFunction=None):
+def _no_handle_with_dc(shFunction, applyDiffusenessConst):
+    if applyDiffusenessConst and shFunction is not None:
+        raise NotImplementedError("applyDiffusenessConst with a custom shFunction is not supported")
+
+
+def getMagLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, fs, len, shDefinition="real", shFunction=None,
+                    applyDiffusenessConst=False):
+    """lib/getMagLsFilters.m:1-2.  applyDiffusenessConst: the option the reference removed (its stale docstring :4 still lists
+    it); specification in oracle/emagls_oracle.py."""
+    _no_handle_with_dc(shFunction, applyDiffusenessConst)
     b, cplx = _basis(shDefinition, shFunction)
     hL, hR, pL, pR = _hrirs(hL, hR)
     n, D = hL.shape
@@ -123,11 +132,15 @@ def getMagLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, fs, len, shDe
         Y, pY = _sh_matrix(shFunction, order, azi, zen, shDefinition, cplx, D)
         L.check(L.load().emagls_get_magls_filters_with_basis(pL, pR, n, D, pY, int(order), float(fs), int(len), b, pwL, pwR))
         return wL, wR
+    if applyDiffusenessConst:
+        L.check(L.load().emagls_get_magls_filters_dc(pL, pR, n, D, pa, pz, int(order), float(fs), int(len), 1, b, pwL, pwR))
+        return wL, wR
     L.check(L.load().emagls_get_magls_filters(pL, pR, n, D, pa, pz, int(order), float(fs), int(len), b, pwL, pwR))
     return wL, wR
 
 
-def _sma(fn_name, raw, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition, shFunction):
+def _sma(fn_name, raw, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition, shFunction, dc=False):
+    _no_handle_with_dc(shFunction, dc)
     b, cplx = _basis(shDefinition, shFunction)
     hL, hR, pL, pR = _hrirs(hL, hR)
     n, D = hL.shape
@@ -147,21 +160,25 @@ def _sma(fn_name, raw, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, l
         fn = getattr(L.load(), fn_name + "_with_basis")
         L.check(fn(pL, pR, n, D, pYh, float(micRadius), pYm, M, int(order), float(fs), int(len), b, pwL, pwR))
         return wL, wR
+    if dc:
+        fn = getattr(L.load(), fn_name + "_dc")
+        L.check(fn(pL, pR, n, D, pa, pz, float(micRadius), pma, pmz, M, int(order), float(fs), int(len), 1, b, pwL, pwR))
+        return wL, wR
     fn = getattr(L.load(), fn_name)
     L.check(fn(pL, pR, n, D, pa, pz, float(micRadius), pma, pmz, M, int(order), float(fs), int(len), b, pwL, pwR))
     return wL, wR
 
 
 def getEMagLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, micGridZenRad, order, fs, len,
-                     shDefinition="real", shFunction=None):
+                     shDefinition="real", shFunction=None, applyDiffusenessConst=False):
     return _sma("emagls_get_emagls_filters", False, hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad,
-                micGridZenRad, order, fs, len, shDefinition, shFunction)
+                micGridZenRad, order, fs, len, shDefinition, shFunction, applyDiffusenessConst)
 
 
 def getEMagLs2Filters(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, micGridZenRad, order, fs, len,
-                      shDefinition="real", shFunction=None):
+                      shDefinition="real", shFunction=None, applyDiffusenessConst=False):
     return _sma("emagls_get_emagls2_filters", True, hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad,
-                micGridZenRad, order, fs, len, shDefinition, shFunction)
+                micGridZenRad, order, fs, len, shDefinition, shFunction, applyDiffusenessConst)
 
 
 def getEMagLsFiltersEMAinCH(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, order, fs, len,

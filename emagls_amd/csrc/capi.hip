@@ -71,6 +71,7 @@ struct emagls_plan {
     bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip)
     emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false, have_basis = false;
+    bool diffuse = false;         // diffuseness (covariance) constraint after the sweep (render.hip: diffuse_constraint_kernel)
     bool custom_basis = false;    // the SH matrices come from the caller (a custom shFunction evaluated on the MATLAB side)
     // profiling
     int prof_level = 0;
@@ -272,6 +273,7 @@ void plan_routes(emagls_plan& p) {
         throw Error(EMAGLS_ERR_UNSUPPORTED, "the ill-conditioned low bins of this design need more than 27 orders on the orthonormal route "
                                             "(Gram route off or moved up by a conditioning check): not supported in this build");
     p.g0 = (p.gram_from > 0 && p.gram_from < k0) ? p.gram_from : k0;
+    if (p.diffuse) p.g0 = 1;   // the constraint renders the HRTFs of every solved bin: G_k from the first one
     p.nb_gram = p.gram_from > 0 ? p.P - p.gram_from : 0;
 }
 // buffers whose size depends on the routes (re-entered when a conditioning check moves the routes: alloc keeps what is large enough)
@@ -320,6 +322,9 @@ void plan_setup(emagls_plan& p) {
     // rule and the SH conjugate rule (:109-118) act on W_c and stay in the epilogue.  eMagLS2 is basis free (T cancels).
     // The real pipeline has a 3x cheaper Gram and half the bytes in T_n and QT: 1460 vs 1295 sets/s at config 3.
     p.custom_basis = d.custom_basis != 0;
+    p.diffuse = d.diffuseness != 0;
+    if (p.diffuse && (d.kind == EMAGLS_KIND_LS || d.kind == EMAGLS_KIND_FROM_ATF))
+        throw Error(EMAGLS_ERR_ARG, "the diffuseness constraint applies to MagLS, eMagLS, eMagLS2 and the EMA variant");
     if (p.custom_basis && (d.kind == EMAGLS_KIND_FROM_ATF || d.kind == EMAGLS_KIND_EMA_CH || d.kind == EMAGLS_KIND_MAGLS_2D))
         throw Error(EMAGLS_ERR_UNSUPPORTED, "caller-supplied SH matrices are available for LS, MagLS, eMagLS and eMagLS2 designs");
     // (a caller-supplied complex basis need not be ours rotated by T: it takes the complex-arithmetic pipeline)
@@ -356,6 +361,7 @@ void plan_setup(emagls_plan& p) {
         p.kcut0 = std::min(p.k_cut - 1, p.P);  // 0-based index of the first magnitude-least-squares bin
         if (magls_kind(d.kind) && p.kcut0 < 1) throw Error(EMAGLS_ERR_ARG, "k_cut must be at least 2");
         p.alloc("tw", sizeof(cplx) * p.nfft);
+        if (p.diffuse) p.alloc("Hfull", sizeof(cplx) * (size_t)2 * p.P * p.ldD);   // time-aligned complex HRTFs of every bin
         p.alloc("dirsum", sizeof(double) * 2 * d.nsamp * hrir_dirsum_chunks(d.ndirs));
     }
 
@@ -532,6 +538,9 @@ void stage_prologue(emagls_plan& p, int mode, const int64_t* didx, int64_t Dh) {
     launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, Dh, didx, p.nfft, p.get("tw"), p.get<double>("grpd"),
                     mode, std::min(p.kcut0, p.P), p.kcut0, p.get("Hc"), p.get<double>("Habs"), p.ldD, st);
     (void)n_c;
+    if (p.diffuse && mode == 0)
+        launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, Dh, didx, p.nfft, p.get("tw"), p.get<double>("grpd"),
+                        0, p.P, p.P, p.get("Hfull"), p.get<double>("Habs"), p.ldD, st);
     p.mark("hrir_prologue");
 }
 
@@ -594,6 +603,8 @@ void execute_magls(emagls_plan& p) {
     }
     if (p.kcut0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
     p.mark("magls_sweep");
+    if (p.diffuse)   // pwGrid is Y_conj for every bin
+        launch_diffuse_constraint(p.get("W"), p.get("Xc"), cb, 0, 1, p.get("Hfull"), (int)p.D, p.C, p.ldD, p.P, st);
     // complex basis: getShFreqDomainConjugate (getMagLsFilters.m) / getChFreqDomainConjugate (getMagLsFilters2D.m:82-83)
     launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"),
                            cb ? (p.d.kind == EMAGLS_KIND_MAGLS_2D ? 2 : 1) : 0, 0, 0,
@@ -688,6 +699,9 @@ void emagls_pre_sweep(emagls_plan& p) {
         launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"),
                         p.get<double>("grpd"), 0, ls_end, p.kcut0, p.get("Hc"), p.get<double>("Habs"), p.ldD, s2,
                         ls_end > 0 ? p.get<double>("HcT") : nullptr, round_up(4 * std::max(ls_end, 1), 64));
+        if (p.diffuse)   // the target covariance needs the complex HRTFs of all bins (the sweep only keeps |H| above k_cut)
+            launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"),
+                            p.get<double>("grpd"), 0, p.P, p.P, p.get("Hfull"), p.get<double>("Habs"), p.ldD, s2);
     }
 
     // s0: SH matrix of the HRIR grid, its Gram matrix Gy, Cholesky factor R of the leading block (Householder-route orders)
@@ -867,6 +881,9 @@ void emagls_post_sweep(emagls_plan& p) {
     const bool cb = p.cplx_basis;
     const bool raw = p.d.kind == EMAGLS_KIND_EMAGLS2;
     const int conj_mode = !p.req_cplx || raw ? 0 : (p.d.kind == EMAGLS_KIND_EMA_CH ? 2 : 1);   // Hermitian mirror / SH rule / CH rule
+    if (p.diffuse)   // (in the real-arithmetic pipeline W is still W_r here: the rendered HRTFs W G are the same in either basis)
+        launch_diffuse_constraint(p.get("W"), p.get("G"), true, (int64_t)p.C * p.ldD, p.g0, p.get("Hfull"), (int)p.D, p.C, p.ldD, p.P,
+                                  p.stream);
     if (p.real_internal && !raw) launch_sh_rows_to_complex(p.get("W"), p.C, 2 * p.P, (int)p.d.order, p.stream);   // W_c = W_r T_N
     (void)cb;
     launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"), conj_mode, 1, 0,
@@ -1322,7 +1339,7 @@ size_t plan_cache_capacity() {
 bool same_desc(const emagls_design_desc& a, const emagls_design_desc& b) {
     return a.kind == b.kind && a.basis == b.basis && a.order == b.order && a.fs == b.fs && a.len == b.len && a.nsamp == b.nsamp &&
            a.ndirs == b.ndirs && a.mic_radius == b.mic_radius && a.nmics == b.nmics && a.f_trans == b.f_trans &&
-           a.atf_taps == b.atf_taps && a.natf == b.natf && a.custom_basis == b.custom_basis;
+           a.atf_taps == b.atf_taps && a.natf == b.natf && a.custom_basis == b.custom_basis && a.diffuseness == b.diffuseness;
 }
 
 int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR, const double* azi, const double* zen,
@@ -1920,6 +1937,33 @@ static int decode_entry(const void* in, bool in_cplx, int64_t nsamp, int64_t nch
     });
 }
 
+int emagls_get_magls_filters_dc(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
+                                int order, double fs, int64_t len, int apply_dc, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_MAGLS; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    d.diffuseness = apply_dc != 0;
+    return one_shot(d, hL, hR, azi, zen, nullptr, nullptr, nullptr, nullptr, nullptr, wL, wR, nullptr);
+}
+static int emagls_array_dc(int kind, const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
+                           double mic_radius, const double* mic_azi, const double* mic_zen, int64_t nmics, int order, double fs, int64_t len,
+                           int apply_dc, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = kind; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    d.mic_radius = mic_radius; d.nmics = nmics; d.diffuseness = apply_dc != 0;
+    return one_shot(d, hL, hR, azi, zen, mic_azi, mic_zen, nullptr, nullptr, nullptr, wL, wR, nullptr);
+}
+int emagls_get_emagls_filters_dc(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
+                                 double mic_radius, const double* mic_azi, const double* mic_zen, int64_t nmics, int order, double fs,
+                                 int64_t len, int apply_dc, int basis, void* wL, void* wR) {
+    return emagls_array_dc(EMAGLS_KIND_EMAGLS, hL, hR, nsamp, ndirs, azi, zen, mic_radius, mic_azi, mic_zen, nmics, order, fs, len, apply_dc,
+                           basis, wL, wR);
+}
+int emagls_get_emagls2_filters_dc(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
+                                  double mic_radius, const double* mic_azi, const double* mic_zen, int64_t nmics, int order, double fs,
+                                  int64_t len, int apply_dc, int basis, void* wL, void* wR) {
+    return emagls_array_dc(EMAGLS_KIND_EMAGLS2, hL, hR, nsamp, ndirs, azi, zen, mic_radius, mic_azi, mic_zen, nmics, order, fs, len, apply_dc,
+                           basis, wL, wR);
+}
 int emagls_get_magls_filters_2d(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, int order, double fs,
                                 int64_t len, int basis, void* wL, void* wR) {
     emagls_design_desc d{};

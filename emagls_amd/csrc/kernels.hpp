@@ -138,6 +138,8 @@ void launch_array_diffuse(const void* bn, int nOrd, const void* Y, bool y_cplx, 
                           double* df_lo, hipStream_t st);
 void launch_eq_spectrum(const double* df_hi, const double* df_lo, const double* df_arr, int P, int mode, void* W, double* W_full,
                         hipStream_t st);
+void launch_diffuse_constraint(void* W, const void* G, bool g_cplx, int64_t g_stride, int g0, const void* H, int D, int C, int64_t ldD,
+                               int P, hipStream_t st);
 void launch_sh_encode(const double* sig, int64_t n, int M, const void* Z, int ldZ, int nOut, bool out_cplx, void* out, hipStream_t st);
 
 // ---- capi.hip: runs f, maps exceptions to the C status codes and records the message for emagls_last_error()

@@ -191,4 +191,102 @@ void launch_sh_encode(const double* sig, int64_t n, int M, const void* Z, int ld
     KERNEL_CHECK();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Diffuseness (covariance) constraint, SURVEY 8(f) rank 1 (absent from the reference snapshot; specification and what the
+// *_wDC fixtures pin of it: oracle/emagls_oracle.py, "Diffuseness (covariance) constraint").  One workgroup per solved bin:
+//   Hhat_e(d) = W_e(k,:) pwGrid_k(:,d)          rendered HRTFs over the HRIR grid
+//   Rhat = E_d[conj(Hhat_i) Hhat_j],  R = E_d[conj(H_i) H_j]   (2x2, the time-aligned HRTFs H)
+//   M = the Hermitian positive definite solution of M Rhat M = R,   W(k,:,[l r]) <- W(k,:,[l r]) M
+// G is pwGrid_k.' as [c][ldD] per bin (g_stride elements between bins; 0: one matrix for every bin, MagLS' Y_conj),
+// W [e][P][C], H [e][P][ldD].  sqrt of a 2x2 Hermitian PSD matrix in closed form: (A + sqrt(det) I) / sqrt(tr + 2 sqrt(det)).
+// ---------------------------------------------------------------------------------------------
+struct Herm2 { double a, d; cplx b; };   // [[a, b], [conj(b), d]]
+__device__ __forceinline__ Herm2 sqrt_herm2(Herm2 A) {
+    const double det = fmax(A.a * A.d - norm2(A.b), 0.0);
+    const double s = sqrt(det), t = sqrt(fmax(A.a + A.d + 2.0 * s, 1e-300));
+    return Herm2{(A.a + s) / t, (A.d + s) / t, mk(A.b.x / t, A.b.y / t)};
+}
+__device__ __forceinline__ Herm2 congruence2(Herm2 S, Herm2 R) {   // S R S for Hermitian S, R
+    // X = S R
+    const cplx x00 = mk(S.a * R.a, 0.0) + S.b * conj(R.b), x01 = S.a * R.b + S.b * R.d;
+    const cplx x10 = conj(S.b) * R.a + S.d * conj(R.b), x11 = conj(S.b) * R.b + mk(S.d * R.d, 0.0);
+    // Y = X S
+    const cplx y00 = x00 * S.a + x01 * conj(S.b), y01 = x00 * S.b + x01 * S.d;
+    const cplx y11 = x10 * S.b + x11 * S.d;
+    (void)x10;
+    return Herm2{y00.x, y11.x, y01};
+}
+template <typename T>
+__global__ void __launch_bounds__(256) diffuse_constraint_kernel(cplx* __restrict__ W, const T* __restrict__ G, int64_t g_stride, int g0,
+                                                                 const cplx* __restrict__ H, int D, int C, int64_t ldD, int P,
+                                                                 size_t bstride) {
+    W = boff(W, bstride); G = boff(G, bstride); H = boff(H, bstride);
+    __shared__ cplx w_s[2][32];
+    __shared__ double red[4][8];
+    __shared__ cplx m_s[4];
+    const int kb = blockIdx.x + 1;
+    cplx* Wl = W + (int64_t)kb * C;
+    cplx* Wr = W + ((int64_t)P + kb) * C;
+    if (threadIdx.x < C) { w_s[0][threadIdx.x] = Wl[threadIdx.x]; w_s[1][threadIdx.x] = Wr[threadIdx.x]; }
+    __syncthreads();
+    const T* Gk = G + (int64_t)(kb - g0) * g_stride;
+    const cplx* Hl = H + (int64_t)kb * ldD;
+    const cplx* Hr = H + ((int64_t)P + kb) * ldD;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // Rhat: a, d, Re b, Im b;  R: a, d, Re b, Im b
+    for (int d = threadIdx.x; d < D; d += 256) {
+        cplx hl = mk(0, 0), hr = mk(0, 0);
+        for (int c = 0; c < C; ++c) {
+            const T g = Gk[(int64_t)c * ldD + d];
+            cfma(hl, w_s[0][c], g);
+            cfma(hr, w_s[1][c], g);
+        }
+        acc[0] += norm2(hl); acc[1] += norm2(hr);
+        acc[2] += hl.x * hr.x + hl.y * hr.y; acc[3] += hl.x * hr.y - hl.y * hr.x;     // conj(hl) hr
+        const cplx tl = Hl[d], tr = Hr[d];
+        acc[4] += norm2(tl); acc[5] += norm2(tr);
+        acc[6] += tl.x * tr.x + tl.y * tr.y; acc[7] += tl.x * tr.y - tl.y * tr.x;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        double v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r[8];
+        for (int i = 0; i < 8; ++i) r[i] = (red[0][i] + red[1][i] + red[2][i] + red[3][i]) / (double)D;
+        const Herm2 Rh{r[0], r[1], mk(r[2], r[3])}, R{r[4], r[5], mk(r[6], r[7])};
+        const Herm2 S = sqrt_herm2(Rh);
+        const double dS = S.a * S.d - norm2(S.b);
+        cplx M[4] = {mk(1, 0), mk(0, 0), mk(0, 0), mk(1, 0)};
+        if (dS > 0.0 && isfinite(dS)) {
+            const Herm2 Si{S.d / dS, S.a / dS, mk(-S.b.x / dS, -S.b.y / dS)};   // inverse of a Hermitian 2x2
+            const Herm2 Q = sqrt_herm2(congruence2(S, R));
+            const Herm2 Mh = congruence2(Si, Q);
+            M[0] = mk(Mh.a, 0.0); M[1] = Mh.b; M[2] = conj(Mh.b); M[3] = mk(Mh.d, 0.0);
+        }
+        m_s[0] = M[0]; m_s[1] = M[1]; m_s[2] = M[2]; m_s[3] = M[3];
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const cplx wl = w_s[0][threadIdx.x], wr = w_s[1][threadIdx.x];
+        Wl[threadIdx.x] = wl * m_s[0] + wr * m_s[2];
+        Wr[threadIdx.x] = wl * m_s[1] + wr * m_s[3];
+    }
+}
+void launch_diffuse_constraint(void* W, const void* G, bool g_cplx, int64_t g_stride, int g0, const void* H, int D, int C, int64_t ldD,
+                               int P, hipStream_t st) {
+    if (P < 2) return;
+    if (C > 32) throw Error(2, "diffuseness constraint: more than 32 channels is not supported");
+    if (g_cplx)
+        diffuse_constraint_kernel<cplx><<<bgrid(P - 1), 256, 0, st>>>((cplx*)W, (const cplx*)G, g_stride, g0, (const cplx*)H, D, C, ldD, P,
+                                                                       batch_ctx().stride);
+    else
+        diffuse_constraint_kernel<double><<<bgrid(P - 1), 256, 0, st>>>((cplx*)W, (const double*)G, g_stride, g0, (const cplx*)H, D, C, ldD, P,
+                                                                         batch_ctx().stride);
+    KERNEL_CHECK();
+}
+
 }  // namespace emagls

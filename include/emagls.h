@@ -144,6 +144,19 @@ int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const d
 int emagls_binaural_decode_complex(const void* in, int in_is_complex, int64_t nsamp, int64_t nch, const void* wL, const void* wR,
                                    int filters_are_complex, int64_t len, int compensate_delay, double* out, double* imag_abs_sum);
 
+/* The three designs with the diffuseness (covariance) constraint, the `applyDiffusenessConst` argument the reference's
+ * functions used to take after `len` (verifyEMagLs.m:106-114 still shows the call form).  Not in the reference snapshot:
+ * specified in oracle/emagls_oracle.py from Zaunschirm/Schoerkhuber/Hoeldrich 2018 and pinned structurally by the *_wDC
+ * fixtures.  Same arguments as the functions without the suffix plus the flag. */
+int emagls_get_magls_filters_dc(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
+                                int order, double fs, int64_t len, int apply_diffuseness_const, int basis, void* wL, void* wR);
+int emagls_get_emagls_filters_dc(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
+                                 double mic_radius, const double* mic_azi, const double* mic_zen, int64_t nmics, int order, double fs,
+                                 int64_t len, int apply_diffuseness_const, int basis, void* wL, void* wR);
+int emagls_get_emagls2_filters_dc(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
+                                  double mic_radius, const double* mic_azi, const double* mic_zen, int64_t nmics, int order, double fs,
+                                  int64_t len, int apply_diffuseness_const, int basis, void* wL, void* wR);
+
 /* ---- render side: what the reference's harness runs between the recording and the decoder ---- */
 
 /* lib/getMagLsFilters2D.m:1 -- [wMlsL, wMlsR] = getMagLsFilters2D(hLHor, hRHor, horHrirGridAziRad, order, fs, len, chDefinition)
@@ -200,6 +213,8 @@ typedef struct emagls_design_desc {
     int64_t atf_taps;    /* FROM_ATF */
     int64_t natf;        /* FROM_ATF: ATF directions */
     int custom_basis;    /* != 0: the SH matrices are supplied by emagls_plan_set_basis (a custom shFunction, lib/getEMagLsFilters.m:32,68) */
+    int diffuseness;     /* != 0: apply the diffuseness (covariance) constraint -- the applyDiffusenessConst option the reference
+                          * removed (CHANGELOG.md:10-12, verifyEMagLs.m:137-145); MAGLS, MAGLS_2D, EMAGLS, EMAGLS2, EMA_CH */
 } emagls_design_desc;
 
 typedef struct emagls_plan_info {

@@ -168,3 +168,38 @@ def test_array_diffuse_filter(grids, basis):
     w2 = E.getMagLsArrayDiffuseFilter(*args, shFunction=sh)
     assert calls == [int(np.ceil(48000.0 * np.pi * grids["mic_radius"] / 343.0))]
     assert rel(w2[:, 0], ow) < 1e-9
+
+
+# --------------------------------------------------------------------------------------------
+# diffuseness (covariance) constraint, SURVEY 8(f) rank 1
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fn,basis", [("getMagLsFilters", "real"), ("getMagLsFilters", "complex"), ("getEMagLsFilters", "real"),
+                                      ("getEMagLsFilters", "complex"), ("getEMagLs2Filters", "real")])
+def test_diffuseness_constraint(grids, thin_hrirs, fn, basis):
+    """The three designs with applyDiffusenessConst against the oracle's specification, and the property itself: the filters
+    differ from the unconstrained ones (by a few per cent), and per bin by a 2x2 Hermitian ear mixing."""
+    import emagls_amd as E
+    hL, hR, azi, zen = thin_hrirs
+    if fn == "getMagLsFilters":
+        args = (hL, hR, azi, zen, 4, 48000.0, 128, basis)
+    else:
+        args = (hL, hR, azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, basis)
+    wL, wR = getattr(E, fn)(*args, applyDiffusenessConst=True)
+    oL, oR = getattr(O, fn)(*args, applyDiffusenessConst=True)
+    uL, uR = getattr(E, fn)(*args)
+    assert wL.dtype == oL.dtype and wL.shape == oL.shape
+    assert rel(wL, oL) < TOL and rel(wR, oR) < TOL, (rel(wL, oL), rel(wR, oR))
+    assert 1e-3 < rel(wL, uL) < 0.5
+    # per-bin structure, as the reference's fixture pairs show it (tests/test_oracle_kats.py::test_diffuseness_*)
+    F = lambda w: np.fft.fft(np.vstack([w, np.zeros_like(w)]), axis=0)
+    Wl, Wr, Dl, Dr = F(uL), F(uR), F(wL), F(wR)
+    for k in (12, 30, 60, 100):
+        M, r = O.fit_ear_mixing(Wl[k], Wr[k], Dl[k], Dr[k])
+        assert r < 5e-2 and np.abs(M - M.conj().T).max() < 5e-2, (k, r, M)
+
+
+def test_diffuseness_constraint_errors(grids, thin_hrirs):
+    from emagls_amd import Plan, _lib as L
+    from emagls_amd._lib import EmaglsError
+    with pytest.raises(EmaglsError, match="diffuseness constraint applies"):
+        Plan(L.KIND_LS, "real", 4, 48000.0, 128, 128, 900, diffuseness=True)
