@@ -119,7 +119,7 @@ def _no_handle_with_dc(shFunction, applyDiffusenessConst):
 def getMagLsFilters(hL, hR, hrirGridAziRad, hrirGridZenRad, order, fs, len, shDefinition="real", shFunction=None,
                     applyDiffusenessConst=False):
     """lib/getMagLsFilters.m:1-2.  applyDiffusenessConst: the option the reference removed (its stale docstring :4 still lists
-    it); specification in oracle/emagls_oracle.py."""
+    it); specification: DESIGN.md section 7."""
     _no_handle_with_dc(shFunction, applyDiffusenessConst)
     b, cplx = _basis(shDefinition, shFunction)
     hL, hR, pL, pR = _hrirs(hL, hR)

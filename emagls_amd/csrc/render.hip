@@ -193,7 +193,7 @@ void launch_sh_encode(const double* sig, int64_t n, int M, const void* Z, int ld
 
 // ---------------------------------------------------------------------------------------------
 // Diffuseness (covariance) constraint, SURVEY 8(f) rank 1 (absent from the reference snapshot; specification and what the
-// *_wDC fixtures pin of it: oracle/emagls_oracle.py, "Diffuseness (covariance) constraint").  One workgroup per solved bin:
+// *_wDC fixtures pin of it: DESIGN.md section 7 and the CPU restatement under oracle/).  One workgroup per solved bin:
 //   Hhat_e(d) = W_e(k,:) pwGrid_k(:,d)          rendered HRTFs over the HRIR grid
 //   Rhat = E_d[conj(Hhat_i) Hhat_j],  R = E_d[conj(H_i) H_j]   (2x2, the time-aligned HRTFs H)
 //   M = the Hermitian positive definite solution of M Rhat M = R,   W(k,:,[l r]) <- W(k,:,[l r]) M

@@ -146,7 +146,7 @@ int emagls_binaural_decode_complex(const void* in, int in_is_complex, int64_t ns
 
 /* The three designs with the diffuseness (covariance) constraint, the `applyDiffusenessConst` argument the reference's
  * functions used to take after `len` (verifyEMagLs.m:106-114 still shows the call form).  Not in the reference snapshot:
- * specified in oracle/emagls_oracle.py from Zaunschirm/Schoerkhuber/Hoeldrich 2018 and pinned structurally by the *_wDC
+ * specified (CPU restatement under oracle/) from Zaunschirm/Schoerkhuber/Hoeldrich 2018 and pinned structurally by the *_wDC
  * fixtures.  Same arguments as the functions without the suffix plus the flag. */
 int emagls_get_magls_filters_dc(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
                                 int order, double fs, int64_t len, int apply_diffuseness_const, int basis, void* wL, void* wR);
