@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libemagls.so")
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NUMERIC = 0, 1, 2, 3, 4
 BASIS = {"real": 0, "complex": 1}
-KIND_LS, KIND_MAGLS, KIND_EMAGLS, KIND_EMAGLS2, KIND_FROM_ATF, KIND_EMA_CH, KIND_MAGLS_2D = range(7)
+KIND_LS, KIND_MAGLS, KIND_EMAGLS, KIND_EMAGLS2, KIND_FROM_ATF, KIND_EMA_CH, KIND_MAGLS_2D, KIND_EMA_SH = range(8)
 RADIAL = {"tikhonov": 0, "softlimit": 1, "full": 2, "none": 3}
 
 c_dp = C.POINTER(C.c_double)
@@ -54,6 +54,8 @@ SYMBOLS = {
                                              C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_double, c_i64, C.c_int,
                                              C.c_void_p, C.c_void_p]),
     "emagls_get_emagls_filters_ema_in_ch": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_double,
+                                                      C.c_void_p, c_i64, C.c_int, C.c_double, c_i64, C.c_int, C.c_void_p, C.c_void_p]),
+    "emagls_get_emagls_filters_ema_in_sh": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_double,
                                                       C.c_void_p, c_i64, C.c_int, C.c_double, c_i64, C.c_int, C.c_void_p, C.c_void_p]),
     "emagls_get_emagls_filters_from_atf": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p,

@@ -7,6 +7,7 @@ hL/hR are [numSamples x numDirections]; filters come back [len x numChannels].
     getEMagLsFilters        lib/getEMagLsFilters.m:1-2
     getEMagLs2Filters       lib/getEMagLs2Filters.m:1-2
     getEMagLsFiltersEMAinCH lib/getEMagLsFiltersEMAinCH.m:1-2
+    getEMagLsFiltersEMAinSH lib/getEMagLsFiltersEMAinSH.m:1-2
     getEMagLsFiltersFromAtf lib/getEMagLsFiltersFromAtf.m:1
     binauralDecode          dependencies/binauralDecode.m:1-2
     getMagLsFilters2D       lib/getMagLsFilters2D.m:1
@@ -198,6 +199,28 @@ def getEMagLsFiltersEMAinCH(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, m
     wL, pwL = _out(int(len), C_, cplx)
     wR, pwR = _out(int(len), C_, cplx)
     L.check(L.load().emagls_get_emagls_filters_ema_in_ch(pL, pR, n, D, pa, pz, float(micRadius), pma, micAzi.size, int(order),
+                                                         float(fs), int(len), b, pwL, pwR))
+    return wL, wR
+
+
+def getEMagLsFiltersEMAinSH(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, order, fs, len,
+                            shDefinition="real", shFunction=None, chFunction=None):
+    """lib/getEMagLsFiltersEMAinSH.m:1-2: eMagLS filters in spherical harmonics for an equatorial microphone array (the
+    horizontal sound field is expanded from circular to spherical harmonics and rotated to every HRIR direction's elevation);
+    returns [len x (order+1)^2] per ear."""
+    if chFunction is not None or shFunction is not None:
+        raise NotImplementedError("custom chFunction / shFunction handles are not supported for the EMA variants; the defaults "
+                                  "@getCH / @getSH are built in")
+    b, cplx = _basis(shDefinition)
+    hL, hR, pL, pR = _hrirs(hL, hR)
+    n, D = hL.shape
+    azi, pa = _vec(hrirGridAziRad, D, "hrirGridAziRad")
+    zen, pz = _vec(hrirGridZenRad, D, "hrirGridZenRad")
+    micAzi, pma = _vec(micGridAziRad)
+    C_ = (int(order) + 1) ** 2
+    wL, pwL = _out(int(len), C_, cplx)
+    wR, pwR = _out(int(len), C_, cplx)
+    L.check(L.load().emagls_get_emagls_filters_ema_in_sh(pL, pR, n, D, pa, pz, float(micRadius), pma, micAzi.size, int(order),
                                                          float(fs), int(len), b, pwL, pwR))
     return wL, wR
 

@@ -239,7 +239,9 @@ void check_pow2(int nfft) {
 // ---------------------------------------------------------------------------------------------
 // kinds that run the array-model pipeline (simulated array -> per-bin factor -> sweep)
 static inline bool magls_kind(int k) { return k == EMAGLS_KIND_MAGLS || k == EMAGLS_KIND_MAGLS_2D; }
-static inline bool array_kind(int k) { return k == EMAGLS_KIND_EMAGLS || k == EMAGLS_KIND_EMAGLS2 || k == EMAGLS_KIND_EMA_CH; }
+static inline bool array_kind(int k) { return k == EMAGLS_KIND_EMAGLS || k == EMAGLS_KIND_EMAGLS2 || k == EMAGLS_KIND_EMA_CH || k == EMAGLS_KIND_EMA_SH; }
+// evaluation points of the SH rotation fit (emash.hip): enough to resolve order N exactly
+static inline int ema_sh_npts(int C) { return 4 * C + 8; }
 
 // Smallest order n such that every order above it contributes less than 1e-20 of the strongest mode to pwGrid at kr = x:
 // |b_n(x)| (2n+1) / |b_0| <= x^n / (2n-1)!! (2n+1) for the rigid sphere (|j_n(x)| <= x^n / (2n+1)!!; the Wronskian form of b_n
@@ -261,7 +263,9 @@ void plan_routes(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     const int k0 = std::max(p.kcut0, 1);
     p.gram_from = emagls_gram_from(p);
-    if (p.gram_from > 0 && p.gram_from < p.gram_floor) p.gram_from = p.gram_floor < p.P ? p.gram_floor : 0;
+    // EMAinSH has no radial terms in its model: pwGrid_k is well conditioned at every bin (emash.hip) and all bins take the Gram route
+    if (d.kind == EMAGLS_KIND_EMA_SH) p.gram_from = 1;
+    else if (p.gram_from > 0 && p.gram_from < p.gram_floor) p.gram_from = p.gram_floor < p.P ? p.gram_floor : 0;
     p.hh_end = p.gram_from > 0 ? p.gram_from : p.P;
     const double f_h = (double)(p.hh_end - 1) * (d.fs / 2.0) / (double)(p.P - 1);
     int n_min = 0;   // the S-space factor needs at least as many rows as channels
@@ -272,6 +276,7 @@ void plan_routes(emagls_plan& p) {
     if (p.S_h > 768)
         throw Error(EMAGLS_ERR_UNSUPPORTED, "the ill-conditioned low bins of this design need more than 27 orders on the orthonormal route "
                                             "(Gram route off or moved up by a conditioning check): not supported in this build");
+    if (d.kind == EMAGLS_KIND_EMA_SH) { p.hh_end = 1; p.n_h = n_min; p.S_h = (n_min + 1) * (n_min + 1); p.ldS_h = round_up(p.S_h, 64); }
     p.g0 = (p.gram_from > 0 && p.gram_from < k0) ? p.gram_from : k0;
     if (p.diffuse) p.g0 = 1;   // the constraint renders the HRTFs of every solved bin: G_k from the first one
     p.nb_gram = p.gram_from > 0 ? p.P - p.gram_from : 0;
@@ -307,7 +312,7 @@ void plan_alloc_routes(emagls_plan& p) {
 
 void plan_setup(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
-    if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_MAGLS_2D) throw Error(EMAGLS_ERR_ARG, "unknown design kind");
+    if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_EMA_SH) throw Error(EMAGLS_ERR_ARG, "unknown design kind");
     if (d.basis != EMAGLS_BASIS_REAL && d.basis != EMAGLS_BASIS_COMPLEX) throw Error(EMAGLS_ERR_ARG, "shDefinition must be 'real' or 'complex'");
     if (d.ndirs < 1 || d.nsamp < 1) throw Error(EMAGLS_ERR_ARG, "empty HRIR set");
     if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
@@ -383,11 +388,14 @@ void plan_setup(emagls_plan& p) {
         p.simOrder = std::max(smair_order, (int)std::ceil(d.fs * kPi * d.mic_radius / C_SOUND));
         p.S = (p.simOrder + 1) * (p.simOrder + 1);
         p.nOut = d.kind == EMAGLS_KIND_EMA_CH ? 2 * N + 1 : (N + 1) * (N + 1);   // EMAinCH.m:66: numHarmonics = 2*order+1
+        if (d.kind == EMAGLS_KIND_EMA_SH && d.nmics < 2 * N + 1)
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than circular harmonics (2*order+1)");
         p.C = d.kind == EMAGLS_KIND_EMAGLS2 ? (int)d.nmics : p.nOut;
         if (p.C > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels is not supported in this build");
         if (p.simOrder > 47) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 47 (array radius > ~10.9 cm at 48 kHz) is not supported in this build");
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than simulated SH channels");
-        if (d.kind != EMAGLS_KIND_EMAGLS2 && d.nmics < p.nOut) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than output channels");
+        if (d.kind != EMAGLS_KIND_EMAGLS2 && d.kind != EMAGLS_KIND_EMA_SH && d.nmics < p.nOut)
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than output channels");
     } else {
         if (d.nmics < 1 || d.natf < 1 || d.atf_taps < 1) throw Error(EMAGLS_ERR_ARG, "invalid ATF set");
         p.C = (int)d.nmics;
@@ -442,6 +450,38 @@ void plan_setup(emagls_plan& p) {
             p.alloc("tau_lo", sizeof(double) * p.nOut);
             p.alloc("R2_lo", sizeof(cplx) * (size_t)p.nOut * p.nOut);
             p.alloc("N_lo", sizeof(cplx) * (size_t)p.nOut * p.nOut);
+        }
+        if (d.kind == EMAGLS_KIND_EMA_SH) {
+            if (N > 4) throw Error(EMAGLS_ERR_UNSUPPORTED, "EMAinSH: SH order above 4 is not supported in this build");
+            const int npts = ema_sh_npts(p.C), ldP = round_up(npts, 64);
+            const int64_t ldA = round_up((int64_t)(p.D + 1) * npts, 64);
+            p.alloc("Ech", esz(cb) * (size_t)(2 * N + 1) * p.ldS);          // pinv(CH(micAzi)) Y_mic
+            p.alloc("sh_tab_lo", sizeof(double) * sh_coeff_count(N));      // recurrence table of the output order (its layout depends on the order)
+            p.alloc("hrir_zen_eq", sizeof(double) * p.D, false);           // pi/2: the horizontal projection of the HRIR grid
+            p.alloc("nnm_azi", sizeof(double) * p.C, false);
+            p.alloc("nnm_zen", sizeof(double) * p.C, false);
+            p.alloc("Ypts", esz(cb) * (size_t)p.C * p.C);
+            p.alloc("rot_azi", sizeof(double) * (size_t)ldA, false);
+            p.alloc("rot_zen", sizeof(double) * (size_t)ldA, false);
+            p.alloc("Arot", esz(cb) * (size_t)p.C * ldA, false);           // SHs of order N at all rotated points (and the fixed set)
+            p.alloc("Bc", sizeof(cplx) * (size_t)p.C * ldP);
+            p.alloc("Zb", sizeof(cplx) * (size_t)p.C * ldP);
+            p.alloc("Vb", sizeof(cplx) * (size_t)p.C * ldP);
+            p.alloc("tau_b", sizeof(double) * p.C);
+            p.alloc("R2_b", sizeof(cplx) * (size_t)p.C * p.C);
+            p.alloc("N_b", sizeof(cplx) * (size_t)p.C * p.C);
+            p.alloc("Rot", esz(cb) * (size_t)p.D * p.C * p.C, false);
+            std::vector<double> eq((size_t)p.D, kPi / 2.0), na((size_t)p.C, 0.0), nz((size_t)p.C, kPi / 2.0);
+            for (int c = 0; c < p.C; ++c) {   // one azimuth per channel at which its circular harmonic is 1 (or sqrt 2)
+                int n = 0;
+                while ((n + 1) * (n + 1) <= c) ++n;
+                const int m = c - n * n - n;
+                na[c] = (!cb && m < 0) ? kPi / (2.0 * -m) : 0.0;
+            }
+            p.upload("hrir_zen_eq", eq.data(), sizeof(double) * p.D);
+            p.upload("nnm_azi", na.data(), sizeof(double) * p.C);
+            p.upload("nnm_zen", nz.data(), sizeof(double) * p.C);
+            HIP_CHECK(hipStreamSynchronize(p.stream));   // (the host vectors go out of scope)
         }
         p.alloc("kr", sizeof(double) * p.P, false);
         p.alloc("bn", sizeof(cplx) * (size_t)p.P * (p.simOrder + 1));
@@ -641,7 +681,97 @@ int emagls_gram_from(const emagls_plan& p) {
     return from < p.P ? from : 0;
 }
 
+// getEMagLsFiltersEMAinSH: everything before the sweep (kernels and derivation: emash.hip).  One stream.
+void ema_sh_pre_sweep(emagls_plan& p) {
+    const emagls_design_desc& d = p.d;
+    const bool cb = p.cplx_basis;
+    hipStream_t st = p.stream;
+    const int M = (int)d.nmics, ldM = round_up(M, 64), N = d.order, nCh = 2 * N + 1, nOrd = p.simOrder + 1;
+    const int ls_end = std::min(p.kcut0, p.P);
+    const int npts = ema_sh_npts(p.C), ldP = round_up(npts, 64);
+    const int64_t ldA = round_up((int64_t)(p.D + 1) * npts, 64);
+    const int64_t g_stride = (int64_t)p.C * p.ldD;
+    p.sync_used = 0;
+    // ---- HRIR prologue
+    launch_twiddles(p.nfft, p.get("tw"), st);
+    launch_hrir_grpdelay(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, d.ndirs, p.nfft, p.get("tw"), p.get<double>("dirsum"),
+                         p.get<double>("grpd"), st);
+    launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"), p.get<double>("grpd"), 0, ls_end,
+                    p.kcut0, p.get("Hc"), p.get<double>("Habs"), p.ldD, st);
+    if (p.diffuse)
+        launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"), p.get<double>("grpd"), 0, p.P,
+                        p.P, p.get("Hfull"), p.get<double>("Habs"), p.ldD, st);
+    p.mark("hrir_prologue");
+    // ---- array model: E0 = J pinv(CH(micAzi)) Y_mic   (EMAinSH.m:66-82), b_n(kr)
+    launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), st);
+    launch_sh_basis(p.simOrder, M, p.get<double>("mic_azi"), p.get<double>("mic_zen"), p.get<double>("sh_tab"), cb, p.get("Ymic_cm"), M, st);
+    launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("Ymic_rm"), M, p.ldS, cb, false, st);
+    launch_ch_basis(N, M, p.get<double>("mic_azi"), cb, p.get("Ylo_c"), ldM, st);
+    {
+        FactorArgs a{};
+        a.S = M; a.C = nCh; a.ldS = ldM; a.kb0 = 0; a.P = 2;
+        a.Xd = p.get<cplx>("Ylo_c"); a.xd_stride = 0;
+        a.reg_mode = 1; a.tol_dim = (double)std::max(M, nCh);
+        a.Z = p.get<cplx>("Zlo"); a.Vws = p.get<cplx>("Vlo");
+        a.tauw = p.get<double>("tau_lo"); a.R2w = p.get<cplx>("R2_lo"); a.Nw = p.get<cplx>("N_lo");
+        launch_factor(a, 1, true, st);
+    }
+    launch_small_gemm(p.get("Zlo"), ldM, true, p.get("Ymic_rm"), p.ldS, cb, p.get("Ech"), p.ldS, cb, nCh, p.S, M, st);
+    launch_sh_coeff(N, p.get<double>("sh_tab_lo"), st);
+    launch_sh_basis(N, p.C, p.get<double>("nnm_azi"), p.get<double>("nnm_zen"), p.get<double>("sh_tab_lo"), cb, p.get("Ypts"), p.C, st);
+    launch_ema_sh_e0(p.get("Ech"), (int)p.ldS, p.get("Ypts"), p.C, p.S, cb, p.get("E"), st);
+    launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, st);
+    p.mark("array_model");
+    // ---- per-direction SH rotations (EMAinSH.m:85-100)
+    launch_rot_points(p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), (int)p.D, npts, p.get<double>("rot_azi"), p.get<double>("rot_zen"), st);
+    launch_sh_basis(N, (p.D + 1) * npts, p.get<double>("rot_azi"), p.get<double>("rot_zen"), p.get<double>("sh_tab_lo"), cb, p.get("Arot"), ldA, st);
+    {
+        const char* B = (const char*)p.get("Arot") + esz(cb) * (size_t)p.D * npts;   // the unrotated point set: columns D*npts..
+        launch_widen(B, ldA, cb, p.get("Bc"), ldP, p.C, npts, false, false, st);
+        FactorArgs a{};
+        a.S = npts; a.C = p.C; a.ldS = ldP; a.kb0 = 0; a.P = 2;
+        a.Xd = p.get<cplx>("Bc"); a.xd_stride = 0;
+        a.reg_mode = 1; a.tol_dim = (double)std::max(npts, p.C);
+        a.Z = p.get<cplx>("Zb"); a.Vws = p.get<cplx>("Vb");
+        a.tauw = p.get<double>("tau_b"); a.R2w = p.get<cplx>("R2_b"); a.Nw = p.get<cplx>("N_b");
+        launch_factor(a, 1, true, st);
+    }
+    launch_rot_from_points(p.get("Arot"), ldA, p.get("Zb"), ldP, p.C, npts, p.get<double>("hrir_zen"), (int)p.D, cb, p.get("Rot"), st);
+    p.mark("sh_rotations");
+    // ---- order terms of pwGrid.' on the horizontal projection of the grid, rotated per direction; G_k of every bin
+    launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen_eq"), p.get<double>("sh_tab"), cb, p.get("Ycm"), p.ldD, st);
+    launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, cb, true, st);
+    launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, cb, p.get("QT"), p.ldD, st);
+    launch_qt_rotate(p.get("QT"), p.ldD, nOrd, p.C, N, (int)p.D, p.get("Rot"), cb, st);
+    launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, p.g0, p.get("G"), st, 0, -1);
+    p.mark("order_terms+G");
+    // ---- per-bin C x C matrices: Gram route for every bin
+    const int ldK = round_up(p.C * p.C, 64), gf = 1, nb = p.P - 1;
+    launch_gram_from_g(p.get("G"), g_stride, p.ldD, (int)p.D, p.C, gf, nb, p.g0, p.get<double>("Apk"), ldK, st);
+    launch_gram_solve(p.get<double>("Apk"), ldK, p.C, gf, nb, SVD_REGUL_CONST, p.get("Mw"), p.get("R2w"), p.get<double>("sv"),
+                      p.get<int>("route"), p.get<int>("jsweeps"), st);
+    {
+        FactorArgs fg{};
+        fg.S = p.C; fg.C = p.C; fg.ldS = round_up(p.C, 64); fg.kb0 = gf; fg.P = p.P;
+        fg.reg_mode = 0; fg.reg_c = SVD_REGUL_CONST;
+        fg.sv = p.get<double>("sv"); fg.route = p.get<int>("route"); fg.status = p.get<int>("flag");
+        fg.cond_limit = 10.0 * GRAM_COND_EST;
+        fg.sweeps_out = p.get<int>("jsweeps");
+        fg.tauw = p.get<double>("tauw"); fg.R2w = p.get<cplx>("R2w"); fg.Nw = p.get<cplx>("Nw"); fg.Mw = p.get<cplx>("Mw");
+        fg.jrun = batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
+        launch_factor_jacobi_gram(fg, nb, st);
+    }
+    launch_cond_flags(p.get<double>("sv"), p.C, p.P, 1, p.get<double>("cond_ok"), st);
+    p.mark("gram_route");
+    // ---- least-squares bins
+    if (ls_end > 1)
+        launch_ls_gram(p.get("Hc"), p.ldD, ls_end, (const cplx*)p.get("G") - (int64_t)p.g0 * g_stride, g_stride, p.ldD, p.get("Mw"), (int)p.D, p.C,
+                       p.P, 1, ls_end, p.get("W"), st);
+    p.mark("ls_bins");
+}
+
 void emagls_pre_sweep(emagls_plan& p) {
+    if (p.d.kind == EMAGLS_KIND_EMA_SH) { ema_sh_pre_sweep(p); return; }
     const emagls_design_desc& d = p.d;
     const bool cb = p.cplx_basis;
     const bool raw = d.kind == EMAGLS_KIND_EMAGLS2;
@@ -966,7 +1096,8 @@ void run_pipeline(emagls_plan& p) {
         case EMAGLS_KIND_MAGLS_2D: execute_magls(p); break;
         case EMAGLS_KIND_EMAGLS:
         case EMAGLS_KIND_EMAGLS2:
-        case EMAGLS_KIND_EMA_CH: execute_emagls(p); break;
+        case EMAGLS_KIND_EMA_CH:
+        case EMAGLS_KIND_EMA_SH: execute_emagls(p); break;
         default: execute_from_atf(p); break;
     }
 }
@@ -1543,7 +1674,7 @@ int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* ze
         if (!p->has("mic_azi")) throw Error(EMAGLS_ERR_ARG, "this design kind has no microphone grid");
         // an equatorial array (EMAinCH) has no zenith argument: pi/2 for every microphone (getEMagLsFiltersEMAinCH.m:60)
         std::vector<double> equator;
-        if (p->d.kind == EMAGLS_KIND_EMA_CH) { equator.assign((size_t)p->d.nmics, kPi / 2.0); zen = equator.data(); }
+        if (p->d.kind == EMAGLS_KIND_EMA_CH || p->d.kind == EMAGLS_KIND_EMA_SH) { equator.assign((size_t)p->d.nmics, kPi / 2.0); zen = equator.data(); }
         if (!zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
         p->upload("mic_azi", azi, sizeof(double) * p->d.nmics);
         p->upload("mic_zen", zen, sizeof(double) * p->d.nmics);
@@ -1873,6 +2004,16 @@ int emagls_get_emagls_filters_ema_in_ch(const double* hL, const double* hR, int6
     std::vector<double> mic_zen((size_t)nmics, kPi / 2.0);   // getEMagLsFiltersEMAinCH.m:60: equatorial array
     return one_shot(d, hL, hR, azi, zen, mic_azi, mic_zen.data(), nullptr, nullptr, nullptr, wL, wR, nullptr);
 }
+int emagls_get_emagls_filters_ema_in_sh(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi,
+                                        const double* zen, double mic_radius, const double* mic_azi, int64_t nmics, int order,
+                                        double fs, int64_t len, int basis, void* wL, void* wR) {
+    emagls_design_desc d{};
+    d.kind = EMAGLS_KIND_EMA_SH; d.basis = basis; d.order = order; d.fs = fs; d.len = len; d.nsamp = nsamp; d.ndirs = ndirs;
+    d.mic_radius = mic_radius; d.nmics = nmics;
+    if (!mic_azi || nmics < 1) { g_last_error = "invalid array geometry"; return EMAGLS_ERR_ARG; }
+    std::vector<double> mic_zen((size_t)nmics, kPi / 2.0);   // getEMagLsFiltersEMAinSH.m:58: equatorial array
+    return one_shot(d, hL, hR, azi, zen, mic_azi, mic_zen.data(), nullptr, nullptr, nullptr, wL, wR, nullptr);
+}
 int emagls_get_emagls_filters_from_atf(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs,
                                        const double* azi, const double* zen, const double* atf_irs, int64_t atf_taps,
                                        int64_t nmics, int64_t natf, const double* atf_azi, const double* atf_zen, double fs,
@@ -1973,7 +2114,7 @@ int emagls_get_magls_filters_2d(const double* hL, const double* hR, int64_t nsam
 
 int emagls_simulation_order(int kind, int order, double fs, double mic_radius) {
     switch (kind) {
-        case EMAGLS_KIND_EMAGLS: case EMAGLS_KIND_EMA_CH:
+        case EMAGLS_KIND_EMAGLS: case EMAGLS_KIND_EMA_CH: case EMAGLS_KIND_EMA_SH:
             return std::max(order, (int)std::ceil(fs * kPi * mic_radius / C_SOUND));                   // getSMAIRMatrix.m:95
         case EMAGLS_KIND_EMAGLS2:
             return std::max(SMAIR_DEFAULT_ORDER, (int)std::ceil(fs * kPi * mic_radius / C_SOUND));     // params.order unset -> 4

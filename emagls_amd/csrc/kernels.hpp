@@ -130,6 +130,15 @@ void decode_cache_clear();
 void filter_channels_by_order(const double* sig, int64_t n_in, int64_t n, int C, const double* ir /* [nOrd][len] */, int nOrd, int64_t len,
                               int64_t skip, double* out /* [C][n-skip] */, hipStream_t st);
 
+// ---- emash.hip (getEMagLsFiltersEMAinSH)
+void launch_ema_sh_e0(const void* Ech, int ldS, const void* Ypts, int C, int S, bool cb, void* E0, hipStream_t st);
+void launch_rot_points(const double* azi, const double* zen, int D, int npts, double* azr, double* znr, hipStream_t st);
+void launch_rot_from_points(const void* A, int64_t ldA, const void* Z, int ldP, int C, int npts, const double* zen, int D, bool cb, void* Rot,
+                            hipStream_t st);
+void launch_qt_rotate(void* QT, int64_t ldD, int nOrd, int C, int N, int D, const void* Rot, bool cb, hipStream_t st);
+void launch_gram_from_g(const void* G, int64_t g_stride, int64_t ldD, int D, int C, int kb0, int nbins, int g0, double* Apk, int ldK,
+                        hipStream_t st);
+
 // ---- render.hip
 void launch_radial_filter(const void* bn, int nOrd, int P, int type, double regul, double g, bool nyq_abs, bool zero_nan,
                           void* out_kn, void* out_cm, hipStream_t st);

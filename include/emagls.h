@@ -52,6 +52,7 @@ extern "C" {
 #define EMAGLS_KIND_FROM_ATF 4
 #define EMAGLS_KIND_EMA_CH 5   /* equatorial array, output in circular harmonics (2*order+1 channels) */
 #define EMAGLS_KIND_MAGLS_2D 6 /* MagLS on a horizontal HRIR set in circular harmonics (2*order+1 channels) */
+#define EMAGLS_KIND_EMA_SH 7   /* equatorial array, output in spherical harmonics ((order+1)^2 channels) */
 
 const char* emagls_last_error(void);
 int emagls_version(void);
@@ -123,6 +124,12 @@ int emagls_get_emagls_filters_with_basis(const double* hL, const double* hR, int
 int emagls_get_emagls2_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir,
                                           double mic_radius, const void* Y_mic, int64_t nmics, int order, double fs, int64_t len,
                                           int basis, void* wL, void* wR);
+
+/* lib/getEMagLsFiltersEMAinSH.m:1-2 -- [wMlsL, wMlsR] = getEMagLsFiltersEMAinSH(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius,
+ * micGridAziRad, order, fs, len, shDefinition): equatorial array (zenith pi/2 for every microphone), filters [len x (order+1)^2] */
+int emagls_get_emagls_filters_ema_in_sh(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi,
+                                        const double* zen, double mic_radius, const double* mic_azi, int64_t nmics, int order,
+                                        double fs, int64_t len, int basis, void* wL, void* wR);
 
 /* atf_irs [atf_taps x nmics x natf]; outputs real [filter_len x nmics];
  * mean_grid_dev_deg (optional) receives the value the reference prints (getEMagLsFiltersFromAtf.m:96). */

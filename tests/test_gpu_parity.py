@@ -646,3 +646,33 @@ def test_error_behaviour(grids, hrirs):
         E.getEMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 0.042, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 4096)
     with pytest.raises(EmaglsError, match="index error"):
         E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 4096)
+
+
+@pytest.mark.parametrize("basis,nmics", [("real", 16), ("complex", 16), ("real", 9)])
+def test_emagls_ema_in_sh(thin, basis, nmics):
+    """getEMagLsFiltersEMAinSH (second half): equatorial array on a 4.2 cm sphere, order 4, filters in the
+    25 spherical harmonics.  Horizontal-projection order terms rotated per direction, Gram route for every bin (the model has
+    no radial terms: cond(pwGrid) < 1e3 at every bin)."""
+    import emagls_amd as E
+    mic_azi = np.linspace(0.0, 2 * np.pi, nmics, endpoint=False) + 0.1
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, mic_azi, 4, 48000.0, 128, basis)
+    wL, wR = E.getEMagLsFiltersEMAinSH(*args)
+    oL, oR = O.getEMagLsFiltersEMAinSH(*args)
+    assert wL.dtype == oL.dtype and wL.shape == (128, 25)
+    assert report("EMAinSH L " + basis, wL, oL) < TOL and report("EMAinSH R " + basis, wR, oR) < TOL
+    from emagls_amd._lib import EmaglsError
+    with pytest.raises(EmaglsError, match="fewer microphones"):
+        E.getEMagLsFiltersEMAinSH(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, mic_azi[:8], 4, 48000.0, 128, basis)
+
+
+def test_emagls_ema_in_sh_low_order_and_horizontal_directions(thin):
+    """Order 2 on a grid that contains directions exactly on the horizon (the reference leaves those unrotated, EMAinSH.m:92)."""
+    import emagls_amd as E
+    azi, zen = thin["azi"].copy(), thin["zen"].copy()
+    zen[::7] = np.pi / 2
+    mic_azi = np.linspace(0.0, 2 * np.pi, 12, endpoint=False)
+    args = (thin["hL"], thin["hR"], azi, zen, 0.05, mic_azi, 2, 48000.0, 256, "real")
+    wL, wR = E.getEMagLsFiltersEMAinSH(*args)
+    oL, oR = O.getEMagLsFiltersEMAinSH(*args)
+    assert wL.shape == (256, 9)
+    assert report("EMAinSH N=2 L", wL, oL) < TOL and report("EMAinSH N=2 R", wR, oR) < TOL
