@@ -65,7 +65,8 @@ void at_exit() { emagls_cache_clear(); }
 // emagls_mex('emagls',  hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition)
 // emagls_mex('emagls2', ... same ...)
 // emagls_mex('fromatf', hL, hR, hrirGridAziZen, atfIrs, atfGridAziZen, fs, filterLen, fTrans)
-// emagls_mex('emainch', hL, hR, azi, zen, micRadius, micAzi, order, fs, len, shDefinition)
+// emagls_mex('emainch' | 'emainsh', hL, hR, azi, zen, micRadius, micAzi, order, fs, len, shDefinition)
+// emagls_mex('magls_dc' | 'emagls_dc' | 'emagls2_dc', <the arguments of 'magls' / 'emagls' / 'emagls2'>, applyDiffusenessConst)
 // emagls_mex('decode',  in, wL, wR, compensateDelay)            real or complex in / filters; [out, imagAbsSum] = ...
 // caller-evaluated shFunction handles (the wrappers evaluate them at emagls_mex('simorder', kind, order, fs, micRadius)):
 // emagls_mex('ls_y', hL, hR, Yhrir, order, shDefinition)        emagls_mex('magls_y', hL, hR, Yhrir, order, fs, len, shDefinition)
@@ -163,6 +164,31 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         return;
     }
     if (nrhs < 6) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+    if (c == "magls_dc" || c == "emagls_dc" || c == "emagls2_dc") {   // the removed applyDiffusenessConst option (include/emagls.h)
+        const bool ml = c == "magls_dc", raw = c == "emagls2_dc";
+        const int o = ml ? 5 : 8;                    // index of `order`
+        if (nrhs < o + 5) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+        const mwSize ns = mxGetM(prhs[1]), nd = mxGetN(prhs[1]);
+        const int order = (int)mxGetScalar(prhs[o]);
+        const double fs = mxGetScalar(prhs[o + 1]);
+        const mwSize len = (mwSize)mxGetScalar(prhs[o + 2]);
+        const int basis = basis_of(prhs[o + 3]);
+        const int dc = mxIsLogicalScalarTrue(prhs[o + 4]) || mxGetScalar(prhs[o + 4]) != 0;
+        const mwSize nmics = ml ? 0 : mxGetNumberOfElements(prhs[6]);
+        const mwSize C = raw ? nmics : (mwSize)((order + 1) * (order + 1));
+        plhs[0] = out_matrix(len, C, basis);
+        plhs[1] = out_matrix(len, C, basis);
+        int rc;
+        if (ml)
+            rc = emagls_get_magls_filters_dc(dbl(prhs[1], "hL"), dbl(prhs[2], "hR"), ns, nd, dbl(prhs[3], "azi"), dbl(prhs[4], "zen"), order, fs,
+                                             len, dc, basis, out_ptr(plhs[0]), out_ptr(plhs[1]));
+        else
+            rc = (raw ? emagls_get_emagls2_filters_dc : emagls_get_emagls_filters_dc)(
+                dbl(prhs[1], "hL"), dbl(prhs[2], "hR"), ns, nd, dbl(prhs[3], "azi"), dbl(prhs[4], "zen"), mxGetScalar(prhs[5]),
+                dbl(prhs[6], "micAzi"), dbl(prhs[7], "micZen"), nmics, order, fs, len, dc, basis, out_ptr(plhs[0]), out_ptr(plhs[1]));
+        if (rc) fail(rc);
+        return;
+    }
     const double* hL = dbl(prhs[1], "hL");
     const double* hR = dbl(prhs[2], "hR");
     const mwSize nsamp = mxGetM(prhs[1]), ndirs = mxGetN(prhs[1]);
@@ -238,7 +264,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         plhs[1] = out_matrix(len, C, basis);
         rc = (raw ? emagls_get_emagls2_filters_with_basis : emagls_get_emagls_filters_with_basis)(
             hL, hR, nsamp, ndirs, Yh, r, Ym, nmics, order, fs, len, basis, out_ptr(plhs[0]), out_ptr(plhs[1]));
-    } else if (c == "emainch") {   // getEMagLsFiltersEMAinCH(hL, hR, azi, zen, micRadius, micGridAziRad, order, fs, len, shDefinition)
+    } else if (c == "emainch" || c == "emainsh") {   // getEMagLsFiltersEMAinCH(hL, hR, azi, zen, micRadius, micGridAziRad, order, fs, len, shDefinition)
         if (nrhs < 10) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
         const double r = mxGetScalar(prhs[5]);
         const mwSize nmics = mxGetNumberOfElements(prhs[6]);
@@ -246,12 +272,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const double fs = mxGetScalar(prhs[8]);
         const mwSize len = (mwSize)mxGetScalar(prhs[9]);
         const int basis = basis_of(nrhs > 10 ? prhs[10] : nullptr);
-        const mwSize C = (mwSize)(2 * order + 1);
+        const bool sh = c == "emainsh";   // getEMagLsFiltersEMAinSH: same arguments, (order+1)^2 spherical-harmonic channels
+        const mwSize C = sh ? (mwSize)((order + 1) * (order + 1)) : (mwSize)(2 * order + 1);
         plhs[0] = out_matrix(len, C, basis);
         plhs[1] = out_matrix(len, C, basis);
-        rc = emagls_get_emagls_filters_ema_in_ch(hL, hR, nsamp, ndirs, dbl(prhs[3], "azi"), dbl(prhs[4], "zen"), r,
-                                                 dbl(prhs[6], "micAzi"), nmics, order, fs, len, basis, out_ptr(plhs[0]),
-                                                 out_ptr(plhs[1]));
+        rc = (sh ? emagls_get_emagls_filters_ema_in_sh : emagls_get_emagls_filters_ema_in_ch)(
+            hL, hR, nsamp, ndirs, dbl(prhs[3], "azi"), dbl(prhs[4], "zen"), r, dbl(prhs[6], "micAzi"), nmics, order, fs, len, basis,
+            out_ptr(plhs[0]), out_ptr(plhs[1]));
     } else if (c == "fromatf") {
         if (nrhs < 9) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
         const double* hg = dbl(prhs[3], "hrirGridAziZenRad");   // [ndirs x 2], column-major: azi then zen
