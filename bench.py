@@ -430,7 +430,9 @@ def main():
             persistent = sweep_n == 1  # one resident launch walks all swept bins (sweep_persist.hip)
             kname = "sweep_persist_kernel" if persistent else "sweep_half_kernel"
             bytes_launch = bytes_bin * nbins_swept / sweep_n
-            traffic = pmc.get(kname, {}).get("bytes")
+            traffic = pmc.get(kname, {}).get("bytes")          # per launch of `designs_per_launch` designs in the PMC run
+            if traffic is not None:
+                traffic = traffic / float(pmc.get("designs_per_launch", 1))
             # one design per launch: sweep stage time of the single-design plan (HIP events on the plan's stream)
             stage_sweep_ms = dict(stages).get("magls_sweep", sweep_ms)
             single_s = stage_sweep_ms / sweep_n * 1e-3

@@ -22,7 +22,8 @@ def demangle(n):
         d = subprocess.run(["c++filt", n.replace(".kd", "")], capture_output=True, text=True).stdout.strip()
     except Exception:
         d = n
-    d = re.sub(r"\(.*", "", d).replace("emagls::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+    d = d.replace("(anonymous namespace)::", "").replace("emagls::", "").replace("void ", "")
+    d = re.sub(r"\(.*", "", d)
     return d or n
 
 
@@ -102,7 +103,8 @@ def main():
             e["bytes"] = int((2 * e["fetch_kb"] + e["write_kb"]) * 1024)
             launches_per_batch[name] = nd
             per_set += e["bytes"] * nd
-        key = name.split("<")[0] if name.split("<")[0] in ("sweep_persist_kernel", "sweep_half_kernel", "dspace_g_kernel") else name
+        base = name.split("<")[0]
+        key = base if base in ("sweep_persist_kernel", "sweep_half_kernel", "dspace_g_kernel") else name
         res[key] = e
         rows.append((name, e))
     # batch executions in the run = dispatches of a kernel that runs once per batch
