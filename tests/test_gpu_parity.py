@@ -676,3 +676,59 @@ def test_emagls_ema_in_sh_low_order_and_horizontal_directions(thin):
     oL, oR = O.getEMagLsFiltersEMAinSH(*args)
     assert wL.shape == (256, 9)
     assert report("EMAinSH N=2 L", wL, oL) < TOL and report("EMAinSH N=2 R", wR, oR) < TOL
+
+
+def test_batch_of_ema_in_sh_designs_on_a_caller_stream(thin):
+    """EMAinSH designs in a lane batch that runs on a stream the caller created (emagls_batch_set_stream): equal to the
+    one-shot entry point; three executes (eager, capture, replay)."""
+    import torch
+    import emagls_amd as E
+    from emagls_amd import Batch, Plan, _lib as L
+    st = torch.cuda.Stream()
+    mazs = [np.linspace(0.0, 2 * np.pi, 12, endpoint=False) + 0.1 * (j + 1) for j in range(3)]
+    plans = []
+    for maz in mazs:
+        p = Plan(L.KIND_EMA_SH, "real", 3, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], 0.042, 12)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(maz)
+        p.set_hrirs(thin["hL"], thin["hR"])
+        plans.append(p)
+    b = Batch(plans)
+    b.set_stream(st.cuda_stream)
+    for it in range(3):
+        b.execute()
+        res = b.get_filters()
+    for (wL, wR), maz in zip(res, mazs):
+        sL, sR = E.getEMagLsFiltersEMAinSH(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, 3, 48000.0, 128, "real")
+        assert wL.shape == (128, 16) and rel(wL, sL) < 1e-12 and rel(wR, sR) < 1e-12
+    b.close()
+    for p in plans:
+        p.close()
+
+
+def test_batch_of_designs_with_the_diffuseness_constraint(grids, thin):
+    """The constraint's kernel in lane mode (grid.z = design): a batch of eMagLS plans with `diffuseness` equals the one-shot
+    calls with applyDiffusenessConst, and differs from the unconstrained design."""
+    import emagls_amd as E
+    from emagls_amd import Batch, Plan, _lib as L
+    sets = [dict(hL=np.ascontiguousarray(thin["hL"]) if j == 0 else np.ascontiguousarray(thin["hL"][:, ::-1]),
+                 hR=np.ascontiguousarray(thin["hR"]) if j == 0 else np.ascontiguousarray(thin["hR"][:, ::-1])) for j in range(2)]
+    plans = []
+    for s_ in sets:
+        p = Plan(L.KIND_EMAGLS, "real", 4, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], grids["mic_radius"], 32, diffuseness=True)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+        p.set_hrirs(s_["hL"], s_["hR"])
+        plans.append(p)
+    b = Batch(plans)
+    for it in range(3):
+        b.execute()
+        res = b.get_filters()
+    for (wL, wR), s_ in zip(res, sets):
+        args = (s_["hL"], s_["hR"], thin["azi"], thin["zen"], grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "real")
+        sL, sR = E.getEMagLsFilters(*args, applyDiffusenessConst=True)
+        uL, _ = E.getEMagLsFilters(*args)
+        assert rel(wL, sL) < 1e-12 and rel(wR, sR) < 1e-12 and rel(wL, uL) > 1e-3
+    b.close()
+    for p in plans:
+        p.close()
