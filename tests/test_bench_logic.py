@@ -14,12 +14,12 @@ def _bench():
 
 def test_schedule_processes_exactly_the_requested_designs():
     """The resident configuration (4 x 8) does not depend on --steps: a region of K designs is K // 8 full batches and one
-    partial batch, never a design more."""
+    partial batch (issued first: the batch with the least work reaches its sweep first), never a design more."""
     sch = _bench().schedule
     for k in range(1, 300):
         s = sch(k)
-        assert sum(s) == k and all(x == 8 for x in s[:-1]) and 1 <= s[-1] <= 8
-    assert sch(20) == [8, 8, 4] and sch(128) == [8] * 16 and sch(5, 8) == [5]
+        assert sum(s) == k and all(x == 8 for x in s[1:]) and 1 <= s[0] <= 8
+    assert sch(20) == [4, 8, 8] and sch(128) == [8] * 16 and sch(5, 8) == [5]
 
 
 def test_gpus_flag_spawns_fresh_ranks(tmp_path):

@@ -1,14 +1,9 @@
-# throughput of bench.py over (resident batches, designs per batch); usage: bash tools/exp_slots.sh "4x8 2x16 3x16 4x16"
-cd $GRAFT_REPO_ROOT
-for cfg in ${1:-4x8 2x16 3x16}; do
-  sl=${cfg%x*}; bs=${cfg#*x}
-  timeout 600 python bench.py --steps 192 --warmup 48 --slots $sl --batch $bs --no-cpu-baseline --no-sh-roofline --no-secondary > gpurun_out/exp_${cfg}.json 2> gpurun_out/exp_${cfg}.err
-  python - <<PY
-import json
-try:
-    d=json.load(open("gpurun_out/exp_${cfg}.json"))
-    print("${cfg}", round(d["value"],1), "sets/s; sweep us/bin", round(d["roofline"]["us_per_bin"],3), "avg launch us", round(d["roofline"]["avg_launch_us"],1))
-except Exception as e:
-    print("${cfg} failed", e); print(open("gpurun_out/exp_${cfg}.err").read()[-800:])
-PY
+#!/bin/bash
+# throughput against the number of batches in flight (and the batch size)
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
+val() { python -c "import sys,json; [print(round(json.loads(l)['value'],1), end=' ') for l in sys.stdin if l.startswith('{')]"; }
+for cfg in "3 8" "4 8" "5 8" "6 8" "8 8" "6 4" "4 6"; do
+  set -- $cfg
+  echo -n "slots $1 batch $2: "
+  for i in 1 2; do timeout 300 python bench.py --steps $((16 * $1 * $2 / 4)) --warmup $(($1 * $2)) --slots $1 --batch $2 --no-cpu-baseline --no-sh-roofline --no-secondary 2>/dev/null | val; done; echo
 done
