@@ -1,4 +1,6 @@
 #!/bin/bash
+# batches of more than 8 designs with several batches in flight: reproduces the stall described in DESIGN.md section 5
+# (expect missing / tiny values for some configurations: the sweep falls back to launch-per-bin after its spin limit)
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 val() { python -c "import sys,json; [print(round(json.loads(l)['value'],1), end=' ') for l in sys.stdin if l.startswith('{')]"; }
 export EMAGLS_BATCH_MAX=16
