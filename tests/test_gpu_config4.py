@@ -127,3 +127,20 @@ def test_radius_sweep_through_job_batching(grids, hrirs64):
         oL, oR = O.getEMagLs2Filters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], float(radii[j]), grids["mic_azi"], grids["mic_zen"],
                                      4, 48000.0, length, "real")
         assert rel(results[j][0], oL) < TOL and rel(results[j][1], oR) < TOL
+
+
+def test_run_batch_composes_with_the_real_designs(grids, hrirs64):
+    """emagls_amd.batch.run_batch (the multi-GPU job runner; its gather is covered on CPU with two gloo ranks) driving the real
+    design function on this GPU: jobs come back in job order and equal direct calls."""
+    import emagls_amd as E
+    from emagls_amd.batch import run_batch, simulation_order
+    radii = [0.06, 0.025, 0.042]
+
+    def design(r):
+        return E.getEMagLs2Filters(hrirs64[0], hrirs64[1], grids["azi"], grids["zen"], r, grids["mic_azi"], grids["mic_zen"], 4,
+                                   48000.0, 64, "real")
+    out = run_batch(radii, design, costs=[(simulation_order(4, 48000.0, r, raw=True) + 1) ** 2 for r in radii])
+    assert len(out) == 3
+    for (wL, wR), r in zip(out, radii):
+        dL, dR = design(r)
+        assert wL.shape == (64, 32) and np.array_equal(wL, dL) and np.array_equal(wR, dR)
