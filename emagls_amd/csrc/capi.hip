@@ -25,6 +25,39 @@ constexpr double F_CUT_MIN_FREQ = 1e3;  // :36
 constexpr double SVD_REGUL_CONST = 0.01;  // :39
 constexpr int SMAIR_DEFAULT_ORDER = 4;    // dependencies/getSMAIRMatrix.m:39-41 (params.order when the caller leaves it unset)
 
+// Streams are recycled through a process-wide pool and never destroyed.  A design plan owns three and a long session creates
+// and drops hundreds of plans (one-shot cache evictions, radius sweeps).  Under the HIP 7.0 runtime that torch bundles, a
+// multi-stream graph capture on stream handles the runtime had recycled after many hipStreamDestroy calls produced a graph
+// whose hipGraphLaunch dereferenced a null pointer (reproduced: tests/test_gpu_config4.py followed by test_gpu_parity.py, crash
+// in the third custom-basis one-shot call; gone with the pool, and gone with single-stream capture).
+struct StreamPool {
+    std::mutex mu;
+    std::map<int, std::vector<hipStream_t>> idle;   // per device
+    static StreamPool& get() { static StreamPool* p = new StreamPool; return *p; }   // (never destroyed: outlives every plan)
+    static bool enabled() { static const bool on = [] { const char* e = getenv("EMAGLS_STREAM_POOL"); return !(e && e[0] == '0'); }(); return on; }
+    hipStream_t take() {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        if (enabled()) {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& v = idle[dev];
+            if (!v.empty()) { hipStream_t st = v.back(); v.pop_back(); return st; }
+        }
+        hipStream_t st = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        return st;
+    }
+    void give(hipStream_t st) {
+        if (!st) return;
+        if (!enabled()) { hipStreamDestroy(st); return; }
+        hipStreamSynchronize(st);
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { hipStreamDestroy(st); return; }
+        std::lock_guard<std::mutex> lk(mu);
+        idle[dev].push_back(st);
+    }
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -116,12 +149,12 @@ struct emagls_plan {
         for (auto e : stage_events) hipEventDestroy(e);
         for (auto e : sweep_events) hipEventDestroy(e);
         for (auto e : sync_events) hipEventDestroy(e);
-        for (auto st : side) if (st) hipStreamDestroy(st);
+        for (auto st : side) StreamPool::get().give(st);
         if (graph_exec) hipGraphExecDestroy(graph_exec);
         if (graph) hipGraphDestroy(graph);
         if (pre_exec) hipGraphExecDestroy(pre_exec);
         if (pre_graph) hipGraphDestroy(pre_graph);
-        if (stream) hipStreamDestroy(stream);
+        StreamPool::get().give(stream);
     }
     void* alloc(const std::string& name, size_t bytes, bool zero = true) {
         if (bytes == 0) bytes = 16;
@@ -202,7 +235,7 @@ struct emagls_batch {
         if (post_exec) hipGraphExecDestroy(post_exec);
         if (post_graph) hipGraphDestroy(post_graph);
         for (auto e : sweep_ev) if (e) hipEventDestroy(e);
-        if (stream && own_stream) hipStreamDestroy(stream);
+        if (stream && own_stream) emagls::pool_stream_give(stream);
         for (auto* p : plans) if (p) { p->sync_stream = nullptr; p->owner = nullptr; }
     }
 };
@@ -316,9 +349,9 @@ void plan_setup(emagls_plan& p) {
     if (d.basis != EMAGLS_BASIS_REAL && d.basis != EMAGLS_BASIS_COMPLEX) throw Error(EMAGLS_ERR_ARG, "shDefinition must be 'real' or 'complex'");
     if (d.ndirs < 1 || d.nsamp < 1) throw Error(EMAGLS_ERR_ARG, "empty HRIR set");
     if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
-    HIP_CHECK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    p.stream = StreamPool::get().take();
     if (const char* ng = getenv("EMAGLS_NO_GRAPH")) p.use_graph = !(ng[0] == '1');
-    for (auto& st : p.side) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto& st : p.side) st = StreamPool::get().take();
     if (const char* ns = getenv("EMAGLS_STREAMS")) p.nstreams = std::max(1, std::min(3, atoi(ns)));
     p.req_cplx = d.basis == EMAGLS_BASIS_COMPLEX;
     // Complex-basis eMagLS / eMagLS2 designs run in real arithmetic.  With Y_c = Y_r T (T unitary, block diagonal per order)
@@ -1420,6 +1453,8 @@ void plan_check_flags(emagls_plan& p) {
 }
 
 }  // namespace
+hipStream_t emagls::pool_stream_take() { return StreamPool::get().take(); }
+void emagls::pool_stream_give(hipStream_t st) { StreamPool::get().give(st); }
 int emagls::guarded_call(const std::function<void()>& f) {
     try {
         f();
@@ -1491,7 +1526,10 @@ int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR,
             fresh.reset(new emagls_plan);
             fresh->d = desc;
             plan_setup(*fresh);
-            if (array_kind(desc.kind)) fresh->nstreams = 3;   // one design at a time: independent branches fork onto side streams
+            if (array_kind(desc.kind)) {   // one design at a time: independent branches fork onto side streams
+                const char* e = getenv("EMAGLS_ONESHOT_STREAMS");
+                fresh->nstreams = e ? std::max(1, std::min(3, atoi(e))) : 3;
+            }
             p = fresh.get();
         }
         auto release = [&](bool ok) {
@@ -1864,7 +1902,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
                 throw Error(EMAGLS_ERR_ARG, "all designs of a batch must have the same shape (directions, channels, bins, k_cut)");
             b->plans.push_back(p);
         }
-        HIP_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        b->stream = StreamPool::get().take();
         if (const char* ng = getenv("EMAGLS_NO_GRAPH")) b->use_graph = !(ng[0] == '1');
         // one persistent sweep launch keeps designs x nWG workgroups resident: one per CU up to 8 designs (one design per XCD),
         // two per CU beyond (77 KB of LDS and 5 waves per workgroup)
@@ -1934,7 +1972,7 @@ int emagls_batch_set_stream(emagls_batch* b, void* stream) {
     return guarded([&] {
         if (!b || !stream) throw Error(EMAGLS_ERR_ARG, "null pointer");
         HIP_CHECK(hipStreamSynchronize(b->stream));
-        if (b->own_stream) HIP_CHECK(hipStreamDestroy(b->stream));
+        if (b->own_stream) emagls::pool_stream_give(b->stream);
         b->stream = (hipStream_t)stream;      // (captured graphs are not tied to a stream: they replay on the new one)
         b->own_stream = false;
         for (auto* p : b->plans) if (p) p->sync_stream = b->stream;
@@ -2040,10 +2078,10 @@ static int decode_entry(const void* in, bool in_cplx, int64_t nsamp, int64_t nch
         hipStream_t st = nullptr;
         auto cleanup = [&] {
             hipFree(d_in); hipFree(d_wL); hipFree(d_wR); hipFree(d_out); hipFree(d_sig2); hipFree(d_w2L); hipFree(d_w2R); hipFree(d_tmp);
-            if (st) hipStreamDestroy(st);
+            emagls::pool_stream_give(st);
         };
         try {
-            HIP_CHECK(hipStreamCreate(&st));
+            st = emagls::pool_stream_take();
             HIP_CHECK(hipMalloc(&d_in, es_in * nsamp * nch));
             HIP_CHECK(hipMalloc(&d_wL, es_w * len * nch));
             HIP_CHECK(hipMalloc(&d_wR, es_w * len * nch));

@@ -151,6 +151,9 @@ void launch_diffuse_constraint(void* W, const void* G, bool g_cplx, int64_t g_st
                                int P, hipStream_t st);
 void launch_sh_encode(const double* sig, int64_t n, int M, const void* Z, int ldZ, int nOut, bool out_cplx, void* out, hipStream_t st);
 
+// ---- capi.hip: process-wide stream pool (streams are recycled, never destroyed: see StreamPool)
+hipStream_t pool_stream_take();
+void pool_stream_give(hipStream_t st);
 // ---- capi.hip: runs f, maps exceptions to the C status codes and records the message for emagls_last_error()
 int guarded_call(const std::function<void()>& f);
 

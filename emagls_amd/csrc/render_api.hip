@@ -17,10 +17,10 @@ constexpr int NFFT_MAX_LEN = 2048;    // lib/getMagLsSphericalHeadFilter.m:23
 struct Scratch {
     std::vector<void*> ptrs;
     hipStream_t st = nullptr;
-    Scratch() { HIP_CHECK(hipStreamCreate(&st)); }
+    Scratch() { st = pool_stream_take(); }
     ~Scratch() {
         for (void* p : ptrs) hipFree(p);
-        if (st) hipStreamDestroy(st);
+        pool_stream_give(st);
     }
     template <typename T = void> T* get(size_t bytes, bool zero = false) {
         void* p = nullptr;
