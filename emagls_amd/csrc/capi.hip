@@ -714,6 +714,13 @@ int emagls_gram_from(const emagls_plan& p) {
     return from < p.P ? from : 0;
 }
 
+// bins per Jacobi workgroup on the Gram route (warm start from the neighbouring bin): 4 in batches of 4+ designs, else 2 / 1
+int jacobi_run_length() {
+    static const int forced = [] { const char* e = getenv("EMAGLS_JACOBI_RUN"); return e ? std::max(1, atoi(e)) : 0; }();
+    if (forced) return forced;
+    return batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
+}
+
 // getEMagLsFiltersEMAinSH: everything before the sweep (kernels and derivation: emash.hip).  One stream.
 void ema_sh_pre_sweep(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
@@ -791,7 +798,7 @@ void ema_sh_pre_sweep(emagls_plan& p) {
         fg.cond_limit = 10.0 * GRAM_COND_EST;
         fg.sweeps_out = p.get<int>("jsweeps");
         fg.tauw = p.get<double>("tauw"); fg.R2w = p.get<cplx>("R2w"); fg.Nw = p.get<cplx>("Nw"); fg.Mw = p.get<cplx>("Mw");
-        fg.jrun = batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
+        fg.jrun = jacobi_run_length();
         launch_factor_jacobi_gram(fg, nb, st);
     }
     launch_cond_flags(p.get<double>("sv"), p.C, p.P, 1, p.get<double>("cond_ok"), st);
@@ -930,7 +937,7 @@ void emagls_pre_sweep(emagls_plan& p) {
         fg.R2w = fa.R2w + off * p.C * p.C; fg.Mw = fa.Mw + off * p.C * p.C; fg.Nw = fa.Nw + off * p.C * p.C; fg.tauw = fa.tauw + off * p.C;
         // batches have workgroups to spare: a Jacobi workgroup walks a run of neighbouring bins, each warm-started from the
         // previous one (a third of the sweeps); a single design keeps one bin per workgroup (shortest critical path)
-        fg.jrun = batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
+        fg.jrun = jacobi_run_length();
         launch_factor_jacobi_gram(fg, p.nb_gram, s0);
         p.mark("gram_route");
     }
