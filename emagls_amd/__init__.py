@@ -6,9 +6,9 @@ Importing the package does not need a GPU; calling any function needs emagls_amd
 """
 from .api import (applyRadialFilter, binauralDecode, encodeSH, getEMagLs2Filters, getEMagLsFilters, getEMagLsFiltersEMAinCH, getEMagLsFiltersEMAinSH,
                   getEMagLsFiltersFromAtf, getLsFilters, getMagLsArrayDiffuseFilter, getMagLsFilters, getMagLsFilters2D,
-                  getMagLsSphericalHeadFilter, getRadialFilter, getSH, sphModalCoeffs)
+                  getMagLsSphericalHeadFilter, getCH, getRadialFilter, getSH, getSMAIRMatrix, sphModalCoeffs)
 from .plan import Batch, Plan
 
 __all__ = ["getLsFilters", "getMagLsFilters", "getEMagLsFilters", "getEMagLs2Filters", "getEMagLsFiltersEMAinCH", "getEMagLsFiltersEMAinSH", "getEMagLsFiltersFromAtf",
-           "binauralDecode", "getSH", "sphModalCoeffs", "getMagLsFilters2D", "getRadialFilter", "applyRadialFilter", "encodeSH",
+           "binauralDecode", "getSH", "getCH", "getSMAIRMatrix", "sphModalCoeffs", "getMagLsFilters2D", "getRadialFilter", "applyRadialFilter", "encodeSH",
            "getMagLsSphericalHeadFilter", "getMagLsArrayDiffuseFilter", "Plan", "Batch"]

@@ -88,6 +88,9 @@ SYMBOLS = {
     "emagls_apply_radial_filter": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_double, C.c_double, c_i64, C.c_int, C.c_int, C.c_double,
                                              C.c_double, C.c_void_p]),
     "emagls_sh_encode": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "emagls_ch_basis": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_int, C.c_void_p]),
+    "emagls_get_smair_matrix": (C.c_int, [C.c_int, C.c_double, c_i64, C.c_int, C.c_double, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int,
+                                          C.c_int, C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_int)]),
     "emagls_eq_filter_nfft": (c_i64, [c_i64]),
     "emagls_get_magls_spherical_head_filter": (C.c_int, [C.c_double, C.c_int, C.c_double, c_i64, C.c_void_p, C.c_void_p]),
     "emagls_get_magls_array_diffuse_filter": (C.c_int, [C.c_double, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_double, c_i64, C.c_int,

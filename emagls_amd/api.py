@@ -17,6 +17,7 @@ hL/hR are [numSamples x numDirections]; filters come back [len x numChannels].
     getMagLsSphericalHeadFilter  lib/getMagLsSphericalHeadFilter.m:1
     getMagLsArrayDiffuseFilter   lib/getMagLsArrayDiffuseFilter.m:1
     getSH / sphModalCoeffs  the un-vendored third-party functions the above call
+    getCH / getSMAIRMatrix  dependencies/getCH.m:1, dependencies/getSMAIRMatrix.m:1 (the array model materialised)
 
 A custom `shFunction` (a callable with getSH's signature: shFunction(N, [azi zen], shDefinition) -> [dirs x (N+1)^2]) cannot
 cross the C ABI as a handle: it is evaluated here, at the simulation order the library reports, and its matrices go through the
@@ -83,6 +84,55 @@ def sphModalCoeffs(N, kr, arrayType="rigid", dirCoeff=0.0):
     b, pb = _out(kr.size, N + 1, True)
     L.check(L.load().emagls_modal_bn(int(N), kr.size, pk, pb))
     return b
+
+
+def getCH(N, aziRad, basisType="real"):
+    """dependencies/getCH.m:1: circular harmonics [numDirs x 2N+1], ordered [C_0, C_-1, C_1, ..., C_-N, C_N]."""
+    azi, pa = _vec(aziRad)
+    b, cplx = _basis(basisType)
+    Y, pY = _out(azi.size, 2 * int(N) + 1, cplx)
+    L.check(L.load().emagls_ch_basis(int(N), azi.size, pa, b, pY))
+    return Y
+
+
+_SMAIR_DEFAULTS = {"order": 4, "oversamplingFactor": 1, "irLen": 2048, "shDefinition": "real", "returnRawMicSigs": False,
+                   "radialFilter": "none", "waveModel": "planeWave", "arrayType": "rigid", "dirCoeff": 0, "regulConst": 1e-2}
+
+
+def getSMAIRMatrix(params=None, **kw):
+    """dependencies/getSMAIRMatrix.m:1: the array model itself, [numShsOut | numMics x numShsSimulation x numFreqs] complex.
+    `params` is the reference's struct as a dict (order, fs, irLen, oversamplingFactor, smaRadius, smaDesignAziZenRad,
+    shDefinition, returnRawMicSigs, radialFilter, ...; plane-wave model, rigid sphere, built-in getSH).  Returns
+    (smairMat, params) like the reference, with params['simulationOrder'] added."""
+    p = dict(_SMAIR_DEFAULTS)
+    p.update(params or {})
+    p.update(kw)
+    for k in ("fs", "smaRadius", "smaDesignAziZenRad"):
+        if k not in p:
+            raise KeyError("params.%s is required" % k)
+    if str(p["waveModel"]).lower() != "planewave" or p["arrayType"] != "rigid" or p["dirCoeff"] != 0:
+        raise NotImplementedError("only the plane-wave model of a rigid sphere is built in (what the filter designs use)")
+    if p.get("shFunction") is not None:
+        raise NotImplementedError("getSMAIRMatrix with a custom shFunction is not supported")
+    kind = str(p["radialFilter"]).lower()
+    if kind not in L.RADIAL:
+        raise ValueError('Unkown radialFilter parameter "%s".' % p["radialFilter"])
+    grid = np.asarray(p["smaDesignAziZenRad"], dtype=np.float64)
+    azi, pa = _vec(grid[:, 0])
+    zen, pz = _vec(grid[:, 1])
+    b, _ = _basis(p["shDefinition"])
+    nfft = int(p["oversamplingFactor"]) * int(p["irLen"])
+    order, M = int(p["order"]), azi.size
+    so = int(max(order, np.ceil(float(p["fs"]) * np.pi * float(p["smaRadius"]) / 343.0)))
+    rows = M if p["returnRawMicSigs"] else (order + 1) ** 2
+    out = np.zeros((rows, (so + 1) ** 2, nfft // 2 + 1), dtype=np.complex128, order="F")
+    sim = C.c_int(0)
+    L.check(L.load().emagls_get_smair_matrix(order, float(p["fs"]), int(p["irLen"]), int(p["oversamplingFactor"]), float(p["smaRadius"]),
+                                             pa, pz, M, b, 1 if p["returnRawMicSigs"] else 0, L.RADIAL[kind], float(p["regulConst"]),
+                                             float(p.get("noiseGainDb", float("nan"))), out.ctypes.data_as(C.c_void_p), C.byref(sim)))
+    assert sim.value == so
+    p["simulationOrder"] = so
+    return out, p
 
 
 def _sh_matrix(shFunction, n, azi, zen, shDefinition, cplx, rows):

@@ -149,6 +149,8 @@ void launch_eq_spectrum(const double* df_hi, const double* df_lo, const double* 
                         hipStream_t st);
 void launch_diffuse_constraint(void* W, const void* G, bool g_cplx, int64_t g_stride, int g0, const void* H, int D, int C, int64_t ldD,
                                int P, hipStream_t st);
+void launch_smair(const void* E, bool e_cplx, int ldS, const void* bn, int nOrd, const void* rad, int nRad, int rows, int S, int P, void* out,
+                  hipStream_t st);
 void launch_sh_encode(const double* sig, int64_t n, int M, const void* Z, int ldZ, int nOut, bool out_cplx, void* out, hipStream_t st);
 
 // ---- capi.hip: process-wide stream pool (streams are recycled, never destroyed: see StreamPool)

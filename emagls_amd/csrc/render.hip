@@ -289,4 +289,39 @@ void launch_diffuse_constraint(void* W, const void* G, bool g_cplx, int64_t g_st
     KERNEL_CHECK();
 }
 
+// getSMAIRMatrix materialised (dependencies/getSMAIRMatrix.m:110-140) for callers that want the array model itself; the filter
+// designs never form it.  out[(k S + s) rows + c] = rad_n(c)(k) E[c][s] b_n(s)(k), the last bin with
+// real(b_n) (:115-117) -- MATLAB's [rows x S x P] column-major array.  rad (optional, [P][nOut orders]) are the radial filters
+// applied to the SH-domain model (:129-138; their last bin is real already).
+template <typename T>
+__global__ void __launch_bounds__(256) smair_kernel(const T* __restrict__ E, int ldS, const cplx* __restrict__ bn, int nOrd,
+                                                    const cplx* __restrict__ rad, int nRad, int rows, int S, int P, cplx* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)rows * S * P) return;
+    const int c = (int)(idx % rows);
+    const int64_t ks = idx / rows;
+    const int s = (int)(ks % S), k = (int)(ks / S);
+    int n = 0;
+    while ((n + 1) * (n + 1) <= s) ++n;
+    cplx b = bn[(size_t)k * nOrd + n];
+    if (k == P - 1) b.y = 0.0;
+    cplx v = mk(1.0, 0.0) * E[(size_t)c * ldS + s];
+    v = v * b;
+    if (rad) {
+        int nc = 0;
+        while ((nc + 1) * (nc + 1) <= c) ++nc;
+        cplx r = rad[(size_t)k * nRad + nc];
+        if (k == P - 1) r.y = 0.0;
+        v = r * v;
+    }
+    out[idx] = v;
+}
+void launch_smair(const void* E, bool e_cplx, int ldS, const void* bn, int nOrd, const void* rad, int nRad, int rows, int S, int P, void* out,
+                  hipStream_t st) {
+    const unsigned g = (unsigned)ceil_div((int64_t)rows * S * P, 256);
+    if (e_cplx) smair_kernel<cplx><<<g, 256, 0, st>>>((const cplx*)E, ldS, (const cplx*)bn, nOrd, (const cplx*)rad, nRad, rows, S, P, (cplx*)out);
+    else smair_kernel<double><<<g, 256, 0, st>>>((const double*)E, ldS, (const cplx*)bn, nOrd, (const cplx*)rad, nRad, rows, S, P, (cplx*)out);
+    KERNEL_CHECK();
+}
+
 }  // namespace emagls

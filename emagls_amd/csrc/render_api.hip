@@ -58,11 +58,11 @@ void check_radial_args(int order, double fs, double radius, int64_t ir_len, int 
 
 // the radial filters on the device: [k][n] with NaNs zeroed (for the IR) and/or [n][P] for the caller
 void radial_on_device(Scratch& s, int order, double fs, double radius, int64_t nfft, int type, double regul, double noise_gain_db,
-                      cplx* out_kn, cplx* out_cm) {
+                      cplx* out_kn, cplx* out_cm, bool zero_nan = true) {
     const int P = (int)(nfft / 2 + 1);
     cplx* bn = modal_on_bins(s, order, P, fs, radius);
     const double g = type == EMAGLS_RADIAL_SOFTLIMIT ? pow(10.0, noise_gain_db / 20.0) : 1.0;
-    launch_radial_filter(bn, order + 1, P, type, regul, g, nfft % 2 == 0, true, out_kn, out_cm, s.st);
+    launch_radial_filter(bn, order + 1, P, type, regul, g, nfft % 2 == 0, zero_nan, out_kn, out_cm, s.st);
 }
 
 }  // namespace
@@ -236,6 +236,86 @@ int emagls_get_magls_array_diffuse_filter(double mic_radius, const double* mic_a
         cplx* W = s.get<cplx>(sizeof(cplx) * e.P);
         launch_eq_spectrum(e.df_hi, e.df_lo, df_arr, e.P, 1, W, nullptr, s.st);
         eq_taps(s, e, W, len, w_adf);
+        s.sync();
+    });
+}
+
+int emagls_ch_basis(int order, int64_t ndirs, const double* azi, int basis, void* Y) {
+    return guarded_call([&] {
+        if (!azi || !Y) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (order < 0 || ndirs < 1) throw Error(EMAGLS_ERR_ARG, "invalid shape");
+        if (basis != EMAGLS_BASIS_REAL && basis != EMAGLS_BASIS_COMPLEX) throw Error(EMAGLS_ERR_ARG, "basisType must be 'real' or 'complex'");
+        const bool cb = basis == EMAGLS_BASIS_COMPLEX;
+        Scratch s;
+        const double* d_azi = s.put(azi, (size_t)ndirs);
+        const size_t bytes = esz(cb) * (size_t)(2 * order + 1) * ndirs;
+        void* d_Y = s.get(bytes);
+        launch_ch_basis(order, (int)ndirs, d_azi, cb, d_Y, (int)ndirs, s.st, !cb);   // [channel][direction] == column-major [ndirs x 2N+1]
+        HIP_CHECK(hipMemcpyAsync(Y, d_Y, bytes, hipMemcpyDeviceToHost, s.st));
+        s.sync();
+    });
+}
+
+int emagls_get_smair_matrix(int order, double fs, int64_t ir_len, int oversampling, double sma_radius, const double* mic_azi,
+                            const double* mic_zen, int64_t nmics, int basis, int return_raw_mic_sigs, int radial_filter_type,
+                            double regul_const, double noise_gain_db, void* smair, int* sim_order) {
+    return guarded_call([&] {
+        if (!mic_azi || !mic_zen || !smair) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (order < 0 || nmics < 1 || !(fs > 0) || !(sma_radius > 0) || ir_len < 1 || oversampling < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        if (basis != EMAGLS_BASIS_REAL && basis != EMAGLS_BASIS_COMPLEX) throw Error(EMAGLS_ERR_ARG, "shDefinition must be 'real' or 'complex'");
+        if (radial_filter_type < EMAGLS_RADIAL_TIKHONOV || radial_filter_type > EMAGLS_RADIAL_NONE) throw Error(EMAGLS_ERR_ARG, "unknown radialFilter");
+        const int64_t nfft = ir_len * oversampling;
+        if (nfft % 2) throw Error(EMAGLS_ERR_ARG, "nfft must be even");      // getSMAIRMatrix.m:88
+        const bool cb = basis == EMAGLS_BASIS_COMPLEX, raw = return_raw_mic_sigs != 0;
+        const int P = (int)(nfft / 2 + 1), M = (int)nmics;
+        const int simOrder = std::max(order, (int)std::ceil(fs * kPi * sma_radius / C_SOUND));     // :95
+        if (sim_order) *sim_order = simOrder;
+        const int S = (simOrder + 1) * (simOrder + 1), nOut = (order + 1) * (order + 1), rows = raw ? M : nOut;
+        if (!raw && nOut > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "SH order above 4 is not supported in this build");
+        if (!raw && M < nOut) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than SH channels");
+        if (simOrder > 95) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 95 is not supported in this build");
+        const int ldM = (int)(ceil_div(M, 64) * 64), ldS = (int)(ceil_div(S, 64) * 64);
+        Scratch s;
+        const double* d_azi = s.put(mic_azi, (size_t)M);
+        const double* d_zen = s.put(mic_zen, (size_t)M);
+        double* tab = s.get<double>(sizeof(double) * sh_coeff_count(simOrder));
+        void* Ycm = s.get(esz(cb) * (size_t)S * M);                       // [S][M]
+        void* Yrm = s.get(esz(cb) * (size_t)ldM * ldS, true);             // [M][ldS]
+        launch_sh_coeff(simOrder, tab, s.st);
+        launch_sh_basis(simOrder, M, d_azi, d_zen, tab, cb, Ycm, M, s.st);
+        launch_transpose_conj(Ycm, M, S, M, Yrm, M, ldS, cb, false, s.st);
+        const void* E = Yrm;
+        if (!raw) {   // E = pinv(Y_Hi(:, 1:numShsOut)) Y_Hi   (:102, :119-121)
+            cplx* Yc = s.get<cplx>(sizeof(cplx) * (size_t)nOut * ldM, true);
+            cplx* Z = s.get<cplx>(sizeof(cplx) * (size_t)nOut * ldM, true);
+            cplx* V = s.get<cplx>(sizeof(cplx) * (size_t)nOut * ldM, true);
+            double* tau = s.get<double>(sizeof(double) * nOut);
+            cplx* R2 = s.get<cplx>(sizeof(cplx) * (size_t)nOut * nOut);
+            cplx* Nw = s.get<cplx>(sizeof(cplx) * (size_t)nOut * nOut);
+            launch_widen(Ycm, M, cb, Yc, ldM, nOut, M, false, false, s.st);
+            FactorArgs a{};
+            a.S = M; a.C = nOut; a.ldS = ldM; a.kb0 = 0; a.P = 2;
+            a.Xd = Yc; a.xd_stride = 0;
+            a.reg_mode = 1; a.tol_dim = (double)std::max(M, nOut);
+            a.Z = Z; a.Vws = V; a.tauw = tau; a.R2w = R2; a.Nw = Nw;
+            launch_factor(a, 1, true, s.st);
+            void* Em = s.get(esz(cb) * (size_t)nOut * ldS, true);
+            launch_small_gemm(Z, ldM, true, Yrm, ldS, cb, Em, ldS, cb, nOut, S, M, s.st);
+            E = Em;
+        }
+        cplx* bn = s.get<cplx>(sizeof(cplx) * (size_t)P * (simOrder + 1));
+        const double kr_step = 2.0 * kPi * ((fs / 2.0) / (double)(P - 1)) / C_SOUND * sma_radius;
+        launch_modal_bn(simOrder, P, nullptr, kr_step, -1.0, bn, simOrder + 1, 1, s.st);            // bnAll = -sphModalCoeffs(...)  (:107)
+        cplx* rad = nullptr;
+        if (!raw && radial_filter_type != EMAGLS_RADIAL_NONE) {
+            if (radial_filter_type == EMAGLS_RADIAL_SOFTLIMIT && !std::isfinite(noise_gain_db)) throw Error(EMAGLS_ERR_ARG, "softlimit needs noiseGainDb");
+            rad = s.get<cplx>(sizeof(cplx) * (size_t)P * (order + 1));
+            radial_on_device(s, order, fs, sma_radius, nfft, radial_filter_type, regul_const, noise_gain_db, rad, nullptr, /*zero_nan=*/false);
+        }
+        const size_t bytes = sizeof(cplx) * (size_t)rows * S * P;
+        cplx* d_out = s.get<cplx>(bytes);
+        launch_smair(E, cb, ldS, bn, simOrder + 1, rad, order + 1, rows, S, P, d_out, s.st);
+        HIP_CHECK(hipMemcpyAsync(smair, d_out, bytes, hipMemcpyDeviceToHost, s.st));
         s.sync();
     });
 }

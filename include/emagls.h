@@ -192,6 +192,18 @@ int emagls_apply_radial_filter(const double* sig, int64_t nsamp, int order, doub
  * sig [nsamp x nmics] real; out [nsamp x (order+1)^2], real or interleaved complex like the basis. */
 int emagls_sh_encode(const double* sig, int64_t nsamp, int64_t nmics, const double* mic_azi, const double* mic_zen, int order,
                      int basis, void* out);
+/* dependencies/getCH.m:1 -- Y = getCH(N, aziRad, basisType): [ndirs x 2N+1] column-major, channels [C_0, C_-1, C_1, ..., C_-N, C_N],
+ * real or interleaved complex like the basis */
+int emagls_ch_basis(int order, int64_t ndirs, const double* azi, int basis, void* Y);
+/* dependencies/getSMAIRMatrix.m:1 -- smairMat = getSMAIRMatrix(params), plane-wave model of a rigid sphere, built-in getSH.
+ * The filter designs never form this array (they work on its factors); this entry materialises it for callers that use the
+ * array model itself.  nfft = oversampling * ir_len (even); smair: interleaved complex [rows x S x nfft/2+1] column-major,
+ * rows = (order+1)^2, or nmics with return_raw_mic_sigs; S = (sim_order+1)^2 with sim_order = max(order, ceil(fs*pi*r/343))
+ * returned through sim_order (optional).  radial_filter_type other than EMAGLS_RADIAL_NONE applies getRadialFilter to the
+ * SH-domain model (:129-138). */
+int emagls_get_smair_matrix(int order, double fs, int64_t ir_len, int oversampling, double sma_radius, const double* mic_azi,
+                            const double* mic_zen, int64_t nmics, int basis, int return_raw_mic_sigs, int radial_filter_type,
+                            double regul_const, double noise_gain_db, void* smair, int* sim_order);
 /* lib/getMagLsSphericalHeadFilter.m:1 -- [wShf, W_Shf] = getMagLsSphericalHeadFilter(micRadius, order, fs, len)
  * w_shf [len]; W_shf (optional) [emagls_eq_filter_nfft(len)] real, the mirrored zero-phase spectrum. */
 int64_t emagls_eq_filter_nfft(int64_t len);

@@ -203,3 +203,42 @@ def test_diffuseness_constraint_errors(grids, thin_hrirs):
     from emagls_amd._lib import EmaglsError
     with pytest.raises(EmaglsError, match="diffuseness constraint applies"):
         Plan(L.KIND_LS, "real", 4, 48000.0, 128, 128, 900, diffuseness=True)
+
+
+# --------------------------------------------------------------------------------------------
+# helper functions of the reference a caller may use on their own
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_get_ch(basis):
+    import emagls_amd as E
+    azi = np.linspace(-3.0, 7.0, 333)
+    Y = E.getCH(6, azi, basis)
+    Yo = O.getCH(6, azi, basis)
+    assert Y.shape == (333, 13) and Y.dtype == Yo.dtype and rel(Y, Yo) < 1e-14
+
+
+@pytest.mark.parametrize("basis,raw", [("real", False), ("complex", False), ("real", True), ("complex", True)])
+def test_get_smair_matrix(grids, basis, raw):
+    """The array model the filter designs only use in factored form, materialised (getSMAIRMatrix.m:110-127): against the
+    oracle's restatement, including the real(b_n) rule of the last bin."""
+    import emagls_amd as E
+    params = dict(order=4, fs=48000.0, irLen=256, oversamplingFactor=1, smaRadius=grids["mic_radius"],
+                  smaDesignAziZenRad=np.column_stack([grids["mic_azi"], grids["mic_zen"]]), shDefinition=basis, returnRawMicSigs=raw)
+    sm, p = E.getSMAIRMatrix(params)
+    so, simOrder = O.getSMAIRMatrix(4, 48000.0, 256, grids["mic_radius"], params["smaDesignAziZenRad"], basis, returnRawMicSigs=raw)
+    assert p["simulationOrder"] == simOrder == 19 and sm.shape == so.shape == (32 if raw else 25, 400, 129)
+    assert rel(sm, so) < 1e-11
+    assert np.all(sm[:, :, -1].imag == 0) or basis == "complex"
+
+
+def test_get_smair_matrix_with_radial_filters(grids):
+    """radialFilter other than 'none' (getSMAIRMatrix.m:129-138): rows of the SH-domain model scaled by the radial filter of
+    their order."""
+    import emagls_amd as E
+    grid = np.column_stack([grids["mic_azi"], grids["mic_zen"]])
+    sm0, _ = E.getSMAIRMatrix(order=3, fs=48000.0, irLen=128, smaRadius=0.042, smaDesignAziZenRad=grid)
+    sm1, _ = E.getSMAIRMatrix(order=3, fs=48000.0, irLen=128, smaRadius=0.042, smaDesignAziZenRad=grid, radialFilter="tikhonov")
+    rad = O.getRadialFilter(3, 48000.0, 0.042, irLen=128, oversamplingFactor=1)          # [P x order+1]
+    n_of_c = np.repeat(np.arange(4), 2 * np.arange(4) + 1)
+    ref = sm0 * rad[:, n_of_c].T[:, None, :]
+    assert rel(sm1, ref) < 1e-12
