@@ -76,6 +76,7 @@ void at_exit() { emagls_cache_clear(); }
 // emagls_mex('radial', order, fs, smaRadius, irLen, oversamplingFactor, radialFilter, regulConst, noiseGainDb)
 // emagls_mex('applyradial', inSig, order, fs, smaRadius, irLen, oversamplingFactor, radialFilter, regulConst, noiseGainDb)
 // emagls_mex('encode', smaRecording, micAzi, micZen, order, shDefinition)
+// emagls_mex('ch', N, aziRad, basisType)        emagls_mex('smair', order, fs, irLen, oversamplingFactor, smaRadius, micAzi, micZen, ...)
 // emagls_mex('shf', micRadius, order, fs, len)                  [wShf, W_Shf] = ...
 // emagls_mex('adf', micRadius, micAzi, micZen, order, fs, len, shDefinition[, Yhi])
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
@@ -130,6 +131,29 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             if (mxGetN(prhs[1]) != (mwSize)((order + 1) * (order + 1))) mexErrMsgIdAndTxt("eMagLS:arg", "inSig must have (order+1)^2 columns");
             rc = emagls_apply_radial_filter(dbl(prhs[1], "inSig"), n, order, fs, r, irLen, ovs, type, regul, gain, mxGetDoubles(plhs[0]));
         }
+        if (rc) fail(rc);
+        return;
+    }
+    if (c == "ch") {   // getCH(N, aziRad, basisType)
+        const int order = (int)mxGetScalar(prhs[1]), basis = basis_of(nrhs > 3 ? prhs[3] : nullptr);
+        const mwSize nd = mxGetNumberOfElements(prhs[2]);
+        plhs[0] = out_matrix(nd, 2 * order + 1, basis);
+        int rc = emagls_ch_basis(order, nd, dbl(prhs[2], "aziRad"), basis, out_ptr(plhs[0]));
+        if (rc) fail(rc);
+        return;
+    }
+    if (c == "smair") {   // (order, fs, irLen, oversamplingFactor, smaRadius, micAzi, micZen, shDefinition, returnRawMicSigs, radialFilter, regulConst, noiseGainDb)
+        if (nrhs < 13) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+        const int order = (int)mxGetScalar(prhs[1]);
+        const double fs = mxGetScalar(prhs[2]), r = mxGetScalar(prhs[5]);
+        const mwSize irLen = (mwSize)mxGetScalar(prhs[3]), M = mxGetNumberOfElements(prhs[6]);
+        const int ovs = (int)mxGetScalar(prhs[4]), basis = basis_of(prhs[8]);
+        const int raw = mxIsLogicalScalarTrue(prhs[9]) || mxGetScalar(prhs[9]) != 0;
+        const int so = emagls_simulation_order(EMAGLS_KIND_EMAGLS, order, fs, r);
+        const mwSize dims[3] = {raw ? M : (mwSize)((order + 1) * (order + 1)), (mwSize)((so + 1) * (so + 1)), (irLen * ovs) / 2 + 1};
+        plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxCOMPLEX);
+        int rc = emagls_get_smair_matrix(order, fs, irLen, ovs, r, dbl(prhs[6], "micAzi"), dbl(prhs[7], "micZen"), M, basis, raw,
+                                         radial_type(prhs[10]), mxGetScalar(prhs[11]), mxGetScalar(prhs[12]), mxGetComplexDoubles(plhs[0]), nullptr);
         if (rc) fail(rc);
         return;
     }
