@@ -101,6 +101,7 @@ struct emagls_plan {
     // [gram_from, P) take the Gram route (gramroute.hip) on all orders.  gram_floor: lower bound of gram_from that a device-side
     // conditioning check imposed (recovery).  g0: first bin whose direction-space operand G_k exists.
     int gram_from = 0, gram_floor = 0, hh_end = 0, n_h = 0, S_h = 0, ldS_h = 0, g0 = 0, nb_gram = 0;
+    int nh_floor = 0;   // least number of orders on the Householder route (a lane batch gives all its designs the same routes)
     bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip)
     emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false, have_basis = false;
@@ -160,7 +161,11 @@ struct emagls_plan {
         if (bytes == 0) bytes = 16;
         auto it = bufs.find(name);
         if (it != bufs.end()) {   // re-allocation (a design's routes changed): keep what is large enough
-            if (it->second.bytes >= bytes) return it->second.p;
+            if (it->second.bytes >= bytes) {   // (the recorded size follows the request: lane batches compare and copy by it)
+                total_bytes -= (int64_t)(it->second.bytes - bytes);
+                it->second.bytes = bytes;
+                return it->second.p;
+            }
             if (it->second.owned) HIP_CHECK(hipFree(it->second.p));
             total_bytes -= (int64_t)it->second.bytes;
         }
@@ -303,7 +308,7 @@ void plan_routes(emagls_plan& p) {
     const double f_h = (double)(p.hh_end - 1) * (d.fs / 2.0) / (double)(p.P - 1);
     int n_min = 0;   // the S-space factor needs at least as many rows as channels
     while ((n_min + 1) * (n_min + 1) < p.C) ++n_min;
-    p.n_h = std::min(p.simOrder, std::max(orders_above_noise(2.0 * kPi * f_h / C_SOUND * d.mic_radius, p.simOrder), n_min));
+    p.n_h = std::min(p.simOrder, std::max({orders_above_noise(2.0 * kPi * f_h / C_SOUND * d.mic_radius, p.simOrder), n_min, p.nh_floor}));
     p.S_h = (p.n_h + 1) * (p.n_h + 1);
     p.ldS_h = round_up(p.S_h, 64);
     if (p.S_h > 768)
@@ -1361,19 +1366,74 @@ void throw_fatal_flags(const int* flag) {
 // graphs, so every plan of the batch changes its configuration together
 // Lane mode needs plans of identical shape (same buffers of the same sizes, same derived constants).  Their
 // buffers are moved into one arena at a constant stride; the plans keep working on their own afterwards.
+// Lane mode launches every kernel once for all designs with the routes of the first one, so the designs of a batch get
+// common routes first: the latest start of the Gram route and the most Householder-route orders any of them asks for (both are
+// valid for every member: the Householder route is accurate anywhere, more orders only add terms below the noise floor).
+// Designs of one simulation-order class but different radii (BASELINE config 4) differ by a bin or an order here.
+bool batch_unify_routes_once(emagls_batch& b);
+void batch_unify_routes(emagls_batch& b) {
+    // (moving a design's route boundary changes the orders its Householder bins need: repeat until nothing moves)
+    for (int it = 0; it < 4 && batch_unify_routes_once(b); ++it) {}
+}
+// returns true when a plan's routes were changed
+bool batch_unify_routes_once(emagls_batch& b) {
+    int gf = 0, nh = 0;
+    bool differ = false;
+    for (auto* p : b.plans) {
+        if (p->gram_from <= 0 || p->d.kind == EMAGLS_KIND_EMA_SH) return false;
+        differ = differ || p->gram_from != b.plans[0]->gram_from || p->n_h != b.plans[0]->n_h;
+        gf = std::max(gf, p->gram_from);
+        nh = std::max(nh, p->n_h);
+    }
+    if (!differ) return false;
+    for (auto* p : b.plans) {
+        if (p->gram_from == gf && p->n_h == nh) continue;
+        const int keep_floor = p->gram_floor, keep_nh = p->nh_floor;
+        try {
+            p->gram_floor = std::max(p->gram_floor, gf);
+            p->nh_floor = nh;
+            plan_routes(*p);
+            plan_alloc_routes(*p);
+        } catch (const Error& e) {   // (e.g. more Householder-route orders than the register tile holds: keep the plan's own routes)
+            if (getenv("EMAGLS_DEBUG_LANES")) fprintf(stderr, "common routes refused: %s\n", e.what());
+            p->gram_floor = keep_floor; p->nh_floor = keep_nh;
+            plan_routes(*p);
+            plan_alloc_routes(*p);
+            return false;
+        }
+        if (p->graph_exec) { HIP_CHECK(hipGraphExecDestroy(p->graph_exec)); p->graph_exec = nullptr; }
+        if (p->graph) { HIP_CHECK(hipGraphDestroy(p->graph)); p->graph = nullptr; }
+        if (p->pre_exec) { HIP_CHECK(hipGraphExecDestroy(p->pre_exec)); p->pre_exec = nullptr; }
+        if (p->pre_graph) { HIP_CHECK(hipGraphDestroy(p->pre_graph)); p->pre_graph = nullptr; }
+        p->eager_runs = 0;
+    }
+    return true;
+}
+
 void batch_try_lanes(emagls_batch& b) {
     if (const char* e = getenv("EMAGLS_BATCH_LANES")) if (e[0] == '0') return;
     emagls_plan& q = *b.plans[0];
     if (!q.sweep_persist) return;
+    for (auto* p : b.plans)
+        if (p->S != q.S || p->simOrder != q.simOrder || p->d.kind != q.d.kind || p->C != q.C || p->P != q.P) return;
+    batch_unify_routes(b);
+    const bool dbg = getenv("EMAGLS_DEBUG_LANES") != nullptr;
     for (auto* p : b.plans) {
         if (p->S != q.S || p->simOrder != q.simOrder || p->nOut != q.nOut || p->nfft != q.nfft || p->ldS != q.ldS || p->ldD != q.ldD ||
             p->Dpad != q.Dpad || p->k_cut != q.k_cut || p->cplx_basis != q.cplx_basis || p->out_cplx != q.out_cplx ||
             p->d.kind != q.d.kind || p->d.nsamp != q.d.nsamp || p->d.nmics != q.d.nmics || p->d.len != q.d.len || p->d.order != q.d.order ||
-            p->bufs.size() != q.bufs.size())
+            p->bufs.size() != q.bufs.size()) {
+            if (dbg) fprintf(stderr, "lanes refused: shape fields differ (bufs %zu vs %zu, gram_from %d vs %d, n_h %d vs %d)\n", p->bufs.size(),
+                             q.bufs.size(), p->gram_from, q.gram_from, p->n_h, q.n_h);
             return;
+        }
         auto it = q.bufs.begin();
         for (auto& kv : p->bufs) {
-            if (kv.first != it->first || kv.second.bytes != it->second.bytes) return;
+            if (kv.first != it->first || kv.second.bytes != it->second.bytes) {
+                if (dbg) fprintf(stderr, "lanes refused: buffer %s %zu vs %s %zu (gram_from %d vs %d, hh_end %d vs %d, n_h %d vs %d)\n", kv.first.c_str(),
+                                 kv.second.bytes, it->first.c_str(), it->second.bytes, p->gram_from, q.gram_from, p->hh_end, q.hh_end, p->n_h, q.n_h);
+                return;
+            }
             ++it;
         }
     }
@@ -1533,9 +1593,13 @@ int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR,
             fresh.reset(new emagls_plan);
             fresh->d = desc;
             plan_setup(*fresh);
-            if (array_kind(desc.kind)) {   // one design at a time: independent branches fork onto side streams
+            if (array_kind(desc.kind)) {
+                // One stream: the independent branches of a single design could fork onto side streams (3 streams: 3.55 instead of
+                // ~4 ms in a plan), but a MULTI-stream capture is what both hipGraphLaunch crashes of this round had in common
+                // (StreamPool above; again with the pool in place after a lane batch of the same shape) and a cached one-shot plan
+                // is captured and replayed inside whatever session the caller runs.  EMAGLS_ONESHOT_STREAMS=3 restores the forks.
                 const char* e = getenv("EMAGLS_ONESHOT_STREAMS");
-                fresh->nstreams = e ? std::max(1, std::min(3, atoi(e))) : 3;
+                fresh->nstreams = e ? std::max(1, std::min(3, atoi(e))) : 1;
             }
             p = fresh.get();
         }
@@ -1973,6 +2037,12 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
             batch_redo(*b, flags);
         }
         for (size_t j = 0; j < n; ++j) throw_fatal_flags(&flags[4 * j]);
+    });
+}
+int emagls_batch_lane_mode(emagls_batch* b, int* lanes) {
+    return guarded([&] {
+        if (!b || !lanes) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        *lanes = b->lanes ? 1 : 0;
     });
 }
 int emagls_batch_set_stream(emagls_batch* b, void* stream) {

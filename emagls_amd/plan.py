@@ -140,6 +140,12 @@ class Batch:
     def set_profiling(self, level):
         L.check(self._lib.emagls_batch_set_profiling(self._h, int(level)))
 
+    def lane_mode(self):
+        """True when one launch of every kernel covers all designs of the batch (identical shapes), False in stream mode."""
+        v = C.c_int(0)
+        L.check(self._lib.emagls_batch_lane_mode(self._h, C.byref(v)))
+        return bool(v.value)
+
     def set_stream(self, hip_stream):
         """Run on the caller's hipStream_t (an integer handle, e.g. torch.cuda.Stream().cuda_stream); the caller keeps it alive."""
         L.check(self._lib.emagls_batch_set_stream(self._h, C.c_void_p(int(hip_stream))))

@@ -300,6 +300,9 @@ int emagls_batch_get_filters(emagls_batch* batch, void* const* wL, void* const* 
 /* profiling: with level >= 1 HIP events bracket the sweep launch of every execute (on the batch stream);
  * emagls_batch_sweep_time returns the duration in ms of the last execute's sweep (synchronises the batch). */
 int emagls_batch_set_profiling(emagls_batch* batch, int level);
+/* *lanes = 1 when the batch runs in lane mode (one launch of every kernel for all its designs), 0 in stream mode.  Designs of
+ * one shape class whose routes differ by a bin or an order (array radii of one simulation order) are given common routes. */
+int emagls_batch_lane_mode(emagls_batch* batch, int* lanes);
 /* Run the batch on the caller's hipStream_t instead of its own (the caller keeps ownership and must not use the stream while a
  * batch call is in progress).  Why one would: the HIP runtime multiplexes all streams of a process onto 4 hardware queues, and
  * two batches whose streams land on the same queue execute strictly one after the other; a caller that creates its streams

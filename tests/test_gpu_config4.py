@@ -107,6 +107,7 @@ def test_radius_sweep_through_job_batching(grids, hrirs64):
                 p.set_hrirs(hrirs[0], hrirs[1])
                 plans.append(p)
             b = Batch(plans)
+            assert b.lane_mode()      # radii of one simulation-order class differ in their routes by a bin: unified by the batch
             b.execute()
             b.execute()     # (second execute: hipGraph capture path)
             for gi, w in zip(group, b.get_filters()):

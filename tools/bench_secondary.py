@@ -40,6 +40,7 @@ def config4(radii, reps=4):
         plans.append(p)
     info = plans[0].info()
     b = Batch(plans)
+    lanes = b.lane_mode()
     for _ in range(3):
         b.execute()
     b.synchronize()
@@ -52,7 +53,7 @@ def config4(radii, reps=4):
     b.close()
     for p in plans:
         p.close()
-    return {"radii_cm": [round(100 * float(radii[0]), 3), round(100 * float(radii[-1]), 3)], "designs_per_batch": len(radii),
+    return {"radii_cm": [round(100 * float(radii[0]), 3), round(100 * float(radii[-1]), 3)], "designs_per_batch": len(radii), "lane_mode": lanes,
             "sim_order": info.sim_order, "orthonormal_route_orders": info.hh_orders, "gram_route_from_bin": info.gram_from,
             "ms_per_batch": round(dt * 1e3, 3), "filter_sets_per_s": round(len(radii) / dt, 1)}
 
