@@ -568,8 +568,14 @@ void plan_setup(emagls_plan& p) {
         if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) p.sweep_persist = e[0] != '0';
         // the persistent sweep keeps one workgroup per CU resident (142 KB of LDS each): it needs the shape to fit one XCD's
         // 32 CUs per design AND that many CUs on this device (a partitioned or CU-masked GPU takes the launch-per-bin form)
-        if (!array_kind(d.kind) || !persist_sweep_supported((int)Dh, p.C) || persist_sweep_nwg((int)Dh) > device_cu_count())
+        if (!(array_kind(d.kind) || magls_kind(d.kind)) || !persist_sweep_supported((int)Dh, p.C) ||
+            persist_sweep_nwg((int)Dh) > device_cu_count())
             p.sweep_persist = false;
+        if (magls_kind(d.kind) && p.sweep_persist) {
+            p.alloc("Gm", sizeof(cplx) * ((size_t)p.C + 32) * p.ldD);      // Y_conj as complex [c][d] (+ 32 rows: whole-slab loads)
+            p.alloc("Mw", sizeof(cplx) * ((size_t)p.P * p.C * p.C + 1024));
+            p.alloc("cond_ok", sizeof(double) * (size_t)p.P);
+        }
         p.alloc("ll", persist_sweep_ll_bytes((int)Dh, p.C));
         p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(p.nWG, p.nWG_dense) * 2 * p.C);
         p.out_rows = d.len;
@@ -657,7 +663,10 @@ void execute_ls(emagls_plan& p) {
     p.mark("ls_filters");
 }
 
-void execute_magls(emagls_plan& p) {
+// MagLS / MagLS-2D: everything before the sweep.  With the persistent sweep (the kernel of the array designs, one resident launch
+// instead of one launch per bin) the operands are the same for every bin: G = Y_conj as complex [c][d] and
+// M = (G^H G)^-1 = R^-1 R^-H from the Cholesky factor, since pinv(Y_conj) = conj(G) conj(M) for a full-rank basis.
+void magls_pre_sweep(emagls_plan& p) {
     hipStream_t st = p.stream;
     const bool cb = p.cplx_basis;
     stage_hrir_basis(p);
@@ -667,6 +676,33 @@ void execute_magls(emagls_plan& p) {
     launch_ls_apply(p.get("Hc"), p.ldD, std::min(p.kcut0, p.P), p.get("Ypinv"), cb, p.ldD, (int)p.D, p.C, p.P, 0,
                     std::min(p.kcut0, p.P), p.get("W"), st);
     p.mark("ls_bins");
+    if (p.sweep_persist) {
+        launch_widen(p.get("Xc"), p.ldD, cb, p.get("Gm"), p.ldD, p.C, (int)p.D, false, false, st);
+        launch_magls_m(p.get("R"), p.S, cb, p.P, p.get("Mw"), p.get<double>("cond_ok"), p.get<int>("flag"), st);
+        p.mark("sweep_operands");
+    }
+}
+void magls_post_sweep(emagls_plan& p) {
+    hipStream_t st = p.stream;
+    const bool cb = p.cplx_basis;
+    if (p.diffuse)   // pwGrid is Y_conj for every bin
+        launch_diffuse_constraint(p.get("W"), p.get("Xc"), cb, 0, 1, p.get("Hfull"), (int)p.D, p.C, p.ldD, p.P, st);
+    // complex basis: getShFreqDomainConjugate (getMagLsFilters.m) / getChFreqDomainConjugate (getMagLsFilters2D.m:82-83)
+    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"),
+                           cb ? (p.d.kind == EMAGLS_KIND_MAGLS_2D ? 2 : 1) : 0, 0, 0,
+                           p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), st);
+    p.mark("epilogue");
+}
+void emagls_run_sweep(emagls_plan& p);
+void execute_magls(emagls_plan& p) {
+    hipStream_t st = p.stream;
+    const bool cb = p.cplx_basis;
+    magls_pre_sweep(p);
+    if (p.sweep_persist) {   // (eager / profiled executes; plan_execute captures the two halves around the sweep otherwise)
+        emagls_run_sweep(p);
+        magls_post_sweep(p);
+        return;
+    }
     DenseSweepArgs a{};
     a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
     a.X = p.get("Xc"); a.x_stride = 0; a.Zd = p.get("Ypinv"); a.z_stride = 0;
@@ -681,13 +717,7 @@ void execute_magls(emagls_plan& p) {
     }
     if (p.kcut0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
     p.mark("magls_sweep");
-    if (p.diffuse)   // pwGrid is Y_conj for every bin
-        launch_diffuse_constraint(p.get("W"), p.get("Xc"), cb, 0, 1, p.get("Hfull"), (int)p.D, p.C, p.ldD, p.P, st);
-    // complex basis: getShFreqDomainConjugate (getMagLsFilters.m) / getChFreqDomainConjugate (getMagLsFilters2D.m:82-83)
-    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"),
-                           cb ? (p.d.kind == EMAGLS_KIND_MAGLS_2D ? 2 : 1) : 0, 0, 0,
-                           p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), st);
-    p.mark("epilogue");
+    magls_post_sweep(p);
 }
 
 // First bin of the Gram route: cond(B_k) is governed by the ratio of the lowest to the highest modal coefficient the C
@@ -982,8 +1012,14 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     HalfSweepArgs a{};
     a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
     a.g_stride = (int64_t)p.C * p.ldD;
+    if (magls_kind(p.d.kind)) {   // one operand for every bin (magls_pre_sweep)
+        a.g_stride = 0;
+        a.G = p.get<cplx>("Gm");
+        a.Yri = a.G;             // (never read: every bin is well conditioned)
+    } else {
     a.G = p.get<cplx>("G") - (int64_t)p.g0 * a.g_stride;    // indexed by kb (G starts at bin g0 <= k0)
     a.Yri = p.get<cplx>("Yri") - (int64_t)k0 * a.g_stride;
+    }
     a.Mw = p.get<cplx>("Mw") - (int64_t)1 * p.C * p.C;      // factor stage stores bin kb at slot kb-1
     a.cond_ok = p.get<double>("cond_ok");
     a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
@@ -1172,14 +1208,14 @@ void plan_execute(emagls_plan& p) {
             throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
     }
     if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
-    const bool persist = array_kind(d.kind) && p.sweep_persist;
+    const bool persist = (array_kind(d.kind) || magls_kind(d.kind)) && p.sweep_persist;
     if (p.prof_level == 0 && p.use_graph && persist) {
         // the persistent sweep is launched directly (SweepChain); the stages before it are captured from the second
         // execute on (the first runs eagerly: one-time function attributes, lazy module load)
         if (!p.pre_exec && p.eager_runs >= 1) capture_into(p.stream, &p.pre_graph, &p.pre_exec, [&] { plan_pre_stage(p); });
         if (p.pre_exec) HIP_CHECK(hipGraphLaunch(p.pre_exec, p.stream)); else plan_pre_stage(p);
         emagls_run_sweep(p);
-        emagls_post_sweep(p);
+        if (magls_kind(d.kind)) magls_post_sweep(p); else emagls_post_sweep(p);
         if (!p.pre_exec) ++p.eager_runs;
         p.executed = true;
         return;
@@ -1219,9 +1255,9 @@ void batch_execute_lanes(emagls_batch& b);
 void plan_pre_stage(emagls_plan& p) {
     p.stage_names.clear();
     launch_zero(p.get("flag"), sizeof(int) * 4, p.stream);
-    launch_zero(p.get("route"), p.bufs["route"].bytes, p.stream);
+    if (p.has("route")) launch_zero(p.get("route"), p.bufs["route"].bytes, p.stream);
     launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
-    emagls_pre_sweep(p);
+    if (magls_kind(p.d.kind)) magls_pre_sweep(p); else emagls_pre_sweep(p);
 }
 void batch_sweep_stage(emagls_batch& b) {
     HalfSweepMulti h{};

@@ -566,4 +566,51 @@ void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int l
     KERNEL_CHECK();
 }
 
+// MagLS on the persistent sweep: M = (R^H R)^-1 = R^-1 R^-H from the Cholesky factor of the basis' Gram matrix (C = S <= 32),
+// written to every bin's slot (the sweep kernel reads M of bin kb at slot kb - 1), and cond_ok = 1 for every bin.  A factor
+// whose diagonal spans more than 1e6 raises status[1] ("take the launch-per-bin sweep"): the reference's pinv would drop
+// singular values there, which the inverse cannot follow.  One workgroup.
+template <typename T>
+__global__ void __launch_bounds__(256) magls_m_kernel(const T* __restrict__ R, int C, int P, cplx* __restrict__ Mw, double* __restrict__ cond_ok,
+                                                      int* __restrict__ status, size_t bstride) {
+    R = boff(R, bstride); Mw = boff(Mw, bstride); cond_ok = boff(cond_ok, bstride); status = boff(status, bstride);
+    __shared__ cplx Ri[32][33];   // R^-1 (upper triangular)
+    __shared__ cplx Ms[32][33];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 32 * 33; idx += 256) Ri[idx / 33][idx % 33] = mk(0.0, 0.0);
+    __syncthreads();
+    if (tid < C) {   // column j of the inverse by back substitution:  sum_k R[i][k] X[k][j] = delta_ij
+        const int j = tid;
+        for (int i = j; i >= 0; --i) {
+            cplx acc = mk(i == j ? 1.0 : 0.0, 0.0);
+            for (int k = i + 1; k <= j; ++k) { cplx t = mk(0.0, 0.0); cfma(t, mk(1.0, 0.0) * R[(size_t)i * C + k], Ri[k][j]); acc = acc - t; }
+            Ri[i][j] = cdiv(acc, mk(1.0, 0.0) * R[(size_t)i * C + i]);
+        }
+    }
+    if (tid == 0) {
+        double dmin = INFINITY, dmax = 0.0;
+        for (int i = 0; i < C; ++i) { const double v = norm2(mk(1.0, 0.0) * R[(size_t)i * C + i]); dmin = fmin(dmin, v); dmax = fmax(dmax, v); }
+        if (!(dmin > 1e-12 * dmax)) atomicExch(status + 1, 1);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < C * C; idx += 256) {
+        const int i = idx / C, j = idx % C;
+        cplx acc = mk(0.0, 0.0);
+        for (int k = (i > j ? i : j); k < C; ++k) cfma(acc, Ri[i][k], conj(Ri[j][k]));
+        Ms[i][j] = acc;
+    }
+    __syncthreads();
+    for (int64_t idx = tid; idx < (int64_t)P * C * C; idx += 256) {
+        const int f = (int)(idx % (C * C));
+        Mw[idx] = Ms[f / C][f % C];
+    }
+    for (int kb = tid; kb < P; kb += 256) cond_ok[kb] = 1.0;
+}
+void launch_magls_m(const void* R, int C, bool is_cplx, int P, void* Mw, double* cond_ok, int* status, hipStream_t st) {
+    if (C > 32) throw Error(2, "MagLS: more than 32 channels is not supported");
+    if (is_cplx) magls_m_kernel<cplx><<<bgrid(1), 256, 0, st>>>((const cplx*)R, C, P, (cplx*)Mw, cond_ok, status, batch_ctx().stride);
+    else magls_m_kernel<double><<<bgrid(1), 256, 0, st>>>((const double*)R, C, P, (cplx*)Mw, cond_ok, status, batch_ctx().stride);
+    KERNEL_CHECK();
+}
+
 }  // namespace emagls

@@ -51,6 +51,8 @@ void launch_tn(const void* R, const void* E, int S, int C, int ldE, int nOrders,
 void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int ldb, bool b_cplx, void* Cm, int ldc,
                        bool c_cplx, int M, int N, int K, hipStream_t st);
 
+void launch_magls_m(const void* R, int C, bool is_cplx, int P, void* Mw, double* cond_ok, int* status, hipStream_t st);
+
 // ---- factor.hip
 struct FactorArgs;
 void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st, int phases = 3);
