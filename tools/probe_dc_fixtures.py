@@ -162,3 +162,13 @@ for m in fits:
     for k in (0, 1, 2, 510, 511, 512):
         M = fits[m][0][k]
         print(f"  {m:8s} k={k:3d} M=[[{M[0,0]:.4f} {M[0,1]:.4f}] [{M[1,0]:.4f} {M[1,1]:.4f}]] res={fits[m][1][k]:.1e}")
+
+
+print("\n== MagLS: candidates for the cross term of Rhat in the SH domain (needed = M^-1 R M^-1 with R implied by eMagLS)")
+Wl, Wr = fits["MagLS"][2]
+for k in (100, 200, 300, 400):
+    Mi = np.linalg.inv(fits["MagLS"][0][k])
+    need = (Mi.conj().T @ Rest["eMagLS"][k] @ Mi)[0, 1]
+    cands = {"conj(Wl).Wr": np.vdot(Wl[k], Wr[k]), "Wl.conj(Wr)": np.vdot(Wr[k], Wl[k]), "Wl.Wr": np.dot(Wl[k], Wr[k]),
+             "conj(Wl).conj(Wr)": np.conj(np.dot(Wl[k], Wr[k]))}
+    print(f"  k={k}: needed {need:.4f} |" + " | ".join(f"{n} {v / (4 * np.pi):.4f}" for n, v in cands.items()))
