@@ -363,7 +363,9 @@ def main():
         torch.cuda.synchronize()
 
     from concurrent.futures import ThreadPoolExecutor
-    launcher = ThreadPoolExecutor(max_workers=max(nslots, 2))
+    # (plans and batches run on the device they were created on whatever the calling thread's current device is; the
+    # initializer only keeps the workers' own HIP calls -- none today -- on this rank's GPU)
+    launcher = ThreadPoolExecutor(max_workers=max(nslots, 2), initializer=lambda: L.check(lib.emagls_set_device(local_rank)))
 
     def run_designs(n_designs, store):
         """Exactly n_designs designs through the resident batches, at most nslots batches in flight (sliding window: a slot is

@@ -21,7 +21,7 @@ class DesignDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("basis", C.c_int), ("order", C.c_int), ("fs", C.c_double), ("len", c_i64),
                 ("nsamp", c_i64), ("ndirs", c_i64), ("mic_radius", C.c_double), ("nmics", c_i64),
                 ("f_trans", C.c_double), ("atf_taps", c_i64), ("natf", c_i64), ("custom_basis", C.c_int),
-                ("diffuseness", C.c_int)]
+                ("diffuseness", C.c_int), ("sim_order_pad", C.c_int)]
 
 
 class PlanInfo(C.Structure):
@@ -29,7 +29,8 @@ class PlanInfo(C.Structure):
                 ("num_sh_sim", C.c_int), ("num_channels", C.c_int), ("out_is_complex", C.c_int),
                 ("out_rows", c_i64), ("out_cols", c_i64), ("grp_delay_l", C.c_double), ("grp_delay_r", C.c_double),
                 ("mean_grid_dev_deg", C.c_double), ("num_sweep_launches", C.c_int), ("device_bytes", c_i64),
-                ("gram_from", C.c_int), ("hh_end", C.c_int), ("hh_orders", C.c_int), ("g_first", C.c_int)]
+                ("gram_from", C.c_int), ("hh_end", C.c_int), ("hh_orders", C.c_int), ("g_first", C.c_int),
+                ("sim_order_own", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/emagls.h declares

@@ -95,28 +95,34 @@ def getCH(N, aziRad, basisType="real"):
     return Y
 
 
-_SMAIR_DEFAULTS = {"order": 4, "oversamplingFactor": 1, "irLen": 2048, "shDefinition": "real", "returnRawMicSigs": False,
-                   "radialFilter": "none", "waveModel": "planeWave", "arrayType": "rigid", "dirCoeff": 0, "regulConst": 1e-2}
+# the reference's own struct defaults (dependencies/getSMAIRMatrix.m:36-84); regulConst: getRadialFilter.m:49-51
+_SMAIR_DEFAULTS = {"order": 4, "fs": 48000, "smaRadius": 0.042, "arrayType": "rigid", "radialFilter": "regul", "sourceDist": 2,
+                   "dirCoeff": 0, "waveModel": "planeWave", "noiseGainDb": 20, "oversamplingFactor": 4, "irLen": 2048,
+                   "returnRawMicSigs": False, "shDefinition": "real", "regulConst": 1e-2}
 
 
 def getSMAIRMatrix(params=None, **kw):
     """dependencies/getSMAIRMatrix.m:1: the array model itself, [numShsOut | numMics x numShsSimulation x numFreqs] complex.
     `params` is the reference's struct as a dict (order, fs, irLen, oversamplingFactor, smaRadius, smaDesignAziZenRad,
-    shDefinition, returnRawMicSigs, radialFilter, ...; plane-wave model, rigid sphere, built-in getSH).  Returns
-    (smairMat, params) like the reference, with params['simulationOrder'] added."""
+    shDefinition, returnRawMicSigs, radialFilter, ...; plane-wave model, rigid sphere, built-in getSH).  Fields left out take
+    the reference's defaults (:36-84) -- including radialFilter 'regul', which getRadialFilter.m:63-64 rejects: like there, a
+    call that wants the SH-domain model must name its radial filter ('none', 'tikhonov', 'softlimit', 'full').  The one field
+    without a default here is smaDesignAziZenRad (the reference loads a t-design file that is not part of its repository).
+    Returns (smairMat, params) like the reference, with params['simulationOrder'] added."""
     p = dict(_SMAIR_DEFAULTS)
     p.update(params or {})
     p.update(kw)
-    for k in ("fs", "smaRadius", "smaDesignAziZenRad"):
-        if k not in p:
-            raise KeyError("params.%s is required" % k)
+    if "smaDesignAziZenRad" not in p:
+        raise KeyError("params.smaDesignAziZenRad is required")
     if str(p["waveModel"]).lower() != "planewave" or p["arrayType"] != "rigid" or p["dirCoeff"] != 0:
         raise NotImplementedError("only the plane-wave model of a rigid sphere is built in (what the filter designs use)")
     if p.get("shFunction") is not None:
         raise NotImplementedError("getSMAIRMatrix with a custom shFunction is not supported")
     kind = str(p["radialFilter"]).lower()
-    if kind not in L.RADIAL:
-        raise ValueError('Unkown radialFilter parameter "%s".' % p["radialFilter"])
+    if p["returnRawMicSigs"]:
+        kind = "none"          # (:124-126: the radial filter is never looked at for raw microphone signals)
+    elif kind not in L.RADIAL:
+        raise ValueError('Unkown radialFilter parameter "%s".' % p["radialFilter"])   # getRadialFilter.m:64, spelling kept
     grid = np.asarray(p["smaDesignAziZenRad"], dtype=np.float64)
     azi, pa = _vec(grid[:, 0])
     zen, pz = _vec(grid[:, 1])
@@ -129,7 +135,7 @@ def getSMAIRMatrix(params=None, **kw):
     sim = C.c_int(0)
     L.check(L.load().emagls_get_smair_matrix(order, float(p["fs"]), int(p["irLen"]), int(p["oversamplingFactor"]), float(p["smaRadius"]),
                                              pa, pz, M, b, 1 if p["returnRawMicSigs"] else 0, L.RADIAL[kind], float(p["regulConst"]),
-                                             float(p.get("noiseGainDb", float("nan"))), out.ctypes.data_as(C.c_void_p), C.byref(sim)))
+                                             float(p["noiseGainDb"]), out.ctypes.data_as(C.c_void_p), C.byref(sim)))
     assert sim.value == so
     p["simulationOrder"] = so
     return out, p
@@ -327,6 +333,9 @@ def binauralDecode(sig, inFs, decodingFilterLeft, decodingFilterRight, decodingF
     im = (C.c_double * 2)(0.0, 0.0)
     L.check(L.load().emagls_binaural_decode_complex(ps, 1 if in_c else 0, n, Cc, pwL, pwR, 1 if w_c else 0, ln,
                                                     1 if compensateDelay else 0, po, im))
+    # binauralDecode.m:59-63: `if ~isreal(binauralOut)` -- whenever the accumulated result is a complex array, which it is as
+    # soon as a signal or a filter is complex (MATLAB only drops an all-zero imaginary part at the end of an arithmetic
+    # operation; a sum that happens to be exactly real is the one case in which the reference stays silent, and so do we)
     if im[0] != 0.0 or im[1] != 0.0:
         warnings.warn("discarding imaginary part with sum of [%.2g, %.2g] in rendering result." % (im[0], im[1]))
     return out
@@ -380,7 +389,7 @@ def getRadialFilter(params=None, **kw):
     rad, pr = _out(nfft // 2 + 1, int(p["order"]) + 1, True)
     L.check(L.load().emagls_get_radial_filter(int(p["order"]), float(p["fs"]), float(p["smaRadius"]), int(p["irLen"]),
                                               int(p["oversamplingFactor"]), kind, float(p["regulConst"]),
-                                              float(p.get("noiseGainDb", float("nan"))), pr))
+                                              float(p["noiseGainDb"]), pr))
     return rad
 
 
@@ -404,7 +413,7 @@ def applyRadialFilter(inSig, params=None, **kw):
     out, po = _out(rows, C_, False)
     L.check(lib.emagls_apply_radial_filter(ps, sig.shape[0], int(p["order"]), float(p["fs"]), float(p["smaRadius"]), int(p["irLen"]),
                                            int(p["oversamplingFactor"]), kind, float(p["regulConst"]),
-                                           float(p.get("noiseGainDb", float("nan"))), po))
+                                           float(p["noiseGainDb"]), po))
     return out
 
 

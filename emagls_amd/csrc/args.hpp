@@ -83,6 +83,8 @@ struct HalfSweepArgs {
     int kfirst;
     unsigned long long* ll;  // persistent sweep: [2][nWG_persist][2C][4] granules {payload32, tag32}
     int* abort_flag;         // persistent sweep: set when a workgroup gave up waiting for its peers
+    const int* skip_flag;    // persistent sweep, optional: non-zero at launch = operands unusable (MagLS basis too ill-conditioned for the
+                             // inverse form, status word 4): the design's workgroups leave at once, the host re-runs on the launch-per-bin sweep
     long long* timing;       // optional [P][16] wall-clock stamps (EMAGLS_SWEEP_TIMING), else null
     int force_global;        // persistent sweep: keep the write-through (sc1) stores even on one XCD (EMAGLS_PERSIST_GLOBAL=1)
 };

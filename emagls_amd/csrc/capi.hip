@@ -23,6 +23,7 @@ constexpr double C_SOUND = 343.0;       // dependencies/getSMAIRMatrix.m:86
 constexpr int NFFT_MAX_LEN = 2048;      // lib/getEMagLsFilters.m:35
 constexpr double F_CUT_MIN_FREQ = 1e3;  // :36
 constexpr double SVD_REGUL_CONST = 0.01;  // :39
+constexpr int NFLAG = 8;                   // device-side status words of a design (plan_recover)
 constexpr int SMAIR_DEFAULT_ORDER = 4;    // dependencies/getSMAIRMatrix.m:39-41 (params.order when the caller leaves it unset)
 
 // Streams are recycled through a process-wide pool and never destroyed.  A design plan owns three and a long session creates
@@ -78,6 +79,7 @@ void emagls_batch_forget(emagls_batch* b, emagls_plan* p);
 
 struct emagls_plan {
     emagls_design_desc d{};
+    int device = -1;              // the HIP device the plan was created on: every C entry point runs on it (DeviceGuard)
     hipStream_t stream = nullptr;
     std::map<std::string, DevBuf> bufs;
     std::shared_ptr<Arena> arena;  // set when a batch moved the buffers into its arena (they are not freed one by one then)
@@ -88,6 +90,7 @@ struct emagls_plan {
     bool real_internal = false;   // complex request served by the real-arithmetic pipeline + a unitary channel transform
     int nfft = 0, P = 0, k_cut = 0, kcut0 = 0;
     int simOrder = 0, S = 0, C = 0, ldS = 0, nOut = 0;
+    int simOrderOwn = 0;          // the design's own simulation order (getSMAIRMatrix.m:95); simOrder may be padded above it
     int64_t D = 0, ldD = 0, Dpad = 0, Dm = 0;  // Dm: matched direction count (FROM_ATF)
     bool hrir_smaller = true;
     bool out_cplx = false;
@@ -102,6 +105,7 @@ struct emagls_plan {
     // conditioning check imposed (recovery).  g0: first bin whose direction-space operand G_k exists.
     int gram_from = 0, gram_floor = 0, hh_end = 0, n_h = 0, S_h = 0, ldS_h = 0, g0 = 0, nb_gram = 0;
     int nh_floor = 0;   // least number of orders on the Householder route (a lane batch gives all its designs the same routes)
+    bool persist_suspended = false;   // sweep_persist switched off for ONE re-run (status word 4), restored afterwards
     bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip)
     emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false, have_basis = false;
@@ -204,6 +208,7 @@ struct emagls_plan {
 
 struct emagls_batch {
     std::vector<emagls_plan*> plans;
+    int device = -1;              // device of its plans
     // lanes: all plans have the same shape and their buffers sit `stride` bytes apart in one arena, so every
     // launch of the design pipeline covers the whole batch (grid.z = design)
     bool lanes = false;
@@ -234,6 +239,9 @@ struct emagls_batch {
         HIP_CHECK(hipStreamWaitEvent(waiter, e, 0));
     }
     ~emagls_batch() {
+        // a batch may still be in flight on a caller-owned stream (emagls_batch_set_stream): its graph execs and events must
+        // outlive it (pool-owned streams are synchronised again when they are handed back)
+        if (stream) hipStreamSynchronize(stream);
         for (auto e : events) hipEventDestroy(e);
         if (graph_exec) hipGraphExecDestroy(graph_exec);
         if (graph) hipGraphDestroy(graph);
@@ -354,6 +362,7 @@ void plan_setup(emagls_plan& p) {
     if (d.basis != EMAGLS_BASIS_REAL && d.basis != EMAGLS_BASIS_COMPLEX) throw Error(EMAGLS_ERR_ARG, "shDefinition must be 'real' or 'complex'");
     if (d.ndirs < 1 || d.nsamp < 1) throw Error(EMAGLS_ERR_ARG, "empty HRIR set");
     if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
+    HIP_CHECK(hipGetDevice(&p.device));
     p.stream = StreamPool::get().take();
     if (const char* ng = getenv("EMAGLS_NO_GRAPH")) p.use_graph = !(ng[0] == '1');
     for (auto& st : p.side) st = StreamPool::get().take();
@@ -382,7 +391,7 @@ void plan_setup(emagls_plan& p) {
     p.alloc("hR", sizeof(double) * d.nsamp * d.ndirs, false);
     p.alloc("hrir_azi", sizeof(double) * p.D, false);
     p.alloc("hrir_zen", sizeof(double) * p.D, false);
-    p.alloc("flag", sizeof(int) * 4);
+    p.alloc("flag", sizeof(int) * NFLAG);
     p.alloc("grpd", sizeof(double) * 2);
 
     if (d.kind != EMAGLS_KIND_LS) {
@@ -423,7 +432,13 @@ void plan_setup(emagls_plan& p) {
         // getSMAIRMatrix.m:95: max(params.order, ceil(fs*pi*r/C)).  lib/getEMagLs2Filters.m:51-63 leaves params.order unset, so
         // getSMAIRMatrix.m:39-41 defaults it to 4 there: for eMagLS2 `order` only sets f_cut (:47), never the simulation order.
         const int smair_order = d.kind == EMAGLS_KIND_EMAGLS2 ? SMAIR_DEFAULT_ORDER : N;
-        p.simOrder = std::max(smair_order, (int)std::ceil(d.fs * kPi * d.mic_radius / C_SOUND));
+        p.simOrderOwn = std::max(smair_order, (int)std::ceil(d.fs * kPi * d.mic_radius / C_SOUND));
+        // sim_order_pad: simulate on more orders than the design's own, with b_n = 0 above its own order -- the same sum, so
+        // the same filters; array radii of neighbouring simulation-order classes then have one shape and share a lane batch
+        if (d.sim_order_pad < 0) throw Error(EMAGLS_ERR_ARG, "negative sim_order_pad");
+        if (d.sim_order_pad > 0 && (p.custom_basis || d.kind == EMAGLS_KIND_EMA_SH))
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "sim_order_pad is available for eMagLS / eMagLS2 / EMAinCH designs on the built-in SH basis");
+        p.simOrder = std::max(p.simOrderOwn, d.sim_order_pad);
         p.S = (p.simOrder + 1) * (p.simOrder + 1);
         p.nOut = d.kind == EMAGLS_KIND_EMA_CH ? 2 * N + 1 : (N + 1) * (N + 1);   // EMAinCH.m:66: numHarmonics = 2*order+1
         if (d.kind == EMAGLS_KIND_EMA_SH && d.nmics < 2 * N + 1)
@@ -522,6 +537,8 @@ void plan_setup(emagls_plan& p) {
             HIP_CHECK(hipStreamSynchronize(p.stream));   // (the host vectors go out of scope)
         }
         p.alloc("kr", sizeof(double) * p.P, false);
+        p.alloc("nvalid", sizeof(int) * 4);
+        p.upload("nvalid", &p.simOrderOwn, sizeof(int));
         p.alloc("bn", sizeof(cplx) * (size_t)p.P * (p.simOrder + 1));
         p.alloc("route", sizeof(int) * (size_t)p.P);
         p.alloc("Gy", esz(cb) * (size_t)p.S * p.S);                    // Gram matrix of conj(Y) (upper block triangle)
@@ -795,7 +812,7 @@ void ema_sh_pre_sweep(emagls_plan& p) {
     launch_sh_coeff(N, p.get<double>("sh_tab_lo"), st);
     launch_sh_basis(N, p.C, p.get<double>("nnm_azi"), p.get<double>("nnm_zen"), p.get<double>("sh_tab_lo"), cb, p.get("Ypts"), p.C, st);
     launch_ema_sh_e0(p.get("Ech"), (int)p.ldS, p.get("Ypts"), p.C, p.S, cb, p.get("E"), st);
-    launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, st);
+    launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, st, p.get<int>("nvalid"));
     p.mark("array_model");
     // ---- per-direction SH rotations (EMAinSH.m:85-100)
     launch_rot_points(p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), (int)p.D, npts, p.get<double>("rot_azi"), p.get<double>("rot_zen"), st);
@@ -892,7 +909,7 @@ void emagls_pre_sweep(emagls_plan& p) {
         launch_small_gemm(p.get("Zlo"), ldM, true, p.get("Ymic_rm"), p.ldS, cb, p.get("E"), p.ldS, cb, p.nOut, p.S, M, s1);
     }
     // bnAll = -sphModalCoeffs(simOrder, kr, 'rigid')   (getSMAIRMatrix.m:107)
-    launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, s1);
+    launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, s1, p.get<int>("nvalid"));
     hipEvent_t e_E = p.next_sync_event();
     if (s1 != s0) HIP_CHECK(hipEventRecord(e_E, s1));
 
@@ -1026,6 +1043,7 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG_dense; a.kfirst = k0;
     a.ll = p.get<unsigned long long>("ll");
     a.abort_flag = p.get<int>("flag") + 1;
+    a.skip_flag = magls_kind(p.d.kind) ? p.get<int>("flag") + 4 : nullptr;
     a.timing = p.has("sweep_timing") ? p.get<long long>("sweep_timing") : nullptr;
     const char* fg = getenv("EMAGLS_PERSIST_GLOBAL");
     a.force_global = (fg && fg[0] == '1') ? 1 : 0;
@@ -1057,7 +1075,14 @@ struct SweepChain {
     ~SweepChain() {   // (the lock is held from the wait to the record: no other sweep can slip in between)
         try {
             State& c = state();
-            if (hipEventRecord(c.ev, st) == hipSuccess) c.recorded = true;
+            const hipError_t e = hipEventRecord(c.ev, st);
+            if (e == hipSuccess) c.recorded = true;
+            else {   // (e.g. the stream belongs to another device than the calling thread's current one: the next sweep would not
+                     // be ordered behind this one -- never silently)
+                (void)hipGetLastError();
+                fprintf(stderr, "emagls: the sweep chain event could not be recorded (%s): persistent sweeps are no longer serialised\n",
+                        hipGetErrorString(e));
+            }
         } catch (...) {}
     }
 };
@@ -1167,7 +1192,7 @@ void execute_from_atf(emagls_plan& p) {
 void run_pipeline(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     p.stage_names.clear();
-    launch_zero(p.get("flag"), sizeof(int) * 4, p.stream);
+    launch_zero(p.get("flag"), sizeof(int) * NFLAG, p.stream);
     if (p.has("route")) launch_zero(p.get("route"), p.bufs["route"].bytes, p.stream);
     if (p.has("W")) launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
     p.mark("begin");
@@ -1254,7 +1279,7 @@ void emagls_post_sweep(emagls_plan& p);
 void batch_execute_lanes(emagls_batch& b);
 void plan_pre_stage(emagls_plan& p) {
     p.stage_names.clear();
-    launch_zero(p.get("flag"), sizeof(int) * 4, p.stream);
+    launch_zero(p.get("flag"), sizeof(int) * NFLAG, p.stream);
     if (p.has("route")) launch_zero(p.get("route"), p.bufs["route"].bytes, p.stream);
     launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
     if (magls_kind(p.d.kind)) magls_pre_sweep(p); else emagls_pre_sweep(p);
@@ -1365,7 +1390,11 @@ void drop_batch_graphs(emagls_batch& b) {
     b.eager_runs = 0;
 }
 // Device-side status words of a design: [0] Cholesky pivot, [1] persistent sweep gave up waiting, [2] a Gram-route bin was
-// worse conditioned than the kr estimate promised.  [1] and [2] are recoverable: the design is re-run without the feature.
+// worse conditioned than the kr estimate promised ([3] = the highest such bin), [4] MagLS: the SH basis is too ill-conditioned
+// for the inverse form M = R^-1 R^-H of the persistent sweep (the reference's pinv would drop singular values).
+// [1], [2] and [4] are recoverable: the design is re-run without the feature.  [1] and [2] stick to the plan (a residency or
+// conditioning property of the shape); [4] is a property of THIS call's grid, so the launch-per-bin sweep only serves the
+// re-run and a cached plan tries the persistent form again on its next call.
 // Returns true when the design has to be executed again; throws when a flag cannot be recovered from.
 bool plan_recover(emagls_plan& p, const int* flag, bool apply) {
     bool redo = false;
@@ -1380,6 +1409,11 @@ bool plan_recover(emagls_plan& p, const int* flag, bool apply) {
             plan_alloc_routes(p);
             HIP_CHECK(hipStreamSynchronize(p.stream));
         }
+        redo = true;
+    }
+    if (flag[4]) {
+        if (!p.sweep_persist) throw Error(EMAGLS_ERR_NUMERIC, "internal: MagLS conditioning flag without the persistent sweep");
+        if (apply) { p.sweep_persist = false; p.persist_suspended = true; }
         redo = true;
     }
     if (flag[1]) {
@@ -1506,8 +1540,8 @@ void batch_try_lanes(emagls_batch& b) {
 }
 
 void batch_redo(emagls_batch& b, const std::vector<int>& flags) {
-    int any[4] = {0, 0, 0, 0};
-    for (size_t j = 0; j < b.plans.size(); ++j) for (int i = 0; i < 4; ++i) any[i] = std::max(any[i], flags[4 * j + i]);
+    int any[NFLAG] = {};
+    for (size_t j = 0; j < b.plans.size(); ++j) for (int i = 0; i < NFLAG; ++i) any[i] = std::max(any[i], flags[NFLAG * j + i]);
     bool moved = false;
     for (auto* q : b.plans) {
         const int64_t before = q->total_bytes;
@@ -1525,14 +1559,14 @@ void batch_redo(emagls_batch& b, const std::vector<int>& flags) {
 }
 std::vector<int> batch_read_flags(emagls_batch& b) {
     const size_t n = b.plans.size();
-    std::vector<int> flags(4 * n, 0);
+    std::vector<int> flags(NFLAG * n, 0);
     for (size_t j = 0; j < n; ++j)
-        HIP_CHECK(hipMemcpyAsync(&flags[4 * j], b.plans[j]->get("flag"), 4 * sizeof(int), hipMemcpyDeviceToHost, b.stream));
+        HIP_CHECK(hipMemcpyAsync(&flags[NFLAG * j], b.plans[j]->get("flag"), NFLAG * sizeof(int), hipMemcpyDeviceToHost, b.stream));
     HIP_CHECK(hipStreamSynchronize(b.stream));
     return flags;
 }
 void plan_check_flags(emagls_plan& p) {
-    int flag[4] = {0, 0, 0, 0};
+    int flag[NFLAG] = {};
     HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
     if (plan_recover(p, flag, false)) {
         if (p.owner) {   // a member of a batch: the batch re-runs as a whole (its graphs cover every member)
@@ -1551,6 +1585,10 @@ void plan_check_flags(emagls_plan& p) {
             else { plan_recover(p, flag, true); drop_plan_graphs(p); plan_execute(p); HIP_CHECK(hipStreamSynchronize(p.stream)); }
             HIP_CHECK(hipMemcpy(flag, p.get("flag"), sizeof flag, hipMemcpyDeviceToHost));
         }
+    }
+    if (p.persist_suspended) {   // (the re-run on the launch-per-bin sweep is done: the next call starts on the persistent form again)
+        p.persist_suspended = false;
+        p.sweep_persist = true;
     }
     throw_fatal_flags(flag);
 }
@@ -1608,7 +1646,8 @@ size_t plan_cache_capacity() {
 bool same_desc(const emagls_design_desc& a, const emagls_design_desc& b) {
     return a.kind == b.kind && a.basis == b.basis && a.order == b.order && a.fs == b.fs && a.len == b.len && a.nsamp == b.nsamp &&
            a.ndirs == b.ndirs && a.mic_radius == b.mic_radius && a.nmics == b.nmics && a.f_trans == b.f_trans &&
-           a.atf_taps == b.atf_taps && a.natf == b.natf && a.custom_basis == b.custom_basis && a.diffuseness == b.diffuseness;
+           a.atf_taps == b.atf_taps && a.natf == b.natf && a.custom_basis == b.custom_basis && a.diffuseness == b.diffuseness &&
+           a.sim_order_pad == b.sim_order_pad;
 }
 
 int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR, const double* azi, const double* zen,
@@ -1798,10 +1837,14 @@ int emagls_plan_create(const emagls_design_desc* desc, emagls_plan** plan) {
     });
 }
 int emagls_plan_destroy(emagls_plan* plan) {
-    return guarded([&] { delete plan; });
+    return guarded([&] {
+        DeviceGuard dg(plan ? plan->device : -1);
+        delete plan;
+    });
 }
 int emagls_plan_set_hrir_grid(emagls_plan* p, const double* azi, const double* zen) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !azi) throw Error(EMAGLS_ERR_ARG, "null pointer");
         // a horizontal HRIR set (getMagLsFilters2D) has no zenith argument: pi/2 for every direction
         std::vector<double> equator;
@@ -1815,6 +1858,7 @@ int emagls_plan_set_hrir_grid(emagls_plan* p, const double* azi, const double* z
 }
 int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* zen) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !azi) throw Error(EMAGLS_ERR_ARG, "null pointer");
         if (!p->has("mic_azi")) throw Error(EMAGLS_ERR_ARG, "this design kind has no microphone grid");
         // an equatorial array (EMAinCH) has no zenith argument: pi/2 for every microphone (getEMagLsFiltersEMAinCH.m:60)
@@ -1836,6 +1880,7 @@ int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* ze
 }
 int emagls_plan_set_basis(emagls_plan* p, const void* Y_hrir, const void* Y_mic) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !Y_hrir) throw Error(EMAGLS_ERR_ARG, "null pointer");
         if (!p->custom_basis) throw Error(EMAGLS_ERR_ARG, "the plan was not created with custom_basis = 1");
         const size_t es = esz(p->cplx_basis);
@@ -1855,6 +1900,7 @@ int emagls_plan_set_basis(emagls_plan* p, const void* Y_hrir, const void* Y_mic)
 }
 int emagls_plan_set_hrirs(emagls_plan* p, const double* hL, const double* hR) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !hL || !hR) throw Error(EMAGLS_ERR_ARG, "null pointer");
         p->upload("hL", hL, sizeof(double) * p->d.nsamp * p->d.ndirs);
         p->upload("hR", hR, sizeof(double) * p->d.nsamp * p->d.ndirs);
@@ -1864,6 +1910,7 @@ int emagls_plan_set_hrirs(emagls_plan* p, const double* hL, const double* hR) {
 }
 int emagls_plan_set_atfs(emagls_plan* p, const double* atf, const double* azi, const double* zen) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !atf || !azi || !zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
         if (!p->has("atf")) throw Error(EMAGLS_ERR_ARG, "this design kind has no ATFs");
         p->upload("atf", atf, sizeof(double) * p->d.atf_taps * p->d.nmics * p->d.natf);
@@ -1875,18 +1922,21 @@ int emagls_plan_set_atfs(emagls_plan* p, const double* atf, const double* azi, c
 }
 int emagls_plan_execute(emagls_plan* p) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
         plan_execute(*p);
     });
 }
 int emagls_plan_synchronize(emagls_plan* p) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
         HIP_CHECK(hipStreamSynchronize(p->sync_stream ? p->sync_stream : p->stream));
     });
 }
 int emagls_plan_get_filters(emagls_plan* p, void* wL, void* wR) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !wL || !wR) throw Error(EMAGLS_ERR_ARG, "null pointer");
         if (!p->executed) throw Error(EMAGLS_ERR_ARG, "plan has not been executed");
         HIP_CHECK(hipStreamSynchronize(p->sync_stream ? p->sync_stream : p->stream));
@@ -1898,6 +1948,7 @@ int emagls_plan_get_filters(emagls_plan* p, void* wL, void* wR) {
 }
 int emagls_plan_get_info(emagls_plan* p, emagls_plan_info* info) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !info) throw Error(EMAGLS_ERR_ARG, "null pointer");
         std::memset(info, 0, sizeof *info);
         info->nfft = p->nfft; info->num_pos_freqs = p->P; info->k_cut = p->k_cut; info->sim_order = p->simOrder;
@@ -1905,6 +1956,7 @@ int emagls_plan_get_info(emagls_plan* p, emagls_plan_info* info) {
         info->out_rows = p->out_rows; info->out_cols = p->out_cols; info->num_sweep_launches = p->sweep_launches;
         info->device_bytes = p->total_bytes;
         info->gram_from = p->gram_from; info->hh_end = p->hh_end; info->hh_orders = p->n_h + 1; info->g_first = p->g0;
+        info->sim_order_own = array_kind(p->d.kind) ? p->simOrderOwn : p->simOrder;
         if (p->executed) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
             double g[2];
@@ -1916,12 +1968,14 @@ int emagls_plan_get_info(emagls_plan* p, emagls_plan_info* info) {
 }
 int emagls_plan_set_profiling(emagls_plan* p, int level) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
         p->prof_level = level;
     });
 }
 int emagls_plan_set_streams(emagls_plan* p, int nstreams) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
         if (nstreams < 1 || nstreams > 3) throw Error(EMAGLS_ERR_ARG, "nstreams must be 1..3");
         HIP_CHECK(hipStreamSynchronize(p->stream));
@@ -1940,6 +1994,7 @@ const char* emagls_plan_stage_name(emagls_plan* p, int i) {
 }
 int emagls_plan_stage_times(emagls_plan* p, double* ms, int n) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !ms) throw Error(EMAGLS_ERR_ARG, "null pointer");
         HIP_CHECK(hipStreamSynchronize(p->stream));
         const int ns = (int)p->stage_names.size();
@@ -1955,6 +2010,7 @@ int emagls_plan_stage_times(emagls_plan* p, double* ms, int n) {
 }
 int emagls_plan_sweep_kernel_time(emagls_plan* p, double* total_ms, int* launches) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !total_ms || !launches) throw Error(EMAGLS_ERR_ARG, "null pointer");
         HIP_CHECK(hipStreamSynchronize(p->stream));
         double tot = 0.0;
@@ -1973,6 +2029,7 @@ int emagls_plan_sweep_kernel_time(emagls_plan* p, double* total_ms, int* launche
 }
 int emagls_plan_debug_buffer(emagls_plan* p, const char* name, void* dst, size_t* nbytes) {
     return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
         if (!p || !name || !nbytes) throw Error(EMAGLS_ERR_ARG, "null pointer");
         auto it = p->bufs.find(name);
         if (it == p->bufs.end()) throw Error(EMAGLS_ERR_ARG, std::string("unknown buffer ") + name);
@@ -2003,12 +2060,15 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
             if (!p) throw Error(EMAGLS_ERR_ARG, "null plan");
             if (!array_kind(p->d.kind)) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH plans");
             if (p->owner) throw Error(EMAGLS_ERR_ARG, "a plan belongs to another batch (destroy that batch first)");
+            if (p->device != plans[0]->device) throw Error(EMAGLS_ERR_ARG, "the plans of a batch must live on one device");
             for (int i = 0; i < j; ++i) if (plans[i] == p) throw Error(EMAGLS_ERR_ARG, "the same plan appears twice in the batch");
             const emagls_plan* q = plans[0];
             if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_persist != q->sweep_persist)
                 throw Error(EMAGLS_ERR_ARG, "all designs of a batch must have the same shape (directions, channels, bins, k_cut)");
             b->plans.push_back(p);
         }
+        b->device = b->plans[0]->device;
+        DeviceGuard dg(b->device);
         b->stream = StreamPool::get().take();
         if (const char* ng = getenv("EMAGLS_NO_GRAPH")) b->use_graph = !(ng[0] == '1');
         // one persistent sweep launch keeps designs x nWG workgroups resident: one per CU up to 8 designs (one design per XCD),
@@ -2031,18 +2091,21 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
 }
 int emagls_batch_execute(emagls_batch* b) {
     return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
         if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
         batch_execute(*b);
     });
 }
 int emagls_batch_synchronize(emagls_batch* b) {
     return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
         if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
         HIP_CHECK(hipStreamSynchronize(b->stream));
     });
 }
 int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) {
     return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
         if (!b || !wL || !wR) throw Error(EMAGLS_ERR_ARG, "null pointer");
         const size_t n = b->plans.size();
         for (size_t j = 0; j < n; ++j) {
@@ -2053,36 +2116,38 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
         emagls_plan& p0 = *b->plans[0];
         const size_t bytes = (p0.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p0.out_rows * p0.out_cols;
         // the copies are ordered behind the batch on its stream; one synchronisation for everything
-        std::vector<int> flags(4 * n, 0);
+        std::vector<int> flags(NFLAG * n, 0);
         for (int attempt = 0; attempt < 3; ++attempt) {
             if (b->lanes)
-                HIP_CHECK(hipMemcpy2DAsync(flags.data(), 4 * sizeof(int), p0.get("flag"), b->stride, 4 * sizeof(int), n,
+                HIP_CHECK(hipMemcpy2DAsync(flags.data(), NFLAG * sizeof(int), p0.get("flag"), b->stride, NFLAG * sizeof(int), n,
                                            hipMemcpyDeviceToHost, b->stream));
             else
                 for (size_t j = 0; j < n; ++j)
-                    HIP_CHECK(hipMemcpyAsync(&flags[4 * j], b->plans[j]->get("flag"), 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+                    HIP_CHECK(hipMemcpyAsync(&flags[NFLAG * j], b->plans[j]->get("flag"), NFLAG * sizeof(int), hipMemcpyDeviceToHost, b->stream));
             for (size_t j = 0; j < n; ++j) {
                 HIP_CHECK(hipMemcpyAsync(wL[j], b->plans[j]->get("wL"), bytes, hipMemcpyDefault, b->stream));
                 HIP_CHECK(hipMemcpyAsync(wR[j], b->plans[j]->get("wR"), bytes, hipMemcpyDefault, b->stream));
             }
             HIP_CHECK(hipStreamSynchronize(b->stream));
             bool redo = false;
-            for (size_t j = 0; j < n; ++j) redo = plan_recover(*b->plans[j], &flags[4 * j], false) || redo;
+            for (size_t j = 0; j < n; ++j) redo = plan_recover(*b->plans[j], &flags[NFLAG * j], false) || redo;
             if (!redo) break;
             // recoverable: a Gram-route bin worse conditioned than estimated, or a persistent sweep that did not become resident
             batch_redo(*b, flags);
         }
-        for (size_t j = 0; j < n; ++j) throw_fatal_flags(&flags[4 * j]);
+        for (size_t j = 0; j < n; ++j) throw_fatal_flags(&flags[NFLAG * j]);
     });
 }
 int emagls_batch_lane_mode(emagls_batch* b, int* lanes) {
     return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
         if (!b || !lanes) throw Error(EMAGLS_ERR_ARG, "null pointer");
         *lanes = b->lanes ? 1 : 0;
     });
 }
 int emagls_batch_set_stream(emagls_batch* b, void* stream) {
     return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
         if (!b || !stream) throw Error(EMAGLS_ERR_ARG, "null pointer");
         HIP_CHECK(hipStreamSynchronize(b->stream));
         if (b->own_stream) emagls::pool_stream_give(b->stream);
@@ -2093,6 +2158,7 @@ int emagls_batch_set_stream(emagls_batch* b, void* stream) {
 }
 int emagls_batch_set_profiling(emagls_batch* b, int level) {
     return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
         if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
         HIP_CHECK(hipStreamSynchronize(b->stream));
         if (level >= 1)
@@ -2102,6 +2168,7 @@ int emagls_batch_set_profiling(emagls_batch* b, int level) {
 }
 int emagls_batch_sweep_time(emagls_batch* b, double* ms) {
     return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
         if (!b || !ms) throw Error(EMAGLS_ERR_ARG, "null pointer");
         if (b->prof_level < 1 || !b->sweep_ev[0]) throw Error(EMAGLS_ERR_ARG, "batch profiling is off");
         HIP_CHECK(hipStreamSynchronize(b->stream));
@@ -2111,7 +2178,10 @@ int emagls_batch_sweep_time(emagls_batch* b, double* ms) {
     });
 }
 int emagls_batch_destroy(emagls_batch* b) {
-    return guarded([&] { delete b; });
+    return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
+        delete b;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2209,8 +2279,10 @@ static int decode_entry(const void* in, bool in_cplx, int64_t nsamp, int64_t nch
                 HIP_CHECK(hipMalloc(&d_w2L, sizeof(double) * 2 * len * nch));
                 HIP_CHECK(hipMalloc(&d_w2R, sizeof(double) * 2 * len * nch));
                 if (imag_abs_sum) HIP_CHECK(hipMalloc(&d_tmp, sizeof(double) * (2 * nsamp + 2)));
+                // (the reference sums the discarded imaginary part AFTER binauralOut(del:end,:), binauralDecode.m:53-62)
+                const int64_t cut = (compensate_delay && len / 2 > 0) ? len / 2 - 1 : 0;
                 binaural_decode_complex(d_in, in_cplx, nsamp, (int)nch, d_wL, d_wR, w_cplx, len, d_sig2, d_w2L, d_w2R, d_out,
-                                        imag_abs_sum, d_tmp, st);
+                                        imag_abs_sum, d_tmp, st, std::min(cut, nsamp));
             }
             if (!compensate_delay) {
                 HIP_CHECK(hipMemcpy(out, d_out, sizeof(double) * nsamp * 2, hipMemcpyDefault));

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -183,6 +184,36 @@ template <int W> __device__ __forceinline__ double group_max(double v) {
     return v;
 }
 #endif
+
+// first() is true once per device (of the calling thread's current device): hipFuncSetAttribute and friends are per-device
+// state, a process-wide `static bool` would leave every device but the first without them
+struct PerDeviceOnce {
+    std::mutex mu;
+    uint64_t seen[4] = {0, 0, 0, 0};
+    bool first() {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        uint64_t& w = seen[(dev >> 6) & 3];
+        const uint64_t bit = 1ull << (dev & 63);
+        if (w & bit) return false;
+        w |= bit;
+        return true;
+    }
+};
+// run a scope on a given device and restore the caller's current device afterwards (plans and batches remember theirs)
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev < 0) return;
+        HIP_CHECK(hipGetDevice(&prev));
+        if (prev != dev) { HIP_CHECK(hipSetDevice(dev)); switched = true; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 constexpr double kPi = 3.14159265358979323846;
 

@@ -77,11 +77,11 @@ __global__ void widen_real_kernel(const double* __restrict__ x, int64_t total, i
         out[(second_half ? 0 : total) + idx] = 0.0;
     }
 }
-__global__ void __launch_bounds__(1024) abs_sum_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+__global__ void __launch_bounds__(1024) abs_sum_kernel(const double* __restrict__ x, int64_t n, int64_t skip, double* __restrict__ out) {
     __shared__ double sh[1024];
     const double* col = x + (int64_t)blockIdx.x * n;
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += fabs(col[i]);
+    for (int64_t i = skip + threadIdx.x; i < n; i += blockDim.x) acc += fabs(col[i]);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s2 = 512; s2 > 0; s2 >>= 1) {
@@ -173,7 +173,7 @@ void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL,
 // warning, is re(w) * im(x) + im(w) * re(x): a second pass on [im x; re x] with [re w; im w], only when asked for.
 // sig2 / w2L / w2R: work buffers of 2 C n and 2 C len doubles; sig, wL, wR device pointers (interleaved complex when flagged)
 void binaural_decode_complex(const void* sig, bool sig_cplx, int64_t n, int C, const void* wL, const void* wR, bool w_cplx, int64_t len,
-                             double* sig2, double* w2L, double* w2R, double* out, double* imag_abs, double* d_tmp, hipStream_t st) {
+                             double* sig2, double* w2L, double* w2R, double* out, double* imag_abs, double* d_tmp, hipStream_t st, int64_t imag_skip) {
     if (n <= 0) return;
     auto planes = [&](const void* x, bool is_cplx, int64_t rows, int swap, int neg_im, double* dst) {
         const int64_t total = (int64_t)C * rows;
@@ -191,7 +191,7 @@ void binaural_decode_complex(const void* sig, bool sig_cplx, int64_t n, int C, c
         planes(wL, w_cplx, len, 0, 0, w2L);        // [re w; im w]
         planes(wR, w_cplx, len, 0, 0, w2R);
         binaural_decode_real(sig2, n, 2 * C, w2L, w2R, len, d_tmp, st);
-        abs_sum_kernel<<<2, 1024, 0, st>>>(d_tmp, n, d_tmp + 2 * n);
+        abs_sum_kernel<<<2, 1024, 0, st>>>(d_tmp, n, imag_skip, d_tmp + 2 * n);   // (binauralDecode.m:53-62: summed after the delay cut)
         KERNEL_CHECK();
         HIP_CHECK(hipMemcpyAsync(imag_abs, d_tmp + 2 * n, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));

@@ -249,10 +249,9 @@ template <typename T, int TD>
 static void qt_launch(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, void* QT, int64_t ldD,
                       hipStream_t st) {
     const size_t dyn = sizeof(T) * (size_t)TD * (S + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;   // (function attributes are per device)
+    if (attr_once.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void*)qt_kernel<T, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
     }
     qt_kernel<T, TD><<<bgrid((unsigned)ceil_div(D, TD)), 512, dyn, st>>>((const T*)Yc, ldY, (const T*)E, ldE, D, S, C, nOrders, (T*)QT, ldD, batch_ctx().stride);
     KERNEL_CHECK();

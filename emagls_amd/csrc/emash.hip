@@ -111,11 +111,10 @@ __global__ void __launch_bounds__(256) rot_from_points_kernel(const T* __restric
 void launch_rot_from_points(const void* A, int64_t ldA, const void* Z, int ldP, int C, int npts, const double* zen, int D, bool cb, void* Rot,
                             hipStream_t st) {
     const size_t sm = (size_t)2 * C * npts * (cb ? sizeof(cplx) : sizeof(double));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;   // (function attributes are per device)
+    if (attr_once.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void*)rot_from_points_kernel<cplx>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void*)rot_from_points_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     if (cb) rot_from_points_kernel<cplx><<<bgrid(D), 256, sm, st>>>((const cplx*)A, ldA, (const cplx*)Z, ldP, C, npts, zen, (cplx*)Rot, batch_ctx().stride);
     else rot_from_points_kernel<double><<<bgrid(D), 256, sm, st>>>((const double*)A, ldA, (const cplx*)Z, ldP, C, npts, zen, (double*)Rot, batch_ctx().stride);

@@ -491,14 +491,13 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
     int TS = HF_TD;
     while (TS > 1 && (size_t)TS * nfft * 16 + shared > budget) TS >>= 1;
     const size_t sm = (size_t)TS * nfft * 16 + shared;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;   // (function attributes are per device)
+    if (attr_once.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void*)real_fft_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const dim3 grid = bgrid((unsigned)ceil_div(D, HF_TD));
 #define EMAGLS_HF(TSV)                                                                                                               \
@@ -520,10 +519,9 @@ void launch_real_fft_gather(const double* x, int64_t L, int64_t ncols, const int
     int TP = 8;
     while (TP > 1 && (size_t)TP * nfft * 16 + (size_t)nfft * 8 > 150 * 1024) TP >>= 1;
     const size_t sm = (size_t)TP * nfft * 16 + (size_t)nfft * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;   // (function attributes are per device)
+    if (attr_once.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void*)real_fft_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const int64_t npairs = (ncols + 1) / 2;
     real_fft_gather_kernel<<<(unsigned)ceil_div(npairs, TP), 512, sm, st>>>(x, L, ncols, colidx, nfft, log2n, TP,
@@ -537,10 +535,9 @@ void launch_filter_epilogue(const void* W, int C, int nfft, int len, const void*
     const int log2n = ilog2(nfft);
     const size_t sm = (size_t)nfft * 16 + (size_t)nfft * 8;
     if (sm > 48 * 1024) {   // (only the radial-filter IRs get here: the designs stop at nfft = 2048)
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDeviceOnce attr_once;   // (function attributes are per device)
+        if (attr_once.first()) {
             HIP_CHECK(hipFuncSetAttribute((const void*)filter_epilogue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
         }
     }
     filter_epilogue_kernel<<<bgrid(dim3(C, n_ears)), 256, sm, st>>>((const cplx*)W, C, nfft, log2n, len, (const cplx*)tw, grpd,

@@ -520,12 +520,11 @@ void launch_zsolve_flagged(void* Z, int ldS, const void* R, const void* Rinv, co
 template <typename T> static void qform_impl(const void* Yc, const void* R, void* Rinv, int S, int64_t D, int64_t ld, void* Q,
                                              hipStream_t st) {
     auto lds = [&](int ch, int tr) { return sizeof(T) * ((size_t)tr * (S + 1) + (size_t)ch * 33 + 32 * 33 + tr * 33); };
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;   // (function attributes are per device)
+    if (attr_once.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void*)qform_kernel<T, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
     }
     rinv_diag_kernel<T><<<bgrid((unsigned)ceil_div(S, NB)), 64, 0, st>>>((const T*)R, S, (T*)Rinv, batch_ctx().stride);
     KERNEL_CHECK();
@@ -568,8 +567,9 @@ void launch_small_gemm(const void* A, int lda, bool a_cplx, const void* B, int l
 
 // MagLS on the persistent sweep: M = (R^H R)^-1 = R^-1 R^-H from the Cholesky factor of the basis' Gram matrix (C = S <= 32),
 // written to every bin's slot (the sweep kernel reads M of bin kb at slot kb - 1), and cond_ok = 1 for every bin.  A factor
-// whose diagonal spans more than 1e6 raises status[1] ("take the launch-per-bin sweep"): the reference's pinv would drop
-// singular values there, which the inverse cannot follow.  One workgroup.
+// whose diagonal spans more than 1e6 raises status[4] ("take the launch-per-bin sweep for this call"; a word of its own, not the
+// sweep's residency time-out status[1]): the reference's pinv would drop singular values there, which the inverse cannot
+// follow.  One workgroup.
 template <typename T>
 __global__ void __launch_bounds__(256) magls_m_kernel(const T* __restrict__ R, int C, int P, cplx* __restrict__ Mw, double* __restrict__ cond_ok,
                                                       int* __restrict__ status, size_t bstride) {
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256) magls_m_kernel(const T* __restrict__ R, i
     if (tid == 0) {
         double dmin = INFINITY, dmax = 0.0;
         for (int i = 0; i < C; ++i) { const double v = norm2(mk(1.0, 0.0) * R[(size_t)i * C + i]); dmin = fmin(dmin, v); dmax = fmax(dmax, v); }
-        if (!(dmin > 1e-12 * dmax)) atomicExch(status + 1, 1);
+        if (!(dmin > 1e-12 * dmax)) atomicExch(status + 4, 1);
     }
     __syncthreads();
     for (int idx = tid; idx < C * C; idx += 256) {

@@ -20,7 +20,7 @@ void launch_transpose_conj(const void* Y, int64_t D, int64_t S, int64_t ldY, voi
 
 // ---- modal.hip
 void launch_modal_bn(int N, int64_t nfreq, const double* kr, double kr_scale, double out_scale, void* bn,
-                     int64_t stride_k, int64_t stride_n, hipStream_t st);
+                     int64_t stride_k, int64_t stride_n, hipStream_t st, const int* n_valid = nullptr);
 
 // ---- fft.hip
 void launch_twiddles(int nfft, void* tw, hipStream_t st);
@@ -127,7 +127,8 @@ double measure_fp64_peak(int which, int reps);
 void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL, const double* wR, int64_t len,
                           double* out /* [n x 2] column-major */, hipStream_t st);
 void binaural_decode_complex(const void* sig, bool sig_cplx, int64_t n, int C, const void* wL, const void* wR, bool w_cplx, int64_t len,
-                             double* sig2, double* w2L, double* w2R, double* out, double* imag_abs, double* d_tmp, hipStream_t st);
+                             double* sig2, double* w2L, double* w2R, double* out, double* imag_abs, double* d_tmp, hipStream_t st,
+                             int64_t imag_skip = 0 /* samples left out of the imaginary-part sums (the compensateDelay cut) */);
 void decode_cache_clear();
 void filter_channels_by_order(const double* sig, int64_t n_in, int64_t n, int C, const double* ir /* [nOrd][len] */, int nOrd, int64_t len,
                               int64_t skip, double* out /* [C][n-skip] */, hipStream_t st);

@@ -13,8 +13,12 @@ namespace emagls {
 
 __global__ void __launch_bounds__(256) modal_bn_kernel(int N, int64_t nfreq, const double* __restrict__ kr,
                                                        double kr_scale, double out_scale, cplx* __restrict__ bn,
-                                                       int64_t stride_k, int64_t stride_n, size_t bstride) {
-    kr = boff(kr, bstride); bn = boff(bn, bstride);
+                                                       int64_t stride_k, int64_t stride_n, const int* __restrict__ n_valid,
+                                                       size_t bstride) {
+    kr = boff(kr, bstride); bn = boff(bn, bstride); n_valid = boff(n_valid, bstride);
+    // orders above n_valid are written as zeros: a design simulated at a padded order (a lane batch across neighbouring
+    // simulation-order classes) sums the same terms as at its own order (dependencies/getSMAIRMatrix.m:95,107)
+    const int nv = n_valid ? *n_valid : N;
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nfreq) return;
     // kr == nullptr: kr_k = k * kr_scale (the FFT-bin grid 2 pi f_k r / c)
@@ -38,6 +42,7 @@ __global__ void __launch_bounds__(256) modal_bn_kernel(int N, int64_t nfreq, con
     for (int n = 1; n <= N; ++n) {
         // here j,y are order n; jm,ym order n-1
         cplx val = mk(0.0, 0.0);
+        if (n > nv) dead = true;
         if (!dead) {
             const double dj = jm - (n + 1) * ix * j;
             const double dy = ym - (n + 1) * ix * y;
@@ -64,10 +69,10 @@ __global__ void __launch_bounds__(256) modal_bn_kernel(int N, int64_t nfreq, con
 }
 
 void launch_modal_bn(int N, int64_t nfreq, const double* kr, double kr_scale, double out_scale, void* bn,
-                     int64_t stride_k, int64_t stride_n, hipStream_t st) {
+                     int64_t stride_k, int64_t stride_n, hipStream_t st, const int* n_valid) {
     if (nfreq <= 0) return;
     modal_bn_kernel<<<bgrid((unsigned)ceil_div(nfreq, 256)), 256, 0, st>>>(N, nfreq, kr, kr_scale, out_scale, (cplx*)bn,
-                                                                    stride_k, stride_n, batch_ctx().stride);
+                                                                    stride_k, stride_n, n_valid, batch_ctx().stride);
     KERNEL_CHECK();
 }
 

@@ -292,7 +292,7 @@ void launch_diffuse_constraint(void* W, const void* G, bool g_cplx, int64_t g_st
 // getSMAIRMatrix materialised (dependencies/getSMAIRMatrix.m:110-140) for callers that want the array model itself; the filter
 // designs never form it.  out[(k S + s) rows + c] = rad_n(c)(k) E[c][s] b_n(s)(k), the last bin with
 // real(b_n) (:115-117) -- MATLAB's [rows x S x P] column-major array.  rad (optional, [P][nOut orders]) are the radial filters
-// applied to the SH-domain model (:129-138; their last bin is real already).
+// applied to the SH-domain model (:129-138): r at every bin and, literally like the reference, r real(r) at the Nyquist bin.
 template <typename T>
 __global__ void __launch_bounds__(256) smair_kernel(const T* __restrict__ E, int ldS, const cplx* __restrict__ bn, int nOrd,
                                                     const cplx* __restrict__ rad, int nRad, int rows, int S, int P, cplx* __restrict__ out) {
@@ -310,9 +310,11 @@ __global__ void __launch_bounds__(256) smair_kernel(const T* __restrict__ E, int
     if (rad) {
         int nc = 0;
         while ((nc + 1) * (nc + 1) <= c) ++nc;
-        cplx r = rad[(size_t)k * nRad + nc];
-        if (k == P - 1) r.y = 0.0;
+        const cplx r = rad[(size_t)k * nRad + nc];
         v = r * v;
+        // the reference applies the filter a SECOND time at the Nyquist bin: smairMat(:,:,k) = BnTi * smairMat(:,:,k) and then, for
+        // k == numPosFreqs, smairMat(:,:,k) = real(BnTi) * smairMat(:,:,k) on the already filtered slice (getSMAIRMatrix.m:134-137)
+        if (k == P - 1) v = r.x * v;
     }
     out[idx] = v;
 }

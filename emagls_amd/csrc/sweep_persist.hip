@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     const int design = (blockIdx.x & 7) + 8 * (two ? (rest & 1) : 0), member = two ? (rest >> 1) : rest;
     if (design >= m.n || member >= nWG) return;
     const HalfSweepArgs& a = m.a[design];
+    if (a.skip_flag && __hip_atomic_load(a.skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // (uniform per design)
     // The chain is latency bound and its waves sleep most of the time; kernels of other batches share the CU.  Highest issue
     // priority for the chain's waves: when they have work they get the next slot, at no cost to the others while they wait.
     __builtin_amdgcn_s_setprio(3);
@@ -432,11 +433,10 @@ void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const unsigned nblocks = 8u * (unsigned)nWG * (m.n > 8 ? 2u : 1u);
     const int dpw = persist_sweep_dpw(a.D);
     const size_t dyn = sizeof(cplx) * ((size_t)PS_CMAX * (dpw + 4) + (size_t)PS_CMAX * PS_MLD + 2 * dpw);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;   // (function attributes are per device)
+    if (attr_once.first()) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
     }
     if (dpw == 64) sweep_persist_kernel<64><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
     else sweep_persist_kernel<96><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);

@@ -10,10 +10,10 @@ from . import _lib as L
 
 class Plan:
     def __init__(self, kind, basis="real", order=4, fs=48000.0, length=512, nsamp=128, ndirs=0, mic_radius=0.0, nmics=0,
-                 f_trans=0.0, atf_taps=0, natf=0, custom_basis=False, diffuseness=False):
+                 f_trans=0.0, atf_taps=0, natf=0, custom_basis=False, diffuseness=False, sim_order_pad=0):
         self._lib = L.load()
         self.desc = L.DesignDesc(kind, L.BASIS[basis], order, fs, length, nsamp, ndirs, mic_radius, nmics, f_trans,
-                                 atf_taps, natf, 1 if custom_basis else 0, 1 if diffuseness else 0)
+                                 atf_taps, natf, 1 if custom_basis else 0, 1 if diffuseness else 0, int(sim_order_pad))
         self._cplx = basis == "complex"
         self._h = C.c_void_p()
         L.check(self._lib.emagls_plan_create(C.byref(self.desc), C.byref(self._h)))

@@ -147,7 +147,7 @@ int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const d
 /* Complex-SH rendering (dependencies/binauralDecode.m:39-42,59-64: complex products accumulated, real part kept).
  * in [nsamp x nch] and wL / wR [len x nch] are interleaved complex where the flag says so, real otherwise; out as above, real.
  * imag_abs_sum (optional, [2]) receives sum(abs(imag(.))) of the discarded imaginary part per ear, the two numbers the
- * reference prints in its warning (:61-62). */
+ * reference prints in its warning (:61-62) -- over the samples that are returned, i.e. after the compensate_delay cut (:53-57). */
 int emagls_binaural_decode_complex(const void* in, int in_is_complex, int64_t nsamp, int64_t nch, const void* wL, const void* wR,
                                    int filters_are_complex, int64_t len, int compensate_delay, double* out, double* imag_abs_sum);
 
@@ -234,6 +234,10 @@ typedef struct emagls_design_desc {
     int custom_basis;    /* != 0: the SH matrices are supplied by emagls_plan_set_basis (a custom shFunction, lib/getEMagLsFilters.m:32,68) */
     int diffuseness;     /* != 0: apply the diffuseness (covariance) constraint -- the applyDiffusenessConst option the reference
                           * removed (CHANGELOG.md:10-12, verifyEMagLs.m:137-145); MAGLS, MAGLS_2D, EMAGLS, EMAGLS2, EMA_CH */
+    int sim_order_pad;   /* EMAGLS / EMAGLS2 / EMA_CH, 0 = off: lay the design out for max(its own simulation order, this) SH orders
+                          * with b_n = 0 above its own order (dependencies/getSMAIRMatrix.m:95,107: the same sum, the same filters).
+                          * Array radii of neighbouring simulation-order classes then have ONE shape and share a lane batch
+                          * (emagls_batch_create; BASELINE config 4: 256 radii = 32 batches of 8) */
 } emagls_design_desc;
 
 typedef struct emagls_plan_info {
@@ -248,6 +252,7 @@ typedef struct emagls_plan_info {
      * (Householder QR + Jacobi SVD) on the lowest hh_orders orders, [gram_from, P) Gram route (gram_from == 0: none);
      * g_first: first bin whose direction-space operand G_k is formed */
     int gram_from, hh_end, hh_orders, g_first;
+    int sim_order_own;               /* the design's own simulation order (sim_order is the padded one with sim_order_pad) */
 } emagls_plan_info;
 
 int emagls_plan_create(const emagls_design_desc* desc, emagls_plan** plan);

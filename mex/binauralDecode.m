@@ -10,13 +10,17 @@ comp = nargin > 5 && compensateDelay;
 if isreal(decodingFilterLeft) ~= isreal(decodingFilterRight)      % both real or both complex at the boundary
     decodingFilterLeft = complex(decodingFilterLeft); decodingFilterRight = complex(decodingFilterRight);
 end
-[binauralOut, imagSum] = emagls_mex('decode', double(in), double(decodingFilterLeft), double(decodingFilterRight), false);
-if any(imagSum > 0)     % the warning of :59-63
-    warning('Complex binaural output signals (sum of imaginary parts: [%f, %f]). Forcing real outputs.', imagSum(1), imagSum(2));
-end
-if nargin > 6 && ~isempty(signal)
+extraConv = nargin > 6 && ~isempty(signal);
+% the library cuts the delay itself (and sums the discarded imaginary part over the samples it returns, like :53-62) unless the
+% extra convolution of :44-48 has to run on the uncut signal first
+[binauralOut, imagSum] = emagls_mex('decode', double(in), double(decodingFilterLeft), double(decodingFilterRight), comp && ~extraConv);
+if extraConv
     if signalFs ~= inFs; signal = resample(signal, inFs, signalFs); end
     binauralOut = [fftfilt(binauralOut(:,1), signal(:,1)), fftfilt(binauralOut(:,2), signal(:,1))];
+    if comp; del = size(decodingFilterLeft,1) / 2; binauralOut = binauralOut(del:end,:); end
 end
-if comp; del = size(decodingFilterLeft,1) / 2; binauralOut = binauralOut(del:end,:); end
+% :59-63, the reference's text; it fires when the accumulated result is complex, i.e. has a non-zero imaginary part
+if (~isreal(in) || ~isreal(decodingFilterLeft)) && any(imagSum ~= 0)
+    warning('discarding imaginary part with sum of [%.2g, %.2g] in rendering result.', imagSum(1), imagSum(2));
+end
 end

@@ -234,11 +234,13 @@ def emagls2_simulation_order(fs, radius):
 
 
 def getSMAIRMatrix(order, fs, irLen, smaRadius, smaDesignAziZenRad, shDefinition="real",
-                   returnRawMicSigs=False, arrayType="rigid", shFunction=None):
-    """dependencies/getSMAIRMatrix.m:86-127 with oversamplingFactor=1, radialFilter='none',
-    planeWave (the only configuration the five entry points use, lib/getEMagLsFilters.m:51-63).
+                   returnRawMicSigs=False, arrayType="rigid", shFunction=None, oversamplingFactor=1, radialFilter="none",
+                   regulConst=1e-2, noiseGainDb=20.0):
+    """dependencies/getSMAIRMatrix.m:86-141, plane-wave model.  The keyword defaults here are what the five entry points pass
+    (oversamplingFactor=1, radialFilter='none': lib/getEMagLsFilters.m:51-63), NOT the reference's struct defaults
+    ('regul' -- which getRadialFilter.m:63-64 rejects -- and 4, getSMAIRMatrix.m:50-51,70-71).
     Returns [C x S x P] like the reference."""
-    nfft = irLen
+    nfft = oversamplingFactor * irLen
     assert nfft % 2 == 0
     f = np.linspace(0, fs / 2, nfft // 2 + 1)
     simOrder = simulation_order(order, fs, smaRadius)
@@ -257,6 +259,14 @@ def getSMAIRMatrix(order, fs, irLen, smaRadius, smaDesignAziZenRad, shDefinition
             Bn = np.real(Bn)  # :115-117
         pM = Y_Hi * Bn[None, :]
         out[:, :, k] = pM if returnRawMicSigs else Y_Lo_pinv @ pM
+    if not returnRawMicSigs and str(radialFilter).lower() != "none":   # :129-138
+        radFilts = getRadialFilter(order, fs, smaRadius, irLen=irLen, oversamplingFactor=oversamplingFactor, radialFilter=str(radialFilter).lower(),
+                                   arrayType=arrayType, regulConst=regulConst, noiseGainDb=noiseGainDb).T
+        for k in range(P):
+            BnTi = sh_repToOrder(radFilts[:, k])
+            out[:, :, k] = BnTi[:, None] * out[:, :, k]
+            if k == P - 1:   # :135-137: the (real part of the) filter once more, on the already filtered slice
+                out[:, :, k] = np.real(BnTi)[:, None] * out[:, :, k]
     return out, simOrder
 
 

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from emagls_amd.batch import run_batch, shard_jobs
+from emagls_amd.batch import run_batch, run_lane_batches, shard_jobs, simulation_order
 
 
 def _design(job):
@@ -29,12 +29,26 @@ def _worker(rank, world, port, cplx, q):
     jobs = [(float(r), cplx) for r in radii]
     costs = [(max(4, int(np.ceil(439.6 * r))) + 1) ** 2 for r in radii]  # (simOrder+1)^2 at 48 kHz
     out = run_batch(jobs, _design, costs)
+    # the class-aware runner (whole padded lane batches per rank): 21 radii -> batches of 7, pad order = the batch's highest
+    radii2 = np.linspace(0.02, 0.10, 21)
+    jobs2 = [(float(r), cplx) for r in radii2]
+    so = [simulation_order(4, 48000.0, r, raw=True) for r in radii2]
+    seen = []
+
+    def batch_fn(bjobs, pad):
+        assert 1 <= len(bjobs) <= 8 and pad >= max(simulation_order(4, 48000.0, r, raw=True) for r, _ in bjobs)
+        seen.append(len(bjobs))
+        return [_design(j) for j in bjobs]
+    out2 = run_lane_batches(jobs2, so, batch_fn)
+    assert seen and all(n == 7 for n in seen)
     if rank == 0:
         ok = all(np.array_equal(out[j][0], _design(jobs[j])[0]) and np.array_equal(out[j][1], _design(jobs[j])[1])
                  for j in range(len(jobs)))
+        ok = ok and len(out2) == 21 and all(np.array_equal(out2[j][0], _design(jobs2[j])[0]) and
+                                              np.array_equal(out2[j][1], _design(jobs2[j])[1]) for j in range(21))
         q.put(("ok" if ok else "mismatch", len(out)))
     else:
-        assert out is None
+        assert out is None and out2 is None
     dist.destroy_process_group()
 
 
@@ -73,3 +87,10 @@ def test_single_process_batch():
     jobs = [(0.03, False), (0.05, False)]
     out = run_batch(jobs, _design)
     assert len(out) == 2 and np.array_equal(out[1][0], _design(jobs[1])[0])
+
+
+def test_single_process_lane_batches():
+    jobs = [(0.03, False), (0.05, False), (0.031, False)]
+    so = [simulation_order(4, 48000.0, r, raw=True) for r, _ in jobs]
+    out = run_lane_batches(jobs, so, lambda bj, pad: [_design(j) for j in bj])
+    assert len(out) == 3 and all(np.array_equal(out[j][0], _design(jobs[j])[0]) for j in range(3))

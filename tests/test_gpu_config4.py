@@ -145,3 +145,69 @@ def test_run_batch_composes_with_the_real_designs(grids, hrirs64):
     for (wL, wR), r in zip(out, radii):
         dL, dR = design(r)
         assert wL.shape == (64, 32) and np.array_equal(wL, dL) and np.array_equal(wR, dR)
+
+
+def test_one_ranks_share_of_config4_in_lane_mode(grids, hrirs64):
+    """BASELINE config 4 as named: 256 radii over 8 ranks.  One rank's full share -- 32 radii = 4 padded lane batches of 8
+    designs of neighbouring simulation-order classes (emagls_amd.batch.padded_lane_batches / shard_lane_batches) -- through
+    Batch: every batch runs in LANE mode, every job equals its own one-shot design (which is laid out for its own simulation
+    order, no padding), and one job of every batch is compared with the oracle."""
+    import emagls_amd as E
+    from emagls_amd import Batch, Plan, _lib as L
+    from emagls_amd.batch import padded_lane_batches, shard_lane_batches, simulation_order
+    hrirs, length = hrirs64, 64
+    radii = np.linspace(0.02, 0.10, 256)
+    so = [simulation_order(4, 48000.0, r, raw=True) for r in radii]
+    per_rank, load = shard_lane_batches(padded_lane_batches(so), 8)
+    mine = per_rank[5]
+    assert len(mine) == 4 and all(len(idx) == 8 for idx, _ in mine)
+    results, padded = {}, 0
+    for idx, pad in mine:
+        plans = []
+        for j in idx:
+            p = Plan(L.KIND_EMAGLS2, "real", 4, 48000.0, length, 64, 2702, float(radii[j]), 32, sim_order_pad=pad)
+            p.set_hrir_grid(grids["azi"], grids["zen"])
+            p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+            p.set_hrirs(hrirs[0], hrirs[1])
+            i = p.info()
+            assert i.sim_order == pad and i.sim_order_own == so[j] and i.num_sh_sim == (pad + 1) ** 2
+            padded += i.sim_order != i.sim_order_own
+            plans.append(p)
+        b = Batch(plans)
+        assert b.lane_mode()
+        b.execute()
+        b.execute()     # (second execute: hipGraph capture path)
+        b.execute()
+        for j, w in zip(idx, b.get_filters()):
+            results[j] = w
+        b.close()
+        for p in plans:
+            p.close()
+    assert len(results) == 32 and padded >= 4      # the share really mixes simulation-order classes
+    worst = 0.0
+    for idx, _ in mine:                             # first and last job of every batch against its one-shot design
+        for j in (idx[0], idx[-1]):
+            wL, wR = E.getEMagLs2Filters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], float(radii[j]), grids["mic_azi"],
+                                         grids["mic_zen"], 4, 48000.0, length, "real")
+            worst = max(worst, rel(results[j][0], wL), rel(results[j][1], wR))
+    print(f"config 4, one rank's share (32 radii, 4 lane batches): padded lane batches vs one-shot designs, worst rel = {worst:.3e}")
+    assert worst < 1e-8
+    worst_o = 0.0
+    for idx, pad in mine:                           # one padded job per batch against the oracle
+        j = next((j for j in idx if so[j] < pad), idx[0])
+        oL, oR = O.getEMagLs2Filters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], float(radii[j]), grids["mic_azi"], grids["mic_zen"],
+                                     4, 48000.0, length, "real")
+        worst_o = max(worst_o, rel(results[j][0], oL), rel(results[j][1], oR))
+    print(f"config 4, one rank's share: 4 jobs vs oracle, worst rel = {worst_o:.3e}")
+    assert worst_o < TOL
+
+
+def test_sim_order_pad_is_refused_where_it_cannot_apply(grids):
+    from emagls_amd import Plan, _lib as L
+    with pytest.raises(L.EmaglsError):
+        Plan(L.KIND_EMA_SH, "real", 2, 48000.0, 64, 64, 2702, 0.05, 16, sim_order_pad=30)
+    with pytest.raises(L.EmaglsError):
+        Plan(L.KIND_EMAGLS, "real", 4, 48000.0, 64, 64, 2702, 0.042, 32, custom_basis=True, sim_order_pad=30)
+    p = Plan(L.KIND_EMAGLS, "real", 4, 48000.0, 64, 64, 2702, 0.042, 32, sim_order_pad=5)   # below the design's own order: no effect
+    assert p.info().sim_order == p.info().sim_order_own == 19
+    p.close()

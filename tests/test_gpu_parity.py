@@ -603,8 +603,15 @@ def test_binaural_decode_complex(golden):
         out = E.binauralDecode(sig, 48000, wL, wR, 48000)
     assert out.shape == (9000, 2) and out.dtype == np.float64 and rel(out, ref) < 1e-12
     assert any("discarding imaginary part" in str(w.message) for w in wlist)
-    out2 = E.binauralDecode(sig, 48000, wL, wR, 48000, True)
+    with warnings.catch_warnings(record=True) as wlist2:
+        warnings.simplefilter("always")
+        out2 = E.binauralDecode(sig, 48000, wL, wR, 48000, True)
     assert rel(out2, O.binauralDecode(sig, wL, wR, True)) < 1e-12
+    # the numbers in the warning are the reference's: sum(abs(imag(binauralOut))) AFTER the compensateDelay cut (:53-62)
+    full = [sum(O.fftfilt(w[:, c], sig[:, c]) for c in range(25)) for w in (wL, wR)]
+    for msgs, skip in ((wlist, 0), (wlist2, 512 // 2 - 1)):
+        m_ = [str(w.message) for w in msgs if "discarding imaginary part" in str(w.message)][0]
+        assert m_ == "discarding imaginary part with sum of [%.2g, %.2g] in rendering result." % tuple(np.abs(f.imag[skip:]).sum() for f in full)
     # a real signal through complex filters
     sr = rng.standard_normal((4000, 25))
     assert rel(E.binauralDecode(sr, 48000, wL, wR, 48000), O.binauralDecode(sr, wL, wR)) < 1e-12
@@ -732,3 +739,28 @@ def test_batch_of_designs_with_the_diffuseness_constraint(grids, thin):
     b.close()
     for p in plans:
         p.close()
+
+
+def test_magls_ill_conditioned_basis_falls_back_for_one_call_only(thin):
+    """MagLS on the persistent sweep uses M = R^-1 R^-H.  A grid on which the order-4 basis is nearly rank deficient (all
+    directions in a thin band about the equator: diagonal of R spans 1e6, Gram matrix still positive definite) raises status word 4 -- a word of its own, not the sweep's
+    residency time-out -- the call is served by the launch-per-bin sweep, and the SAME plan (what a cached one-shot plan is)
+    goes back to the persistent sweep on the next, well-conditioned grid."""
+    from emagls_amd import Plan, _lib as L
+    from emagls_amd import synth
+    n = thin["hL"].shape[1]
+    azi, zen = synth.fibonacci_grid(n)
+    p = Plan(L.KIND_MAGLS, "real", 4, 48000.0, 128, thin["hL"].shape[0], n)
+    p.set_hrirs(thin["hL"], thin["hR"])
+    p.set_hrir_grid(azi, np.pi / 2 + (zen - np.pi / 2) * 0.023)   # an equatorial band: cos-odd harmonics nearly coincide
+    p.execute()
+    wL, wR = p.get_filters()
+    assert p.info().num_sweep_launches > 1 and np.isfinite(wL).all() and np.isfinite(wR).all()
+    p.set_hrir_grid(thin["azi"], thin["zen"])
+    for _ in range(3):
+        p.execute()
+        wL, wR = p.get_filters()
+        assert p.info().num_sweep_launches == 1
+    p.close()
+    oL, oR = O.getMagLsFilters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 4, 48000.0, 128, "real")
+    assert report("MagLS after a fallback call L", wL, oL) < TOL and report("R", wR, oR) < TOL

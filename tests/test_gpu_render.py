@@ -232,13 +232,40 @@ def test_get_smair_matrix(grids, basis, raw):
 
 
 def test_get_smair_matrix_with_radial_filters(grids):
-    """radialFilter other than 'none' (getSMAIRMatrix.m:129-138): rows of the SH-domain model scaled by the radial filter of
-    their order."""
+    """radialFilter other than 'none' (getSMAIRMatrix.m:129-138) against the oracle's restatement of those lines: rows of the
+    SH-domain model scaled by the radial filter of their order -- and, literally like the reference, scaled TWICE at the
+    Nyquist bin (:134 applies BnTi, :136 applies real(BnTi) to the already filtered slice)."""
     import emagls_amd as E
     grid = np.column_stack([grids["mic_azi"], grids["mic_zen"]])
-    sm0, _ = E.getSMAIRMatrix(order=3, fs=48000.0, irLen=128, smaRadius=0.042, smaDesignAziZenRad=grid)
-    sm1, _ = E.getSMAIRMatrix(order=3, fs=48000.0, irLen=128, smaRadius=0.042, smaDesignAziZenRad=grid, radialFilter="tikhonov")
+    for kind, kw in (("tikhonov", {}), ("softlimit", {"noiseGainDb": 15.0}), ("full", {})):
+        sm1, p1 = E.getSMAIRMatrix(order=3, fs=48000.0, irLen=128, oversamplingFactor=1, smaRadius=0.042, smaDesignAziZenRad=grid,
+                                   radialFilter=kind, **kw)
+        so, _ = O.getSMAIRMatrix(3, 48000.0, 128, 0.042, grid, "real", radialFilter=kind, noiseGainDb=kw.get("noiseGainDb", 20.0))
+        ok = np.isfinite(so)      # ('softlimit' / 'full' are 0/0 or 1/0 at DC for the orders above 0, there like here)
+        assert sm1.shape == so.shape and np.array_equal(np.isfinite(sm1), ok) and rel(sm1[ok], so[ok]) < 1e-11, kind
+    sm0, _ = E.getSMAIRMatrix(order=3, fs=48000.0, irLen=128, oversamplingFactor=1, smaRadius=0.042, smaDesignAziZenRad=grid,
+                               radialFilter="none")
+    sm1, _ = E.getSMAIRMatrix(order=3, fs=48000.0, irLen=128, oversamplingFactor=1, smaRadius=0.042, smaDesignAziZenRad=grid,
+                               radialFilter="tikhonov")
     rad = O.getRadialFilter(3, 48000.0, 0.042, irLen=128, oversamplingFactor=1)          # [P x order+1]
     n_of_c = np.repeat(np.arange(4), 2 * np.arange(4) + 1)
-    ref = sm0 * rad[:, n_of_c].T[:, None, :]
-    assert rel(sm1, ref) < 1e-12
+    scale = rad[:, n_of_c].T[:, None, :].copy()
+    scale[:, :, -1] = scale[:, :, -1] ** 2            # the Nyquist quirk, spelled out
+    assert rel(sm1, sm0 * scale) < 1e-12
+
+
+def test_get_smair_matrix_defaults_are_the_references(grids):
+    """dependencies/getSMAIRMatrix.m:36-84: order 4, fs 48 kHz, r = 4.2 cm, radialFilter 'regul', noiseGainDb 20,
+    oversamplingFactor 4, irLen 2048.  'regul' is not a filter getRadialFilter.m knows (:63-64 -> error), so a call that leaves
+    radialFilter unset fails exactly like the reference's unless the raw microphone signals are requested."""
+    import emagls_amd as E
+    grid = np.column_stack([grids["mic_azi"], grids["mic_zen"]])
+    with pytest.raises(ValueError, match='Unkown radialFilter parameter "regul"'):
+        E.getSMAIRMatrix(smaDesignAziZenRad=grid, irLen=32)
+    sm, p = E.getSMAIRMatrix(smaDesignAziZenRad=grid, irLen=32, returnRawMicSigs=True)
+    assert p["oversamplingFactor"] == 4 and p["order"] == 4 and p["fs"] == 48000 and p["smaRadius"] == 0.042 and p["noiseGainDb"] == 20
+    assert sm.shape == (32, 400, 4 * 32 // 2 + 1)
+    so, _ = O.getSMAIRMatrix(4, 48000.0, 32, 0.042, grid, "real", returnRawMicSigs=True, oversamplingFactor=4)
+    assert rel(sm, so) < 1e-11
+    with pytest.raises(KeyError):      # the reference would load its t-design file here; the mirror asks for the grid
+        E.getSMAIRMatrix(irLen=32, returnRawMicSigs=True)

@@ -58,6 +58,61 @@ def config4(radii, reps=4):
             "ms_per_batch": round(dt * 1e3, 3), "filter_sets_per_s": round(len(radii) / dt, 1)}
 
 
+def config4_rank_share(world=8, rank=5, reps=2):
+    """BASELINE config 4 as named: 256 radii on 2..10 cm over 8 GPUs.  One rank's full share -- 32 radii as 4 padded lane
+    batches of 8 (emagls_amd.batch.padded_lane_batches / shard_lane_batches) -- all four batches resident and in flight
+    together, full size (1024 taps).  filter_sets_per_s is what ONE GPU of the 8 delivers on the job list."""
+    from emagls_amd import Batch, Plan, synth, _lib as L
+    from emagls_amd.batch import padded_lane_batches, shard_lane_batches, simulation_order
+    azi, zen, maz, mzn = _grids()
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen)
+    radii = np.linspace(0.02, 0.10, 256)
+    so = [simulation_order(4, 48000.0, r, raw=True) for r in radii]
+    per_rank, load = shard_lane_batches(padded_lane_batches(so), world)
+    mine = per_rank[rank]
+    import torch
+    streams = [torch.cuda.Stream() for _ in mine]
+    units = []
+    for (idx, pad), st in zip(mine, streams):
+        plans = []
+        for j in idx:
+            p = Plan(L.KIND_EMAGLS2, "real", 4, 48000.0, 1024, hL.shape[0], hL.shape[1], float(radii[j]), 32, sim_order_pad=pad)
+            p.set_hrir_grid(azi, zen)
+            p.set_mic_grid(maz, mzn)
+            p.set_hrirs(hL, hR)
+            plans.append(p)
+        b = Batch(plans)
+        b.set_stream(st.cuda_stream)
+        units.append((b, plans))
+    lanes = [b.lane_mode() for b, _ in units]
+    for b, _ in units:
+        for _ in range(3):
+            b.execute()
+        b.synchronize()
+    each = []
+    for b, _ in units:      # one batch at a time
+        t0 = time.perf_counter()
+        b.execute()
+        b.synchronize()
+        each.append(round((time.perf_counter() - t0) * 1e3, 3))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for b, _ in units:
+            b.execute()
+        for b, _ in units:
+            b.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    n = sum(len(idx) for idx, _ in mine)
+    for b, plans in units:
+        b.get_filters()
+        b.close()
+        for p in plans:
+            p.close()
+    return {"ranks": world, "rank": rank, "designs": n, "lane_batches": [len(idx) for idx, _ in mine], "pad_orders": [pad for _, pad in mine],
+            "lane_mode": lanes, "rank_load_spread": round(max(load) / min(load), 4), "ms_per_batch_alone": each,
+            "ms_per_share": round(dt * 1e3, 3), "filter_sets_per_s": round(n / dt, 1)}
+
+
 def config5(reps=4):
     from emagls_amd import Plan, synth, _lib as L
     azi, zen, _, _ = _grids()
@@ -87,6 +142,10 @@ def run():
             out[name] = config4(radii)
         except Exception as e:
             out[name] = {"error": repr(e)}
+    try:
+        out["config4_rank_share"] = config4_rank_share()
+    except Exception as e:
+        out["config4_rank_share"] = {"error": repr(e)}
     try:
         out["config5"] = config5()
     except Exception as e:
