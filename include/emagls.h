@@ -151,10 +151,14 @@ int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const d
 int emagls_binaural_decode_complex(const void* in, int in_is_complex, int64_t nsamp, int64_t nch, const void* wL, const void* wR,
                                    int filters_are_complex, int64_t len, int compensate_delay, double* out, double* imag_abs_sum);
 
-/* The three designs with the diffuseness (covariance) constraint, the `applyDiffusenessConst` argument the reference's
- * functions used to take after `len` (verifyEMagLs.m:106-114 still shows the call form).  Not in the reference snapshot:
- * specified (CPU restatement under oracle/) from Zaunschirm/Schoerkhuber/Hoeldrich 2018 and pinned structurally by the *_wDC
- * fixtures.  Same arguments as the functions without the suffix plus the flag. */
+/* The three designs with a covariance constraint in the place of the `applyDiffusenessConst` argument the reference's
+ * functions used to take after `len` (verifyEMagLs.m:106-114 still shows the call form).  OWN SPECIFICATION, not the reference's
+ * implementation: that code is not in the snapshot (CHANGELOG.md:10-12).  Per solved bin the two ears' filters are mixed by the
+ * Hermitian positive definite 2x2 matrix M with M Rhat M = R (Rhat: ear covariance of the rendered HRTFs over the HRIR grid,
+ * R: that of the time-aligned HRTFs) -- the closed form of Zaunschirm/Schoerkhuber/Hoeldrich 2018's covariance constraint.
+ * The reference's surviving *_wDC fixtures agree with it for eMagLS / eMagLS2 (their mixing is predicted to 4e-3) and do NOT
+ * for MagLS (interaural cross term off by 6e-2; candidates tried and rejected: DESIGN.md section 7).  Same arguments as the
+ * functions without the suffix plus the flag. */
 int emagls_get_magls_filters_dc(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
                                 int order, double fs, int64_t len, int apply_diffuseness_const, int basis, void* wL, void* wR);
 int emagls_get_emagls_filters_dc(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const double* azi, const double* zen,
@@ -232,8 +236,9 @@ typedef struct emagls_design_desc {
     int64_t atf_taps;    /* FROM_ATF */
     int64_t natf;        /* FROM_ATF: ATF directions */
     int custom_basis;    /* != 0: the SH matrices are supplied by emagls_plan_set_basis (a custom shFunction, lib/getEMagLsFilters.m:32,68) */
-    int diffuseness;     /* != 0: apply the diffuseness (covariance) constraint -- the applyDiffusenessConst option the reference
-                          * removed (CHANGELOG.md:10-12, verifyEMagLs.m:137-145); MAGLS, MAGLS_2D, EMAGLS, EMAGLS2, EMA_CH */
+    int diffuseness;     /* != 0: apply the covariance constraint (own specification, see emagls_get_magls_filters_dc) in the
+                          * place of the applyDiffusenessConst option the reference removed (CHANGELOG.md:10-12,
+                          * verifyEMagLs.m:137-145); MAGLS, MAGLS_2D, EMAGLS, EMAGLS2, EMA_CH */
     int sim_order_pad;   /* EMAGLS / EMAGLS2 / EMA_CH, 0 = off: lay the design out for max(its own simulation order, this) SH orders
                           * with b_n = 0 above its own order (dependencies/getSMAIRMatrix.m:95,107: the same sum, the same filters).
                           * Array radii of neighbouring simulation-order classes then have ONE shape and share a lane batch

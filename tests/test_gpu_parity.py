@@ -61,6 +61,21 @@ def test_magls_filters_config2(grids, hrirs, basis):
     assert report("MagLS L " + basis, wL, oL) < TOL and report("MagLS R " + basis, wR, oR) < TOL
 
 
+def test_magls_filters_config2_with_the_covariance_constraint(grids, hrirs):
+    """BASELINE config 2 as named -- getMagLsFilters N=4, full L2702 grid, 512 taps, covariance constraint ON -- at full size
+    against the oracle's specification of the constraint (the Hermitian positive definite 2x2 ear mixing with M Rhat M = R;
+    own specification: the reference's implementation was removed from the snapshot and its *_wDC fixture pins this form for
+    eMagLS / eMagLS2 only)."""
+    import emagls_amd as E
+    args = (hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 512, "real")
+    wL, wR = E.getMagLsFilters(*args, applyDiffusenessConst=True)
+    oL, oR = O.getMagLsFilters(*args, applyDiffusenessConst=True)
+    uL, uR = E.getMagLsFilters(*args)
+    assert wL.shape == (512, 25)
+    assert report("MagLS + covariance constraint, config 2 full size L", wL, oL) < TOL and report("R", wR, oR) < TOL
+    assert 1e-3 < rel(wL, uL) < 0.5      # the constraint does something
+
+
 @pytest.mark.parametrize("basis,length", [("real", 128), ("complex", 256)])
 def test_emagls_filters_thin(grids, thin, basis, length):
     import emagls_amd as E
