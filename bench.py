@@ -36,6 +36,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes the streams of a process onto this many hardware queues (default 4), and work of two streams
+# that share a queue executes strictly in order -- a side stream of one batch would wait behind another batch's 2 ms sweep.
+# Four batches in flight x four streams each: every stream gets a queue of its own.  (Read by the runtime when it initialises,
+# i.e. before torch / the library touch the GPU; inherited by the ranks `--gpus N` spawns.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 SLOTS, BSZ = 4, 8      # resident batches per GPU x designs per batch (a persistent sweep launch covers eight designs)
@@ -233,6 +238,8 @@ def main():
                     help="resident batches per GPU (profiling runs use 1)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", str(BSZ))),
                     help="designs per batch (<= 16; profiling runs use 1 for the single-design kernel times)")
+    ap.add_argument("--fork", type=int, default=int(os.environ.get("EMAGLS_BENCH_FORK", "4")),
+                    help="streams the stages before a batch's sweep fork onto (1..4, emagls_batch_set_streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sh-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 4 / config 5 / one-shot secondary figures")
@@ -323,6 +330,8 @@ def main():
                 st = next(next_stream, None)
                 if st is not None:
                     self.batch.set_stream(st.cuda_stream)
+                if args.fork > 1 and self.batch.lane_mode():
+                    self.batch.set_streams(args.fork)
 
         def execute(self):
             self.batch.execute() if self.batch is not None else self.plans[0].execute()
@@ -452,7 +461,10 @@ def main():
                 traffic = traffic * Bsz if traffic is not None else None
             ach = bytes_launch / avg_s / 1e9
             roof = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launches_per_step": sweep_n / designs_per_launch,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of build %s; not measured in this run)"
+                                      % pmc.get("build", "?"),
+                    "launches_per_step": sweep_n / designs_per_launch,
                     "designs_per_launch": designs_per_launch, "avg_launch_us": avg_s * 1e6,
                     "avg_launch_us_single_design": single_s * 1e6,
                     "algorithmic_bytes_per_launch": bytes_launch, "bins_per_launch": nbins_swept / sweep_n,
@@ -468,6 +480,15 @@ def main():
         peak_mfma, peak_vec = C.c_double(0.0), C.c_double(0.0)
         lib.emagls_fp64_peak_tflops(0, C.byref(peak_mfma))
         lib.emagls_fp64_peak_tflops(1, C.byref(peak_vec))
+        # the same loops as short launches (<= 1 ms, before the chip settles at its sustained power state) and the shader clock
+        # each loop ran at: the sustained MFMA figure is below AMD's 78.6 TFLOP/s (= 100 % SQ_VALU_MFMA_BUSY_CYCLES, which is
+        # how profiles/ prices gram_mfma_kernel's 41 % utilisation)
+        peaks_detail = {}
+        for nm, which in (("mfma", 0), ("vector", 1)):
+            for mode, burst in (("sustained", 0), ("burst", 1)):
+                tf, mhz = C.c_double(0.0), C.c_double(0.0)
+                if lib.emagls_fp64_peak_tflops_ex(which, burst, C.byref(tf), C.byref(mhz)) == 0:
+                    peaks_detail["%s_%s" % (nm, mode)] = {"tflops": round(tf.value, 2), "shader_mhz": round(mhz.value, 0)}
         # the reference formulation needs F_ref FP64 flop per set (pwGrid GEMM + SVD-equivalent + apply);
         # the factorised pipeline executes F_exec (per stage in DESIGN.md section 5)
         Kb, Sx = info.num_pos_freqs - 1, info.num_sh_sim
@@ -479,6 +500,7 @@ def main():
                   + 8.0 * nbins_swept * 4 * D * Cc + 5.0 * D * info.nfft * 10) / 1e9
         flops = {"F_ref_gflop_per_set": f_ref, "F_exec_gflop_per_set": f_exec, "exec_tflops": f_exec * world * K / dt / 1e3,
                  "fp64_mfma_peak_tflops_measured": round(peak_mfma.value, 2), "fp64_vector_peak_tflops_measured": round(peak_vec.value, 2),
+                 "fp64_peaks_by_launch_length": peaks_detail, "fp64_mfma_peak_tflops_spec": 78.6,
                  "exec_frac_of_vector_peak": (f_exec * K / dt / 1e3) / peak_vec.value if peak_vec.value > 0 else None,
                  "note": "F_ref: reference formulation (SURVEY 8d: 126 GFLOP at config 3, 111 of them the pwGrid GEMM the "
                          "factorised pipeline never executes); F_exec: flops the pipeline executes per set; peaks measured on "
@@ -491,7 +513,7 @@ def main():
                                    "48 kHz; one filter set per step, inputs resident in HBM",
                        "dirs": int(D), "taps": 512, "sim_order": info.sim_order, "bins": info.num_pos_freqs - 1,
                        "k_cut": info.k_cut, "designs_resident_per_gpu": nslots * Bsz, "designs_per_batch": Bsz,
-                       "batches_in_flight": nslots, "timed_schedule": "%d full batches of %d + tail %d" % (K // Bsz, Bsz, K % Bsz),
+                       "batches_in_flight": nslots, "streams_per_batch": args.fork, "timed_schedule": "%d full batches of %d + tail %d" % (K // Bsz, Bsz, K % Bsz),
                        "setup": "each resident batch executed 3x (eager, hipGraph capture, replay) before the warm-up",
                        "parallelism": "independent jobs per GPU, one RCCL gather"},
             "roofline": roof,

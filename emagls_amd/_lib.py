@@ -41,6 +41,7 @@ SYMBOLS = {
     "emagls_set_device": (C.c_int, [C.c_int]),
     "emagls_cache_clear": (C.c_int, []),
     "emagls_fp64_peak_tflops": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "emagls_fp64_peak_tflops_ex": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "emagls_sh_basis": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "emagls_sh_basis_device": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "emagls_modal_bn": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p]),
@@ -74,6 +75,8 @@ SYMBOLS = {
     "emagls_binaural_decode": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_void_p]),
     "emagls_binaural_decode_complex": (C.c_int, [C.c_void_p, C.c_int, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int, c_i64, C.c_int,
                                                  C.c_void_p, C.c_void_p]),
+    "emagls_binaural_decode_device": (C.c_int, [C.c_void_p, C.c_int, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int, c_i64, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]),
     "emagls_get_magls_filters_dc": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_double, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "emagls_get_emagls_filters_dc": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_double,
@@ -121,6 +124,7 @@ SYMBOLS = {
     "emagls_batch_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "emagls_batch_lane_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "emagls_batch_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "emagls_batch_set_streams": (C.c_int, [C.c_void_p, C.c_int]),
     "emagls_batch_sweep_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "emagls_batch_destroy": (C.c_int, [C.c_void_p]),
 }

@@ -389,7 +389,7 @@ def getRadialFilter(params=None, **kw):
     rad, pr = _out(nfft // 2 + 1, int(p["order"]) + 1, True)
     L.check(L.load().emagls_get_radial_filter(int(p["order"]), float(p["fs"]), float(p["smaRadius"]), int(p["irLen"]),
                                               int(p["oversamplingFactor"]), kind, float(p["regulConst"]),
-                                              float(p["noiseGainDb"]), pr))
+                                              float(p.get("noiseGainDb", float("nan"))), pr))
     return rad
 
 
@@ -413,7 +413,7 @@ def applyRadialFilter(inSig, params=None, **kw):
     out, po = _out(rows, C_, False)
     L.check(lib.emagls_apply_radial_filter(ps, sig.shape[0], int(p["order"]), float(p["fs"]), float(p["smaRadius"]), int(p["irLen"]),
                                            int(p["oversamplingFactor"]), kind, float(p["regulConst"]),
-                                           float(p["noiseGainDb"]), po))
+                                           float(p.get("noiseGainDb", float("nan"))), po))
     return out
 
 

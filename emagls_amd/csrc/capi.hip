@@ -129,7 +129,7 @@ struct emagls_plan {
     int nstreams = 1;
     hipStream_t sync_stream = nullptr;  // stream whose completion means this plan's results are ready
     // fork/join inside one design: independent branches run on side streams (captured into the same graph)
-    hipStream_t side[2] = {nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
     hipEvent_t next_sync_event() {
@@ -215,6 +215,8 @@ struct emagls_batch {
     size_t stride = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;                    // false once the caller supplied the stream (emagls_batch_set_stream)
+    int nstreams = 1;                          // lane mode: streams the stages before the sweep fork onto (emagls_batch_set_streams)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int prof_level = 0;
@@ -249,6 +251,7 @@ struct emagls_batch {
         if (post_graph) hipGraphDestroy(post_graph);
         for (auto e : sweep_ev) if (e) hipEventDestroy(e);
         if (stream && own_stream) emagls::pool_stream_give(stream);
+        for (auto st : side) if (st) emagls::pool_stream_give(st);
         for (auto* p : plans) if (p) { p->sync_stream = nullptr; p->owner = nullptr; }
     }
 };
@@ -366,7 +369,7 @@ void plan_setup(emagls_plan& p) {
     p.stream = StreamPool::get().take();
     if (const char* ng = getenv("EMAGLS_NO_GRAPH")) p.use_graph = !(ng[0] == '1');
     for (auto& st : p.side) st = StreamPool::get().take();
-    if (const char* ns = getenv("EMAGLS_STREAMS")) p.nstreams = std::max(1, std::min(3, atoi(ns)));
+    if (const char* ns = getenv("EMAGLS_STREAMS")) p.nstreams = std::max(1, std::min(4, atoi(ns)));
     p.req_cplx = d.basis == EMAGLS_BASIS_COMPLEX;
     // Complex-basis eMagLS / eMagLS2 designs run in real arithmetic.  With Y_c = Y_r T (T unitary, block diagonal per order)
     // smair_c = T_N^H smair_r T and pwGrid_c = T_N^H pwGrid_r, hence Y_reg_inv_c = Y_reg_inv_r T_N, the angles
@@ -872,6 +875,7 @@ void emagls_pre_sweep(emagls_plan& p) {
     // side streams shorten one design's critical path; with several designs in flight they only add queue
     // contention, so a plan can be restricted to its main stream (emagls_plan_set_streams / EMAGLS_STREAMS=1)
     hipStream_t s0 = p.stream, s1 = p.nstreams >= 2 ? p.side[0] : s0, s2 = p.nstreams >= 3 ? p.side[1] : s0;
+    hipStream_t s3 = p.nstreams >= 4 ? p.side[2] : s0;   // the Gram route of the per-bin factors (needs Gy, E, b_n; not the Cholesky factor)
     const int nOrd = p.simOrder + 1;
     const int ls_end = std::min(p.kcut0, p.P);
     const int k0 = std::max(p.kcut0, 1);
@@ -936,6 +940,8 @@ void emagls_pre_sweep(emagls_plan& p) {
     if (s1 != s0) HIP_CHECK(hipEventRecord(e_Yc, s0));
     launch_gram(p.get("Yc"), p.D, p.S, p.ldS, cb, p.get("Gp"), p.get("Gy"), p.get("R"), Sh, s0);
     p.mark("gram_mfma");
+    hipEvent_t e_Gy = p.next_sync_event();
+    if (s3 != s0) HIP_CHECK(hipEventRecord(e_Gy, s0));
     launch_cholesky(p.get("R"), Sh, cb, p.get<int>("flag"), s0);
     p.mark("cholesky");
     hipEvent_t e_R = p.next_sync_event();
@@ -961,7 +967,9 @@ void emagls_pre_sweep(emagls_plan& p) {
     }
 
     // s0: per-bin factors.  Gram route first (needs E, b_n, Gy): K matrices, one GEMM over the bins, direct inverses
+    // (on a stream of its own with four streams: it does not need the Cholesky factor, the Householder route does)
     if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s0, e_E, 0));
+    if (s3 != s0) { HIP_CHECK(hipStreamWaitEvent(s3, e_Gy, 0)); HIP_CHECK(hipStreamWaitEvent(s3, e_E, 0)); }
     FactorArgs fa{};
     fa.S = Sh; fa.C = p.C; fa.ldS = ldSh; fa.kb0 = 1; fa.P = p.P;
     fa.Tn = p.get("Tn"); fa.bn = p.get<cplx>("bn"); fa.nOrders = nOrdH; fa.bn_stride = nOrd;
@@ -977,11 +985,11 @@ void emagls_pre_sweep(emagls_plan& p) {
     fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
     if (p.nb_gram > 0) {
         const int ldK = round_up(p.C * p.C, 64), ldCf = round_up(p.P, 64);
-        launch_gram_kmat(p.get("Gy"), p.get("E"), p.S, p.ldS, p.C, nOrd, cb, p.get("Fg"), p.ldS, p.get<double>("Kmat"), ldK, s0);
+        launch_gram_kmat(p.get("Gy"), p.get("E"), p.S, p.ldS, p.C, nOrd, cb, p.get("Fg"), p.ldS, p.get<double>("Kmat"), ldK, s3);
         launch_gram_gemm(p.get("bn"), nOrd, p.P, gf, p.nb_gram, p.get<double>("Cf"), ldCf, p.get<double>("Kmat"), ldK, p.C,
-                         p.get<double>("Apk"), ldK, s0);
+                         p.get<double>("Apk"), ldK, s3);
         launch_gram_solve(p.get<double>("Apk"), ldK, p.C, gf, p.nb_gram, SVD_REGUL_CONST, p.get("Mw"), p.get("R2w"), p.get<double>("sv"),
-                          p.get<int>("route"), p.get<int>("jsweeps"), s0);
+                          p.get<int>("route"), p.get<int>("jsweeps"), s3);
         // bins in which the 1 % clipping is active (cond > 100) or the certificate failed: Jacobi SVD of the Gram matrix
         FactorArgs fg = fa;
         fg.kb0 = gf;
@@ -990,7 +998,7 @@ void emagls_pre_sweep(emagls_plan& p) {
         // batches have workgroups to spare: a Jacobi workgroup walks a run of neighbouring bins, each warm-started from the
         // previous one (a third of the sweeps); a single design keeps one bin per workgroup (shortest critical path)
         fg.jrun = jacobi_run_length();
-        launch_factor_jacobi_gram(fg, p.nb_gram, s0);
+        launch_factor_jacobi_gram(fg, p.nb_gram, s3);
         p.mark("gram_route");
     }
     // Householder route: T_n of the orders 0..n_h, per-bin QR + Jacobi
@@ -1001,6 +1009,7 @@ void emagls_pre_sweep(emagls_plan& p) {
     }
     // cond_ok[kb]: the cheap direction-space identity is accurate for this bin.  Only the other swept bins (and the
     // least-squares bins) need Z_k, i.e. the back-transform
+    p.depend(s0, s3);   // (singular-value bounds of the Gram-route bins)
     launch_cond_flags(p.get<double>("sv"), p.C, p.P, hh_end, p.get<double>("cond_ok"), s0);
     fa.cond_ok = p.get<double>("cond_ok");
     p.mark("factor_qr_jacobi");
@@ -1307,18 +1316,20 @@ void batch_sweep_stage(emagls_batch& b) {
 // part 0: stages before the sweep, part 2: stages after it
 void batch_lanes_part(emagls_batch& b, int part) {
     emagls_plan& p0 = *b.plans[0];
-    hipStream_t keep = p0.stream;
+    hipStream_t keep = p0.stream, keep_side[3] = {p0.side[0], p0.side[1], p0.side[2]};
     const int keep_streams = p0.nstreams;
     p0.stream = b.stream;
-    p0.nstreams = 1;
+    p0.nstreams = part == 0 ? b.nstreams : 1;
+    if (p0.nstreams > 1) for (int i = 0; i < 3; ++i) p0.side[i] = b.side[i];
+    auto restore = [&] { p0.stream = keep; p0.nstreams = keep_streams; for (int i = 0; i < 3; ++i) p0.side[i] = keep_side[i]; };
     try {
         BatchScope sc((int)b.plans.size(), b.stride);
         if (part == 0) plan_pre_stage(p0); else emagls_post_sweep(p0);
     } catch (...) {
-        p0.stream = keep; p0.nstreams = keep_streams;
+        restore();
         throw;
     }
-    p0.stream = keep; p0.nstreams = keep_streams;
+    restore();
 }
 void batch_execute_lanes(emagls_batch& b) {
     const bool replay = b.use_graph && b.eager_runs >= 1;
@@ -1729,6 +1740,32 @@ int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR,
 
 }  // namespace
 
+// work planes of the complex device-resident decode, grown on demand and kept (released by emagls_cache_clear)
+namespace {
+struct DecodeScratch {
+    std::mutex mu;
+    int device = -1;
+    size_t cap_sig = 0, cap_w = 0, cap_tmp = 0;
+    double *sig2 = nullptr, *w2L = nullptr, *w2R = nullptr, *tmp = nullptr;
+    void release() {
+        hipFree(sig2); hipFree(w2L); hipFree(w2R); hipFree(tmp);
+        sig2 = w2L = w2R = tmp = nullptr; cap_sig = cap_w = cap_tmp = 0; device = -1;
+    }
+    void ensure(size_t nsig, size_t nw, size_t ntmp) {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        if (dev != device) { release(); device = dev; }
+        if (nsig > cap_sig) { hipFree(sig2); sig2 = nullptr; cap_sig = 0; HIP_CHECK(hipMalloc(&sig2, sizeof(double) * nsig)); cap_sig = nsig; }
+        if (nw > cap_w) {
+            hipFree(w2L); hipFree(w2R); w2L = w2R = nullptr; cap_w = 0;
+            HIP_CHECK(hipMalloc(&w2L, sizeof(double) * nw)); HIP_CHECK(hipMalloc(&w2R, sizeof(double) * nw)); cap_w = nw;
+        }
+        if (ntmp > cap_tmp) { hipFree(tmp); tmp = nullptr; cap_tmp = 0; HIP_CHECK(hipMalloc(&tmp, sizeof(double) * ntmp)); cap_tmp = ntmp; }
+    }
+};
+DecodeScratch g_decode_scratch;
+}  // namespace
+
 // =============================================================================================
 extern "C" {
 
@@ -1753,6 +1790,8 @@ int emagls_cache_clear(void) {
                 if (!g_cache[i].busy) g_cache.erase(g_cache.begin() + i);
         }
         decode_cache_clear();
+        std::lock_guard<std::mutex> lk(g_decode_scratch.mu);
+        g_decode_scratch.release();
     });
 }
 
@@ -1760,6 +1799,13 @@ int emagls_fp64_peak_tflops(int which, double* tflops) {
     return guarded([&] {
         if (!tflops || which < 0 || which > 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
         *tflops = measure_fp64_peak(which, 3);
+    });
+}
+
+int emagls_fp64_peak_tflops_ex(int which, int burst, double* tflops, double* shader_mhz) {
+    return guarded([&] {
+        if (!tflops || which < 0 || which > 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        *tflops = measure_fp64_peak(which, 3, burst != 0, shader_mhz);
     });
 }
 
@@ -1977,7 +2023,7 @@ int emagls_plan_set_streams(emagls_plan* p, int nstreams) {
     return guarded([&] {
         DeviceGuard dg(p ? p->device : -1);
         if (!p) throw Error(EMAGLS_ERR_ARG, "null pointer");
-        if (nstreams < 1 || nstreams > 3) throw Error(EMAGLS_ERR_ARG, "nstreams must be 1..3");
+        if (nstreams < 1 || nstreams > 4) throw Error(EMAGLS_ERR_ARG, "nstreams must be 1..4");
         HIP_CHECK(hipStreamSynchronize(p->stream));
         if (p->graph_exec) { HIP_CHECK(hipGraphExecDestroy(p->graph_exec)); p->graph_exec = nullptr; }
         if (p->graph) { HIP_CHECK(hipGraphDestroy(p->graph)); p->graph = nullptr; }
@@ -2156,6 +2202,17 @@ int emagls_batch_set_stream(emagls_batch* b, void* stream) {
         for (auto* p : b->plans) if (p) p->sync_stream = b->stream;
     });
 }
+int emagls_batch_set_streams(emagls_batch* b, int nstreams) {
+    return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
+        if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (nstreams < 1 || nstreams > 4) throw Error(EMAGLS_ERR_ARG, "nstreams must be 1..4");
+        HIP_CHECK(hipStreamSynchronize(b->stream));
+        for (int i = 0; i < nstreams - 1; ++i) if (!b->side[i]) b->side[i] = emagls::pool_stream_take();
+        if (nstreams != b->nstreams) drop_batch_graphs(*b);   // (the next execute runs eagerly, the one after it captures the forks)
+        b->nstreams = nstreams;
+    });
+}
 int emagls_batch_set_profiling(emagls_batch* b, int level) {
     return guarded([&] {
         DeviceGuard dg(b ? b->device : -1);
@@ -2298,6 +2355,25 @@ static int decode_entry(const void* in, bool in_cplx, int64_t nsamp, int64_t nch
             }
         } catch (...) { cleanup(); throw; }
         cleanup();
+    });
+}
+
+int emagls_binaural_decode_device(const void* d_in, int in_is_complex, int64_t nsamp, int64_t nch, const void* d_wL, const void* d_wR,
+                                  int filters_are_complex, int64_t len, double* d_out, double* imag_abs_sum, void* stream) {
+    return guarded([&] {
+        if (!d_in || !d_wL || !d_wR || !d_out) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (nsamp < 0 || nch < 1 || len < 1) throw Error(EMAGLS_ERR_ARG, "invalid shape");
+        if (imag_abs_sum) imag_abs_sum[0] = imag_abs_sum[1] = 0.0;
+        if (nsamp == 0) return;
+        hipStream_t st = (hipStream_t)stream;
+        if (!in_is_complex && !filters_are_complex) {
+            binaural_decode_real((const double*)d_in, nsamp, (int)nch, (const double*)d_wL, (const double*)d_wR, len, d_out, st);
+            return;
+        }
+        std::lock_guard<std::mutex> lk(g_decode_scratch.mu);
+        g_decode_scratch.ensure((size_t)2 * nsamp * nch, (size_t)2 * len * nch, imag_abs_sum ? (size_t)(2 * nsamp + 2) : 0);
+        binaural_decode_complex(d_in, in_is_complex != 0, nsamp, (int)nch, d_wL, d_wR, filters_are_complex != 0, len, g_decode_scratch.sig2,
+                                g_decode_scratch.w2L, g_decode_scratch.w2R, d_out, imag_abs_sum, g_decode_scratch.tmp, st, 0);
     });
 }
 

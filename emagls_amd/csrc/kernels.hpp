@@ -121,7 +121,7 @@ void launch_grid_match(const double* aziA, const double* zenA, int64_t nA, const
 void launch_atf_colidx(const int64_t* idx, int64_t nA, int M, int64_t* colidx, hipStream_t st);
 
 // ---- microbench.hip
-double measure_fp64_peak(int which, int reps);
+double measure_fp64_peak(int which, int reps, bool burst = false, double* mhz = nullptr);
 
 // ---- decode.hip
 void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL, const double* wR, int64_t len,

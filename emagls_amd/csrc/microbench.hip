@@ -9,6 +9,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // every wave: `iters` rounds of 8 independent accumulator tiles (8 x 2048 flop per round)
 __global__ void __launch_bounds__(256) mfma_f64_peak_kernel(int iters, double* __restrict__ sink) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     double4_t acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -21,10 +22,15 @@ __global__ void __launch_bounds__(256) mfma_f64_peak_kernel(int iters, double* _
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) sink[0] = s;   // keeps the loop alive; never true
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // shader cycles and 100 MHz wall ticks of this wave: the clock the loop ran at
+        sink[1] = (double)(clock64() - c0);
+        sink[2] = (double)(wall_clock64() - w0);
+    }
 }
 
 // every lane: `iters` rounds of 16 independent FMA chains (16 x 2 flop per lane and round)
 __global__ void __launch_bounds__(256) fma_f64_peak_kernel(int iters, double* __restrict__ sink) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     double acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 1e-3 * (double)(i + 1);
@@ -37,10 +43,16 @@ __global__ void __launch_bounds__(256) fma_f64_peak_kernel(int iters, double* __
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc[i];
     if (s == 12345.678) sink[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sink[1] = (double)(clock64() - c0);
+        sink[2] = (double)(wall_clock64() - w0);
+    }
 }
 
-// returns the best of `reps` timings in TFLOP/s; which = 0: MFMA (v_mfma_f64_16x16x4_f64), 1: vector FMA (v_fma_f64)
-double measure_fp64_peak(int which, int reps) {
+// returns the best of `reps` timings in TFLOP/s; which = 0: MFMA (v_mfma_f64_16x16x4_f64), 1: vector FMA (v_fma_f64).
+// burst: a launch of <= 1 ms (the chip has no time to settle at its sustained power state) instead of ~10 ms; *mhz (optional)
+// receives the shader clock the measured loop ran at (s_memtime cycles over the 100 MHz wall counter, one wave).
+double measure_fp64_peak(int which, int reps, bool burst, double* mhz) {
     int dev = 0, cus = 0;
     HIP_CHECK(hipGetDevice(&dev));
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -50,7 +62,7 @@ double measure_fp64_peak(int which, int reps) {
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
     const int blocks = cus * 8;          // 8 x 4 waves per CU: two waves per SIMD cover the dependent-issue latency
-    const int iters = which == 0 ? 4096 : 16384;
+    const int iters = (which == 0 ? 4096 : 16384) / (burst ? 16 : 1);
     const double flop = which == 0 ? (double)blocks * 4 * iters * 8 * 2048.0 : (double)blocks * 256 * iters * 16 * 2.0;
     double best = 0.0;
     for (int r = 0; r < reps + 1; ++r) {
@@ -61,7 +73,17 @@ double measure_fp64_peak(int which, int reps) {
         HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0.f;
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        if (r > 0 && ms > 0.f) best = std::max(best, flop / (ms * 1e-3) / 1e12);   // (first launch: module load)
+        if (r > 0 && ms > 0.f) {   // (first launch: module load)
+            const double tf = flop / (ms * 1e-3) / 1e12;
+            if (tf > best) {
+                best = tf;
+                if (mhz) {
+                    double h[3] = {0, 0, 0};
+                    HIP_CHECK(hipMemcpy(h, sink, sizeof h, hipMemcpyDeviceToHost));
+                    *mhz = h[2] > 0 ? h[1] / (h[2] * 0.01) : 0.0;
+                }
+            }
+        }
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);

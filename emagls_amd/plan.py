@@ -150,6 +150,10 @@ class Batch:
         """Run on the caller's hipStream_t (an integer handle, e.g. torch.cuda.Stream().cuda_stream); the caller keeps it alive."""
         L.check(self._lib.emagls_batch_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
+    def set_streams(self, n):
+        """Lane mode: fork the stages before the sweep onto n (1..4) streams (see emagls_batch_set_streams)."""
+        L.check(self._lib.emagls_batch_set_streams(self._h, int(n)))
+
     def sweep_time_ms(self):
         ms = C.c_double(0.0)
         L.check(self._lib.emagls_batch_sweep_time(self._h, C.byref(ms)))

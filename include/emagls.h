@@ -67,6 +67,10 @@ int emagls_cache_clear(void);
 /* Measured FP64 peak of the current device in TFLOP/s (best of a few launches that keep every CU busy): which = 0 the matrix
  * pipe (v_mfma_f64_16x16x4_f64), which = 1 the vector pipe (v_fma_f64).  bench.py prices its executed flops against it. */
 int emagls_fp64_peak_tflops(int which, double* tflops);
+/* The same with the launch length chosen: burst != 0 times launches of <= 1 ms (before the chip settles at its sustained power
+ * state), burst == 0 the ~10 ms launches of the call above; shader_mhz (optional) receives the shader clock the timed loop ran
+ * at (in-kernel cycle counter over the 100 MHz wall counter). */
+int emagls_fp64_peak_tflops_ex(int which, int burst, double* tflops, double* shader_mhz);
 
 /* ---- kernel-level entry points ------------------------------------------------------------- */
 
@@ -150,6 +154,13 @@ int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const d
  * reference prints in its warning (:61-62) -- over the samples that are returned, i.e. after the compensate_delay cut (:53-57). */
 int emagls_binaural_decode_complex(const void* in, int in_is_complex, int64_t nsamp, int64_t nch, const void* wL, const void* wR,
                                    int filters_are_complex, int64_t len, int compensate_delay, double* out, double* imag_abs_sum);
+
+/* The render loop on buffers that are already in HBM (no staging copies, no allocation after the first call of a shape): d_in
+ * [nsamp x nch], d_wL / d_wR [len x nch] real or interleaved complex as flagged, d_out [nsamp x 2] real (no delay cut: the caller
+ * offsets its read).  Enqueued on `stream` (hipStream_t, NULL = default) and synchronised before returning (the hipFFT work
+ * buffers are shared per process).  What bench.py times for north_star item (iii). */
+int emagls_binaural_decode_device(const void* d_in, int in_is_complex, int64_t nsamp, int64_t nch, const void* d_wL, const void* d_wR,
+                                  int filters_are_complex, int64_t len, double* d_out, double* imag_abs_sum, void* stream);
 
 /* The three designs with a covariance constraint in the place of the `applyDiffusenessConst` argument the reference's
  * functions used to take after `len` (verifyEMagLs.m:106-114 still shows the call form).  OWN SPECIFICATION, not the reference's
@@ -276,7 +287,7 @@ int emagls_plan_synchronize(emagls_plan* plan);
 /* synchronise, check device-side status flags, copy the filters out */
 int emagls_plan_get_filters(emagls_plan* plan, void* wL, void* wR);
 int emagls_plan_get_info(emagls_plan* plan, emagls_plan_info* info);
-/* 1..3: number of HIP streams one design may use (independent branches fork onto side streams; default 3,
+/* 1..4: number of HIP streams one design may use (independent branches fork onto side streams; default 3,
  * best for the latency of ONE design; use 1 when several plans are in flight). Drops the captured graph. */
 int emagls_plan_set_streams(emagls_plan* plan, int nstreams);
 /* profiling: level 0 none, 1 = HIP events between stages, 2 = additionally around every sweep launch */
@@ -319,6 +330,12 @@ int emagls_batch_lane_mode(emagls_batch* batch, int* lanes);
  * first and hands one to each batch in flight decides the mapping itself (bench.py does). */
 int emagls_batch_set_stream(emagls_batch* batch, void* hip_stream);
 int emagls_batch_sweep_time(emagls_batch* batch, double* ms);
+/* Lane mode: 1..4 HIP streams for the stages before the sweep (default 1).  With more than one the independent branches of the
+ * design fork onto side streams and the captured graph carries the forks: [HRIR-grid SH matrix, Gram matrix, Cholesky factor,
+ * Householder-route factors] | [array model, order terms, G_k of every bin] | [HRIR prologue, least-squares right-hand sides]
+ * | [Gram-route factors].  Shortens the path to the batch's sweep from the sum of the kernels to its longest branch (what a
+ * short run, a pipeline filling from empty, is bound by); with many batches in flight it only adds queue contention. */
+int emagls_batch_set_streams(emagls_batch* batch, int nstreams);
 int emagls_batch_destroy(emagls_batch* batch);
 
 #ifdef __cplusplus

@@ -292,6 +292,17 @@ def test_lane_batch_matches_single_designs(grids, thin):
         else:
             for (wL, wR), (fL, fR) in zip(res, first):
                 assert np.array_equal(wL, fL) and np.array_equal(wR, fR), it
+    # the stages before the sweep forked onto four streams (emagls_batch_set_streams; what bench.py runs): eager, captured with
+    # the forks, replayed -- bitwise the same filters as on one stream
+    b.set_streams(4)
+    for it in range(3):
+        b.execute()
+        for (wL, wR), (fL, fR) in zip(b.get_filters(), first):
+            assert np.array_equal(wL, fL) and np.array_equal(wR, fR), it
+    b.set_streams(1)
+    b.execute()
+    for (wL, wR), (fL, fR) in zip(b.get_filters(), first):
+        assert np.array_equal(wL, fL) and np.array_equal(wR, fR)
     # the plans still work on their own after the batch moved their buffers into its arena
     plans[1].execute()
     wL, wR = plans[1].get_filters()

@@ -135,6 +135,44 @@ def config5(reps=4):
     return {"atf_dirs": 16384, "mics": 8, "taps": 2048, "ms_per_subject": round(dt * 1e3, 3), "filter_sets_per_s": round(1.0 / dt, 1)}
 
 
+def binaural_decode(nsamp=120000, nch=25, length=512, reps=10):
+    """north_star item (iii) / SURVEY a13: dependencies/binauralDecode.m:33-42 at the harness's size -- a 120 000-sample SH
+    recording x 25 channels through 512-tap filters, both ears -- real and complex SH, buffers resident in HBM
+    (emagls_binaural_decode_device: overlap-save on hipFFT).  Algorithmic bytes = signal in + filters in + two ears out;
+    achieved = those bytes / time against the 8 TB/s HBM peak (the overlap-save passes move several times as much)."""
+    import ctypes as C
+    import torch
+    from emagls_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    out = {}
+    for name, cplx in (("real", False), ("complex", True)):
+        dt = np.complex128 if cplx else np.float64
+        sig = rng.standard_normal((nch, nsamp)) + (1j * rng.standard_normal((nch, nsamp)) if cplx else 0)
+        wl = rng.standard_normal((nch, length)) + (1j * rng.standard_normal((nch, length)) if cplx else 0)
+        wr = rng.standard_normal((nch, length)) + (1j * rng.standard_normal((nch, length)) if cplx else 0)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).cuda()     # [nch][nsamp] row-major == [nsamp x nch] column-major
+        d_sig, d_wl, d_wr = to(sig), to(wl), to(wr)
+        d_out = torch.zeros((2, nsamp), dtype=torch.float64, device="cuda")
+        call = lambda: L.check(lib.emagls_binaural_decode_device(C.c_void_p(d_sig.data_ptr()), int(cplx), nsamp, nch, C.c_void_p(d_wl.data_ptr()),
+                                                                 C.c_void_p(d_wr.data_ptr()), int(cplx), length, C.c_void_p(d_out.data_ptr()), None, None))
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            call()                       # (synchronises its stream before returning)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        es = 16 if cplx else 8
+        nbytes = es * nsamp * nch + 2 * es * length * nch + 8.0 * nsamp * 2
+        out[name] = {"ms": round(t * 1e3, 4), "samples_per_s": round(nsamp / t, 1), "realtime_factor_48k": round(nsamp / 48000.0 / t, 1),
+                     "algorithmic_bytes": nbytes, "achieved_GBps": round(nbytes / t / 1e9, 2), "frac_of_hbm_peak": round(nbytes / t / 1e9 / 8000.0, 5)}
+    out["shape"] = {"samples": nsamp, "channels": nch, "taps": length}
+    return out
+
+
 def run():
     out = {}
     for name, radii in (("config4_r5cm", np.linspace(0.0480, 0.0500, 8)), ("config4_r10cm", np.linspace(0.0980, 0.1000, 8))):
@@ -146,6 +184,10 @@ def run():
         out["config4_rank_share"] = config4_rank_share()
     except Exception as e:
         out["config4_rank_share"] = {"error": repr(e)}
+    try:
+        out["binaural_decode"] = binaural_decode()
+    except Exception as e:
+        out["binaural_decode"] = {"error": repr(e)}
     try:
         out["config5"] = config5()
     except Exception as e:
