@@ -109,6 +109,7 @@ struct emagls_plan {
     bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip)
     emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false, have_basis = false;
+    uint64_t atf_side_version = 0;   // bumped when the grids or the ATF set are replaced (a FromAtf batch re-checks that its plans agree)
     bool diffuse = false;         // diffuseness (covariance) constraint after the sweep (render.hip: diffuse_constraint_kernel)
     bool custom_basis = false;    // the SH matrices come from the caller (a custom shFunction evaluated on the MATLAB side)
     // profiling
@@ -215,6 +216,11 @@ struct emagls_batch {
     size_t stride = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;                    // false once the caller supplied the stream (emagls_batch_set_stream)
+    // FromAtf subjects: the ATF side (spectra of the matched ATFs, per-bin factors) is computed by plan 0 and read by all plans when
+    // they hold the same grids and ATF set (checked on the device whenever one of them was replaced)
+    bool atf = false, atf_share = false, atf_inputs_same = false;
+    uint64_t atf_checked_version = ~0ull;
+    int* cmp_flag = nullptr;
     int nstreams = 1;                          // lane mode: streams the stages before the sweep fork onto (emagls_batch_set_streams)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipGraph_t graph = nullptr;
@@ -252,6 +258,7 @@ struct emagls_batch {
         for (auto e : sweep_ev) if (e) hipEventDestroy(e);
         if (stream && own_stream) emagls::pool_stream_give(stream);
         for (auto st : side) if (st) emagls::pool_stream_give(st);
+        if (cmp_flag) hipFree(cmp_flag);
         for (auto* p : plans) if (p) { p->sync_stream = nullptr; p->owner = nullptr; }
     }
 };
@@ -568,8 +575,15 @@ void plan_setup(emagls_plan& p) {
         p.alloc("mean_dev", sizeof(double));
         p.alloc("colidx", sizeof(int64_t) * (size_t)p.Dm * M);
         p.ldD = round_up(p.Dm, 64);
-        p.alloc("X", sizeof(cplx) * (size_t)p.P * M * p.ldD);
-        p.alloc("Z", sizeof(cplx) * (size_t)p.P * M * p.ldD);
+        p.alloc("X", sizeof(cplx) * ((size_t)p.P * M + 32) * p.ldD);   // (+ 32 rows: the persistent sweep loads whole 32-row slabs)
+        p.alloc("Z", sizeof(cplx) * ((size_t)p.P * M + 32) * p.ldD);
+        // the per-bin M x M factors of the persistent sweep's form (Gram route, gramroute.hip): A_k = X_k X_k^H from the matched
+        // ATF spectra themselves, M_k = V diag(s_reg / s) V^H
+        p.alloc("Apk", sizeof(double) * (size_t)p.P * round_up(M * M, 64));
+        p.alloc("Mw", sizeof(cplx) * ((size_t)p.P * M * M + 1024));
+        p.alloc("cond_ok", sizeof(double) * (size_t)p.P);
+        p.alloc("route", sizeof(int) * (size_t)p.P);
+        p.gram_from = 1;   // every bin starts on the Gram route; a device-side conditioning flag moves the start up (plan_recover)
         p.alloc("Vws", sizeof(cplx) * (size_t)p.P * M * p.ldD);
         p.alloc("sv", sizeof(double) * (size_t)p.P * M);
         p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
@@ -588,7 +602,7 @@ void plan_setup(emagls_plan& p) {
         if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) p.sweep_persist = e[0] != '0';
         // the persistent sweep keeps one workgroup per CU resident (142 KB of LDS each): it needs the shape to fit one XCD's
         // 32 CUs per design AND that many CUs on this device (a partitioned or CU-masked GPU takes the launch-per-bin form)
-        if (!(array_kind(d.kind) || magls_kind(d.kind)) || !persist_sweep_supported((int)Dh, p.C) ||
+        if (!persist_sweep_supported((int)Dh, p.C) ||
             persist_sweep_nwg((int)Dh) > device_cu_count())
             p.sweep_persist = false;
         if (magls_kind(d.kind) && p.sweep_persist) {
@@ -1038,7 +1052,11 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     HalfSweepArgs a{};
     a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
     a.g_stride = (int64_t)p.C * p.ldD;
-    if (magls_kind(p.d.kind)) {   // one operand for every bin (magls_pre_sweep)
+    if (p.d.kind == EMAGLS_KIND_FROM_ATF) {   // G_k = the matched ATF spectra of bin k, [kb][m][ldD]; bins below the Gram route: Y_reg_inv in Z
+        a.D = (int)p.Dm;
+        a.G = p.get<cplx>("X");
+        a.Yri = p.get<cplx>("Z");
+    } else if (magls_kind(p.d.kind)) {   // one operand for every bin (magls_pre_sweep)
         a.g_stride = 0;
         a.G = p.get<cplx>("Gm");
         a.Yri = a.G;             // (never read: every bin is well conditioned)
@@ -1142,7 +1160,96 @@ void execute_emagls(emagls_plan& p) {
     emagls_post_sweep(p);
 }
 
+// ---- getEMagLsFiltersFromAtf on the persistent sweep --------------------------------------------------------------------------
+// pwGrid_k = atfsMatched(k,:,:) (M x Dm) is given, not modelled (FromAtf.m:100-104): G_k = X_k, its M x M Gram matrix from G_k
+// itself (the EMAinSH route), M_k by the direct inverse / the Jacobi SVD of the Gram matrix.  Measured ATFs can be arbitrarily
+// ill-conditioned at low frequencies: the device check of the Gram route (cond < 3e4) raises the status flag with the highest
+// offending bin, the host moves the route's start behind it (plan_recover) and the bins below take the dense route
+// (Householder QR + Jacobi SVD of X_k itself), whose Y_reg_inv the sweep reads directly (cond_ok = 0).
+// What depends on the HRIR set of the subject, and what only on the grids and the ATFs (shared by a batch of subjects):
+void from_atf_subject_stage(emagls_plan& p) {   // grid matching (cheap; the prologue needs the match) + HRIR prologue
+    hipStream_t st = p.stream;
+    const emagls_design_desc& d = p.d;
+    if (p.hrir_smaller)
+        launch_grid_match(p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), d.ndirs, p.get<double>("atf_azi"),
+                          p.get<double>("atf_zen"), d.natf, p.get<double>("cartB"), p.get<int64_t>("match_idx"),
+                          p.get<double>("match_dev"), p.get<double>("mean_dev"), st);
+    else
+        launch_grid_match(p.get<double>("atf_azi"), p.get<double>("atf_zen"), d.natf, p.get<double>("hrir_azi"),
+                          p.get<double>("hrir_zen"), d.ndirs, p.get<double>("cartB"), p.get<int64_t>("match_idx"),
+                          p.get<double>("match_dev"), p.get<double>("mean_dev"), st);
+    launch_atf_colidx(p.hrir_smaller ? p.get<int64_t>("match_idx") : nullptr, p.Dm, p.C, p.get<int64_t>("colidx"), st);
+    p.mark("grid_match");
+    stage_prologue(p, 1, p.hrir_smaller ? nullptr : p.get<int64_t>("match_idx"), p.Dm);
+}
+void from_atf_shared_stage(emagls_plan& p) {    // ATF spectra on the matched directions and the per-bin factors
+    hipStream_t st = p.stream;
+    const emagls_design_desc& d = p.d;
+    const int M = p.C, gf = p.gram_from, nb = gf > 0 ? p.P - gf : 0;
+    const int64_t g_stride = (int64_t)M * p.ldD;
+    const int ls_end = std::min(p.kcut0, p.P);
+    launch_real_fft_gather(p.get<double>("atf"), d.atf_taps, (int64_t)M * p.Dm, p.get<int64_t>("colidx"), p.nfft, p.get("tw"),
+                           p.get("X"), g_stride, p.Dm, p.ldD, st);
+    p.mark("atf_fft");
+    if (nb > 0) {
+        const int ldK = round_up(M * M, 64);
+        launch_gram_from_g(p.get("X"), g_stride, p.ldD, (int)p.Dm, M, gf, nb, 0, p.get<double>("Apk"), ldK, st);
+        launch_gram_solve(p.get<double>("Apk"), ldK, M, gf, nb, SVD_REGUL_CONST, p.get("Mw"), p.get("R2w"), p.get<double>("sv"),
+                          p.get<int>("route"), p.get<int>("jsweeps"), st);
+        FactorArgs fg{};
+        fg.S = M; fg.C = M; fg.ldS = round_up(M, 64); fg.kb0 = gf; fg.P = p.P;
+        fg.reg_mode = 0; fg.reg_c = SVD_REGUL_CONST;
+        fg.sv = p.get<double>("sv"); fg.route = p.get<int>("route"); fg.status = p.get<int>("flag");
+        fg.cond_limit = 10.0 * GRAM_COND_EST;
+        fg.sweeps_out = p.get<int>("jsweeps");
+        const int64_t off = (int64_t)(gf - 1);   // (gram_solve stores bin kb at slot kb - 1; the Jacobi kernel indexes from its first bin)
+        fg.tauw = p.get<double>("tauw") + off * M; fg.R2w = p.get<cplx>("R2w") + off * M * M; fg.Nw = p.get<cplx>("Nw") + off * M * M;
+        fg.Mw = p.get<cplx>("Mw") + off * M * M;
+        fg.jrun = 1;
+        launch_factor_jacobi_gram(fg, nb, st);
+    }
+    launch_cond_flags(p.get<double>("sv"), M, p.P, 1, p.get<double>("cond_ok"), st);   // 1 for every bin ...
+    const int dense_end = gf > 0 ? gf : p.P;   // bins [1, dense_end) on the dense route
+    if (dense_end > 1) {
+        FactorArgs a{};
+        a.S = (int)p.Dm; a.C = M; a.ldS = (int)p.ldD; a.kb0 = 1; a.P = p.P;
+        a.Xd = p.get<cplx>("X"); a.xd_stride = g_stride;
+        a.reg_mode = 0; a.reg_c = SVD_REGUL_CONST;
+        a.Z = p.get<cplx>("Z"); a.Vws = p.get<cplx>("Vws"); a.sv = p.get<double>("sv");
+        a.Hq = p.get<cplx>("Hc"); a.ldHq = p.ldD; a.hq_estride = (int64_t)ls_end * p.ldD; a.ls_end = std::min(ls_end, dense_end);
+        a.W = p.get<cplx>("W"); a.sweeps_out = p.get<int>("jsweeps");
+        a.tauw = p.get<double>("tauw"); a.R2w = p.get<cplx>("R2w"); a.Nw = p.get<cplx>("Nw");
+        launch_factor(a, dense_end - 1, true, st);
+        launch_zero(p.get<double>("cond_ok"), sizeof(double) * (size_t)dense_end, st);   // ... but the dense-route ones: the sweep reads their Y_reg_inv
+    }
+    p.mark("factor_bins");
+}
+// least-squares bins on the Gram route with the operands of `sh` (the plan itself, or the plan whose ATF side a batch shares)
+void from_atf_ls_rows(emagls_plan& p, emagls_plan& sh, hipStream_t st) {
+    const int ls_end = std::min(p.kcut0, p.P), gf = sh.gram_from;
+    if (gf > 0 && gf < ls_end)
+        launch_ls_gram(p.get("Hc"), p.ldD, ls_end, sh.get("X"), (int64_t)p.C * p.ldD, p.ldD, sh.get("Mw"), (int)p.Dm, p.C, p.P, gf, ls_end,
+                       p.get("W"), st);
+}
+void from_atf_pre_sweep(emagls_plan& p) {
+    from_atf_subject_stage(p);
+    from_atf_shared_stage(p);
+    from_atf_ls_rows(p, p, p.stream);
+    p.mark("ls_bins");
+}
+void from_atf_post_sweep(emagls_plan& p) {
+    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"), 0, 1, 1, 0, p.get("wL"),
+                           p.get("wR"), p.stream);
+    p.mark("epilogue");
+}
+
 void execute_from_atf(emagls_plan& p) {
+    if (p.sweep_persist) {   // (eager / profiled executes; plan_execute captures the stages around the sweep otherwise)
+        from_atf_pre_sweep(p);
+        emagls_run_sweep(p);
+        from_atf_post_sweep(p);
+        return;
+    }
     hipStream_t st = p.stream;
     const emagls_design_desc& d = p.d;
     const int M = p.C;
@@ -1242,14 +1349,16 @@ void plan_execute(emagls_plan& p) {
             throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
     }
     if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
-    const bool persist = (array_kind(d.kind) || magls_kind(d.kind)) && p.sweep_persist;
+    const bool persist = d.kind != EMAGLS_KIND_LS && p.sweep_persist;
     if (p.prof_level == 0 && p.use_graph && persist) {
         // the persistent sweep is launched directly (SweepChain); the stages before it are captured from the second
         // execute on (the first runs eagerly: one-time function attributes, lazy module load)
         if (!p.pre_exec && p.eager_runs >= 1) capture_into(p.stream, &p.pre_graph, &p.pre_exec, [&] { plan_pre_stage(p); });
         if (p.pre_exec) HIP_CHECK(hipGraphLaunch(p.pre_exec, p.stream)); else plan_pre_stage(p);
         emagls_run_sweep(p);
-        if (magls_kind(d.kind)) magls_post_sweep(p); else emagls_post_sweep(p);
+        if (d.kind == EMAGLS_KIND_FROM_ATF) from_atf_post_sweep(p);
+        else if (magls_kind(d.kind)) magls_post_sweep(p);
+        else emagls_post_sweep(p);
         if (!p.pre_exec) ++p.eager_runs;
         p.executed = true;
         return;
@@ -1291,12 +1400,16 @@ void plan_pre_stage(emagls_plan& p) {
     launch_zero(p.get("flag"), sizeof(int) * NFLAG, p.stream);
     if (p.has("route")) launch_zero(p.get("route"), p.bufs["route"].bytes, p.stream);
     launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
-    if (magls_kind(p.d.kind)) magls_pre_sweep(p); else emagls_pre_sweep(p);
+    if (p.d.kind == EMAGLS_KIND_FROM_ATF) from_atf_pre_sweep(p);
+    else if (magls_kind(p.d.kind)) magls_pre_sweep(p);
+    else emagls_pre_sweep(p);
 }
 void batch_sweep_stage(emagls_batch& b) {
     HalfSweepMulti h{};
     h.n = (int)b.plans.size();
     for (int j = 0; j < h.n; ++j) h.a[j] = emagls_half_args(*b.plans[j]);
+    if (b.atf_share)   // one ATF side for every subject
+        for (int j = 1; j < h.n; ++j) { h.a[j].G = h.a[0].G; h.a[j].Yri = h.a[0].Yri; h.a[j].Mw = h.a[0].Mw; h.a[j].cond_ok = h.a[0].cond_ok; }
     emagls_plan& q0 = *b.plans[0];
     const int kk0 = std::max(q0.kcut0, 1);
     if (kk0 >= q0.P) return;
@@ -1348,9 +1461,81 @@ void batch_execute_lanes(emagls_batch& b) {
     if (!replay) ++b.eager_runs;
 }
 
+void drop_plan_graphs(emagls_plan& p);
+void drop_batch_graphs(emagls_batch& b);
+// FromAtf subjects share their ATF side when every plan holds the same grids and ATF set and no bin needs the dense route
+void batch_atf_decide_sharing(emagls_batch& b) {
+    uint64_t ver = 0;
+    for (auto* p : b.plans) ver = ver * 1000003ull + p->atf_side_version;
+    bool same = true;
+    if (ver != b.atf_checked_version) {
+        if (!b.cmp_flag) HIP_CHECK(hipMalloc(&b.cmp_flag, 16));
+        HIP_CHECK(hipStreamSynchronize(b.stream));
+        HIP_CHECK(hipMemsetAsync(b.cmp_flag, 0, 16, b.stream));
+        emagls_plan& p0 = *b.plans[0];
+        for (size_t j = 1; j < b.plans.size(); ++j)
+            for (const char* name : {"atf", "atf_azi", "atf_zen", "hrir_azi", "hrir_zen"})
+                launch_compare_words(p0.get(name), b.plans[j]->get(name), p0.bufs[name].bytes, b.cmp_flag, b.stream);
+        int differ = 0;
+        HIP_CHECK(hipMemcpyAsync(&differ, b.cmp_flag, sizeof differ, hipMemcpyDeviceToHost, b.stream));
+        HIP_CHECK(hipStreamSynchronize(b.stream));
+        b.atf_checked_version = ver;
+        same = differ == 0;
+    } else {
+        same = b.atf_inputs_same;   // (nothing was replaced since the last comparison)
+    }
+    b.atf_inputs_same = same;
+    bool routes_ok = true;
+    for (auto* p : b.plans) routes_ok = routes_ok && p->gram_from == 1 && p->sweep_persist == b.plans[0]->sweep_persist;
+    const bool share = same && routes_ok && b.plans.size() > 1;
+    if (share != b.atf_share) {   // the captured per-plan stages differ between the two modes
+        for (auto* p : b.plans) drop_plan_graphs(*p);
+        drop_batch_graphs(b);
+        b.atf_share = share;
+    }
+}
+void from_atf_subject_pre_stage(emagls_plan& p) {   // a subject of a sharing batch: everything but the ATF side
+    p.stage_names.clear();
+    launch_zero(p.get("flag"), sizeof(int) * NFLAG, p.stream);
+    launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
+    from_atf_subject_stage(p);
+}
+void batch_execute_atf(emagls_batch& b) {
+    for (auto* p : b.plans)
+        if (!p->have_hrirs || !p->have_hrir_grid || !p->have_atfs)
+            throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its HRIRs, its grid and the ATFs");
+    batch_atf_decide_sharing(b);
+    const bool replay = b.use_graph && b.eager_runs >= 1;
+    emagls_plan& p0 = *b.plans[0];
+    auto pre = [&](emagls_plan& p) { if (b.atf_share && &p != &p0) from_atf_subject_pre_stage(p); else plan_pre_stage(p); };
+    if (replay && !p0.pre_exec) {
+        for (auto* p : b.plans) capture_into(p->stream, &p->pre_graph, &p->pre_exec, [&] { pre(*p); });
+        if (!p0.sweep_persist) capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_sweep_stage(b); });
+    }
+    b.used = 0;
+    for (auto* p : b.plans) b.depend(p->stream, b.stream);   // (the previous execute of this batch is done with the buffers)
+    for (auto* p : b.plans) {
+        if (replay) HIP_CHECK(hipGraphLaunch(p->pre_exec, p->stream)); else pre(*p);
+        b.depend(b.stream, p->stream);
+    }
+    if (b.atf_share)   // least-squares bins of the other subjects on plan 0's operands
+        for (size_t j = 1; j < b.plans.size(); ++j) from_atf_ls_rows(*b.plans[j], p0, b.stream);
+    if (p0.sweep_persist) batch_sweep_stage(b);   // (never captured: see SweepChain)
+    else if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_sweep_stage(b);
+    for (auto* p : b.plans) {
+        b.depend(p->stream, b.stream);
+        from_atf_post_sweep(*p);
+        b.depend(b.stream, p->stream);  // batch stream completion == all results ready
+        p->executed = true;
+        p->sweep_launches = p0.sweep_persist ? 1 : p0.P - std::max(p0.kcut0, 1);
+    }
+    if (!replay) ++b.eager_runs;
+}
+
 void batch_execute(emagls_batch& b) {
     for (auto* p : b.plans)
         if (!p) throw Error(EMAGLS_ERR_ARG, "a plan of this batch has been destroyed");
+    if (b.atf) { batch_execute_atf(b); return; }
     for (auto* p : b.plans)
         if (!p->have_hrirs || (p->custom_basis ? !p->have_basis : (!p->have_hrir_grid || !p->have_mic_grid)))
             throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grids (or SH matrices) and HRIRs");
@@ -1414,7 +1599,10 @@ bool plan_recover(emagls_plan& p, const int* flag, bool apply) {
         // Householder route then covers more bins and, at their higher kr, more orders: plan_routes refuses beyond its tile)
         if (p.gram_from == 0 || flag[3] < p.gram_from)
             throw Error(EMAGLS_ERR_NUMERIC, "internal: Gram-route conditioning flag outside the route (stale graph)");
-        if (apply) {
+        if (apply && p.d.kind == EMAGLS_KIND_FROM_ATF) {
+            // measured ATFs: the bins up to the offending one take the dense route (QR + Jacobi of the matched ATF matrix itself)
+            p.gram_from = flag[3] + 1 < p.P ? flag[3] + 1 : 0;
+        } else if (apply) {
             p.gram_floor = std::max(p.gram_floor, flag[3] + 1);
             plan_routes(p);
             plan_alloc_routes(p);
@@ -1900,6 +2088,7 @@ int emagls_plan_set_hrir_grid(emagls_plan* p, const double* azi, const double* z
         p->upload("hrir_zen", zen, sizeof(double) * p->d.ndirs);
         HIP_CHECK(hipStreamSynchronize(p->stream));
         p->have_hrir_grid = true;
+        ++p->atf_side_version;
     });
 }
 int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* zen) {
@@ -1964,6 +2153,7 @@ int emagls_plan_set_atfs(emagls_plan* p, const double* atf, const double* azi, c
         p->upload("atf_zen", zen, sizeof(double) * p->d.natf);
         HIP_CHECK(hipStreamSynchronize(p->stream));
         p->have_atfs = true;
+        ++p->atf_side_version;
     });
 }
 int emagls_plan_execute(emagls_plan* p) {
@@ -2104,12 +2294,16 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         for (int j = 0; j < nplans; ++j) {
             emagls_plan* p = plans[j];
             if (!p) throw Error(EMAGLS_ERR_ARG, "null plan");
-            if (!array_kind(p->d.kind)) throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH plans");
+            if (!array_kind(p->d.kind) && p->d.kind != EMAGLS_KIND_FROM_ATF)
+                throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH / EMAinSH plans, or FromAtf plans (subjects of one ATF set)");
+            if ((p->d.kind == EMAGLS_KIND_FROM_ATF) != (plans[0]->d.kind == EMAGLS_KIND_FROM_ATF))
+                throw Error(EMAGLS_ERR_ARG, "FromAtf plans cannot share a batch with array designs");
             if (p->owner) throw Error(EMAGLS_ERR_ARG, "a plan belongs to another batch (destroy that batch first)");
             if (p->device != plans[0]->device) throw Error(EMAGLS_ERR_ARG, "the plans of a batch must live on one device");
             for (int i = 0; i < j; ++i) if (plans[i] == p) throw Error(EMAGLS_ERR_ARG, "the same plan appears twice in the batch");
             const emagls_plan* q = plans[0];
-            if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_persist != q->sweep_persist)
+            if (p->P != q->P || p->kcut0 != q->kcut0 || p->C != q->C || p->nWG_dense != q->nWG_dense || p->D != q->D || p->sweep_persist != q->sweep_persist ||
+                p->Dm != q->Dm || p->d.natf != q->d.natf || p->d.atf_taps != q->d.atf_taps || p->d.len != q->d.len)
                 throw Error(EMAGLS_ERR_ARG, "all designs of a batch must have the same shape (directions, channels, bins, k_cut)");
             b->plans.push_back(p);
         }
@@ -2131,7 +2325,8 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
             p->sync_stream = b->stream;
             p->owner = b.get();
         }
-        batch_try_lanes(*b);
+        b->atf = b->plans[0]->d.kind == EMAGLS_KIND_FROM_ATF;
+        if (!b->atf) batch_try_lanes(*b);
         *batch = b.release();
     });
 }
@@ -2189,6 +2384,12 @@ int emagls_batch_lane_mode(emagls_batch* b, int* lanes) {
         DeviceGuard dg(b ? b->device : -1);
         if (!b || !lanes) throw Error(EMAGLS_ERR_ARG, "null pointer");
         *lanes = b->lanes ? 1 : 0;
+    });
+}
+int emagls_batch_shares_atf_side(emagls_batch* b, int* shared) {
+    return guarded([&] {
+        if (!b || !shared) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        *shared = b->atf_share ? 1 : 0;
     });
 }
 int emagls_batch_set_stream(emagls_batch* b, void* stream) {

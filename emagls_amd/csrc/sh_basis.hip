@@ -138,6 +138,21 @@ void launch_zero(void* p, size_t bytes, hipStream_t st) {
     KERNEL_CHECK();
 }
 
+// *differ = 1 when two device buffers differ in any 8-byte word (a batch of FromAtf subjects checks that its plans really hold
+// the same ATF set and grids before it computes the ATF side once for all of them)
+__global__ void compare_words_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, int64_t n8, int* differ) {
+    bool d = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) d = d || a[i] != b[i];
+    if (d) atomicExch(differ, 1);
+}
+void launch_compare_words(const void* a, const void* b, size_t bytes, int* differ, hipStream_t st) {
+    const int64_t n8 = (int64_t)(bytes / 8);
+    if (n8 == 0) return;
+    const unsigned grid = (unsigned)std::min<int64_t>(4096, ceil_div(n8, 256));
+    compare_words_kernel<<<grid, 256, 0, st>>>((const unsigned long long*)a, (const unsigned long long*)b, n8, differ);
+    KERNEL_CHECK();
+}
+
 // circular harmonics of an equatorial array (dependencies/getCH.m:17-28), written as the complex [channel][mic] matrix
 // that the pinv factorisation takes:  out[c * ld + m] = C_c(azi_m),  channels [C_0, C_-1, C_1, ..., C_-N, C_N]
 // (out_real: the real basis as doubles, the layout the HRIR-side pipeline keeps a real basis in)

@@ -107,7 +107,9 @@ template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and
 constexpr int PS_NT = 256, PS_COMM0 = 192;
 constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 
-template <int PS_DPW>
+// NI: channel quarters that are swept in the M and p phases (channels part + 4 i, i < NI): ceil(C / 4), so that an 8-microphone
+// design (FromAtf) does a quarter of the multiply-adds of a 32-channel one instead of multiplying zeros
+template <int PS_DPW, int NI>
 __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
     constexpr int XLD = PS_DPW + 4;     // row stride of the G slab (16 dwords mod 64: conflict-free quarter-wave reads)
     constexpr int PUNR = PS_DPW == 96 ? 3 : 4;
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
                 if (part == 0) acc = vt[e * PS_CMAX + c];
             } else {
 #pragma unroll
-                for (int i = 0; i < PS_NI; ++i)  // vt and ms are 0 beyond C
+                for (int i = 0; i < NI; ++i)  // vt and ms are 0 beyond C
                     cfma(acc, vt[e * PS_CMAX + part + 4 * i], conj(ms[(part + 4 * i) * PS_MLD + c]));
             }
             acc = group_sum<4>(acc);
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             const int dA = tid >> 2, dB = dA + PS_DPW / 2;
             cplx pA0 = mk(0, 0), pA1 = mk(0, 0), pB0 = mk(0, 0), pB1 = mk(0, 0);   // p[direction][ear]
 #pragma unroll
-            for (int i = 0; i < PS_NI; ++i) {  // Wp and xs are 0 beyond C
+            for (int i = 0; i < NI; ++i) {  // Wp and xs are 0 beyond C
                 const cplx w0 = Wp[part + 4 * i], w1 = Wp[PS_CMAX + part + 4 * i];
                 const cplx gA = xs[(part + 4 * i) * XLD + dA], gB = xs[(part + 4 * i) * XLD + dB];
                 cfma(pA0, w0, gA); cfma(pA1, w1, gA); cfma(pB0, w0, gB); cfma(pB1, w1, gB);
@@ -435,11 +437,16 @@ void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const size_t dyn = sizeof(cplx) * ((size_t)PS_CMAX * (dpw + 4) + (size_t)PS_CMAX * PS_MLD + 2 * dpw);
     static PerDeviceOnce attr_once;   // (function attributes are per device)
     if (attr_once.first()) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#define EMAGLS_PS_ATTR(D, N) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<D, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+        EMAGLS_PS_ATTR(64, 2); EMAGLS_PS_ATTR(64, 4); EMAGLS_PS_ATTR(64, 7); EMAGLS_PS_ATTR(64, 8);
+        EMAGLS_PS_ATTR(96, 2); EMAGLS_PS_ATTR(96, 4); EMAGLS_PS_ATTR(96, 7); EMAGLS_PS_ATTR(96, 8);
+#undef EMAGLS_PS_ATTR
     }
-    if (dpw == 64) sweep_persist_kernel<64><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
-    else sweep_persist_kernel<96><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG);
+    const int ni = a.C <= 8 ? 2 : (a.C <= 16 ? 4 : (a.C <= 28 ? 7 : 8));
+#define EMAGLS_PS_GO(D, N) sweep_persist_kernel<D, N><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG)
+    if (dpw == 64) { if (ni == 2) EMAGLS_PS_GO(64, 2); else if (ni == 4) EMAGLS_PS_GO(64, 4); else if (ni == 7) EMAGLS_PS_GO(64, 7); else EMAGLS_PS_GO(64, 8); }
+    else { if (ni == 2) EMAGLS_PS_GO(96, 2); else if (ni == 4) EMAGLS_PS_GO(96, 4); else if (ni == 7) EMAGLS_PS_GO(96, 7); else EMAGLS_PS_GO(96, 8); }
+#undef EMAGLS_PS_GO
     KERNEL_CHECK();
 }
 

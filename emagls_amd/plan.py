@@ -109,8 +109,9 @@ class Plan:
 
 
 class Batch:
-    """Several eMagLS / eMagLS2 plans of identical shape executed together: per-design stages on the plans' own
-    streams, one sweep launch per frequency bin for all of them."""
+    """Several plans of identical shape executed together, the sequential sweep as ONE resident launch for all of them:
+    eMagLS / eMagLS2 / EMA designs (lane mode: one launch of every kernel for all designs), or FromAtf plans -- the HRTF subjects
+    of one ATF set, whose ATF side is computed once (shares_atf_side)."""
 
     def __init__(self, plans):
         self._lib = L.load()
@@ -149,6 +150,12 @@ class Batch:
     def set_stream(self, hip_stream):
         """Run on the caller's hipStream_t (an integer handle, e.g. torch.cuda.Stream().cuda_stream); the caller keeps it alive."""
         L.check(self._lib.emagls_batch_set_stream(self._h, C.c_void_p(int(hip_stream))))
+
+    def shares_atf_side(self):
+        """FromAtf subjects: True when the last execute computed the ATF side once for all plans (same grids and ATF set)."""
+        v = C.c_int(0)
+        L.check(self._lib.emagls_batch_shares_atf_side(self._h, C.byref(v)))
+        return bool(v.value)
 
     def set_streams(self, n):
         """Lane mode: fork the stages before the sweep onto n (1..4) streams (see emagls_batch_set_streams)."""

@@ -313,6 +313,13 @@ void* emagls_plan_stream(emagls_plan* plan);
  * caller and must outlive the batch.  Results: emagls_batch_get_filters, or emagls_plan_get_filters on each plan. */
 typedef struct emagls_batch emagls_batch;
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch);
+/* A batch may also hold EMAGLS_KIND_FROM_ATF plans of one shape -- the HRTF subjects of one ATF set (BASELINE config 5: 8 subjects).
+ * lib/getEMagLsFiltersFromAtf.m:54-95,100-104: the spectra of the matched ATFs and their per-bin factors do not depend on the
+ * HRIRs.  When all plans hold the same grids and the same ATF set (compared on the device whenever one of them was replaced) the
+ * batch computes that side ONCE, on plan 0, and every subject's prologue, least-squares rows and sweep lane read it; the sweep is
+ * one resident launch for all subjects.  Plans with different ATF sets, or ATFs whose low bins need the dense route, run
+ * unshared (still one sweep launch).  *shared reports which after an execute. */
+int emagls_batch_shares_atf_side(emagls_batch* batch, int* shared);
 int emagls_batch_execute(emagls_batch* batch);
 int emagls_batch_synchronize(emagls_batch* batch);
 /* synchronise once, check every plan's device-side status flags, copy all filters out: wL[j], wR[j] receive the filters of

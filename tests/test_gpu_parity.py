@@ -541,6 +541,104 @@ def test_from_atf_atf_grid_smaller(thin):
     assert report("FromAtf(small ATF grid) L", wL, oL) < TOL and report("FromAtf(small ATF grid) R", wR, oR) < TOL
 
 
+def _atf_plan(thin, hL, hR, atf, aazi, azen, length=256, f_trans=2000.0):
+    from emagls_amd import Plan, _lib as L
+    p = Plan(L.KIND_FROM_ATF, "real", 0, 48000.0, length, hL.shape[0], hL.shape[1], nmics=atf.shape[1], f_trans=f_trans,
+             atf_taps=atf.shape[0], natf=atf.shape[2])
+    p.set_hrir_grid(thin["azi"], thin["zen"])
+    p.set_hrirs(hL, hR)
+    p.set_atfs(atf, aazi, azen)
+    return p
+
+
+def test_from_atf_runs_on_the_persistent_sweep(thin):
+    """One resident sweep launch instead of one launch per bin (938 at config 5), the per-bin factors from the M x M Gram
+    matrices of the matched ATF spectra; EMAGLS_SWEEP_PERSIST=0 keeps the launch-per-bin form, same filters."""
+    from emagls_amd import synth
+    atf, aazi, azen = synth.glasses_atfs(natf=2048, nmics=8, taps=128)
+    p = _atf_plan(thin, thin["hL"], thin["hR"], atf, aazi, azen)
+    outs = []
+    for _ in range(3):   # eager, captured, replayed
+        p.execute()
+        outs.append(p.get_filters())
+    i = p.info()
+    p.close()
+    assert i.num_sweep_launches == 1 and i.gram_from == 1
+    for wL, wR in outs[1:]:
+        assert np.array_equal(wL, outs[0][0]) and np.array_equal(wR, outs[0][1])
+    hg, ag = np.column_stack([thin["azi"], thin["zen"]]), np.column_stack([aazi, azen])
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 256, 2000.0)
+    assert report("FromAtf persistent L", outs[0][0], oL) < TOL and report("R", outs[0][1], oR) < TOL
+
+
+def test_from_atf_batch_of_subjects_shares_the_atf_side(thin):
+    """BASELINE config 5's batch: HRTF subjects of ONE ATF set.  The batch computes the ATF side (spectra of the matched ATFs,
+    per-bin factors) once and sweeps all subjects in one resident launch; every subject equals its single design and the
+    oracle.  A batch whose plans hold different ATF sets is detected (device-side comparison) and runs unshared."""
+    from emagls_amd import Batch, synth
+    atf, aazi, azen = synth.glasses_atfs(natf=2048, nmics=8, taps=128)
+    subjects = [synth.rigid_sphere_hrirs(thin["azi"], thin["zen"], seed=40 + j, head_radius=0.075 + 0.005 * j) for j in range(4)]
+    singles = []
+    for hL, hR in subjects:
+        q = _atf_plan(thin, hL, hR, atf, aazi, azen)
+        q.execute()
+        singles.append(q.get_filters())
+        q.close()
+    plans = [_atf_plan(thin, hL, hR, atf, aazi, azen) for hL, hR in subjects]
+    b = Batch(plans)
+    first = None
+    for it in range(3):
+        b.execute()
+        res = b.get_filters()
+        assert b.shares_atf_side()
+        for (wL, wR), (sL, sR) in zip(res, singles):
+            assert rel(wL, sL) < 1e-12 and rel(wR, sR) < 1e-12, it
+        if first is None:
+            first = res
+        else:
+            for (wL, wR), (fL, fR) in zip(res, first):
+                assert np.array_equal(wL, fL) and np.array_equal(wR, fR), it
+    assert plans[0].info().num_sweep_launches == 1
+    hg, ag = np.column_stack([thin["azi"], thin["zen"]]), np.column_stack([aazi, azen])
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(subjects[3][0], subjects[3][1], hg, atf, ag, 48000.0, 256, 2000.0)
+    assert report("FromAtf batch, subject 3 L", res[3][0], oL) < TOL and report("R", res[3][1], oR) < TOL
+    # one subject gets another ATF set: no sharing any more, results still per plan
+    atf2 = atf * 1.0
+    atf2[:, 3, :] *= 0.5
+    plans[2].set_atfs(atf2, aazi, azen)
+    b.execute()
+    res2 = b.get_filters()
+    assert not b.shares_atf_side()
+    q = _atf_plan(thin, subjects[2][0], subjects[2][1], atf2, aazi, azen)
+    q.execute()
+    sL, sR = q.get_filters()
+    q.close()
+    assert rel(res2[2][0], sL) < 1e-12 and rel(res2[2][1], sR) < 1e-12
+    assert rel(res2[1][0], singles[1][0]) < 1e-12 and rel(res2[0][1], singles[0][1]) < 1e-12
+    b.close()
+    for p in plans:
+        p.close()
+
+
+def test_from_atf_ill_conditioned_atfs_take_the_dense_route(thin):
+    """Two nearly identical microphones: cond(atfsMatched(k,:,:)) ~ 1e5 at every bin, beyond what the Gram route is accurate for.
+    Its device-side check raises the status flag, the route's start moves behind the offending bins and the design is re-run on
+    the dense route (Householder QR + Jacobi SVD of the matched ATF matrix itself): still the oracle's filters."""
+    from emagls_amd import synth
+    atf, aazi, azen = synth.glasses_atfs(natf=2048, nmics=6, taps=128, noise=0.0)
+    rng = np.random.default_rng(3)
+    atf[:, 5, :] = atf[:, 4, :] + 1e-5 * rng.standard_normal(atf[:, 4, :].shape)
+    p = _atf_plan(thin, thin["hL"], thin["hR"], atf, aazi, azen)
+    p.execute()
+    wL, wR = p.get_filters()
+    i = p.info()
+    p.close()
+    assert i.gram_from != 1            # the route moved (0: every bin on the dense route)
+    hg, ag = np.column_stack([thin["azi"], thin["zen"]]), np.column_stack([aazi, azen])
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 256, 2000.0)
+    assert report("FromAtf ill-conditioned L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
 def test_binaural_decode(golden):
     import emagls_amd as E
     rng = np.random.default_rng(5)

@@ -113,15 +113,21 @@ def config4_rank_share(world=8, rank=5, reps=2):
             "ms_per_share": round(dt * 1e3, 3), "filter_sets_per_s": round(n / dt, 1)}
 
 
-def config5(reps=4):
-    from emagls_amd import Plan, synth, _lib as L
+def config5(reps=4, subjects=8):
+    """BASELINE config 5: one HRTF subject alone, and the batch of 8 subjects of one ATF set (ATF side computed once, one
+    resident sweep launch for all subjects)."""
+    from emagls_amd import Batch, Plan, synth, _lib as L
     azi, zen, _, _ = _grids()
-    hL, hR = synth.rigid_sphere_hrirs(azi, zen)
     atf, aazi, azen = synth.glasses_atfs(natf=16384, nmics=8, taps=256)
-    p = Plan(L.KIND_FROM_ATF, "real", 0, 48000.0, 2048, hL.shape[0], hL.shape[1], nmics=8, f_trans=2000.0, atf_taps=256, natf=16384)
-    p.set_hrir_grid(azi, zen)
-    p.set_hrirs(hL, hR)
-    p.set_atfs(atf, aazi, azen)
+
+    def mk(j):
+        hL, hR = synth.rigid_sphere_hrirs(azi, zen, seed=100 + j, head_radius=0.075 + 0.02 * j / max(subjects - 1, 1))
+        p = Plan(L.KIND_FROM_ATF, "real", 0, 48000.0, 2048, hL.shape[0], hL.shape[1], nmics=8, f_trans=2000.0, atf_taps=256, natf=16384)
+        p.set_hrir_grid(azi, zen)
+        p.set_hrirs(hL, hR)
+        p.set_atfs(atf, aazi, azen)
+        return p
+    p = mk(0)
     for _ in range(3):
         p.execute()
     p.synchronize()
@@ -131,8 +137,27 @@ def config5(reps=4):
         p.synchronize()
     dt = (time.perf_counter() - t0) / reps
     p.get_filters()
+    launches = p.info().num_sweep_launches
     p.close()
-    return {"atf_dirs": 16384, "mics": 8, "taps": 2048, "ms_per_subject": round(dt * 1e3, 3), "filter_sets_per_s": round(1.0 / dt, 1)}
+    out = {"atf_dirs": 16384, "mics": 8, "taps": 2048, "ms_per_subject": round(dt * 1e3, 3), "filter_sets_per_s": round(1.0 / dt, 1),
+           "sweep_launches": launches}
+    plans = [mk(j) for j in range(subjects)]
+    b = Batch(plans)
+    for _ in range(3):
+        b.execute()
+    b.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b.execute()
+        b.synchronize()
+    dtb = (time.perf_counter() - t0) / reps
+    b.get_filters()
+    out["batch"] = {"subjects": subjects, "atf_side_shared": b.shares_atf_side(), "ms_per_batch": round(dtb * 1e3, 3),
+                    "ms_per_subject": round(dtb * 1e3 / subjects, 3), "filter_sets_per_s": round(subjects / dtb, 1)}
+    b.close()
+    for q in plans:
+        q.close()
+    return out
 
 
 def binaural_decode(nsamp=120000, nch=25, length=512, reps=10):
