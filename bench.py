@@ -36,11 +36,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The HIP runtime multiplexes the streams of a process onto this many hardware queues (default 4), and work of two streams
-# that share a queue executes strictly in order -- a side stream of one batch would wait behind another batch's 2 ms sweep.
-# Four batches in flight x four streams each: every stream gets a queue of its own.  (Read by the runtime when it initialises,
-# i.e. before torch / the library touch the GPU; inherited by the ranks `--gpus N` spawns.)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# (measured, profiles/r03_*: more hardware queues than the runtime's default 4 -- GPU_MAX_HW_QUEUES=8 / 16 / 24 -- change nothing
+# up to 16 and cost 12-25 % at 24; forking a batch's stages before the sweep onto side streams (--fork 4) costs 13-20 % with
+# four batches in flight: the forks compete with the other batches' kernels and with the resident sweep for the same CUs)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 SLOTS, BSZ = 4, 8      # resident batches per GPU x designs per batch (a persistent sweep launch covers eight designs)
@@ -238,7 +236,7 @@ def main():
                     help="resident batches per GPU (profiling runs use 1)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", str(BSZ))),
                     help="designs per batch (<= 16; profiling runs use 1 for the single-design kernel times)")
-    ap.add_argument("--fork", type=int, default=int(os.environ.get("EMAGLS_BENCH_FORK", "4")),
+    ap.add_argument("--fork", type=int, default=int(os.environ.get("EMAGLS_BENCH_FORK", "1")),
                     help="streams the stages before a batch's sweep fork onto (1..4, emagls_batch_set_streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sh-roofline", action="store_true")

@@ -112,6 +112,7 @@ struct emagls_plan {
     uint64_t atf_side_version = 0;   // bumped when the grids or the ATF set are replaced (a FromAtf batch re-checks that its plans agree)
     bool diffuse = false;         // diffuseness (covariance) constraint after the sweep (render.hip: diffuse_constraint_kernel)
     bool custom_basis = false;    // the SH matrices come from the caller (a custom shFunction evaluated on the MATLAB side)
+    bool wide = false;            // LS / MagLS with 33..64 channels (SH orders 5..7): the plain path of wide.hip
     // profiling
     int prof_level = 0;
     std::vector<std::string> stage_names;
@@ -434,8 +435,12 @@ void plan_setup(emagls_plan& p) {
         p.S = d.kind == EMAGLS_KIND_MAGLS_2D ? 2 * N + 1 : (N + 1) * (N + 1);
         p.C = p.S;
         p.nOut = p.S;
-        if (p.S > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, d.kind == EMAGLS_KIND_MAGLS_2D ? "CH order above 15 is not supported in this build"
-                                                                                           : "SH order above 4 is not supported for LS/MagLS in this build");
+        // up to 32 channels: the tuned kernels (register tiles, the persistent sweep); 33..64 (SH orders 5..7): the plain path of
+        // wide.hip -- pinv(Y_conj) from the inverse of the Gram matrix, one sweep launch per bin
+        p.wide = p.S > 32;
+        if (p.S > 64) throw Error(EMAGLS_ERR_UNSUPPORTED, d.kind == EMAGLS_KIND_MAGLS_2D ? "CH order above 31 is not supported in this build"
+                                                                                           : "SH order above 7 is not supported for LS/MagLS in this build");
+        if (p.wide && p.diffuse) throw Error(EMAGLS_ERR_UNSUPPORTED, "the covariance constraint is available up to 32 channels");
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than SH channels");
     } else if (array_kind(d.kind)) {
         if (!(d.mic_radius > 0) || d.nmics < 1) throw Error(EMAGLS_ERR_ARG, "invalid array geometry");
@@ -462,7 +467,9 @@ void plan_setup(emagls_plan& p) {
     } else {
         if (d.nmics < 1 || d.natf < 1 || d.atf_taps < 1) throw Error(EMAGLS_ERR_ARG, "invalid ATF set");
         p.C = (int)d.nmics;
-        if (p.C > 8) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 8 ATF microphones is not supported in this build");
+        // up to 32 microphones on the Gram route (the M x M factors of the persistent sweep's form); the dense route behind its
+        // conditioning flag -- QR + Jacobi of the Dm x M matrix itself -- holds up to 8 columns at this row count (factor.hip)
+        if (p.C > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 ATF microphones is not supported in this build");
         p.hrir_smaller = d.ndirs <= d.natf;  // min([a b]) returns the first index on ties (FromAtf.m:62)
         p.Dm = p.hrir_smaller ? d.ndirs : d.natf;
         if (p.Dm > 4096) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 4096 matched directions is not supported in this build");
@@ -492,6 +499,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("R2w", sizeof(cplx) * (size_t)p.C * p.C);
         p.alloc("Nw", sizeof(cplx) * (size_t)p.C * p.C);
         p.alloc("Ypinv", esz(cb) * (size_t)p.C * p.ldD);
+        if (p.wide) p.alloc("Mg", sizeof(cplx) * (size_t)p.S * p.S);   // (Y^T conj(Y))^-1
         if (d.kind == EMAGLS_KIND_LS) {
             p.out_rows = d.nsamp;
         } else {
@@ -602,7 +610,7 @@ void plan_setup(emagls_plan& p) {
         if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) p.sweep_persist = e[0] != '0';
         // the persistent sweep keeps one workgroup per CU resident (142 KB of LDS each): it needs the shape to fit one XCD's
         // 32 CUs per design AND that many CUs on this device (a partitioned or CU-masked GPU takes the launch-per-bin form)
-        if (!persist_sweep_supported((int)Dh, p.C) ||
+        if (p.wide || !persist_sweep_supported((int)Dh, p.C) ||
             persist_sweep_nwg((int)Dh) > device_cu_count())
             p.sweep_persist = false;
         if (magls_kind(d.kind) && p.sweep_persist) {
@@ -641,6 +649,7 @@ void stage_hrir_basis(emagls_plan& p) {
     p.mark("gram_mfma");
     launch_cholesky(p.get("R"), p.S, cb, p.get<int>("flag"), st);
     p.mark("cholesky");
+    if (p.wide) return;   // (no orthonormal factor: pinv(Y_conj) = Y conj((Y^T conj(Y))^-1), run_pinv_of_R)
     launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, cb, p.get("Q"), st);
     p.mark("qform");
 }
@@ -675,6 +684,12 @@ void run_pinv_of_R(emagls_plan& p) {
     // pinv(Y_conj) = conj(Q) Z_B, Z_B from the SVD of B = R with MATLAB's pinv tolerance
     hipStream_t st = p.stream;
     const bool cb = p.cplx_basis;
+    if (p.wide) {   // 33..64 channels: the inverse of the Gram matrix, certified well conditioned on the device (wide.hip)
+        launch_gram_inverse(p.get("R"), p.S, cb, p.get("Mg"), p.get<int>("flag"), st);
+        launch_ypinv_gram(p.get("Ycm"), p.ldD, cb, p.get("Mg"), p.S, (int)p.D, p.get("Ypinv"), st);
+        p.mark("pinv");
+        return;
+    }
     launch_widen(p.get("R"), p.S, cb, p.get("Rb"), p.ldS, p.C, p.S, /*transpose=*/true, /*upper_only=*/true, st);
     FactorArgs a{};
     a.S = p.S; a.C = p.C; a.ldS = p.ldS; a.kb0 = 0; a.P = 2;  // P=2: bin 0 is not a Nyquist bin
@@ -745,11 +760,14 @@ void execute_magls(emagls_plan& p) {
     p.sweep_launches = 0;
     for (int kb = p.kcut0; kb < p.P; ++kb) {
         if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches);
-        launch_sweep_dense(a, kb, cb, st);
+        if (p.wide) launch_sweep_wide(a, kb, cb, st); else launch_sweep_dense(a, kb, cb, st);
         if (p.prof_level >= 2) record_sweep_event(p, 2 * (size_t)p.sweep_launches + 1);
         ++p.sweep_launches;
     }
-    if (p.kcut0 < p.P) launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
+    if (p.kcut0 < p.P) {
+        if (p.wide) launch_sweep_wide_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
+        else launch_sweep_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
+    }
     p.mark("magls_sweep");
     magls_post_sweep(p);
 }
@@ -1587,7 +1605,8 @@ void drop_batch_graphs(emagls_batch& b) {
 }
 // Device-side status words of a design: [0] Cholesky pivot, [1] persistent sweep gave up waiting, [2] a Gram-route bin was
 // worse conditioned than the kr estimate promised ([3] = the highest such bin), [4] MagLS: the SH basis is too ill-conditioned
-// for the inverse form M = R^-1 R^-H of the persistent sweep (the reference's pinv would drop singular values).
+// for the inverse form M = R^-1 R^-H of the persistent sweep (the reference's pinv would drop singular values), [5] LS / MagLS
+// above 32 channels: basis too ill-conditioned for the Gram-inverse form of pinv (fatal: no SVD route at that width).
 // [1], [2] and [4] are recoverable: the design is re-run without the feature.  [1] and [2] stick to the plan (a residency or
 // conditioning property of the shape); [4] is a property of THIS call's grid, so the launch-per-bin sweep only serves the
 // re-run and a cached plan tries the persistent form again on its next call.
@@ -1599,6 +1618,9 @@ bool plan_recover(emagls_plan& p, const int* flag, bool apply) {
         // Householder route then covers more bins and, at their higher kr, more orders: plan_routes refuses beyond its tile)
         if (p.gram_from == 0 || flag[3] < p.gram_from)
             throw Error(EMAGLS_ERR_NUMERIC, "internal: Gram-route conditioning flag outside the route (stale graph)");
+        if (p.d.kind == EMAGLS_KIND_FROM_ATF && p.C > 8)
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "the ATF matrices of some bins are too ill-conditioned for the Gram route (cond > 3e4) and the "
+                                                "dense route holds at most 8 microphones in this build");
         if (apply && p.d.kind == EMAGLS_KIND_FROM_ATF) {
             // measured ATFs: the bins up to the offending one take the dense route (QR + Jacobi of the matched ATF matrix itself)
             p.gram_from = flag[3] + 1 < p.P ? flag[3] + 1 : 0;
@@ -1627,6 +1649,9 @@ bool plan_recover(emagls_plan& p, const int* flag, bool apply) {
 void throw_fatal_flags(const int* flag) {
     if (flag[1]) throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");
     if (flag[2]) throw Error(EMAGLS_ERR_NUMERIC, "per-bin factorisation: ill-conditioned bin on the Gram route after the re-run");
+    if (flag[5])
+        throw Error(EMAGLS_ERR_UNSUPPORTED, "the SH basis of this order is too ill-conditioned on the HRIR grid for the 33..64-channel path "
+                                            "(cond > 1e4: pinv would need the SVD route, which stops at 32 channels in this build)");
     if (flag[0])
         throw Error(EMAGLS_ERR_NUMERIC,
                     "SH Gram matrix of the HRIR grid is not positive definite (the grid cannot resolve the required SH order)");

@@ -105,6 +105,12 @@ void launch_sh_rows_to_complex(void* W, int C, int nrows, int order, hipStream_t
 void launch_widen(const void* in, int64_t ldi, bool in_cplx, void* out, int64_t ldo, int rows, int cols, bool transpose,
                   bool upper_only, hipStream_t st);
 
+// ---- wide.hip: LS / MagLS above 32 channels (SH orders 5..7)
+void launch_gram_inverse(const void* R, int S, bool is_cplx, void* M, int* status, hipStream_t st);
+void launch_ypinv_gram(const void* Ycm, int64_t ldD, bool is_cplx, const void* M, int S, int D, void* Ypinv, hipStream_t st);
+void launch_sweep_wide(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st);
+void launch_sweep_wide_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
+
 // ---- dspace.hip
 void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
                int64_t ldD, hipStream_t st);

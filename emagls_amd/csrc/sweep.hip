@@ -473,8 +473,8 @@ __global__ void __launch_bounds__(256) ls_apply_kernel(const cplx* __restrict__ 
     const int kb = blockIdx.x, e = blockIdx.y;
     const int tid = threadIdx.x;
     const cplx* h = Hc + ((int64_t)e * n_c + kb) * ldH;
-    const int pair = tid >> 3, part = tid & 7;  // 32 channels x 8 lanes
-    if (pair < C) {
+    const int part = tid & 7;  // 32 channels x 8 lanes per pass
+    for (int pair = tid >> 3; pair < C; pair += 32) {
         cplx acc = mk(0, 0);
         for (int d = part; d < D; d += 8) cfma(acc, h[d], Zf[(int64_t)pair * ldD + d]);
         acc = group_sum<8>(acc);

@@ -1,0 +1,166 @@
+// LS / MagLS above 32 channels (SH orders 5..7, up to 64 channels): a plain path for the shapes the tuned kernels (32-channel
+// register tiles, 32-row LDS slabs) do not cover.  lib/getMagLsFilters.m:45-48 takes any order; order 5-7 decoders are
+// ordinary use.
+//
+//   pinv(Y_conj) = Y conj(M),  M = (Y^T conj(Y))^-1 = R^-1 R^-H  from the Cholesky factor R of the Gram matrix -- valid where
+//   MATLAB's pinv drops no singular value (tolerance max(size) eps(norm)); the kernel certifies cond(Gy) <= ||Gy||_F ||M||_F
+//   < 1e8 (cond(Y) < 1e4: relative error eps cond(Y)^2 < 2e-8) and raises status word 5 otherwise;
+//   the sweep (lib/getMagLsFilters.m:64-72) as one launch per bin: a workgroup sums the partial sums of the previous bin,
+//   forms p and t = |H| p / |p| for its 64 directions and its partial sums of t pinv(Y_conj).
+#include "kernels.hpp"
+
+namespace emagls {
+
+namespace {
+
+constexpr int WD_SMAX = 64;
+
+// M = R^-1 R^-H for upper-triangular R (S x S, row major), as complex [S][S]; status[5] = 1 when the certificate fails
+template <typename T>
+__global__ void __launch_bounds__(256) gram_inverse_kernel(const T* __restrict__ R, int S, cplx* __restrict__ M, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* Ri = reinterpret_cast<cplx*>(dyn);            // [S][S + 1]  R^-1 (upper triangular)
+    __shared__ double red[256];
+    const int tid = threadIdx.x, ld = S + 1;
+    for (int idx = tid; idx < S * ld; idx += 256) Ri[idx] = mk(0.0, 0.0);
+    __syncthreads();
+    if (tid < S) {   // column j of the inverse by back substitution:  sum_k R[i][k] X[k][j] = delta_ij
+        const int j = tid;
+        for (int i = j; i >= 0; --i) {
+            cplx acc = mk(i == j ? 1.0 : 0.0, 0.0);
+            for (int k = i + 1; k <= j; ++k) { cplx t = mk(0.0, 0.0); cfma(t, to_cplx(R[(size_t)i * S + k]), Ri[k * ld + j]); acc = acc - t; }
+            Ri[i * ld + j] = cdiv(acc, to_cplx(R[(size_t)i * S + i]));
+        }
+    }
+    __syncthreads();
+    double fm = 0.0, fg = 0.0;
+    for (int idx = tid; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx % S;
+        cplx acc = mk(0.0, 0.0), g = mk(0.0, 0.0);
+        for (int k = (i > j ? i : j); k < S; ++k) cfma(acc, Ri[i * ld + k], conj(Ri[j * ld + k]));
+        for (int k = 0; k <= (i < j ? i : j); ++k) cfma_conj(g, to_cplx(R[(size_t)k * S + i]), to_cplx(R[(size_t)k * S + j]));   // Gy = R^H R
+        M[idx] = acc;
+        fm += norm2(acc); fg += norm2(g);
+    }
+    red[tid] = fm; __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
+    fm = red[0]; __syncthreads();
+    red[tid] = fg; __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
+    fg = red[0];
+    if (tid == 0 && !(fm * fg < 1e16)) atomicExch(status + 5, 1);   // (||Gy||_F ||M||_F)^2 >= (1e8)^2, or not finite
+}
+
+// Ypinv[c][d] = sum_s Ycm[s][d] conj(M[s][c])
+template <typename T>
+__global__ void __launch_bounds__(256) ypinv_gram_kernel(const T* __restrict__ Ycm, int64_t ldD, const cplx* __restrict__ M, int S, int D,
+                                                         T* __restrict__ Ypinv) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (d >= D) return;
+    cplx acc = mk(0.0, 0.0);
+    for (int s = 0; s < S; ++s) cfma(acc, to_cplx(Ycm[(int64_t)s * ldD + d]), conj(M[(size_t)s * S + c]));
+    if constexpr (sizeof(T) == sizeof(double)) Ypinv[(int64_t)c * ldD + d] = acc.x; else Ypinv[(int64_t)c * ldD + d] = acc;
+}
+
+// one bin of the sweep: X = Y_conj [c][ldD], Z = pinv(Y_conj) [c][ldD] (both fixed over the bins), 64 directions per workgroup
+template <typename TX>
+__global__ void __launch_bounds__(256) sweep_wide_kernel(DenseSweepArgs a, int kb) {
+    __shared__ __attribute__((aligned(16))) cplx Wp[2][WD_SMAX];
+    __shared__ __attribute__((aligned(16))) cplx ts[2][64];
+    const int C = a.C, nWG = a.nWG, tid = threadIdx.x;
+    const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * nWG * 2 * C;
+    cplx* Wout = a.Wpart + (int64_t)(kb & 1) * nWG * 2 * C;
+    const TX* X = reinterpret_cast<const TX*>(a.X);
+    const TX* Z = reinterpret_cast<const TX*>(a.Zd);
+    const int64_t d0 = (int64_t)blockIdx.x * 64, na = a.P - a.kabs0;
+    const bool first = kb == a.kfirst;
+    // ---- W(kb-1,:): the least-squares row for the first swept bin, the sum of the workgroups' partial sums afterwards
+    for (int pair = tid >> 1; pair < 2 * C; pair += 128) {
+        const int e = pair / C, c = pair % C, half = tid & 1;
+        cplx acc = mk(0.0, 0.0);
+        if (first) { if (half == 0) acc = a.W[((int64_t)e * a.P + (kb - 1)) * C + c]; }
+        else for (int w = half; w < nWG; w += 2) acc += Wprev[(int64_t)pair * nWG + w];
+        acc = group_sum<2>(acc);
+        if (half == 0) {
+            Wp[e][c] = acc;
+            if (blockIdx.x == 0 && !first) a.W[((int64_t)e * a.P + (kb - 1)) * C + c] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- p = W(kb-1,:) Y_conj, t = |H| exp(i angle(p)) (Nyquist: real part)
+    {
+        const int dd = tid & 63, e = (tid >> 6) & 1, half = tid >> 7;
+        const int64_t d = d0 + dd;
+        cplx p = mk(0.0, 0.0);
+        if (d < a.D) for (int c = half; c < C; c += 2) cfma(p, Wp[e][c], to_cplx(X[(int64_t)c * a.ldD + d]));
+        if (half == 1) ts[e][dd] = p;
+        __syncthreads();
+        cplx t = mk(0.0, 0.0);
+        if (half == 0) {
+            p += ts[e][dd];
+            if (d < a.D) {
+                const double h = a.Habs[((int64_t)e * na + (kb - a.kabs0)) * a.ldH + d];
+                const double a2 = norm2(p);
+                t = mk(h, 0.0);                                   // angle(0) = 0
+                if (a2 > 0.0) { const double ia = h / sqrt(a2); t = mk(p.x * ia, p.y * ia); }
+                if (kb == a.P - 1) t.y = 0.0;
+            }
+        }
+        __syncthreads();   // (every wave has read the half sums)
+        if (half == 0) ts[e][dd] = t;
+    }
+    __syncthreads();
+    // ---- this workgroup's partial sums of t pinv(Y_conj)
+    for (int pair = tid >> 1; pair < 2 * C; pair += 128) {
+        const int e = pair / C, c = pair % C, half = tid & 1;
+        cplx acc = mk(0.0, 0.0);
+        for (int dd = half; dd < 64; dd += 2)
+            if (d0 + dd < a.D) cfma(acc, ts[e][dd], to_cplx(Z[(int64_t)c * a.ldD + d0 + dd]));
+        acc = group_sum<2>(acc);
+        if (half == 0) Wout[(int64_t)pair * nWG + blockIdx.x] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) sweep_wide_finalize_kernel(const cplx* __restrict__ Wpart, cplx* __restrict__ W, int nWG, int C, int P,
+                                                                  int kb_last) {
+    const cplx* Wprev = Wpart + (int64_t)(kb_last & 1) * nWG * 2 * C;
+    for (int pair = threadIdx.x; pair < 2 * C; pair += 256) {
+        cplx acc = mk(0.0, 0.0);
+        for (int w = 0; w < nWG; ++w) acc += Wprev[(int64_t)pair * nWG + w];
+        W[((int64_t)(pair / C) * P + kb_last) * C + pair % C] = acc;
+    }
+}
+
+}  // namespace
+
+void launch_gram_inverse(const void* R, int S, bool is_cplx, void* M, int* status, hipStream_t st) {
+    if (S > WD_SMAX) throw Error(2, "more than 64 channels is not supported");
+    const size_t dyn = sizeof(cplx) * (size_t)S * (S + 1);
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gram_inverse_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gram_inverse_kernel<cplx>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    }
+    if (is_cplx) gram_inverse_kernel<cplx><<<1, 256, dyn, st>>>((const cplx*)R, S, (cplx*)M, status);
+    else gram_inverse_kernel<double><<<1, 256, dyn, st>>>((const double*)R, S, (cplx*)M, status);
+    KERNEL_CHECK();
+}
+void launch_ypinv_gram(const void* Ycm, int64_t ldD, bool is_cplx, const void* M, int S, int D, void* Ypinv, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(D, 256), S);
+    if (is_cplx) ypinv_gram_kernel<cplx><<<grid, 256, 0, st>>>((const cplx*)Ycm, ldD, (const cplx*)M, S, D, (cplx*)Ypinv);
+    else ypinv_gram_kernel<double><<<grid, 256, 0, st>>>((const double*)Ycm, ldD, (const cplx*)M, S, D, (double*)Ypinv);
+    KERNEL_CHECK();
+}
+void launch_sweep_wide(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st) {
+    if (a.C > WD_SMAX) throw Error(2, "wide sweep: more than 64 channels");
+    if (x_cplx) sweep_wide_kernel<cplx><<<a.nWG, 256, 0, st>>>(a, kb);
+    else sweep_wide_kernel<double><<<a.nWG, 256, 0, st>>>(a, kb);
+    KERNEL_CHECK();
+}
+void launch_sweep_wide_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st) {
+    sweep_wide_finalize_kernel<<<1, 256, 0, st>>>((const cplx*)Wpart, (cplx*)W, nWG, C, P, kb_last);
+    KERNEL_CHECK();
+}
+
+}  // namespace emagls

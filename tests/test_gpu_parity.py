@@ -61,6 +61,39 @@ def test_magls_filters_config2(grids, hrirs, basis):
     assert report("MagLS L " + basis, wL, oL) < TOL and report("MagLS R " + basis, wR, oR) < TOL
 
 
+@pytest.mark.parametrize("order,basis", [(5, "real"), (7, "real"), (6, "complex"), (7, "complex")])
+def test_ls_and_magls_orders_5_to_7(grids, hrirs, order, basis):
+    """SH orders above 4 (lib/getMagLsFilters.m:45-48 takes any order; 36..64 channels): the plain path for more than 32
+    channels -- pinv(Y_conj) from the inverse of the SH Gram matrix (the 2702-point grid is well conditioned up to order 7 and
+    far beyond: certified on the device), one sweep launch per bin -- against the oracle at full size."""
+    import emagls_amd as E
+    C = (order + 1) ** 2
+    wL, wR = E.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, basis)
+    oL, oR = O.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, basis)
+    assert wL.shape == (128, C) and wL.dtype == oL.dtype
+    assert report(f"LS order {order} {basis} L", wL, oL) < 1e-11 and report("R", wR, oR) < 1e-11
+    wL, wR = E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, 48000.0, 256, basis)
+    oL, oR = O.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, 48000.0, 256, basis)
+    assert wL.shape == (256, C) and wL.dtype == oL.dtype
+    assert report(f"MagLS order {order} {basis} L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
+def test_wide_orders_refuse_what_they_cannot_do(grids, hrirs, thin):
+    import emagls_amd as E
+    from emagls_amd._lib import EmaglsError
+    with pytest.raises(EmaglsError, match="order above 7"):
+        E.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 8, "real")
+    with pytest.raises(EmaglsError, match="covariance constraint"):
+        E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 6, 48000.0, 256, "real", applyDiffusenessConst=True)
+    # an order the grid cannot resolve well: 49 SH channels on 60 directions of a polar cap -> the certificate (or the Cholesky
+    # pivot) refuses instead of returning garbage
+    from emagls_amd import synth
+    azi, zen = synth.fibonacci_grid(60)
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen * 0.3, taps=32)
+    with pytest.raises(EmaglsError):
+        E.getLsFilters(hL, hR, azi, zen * 0.3, 6, "real")
+
+
 def test_magls_filters_config2_with_the_covariance_constraint(grids, hrirs):
     """BASELINE config 2 as named -- getMagLsFilters N=4, full L2702 grid, 512 taps, covariance constraint ON -- at full size
     against the oracle's specification of the constraint (the Hermitian positive definite 2x2 ear mixing with M Rhat M = R;
@@ -618,6 +651,18 @@ def test_from_atf_batch_of_subjects_shares_the_atf_side(thin):
     b.close()
     for p in plans:
         p.close()
+
+
+def test_from_atf_sixteen_microphones(thin):
+    """More than 8 ATF microphones (lib/getEMagLsFiltersFromAtf.m:40 takes any count): the Gram route carries up to 32."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    atf, aazi, azen = synth.glasses_atfs(natf=2048, nmics=16, taps=128)
+    hg, ag = np.column_stack([thin["azi"], thin["zen"]]), np.column_stack([aazi, azen])
+    wL, wR = E.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 256, 2000.0, verbose=False)
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 256, 2000.0)
+    assert wL.shape == (256, 16)
+    assert report("FromAtf 16 mics L", wL, oL) < TOL and report("R", wR, oR) < TOL
 
 
 def test_from_atf_ill_conditioned_atfs_take_the_dense_route(thin):

@@ -112,7 +112,8 @@ def horizontal_hrirs():
     return hL, hR, azi
 
 
-@pytest.mark.parametrize("basis,order,length", [("real", 4, 256), ("complex", 4, 256), ("real", 7, 512), ("complex", 15, 128)])
+@pytest.mark.parametrize("basis,order,length", [("real", 4, 256), ("complex", 4, 256), ("real", 7, 512), ("complex", 15, 128),
+                                                ("real", 20, 128), ("complex", 24, 128)])   # (orders above 15: more than 32 channels, wide.hip)
 def test_magls_filters_2d(horizontal_hrirs, basis, order, length):
     import emagls_amd as E
     hL, hR, azi = horizontal_hrirs
@@ -131,8 +132,8 @@ def test_magls_filters_2d_errors(horizontal_hrirs):
     hL, hR, azi = horizontal_hrirs
     with pytest.raises(EmaglsError, match="HRIR len too short"):       # getMagLsFilters2D.m:38
         E.getMagLsFilters2D(hL, hR, azi, 4, 48000.0, 64)
-    with pytest.raises(EmaglsError, match="order above 15"):
-        E.getMagLsFilters2D(hL, hR, azi, 16, 48000.0, 256)
+    with pytest.raises(EmaglsError, match="order above 31"):
+        E.getMagLsFilters2D(hL, hR, azi, 32, 48000.0, 256)
 
 
 @pytest.mark.parametrize("radius,order,fs,length", [(0.042, 4, 48000.0, 512), (0.0875, 3, 44100.0, 256), (0.042, 1, 48000.0, 2048)])
@@ -222,7 +223,7 @@ def test_get_smair_matrix(grids, basis, raw):
     """The array model the filter designs only use in factored form, materialised (getSMAIRMatrix.m:110-127): against the
     oracle's restatement, including the real(b_n) rule of the last bin."""
     import emagls_amd as E
-    params = dict(order=4, fs=48000.0, irLen=256, oversamplingFactor=1, smaRadius=grids["mic_radius"],
+    params = dict(order=4, fs=48000.0, irLen=256, oversamplingFactor=1, smaRadius=grids["mic_radius"], radialFilter="none",
                   smaDesignAziZenRad=np.column_stack([grids["mic_azi"], grids["mic_zen"]]), shDefinition=basis, returnRawMicSigs=raw)
     sm, p = E.getSMAIRMatrix(params)
     so, simOrder = O.getSMAIRMatrix(4, 48000.0, 256, grids["mic_radius"], params["smaDesignAziZenRad"], basis, returnRawMicSigs=raw)
