@@ -129,8 +129,13 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     double* hs_all = reinterpret_cast<double*>(ms + (size_t)PS_CMAX * PS_MLD);  // [2][2][DPW]  |H_kb| (two buffers: 3 KB)
     // up to 8 designs: block b serves design b & 7 (the dispatcher is observed to place block b on XCD b % 8: one design per
     // XCD); 9 to 16 designs: designs j and j + 8 share XCD j, two workgroups per CU
+    // Design-major within an XCD: the nWG blocks of design j come before those of design j + 8.  Workgroups are placed in block
+    // order; when other kernels hold part of the CUs and only some of an XCD's 2 nWG blocks find room, the resident ones then
+    // always include a COMPLETE design, which runs, finishes and makes room for the other.  (Interleaved, half of each design
+    // could become resident and both would wait for peers that the other's workgroups keep out: the stall-until-time-out that
+    // kept batches above 8 designs opt-in in round 2.)
     const int two = m.n > 8 ? 1 : 0, rest = blockIdx.x >> 3;
-    const int design = (blockIdx.x & 7) + 8 * (two ? (rest & 1) : 0), member = two ? (rest >> 1) : rest;
+    const int design = (blockIdx.x & 7) + 8 * ((two && rest >= nWG) ? 1 : 0), member = (two && rest >= nWG) ? rest - nWG : rest;
     if (design >= m.n || member >= nWG) return;
     const HalfSweepArgs& a = m.a[design];
     if (a.skip_flag && __hip_atomic_load(a.skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // (uniform per design)

@@ -565,3 +565,33 @@ def test_diffuseness_constraint_restores_the_hrtf_covariance(grids, hrirs):
         assert np.abs(after - R).max() < 1e-9 * np.abs(R).max()
         if k >= 40:
             assert np.abs(before - R).max() > 1e-3 * np.abs(R).max()
+
+
+def test_sh_rotation_closed_forms():
+    """Independent checks of the un-vendored SH rotation that EMAinSH applies per direction: (1) the order-1 block of
+    the rotation matrix in closed form -- real SHs of order 1 are k (y, z, x) in ACN order, so Y_1(R^-1 x) = [P R^T P^T] Y_1(x)
+    with the permutation P: (x, y, z) -> (y, z, x); (2) orthogonality of every order block; (3) what the rotation is FOR
+    (lib/getEMagLsFiltersEMAinSH.m:92-98): the SH coefficient row of a plane wave from (azi, pi/2) becomes the row of a plane
+    wave from (azi, zen) -- elevated, not lowered (the direction the 2023-03-31 changelog entry says was inverted before)."""
+    import math
+    for azi, zen in ((0.3, 0.9), (2.1, 2.2), (-1.0, 0.4)):
+        D = O.shRotationForElevation(azi, zen, 3, "real")
+        alpha = math.pi / 2 - zen
+        ax = np.array([math.sin(azi), -math.cos(azi), 0.0])
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + math.sin(alpha) * K + (1 - math.cos(alpha)) * (K @ K)
+        # R lifts the horizontal direction of azimuth azi to the zenith angle zen
+        u0 = np.array([math.cos(azi), math.sin(azi), 0.0])
+        u1 = np.array([math.sin(zen) * math.cos(azi), math.sin(zen) * math.sin(azi), math.cos(zen)])
+        assert np.abs(R @ u0 - u1).max() < 1e-14
+        P = np.array([[0, 1, 0], [0, 0, 1], [1, 0, 0]], float)            # (x, y, z) -> (y, z, x)
+        assert np.abs(D[1:4, 1:4] - P @ R.T @ P.T).max() < 1e-12          # (1)
+        assert abs(D[0, 0] - 1) < 1e-12
+        for n in range(4):                                                # (2) block diagonal and orthogonal
+            b = slice(n * n, (n + 1) ** 2)
+            assert np.abs(D[b, b] @ D[b, b].T - np.eye(2 * n + 1)).max() < 1e-12
+            off = D[b].copy(); off[:, b] = 0
+            assert np.abs(off).max() < 1e-12
+        y_hor = O.getSH(3, np.array([[azi, math.pi / 2]]), "real")[0]     # (3) plane-wave coefficient rows (real SH: Y itself)
+        y_el = O.getSH(3, np.array([[azi, zen]]), "real")[0]
+        assert np.abs(y_hor @ D - y_el).max() < 1e-12
