@@ -7,20 +7,21 @@ namespace emagls {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// every wave: `iters` rounds of 8 independent accumulator tiles (8 x 2048 flop per round)
+// every wave: `iters` rounds of NACC independent accumulator tiles (NACC x 2048 flop per round)
+template <int NACC>
 __global__ void __launch_bounds__(256) mfma_f64_peak_kernel(int iters, double* __restrict__ sink) {
     const long long c0 = clock64(), w0 = wall_clock64();
-    double4_t acc[8];
+    double4_t acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < NACC; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
     const double a = 1.0 + 1e-9 * (double)(threadIdx.x & 63), b = 1.0 - 1e-9 * (double)(threadIdx.x & 15);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) sink[0] = s;   // keeps the loop alive; never true
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // shader cycles and 100 MHz wall ticks of this wave: the clock the loop ran at
         sink[1] = (double)(clock64() - c0);
@@ -61,26 +62,36 @@ double measure_fp64_peak(int which, int reps, bool burst, double* mhz) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
-    const int blocks = cus * 8;          // 8 x 4 waves per CU: two waves per SIMD cover the dependent-issue latency
-    const int iters = (which == 0 ? 4096 : 16384) / (burst ? 16 : 1);
-    const double flop = which == 0 ? (double)blocks * 4 * iters * 8 * 2048.0 : (double)blocks * 256 * iters * 16 * 2.0;
+    // shapes tried (the best counts): workgroups of 4 waves per CU x independent accumulator tiles per wave (MFMA), 8 per CU (FMA)
+    const int shapes[][2] = {{8, 8}, {4, 8}, {8, 4}, {4, 16}, {2, 16}, {8, 16}};
+    const int nshapes = which == 0 ? 6 : 1;
     double best = 0.0;
-    for (int r = 0; r < reps + 1; ++r) {
-        HIP_CHECK(hipEventRecord(e0, nullptr));
-        if (which == 0) mfma_f64_peak_kernel<<<blocks, 256, 0, nullptr>>>(iters, sink);
-        else fma_f64_peak_kernel<<<blocks, 256, 0, nullptr>>>(iters, sink);
-        HIP_CHECK(hipEventRecord(e1, nullptr));
-        HIP_CHECK(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        if (r > 0 && ms > 0.f) {   // (first launch: module load)
-            const double tf = flop / (ms * 1e-3) / 1e12;
-            if (tf > best) {
-                best = tf;
-                if (mhz) {
-                    double h[3] = {0, 0, 0};
-                    HIP_CHECK(hipMemcpy(h, sink, sizeof h, hipMemcpyDeviceToHost));
-                    *mhz = h[2] > 0 ? h[1] / (h[2] * 0.01) : 0.0;
+    for (int sh = 0; sh < nshapes; ++sh) {
+        const int blocks = cus * shapes[sh][0], nacc = shapes[sh][1];
+        const int iters = (which == 0 ? 4096 * 8 / nacc * 8 / shapes[sh][0] : 16384) / (burst ? 16 : 1);
+        const double flop = which == 0 ? (double)blocks * 4 * iters * nacc * 2048.0 : (double)blocks * 256 * iters * 16 * 2.0;
+        for (int r = 0; r < reps + 1; ++r) {
+            HIP_CHECK(hipEventRecord(e0, nullptr));
+            if (which == 0) {
+                if (nacc == 4) mfma_f64_peak_kernel<4><<<blocks, 256, 0, nullptr>>>(iters, sink);
+                else if (nacc == 8) mfma_f64_peak_kernel<8><<<blocks, 256, 0, nullptr>>>(iters, sink);
+                else mfma_f64_peak_kernel<16><<<blocks, 256, 0, nullptr>>>(iters, sink);
+            } else {
+                fma_f64_peak_kernel<<<blocks, 256, 0, nullptr>>>(iters, sink);
+            }
+            HIP_CHECK(hipEventRecord(e1, nullptr));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0 && ms > 0.f) {   // (first launch: module load)
+                const double tf = flop / (ms * 1e-3) / 1e12;
+                if (tf > best) {
+                    best = tf;
+                    if (mhz) {
+                        double h[3] = {0, 0, 0};
+                        HIP_CHECK(hipMemcpy(h, sink, sizeof h, hipMemcpyDeviceToHost));
+                        *mhz = h[2] > 0 ? h[1] / (h[2] * 0.01) : 0.0;
+                    }
                 }
             }
         }
