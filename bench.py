@@ -15,8 +15,8 @@ under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WO
 one of the ranks.  A rank that does not find its GPU fails loudly.
 
 Protocol: SETUP builds the resident configuration, which does not depend on --steps: four batches of
-eight designs per GPU (eight designs share every launch of the pipeline, the sweep runs one design
-per XCD), each executed three times (eager, hipGraph capture, first replay).  Then exactly W warm-up
+sixteen designs per GPU (the designs of a batch share every launch of the pipeline, the sweep runs two
+designs per XCD), each executed three times (eager, hipGraph capture, first replay).  Then exactly W warm-up
 designs and exactly K timed designs are run through those batches (a last partial batch has its own
 smaller batch object), with a barrier + device synchronisation on both sides of the timed region.
 
@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 # four batches in flight: the forks compete with the other batches' kernels and with the resident sweep for the same CUs)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-SLOTS, BSZ = 4, 8      # resident batches per GPU x designs per batch (a persistent sweep launch covers eight designs)
+SLOTS, BSZ = 4, 16     # resident batches per GPU x designs per batch (a persistent sweep launch covers 16 designs, two per XCD)
 
 
 # --------------------------------------------------------------------------------------------
@@ -273,6 +273,8 @@ def main():
     from emagls_amd import Batch, Plan, _lib as L
     lib = L.load()
     L.check(lib.emagls_set_device(local_rank))
+    if args.batch > 8:   # 9..16 designs per batch: two designs per XCD in the resident sweep (the library's default limit is 8)
+        L.check(lib.emagls_set_batch_max(args.batch, None))
     K, W = args.steps, args.warmup
     nslots, Bsz = args.slots, args.batch
     # The HIP runtime multiplexes every stream of the process onto 4 hardware queues, and two batches whose streams share a
@@ -452,7 +454,7 @@ def main():
             designs_per_launch = 1
             avg_s = single_s
             if persistent and batch_sweep_ms and Bsz > 1:
-                # the timed region launches the kernel once per batch of Bsz designs (design j on XCD j)
+                # the timed region launches the kernel once per batch of Bsz designs (designs j and j + 8 on XCD j)
                 designs_per_launch = Bsz
                 avg_s = sum(batch_sweep_ms) / len(batch_sweep_ms) * 1e-3
                 bytes_launch *= Bsz

@@ -2,6 +2,7 @@
 // The host code only sequences launches and derives scalar constants (nfft, k_cut, simulation
 // order: lib/getEMagLsFilters.m:44-48, dependencies/getSMAIRMatrix.m:95); all array arithmetic runs
 // in the HIP kernels.  There is no CPU fallback: without a GPU every entry point returns an error.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -1953,6 +1954,10 @@ int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR,
 
 }  // namespace
 
+// designs per batch: 8 by default (one per XCD in the resident sweep), up to 16 (two per XCD) after emagls_set_batch_max / EMAGLS_BATCH_MAX
+namespace {
+std::atomic<int> g_batch_max{[] { const char* e = getenv("EMAGLS_BATCH_MAX"); return e ? std::max(1, std::min(SWEEP_MULTI_MAX, atoi(e))) : 8; }()};
+}
 // work planes of the complex device-resident decode, grown on demand and kept (released by emagls_cache_clear)
 namespace {
 struct DecodeScratch {
@@ -2311,10 +2316,10 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         // (e.g. factor_qr: 1024 threads x 128 registers) makes the dispatcher hold back the sweep's remaining workgroups
         // while the resident ones wait for them -- observed as a 0.4 s stall until the sweep's own time-out falls back to the
         // launch-per-bin form.  Hence opt-in: EMAGLS_BATCH_MAX=16.
-        static const int batch_max = [] { const char* e = getenv("EMAGLS_BATCH_MAX"); return e ? std::max(1, std::min(SWEEP_MULTI_MAX, atoi(e))) : 8; }();
+        const int batch_max = g_batch_max.load();
         if (nplans > batch_max)
             throw Error(EMAGLS_ERR_UNSUPPORTED, batch_max >= SWEEP_MULTI_MAX ? "at most 16 designs per batch"
-                                                                             : "at most 8 designs per batch (EMAGLS_BATCH_MAX=16 allows 16 on an otherwise idle device)");
+                                                                             : "at most 8 designs per batch (emagls_set_batch_max(16) / EMAGLS_BATCH_MAX=16 allows 16)");
         std::unique_ptr<emagls_batch> b(new emagls_batch);
         for (int j = 0; j < nplans; ++j) {
             emagls_plan* p = plans[j];
@@ -2409,6 +2414,13 @@ int emagls_batch_lane_mode(emagls_batch* b, int* lanes) {
         DeviceGuard dg(b ? b->device : -1);
         if (!b || !lanes) throw Error(EMAGLS_ERR_ARG, "null pointer");
         *lanes = b->lanes ? 1 : 0;
+    });
+}
+int emagls_set_batch_max(int max_designs, int* previous) {
+    return guarded([&] {
+        if (max_designs < 1 || max_designs > SWEEP_MULTI_MAX) throw Error(EMAGLS_ERR_ARG, "a batch holds 1..16 designs");
+        const int prev = g_batch_max.exchange(max_designs);
+        if (previous) *previous = prev;
     });
 }
 int emagls_batch_shares_atf_side(emagls_batch* b, int* shared) {

@@ -105,6 +105,7 @@ template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and
 //                        no operand loads of G, so its polls never queue behind an HBM miss in the wave's in-order memory queue)
 // One LDS buffer (77 KB) and four waves: a launch sweeps up to 16 designs, two per XCD, two workgroups per CU.
 constexpr int PS_NT = 256, PS_COMM0 = 192;
+constexpr int PS_PMAX = 1040;   // bins whose conditioning flags fit the kernel's LDS table
 constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 
 // NI: channel quarters that are swept in the M and p phases (channels part + 4 i, i < NI): ceil(C / 4), so that an 8-microphone
@@ -122,6 +123,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     __shared__ __attribute__((aligned(16))) cplx Wp[64];          // W(kb-1,:), same layout
     __shared__ __attribute__((aligned(16))) cplx ts[2][PS_DPW];   // t per ear and direction
     __shared__ int s_abort, s_local;
+    __shared__ unsigned char s_ok[PS_PMAX];    // cond_ok of every bin (the designs stop at nfft 2048: P <= 1025; checked at launch)
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     // operands of the current bin; rows beyond C stay zero
     cplx* xs = reinterpret_cast<cplx*>(dyn);                            // [32][XLD]   G_kb slab
@@ -155,6 +157,8 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     u64* xcc_ll = tot_ll + (size_t)2 * 2 * nd2;             // [nWG] start-up exchange of the XCC ids
     if (tid < 64) { vt[tid] = mk(0, 0); Wp[tid] = mk(0, 0); }
     if (tid == 0) { s_abort = 0; s_local = 0; }
+    // (the per-bin flags are read in every bin of the chain: once from memory, then from LDS)
+    for (int i = tid; i < PS_PMAX; i += PS_NT) s_ok[i] = (i < P) ? (a.cond_ok[i] != 0.0 ? 1 : 0) : 1;
     {
         const size_t ncplx = (size_t)PS_CMAX * XLD + (size_t)PS_CMAX * PS_MLD + PS_DPW * 2;  // hs: 4 DPW doubles
         for (size_t i = tid; i < ncplx; i += PS_NT) xs[i] = mk(0, 0);
@@ -231,9 +235,13 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         fetch_g(a.kfirst, 0, gReg, hReg);
         fetch_g(a.kfirst, 1, gReg, hReg);
         stage_g(a.kfirst, gReg, hReg);
+        // the operands of the second bin are requested now and staged when the first bin's partial phase is over (B4)
+        fetch_g(a.kfirst + 1, 0, gReg, hReg);
+        fetch_g(a.kfirst + 1, 1, gReg, hReg);
     }
     fetch_m(a.kfirst, mReg);
     stage_m(mReg);
+    fetch_m(a.kfirst + 1, mReg);
     if (comm) {  // do all workgroups of this design share an XCD?
         const unsigned xcc = read_xcc_id();
         const unsigned tag0 = 0x58434300u;  // 'XCC'
@@ -327,15 +335,14 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             }
             if (lane == 0) PSTAMP(2);
         }
-        const bool prev_ok = first ? true : (a.cond_ok[kb - 1] != 0.0);
-        const bool cur_ok = last ? true : (a.cond_ok[kb] != 0.0);
+        const bool prev_ok = first ? true : (s_ok[kb - 1] != 0);
+        const bool cur_ok = last ? true : (s_ok[kb] != 0);
         const double* hs = hs_all + (size_t)(kb & 1) * 2 * PS_DPW;
         __syncthreads();  // B1: vt is complete (and this bin's operands are staged)
         if (s_abort) break;
-        // The next bin's G is requested NOW: a CU's vector memory pipeline returns in order, so loads that miss to HBM
-        // (1.2-1.5 us) delay every later poll of the communication wave behind them.  Issued here they drain during the
-        // three compute phases.
-        if (loader) fetch_g(kb + 1, 0, gReg, hReg);
+        // (No operand loads are issued inside the three compute phases: their issue time -- half a slab is 8 wide loads per
+        // thread through the CU's 64 B/clk address path, ~0.15 us -- and M's used to sit on the chain's critical path.  The
+        // operands of bin kb + 1 were requested a whole bin period ago, right after bin kb's were staged; see B4.)
         // ---- W(kb-1,:) = v_total conj(M_{kb-1})  (identity for the first swept bin and after an ill-conditioned bin)
         if (pvalid) {
             cplx acc = mk(0, 0);
@@ -353,7 +360,6 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             }
         }
         if (last) break;
-        fetch_m(kb + 1, mReg);
         __syncthreads();  // B2: Wp is complete
         // ---- p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
         // thread = (direction pair (dA, dA + DPW/2), channel quarter): a W value read from LDS feeds two directions
@@ -374,7 +380,6 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             }
         }
         __syncthreads();  // B3: ts is complete
-        if (loader) fetch_g(kb + 1, 1, gReg, hReg);
         // ---- this slab's partial v = t conj(G) (or t Y_reg_inv for an ill-conditioned bin), published as granules
         if (tid == 0) PSTAMP(4);
         // thread = (channel pair cp, 16 direction slices): every t and every G element it reads from LDS feeds two
@@ -418,8 +423,16 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         // the slab buffer is free once every wave has left the partial phase (M was last read before B2): refill both while
         // everybody waits for the exchange
         __syncthreads();  // B4
-        if (loader) stage_g(kb + 1, gReg, hReg);
+        // Stage the operands of bin kb + 1 (requested one bin period ago: they have arrived) and request those of bin kb + 2 into
+        // the same registers.  This is the exchange wait of the compute waves: nothing here delays the chain, and the
+        // communication wave (wave 3, no G loads of its own) polls meanwhile.
+        if (loader) {
+            stage_g(kb + 1, gReg, hReg);
+            fetch_g(kb + 2, 0, gReg, hReg);
+            fetch_g(kb + 2, 1, gReg, hReg);
+        }
         stage_m(mReg);
+        fetch_m(kb + 2, mReg);
     }
 #undef PSTAMP
 }
@@ -436,7 +449,7 @@ size_t persist_sweep_ll_bytes(int D, int C) {
 void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const HalfSweepArgs& a = m.a[0];
     const int nWG = persist_sweep_nwg(a.D);
-    if (!persist_sweep_supported(a.D, a.C) || m.n > SWEEP_MULTI_MAX) throw Error(2, "persistent sweep: shape not supported");
+    if (!persist_sweep_supported(a.D, a.C) || m.n > SWEEP_MULTI_MAX || a.P > PS_PMAX) throw Error(2, "persistent sweep: shape not supported");
     const unsigned nblocks = 8u * (unsigned)nWG * (m.n > 8 ? 2u : 1u);
     const int dpw = persist_sweep_dpw(a.D);
     const size_t dyn = sizeof(cplx) * ((size_t)PS_CMAX * (dpw + 4) + (size_t)PS_CMAX * PS_MLD + 2 * dpw);

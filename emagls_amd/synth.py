@@ -59,6 +59,9 @@ def _sphere_surface_tf(ka, cos_theta, nmax):
     return out
 
 
+_CLEAN_HRIRS = {}
+
+
 def rigid_sphere_hrirs(azi, zen, fs=48000.0, taps=128, head_radius=0.0875, noise=1e-4, seed=20250310,
                        centre_delay=40.0):
     """(hL, hR), each [taps x D] float64 (MATLAB layout: samples down, directions across)."""
@@ -73,14 +76,22 @@ def rigid_sphere_hrirs(azi, zen, fs=48000.0, taps=128, head_radius=0.0875, noise
     w = 2 * np.pi * f
     # smooth roll-off towards Nyquist so the truncated IR does not ring
     lp = 0.5 * (1 + np.cos(np.pi * np.clip((f - 0.7 * fs / 2) / (0.3 * fs / 2), 0, 1)))
-    out = []
     rng = np.random.default_rng(seed)
-    for name in ("L", "R"):
-        H = _sphere_surface_tf(ka, u @ ears[name], nmax)
-        H = H * (lp * np.exp(-1j * w * centre_delay / fs))[:, None]
-        H[-1] = H[-1].real
-        h = np.fft.irfft(H, n=taps, axis=0)
-        out.append(h)
+    # the noise-free responses depend on the geometry only: kept for the next call (a bench run builds ~70 HRIR sets that differ
+    # in their noise seed)
+    key = (azi.tobytes(), zen.tobytes(), float(fs), int(taps), float(head_radius), float(centre_delay))
+    out = _CLEAN_HRIRS.get(key)
+    if out is None:
+        out = []
+        for name in ("L", "R"):
+            H = _sphere_surface_tf(ka, u @ ears[name], nmax)
+            H = H * (lp * np.exp(-1j * w * centre_delay / fs))[:, None]
+            H[-1] = H[-1].real
+            h = np.fft.irfft(H, n=taps, axis=0)
+            out.append(h)
+        if len(_CLEAN_HRIRS) >= 8:
+            _CLEAN_HRIRS.clear()
+        _CLEAN_HRIRS[key] = out
     peak = max(np.abs(out[0]).max(), np.abs(out[1]).max())
     res = []
     for h in out:

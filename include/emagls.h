@@ -313,6 +313,11 @@ void* emagls_plan_stream(emagls_plan* plan);
  * caller and must outlive the batch.  Results: emagls_batch_get_filters, or emagls_plan_get_filters on each plan. */
 typedef struct emagls_batch emagls_batch;
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch);
+/* Largest batch emagls_batch_create accepts from now on: 8 by default (EMAGLS_BATCH_MAX in the environment sets the initial
+ * value), up to 16 -- two designs per XCD in the resident sweep, two sweep workgroups per CU (154 of 160 KB of LDS): fastest per
+ * design when the batch has the device to itself, but kernels of other batches then only find room on the CUs the sweep does not
+ * use, so keep 8 when several batches are in flight.  *previous (optional) receives the old value. */
+int emagls_set_batch_max(int max_designs, int* previous);
 /* A batch may also hold EMAGLS_KIND_FROM_ATF plans of one shape -- the HRTF subjects of one ATF set (BASELINE config 5: 8 subjects).
  * lib/getEMagLsFiltersFromAtf.m:54-95,100-104: the spectra of the matched ATFs and their per-bin factors do not depend on the
  * HRIRs.  When all plans hold the same grids and the same ATF set (compared on the device whenever one of them was replaced) the

@@ -9,8 +9,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# 9..16-design lane batches are opt-in (they need an otherwise idle device, which a test process is): enable them for the suite
-os.environ.setdefault("EMAGLS_BATCH_MAX", "16")
 
 
 def pytest_configure(config):

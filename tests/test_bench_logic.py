@@ -13,13 +13,15 @@ def _bench():
 
 
 def test_schedule_processes_exactly_the_requested_designs():
-    """The resident configuration (4 x 8) does not depend on --steps: a region of K designs is K // 8 full batches and one
+    """The resident configuration (4 x 16) does not depend on --steps: a region of K designs is K // 16 full batches and one
     partial batch (issued first: the batch with the least work reaches its sweep first), never a design more."""
-    sch = _bench().schedule
+    b = _bench()
+    sch = b.schedule
+    assert (b.SLOTS, b.BSZ) == (4, 16)
     for k in range(1, 300):
         s = sch(k)
-        assert sum(s) == k and all(x == 8 for x in s[1:]) and 1 <= s[0] <= 8
-    assert sch(20) == [4, 8, 8] and sch(128) == [8] * 16 and sch(5, 8) == [5]
+        assert sum(s) == k and all(x == 16 for x in s[1:]) and 1 <= s[0] <= 16
+    assert sch(20) == [4, 16] and sch(128) == [16] * 8 and sch(5, 8) == [5] and sch(20, 8) == [4, 8, 8]
 
 
 def test_gpus_flag_spawns_fresh_ranks(tmp_path):
