@@ -86,6 +86,7 @@ struct HalfSweepArgs {
     const int* skip_flag;    // persistent sweep, optional: non-zero at launch = operands unusable (MagLS basis too ill-conditioned for the
                              // inverse form, status word 4): the design's workgroups leave at once, the host re-runs on the launch-per-bin sweep
     long long* timing;       // optional [P][16] wall-clock stamps (EMAGLS_SWEEP_TIMING), else null
+    int fetch_mode;          // persistent sweep: where the next bin's operands are requested (sweep_persist.hip; EMAGLS_SWEEP_FETCH, default 0)
     int force_global;        // persistent sweep: keep the write-through (sc1) stores even on one XCD (EMAGLS_PERSIST_GLOBAL=1)
 };
 constexpr int SWEEP_MULTI_MAX = 16;   // designs per sweep launch: one per XCD up to 8, two per XCD (two workgroups per CU) up to 16

@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     const bool comm = tid >= PS_COMM0;
     const bool loader = tid < PS_NL;
     const int C = a.C, P = a.P, npairs = 2 * a.C;
+    const int fm = a.fetch_mode;
     const int64_t d0 = (int64_t)member * PS_DPW;
     const int64_t na = P - a.kabs0;
     // totals: granule words of a double x (x = 2 pair + re/im): low halves lo[x], high halves hi[x], each array contiguous
@@ -235,13 +236,11 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         fetch_g(a.kfirst, 0, gReg, hReg);
         fetch_g(a.kfirst, 1, gReg, hReg);
         stage_g(a.kfirst, gReg, hReg);
-        // the operands of the second bin are requested now and staged when the first bin's partial phase is over (B4)
-        fetch_g(a.kfirst + 1, 0, gReg, hReg);
-        fetch_g(a.kfirst + 1, 1, gReg, hReg);
+        if (fm == 3) { fetch_g(a.kfirst + 1, 0, gReg, hReg); fetch_g(a.kfirst + 1, 1, gReg, hReg); }
     }
     fetch_m(a.kfirst, mReg);
     stage_m(mReg);
-    fetch_m(a.kfirst + 1, mReg);
+    if (fm == 3) fetch_m(a.kfirst + 1, mReg);
     if (comm) {  // do all workgroups of this design share an XCD?
         const unsigned xcc = read_xcc_id();
         const unsigned tag0 = 0x58434300u;  // 'XCC'
@@ -340,9 +339,12 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         const double* hs = hs_all + (size_t)(kb & 1) * 2 * PS_DPW;
         __syncthreads();  // B1: vt is complete (and this bin's operands are staged)
         if (s_abort) break;
-        // (No operand loads are issued inside the three compute phases: their issue time -- half a slab is 8 wide loads per
-        // thread through the CU's 64 B/clk address path, ~0.15 us -- and M's used to sit on the chain's critical path.  The
-        // operands of bin kb + 1 were requested a whole bin period ago, right after bin kb's were staged; see B4.)
+        // Where the next bin's operands are requested (a.fetch_mode).  A CU's vector memory pipeline returns in order across its
+        // waves: loads that miss to HBM (1.2-1.5 us) delay every later poll of the communication wave behind them, so they must
+        // have drained when the exchange starts -- requesting them after B4 (mode 3, a whole bin period of lead and no issue
+        // time on the chain) costs +0.8 us per bin in hop 1 (measured).  Issued here (and after B3 / B2) they drain during the
+        // compute phases, at the price of their issue time (~0.15 us per half slab) on the chain.
+        if (loader && fm != 3) { fetch_g(kb + 1, 0, gReg, hReg); if (fm == 2) fetch_g(kb + 1, 1, gReg, hReg); }
         // ---- W(kb-1,:) = v_total conj(M_{kb-1})  (identity for the first swept bin and after an ill-conditioned bin)
         if (pvalid) {
             cplx acc = mk(0, 0);
@@ -360,7 +362,9 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             }
         }
         if (last) break;
+        if (fm != 3) fetch_m(kb + 1, mReg);
         __syncthreads();  // B2: Wp is complete
+        if (loader && fm == 1) fetch_g(kb + 1, 1, gReg, hReg);
         // ---- p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
         // thread = (direction pair (dA, dA + DPW/2), channel quarter): a W value read from LDS feeds two directions
         if (tid == 0) PSTAMP(3);
@@ -380,6 +384,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             }
         }
         __syncthreads();  // B3: ts is complete
+        if (loader && fm == 0) fetch_g(kb + 1, 1, gReg, hReg);
         // ---- this slab's partial v = t conj(G) (or t Y_reg_inv for an ill-conditioned bin), published as granules
         if (tid == 0) PSTAMP(4);
         // thread = (channel pair cp, 16 direction slices): every t and every G element it reads from LDS feeds two
@@ -428,11 +433,10 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         // communication wave (wave 3, no G loads of its own) polls meanwhile.
         if (loader) {
             stage_g(kb + 1, gReg, hReg);
-            fetch_g(kb + 2, 0, gReg, hReg);
-            fetch_g(kb + 2, 1, gReg, hReg);
+            if (fm == 3) { fetch_g(kb + 2, 0, gReg, hReg); fetch_g(kb + 2, 1, gReg, hReg); }
         }
         stage_m(mReg);
-        fetch_m(kb + 2, mReg);
+        if (fm == 3) fetch_m(kb + 2, mReg);
     }
 #undef PSTAMP
 }
