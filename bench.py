@@ -36,6 +36,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Hardware queues: the runtime multiplexes the streams of the process onto GPU_MAX_HW_QUEUES queues (default 4) and work of two
+# streams that share a queue executes in order.  Four batches in flight with two lane groups each: 8 streams (+ the partial
+# batches' 4) -> 16 queues, set before the runtime initialises and inherited by the ranks `--gpus N` spawns.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # (measured, profiles/r03_*: more hardware queues than the runtime's default 4 -- GPU_MAX_HW_QUEUES=8 / 16 / 24 -- change nothing
 # up to 16 and cost 12-25 % at 24; forking a batch's stages before the sweep onto side streams (--fork 4) costs 13-20 % with
 # four batches in flight: the forks compete with the other batches' kernels and with the resident sweep for the same CUs)
@@ -286,6 +290,9 @@ def main():
     # vs 1400 sets/s at 20 steps and 1750 vs 1910 at 128)
     lane_streams = [torch.cuda.Stream(device=local_rank) for _ in range(nslots + 2)]
     next_stream = iter(lane_streams)
+    # (batches of more than 8 designs run the stages before their sweep as two lane groups: the second group's streams)
+    side_streams = [torch.cuda.Stream(device=local_rank) for _ in range(nslots + 2)] if Bsz > 8 else []
+    next_side = iter(side_streams)
 
     def make_plan(seed_offset, streams=1):
         azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=seed_offset)
@@ -332,6 +339,10 @@ def main():
                     self.batch.set_stream(st.cuda_stream)
                 if args.fork > 1 and self.batch.lane_mode():
                     self.batch.set_streams(args.fork)
+                if size > 8:
+                    st2 = next(next_side, None)
+                    if st2 is not None:
+                        self.batch.set_side_stream(st2.cuda_stream)
 
         def execute(self):
             self.batch.execute() if self.batch is not None else self.plans[0].execute()

@@ -52,7 +52,7 @@ def build(jobs=4, force=False, verbose=True):
         res = list(ex.map(lambda s: _compile(s, force), SOURCES))
     objs = [o for o, _ in res]
     if any(c for _, c in res) or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lhipfft",
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lhipfft", "-pthread",
                "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

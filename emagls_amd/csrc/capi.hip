@@ -9,6 +9,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/emagls.h"
@@ -231,6 +232,10 @@ struct emagls_batch {
     hipEvent_t sweep_ev[2] = {nullptr, nullptr};
     hipGraph_t post_graph = nullptr;           // lane mode: the stages after the sweep (the sweep is launched directly)
     hipGraphExec_t post_exec = nullptr;
+    bool side0_external = false;               // side[0] belongs to the caller (emagls_batch_set_side_stream)
+    int groups = 1;                            // lane groups before the sweep (2 for more than 8 designs: batch_execute_lanes)
+    hipGraph_t graph2 = nullptr;               // the second lane group's stages before the sweep (on side[0])
+    hipGraphExec_t graph2_exec = nullptr;
     int eager_runs = 0;
     bool use_graph = true;
     std::vector<hipEvent_t> events;
@@ -257,9 +262,11 @@ struct emagls_batch {
         if (graph) hipGraphDestroy(graph);
         if (post_exec) hipGraphExecDestroy(post_exec);
         if (post_graph) hipGraphDestroy(post_graph);
+        if (graph2_exec) hipGraphExecDestroy(graph2_exec);
+        if (graph2) hipGraphDestroy(graph2);
         for (auto e : sweep_ev) if (e) hipEventDestroy(e);
         if (stream && own_stream) emagls::pool_stream_give(stream);
-        for (auto st : side) if (st) emagls::pool_stream_give(st);
+        for (int i = 0; i < 3; ++i) if (side[i] && !(i == 0 && side0_external)) { hipStreamSynchronize(side[i]); emagls::pool_stream_give(side[i]); }
         if (cmp_flag) hipFree(cmp_flag);
         for (auto* p : plans) if (p) { p->sync_stream = nullptr; p->owner = nullptr; }
     }
@@ -1446,18 +1453,18 @@ void batch_sweep_stage(emagls_batch& b) {
     launch_sweep_half_finalize(h, q0.P - 1, b.stream);
 }
 
-// lane mode: the pipeline of plan 0 is enqueued once on the batch stream with grid.z = designs
+// lane mode: the pipeline of plan `first` is enqueued once on `st` with grid.z = `count` designs (plans first .. first + count - 1)
 // part 0: stages before the sweep, part 2: stages after it
-void batch_lanes_part(emagls_batch& b, int part) {
-    emagls_plan& p0 = *b.plans[0];
+void batch_lanes_part(emagls_batch& b, int part, int first, int count, hipStream_t st) {
+    emagls_plan& p0 = *b.plans[first];
     hipStream_t keep = p0.stream, keep_side[3] = {p0.side[0], p0.side[1], p0.side[2]};
     const int keep_streams = p0.nstreams;
-    p0.stream = b.stream;
-    p0.nstreams = part == 0 ? b.nstreams : 1;
+    p0.stream = st;
+    p0.nstreams = (part == 0 && b.groups == 1) ? b.nstreams : 1;
     if (p0.nstreams > 1) for (int i = 0; i < 3; ++i) p0.side[i] = b.side[i];
     auto restore = [&] { p0.stream = keep; p0.nstreams = keep_streams; for (int i = 0; i < 3; ++i) p0.side[i] = keep_side[i]; };
     try {
-        BatchScope sc((int)b.plans.size(), b.stride);
+        BatchScope sc(count, b.stride);
         if (part == 0) plan_pre_stage(p0); else emagls_post_sweep(p0);
     } catch (...) {
         restore();
@@ -1465,15 +1472,45 @@ void batch_lanes_part(emagls_batch& b, int part) {
     }
     restore();
 }
+// Lane GROUPS: a batch of more than 8 designs runs the stages before its sweep as two half-batches on two streams (each one
+// launch of every kernel for its lanes, each a captured single-stream graph) and then ONE resident sweep launch for all designs.
+// Sixteen lanes in one launch sequence take about twice as long per kernel as eight (the bandwidth-bound kernels scale with
+// the lanes, and the latency-bound ones get 2x the workgroups), and that sequence is the path to the sweep; two half-batches
+// next to each other overlap their latency-bound kernels (measured at --steps 20: the 16-lane sequence 8.6 ms).
+int batch_group_first(const emagls_batch& b, int g) { const int n = (int)b.plans.size(), h = (n + b.groups - 1) / b.groups; return std::min(n, g * h); }
 void batch_execute_lanes(emagls_batch& b) {
     const bool replay = b.use_graph && b.eager_runs >= 1;
+    const int n = (int)b.plans.size();
+    if (b.groups > 1 && !b.side[0]) b.side[0] = emagls::pool_stream_take();
+    hipStream_t gs[2] = {b.stream, b.groups > 1 ? b.side[0] : b.stream};
     if (replay && !b.graph_exec) {
-        capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_lanes_part(b, 0); });
-        capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_lanes_part(b, 2); });
+        for (int g = 0; g < b.groups; ++g) {
+            const int f = batch_group_first(b, g), c = batch_group_first(b, g + 1) - f;
+            capture_into(gs[g], g == 0 ? &b.graph : &b.graph2, g == 0 ? &b.graph_exec : &b.graph2_exec, [&] { batch_lanes_part(b, 0, f, c, gs[g]); });
+        }
+        capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_lanes_part(b, 2, 0, n, b.stream); });
     }
-    if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_lanes_part(b, 0);
+    b.used = 0;
+    if (b.groups > 1) b.depend(gs[1], b.stream);   // (the previous execute of this batch is done with the buffers)
+    if (replay && b.groups > 1) {
+        // a graph launch of ~60 kernel nodes costs ~1 ms of host time: the second group's launch goes out from a thread of its
+        // own, or its stages would start a millisecond (three under a profiler) behind the first group's
+        hipError_t e2 = hipSuccess;
+        const int dev = b.device;
+        std::thread t2([&] { e2 = hipSetDevice(dev); if (e2 == hipSuccess) e2 = hipGraphLaunch(b.graph2_exec, gs[1]); });
+        const hipError_t e1 = hipGraphLaunch(b.graph_exec, gs[0]);
+        t2.join();
+        HIP_CHECK(e1);
+        HIP_CHECK(e2);
+    } else {
+        for (int g = 0; g < b.groups; ++g) {
+            const int f = batch_group_first(b, g), c = batch_group_first(b, g + 1) - f;
+            if (replay) HIP_CHECK(hipGraphLaunch(g == 0 ? b.graph_exec : b.graph2_exec, gs[g])); else batch_lanes_part(b, 0, f, c, gs[g]);
+        }
+    }
+    if (b.groups > 1) b.depend(b.stream, gs[1]);
     batch_sweep_stage(b);   // (never captured: see SweepChain)
-    if (replay) HIP_CHECK(hipGraphLaunch(b.post_exec, b.stream)); else batch_lanes_part(b, 2);
+    if (replay) HIP_CHECK(hipGraphLaunch(b.post_exec, b.stream)); else batch_lanes_part(b, 2, 0, n, b.stream);
     emagls_plan& p0 = *b.plans[0];
     for (auto* p : b.plans) {
         p->executed = true;
@@ -1604,6 +1641,8 @@ void drop_batch_graphs(emagls_batch& b) {
     if (b.graph) { HIP_CHECK(hipGraphDestroy(b.graph)); b.graph = nullptr; }
     if (b.post_exec) { HIP_CHECK(hipGraphExecDestroy(b.post_exec)); b.post_exec = nullptr; }
     if (b.post_graph) { HIP_CHECK(hipGraphDestroy(b.post_graph)); b.post_graph = nullptr; }
+    if (b.graph2_exec) { HIP_CHECK(hipGraphExecDestroy(b.graph2_exec)); b.graph2_exec = nullptr; }
+    if (b.graph2) { HIP_CHECK(hipGraphDestroy(b.graph2)); b.graph2 = nullptr; }
     b.eager_runs = 0;
 }
 // Device-side status words of a design: [0] Cholesky pivot, [1] persistent sweep gave up waiting, [2] a Gram-route bin was
@@ -1764,6 +1803,11 @@ void batch_try_lanes(emagls_batch& b) {
     HIP_CHECK(hipDeviceSynchronize());
     b.lanes = true;
     b.stride = stride;
+    {   // more than 8 designs: two lane groups before the sweep (EMAGLS_BATCH_GROUPS=1 keeps one launch sequence for all lanes)
+        const char* e = getenv("EMAGLS_BATCH_GROUPS");
+        const int want = e ? atoi(e) : 2;
+        b.groups = (b.plans.size() > 8 && want >= 2) ? 2 : 1;
+    }
 }
 
 void batch_redo(emagls_batch& b, const std::vector<int>& flags) {
@@ -2451,6 +2495,16 @@ int emagls_batch_set_streams(emagls_batch* b, int nstreams) {
         for (int i = 0; i < nstreams - 1; ++i) if (!b->side[i]) b->side[i] = emagls::pool_stream_take();
         if (nstreams != b->nstreams) drop_batch_graphs(*b);   // (the next execute runs eagerly, the one after it captures the forks)
         b->nstreams = nstreams;
+    });
+}
+int emagls_batch_set_side_stream(emagls_batch* b, void* stream) {
+    return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
+        if (!b || !stream) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        HIP_CHECK(hipStreamSynchronize(b->stream));
+        if (b->side[0] && !b->side0_external) { HIP_CHECK(hipStreamSynchronize(b->side[0])); emagls::pool_stream_give(b->side[0]); }
+        b->side[0] = (hipStream_t)stream;
+        b->side0_external = true;
     });
 }
 int emagls_batch_set_profiling(emagls_batch* b, int level) {

@@ -161,6 +161,10 @@ class Batch:
         """Lane mode: fork the stages before the sweep onto n (1..4) streams (see emagls_batch_set_streams)."""
         L.check(self._lib.emagls_batch_set_streams(self._h, int(n)))
 
+    def set_side_stream(self, hip_stream):
+        """The stream of the second lane group of a batch of more than 8 designs (see emagls_batch_set_side_stream)."""
+        L.check(self._lib.emagls_batch_set_side_stream(self._h, C.c_void_p(int(hip_stream))))
+
     def sweep_time_ms(self):
         ms = C.c_double(0.0)
         L.check(self._lib.emagls_batch_sweep_time(self._h, C.byref(ms)))

@@ -341,6 +341,10 @@ int emagls_batch_lane_mode(emagls_batch* batch, int* lanes);
  * two batches whose streams land on the same queue execute strictly one after the other; a caller that creates its streams
  * first and hands one to each batch in flight decides the mapping itself (bench.py does). */
 int emagls_batch_set_stream(emagls_batch* batch, void* hip_stream);
+/* A lane batch of more than 8 designs runs the stages before its sweep as two lane groups on two streams (then one sweep launch
+ * for all designs).  The second group's stream comes from the library unless the caller hands one over here -- for the same
+ * reason as emagls_batch_set_stream: which hardware queue a stream lands on is decided by the order the streams are created in. */
+int emagls_batch_set_side_stream(emagls_batch* batch, void* hip_stream);
 int emagls_batch_sweep_time(emagls_batch* batch, double* ms);
 /* Lane mode: 1..4 HIP streams for the stages before the sweep (default 1).  With more than one the independent branches of the
  * design fork onto side streams and the captured graph carries the forks: [HRIR-grid SH matrix, Gram matrix, Cholesky factor,

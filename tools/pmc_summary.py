@@ -84,7 +84,7 @@ def main():
             merged[k].update(cs)
     res = {"note": "means per dispatch from separate rocprofv3 --pmc passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE "
                    "doubled per the gfx950 correction of MI355X_MICROARCH.md; WRITE_SIZE matched the algorithmic bytes on sh_basis_kernel)",
-           "designs_per_launch": LANES}
+           "designs_per_launch": LANES, "build": os.environ.get("EMAGLS_BUILD_TAG", "?")}
     per_set = 0.0
     rows = []
     launches_per_batch = {}
