@@ -9,6 +9,7 @@
 // + svd(pwGrid.')  (:88) on a D x C matrix by an S x C problem:  pwGrid.' = conj(Y) A_k^T = Q (R A_k^T).
 // The HRIR grid's SH matrix is well conditioned (cond 1.5 at N=19 on the 2702-point grid), so
 // Cholesky-QR loses nothing; a non-positive pivot raises a device flag and the host reports it.
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace emagls {
@@ -89,6 +90,77 @@ __global__ void __launch_bounds__(256) gram_mfma_kernel(const T* __restrict__ Yc
             for (int r = 0; r < 4; ++r) {
                 const int gi = i0 + 16 * x + kk + 4 * r, gj = j0 + 16 * y + ii;
                 if (gi < S && gj < S) out[(int64_t)gi * S + gj] = gram_get(acc, x, y, r, (T*)nullptr);
+            }
+}
+
+// The same Gram matrix without the K split, for launches that fill the chip with tiles alone (lane batches: 28 tiles x 8 designs
+// at config 3): one workgroup walks ALL rows of its 64 x 64 tile, 16 rows at a time through a double-buffered LDS stage (the
+// next 16 rows are in flight in registers while the MFMAs run on the current ones), and writes the finished tile straight into
+// Gy and into the leading block of R -- no K-split partials (20 MB per design written and read back) and no reduce kernel.
+// The MFMA fragments come from LDS (16 consecutive doubles per k row: conflict free), not from global memory.
+constexpr int GL_KC = 16;          // rows per stage
+constexpr int GL_LD = 64 + 16;     // row stride of a stage in doubles (32 banks mod 64: the four k rows of a fragment read tile the banks)
+__global__ void __launch_bounds__(256) gram_lds_kernel(const double* __restrict__ Yc, int64_t ld, int S, int64_t rows, int nbt,
+                                                       double* __restrict__ G, double* __restrict__ R, int Sh, size_t bstride) {
+    Yc = boff(Yc, bstride); G = boff(G, bstride); R = boff(R, bstride);
+    __shared__ __attribute__((aligned(16))) double As[2][GL_KC][GL_LD];
+    __shared__ __attribute__((aligned(16))) double Bs[2][GL_KC][GL_LD];
+    int t = blockIdx.x, ti = 0;
+    while (t >= nbt - ti) { t -= nbt - ti; ++ti; }
+    const int tj = ti + t;
+    const bool diag = ti == tj;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;      // the wave's 32 x 32 sub-tile
+    const int ii = lane & 15, kk = lane >> 4;
+    // loader role: row lr of the stage, columns 4 lc .. 4 lc + 3 of the panel (16 threads cover one 512-byte row segment)
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    const double* pa = Yc + (int64_t)lr * ld + ti * 64 + lc;
+    const double* pb = Yc + (int64_t)lr * ld + tj * 64 + lc;
+    // (columns beyond S are the zero padding of Yc's rows, ld >= 64 nbt; rows beyond D are zero up to `rows`)
+    double4_t ra, rb;
+    auto fetch = [&](int64_t d0) __attribute__((always_inline)) {
+        const bool ok = d0 + lr < rows;
+        ra = ok ? *reinterpret_cast<const double4_t*>(pa + d0 * ld) : double4_t{0, 0, 0, 0};
+        if (!diag) rb = ok ? *reinterpret_cast<const double4_t*>(pb + d0 * ld) : double4_t{0, 0, 0, 0};
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        As[buf][lr][lc] = ra[0]; As[buf][lr][lc + 1] = ra[1]; As[buf][lr][lc + 2] = ra[2]; As[buf][lr][lc + 3] = ra[3];
+        if (!diag) { Bs[buf][lr][lc] = rb[0]; Bs[buf][lr][lc + 1] = rb[1]; Bs[buf][lr][lc + 2] = rb[2]; Bs[buf][lr][lc + 3] = rb[3]; }
+    };
+    GramAcc<double> acc;
+    acc.init();
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int64_t nst = (rows + GL_KC - 1) / GL_KC;
+    for (int64_t c = 0; c < nst; ++c) {
+        const int buf = (int)(c & 1);
+        if (c + 1 < nst) fetch((c + 1) * GL_KC);
+        const double (*A)[GL_LD] = As[buf];
+        const double (*B)[GL_LD] = diag ? As[buf] : Bs[buf];
+#pragma unroll
+        for (int k4 = 0; k4 < GL_KC; k4 += 4) {
+            double a[2], b[2];
+            a[0] = A[k4 + kk][wi + ii]; a[1] = A[k4 + kk][wi + 16 + ii];
+            b[0] = B[k4 + kk][wj + ii]; b[1] = B[k4 + kk][wj + 16 + ii];
+            gram_step(acc, a, b);
+        }
+        if (c + 1 < nst) stage(buf ^ 1);
+        __syncthreads();
+    }
+    const int i0 = ti * 64 + wi, j0 = tj * 64 + wj;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = i0 + 16 * x + kk + 4 * r, gj = j0 + 16 * y + ii;
+                if (gi < S && gj < S) {
+                    const double v = acc.r[x][y][r];
+                    if (G) { G[(int64_t)gi * S + gj] = v; if (!diag) G[(int64_t)gj * S + gi] = 0.0; }   // (block lower triangle: zeros, like the reduce kernel)
+                    if (R && gi < Sh && gj < Sh) { R[(int64_t)gi * Sh + gj] = v; if (!diag) R[(int64_t)gj * Sh + gi] = 0.0; }
+                }
             }
 }
 
@@ -436,6 +508,15 @@ static void gram_impl(const void* Yc, int64_t D, int S, int64_t ld, void* Gp, vo
     const int kc = (int)(gram_dpad(D, S) / ks);
     const int nbt = (S + 63) / 64;
     const int ntiles = nbt * (nbt + 1) / 2;
+    if constexpr (std::is_same<T, double>::value) {
+        // enough tiles to fill the chip without a K split (lane batches of array designs): the LDS-staged kernel, no partials
+        static const bool lds_ok = [] { const char* e = getenv("EMAGLS_GRAM_LDS"); return !(e && e[0] == '0'); }();
+        if (lds_ok && (int64_t)ntiles * batch_ctx().n >= 128 && ld >= 64 * nbt) {
+            gram_lds_kernel<<<bgrid(ntiles), 256, 0, st>>>((const double*)Yc, ld, S, gram_dpad(D, S), nbt, (double*)G, (double*)R, Sh, batch_ctx().stride);
+            KERNEL_CHECK();
+            return;
+        }
+    }
     gram_mfma_kernel<T><<<bgrid(dim3(ntiles, ks)), 256, 0, st>>>((const T*)Yc, ld, S, kc, nbt, (T*)Gp, batch_ctx().stride);
     KERNEL_CHECK();
     gram_reduce_kernel<T><<<bgrid((unsigned)ceil_div((int64_t)S * S, 256)), 256, 0, st>>>((const T*)Gp, S, ks, (T*)G, (T*)R, Sh, batch_ctx().stride);

@@ -348,6 +348,46 @@ def test_lane_batch_matches_single_designs(grids, thin):
         p.close()
 
 
+def test_gram_matrix_of_a_lane_batch(grids, thin):
+    """Lane batches with enough Gram tiles to fill the chip (28 tiles x 6 designs here) take the LDS-staged Gram kernel without a
+    K split (gram_lds_kernel): the Gram matrix of every design against NumPy on the design's own conj(Y), its leading block
+    copied for the Cholesky factorisation, and the filters against the single designs (which take the K-split kernel)."""
+    from emagls_amd import Batch, Plan, _lib as L, synth
+    plans, singles = [], []
+    for j in range(6):
+        azi = np.mod(thin["azi"] + 0.21 * j, 2 * np.pi)
+        hL, hR = synth.rigid_sphere_hrirs(azi, thin["zen"], seed=70 + j)
+        p = Plan(L.KIND_EMAGLS, "real", 4, 48000.0, 128, hL.shape[0], hL.shape[1], 0.042, 32)
+        p.set_hrir_grid(azi, thin["zen"])
+        p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+        p.set_hrirs(hL, hR)
+        p.execute()
+        singles.append(p.get_filters())
+        plans.append(p)
+    b = Batch(plans)
+    assert b.lane_mode()
+    b.execute()
+    res = b.get_filters()
+    i = plans[0].info()
+    S, D = i.num_sh_sim, thin["azi"].size
+    ldS = -(-S // 64) * 64
+    worst = 0.0
+    for j in (0, 3, 5):
+        Yc = plans[j].debug("Yc", np.float64).reshape(-1, ldS)[:D, :S]
+        Gy = plans[j].debug("Gy", np.float64, (S, S))
+        ref = Yc.T @ Yc
+        blk = (np.arange(S)[:, None] // 64) <= (np.arange(S)[None, :] // 64)      # the upper block triangle is what is formed
+        worst = max(worst, np.abs(Gy - ref)[blk].max() / np.abs(ref).max())
+        assert np.all(Gy[~blk] == 0.0)
+    print(f"Gram matrix of a 6-design lane batch (LDS-staged kernel) vs NumPy: rel = {worst:.3e}")
+    assert worst < 1e-13
+    for (wL, wR), (sL, sR) in zip(res, singles):
+        assert rel(wL, sL) < 1e-11 and rel(wR, sR) < 1e-11
+    b.close()
+    for p in plans:
+        p.close()
+
+
 def test_sixteen_design_lane_batch(grids, thin, monkeypatch):
     """9 to 16 designs (opt-in: emagls_set_batch_max(16), the product's default stays 8 and so does the suite's) share one sweep
     launch with two designs per XCD (two workgroups per CU): a batch of 12 designs (different HRIR sets and microphone grids)

@@ -41,7 +41,7 @@ python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch 8 > gpurun_out/${tag}_k
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch > gpurun_out/${tag}_kernels_batch_all.md 2>&1
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch16 8 > gpurun_out/${tag}_kernels_batch16_groups.md 2>&1
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch16 > gpurun_out/${tag}_kernels_batch16_all.md 2>&1
-python tools/sweep_launches.py gpurun_out/${tag}_prof_default20 > gpurun_out/${tag}_default20_sweep_launches.md 2>&1
+python tools/sweep_launches.py gpurun_out/${tag}_prof_default20 gpurun_out/${tag}_prof_default20.log > gpurun_out/${tag}_default20_sweep_launches.md 2>&1
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_default20 > gpurun_out/${tag}_default20_kernels.md 2>&1
 python tools/fill_timeline.py gpurun_out/${tag}_prof_default20 2 > gpurun_out/${tag}_fill_timeline20.md 2>&1
 python tools/timeline.py gpurun_out/${tag}_prof_slots4 10 > gpurun_out/${tag}_timeline_slots4.md 2>&1

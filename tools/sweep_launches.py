@@ -3,7 +3,7 @@ measured live with HIP events (roofline.avg_launch_us in the JSON line of the sa
 
     python tools/sweep_launches.py <rocprof dir> <bench stdout of the same run> [n_timed_launches]
 
-bench.py averages the sweep launches of the FULL batches of its timed region (K // 8 launches of 8 designs each); in the trace
+bench.py averages the sweep launches of the FULL batches of its timed region (K // B launches of B designs each, B = designs per batch); in the trace
 these are the last K // 8 launches with the full grid (the earlier full-grid launches belong to the set-up executes of the
 batches and the warm-up; smaller grids to the single-design plan, the partial batch, the one-shot and parity checks)."""
 import glob
@@ -17,7 +17,8 @@ def main():
     d, out = sys.argv[1], sys.argv[2]
     line = [l for l in open(out) if l.startswith("{")][-1]
     js = json.loads(line)
-    n_timed = int(sys.argv[3]) if len(sys.argv) > 3 else max(js["steps"] // 8, 1)
+    bsz = int(js.get("config", {}).get("designs_per_batch", 8))
+    n_timed = int(sys.argv[3]) if len(sys.argv) > 3 else max(js["steps"] // bsz, 1)
     db = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)[0]
     cur = sqlite3.connect(db).cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -30,7 +31,7 @@ def main():
     full = [(e - s) / 1e3 for s, e, g in rows if g == gmax]
     print(f"command: python3 bench.py --steps {js['steps']} --warmup {js['warmup']} --no-secondary   ->  {js['value']:.1f} {js['unit']}")
     print(f"sweep_persist_kernel launches in the trace: {len(dur)}; all: avg {sum(dur) / len(dur):.1f} us, min {min(dur):.1f}, max {max(dur):.1f}")
-    print(f"launches with the full grid of {gmax} workgroups (8 designs): {len(full)}; avg {sum(full) / len(full):.1f} us")
+    print(f"launches with the full grid of {gmax} workgroups ({bsz} designs): {len(full)}; avg {sum(full) / len(full):.1f} us")
     last = full[-n_timed:]
     print(f"the {n_timed} full-batch launches of the timed region (the last ones): " + ", ".join(f"{x:.1f}" for x in last) + f" us; avg {sum(last) / len(last):.1f} us")
     r = js["roofline"]
