@@ -177,3 +177,91 @@ def run_lane_batches(jobs, sim_orders, batch_fn, group=None, device=None, max_ba
             out[j] = r
         return out
     return _gather_on_rank0(local, shards, n, group, device)
+
+
+# --------------------------------------------------------------------------------------------
+# the two job lists BASELINE.json names, on the plan / batch API (one process per GPU)
+# --------------------------------------------------------------------------------------------
+def emagls2_radius_sweep(hL, hR, hrirGridAziRad, hrirGridZenRad, radii, micGridAziRad, micGridZenRad, order, fs, length,
+                         shDefinition="real", group=None, max_batch=8):
+    """getEMagLs2Filters (lib/getEMagLs2Filters.m:1-2) for every array radius of `radii` (BASELINE config 4): padded lane batches,
+    whole batches per rank, one gather.  Returns [(wMlsL, wMlsR), ...] in the order of `radii` on rank 0, None elsewhere."""
+    from . import Batch, Plan, _lib as L
+    hL = np.asfortranarray(hL, dtype=np.float64)
+    hR = np.asfortranarray(hR, dtype=np.float64)
+    radii = [float(r) for r in radii]
+    so = [simulation_order(order, fs, r, raw=True) for r in radii]
+    nmics = int(np.asarray(micGridAziRad).size)
+
+    def batch_fn(rs, pad):
+        plans = []
+        try:
+            for r in rs:
+                p = Plan(L.KIND_EMAGLS2, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], r, nmics,
+                         sim_order_pad=int(pad))
+                p.set_hrir_grid(hrirGridAziRad, hrirGridZenRad)
+                p.set_mic_grid(micGridAziRad, micGridZenRad)
+                p.set_hrirs(hL, hR)
+                plans.append(p)
+            if len(plans) == 1:
+                plans[0].execute()
+                return [plans[0].get_filters()]
+            b = Batch(plans)
+            try:
+                b.execute()
+                return b.get_filters()
+            finally:
+                b.close()
+        finally:
+            for p in plans:
+                p.close()
+    return run_lane_batches(radii, so, batch_fn, group=group, max_batch=max_batch)
+
+
+def emagls_from_atf_subjects(subjects, hrirGridAziZenRad, atfIrs, atfGridAziZenRad, fs, filterLen, fTrans, group=None,
+                             max_batch=8):
+    """getEMagLsFiltersFromAtf (lib/getEMagLsFiltersFromAtf.m:1) for every HRTF subject of `subjects` = [(hL, hR), ...] on ONE
+    ATF set and HRIR grid (BASELINE config 5): the subjects are spread over the ranks, each rank runs its share in batches
+    that compute the ATF side once (Batch.shares_atf_side) and sweep all their subjects in one resident launch; one gather.
+    Returns [(wMlsL, wMlsR), ...] in the order of `subjects` on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    from . import Batch, Plan, _lib as L
+    hg = np.asarray(hrirGridAziZenRad, dtype=np.float64)
+    ag = np.asarray(atfGridAziZenRad, dtype=np.float64)
+    atf = np.asfortranarray(atfIrs, dtype=np.float64)
+    taps, M, Da = atf.shape
+    have_pg = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if have_pg else 0
+    world = dist.get_world_size(group) if have_pg else 1
+    n = len(subjects)
+    shards = shard_jobs(np.ones(n), world)
+    local = []
+    mine = shards[rank]
+    for i in range(0, len(mine), max_batch):
+        plans = []
+        try:
+            for j in mine[i:i + max_batch]:
+                hL = np.asfortranarray(subjects[j][0], dtype=np.float64)
+                hR = np.asfortranarray(subjects[j][1], dtype=np.float64)
+                p = Plan(L.KIND_FROM_ATF, "real", 0, float(fs), int(filterLen), hL.shape[0], hL.shape[1], nmics=M, f_trans=float(fTrans),
+                         atf_taps=taps, natf=Da)
+                p.set_hrir_grid(hg[:, 0], hg[:, 1])
+                p.set_hrirs(hL, hR)
+                p.set_atfs(atf, ag[:, 0], ag[:, 1])
+                plans.append(p)
+            if len(plans) == 1:
+                plans[0].execute()
+                local.append(plans[0].get_filters())
+            else:
+                b = Batch(plans)
+                try:
+                    b.execute()
+                    local += b.get_filters()
+                finally:
+                    b.close()
+        finally:
+            for p in plans:
+                p.close()
+    if world == 1:
+        return local
+    return _gather_on_rank0(local, shards, n, group, None)

@@ -211,3 +211,28 @@ def test_sim_order_pad_is_refused_where_it_cannot_apply(grids):
     p = Plan(L.KIND_EMAGLS, "real", 4, 48000.0, 64, 64, 2702, 0.042, 32, sim_order_pad=5)   # below the design's own order: no effect
     assert p.info().sim_order == p.info().sim_order_own == 19
     p.close()
+
+
+def test_job_lists_of_config4_and_config5(grids, hrirs64):
+    """emagls_amd.batch.emagls2_radius_sweep / emagls_from_atf_subjects: the two job lists BASELINE.json names as one call each
+    (single process here; the split over ranks and the gather are covered by the gloo tests)."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    from emagls_amd.batch import emagls2_radius_sweep, emagls_from_atf_subjects
+    radii = [0.031, 0.0312, 0.0335, 0.047, 0.0471, 0.0472, 0.0473, 0.0474, 0.0475, 0.0476]     # 10 radii -> batches of 5 + 5
+    out = emagls2_radius_sweep(hrirs64[0], hrirs64[1], grids["azi"], grids["zen"], radii, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 64)
+    assert len(out) == len(radii)
+    for j in (0, 2, 9):
+        wL, wR = E.getEMagLs2Filters(hrirs64[0], hrirs64[1], grids["azi"], grids["zen"], radii[j], grids["mic_azi"], grids["mic_zen"], 4,
+                                     48000.0, 64, "real")
+        assert rel(out[j][0], wL) < 1e-9 and rel(out[j][1], wR) < 1e-9
+    sub = slice(0, 2702, 3)
+    azi, zen = grids["azi"][sub], grids["zen"][sub]
+    subjects = [synth.rigid_sphere_hrirs(azi, zen, seed=5 + j, head_radius=0.08 + 0.004 * j) for j in range(3)]
+    atf, aazi, azen = synth.glasses_atfs(natf=1024, nmics=6, taps=64)
+    hg, ag = np.column_stack([azi, zen]), np.column_stack([aazi, azen])
+    res = emagls_from_atf_subjects(subjects, hg, atf, ag, 48000.0, 128, 2000.0)
+    assert len(res) == 3
+    for j in range(3):
+        wL, wR = E.getEMagLsFiltersFromAtf(subjects[j][0], subjects[j][1], hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)
+        assert rel(res[j][0], wL) < 1e-11 and rel(res[j][1], wR) < 1e-11

@@ -198,6 +198,13 @@ def binaural_decode(nsamp=120000, nch=25, length=512, reps=10):
     return out
 
 
+def binaural_decode_long(nsamp=4800000, nch=25, length=512, reps=3):
+    """The same render loop on 100 s of audio (4.8 M samples): launch overheads no longer count, what remains is the traffic of
+    the overlap-save passes."""
+    out = binaural_decode(nsamp, nch, length, reps)
+    return out
+
+
 def run():
     out = {}
     for name, radii in (("config4_r5cm", np.linspace(0.0480, 0.0500, 8)), ("config4_r10cm", np.linspace(0.0980, 0.1000, 8))):
@@ -213,6 +220,10 @@ def run():
         out["binaural_decode"] = binaural_decode()
     except Exception as e:
         out["binaural_decode"] = {"error": repr(e)}
+    try:
+        out["binaural_decode_100s"] = binaural_decode_long()
+    except Exception as e:
+        out["binaural_decode_100s"] = {"error": repr(e)}
     try:
         out["config5"] = config5()
     except Exception as e:
