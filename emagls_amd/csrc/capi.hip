@@ -467,7 +467,20 @@ void plan_setup(emagls_plan& p) {
         if (d.kind == EMAGLS_KIND_EMA_SH && d.nmics < 2 * N + 1)
             throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than circular harmonics (2*order+1)");
         p.C = d.kind == EMAGLS_KIND_EMAGLS2 ? (int)d.nmics : p.nOut;
-        if (p.C > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels is not supported in this build");
+        // up to 32 channels / microphones: the tuned per-bin kernels.  33..64 (a 64-capsule array; SH orders 5..7 in the SH domain):
+        // the plain S-space path of wide_array.hip -- real-arithmetic pipeline, simulation order <= 26 (array radius <= 5.9 cm at
+        // 48 kHz), one design at a time
+        if (p.C > 32) {
+            if (p.C > 64) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 64 output channels is not supported in this build");
+            if (d.kind != EMAGLS_KIND_EMAGLS && d.kind != EMAGLS_KIND_EMAGLS2)
+                throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: eMagLS / eMagLS2 only");
+            if (p.custom_basis || p.diffuse || d.sim_order_pad > 0)
+                throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: built-in SH basis, no covariance constraint, no padding");
+            if (p.req_cplx && !p.real_internal) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: the real-arithmetic pipeline only");
+            if (p.simOrder > 26) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: simulation order above 26 (array radius > ~5.9 cm at 48 kHz) "
+                                                                     "is not supported in this build");
+            p.wide = true;
+        }
         if (p.simOrder > 47) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 47 (array radius > ~10.9 cm at 48 kHz) is not supported in this build");
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than simulated SH channels");
         if (d.kind != EMAGLS_KIND_EMAGLS2 && d.kind != EMAGLS_KIND_EMA_SH && d.nmics < p.nOut)
@@ -522,7 +535,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Ymic_cm", esz(cb) * (size_t)p.S * M);                 // [S][M]
         p.alloc("Ymic_rm", esz(cb) * (size_t)ldM * p.ldS);             // [M][ldS]
         p.alloc("E", esz(cb) * (size_t)p.C * p.ldS);                   // [C][ldS]
-        if (d.kind != EMAGLS_KIND_EMAGLS2) {
+        if (d.kind != EMAGLS_KIND_EMAGLS2 && p.nOut <= 32) {
             p.alloc("Ylo_c", sizeof(cplx) * (size_t)p.nOut * ldM);     // [nOut][ldM] complex copy of Y_Lo^T
             p.alloc("Zlo", sizeof(cplx) * (size_t)p.nOut * ldM);
             p.alloc("Vlo", sizeof(cplx) * (size_t)p.nOut * ldM);
@@ -566,6 +579,28 @@ void plan_setup(emagls_plan& p) {
         p.alloc("nvalid", sizeof(int) * 4);
         p.upload("nvalid", &p.simOrderOwn, sizeof(int));
         p.alloc("bn", sizeof(cplx) * (size_t)p.P * (p.simOrder + 1));
+        if (p.wide) {   // wide_array.hip: every bin on the S-space route in global memory, Y_reg_inv of every bin materialised
+            const size_t nb = (size_t)p.P - 1, nOrdW = (size_t)p.simOrder + 1;
+            p.alloc("R", sizeof(double) * (size_t)p.S * p.S);
+            p.alloc("Rinv", sizeof(double) * (size_t)ceil_div(p.S, 32) * 32 * 32);
+            p.alloc("Q", sizeof(double) * (size_t)p.D * p.ldS);
+            p.alloc("Tn", sizeof(double) * nOrdW * p.C * p.ldS);
+            p.alloc("QT", sizeof(double) * nOrdW * p.C * p.ldD);
+            p.alloc("G", sizeof(cplx) * (nb * p.C + 32) * p.ldD, false);
+            p.alloc("Yri", sizeof(cplx) * (nb * p.C + 32) * p.ldD, false);
+            p.alloc("Bw", sizeof(cplx) * nb * p.C * p.ldS, false);
+            p.alloc("Vw", sizeof(cplx) * nb * p.C * p.ldS, false);
+            p.alloc("Zw", sizeof(cplx) * nb * p.C * p.ldS, false);
+            p.alloc("tauw", sizeof(double) * nb * p.C);
+            p.alloc("R2w", sizeof(cplx) * nb * p.C * p.C);
+            p.alloc("Nw", sizeof(cplx) * nb * p.C * p.C);
+            p.alloc("sv", sizeof(double) * (size_t)p.P * p.C);
+            p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
+            if (d.kind == EMAGLS_KIND_EMAGLS && p.nOut > 32) {
+                p.alloc("Ag", sizeof(double) * (size_t)p.nOut * p.nOut);
+                p.alloc("Minv", sizeof(cplx) * (size_t)p.nOut * p.nOut);
+            }
+        } else {
         p.alloc("route", sizeof(int) * (size_t)p.P);
         p.alloc("Gy", esz(cb) * (size_t)p.S * p.S);                    // Gram matrix of conj(Y) (upper block triangle)
         plan_routes(p);
@@ -579,6 +614,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("cond_ok", sizeof(double) * (size_t)p.P);
         p.alloc("QT", esz(cb) * (size_t)(p.simOrder + 1) * p.C * p.ldD);
         if (getenv("EMAGLS_SWEEP_TIMING")) p.alloc("sweep_timing", sizeof(long long) * 16 * (size_t)p.P);
+        }
     }
     if (d.kind == EMAGLS_KIND_FROM_ATF) {
         const int M = p.C;
@@ -613,7 +649,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Hc", sizeof(cplx) * (size_t)2 * n_c * p.ldD);
         p.alloc("Habs", sizeof(double) * (size_t)2 * std::max(p.P - p.kcut0, 1) * p.ldD);
         p.alloc("W", sizeof(cplx) * (size_t)2 * p.P * p.C);
-        if (magls_kind(d.kind) || d.kind == EMAGLS_KIND_FROM_ATF) p.nWG = dense_sweep_nwg((int)Dh);
+        if (magls_kind(d.kind) || d.kind == EMAGLS_KIND_FROM_ATF || p.wide) p.nWG = dense_sweep_nwg((int)Dh);
         p.nWG_dense = dense_sweep_nwg((int)Dh);
         if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) p.sweep_persist = e[0] != '0';
         // the persistent sweep keeps one workgroup per CU resident (142 KB of LDS each): it needs the shape to fit one XCD's
@@ -1182,7 +1218,81 @@ void emagls_post_sweep(emagls_plan& p) {
     p.mark("epilogue");
 }
 
+// eMagLS / eMagLS2 with 33..64 channels: wide_array.hip.  One stream, every bin on the S-space route.
+void execute_emagls_wide(emagls_plan& p) {
+    const emagls_design_desc& d = p.d;
+    hipStream_t st = p.stream;
+    const bool raw = d.kind == EMAGLS_KIND_EMAGLS2;
+    const int M = (int)d.nmics, nOrd = p.simOrder + 1, nb = p.P - 1;
+    const int ls_end = std::min(p.kcut0, p.P), k0 = std::max(p.kcut0, 1);
+    const int64_t g_stride = (int64_t)p.C * p.ldD;
+    // ---- SH matrices, array model, modal terms
+    launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), st);
+    launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), false, p.get("Ycm"), p.ldD, st);
+    launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, false, true, st);
+    launch_sh_basis(p.simOrder, M, p.get<double>("mic_azi"), p.get<double>("mic_zen"), p.get<double>("sh_tab"), false, p.get("Ymic_cm"), M, st);
+    if (raw) {
+        launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("E"), M, p.ldS, false, false, st);   // E = Y_mic
+    } else if (p.nOut <= 32) {
+        const int ldM = round_up(M, 64);
+        launch_transpose_conj(p.get("Ymic_cm"), M, p.S, M, p.get("Ymic_rm"), M, p.ldS, false, false, st);
+        launch_widen(p.get("Ymic_cm"), M, false, p.get("Ylo_c"), ldM, p.nOut, M, false, false, st);
+        FactorArgs a{};
+        a.S = M; a.C = p.nOut; a.ldS = ldM; a.kb0 = 0; a.P = 2;
+        a.Xd = p.get<cplx>("Ylo_c"); a.xd_stride = 0;
+        a.reg_mode = 1; a.tol_dim = (double)std::max(M, p.nOut);
+        a.Z = p.get<cplx>("Zlo"); a.Vws = p.get<cplx>("Vlo");
+        a.tauw = p.get<double>("tau_lo"); a.R2w = p.get<cplx>("R2_lo"); a.Nw = p.get<cplx>("N_lo");
+        launch_factor(a, 1, true, st);
+        launch_small_gemm(p.get("Zlo"), ldM, true, p.get("Ymic_rm"), p.ldS, false, p.get("E"), p.ldS, false, p.nOut, p.S, M, st);
+    } else {
+        // pinv(Y_lo) = (Y_lo^T Y_lo)^-1 Y_lo^T: the M x nOut SH matrix of the microphone grid has full column rank and is well
+        // conditioned for any array that resolves the order (certified on the device like the SH Gram matrix of wide.hip)
+        launch_wa_lo_gram(p.get("Ymic_cm"), M, p.nOut, p.get<double>("Ag"), st);
+        launch_cholesky(p.get("Ag"), p.nOut, false, p.get<int>("flag"), st);
+        launch_gram_inverse(p.get("Ag"), p.nOut, false, p.get("Minv"), p.get<int>("flag"), st);
+        launch_wa_e(p.get("Ymic_cm"), M, p.nOut, p.S, p.get("Minv"), p.get("E"), (int)p.ldS, st);
+    }
+    launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, st, p.get<int>("nvalid"));
+    p.mark("array_model");
+    // ---- HRIR prologue
+    launch_twiddles(p.nfft, p.get("tw"), st);
+    launch_hrir_grpdelay(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, d.ndirs, p.nfft, p.get("tw"), p.get<double>("dirsum"), p.get<double>("grpd"), st);
+    launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"), p.get<double>("grpd"), 0, ls_end, p.kcut0,
+                    p.get("Hc"), p.get<double>("Habs"), p.ldD, st);
+    p.mark("hrir_prologue");
+    // ---- conj(Y) = Q R, order terms T_n = R(:,blk_n) E(:,blk_n)^T and QT_n, G_k of every solved bin
+    launch_gram(p.get("Yc"), p.D, p.S, p.ldS, false, p.get("Gp"), nullptr, p.get("R"), p.S, st);
+    launch_cholesky(p.get("R"), p.S, false, p.get<int>("flag"), st);
+    launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, false, p.get("Q"), st);
+    launch_tn(p.get("R"), p.get("E"), p.S, p.C, (int)p.ldS, nOrd, false, p.get("Tn"), p.ldS, st);
+    launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, false, p.get("QT"), p.ldD, st);
+    launch_dspace_g(p.get("QT"), p.ldD, false, p.get("bn"), nOrd, (int)p.D, p.C, p.P, 1, p.get("G"), st, 0, raw ? -1 : (int)d.order);
+    p.mark("order_terms+G");
+    // ---- per-bin factors (bins 1 .. P-1) and Y_reg_inv
+    launch_wa_assemble(p.get("Tn"), p.get("bn"), nOrd, p.S, p.C, (int)p.ldS, p.P, 1, nb, p.get("Bw"), st);
+    launch_wa_factor(p.get("Bw"), p.get("Vw"), p.S, p.C, (int)p.ldS, nb, SVD_REGUL_CONST, p.get<double>("tauw"), p.get("R2w"), p.get("Nw"),
+                     p.get<double>("sv") + p.C, p.get<int>("jsweeps") + 1, p.get("Zw"), st);
+    launch_wa_yri(p.get("Q"), p.ldS, p.get("Zw"), p.S, p.C, (int)p.ldS, (int)p.D, p.ldD, nb, p.get("Yri"), st);
+    p.mark("factor_bins");
+    // ---- least-squares bins, sweep (G and Yri start at bin 1)
+    launch_wa_ls(p.get("Hc"), p.ldD, ls_end, p.get("Yri"), p.ldD, (int)p.D, p.C, p.P, 1, ls_end, p.get("W"), st);
+    p.mark("ls_bins");
+    DenseSweepArgs a{};
+    a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
+    a.X = p.get<cplx>("G") - g_stride; a.x_stride = g_stride;
+    a.Zd = p.get<cplx>("Yri") - g_stride; a.z_stride = g_stride;
+    a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
+    a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG; a.dpw = 0; a.kfirst = k0;
+    p.sweep_launches = 0;
+    for (int kb = k0; kb < p.P; ++kb) { launch_sweep_wide(a, kb, true, st); ++p.sweep_launches; }
+    if (k0 < p.P) launch_sweep_wide_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
+    p.mark("magls_sweep");
+    emagls_post_sweep(p);
+}
+
 void execute_emagls(emagls_plan& p) {
+    if (p.wide) { execute_emagls_wide(p); return; }
     emagls_pre_sweep(p);
     emagls_run_sweep(p);
     emagls_post_sweep(p);
@@ -2374,6 +2484,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
                 throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH / EMAinSH plans, or FromAtf plans (subjects of one ATF set)");
             if ((p->d.kind == EMAGLS_KIND_FROM_ATF) != (plans[0]->d.kind == EMAGLS_KIND_FROM_ATF))
                 throw Error(EMAGLS_ERR_ARG, "FromAtf plans cannot share a batch with array designs");
+            if (p->wide) throw Error(EMAGLS_ERR_UNSUPPORTED, "designs with more than 32 channels run one at a time");
             if (p->owner) throw Error(EMAGLS_ERR_ARG, "a plan belongs to another batch (destroy that batch first)");
             if (p->device != plans[0]->device) throw Error(EMAGLS_ERR_ARG, "the plans of a batch must live on one device");
             for (int i = 0; i < j; ++i) if (plans[i] == p) throw Error(EMAGLS_ERR_ARG, "the same plan appears twice in the batch");

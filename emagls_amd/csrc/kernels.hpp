@@ -111,6 +111,15 @@ void launch_ypinv_gram(const void* Ycm, int64_t ldD, bool is_cplx, const void* M
 void launch_sweep_wide(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st);
 void launch_sweep_wide_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
 
+// ---- wide_array.hip: eMagLS / eMagLS2 with 33..64 channels
+void launch_wa_assemble(const void* Tn, const void* bn, int nOrd, int S, int C, int ldS, int P, int kb0, int nbins, void* B, hipStream_t st);
+void launch_wa_factor(void* B, void* Vw, int S, int C, int ldS, int nbins, double reg_c, double* tauw, void* R2w, void* Nw, double* sv, int* sweeps,
+                      void* Z, hipStream_t st);
+void launch_wa_yri(const void* Q, int64_t ldQ, const void* Z, int S, int C, int ldS, int D, int64_t ldD, int nbins, void* Yri, hipStream_t st);
+void launch_wa_ls(const void* Hc, int64_t ldH, int n_c, const void* Yri, int64_t ldD, int D, int C, int P, int kb_first, int kb_end, void* W, hipStream_t st);
+void launch_wa_lo_gram(const void* Ycm, int M, int nOut, double* Ag, hipStream_t st);
+void launch_wa_e(const void* Ycm, int M, int nOut, int S, const void* Minv, void* E, int ldE, hipStream_t st);
+
 // ---- dspace.hip
 void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S, int C, int nOrders, bool is_cplx, void* QT,
                int64_t ldD, hipStream_t st);

@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(256) sweep_wide_kernel(DenseSweepArgs a, int k
     const int C = a.C, nWG = a.nWG, tid = threadIdx.x;
     const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * nWG * 2 * C;
     cplx* Wout = a.Wpart + (int64_t)(kb & 1) * nWG * 2 * C;
-    const TX* X = reinterpret_cast<const TX*>(a.X);
-    const TX* Z = reinterpret_cast<const TX*>(a.Zd);
+    const TX* X = reinterpret_cast<const TX*>(a.X) + (int64_t)kb * a.x_stride;   // (strides 0: MagLS, one operand pair for every bin)
+    const TX* Z = reinterpret_cast<const TX*>(a.Zd) + (int64_t)kb * a.z_stride;
     const int64_t d0 = (int64_t)blockIdx.x * 64, na = a.P - a.kabs0;
     const bool first = kb == a.kfirst;
     // ---- W(kb-1,:): the least-squares row for the first swept bin, the sum of the workgroups' partial sums afterwards

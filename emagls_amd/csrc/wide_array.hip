@@ -1,0 +1,361 @@
+// eMagLS / eMagLS2 with 33..64 output channels or microphones (e.g. a 64-capsule array): a plain path for the widths the tuned
+// per-bin kernels (32-column register tiles, factor.hip / gramroute.hip / sweep_persist.hip) do not hold.
+//
+// Reference per bin (lib/getEMagLs2Filters.m:84-99): pwGrid = smairMat(:,:,k) * Y_Hi_conj; [U,s,V] = svd(pwGrid.','econ');
+// s = 1 ./ max(s, 0.01*max(s)); Y_reg_inv = conj(U) * (s .* V.'), then least squares below k_cut and the phase recurrence above.
+//
+// Every bin takes the orthonormal S-space route of factor.hip, in global memory instead of registers:
+//   pwGrid.' = Q B_k,  Q = conj(Y) R^-1 (Cholesky-QR of the HRIR-grid SH matrix),  B_k = R diag(b_n(k)) E^T = sum_n b_n(k) T_n (S x C)
+//   B_k = Q2 R2                      Householder QR, one workgroup per bin (wa_qr_kernel)
+//   R2^H J = A (columns orthogonal)  one-sided Jacobi in LDS on the ROWS of R2 -- the form that is accurate for the row-graded
+//                                    B_k, s_min / s_max down to 1e-13 (wa_jacobi_kernel);  s_j = |a_j|
+//   N = conj(J) diag(s_reg / s) A^T  (C x C),  Z_k = conj(Q2 [conj(N); 0])  (back-transform, wa_back_kernel)
+//   Y_reg_inv_k = conj(Q) Z_k        (D x C, materialised for every bin: wa_yri_kernel)
+// and the sweep runs one launch per bin on G_k = pwGrid_k.' (dspace.hip) and Y_reg_inv_k (wide.hip: sweep_wide_kernel).
+// Slow next to the 32-channel pipeline (tens of milliseconds per design), exact in the same sense.
+#include "kernels.hpp"
+
+namespace emagls {
+
+namespace {
+
+constexpr int WA_CMAX = 64;
+
+__device__ __forceinline__ double block_sum(double v, double* red) {   // all threads of the workgroup receive the sum
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[w];
+    return t;
+}
+
+// B[kb][c][s] = sum_n b_n(kb) Tn[n][c][s]   (T_n is zero for s >= (n+1)^2; Nyquist: real(b_n), getSMAIRMatrix.m:115-117)
+__global__ void __launch_bounds__(256) wa_assemble_kernel(const double* __restrict__ Tn, const cplx* __restrict__ bn, int nOrd, int S, int C, int ldS,
+                                                          int P, int kb0, cplx* __restrict__ B) {
+    const int kb = kb0 + blockIdx.x, c = blockIdx.y;
+    __shared__ cplx bs[96];
+    for (int n = threadIdx.x; n < nOrd; n += 256) {
+        cplx b = bn[(int64_t)kb * nOrd + n];
+        if (kb == P - 1) b.y = 0.0;
+        bs[n] = b;
+    }
+    __syncthreads();
+    cplx* out = B + ((int64_t)blockIdx.x * C + c) * ldS;
+    for (int s = threadIdx.x; s < ldS; s += 256) {
+        cplx acc = mk(0.0, 0.0);
+        if (s < S) {
+            int n0 = (int)sqrt((double)s);
+            while ((n0 + 1) * (n0 + 1) <= s) ++n0;
+            while (n0 > 0 && n0 * n0 > s) --n0;
+            for (int n = n0; n < nOrd; ++n) cfma(acc, bs[n], Tn[((int64_t)n * C + c) * ldS + s]);
+        }
+        out[s] = acc;
+    }
+}
+
+// Householder QR of the S x C matrix of one bin (columns B[c][0..S)), in place: R2 (upper, row major [i][k]) to R2w, the
+// reflector vectors v_j (unnormalised, entries j..S-1) to Vw[c = j], tau_j = 2 / |v_j|^2.
+__global__ void __launch_bounds__(512) wa_qr_kernel(cplx* __restrict__ B, cplx* __restrict__ Vw, int S, int C, int ldS, double* __restrict__ tauw,
+                                                    cplx* __restrict__ R2w) {
+    __shared__ double red[8];
+    __shared__ cplx s_alpha;
+    __shared__ double s_tau;
+    cplx* Bk = B + (int64_t)blockIdx.x * C * ldS;
+    cplx* Vk = Vw + (int64_t)blockIdx.x * C * ldS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int j = 0; j < C; ++j) {
+        cplx* aj = Bk + (int64_t)j * ldS;
+        double n2 = 0.0;
+        for (int s = j + tid; s < S; s += 512) n2 += norm2(aj[s]);
+        n2 = block_sum(n2, red);
+        if (tid == 0) {
+            const cplx x0 = aj[j];
+            const double nx = sqrt(n2), ax = cabs(x0);
+            cplx alpha = mk(-nx, 0.0);
+            if (ax > 0.0) alpha = mk(-x0.x / ax * nx, -x0.y / ax * nx);
+            const double nv2 = 2.0 * nx * (nx + ax);          // |x - alpha e_1|^2
+            s_alpha = alpha;
+            s_tau = nv2 > 0.0 ? 2.0 / nv2 : 0.0;
+        }
+        __syncthreads();
+        const cplx alpha = s_alpha;
+        const double tau = s_tau;
+        cplx* vj = Vk + (int64_t)j * ldS;
+        for (int s = j + tid; s < S; s += 512) {
+            cplx v = aj[s];
+            if (s == j) v = v - alpha;
+            vj[s] = v;
+        }
+        if (tid == 0) tauw[(int64_t)blockIdx.x * C + j] = tau;
+        __syncthreads();   // v_j is complete (global memory, this workgroup)
+        // columns k > j: a_k -= tau v (v^H a_k); a wave per column
+        for (int k = j + 1 + wave; k < C; k += 8) {
+            cplx* ak = Bk + (int64_t)k * ldS;
+            cplx w = mk(0.0, 0.0);
+            for (int s = j + lane; s < S; s += 64) cfma_conj(w, vj[s], ak[s]);
+            w = wave_sum(w);
+            w = mk(w.x * tau, w.y * tau);
+            for (int s = j + lane; s < S; s += 64) { cplx t = mk(0.0, 0.0); cfma(t, vj[s], w); ak[s] = ak[s] - t; }
+        }
+        // column j itself: alpha on the diagonal, zeros below
+        for (int s = j + tid; s < S; s += 512) aj[s] = s == j ? alpha : mk(0.0, 0.0);
+        __syncthreads();
+    }
+    cplx* R2 = R2w + (int64_t)blockIdx.x * C * C;
+    for (int idx = tid; idx < C * C; idx += 512) {
+        const int i = idx / C, k = idx % C;
+        R2[idx] = (i <= k && i < S) ? Bk[(int64_t)k * ldS + i] : mk(0.0, 0.0);
+    }
+}
+
+// One-sided Jacobi on M = R2^H (C x C, columns of M = conjugated rows of R2): M J = A with orthogonal columns a_j = s_j u_j.
+// 32 disjoint column pairs per round (round-robin tournament, C - 1 rounds per sweep), 32 lanes per pair.
+// Output N = conj(J) diag(s_reg / s) A^T (C x C, row major) and the singular values.
+__global__ void __launch_bounds__(1024) wa_jacobi_kernel(const cplx* __restrict__ R2w, int C, double reg_c, cplx* __restrict__ Nw, double* __restrict__ sv,
+                                                         int* __restrict__ sweeps_out) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    const int Cp = (C + 1) & ~1, ld = Cp + 1;            // even column count (a zero column pads an odd C)
+    cplx* A = reinterpret_cast<cplx*>(dyn);               // [Cp][ld]  A[col][row]
+    cplx* J = A + (size_t)Cp * ld;                        // [Cp][ld]  J[col][row]
+    __shared__ int s_rot;
+    __shared__ double s_s[WA_CMAX + 2];
+    const cplx* R2 = R2w + (int64_t)blockIdx.x * C * C;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < Cp * ld; idx += 1024) { A[idx] = mk(0.0, 0.0); J[idx] = mk(0.0, 0.0); }
+    __syncthreads();
+    for (int idx = tid; idx < C * C; idx += 1024) {
+        const int col = idx / C, row = idx % C;          // M[row][col] = conj(R2[col][row])
+        A[col * ld + row] = conj(R2[col * C + row]);
+    }
+    for (int i = tid; i < Cp; i += 1024) J[i * ld + i] = mk(1.0, 0.0);
+    __syncthreads();
+    const int pr = tid >> 5, l32 = tid & 31;             // pair index within the round, lane within the pair
+    const int npairs = Cp / 2;
+    int sweeps = 0;
+    for (int sw = 0; sw < 60; ++sw) {
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+        for (int rnd = 0; rnd < Cp - 1; ++rnd) {
+            if (pr < npairs) {
+                // positions pr and Cp - 1 - pr of the tournament order: position 0 is fixed, the others rotate
+                auto player = [&](int pos) { return pos == 0 ? 0 : 1 + ((pos - 1 - rnd) % (Cp - 1) + (Cp - 1)) % (Cp - 1); };
+                int p = player(pr), q = player(Cp - 1 - pr);
+                if (p > q) { const int t = p; p = q; q = t; }
+                cplx* ap = A + p * ld; cplx* aq = A + q * ld;
+                double al = 0.0, be = 0.0; cplx ga = mk(0.0, 0.0);
+                for (int r = l32; r < Cp; r += 32) { const cplx x = ap[r], y = aq[r]; al += norm2(x); be += norm2(y); cfma_conj(ga, x, y); }
+                al = group_sum<32>(al); be = group_sum<32>(be); ga = group_sum<32>(ga);
+                const double g = sqrt(norm2(ga));
+                if (g > 0.0 && g > 1e-15 * sqrt(al * be)) {
+                    const cplx ph = mk(ga.x / g, ga.y / g);
+                    const double zeta = (be - al) / (2.0 * g);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                    const cplx sph = mk(s * ph.x, s * ph.y), sphc = mk(s * ph.x, -s * ph.y);   // s e^{i phi}, s e^{-i phi}
+                    cplx* jp = J + p * ld; cplx* jq = J + q * ld;
+                    for (int r = l32; r < Cp; r += 32) {
+                        const cplx x = ap[r], y = aq[r];
+                        cplx nx = mk(c * x.x, c * x.y), ny = mk(c * y.x, c * y.y);
+                        cplx t1 = mk(0.0, 0.0), t2 = mk(0.0, 0.0);
+                        cfma(t1, sphc, y); cfma(t2, sph, x);
+                        ap[r] = nx - t1; aq[r] = t2 + ny;
+                        const cplx u = jp[r], v = jq[r];
+                        cplx nu = mk(c * u.x, c * u.y), nv = mk(c * v.x, c * v.y);
+                        cplx t3 = mk(0.0, 0.0), t4 = mk(0.0, 0.0);
+                        cfma(t3, sphc, v); cfma(t4, sph, u);
+                        jp[r] = nu - t3; jq[r] = t4 + nv;
+                    }
+                    if (l32 == 0 && g > 1e-14 * sqrt(al * be)) s_rot = 1;
+                }
+            }
+            __syncthreads();
+        }
+        sweeps = sw + 1;
+        const int again = s_rot;
+        __syncthreads();
+        if (!again) break;
+    }
+    // singular values and their regularised inverses
+    for (int j = tid >> 5; j < Cp; j += 32) {
+        double n2 = 0.0;
+        for (int r = l32; r < Cp; r += 32) n2 += norm2(A[j * ld + r]);
+        n2 = group_sum<32>(n2);
+        if (l32 == 0) s_s[j] = sqrt(n2);
+    }
+    __syncthreads();
+    double smax = 0.0;
+    for (int j = 0; j < C; ++j) smax = fmax(smax, s_s[j]);
+    // (a padded zero column ends as a column of the null space: it is simply not used below -- only the C real columns count,
+    //  and for an odd C the pad column never mixes with the others because its dot products are exactly zero)
+    cplx* N = Nw + (int64_t)blockIdx.x * C * C;
+    for (int idx = tid; idx < C * C; idx += 1024) {
+        const int i = idx / C, k = idx % C;   // N[i][k] = sum_j conj(J[i][j]) (s_reg_j / s_j) A[k][j]   (J[row i][col j] = J[j*ld + i])
+        cplx acc = mk(0.0, 0.0);
+        for (int j = 0; j < Cp; ++j) {
+            const double sj = s_s[j];
+            if (!(sj > 0.0)) continue;
+            const double w = 1.0 / (fmax(sj, reg_c * smax) * sj);
+            const cplx jc = conj(J[j * ld + i]), a = A[j * ld + k];
+            cplx t = mk(0.0, 0.0);
+            cfma(t, jc, a);
+            acc.x += w * t.x; acc.y += w * t.y;
+        }
+        N[idx] = acc;
+    }
+    if (sv) for (int j = tid; j < C; j += 1024) sv[(int64_t)blockIdx.x * C + j] = s_s[j];
+    if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = sweeps;
+}
+
+// Z_k = conj(Q2 [conj(N); 0]): the reflectors applied in reverse to X = [conj(N); 0] (S x C), then the conjugate.  Z[kb][c][s].
+__global__ void __launch_bounds__(512) wa_back_kernel(const cplx* __restrict__ Vw, const double* __restrict__ tauw, const cplx* __restrict__ Nw, int S, int C,
+                                                      int ldS, cplx* __restrict__ Z) {
+    const cplx* Vk = Vw + (int64_t)blockIdx.x * C * ldS;
+    const cplx* N = Nw + (int64_t)blockIdx.x * C * C;
+    cplx* Zk = Z + (int64_t)blockIdx.x * C * ldS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int idx = tid; idx < C * ldS; idx += 512) {
+        const int c = idx / ldS, s = idx % ldS;
+        Zk[idx] = (s < C && s < S) ? conj(N[s * C + c]) : mk(0.0, 0.0);   // X[s][c] = conj(N[s][c])
+    }
+    __syncthreads();
+    for (int j = C - 1; j >= 0; --j) {
+        const cplx* vj = Vk + (int64_t)j * ldS;
+        const double tau = tauw[(int64_t)blockIdx.x * C + j];
+        for (int k = wave; k < C; k += 8) {
+            cplx* xk = Zk + (int64_t)k * ldS;
+            cplx w = mk(0.0, 0.0);
+            for (int s = j + lane; s < S; s += 64) cfma_conj(w, vj[s], xk[s]);
+            w = wave_sum(w);
+            w = mk(w.x * tau, w.y * tau);
+            for (int s = j + lane; s < S; s += 64) { cplx t = mk(0.0, 0.0); cfma(t, vj[s], w); xk[s] = xk[s] - t; }
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < C * ldS; idx += 512) Zk[idx] = conj(Zk[idx]);
+}
+
+// Yri[kb][c][d] = sum_s conj(Q[d][s]) Z[kb][c][s]   (Q real: the real-arithmetic pipeline).  A workgroup: 64 directions x all
+// channels of one bin, S walked in chunks of 32 through LDS.
+__global__ void __launch_bounds__(256) wa_yri_kernel(const double* __restrict__ Q, int64_t ldQ, const cplx* __restrict__ Z, int S, int C, int ldS, int D,
+                                                     int64_t ldD, cplx* __restrict__ Yri) {
+    __shared__ double qs[32][65];
+    __shared__ cplx zs[WA_CMAX][33];
+    const int kbi = blockIdx.y, d0 = blockIdx.x * 64;
+    const cplx* Zk = Z + (int64_t)kbi * C * ldS;
+    const int tid = threadIdx.x, dl = tid & 63, cg = tid >> 6;     // channels cg, cg + 4, ...
+    cplx acc[WA_CMAX / 4];
+#pragma unroll
+    for (int i = 0; i < WA_CMAX / 4; ++i) acc[i] = mk(0.0, 0.0);
+    for (int s0 = 0; s0 < S; s0 += 32) {
+        __syncthreads();
+        for (int idx = tid; idx < 32 * 64; idx += 256) {
+            const int dd = idx >> 5, ss = idx & 31;
+            qs[ss][dd] = (d0 + dd < D && s0 + ss < S) ? Q[(int64_t)(d0 + dd) * ldQ + s0 + ss] : 0.0;
+        }
+        for (int idx = tid; idx < C * 32; idx += 256) {
+            const int c = idx >> 5, ss = idx & 31;
+            zs[c][ss] = (s0 + ss < S) ? Zk[(int64_t)c * ldS + s0 + ss] : mk(0.0, 0.0);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ss = 0; ss < 32; ++ss) {
+            const double q = qs[ss][dl];
+#pragma unroll
+            for (int i = 0; i < WA_CMAX / 4; ++i) {
+                const int c = cg + 4 * i;
+                if (c < C) cfma(acc[i], q, zs[c][ss]);
+            }
+        }
+    }
+    if (d0 + dl < D)
+#pragma unroll
+        for (int i = 0; i < WA_CMAX / 4; ++i) {
+            const int c = cg + 4 * i;
+            if (c < C) Yri[((int64_t)kbi * C + c) * ldD + d0 + dl] = acc[i];
+        }
+}
+
+// least-squares rows: W[e][kb][c] = sum_d Hc[e][kb][d] Yri[kb][c][d]   (kb < n_c)
+__global__ void __launch_bounds__(256) wa_ls_kernel(const cplx* __restrict__ Hc, int64_t ldH, int n_c, const cplx* __restrict__ Yri, int64_t ldD, int D, int C,
+                                                    int P, int kb_first, cplx* __restrict__ W) {
+    const int kb = kb_first + blockIdx.x, e = blockIdx.y;
+    const cplx* h = Hc + ((int64_t)e * n_c + kb) * ldH;
+    const cplx* Y = Yri + (int64_t)(kb - kb_first) * C * ldD;
+    const int part = threadIdx.x & 7;
+    for (int c = threadIdx.x >> 3; c < C; c += 32) {
+        cplx acc = mk(0.0, 0.0);
+        for (int d = part; d < D; d += 8) cfma(acc, h[d], Y[(int64_t)c * ldD + d]);
+        acc = group_sum<8>(acc);
+        if (part == 0) W[((int64_t)e * P + kb) * C + c] = acc;
+    }
+}
+
+// E = pinv(Y_lo) Y_mic with pinv(Y_lo) = (Y_lo^T Y_lo)^-1 Y_lo^T (real basis, full column rank certified by the caller):
+//   Ag[c][c'] = sum_m Ycm[c][m] Ycm[c'][m]   (Ycm = [S][M], rows = SH channels)
+__global__ void wa_lo_gram_kernel(const double* __restrict__ Ycm, int M, int nOut, double* __restrict__ Ag) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nOut * nOut) return;
+    const int c = idx / nOut, c2 = idx % nOut;
+    double acc = 0.0;
+    for (int m = 0; m < M; ++m) acc = fma(Ycm[(int64_t)c * M + m], Ycm[(int64_t)c2 * M + m], acc);
+    Ag[idx] = acc;
+}
+//   E[c][s] = sum_c' Minv[c][c'] sum_m Ycm[c'][m] Ycm[s][m]
+__global__ void wa_e_kernel(const double* __restrict__ Ycm, int M, int nOut, int S, const cplx* __restrict__ Minv, double* __restrict__ E, int ldE) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    if (s >= S) return;
+    double acc = 0.0;
+    for (int c2 = 0; c2 < nOut; ++c2) {
+        double g = 0.0;
+        for (int m = 0; m < M; ++m) g = fma(Ycm[(int64_t)c2 * M + m], Ycm[(int64_t)s * M + m], g);
+        acc = fma(Minv[(int64_t)c * nOut + c2].x, g, acc);
+    }
+    E[(int64_t)c * ldE + s] = acc;
+}
+
+}  // namespace
+
+void launch_wa_assemble(const void* Tn, const void* bn, int nOrd, int S, int C, int ldS, int P, int kb0, int nbins, void* B, hipStream_t st) {
+    if (nbins <= 0) return;
+    if (nOrd > 96) throw Error(2, "wide array path: simulation order above 95");
+    wa_assemble_kernel<<<dim3(nbins, C), 256, 0, st>>>((const double*)Tn, (const cplx*)bn, nOrd, S, C, ldS, P, kb0, (cplx*)B);
+    KERNEL_CHECK();
+}
+void launch_wa_factor(void* B, void* Vw, int S, int C, int ldS, int nbins, double reg_c, double* tauw, void* R2w, void* Nw, double* sv, int* sweeps,
+                      void* Z, hipStream_t st) {
+    if (nbins <= 0) return;
+    if (C > WA_CMAX || S < C) throw Error(2, "wide array path: at most 64 channels and at least as many SH rows");
+    wa_qr_kernel<<<nbins, 512, 0, st>>>((cplx*)B, (cplx*)Vw, S, C, ldS, tauw, (cplx*)R2w);
+    KERNEL_CHECK();
+    const int Cp = (C + 1) & ~1;
+    const size_t dyn = sizeof(cplx) * (size_t)2 * Cp * (Cp + 1);
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) HIP_CHECK(hipFuncSetAttribute((const void*)wa_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    wa_jacobi_kernel<<<nbins, 1024, dyn, st>>>((const cplx*)R2w, C, reg_c, (cplx*)Nw, sv, sweeps);
+    KERNEL_CHECK();
+    wa_back_kernel<<<nbins, 512, 0, st>>>((const cplx*)Vw, tauw, (const cplx*)Nw, S, C, ldS, (cplx*)Z);
+    KERNEL_CHECK();
+}
+void launch_wa_yri(const void* Q, int64_t ldQ, const void* Z, int S, int C, int ldS, int D, int64_t ldD, int nbins, void* Yri, hipStream_t st) {
+    if (nbins <= 0) return;
+    wa_yri_kernel<<<dim3((unsigned)ceil_div(D, 64), nbins), 256, 0, st>>>((const double*)Q, ldQ, (const cplx*)Z, S, C, ldS, D, ldD, (cplx*)Yri);
+    KERNEL_CHECK();
+}
+void launch_wa_ls(const void* Hc, int64_t ldH, int n_c, const void* Yri, int64_t ldD, int D, int C, int P, int kb_first, int kb_end, void* W, hipStream_t st) {
+    if (kb_end <= kb_first) return;
+    wa_ls_kernel<<<dim3(kb_end - kb_first, 2), 256, 0, st>>>((const cplx*)Hc, ldH, n_c, (const cplx*)Yri, ldD, D, C, P, kb_first, (cplx*)W);
+    KERNEL_CHECK();
+}
+void launch_wa_lo_gram(const void* Ycm, int M, int nOut, double* Ag, hipStream_t st) {
+    wa_lo_gram_kernel<<<(unsigned)ceil_div(nOut * nOut, 256), 256, 0, st>>>((const double*)Ycm, M, nOut, Ag);
+    KERNEL_CHECK();
+}
+void launch_wa_e(const void* Ycm, int M, int nOut, int S, const void* Minv, void* E, int ldE, hipStream_t st) {
+    wa_e_kernel<<<dim3((unsigned)ceil_div(S, 256), nOut), 256, 0, st>>>((const double*)Ycm, M, nOut, S, (const cplx*)Minv, (double*)E, ldE);
+    KERNEL_CHECK();
+}
+
+}  // namespace emagls

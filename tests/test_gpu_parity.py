@@ -977,3 +977,35 @@ def test_magls_ill_conditioned_basis_falls_back_for_one_call_only(thin):
     p.close()
     oL, oR = O.getMagLsFilters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 4, 48000.0, 128, "real")
     assert report("MagLS after a fallback call L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
+@pytest.mark.parametrize("fn,order,nmics,basis", [("getEMagLs2Filters", 4, 64, "real"), ("getEMagLs2Filters", 4, 48, "complex"),
+                                                  ("getEMagLsFilters", 6, 64, "real"), ("getEMagLsFilters", 5, 64, "complex"),
+                                                  ("getEMagLsFilters", 7, 64, "real")])
+def test_arrays_with_more_than_32_channels(thin, fn, order, nmics, basis):
+    """A 64-capsule array (lib/getEMagLs2Filters.m:66 takes any microphone count; SH-domain designs of order 5..7 need 36..64
+    microphones): 33..64 channels run on the plain S-space path of wide_array.hip -- Householder QR + one-sided Jacobi of every
+    bin's S x C matrix in global memory / LDS, Y_reg_inv of every bin materialised, one sweep launch per bin."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    maz, mzn = synth.fibonacci_grid(nmics)
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, order, 48000.0, 128, basis)
+    wL, wR = getattr(E, fn)(*args)
+    oL, oR = getattr(O, fn)(*args)
+    C = nmics if fn == "getEMagLs2Filters" else (order + 1) ** 2
+    assert wL.shape == (128, C) and wL.dtype == oL.dtype
+    assert report(f"{fn} N={order} {nmics} mics {basis} L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
+def test_wide_arrays_refuse_what_they_cannot_do(thin):
+    import emagls_amd as E
+    from emagls_amd import synth
+    from emagls_amd._lib import EmaglsError
+    maz, mzn = synth.fibonacci_grid(80)
+    with pytest.raises(EmaglsError, match="more than 64"):
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128)
+    maz, mzn = synth.fibonacci_grid(64)
+    with pytest.raises(EmaglsError, match="simulation order above 26"):
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.08, maz, mzn, 4, 48000.0, 128)
+    with pytest.raises(EmaglsError, match="covariance constraint"):
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128, applyDiffusenessConst=True)

@@ -113,6 +113,32 @@ def config4_rank_share(world=8, rank=5, reps=2):
             "ms_per_share": round(dt * 1e3, 3), "filter_sets_per_s": round(n / dt, 1)}
 
 
+def em64(reps=2):
+    """A 64-capsule array (33..64 channels: the plain S-space path of wide_array.hip): getEMagLs2Filters, 64 microphones,
+    r = 4.2 cm, 2702 directions, 1024 taps -- one design at a time."""
+    from emagls_amd import Plan, synth, _lib as L
+    azi, zen, _, _ = _grids()
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen)
+    maz, mzn = synth.fibonacci_grid(64)
+    p = Plan(L.KIND_EMAGLS2, "real", 4, 48000.0, 1024, hL.shape[0], hL.shape[1], 0.042, 64)
+    p.set_hrir_grid(azi, zen)
+    p.set_mic_grid(maz, mzn)
+    p.set_hrirs(hL, hR)
+    for _ in range(2):
+        p.execute()
+    p.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        p.execute()
+        p.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    p.get_filters()
+    i = p.info()
+    p.close()
+    return {"mics": 64, "radius_cm": 4.2, "taps": 1024, "sim_order": i.sim_order, "ms_per_design": round(dt * 1e3, 2), "filter_sets_per_s": round(1.0 / dt, 1),
+            "device_GB": round(i.device_bytes / 1e9, 2)}
+
+
 def config5(reps=4, subjects=8):
     """BASELINE config 5: one HRTF subject alone, and the batch of 8 subjects of one ATF set (ATF side computed once, one
     resident sweep launch for all subjects)."""
@@ -216,6 +242,10 @@ def run():
         out["config4_rank_share"] = config4_rank_share()
     except Exception as e:
         out["config4_rank_share"] = {"error": repr(e)}
+    try:
+        out["em64_emagls2"] = em64()
+    except Exception as e:
+        out["em64_emagls2"] = {"error": repr(e)}
     try:
         out["binaural_decode"] = binaural_decode()
     except Exception as e:
