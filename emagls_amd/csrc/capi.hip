@@ -294,9 +294,9 @@ int device_cu_count() {
     return n;
 }
 
-void check_pow2(int nfft) {
-    if (nfft < 8 || (nfft & (nfft - 1)) != 0)
-        throw Error(EMAGLS_ERR_UNSUPPORTED, "filter length must give a power-of-two nfft = min(2048, 2*len) in this build");
+// (power-of-two FFT lengths run on the LDS FFTs of fft.hip, any other even length on its direct-DFT kernels)
+void check_nfft(int nfft) {
+    if (nfft < 8) throw Error(EMAGLS_ERR_UNSUPPORTED, "filter length below 4 is not supported");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,7 +418,7 @@ void plan_setup(emagls_plan& p) {
             throw Error(EMAGLS_ERR_ARG, magls_kind(d.kind) ? "HRIR len too short" : "len too short");
         if (!(d.fs > 0)) throw Error(EMAGLS_ERR_ARG, "fs must be positive");
         p.nfft = (int)std::min<int64_t>(NFFT_MAX_LEN, 2 * d.len);
-        check_pow2(p.nfft);
+        check_nfft(p.nfft);
         if (d.len % 2) throw Error(EMAGLS_ERR_ARG, "filter length must be even");
         // nfft is capped at NFFT_MAX_LEN: a longer filter makes the reference index wMlsL(n_shift-len/2+1 : n_shift+len/2) with a
         // non-positive start (lib/getEMagLsFilters.m:135-136) and fail; the kernels would read outside their LDS buffers.

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(1024) grpdelay_median_kernel(const double* __r
         if (k < P) {
             cplx num = mk(0, 0), den = mk(0, 0);
             for (int64_t n = 0; n < L; ++n) {
-                const cplx w = tw[(int)(((int64_t)k * n) & (nfft - 1))];  // nfft is a power of two
+                const cplx w = tw[(int)(((int64_t)k * n) % nfft)];
                 cfma(den, b[n], w);
                 cfma(num, (double)n * b[n], w);
             }
@@ -454,9 +454,157 @@ __global__ void __launch_bounds__(256) filter_epilogue_kernel(const cplx* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same three transforms for an FFT length that is not a power of two (lib/getEMagLsFilters.m:44: nfft = min(2048, 2*len)
+// for any even len), as direct DFTs: the HRIRs have ~128 taps and only len output samples of the inverse transform are kept,
+// so O(N L) costs a few GFLOP at most.  Same outputs, same quirks (Nyquist phase forced real, DC rule, mirror rules).
+// ---------------------------------------------------------------------------------------------
+constexpr int HD_TD = 8;
+__global__ void __launch_bounds__(256) hrir_dft_kernel(const double* __restrict__ hL, const double* __restrict__ hR, int64_t L, int64_t D,
+                                                       const int64_t* __restrict__ didx, int nfft, const cplx* __restrict__ tw,
+                                                       const double* __restrict__ grpd, int mode, int n_c, int kabs0, cplx* __restrict__ Hc,
+                                                       double* __restrict__ Habs, int64_t ldD, double* __restrict__ HcT, int ldT, int td, size_t bstride) {
+    hL = boff(hL, bstride); hR = boff(hR, bstride); didx = boff(didx, bstride); tw = boff(tw, bstride); grpd = boff(grpd, bstride);
+    Hc = boff(Hc, bstride); Habs = boff(Habs, bstride); HcT = boff(HcT, bstride);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* hs = reinterpret_cast<double*>(smem);   // [td][2][L]
+    const int P = nfft / 2 + 1;
+    const int64_t d0 = (int64_t)blockIdx.x * td;
+    const int nt = (int)min((int64_t)td, D - d0);
+    for (int64_t idx = threadIdx.x; idx < (int64_t)nt * 2 * L; idx += blockDim.x) {
+        const int t = (int)(idx / (2 * L)), e = (int)((idx / L) & 1);
+        const int64_t n = idx % L;
+        const int64_t dsrc = didx ? didx[d0 + t] : d0 + t;
+        hs[idx] = (e ? hR : hL)[dsrc * L + n];
+    }
+    __syncthreads();
+    const double g[2] = {grpd[0], grpd[1]};
+    const int64_t na = P - kabs0;
+    for (int kb = threadIdx.x; kb < P; kb += blockDim.x) {
+        cplx ph[2];
+        for (int e = 0; e < 2; ++e) {
+            if (mode == 0) {   // exp(-1j*2*pi*omega*(-grpD)), Nyquist bin forced real (applySubsampleDelay.m:12)
+                double sn, cs;
+                sincos((6.283185307179586 * ((double)kb / (double)nfft)) * g[e], &sn, &cs);
+                if (kb == P - 1) sn = 0.0;
+                ph[e] = mk(cs, sn);
+            } else {           // circshift by -round(grpD): exp(+2 pi i kb s / nfft), an exact table entry
+                const int64_t sft = (int64_t)round(g[e]);
+                int64_t j = (-(int64_t)kb * sft) % nfft;
+                if (j < 0) j += nfft;
+                ph[e] = tw[j];
+            }
+        }
+        for (int t = 0; t < nt; ++t) {
+            cplx H[2] = {mk(0.0, 0.0), mk(0.0, 0.0)};
+            const double* h0 = hs + (int64_t)t * 2 * L;
+            int j = 0;
+            for (int64_t n = 0; n < L; ++n) {
+                const cplx w = tw[j];
+                cfma(H[0], h0[n], w); cfma(H[1], h0[L + n], w);
+                j += kb; if (j >= nfft) j -= nfft;
+            }
+            const int64_t d = d0 + t;
+            for (int e = 0; e < 2; ++e) {
+                const cplx v = H[e] * ph[e];
+                if (kb < n_c) {
+                    Hc[((int64_t)e * n_c + kb) * ldD + d] = v;
+                    if (HcT) { double* row = HcT + d * ldT; row[2 * (e * n_c + kb)] = v.x; row[2 * (e * n_c + kb) + 1] = v.y; }
+                }
+                if (kb >= kabs0) Habs[((int64_t)e * na + (kb - kabs0)) * ldD + d] = sqrt(norm2(v));
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) real_dft_gather_kernel(const double* __restrict__ x, int64_t L, int64_t ncols, const int64_t* __restrict__ colidx,
+                                                              int nfft, const cplx* __restrict__ tw, cplx* __restrict__ out, int64_t ldo, int64_t inner,
+                                                              int64_t ld_inner) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* xs = reinterpret_cast<double*>(smem);   // [L]
+    const int64_t j = blockIdx.x;
+    const int P = nfft / 2 + 1;
+    const double* col = x + (colidx ? colidx[j] : j) * L;
+    for (int64_t n = threadIdx.x; n < L; n += blockDim.x) xs[n] = col[n];
+    __syncthreads();
+    for (int kb = threadIdx.x; kb < P; kb += blockDim.x) {
+        cplx acc = mk(0.0, 0.0);
+        int jj = 0;
+        for (int64_t n = 0; n < L && n < nfft; ++n) { cfma(acc, xs[n], tw[jj]); jj += kb; if (jj >= nfft) jj -= nfft; }
+        out[(int64_t)kb * ldo + (j / inner) * ld_inner + (j % inner)] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) filter_epilogue_dft_kernel(const cplx* __restrict__ W, int C, int nfft, int len, const cplx* __restrict__ tw,
+                                                                  const double* __restrict__ grpd, int conj_mode, int dc_rule, int shift_mode, int out_cplx,
+                                                                  double fade_rel, void* __restrict__ outL, void* __restrict__ outR, size_t bstride) {
+    W = boff(W, bstride); tw = boff(tw, bstride); grpd = boff(grpd, bstride); outL = boff(outL, bstride); outR = boff(outR, bstride);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* buf = reinterpret_cast<cplx*>(smem);   // the full spectrum, nfft entries
+    const int c = blockIdx.x, e = blockIdx.y;
+    const int P = nfft / 2 + 1;
+    const cplx* We = W + (size_t)e * P * C;
+    int cpart = c;
+    double sgn = 1.0;
+    if (conj_mode == 1) {
+        const int n = (int)floor(sqrt((double)c));
+        const int m = c - n * n - n;
+        cpart = n * n + n - m;
+        sgn = (m & 1) ? -1.0 : 1.0;
+    } else if (conj_mode == 2) {
+        cpart = (c == 0) ? 0 : ((c & 1) ? c + 1 : c - 1);
+    }
+    const int n_shift = nfft / 2;
+    const double delay = (e == 0) ? (double)n_shift : ((double)n_shift + grpd[1]) - grpd[0];
+    for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
+        cplx v;
+        int kb;
+        if (k < P) {
+            kb = k;
+            v = We[(size_t)kb * C + c];
+            if (kb == 0 && dc_rule) v = mk(We[(size_t)1 * C + c].x, 0.0);
+        } else {
+            kb = nfft - k;
+            v = conj(We[(size_t)kb * C + cpart]);
+            v.x *= sgn; v.y *= sgn;
+        }
+        if (shift_mode == 0) {
+            const double omega = (double)kb / (double)nfft;
+            double sn, cs;
+            sincos((6.283185307179586 * omega) * delay, &sn, &cs);
+            cplx E = mk(cs, -sn);
+            if (kb == P - 1) E.y = 0.0;
+            if (k >= P) E.y = -E.y;
+            v = v * E;
+        }
+        buf[k] = v;
+    }
+    __syncthreads();
+    const double inv_n = 1.0 / (double)nfft;
+    const int nf = (int)round(fade_rel * (double)len);
+    const int t0 = n_shift - len / 2;
+    for (int tt = threadIdx.x; tt < len; tt += blockDim.x) {
+        int t = t0 + tt;
+        if (shift_mode == 1) { t = (t - n_shift) % nfft; if (t < 0) t += nfft; }
+        cplx v = mk(0.0, 0.0);
+        int j = 0;
+        for (int k = 0; k < nfft; ++k) { cfma(v, buf[k], conj(tw[j])); j += t; if (j >= nfft) j -= nfft; }   // ifft: exp(+2 pi i k t / nfft)
+        double win = 1.0;
+        if (tt < nf || tt >= len - nf) {
+            int i = (tt < nf) ? tt : (2 * nf - 1 - (nf + (tt - (len - nf))));
+            win = 0.5 - 0.5 * cos(2.0 * kPi * (double)i / (double)(2 * nf - 1));
+        }
+        v.x *= inv_n * win;
+        v.y *= inv_n * win;
+        if (out_cplx) reinterpret_cast<cplx*>(e ? outR : outL)[(size_t)c * len + tt] = v;
+        else reinterpret_cast<double*>(e ? outR : outL)[(size_t)c * len + tt] = v.x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 void launch_twiddles(int nfft, void* tw, hipStream_t st) {
     twiddle_kernel<<<bgrid((nfft + 255) / 256), 256, 0, st>>>(nfft, (cplx*)tw, batch_ctx().stride);
@@ -482,6 +630,15 @@ void launch_hrir_grpdelay(const double* hL, const double* hR, int64_t L, int64_t
 void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, const int64_t* didx, int nfft,
                      const void* tw, const double* grpd, int mode, int n_c, int kabs0, void* Hc, double* Habs,
                      int64_t ldD, hipStream_t st, double* HcT, int ldT) {
+    if (!is_pow2(nfft)) {   // direct DFT (hrir_dft_kernel)
+        int td = HD_TD;
+        while (td > 1 && (size_t)td * 2 * L * 8 > 48 * 1024) td >>= 1;
+        if ((size_t)td * 2 * L * 8 > 64 * 1024) throw Error(2, "HRIR DFT: more than 4096 taps is not supported");
+        hrir_dft_kernel<<<bgrid((unsigned)ceil_div(D, td)), 256, (size_t)td * 2 * L * 8, st>>>(hL, hR, L, D, didx, nfft, (const cplx*)tw, grpd, mode, n_c, kabs0,
+                                                                                                (cplx*)Hc, Habs, ldD, HcT, ldT, td, batch_ctx().stride);
+        KERNEL_CHECK();
+        return;
+    }
     const int log2n = ilog2(nfft);
     const int P = nfft / 2 + 1;
     if (P > HF_MAXS * 512) throw Error(2, "HRIR FFT: nfft above 2048 is not supported");
@@ -515,6 +672,12 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
 
 void launch_real_fft_gather(const double* x, int64_t L, int64_t ncols, const int64_t* colidx, int nfft, const void* tw,
                             void* out, int64_t ldo, int64_t inner, int64_t ld_inner, hipStream_t st) {
+    if (!is_pow2(nfft)) {   // direct DFT, one workgroup per column
+        if ((size_t)L * 8 > 64 * 1024) throw Error(2, "ATF DFT: more than 8192 taps is not supported");
+        real_dft_gather_kernel<<<(unsigned)ncols, 256, (size_t)L * 8, st>>>(x, L, ncols, colidx, nfft, (const cplx*)tw, (cplx*)out, ldo, inner, ld_inner);
+        KERNEL_CHECK();
+        return;
+    }
     const int log2n = ilog2(nfft);
     int TP = 8;
     while (TP > 1 && (size_t)TP * nfft * 16 + (size_t)nfft * 8 > 150 * 1024) TP >>= 1;
@@ -532,6 +695,14 @@ void launch_real_fft_gather(const double* x, int64_t L, int64_t ncols, const int
 void launch_filter_epilogue(const void* W, int C, int nfft, int len, const void* tw, const double* grpd, int conj_mode,
                             int dc_rule, int shift_mode, int out_cplx, void* outL, void* outR, hipStream_t st, int n_ears,
                             double fade_rel) {
+    if (!is_pow2(nfft)) {   // direct inverse DFT of the len samples that are kept
+        const size_t smd = (size_t)nfft * 16;
+        if (smd > 64 * 1024) throw Error(2, "filter epilogue: a non-power-of-two FFT length above 4096 is not supported");
+        filter_epilogue_dft_kernel<<<bgrid(dim3(C, n_ears)), 256, smd, st>>>((const cplx*)W, C, nfft, len, (const cplx*)tw, grpd, conj_mode, dc_rule, shift_mode,
+                                                                           out_cplx, fade_rel, outL, outR, batch_ctx().stride);
+        KERNEL_CHECK();
+        return;
+    }
     const int log2n = ilog2(nfft);
     const size_t sm = (size_t)nfft * 16 + (size_t)nfft * 8;
     if (sm > 48 * 1024) {   // (only the radial-filter IRs get here: the designs stop at nfft = 2048)

@@ -96,8 +96,8 @@ int emagls_apply_radial_filter(const double* sig, int64_t nsamp, int order, doub
         if (nsamp < 0) throw Error(EMAGLS_ERR_ARG, "invalid shape");
         check_radial_args(order, fs, sma_radius, ir_len, oversampling, filter_type, noise_gain_db);
         const int64_t nfft = ir_len * oversampling;
-        if (!is_pow2(nfft) || nfft < 8 || nfft > 4096)
-            throw Error(EMAGLS_ERR_UNSUPPORTED, "radial-filter FFT length must be a power of two in [8, 4096] in this build");
+        if (nfft % 2 || nfft < 8 || nfft > 4096)
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "radial-filter FFT length must be even and in [8, 4096] in this build");
         const int P = (int)(nfft / 2 + 1), nOrd = order + 1, C = nOrd * nOrd;
         const int64_t n = std::max(nsamp, nfft);     // applyRadialFilter.m:20-22: shorter signals are zero-padded to nfft
         Scratch s;
@@ -170,7 +170,7 @@ EqSetup eq_setup(Scratch& s, double radius, int order, double fs, int64_t len) {
     if (len % 2) throw Error(EMAGLS_ERR_ARG, "filter length must be even");
     EqSetup e{};
     e.nfft = (int)std::min<int64_t>(NFFT_MAX_LEN, 2 * len);
-    if (!is_pow2(e.nfft)) throw Error(EMAGLS_ERR_UNSUPPORTED, "FFT length min(2048, 2*len) must be a power of two in this build");
+    if (e.nfft < 8) throw Error(EMAGLS_ERR_UNSUPPORTED, "filter length below 4 is not supported");
     if (len > e.nfft) throw Error(EMAGLS_ERR_ARG, "len exceeds the oversampled FFT length min(2048, 2*len): the reference fails with an index error");
     e.P = e.nfft / 2 + 1;
     e.simOrder = (int)std::ceil(fs * kPi * radius / C_SOUND);     // (no max(order, .) here: SphericalHeadFilter.m:31)

@@ -1009,3 +1009,27 @@ def test_wide_arrays_refuse_what_they_cannot_do(thin):
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.08, maz, mzn, 4, 48000.0, 128)
     with pytest.raises(EmaglsError, match="covariance constraint"):
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128, applyDiffusenessConst=True)
+
+
+@pytest.mark.parametrize("length", [100, 150, 300])
+def test_filter_lengths_whose_fft_length_is_not_a_power_of_two(grids, thin, length):
+    """nfft = min(2048, 2*len) for any even len (lib/getEMagLsFilters.m:44): lengths such as 100, 150, 300 give nfft = 200, 300, 600.
+    Those run on direct-DFT kernels (prologue, ATF spectra, epilogue) instead of the LDS FFTs; every design against the oracle."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    hL, hR = thin["hL"][:64], thin["hR"][:64]
+    a = (hL, hR, thin["azi"], thin["zen"])
+    wL, wR = E.getMagLsFilters(*a, 4, 48000.0, length, "real")
+    oL, oR = O.getMagLsFilters(*a, 4, 48000.0, length, "real")
+    assert wL.shape == (length, 25)
+    assert report(f"MagLS len {length} L", wL, oL) < TOL and report("R", wR, oR) < TOL
+    for fn, basis in (("getEMagLsFilters", "complex"), ("getEMagLs2Filters", "real")):
+        args = a + (0.042, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, length, basis)
+        wL, wR = getattr(E, fn)(*args)
+        oL, oR = getattr(O, fn)(*args)
+        assert report(f"{fn} {basis} len {length} L", wL, oL) < TOL and report("R", wR, oR) < TOL
+    atf, aazi, azen = synth.glasses_atfs(natf=1024, nmics=6, taps=48)
+    hg, ag = np.column_stack([thin["azi"], thin["zen"]]), np.column_stack([aazi, azen])
+    wL, wR = E.getEMagLsFiltersFromAtf(hL, hR, hg, atf, ag, 48000.0, length, 2000.0, verbose=False)
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(hL, hR, hg, atf, ag, 48000.0, length, 2000.0)
+    assert report(f"FromAtf len {length} L", wL, oL) < TOL and report("R", wR, oR) < TOL

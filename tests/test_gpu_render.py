@@ -270,3 +270,18 @@ def test_get_smair_matrix_defaults_are_the_references(grids):
     assert rel(sm, so) < 1e-11
     with pytest.raises(KeyError):      # the reference would load its t-design file here; the mirror asks for the grid
         E.getSMAIRMatrix(irLen=32, returnRawMicSigs=True)
+
+
+def test_render_side_with_fft_lengths_that_are_not_powers_of_two():
+    """The equalisation filters (nfft = min(2048, 2*len)) and the radial-filter chain (nfft = oversamplingFactor * irLen) at
+    lengths such as 120 -> 240 and 100 x 2 -> 200."""
+    import emagls_amd as E
+    w, Wf = E.getMagLsSphericalHeadFilter(0.0875, 3, 44100.0, 120)
+    ow, oW = O.getMagLsSphericalHeadFilter(0.0875, 3, 44100.0, 120)
+    assert w.shape == (120, 1) and Wf.shape == (240, 1) and rel(w[:, 0], ow) < 1e-9 and rel(Wf[:, 0], oW) < 1e-9
+    rng = np.random.default_rng(2)
+    sig = rng.standard_normal((900, 9))
+    params = dict(order=2, fs=48000.0, smaRadius=0.042, arrayType="rigid", irLen=100, oversamplingFactor=2, nfft=200, radialFilter="tikhonov")
+    out = E.applyRadialFilter(sig, params)
+    ref = O.applyRadialFilter(sig, 2, 48000.0, 0.042, 100, 2, radialFilter="tikhonov")
+    assert out.shape == ref.shape and rel(out, ref) < 1e-9
