@@ -3,8 +3,9 @@
 The fixtures under resources/ were computed from HRIR_L2702.mat, which the reference does not ship
 (.MISSING_LARGE_BLOBS), so these tests are skipped unless the user supplies that HRIR set as plain arrays:
 
-    EMAGLS_HRIR_FILE=/path/to/hrir_l2702.npz | .mat    (emagls_amd.io.load_hrir_set: hL, hR [numSamples x 2702] or the MIRO
-                                                        field names irChOne / irChTwo; 48 kHz, the fixture grid order)
+    EMAGLS_HRIR_FILE=/path/to/HRIR_L2702.sofa | .mat | .npz    (emagls_amd.io.load_hrir_set: the published SOFA file, a MAT
+                                                        file with irChOne / irChTwo ..., or hL, hR [numSamples x 2702];
+                                                        48 kHz, the fixture grid order)
     (EMAGLS_HRIR_NPZ is still read, for the same thing.)
 
 They then compare, with the reference's own assertAllClose rule (verifyEMagLs.m:370-395), all eight reachable fixture

@@ -91,4 +91,128 @@ def test_load_hrir_set_errors(tmp_path):
     with pytest.raises(ValueError, match="grid angles"):
         IO.load_hrir_set(str(tmp_path / "grid.mat"))
     with pytest.raises(ValueError, match="unsupported"):
+        IO.load_hrir_set(str(tmp_path / "x.wav"))
+    (tmp_path / "x.sofa").write_bytes(b"not an HDF5 file at all")
+    with pytest.raises(ValueError, match="not an HDF5 file"):
         IO.load_hrir_set(str(tmp_path / "x.sofa"))
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _check_set(d, e, tol=0.0):
+    assert d["hL"].shape == e["hL"].shape and d["hL"].dtype == np.float64
+    for k in ("hL", "hR", "azi", "zen"):
+        assert np.abs(d[k] - e[k]).max() <= max(tol, 2e-15), k
+    assert d["fs"] == float(e["fs"])
+
+
+def test_load_hrir_set_from_the_sofa_twin_and_from_mat_v73():
+    """f3: the published set's SOFA container (netCDF-4 / HDF5: creation-order-tracked root group with dense link and
+    attribute storage, Data.IR chunked + shuffled + deflated) and a -v7.3 MAT file (HDF5 behind a 512-byte user block,
+    column-major data) -- committed files written by libhdf5 1.10.6 (tests/h5gen.py), read by emagls_amd/hdf5_min.py."""
+    e = np.load(os.path.join(GOLD, "hrir_small_expected.npz"))
+    _check_set(IO.load_hrir_set(os.path.join(GOLD, "hrir_small.sofa")), e)
+    _check_set(IO.load_hrir_set(os.path.join(GOLD, "hrir_small_v73.mat")), e)
+    from emagls_amd import hdf5_min as H5
+    f = H5.File(os.path.join(GOLD, "hrir_small.sofa"))
+    assert f.attrs["SOFAConventions"] == "SimpleFreeFieldHRIR" and len(f.attrs) == 16 and len(f.keys()) == 15
+    kinds = {m[0] for m in f._msgs}
+    assert 0x02 in kinds and 0x11 not in kinds      # link info message, no symbol table: the dense link storage was read
+    assert f["Data.IR"]._filters and f["Data.IR"].shape == (38, 2, 24)
+    assert f["SourcePosition"].attrs == {"Type": "spherical", "Units": "degree, degree, metre"}
+
+
+def _libhdf5():
+    import h5gen
+    return h5gen.find_libhdf5()
+
+
+@pytest.mark.skipif("_libhdf5() is None", reason="libhdf5 (test tooling) not in this image")
+@pytest.mark.parametrize("kw", [dict(latest=True), dict(vlen_attrs=True), dict(chunked=False, ir_dtype="f4"),
+                                dict(position_type="cartesian")])
+def test_sofa_variants_written_by_libhdf5(tmp_path, kw):
+    """Newest file format (superblock 3, version-2 object headers, fixed-array chunk index), variable-length string
+    attributes (global heap), contiguous single-precision data, Cartesian source positions."""
+    import h5gen
+    hs = h5gen.small_hrir_set(seed=11, ndirs=50, nsamp=32)
+    f = str(tmp_path / "v.sofa")
+    h5gen.write_sofa(f, hs, **kw)
+    _check_set(IO.load_hrir_set(f), hs, tol=1e-6 if "ir_dtype" in kw else 1e-12)
+
+
+@pytest.mark.skipif("_libhdf5() is None", reason="libhdf5 (test tooling) not in this image")
+@pytest.mark.parametrize("latest", [False, True])
+@pytest.mark.parametrize("track", [False, True])
+def test_hdf5_reader_on_large_groups_and_filtered_chunks(tmp_path, latest, track):
+    """300 links in one group (symbol-table B-tree with several nodes / fractal heap with indirect blocks and a version-2
+    B-tree of depth > 0), 40 attributes on one object, big-endian + shuffle + deflate + fletcher32 chunks with partial edge
+    chunks, a paged fixed-array index (1750 chunks), fixed-length strings, nested groups."""
+    import h5gen
+    from emagls_amd import hdf5_min as H5
+    rng = np.random.default_rng(0)
+    w = h5gen.Writer(str(tmp_path / "m.h5"), latest=latest, track_order=track)
+    w.group("g")
+    w.group("g/sub")
+    exp = {}
+    for i in range(300):
+        exp["g/sub/ds_%03d_long_name_to_fill_heaps" % i] = rng.standard_normal((3, i % 5 + 1))
+        w.dataset("g/sub/ds_%03d_long_name_to_fill_heaps" % i, exp["g/sub/ds_%03d_long_name_to_fill_heaps" % i])
+    for i in range(40):
+        w.attr("g", "attr%02d" % i, np.arange(i + 1, dtype=np.int32))
+    w.dataset("be", np.arange(12, dtype="f8").reshape(3, 4), big_endian=True, chunks=(2, 3), fletcher=True, deflate=2, shuffle=True)
+    big = rng.standard_normal((70, 50))
+    w.dataset("paged", big, chunks=(2, 1), deflate=1)
+    w.dataset("s", np.array([b"ab", b"cde"], dtype="S4"))
+    w.close()
+    f = H5.File(str(tmp_path / "m.h5"))
+    assert sorted(f["g/sub"].keys()) == sorted(k.split("/")[-1] for k in exp)
+    assert all(np.array_equal(f[k].read(), v) for k, v in exp.items())
+    at = f["g"].attrs
+    assert len(at) == 40 and all(np.array_equal(at["attr%02d" % i], np.arange(i + 1)) for i in range(40))
+    if latest:
+        assert 0x15 in {m[0] for m in f["g"]._msgs}      # attribute info message: dense attribute storage was read
+    assert np.array_equal(f["be"].read(), np.arange(12.0).reshape(3, 4)) and np.array_equal(f["paged"].read(), big)
+    assert f["s"].read().tolist() == ["ab", "cde"]
+    with pytest.raises(KeyError):
+        f["g/nothing"]
+
+
+def test_mat_v73_object_variable_is_refused_with_the_way_out(tmp_path):
+    if _libhdf5() is None:
+        pytest.skip("libhdf5 (test tooling) not in this image")
+    import h5gen
+    w = h5gen.Writer(str(tmp_path / "o.mat"), userblock=512)
+    w.group("HRIR_L2702")
+    w.attr("HRIR_L2702", "MATLAB_class", "miro")
+    w.close()
+    h5gen.stamp_mat73_header(str(tmp_path / "o.mat"))
+    with pytest.raises(ValueError, match="class 'miro'"):
+        IO.load_hrir_set(str(tmp_path / "o.mat"))
+
+
+def test_load_hrir_set_from_a_classdef_object(tmp_path):
+    """A -v7 file holding the MIRO instance itself (opaque variable + subsystem element).  The file is built by
+    tests/mcosgen.py from the layout emagls_amd/mcos.py describes -- a consistency test of the decoder, not a check against
+    MATLAB's output (none exists in the image)."""
+    import mcosgen
+    hL, hR, azi, zen = _hrir_arrays()
+    props = dict(irChOne=hL.astype(np.float32), irChTwo=hR.astype(np.float32), azimuth=azi[None, :], elevation=zen[None, :],
+                 fs=np.array([[48000.0]]), name="HRIR_L2702")
+    for version in (2, 3, 4):
+        f = str(tmp_path / ("obj%d.mat" % version))
+        mcosgen.write_object_mat(f, "HRIR_L2702", "miro", props, defaults=dict(radius=np.array([[3.25]])), version=version)
+        d = IO.load_hrir_set(f)
+        assert np.allclose(d["hL"], hL, atol=1e-6) and np.array_equal(d["azi"], azi) and np.array_equal(d["zen"], zen) and d["fs"] == 48000.0
+    from emagls_amd import mcos
+    objs = mcos.object_properties(sio.loadmat(f, struct_as_record=False))
+    cls, p = objs["HRIR_L2702"]
+    assert cls == "miro" and float(np.asarray(p["radius"]).ravel()[0]) == 3.25          # a property the object leaves unset reads as the class default
+    mcosgen.write_object_mat(f, "other", "thing", dict(a=np.zeros((2, 2))))
+    with pytest.raises(ValueError, match="no irChOne"):
+        IO.load_hrir_set(f)
+    raw = bytearray(open(f, "rb").read())
+    raw[-200:] = b"\0" * 200
+    (tmp_path / "broken.mat").write_bytes(bytes(raw))
+    with pytest.raises(Exception):
+        IO.load_hrir_set(str(tmp_path / "broken.mat"))
