@@ -1136,7 +1136,7 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     a.timing = p.has("sweep_timing") ? p.get<long long>("sweep_timing") : nullptr;
     const char* fg = getenv("EMAGLS_PERSIST_GLOBAL");
     a.force_global = (fg && fg[0] == '1') ? 1 : 0;
-    static const int fetch_mode = [] { const char* e = getenv("EMAGLS_SWEEP_FETCH"); return e ? std::max(0, std::min(3, atoi(e))) : 0; }();
+    static const int fetch_mode = [] { const char* e = getenv("EMAGLS_SWEEP_FETCH"); return e ? std::max(0, std::min(4, atoi(e))) : 0; }();
     a.fetch_mode = fetch_mode;
     return a;
 }

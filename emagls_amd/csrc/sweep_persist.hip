@@ -1,4 +1,4 @@
-// Persistent form of the halved MagLS phase sweep: ONE launch walks all swept bins of up to 8 designs.
+// Persistent form of the halved MagLS phase sweep: ONE launch walks all swept bins of up to 16 designs.
 //
 // Reference recurrence (lib/getEMagLsFilters.m:95-103): W(k,:) depends on W(k-1,:), so the bins are a chain of
 // P - k_cut dependent steps.  The launch-per-bin kernels (sweep.hip) pay a kernel boundary per step: cold L2s
@@ -38,7 +38,6 @@ namespace {
 // thread) + one communication wave.  One workgroup per CU (register budget), and a design's workgroups share an
 // XCD (32 CUs), so nWG = ceil(D / DPW) must not exceed 32: DPW = 64 up to 2048 directions, 96 up to 3072.
 constexpr int PS_CMAX = 32;
-constexpr int PS_NI = PS_CMAX / 4;  // channels per lane (p phase), rows of M per lane
 constexpr unsigned PS_SPIN_LIMIT = 1u << 21;
 typedef unsigned long long u64;
 
@@ -103,15 +102,25 @@ template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and
 //   tid < 256            M and partial phases: (pair, quarter); fetch and stage M
 //   tid >= 192 (wave 3)  communication wave: besides its share of the M and partial phases it runs the exchange (it issues
 //                        no operand loads of G, so its polls never queue behind an HBM miss in the wave's in-order memory queue)
-// One LDS buffer (77 KB) and four waves: a launch sweeps up to 16 designs, two per XCD, two workgroups per CU.
+// One LDS buffer (77 KB) and four waves per slab.
+// NH = 1: one slab per workgroup (256 threads); a launch sweeps up to 8 designs, one per XCD.
+// NH = 2 ("twin" workgroups, 512 threads, 9-16 designs per launch, two per XCD): a workgroup carries TWO slabs of the same
+//   design -- threads 0-255 the slab 2 member, threads 256-511 the slab 2 member + 1 -- and publishes two partials per pair,
+//   so the exchange sees 2 nWG producers as before; the halves share the communication wave, M, vt and Wp.  Two
+//   independent 256-thread workgroups of DIFFERENT designs on one CU (the round-3 form of 16-design launches) cost
+//   +0.5..0.9 us in hop 1 and +0.5 us in hop 2 per bin (5.7-6.0 us against 4.36 us, tools/sweep_timing.py 16): a CU's vector
+//   memory pipeline returns in order across its waves, so one design's polls queued behind the other design's operand
+//   loads (HBM misses), whose phases are not aligned with its own.  The two slabs of a twin move in lock step: their loads
+//   are issued after B1 / B3 and have drained when the exchange starts, exactly as with one slab per CU.
 constexpr int PS_NT = 256, PS_COMM0 = 192;
 constexpr int PS_PMAX = 1040;   // bins whose conditioning flags fit the kernel's LDS table
 constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 
 // NI: channel quarters that are swept in the M and p phases (channels part + 4 i, i < NI): ceil(C / 4), so that an 8-microphone
 // design (FromAtf) does a quarter of the multiply-adds of a 32-channel one instead of multiplying zeros
-template <int PS_DPW, int NI>
-__global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
+template <int PS_DPW, int NI, int NH>
+__global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
+    constexpr int NTT = PS_NT * NH;     // threads of the workgroup
     constexpr int XLD = PS_DPW + 4;     // row stride of the G slab (16 dwords mod 64: conflict-free quarter-wave reads)
     constexpr int PUNR = PS_DPW == 96 ? 3 : 4;
     constexpr int PS_NL = 2 * PS_DPW;   // loader threads = the p-phase threads
@@ -121,14 +130,14 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     static_assert(2 * PS_DPW <= PS_COMM0 && PS_DPW >= 64, "role layout");
     __shared__ __attribute__((aligned(16))) cplx vt[64];          // totals of the previous bin, [ear][32] zero padded
     __shared__ __attribute__((aligned(16))) cplx Wp[64];          // W(kb-1,:), same layout
-    __shared__ __attribute__((aligned(16))) cplx ts[2][PS_DPW];   // t per ear and direction
+    __shared__ __attribute__((aligned(16))) cplx ts_all[NH][2][PS_DPW];   // t per slab, ear and direction
     __shared__ int s_abort, s_local;
     __shared__ unsigned char s_ok[PS_PMAX];    // cond_ok of every bin (the designs stop at nfft 2048: P <= 1025; checked at launch)
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     // operands of the current bin; rows beyond C stay zero
-    cplx* xs = reinterpret_cast<cplx*>(dyn);                            // [32][XLD]   G_kb slab
-    cplx* ms = xs + (size_t)PS_CMAX * XLD;                              // [32][MLD]   M_{kb-1}
-    double* hs_all = reinterpret_cast<double*>(ms + (size_t)PS_CMAX * PS_MLD);  // [2][2][DPW]  |H_kb| (two buffers: 3 KB)
+    cplx* xs0 = reinterpret_cast<cplx*>(dyn);                           // [NH][32][XLD]   G_kb slabs
+    cplx* ms = xs0 + (size_t)NH * PS_CMAX * XLD;                        // [32][MLD]   M_{kb-1}
+    double* hs0 = reinterpret_cast<double*>(ms + (size_t)PS_CMAX * PS_MLD);  // [NH][2][2][DPW]  |H_kb| (two buffers per slab: 3 KB)
     // up to 8 designs: block b serves design b & 7 (the dispatcher is observed to place block b on XCD b % 8: one design per
     // XCD); 9 to 16 designs: designs j and j + 8 share XCD j, two workgroups per CU
     // Design-major within an XCD: the nWG blocks of design j come before those of design j + 8.  Workgroups are placed in block
@@ -144,30 +153,36 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
     // The chain is latency bound and its waves sleep most of the time; kernels of other batches share the CU.  Highest issue
     // priority for the chain's waves: when they have work they get the next slot, at no cost to the others while they wait.
     __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const bool comm = tid >= PS_COMM0;
+    // wtid: thread of the workgroup; tid: thread of its slab (half); the roles below are per slab
+    const int wtid = threadIdx.x, half = NH == 1 ? 0 : (wtid >> 8), tid = wtid & (PS_NT - 1), lane = tid & 63;
+    const bool comm = half == 0 && tid >= PS_COMM0;
     const bool loader = tid < PS_NL;
     const int C = a.C, P = a.P, npairs = 2 * a.C;
     const int fm = a.fetch_mode;
-    const int64_t d0 = (int64_t)member * PS_DPW;
+    const int nProd = NH * nWG;                        // producers of partials (slabs) of this design
+    const int slab = NH * member + half;
+    const int64_t d0 = (int64_t)slab * PS_DPW;
+    cplx* xs = xs0 + (size_t)half * PS_CMAX * XLD;
+    double* hs_all = hs0 + (size_t)half * 4 * PS_DPW;
+    cplx (*ts)[PS_DPW] = ts_all[half];
     const int64_t na = P - a.kabs0;
     // totals: granule words of a double x (x = 2 pair + re/im): low halves lo[x], high halves hi[x], each array contiguous
-    u64* part_ll = a.ll;                                    // [2][2C][nWG][re lo, im lo, re hi, im hi]: an owner reads nWG x 32 contiguous bytes
-    u64* tot_ll = a.ll + (size_t)2 * nWG * 4 * npairs;      // [2][lo 4C | hi 4C]
+    u64* part_ll = a.ll;                                    // [2][2C][nProd][re lo, im lo, re hi, im hi]: an owner reads nProd x 32 contiguous bytes
+    u64* tot_ll = a.ll + (size_t)2 * nProd * 4 * npairs;    // [2][lo 4C | hi 4C]
     const int nd2 = 2 * npairs;                             // doubles per workgroup and bin
     u64* xcc_ll = tot_ll + (size_t)2 * 2 * nd2;             // [nWG] start-up exchange of the XCC ids
-    if (tid < 64) { vt[tid] = mk(0, 0); Wp[tid] = mk(0, 0); }
-    if (tid == 0) { s_abort = 0; s_local = 0; }
+    if (wtid < 64) { vt[wtid] = mk(0, 0); Wp[wtid] = mk(0, 0); }
+    if (wtid == 0) { s_abort = 0; s_local = 0; }
     // (the per-bin flags are read in every bin of the chain: once from memory, then from LDS)
-    for (int i = tid; i < PS_PMAX; i += PS_NT) s_ok[i] = (i < P) ? (a.cond_ok[i] != 0.0 ? 1 : 0) : 1;
+    for (int i = wtid; i < PS_PMAX; i += NTT) s_ok[i] = (i < P) ? (a.cond_ok[i] != 0.0 ? 1 : 0) : 1;
     {
-        const size_t ncplx = (size_t)PS_CMAX * XLD + (size_t)PS_CMAX * PS_MLD + PS_DPW * 2;  // hs: 4 DPW doubles
-        for (size_t i = tid; i < ncplx; i += PS_NT) xs[i] = mk(0, 0);
+        const size_t ncplx = (size_t)NH * PS_CMAX * XLD + (size_t)PS_CMAX * PS_MLD + NH * PS_DPW * 2;  // hs: 4 DPW doubles per slab
+        for (size_t i = wtid; i < ncplx; i += NTT) xs0[i] = mk(0, 0);
     }
     // roles
     const int part = tid & 3;
     const int pair = tid >> 2;                        // M / partial phases: (pair, quarter)
-    const bool pvalid = pair < npairs;                // (npairs <= 64)
+    const bool pvalid = half == 0 && pair < npairs;   // (npairs <= 64; the M phase runs in the first slab's threads)
     const int e = pvalid ? pair / C : 0, c = pvalid ? pair % C : 0;
     // ---- loaders: operands of bin kb (the G_kb slab, |H_kb|; M_{kb-1} by all threads) from memory into registers ...
     // The loads are unconditional at clamped / padded addresses (a branch or a select around them makes the wave wait on
@@ -238,9 +253,11 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         stage_g(a.kfirst, gReg, hReg);
         if (fm == 3) { fetch_g(a.kfirst + 1, 0, gReg, hReg); fetch_g(a.kfirst + 1, 1, gReg, hReg); }
     }
-    fetch_m(a.kfirst, mReg);
-    stage_m(mReg);
-    if (fm == 3) fetch_m(a.kfirst + 1, mReg);
+    if (half == 0) {
+        fetch_m(a.kfirst, mReg);
+        stage_m(mReg);
+        if (fm == 3) fetch_m(a.kfirst + 1, mReg);
+    }
     if (comm) {  // do all workgroups of this design share an XCD?
         const unsigned xcc = read_xcc_id();
         const unsigned tag0 = 0x58434300u;  // 'XCC'
@@ -278,7 +295,40 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
                 const int slot = (kb - 1) & 1;
                 bool alive = true;
                 unsigned spins1 = 0;
-                // hop 1 (reduce-scatter): the pairs this workgroup owns, two per pass
+                // hop 1 (reduce-scatter): the pairs this workgroup owns.  Twin workgroups own the pairs of both their slabs
+                // (pair q belongs to slab q % nProd): lanes 0-31 collect those of slab 2 member, lanes 32-63 those of slab
+                // 2 member + 1, two pairs each -- four pairs in the one pass the single-slab form needs for two.
+                if constexpr (NH == 2) {
+                    const int grp = lane >> 5, w = lane & 31;
+                    for (int qb = slab + grp; qb - grp < npairs && alive; qb += 2 * nProd) {
+                        const int q = qb, q2 = q + nProd;
+                        const bool act = w < nProd && q < npairs, twoq = act && q2 < npairs;
+                        const u64* src = part_ll + (((size_t)slot * npairs + (act ? q : 0)) * nProd + (act ? w : 0)) * 4;
+                        const u64* src2 = twoq ? src + (size_t)nProd * nProd * 4 : src;
+                        u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+                        alive = ll_wait([&] {
+                            w0 = ll_load(src); w1 = ll_load(src + 2); w2 = ll_load(src + 1); w3 = ll_load(src + 3);
+                            u0 = ll_load(src2); u1 = ll_load(src2 + 2); u2 = ll_load(src2 + 1); u3 = ll_load(src2 + 3);
+                            if (!act) return true;
+                            bool ok = ll_ok(w0, tag) && ll_ok(w1, tag) && ll_ok(w2, tag) && ll_ok(w3, tag);
+                            if (twoq) ok = ok && ll_ok(u0, tag) && ll_ok(u1, tag) && ll_ok(u2, tag) && ll_ok(u3, tag);
+                            return ok;
+                        }, a.abort_flag, &spins1, (a.timing && member == 1 && lane == 0 && qb == slab) ? &a.timing[(int64_t)kb * 16 + 6] : nullptr);
+                        const double re = group_sum<32>(act ? ll_value(w0, w1) : 0.0);
+                        const double im = group_sum<32>(act ? ll_value(w2, w3) : 0.0);
+                        const double re2 = group_sum<32>(twoq ? ll_value(u0, u1) : 0.0);
+                        const double im2 = group_sum<32>(twoq ? ll_value(u2, u3) : 0.0);
+                        if (w == 0 && q < npairs) {
+                            u64* dst = tot_ll + (size_t)slot * 2 * nd2 + 2 * q;
+                            ll_store(dst, dst + nd2, re, tag, local);
+                            ll_store(dst + 1, dst + nd2 + 1, im, tag, local);
+                            if (q2 < npairs) {
+                                ll_store(dst + 2 * nProd, dst + 2 * nProd + nd2, re2, tag, local);
+                                ll_store(dst + 2 * nProd + 1, dst + 2 * nProd + nd2 + 1, im2, tag, local);
+                            }
+                        }
+                    }
+                } else
                 for (int q = member; q < npairs && alive; q += 2 * nWG) {
                     const int q2 = q + nWG;
                     const bool twoq = q2 < npairs;
@@ -344,7 +394,7 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         // have drained when the exchange starts -- requesting them after B4 (mode 3, a whole bin period of lead and no issue
         // time on the chain) costs +0.8 us per bin in hop 1 (measured).  Issued here (and after B3 / B2) they drain during the
         // compute phases, at the price of their issue time (~0.15 us per half slab) on the chain.
-        if (loader && fm != 3) { fetch_g(kb + 1, 0, gReg, hReg); if (fm == 2) fetch_g(kb + 1, 1, gReg, hReg); }
+        if (loader && fm != 3 && fm != 4) { fetch_g(kb + 1, 0, gReg, hReg); if (fm == 2) fetch_g(kb + 1, 1, gReg, hReg); }
         // ---- W(kb-1,:) = v_total conj(M_{kb-1})  (identity for the first swept bin and after an ill-conditioned bin)
         if (pvalid) {
             cplx acc = mk(0, 0);
@@ -362,12 +412,12 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             }
         }
         if (last) break;
-        if (fm != 3) fetch_m(kb + 1, mReg);
+        if (fm != 3 && half == 0) fetch_m(kb + 1, mReg);
         __syncthreads();  // B2: Wp is complete
         if (loader && fm == 1) fetch_g(kb + 1, 1, gReg, hReg);
         // ---- p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
         // thread = (direction pair (dA, dA + DPW/2), channel quarter): a W value read from LDS feeds two directions
-        if (tid == 0) PSTAMP(3);
+        if (wtid == 0) PSTAMP(3);
         if (tid < 2 * PS_DPW) {
             const int dA = tid >> 2, dB = dA + PS_DPW / 2;
             cplx pA0 = mk(0, 0), pA1 = mk(0, 0), pB0 = mk(0, 0), pB1 = mk(0, 0);   // p[direction][ear]
@@ -385,8 +435,9 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
         }
         __syncthreads();  // B3: ts is complete
         if (loader && fm == 0) fetch_g(kb + 1, 1, gReg, hReg);
+        if (loader && fm == 4) { fetch_g(kb + 1, 0, gReg, hReg); fetch_g(kb + 1, 1, gReg, hReg); }   // (experiment: everything after B3)
         // ---- this slab's partial v = t conj(G) (or t Y_reg_inv for an ill-conditioned bin), published as granules
-        if (tid == 0) PSTAMP(4);
+        if (wtid == 0) PSTAMP(4);
         // thread = (channel pair cp, 16 direction slices): every t and every G element it reads from LDS feeds two
         // complex FMAs (2 ears x 2 channels), half the LDS traffic of one (ear, channel) pair per thread
         {
@@ -419,12 +470,12 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
                 if (cc < C) {
                     const u64 bits = (u64)__double_as_longlong((wi & 1) ? acc.y : acc.x);
                     const u64 word = ((u64)(unsigned)kb << 32) | ((wi & 2) ? (bits >> 32) : (bits & 0xffffffffull));
-                    u64* dst = part_ll + (((size_t)(kb & 1) * npairs + (ee * C + cc)) * nWG + member) * 4 + wi;
+                    u64* dst = part_ll + (((size_t)(kb & 1) * npairs + (ee * C + cc)) * nProd + slab) * 4 + wi;
                     ll_put(dst, word, local);
                 }
             }
         }
-        if (tid == 0) PSTAMP(5);
+        if (wtid == 0) PSTAMP(5);
         // the slab buffer is free once every wave has left the partial phase (M was last read before B2): refill both while
         // everybody waits for the exchange
         __syncthreads();  // B4
@@ -435,8 +486,10 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
             stage_g(kb + 1, gReg, hReg);
             if (fm == 3) { fetch_g(kb + 2, 0, gReg, hReg); fetch_g(kb + 2, 1, gReg, hReg); }
         }
-        stage_m(mReg);
-        if (fm == 3) fetch_m(kb + 2, mReg);
+        if (half == 0) {
+            stage_m(mReg);
+            if (fm == 3) fetch_m(kb + 2, mReg);
+        }
     }
 #undef PSTAMP
 }
@@ -446,26 +499,37 @@ __global__ void __launch_bounds__(PS_NT) sweep_persist_kernel(HalfSweepMulti m, 
 int persist_sweep_dpw(int D) { return D <= 32 * 64 ? 64 : 96; }
 int persist_sweep_nwg(int D) { return (int)ceil_div(D, persist_sweep_dpw(D)); }
 bool persist_sweep_supported(int D, int C) { return C <= PS_CMAX && persist_sweep_nwg(D) <= 32; }
+// (sized for the twin form as well: 2 ceil(nWG / 2) producers)
 size_t persist_sweep_ll_bytes(int D, int C) {
-    return sizeof(u64) * ((size_t)2 * persist_sweep_nwg(D) * 8 * C + (size_t)2 * 8 * C + 64);
+    const size_t nprod = 2 * (size_t)ceil_div(persist_sweep_nwg(D), 2);
+    return sizeof(u64) * ((size_t)2 * nprod * 8 * C + (size_t)2 * 8 * C + 64);
 }
+// EMAGLS_SWEEP_TWIN=0: launches of 9-16 designs as two independent 256-thread workgroups per CU (the earlier form)
+// (read at every launch: a test switches forms inside one process)
+static bool sweep_twin_enabled() { const char* e = getenv("EMAGLS_SWEEP_TWIN"); return !(e && e[0] == '0'); }
 
 void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const HalfSweepArgs& a = m.a[0];
-    const int nWG = persist_sweep_nwg(a.D);
+    const int nSlab = persist_sweep_nwg(a.D);
     if (!persist_sweep_supported(a.D, a.C) || m.n > SWEEP_MULTI_MAX || a.P > PS_PMAX) throw Error(2, "persistent sweep: shape not supported");
+    const bool twin = m.n > 8 && sweep_twin_enabled();
+    const int nh = twin ? 2 : 1;
+    const int nWG = (int)ceil_div(nSlab, nh);
     const unsigned nblocks = 8u * (unsigned)nWG * (m.n > 8 ? 2u : 1u);
     const int dpw = persist_sweep_dpw(a.D);
-    const size_t dyn = sizeof(cplx) * ((size_t)PS_CMAX * (dpw + 4) + (size_t)PS_CMAX * PS_MLD + 2 * dpw);
+    const size_t dyn = sizeof(cplx) * ((size_t)nh * PS_CMAX * (dpw + 4) + (size_t)PS_CMAX * PS_MLD + (size_t)nh * 2 * dpw);
     static PerDeviceOnce attr_once;   // (function attributes are per device)
     if (attr_once.first()) {
-#define EMAGLS_PS_ATTR(D, N) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<D, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+#define EMAGLS_PS_ATTR(D, N) do { \
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<D, N, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<D, N, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); } while (0)
         EMAGLS_PS_ATTR(64, 2); EMAGLS_PS_ATTR(64, 4); EMAGLS_PS_ATTR(64, 7); EMAGLS_PS_ATTR(64, 8);
         EMAGLS_PS_ATTR(96, 2); EMAGLS_PS_ATTR(96, 4); EMAGLS_PS_ATTR(96, 7); EMAGLS_PS_ATTR(96, 8);
 #undef EMAGLS_PS_ATTR
     }
     const int ni = a.C <= 8 ? 2 : (a.C <= 16 ? 4 : (a.C <= 28 ? 7 : 8));
-#define EMAGLS_PS_GO(D, N) sweep_persist_kernel<D, N><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG)
+#define EMAGLS_PS_GO(D, N) do { if (twin) sweep_persist_kernel<D, N, 2><<<dim3(nblocks), 2 * PS_NT, dyn, st>>>(m, nWG); \
+                                else sweep_persist_kernel<D, N, 1><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG); } while (0)
     if (dpw == 64) { if (ni == 2) EMAGLS_PS_GO(64, 2); else if (ni == 4) EMAGLS_PS_GO(64, 4); else if (ni == 7) EMAGLS_PS_GO(64, 7); else EMAGLS_PS_GO(64, 8); }
     else { if (ni == 2) EMAGLS_PS_GO(96, 2); else if (ni == 4) EMAGLS_PS_GO(96, 4); else if (ni == 7) EMAGLS_PS_GO(96, 7); else EMAGLS_PS_GO(96, 8); }
 #undef EMAGLS_PS_GO

@@ -390,9 +390,10 @@ def test_gram_matrix_of_a_lane_batch(grids, thin):
 
 def test_sixteen_design_lane_batch(grids, thin, monkeypatch):
     """9 to 16 designs (opt-in: emagls_set_batch_max(16), the product's default stays 8 and so does the suite's) share one sweep
-    launch with two designs per XCD (two workgroups per CU): a batch of 12 designs (different HRIR sets and microphone grids)
-    equals the single designs and sweeps with the persistent kernel; replays are bitwise reproducible.  Without the opt-in a
-    batch holds at most 8."""
+    launch with two designs per XCD: a batch of 12 designs (different HRIR sets and microphone grids) equals the single designs
+    and sweeps with the persistent kernel; replays are bitwise reproducible.  Both forms of the launch: twin workgroups (two
+    slabs of one design per CU, the default) and two independent workgroups per CU (EMAGLS_SWEEP_TWIN=0).  Without the opt-in
+    a batch holds at most 8."""
     import ctypes
     from emagls_amd import Batch, Plan, _lib as L
     from emagls_amd._lib import EmaglsError
@@ -431,6 +432,14 @@ def test_sixteen_design_lane_batch(grids, thin, monkeypatch):
         for a, c in zip(outs[0], outs[it]):
             assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
     assert rel(singles[0][0], singles[5][0]) > 1e-3
+    monkeypatch.setenv("EMAGLS_SWEEP_TWIN", "0")
+    b.execute()
+    plain = b.get_filters()
+    monkeypatch.delenv("EMAGLS_SWEEP_TWIN")
+    assert plans[0].info().num_sweep_launches == 1
+    worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(plain, singles))
+    print(f"12-design lane batch, two workgroups per CU, vs single plans: worst rel = {worst:.3e}")
+    assert worst < 1e-12
     b.close()
     for p in plans:
         p.close()

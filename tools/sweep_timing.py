@@ -18,6 +18,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     import bench
     from emagls_amd import Batch, Plan, _lib as L
+    if n > 8:
+        L.check(L.load().emagls_set_batch_max(n, None))
     plans = []
     for j in range(n):
         azi, zen, maz, mzn, hL, hR = bench.load_inputs(seed_offset=j)
@@ -33,7 +35,7 @@ def main():
     (b.synchronize() if b else plans[0].synchronize())
     info = plans[0].info()
     P, k0 = info.num_pos_freqs, max(info.k_cut - 1, 1)
-    for j, p in enumerate(plans[:2]):
+    for j, p in [(0, plans[0]), (n - 1, plans[-1])][:min(n, 2)]:
         t = p.debug("sweep_timing", np.int64).reshape(P, 16).astype(np.float64) * 0.01   # microseconds
         kb = np.arange(k0 + 2, P - 2)
         rows = {
