@@ -115,6 +115,27 @@ template <typename T> __device__ __forceinline__ T* boff(T* p, size_t stride) { 
 template <typename T> __device__ __forceinline__ T* boff_flat(T* p, size_t stride, unsigned z) {
     return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)z * stride) : p;
 }
+// streaming (write-once, read by a LATER kernel from HBM anyway) stores: nontemporal, so that a result of hundreds of MB does
+// not evict what other kernels keep in L2 / MALL.  EMAGLS_NT_STORES is defined by the build; -DEMAGLS_NT_STORES=0 restores plain stores.
+#ifndef EMAGLS_NT_STORES
+#define EMAGLS_NT_STORES 1
+#endif
+typedef double nt_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store(double* p, double v) {
+#if EMAGLS_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void stream_store(cplx* p, cplx v) {
+#if EMAGLS_NT_STORES
+    nt_d2 w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_d2*>(p));
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ cplx shfl_xor_c(cplx v, int m) { return {__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64)}; }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }

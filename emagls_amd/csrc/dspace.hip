@@ -107,8 +107,8 @@ __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT,
                 cfma(g1, bb[n + 1], qa[n + 1]); cfma(h1, bb[n + 1], qb[n + 1]);
             }
             if (NMAX & 1) { cfma(g0, bb[NMAX - 1], qa[NMAX - 1]); cfma(h0, bb[NMAX - 1], qb[NMAX - 1]); }
-            g[0] = g0 + g1;
-            if (two) g[4 * ldD] = h0 + h1;
+            stream_store(g, g0 + g1);
+            if (two) stream_store(g + 4 * ldD, h0 + h1);
         }
     }
 }
@@ -204,8 +204,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                 __builtin_nontemporal_store(o0.x, q0); __builtin_nontemporal_store(o0.y, q0 + 1);
                 if (two) { double* q1 = reinterpret_cast<double*>(ga_p + boffs); __builtin_nontemporal_store(o1.x, q1); __builtin_nontemporal_store(o1.y, q1 + 1); }
             } else {
-                ga_p[0] = o0;
-                if (two) ga_p[boffs] = o1;
+                stream_store(ga_p, o0);
+                if (two) stream_store(ga_p + boffs, o1);
             }
         }
     }

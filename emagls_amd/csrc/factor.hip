@@ -283,7 +283,10 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
                             Vs[p][row] = cs * vp[t] - spc * vq[t];
                             Vs[q][row] = sph * vp[t] + cs * vq[t];
                         }
-                        rotated = 1;
+                        // Another sweep is needed only after a rotation that was not already tiny: Jacobi converges quadratically,
+                        // so a sweep whose largest |gamma| / sqrt(alpha beta) is below 1e-8 leaves off-diagonal terms of ~1e-16 --
+                        // the verification sweep that would follow (25 rounds without a rotation) is skipped.
+                        if (ag2 > 1.0e-16 * (al * be)) rotated = 1;
                     }
                 }
                 __syncthreads();

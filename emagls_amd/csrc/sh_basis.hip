@@ -83,17 +83,17 @@ __global__ void __launch_bounds__(256) sh_basis_kernel(int N, int64_t D, const d
             if (COMPLEX) {
                 cplx* Yc = reinterpret_cast<cplx*>(Y);
                 if (m == 0) {
-                    Yc[base * ld + d] = mk(p, 0.0);
+                    stream_store(Yc + base * ld + d, mk(p, 0.0));
                 } else {
-                    Yc[(base + m) * ld + d] = mk(sign * p * cs, sign * p * sn);  // Condon-Shortley
-                    Yc[(base - m) * ld + d] = mk(p * cs, -p * sn);               // (-1)^m conj(Y_n^m)
+                    stream_store(Yc + (base + m) * ld + d, mk(sign * p * cs, sign * p * sn));  // Condon-Shortley
+                    stream_store(Yc + (base - m) * ld + d, mk(p * cs, -p * sn));               // (-1)^m conj(Y_n^m)
                 }
             } else {
                 if (m == 0) {
-                    Y[base * ld + d] = p;
+                    stream_store(Y + base * ld + d, p);
                 } else {
-                    Y[(base + m) * ld + d] = SQ2 * p * cs;
-                    Y[(base - m) * ld + d] = SQ2 * p * sn;
+                    stream_store(Y + (base + m) * ld + d, SQ2 * p * cs);
+                    stream_store(Y + (base - m) * ld + d, SQ2 * p * sn);
                 }
             }
         }

@@ -121,6 +121,7 @@ constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 template <int PS_DPW, int NI, int NH>
 __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
     constexpr int NTT = PS_NT * NH;     // threads of the workgroup
+    constexpr int ROWS = 4 * NI;        // channel rows kept in LDS (the quarters that are swept; rows beyond C stay zero)
     constexpr int XLD = PS_DPW + 4;     // row stride of the G slab (16 dwords mod 64: conflict-free quarter-wave reads)
     constexpr int PUNR = PS_DPW == 96 ? 3 : 4;
     constexpr int PS_NL = 2 * PS_DPW;   // loader threads = the p-phase threads
@@ -135,9 +136,9 @@ __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMult
     __shared__ unsigned char s_ok[PS_PMAX];    // cond_ok of every bin (the designs stop at nfft 2048: P <= 1025; checked at launch)
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     // operands of the current bin; rows beyond C stay zero
-    cplx* xs0 = reinterpret_cast<cplx*>(dyn);                           // [NH][32][XLD]   G_kb slabs
-    cplx* ms = xs0 + (size_t)NH * PS_CMAX * XLD;                        // [32][MLD]   M_{kb-1}
-    double* hs0 = reinterpret_cast<double*>(ms + (size_t)PS_CMAX * PS_MLD);  // [NH][2][2][DPW]  |H_kb| (two buffers per slab: 3 KB)
+    cplx* xs0 = reinterpret_cast<cplx*>(dyn);                           // [NH][ROWS][XLD]   G_kb slabs
+    cplx* ms = xs0 + (size_t)NH * ROWS * XLD;                           // [ROWS][MLD]   M_{kb-1}
+    double* hs0 = reinterpret_cast<double*>(ms + (size_t)ROWS * PS_MLD);  // [NH][2][2][DPW]  |H_kb| (two buffers per slab: 3 KB)
     // up to 8 designs: block b serves design b & 7 (the dispatcher is observed to place block b on XCD b % 8: one design per
     // XCD); 9 to 16 designs: designs j and j + 8 share XCD j, two workgroups per CU
     // Design-major within an XCD: the nWG blocks of design j come before those of design j + 8.  Workgroups are placed in block
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMult
     const int nProd = NH * nWG;                        // producers of partials (slabs) of this design
     const int slab = NH * member + half;
     const int64_t d0 = (int64_t)slab * PS_DPW;
-    cplx* xs = xs0 + (size_t)half * PS_CMAX * XLD;
+    cplx* xs = xs0 + (size_t)half * ROWS * XLD;
     double* hs_all = hs0 + (size_t)half * 4 * PS_DPW;
     cplx (*ts)[PS_DPW] = ts_all[half];
     const int64_t na = P - a.kabs0;
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMult
     // (the per-bin flags are read in every bin of the chain: once from memory, then from LDS)
     for (int i = wtid; i < PS_PMAX; i += NTT) s_ok[i] = (i < P) ? (a.cond_ok[i] != 0.0 ? 1 : 0) : 1;
     {
-        const size_t ncplx = (size_t)NH * PS_CMAX * XLD + (size_t)PS_CMAX * PS_MLD + NH * PS_DPW * 2;  // hs: 4 DPW doubles per slab
+        const size_t ncplx = (size_t)NH * ROWS * XLD + (size_t)ROWS * PS_MLD + NH * PS_DPW * 2;  // hs: 4 DPW doubles per slab
         for (size_t i = wtid; i < ncplx; i += NTT) xs0[i] = mk(0, 0);
     }
     // roles
@@ -517,7 +518,9 @@ void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const int nWG = (int)ceil_div(nSlab, nh);
     const unsigned nblocks = 8u * (unsigned)nWG * (m.n > 8 ? 2u : 1u);
     const int dpw = persist_sweep_dpw(a.D);
-    const size_t dyn = sizeof(cplx) * ((size_t)nh * PS_CMAX * (dpw + 4) + (size_t)PS_CMAX * PS_MLD + (size_t)nh * 2 * dpw);
+    const int ni = a.C <= 8 ? 2 : (a.C <= 16 ? 4 : (a.C <= 28 ? 7 : 8));
+    const size_t rows = 4 * (size_t)ni;   // (only the swept channel quarters take LDS: 28 rows for the 25 channels of order 4)
+    const size_t dyn = sizeof(cplx) * ((size_t)nh * rows * (dpw + 4) + rows * PS_MLD + (size_t)nh * 2 * dpw);
     static PerDeviceOnce attr_once;   // (function attributes are per device)
     if (attr_once.first()) {
 #define EMAGLS_PS_ATTR(D, N) do { \
@@ -527,7 +530,6 @@ void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
         EMAGLS_PS_ATTR(96, 2); EMAGLS_PS_ATTR(96, 4); EMAGLS_PS_ATTR(96, 7); EMAGLS_PS_ATTR(96, 8);
 #undef EMAGLS_PS_ATTR
     }
-    const int ni = a.C <= 8 ? 2 : (a.C <= 16 ? 4 : (a.C <= 28 ? 7 : 8));
 #define EMAGLS_PS_GO(D, N) do { if (twin) sweep_persist_kernel<D, N, 2><<<dim3(nblocks), 2 * PS_NT, dyn, st>>>(m, nWG); \
                                 else sweep_persist_kernel<D, N, 1><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG); } while (0)
     if (dpw == 64) { if (ni == 2) EMAGLS_PS_GO(64, 2); else if (ni == 4) EMAGLS_PS_GO(64, 4); else if (ni == 7) EMAGLS_PS_GO(64, 7); else EMAGLS_PS_GO(64, 8); }
