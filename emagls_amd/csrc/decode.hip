@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include "kernels.hpp"
+#include "lds_fft.hpp"
 
 namespace emagls {
 
@@ -57,6 +58,129 @@ __global__ void ols_unpack_kernel(const double* __restrict__ y, int64_t n, int64
         const int64_t t = idx % n, e = idx / n;
         const int64_t b = t / B, i = t % B;
         out[idx] = y[((int64_t)e * nblocks + b) * Nf + (len - 1) + i] * scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused overlap-save block (filters up to 2048 taps): one workgroup = one output block.  The hipFFT passes above write the
+// segments, their spectra and the products to HBM and read them back (~6x the algorithmic bytes); here a block's segments go
+// from the signal straight into LDS -- two real channels packed into one complex transform, `nt` transforms at a time --
+// the spectra are unpacked, multiplied with the filter spectra and accumulated in registers (thread = frequency bin), and
+// both ears leave through ONE packed inverse transform (y_L + i y_R).  HBM sees the signal (each sample in two
+// segments: the second read is an L2 hit), the filter spectra (L2 resident) and the output.
+//   sig [C][n], Wf [2][C][Pf] (spectra of the zero-padded filters, hipFFT D2Z), out [2][n]
+// ---------------------------------------------------------------------------------------------
+constexpr int OLSF_NT = 512;   // threads
+// KU: frequency bins per thread (Pf <= KU * 512); NTP: transforms (channel pairs) per round -- (2, 4) up to Nf = 1024,
+// (3, 2) for 2048, (5, 1) for 4096: NTP * Nf <= 4096 elements, i.e. 8 loads per thread and round
+template <int KU, int NTP>
+__global__ void __launch_bounds__(OLSF_NT) ols_fused_kernel(const double* __restrict__ sig, int64_t n, int C, const cplx* __restrict__ Wf,
+                                                            int64_t len, int Nf, int log2n, int64_t B, double* __restrict__ out) {
+    constexpr int NLD = 8;         // loads per thread and round
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* buf = reinterpret_cast<cplx*>(dyn);          // [NTP][Nf], padded (lds_fft_ix)
+    cplx* tws = buf + (size_t)NTP * (Nf + Nf / 16);     // [Nf / 2]
+    const int tid = threadIdx.x;
+    const int64_t blk = blockIdx.x;
+    const int Pf = Nf / 2 + 1, mask = Nf - 1;
+    for (int j = tid; j < Nf / 2; j += OLSF_NT) {
+        double sn, cs;
+        sincospi(-2.0 * (double)j / (double)Nf, &sn, &cs);   // (exact at the multiples of 1/4: Nf is a power of two)
+        tws[j] = mk(cs, sn);
+    }
+    cplx accL[KU], accR[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) { accL[u] = mk(0, 0); accR[u] = mk(0, 0); }
+    const int npairs = (C + 1) / 2;
+    const int64_t s0 = blk * B - (len - 1);
+    // a round's samples travel global -> registers -> LDS; the loads of round r + 1 are issued before the transforms of round r
+    // (all of a thread's loads back to back: one latency per round instead of one per element)
+    double xa[NLD], xb[NLD];
+    auto fetch = [&](int p0) __attribute__((always_inline)) {
+        const int np = min(NTP, npairs - p0);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + OLSF_NT * j;
+            const int t = idx >> log2n, i = idx & mask;
+            const int ca = 2 * (p0 + t), cb = ca + 1;
+            const int64_t src = s0 + i;
+            const bool in = idx < np * Nf && src >= 0 && src < n;
+            xa[j] = in ? sig[(int64_t)ca * n + src] : 0.0;
+            xb[j] = (in && cb < C) ? sig[(int64_t)cb * n + src] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int p0 = 0; p0 < npairs; p0 += NTP) {
+        const int np = min(NTP, npairs - p0);
+        __syncthreads();   // the previous round's spectra have been read (first round: the twiddles are written)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + OLSF_NT * j;
+            if (idx < np * Nf) {
+                const int t = idx >> log2n, i = idx & mask;
+                buf[lds_fft_ix<true>((t << log2n) + (int)bitrev((unsigned)i, log2n))] = mk(xa[j], xb[j]);
+            }
+        }
+        if (p0 + NTP < npairs) fetch(p0 + NTP);
+        __syncthreads();
+        lds_fft_stages<false, true>(buf, tws, Nf, log2n, np);
+        // Z = X_a + i X_b with real x_a, x_b:  X_a[k] = (Z[k] + conj(Z[N-k])) / 2,  X_b[k] = (Z[k] - conj(Z[N-k])) / (2i)
+        // (the filter spectra of the round are requested together, before the first use)
+        cplx wla[KU][NTP], wra[KU][NTP], wlb[KU][NTP], wrb[KU][NTP];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = min(tid + OLSF_NT * u, Pf - 1);
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) {
+                const int ca = min(2 * (p0 + t), C - 1), cb = min(ca + 1, C - 1);
+                wla[u][t] = Wf[(int64_t)ca * Pf + k];
+                wra[u][t] = Wf[((int64_t)C + ca) * Pf + k];
+                wlb[u][t] = Wf[(int64_t)cb * Pf + k];
+                wrb[u][t] = Wf[((int64_t)C + cb) * Pf + k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = tid + OLSF_NT * u;
+            if (k < Pf) {
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) {
+                    if (t < np) {
+                        const cplx z = buf[lds_fft_ix<true>((t << log2n) + k)], zr = conj(buf[lds_fft_ix<true>((t << log2n) + ((Nf - k) & mask))]);
+                        const cplx pa = mk(0.5 * (z.x + zr.x), 0.5 * (z.y + zr.y));
+                        const cplx pb = mk(0.5 * (z.y - zr.y), -0.5 * (z.x - zr.x));
+                        cfma(accL[u], pa, wla[u][t]);
+                        cfma(accR[u], pa, wra[u][t]);
+                        if (2 * (p0 + t) + 1 < C) {
+                            cfma(accL[u], pb, wlb[u][t]);
+                            cfma(accR[u], pb, wrb[u][t]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // packed inverse: Yc = Y_L + i Y_R on all Nf bins (Y_e[N-k] = conj(Y_e[k]): the outputs are real)
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const int k = tid + OLSF_NT * u;
+        if (k < Pf) {
+            const cplx l = accL[u], r = accR[u];
+            buf[lds_fft_ix<true>((int)bitrev((unsigned)k, log2n))] = mk(l.x - r.y, l.y + r.x);
+            if (k > 0 && k < Nf / 2) buf[lds_fft_ix<true>((int)bitrev((unsigned)(Nf - k), log2n))] = mk(l.x + r.y, r.x - l.y);
+        }
+    }
+    __syncthreads();
+    lds_fft_stages<true, true>(buf, tws, Nf, log2n, 1);
+    const double scale = 1.0 / (double)Nf;
+    for (int64_t i = tid; i < B; i += OLSF_NT) {
+        const int64_t t = blk * B + i;
+        if (t < n) {
+            const cplx y = buf[lds_fft_ix<true>((int)((len - 1) + i))];
+            stream_store(out + t, y.x * scale);
+            stream_store(out + n + t, y.y * scale);
+        }
     }
 }
 
@@ -116,16 +240,18 @@ struct DecodeWork {
         release();
         const int Pf = Nf_ / 2 + 1;
         try {
-            HIP_CHECK(hipMalloc(&seg, sizeof(double) * C_ * nblocks_ * Nf_));
-            HIP_CHECK(hipMalloc(&wpad, sizeof(double) * 2 * C_ * Nf_));
-            HIP_CHECK(hipMalloc(&y, sizeof(double) * 2 * nblocks_ * Nf_));
-            HIP_CHECK(hipMalloc(&Xf, sizeof(cplx) * C_ * nblocks_ * Pf));
-            HIP_CHECK(hipMalloc(&Wf, sizeof(cplx) * 2 * C_ * Pf));
-            HIP_CHECK(hipMalloc(&Yf, sizeof(cplx) * 2 * nblocks_ * Pf));
             int nn[1] = {Nf_};
-            fft_check(hipfftPlanMany(&pf, 1, nn, nullptr, 1, Nf_, nullptr, 1, Pf, HIPFFT_D2Z, (int)(C_ * nblocks_)), "plan D2Z signal");
+            HIP_CHECK(hipMalloc(&wpad, sizeof(double) * 2 * C_ * Nf_));
+            HIP_CHECK(hipMalloc(&Wf, sizeof(cplx) * 2 * C_ * Pf));
             fft_check(hipfftPlanMany(&pw, 1, nn, nullptr, 1, Nf_, nullptr, 1, Pf, HIPFFT_D2Z, 2 * C_), "plan D2Z filters");
-            fft_check(hipfftPlanMany(&pi, 1, nn, nullptr, 1, Pf, nullptr, 1, Nf_, HIPFFT_Z2D, (int)(2 * nblocks_)), "plan Z2D");
+            if (nblocks_ > 0) {   // (0: the fused kernel keeps the signal side in LDS; only the filter spectra pass through hipFFT)
+                HIP_CHECK(hipMalloc(&seg, sizeof(double) * C_ * nblocks_ * Nf_));
+                HIP_CHECK(hipMalloc(&y, sizeof(double) * 2 * nblocks_ * Nf_));
+                HIP_CHECK(hipMalloc(&Xf, sizeof(cplx) * C_ * nblocks_ * Pf));
+                HIP_CHECK(hipMalloc(&Yf, sizeof(cplx) * 2 * nblocks_ * Pf));
+                fft_check(hipfftPlanMany(&pf, 1, nn, nullptr, 1, Nf_, nullptr, 1, Pf, HIPFFT_D2Z, (int)(C_ * nblocks_)), "plan D2Z signal");
+                fft_check(hipfftPlanMany(&pi, 1, nn, nullptr, 1, Pf, nullptr, 1, Nf_, HIPFFT_Z2D, (int)(2 * nblocks_)), "plan Z2D");
+            }
         } catch (...) { release(); throw; }
         C = C_; nblocks = nblocks_; Nf = Nf_; device = dev;
     }
@@ -139,9 +265,41 @@ void decode_cache_clear() {
     g_decode.release();
 }
 
+// EMAGLS_DECODE_FUSED=0: always the hipFFT passes
+static bool decode_fused_enabled() { const char* e = getenv("EMAGLS_DECODE_FUSED"); return !(e && e[0] == '0'); }
+
 void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL, const double* wR, int64_t len,
                           double* out, hipStream_t st) {
     if (n <= 0) return;
+    if (len <= 2048 && decode_fused_enabled()) {
+        // block length ~ filter length: twice the transforms of the 4x blocks below, but every one of them stays in LDS
+        int Nf = 256, log2n = 8;
+        while (Nf < 2 * len) { Nf <<= 1; ++log2n; }
+        const int64_t B = Nf - (len - 1);
+        const int64_t nblocks = ceil_div(n, B);
+        std::lock_guard<std::mutex> lk(g_decode_mu);
+        DecodeWork& w = g_decode;
+        w.ensure(C, 0, Nf);
+        fft_check(hipfftSetStream(w.pw, st), "set stream");
+        ols_padfilt_kernel<<<256, 256, 0, st>>>(wL, wR, C, len, Nf, w.wpad);
+        KERNEL_CHECK();
+        fft_check(hipfftExecD2Z(w.pw, w.wpad, (hipfftDoubleComplex*)w.Wf), "exec D2Z filters");
+        const int ntp = Nf <= 1024 ? 4 : (Nf == 2048 ? 2 : 1);
+        const size_t dyn = sizeof(cplx) * ((size_t)ntp * (Nf + Nf / 16) + Nf / 2);
+        static PerDeviceOnce attr_once;
+        if (attr_once.first()) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_fused_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_fused_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_fused_kernel<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        }
+        const dim3 grid((unsigned)nblocks);
+        if (ntp == 4) ols_fused_kernel<2, 4><<<grid, OLSF_NT, dyn, st>>>(sig, n, C, w.Wf, len, Nf, log2n, B, out);
+        else if (ntp == 2) ols_fused_kernel<3, 2><<<grid, OLSF_NT, dyn, st>>>(sig, n, C, w.Wf, len, Nf, log2n, B, out);
+        else ols_fused_kernel<5, 1><<<grid, OLSF_NT, dyn, st>>>(sig, n, C, w.Wf, len, Nf, log2n, B, out);
+        KERNEL_CHECK();
+        HIP_CHECK(hipStreamSynchronize(st));
+        return;
+    }
     int Nf = 1024;
     while (Nf < 4 * len) Nf <<= 1;
     const int64_t B = Nf - (len - 1);

@@ -754,6 +754,27 @@ def test_binaural_decode(golden):
     assert rel(a, 2.5 * out) < 1e-13
 
 
+@pytest.mark.parametrize("nsamp,nch,length", [(5000, 25, 512), (777, 4, 64), (100, 9, 256), (3000, 1, 2), (4097, 7, 1000),
+                                              (9000, 36, 2048), (2600, 16, 3000)])
+def test_binaural_decode_shapes(nsamp, nch, length, monkeypatch):
+    """The fused overlap-save kernel (filters up to 2048 taps: segments, spectra and products stay in LDS) on ragged shapes --
+    odd channel counts (the last transform carries one channel), signals shorter than a block, one channel, two taps, a length
+    that is not a power of two -- against the oracle's time-domain sum, and against the hipFFT passes (EMAGLS_DECODE_FUSED=0),
+    which also serve the filters above 2048 taps."""
+    import emagls_amd as E
+    rng = np.random.default_rng(nsamp + nch)
+    sig = rng.standard_normal((nsamp, nch))
+    wL = rng.standard_normal((length, nch)) * np.exp(-np.arange(length) / (0.3 * length))[:, None]
+    wR = rng.standard_normal((length, nch)) * np.exp(-np.arange(length) / (0.3 * length))[:, None]
+    out = E.binauralDecode(sig, 48000, wL, wR, 48000)
+    ref = O.binauralDecode(sig, wL, wR)
+    assert out.shape == ref.shape == (nsamp, 2)
+    monkeypatch.setenv("EMAGLS_DECODE_FUSED", "0")
+    plain = E.binauralDecode(sig, 48000, wL, wR, 48000)
+    print(f"decode {nsamp} x {nch}, {length} taps: fused vs oracle rel = {rel(out, ref):.3e}, hipFFT passes vs oracle {rel(plain, ref):.3e}")
+    assert rel(out, ref) < 1e-12 and rel(plain, ref) < 1e-12
+
+
 def _sn3d_sh(N, dirs, basisType="real"):
     """A custom shFunction as a user of the reference would pass it (lib/getEMagLsFilters.m:32): SN3D-weighted harmonics."""
     Y = O.getSH(N, dirs, basisType)
