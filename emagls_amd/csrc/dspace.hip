@@ -281,6 +281,8 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
     const int nmax = nOrders <= 20 ? 20 : nOrders <= 32 ? 32 : DSP_NMAX;
     while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nmax > 56 * 1024) ++chunks;  // b_n table of a chunk in LDS
     const int bpc = (nbins + chunks - 1) / chunks;
+    // (tried: capping the kernel at 1-3 workgroups per CU through a larger LDS request, so that other batches' kernels find
+    // room next to it: 2099-2118 sets/s against 2142 uncapped in long runs -- it is not this kernel's occupancy that limits them)
     const size_t dyn = sizeof(cplx) * (size_t)bpc * nmax;
     const dim3 grid((unsigned)ceil_div(D, DSP_TD), chunks);
     if (nOrders <= 20)

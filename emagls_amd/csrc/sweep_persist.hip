@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMult
         // ================= communication wave: the totals of bin kb-1 into vt =================
         if (comm) {
             if (lane == 0) PSTAMP(0);
+            if (lane == 0 && a.timing && member == 1 && kb < P) a.timing[(int64_t)kb * 16 + 10] = (long long)clock64();   // shader clock: MHz under load
             if (first) {
                 if (lane < npairs) vt[(lane / C) * PS_CMAX + lane % C] = a.W[((int64_t)(lane / C) * P + (kb - 1)) * C + lane % C];
             } else {
