@@ -342,6 +342,11 @@ void plan_routes(emagls_plan& p) {
         throw Error(EMAGLS_ERR_UNSUPPORTED, "the ill-conditioned low bins of this design need more than 27 orders on the orthonormal route "
                                             "(Gram route off or moved up by a conditioning check): not supported in this build");
     if (d.kind == EMAGLS_KIND_EMA_SH) { p.hh_end = 1; p.n_h = n_min; p.S_h = (n_min + 1) * (n_min + 1); p.ldS_h = round_up(p.S_h, 64); }
+    // the orthonormal route factors the first S_h columns of the grid's SH matrix (Cholesky of their Gram block): they must be
+    // independent.  The columns beyond S_h only enter through products (Gram matrix, order terms), so D < S is no obstacle.
+    if (p.D < p.S_h)
+        throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than the SH channels of the orthonormal route (the low bins need "
+                                            "(n_h + 1)^2 independent columns of the grid's SH matrix)");
     p.g0 = (p.gram_from > 0 && p.gram_from < k0) ? p.gram_from : k0;
     if (p.diffuse) p.g0 = 1;   // the constraint renders the HRTFs of every solved bin: G_k from the first one
     p.nb_gram = p.gram_from > 0 ? p.P - p.gram_from : 0;
@@ -482,7 +487,10 @@ void plan_setup(emagls_plan& p) {
             p.wide = true;
         }
         if (p.simOrder > 47) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 47 (array radius > ~10.9 cm at 48 kHz) is not supported in this build");
-        if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than simulated SH channels");
+        // (fewer directions than simulated SH channels are fine as long as the orders of the orthonormal route are covered:
+        // plan_routes checks D >= S_h.  The wide path orthogonalises all S columns.)
+        if (p.D < p.S && (p.wide || d.kind == EMAGLS_KIND_EMA_SH)) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than simulated SH channels");
+        if (p.D < p.C) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than channels");
         if (d.kind != EMAGLS_KIND_EMAGLS2 && d.kind != EMAGLS_KIND_EMA_SH && d.nmics < p.nOut)
             throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than output channels");
     } else {

@@ -53,6 +53,13 @@ for (D, taps, ln, natf, M, ataps, ft) in [(450, 64, 64, 450, 1, 32, 1000.0), (45
                                           (4096, 64, 64, 5000, 4, 64, 2000.0), (500, 64, 64, 37, 6, 64, 2000.0)]:
     CASES.append(("atf", D, taps, ln, 48000.0, natf, M, ataps, ft))
 
+# fewer HRIR directions than simulated SH channels (D < (N_sim+1)^2, the reference's SVD takes them as they come): fine as long
+# as the orders of the orthonormal route are covered (capi.hip, plan_routes); found by tools/fuzz_random.py
+D_BELOW_S = len(CASES)
+CASES.append(("emagls2", 590, 128, 342, 48000.0, 0.05603182265749108, 6, 4, "real"))     # simulation order 25: S = 676
+CASES.append(("emagls", 486, 64, 248, 96000.0, 0.027496569985500114, 30, 4, "real"))     # simulation order 25
+CASES.append(("emainch", 438, 128, 336, 32000.0, 0.06818923842651228, 13, 2, "complex"))  # simulation order 21: S = 484
+CASES.append(("emagls", 300, 64, 128, 48000.0, 0.042, 32, 4, "real"))                    # config 3's array on 300 directions: S = 400
 
 def run(case):
     kind = case[0]
@@ -87,7 +94,7 @@ def run(case):
 
 
 # cases of the sweep that run in the GPU test suite (each finishes in a few seconds including the oracle)
-FAST = [0, 3, 4, 5, 16, 18, 22, 23, 24, 26, 30, 31, 32, 33, 34, 36, 38, 40, 42, 47, 48, 49, 52, 53, 57, 58, 59]
+FAST = [0, 3, 4, 5, 16, 18, 22, 23, 24, 26, 30, 31, 32, 33, 34, 36, 38, 40, 42, 47, 48, 49, 52, 53, 57, 58, 59] + list(range(D_BELOW_S, D_BELOW_S + 4))
 # case 35 (order-15 circular harmonics, 31 microphones) is kept as a documented ill-posed comparison: the lowest bins have
 # cond(pwGrid) > 1/eps, where the clipped singular subspace -- hence the reference's own result -- is rounding noise
 ILL_POSED = [35]
