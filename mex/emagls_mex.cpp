@@ -7,8 +7,9 @@
 //
 // Build on a machine that has MATLAB (R2018a+, interleaved complex) and ROCm:
 //     mex -R2018a emagls_mex.cpp -I../include -L../emagls_amd/lib -lemagls
-// This container has neither mex.h nor MATLAB, so the file is compiled nowhere here; it is a thin
-// adapter: argument checks, pointer hand-over, mxArray allocation, error forwarding.
+// The build image has neither mex.h nor MATLAB: there the file is compiled against a test stand-in for mex.h and driven
+// by tests/test_mex_gateway.py (tests/mexstub/).  It is a thin adapter: argument checks, pointer hand-over, mxArray
+// allocation, error forwarding.
 #include <cctype>
 #include <cstring>
 #include <string>

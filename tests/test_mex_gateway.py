@@ -1,0 +1,150 @@
+"""The MATLAB gateway mex/emagls_mex.cpp, compiled against a test stand-in for mex.h (tests/mexstub/: MATLAB is not in the
+image) and driven from Python: the command dispatch, the argument marshalling (column-major arrays, interleaved complex,
+3-D ATF arrays, strings, logicals), the output allocation and the error forwarding are the gateway's own code; the stand-in
+only supplies the mx* / mex* functions it calls.  What this cannot show is that MATLAB's real mex.h agrees with the stand-in."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "mexstub")
+LIBDIR = os.path.join(ROOT, "emagls_amd", "lib")
+
+
+@pytest.fixture(scope="module")
+def mex():
+    if not os.path.exists(os.path.join(LIBDIR, "libemagls.so")):
+        pytest.skip("libemagls.so is not built")
+    out = os.path.join(STUB, "_build", "libmexharness.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    srcs = [os.path.join(ROOT, "mex", "emagls_mex.cpp"), os.path.join(STUB, "mexstub.cpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs + [os.path.join(STUB, "mex.h")]):
+        cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + STUB] + srcs + \
+              ["-L" + LIBDIR, "-lemagls", "-Wl,-rpath," + LIBDIR, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+    import torch  # noqa: F401  (first: the library then shares torch's HIP runtime, as in emagls_amd/_lib.py)
+    h = C.CDLL(out)
+    h.stub_array.restype = C.c_void_p
+    h.stub_array.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.c_void_p, C.c_int]
+    h.stub_string.restype = C.c_void_p
+    h.stub_string.argtypes = [C.c_char_p]
+    h.stub_logical.restype = C.c_void_p
+    h.stub_logical.argtypes = [C.c_int]
+    h.stub_free.argtypes = [C.c_void_p]
+    h.stub_ndim.argtypes = [C.c_void_p]
+    h.stub_dims.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    h.stub_is_complex.argtypes = [C.c_void_p]
+    h.stub_data.restype = C.c_void_p
+    h.stub_data.argtypes = [C.c_void_p]
+    h.stub_call.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+
+    class MexCallError(RuntimeError):
+        pass
+
+    def to_mx(v):
+        if isinstance(v, str):
+            return h.stub_string(v.encode())
+        if isinstance(v, (bool, np.bool_)):
+            return h.stub_logical(int(v))
+        a = np.asarray(v)
+        a = np.asfortranarray(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64))
+        if a.ndim < 2:
+            a = a.reshape((1, 1) if a.ndim == 0 else (-1, 1), order="F")
+        dims = (C.c_size_t * a.ndim)(*a.shape)
+        return h.stub_array(a.ndim, dims, a.ctypes.data_as(C.c_void_p), int(np.iscomplexobj(a)))
+
+    def from_mx(p):
+        nd = h.stub_ndim(p)
+        dims = (C.c_size_t * nd)()
+        h.stub_dims(p, dims)
+        shape = tuple(int(d) for d in dims)
+        n = int(np.prod(shape))
+        cplx = bool(h.stub_is_complex(p))
+        raw = np.ctypeslib.as_array(C.cast(h.stub_data(p), C.POINTER(C.c_double)), shape=(n * (2 if cplx else 1),)).copy()
+        return (raw.view(np.complex128) if cplx else raw).reshape(shape, order="F")
+
+    def call(nlhs, *args):
+        """[out1, ...] = emagls_mex(args...)"""
+        ins = [to_mx(a) for a in args]
+        prhs = (C.c_void_p * len(ins))(*ins)
+        plhs = (C.c_void_p * max(nlhs, 1))()
+        err = C.create_string_buffer(2048)
+        rc = h.stub_call(nlhs, plhs, len(ins), prhs, err, len(err))
+        for p in ins:
+            h.stub_free(p)
+        if rc:
+            raise MexCallError(err.value.decode())
+        outs = [from_mx(plhs[i]) for i in range(nlhs)]
+        for i in range(nlhs):
+            h.stub_free(plhs[i])
+        return outs
+
+    call.Error = MexCallError
+    return call
+
+
+def test_gateway_compiles_and_dispatches(mex):
+    """No GPU needed: the command string, the simulation-order query the wrappers use for caller-evaluated shFunction handles
+    (mex/getEMagLsFilters.m), and the gateway's own argument errors."""
+    from oracle import emagls_oracle as O
+    assert mex(1, "simorder", "emagls", 4, 48000.0, 0.042)[0].item() == O.simulation_order(4, 48000.0, 0.042) == 19
+    assert mex(1, "simorder", "emagls2", 1, 48000.0, 0.1)[0].item() == O.emagls2_simulation_order(48000.0, 0.1) == 44
+    with pytest.raises(mex.Error, match="first argument must be a command string"):
+        mex(0, 3.0)
+    with pytest.raises(mex.Error, match="not enough input arguments"):
+        mex(2, "nothing", np.zeros((4, 4)), np.zeros((4, 4)))
+    with pytest.raises(mex.Error, match="unknown command 'nothing'"):
+        mex(2, "nothing", *([np.zeros((4, 4))] * 12))
+    with pytest.raises(mex.Error, match="decode needs"):
+        mex(1, "decode", np.zeros((4, 4)))
+
+
+@pytest.fixture(scope="module")
+def thin(grids, hrirs):
+    sub = slice(0, 2702, 3)
+    return dict(hL=hrirs[0][:, sub], hR=hrirs[1][:, sub], azi=grids["azi"][sub], zen=grids["zen"][sub])
+
+
+@pytest.mark.gpu
+def test_gateway_design_calls_match_the_python_binding(mex, grids, thin):
+    """'ls' / 'magls' / 'emagls' (both bases) / 'fromatf' (3-D array) / 'decode' (real, complex, compensateDelay) through the
+    gateway equal the ctypes binding's results bit for bit: same library, same buffers, the marshalling is what differs."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    hL, hR, azi, zen = thin["hL"], thin["hR"], thin["azi"], thin["zen"]
+    wL, wR = mex(2, "ls", hL, hR, azi, zen, 3, "real")
+    eL, eR = E.getLsFilters(hL, hR, azi, zen, 3, "real")
+    assert wL.shape == eL.shape and np.array_equal(wL, eL) and np.array_equal(wR, eR)
+    for basis in ("real", "complex"):
+        wL, wR = mex(2, "emagls", hL, hR, azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, basis)
+        eL, eR = E.getEMagLsFilters(hL, hR, azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, basis)
+        assert wL.dtype == eL.dtype and wL.shape == eL.shape == (128, 25) and np.array_equal(wL, eL) and np.array_equal(wR, eR)
+    wL, wR = mex(2, "magls", hL, hR, azi, zen, 2, 48000.0, 128, "complex")
+    eL, eR = E.getMagLsFilters(hL, hR, azi, zen, 2, 48000.0, 128, "complex")
+    assert np.array_equal(wL, eL) and np.array_equal(wR, eR)
+    with pytest.raises(mex.Error, match="shDefinition must be 'real' or 'complex'"):
+        mex(2, "ls", hL, hR, azi, zen, 3, "imaginary")
+    with pytest.raises(mex.Error, match="eMagLS:native.*len too short"):      # the library's message, forwarded
+        mex(2, "magls", hL, hR, azi, zen, 2, 48000.0, 16, "real")
+    atf, aazi, azen = synth.glasses_atfs(natf=300, nmics=5, taps=48, fs=48000.0)
+    hg, ag = np.column_stack([azi, zen]), np.column_stack([aazi + 0.01, azen])
+    wL, wR = mex(2, "fromatf", hL, hR, hg, atf, ag, 48000.0, 128, 2000.0)
+    eL, eR = E.getEMagLsFiltersFromAtf(hL, hR, hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)[:2]
+    assert wL.shape == (128, 5) and np.array_equal(wL, eL) and np.array_equal(wR, eR)
+    rng = np.random.default_rng(3)
+    sig = rng.standard_normal((3000, 25))
+    fL, fR = E.getEMagLsFilters(hL, hR, azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "real")
+    assert np.array_equal(mex(1, "decode", sig, fL, fR, False)[0], E.binauralDecode(sig, 48000, fL, fR, 48000))
+    assert np.array_equal(mex(1, "decode", sig, fL, fR, True)[0], E.binauralDecode(sig, 48000, fL, fR, 48000, True))
+    cL, cR = E.getEMagLsFilters(hL, hR, azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "complex")
+    sc = sig + 1j * rng.standard_normal(sig.shape)
+    out, imag = mex(2, "decode", sc, cL, cR, False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = E.binauralDecode(sc, 48000, cL, cR, 48000)
+    assert np.array_equal(out, ref) and imag.shape == (1, 2) and np.all(imag > 0)
