@@ -223,6 +223,10 @@ struct emagls_batch {
     // they hold the same grids and ATF set (checked on the device whenever one of them was replaced)
     bool atf = false, atf_share = false, atf_inputs_same = false;
     uint64_t atf_checked_version = ~0ull;
+    // array designs that differ only in their HRIR sets (same grids, array, orders): the geometry stages run once (opt-in,
+    // emagls_batch_set_geometry_sharing; checked on the device whenever a grid was replaced)
+    bool geo_want = false, geo_share = false, geo_inputs_same = false;
+    uint64_t geo_checked_version = ~0ull;
     int* cmp_flag = nullptr;
     int nstreams = 1;                          // lane mode: streams the stages before the sweep fork onto (emagls_batch_set_streams)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
@@ -1554,7 +1558,7 @@ void batch_sweep_stage(emagls_batch& b) {
     HalfSweepMulti h{};
     h.n = (int)b.plans.size();
     for (int j = 0; j < h.n; ++j) h.a[j] = emagls_half_args(*b.plans[j]);
-    if (b.atf_share)   // one ATF side for every subject
+    if (b.atf_share || b.geo_share)   // one ATF side / one geometry for every subject
         for (int j = 1; j < h.n; ++j) { h.a[j].G = h.a[0].G; h.a[j].Yri = h.a[0].Yri; h.a[j].Mw = h.a[0].Mw; h.a[j].cond_ok = h.a[0].cond_ok; }
     emagls_plan& q0 = *b.plans[0];
     const int kk0 = std::max(q0.kcut0, 1);
@@ -1708,6 +1712,124 @@ void batch_execute_atf(emagls_batch& b) {
     if (!replay) ++b.eager_runs;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batches of HRIR sets on ONE geometry (north_star: independent jobs "per HRTF set"): same HRIR grid, same array, same
+// orders and lengths.  Everything of lib/getEMagLsFilters.m:44-70,85-93 -- the SH matrices, the array model, pwGrid_k and its
+// regularised inverse of every bin -- depends on the geometry only; the HRIR set enters through the spectra (:72-81), the
+// least-squares rows (:94) and the sweep's magnitudes (:99-102).  Plan 0 runs the whole pipeline; the other plans run their
+// HRIR prologue, their least-squares rows on plan 0's factors, and sweep on plan 0's G_k / M_k (batch_sweep_stage).
+// ---------------------------------------------------------------------------------------------
+void batch_geo_decide_sharing(emagls_batch& b) {
+    bool share = false;
+    if (b.geo_want && b.plans.size() > 1) {
+        emagls_plan& p0 = *b.plans[0];
+        bool eligible = (p0.d.kind == EMAGLS_KIND_EMAGLS || p0.d.kind == EMAGLS_KIND_EMAGLS2 || p0.d.kind == EMAGLS_KIND_EMA_CH) && !p0.wide &&
+                        !p0.diffuse && !p0.custom_basis;
+        for (auto* p : b.plans) {
+            const emagls_design_desc &x = p->d, &y = p0.d;
+            eligible = eligible && x.kind == y.kind && x.order == y.order && x.fs == y.fs && x.len == y.len && x.nsamp == y.nsamp &&
+                       x.ndirs == y.ndirs && x.mic_radius == y.mic_radius && x.nmics == y.nmics && x.basis == y.basis &&
+                       x.sim_order_pad == y.sim_order_pad && p->wide == p0.wide && p->diffuse == p0.diffuse && p->custom_basis == p0.custom_basis &&
+                       p->real_internal == p0.real_internal && p->gram_from == p0.gram_from && p->hh_end == p0.hh_end && p->n_h == p0.n_h &&
+                       p->g0 == p0.g0 && p->sweep_persist == p0.sweep_persist;
+        }
+        if (eligible) {
+            uint64_t ver = 0;
+            for (auto* p : b.plans) ver = ver * 1000003ull + p->atf_side_version;
+            if (ver != b.geo_checked_version) {
+                if (!b.cmp_flag) HIP_CHECK(hipMalloc(&b.cmp_flag, 16));
+                HIP_CHECK(hipStreamSynchronize(b.stream));
+                HIP_CHECK(hipMemsetAsync(b.cmp_flag, 0, 16, b.stream));
+                for (size_t j = 1; j < b.plans.size(); ++j)
+                    for (const char* name : {"hrir_azi", "hrir_zen", "mic_azi", "mic_zen"})
+                        launch_compare_words(p0.get(name), b.plans[j]->get(name), p0.bufs[name].bytes, b.cmp_flag, b.stream);
+                int differ = 0;
+                HIP_CHECK(hipMemcpyAsync(&differ, b.cmp_flag, sizeof differ, hipMemcpyDeviceToHost, b.stream));
+                HIP_CHECK(hipStreamSynchronize(b.stream));
+                b.geo_checked_version = ver;
+                b.geo_inputs_same = differ == 0;
+            }
+            share = b.geo_inputs_same;
+        }
+    }
+    if (share != b.geo_share) {   // (the two modes enqueue different stages: nothing captured for the other one may be replayed)
+        for (auto* p : b.plans) drop_plan_graphs(*p);
+        drop_batch_graphs(b);
+        b.geo_share = share;
+    }
+}
+// a subject of a geometry-sharing batch, first part: what needs its HRIRs only (lib/getEMagLsFilters.m:72-81)
+void emagls_subject_prologue(emagls_plan& p, const emagls_plan& g) {
+    const emagls_design_desc& d = p.d;
+    hipStream_t st = p.stream;
+    const int ls_end = std::min(g.kcut0, g.P);
+    p.stage_names.clear();
+    p.sync_used = 0;
+    launch_zero(p.get("flag"), sizeof(int) * NFLAG, st);
+    launch_zero(p.get("W"), p.bufs["W"].bytes, st);
+    launch_twiddles(p.nfft, p.get("tw"), st);
+    launch_hrir_grpdelay(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, d.ndirs, p.nfft, p.get("tw"), p.get<double>("dirsum"),
+                         p.get<double>("grpd"), st);
+    launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"), p.get<double>("grpd"), 0, ls_end,
+                    p.kcut0, p.get("Hc"), p.get<double>("Habs"), p.ldD, st, ls_end > 0 ? p.get<double>("HcT") : nullptr,
+                    round_up(4 * std::max(ls_end, 1), 64));
+}
+// second part, behind plan g's stages: the least-squares bins (:94) on g's factors -- H conj(Q) R^-1 rows and the
+// back-transform of the Householder-route bins (into the subject's own Z), G_k / M_k of g for the Gram-route bins
+void emagls_subject_rows(emagls_plan& p, emagls_plan& g) {
+    hipStream_t st = p.stream;
+    const bool cb = g.cplx_basis;
+    const int gf = g.gram_from, hh_end = g.hh_end, Sh = g.S_h, ldSh = g.ldS_h, nOrdH = g.n_h + 1, nOrd = g.simOrder + 1;
+    const int ls_end = std::min(g.kcut0, g.P);
+    const int ls_h = std::min(ls_end, hh_end);
+    const int64_t g_stride = (int64_t)g.C * g.ldD;
+    if (hh_end > 1) {
+        launch_hy_conj_mfma(p.get<double>("HcT"), round_up(4 * std::max(ls_end, 1), 64), ls_end, g.get("Yc"), g.ldS, cb, (int)g.D, Sh,
+                            p.get<double>("Hyp"), p.get("Hq"), ldSh, st);
+        launch_qform(p.get("Hq"), g.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), Sh, 2 * (int64_t)std::max(ls_end, 1), ldSh, true, p.get("Hq"), st);
+        FactorArgs fa{};
+        fa.S = Sh; fa.C = g.C; fa.ldS = ldSh; fa.kb0 = 1; fa.P = g.P;
+        fa.Tn = g.get("Tn"); fa.bn = g.get<cplx>("bn"); fa.nOrders = nOrdH; fa.bn_stride = nOrd;
+        fa.reg_mode = 0; fa.reg_c = SVD_REGUL_CONST;
+        fa.Z = p.get<cplx>("Z");
+        fa.Mw = g.get<cplx>("Mw");
+        fa.Vws = g.get<cplx>("Vws"); fa.sv = g.get<double>("sv");
+        fa.Hq = p.get<cplx>("Hq"); fa.ldHq = ldSh; fa.hq_estride = (int64_t)ls_end * ldSh; fa.ls_end = ls_h;
+        fa.hq_conj = 1;
+        fa.route = g.get<int>("route"); fa.status = p.get<int>("flag");
+        fa.cond_limit = 10.0 * GRAM_COND_EST;
+        fa.W = p.get<cplx>("W"); fa.sweeps_out = nullptr;
+        fa.tauw = g.get<double>("tauw"); fa.R2w = g.get<cplx>("R2w"); fa.Nw = g.get<cplx>("Nw");
+        fa.cond_ok = g.get<double>("cond_ok");
+        launch_factor(fa, hh_end - 1, cb, st, 2);
+    }
+    if (gf > 0 && gf < ls_end)
+        launch_ls_gram(p.get("Hc"), p.ldD, ls_end, g.get<cplx>("G") - (int64_t)g.g0 * g_stride, g_stride, g.ldD, g.get("Mw"), (int)g.D, g.C, g.P, gf,
+                       ls_end, p.get("W"), st);
+}
+void batch_execute_geo(emagls_batch& b) {
+    emagls_plan& p0 = *b.plans[0];
+    b.used = 0;
+    for (auto* p : b.plans) b.depend(p->stream, b.stream);   // (the previous execute of this batch is done with the buffers)
+    // (eager launches: the subjects' stages wait on plan 0's stream, which separately captured graphs cannot express)
+    plan_pre_stage(p0);
+    for (size_t j = 1; j < b.plans.size(); ++j) emagls_subject_prologue(*b.plans[j], p0);
+    for (size_t j = 1; j < b.plans.size(); ++j) {
+        emagls_plan& p = *b.plans[j];
+        b.depend(p.stream, p0.stream);
+        emagls_subject_rows(p, p0);
+    }
+    for (auto* p : b.plans) b.depend(b.stream, p->stream);
+    batch_sweep_stage(b);
+    for (auto* p : b.plans) {
+        b.depend(p->stream, b.stream);
+        emagls_post_sweep(*p);
+        b.depend(b.stream, p->stream);  // batch stream completion == all results ready
+        p->executed = true;
+        p->sweep_launches = p0.sweep_persist ? 1 : p0.P - std::max(p0.kcut0, 1);
+    }
+}
+
 void batch_execute(emagls_batch& b) {
     for (auto* p : b.plans)
         if (!p) throw Error(EMAGLS_ERR_ARG, "a plan of this batch has been destroyed");
@@ -1715,6 +1837,8 @@ void batch_execute(emagls_batch& b) {
     for (auto* p : b.plans)
         if (!p->have_hrirs || (p->custom_basis ? !p->have_basis : (!p->have_hrir_grid || !p->have_mic_grid)))
             throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grids (or SH matrices) and HRIRs");
+    batch_geo_decide_sharing(b);
+    if (b.geo_share) { batch_execute_geo(b); return; }
     if (b.lanes) {
         batch_execute_lanes(b);
         return;
@@ -2305,6 +2429,7 @@ int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* ze
         p->upload("kr", kr.data(), sizeof(double) * p->P);
         HIP_CHECK(hipStreamSynchronize(p->stream));
         p->have_mic_grid = true;
+        ++p->atf_side_version;   // (a geometry-sharing batch compares the grids again)
     });
 }
 int emagls_plan_set_basis(emagls_plan* p, const void* Y_hrir, const void* Y_mic) {
@@ -2586,6 +2711,21 @@ int emagls_set_batch_max(int max_designs, int* previous) {
         if (max_designs < 1 || max_designs > SWEEP_MULTI_MAX) throw Error(EMAGLS_ERR_ARG, "a batch holds 1..16 designs");
         const int prev = g_batch_max.exchange(max_designs);
         if (previous) *previous = prev;
+    });
+}
+int emagls_batch_set_geometry_sharing(emagls_batch* b, int enable) {
+    return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
+        if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        HIP_CHECK(hipStreamSynchronize(b->stream));
+        b->geo_want = enable != 0;
+        b->geo_checked_version = ~0ull;
+    });
+}
+int emagls_batch_shares_geometry(emagls_batch* b, int* shared) {
+    return guarded([&] {
+        if (!b || !shared) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        *shared = b->geo_share ? 1 : 0;
     });
 }
 int emagls_batch_shares_atf_side(emagls_batch* b, int* shared) {

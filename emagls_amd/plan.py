@@ -157,6 +157,17 @@ class Batch:
         L.check(self._lib.emagls_batch_shares_atf_side(self._h, C.byref(v)))
         return bool(v.value)
 
+    def share_geometry(self, enable=True):
+        """HRIR sets on one geometry (same grids, array, orders): run the geometry stages once for the batch (opt-in; the grids
+        are compared on the device, plans that differ run as independent designs)."""
+        L.check(self._lib.emagls_batch_set_geometry_sharing(self._h, int(bool(enable))))
+
+    def shares_geometry(self):
+        """True when the last execute ran the geometry stages once for all plans."""
+        v = C.c_int(0)
+        L.check(self._lib.emagls_batch_shares_geometry(self._h, C.byref(v)))
+        return bool(v.value)
+
     def set_streams(self, n):
         """Lane mode: fork the stages before the sweep onto n (1..4) streams (see emagls_batch_set_streams)."""
         L.check(self._lib.emagls_batch_set_streams(self._h, int(n)))

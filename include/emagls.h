@@ -318,6 +318,15 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch);
  * design when the batch has the device to itself, but kernels of other batches then only find room on the CUs the sweep does not
  * use, so keep 8 when several batches are in flight.  *previous (optional) receives the old value. */
 int emagls_set_batch_max(int max_designs, int* previous);
+/* Batches of HRIR sets on ONE geometry (the loop over subjects around lib/getEMagLsFilters.m:32 / getEMagLs2Filters.m:32 /
+ * getEMagLsFiltersEMAinCH.m:32 with the same grids and array): with sharing enabled, a batch whose plans agree in every
+ * geometry input (compared on the device whenever a grid is replaced) runs the SH matrices, the array model, pwGrid_k and its
+ * regularised inverses ONCE (plan 0) and per plan only what its HRIRs enter: spectra, least-squares rows, the sweep (on plan
+ * 0's operands) and the epilogue.  Off by default: a batch then treats its designs as independent.  Plans that do not agree
+ * (or kinds without the option: LS / MagLS / FromAtf / EMAinSH / more than 32 channels) run as before;
+ * emagls_batch_shares_geometry reports what the last execute did. */
+int emagls_batch_set_geometry_sharing(emagls_batch* batch, int enable);
+int emagls_batch_shares_geometry(emagls_batch* batch, int* shared);
 /* A batch may also hold EMAGLS_KIND_FROM_ATF plans of one shape -- the HRTF subjects of one ATF set (BASELINE config 5: 8 subjects).
  * lib/getEMagLsFiltersFromAtf.m:54-95,100-104: the spectra of the matched ATFs and their per-bin factors do not depend on the
  * HRIRs.  When all plans hold the same grids and the same ATF set (compared on the device whenever one of them was replaced) the

@@ -388,6 +388,117 @@ def test_gram_matrix_of_a_lane_batch(grids, thin):
         p.close()
 
 
+@pytest.mark.parametrize("kind", ["emagls", "emagls2", "emainch"])
+def test_hrir_sets_on_one_geometry_share_it(grids, thin, kind):
+    """Batches of HRIR sets on one geometry (the loop over subjects around getEMagLsFilters with the same grids and array):
+    with Batch.share_geometry() the SH matrices, the array model, pwGrid_k and its regularised inverses run once (plan 0) and
+    every other plan only runs what its HRIRs enter -- same filters as the single designs; replays are bitwise reproducible;
+    a plan whose microphone grid is replaced afterwards makes the batch fall back to independent designs."""
+    import ctypes
+    from emagls_amd import Batch, Plan, _lib as L
+    rng = np.random.default_rng(31)
+    K = {"emagls": L.KIND_EMAGLS, "emagls2": L.KIND_EMAGLS2, "emainch": L.KIND_EMA_CH}[kind]
+    order, nm = (4, 32) if kind != "emainch" else (3, 9)
+    maz = grids["mic_azi"] if kind != "emainch" else np.linspace(0, 2 * np.pi, nm, endpoint=False) + 0.2
+    plans, singles = [], []
+    n = 6
+    for j in range(n):
+        hL = thin["hL"] * (1.0 + 0.07 * j) + 1e-3 * rng.standard_normal(thin["hL"].shape)
+        hR = thin["hR"] * (1.0 - 0.03 * j) + 1e-3 * rng.standard_normal(thin["hR"].shape)
+        p = Plan(K, "complex", order, 48000.0, 128, hL.shape[0], hL.shape[1], grids["mic_radius"], nm)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(maz, None if kind == "emainch" else grids["mic_zen"])
+        p.set_hrirs(hL, hR)
+        p.execute()
+        singles.append(p.get_filters())
+        plans.append(p)
+    b = Batch(plans)
+    b.execute()
+    assert not b.shares_geometry()                        # off by default: independent designs
+    indep = b.get_filters()
+    b.share_geometry(True)
+    outs = []
+    for it in range(3):
+        b.execute()
+        assert b.shares_geometry()
+        outs.append(b.get_filters())
+    assert plans[1].info().num_sweep_launches == 1
+    worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(outs[0], singles))
+    worst_i = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(outs[0], indep))
+    print(f"{kind}: {n} HRIR sets on one geometry vs single plans: worst rel = {worst:.3e}; vs the same batch unshared {worst_i:.3e}")
+    assert worst < 1e-12 and worst_i < 1e-9      # (a lane batch warm-starts its Jacobi runs differently from a single design)
+    for it in (1, 2):
+        for a, c in zip(outs[0], outs[it]):
+            assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    assert rel(singles[0][0], singles[3][0]) > 1e-3
+    # one plan leaves the common geometry: the batch runs its designs independently again, with the new array
+    plans[2].set_mic_grid(maz + 0.11, None if kind == "emainch" else grids["mic_zen"])
+    b.execute()
+    assert not b.shares_geometry()
+    moved = b.get_filters()
+    plans[2].execute()
+    ref2 = plans[2].get_filters()
+    assert max(rel(moved[2][0], ref2[0]), rel(moved[2][1], ref2[1])) < 1e-9
+    assert max(rel(moved[0][0], singles[0][0]), rel(moved[5][1], singles[5][1])) < 1e-9
+    assert rel(moved[2][0], singles[2][0]) > 1e-4
+    b.close()
+    for p in plans:
+        p.close()
+
+
+def test_geometry_sharing_with_twelve_hrir_sets_and_kinds_without_the_option(grids, thin):
+    """9-16 HRIR sets share one sweep launch (twin workgroups) on plan 0's operands; a kind without the option (EMAinSH) accepts the switch
+    and runs as before."""
+    import ctypes
+    from emagls_amd import Batch, Plan, _lib as L
+    rng = np.random.default_rng(32)
+    lib = L.load()
+    prev = ctypes.c_int(0)
+    L.check(lib.emagls_set_batch_max(16, ctypes.byref(prev)))
+    try:
+        plans, singles = [], []
+        for j in range(12):
+            hL = thin["hL"] * (1.0 + 0.05 * j) + 1e-3 * rng.standard_normal(thin["hL"].shape)
+            p = Plan(L.KIND_EMAGLS, "real", 4, 48000.0, 128, hL.shape[0], hL.shape[1], grids["mic_radius"], 32)
+            p.set_hrir_grid(thin["azi"], thin["zen"])
+            p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+            p.set_hrirs(hL, thin["hR"])
+            p.execute()
+            singles.append(p.get_filters())
+            plans.append(p)
+        b = Batch(plans)
+    finally:
+        L.check(lib.emagls_set_batch_max(prev.value, None))
+    b.share_geometry(True)
+    b.execute()
+    out = b.get_filters()
+    assert b.shares_geometry() and plans[0].info().num_sweep_launches == 1
+    worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(out, singles))
+    print(f"12 HRIR sets on one geometry vs single plans: worst rel = {worst:.3e}")
+    assert worst < 1e-12
+    b.close()
+    for p in plans:
+        p.close()
+    mp = []
+    ma = np.linspace(0, 2 * np.pi, 9, endpoint=False) + 0.2
+    for j in range(3):
+        p = Plan(L.KIND_EMA_SH, "real", 2, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], grids["mic_radius"], 9)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(ma, None)
+        p.set_hrirs(thin["hL"] * (1 + 0.1 * j), thin["hR"])
+        p.execute()
+        mp.append((p, p.get_filters()))
+    b = Batch([p for p, _ in mp])
+    b.share_geometry(True)
+    b.execute()
+    assert not b.shares_geometry()
+    for (p, ref), o in zip(mp, b.get_filters()):
+        assert rel(o[0], ref[0]) < 1e-10
+    b.close()
+    for p, _ in mp:
+        p.close()
+
+
 def test_sixteen_design_lane_batch(grids, thin, monkeypatch):
     """9 to 16 designs (opt-in: emagls_set_batch_max(16), the product's default stays 8 and so does the suite's) share one sweep
     launch with two designs per XCD: a batch of 12 designs (different HRIR sets and microphone grids) equals the single designs
