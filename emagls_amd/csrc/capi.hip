@@ -1807,27 +1807,84 @@ void emagls_subject_rows(emagls_plan& p, emagls_plan& g) {
         launch_ls_gram(p.get("Hc"), p.ldD, ls_end, g.get<cplx>("G") - (int64_t)g.g0 * g_stride, g_stride, g.ldD, g.get("Mw"), (int)g.D, g.C, g.P, gf,
                        ls_end, p.get("W"), st);
 }
+// One stream for the whole batch (the subjects' stages are short and the sweep chain is what bounds a batch of HRIR sets), so
+// that the stages before and after the sweep are two single-stream graphs: issued eagerly, the ~250 launches of a 16-set batch
+// cost 11 ms of host time (measured: 1380 sets/s whatever the number of batches in flight).
+void batch_geo_stage(emagls_batch& b, int part) {
+    emagls_plan& p0 = *b.plans[0];
+    std::vector<hipStream_t> keep;
+    for (auto* p : b.plans) { keep.push_back(p->stream); p->stream = b.stream; }
+    auto restore = [&] { for (size_t j = 0; j < b.plans.size(); ++j) b.plans[j]->stream = keep[j]; };
+    const int nsub = (int)b.plans.size() - 1;
+    try {
+        if (part == 0) {
+            plan_pre_stage(p0);
+            if (b.lanes && nsub > 0) {
+                // lane batch: the subjects' stages are ONE launch per kernel for all of them (plans 1.. at the arena stride).  The
+                // few geometry operands those kernels read (conj(Y), R, the Householder-route factors, M_k and G_k of the
+                // least-squares bins: ~40 MB) are copied into the subjects' own slots first, so that every pointer of a launch
+                // moves by the same stride; the large ones (G_k, M_k of the swept bins) are only read by the sweep, through
+                // plan 0's pointers.
+                emagls_plan& g = p0;
+                emagls_plan& p1 = *b.plans[1];
+                const bool cb = g.cplx_basis;
+                const int gf = g.gram_from, hh_end = g.hh_end, ldSh = g.ldS_h;
+                const int ls_end = std::min(g.kcut0, g.P);
+                const size_t g_stride_b = sizeof(cplx) * (size_t)g.C * g.ldD;
+                auto bc = [&](const char* name, size_t off, size_t bytes) {
+                    if (!g.has(name) || bytes == 0) return;
+                    bytes = std::min(bytes, g.bufs[name].bytes - off);
+                    launch_broadcast_lanes(g.get<char>(name) + off, bytes, b.stride, nsub, b.stream);
+                };
+                if (hh_end > 1) {
+                    bc("Yc", 0, g.bufs["Yc"].bytes);
+                    bc(cb ? "R" : "Rc", 0, g.bufs[cb ? "R" : "Rc"].bytes);
+                    bc("Vws", 0, sizeof(cplx) * (size_t)(hh_end - 1) * g.C * ldSh);
+                    bc("Nw", 0, sizeof(cplx) * (size_t)(hh_end - 1) * g.C * g.C);
+                    bc("tauw", 0, sizeof(double) * (size_t)(hh_end - 1) * g.C);
+                    bc("cond_ok", 0, sizeof(double) * (size_t)g.P);
+                }
+                if (gf > 0 && gf < ls_end) {
+                    bc("G", (size_t)(gf - g.g0) * g_stride_b, (size_t)(ls_end - gf) * g_stride_b);
+                    bc("Mw", 0, sizeof(cplx) * (size_t)ls_end * g.C * g.C);
+                }
+                BatchScope sc(nsub, b.stride);
+                emagls_subject_prologue(p1, p0);
+                emagls_subject_rows(p1, p1);
+            } else {
+                for (size_t j = 1; j < b.plans.size(); ++j) {
+                    emagls_subject_prologue(*b.plans[j], p0);
+                    emagls_subject_rows(*b.plans[j], p0);
+                }
+            }
+        } else if (b.lanes) {
+            BatchScope sc((int)b.plans.size(), b.stride);
+            emagls_post_sweep(p0);
+        } else {
+            for (auto* p : b.plans) emagls_post_sweep(*p);
+        }
+    } catch (...) {
+        restore();
+        throw;
+    }
+    restore();
+}
 void batch_execute_geo(emagls_batch& b) {
     emagls_plan& p0 = *b.plans[0];
-    b.used = 0;
-    for (auto* p : b.plans) b.depend(p->stream, b.stream);   // (the previous execute of this batch is done with the buffers)
-    // (eager launches: the subjects' stages wait on plan 0's stream, which separately captured graphs cannot express)
-    plan_pre_stage(p0);
-    for (size_t j = 1; j < b.plans.size(); ++j) emagls_subject_prologue(*b.plans[j], p0);
-    for (size_t j = 1; j < b.plans.size(); ++j) {
-        emagls_plan& p = *b.plans[j];
-        b.depend(p.stream, p0.stream);
-        emagls_subject_rows(p, p0);
+    const bool replay = b.use_graph && b.eager_runs >= 1;
+    if (replay && !b.graph_exec) {
+        capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_geo_stage(b, 0); });
+        capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_geo_stage(b, 2); });
     }
-    for (auto* p : b.plans) b.depend(b.stream, p->stream);
-    batch_sweep_stage(b);
+    b.used = 0;
+    if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_geo_stage(b, 0);
+    batch_sweep_stage(b);   // (never captured: see SweepChain)
+    if (replay) HIP_CHECK(hipGraphLaunch(b.post_exec, b.stream)); else batch_geo_stage(b, 2);
     for (auto* p : b.plans) {
-        b.depend(p->stream, b.stream);
-        emagls_post_sweep(*p);
-        b.depend(b.stream, p->stream);  // batch stream completion == all results ready
         p->executed = true;
         p->sweep_launches = p0.sweep_persist ? 1 : p0.P - std::max(p0.kcut0, 1);
     }
+    if (!replay) ++b.eager_runs;
 }
 
 void batch_execute(emagls_batch& b) {

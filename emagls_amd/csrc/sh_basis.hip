@@ -138,6 +138,20 @@ void launch_zero(void* p, size_t bytes, hipStream_t st) {
     KERNEL_CHECK();
 }
 
+// dst_z = src for z < n lanes, dst_z = src + (z + 1) * stride bytes: a lane batch's plan 0 hands operands that are the same for
+// every lane to the other lanes' own slots (16-byte words; every buffer is allocated in multiples of 16 bytes)
+__global__ void broadcast_lanes_kernel(const uint4* __restrict__ src, int64_t n16, size_t stride) {
+    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(const_cast<uint4*>(src)) + ((size_t)blockIdx.z + 1) * stride);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_broadcast_lanes(const void* src, size_t bytes, size_t stride, int nlanes, hipStream_t st) {
+    const int64_t n16 = (int64_t)((bytes + 15) / 16);
+    if (n16 == 0 || nlanes <= 0) return;
+    const unsigned gx = (unsigned)std::min<int64_t>(1024, ceil_div(n16, 256));
+    broadcast_lanes_kernel<<<dim3(gx, 1, (unsigned)nlanes), 256, 0, st>>>((const uint4*)src, n16, stride);
+    KERNEL_CHECK();
+}
+
 // *differ = 1 when two device buffers differ in any 8-byte word (a batch of FromAtf subjects checks that its plans really hold
 // the same ATF set and grids before it computes the ATF side once for all of them)
 __global__ void compare_words_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, int64_t n8, int* differ) {

@@ -186,6 +186,61 @@ def config5(reps=4, subjects=8):
     return out
 
 
+def config3_hrir_sets(n_batches=3, per_batch=16, rounds=6):
+    """BASELINE config 3's design (em32, r = 4.2 cm, N = 4, complex SH, 2702 directions, 512 taps) as a job list of HRIR SETS on
+    one geometry -- the loop over subjects around getEMagLsFilters with the same grids and array: batches with
+    emagls_batch_set_geometry_sharing run the geometry stages once per batch.  n_batches batches of per_batch sets in flight,
+    every execute recomputes everything (plan 0's geometry included) from the inputs resident in HBM."""
+    import ctypes
+    import torch
+    from emagls_amd import Batch, Plan, synth, _lib as L
+    azi, zen, maz, mzn = _grids()
+    lib = L.load()
+    prev = ctypes.c_int(0)
+    L.check(lib.emagls_set_batch_max(max(per_batch, 8), ctypes.byref(prev)))
+    units = []
+    try:
+        for u in range(n_batches):
+            plans = []
+            for j in range(per_batch):
+                hL, hR = synth.rigid_sphere_hrirs(azi, zen, seed=777 + 100 * u + j)
+                p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 512, hL.shape[0], hL.shape[1], 0.042, 32)
+                p.set_hrir_grid(azi, zen)
+                p.set_mic_grid(maz, mzn)
+                p.set_hrirs(hL, hR)
+                plans.append(p)
+            b = Batch(plans)
+            b.set_stream(torch.cuda.Stream().cuda_stream)
+            b.share_geometry(True)
+            units.append((plans, b))
+    finally:
+        L.check(lib.emagls_set_batch_max(prev.value, None))
+    for plans, b in units:
+        for _ in range(2):
+            b.execute()
+        b.synchronize()
+    shared = all(b.shares_geometry() for _, b in units)
+    t0 = time.perf_counter()
+    for r in range(rounds):
+        for plans, b in units:
+            if r:
+                b.synchronize()
+            b.execute()
+    for plans, b in units:
+        b.synchronize()
+    dt = time.perf_counter() - t0
+    for plans, b in units:
+        b.get_filters()   # (status check)
+        b.close()
+        for p in plans:
+            p.close()
+    n = rounds * n_batches * per_batch
+    return {"hrir_sets": n, "batches_in_flight": n_batches, "sets_per_batch": per_batch, "geometry_shared": shared,
+            "ms_per_set": round(dt / n * 1e3, 4), "filter_sets_per_s": round(n / dt, 1),
+            "note": "same filters as independent designs (bit-identical to single plans in tests/test_gpu_parity.py); the headline "
+                    "figure of this line treats its designs as independent and does NOT use this"}
+
+
 def binaural_decode(nsamp=120000, nch=25, length=512, reps=10):
     """north_star item (iii) / SURVEY a13: dependencies/binauralDecode.m:33-42 at the harness's size -- a 120 000-sample SH
     recording x 25 channels through 512-tap filters, both ears -- real and complex SH, buffers resident in HBM
@@ -242,6 +297,10 @@ def run():
         out["config4_rank_share"] = config4_rank_share()
     except Exception as e:
         out["config4_rank_share"] = {"error": repr(e)}
+    try:
+        out["config3_hrir_sets_on_one_geometry"] = config3_hrir_sets()
+    except Exception as e:
+        out["config3_hrir_sets_on_one_geometry"] = {"error": repr(e)}
     try:
         out["em64_emagls2"] = em64()
     except Exception as e:
