@@ -265,3 +265,55 @@ def emagls_from_atf_subjects(subjects, hrirGridAziZenRad, atfIrs, atfGridAziZenR
     if world == 1:
         return local
     return _gather_on_rank0(local, shards, n, group, None)
+
+
+def emagls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, micGridZenRad, order, fs, length,
+                     shDefinition="real", kind="emagls", group=None, max_batch=8):
+    """getEMagLsFilters (lib/getEMagLsFilters.m:32; kind 'emagls2': getEMagLs2Filters, 'emainch': getEMagLsFiltersEMAinCH with
+    micGridZenRad None) for every HRIR set of `subjects` = [(hL, hR), ...] on ONE HRIR grid and ONE array: the loop over
+    subjects a user of the reference writes around the call.  The sets are spread over the ranks; each rank runs its share in
+    batches that compute the geometry stages once (Batch.share_geometry: SH matrices, array model, every bin's regularised
+    inverse) and sweep all their sets in one resident launch; one gather.  Same filters as the single calls.
+    Returns [(wL, wR), ...] in the order of `subjects` on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    from . import Batch, Plan, _lib as L
+    K = {"emagls": L.KIND_EMAGLS, "emagls2": L.KIND_EMAGLS2, "emainch": L.KIND_EMA_CH}[kind]
+    azi = np.asarray(hrirGridAziRad, dtype=np.float64)
+    zen = np.asarray(hrirGridZenRad, dtype=np.float64)
+    maz = np.asarray(micGridAziRad, dtype=np.float64)
+    mzn = None if micGridZenRad is None else np.asarray(micGridZenRad, dtype=np.float64)
+    have_pg = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if have_pg else 0
+    world = dist.get_world_size(group) if have_pg else 1
+    n = len(subjects)
+    shards = shard_jobs(np.ones(n), world)
+    local = []
+    mine = shards[rank]
+    for i in range(0, len(mine), max_batch):
+        plans = []
+        try:
+            for j in mine[i:i + max_batch]:
+                hL = np.asfortranarray(subjects[j][0], dtype=np.float64)
+                hR = np.asfortranarray(subjects[j][1], dtype=np.float64)
+                p = Plan(K, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], float(micRadius), maz.size)
+                p.set_hrir_grid(azi, zen)
+                p.set_mic_grid(maz, mzn)
+                p.set_hrirs(hL, hR)
+                plans.append(p)
+            if len(plans) == 1:
+                plans[0].execute()
+                local.append(plans[0].get_filters())
+            else:
+                b = Batch(plans)
+                try:
+                    b.share_geometry(True)
+                    b.execute()
+                    local += b.get_filters()
+                finally:
+                    b.close()
+        finally:
+            for p in plans:
+                p.close()
+    if world == 1:
+        return local
+    return _gather_on_rank0(local, shards, n, group, None)

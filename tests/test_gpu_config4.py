@@ -236,3 +236,12 @@ def test_job_lists_of_config4_and_config5(grids, hrirs64):
     for j in range(3):
         wL, wR = E.getEMagLsFiltersFromAtf(subjects[j][0], subjects[j][1], hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)
         assert rel(res[j][0], wL) < 1e-11 and rel(res[j][1], wR) < 1e-11
+    # HRIR sets on one grid and one array (the loop over subjects around getEMagLsFilters): batches that share the geometry stages
+    from emagls_amd.batch import emagls_hrir_sets
+    subjects5 = [synth.rigid_sphere_hrirs(azi, zen, seed=50 + j, head_radius=0.08 + 0.003 * j) for j in range(5)]
+    res = emagls_hrir_sets(subjects5, azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "complex", max_batch=3)
+    assert len(res) == 5     # batches of 3 + 2
+    for j in range(5):
+        wL, wR = E.getEMagLsFilters(subjects5[j][0], subjects5[j][1], azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4,
+                                    48000.0, 128, "complex")
+        assert res[j][0].dtype == wL.dtype and rel(res[j][0], wL) < 1e-12 and rel(res[j][1], wR) < 1e-12
