@@ -118,6 +118,9 @@ constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 
 // NI: channel quarters that are swept in the M and p phases (channels part + 4 i, i < NI): ceil(C / 4), so that an 8-microphone
 // design (FromAtf) does a quarter of the multiply-adds of a 32-channel one instead of multiplying zeros
+// (tried: amdgpu_waves_per_eu(3) / (4), i.e. 168 / 128 instead of ~200 VGPRs, so that kernels of other batches with up to four
+// waves per SIMD fit next to a twin workgroup: 21-40 / 160-179 spilled registers on the chain, 5.6 instead of 4.4 us per bin with
+// 8 designs and 8.2 instead of 6.1 with 16 -- 1455 sets/s at 20 steps, 1900 in long runs, 3100 for HRIR-set batches: rejected)
 template <int PS_DPW, int NI, int NH>
 __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
     constexpr int NTT = PS_NT * NH;     // threads of the workgroup
