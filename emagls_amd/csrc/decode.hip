@@ -7,6 +7,7 @@
 
 #include "kernels.hpp"
 #include "lds_fft.hpp"
+#include "reg_fft.hpp"
 
 namespace emagls {
 
@@ -184,6 +185,151 @@ __global__ void __launch_bounds__(OLSF_NT) ols_fused_kernel(const double* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same block on register-resident transforms (reg_fft.hpp) for Nf = N1 * N2 = 256 (16 x 16), 512 (16 x 32), 1024 (32 x 32):
+// 32 threads per transform, 8 transforms (channel pairs) per round.
+//   stage A  lane n2 (< N2): a[n1] = z[N2 n1 + n2], length-N1 transform in registers, times W_N^(n2 k1), into LDS row k1
+//   stage B  lane k1 (< N1): the row [k1][n2], length-N2 transform in registers: Z[k1 + N1 k2], back into LDS in natural order
+//   then thread = frequency bin as above (unpack the two real channels, multiply, accumulate), and the packed inverse
+//   transform of Y_L + i Y_R as conj(FFT(conj(.))) by the first 32 threads.
+// ---------------------------------------------------------------------------------------------
+// OLSR_NT threads, OLSR_TP = OLSR_NT / 32 transforms per round: (256, 8) -- one block per CU (143 KB of LDS at Nf = 1024), the
+// shortest path through a block, for signals of a few hundred blocks; (128, 4) -- 76 KB, two blocks per CU hide each other's
+// latencies: 10 % more throughput on long signals (1.24 against 1.37 ms for 100 s x 25 channels), 30 % slower on 2.5 s
+template <int N1, int N2, int OLSR_NT>
+__global__ void __launch_bounds__(OLSR_NT) ols_fused_rr_kernel(const double* __restrict__ sig, int64_t n, int C, const cplx* __restrict__ Wf,
+                                                               int64_t len, int64_t B, double* __restrict__ out) {
+    constexpr int OLSR_TP = OLSR_NT / 32;
+    constexpr int Nf = N1 * N2, Pf = Nf / 2 + 1, L1 = rf_log2<N1>(), L2 = rf_log2<N2>();
+    constexpr int ROW = N2 + 1;                   // padded row of the transposition buffer (lane k1 reads row k1: stride != 0 mod 64 dwords)
+    constexpr int TSZ = (N1 * ROW > Nf ? N1 * ROW : Nf);   // elements per transform buffer
+    constexpr int KU = (Pf + OLSR_NT - 1) / OLSR_NT;
+    static_assert(N1 <= N2 && N2 <= 32, "factor sizes");
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* buf = reinterpret_cast<cplx*>(dyn);     // [OLSR_TP][TSZ]
+    cplx* tws = buf + (size_t)OLSR_TP * TSZ;       // [Nf / 2]  exp(-2 pi i j / Nf)
+    const int tid = threadIdx.x, tr = tid >> 5, l = tid & 31;
+    const int64_t blk = blockIdx.x;
+    for (int j = tid; j < Nf / 2; j += OLSR_NT) {
+        double sn, cs;
+        sincospi(-2.0 * (double)j / (double)Nf, &sn, &cs);
+        tws[j] = mk(cs, sn);
+    }
+    auto twiddle = [&](int m) __attribute__((always_inline)) {   // W_Nf^m, 0 <= m < Nf
+        const cplx w = tws[m & (Nf / 2 - 1)];
+        return (m & (Nf / 2)) ? mk(-w.x, -w.y) : w;
+    };
+    // one forward transform of the 32-thread group's buffer `tb`; input in registers a[n1] = z[N2 n1 + lane] (lanes < N2)
+    auto transform = [&](cplx (&a)[N1], cplx* tb) __attribute__((always_inline)) {
+        if (l < N2) {
+            reg_fft<N1>(a);
+#pragma unroll
+            for (int i = 0; i < N1; ++i) {
+                const int k1 = rf_bitrev<L1>(i);
+                tb[k1 * ROW + l] = a[i] * twiddle(l * k1);
+            }
+        }
+        __syncthreads();
+        cplx b[N2];
+        if (l < N1) {
+#pragma unroll
+            for (int n2 = 0; n2 < N2; ++n2) b[n2] = tb[l * ROW + n2];
+        }
+        __syncthreads();   // (every row has been read: the natural-order result may overwrite the buffer)
+        if (l < N1) {
+            reg_fft<N2>(b);
+#pragma unroll
+            for (int i = 0; i < N2; ++i) tb[l + N1 * rf_bitrev<L2>(i)] = b[i];
+        }
+        __syncthreads();
+    };
+    cplx accL[KU], accR[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) { accL[u] = mk(0, 0); accR[u] = mk(0, 0); }
+    const int npairs = (C + 1) / 2;
+    const int64_t s0 = blk * B - (len - 1);
+    cplx* tb = buf + (size_t)tr * TSZ;
+    __syncthreads();   // the twiddles are written
+    // a round's samples: global -> registers, requested one round ahead (before the previous round's multiply-accumulate)
+    cplx a[N1];
+    auto fetch = [&](int p0) __attribute__((always_inline)) {
+        const int np = min(OLSR_TP, npairs - p0);
+        const int ca = min(2 * (p0 + tr), C - 1), cb = 2 * (p0 + tr) + 1;
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+            const int64_t src = s0 + N2 * n1 + l;
+            const bool in = tr < np && l < N2 && src >= 0 && src < n;
+            a[n1] = mk(in ? sig[(int64_t)ca * n + src] : 0.0, (in && cb < C) ? sig[(int64_t)cb * n + src] : 0.0);
+        }
+    };
+    fetch(0);
+    for (int p0 = 0; p0 < npairs; p0 += OLSR_TP) {
+        const int np = min(OLSR_TP, npairs - p0);
+        transform(a, tb);
+        if (p0 + OLSR_TP < npairs) fetch(p0 + OLSR_TP);
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = tid + OLSR_NT * u;
+            if (k < Pf) {
+                // all 32 filter values of the round are requested before the first use (a loop that loads and uses one transform
+                // at a time pays an L2 round trip per transform: 48 us per block, four times the transforms themselves)
+                cplx wl[2 * OLSR_TP], wr[2 * OLSR_TP];
+#pragma unroll
+                for (int t = 0; t < OLSR_TP; ++t) {
+                    const int c0 = min(2 * (p0 + t), C - 1), c1 = min(c0 + 1, C - 1);
+                    wl[2 * t] = Wf[(int64_t)c0 * Pf + k];
+                    wr[2 * t] = Wf[((int64_t)C + c0) * Pf + k];
+                    wl[2 * t + 1] = Wf[(int64_t)c1 * Pf + k];
+                    wr[2 * t + 1] = Wf[((int64_t)C + c1) * Pf + k];
+                }
+#pragma unroll
+                for (int t = 0; t < OLSR_TP; ++t) {
+                    if (t < np) {
+                        const cplx* x = buf + (size_t)t * TSZ;
+                        const cplx z = x[k], zr = conj(x[(Nf - k) & (Nf - 1)]);
+                        const cplx pa = mk(0.5 * (z.x + zr.x), 0.5 * (z.y + zr.y));
+                        const cplx pb = mk(0.5 * (z.y - zr.y), -0.5 * (z.x - zr.x));
+                        cfma(accL[u], pa, wl[2 * t]);
+                        cfma(accR[u], pa, wr[2 * t]);
+                        if (2 * (p0 + t) + 1 < C) {
+                            cfma(accL[u], pb, wl[2 * t + 1]);
+                            cfma(accR[u], pb, wr[2 * t + 1]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the spectra have been read: the next round may overwrite the buffers
+    }
+    // packed inverse: y_L + i y_R = IFFT(Y_L + i Y_R) = conj(FFT(conj(Y_L + i Y_R))) / Nf; transform 0's buffer, natural order in
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const int k = tid + OLSR_NT * u;
+        if (k < Pf) {
+            const cplx lft = accL[u], r = accR[u];
+            buf[k] = mk(lft.x - r.y, -(lft.y + r.x));                                  // conj(Y_L + i Y_R)
+            if (k > 0 && k < Nf / 2) buf[Nf - k] = mk(lft.x + r.y, -(r.x - lft.y));     // conj of the mirrored bin
+        }
+    }
+    __syncthreads();
+    {
+        cplx a[N1];
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) a[n1] = (tr == 0 && l < N2) ? buf[N2 * n1 + l] : mk(0, 0);
+        __syncthreads();   // (read before stage A of transform 0 rewrites the buffer)
+        transform(a, tb);
+    }
+    const double scale = 1.0 / (double)Nf;
+    for (int64_t i = tid; i < B; i += OLSR_NT) {
+        const int64_t t = blk * B + i;
+        if (t < n) {
+            const cplx y = buf[(len - 1) + i];
+            stream_store(out + t, y.x * scale);
+            stream_store(out + n + t, -y.y * scale);
+        }
+    }
+}
+
 // [re(x_0..x_C-1), im(x_0..x_C-1)] planes (2C real channels of n samples) from interleaved complex columns; `swap` exchanges
 // the two halves and `neg_im` negates the imaginary planes
 __global__ void split_complex_kernel(const cplx* __restrict__ x, int64_t n, int C, int swap, int neg_im, double* __restrict__ out) {
@@ -284,6 +430,33 @@ void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL,
         ols_padfilt_kernel<<<256, 256, 0, st>>>(wL, wR, C, len, Nf, w.wpad);
         KERNEL_CHECK();
         fft_check(hipfftExecD2Z(w.pw, w.wpad, (hipfftDoubleComplex*)w.Wf), "exec D2Z filters");
+        const char* e_rr = getenv("EMAGLS_DECODE_REGFFT");   // (read at every call: a test switches forms inside one process)
+        const bool use_rr = !(e_rr && e_rr[0] == '0');
+        if (use_rr && Nf <= 1024) {   // register-resident transforms (two-factor form)
+            const int n1 = Nf == 1024 ? 32 : 16, n2 = Nf == 256 ? 16 : 32;
+            int dev_rr = 0, ncu = 256;
+            HIP_CHECK(hipGetDevice(&dev_rr));
+            HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_rr));
+            const bool wide_blocks = nblocks < 2 * (int64_t)ncu;   // few blocks: the shortest path through each
+            const int nt_rr = wide_blocks ? 256 : 128;
+            const size_t tsz = (size_t)std::max(n1 * (n2 + 1), Nf);
+            const size_t dyn_rr = sizeof(cplx) * ((size_t)(nt_rr / 32) * tsz + Nf / 2);
+            static PerDeviceOnce rr_once;
+            if (rr_once.first()) {
+#define EMAGLS_RR_ATTR(A, B_, T) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_fused_rr_kernel<A, B_, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+                EMAGLS_RR_ATTR(16, 16, 128); EMAGLS_RR_ATTR(16, 32, 128); EMAGLS_RR_ATTR(32, 32, 128);
+                EMAGLS_RR_ATTR(16, 16, 256); EMAGLS_RR_ATTR(16, 32, 256); EMAGLS_RR_ATTR(32, 32, 256);
+#undef EMAGLS_RR_ATTR
+            }
+            const dim3 grid_rr((unsigned)nblocks);
+#define EMAGLS_RR_GO(A, B_) do { if (wide_blocks) ols_fused_rr_kernel<A, B_, 256><<<grid_rr, 256, dyn_rr, st>>>(sig, n, C, w.Wf, len, B, out); \
+                                 else ols_fused_rr_kernel<A, B_, 128><<<grid_rr, 128, dyn_rr, st>>>(sig, n, C, w.Wf, len, B, out); } while (0)
+            if (Nf == 1024) EMAGLS_RR_GO(32, 32); else if (Nf == 512) EMAGLS_RR_GO(16, 32); else EMAGLS_RR_GO(16, 16);
+#undef EMAGLS_RR_GO
+            KERNEL_CHECK();
+            HIP_CHECK(hipStreamSynchronize(st));
+            return;
+        }
         const int ntp = Nf <= 1024 ? 4 : (Nf == 2048 ? 2 : 1);
         const size_t dyn = sizeof(cplx) * ((size_t)ntp * (Nf + Nf / 16) + Nf / 2);
         static PerDeviceOnce attr_once;
