@@ -24,6 +24,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_single
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_batch -o bench -- python3 $R/bench.py --steps 32 --warmup 0 --slots 1 --batch 8 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_batch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_batch16 -o bench -- python3 $R/bench.py --steps 64 --warmup 0 --slots 1 --batch 16 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_batch16.log 2>&1
 timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${tag}_prof_slots4 -o bench -- python3 $R/bench.py --steps 128 --warmup 0 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_slots4.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_hrirsets -o hs -- python3 $R/tools/experiments/hrir_sets_prof.py 4 > $R/gpurun_out/${tag}_prof_hrirsets.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_default20 -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_default20.log 2>&1
 if [ "$pmc" = "pmc" ]; then
   # counters in passes of their own (kernel-trace only next to --pmc); one batch of 8 designs, 4 batches executed
@@ -46,6 +47,8 @@ python tools/kernel_avgs.py gpurun_out/${tag}_prof_default20 > gpurun_out/${tag}
 python tools/fill_timeline.py gpurun_out/${tag}_prof_default20 2 > gpurun_out/${tag}_fill_timeline20.md 2>&1
 python tools/timeline.py gpurun_out/${tag}_prof_slots4 10 > gpurun_out/${tag}_timeline_slots4.md 2>&1
 python tools/timeline.py gpurun_out/${tag}_prof_batch 3 > gpurun_out/${tag}_timeline_slots1.md 2>&1
+python tools/kernel_avgs.py gpurun_out/${tag}_prof_hrirsets > gpurun_out/${tag}_hrir_sets_kernels.md 2>&1
+python tools/timeline.py gpurun_out/${tag}_prof_hrirsets 12 > gpurun_out/${tag}_hrir_sets_timeline.md 2>&1
 # the raw databases are large: keep the summaries
-rm -rf gpurun_out/${tag}_prof_single gpurun_out/${tag}_prof_batch gpurun_out/${tag}_prof_slots4 gpurun_out/${tag}_prof_batch16 gpurun_out/${tag}_prof_default20
+rm -rf gpurun_out/${tag}_prof_hrirsets gpurun_out/${tag}_prof_single gpurun_out/${tag}_prof_batch gpurun_out/${tag}_prof_slots4 gpurun_out/${tag}_prof_batch16 gpurun_out/${tag}_prof_default20
 cat gpurun_out/${tag}_tests.log gpurun_out/${tag}_smoke.log 2>/dev/null; cut -c1-600 gpurun_out/${tag}_bench20.json; echo; cut -c1-300 gpurun_out/${tag}_bench128.json; echo; tail -3 gpurun_out/${tag}_bench20.err; head -32 gpurun_out/${tag}_kernels_batch.md; head -12 gpurun_out/${tag}_timeline_slots4.md
