@@ -20,7 +20,11 @@ import numpy as np  # noqa: E402
 
 
 def draw(rng):
-    kind = str(rng.choice(["emagls", "emagls2", "magls", "ls", "emainch", "atf", "emainsh", "magls2d"], p=[0.25, 0.2, 0.15, 0.05, 0.1, 0.1, 0.08, 0.07]))
+    kind = str(rng.choice(["emagls", "emagls2", "magls", "ls", "emainch", "atf", "emainsh", "magls2d", "decode"],
+                          p=[0.22, 0.18, 0.13, 0.05, 0.1, 0.1, 0.07, 0.05, 0.1]))
+    if kind == "decode":     # binauralDecode: (samples, channels, taps, complex signal / filters, compensateDelay)
+        return (kind, int(rng.integers(1, 30000)), int(rng.integers(1, 50)), int(rng.integers(1, 1600)) * (2 if rng.random() < 0.5 else 1),
+                bool(rng.random() < 0.3), bool(rng.random() < 0.3), bool(rng.random() < 0.5))
     fs = float(rng.choice([16000.0, 32000.0, 44100.0, 48000.0, 96000.0]))
     D = int(rng.integers(60, 1600))
     taps = int(rng.choice([16, 33, 64, 100, 128, 200]))
@@ -51,6 +55,21 @@ def run(case):
     from oracle import emagls_oracle as O
     import shape_cases as SC
     kind = case[0]
+    if kind == "decode":
+        import warnings
+        _, nsamp, nch, length, sig_c, w_c, comp = case
+        rng = np.random.default_rng(nsamp + 31 * nch + length)
+        cx = lambda shape, on: rng.standard_normal(shape) + (1j * rng.standard_normal(shape) if on else 0.0)
+        env = np.exp(-np.arange(length) / (0.3 * length + 1.0))[:, None]
+        sig, wL, wR = cx((nsamp, nch), sig_c), cx((length, nch), w_c) * env, cx((length, nch), w_c) * env
+        if comp and (nsamp <= length // 2 or length < 2):
+            comp = False
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = E.binauralDecode(sig, 48000, wL, wR, 48000, comp)
+            ref = O.binauralDecode(sig, wL, wR, comp)
+        assert out.shape == ref.shape
+        return SC.rel(out, ref)
     if kind not in ("emainsh", "magls2d"):
         return SC.run(case)
     _, D, taps, ln, fs, r, M, N, basis = case
@@ -123,6 +142,9 @@ def main():
                 tally["ok"] += 1
                 worst = max(worst, e)
                 print(f"case {i} {c} -> ok rel={e:.2e} ({time.time() - t:.1f} s)", flush=True)
+            elif c[0] == "decode":
+                tally["mismatch"] += 1
+                print(f"case {i} {c} -> MISMATCH rel={e:.2e} ({time.time() - t:.1f} s)", flush=True)
             else:
                 # is the REFERENCE's result defined to that accuracy?  the oracle against itself with the other LAPACK SVD driver
                 import shape_cases as SC
