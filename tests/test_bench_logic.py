@@ -2,6 +2,8 @@
 import importlib.util
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -114,3 +116,27 @@ def test_config4_split_is_class_aware():
     assert [len(idx) for idx, _ in padded_lane_batches([5] * 9 + [7] * 8)] == [6, 6, 5]
     assert [len(idx) for idx, _ in padded_lane_batches([4] * 3)] == [3] and padded_lane_batches([]) == []
     assert batch_cost(8, 44) > batch_cost(8, 9) > batch_cost(1, 9)
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_on_the_gpus_that_exist():
+    """The N > 1 control flow of bench.py with real GPU work: `python bench.py --gpus 2` (no launcher: the parent spawns the
+    ranks) in the test mode EMAGLS_BENCH_SHARED_GPU=1 -- the ranks share the GPUs that exist, the collectives (barrier, gather of
+    every rank's filters to rank 0, max over the ranks' times) run on gloo with host tensors.  One JSON line from rank 0, exit code
+    0, the line marked invalid as a measurement when ranks had to share a GPU.  Small batches: two resident sweeps of four
+    designs fit the chip side by side."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, EMAGLS_BENCH_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--slots", "1", "--batch", "4",
+                        "--no-cpu-baseline", "--no-secondary", "--no-sh-roofline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["warmup"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
+    import torch
+    assert ("INVALID_as_a_measurement" in d) == (torch.cuda.device_count() < 2)
