@@ -94,3 +94,58 @@ def test_single_process_lane_batches():
     so = [simulation_order(4, 48000.0, r, raw=True) for r, _ in jobs]
     out = run_lane_batches(jobs, so, lambda bj, pad: [_design(j) for j in bj])
     assert len(out) == 3 and all(np.array_equal(out[j][0], _design(jobs[j])[0]) for j in range(3))
+
+
+def _gpu_worker(rank, world, port, q):
+    """Two ranks with REAL designs: both ranks use GPU 0 (a 1-GPU box), the gather runs on gloo.  The job lists north_star names:
+    array radii (class-aware lane batches), HRIR sets on one geometry (geometry-sharing batches), FromAtf subjects."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import emagls_amd as E
+        from emagls_amd import synth
+        from emagls_amd.batch import emagls2_radius_sweep, emagls_from_atf_subjects, emagls_hrir_sets
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        azi, zen = synth.fibonacci_grid(700)
+        maz, mzn = synth.em32_grid()
+        hL, hR = synth.rigid_sphere_hrirs(azi, zen, taps=64)
+        radii = [0.031, 0.0312, 0.0335, 0.047, 0.0471, 0.0472, 0.0473]
+        out_r = emagls2_radius_sweep(hL, hR, azi, zen, radii, maz, mzn, 4, 48000.0, 64)
+        subjects = [synth.rigid_sphere_hrirs(azi, zen, taps=64, seed=40 + j, head_radius=0.08 + 0.002 * j) for j in range(5)]
+        out_s = emagls_hrir_sets(subjects, azi, zen, 0.042, maz, mzn, 4, 48000.0, 128, "complex", max_batch=3)
+        atf, aazi, azen = synth.glasses_atfs(natf=600, nmics=5, taps=48)
+        hg, ag = np.column_stack([azi, zen]), np.column_stack([aazi, azen])
+        out_a = emagls_from_atf_subjects(subjects[:3], hg, atf, ag, 48000.0, 128, 2000.0)
+        if rank == 0:
+            worst = 0.0
+            for j in (0, 3, 6):
+                w = E.getEMagLs2Filters(hL, hR, azi, zen, radii[j], maz, mzn, 4, 48000.0, 64, "real")
+                worst = max(worst, rel(out_r[j][0], w[0]), rel(out_r[j][1], w[1]))
+            for j in range(5):
+                w = E.getEMagLsFilters(subjects[j][0], subjects[j][1], azi, zen, 0.042, maz, mzn, 4, 48000.0, 128, "complex")
+                worst = max(worst, rel(out_s[j][0], w[0]), rel(out_s[j][1], w[1]))
+            for j in range(3):
+                w = E.getEMagLsFiltersFromAtf(subjects[j][0], subjects[j][1], hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)
+                worst = max(worst, rel(out_a[j][0], w[0]), rel(out_a[j][1], w[1]))
+            q.put(("ok" if (len(out_r), len(out_s), len(out_a)) == (7, 5, 3) else "counts", worst))
+        else:
+            assert out_r is None and out_s is None and out_a is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_real_designs_on_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    tag, worst = q.get(timeout=5)
+    print(f"two ranks, three job lists, gathered on rank 0: worst rel vs single calls = {worst:.3e}")
+    assert tag == "ok" and worst < 1e-9
