@@ -2742,10 +2742,29 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
             else
                 for (size_t j = 0; j < n; ++j)
                     HIP_CHECK(hipMemcpyAsync(&flags[NFLAG * j], b->plans[j]->get("flag"), NFLAG * sizeof(int), hipMemcpyDeviceToHost, b->stream));
-            for (size_t j = 0; j < n; ++j) {
-                HIP_CHECK(hipMemcpyAsync(wL[j], b->plans[j]->get("wL"), bytes, hipMemcpyDefault, b->stream));
-                HIP_CHECK(hipMemcpyAsync(wR[j], b->plans[j]->get("wR"), bytes, hipMemcpyDefault, b->stream));
+            // lane batch into device buffers of this GPU: one scatter launch instead of 2 n copies (0.25 ms on the stream for 16
+            // designs -- the tail of a short run's timed region)
+            bool scattered = false;
+            if (b->lanes && n <= 16 && bytes % 16 == 0) {
+                bool dev_dst = true;
+                for (size_t j = 0; j < n && dev_dst; ++j)
+                    for (void* q : {wL[j], wR[j]}) {
+                        hipPointerAttribute_t at{};
+                        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); dev_dst = false; break; }
+                        if (at.type != hipMemoryTypeDevice || at.device != b->device || ((uintptr_t)q & 15)) { dev_dst = false; break; }
+                    }
+                if (dev_dst) {
+                    LanePtrs lp{};
+                    for (size_t j = 0; j < n; ++j) { lp.p[2 * j] = wL[j]; lp.p[2 * j + 1] = wR[j]; }
+                    launch_scatter_lanes(p0.get("wL"), p0.get("wR"), b->stride, bytes, (int)n, lp, b->stream);
+                    scattered = true;
+                }
             }
+            if (!scattered)
+                for (size_t j = 0; j < n; ++j) {
+                    HIP_CHECK(hipMemcpyAsync(wL[j], b->plans[j]->get("wL"), bytes, hipMemcpyDefault, b->stream));
+                    HIP_CHECK(hipMemcpyAsync(wR[j], b->plans[j]->get("wR"), bytes, hipMemcpyDefault, b->stream));
+                }
             HIP_CHECK(hipStreamSynchronize(b->stream));
             bool redo = false;
             for (size_t j = 0; j < n; ++j) redo = plan_recover(*b->plans[j], &flags[NFLAG * j], false) || redo;

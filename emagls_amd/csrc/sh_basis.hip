@@ -152,6 +152,22 @@ void launch_broadcast_lanes(const void* src, size_t bytes, size_t stride, int nl
     KERNEL_CHECK();
 }
 
+// a lane batch's results (wL / wR of every lane, at the arena stride) into the caller's device buffers: one launch instead of
+// two copies per design (blockIdx.y = design, blockIdx.z = ear)
+__global__ void scatter_lanes_kernel(const uint4* __restrict__ srcL, const uint4* __restrict__ srcR, size_t stride, int64_t n16, LanePtrs dst) {
+    const int j = blockIdx.y, e = blockIdx.z;
+    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(e ? srcR : srcL) + (size_t)j * stride);
+    uint4* d = reinterpret_cast<uint4*>(dst.p[2 * j + e]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) d[i] = src[i];
+}
+void launch_scatter_lanes(const void* srcL, const void* srcR, size_t stride, size_t bytes, int n, const LanePtrs& dst, hipStream_t st) {
+    const int64_t n16 = (int64_t)(bytes / 16);
+    if (n16 == 0 || n <= 0) return;
+    const unsigned gx = (unsigned)std::min<int64_t>(64, ceil_div(n16, 256));
+    scatter_lanes_kernel<<<dim3(gx, (unsigned)n, 2), 256, 0, st>>>((const uint4*)srcL, (const uint4*)srcR, stride, n16, dst);
+    KERNEL_CHECK();
+}
+
 // *differ = 1 when two device buffers differ in any 8-byte word (a batch of FromAtf subjects checks that its plans really hold
 // the same ATF set and grids before it computes the ATF side once for all of them)
 __global__ void compare_words_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, int64_t n8, int* differ) {
