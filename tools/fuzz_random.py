@@ -20,8 +20,15 @@ import numpy as np  # noqa: E402
 
 
 def draw(rng):
-    kind = str(rng.choice(["emagls", "emagls2", "magls", "ls", "emainch", "atf", "emainsh", "magls2d", "decode"],
-                          p=[0.22, 0.18, 0.13, 0.05, 0.1, 0.1, 0.07, 0.05, 0.1]))
+    kind = str(rng.choice(["emagls", "emagls2", "magls", "ls", "emainch", "atf", "emainsh", "magls2d", "decode", "geo"],
+                          p=[0.17, 0.13, 0.13, 0.05, 0.1, 0.1, 0.07, 0.05, 0.1, 0.1]))
+    if kind == "geo":        # HRIR sets on one geometry: (sets, directions, taps, len, fs, radius, mics, order, basis, design kind)
+        sub = str(rng.choice(["emagls", "emagls2", "emainch"]))
+        N = int(rng.integers(0, 5)) if sub != "emainch" else int(rng.integers(0, 9))
+        M = int(rng.integers(max(2, (N + 1) ** 2), 33)) if sub == "emagls" else (int(rng.integers(2 * N + 1, 33)) if sub == "emainch" else int(rng.integers(4, 33)))
+        taps = int(rng.choice([16, 33, 64, 100]))
+        return (kind, int(rng.integers(2, 8)), int(rng.integers(300, 1500)), taps, int(2 * rng.integers(max(4, taps // 2), 130)),
+                float(rng.choice([16000.0, 32000.0, 44100.0, 48000.0])), float(rng.uniform(0.01, 0.07)), M, N, str(rng.choice(["real", "complex"])), sub)
     if kind == "decode":     # binauralDecode: (samples, channels, taps, complex signal / filters, compensateDelay)
         return (kind, int(rng.integers(1, 30000)), int(rng.integers(1, 50)), int(rng.integers(1, 1600)) * (2 if rng.random() < 0.5 else 1),
                 bool(rng.random() < 0.3), bool(rng.random() < 0.3), bool(rng.random() < 0.5))
@@ -55,6 +62,25 @@ def run(case):
     from oracle import emagls_oracle as O
     import shape_cases as SC
     kind = case[0]
+    if kind == "geo":
+        from emagls_amd import synth
+        from emagls_amd.batch import emagls_hrir_sets
+        _, nset, D, taps, ln, fs, r, M, N, basis, sub = case
+        azi, zen = synth.fibonacci_grid(D)
+        if sub == "emainch":
+            ma, mz = np.linspace(0, 2 * np.pi, M, endpoint=False) + 0.2, None
+        else:
+            ma, mz = SC.mics(M, D + M)
+        subjects = [synth.rigid_sphere_hrirs(azi, zen, fs=fs, taps=taps, centre_delay=taps / 4, seed=7 + j, head_radius=0.08 + 0.003 * j)
+                    for j in range(nset)]
+        res = emagls_hrir_sets(subjects, azi, zen, r, ma, mz, N, fs, ln, basis, kind=sub, max_batch=8)
+        fn = {"emagls": E.getEMagLsFilters, "emagls2": E.getEMagLs2Filters}.get(sub)
+        worst = 0.0
+        for j in (0, nset - 1):     # the shared batch against the single designs (the oracle comparison is the other kinds' job)
+            w = fn(subjects[j][0], subjects[j][1], azi, zen, r, ma, mz, N, fs, ln, basis) if fn else \
+                E.getEMagLsFiltersEMAinCH(subjects[j][0], subjects[j][1], azi, zen, r, ma, N, fs, ln, basis)
+            worst = max(worst, SC.rel(res[j][0], w[0]), SC.rel(res[j][1], w[1]))
+        return worst
     if kind == "decode":
         import warnings
         _, nsamp, nch, length, sig_c, w_c, comp = case
@@ -142,7 +168,7 @@ def main():
                 tally["ok"] += 1
                 worst = max(worst, e)
                 print(f"case {i} {c} -> ok rel={e:.2e} ({time.time() - t:.1f} s)", flush=True)
-            elif c[0] == "decode":
+            elif c[0] in ("decode", "geo"):
                 tally["mismatch"] += 1
                 print(f"case {i} {c} -> MISMATCH rel={e:.2e} ({time.time() - t:.1f} s)", flush=True)
             else:
