@@ -562,7 +562,8 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
     // directions per sub-tile: the largest power of two whose buffers stay below the LDS a CU has left next to a resident
     // sweep workgroup (160 KB - 77 KB)
     // (tried: 2 or 1 directions per sub-tile, 49 / 33 KB, so that three or four workgroups share a CU and the kernel fits next to a
-    // twin sweep workgroup: 2062 / 2047 against 2174 sets/s in long runs, 1393 / 1633 against 1697 at 20 steps)
+    // twin sweep workgroup: 2062 / 2047 against 2174 sets/s in long runs, 1393 / 1633 against 1697 at 20 steps; all 8 directions in
+    // one sub-tile, 148 KB: 2149-2152 against 2176-2186)
     const size_t budget = 83 * 1024, shared = (size_t)2 * P * 16;
     int TS = HF_TD;
     while (TS > 1 && (size_t)TS * nfft * 16 + shared > budget) TS >>= 1;
