@@ -44,6 +44,9 @@ __global__ void __launch_bounds__(512) qt_kernel(const T* __restrict__ Yc, int64
     for (int c = threadIdx.x / QT_TD; c < C; c += 512 / QT_TD) {
         const T* e = E + (int64_t)c * ldE;
         // (tried: eight masked loads of E in flight per pass instead of this two-term loop: 273 -> 313 us per 8-design launch)
+        // (tried at the end of round 3: the order terms from the column-major SH matrix, lanes = 64 directions, no LDS: 154 us with
+        // four channel groups per direction block -- the matrix is then re-read four times from beyond the L2 -- and 452 us with
+        // all channels in one wave, against 155 us here: every multiply-add still needs its own load of an E entry)
         for (int n = 0; n < nOrders; ++n) {
             const int sb = n * n, se = min(S, (n + 1) * (n + 1));
             T a0 = zero_of<T>(), a1 = zero_of<T>();
