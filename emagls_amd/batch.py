@@ -317,3 +317,49 @@ def emagls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, micRadius, micGri
     if world == 1:
         return local
     return _gather_on_rank0(local, shards, n, group, None)
+
+
+def magls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, order, fs, length, shDefinition="real", group=None, max_batch=8):
+    """getMagLsFilters (lib/getMagLsFilters.m:30; hrirGridZenRad None: getMagLsFilters2D on a horizontal grid) for every HRIR
+    set of `subjects` = [(hL, hR), ...] on ONE grid: spread over the ranks, each rank's share in batches that compute the SH
+    side once (Batch.share_geometry) and sweep all their sets in one resident launch; one gather.  Same filters as the single
+    calls.  Returns [(wL, wR), ...] in the order of `subjects` on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    from . import Batch, Plan, _lib as L
+    azi = np.asarray(hrirGridAziRad, dtype=np.float64)
+    zen = None if hrirGridZenRad is None else np.asarray(hrirGridZenRad, dtype=np.float64)
+    K = L.KIND_MAGLS if zen is not None else L.KIND_MAGLS_2D
+    have_pg = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if have_pg else 0
+    world = dist.get_world_size(group) if have_pg else 1
+    n = len(subjects)
+    shards = shard_jobs(np.ones(n), world)
+    local = []
+    mine = shards[rank]
+    for i in range(0, len(mine), max_batch):
+        plans = []
+        try:
+            for j in mine[i:i + max_batch]:
+                hL = np.asfortranarray(subjects[j][0], dtype=np.float64)
+                hR = np.asfortranarray(subjects[j][1], dtype=np.float64)
+                p = Plan(K, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], 0.0, 0)
+                p.set_hrir_grid(azi, zen)
+                p.set_hrirs(hL, hR)
+                plans.append(p)
+            if len(plans) == 1:
+                plans[0].execute()
+                local.append(plans[0].get_filters())
+            else:
+                b = Batch(plans)
+                try:
+                    b.share_geometry(True)
+                    b.execute()
+                    local += b.get_filters()
+                finally:
+                    b.close()
+        finally:
+            for p in plans:
+                p.close()
+    if world == 1:
+        return local
+    return _gather_on_rank0(local, shards, n, group, None)

@@ -225,6 +225,7 @@ struct emagls_batch {
     uint64_t atf_checked_version = ~0ull;
     // array designs that differ only in their HRIR sets (same grids, array, orders): the geometry stages run once (opt-in,
     // emagls_batch_set_geometry_sharing; checked on the device whenever a grid was replaced)
+    bool magls = false;     // MagLS / MagLS-2D plans (HRIR sets on one or several grids): batch_execute_magls
     bool geo_want = false, geo_share = false, geo_inputs_same = false;
     uint64_t geo_checked_version = ~0ull;
     int* cmp_flag = nullptr;
@@ -1559,7 +1560,10 @@ void batch_sweep_stage(emagls_batch& b) {
     h.n = (int)b.plans.size();
     for (int j = 0; j < h.n; ++j) h.a[j] = emagls_half_args(*b.plans[j]);
     if (b.atf_share || b.geo_share)   // one ATF side / one geometry for every subject
-        for (int j = 1; j < h.n; ++j) { h.a[j].G = h.a[0].G; h.a[j].Yri = h.a[0].Yri; h.a[j].Mw = h.a[0].Mw; h.a[j].cond_ok = h.a[0].cond_ok; }
+        for (int j = 1; j < h.n; ++j) {
+            h.a[j].G = h.a[0].G; h.a[j].Yri = h.a[0].Yri; h.a[j].Mw = h.a[0].Mw; h.a[j].cond_ok = h.a[0].cond_ok;
+            h.a[j].skip_flag = h.a[0].skip_flag;   // (MagLS: plan 0 judged the basis for everybody)
+        }
     emagls_plan& q0 = *b.plans[0];
     const int kk0 = std::max(q0.kcut0, 1);
     if (kk0 >= q0.P) return;
@@ -1887,10 +1891,105 @@ void batch_execute_geo(emagls_batch& b) {
     if (!replay) ++b.eager_runs;
 }
 
+// ---------------------------------------------------------------------------------------------
+// MagLS / MagLS-2D batches (lib/getMagLsFilters.m:30, getMagLsFilters2D.m:1 in a loop over HRIR sets): every plan's stages before
+// and after the sweep on the batch's stream (two single-stream graphs) and ONE resident sweep launch for all designs instead
+// of one per design.  With geometry sharing (same grid: SH matrix, its Cholesky factor, pinv(Y_conj), the sweep's operands
+// G = Y_conj and M = R^-1 R^-H are the same for every set) plan 0 computes that side and the other plans run their HRIR
+// prologue and least-squares bins on it.
+// ---------------------------------------------------------------------------------------------
+void batch_magls_decide_sharing(emagls_batch& b) {
+    bool share = false;
+    emagls_plan& p0 = *b.plans[0];
+    if (b.geo_want && b.plans.size() > 1 && !p0.custom_basis && !p0.diffuse && p0.sweep_persist) {
+        uint64_t ver = 0;
+        for (auto* p : b.plans) ver = ver * 1000003ull + p->atf_side_version;
+        if (ver != b.geo_checked_version) {
+            if (!b.cmp_flag) HIP_CHECK(hipMalloc(&b.cmp_flag, 16));
+            HIP_CHECK(hipStreamSynchronize(b.stream));
+            HIP_CHECK(hipMemsetAsync(b.cmp_flag, 0, 16, b.stream));
+            for (size_t j = 1; j < b.plans.size(); ++j)
+                for (const char* name : {"hrir_azi", "hrir_zen"})
+                    launch_compare_words(p0.get(name), b.plans[j]->get(name), p0.bufs[name].bytes, b.cmp_flag, b.stream);
+            int differ = 0;
+            HIP_CHECK(hipMemcpyAsync(&differ, b.cmp_flag, sizeof differ, hipMemcpyDeviceToHost, b.stream));
+            HIP_CHECK(hipStreamSynchronize(b.stream));
+            b.geo_checked_version = ver;
+            b.geo_inputs_same = differ == 0;
+        }
+        share = b.geo_inputs_same;
+        for (auto* p : b.plans) share = share && !p->custom_basis && p->d.fs == p0.d.fs;
+    }
+    if (share != b.geo_share) {
+        for (auto* p : b.plans) drop_plan_graphs(*p);
+        drop_batch_graphs(b);
+        b.geo_share = share;
+    }
+}
+void batch_magls_stage(emagls_batch& b, int part) {
+    emagls_plan& g = *b.plans[0];
+    std::vector<hipStream_t> keep;
+    for (auto* p : b.plans) { keep.push_back(p->stream); p->stream = b.stream; }
+    auto restore = [&] { for (size_t j = 0; j < b.plans.size(); ++j) b.plans[j]->stream = keep[j]; };
+    try {
+        if (part == 0) {
+            for (size_t j = 0; j < b.plans.size(); ++j) {
+                emagls_plan& p = *b.plans[j];
+                if (j == 0 || !b.geo_share) { plan_pre_stage(p); continue; }
+                // a subject of plan 0's grid: spectra, least-squares bins on plan 0's pinv(Y_conj)
+                p.stage_names.clear();
+                launch_zero(p.get("flag"), sizeof(int) * NFLAG, b.stream);
+                launch_zero(p.get("W"), p.bufs["W"].bytes, b.stream);
+                stage_prologue(p, 0, nullptr, p.D);
+                launch_ls_apply(p.get("Hc"), p.ldD, std::min(p.kcut0, p.P), g.get("Ypinv"), g.cplx_basis, g.ldD, (int)p.D, p.C, p.P, 0,
+                                std::min(p.kcut0, p.P), p.get("W"), b.stream);
+            }
+        } else {
+            for (auto* p : b.plans) magls_post_sweep(*p);
+        }
+    } catch (...) {
+        restore();
+        throw;
+    }
+    restore();
+}
+void batch_execute_magls(emagls_batch& b) {
+    emagls_plan& p0 = *b.plans[0];
+    for (auto* p : b.plans)
+        if (!p->have_hrirs || (p->custom_basis ? !p->have_basis : !p->have_hrir_grid))
+            throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grid (or SH matrix) and HRIRs");
+    bool persist = true;
+    for (auto* p : b.plans) persist = persist && p->sweep_persist;
+    if (!persist) {   // (an ill-conditioned basis or a sweep that did not become resident: the designs one at a time, launch-per-bin sweeps)
+        if (b.geo_share) { for (auto* p : b.plans) drop_plan_graphs(*p); drop_batch_graphs(b); b.geo_share = false; }
+        for (auto* p : b.plans) {
+            hipStream_t keep = p->stream;
+            p->stream = b.stream;
+            try { plan_execute(*p); } catch (...) { p->stream = keep; throw; }
+            p->stream = keep;
+        }
+        return;
+    }
+    batch_magls_decide_sharing(b);
+    const bool replay = b.use_graph && b.eager_runs >= 1;
+    if (replay && !b.graph_exec) {
+        capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_magls_stage(b, 0); });
+        capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_magls_stage(b, 2); });
+    }
+    b.used = 0;
+    if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_magls_stage(b, 0);
+    batch_sweep_stage(b);   // (never captured: see SweepChain)
+    if (replay) HIP_CHECK(hipGraphLaunch(b.post_exec, b.stream)); else batch_magls_stage(b, 2);
+    for (auto* p : b.plans) { p->executed = true; p->sweep_launches = 1; }
+    (void)p0;
+    if (!replay) ++b.eager_runs;
+}
+
 void batch_execute(emagls_batch& b) {
     for (auto* p : b.plans)
         if (!p) throw Error(EMAGLS_ERR_ARG, "a plan of this batch has been destroyed");
     if (b.atf) { batch_execute_atf(b); return; }
+    if (b.magls) { batch_execute_magls(b); return; }
     for (auto* p : b.plans)
         if (!p->have_hrirs || (p->custom_basis ? !p->have_basis : (!p->have_hrir_grid || !p->have_mic_grid)))
             throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grids (or SH matrices) and HRIRs");
@@ -2670,10 +2769,15 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         for (int j = 0; j < nplans; ++j) {
             emagls_plan* p = plans[j];
             if (!p) throw Error(EMAGLS_ERR_ARG, "null plan");
-            if (!array_kind(p->d.kind) && p->d.kind != EMAGLS_KIND_FROM_ATF)
-                throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH / EMAinSH plans, or FromAtf plans (subjects of one ATF set)");
+            if (!array_kind(p->d.kind) && p->d.kind != EMAGLS_KIND_FROM_ATF && !magls_kind(p->d.kind))
+                throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH / EMAinSH plans, MagLS / MagLS-2D plans, or FromAtf plans "
+                                                    "(subjects of one ATF set)");
             if ((p->d.kind == EMAGLS_KIND_FROM_ATF) != (plans[0]->d.kind == EMAGLS_KIND_FROM_ATF))
                 throw Error(EMAGLS_ERR_ARG, "FromAtf plans cannot share a batch with array designs");
+            if (magls_kind(p->d.kind) != magls_kind(plans[0]->d.kind) || (magls_kind(p->d.kind) && p->d.kind != plans[0]->d.kind))
+                throw Error(EMAGLS_ERR_ARG, "MagLS plans share a batch only with MagLS plans of the same kind");
+            if (magls_kind(p->d.kind) && (p->diffuse != plans[0]->diffuse || p->cplx_basis != plans[0]->cplx_basis || p->d.order != plans[0]->d.order))
+                throw Error(EMAGLS_ERR_ARG, "all designs of a batch must have the same shape (order, basis, constraint)");
             if (p->wide) throw Error(EMAGLS_ERR_UNSUPPORTED, "designs with more than 32 channels run one at a time");
             if (p->owner) throw Error(EMAGLS_ERR_ARG, "a plan belongs to another batch (destroy that batch first)");
             if (p->device != plans[0]->device) throw Error(EMAGLS_ERR_ARG, "the plans of a batch must live on one device");
@@ -2703,7 +2807,8 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
             p->owner = b.get();
         }
         b->atf = b->plans[0]->d.kind == EMAGLS_KIND_FROM_ATF;
-        if (!b->atf) batch_try_lanes(*b);
+        b->magls = magls_kind(b->plans[0]->d.kind);
+        if (!b->atf && !b->magls) batch_try_lanes(*b);
         *batch = b.release();
     });
 }
@@ -2772,6 +2877,8 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
             // recoverable: a Gram-route bin worse conditioned than estimated, or a persistent sweep that did not become resident
             batch_redo(*b, flags);
         }
+        for (auto* q : b->plans)   // (a MagLS re-run on the launch-per-bin sweeps is done: the next execute starts on the persistent form again)
+            if (q->persist_suspended) { q->persist_suspended = false; q->sweep_persist = true; }
         for (size_t j = 0; j < n; ++j) throw_fatal_flags(&flags[NFLAG * j]);
     });
 }

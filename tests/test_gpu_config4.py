@@ -245,3 +245,10 @@ def test_job_lists_of_config4_and_config5(grids, hrirs64):
         wL, wR = E.getEMagLsFilters(subjects5[j][0], subjects5[j][1], azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4,
                                     48000.0, 128, "complex")
         assert res[j][0].dtype == wL.dtype and rel(res[j][0], wL) < 1e-12 and rel(res[j][1], wR) < 1e-12
+    # the same loop around getMagLsFilters (BASELINE config 2's design): MagLS plans in batches, one sweep launch per batch
+    from emagls_amd.batch import magls_hrir_sets
+    res = magls_hrir_sets(subjects5, azi, zen, 4, 48000.0, 128, "real", max_batch=4)
+    assert len(res) == 5     # batches of 4 + 1
+    for j in range(5):
+        wL, wR = E.getMagLsFilters(subjects5[j][0], subjects5[j][1], azi, zen, 4, 48000.0, 128, "real")
+        assert res[j][0].dtype == wL.dtype and rel(res[j][0], wL) < 1e-12 and rel(res[j][1], wR) < 1e-12

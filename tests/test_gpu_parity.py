@@ -446,6 +446,66 @@ def test_hrir_sets_on_one_geometry_share_it(grids, thin, kind):
         p.close()
 
 
+@pytest.mark.parametrize("two_d", [False, True])
+def test_magls_batches(grids, thin, two_d):
+    """MagLS / MagLS-2D plans in a batch (getMagLsFilters in a loop over HRIR sets): one resident sweep launch for all designs
+    instead of one per design; with Batch.share_geometry() the SH side (basis, Cholesky factor, pinv, the sweep's operands) is
+    computed once for sets on one grid.  Same filters as the single designs in both forms; sets on different grids run
+    unshared; orders above 4 (the plain path) stay out of batches."""
+    from emagls_amd import Batch, Plan, _lib as L
+    from emagls_amd._lib import EmaglsError
+    rng = np.random.default_rng(41)
+    if two_d:
+        azi = np.sort(np.mod(np.linspace(0, 2 * np.pi, 360, endpoint=False) + 0.002 * rng.standard_normal(360), 2 * np.pi))
+        from emagls_amd import synth
+        base = synth.rigid_sphere_hrirs(azi, np.full(360, np.pi / 2))
+        zen, K, order = None, L.KIND_MAGLS_2D, 6
+    else:
+        azi, zen, base, K, order = thin["azi"], thin["zen"], (thin["hL"], thin["hR"]), L.KIND_MAGLS, 4
+    plans, singles = [], []
+    for j in range(7):
+        hL = base[0] * (1.0 + 0.06 * j) + 1e-3 * rng.standard_normal(base[0].shape)
+        hR = base[1] * (1.0 - 0.04 * j) + 1e-3 * rng.standard_normal(base[1].shape)
+        p = Plan(K, "complex", order, 48000.0, 128, hL.shape[0], hL.shape[1], 0.0, 0)
+        p.set_hrir_grid(azi, zen)
+        p.set_hrirs(hL, hR)
+        p.execute()
+        singles.append(p.get_filters())
+        plans.append(p)
+    b = Batch(plans)
+    outs = {}
+    for share in (False, True):
+        b.share_geometry(share)
+        for it in range(3):
+            b.execute()
+            got = b.get_filters()
+            assert b.shares_geometry() == share and plans[3].info().num_sweep_launches == 1
+            if it:
+                assert all(np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) for a, c in zip(got, outs[share]))
+            outs[share] = got
+        worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(outs[share], singles))
+        print(f"{'MagLS-2D' if two_d else 'MagLS'} batch of 7, geometry shared = {share}: worst rel vs single designs = {worst:.3e}")
+        assert worst < 1e-12
+    assert rel(singles[0][0], singles[4][0]) > 1e-3
+    # one set moves to another grid: the batch still runs (unshared) and follows
+    plans[5].set_hrir_grid(np.mod(azi + 0.01, 2 * np.pi), zen)
+    b.execute()
+    assert not b.shares_geometry()
+    moved = b.get_filters()
+    plans[5].execute()
+    ref5 = plans[5].get_filters()
+    assert max(rel(moved[5][0], ref5[0]), rel(moved[5][1], ref5[1])) < 1e-12 and rel(moved[0][0], singles[0][0]) < 1e-12
+    assert rel(moved[5][0], singles[5][0]) > 1e-6
+    b.close()
+    if not two_d:
+        wide = Plan(L.KIND_MAGLS, "real", 5, 48000.0, 128, base[0].shape[0], base[0].shape[1], 0.0, 0)
+        with pytest.raises(EmaglsError, match="more than 32 channels"):
+            Batch([wide, wide])
+        wide.close()
+    for p in plans:
+        p.close()
+
+
 def test_geometry_sharing_with_twelve_hrir_sets_and_kinds_without_the_option(grids, thin):
     """9-16 HRIR sets share one sweep launch (twin workgroups) on plan 0's operands; a kind without the option (EMAinSH) accepts the switch
     and runs as before."""

@@ -241,6 +241,69 @@ def config3_hrir_sets(n_batches=3, per_batch=16, rounds=6):
                     "figure of this line treats its designs as independent and does NOT use this"}
 
 
+def config2_hrir_sets(n_batches=3, per_batch=16, rounds=6, share=True, diffuse=False):
+    """BASELINE config 2's design (getMagLsFilters N = 4, 2702 directions, 512 taps) as a job list of HRIR sets: MagLS plans in
+    batches -- one resident sweep launch per batch instead of one per design; share=True: sets on one grid, SH side once per
+    batch (not available with the covariance constraint, whose rendering needs every plan's own operands)."""
+    import ctypes
+    import torch
+    from emagls_amd import Batch, Plan, synth, _lib as L
+    azi, zen, _, _ = _grids()
+    lib = L.load()
+    prev = ctypes.c_int(0)
+    L.check(lib.emagls_set_batch_max(max(per_batch, 8), ctypes.byref(prev)))
+    units = []
+    single_ms = None
+    try:
+        for u in range(n_batches):
+            plans = []
+            for j in range(per_batch):
+                hL, hR = synth.rigid_sphere_hrirs(azi, zen, seed=900 + 100 * u + j)
+                p = Plan(L.KIND_MAGLS, "real", 4, 48000.0, 512, hL.shape[0], hL.shape[1], 0.0, 0, diffuseness=diffuse)
+                p.set_hrir_grid(azi, zen)
+                p.set_hrirs(hL, hR)
+                plans.append(p)
+            if single_ms is None:    # one design alone, for comparison
+                p = plans[0]
+                for _ in range(3):
+                    p.execute()
+                p.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(8):
+                    p.execute()
+                    p.synchronize()
+                single_ms = (time.perf_counter() - t0) / 8 * 1e3
+            b = Batch(plans)
+            b.set_stream(torch.cuda.Stream().cuda_stream)
+            b.share_geometry(share)
+            units.append((plans, b))
+    finally:
+        L.check(lib.emagls_set_batch_max(prev.value, None))
+    for plans, b in units:
+        for _ in range(2):
+            b.execute()
+        b.synchronize()
+    shared = all(b.shares_geometry() for _, b in units)
+    t0 = time.perf_counter()
+    for r in range(rounds):
+        for plans, b in units:
+            if r:
+                b.synchronize()
+            b.execute()
+    for plans, b in units:
+        b.synchronize()
+    dt = time.perf_counter() - t0
+    for plans, b in units:
+        b.get_filters()
+        b.close()
+        for p in plans:
+            p.close()
+    n = rounds * n_batches * per_batch
+    return {"hrir_sets": n, "batches_in_flight": n_batches, "sets_per_batch": per_batch, "geometry_shared": shared,
+            "covariance_constraint": bool(diffuse), "single_design_ms": round(single_ms, 3), "ms_per_set": round(dt / n * 1e3, 4),
+            "filter_sets_per_s": round(n / dt, 1)}
+
+
 def binaural_decode(nsamp=120000, nch=25, length=512, reps=10):
     """north_star item (iii) / SURVEY a13: dependencies/binauralDecode.m:33-42 at the harness's size -- a 120 000-sample SH
     recording x 25 channels through 512-tap filters, both ears -- real and complex SH, buffers resident in HBM
@@ -301,6 +364,11 @@ def run():
         out["config3_hrir_sets_on_one_geometry"] = config3_hrir_sets()
     except Exception as e:
         out["config3_hrir_sets_on_one_geometry"] = {"error": repr(e)}
+    try:
+        out["config2_magls_hrir_sets"] = {"one_grid_shared": config2_hrir_sets(), "independent": config2_hrir_sets(share=False),
+                                          "with_covariance_constraint": config2_hrir_sets(share=False, diffuse=True)}
+    except Exception as e:
+        out["config2_magls_hrir_sets"] = {"error": repr(e)}
     try:
         out["em64_emagls2"] = em64()
     except Exception as e:
