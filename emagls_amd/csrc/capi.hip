@@ -1958,6 +1958,29 @@ void batch_execute_magls(emagls_batch& b) {
     for (auto* p : b.plans)
         if (!p->have_hrirs || (p->custom_basis ? !p->have_basis : !p->have_hrir_grid))
             throw Error(EMAGLS_ERR_ARG, "every plan of the batch needs its grid (or SH matrix) and HRIRs");
+    if (p0.d.kind == EMAGLS_KIND_LS) {
+        // getLsFilters (lib/getLsFilters.m:30-34) has no sweep: wLs = h pinv(Y).  Sets on one grid: pinv(Y) once (plan 0), one
+        // small product per set; otherwise every plan's own pipeline, all on the batch's stream.
+        bool keep_persist = p0.sweep_persist;
+        p0.sweep_persist = true;                 // (the sharing decision only asks for it on behalf of the sweep; LS has none)
+        try { batch_magls_decide_sharing(b); } catch (...) { p0.sweep_persist = keep_persist; throw; }
+        p0.sweep_persist = keep_persist;
+        for (size_t j = 0; j < b.plans.size(); ++j) {
+            emagls_plan& p = *b.plans[j];
+            hipStream_t keep = p.stream;
+            p.stream = b.stream;
+            try {
+                p.stage_names.clear();
+                launch_zero(p.get("flag"), sizeof(int) * NFLAG, b.stream);
+                if (j == 0 || !b.geo_share) execute_ls(p);
+                else launch_ls_filters(p.get<double>("hL"), p.get<double>("hR"), p.d.nsamp, (int)p.D, p0.get("Ypinv"), p0.cplx_basis, p0.ldD, p.C,
+                                       p.get("wL"), p.get("wR"), b.stream);
+            } catch (...) { p.stream = keep; throw; }
+            p.stream = keep;
+            p.executed = true;
+        }
+        return;
+    }
     bool persist = true;
     for (auto* p : b.plans) persist = persist && p->sweep_persist;
     if (!persist) {   // (an ill-conditioned basis or a sweep that did not become resident: the designs one at a time, launch-per-bin sweeps)
@@ -2769,9 +2792,12 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         for (int j = 0; j < nplans; ++j) {
             emagls_plan* p = plans[j];
             if (!p) throw Error(EMAGLS_ERR_ARG, "null plan");
-            if (!array_kind(p->d.kind) && p->d.kind != EMAGLS_KIND_FROM_ATF && !magls_kind(p->d.kind))
-                throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH / EMAinSH plans, MagLS / MagLS-2D plans, or FromAtf plans "
+            if (!array_kind(p->d.kind) && p->d.kind != EMAGLS_KIND_FROM_ATF && !magls_kind(p->d.kind) && p->d.kind != EMAGLS_KIND_LS)
+                throw Error(EMAGLS_ERR_UNSUPPORTED, "batches take eMagLS / eMagLS2 / EMAinCH / EMAinSH plans, LS / MagLS / MagLS-2D plans, or FromAtf plans "
                                                     "(subjects of one ATF set)");
+            if ((p->d.kind == EMAGLS_KIND_LS) != (plans[0]->d.kind == EMAGLS_KIND_LS) ||
+                (p->d.kind == EMAGLS_KIND_LS && (p->cplx_basis != plans[0]->cplx_basis || p->d.order != plans[0]->d.order || p->d.nsamp != plans[0]->d.nsamp)))
+                throw Error(EMAGLS_ERR_ARG, "LS plans share a batch only with LS plans of the same order, basis and HRIR length");
             if ((p->d.kind == EMAGLS_KIND_FROM_ATF) != (plans[0]->d.kind == EMAGLS_KIND_FROM_ATF))
                 throw Error(EMAGLS_ERR_ARG, "FromAtf plans cannot share a batch with array designs");
             if (magls_kind(p->d.kind) != magls_kind(plans[0]->d.kind) || (magls_kind(p->d.kind) && p->d.kind != plans[0]->d.kind))
@@ -2807,7 +2833,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
             p->owner = b.get();
         }
         b->atf = b->plans[0]->d.kind == EMAGLS_KIND_FROM_ATF;
-        b->magls = magls_kind(b->plans[0]->d.kind);
+        b->magls = magls_kind(b->plans[0]->d.kind) || b->plans[0]->d.kind == EMAGLS_KIND_LS;
         if (!b->atf && !b->magls) batch_try_lanes(*b);
         *batch = b.release();
     });

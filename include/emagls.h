@@ -311,8 +311,8 @@ void* emagls_plan_stream(emagls_plan* plan);
  * with EMAGLS_BATCH_MAX=16 in the environment up to 16 (two designs per XCD, two sweep workgroups per CU: for an otherwise
  * idle device only, see emagls_batch_create in capi.hip); the plans stay owned by the
  * caller and must outlive the batch.  Results: emagls_batch_get_filters, or emagls_plan_get_filters on each plan.
- * MagLS / MagLS-2D plans of one kind, order and basis (up to 32 channels) form batches as well (lib/getMagLsFilters.m:30 in a
- * loop over HRIR sets): their stages run on the batch's stream and ONE resident sweep launch serves all designs; with
+ * LS / MagLS / MagLS-2D plans of one kind, order and basis (up to 32 channels) form batches as well (lib/getLsFilters.m:30,
+ * lib/getMagLsFilters.m:30 in a loop over HRIR sets): their stages run on the batch's stream and ONE resident sweep launch serves all designs; with
  * emagls_batch_set_geometry_sharing, sets on one grid compute the SH side once. */
 typedef struct emagls_batch emagls_batch;
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch);
@@ -326,7 +326,7 @@ int emagls_set_batch_max(int max_designs, int* previous);
  * geometry input (compared on the device whenever a grid is replaced) runs the SH matrices, the array model, pwGrid_k and its
  * regularised inverses ONCE (plan 0) and per plan only what its HRIRs enter: spectra, least-squares rows, the sweep (on plan
  * 0's operands) and the epilogue.  Off by default: a batch then treats its designs as independent.  Plans that do not agree
- * (or kinds without the option: LS / FromAtf / EMAinSH / more than 32 channels / designs with the covariance constraint) run
+ * (or kinds without the option: FromAtf / EMAinSH / more than 32 channels / designs with the covariance constraint) run
  * as before;
  * emagls_batch_shares_geometry reports what the last execute did. */
 int emagls_batch_set_geometry_sharing(emagls_batch* batch, int enable);

@@ -506,6 +506,34 @@ def test_magls_batches(grids, thin, two_d):
         p.close()
 
 
+def test_ls_batches(thin):
+    """getLsFilters in a loop over HRIR sets: LS plans in a batch, pinv(Y) once for sets on one grid (Batch.share_geometry)."""
+    from emagls_amd import Batch, Plan, _lib as L
+    rng = np.random.default_rng(43)
+    plans, singles = [], []
+    for j in range(5):
+        hL = thin["hL"] * (1.0 + 0.1 * j) + 1e-3 * rng.standard_normal(thin["hL"].shape)
+        p = Plan(L.KIND_LS, "real", 4, 48000.0, thin["hL"].shape[0], hL.shape[0], hL.shape[1], 0.0, 0)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_hrirs(hL, thin["hR"])
+        p.execute()
+        singles.append(p.get_filters())
+        plans.append(p)
+    b = Batch(plans)
+    for share in (False, True):
+        b.share_geometry(share)
+        b.execute()
+        out = b.get_filters()
+        assert b.shares_geometry() == share
+        worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(out, singles))
+        print(f"LS batch of 5, geometry shared = {share}: worst rel vs single designs = {worst:.3e}")
+        assert worst < 1e-13
+    assert rel(singles[0][0], singles[3][0]) > 1e-3
+    b.close()
+    for p in plans:
+        p.close()
+
+
 def test_geometry_sharing_with_twelve_hrir_sets_and_kinds_without_the_option(grids, thin):
     """9-16 HRIR sets share one sweep launch (twin workgroups) on plan 0's operands; a kind without the option (EMAinSH) accepts the switch
     and runs as before."""
