@@ -238,6 +238,40 @@ def getEMagLs2Filters(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGrid
                 micGridZenRad, order, fs, len, shDefinition, shFunction, applyDiffusenessConst)
 
 
+def designHrirSets(kind, hL, hR, hrirGridAziRad, hrirGridZenRad=None, micRadius=0.0, micGridAziRad=None, micGridZenRad=None, order=4,
+                   fs=48000.0, len=512, shDefinition="real"):
+    """The loop over HRIR sets around one of the reference's design functions, as ONE call (emagls_design_hrir_sets): hL, hR
+    [numSamples x numDirections x numSets] on one grid (and one array); kind in 'ls', 'magls', 'magls2d', 'emagls', 'emagls2',
+    'emainch'.  Returns wL, wR [len x channels x numSets] -- the filters nsets single calls return (lib/getLsFilters.m:30,
+    getMagLsFilters.m:30, getMagLsFilters2D.m:1, getEMagLsFilters.m:32, getEMagLs2Filters.m:32, getEMagLsFiltersEMAinCH.m:32)."""
+    kinds = {"ls": L.KIND_LS, "magls": L.KIND_MAGLS, "magls2d": L.KIND_MAGLS_2D, "emagls": L.KIND_EMAGLS, "emagls2": L.KIND_EMAGLS2,
+             "emainch": L.KIND_EMA_CH}
+    if kind not in kinds:
+        raise ValueError("kind must be one of %s" % sorted(kinds))
+    b, cplx = _basis(shDefinition)
+    hL = np.asfortranarray(hL, dtype=np.float64)
+    hR = np.asfortranarray(hR, dtype=np.float64)
+    if hL.ndim != 3 or hL.shape != hR.shape:
+        raise ValueError("hL / hR must be equal-shaped [numSamples x numDirections x numSets] arrays")
+    n, D, nsets = hL.shape
+    azi, pa = _vec(hrirGridAziRad, D, "hrirGridAziRad")
+    zen, pz = (None, None) if hrirGridZenRad is None else _vec(hrirGridZenRad, D, "hrirGridZenRad")
+    arr = kind in ("emagls", "emagls2", "emainch")
+    micAzi, pma = _vec(micGridAziRad) if arr else (None, None)
+    micZen, pmz = (None, None) if (not arr or micGridZenRad is None) else _vec(micGridZenRad, micAzi.size, "micGridZenRad")
+    N = int(order)
+    C_ = {"ls": (N + 1) ** 2, "magls": (N + 1) ** 2, "magls2d": 2 * N + 1, "emagls": (N + 1) ** 2, "emainch": 2 * N + 1}.get(kind)
+    if kind == "emagls2":
+        C_ = micAzi.size
+    rows = n if kind == "ls" else int(len)
+    dt = np.complex128 if cplx else np.float64      # (complex SH definition: complex filters for every kind, eMagLS2 included)
+    wL = np.zeros((rows, C_, nsets), dtype=dt, order="F")
+    wR = np.zeros((rows, C_, nsets), dtype=dt, order="F")
+    L.check(L.load().emagls_design_hrir_sets(kinds[kind], hL.ctypes.data, hR.ctypes.data, n, D, nsets, pa, pz, float(micRadius), pma, pmz,
+                                             micAzi.size if arr else 0, N, float(fs), int(len), b, wL.ctypes.data, wR.ctypes.data))
+    return wL, wR
+
+
 def getEMagLsFiltersEMAinCH(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, order, fs, len,
                             shDefinition="real", shFunction=None, chFunction=None):
     """lib/getEMagLsFiltersEMAinCH.m:1-2: eMagLS filters in circular harmonics for an equatorial microphone array;

@@ -2424,6 +2424,7 @@ int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR,
 // designs per batch: 8 by default (one per XCD in the resident sweep), up to 16 (two per XCD) after emagls_set_batch_max / EMAGLS_BATCH_MAX
 namespace {
 std::atomic<int> g_batch_max{[] { const char* e = getenv("EMAGLS_BATCH_MAX"); return e ? std::max(1, std::min(SWEEP_MULTI_MAX, atoi(e))) : 8; }()};
+thread_local int g_batch_max_override = 0;   // emagls_design_hrir_sets builds batches of 16 of its own whatever the caller's limit is
 }
 // work planes of the complex device-resident decode, grown on demand and kept (released by emagls_cache_clear)
 namespace {
@@ -2467,6 +2468,7 @@ int emagls_set_device(int device) {
     return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
 }
 
+void emagls_sets_cache_clear_internal();
 int emagls_cache_clear(void) {
     return guarded([&] {
         {
@@ -2475,8 +2477,11 @@ int emagls_cache_clear(void) {
                 if (!g_cache[i].busy) g_cache.erase(g_cache.begin() + i);
         }
         decode_cache_clear();
-        std::lock_guard<std::mutex> lk(g_decode_scratch.mu);
-        g_decode_scratch.release();
+        {
+            std::lock_guard<std::mutex> lk(g_decode_scratch.mu);
+            g_decode_scratch.release();
+        }
+        emagls_sets_cache_clear_internal();
     });
 }
 
@@ -2784,7 +2789,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         // (e.g. factor_qr: 1024 threads x 128 registers) makes the dispatcher hold back the sweep's remaining workgroups
         // while the resident ones wait for them -- observed as a 0.4 s stall until the sweep's own time-out falls back to the
         // launch-per-bin form.  Hence opt-in: EMAGLS_BATCH_MAX=16.
-        const int batch_max = g_batch_max.load();
+        const int batch_max = std::max(g_batch_max.load(), g_batch_max_override);
         if (nplans > batch_max)
             throw Error(EMAGLS_ERR_UNSUPPORTED, batch_max >= SWEEP_MULTI_MAX ? "at most 16 designs per batch"
                                                                              : "at most 8 designs per batch (emagls_set_batch_max(16) / EMAGLS_BATCH_MAX=16 allows 16)");
@@ -3211,6 +3216,96 @@ int emagls_get_emagls2_filters_with_basis(const double* hL, const double* hR, in
     d.mic_radius = mic_radius; d.nmics = nmics; d.custom_basis = 1;
     if (!Y_mic) { g_last_error = "null microphone SH matrix"; return EMAGLS_ERR_ARG; }
     return one_shot(d, hL, hR, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, wL, wR, nullptr, Y_hrir, Y_mic);
+}
+
+// ---------------------------------------------------------------------------------------------
+// HRIR sets on one geometry in ONE call (what a loop over subjects around lib/get*Filters.m does): plans + a geometry-sharing
+// batch per chunk of up to 16 sets, kept for the next call of the same shape (emagls_cache_clear releases them).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct SetsCache {
+    emagls_design_desc desc{};
+    int device = -1, n = 0;
+    std::vector<emagls_plan*> plans;
+    emagls_batch* batch = nullptr;
+    void release() {
+        if (batch) { emagls_batch_destroy(batch); batch = nullptr; }
+        for (auto* p : plans) emagls_plan_destroy(p);
+        plans.clear();
+        n = 0; device = -1;
+    }
+};
+std::mutex g_sets_mu;
+SetsCache g_sets[2];   // (a job list is chunks of one size plus one tail chunk)
+}  // namespace
+void emagls_sets_cache_clear_internal() {
+    std::lock_guard<std::mutex> lk(g_sets_mu);
+    for (auto& c : g_sets) c.release();
+}
+
+int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, int64_t nsets,
+                            const double* hrir_azi, const double* hrir_zen, double mic_radius, const double* mic_azi, const double* mic_zen,
+                            int64_t nmics, int order, double fs, int64_t len, int basis, void* wL, void* wR) {
+    int rc_all = EMAGLS_OK;
+    const int rc = guarded([&] {
+        if (!hL || !hR || !hrir_azi || !wL || !wR || nsets < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        const bool arr = kind == EMAGLS_KIND_EMAGLS || kind == EMAGLS_KIND_EMAGLS2 || kind == EMAGLS_KIND_EMA_CH;
+        if (!arr && kind != EMAGLS_KIND_LS && kind != EMAGLS_KIND_MAGLS && kind != EMAGLS_KIND_MAGLS_2D)
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "HRIR-set job lists: LS, MagLS, MagLS-2D, eMagLS, eMagLS2, EMAinCH");
+        emagls_design_desc d{};
+        d.kind = kind; d.basis = basis; d.order = order; d.fs = fs; d.len = kind == EMAGLS_KIND_LS ? nsamp : len; d.nsamp = nsamp; d.ndirs = ndirs;
+        d.mic_radius = arr ? mic_radius : 0.0; d.nmics = arr ? nmics : 0;
+        auto req = [](int r) { if (r != EMAGLS_OK) throw Error(r, g_last_error); };
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(g_sets_mu);
+        size_t out_bytes = 0;
+        for (int64_t first = 0; first < nsets;) {
+            const int n = (int)std::min<int64_t>(SWEEP_MULTI_MAX, nsets - first);
+            SetsCache* c = &g_sets[n == SWEEP_MULTI_MAX ? 0 : 1];   // slot 0: full chunks, slot 1: the tail chunk
+            if (!(c->n == n && c->device == dev && same_desc(c->desc, d))) {
+                c->release();
+                try {
+                    for (int j = 0; j < n; ++j) {
+                        emagls_plan* p = nullptr;
+                        req(emagls_plan_create(&d, &p));
+                        c->plans.push_back(p);
+                    }
+                    if (n > 1) {
+                        g_batch_max_override = SWEEP_MULTI_MAX;
+                        const int r = emagls_batch_create(c->plans.data(), n, &c->batch);
+                        g_batch_max_override = 0;
+                        req(r);
+                        req(emagls_batch_set_geometry_sharing(c->batch, 1));
+                    }
+                } catch (...) { g_batch_max_override = 0; c->release(); throw; }
+                c->desc = d; c->device = dev; c->n = n;
+            }
+            try {
+                for (int j = 0; j < n; ++j) {
+                    emagls_plan* p = c->plans[(size_t)j];
+                    req(emagls_plan_set_hrir_grid(p, hrir_azi, hrir_zen));
+                    if (arr) req(emagls_plan_set_mic_grid(p, mic_azi, mic_zen));
+                    req(emagls_plan_set_hrirs(p, hL + (first + j) * nsamp * ndirs, hR + (first + j) * nsamp * ndirs));
+                }
+                emagls_plan_info info;
+                req(emagls_plan_get_info(c->plans[0], &info));
+                out_bytes = (info.out_is_complex ? sizeof(cplx) : sizeof(double)) * (size_t)info.out_rows * info.out_cols;
+                if (n == 1) {
+                    req(emagls_plan_execute(c->plans[0]));
+                    req(emagls_plan_get_filters(c->plans[0], (char*)wL + first * out_bytes, (char*)wR + first * out_bytes));
+                } else {
+                    std::vector<void*> pl((size_t)n), pr((size_t)n);
+                    for (int j = 0; j < n; ++j) { pl[(size_t)j] = (char*)wL + (first + j) * out_bytes; pr[(size_t)j] = (char*)wR + (first + j) * out_bytes; }
+                    req(emagls_batch_execute(c->batch));
+                    req(emagls_batch_get_filters(c->batch, pl.data(), pr.data()));
+                }
+            } catch (...) { c->release(); throw; }   // (a failed call leaves the plans in an unknown state)
+            first += n;
+        }
+    });
+    (void)rc_all;
+    return rc;
 }
 
 int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const double* wL, const double* wR, int64_t len,

@@ -331,6 +331,16 @@ int emagls_set_batch_max(int max_designs, int* previous);
  * emagls_batch_shares_geometry reports what the last execute did. */
 int emagls_batch_set_geometry_sharing(emagls_batch* batch, int enable);
 int emagls_batch_shares_geometry(emagls_batch* batch, int* shared);
+/* HRIR sets on ONE grid (and, for the array kinds, ONE array) in one call -- the loop
+ *     for i = 1:nsets, [wL(:,:,i), wR(:,:,i)] = getEMagLsFilters(hL(:,:,i), hR(:,:,i), grid..., array..., order, fs, len, shDefinition); end
+ * around lib/getLsFilters.m:30 / getMagLsFilters.m:30 / getMagLsFilters2D.m:1 (hrir_zen NULL) / getEMagLsFilters.m:32 /
+ * getEMagLs2Filters.m:32 / getEMagLsFiltersEMAinCH.m:32 (mic_zen NULL), kind = EMAGLS_KIND_LS / _MAGLS / _MAGLS_2D / _EMAGLS /
+ * _EMAGLS2 / _EMA_CH.  hL, hR [nsamp x ndirs x nsets] (MATLAB 3-D arrays), wL, wR [len x channels x nsets] (LS: nsamp rows; `fs`
+ * and `len` are ignored for LS).  Internally: plans and geometry-sharing batches of up to 16 sets (kept for the next call of the
+ * same shape; emagls_cache_clear releases them), one resident sweep launch per batch; the same filters as nsets single calls. */
+int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, int64_t nsets,
+                            const double* hrir_azi, const double* hrir_zen, double mic_radius, const double* mic_azi, const double* mic_zen,
+                            int64_t nmics, int order, double fs, int64_t len, int basis, void* wL, void* wR);
 /* A batch may also hold EMAGLS_KIND_FROM_ATF plans of one shape -- the HRTF subjects of one ATF set (BASELINE config 5: 8 subjects).
  * lib/getEMagLsFiltersFromAtf.m:54-95,100-104: the spectra of the matched ATFs and their per-bin factors do not depend on the
  * HRIRs.  When all plans hold the same grids and the same ATF set (compared on the device whenever one of them was replaced) the
