@@ -3228,7 +3228,9 @@ struct SetsCache {
     int device = -1, n = 0;
     std::vector<emagls_plan*> plans;
     emagls_batch* batch = nullptr;
+    std::vector<double> grid[4];      // the grids the plans hold (hrir azi / zen, mic azi / zen): unchanged grids are not uploaded again
     void release() {
+        for (auto& g : grid) g.clear();
         if (batch) { emagls_batch_destroy(batch); batch = nullptr; }
         for (auto* p : plans) emagls_plan_destroy(p);
         plans.clear();
@@ -3282,12 +3284,20 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
                 c->desc = d; c->device = dev; c->n = n;
             }
             try {
+                auto same = [](const std::vector<double>& have, const double* now, size_t cnt) {
+                    return now ? (have.size() == cnt && std::memcmp(have.data(), now, cnt * sizeof(double)) == 0) : have.empty();
+                };
+                const bool hgrid_same = same(c->grid[0], hrir_azi, (size_t)ndirs) && same(c->grid[1], hrir_zen, (size_t)ndirs) && !c->grid[0].empty();
+                const bool mgrid_same = !arr || (same(c->grid[2], mic_azi, (size_t)nmics) && same(c->grid[3], mic_zen, (size_t)nmics) && !c->grid[2].empty());
                 for (int j = 0; j < n; ++j) {
                     emagls_plan* p = c->plans[(size_t)j];
-                    req(emagls_plan_set_hrir_grid(p, hrir_azi, hrir_zen));
-                    if (arr) req(emagls_plan_set_mic_grid(p, mic_azi, mic_zen));
+                    if (!hgrid_same) req(emagls_plan_set_hrir_grid(p, hrir_azi, hrir_zen));
+                    if (arr && !mgrid_same) req(emagls_plan_set_mic_grid(p, mic_azi, mic_zen));
                     req(emagls_plan_set_hrirs(p, hL + (first + j) * nsamp * ndirs, hR + (first + j) * nsamp * ndirs));
                 }
+                auto keep = [](std::vector<double>& dst, const double* src, size_t cnt) { if (src) dst.assign(src, src + cnt); else dst.clear(); };
+                keep(c->grid[0], hrir_azi, (size_t)ndirs); keep(c->grid[1], hrir_zen, (size_t)ndirs);
+                if (arr) { keep(c->grid[2], mic_azi, (size_t)nmics); keep(c->grid[3], mic_zen, (size_t)nmics); }
                 emagls_plan_info info;
                 req(emagls_plan_get_info(c->plans[0], &info));
                 out_bytes = (info.out_is_complex ? sizeof(cplx) : sizeof(double)) * (size_t)info.out_rows * info.out_cols;

@@ -69,6 +69,7 @@ void at_exit() { emagls_cache_clear(); }
 // emagls_mex('emainch' | 'emainsh', hL, hR, azi, zen, micRadius, micAzi, order, fs, len, shDefinition)
 // emagls_mex('magls_dc' | 'emagls_dc' | 'emagls2_dc', <the arguments of 'magls' / 'emagls' / 'emagls2'>, applyDiffusenessConst)
 // emagls_mex('decode',  in, wL, wR, compensateDelay)            real or complex in / filters; [out, imagAbsSum] = ...
+// emagls_mex('sets', kind, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition)   3-D hL / hR: a loop over HRIR sets in one call
 // caller-evaluated shFunction handles (the wrappers evaluate them at emagls_mex('simorder', kind, order, fs, micRadius)):
 // emagls_mex('ls_y', hL, hR, Yhrir, order, shDefinition)        emagls_mex('magls_y', hL, hR, Yhrir, order, fs, len, shDefinition)
 // emagls_mex('emagls_y' | 'emagls2_y', hL, hR, Yhrir, micRadius, Ymic, order, fs, len, shDefinition)
@@ -104,6 +105,52 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                                                 mxGetDoubles(plhs[0]), imag_sum);
             if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix(1, 2, mxREAL); mxGetDoubles(plhs[1])[0] = imag_sum[0]; mxGetDoubles(plhs[1])[1] = imag_sum[1]; }
         }
+        if (rc) fail(rc);
+        return;
+    }
+    if (c == "sets") {
+        // [wL, wR] = emagls_mex('sets', kind, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition)
+        // hL, hR [numSamples x numDirections x numSets]; zen / micAzi / micZen may be [] where the single call has no such argument.
+        // The loop over HRIR sets around lib/getLsFilters.m:30, getMagLsFilters.m:30, getMagLsFilters2D.m:1, getEMagLsFilters.m:32,
+        // getEMagLs2Filters.m:32, getEMagLsFiltersEMAinCH.m:32 in one call (emagls_design_hrir_sets).
+        if (nrhs < 13) mexErrMsgIdAndTxt("eMagLS:arg", "sets needs (kind, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition)");
+        char kb[16] = {0};
+        mxGetString(prhs[1], kb, sizeof kb);
+        const std::string ks(kb);
+        int kind;
+        if (ks == "ls") kind = EMAGLS_KIND_LS; else if (ks == "magls") kind = EMAGLS_KIND_MAGLS; else if (ks == "magls2d") kind = EMAGLS_KIND_MAGLS_2D;
+        else if (ks == "emagls") kind = EMAGLS_KIND_EMAGLS; else if (ks == "emagls2") kind = EMAGLS_KIND_EMAGLS2;
+        else if (ks == "emainch") kind = EMAGLS_KIND_EMA_CH;
+        else { mexErrMsgIdAndTxt("eMagLS:arg", "unknown design kind '%s'", kb); return; }
+        const double* hL = dbl(prhs[2], "hL");
+        const double* hR = dbl(prhs[3], "hR");
+        const mwSize nd = mxGetNumberOfDimensions(prhs[2]);
+        const mwSize* hd = mxGetDimensions(prhs[2]);
+        const mwSize nsamp = hd[0], ndirs = hd[1], nsets = nd > 2 ? hd[2] : 1;
+        if (mxGetNumberOfElements(prhs[3]) != mxGetNumberOfElements(prhs[2])) mexErrMsgIdAndTxt("eMagLS:arg", "hL and hR must have the same size");
+        auto opt = [&](int i, const char* what) -> const double* { return mxIsEmpty(prhs[i]) ? nullptr : dbl(prhs[i], what); };
+        const double* azi = dbl(prhs[4], "hrirGridAziRad");
+        const double* zen = opt(5, "hrirGridZenRad");
+        const double r = mxIsEmpty(prhs[6]) ? 0.0 : mxGetScalar(prhs[6]);
+        const double* mazi = opt(7, "micGridAziRad");
+        const double* mzen = opt(8, "micGridZenRad");
+        const mwSize nmics = mazi ? mxGetNumberOfElements(prhs[7]) : 0;
+        const int order = (int)mxGetScalar(prhs[9]);
+        const double fs = mxIsEmpty(prhs[10]) ? 48000.0 : mxGetScalar(prhs[10]);
+        const mwSize len = kind == EMAGLS_KIND_LS ? nsamp : (mwSize)mxGetScalar(prhs[11]);
+        const int basis = basis_of(prhs[12]);
+        mwSize C;
+        switch (kind) {
+            case EMAGLS_KIND_MAGLS_2D: case EMAGLS_KIND_EMA_CH: C = (mwSize)(2 * order + 1); break;
+            case EMAGLS_KIND_EMAGLS2: C = nmics; break;
+            default: C = (mwSize)((order + 1) * (order + 1));
+        }
+        const mwSize od[3] = {len, C, nsets};
+        plhs[0] = mxCreateNumericArray(3, od, mxDOUBLE_CLASS, basis == EMAGLS_BASIS_COMPLEX ? mxCOMPLEX : mxREAL);
+        mxArray* wR = mxCreateNumericArray(3, od, mxDOUBLE_CLASS, basis == EMAGLS_BASIS_COMPLEX ? mxCOMPLEX : mxREAL);
+        const int rc = emagls_design_hrir_sets(kind, hL, hR, nsamp, ndirs, nsets, azi, zen, r, mazi, mzen, nmics, order, fs, len, basis,
+                                               out_ptr(plhs[0]), out_ptr(wR));
+        if (nlhs > 1) plhs[1] = wR; else mxDestroyArray(wR);
         if (rc) fail(rc);
         return;
     }

@@ -135,6 +135,21 @@ def test_gateway_design_calls_match_the_python_binding(mex, grids, thin):
     wL, wR = mex(2, "fromatf", hL, hR, hg, atf, ag, 48000.0, 128, 2000.0)
     eL, eR = E.getEMagLsFiltersFromAtf(hL, hR, hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)[:2]
     assert wL.shape == (128, 5) and np.array_equal(wL, eL) and np.array_equal(wR, eR)
+    # 'sets': 3-D HRIR arrays, a loop over HRIR sets in one call (MagLS and eMagLS2; [] for the arguments a kind does not have)
+    h3L = np.stack([hL * (1 + 0.05 * j) for j in range(5)], axis=2)
+    h3R = np.stack([hR * (1 - 0.03 * j) for j in range(5)], axis=2)
+    empty = np.zeros((0, 0))
+    sL, sR = mex(2, "sets", "magls", h3L, h3R, azi, zen, empty, empty, empty, 3, 48000.0, 128, "complex")
+    assert sL.shape == (128, 16, 5) and np.iscomplexobj(sL)
+    for j in (0, 4):
+        eL, eR = E.getMagLsFilters(h3L[:, :, j], h3R[:, :, j], azi, zen, 3, 48000.0, 128, "complex")
+        assert np.array_equal(sL[:, :, j], eL) and np.array_equal(sR[:, :, j], eR)
+    sL, sR = mex(2, "sets", "emagls2", h3L, h3R, azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "real")
+    assert sL.shape == (128, 32, 5) and not np.iscomplexobj(sL)
+    eL, eR = E.getEMagLs2Filters(h3L[:, :, 3], h3R[:, :, 3], azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "real")
+    assert np.array_equal(sL[:, :, 3], eL) and np.array_equal(sR[:, :, 3], eR)
+    with pytest.raises(mex.Error, match="unknown design kind"):
+        mex(2, "sets", "fromatf", h3L, h3R, azi, zen, empty, empty, empty, 3, 48000.0, 128, "real")
     rng = np.random.default_rng(3)
     sig = rng.standard_normal((3000, 25))
     fL, fR = E.getEMagLsFilters(hL, hR, azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "real")
