@@ -128,6 +128,9 @@ SYMBOLS = {
     "emagls_batch_shares_atf_side": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "emagls_design_hrir_sets": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_double,
                                           C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "emagls_from_atf_hrir_sets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_double)]),
     "emagls_batch_set_geometry_sharing": (C.c_int, [C.c_void_p, C.c_int]),
     "emagls_batch_shares_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "emagls_batch_set_side_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -272,6 +272,31 @@ def designHrirSets(kind, hL, hR, hrirGridAziRad, hrirGridZenRad=None, micRadius=
     return wL, wR
 
 
+def fromAtfHrirSets(hL, hR, hrirGridAziZenRad, atfIrs, atfGridAziZenRad, fs, filterLen, fTrans):
+    """getEMagLsFiltersFromAtf (lib/getEMagLsFiltersFromAtf.m:1) for every HRIR set (subject) of hL, hR [numSamples x
+    numDirections x numSets] on ONE ATF set, as one call (emagls_from_atf_hrir_sets): the ATF set is uploaded once and its side
+    computed once per batch of up to 16 subjects.  Returns wL, wR [filterLen x numMics x numSets], meanGridDevDeg."""
+    hL = np.asfortranarray(hL, dtype=np.float64)
+    hR = np.asfortranarray(hR, dtype=np.float64)
+    if hL.ndim != 3 or hL.shape != hR.shape:
+        raise ValueError("hL / hR must be equal-shaped [numSamples x numDirections x numSets] arrays")
+    n, D, nsets = hL.shape
+    hg = np.asarray(hrirGridAziZenRad, dtype=np.float64)
+    ag = np.asarray(atfGridAziZenRad, dtype=np.float64)
+    atf = np.asfortranarray(atfIrs, dtype=np.float64)
+    taps, M, Da = atf.shape
+    azi, pa = _vec(hg[:, 0], D, "hrirGridAziZenRad(:,1)")
+    zen, pz = _vec(hg[:, 1], D, "hrirGridAziZenRad(:,2)")
+    aazi, paa = _vec(ag[:, 0], Da, "atfGridAziZenRad(:,1)")
+    azen, paz = _vec(ag[:, 1], Da, "atfGridAziZenRad(:,2)")
+    wL = np.zeros((int(filterLen), M, nsets), dtype=np.float64, order="F")
+    wR = np.zeros((int(filterLen), M, nsets), dtype=np.float64, order="F")
+    dev = C.c_double(0.0)
+    L.check(L.load().emagls_from_atf_hrir_sets(hL.ctypes.data, hR.ctypes.data, n, D, nsets, pa, pz, atf.ctypes.data, taps, M, Da, paa, paz, float(fs),
+                                               int(filterLen), float(fTrans), wL.ctypes.data, wR.ctypes.data, C.byref(dev)))
+    return wL, wR, dev.value
+
+
 def getEMagLsFiltersEMAinCH(hL, hR, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, order, fs, len,
                             shDefinition="real", shFunction=None, chFunction=None):
     """lib/getEMagLsFiltersEMAinCH.m:1-2: eMagLS filters in circular harmonics for an equatorial microphone array;

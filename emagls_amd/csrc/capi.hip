@@ -2469,6 +2469,7 @@ int emagls_set_device(int device) {
 }
 
 void emagls_sets_cache_clear_internal();
+void emagls_atfsets_cache_clear_internal();
 int emagls_cache_clear(void) {
     return guarded([&] {
         {
@@ -2482,6 +2483,7 @@ int emagls_cache_clear(void) {
             g_decode_scratch.release();
         }
         emagls_sets_cache_clear_internal();
+        emagls_atfsets_cache_clear_internal();
     });
 }
 
@@ -3316,6 +3318,86 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
     });
     (void)rc_all;
     return rc;
+}
+
+// The HRTF subjects of ONE ATF set in one call (BASELINE config 5; lib/getEMagLsFiltersFromAtf.m:1 in a loop over subjects).  The
+// ATF set is uploaded once (plan 0) and handed to the other plans device to device; the batch then finds equal ATF sides and
+// computes that side once (batch_atf_decide_sharing).
+namespace {
+std::mutex g_atfsets_mu;
+SetsCache g_atfsets[2];
+}  // namespace
+void emagls_atfsets_cache_clear_internal() {
+    std::lock_guard<std::mutex> lk(g_atfsets_mu);
+    for (auto& c : g_atfsets) c.release();
+}
+int emagls_from_atf_hrir_sets(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, int64_t nsets, const double* hrir_azi,
+                              const double* hrir_zen, const double* atf_irs, int64_t atf_taps, int64_t nmics, int64_t natf, const double* atf_azi,
+                              const double* atf_zen, double fs, int64_t filter_len, double f_trans, double* wL, double* wR, double* mean_dev) {
+    return guarded([&] {
+        if (!hL || !hR || !hrir_azi || !hrir_zen || !atf_irs || !atf_azi || !atf_zen || !wL || !wR || nsets < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        emagls_design_desc d{};
+        d.kind = EMAGLS_KIND_FROM_ATF; d.basis = EMAGLS_BASIS_REAL; d.fs = fs; d.len = filter_len; d.nsamp = nsamp; d.ndirs = ndirs;
+        d.nmics = nmics; d.f_trans = f_trans; d.atf_taps = atf_taps; d.natf = natf;
+        auto req = [](int r) { if (r != EMAGLS_OK) throw Error(r, g_last_error); };
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(g_atfsets_mu);
+        const size_t out_bytes = sizeof(double) * (size_t)filter_len * (size_t)nmics;
+        for (int64_t first = 0; first < nsets;) {
+            const int n = (int)std::min<int64_t>(SWEEP_MULTI_MAX, nsets - first);
+            const int slot = n == SWEEP_MULTI_MAX ? 0 : 1;
+            SetsCache* c = &g_atfsets[slot];
+            if (!(c->n == n && c->device == dev && same_desc(c->desc, d))) {
+                c->release();
+                try {
+                    for (int j = 0; j < n; ++j) {
+                        emagls_plan* p = nullptr;
+                        req(emagls_plan_create(&d, &p));
+                        c->plans.push_back(p);
+                    }
+                    if (n > 1) {
+                        g_batch_max_override = SWEEP_MULTI_MAX;
+                        const int r = emagls_batch_create(c->plans.data(), n, &c->batch);
+                        g_batch_max_override = 0;
+                        req(r);
+                    }
+                } catch (...) { g_batch_max_override = 0; c->release(); throw; }
+                c->desc = d; c->device = dev; c->n = n;
+            }
+            try {
+                // the ATF set and the grids: host -> plan 0, plan 0 -> the others on the device (the set is 268 MB at config 5)
+                emagls_plan* p0 = c->plans[0];
+                req(emagls_plan_set_hrir_grid(p0, hrir_azi, hrir_zen));
+                req(emagls_plan_set_atfs(p0, atf_irs, atf_azi, atf_zen));
+                for (int j = 1; j < n; ++j) {
+                    emagls_plan* p = c->plans[(size_t)j];
+                    for (const char* name : {"atf", "atf_azi", "atf_zen", "hrir_azi", "hrir_zen"})
+                        HIP_CHECK(hipMemcpyAsync(p->get(name), p0->get(name), p0->bufs[name].bytes, hipMemcpyDeviceToDevice, p0->stream));
+                    p->have_atfs = true; p->have_hrir_grid = true;
+                    ++p->atf_side_version;
+                }
+                HIP_CHECK(hipStreamSynchronize(p0->stream));
+                for (int j = 0; j < n; ++j)
+                    req(emagls_plan_set_hrirs(c->plans[(size_t)j], hL + (first + j) * nsamp * ndirs, hR + (first + j) * nsamp * ndirs));
+                if (n == 1) {
+                    req(emagls_plan_execute(p0));
+                    req(emagls_plan_get_filters(p0, (char*)wL + first * out_bytes, (char*)wR + first * out_bytes));
+                } else {
+                    std::vector<void*> pl((size_t)n), pr((size_t)n);
+                    for (int j = 0; j < n; ++j) { pl[(size_t)j] = (char*)wL + (first + j) * out_bytes; pr[(size_t)j] = (char*)wR + (first + j) * out_bytes; }
+                    req(emagls_batch_execute(c->batch));
+                    req(emagls_batch_get_filters(c->batch, pl.data(), pr.data()));
+                }
+                if (mean_dev) {
+                    emagls_plan_info info;
+                    req(emagls_plan_get_info(p0, &info));
+                    *mean_dev = info.mean_grid_dev_deg;
+                }
+            } catch (...) { c->release(); throw; }
+            first += n;
+        }
+    });
 }
 
 int emagls_binaural_decode(const double* in, int64_t nsamp, int64_t nch, const double* wL, const double* wR, int64_t len,

@@ -341,6 +341,13 @@ int emagls_batch_shares_geometry(emagls_batch* batch, int* shared);
 int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, int64_t nsets,
                             const double* hrir_azi, const double* hrir_zen, double mic_radius, const double* mic_azi, const double* mic_zen,
                             int64_t nmics, int order, double fs, int64_t len, int basis, void* wL, void* wR);
+/* The HRTF subjects of ONE ATF set in one call (BASELINE config 5: the loop over subjects around
+ * lib/getEMagLsFiltersFromAtf.m:1): hL, hR [nsamp x ndirs x nsets], the other arguments as emagls_get_emagls_filters_from_atf;
+ * wL, wR [filter_len x nmics x nsets].  The ATF set is uploaded once and its side (spectra, matching, per-bin factors) computed
+ * once per batch of up to 16 subjects; one resident sweep launch per batch.  The same filters as nsets single calls. */
+int emagls_from_atf_hrir_sets(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, int64_t nsets, const double* hrir_azi,
+                              const double* hrir_zen, const double* atf_irs, int64_t atf_taps, int64_t nmics, int64_t natf, const double* atf_azi,
+                              const double* atf_zen, double fs, int64_t filter_len, double f_trans, double* wL, double* wR, double* mean_dev);
 /* A batch may also hold EMAGLS_KIND_FROM_ATF plans of one shape -- the HRTF subjects of one ATF set (BASELINE config 5: 8 subjects).
  * lib/getEMagLsFiltersFromAtf.m:54-95,100-104: the spectra of the matched ATFs and their per-bin factors do not depend on the
  * HRIRs.  When all plans hold the same grids and the same ATF set (compared on the device whenever one of them was replaced) the

@@ -70,6 +70,7 @@ void at_exit() { emagls_cache_clear(); }
 // emagls_mex('magls_dc' | 'emagls_dc' | 'emagls2_dc', <the arguments of 'magls' / 'emagls' / 'emagls2'>, applyDiffusenessConst)
 // emagls_mex('decode',  in, wL, wR, compensateDelay)            real or complex in / filters; [out, imagAbsSum] = ...
 // emagls_mex('sets', kind, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition)   3-D hL / hR: a loop over HRIR sets in one call
+// emagls_mex('fromatfsets', hL, hR, hrirGridAziZen, atfIrs, atfGridAziZen, fs, filterLen, fTrans)      3-D hL / hR: the subjects of one ATF set
 // caller-evaluated shFunction handles (the wrappers evaluate them at emagls_mex('simorder', kind, order, fs, micRadius)):
 // emagls_mex('ls_y', hL, hR, Yhrir, order, shDefinition)        emagls_mex('magls_y', hL, hR, Yhrir, order, fs, len, shDefinition)
 // emagls_mex('emagls_y' | 'emagls2_y', hL, hR, Yhrir, micRadius, Ymic, order, fs, len, shDefinition)
@@ -152,6 +153,31 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                                                out_ptr(plhs[0]), out_ptr(wR));
         if (nlhs > 1) plhs[1] = wR; else mxDestroyArray(wR);
         if (rc) fail(rc);
+        return;
+    }
+    if (c == "fromatfsets") {
+        // [wL, wR] = emagls_mex('fromatfsets', hL, hR, hrirGridAziZenRad, atfIrs, atfGridAziZenRad, fs, filterLen, fTrans)
+        // hL, hR [numSamples x numDirections x numSubjects]: lib/getEMagLsFiltersFromAtf.m:1 in a loop over subjects, one call
+        if (nrhs < 9) mexErrMsgIdAndTxt("eMagLS:arg", "not enough input arguments");
+        const double* hL = dbl(prhs[1], "hL");
+        const double* hR = dbl(prhs[2], "hR");
+        const mwSize* hd = mxGetDimensions(prhs[1]);
+        const mwSize nsamp = hd[0], ndirs = hd[1], nsets = mxGetNumberOfDimensions(prhs[1]) > 2 ? hd[2] : 1;
+        if (mxGetNumberOfElements(prhs[2]) != mxGetNumberOfElements(prhs[1])) mexErrMsgIdAndTxt("eMagLS:arg", "hL and hR must have the same size");
+        const double* hg = dbl(prhs[3], "hrirGridAziZenRad");
+        const mwSize* ad = mxGetDimensions(prhs[4]);
+        const mwSize taps = ad[0], mics = ad[1], natf = mxGetNumberOfDimensions(prhs[4]) > 2 ? ad[2] : 1;
+        const double* ag = dbl(prhs[5], "atfGridAziZenRad");
+        const mwSize len = (mwSize)mxGetScalar(prhs[7]);
+        const mwSize od[3] = {len, mics, nsets};
+        plhs[0] = mxCreateNumericArray(3, od, mxDOUBLE_CLASS, mxREAL);
+        mxArray* wR = mxCreateNumericArray(3, od, mxDOUBLE_CLASS, mxREAL);
+        double dev = 0.0;
+        const int rc = emagls_from_atf_hrir_sets(hL, hR, nsamp, ndirs, nsets, hg, hg + ndirs, dbl(prhs[4], "atfIrs"), taps, mics, natf, ag, ag + natf,
+                                                 mxGetScalar(prhs[6]), len, mxGetScalar(prhs[8]), mxGetDoubles(plhs[0]), mxGetDoubles(wR), &dev);
+        if (nlhs > 1) plhs[1] = wR; else mxDestroyArray(wR);
+        if (rc) fail(rc);
+        mexPrintf("Matching HRTF and ATF grids, average grid deviation: %g deg\n", dev);  // FromAtf.m:96
         return;
     }
     if (c == "simorder") {   // kind: 'emagls' | 'emagls2'

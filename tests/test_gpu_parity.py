@@ -574,6 +574,31 @@ def test_design_hrir_sets_in_one_call(grids, thin, kind):
     assert rel(wL[:, :, 0], wL[:, :, 9]) > 1e-3
 
 
+def test_from_atf_subjects_in_one_call(thin):
+    """emagls_from_atf_hrir_sets: the HRTF subjects of one ATF set as ONE call (BASELINE config 5's job list): the ATF set goes to
+    the GPU once, its side is computed once per batch; 5 subjects equal their single calls, twice (the second call reuses the
+    cached plans)."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    rng = np.random.default_rng(61)
+    azi, zen = thin["azi"], thin["zen"]
+    hL = np.stack([thin["hL"] * (1 + 0.04 * j) + 1e-3 * rng.standard_normal(thin["hL"].shape) for j in range(5)], axis=2)
+    hR = np.stack([thin["hR"] * (1 - 0.03 * j) for j in range(5)], axis=2)
+    atf, aazi, azen = synth.glasses_atfs(natf=700, nmics=6, taps=64)
+    hg, ag = np.column_stack([azi, zen]), np.column_stack([aazi + 0.01, azen])
+    for rep in range(2):
+        wL, wR, dev = E.fromAtfHrirSets(hL, hR, hg, atf, ag, 48000.0, 128, 2000.0)
+        assert wL.shape == (128, 6, 5)
+        worst = 0.0
+        for j in (0, 2, 4):
+            sL, sR = E.getEMagLsFiltersFromAtf(hL[:, :, j], hR[:, :, j], hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)
+            worst = max(worst, rel(wL[:, :, j], sL), rel(wR[:, :, j], sR))
+        assert 0.0 < dev < 20.0       # mean grid deviation in degrees (lib/getEMagLsFiltersFromAtf.m:96)
+        print(f"5 FromAtf subjects in one call (pass {rep}): worst rel vs single calls = {worst:.3e}")
+        assert worst < 1e-11
+    assert rel(wL[:, :, 0], wL[:, :, 3]) > 1e-3
+
+
 def test_geometry_sharing_with_twelve_hrir_sets_and_kinds_without_the_option(grids, thin):
     """9-16 HRIR sets share one sweep launch (twin workgroups) on plan 0's operands; a kind without the option (EMAinSH) accepts the switch
     and runs as before."""

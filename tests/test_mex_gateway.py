@@ -148,6 +148,10 @@ def test_gateway_design_calls_match_the_python_binding(mex, grids, thin):
     assert sL.shape == (128, 32, 5) and not np.iscomplexobj(sL)
     eL, eR = E.getEMagLs2Filters(h3L[:, :, 3], h3R[:, :, 3], azi, zen, grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "real")
     assert np.array_equal(sL[:, :, 3], eL) and np.array_equal(sR[:, :, 3], eR)
+    aL, aR = mex(2, "fromatfsets", h3L, h3R, hg, atf, ag, 48000.0, 128, 2000.0)
+    assert aL.shape == (128, 5, 5)
+    eL, eR = E.getEMagLsFiltersFromAtf(h3L[:, :, 2], h3R[:, :, 2], hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)[:2]
+    assert np.array_equal(aL[:, :, 2], eL) and np.array_equal(aR[:, :, 2], eR)
     with pytest.raises(mex.Error, match="unknown design kind"):
         mex(2, "sets", "fromatf", h3L, h3R, azi, zen, empty, empty, empty, 3, 48000.0, 128, "real")
     rng = np.random.default_rng(3)
