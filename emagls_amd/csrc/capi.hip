@@ -3240,7 +3240,7 @@ struct SetsCache {
     }
 };
 std::mutex g_sets_mu;
-SetsCache g_sets[2];   // (a job list is chunks of one size plus one tail chunk)
+SetsCache g_sets[3];   // (two sets of plans for the full chunks, which alternate, and one for the tail chunk)
 }  // namespace
 void emagls_sets_cache_clear_internal() {
     std::lock_guard<std::mutex> lk(g_sets_mu);
@@ -3250,8 +3250,7 @@ void emagls_sets_cache_clear_internal() {
 int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, int64_t nsets,
                             const double* hrir_azi, const double* hrir_zen, double mic_radius, const double* mic_azi, const double* mic_zen,
                             int64_t nmics, int order, double fs, int64_t len, int basis, void* wL, void* wR) {
-    int rc_all = EMAGLS_OK;
-    const int rc = guarded([&] {
+    return guarded([&] {
         if (!hL || !hR || !hrir_azi || !wL || !wR || nsets < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
         const bool arr = kind == EMAGLS_KIND_EMAGLS || kind == EMAGLS_KIND_EMAGLS2 || kind == EMAGLS_KIND_EMA_CH;
         if (!arr && kind != EMAGLS_KIND_LS && kind != EMAGLS_KIND_MAGLS && kind != EMAGLS_KIND_MAGLS_2D)
@@ -3263,29 +3262,49 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lk(g_sets_mu);
+        // Full chunks alternate between two plan sets: while one computes, the next chunk's HRIRs are uploaded into the other
+        // (5.5 MB per set from pageable memory: as long as the chunk's compute).  The tail chunk has a set of its own.
+        struct Pending { SetsCache* c = nullptr; int64_t first = 0; };
+        Pending pend[3];
         size_t out_bytes = 0;
-        for (int64_t first = 0; first < nsets;) {
-            const int n = (int)std::min<int64_t>(SWEEP_MULTI_MAX, nsets - first);
-            SetsCache* c = &g_sets[n == SWEEP_MULTI_MAX ? 0 : 1];   // slot 0: full chunks, slot 1: the tail chunk
-            if (!(c->n == n && c->device == dev && same_desc(c->desc, d))) {
-                c->release();
-                try {
-                    for (int j = 0; j < n; ++j) {
-                        emagls_plan* p = nullptr;
-                        req(emagls_plan_create(&d, &p));
-                        c->plans.push_back(p);
-                    }
-                    if (n > 1) {
-                        g_batch_max_override = SWEEP_MULTI_MAX;
-                        const int r = emagls_batch_create(c->plans.data(), n, &c->batch);
-                        g_batch_max_override = 0;
-                        req(r);
-                        req(emagls_batch_set_geometry_sharing(c->batch, 1));
-                    }
-                } catch (...) { g_batch_max_override = 0; c->release(); throw; }
-                c->desc = d; c->device = dev; c->n = n;
+        auto collect = [&](Pending& q) {
+            if (!q.c) return;
+            SetsCache* c = q.c;
+            q.c = nullptr;
+            const int n = c->n;
+            if (n == 1) {
+                req(emagls_plan_get_filters(c->plans[0], (char*)wL + q.first * out_bytes, (char*)wR + q.first * out_bytes));
+            } else {
+                std::vector<void*> pl((size_t)n), pr((size_t)n);
+                for (int j = 0; j < n; ++j) { pl[(size_t)j] = (char*)wL + (q.first + j) * out_bytes; pr[(size_t)j] = (char*)wR + (q.first + j) * out_bytes; }
+                req(emagls_batch_get_filters(c->batch, pl.data(), pr.data()));
             }
-            try {
+        };
+        try {
+            int64_t k = 0;
+            for (int64_t first = 0; first < nsets; ++k) {
+                const int n = (int)std::min<int64_t>(SWEEP_MULTI_MAX, nsets - first);
+                const int slot = n == SWEEP_MULTI_MAX ? (int)(k % 2) : 2;
+                SetsCache* c = &g_sets[slot];
+                collect(pend[slot]);      // (the chunk this plan set computed two chunks ago)
+                if (!(c->n == n && c->device == dev && same_desc(c->desc, d))) {
+                    c->release();
+                    try {
+                        for (int j = 0; j < n; ++j) {
+                            emagls_plan* p = nullptr;
+                            req(emagls_plan_create(&d, &p));
+                            c->plans.push_back(p);
+                        }
+                        if (n > 1) {
+                            g_batch_max_override = SWEEP_MULTI_MAX;
+                            const int r = emagls_batch_create(c->plans.data(), n, &c->batch);
+                            g_batch_max_override = 0;
+                            req(r);
+                            req(emagls_batch_set_geometry_sharing(c->batch, 1));
+                        }
+                    } catch (...) { g_batch_max_override = 0; c->release(); throw; }
+                    c->desc = d; c->device = dev; c->n = n;
+                }
                 auto same = [](const std::vector<double>& have, const double* now, size_t cnt) {
                     return now ? (have.size() == cnt && std::memcmp(have.data(), now, cnt * sizeof(double)) == 0) : have.empty();
                 };
@@ -3303,21 +3322,17 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
                 emagls_plan_info info;
                 req(emagls_plan_get_info(c->plans[0], &info));
                 out_bytes = (info.out_is_complex ? sizeof(cplx) : sizeof(double)) * (size_t)info.out_rows * info.out_cols;
-                if (n == 1) {
-                    req(emagls_plan_execute(c->plans[0]));
-                    req(emagls_plan_get_filters(c->plans[0], (char*)wL + first * out_bytes, (char*)wR + first * out_bytes));
-                } else {
-                    std::vector<void*> pl((size_t)n), pr((size_t)n);
-                    for (int j = 0; j < n; ++j) { pl[(size_t)j] = (char*)wL + (first + j) * out_bytes; pr[(size_t)j] = (char*)wR + (first + j) * out_bytes; }
-                    req(emagls_batch_execute(c->batch));
-                    req(emagls_batch_get_filters(c->batch, pl.data(), pr.data()));
-                }
-            } catch (...) { c->release(); throw; }   // (a failed call leaves the plans in an unknown state)
-            first += n;
+                if (n == 1) req(emagls_plan_execute(c->plans[0])); else req(emagls_batch_execute(c->batch));   // (asynchronous)
+                pend[slot].c = c;
+                pend[slot].first = first;
+                first += n;
+            }
+            for (auto& q : pend) collect(q);
+        } catch (...) {   // (a failed call leaves the plans in an unknown state)
+            for (auto& c : g_sets) c.release();
+            throw;
         }
     });
-    (void)rc_all;
-    return rc;
 }
 
 // The HRTF subjects of ONE ATF set in one call (BASELINE config 5; lib/getEMagLsFiltersFromAtf.m:1 in a loop over subjects).  The
