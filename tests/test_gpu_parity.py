@@ -574,6 +574,25 @@ def test_design_hrir_sets_in_one_call(grids, thin, kind):
     assert rel(wL[:, :, 0], wL[:, :, 9]) > 1e-3
 
 
+def test_design_hrir_sets_alternating_plan_sets(thin):
+    """40 sets = two full chunks (which alternate between two sets of plans, the second chunk's upload overlapping the first
+    chunk's compute) and a tail of 8: every chunk lands in its place."""
+    import emagls_amd as E
+    rng = np.random.default_rng(52)
+    nsets = 40
+    hL = np.stack([thin["hL"] * (1 + 0.01 * j) + 1e-3 * rng.standard_normal(thin["hL"].shape) for j in range(nsets)], axis=2)
+    hR = np.stack([thin["hR"] * (1 - 0.01 * j) for j in range(nsets)], axis=2)
+    for rep in range(2):
+        wL, wR = E.designHrirSets("magls", hL, hR, thin["azi"], thin["zen"], order=3, fs=48000.0, len=128, shDefinition="real")
+        worst = 0.0
+        for j in (0, 15, 16, 31, 32, 39):
+            sL, sR = E.getMagLsFilters(hL[:, :, j], hR[:, :, j], thin["azi"], thin["zen"], 3, 48000.0, 128, "real")
+            worst = max(worst, rel(wL[:, :, j], sL), rel(wR[:, :, j], sR))
+        print(f"40 HRIR sets in one call (pass {rep}): worst rel vs single calls = {worst:.3e}")
+        assert worst < 1e-12
+    assert rel(wL[:, :, 3], wL[:, :, 30]) > 1e-3
+
+
 def test_from_atf_subjects_in_one_call(thin):
     """emagls_from_atf_hrir_sets: the HRTF subjects of one ATF set as ONE call (BASELINE config 5's job list): the ATF set goes to
     the GPU once, its side is computed once per batch; 5 subjects equal their single calls, twice (the second call reuses the
