@@ -102,6 +102,10 @@ def schedule(n_designs, bsz=BSZ):
     full, tail = divmod(int(n_designs), bsz)
     if os.environ.get("EMAGLS_BENCH_TAIL_LAST"):
         return [bsz] * full + ([tail] if tail else [])
+    split = int(os.environ.get("EMAGLS_BENCH_SPLIT", "0"))
+    if split and tail and full and 0 < split < bsz + tail and bsz + tail - split <= bsz:
+        # (experiment) the partial batch and one full batch re-divided: `split` designs first, the rest last
+        return [split] + [bsz] * (full - 1) + [bsz + tail - split]
     return ([tail] if tail else []) + [bsz] * full
 
 
@@ -370,13 +374,14 @@ def main():
             for p in self.plans:
                 p.close()
 
-    tails = {}
+    tails = {}      # size -> the batch objects of that size (as many as one schedule holds)
     for n_designs in (K, W):
-        t = n_designs % Bsz
-        if t and t not in tails:
-            tails[t] = Unit(t, rank * 1000 + 500 + t)
+        sizes = [t for t in schedule(n_designs, Bsz) if t != Bsz]
+        for t in set(sizes):
+            while len(tails.setdefault(t, [])) < sizes.count(t):
+                tails[t].append(Unit(t, rank * 1000 + 500 + t + 40 * len(tails[t])))
     units = [Unit(Bsz, rank * 1000 + b * Bsz) for b in range(nslots)]
-    for u in units + list(tails.values()):   # eager run, hipGraph capture, first replay
+    for u in units + [v for vs in tails.values() for v in vs]:   # eager run, hipGraph capture, first replay
         for _ in range(3):
             u.execute()
         u.wait()
@@ -411,7 +416,7 @@ def main():
                         break
                     u = free.pop(0)
                 else:
-                    u = tails[size]   # (the partial batch at the end of the schedule)
+                    u = tails[size].pop(0)   # (a partial batch of the schedule)
                 launch.append(u)
                 inflight.append((u, first))
                 first += size
@@ -426,8 +431,7 @@ def main():
             dst, base = (out, f0) if store else (scratch, 0)
             u.collect([dst[base + j, 0].data_ptr() for j in range(u.size)], [dst[base + j, 1].data_ptr() for j in range(u.size)])
             done += u.size
-            if u.size == Bsz:
-                free.append(u)
+            (free if u.size == Bsz else tails[u.size]).append(u)
         assert done == n_designs
 
     # ---- W warm-up designs, untimed (also warms the collective)
@@ -451,7 +455,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     # duration of the dominant kernel's launches inside the timed region (the last execute of every full batch)
-    batch_sweep_ms = [u.batch.sweep_time_ms() for u in units[:min(nslots, K // Bsz)] if u.batch is not None]
+    n_full = schedule(K, Bsz).count(Bsz)
+    batch_sweep_ms = [u.batch.sweep_time_ms() for u in units[:min(nslots, n_full)] if u.batch is not None]
 
     if rank == 0:
         D, Cc = inputs[4].shape[1], info.num_channels
@@ -533,7 +538,7 @@ def main():
                                    "48 kHz; one filter set per step, inputs resident in HBM",
                        "dirs": int(D), "taps": 512, "sim_order": info.sim_order, "bins": info.num_pos_freqs - 1,
                        "k_cut": info.k_cut, "designs_resident_per_gpu": nslots * Bsz, "designs_per_batch": Bsz,
-                       "batches_in_flight": nslots, "streams_per_batch": args.fork, "timed_schedule": "%d full batches of %d + tail %d" % (K // Bsz, Bsz, K % Bsz),
+                       "batches_in_flight": nslots, "streams_per_batch": args.fork, "timed_schedule": "batches of %s designs" % schedule(K, Bsz),
                        "setup": "each resident batch executed 3x (eager, hipGraph capture, replay) before the warm-up",
                        "parallelism": "independent jobs per GPU, one RCCL gather"},
             "roofline": roof,
@@ -550,7 +555,7 @@ def main():
             except Exception as e:  # the large launch needs ~3.5 GB; never fail the bench on it
                 res["sh_basis_roofline"] = {"error": str(e)}
         if not args.no_secondary and world == 1:
-            for u in units + list(tails.values()):
+            for u in units + [v for vs in tails.values() for v in vs]:
                 u.close()
             units, tails = [], {}
             try:
@@ -568,7 +573,7 @@ def main():
             res["parity"] = parity_check()
         print(json.dumps(res))
         sys.stdout.flush()
-    for u in units + list(tails.values()):
+    for u in units + [v for vs in tails.values() for v in vs]:
         u.close()
     if use_pg:
         dist.destroy_process_group()
