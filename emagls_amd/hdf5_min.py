@@ -26,6 +26,25 @@ class Hdf5Error(ValueError):
     pass
 
 
+def _guarded(fn):
+    """A damaged or truncated file surfaces as Hdf5Error from the public entry points, whatever the parser tripped over
+    (a field that points outside the file, a short read, an undecodable deflate stream, a type it cannot build); KeyError
+    stays the answer to a name that does not exist."""
+    import functools
+    import struct
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except (Hdf5Error, KeyError):
+            raise
+        except (IndexError, TypeError, AttributeError, ValueError, OverflowError, MemoryError, RecursionError,
+                struct.error, zlib.error) as e:
+            raise Hdf5Error("damaged or truncated HDF5 file (%s: %s)" % (type(e).__name__, e)) from e
+    return wrapped
+
+
 def _uint(buf, pos, n):
     return int.from_bytes(buf[pos:pos + n], "little")
 
@@ -503,6 +522,7 @@ class _Object:
         self._attrs = None
 
     @property
+    @_guarded
     def attrs(self):
         if self._attrs is None:
             r = self._r
@@ -550,6 +570,7 @@ class Dataset(_Object):
                 self._filters = self._parse_filters(p)
 
     @property
+    @_guarded
     def dtype(self):
         return self._type.dtype
 
@@ -594,6 +615,7 @@ class Dataset(_Object):
                 raise Hdf5Error("filter %d (dataset '%s') is not supported" % (fid, self.name))
         return raw
 
+    @_guarded
     def read(self):
         """The whole dataset as an ndarray in the file's (C order) dimension order; strings as object arrays of str."""
         r, b, t = self._r, self._r.b, self._type
@@ -785,14 +807,17 @@ class Group(_Object):
                             links[k] = a
         self._links = links
 
+    @_guarded
     def keys(self):
         self._load()
         return list(self._links)
 
+    @_guarded
     def __contains__(self, name):
         self._load()
         return name in self._links
 
+    @_guarded
     def __getitem__(self, name):
         self._load()
         node = self
@@ -817,6 +842,7 @@ def _open_object(r, addr, name):
 class File(Group):
     """hdf5_min.File(path)['Data.IR'].read(); .keys(), .attrs, nested groups by 'a/b' paths."""
 
+    @_guarded
     def __init__(self, path):
         with open(path, "rb") as f:
             data = f.read()
@@ -847,6 +873,7 @@ class File(Group):
         self.path = path
         super().__init__(r, root, "/")
 
+    @_guarded
     def deref(self, ref):
         """The object an 8-byte object reference (MAT v7.3 cell / struct arrays) points to."""
         return _open_object(self._r, int(ref) + self._r.base, "<ref>")

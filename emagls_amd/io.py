@@ -11,6 +11,9 @@ directly (emagls_amd/hdf5_min.py, a plain-Python HDF5 reader: the image has no H
 (-v7 through scipy, -v7.3 through the same HDF5 reader) that hold the five fields as plain arrays or one struct, and .npz.
 A -v7 file that holds the MIRO instance itself goes through emagls_amd/mcos.py, a decoder of MATLAB's undocumented object
 storage that could only be tried on constructed files here (its docstring says so): prefer the SOFA file.
+Damaged files: the HDF5 reader refuses them with Hdf5Error (a ValueError; tests/test_io.py damages the committed files 240 ways);
+-v7 MAT files are parsed by scipy, whose compiled reader can crash the process on a damaged object file (600 damaged copies of
+a constructed MIRO file: a segmentation fault inside scipy.io.matlab._mio5 among them) -- do not feed it files from strangers.
 The plain-array export from MATLAB, where that is the handier route:
 
     load HRIR_L2702.mat; s = struct('irChOne', HRIR_L2702.irChOne, 'irChTwo', HRIR_L2702.irChTwo, 'azimuth', HRIR_L2702.azimuth, ...

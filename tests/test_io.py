@@ -216,3 +216,39 @@ def test_load_hrir_set_from_a_classdef_object(tmp_path):
     (tmp_path / "broken.mat").write_bytes(bytes(raw))
     with pytest.raises(Exception):
         IO.load_hrir_set(str(tmp_path / "broken.mat"))
+
+
+@pytest.mark.parametrize("name", ["hrir_small.sofa", "hrir_small_v73.mat"])
+def test_damaged_hdf5_containers_fail_with_a_value_error(tmp_path, name):
+    """A truncated or bit-damaged SOFA / -v7.3 file either still loads (the damage missed every structure the loader walks) or
+    is refused with a ValueError (hdf5_min.Hdf5Error is one): no IndexError / struct.error / zlib.error from inside the parser,
+    no endless walk (every case finishes in well under a second)."""
+    import random
+    import time
+    raw = open(os.path.join(GOLD, name), "rb").read()
+    rng = random.Random(20250311)
+    ext = os.path.splitext(name)[1]
+    outcomes = {"loaded": 0, "refused": 0}
+    worst = 0.0
+    for trial in range(120):
+        b = bytearray(raw)
+        if trial % 3 == 0:
+            for _ in range(rng.randint(1, 8)):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+        elif trial % 3 == 1:
+            b = b[:rng.randrange(16, len(b))]
+        else:
+            p = rng.randrange(len(b) - 64)
+            b[p:p + 8] = b"\xff" * 8          # (the "undefined address" of every offset field)
+        path = tmp_path / ("damaged%d%s" % (trial, ext))
+        path.write_bytes(bytes(b))
+        t0 = time.perf_counter()
+        try:
+            IO.load_hrir_set(str(path))
+            outcomes["loaded"] += 1
+        except ValueError:
+            outcomes["refused"] += 1
+        worst = max(worst, time.perf_counter() - t0)
+        path.unlink()
+    print(name, outcomes, "slowest case %.3f s" % worst)
+    assert outcomes["refused"] >= 20 and worst < 5.0
