@@ -121,6 +121,11 @@ constexpr int PS_MLD = 36;  // row stride of M in LDS (16 dwords mod 64)
 // (tried: amdgpu_waves_per_eu(3) / (4), i.e. 168 / 128 instead of ~200 VGPRs, so that kernels of other batches with up to four
 // waves per SIMD fit next to a twin workgroup: 21-40 / 160-179 spilled registers on the chain, 5.6 instead of 4.4 us per bin with
 // 8 designs and 8.2 instead of 6.1 with 16 -- 1455 sets/s at 20 steps, 1900 in long runs, 3100 for HRIR-set batches: rejected)
+// (tried at the end of round 3: W(kb-1,:) = v conj(M) formed by the communication wave itself right after hop 2 -- 2 C lanes, one
+// output each, four independent chains of C / 4 complex multiply-adds from LDS, `ms` published by an LDS arrival counter --
+// so that the M phase and the barrier B2 go away: bit-identical filters, 2.35 against 2.07 ms per 8-design sweep and 3.35
+// against 2.99 ms per 16-design sweep, i.e. +0.6 us per bin.  One wave issues the 2 x 28 LDS reads and 112 FP64 FMAs that the
+// M phase spreads over four SIMDs, and that costs more than the two barriers it saves: rejected)
 template <int PS_DPW, int NI, int NH>
 __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMulti m, int nWG) {
     constexpr int NTT = PS_NT * NH;     // threads of the workgroup
