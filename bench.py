@@ -103,7 +103,7 @@ def schedule(n_designs, bsz=BSZ):
     if os.environ.get("EMAGLS_BENCH_TAIL_LAST"):
         return [bsz] * full + ([tail] if tail else [])
     split = int(os.environ.get("EMAGLS_BENCH_SPLIT", "0"))
-    if split and tail and full and 0 < split < bsz + tail and bsz + tail - split <= bsz:
+    if split and tail and full and 0 < split <= bsz and 0 < bsz + tail - split <= bsz:
         # (experiment) the partial batch and one full batch re-divided: `split` designs first, the rest last
         return [split] + [bsz] * (full - 1) + [bsz + tail - split]
     return ([tail] if tail else []) + [bsz] * full

@@ -26,6 +26,21 @@ def test_schedule_processes_exactly_the_requested_designs():
     assert sch(20) == [4, 16] and sch(128) == [16] * 8 and sch(5, 8) == [5] and sch(20, 8) == [4, 8, 8]
 
 
+def test_schedule_split_experiment_keeps_the_design_count(monkeypatch):
+    """EMAGLS_BENCH_SPLIT (an experiment knob: the partial batch and one full batch re-divided) never changes how many designs
+    a timed region holds, and values that do not fit fall back to the default division."""
+    b = _bench()
+    for split in (1, 8, 10, 12, 16, 19, 40):
+        monkeypatch.setenv("EMAGLS_BENCH_SPLIT", str(split))
+        for k in (5, 16, 20, 36, 37, 128):
+            s = b.schedule(k)
+            assert sum(s) == k and all(1 <= x <= 16 for x in s)
+    monkeypatch.setenv("EMAGLS_BENCH_SPLIT", "12")
+    assert b.schedule(20) == [12, 8] and b.schedule(36) == [12, 16, 8] and b.schedule(128) == [16] * 8
+    monkeypatch.setenv("EMAGLS_BENCH_SPLIT", "2")     # (the rest would be 18 > 16 designs: default division)
+    assert b.schedule(20) == [4, 16]
+
+
 def test_gpus_flag_spawns_fresh_ranks(tmp_path):
     """`bench.py --gpus N` without WORLD_SIZE starts N children with the torch.distributed environment (gloo here: the
     children rendezvous on 127.0.0.1 and all-reduce their ranks), before the parent imports torch or touches HIP."""
