@@ -94,6 +94,12 @@ def _loadmat(path):
         return sio.loadmat(path, squeeze_me=False, struct_as_record=False)
     except NotImplementedError:            # MAT v7.3 is HDF5
         return _loadmat73(path)
+    except FileNotFoundError:
+        raise
+    except ValueError:
+        raise
+    except Exception as e:                 # what scipy's reader raises on a damaged file: OSError, TypeError, UnboundLocalError ...
+        raise ValueError("%s could not be read as a MAT file (%s: %s)" % (path, type(e).__name__, e)) from e
 
 
 def load_fixture(path):
@@ -149,9 +155,9 @@ def _mat_objects(raw, path):
         return None
     try:
         objs = mcos.object_properties(raw)
-    except mcos.McosError as e:
-        raise ValueError("%s holds a MATLAB object that could not be decoded (%s); use the set's .sofa file or export the "
-                         "fields as plain arrays (see the module docstring of emagls_amd.io)" % (path, e)) from e
+    except Exception as e:   # McosError, or whatever scipy / the decoder tripped over in a damaged subsystem element
+        raise ValueError("%s holds a MATLAB object that could not be decoded (%s: %s); use the set's .sofa file or export the "
+                         "fields as plain arrays (see the module docstring of emagls_amd.io)" % (path, type(e).__name__, e)) from e
     for var, (cls, props) in objs.items():
         if all(f in props for f in _HRIR_FIELDS[:2]):
             return props
