@@ -341,6 +341,8 @@ def main():
     # ---- SETUP: the resident configuration (independent of --steps): nslots batches of Bsz designs, plus one smaller batch
     # object per distinct tail size of the warm-up and the timed schedule
     class Unit:
+        count = 0
+
         def __init__(self, size, seed0):
             self.plans = [make_plan(seed0 + j)[0] for j in range(size)]
             self.batch = Batch(self.plans) if size > 1 else None
@@ -351,6 +353,12 @@ def main():
                     self.batch.set_stream(st.cuda_stream)
                 if args.fork > 1 and self.batch.lane_mode():
                     self.batch.set_streams(args.fork)
+                # batches of up to 8 designs that run side by side issue the stages before their sweeps in complementary
+                # orders (emagls_batch_set_stage_order; the two lane groups of a larger batch do so by themselves)
+                so = os.environ.get("EMAGLS_BENCH_STAGE_ORDER", "alt")
+                if size <= 8 and self.batch.lane_mode() and args.fork == 1 and so != "0":
+                    self.batch.set_stage_order(1 + Unit.count % 2 if so == "alt" else int(so))
+                Unit.count += 1
                 if size > 8:
                     st2 = next(next_side, None)
                     if st2 is not None:

@@ -135,6 +135,7 @@ SYMBOLS = {
     "emagls_batch_shares_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "emagls_batch_set_side_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "emagls_batch_set_streams": (C.c_int, [C.c_void_p, C.c_int]),
+    "emagls_batch_set_stage_order": (C.c_int, [C.c_void_p, C.c_int]),
     "emagls_batch_sweep_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "emagls_batch_destroy": (C.c_int, [C.c_void_p]),
 }

@@ -97,15 +97,48 @@ def shard_lane_batches(batches, world_size, cost=batch_cost):
     return [[batches[b] for b in sorted(s, key=lambda b: (costs[b], b))] for s in shards], load
 
 
+def _pg(group):
+    """(have a process group, rank, world size)"""
+    import torch.distributed as dist
+    have = dist.is_available() and dist.is_initialized()
+    return have, (dist.get_rank(group) if have else 0), (dist.get_world_size(group) if have else 1)
+
+
+def _collective_device(group, device=None):
+    import torch.distributed as dist
+    if device is not None:
+        return device
+    return "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+
+def _agree_or_raise(err, group, device=None):
+    """Every rank enters the gather or none does: the ranks agree on an error flag first (one 8-byte all-reduce).  A rank whose
+    share failed (an unsupported shape, out of memory) raises its own exception, the others a RuntimeError that names the
+    failing rank -- nobody is left waiting inside a collective."""
+    import torch
+    import torch.distributed as dist
+    have, rank, world = _pg(group)
+    if not have or world == 1:
+        if err is not None:
+            raise err
+        return
+    flag = torch.tensor([rank + 1 if err is not None else 0], dtype=torch.int64, device=_collective_device(group, device))
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if err is not None:
+        raise err
+    if int(flag.item()):
+        raise RuntimeError("rank %d failed in its share of the job list; no rank entered the gather" % (int(flag.item()) - 1))
+
+
 def _gather_on_rank0(local, shards, n, group, device):
-    """`local`: this rank's (wL, wR) list in the order of shards[rank]; one gather brings everything to rank 0 (the only
-    collective on the data path).  Returns the list in job order on rank 0, None elsewhere."""
+    """`local`: this rank's (wL, wR) list in the order of shards[rank] as host arrays (the results of a caller-supplied design
+    function); one gather brings everything to rank 0 (the only collective on the data path).  Returns the list in job order on
+    rank 0, None elsewhere.  (The job lists of this module that run on plans keep their filters on the device: `_Results`.)"""
     import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    if device is None:
-        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    device = _collective_device(group, device)
     # every rank needs the result shape even when it has no job: agree on it through one tiny collective
     meta = torch.zeros(4, dtype=torch.int64, device=device)
     if local:
@@ -140,14 +173,15 @@ def run_batch(jobs, design_fn, costs=None, group=None, device=None):
     """Run `design_fn(job) -> (wL, wR)` (equal shapes/dtypes for every job) for this rank's share of `jobs`
     and gather everything on rank 0.  Returns the list of (wL, wR) in job order on rank 0, None elsewhere.
     Works without an initialised process group (single process)."""
-    import torch.distributed as dist
-
-    have_pg = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if have_pg else 0
-    world = dist.get_world_size(group) if have_pg else 1
+    have_pg, rank, world = _pg(group)
     n = len(jobs)
     shards = shard_jobs(costs if costs is not None else np.ones(n), world)
-    local = [design_fn(jobs[j]) for j in shards[rank]]
+    local, err = [], None
+    try:
+        local = [design_fn(jobs[j]) for j in shards[rank]]
+    except Exception as e:   # (agreed on with the other ranks before anybody enters the gather)
+        err = e
+    _agree_or_raise(err, group, device)
     if world == 1:
         return local
     return _gather_on_rank0(local, shards, n, group, device)
@@ -157,20 +191,20 @@ def run_lane_batches(jobs, sim_orders, batch_fn, group=None, device=None, max_ba
     """The class-aware form of `run_batch` for shape-dependent jobs (a sweep over array radii): the jobs are cut into padded
     lane batches (`padded_lane_batches`), whole batches go to ranks (`shard_lane_batches`), and every rank calls
     `batch_fn([jobs of one batch], pad_order) -> [(wL, wR), ...]` for each of its batches.  One gather to rank 0."""
-    import torch.distributed as dist
-
-    have_pg = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if have_pg else 0
-    world = dist.get_world_size(group) if have_pg else 1
+    have_pg, rank, world = _pg(group)
     n = len(jobs)
     per_rank, _ = shard_lane_batches(padded_lane_batches(list(sim_orders), max_batch), world)
     shards = [[j for idx, _ in bl for j in idx] for bl in per_rank]
-    local = []
-    for idx, pad in per_rank[rank]:
-        res = batch_fn([jobs[j] for j in idx], pad)
-        if len(res) != len(idx):
-            raise ValueError("batch_fn must return one (wL, wR) per job of the batch")
-        local += list(res)
+    local, err = [], None
+    try:
+        for idx, pad in per_rank[rank]:
+            res = batch_fn([jobs[j] for j in idx], pad)
+            if len(res) != len(idx):
+                raise ValueError("batch_fn must return one (wL, wR) per job of the batch")
+            local += list(res)
+    except Exception as e:
+        err = e
+    _agree_or_raise(err, group, device)
     if world == 1:
         out = [None] * n
         for j, r in zip(shards[0], local):
@@ -180,42 +214,167 @@ def run_lane_batches(jobs, sim_orders, batch_fn, group=None, device=None, max_ba
 
 
 # --------------------------------------------------------------------------------------------
-# the two job lists BASELINE.json names, on the plan / batch API (one process per GPU)
+# job lists on the plan / batch API (one process per GPU): the filters stay where the gather wants them
 # --------------------------------------------------------------------------------------------
+class _Results:
+    """The finished filters of one rank, slot i = the i-th job of its share, in ONE buffer laid out for the gather:
+    [slots][ear][column][row] (the library's column-major len x channels matrices), complex as (re, im) pairs.  With RCCL the
+    buffer is a device tensor that the library writes device-to-device (emagls_batch_get_filters / emagls_plan_get_filters take
+    device addresses) and the gather reads directly -- no host round trip; with gloo, or without a process group, a host array."""
+
+    def __init__(self, nslots, on_device):
+        self.nslots, self.on_device, self.buf, self.shape = int(nslots), bool(on_device), None, None
+
+    def ensure(self, rows, cols, cplx):
+        if self.buf is not None:
+            if self.shape != (rows, cols, cplx):
+                raise ValueError("the jobs of one list must give filters of one shape")
+            return
+        self.shape = (int(rows), int(cols), bool(cplx))
+        dims = (max(self.nslots, 1), 2, int(cols), int(rows)) + ((2,) if cplx else ())
+        if self.on_device:
+            import torch
+            self.buf = torch.zeros(dims, dtype=torch.float64, device="cuda")
+        else:
+            self.buf = np.zeros(dims, dtype=np.float64)
+
+    def _addr(self, i, ear):
+        if self.on_device:
+            return self.buf[i, ear].data_ptr()
+        return self.buf[i, ear].ctypes.data
+
+    def ptrs(self, first, count):
+        return [self._addr(first + j, 0) for j in range(count)], [self._addr(first + j, 1) for j in range(count)]
+
+    @staticmethod
+    def unpack(block, cplx):
+        """[ear][column][row](re, im) of one job as a host array -> (wL, wR), len x channels like the single calls return."""
+        if cplx:
+            block = block[..., 0] + 1j * block[..., 1]
+        return np.asfortranarray(block[0].T), np.asfortranarray(block[1].T)
+
+
+def _execute_plans(plans, res, first, share_geometry=False):
+    """One chunk of a rank's share: a Batch when the library takes the plans as one (lane mode, shared sweep launch), plan by plan
+    when it refuses them as a batch (EMAGLS_ERR_UNSUPPORTED: designs with more than 32 channels run one at a time -- same
+    filters).  The filters go straight into `res` (slots first .. first + len(plans) - 1)."""
+    import ctypes as C
+    from . import Batch, _lib as L
+    info = plans[0].info()
+    res.ensure(info.out_rows, info.out_cols, info.out_is_complex)
+    pl, pr = res.ptrs(first, len(plans))
+    b = None
+    if len(plans) > 1:
+        try:
+            b = Batch(plans)
+        except L.EmaglsError as e:
+            if e.code != L.ERR_UNSUPPORTED:
+                raise
+    if b is not None:
+        try:
+            if share_geometry:
+                b.share_geometry(True)
+            b.execute()
+            b.get_filters_into(pl, pr)
+        finally:
+            b.close()
+        return
+    lib = L.load()
+    for p in plans:
+        p.execute()
+    for j, p in enumerate(plans):
+        L.check(lib.emagls_plan_get_filters(p._h, C.c_void_p(pl[j]), C.c_void_p(pr[j])))
+
+
+def _run_plan_jobs(n, chunks_per_rank, make_plans, group=None, share_geometry=False):
+    """The shared loop of the job lists below.  `chunks_per_rank[r]` = [(job indices, extra), ...] for rank r;
+    `make_plans(indices, extra)` returns the plans of one chunk with their inputs set.  Every rank runs its chunks, the ranks
+    agree that nobody failed, ONE gather of the device buffers brings the filters to rank 0.  Returns [(wL, wR), ...] in job
+    order on rank 0 (and in a single process), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    have_pg, rank, world = _pg(group)
+    on_device = have_pg and world > 1 and dist.get_backend(group) == "nccl"
+    shards = [[j for idx, _ in ch for j in idx] for ch in chunks_per_rank]
+    res = _Results(len(shards[rank]), on_device)
+    err, first = None, 0
+    try:
+        for idx, extra in chunks_per_rank[rank]:
+            plans = make_plans(idx, extra)
+            try:
+                _execute_plans(plans, res, first, share_geometry)
+            finally:
+                for p in plans:
+                    p.close()
+            first += len(idx)
+    except Exception as e:
+        err = e
+    _agree_or_raise(err, group)
+    if world == 1:
+        out = [None] * n
+        for i, j in enumerate(shards[0]):
+            out[j] = _Results.unpack(res.buf[i], res.shape[2])
+        return out
+    # the result shape, for ranks without a job
+    device = _collective_device(group)
+    meta = torch.tensor(list(res.shape) + [1] if res.shape else [0, 0, 0, 0], dtype=torch.int64, device=device)
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+    rows, cols, cplx = int(meta[0]), int(meta[1]), bool(meta[2])
+    nmax = max(len(s) for s in shards)
+    send = _Results(nmax, on_device)
+    send.ensure(rows, cols, cplx)
+    if res.buf is not None and len(shards[rank]):
+        if on_device:
+            send.buf[:len(shards[rank])].copy_(res.buf[:len(shards[rank])])
+        else:
+            send.buf[:len(shards[rank])] = res.buf[:len(shards[rank])]
+    buf = send.buf if on_device else torch.from_numpy(send.buf)
+    gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = [None] * n
+    for r, s in enumerate(shards):
+        g = gathered[r].cpu().numpy()   # (the one copy to the host, on rank 0)
+        for i, j in enumerate(s):
+            out[j] = _Results.unpack(g[i], cplx)
+    return out
+
+
+def _even_chunks(n, world, max_batch):
+    """Equal-shape jobs: longest-processing-time shares, each cut into chunks of at most max_batch."""
+    return [[(s[i:i + max_batch], None) for i in range(0, len(s), max_batch)] for s in shard_jobs(np.ones(n), world)]
+
+
 def emagls2_radius_sweep(hL, hR, hrirGridAziRad, hrirGridZenRad, radii, micGridAziRad, micGridZenRad, order, fs, length,
                          shDefinition="real", group=None, max_batch=8):
     """getEMagLs2Filters (lib/getEMagLs2Filters.m:1-2) for every array radius of `radii` (BASELINE config 4): padded lane batches,
     whole batches per rank, one gather.  Returns [(wMlsL, wMlsR), ...] in the order of `radii` on rank 0, None elsewhere."""
-    from . import Batch, Plan, _lib as L
+    from . import Plan, _lib as L
     hL = np.asfortranarray(hL, dtype=np.float64)
     hR = np.asfortranarray(hR, dtype=np.float64)
     radii = [float(r) for r in radii]
     so = [simulation_order(order, fs, r, raw=True) for r in radii]
     nmics = int(np.asarray(micGridAziRad).size)
+    _, _, world = _pg(group)
+    per_rank, _ = shard_lane_batches(padded_lane_batches(so, max_batch), world)
 
-    def batch_fn(rs, pad):
+    def make_plans(idx, pad):
         plans = []
         try:
-            for r in rs:
-                p = Plan(L.KIND_EMAGLS2, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], r, nmics,
-                         sim_order_pad=int(pad))
+            for j in idx:
+                p = Plan(L.KIND_EMAGLS2, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], radii[j], nmics,
+                         sim_order_pad=int(pad) if nmics <= 32 else 0)   # (no padding on the path of more than 32 microphones)
+                plans.append(p)
                 p.set_hrir_grid(hrirGridAziRad, hrirGridZenRad)
                 p.set_mic_grid(micGridAziRad, micGridZenRad)
                 p.set_hrirs(hL, hR)
-                plans.append(p)
-            if len(plans) == 1:
-                plans[0].execute()
-                return [plans[0].get_filters()]
-            b = Batch(plans)
-            try:
-                b.execute()
-                return b.get_filters()
-            finally:
-                b.close()
-        finally:
+        except Exception:
             for p in plans:
                 p.close()
-    return run_lane_batches(radii, so, batch_fn, group=group, max_batch=max_batch)
+            raise
+        return plans
+    return _run_plan_jobs(len(radii), per_rank, make_plans, group)
 
 
 def emagls_from_atf_subjects(subjects, hrirGridAziZenRad, atfIrs, atfGridAziZenRad, fs, filterLen, fTrans, group=None,
@@ -224,47 +383,31 @@ def emagls_from_atf_subjects(subjects, hrirGridAziZenRad, atfIrs, atfGridAziZenR
     ATF set and HRIR grid (BASELINE config 5): the subjects are spread over the ranks, each rank runs its share in batches
     that compute the ATF side once (Batch.shares_atf_side) and sweep all their subjects in one resident launch; one gather.
     Returns [(wMlsL, wMlsR), ...] in the order of `subjects` on rank 0, None elsewhere."""
-    import torch.distributed as dist
-    from . import Batch, Plan, _lib as L
+    from . import Plan, _lib as L
     hg = np.asarray(hrirGridAziZenRad, dtype=np.float64)
     ag = np.asarray(atfGridAziZenRad, dtype=np.float64)
     atf = np.asfortranarray(atfIrs, dtype=np.float64)
     taps, M, Da = atf.shape
-    have_pg = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if have_pg else 0
-    world = dist.get_world_size(group) if have_pg else 1
-    n = len(subjects)
-    shards = shard_jobs(np.ones(n), world)
-    local = []
-    mine = shards[rank]
-    for i in range(0, len(mine), max_batch):
+    _, _, world = _pg(group)
+
+    def make_plans(idx, _):
         plans = []
         try:
-            for j in mine[i:i + max_batch]:
+            for j in idx:
                 hL = np.asfortranarray(subjects[j][0], dtype=np.float64)
                 hR = np.asfortranarray(subjects[j][1], dtype=np.float64)
                 p = Plan(L.KIND_FROM_ATF, "real", 0, float(fs), int(filterLen), hL.shape[0], hL.shape[1], nmics=M, f_trans=float(fTrans),
                          atf_taps=taps, natf=Da)
+                plans.append(p)
                 p.set_hrir_grid(hg[:, 0], hg[:, 1])
                 p.set_hrirs(hL, hR)
                 p.set_atfs(atf, ag[:, 0], ag[:, 1])
-                plans.append(p)
-            if len(plans) == 1:
-                plans[0].execute()
-                local.append(plans[0].get_filters())
-            else:
-                b = Batch(plans)
-                try:
-                    b.execute()
-                    local += b.get_filters()
-                finally:
-                    b.close()
-        finally:
+        except Exception:
             for p in plans:
                 p.close()
-    if world == 1:
-        return local
-    return _gather_on_rank0(local, shards, n, group, None)
+            raise
+        return plans
+    return _run_plan_jobs(len(subjects), _even_chunks(len(subjects), world, max_batch), make_plans, group)
 
 
 def emagls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, micGridZenRad, order, fs, length,
@@ -273,93 +416,60 @@ def emagls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, micRadius, micGri
     micGridZenRad None) for every HRIR set of `subjects` = [(hL, hR), ...] on ONE HRIR grid and ONE array: the loop over
     subjects a user of the reference writes around the call.  The sets are spread over the ranks; each rank runs its share in
     batches that compute the geometry stages once (Batch.share_geometry: SH matrices, array model, every bin's regularised
-    inverse) and sweep all their sets in one resident launch; one gather.  Same filters as the single calls.
-    Returns [(wL, wR), ...] in the order of `subjects` on rank 0, None elsewhere."""
-    import torch.distributed as dist
-    from . import Batch, Plan, _lib as L
+    inverse) and sweep all their sets in one resident launch (designs with more than 32 channels: one at a time); one gather.
+    Same filters as the single calls.  Returns [(wL, wR), ...] in the order of `subjects` on rank 0, None elsewhere."""
+    from . import Plan, _lib as L
     K = {"emagls": L.KIND_EMAGLS, "emagls2": L.KIND_EMAGLS2, "emainch": L.KIND_EMA_CH}[kind]
     azi = np.asarray(hrirGridAziRad, dtype=np.float64)
     zen = np.asarray(hrirGridZenRad, dtype=np.float64)
     maz = np.asarray(micGridAziRad, dtype=np.float64)
     mzn = None if micGridZenRad is None else np.asarray(micGridZenRad, dtype=np.float64)
-    have_pg = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if have_pg else 0
-    world = dist.get_world_size(group) if have_pg else 1
-    n = len(subjects)
-    shards = shard_jobs(np.ones(n), world)
-    local = []
-    mine = shards[rank]
-    for i in range(0, len(mine), max_batch):
+    _, _, world = _pg(group)
+
+    def make_plans(idx, _):
         plans = []
         try:
-            for j in mine[i:i + max_batch]:
+            for j in idx:
                 hL = np.asfortranarray(subjects[j][0], dtype=np.float64)
                 hR = np.asfortranarray(subjects[j][1], dtype=np.float64)
                 p = Plan(K, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], float(micRadius), maz.size)
+                plans.append(p)
                 p.set_hrir_grid(azi, zen)
                 p.set_mic_grid(maz, mzn)
                 p.set_hrirs(hL, hR)
-                plans.append(p)
-            if len(plans) == 1:
-                plans[0].execute()
-                local.append(plans[0].get_filters())
-            else:
-                b = Batch(plans)
-                try:
-                    b.share_geometry(True)
-                    b.execute()
-                    local += b.get_filters()
-                finally:
-                    b.close()
-        finally:
+        except Exception:
             for p in plans:
                 p.close()
-    if world == 1:
-        return local
-    return _gather_on_rank0(local, shards, n, group, None)
+            raise
+        return plans
+    return _run_plan_jobs(len(subjects), _even_chunks(len(subjects), world, max_batch), make_plans, group, share_geometry=True)
 
 
 def magls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, order, fs, length, shDefinition="real", group=None, max_batch=8):
     """getMagLsFilters (lib/getMagLsFilters.m:30; hrirGridZenRad None: getMagLsFilters2D on a horizontal grid) for every HRIR
     set of `subjects` = [(hL, hR), ...] on ONE grid: spread over the ranks, each rank's share in batches that compute the SH
-    side once (Batch.share_geometry) and sweep all their sets in one resident launch; one gather.  Same filters as the single
-    calls.  Returns [(wL, wR), ...] in the order of `subjects` on rank 0, None elsewhere."""
-    import torch.distributed as dist
-    from . import Batch, Plan, _lib as L
+    side once (Batch.share_geometry) and sweep all their sets in one resident launch (orders 5..7, more than 32 channels: one
+    design at a time); one gather.  Same filters as the single calls.  Returns [(wL, wR), ...] in the order of `subjects` on
+    rank 0, None elsewhere."""
+    from . import Plan, _lib as L
     azi = np.asarray(hrirGridAziRad, dtype=np.float64)
     zen = None if hrirGridZenRad is None else np.asarray(hrirGridZenRad, dtype=np.float64)
     K = L.KIND_MAGLS if zen is not None else L.KIND_MAGLS_2D
-    have_pg = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if have_pg else 0
-    world = dist.get_world_size(group) if have_pg else 1
-    n = len(subjects)
-    shards = shard_jobs(np.ones(n), world)
-    local = []
-    mine = shards[rank]
-    for i in range(0, len(mine), max_batch):
+    _, _, world = _pg(group)
+
+    def make_plans(idx, _):
         plans = []
         try:
-            for j in mine[i:i + max_batch]:
+            for j in idx:
                 hL = np.asfortranarray(subjects[j][0], dtype=np.float64)
                 hR = np.asfortranarray(subjects[j][1], dtype=np.float64)
                 p = Plan(K, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], 0.0, 0)
+                plans.append(p)
                 p.set_hrir_grid(azi, zen)
                 p.set_hrirs(hL, hR)
-                plans.append(p)
-            if len(plans) == 1:
-                plans[0].execute()
-                local.append(plans[0].get_filters())
-            else:
-                b = Batch(plans)
-                try:
-                    b.share_geometry(True)
-                    b.execute()
-                    local += b.get_filters()
-                finally:
-                    b.close()
-        finally:
+        except Exception:
             for p in plans:
                 p.close()
-    if world == 1:
-        return local
-    return _gather_on_rank0(local, shards, n, group, None)
+            raise
+        return plans
+    return _run_plan_jobs(len(subjects), _even_chunks(len(subjects), world, max_batch), make_plans, group, share_geometry=True)

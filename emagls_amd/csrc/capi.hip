@@ -131,6 +131,7 @@ struct emagls_plan {
     hipGraph_t pre_graph = nullptr;          // batches: stages before the sweep, captured on the plan's own stream
     hipGraphExec_t pre_exec = nullptr;
     int nstreams = 1;
+    int stage_order = 0;          // order of the stages before the sweep (emagls_pre_sweep): 0 branches, 1 / 2 the complementary single-stream orders of lane groups
     hipStream_t sync_stream = nullptr;  // stream whose completion means this plan's results are ready
     // fork/join inside one design: independent branches run on side streams (captured into the same graph)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
@@ -238,6 +239,7 @@ struct emagls_batch {
     hipGraph_t post_graph = nullptr;           // lane mode: the stages after the sweep (the sweep is launched directly)
     hipGraphExec_t post_exec = nullptr;
     bool side0_external = false;               // side[0] belongs to the caller (emagls_batch_set_side_stream)
+    int order_hint = 0;                        // single-group batches: 1 / 2 = stage order of emagls_pre_sweep the caller asks for (emagls_batch_set_stage_order)
     int groups = 1;                            // lane groups before the sweep (2 for more than 8 designs: batch_execute_lanes)
     hipGraph_t graph2 = nullptr;               // the second lane group's stages before the sweep (on side[0])
     hipGraphExec_t graph2_exec = nullptr;
@@ -975,11 +977,21 @@ void emagls_pre_sweep(emagls_plan& p) {
     cplx* Gk = p.get<cplx>("G") - (int64_t)p.g0 * g_stride;   // indexed by kb
     p.sync_used = 0;
 
-    // ---- fork: three independent branches
-    launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), s0);
-    p.depend(s1, s0);
-    p.depend(s2, s0);
+    // The stages before the sweep as blocks.  Their data dependencies: array (mic SH matrix, E, b_n) <- nothing; prologue (HRIR
+    // spectra) <- nothing; basis (Yc) <- nothing; gram (Gy, R) <- basis; chol <- gram; gterms (QT_n, G_k) <- basis, array;
+    // rows (H conj(Q)) <- prologue, chol; gram_route (M_k of the Gram-route bins) <- gram, array; hh_route (QR + Jacobi of the
+    // Householder-route bins) <- chol, array; flags <- gram_route, hh_route; back (Z_k, least-squares rows) <- flags, rows;
+    // tail (least-squares rows of the Gram route, accurate Y_reg_inv) <- gterms, back.
+    // order 0 issues them as three or four branches on the plan's streams (one design: shortest critical path).  Orders 1 and 2
+    // are single-stream sequences for lane groups that run side by side (batch_execute_lanes): order 1 issues the kernels that
+    // fill the chip first (HRIR transform, Gram matrix, G_k) and the latency-bound chains after them (Cholesky, per-bin
+    // factors), order 2 the other way round -- two groups in the SAME order meet at the same kernels and add up their times,
+    // two groups in complementary orders hide one's chains behind the other's bandwidth-bound kernels.
+    const int order = (s1 == s0 && s2 == s0 && s3 == s0) ? p.stage_order : 0;
+    hipEvent_t e_E = nullptr, e_Yc = nullptr, e_Gy = nullptr, e_R = nullptr;
+    FactorArgs fa{};
 
+    auto blk_array = [&] {
     // s1: array model  E = Y_mic (raw) or pinv(Y_mic(:,1:nOut)) Y_mic   (getSMAIRMatrix.m:101-102,119-121), b_n(kr)
     if (!p.custom_basis)
         launch_sh_basis(p.simOrder, M, p.get<double>("mic_azi"), p.get<double>("mic_zen"), p.get<double>("sh_tab"), cb,
@@ -1003,11 +1015,12 @@ void emagls_pre_sweep(emagls_plan& p) {
     }
     // bnAll = -sphModalCoeffs(simOrder, kr, 'rigid')   (getSMAIRMatrix.m:107)
     launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, s1, p.get<int>("nvalid"));
-    hipEvent_t e_E = p.next_sync_event();
+    e_E = p.next_sync_event();
     if (s1 != s0) HIP_CHECK(hipEventRecord(e_E, s1));
+    };
 
+    auto blk_prologue = [&] {
     // s2: HRIR prologue
-    {
         launch_twiddles(p.nfft, p.get("tw"), s2);
         launch_hrir_grpdelay(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, d.ndirs, p.nfft, p.get("tw"),
                              p.get<double>("dirsum"), p.get<double>("grpd"), s2);
@@ -1017,25 +1030,33 @@ void emagls_pre_sweep(emagls_plan& p) {
         if (p.diffuse)   // the target covariance needs the complex HRTFs of all bins (the sweep only keeps |H| above k_cut)
             launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"),
                             p.get<double>("grpd"), 0, p.P, p.P, p.get("Hfull"), p.get<double>("Habs"), p.ldD, s2);
-    }
+    };
 
-    // s0: SH matrix of the HRIR grid, its Gram matrix Gy, Cholesky factor R of the leading block (Householder-route orders)
+    auto blk_basis = [&] {
+    // s0: SH matrix of the HRIR grid
     if (!p.custom_basis)
         launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), cb,
                         p.get("Ycm"), p.ldD, s0);
     launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, cb, true, s0);
     p.mark("sh_basis");
-    hipEvent_t e_Yc = p.next_sync_event();
+    e_Yc = p.next_sync_event();
     if (s1 != s0) HIP_CHECK(hipEventRecord(e_Yc, s0));
+    };
+    auto blk_gram = [&] {
+    // s0: Gram matrix Gy of conj(Y); its leading block (Householder-route orders) goes to R
     launch_gram(p.get("Yc"), p.D, p.S, p.ldS, cb, p.get("Gp"), p.get("Gy"), p.get("R"), Sh, s0);
     p.mark("gram_mfma");
-    hipEvent_t e_Gy = p.next_sync_event();
+    e_Gy = p.next_sync_event();
     if (s3 != s0) HIP_CHECK(hipEventRecord(e_Gy, s0));
+    };
+    auto blk_chol = [&] {
     launch_cholesky(p.get("R"), Sh, cb, p.get<int>("flag"), s0);
     p.mark("cholesky");
-    hipEvent_t e_R = p.next_sync_event();
+    e_R = p.next_sync_event();
     if (s2 != s0) HIP_CHECK(hipEventRecord(e_R, s0));
+    };
 
+    auto blk_gterms = [&] {
     // s1 (after the array model): order terms of pwGrid.' and G_k of every bin from g0 on -- needs only conj(Y) and E
     if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s1, e_Yc, 0));
     launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, cb, p.get("QT"), p.ldD, s1);
@@ -1043,6 +1064,8 @@ void emagls_pre_sweep(emagls_plan& p) {
     // channels would need their own channel transform and take the complex kernel)
     launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, p.g0, p.get("G"), s1,
                     (cb && d.kind != EMAGLS_KIND_EMA_CH && !p.custom_basis) ? 1 : 0, raw ? -1 : (int)d.order);
+    };
+    auto blk_rows = [&] {
     // s2 (after the prologue): the least-squares right-hand sides H conj(Q) of the Householder-route bins.  Q itself is never
     // formed: H conj(Q) is conj( conj(H conj(Yc)) R^-1 ), one D-long product and a row solve for the least-squares rows.
     if (s2 != s0) HIP_CHECK(hipStreamWaitEvent(s2, e_R, 0));
@@ -1054,12 +1077,10 @@ void emagls_pre_sweep(emagls_plan& p) {
         // (also forms the inverses of R's diagonal blocks, which the ill-conditioned swept bins need: at least one row)
         launch_qform(p.get("Hq"), p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), Sh, 2 * (int64_t)std::max(ls_end, 1), ldSh, true, p.get("Hq"), s2);
     }
+    };
 
     // s0: per-bin factors.  Gram route first (needs E, b_n, Gy): K matrices, one GEMM over the bins, direct inverses
     // (on a stream of its own with four streams: it does not need the Cholesky factor, the Householder route does)
-    if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s0, e_E, 0));
-    if (s3 != s0) { HIP_CHECK(hipStreamWaitEvent(s3, e_Gy, 0)); HIP_CHECK(hipStreamWaitEvent(s3, e_E, 0)); }
-    FactorArgs fa{};
     fa.S = Sh; fa.C = p.C; fa.ldS = ldSh; fa.kb0 = 1; fa.P = p.P;
     fa.Tn = p.get("Tn"); fa.bn = p.get<cplx>("bn"); fa.nOrders = nOrdH; fa.bn_stride = nOrd;
     fa.reg_mode = 0; fa.reg_c = SVD_REGUL_CONST;
@@ -1072,6 +1093,9 @@ void emagls_pre_sweep(emagls_plan& p) {
     fa.cond_limit = 10.0 * GRAM_COND_EST;   // (not the env override: the forced-estimate test must trip this check)
     fa.W = p.get<cplx>("W"); fa.sweeps_out = p.get<int>("jsweeps");
     fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
+    auto blk_gram_route = [&] {
+    if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s0, e_E, 0));
+    if (s3 != s0) { HIP_CHECK(hipStreamWaitEvent(s3, e_Gy, 0)); HIP_CHECK(hipStreamWaitEvent(s3, e_E, 0)); }
     if (p.nb_gram > 0) {
         const int ldK = round_up(p.C * p.C, 64), ldCf = round_up(p.P, 64);
         launch_gram_kmat(p.get("Gy"), p.get("E"), p.S, p.ldS, p.C, nOrd, cb, p.get("Fg"), p.ldS, p.get<double>("Kmat"), ldK, s3);
@@ -1090,22 +1114,30 @@ void emagls_pre_sweep(emagls_plan& p) {
         launch_factor_jacobi_gram(fg, p.nb_gram, s3);
         p.mark("gram_route");
     }
+    };
+    auto blk_hh_route = [&] {
     // Householder route: T_n of the orders 0..n_h, per-bin QR + Jacobi
     if (hh_end > 1) {
         launch_tn(p.get("R"), p.get("E"), Sh, p.C, p.ldS, nOrdH, cb, p.get("Tn"), ldSh, s0);
         p.mark("array_model+tn");
         launch_factor(fa, hh_end - 1, cb, s0, 1);
     }
+    };
+    auto blk_flags = [&] {
     // cond_ok[kb]: the cheap direction-space identity is accurate for this bin.  Only the other swept bins (and the
     // least-squares bins) need Z_k, i.e. the back-transform
     p.depend(s0, s3);   // (singular-value bounds of the Gram-route bins)
     launch_cond_flags(p.get<double>("sv"), p.C, p.P, hh_end, p.get<double>("cond_ok"), s0);
     fa.cond_ok = p.get<double>("cond_ok");
     p.mark("factor_qr_jacobi");
+    };
+    auto blk_back = [&] {
     // join s2 (Hq, spectra, group delays): back-transform + least-squares bins of the Householder route
     p.depend(s0, s2);
     if (hh_end > 1) launch_factor(fa, hh_end - 1, cb, s0, 2);
     p.mark("factor_back+ls_bins");
+    };
+    auto blk_tail = [&] {
     // join s1 (G)
     p.depend(s0, s1);
     // least-squares bins on the Gram route
@@ -1118,6 +1150,22 @@ void emagls_pre_sweep(emagls_plan& p) {
                               hh_end, k0, s0);
         launch_yri_accurate(p.get("Yc"), p.ldS, cb, p.get("Z"), ldSh, p.get<double>("cond_ok"), (int)p.D, Sh, p.C, hh_end, k0,
                             p.get("Yri"), p.ldD, s0);
+    }
+    };
+
+    launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), s0);
+    if (order == 1) {          // bandwidth-bound kernels first
+        blk_array(); blk_prologue(); blk_basis(); blk_gram(); blk_gterms();
+        blk_chol(); blk_rows(); blk_gram_route(); blk_hh_route(); blk_flags(); blk_back(); blk_tail();
+    } else if (order == 2) {   // latency-bound chains first
+        blk_array(); blk_basis(); blk_gram(); blk_chol(); blk_gram_route(); blk_hh_route(); blk_flags();
+        blk_prologue(); blk_rows(); blk_gterms(); blk_back(); blk_tail();
+    } else {
+        // ---- fork: three independent branches
+        p.depend(s1, s0);
+        p.depend(s2, s0);
+        blk_array(); blk_prologue(); blk_basis(); blk_gram(); blk_chol(); blk_gterms(); blk_rows();
+        blk_gram_route(); blk_hh_route(); blk_flags(); blk_back(); blk_tail();
     }
     p.mark("yri_operands");
 }
@@ -1581,14 +1629,26 @@ void batch_sweep_stage(emagls_batch& b) {
 
 // lane mode: the pipeline of plan `first` is enqueued once on `st` with grid.z = `count` designs (plans first .. first + count - 1)
 // part 0: stages before the sweep, part 2: stages after it
-void batch_lanes_part(emagls_batch& b, int part, int first, int count, hipStream_t st) {
+// EMAGLS_STAGGER (default 1): the two lane groups of a batch issue the stages before the sweep in complementary orders
+// (emagls_pre_sweep, orders 1 and 2); 0: both in the order of a single design
+static int stagger_mode() {
+    static const int m = [] { const char* e = getenv("EMAGLS_STAGGER"); return e ? atoi(e) : 1; }();
+    return m;
+}
+void batch_lanes_part(emagls_batch& b, int part, int first, int count, hipStream_t st, int group = 0) {
     emagls_plan& p0 = *b.plans[first];
     hipStream_t keep = p0.stream, keep_side[3] = {p0.side[0], p0.side[1], p0.side[2]};
-    const int keep_streams = p0.nstreams;
+    const int keep_streams = p0.nstreams, keep_order = p0.stage_order;
     p0.stream = st;
     p0.nstreams = (part == 0 && b.groups == 1) ? b.nstreams : 1;
+    p0.stage_order = 0;
+    if (part == 0 && p0.nstreams == 1) {
+        const int sm = stagger_mode();
+        if (sm == 1) p0.stage_order = b.groups > 1 ? 1 + group : (b.order_hint ? 1 + (b.order_hint - 1) % 2 : 0);
+        else if (sm >= 10) p0.stage_order = group == 0 ? sm / 10 % 10 : sm % 10;   // (experiments: "12", "21", "11", "22")
+    }
     if (p0.nstreams > 1) for (int i = 0; i < 3; ++i) p0.side[i] = b.side[i];
-    auto restore = [&] { p0.stream = keep; p0.nstreams = keep_streams; for (int i = 0; i < 3; ++i) p0.side[i] = keep_side[i]; };
+    auto restore = [&] { p0.stream = keep; p0.nstreams = keep_streams; p0.stage_order = keep_order; for (int i = 0; i < 3; ++i) p0.side[i] = keep_side[i]; };
     try {
         BatchScope sc(count, b.stride);
         if (part == 0) plan_pre_stage(p0); else emagls_post_sweep(p0);
@@ -1612,7 +1672,7 @@ void batch_execute_lanes(emagls_batch& b) {
     if (replay && !b.graph_exec) {
         for (int g = 0; g < b.groups; ++g) {
             const int f = batch_group_first(b, g), c = batch_group_first(b, g + 1) - f;
-            capture_into(gs[g], g == 0 ? &b.graph : &b.graph2, g == 0 ? &b.graph_exec : &b.graph2_exec, [&] { batch_lanes_part(b, 0, f, c, gs[g]); });
+            capture_into(gs[g], g == 0 ? &b.graph : &b.graph2, g == 0 ? &b.graph_exec : &b.graph2_exec, [&] { batch_lanes_part(b, 0, f, c, gs[g], g); });
         }
         capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_lanes_part(b, 2, 0, n, b.stream); });
     }
@@ -1631,7 +1691,7 @@ void batch_execute_lanes(emagls_batch& b) {
     } else {
         for (int g = 0; g < b.groups; ++g) {
             const int f = batch_group_first(b, g), c = batch_group_first(b, g + 1) - f;
-            if (replay) HIP_CHECK(hipGraphLaunch(g == 0 ? b.graph_exec : b.graph2_exec, gs[g])); else batch_lanes_part(b, 0, f, c, gs[g]);
+            if (replay) HIP_CHECK(hipGraphLaunch(g == 0 ? b.graph_exec : b.graph2_exec, gs[g])); else batch_lanes_part(b, 0, f, c, gs[g], g);
         }
     }
     if (b.groups > 1) b.depend(b.stream, gs[1]);
@@ -2972,6 +3032,16 @@ int emagls_batch_set_streams(emagls_batch* b, int nstreams) {
         b->nstreams = nstreams;
     });
 }
+int emagls_batch_set_stage_order(emagls_batch* b, int order) {
+    return guarded([&] {
+        DeviceGuard dg(b ? b->device : -1);
+        if (!b) throw Error(EMAGLS_ERR_ARG, "null pointer");
+        if (order < 0 || order > 2) throw Error(EMAGLS_ERR_ARG, "stage order must be 0, 1 or 2");
+        HIP_CHECK(hipStreamSynchronize(b->stream));
+        if (order != b->order_hint) drop_batch_graphs(*b);
+        b->order_hint = order;
+    });
+}
 int emagls_batch_set_side_stream(emagls_batch* b, void* stream) {
     return guarded([&] {
         DeviceGuard dg(b ? b->device : -1);
@@ -3272,8 +3342,9 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
             SetsCache* c = q.c;
             q.c = nullptr;
             const int n = c->n;
-            if (n == 1) {
-                req(emagls_plan_get_filters(c->plans[0], (char*)wL + q.first * out_bytes, (char*)wR + q.first * out_bytes));
+            if (n == 1 || !c->batch) {   // (no batch: designs with more than 32 channels run one at a time)
+                for (int j = 0; j < n; ++j)
+                    req(emagls_plan_get_filters(c->plans[(size_t)j], (char*)wL + (q.first + j) * out_bytes, (char*)wR + (q.first + j) * out_bytes));
             } else {
                 std::vector<void*> pl((size_t)n), pr((size_t)n);
                 for (int j = 0; j < n; ++j) { pl[(size_t)j] = (char*)wL + (q.first + j) * out_bytes; pr[(size_t)j] = (char*)wR + (q.first + j) * out_bytes; }
@@ -3283,8 +3354,11 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
         try {
             int64_t k = 0;
             for (int64_t first = 0; first < nsets; ++k) {
-                const int n = (int)std::min<int64_t>(SWEEP_MULTI_MAX, nsets - first);
-                const int slot = n == SWEEP_MULTI_MAX ? (int)(k % 2) : 2;
+                // (chunks of designs with more than 32 channels run plan by plan and hold gigabytes per plan: four at a time)
+                const bool wide_kind = ((kind == EMAGLS_KIND_MAGLS_2D || kind == EMAGLS_KIND_EMA_CH) ? 2 * order + 1 : kind == EMAGLS_KIND_EMAGLS2 ? (int)nmics : (order + 1) * (order + 1)) > 32;
+                const int chunk_max = wide_kind ? 4 : SWEEP_MULTI_MAX;
+                const int n = (int)std::min<int64_t>(chunk_max, nsets - first);
+                const int slot = n == chunk_max ? (int)(k % 2) : 2;
                 SetsCache* c = &g_sets[slot];
                 collect(pend[slot]);      // (the chunk this plan set computed two chunks ago)
                 if (!(c->n == n && c->device == dev && same_desc(c->desc, d))) {
@@ -3295,7 +3369,9 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
                             req(emagls_plan_create(&d, &p));
                             c->plans.push_back(p);
                         }
-                        if (n > 1) {
+                        // designs with more than 32 channels (LS / MagLS orders 5..7, arrays of 33..64 channels) do not enter
+                        // batches (emagls_batch_create): their chunk runs plan by plan, same filters as nsets single calls
+                        if (n > 1 && !c->plans[0]->wide) {
                             g_batch_max_override = SWEEP_MULTI_MAX;
                             const int r = emagls_batch_create(c->plans.data(), n, &c->batch);
                             g_batch_max_override = 0;
@@ -3322,7 +3398,8 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
                 emagls_plan_info info;
                 req(emagls_plan_get_info(c->plans[0], &info));
                 out_bytes = (info.out_is_complex ? sizeof(cplx) : sizeof(double)) * (size_t)info.out_rows * info.out_cols;
-                if (n == 1) req(emagls_plan_execute(c->plans[0])); else req(emagls_batch_execute(c->batch));   // (asynchronous)
+                if (n > 1 && c->batch) req(emagls_batch_execute(c->batch));   // (asynchronous)
+                else for (int j = 0; j < n; ++j) req(emagls_plan_execute(c->plans[(size_t)j]));
                 pend[slot].c = c;
                 pend[slot].first = first;
                 first += n;

@@ -597,13 +597,21 @@ class Dataset(_Object):
             out.append((fid, cd))
         return out
 
-    def _unfilter(self, raw, mask):
+    def _unfilter(self, raw, mask, limit=None):
+        """`limit`: the declared size of the chunk in bytes -- a deflate stream that expands beyond it (plus the checksum and
+        padding a later filter may strip) is refused instead of being inflated to whatever it claims."""
         for i in range(len(self._filters) - 1, -1, -1):
             if mask & (1 << i):
                 continue
             fid, cd = self._filters[i]
             if fid == 1:
-                raw = zlib.decompress(bytes(raw))
+                if limit is None:
+                    raw = zlib.decompress(bytes(raw))
+                else:
+                    z = zlib.decompressobj()
+                    raw = z.decompress(bytes(raw), int(limit) + 65)
+                    if len(raw) > int(limit) + 64 or z.unconsumed_tail:
+                        raise Hdf5Error("a chunk of dataset '%s' inflates beyond its declared size of %d bytes" % (self.name, limit))
             elif fid == 2:
                 es = cd[0] if cd else self._type.size
                 a = np.frombuffer(bytes(raw), dtype=np.uint8)
@@ -736,12 +744,18 @@ class Dataset(_Object):
 
     def _btree1_chunks(self, addr, rank):
         r, b = self._r, self._r.b
-        stack = [addr]
+        stack = [(addr, None)]
+        seen = set()
         while stack:
-            a = stack.pop()
+            a, want = stack.pop()
+            if a is None or a in seen:   # (a node that points to itself or to an ancestor would never end)
+                raise Hdf5Error("the chunk B-tree of dataset '%s' revisits node %s" % (self.name, a))
+            seen.add(a)
             if bytes(b[a:a + 4]) != b"TREE" or b[a + 4] != 1:
                 raise Hdf5Error("no chunk B-tree node at %d" % a)
             level, n = b[a + 5], _uint(b, a + 6, 2)
+            if want is not None and level != want:
+                raise Hdf5Error("chunk B-tree node at %d has level %d where %d is expected" % (a, level, want))
             p = a + 8 + 2 * r.O
             ksize = 8 + 8 * (rank + 1)
             for i in range(n):
@@ -751,7 +765,7 @@ class Dataset(_Object):
                 if level == 0:
                     yield offs, b[child:child + csize], mask
                 else:
-                    stack.append(child)
+                    stack.append((child, level - 1))
                 p += ksize + r.O
 
     def _read_chunked_v1(self, addr, cdims, esize):
@@ -766,7 +780,7 @@ class Dataset(_Object):
         out = np.zeros(self.shape, dtype=t.dtype)
         for offs, raw, mask in chunks:
             if self._filters and mask != 0xFFFFFFFF:
-                raw = self._unfilter(raw, mask)
+                raw = self._unfilter(raw, mask, limit=int(np.prod(cdims)) * t.dtype.itemsize)
             c = np.frombuffer(bytes(raw), dtype=t.dtype, count=int(np.prod(cdims))).reshape(cdims)
             sl = tuple(slice(o, min(o + d, s)) for o, d, s in zip(offs, cdims, self.shape))
             out[sl] = c[tuple(slice(0, s.stop - s.start) for s in sl)]

@@ -172,6 +172,10 @@ class Batch:
         """Lane mode: fork the stages before the sweep onto n (1..4) streams (see emagls_batch_set_streams)."""
         L.check(self._lib.emagls_batch_set_streams(self._h, int(n)))
 
+    def set_stage_order(self, order):
+        """Order of the stages before the sweep of a batch of up to 8 designs (0 / 1 / 2, see emagls_batch_set_stage_order)."""
+        L.check(self._lib.emagls_batch_set_stage_order(self._h, int(order)))
+
     def set_side_stream(self, hip_stream):
         """The stream of the second lane group of a batch of more than 8 designs (see emagls_batch_set_side_stream)."""
         L.check(self._lib.emagls_batch_set_side_stream(self._h, C.c_void_p(int(hip_stream))))

@@ -382,6 +382,13 @@ int emagls_batch_sweep_time(emagls_batch* batch, double* ms);
  * | [Gram-route factors].  Shortens the path to the batch's sweep from the sum of the kernels to its longest branch (what a
  * short run, a pipeline filling from empty, is bound by); with many batches in flight it only adds queue contention. */
 int emagls_batch_set_streams(emagls_batch* batch, int nstreams);
+/* Lane mode, one stream: the order in which a batch of up to 8 designs issues the stages before its sweep.  0 (default): the
+ * order of a single design.  1: the kernels that fill the chip first (HRIR transform, SH Gram matrix, G_k of every bin), the
+ * latency-bound chains (Cholesky, per-bin QR / Jacobi) after them.  2: the chains first.  Batches that run side by side in the
+ * SAME order meet at the same kernels and add up their times; complementary orders hide one batch's chains behind the other's
+ * bandwidth-bound kernels.  The two lane groups of a batch of more than 8 designs take orders 1 and 2 by themselves
+ * (EMAGLS_STAGGER=0 switches that off).  Same filters in every order (no arithmetic changes, only the issue order). */
+int emagls_batch_set_stage_order(emagls_batch* batch, int order);
 int emagls_batch_destroy(emagls_batch* batch);
 
 #ifdef __cplusplus
