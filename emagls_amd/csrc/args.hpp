@@ -88,6 +88,19 @@ struct HalfSweepArgs {
     long long* timing;       // optional [P][16] wall-clock stamps (EMAGLS_SWEEP_TIMING), else null
     int fetch_mode;          // persistent sweep: where the next bin's operands are requested (sweep_persist.hip; EMAGLS_SWEEP_FETCH, default 0)
     int force_global;        // persistent sweep: keep the write-through (sc1) stores even on one XCD (EMAGLS_PERSIST_GLOBAL=1)
+    // operand synthesis (sweep_synth.hip): the chain runs on the C microphones, the slab of bin k is evaluated inside the launch as
+    // g_k[d][j] = sum_n bsc[k][n] pi_n(cos(angle between HRIR direction d and microphone j)); Mw then holds Pm^T M_k Pm (C x C)
+    const double* dir_azi;   // [D] HRIR grid
+    const double* dir_zen;
+    const double* mic_azi;   // [C] microphone grid (mic_zen null: equatorial array)
+    const double* mic_zen;
+    const int* smap;         // [34] row -> microphone in the chain's order (antipodal pairs first: rows 2u, 2u + 1), [32] pairs, [33] singles
+    const cplx* bsc;         // [P][nord_pad] Chebyshev coefficients of the bin's Legendre series, zero beyond the design's own orders
+    int nord_pad;            // even
+    int synth_split;         // per cent of the producers' unit groups evaluated before barrier B1 (the rest between B1 and B2); 0 = all
+    int synth_prio;          // issue priority of the producer waves (0..2; the chain's waves run at 3)
+    const cplx* Winit;       // [2][32] W(kfirst-1,:) Pm: the chain's start value
+    cplx* U;                 // [2][P][32] totals u(k) of every swept bin (the filters' rows are formed from them after the launch)
 };
 constexpr int SWEEP_MULTI_MAX = 16;   // designs per sweep launch: one per XCD up to 8, two per XCD (two workgroups per CU) up to 16
 struct HalfSweepMulti {

@@ -109,6 +109,13 @@ struct emagls_plan {
     int nh_floor = 0;   // least number of orders on the Householder route (a lane batch gives all its designs the same routes)
     bool persist_suspended = false;   // sweep_persist switched off for ONE re-run (status word 4), restored afterwards
     bool sweep_persist = true;  // (EMAGLS_SWEEP_PERSIST=0 disables) one resident launch for all swept bins (sweep_persist.hip)
+    // Operand synthesis (sweep_synth.hip): the resident sweep evaluates the slab of pwGrid_k.' of every bin itself from the angles
+    // between HRIR directions and microphones instead of reading a materialised G_k (540 MB per design at config 3).  synth_want:
+    // the design qualifies (built-in real SH machinery, <= 32 microphones, no covariance constraint); synth: it is in effect
+    // (persistent sweep, no swept bin on the Householder route) -- plan_update_synth
+    bool synth_want = false, synth = false;
+    bool synth_block = false;     // a batch whose designs do not all qualify keeps every one of them on the materialised operands
+    const emagls_plan* geo_from = nullptr;   // set while a geometry-sharing batch runs this plan's stages on plan 0's geometry
     emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
     bool have_hrir_grid = false, have_mic_grid = false, have_hrirs = false, have_atfs = false, have_basis = false;
     uint64_t atf_side_version = 0;   // bumped when the grids or the ATF set are replaced (a FromAtf batch re-checks that its plans agree)
@@ -358,6 +365,49 @@ void plan_routes(emagls_plan& p) {
     if (p.diffuse) p.g0 = 1;   // the constraint renders the HRTFs of every solved bin: G_k from the first one
     p.nb_gram = p.gram_from > 0 ? p.P - p.gram_from : 0;
 }
+// Row order of the microphones in the synthesising sweep: smap[0..M) = microphone of row r, smap[32] = antipodal pairs (rows 2u,
+// 2u + 1), smap[33] = single microphones after them.  Two microphones are a pair when their unit vectors cancel to a few ulps:
+// cos(d, j') = -cos(d, j) then holds to the rounding error of either cosine, and one polynomial evaluation serves both.
+// EMAGLS_SYNTH_PAIRS=0: no pairing.
+static void synth_pairing(const double* azi, const double* zen, int M, int* smap) {
+    static const bool pairs_on = [] { const char* e = getenv("EMAGLS_SYNTH_PAIRS"); return !(e && e[0] == '0'); }();
+    std::vector<double> u((size_t)3 * M);
+    for (int j = 0; j < M; ++j) {
+        u[3 * j] = std::sin(zen[j]) * std::cos(azi[j]); u[3 * j + 1] = std::sin(zen[j]) * std::sin(azi[j]); u[3 * j + 2] = std::cos(zen[j]);
+    }
+    std::vector<int> partner((size_t)M, -1);
+    const double tol = 8.0 * 2.220446049250313e-16;
+    if (pairs_on && M <= 32)
+        for (int j = 0; j < M; ++j) {
+            if (partner[j] >= 0) continue;
+            for (int k = j + 1; k < M; ++k) {
+                if (partner[k] >= 0) continue;
+                if (std::fabs(u[3 * j] + u[3 * k]) <= tol && std::fabs(u[3 * j + 1] + u[3 * k + 1]) <= tol && std::fabs(u[3 * j + 2] + u[3 * k + 2]) <= tol) {
+                    partner[j] = k; partner[k] = j;
+                    break;
+                }
+            }
+        }
+    for (int i = 0; i < 34; ++i) smap[i] = 0;
+    int row = 0, npr = 0, nsg = 0;
+    for (int j = 0; j < M && j < 32; ++j) if (partner[j] > j) { smap[row++] = j; smap[row++] = partner[j]; ++npr; }
+    for (int j = 0; j < M && j < 32; ++j) if (partner[j] < 0) { smap[row++] = j; ++nsg; }
+    smap[32] = npr; smap[33] = nsg;
+}
+// EMAGLS_SWEEP_SYNTH=0: every design on the materialised operands (dspace_g + sweep_persist_kernel)
+// (read when a plan is created: a test switches forms inside one process)
+static bool synth_enabled() { const char* e = getenv("EMAGLS_SWEEP_SYNTH"); return !(e && e[0] == '0'); }
+static bool plan_persist_possible(const emagls_plan& p) {
+    const int64_t Dh = (p.d.kind == EMAGLS_KIND_FROM_ATF) ? p.Dm : p.D;
+    if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) if (e[0] == '0') return false;
+    return !p.wide && persist_sweep_supported((int)Dh, p.C) && persist_sweep_nwg((int)Dh) <= device_cu_count();
+}
+// Is the synthesising sweep in effect?  Needs the persistent form (all workgroups resident) and every swept bin on the Gram
+// route (the ill-conditioned swept bins of tiny arrays read Y_reg_inv_k from memory: they keep the materialised operands).
+void plan_update_synth(emagls_plan& p) {
+    const int k0 = std::max(p.kcut0, 1);
+    p.synth = p.synth_want && !p.synth_block && p.sweep_persist && p.hh_end <= k0 && p.gram_from > 0 && k0 < p.P;
+}
 // buffers whose size depends on the routes (re-entered when a conditioning check moves the routes: alloc keeps what is large enough)
 void plan_alloc_routes(emagls_plan& p) {
     const bool cb = p.cplx_basis;
@@ -376,7 +426,26 @@ void plan_alloc_routes(emagls_plan& p) {
     p.alloc("HcT", sizeof(double) * (size_t)hy_mfma_kpad((int)p.D) * round_up(4 * ls_end, 64));   // (rows >= D stay zero)
     p.alloc("Z", sizeof(cplx) * (size_t)p.hh_end * p.C * p.ldS_h);
     p.alloc("Vws", sizeof(cplx) * (size_t)p.hh_end * p.C * p.ldS_h);
-    p.alloc("G", sizeof(cplx) * ((size_t)std::max(p.P - p.g0, 1) * p.C + 32) * p.ldD, false);  // + 32 rows: the persistent sweep loads all 32 slab rows of a bin unconditionally
+    plan_update_synth(p);
+    // (the synthesising sweep and its least-squares bins evaluate their operands themselves: no G_k in memory)
+    const int g_end = p.synth ? p.g0 : p.P;
+    p.alloc("G", sizeof(cplx) * ((size_t)std::max(g_end - p.g0, 1) * p.C + 32) * p.ldD, false);  // + 32 rows: the persistent sweep loads all 32 slab rows of a bin unconditionally
+    if (p.synth_want) {
+        const int M = (int)p.d.nmics;
+        p.alloc("bsc", sizeof(cplx) * (size_t)p.P * synth_nord_pad(nOrd));
+        p.alloc("Pm", sizeof(double) * 32 * 32);
+        if (!p.has("smap")) {   // (identity order until the microphone grid arrives)
+            int smap[34] = {0};
+            for (int j = 0; j < 32; ++j) smap[j] = j < M ? j : 0;
+            smap[33] = M;
+            p.alloc("smap", sizeof smap);
+            p.upload("smap", smap, sizeof smap);
+            HIP_CHECK(hipStreamSynchronize(p.stream));
+        }
+        p.alloc("Mt", sizeof(cplx) * ((size_t)p.P * M * M + 1024));
+        p.alloc("Winit", sizeof(cplx) * 64);
+        p.alloc("Usw", sizeof(cplx) * (size_t)synth_ls_chunks((int)p.D) * 2 * p.P * 32);   // [chunk][e][bin][32]: the chain's totals use chunk 0
+    }
     p.alloc("Yri", sizeof(cplx) * (size_t)std::max(p.hh_end - k0, 1) * p.C * p.ldD, false);    // only Householder-route bins can be flagged ill-conditioned
     if (p.nb_gram > 0) {
         const int ldK = round_up(p.C * p.C, 64), Kp = round_up(nOrd * nOrd, 4);
@@ -618,6 +687,9 @@ void plan_setup(emagls_plan& p) {
         } else {
         p.alloc("route", sizeof(int) * (size_t)p.P);
         p.alloc("Gy", esz(cb) * (size_t)p.S * p.S);                    // Gram matrix of conj(Y) (upper block triangle)
+        p.sweep_persist = plan_persist_possible(p);
+        p.synth_want = synth_enabled() && !cb && !p.custom_basis && !p.diffuse && d.kind != EMAGLS_KIND_EMA_SH &&
+                       synth_sweep_supported((int)p.D, (int)d.nmics, p.simOrder + 1) && persist_sweep_supported((int)p.D, (int)d.nmics);
         plan_routes(p);
         plan_alloc_routes(p);
         p.alloc("sv", sizeof(double) * (size_t)p.P * p.C);
@@ -666,18 +738,15 @@ void plan_setup(emagls_plan& p) {
         p.alloc("W", sizeof(cplx) * (size_t)2 * p.P * p.C);
         if (magls_kind(d.kind) || d.kind == EMAGLS_KIND_FROM_ATF || p.wide) p.nWG = dense_sweep_nwg((int)Dh);
         p.nWG_dense = dense_sweep_nwg((int)Dh);
-        if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) p.sweep_persist = e[0] != '0';
         // the persistent sweep keeps one workgroup per CU resident (142 KB of LDS each): it needs the shape to fit one XCD's
         // 32 CUs per design AND that many CUs on this device (a partitioned or CU-masked GPU takes the launch-per-bin form)
-        if (p.wide || !persist_sweep_supported((int)Dh, p.C) ||
-            persist_sweep_nwg((int)Dh) > device_cu_count())
-            p.sweep_persist = false;
+        p.sweep_persist = plan_persist_possible(p);
         if (magls_kind(d.kind) && p.sweep_persist) {
             p.alloc("Gm", sizeof(cplx) * ((size_t)p.C + 32) * p.ldD);      // Y_conj as complex [c][d] (+ 32 rows: whole-slab loads)
             p.alloc("Mw", sizeof(cplx) * ((size_t)p.P * p.C * p.C + 1024));
             p.alloc("cond_ok", sizeof(double) * (size_t)p.P);
         }
-        p.alloc("ll", persist_sweep_ll_bytes((int)Dh, p.C));
+        p.alloc("ll", persist_sweep_ll_bytes((int)Dh, p.synth_want ? std::max(p.C, (int)d.nmics) : p.C));
         p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(p.nWG, p.nWG_dense) * 2 * p.C);
         p.out_rows = d.len;
     }
@@ -1015,6 +1084,8 @@ void emagls_pre_sweep(emagls_plan& p) {
     }
     // bnAll = -sphModalCoeffs(simOrder, kr, 'rigid')   (getSMAIRMatrix.m:107)
     launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, s1, p.get<int>("nvalid"));
+    if (p.synth)   // scaled modal terms of the Legendre series and pinv(Y_lo) as the real matrix Pm (identity: raw microphones)
+        launch_synth_prepare(p.get("bn"), nOrd, p.P, p.get("bsc"), raw ? nullptr : p.get("Zlo"), ldM, p.C, M, p.get<int>("smap"), p.get<double>("Pm"), s1);
     e_E = p.next_sync_event();
     if (s1 != s0) HIP_CHECK(hipEventRecord(e_E, s1));
     };
@@ -1059,11 +1130,15 @@ void emagls_pre_sweep(emagls_plan& p) {
     auto blk_gterms = [&] {
     // s1 (after the array model): order terms of pwGrid.' and G_k of every bin from g0 on -- needs only conj(Y) and E
     if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s1, e_Yc, 0));
+    // (the synthesising sweep and its least-squares bins evaluate their operands themselves: neither order terms nor G_k)
+    const int g_end = p.synth ? p.g0 : p.P;
+    if (g_end > p.g0) {
     launch_qt(p.get("Yc"), p.ldS, p.get("E"), p.ldS, (int)p.D, p.S, p.C, nOrd, cb, p.get("QT"), p.ldD, s1);
     // (complex-arithmetic pipeline: G_k is still evaluated on the real order terms; circular-harmonic
     // channels would need their own channel transform and take the complex kernel)
     launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, p.g0, p.get("G"), s1,
-                    (cb && d.kind != EMAGLS_KIND_EMA_CH && !p.custom_basis) ? 1 : 0, raw ? -1 : (int)d.order);
+                    (cb && d.kind != EMAGLS_KIND_EMA_CH && !p.custom_basis) ? 1 : 0, raw ? -1 : (int)d.order, g_end);
+    }
     };
     auto blk_rows = [&] {
     // s2 (after the prologue): the least-squares right-hand sides H conj(Q) of the Householder-route bins.  Q itself is never
@@ -1141,8 +1216,14 @@ void emagls_pre_sweep(emagls_plan& p) {
     // join s1 (G)
     p.depend(s0, s1);
     // least-squares bins on the Gram route
-    if (gf > 0 && gf < ls_end)
+    if (gf > 0 && gf < ls_end) {
+        if (p.synth) {   // u(k) = H(k,:) conj(g_k) from the angles, then W(k,:) = (u Pm^T) conj(M_k) like the swept bins' rows
+            launch_synth_ls(p.get("Hc"), p.ldD, ls_end, p.get("bsc"), synth_nord_pad(nOrd), p.get<double>("hrir_azi"), p.get<double>("hrir_zen"),
+                            p.get<double>("mic_azi"), p.get<double>("mic_zen"), p.get<int>("smap"), (int)p.D, M, p.P, gf, ls_end, p.get("Usw"), s0);
+            launch_synth_rows(p.get("Usw"), synth_ls_chunks((int)p.D), p.get("Pm"), p.get("Mw"), p.C, M, gf, ls_end, p.P, p.get("W"), s0);
+        } else
         launch_ls_gram(p.get("Hc"), p.ldD, ls_end, Gk, g_stride, p.ldD, p.get("Mw"), (int)p.D, p.C, p.P, gf, ls_end, p.get("W"), s0);
+    }
     // ill-conditioned swept bins (Householder route only): Y_reg_inv_k = conj(Q) Z_k = conj(Yc) (Z_k R^-H); the flagged bins'
     // Z rows are solved in place first
     if (hh_end > k0) {
@@ -1151,6 +1232,8 @@ void emagls_pre_sweep(emagls_plan& p) {
         launch_yri_accurate(p.get("Yc"), p.ldS, cb, p.get("Z"), ldSh, p.get<double>("cond_ok"), (int)p.D, Sh, p.C, hh_end, k0,
                             p.get("Yri"), p.ldD, s0);
     }
+    // synthesising sweep: the chain runs in the microphone domain on Mt_k = Pm^T M_k Pm, from the start value W(k0-1,:) Pm
+    if (p.synth) launch_synth_mt(p.get("Mw"), p.get<double>("Pm"), p.C, M, k0, p.P, p.get("W"), p.get("Mt"), p.get("Winit"), s0);
     };
 
     launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), s0);
@@ -1199,6 +1282,21 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     a.force_global = (fg && fg[0] == '1') ? 1 : 0;
     static const int fetch_mode = [] { const char* e = getenv("EMAGLS_SWEEP_FETCH"); return e ? std::max(0, std::min(4, atoi(e))) : 0; }();
     a.fetch_mode = fetch_mode;
+    if (p.synth) {   // the chain's channels are the microphones (sweep_synth.hip)
+        const int M = (int)p.d.nmics;
+        a.C = M;
+        a.G = nullptr; a.Yri = nullptr;
+        a.Mw = p.get<cplx>("Mt") - (int64_t)M * M;
+        a.dir_azi = p.get<double>("hrir_azi"); a.dir_zen = p.get<double>("hrir_zen");
+        a.mic_azi = p.get<double>("mic_azi"); a.mic_zen = p.get<double>("mic_zen");
+        a.smap = p.get<int>("smap");
+        a.bsc = p.get<cplx>("bsc"); a.nord_pad = synth_nord_pad(p.simOrder + 1);
+        static const int split = [] { const char* e = getenv("EMAGLS_SYNTH_SPLIT"); return e ? atoi(e) : 67; }();
+        a.synth_split = split;
+        static const int prio = [] { const char* e = getenv("EMAGLS_SYNTH_PRIO"); return e ? std::max(0, std::min(2, atoi(e))) : 0; }();
+        a.synth_prio = prio;
+        a.Winit = p.get<cplx>("Winit"); a.U = p.get<cplx>("Usw");
+    }
     return a;
 }
 
@@ -1250,7 +1348,7 @@ void emagls_run_sweep(emagls_plan& p) {
         SweepChain chain(s0);
         launch_zero(p.get("ll"), p.bufs["ll"].bytes, s0);
         if (p.prof_level >= 2) record_sweep_event(p, 0);
-        launch_sweep_persist(m, s0);
+        if (p.synth) launch_sweep_synth(m, s0); else launch_sweep_persist(m, s0);
         if (p.prof_level >= 2) record_sweep_event(p, 1);
         p.sweep_launches = 1;
     } else if (k0 < p.P) {
@@ -1269,6 +1367,11 @@ void emagls_post_sweep(emagls_plan& p) {
     const bool cb = p.cplx_basis;
     const bool raw = p.d.kind == EMAGLS_KIND_EMAGLS2;
     const int conj_mode = !p.req_cplx || raw ? 0 : (p.d.kind == EMAGLS_KIND_EMA_CH ? 2 : 1);   // Hermitian mirror / SH rule / CH rule
+    if (p.synth) {   // the chain stored the microphone-domain totals u(k): W(k,:) = (u(k) Pm^T) conj(M_k) for the swept bins
+        const emagls_plan& g = p.geo_from ? *p.geo_from : p;   // (geometry-sharing batches: plan 0's Pm and M_k)
+        launch_synth_rows(p.get("Usw"), 1, g.bufs.at("Pm").p, g.bufs.at("Mw").p, p.C, (int)p.d.nmics, std::max(p.kcut0, 1), p.P, p.P, p.get("W"), p.stream,
+                          p.geo_from != nullptr);
+    }
     if (p.diffuse)   // (in the real-arithmetic pipeline W is still W_r here: the rendered HRTFs W G are the same in either basis)
         launch_diffuse_constraint(p.get("W"), p.get("G"), true, (int64_t)p.C * p.ldD, p.g0, p.get("Hfull"), (int)p.D, p.C, p.ldD, p.P,
                                   p.stream);
@@ -1610,6 +1713,7 @@ void batch_sweep_stage(emagls_batch& b) {
     if (b.atf_share || b.geo_share)   // one ATF side / one geometry for every subject
         for (int j = 1; j < h.n; ++j) {
             h.a[j].G = h.a[0].G; h.a[j].Yri = h.a[0].Yri; h.a[j].Mw = h.a[0].Mw; h.a[j].cond_ok = h.a[0].cond_ok;
+            h.a[j].bsc = h.a[0].bsc; h.a[j].smap = h.a[0].smap;   // (synthesising sweep: plan 0's scaled modal terms and Mt; the grids are the same by the sharing check)
             h.a[j].skip_flag = h.a[0].skip_flag;   // (MagLS: plan 0 judged the basis for everybody)
         }
     emagls_plan& q0 = *b.plans[0];
@@ -1619,7 +1723,7 @@ void batch_sweep_stage(emagls_batch& b) {
         SweepChain chain(b.stream);
         for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, b.stream);
         if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[0], b.stream));
-        launch_sweep_persist(h, b.stream);
+        if (q0.synth) launch_sweep_synth(h, b.stream); else launch_sweep_persist(h, b.stream);
         if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[1], b.stream));
         return;
     }
@@ -1867,9 +1971,16 @@ void emagls_subject_rows(emagls_plan& p, emagls_plan& g) {
         fa.cond_ok = g.get<double>("cond_ok");
         launch_factor(fa, hh_end - 1, cb, st, 2);
     }
-    if (gf > 0 && gf < ls_end)
+    if (gf > 0 && gf < ls_end) {
+        if (g.synth) {   // (lane launches: the subject's own copies of the grids and of the row order, plan 0's coefficients, Pm and M_k)
+            const emagls_plan& g0p = g.geo_from ? *g.geo_from : g;
+            launch_synth_ls(p.get("Hc"), p.ldD, ls_end, g0p.bufs.at("bsc").p, synth_nord_pad(nOrd), p.get<double>("hrir_azi"), p.get<double>("hrir_zen"),
+                            p.get<double>("mic_azi"), p.get<double>("mic_zen"), p.get<int>("smap"), (int)g.D, (int)g.d.nmics, g.P, gf, ls_end, p.get("Usw"), st, true);
+            launch_synth_rows(p.get("Usw"), synth_ls_chunks((int)g.D), g0p.bufs.at("Pm").p, g0p.bufs.at("Mw").p, g.C, (int)g.d.nmics, gf, ls_end, g.P, p.get("W"), st, true);
+        } else
         launch_ls_gram(p.get("Hc"), p.ldD, ls_end, g.get<cplx>("G") - (int64_t)g.g0 * g_stride, g_stride, g.ldD, g.get("Mw"), (int)g.D, g.C, g.P, gf,
                        ls_end, p.get("W"), st);
+    }
 }
 // One stream for the whole batch (the subjects' stages are short and the sweep chain is what bounds a batch of HRIR sets), so
 // that the stages before and after the sweep are two single-stream graphs: issued eagerly, the ~250 launches of a 16-set batch
@@ -1914,18 +2025,31 @@ void batch_geo_stage(emagls_batch& b, int part) {
                 }
                 BatchScope sc(nsub, b.stride);
                 emagls_subject_prologue(p1, p0);
-                emagls_subject_rows(p1, p1);
+                p1.geo_from = &p0;   // (synthesising designs: plan 0's coefficients, Pm and M_k for every lane)
+                try { emagls_subject_rows(p1, p1); } catch (...) { p1.geo_from = nullptr; throw; }
+                p1.geo_from = nullptr;
+                if (p0.synth)   // every set's own start value of the microphone-domain chain, on plan 0's Pm
+                    launch_synth_winit(p1.get("W"), p0.get("Pm"), p0.C, (int)p0.d.nmics, std::max(p0.kcut0, 1), p0.P, p1.get("Winit"), b.stream, true);
             } else {
                 for (size_t j = 1; j < b.plans.size(); ++j) {
                     emagls_subject_prologue(*b.plans[j], p0);
                     emagls_subject_rows(*b.plans[j], p0);
+                    if (p0.synth)
+                        launch_synth_winit(b.plans[j]->get("W"), p0.get("Pm"), p0.C, (int)p0.d.nmics, std::max(p0.kcut0, 1), p0.P, b.plans[j]->get("Winit"),
+                                           b.stream, true);
                 }
             }
         } else if (b.lanes) {
             BatchScope sc((int)b.plans.size(), b.stride);
-            emagls_post_sweep(p0);
+            p0.geo_from = &p0;   // (the filters' rows of every lane from plan 0's Pm and M_k)
+            try { emagls_post_sweep(p0); } catch (...) { p0.geo_from = nullptr; throw; }
+            p0.geo_from = nullptr;
         } else {
-            for (auto* p : b.plans) emagls_post_sweep(*p);
+            for (auto* p : b.plans) {
+                p->geo_from = &p0;
+                try { emagls_post_sweep(*p); } catch (...) { p->geo_from = nullptr; throw; }
+                p->geo_from = nullptr;
+            }
         }
     } catch (...) {
         restore();
@@ -2157,14 +2281,14 @@ bool plan_recover(emagls_plan& p, const int* flag, bool apply) {
     }
     if (flag[4]) {
         if (!p.sweep_persist) throw Error(EMAGLS_ERR_NUMERIC, "internal: MagLS conditioning flag without the persistent sweep");
-        if (apply) { p.sweep_persist = false; p.persist_suspended = true; }
+        if (apply) { p.sweep_persist = false; p.persist_suspended = true; if (p.synth_want) { plan_alloc_routes(p); HIP_CHECK(hipStreamSynchronize(p.stream)); } }
         redo = true;
     }
     if (flag[1]) {
         // not every workgroup of the persistent sweep became resident (CUs held by another process, partitioned device):
         // the launch-per-bin sweep needs no co-residency
         if (!p.sweep_persist) throw Error(EMAGLS_ERR_HIP, "phase sweep: a workgroup timed out waiting for its peers' partial sums");
-        if (apply) p.sweep_persist = false;
+        if (apply) { p.sweep_persist = false; if (p.synth_want) { plan_alloc_routes(p); HIP_CHECK(hipStreamSynchronize(p.stream)); } }
         redo = true;
     }
     return redo;
@@ -2227,6 +2351,14 @@ bool batch_unify_routes_once(emagls_batch& b) {
     return true;
 }
 
+// One sweep launch serves every design of a batch: the synthesising form only when all of them qualify
+void batch_unify_synth(emagls_batch& b) {
+    bool all = true, any = false;
+    for (auto* p : b.plans) { all = all && p->synth; any = any || p->synth; }
+    if (all || !any) return;
+    for (auto* p : b.plans)
+        if (p->synth) { p->synth_block = true; plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); drop_plan_graphs(*p); }
+}
 void batch_try_lanes(emagls_batch& b) {
     if (const char* e = getenv("EMAGLS_BATCH_LANES")) if (e[0] == '0') return;
     emagls_plan& q = *b.plans[0];
@@ -2234,6 +2366,7 @@ void batch_try_lanes(emagls_batch& b) {
     for (auto* p : b.plans)
         if (p->S != q.S || p->simOrder != q.simOrder || p->d.kind != q.d.kind || p->C != q.C || p->P != q.P) return;
     batch_unify_routes(b);
+    batch_unify_synth(b);
     const bool dbg = getenv("EMAGLS_DEBUG_LANES") != nullptr;
     for (auto* p : b.plans) {
         if (p->S != q.S || p->simOrder != q.simOrder || p->nOut != q.nOut || p->nfft != q.nfft || p->ldS != q.ldS || p->ldD != q.ldD ||
@@ -2302,6 +2435,11 @@ void batch_redo(emagls_batch& b, const std::vector<int>& flags) {
         drop_plan_graphs(*q);
     }
     drop_batch_graphs(b);
+    {
+        const std::vector<int64_t> before = [&] { std::vector<int64_t> v; for (auto* q : b.plans) v.push_back(q->total_bytes); return v; }();
+        batch_unify_synth(b);
+        for (size_t j = 0; j < b.plans.size(); ++j) moved = moved || b.plans[j]->total_bytes != before[j];
+    }
     if (b.lanes && moved) {   // re-allocated buffers left the arena: lane mode needs them at the common stride again
         b.lanes = false;
         batch_try_lanes(b);
@@ -2666,6 +2804,12 @@ int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* ze
         if (!zen) throw Error(EMAGLS_ERR_ARG, "null pointer");
         p->upload("mic_azi", azi, sizeof(double) * p->d.nmics);
         p->upload("mic_zen", zen, sizeof(double) * p->d.nmics);
+        if (p->has("smap")) {   // the synthesising sweep's row order of the microphones: antipodal pairs first (sweep_synth.hip)
+            int smap[34];
+            synth_pairing(azi, zen, (int)p->d.nmics, smap);
+            p->upload("smap", smap, sizeof smap);
+            HIP_CHECK(hipStreamSynchronize(p->stream));   // (the host array goes out of scope)
+        }
         // kr = 2*pi*f/C * smaRadius on f = linspace(0, fs/2, P)   (getSMAIRMatrix.m:90,107)
         std::vector<double> kr(p->P);
         for (int k = 0; k < p->P; ++k) {
@@ -2893,7 +3037,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         const bool fits = nplans > 8 ? nplans * nwg_b <= 2 * device_cu_count() : nplans * nwg_b <= device_cu_count() - 16;
         for (auto* p : b->plans) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
-            if (!fits) p->sweep_persist = false;
+            if (!fits && p->sweep_persist) { p->sweep_persist = false; if (p->synth_want) { plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); } }
             p->nstreams = 1;
             p->prof_level = 0;
             p->sync_stream = b->stream;
@@ -2901,7 +3045,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         }
         b->atf = b->plans[0]->d.kind == EMAGLS_KIND_FROM_ATF;
         b->magls = magls_kind(b->plans[0]->d.kind) || b->plans[0]->d.kind == EMAGLS_KIND_LS;
-        if (!b->atf && !b->magls) batch_try_lanes(*b);
+        if (!b->atf && !b->magls) { batch_unify_synth(*b); batch_try_lanes(*b); }
         *batch = b.release();
     });
 }

@@ -69,14 +69,14 @@ constexpr int DSP_NMAX = 48;  // orders held in registers (simulation order <= 4
 template <typename T, int NMAX>
 __global__ void __launch_bounds__(256) dspace_g_kernel(const T* __restrict__ QT, int64_t ldD, const cplx* __restrict__ bn,
                                                        int nOrders, int D, int C, int P, int k0, int bins_per_chunk,
-                                                       cplx* __restrict__ G, size_t bstride) {
+                                                       cplx* __restrict__ G, int k_end, size_t bstride) {
     QT = boff(QT, bstride); bn = boff(bn, bstride); G = boff(G, bstride);
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     cplx* bs = reinterpret_cast<cplx*>(dyn);  // [bins_per_chunk][NMAX], rows zero padded (branch-free inner loop, see below)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int d = blockIdx.x * DSP_TD + lane;
     const int kb_begin = k0 + blockIdx.y * bins_per_chunk;
-    const int kb_end = min(P, kb_begin + bins_per_chunk);
+    const int kb_end = min(k_end, kb_begin + bins_per_chunk);   // (k_end <= P: the bins that need a materialised operand)
     for (int idx = threadIdx.x; idx < (kb_end - kb_begin) * NMAX; idx += 256) {
         const int kb = kb_begin + idx / NMAX, n = idx % NMAX;
         cplx b = mk(0, 0);
@@ -276,11 +276,11 @@ void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S
 
 template <typename T>
 static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
-                          hipStream_t st) {
-    const int nbins = P - k0;
+                          hipStream_t st, int k_end) {
+    const int nbins = k_end - k0;
     if (nbins <= 0) return;
     if (nOrders > DSP_NMAX) throw Error(2, "dspace: simulation order above 47 is not supported in this build");
-    int chunks = 8;
+    int chunks = nbins >= 64 ? 8 : 1;
     const int nmax = nOrders <= 20 ? 20 : nOrders <= 32 ? 32 : DSP_NMAX;
     while (sizeof(cplx) * (size_t)ceil_div(nbins, chunks) * nmax > 56 * 1024) ++chunks;  // b_n table of a chunk in LDS
     const int bpc = (nbins + chunks - 1) / chunks;
@@ -289,15 +289,17 @@ static void dspace_g_impl(const void* QT, int64_t ldD, const void* bn, int nOrde
     const size_t dyn = sizeof(cplx) * (size_t)bpc * nmax;
     const dim3 grid((unsigned)ceil_div(D, DSP_TD), chunks);
     if (nOrders <= 20)
-        dspace_g_kernel<T, 20><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
+        dspace_g_kernel<T, 20><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, k_end, batch_ctx().stride);
     else if (nOrders <= 32)
-        dspace_g_kernel<T, 32><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
+        dspace_g_kernel<T, 32><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, k_end, batch_ctx().stride);
     else
-        dspace_g_kernel<T, DSP_NMAX><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, batch_ctx().stride);
+        dspace_g_kernel<T, DSP_NMAX><<<bgrid(grid), 256, dyn, st>>>((const T*)QT, ldD, (const cplx*)bn, nOrders, D, C, P, k0, bpc, (cplx*)G, k_end, batch_ctx().stride);
     KERNEL_CHECK();
 }
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
-                     hipStream_t st, int real_mode, int sh_order) {
+                     hipStream_t st, int real_mode, int sh_order, int k_end) {
+    if (k_end < 0 || k_end > P) k_end = P;
+    if (k_end < P && is_cplx) throw Error(2, "dspace: a bin range is only available on the real order terms");
     if (is_cplx && real_mode && nOrders <= 32 && C <= 64 && P - k0 > 0) {
         int chunks = 8;    // 8-design launch: 2 -> 929, 4 -> 896, 8 -> 894, 12 -> 1032, 16 -> 1115, 24 -> 1385 us (every chunk re-reads QT)
         const bool nt = true;  // streaming stores: G is written once here and read once by the sweep
@@ -315,8 +317,8 @@ void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, 
         KERNEL_CHECK();
         return;
     }
-    if (is_cplx) dspace_g_impl<cplx>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
-    else dspace_g_impl<double>(QT, ldD, bn, nOrders, D, C, P, k0, G, st);
+    if (is_cplx) dspace_g_impl<cplx>(QT, ldD, bn, nOrders, D, C, P, k0, G, st, k_end);
+    else dspace_g_impl<double>(QT, ldD, bn, nOrders, D, C, P, k0, G, st, k_end);
 }
 void launch_cond_flags(const double* sv, int C, int P, int hh_end, double* cond_ok, hipStream_t st) {
     cond_flag_kernel<<<bgrid((P + 255) / 256), 256, 0, st>>>(sv, C, P, hh_end, cond_ok, batch_ctx().stride);

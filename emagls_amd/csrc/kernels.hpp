@@ -92,6 +92,26 @@ int persist_sweep_nwg(int D);
 bool persist_sweep_supported(int D, int C);
 size_t persist_sweep_ll_bytes(int D, int C);
 void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st);
+int persist_sweep_dpw(int D);
+// ---- sweep_synth.hip: the resident sweep with the slab of every bin evaluated inside the launch (Legendre addition theorem)
+bool synth_sweep_supported(int D, int nmics, int nOrd);
+int synth_nord_pad(int nOrd);
+// bsc [P][nord_pad] from bn [P][nOrd]; Pm [32][32] from the complex copy of pinv(Y_lo) (Zlo null: identity, raw microphones)
+// smap [34]: the chain's row order of the microphones (row -> microphone), then the numbers of antipodal pairs and of single microphones
+void launch_synth_prepare(const void* bn, int nOrd, int P, void* bsc, const void* Zlo, int ldZ, int nOut, int M, const int* smap, double* Pm, hipStream_t st);
+// Mt[kb] = Pm^T M_kb Pm for kb in [k0, P) (slot kb - 1 like Mw) and Winit = W(k0-1,:) Pm
+void launch_synth_mt(const void* Mw, const double* Pm, int nOut, int M, int k0, int P, const void* W, void* Mt, void* Winit, hipStream_t st);
+// W[e][kb][:] = (U[e][kb][:] Pm^T) conj(M_kb) for kb in [k0, P)
+void launch_synth_winit(const void* W, const void* Pm, int nOut, int M, int k0, int P, void* Winit, hipStream_t st, bool shared_geometry);
+// (shared_geometry: Pm and Mw are ONE design's for every lane of the launch)
+void launch_synth_rows(const void* U, int nchunks, const void* Pm, const void* Mw, int nOut, int M, int k_lo, int k_hi, int P, void* W, hipStream_t st,
+                       bool shared_geometry = false);
+// least-squares bins [kb_lo, kb_hi) of the Gram route: Upart[chunk][e][kb][row] = partial sums of H(kb,:) conj(g_kb) over a chunk of directions
+// (synth_ls_chunks(D) chunks; launch_synth_rows with that many chunks turns them into W)
+int synth_ls_chunks(int D);
+void launch_synth_ls(const void* Hc, int64_t ldH, int n_c, const void* bsc, int nord_pad, const double* dir_azi, const double* dir_zen, const double* mic_azi,
+                     const double* mic_zen, const int* smap, int D, int M, int P, int kb_lo, int kb_hi, void* Upart, hipStream_t st, bool shared_geometry = false);
+void launch_sweep_synth(const HalfSweepMulti& m, hipStream_t st);
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
 void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, bool y_cplx, int D, int S, void* Pw, void* out,
                     int ldS, hipStream_t st);
@@ -128,8 +148,10 @@ void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S
                int64_t ldD, hipStream_t st);
 // real_mode: complex basis evaluated on the real order terms (sh_order >= 0: channels are SH coefficients up to that order;
 // < 0: channels are independent, e.g. microphones)
+// k_end (< 0: P): bins [k0, k_end) only -- the designs whose sweep evaluates its operands itself (sweep_synth.hip) need G_k for their
+// least-squares bins alone
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
-                     hipStream_t st, int real_mode = 0, int sh_order = -1);
+                     hipStream_t st, int real_mode = 0, int sh_order = -1, int k_end = -1);
 void launch_cond_flags(const double* sv, int C, int P, int hh_end, double* cond_ok, hipStream_t st);
 void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S,
                          int C, int P, int k0, void* Yri, int64_t ldD, hipStream_t st);

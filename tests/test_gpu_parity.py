@@ -752,13 +752,16 @@ def test_batch_of_ema_in_ch_designs(thin):
         p.close()
 
 
-@pytest.mark.parametrize("mode", ["launch_per_bin", "persistent_write_through"])
+@pytest.mark.parametrize("mode", ["launch_per_bin", "persistent_write_through", "synthesising"])
 def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
-    """The phase sweep has three forms: the persistent launch with XCD-local granule stores (default when all
-    workgroups of a design share an XCD), the same with write-through stores (any placement), and one launch per
+    """The phase sweep on materialised operands has three forms: the persistent launch with XCD-local granule stores (default
+    when all workgroups of a design share an XCD), the same with write-through stores (any placement), and one launch per
     bin (shapes the persistent kernel does not cover).  They sum the per-workgroup partials in different fixed
-    orders, so they agree to rounding; each is bitwise reproducible."""
+    orders, so they agree to rounding; each is bitwise reproducible.  The synthesising sweep (sweep_synth.hip) evaluates
+    pwGrid from the angles between directions and microphones instead of the SH matrices: the same operand to 1e-15, the
+    same filters to what the bins' conditioning makes of that (measured 1e-8; the tolerance of the design path is 1e-6)."""
     from emagls_amd import Plan, _lib as L
+    monkeypatch.setenv("EMAGLS_SWEEP_SYNTH", "0")
 
     def run():
         p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], 0.042, 32)
@@ -779,11 +782,17 @@ def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
     assert n_default == 1  # the persistent kernel is the default
     if mode == "launch_per_bin":
         monkeypatch.setenv("EMAGLS_SWEEP_PERSIST", "0")
+    elif mode == "synthesising":
+        monkeypatch.setenv("EMAGLS_SWEEP_SYNTH", "1")
     else:
         monkeypatch.setenv("EMAGLS_PERSIST_GLOBAL", "1")
     (vL, vR), n_variant = run()
     assert (n_variant > 1) == (mode == "launch_per_bin")
-    assert rel(vL, dL) < 1e-12 and rel(vR, dR) < 1e-12
+    print(f"sweep variant {mode} vs default: rel = {max(rel(vL, dL), rel(vR, dR)):.3e}")
+    tol = 1e-6 if mode == "synthesising" else 1e-12
+    assert rel(vL, dL) < tol and rel(vR, dR) < tol
+    if mode == "synthesising":
+        assert rel(vL, dL) > 0   # (it did take the other kernel)
 
 
 def test_emagls2_filters_config4_shape(grids, hrirs):
@@ -1082,7 +1091,10 @@ def test_custom_sh_function(grids, thin, basis):
                      ("getEMagLs2Filters", (hL, hR, azi, zen) + mic + (3, 48000.0, 128))):
         bL, bR = getattr(E, fn)(*args, basis)
         cL, cR = getattr(E, fn)(*args, basis, O.getSH)
-        assert cL.dtype == bL.dtype and rel(cL, bL) < 1e-9 and rel(cR, bR) < 1e-9, (fn, rel(cL, bL), rel(cR, bR))
+        # (the built-in array designs take the synthesising sweep, a caller's matrices the materialised operands: the same filters
+        # to what the bins' conditioning makes of operands that agree to 1e-15)
+        tol_b = 1e-6 if "EMagLs" in fn else 1e-9
+        assert cL.dtype == bL.dtype and rel(cL, bL) < tol_b and rel(cR, bR) < tol_b, (fn, rel(cL, bL), rel(cR, bR))
         sL, sR = getattr(E, fn)(*args, basis, _sn3d_sh)
         oL, oR = getattr(O, fn)(*args, basis, shFunction=_sn3d_sh)
         assert report(fn + " SN3D shFunction " + basis, sL, oL) < TOL and rel(sR, oR) < TOL

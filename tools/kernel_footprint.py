@@ -32,7 +32,7 @@ def main():
         per[r[0]].append(r[1:])
     sweep_lds, sweep_waves, sweep_vgpr = 0, 0, 0
     for n, rows in per.items():
-        if "sweep_persist" in n:
+        if "sweep_persist" in n or "sweep_synth" in n:
             sweep_lds = max(r[2] for r in rows)
             sweep_waves = rows[0][0] // 64
             sweep_vgpr = (rows[0][5] + rows[0][6]) if len(rows[0]) > 6 else 0

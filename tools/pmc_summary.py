@@ -58,7 +58,7 @@ def read(d):
     dur = defaultdict(list)
     sweeps = defaultdict(list)
     for kname, cname, _, val, gz, ns in cur.execute(q2):
-        if "sweep_persist" in kname:      # (design = blockIdx.x there, not grid.z: the batch launches are the LAST ones of the run)
+        if "sweep_persist" in kname or "sweep_synth" in kname:      # (design = blockIdx.x there, not grid.z: the batch launches are the LAST ones of the run)
             sweeps[(kname, cname)].append((val, ns))
             continue
         if gz != LANES:
