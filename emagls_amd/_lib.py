@@ -30,7 +30,7 @@ class PlanInfo(C.Structure):
                 ("out_rows", c_i64), ("out_cols", c_i64), ("grp_delay_l", C.c_double), ("grp_delay_r", C.c_double),
                 ("mean_grid_dev_deg", C.c_double), ("num_sweep_launches", C.c_int), ("device_bytes", c_i64),
                 ("gram_from", C.c_int), ("hh_end", C.c_int), ("hh_orders", C.c_int), ("g_first", C.c_int),
-                ("sim_order_own", C.c_int)]
+                ("sim_order_own", C.c_int), ("sweep_form", C.c_int), ("sweep_units", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/emagls.h declares

@@ -87,6 +87,7 @@ struct HalfSweepArgs {
                              // inverse form, status word 4): the design's workgroups leave at once, the host re-runs on the launch-per-bin sweep
     long long* timing;       // optional [P][16] wall-clock stamps (EMAGLS_SWEEP_TIMING), else null
     int fetch_mode;          // persistent sweep: where the next bin's operands are requested (sweep_persist.hip; EMAGLS_SWEEP_FETCH, default 0)
+    long long wait_ticks;    // persistent sweep: ticks of the 100 MHz wall clock after which a wait for peers gives up (EMAGLS_SWEEP_WAIT_MS, default 20 ms)
     int force_global;        // persistent sweep: keep the write-through (sc1) stores even on one XCD (EMAGLS_PERSIST_GLOBAL=1)
     // operand synthesis (sweep_synth.hip): the chain runs on the C microphones, the slab of bin k is evaluated inside the launch as
     // g_k[d][j] = sum_n bsc[k][n] pi_n(cos(angle between HRIR direction d and microphone j)); Mw then holds Pm^T M_k Pm (C x C)

@@ -114,6 +114,7 @@ struct emagls_plan {
     // the design qualifies (built-in real SH machinery, <= 32 microphones, no covariance constraint); synth: it is in effect
     // (persistent sweep, no swept bin on the Householder route) -- plan_update_synth
     bool synth_want = false, synth = false;
+    int synth_units = 0;          // antipodal microphone pairs + single microphones (set with the microphone grid)
     bool synth_block = false;     // a batch whose designs do not all qualify keeps every one of them on the materialised operands
     const emagls_plan* geo_from = nullptr;   // set while a geometry-sharing batch runs this plan's stages on plan 0's geometry
     emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
@@ -400,13 +401,14 @@ static bool synth_enabled() { const char* e = getenv("EMAGLS_SWEEP_SYNTH"); retu
 static bool plan_persist_possible(const emagls_plan& p) {
     const int64_t Dh = (p.d.kind == EMAGLS_KIND_FROM_ATF) ? p.Dm : p.D;
     if (const char* e = getenv("EMAGLS_SWEEP_PERSIST")) if (e[0] == '0') return false;
-    return !p.wide && persist_sweep_supported((int)Dh, p.C) && persist_sweep_nwg((int)Dh) <= device_cu_count();
+    return !p.wide && persist_sweep_fits((int)Dh, p.C, 1);
 }
 // Is the synthesising sweep in effect?  Needs the persistent form (all workgroups resident) and every swept bin on the Gram
 // route (the ill-conditioned swept bins of tiny arrays read Y_reg_inv_k from memory: they keep the materialised operands).
 void plan_update_synth(emagls_plan& p) {
     const int k0 = std::max(p.kcut0, 1);
-    p.synth = p.synth_want && !p.synth_block && p.sweep_persist && p.hh_end <= k0 && p.gram_from > 0 && k0 < p.P;
+    p.synth = p.synth_want && !p.synth_block && p.sweep_persist && p.hh_end <= k0 && p.gram_from > 0 && k0 < p.P &&
+              synth_sweep_fits((int)p.D, (int)p.d.nmics, p.simOrder + 1, 1);
 }
 // buffers whose size depends on the routes (re-entered when a conditioning check moves the routes: alloc keeps what is large enough)
 void plan_alloc_routes(emagls_plan& p) {
@@ -440,6 +442,7 @@ void plan_alloc_routes(emagls_plan& p) {
             smap[33] = M;
             p.alloc("smap", sizeof smap);
             p.upload("smap", smap, sizeof smap);
+            p.synth_units = M;
             HIP_CHECK(hipStreamSynchronize(p.stream));
         }
         p.alloc("Mt", sizeof(cplx) * ((size_t)p.P * M * M + 1024));
@@ -1282,6 +1285,8 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
     a.force_global = (fg && fg[0] == '1') ? 1 : 0;
     static const int fetch_mode = [] { const char* e = getenv("EMAGLS_SWEEP_FETCH"); return e ? std::max(0, std::min(4, atoi(e))) : 0; }();
     a.fetch_mode = fetch_mode;
+    static const long long wait_ticks = [] { const char* e = getenv("EMAGLS_SWEEP_WAIT_MS"); return (long long)(e ? std::max(1, atoi(e)) : 20) * 100000ll; }();
+    a.wait_ticks = wait_ticks;
     if (p.synth) {   // the chain's channels are the microphones (sweep_synth.hip)
         const int M = (int)p.d.nmics;
         a.C = M;
@@ -1720,11 +1725,19 @@ void batch_sweep_stage(emagls_batch& b) {
     const int kk0 = std::max(q0.kcut0, 1);
     if (kk0 >= q0.P) return;
     if (q0.sweep_persist) {
-        SweepChain chain(b.stream);
-        for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, b.stream);
-        if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[0], b.stream));
-        if (q0.synth) launch_sweep_synth(h, b.stream); else launch_sweep_persist(h, b.stream);
-        if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[1], b.stream));
+        // (tried in round 4: the launch on a stream of the highest priority, so that the dispatcher places the sweep's workgroups
+        // before other batches' refilling kernels -- per batch, or one per device: 1744 against 1646 sets/s at 20 steps in one
+        // session, nothing in the next, and with six / eight batches in flight the extra streams, multiplexed onto hardware
+        // queues that held each other's waits, stalled runs for seconds (28-880 sets/s): rejected)
+        hipStream_t ss = b.stream;
+        {
+            SweepChain chain(ss);
+            for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, ss);
+            if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[0], ss));
+            if (q0.synth) launch_sweep_synth(h, ss); else launch_sweep_persist(h, ss);
+            if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[1], ss));
+        }
+        if (ss != b.stream) b.depend(b.stream, ss);
         return;
     }
     for (int kb = kk0; kb < q0.P; ++kb) launch_sweep_half(h, kb, b.stream);
@@ -2808,6 +2821,7 @@ int emagls_plan_set_mic_grid(emagls_plan* p, const double* azi, const double* ze
             int smap[34];
             synth_pairing(azi, zen, (int)p->d.nmics, smap);
             p->upload("smap", smap, sizeof smap);
+            p->synth_units = smap[32] + smap[33];
             HIP_CHECK(hipStreamSynchronize(p->stream));   // (the host array goes out of scope)
         }
         // kr = 2*pi*f/C * smaRadius on f = linspace(0, fs/2, P)   (getSMAIRMatrix.m:90,107)
@@ -2902,6 +2916,8 @@ int emagls_plan_get_info(emagls_plan* p, emagls_plan_info* info) {
         info->device_bytes = p->total_bytes;
         info->gram_from = p->gram_from; info->hh_end = p->hh_end; info->hh_orders = p->n_h + 1; info->g_first = p->g0;
         info->sim_order_own = array_kind(p->d.kind) ? p->simOrderOwn : p->simOrder;
+        info->sweep_form = p->d.kind == EMAGLS_KIND_LS ? 0 : (p->synth ? 2 : (p->sweep_persist ? 1 : 0));
+        info->sweep_units = p->synth ? p->synth_units : 0;
         if (p->executed) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
             double g[2];
@@ -3033,8 +3049,10 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         // two per CU beyond (77 KB of LDS and 5 waves per workgroup)
         // (up to 8 designs: 16 CUs stay free of sweep workgroups, so that kernels of other batches which need a whole CU keep
         // making progress and the dispatcher never has a reason to hold the sweep's own workgroups back)
-        const int nwg_b = persist_sweep_nwg((int)b->plans[0]->D);
-        const bool fits = nplans > 8 ? nplans * nwg_b <= 2 * device_cu_count() : nplans * nwg_b <= device_cu_count() - 16;
+        // (decided here, before any launch, from the runtime's occupancy of the kernel variant: persist_sweep_fits)
+        const emagls_plan& f0 = *b->plans[0];
+        const int64_t Dh0 = f0.d.kind == EMAGLS_KIND_FROM_ATF ? f0.Dm : f0.D;
+        const bool fits = f0.synth ? synth_sweep_fits((int)Dh0, (int)f0.d.nmics, f0.simOrder + 1, nplans) : persist_sweep_fits((int)Dh0, f0.C, nplans);
         for (auto* p : b->plans) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
             if (!fits && p->sweep_persist) { p->sweep_persist = false; if (p->synth_want) { plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); } }

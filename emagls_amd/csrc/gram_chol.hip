@@ -328,6 +328,135 @@ __global__ void __launch_bounds__(256) chol_update_kernel(T* __restrict__ G, int
     }
 }
 
+// The whole factorisation in ONE launch: a workgroup of 256 threads per design walks the block columns (diagonal block, row
+// panel, trailing update) with the panel's rows R(J, :) in LDS; the matrix itself stays in global memory (L2 resident: 512 KB at
+// S = 256).  The three-kernel form above costs 22 launches at S = 256 (8 x diag + 7 x panel + 7 x update: 290 us for 8
+// designs, every launch a dependent step of ~13 us) -- the chain of a design is latency, not work; one resident workgroup
+// per design removes the launch boundaries (dependent steps become workgroup barriers).
+//   panel: thread = one trailing column, forward substitution in registers against the factored diagonal block (LDS broadcast)
+//   update: 4 x 4 register tiles of the upper triangle of the trailing block, panel rows from LDS
+template <typename T>
+__global__ void __launch_bounds__(256) chol_fused_kernel(T* __restrict__ G, int S, int* __restrict__ flag, int ldp, size_t bstride) {
+    G = boff(G, bstride); flag = boff(flag, bstride);
+    __shared__ T Rd[NB][NB + 1];
+    __shared__ int bad_s;
+    extern __shared__ __attribute__((aligned(16))) char dynp[];
+    T* Ps = reinterpret_cast<T*>(dynp);   // [NB][ldp]: the panel's rows over the trailing columns
+    const int tid = threadIdx.x;
+    if (tid == 0) bad_s = 0;
+    for (int j0 = 0; j0 < S; j0 += NB) {
+        const int nb = min(NB, S - j0);
+        const int c0 = j0 + NB, W = max(S - c0, 0);   // trailing columns
+        __syncthreads();   // (the previous step's updates of G are visible; Rd / Ps are free)
+        // ---- diagonal block: 256 threads, two barriers per elimination step (chol_diag_kernel)
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int r = idx / NB, c = idx % NB;
+            Rd[r][c] = (r < nb && c < nb && r <= c) ? G[(int64_t)(j0 + r) * S + j0 + c] : zero_of<T>();
+        }
+        // the panel's rows load while the diagonal block is factored (they are only read after it)
+        for (int idx = tid; idx < NB * W; idx += 256) {
+            const int i = idx / W, c = idx % W;
+            Ps[(size_t)i * ldp + c] = i < nb ? G[(int64_t)(j0 + i) * S + c0 + c] : zero_of<T>();
+        }
+        __syncthreads();
+        const int r4 = tid >> 5, cc = tid & 31;
+        for (int j = 0; j < nb; ++j) {
+            const double piv = real_of(Rd[j][j]);
+            if (!(piv > 0.0) && tid == 0) bad_s = 1 + j0;
+            const double dinv = fast_rsqrt(piv > 0.0 ? piv : 1.0);
+            __syncthreads();
+            if (tid >= j && tid < nb) Rd[j][tid] = scale_real(Rd[j][tid], dinv);
+            __syncthreads();
+            const T rjc = Rd[j][cc];
+#pragma unroll
+            for (int i = 0; i < NB / 8; ++i) {
+                const int r = r4 + 8 * i;
+                if (r > j && r <= cc && cc < nb) {
+                    T acc = zero_of<T>();
+                    cfma_conj(acc, Rd[j][r], rjc);
+                    Rd[r][cc] = Rd[r][cc] - acc;
+                }
+            }
+            __syncthreads();
+        }
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int r = idx / NB, c = idx % NB;
+            if (r < nb && c < nb && r <= c) G[(int64_t)(j0 + r) * S + j0 + c] = Rd[r][c];
+        }
+        if (W == 0) break;
+        // ---- row panel: R(J, c) = L^-1 G(J, c), L = R_JJ^H; one column per thread, the column in registers
+        for (int c = tid; c < W; c += 256) {
+            T x[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) x[i] = Ps[(size_t)i * ldp + c];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (i < nb) {
+                    T acc = x[i];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        if (k < i) { T t = zero_of<T>(); cfma_conj(t, Rd[k][i], x[k]); acc = acc - t; }
+                    x[i] = scale_real(acc, 1.0 / real_of(Rd[i][i]));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (i < nb) {
+                    Ps[(size_t)i * ldp + c] = x[i];
+                    G[(int64_t)(j0 + i) * S + c0 + c] = x[i];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- trailing update: G(r, c) -= sum_i conj(R(i, r)) R(i, c), r <= c, in 4 x 4 tiles (tile rows tr <= tile columns tc)
+        const int nt = (W + 3) / 4;
+        const int ntiles = nt * (nt + 1) / 2;
+        for (int t = tid; t < ntiles; t += 256) {
+            // tile index -> (tr, tc), tr <= tc: row tr holds nt - tr tiles
+            int tr = 0, rem = t;
+            {   // closed form of the triangular index, then a correction step
+                const double nn = (double)nt + 0.5;
+                tr = (int)(nn - sqrt(nn * nn - 2.0 * (double)t));
+                if (tr < 0) tr = 0;
+                while (tr > 0 && tr * nt - tr * (tr - 1) / 2 > t) --tr;
+                while ((tr + 1) * nt - (tr + 1) * tr / 2 <= t) ++tr;
+                rem = t - (tr * nt - tr * (tr - 1) / 2);
+            }
+            const int tc = tr + rem;
+            const int r0 = 4 * tr, q0 = 4 * tc;
+            T acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = zero_of<T>();
+            for (int i = 0; i < nb; ++i) {
+                T pr[4], pc[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    pr[a] = Ps[(size_t)i * ldp + r0 + a];   // (ldp >= W + 4, zero beyond W)
+                    pc[a] = Ps[(size_t)i * ldp + q0 + a];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) cfma_conj(acc[a][b], pr[a], pc[b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int r = r0 + a, c = q0 + b;
+                    if (r < W && c < W && r <= c) {
+                        T* g = &G[(int64_t)(c0 + r) * S + c0 + c];
+                        *g = *g - acc[a][b];
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    if (bad_s && tid == 0) atomicExch(flag, bad_s);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Q = Yc R^-1, blocked by 32 columns.  A workgroup owns 8 rows (directions) and keeps their finished Q
 // entries in LDS; thread = (row r = tid/32, column-in-block c = tid%32).  Per block J:
@@ -527,7 +656,23 @@ void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, voi
     if (is_cplx) gram_impl<cplx>(Yc, D, S, ld, Gp, G, R, Sh, st); else gram_impl<double>(Yc, D, S, ld, Gp, G, R, Sh, st);
 }
 
+// EMAGLS_CHOL_FUSED=0: the three-kernel form for every size
+static bool chol_fused_enabled() { static const bool on = [] { const char* e = getenv("EMAGLS_CHOL_FUSED"); return !(e && e[0] == '0'); }(); return on; }
 template <typename T> static void chol_impl(void* G, int S, int* flag, hipStream_t st) {
+    {   // one resident workgroup per design while the panel's rows fit the LDS (S <= 544 real, 288 complex)
+        const int W = std::max(S - NB, 0), ldp = (W + 4 + 3) / 4 * 4 + 4;
+        const size_t dyn = sizeof(T) * (size_t)NB * ldp;
+        if (chol_fused_enabled() && S > NB && dyn <= 130 * 1024) {
+            static PerDeviceOnce attr_once;
+            if (attr_once.first()) {
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fused_kernel<cplx>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+            }
+            chol_fused_kernel<T><<<bgrid(1), 256, dyn, st>>>((T*)G, S, flag, ldp, batch_ctx().stride);
+            KERNEL_CHECK();
+            return;
+        }
+    }
     for (int j0 = 0; j0 < S; j0 += NB) {
         const int rem = S - j0;
         const int ncb = (rem + NB - 1) / NB;  // column blocks incl. the diagonal one

@@ -93,6 +93,11 @@ bool persist_sweep_supported(int D, int C);
 size_t persist_sweep_ll_bytes(int D, int C);
 void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st);
 int persist_sweep_dpw(int D);
+// residency, decided before a launch: the runtime's occupancy of the kernel variant x the CUs of an XCD (EMAGLS_CU_BUDGET overrides
+// the device's CU count) against the workgroups `ndesigns` designs place there
+int sweep_cu_budget();
+bool persist_sweep_fits(int D, int C, int ndesigns);
+bool synth_sweep_fits(int D, int nmics, int nOrd, int ndesigns);
 // ---- sweep_synth.hip: the resident sweep with the slab of every bin evaluated inside the launch (Legendre addition theorem)
 bool synth_sweep_supported(int D, int nmics, int nOrd);
 int synth_nord_pad(int nOrd);

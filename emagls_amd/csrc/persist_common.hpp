@@ -11,6 +11,10 @@ namespace {
 // XCD (32 CUs), so nWG = ceil(D / DPW) must not exceed 32: DPW = 64 up to 2048 directions, 96 up to 3072.
 constexpr int PS_CMAX = 32;
 constexpr unsigned PS_SPIN_LIMIT = 1u << 21;
+// a wait for peers gives up after this many ticks of the 100 MHz wall clock (20 ms: a kernel of another batch that holds a CU
+// for a millisecond or two is waited out; a peer that cannot become resident is not -- residency is decided before the launch,
+// persist_sweep_fits, so this only fires when something else took the CUs in between)
+constexpr long long PS_WAIT_TICKS = 2000000;
 typedef unsigned long long u64;
 
 __device__ __forceinline__ cplx unit_phase(double h, cplx p, bool nyquist) {
@@ -51,8 +55,9 @@ __device__ __forceinline__ double ll_value(u64 lo, u64 hi) {
 __device__ __forceinline__ bool ll_ok(u64 w, unsigned tag) { return (unsigned)(w >> 32) == tag; }
 
 // wave-uniform wait: returns false when the wait was abandoned
-template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and_check, int* abort_flag, unsigned* nspins = nullptr, long long* t_first = nullptr) {
+template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and_check, int* abort_flag, long long wait_ticks, unsigned* nspins = nullptr, long long* t_first = nullptr) {
     unsigned spins = 0;
+    long long t_begin = 0;
     for (;;) {
         const bool ok = load_and_check();
         if (t_first && spins == 0) *t_first = (long long)wall_clock64();
@@ -60,7 +65,12 @@ template <typename Load> __device__ __forceinline__ bool ll_wait(Load&& load_and
         __builtin_amdgcn_s_sleep(1);
         ++spins;
         if ((spins & 255u) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        if (spins >= PS_SPIN_LIMIT) {
+        bool timed_out = false;
+        if ((spins & 255u) == 0) {   // (the wall clock only every 256 polls: ~0.1 ms)
+            const long long now = (long long)wall_clock64();
+            if (t_begin == 0) t_begin = now; else timed_out = now - t_begin > wait_ticks;
+        }
+        if (spins >= PS_SPIN_LIMIT || timed_out) {
             __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }

@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMult
             if (lane >= nWG) return true;
             w = ll_load(xcc_ll + lane);
             return ll_ok(w, tag0);
-        }, a.abort_flag);
+        }, a.abort_flag, a.wait_ticks);
         const bool same = lane >= nWG || (unsigned)w == xcc;
         if (lane == 0) {
             s_local = alive && __builtin_amdgcn_ballot_w64(!same) == 0 && a.force_global == 0;
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMult
                             bool ok = ll_ok(w0, tag) && ll_ok(w1, tag) && ll_ok(w2, tag) && ll_ok(w3, tag);
                             if (twoq) ok = ok && ll_ok(u0, tag) && ll_ok(u1, tag) && ll_ok(u2, tag) && ll_ok(u3, tag);
                             return ok;
-                        }, a.abort_flag, &spins1, (a.timing && member == 1 && lane == 0 && qb == slab) ? &a.timing[(int64_t)kb * 16 + 6] : nullptr);
+                        }, a.abort_flag, a.wait_ticks, &spins1, (a.timing && member == 1 && lane == 0 && qb == slab) ? &a.timing[(int64_t)kb * 16 + 6] : nullptr);
                         const double re = group_sum<32>(act ? ll_value(w0, w1) : 0.0);
                         const double im = group_sum<32>(act ? ll_value(w2, w3) : 0.0);
                         const double re2 = group_sum<32>(twoq ? ll_value(u0, u1) : 0.0);
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMult
                             ok = ll_ok(u0, tag) && ll_ok(u1, tag) && ll_ok(u2, tag) && ll_ok(u3, tag);
                         }
                         return ok && ll_ok(w0, tag) && ll_ok(w1, tag) && ll_ok(w2, tag) && ll_ok(w3, tag);
-                    }, a.abort_flag, &spins1, (a.timing && member == 1 && lane == 0 && q == member) ? &a.timing[(int64_t)kb * 16 + 6] : nullptr);
+                    }, a.abort_flag, a.wait_ticks, &spins1, (a.timing && member == 1 && lane == 0 && q == member) ? &a.timing[(int64_t)kb * 16 + 6] : nullptr);
                     const double re = wave_sum(lane < nWG ? ll_value(w0, w1) : 0.0);
                     const double im = wave_sum(lane < nWG ? ll_value(w2, w3) : 0.0);
                     double re2 = 0.0, im2 = 0.0;
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(PS_NT * NH) sweep_persist_kernel(HalfSweepMult
                         if (x0 < nd2) { w0 = ll_load(src + x0); w1 = ll_load(src + nd2 + x0); ok = ll_ok(w0, tag) && ll_ok(w1, tag); }
                         if (x1 < nd2) { w2 = ll_load(src + x1); w3 = ll_load(src + nd2 + x1); ok = ok && ll_ok(w2, tag) && ll_ok(w3, tag); }
                         return ok;
-                    }, a.abort_flag);
+                    }, a.abort_flag, a.wait_ticks);
                     double* vd = reinterpret_cast<double*>(vt);
                     // double x = 2 (e C + c) + re/im  ->  padded slot 2 (32 e + c) + re/im
                     if (x0 < nd2) vd[x0 + ((x0 >> 1) >= C ? 2 * (PS_CMAX - C) : 0)] = ll_value(w0, w1);
@@ -454,9 +454,54 @@ size_t persist_sweep_ll_bytes(int D, int C) {
     const size_t nprod = 2 * (size_t)ceil_div(persist_sweep_nwg(D), 2);
     return sizeof(u64) * ((size_t)2 * nprod * 8 * C + (size_t)2 * 8 * C + 64);
 }
+
 // EMAGLS_SWEEP_TWIN=0: launches of 9-16 designs as two independent 256-thread workgroups per CU (the earlier form)
 // (read at every launch: a test switches forms inside one process)
 static bool sweep_twin_enabled() { const char* e = getenv("EMAGLS_SWEEP_TWIN"); return !(e && e[0] == '0'); }
+static void persist_set_attributes() {
+    static PerDeviceOnce attr_once;   // (function attributes are per device)
+    if (attr_once.first()) {
+#define EMAGLS_PS_ATTR(D, N) do { \
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<D, N, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<D, N, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); } while (0)
+        EMAGLS_PS_ATTR(64, 2); EMAGLS_PS_ATTR(64, 4); EMAGLS_PS_ATTR(64, 7); EMAGLS_PS_ATTR(64, 8);
+        EMAGLS_PS_ATTR(96, 2); EMAGLS_PS_ATTR(96, 4); EMAGLS_PS_ATTR(96, 7); EMAGLS_PS_ATTR(96, 8);
+#undef EMAGLS_PS_ATTR
+    }
+}
+static const void* persist_kernel_ptr(int dpw, int ni, int nh) {
+#define EMAGLS_PS_PTR(D, N) (nh == 2 ? reinterpret_cast<const void*>(sweep_persist_kernel<D, N, 2>) : reinterpret_cast<const void*>(sweep_persist_kernel<D, N, 1>))
+    if (dpw == 64) return ni == 2 ? EMAGLS_PS_PTR(64, 2) : ni == 4 ? EMAGLS_PS_PTR(64, 4) : ni == 7 ? EMAGLS_PS_PTR(64, 7) : EMAGLS_PS_PTR(64, 8);
+    return ni == 2 ? EMAGLS_PS_PTR(96, 2) : ni == 4 ? EMAGLS_PS_PTR(96, 4) : ni == 7 ? EMAGLS_PS_PTR(96, 7) : EMAGLS_PS_PTR(96, 8);
+#undef EMAGLS_PS_PTR
+}
+static int persist_ni(int C) { return C <= 8 ? 2 : (C <= 16 ? 4 : (C <= 28 ? 7 : 8)); }
+static size_t persist_dyn_bytes(int dpw, int ni, int nh) {
+    const size_t rows = 4 * (size_t)ni;   // (only the swept channel quarters take LDS: 28 rows for the 25 channels of order 4)
+    return sizeof(cplx) * ((size_t)nh * rows * (dpw + 4) + rows * PS_MLD + (size_t)nh * 2 * dpw);
+}
+// CUs the resident kernels may count on: the device's, or EMAGLS_CU_BUDGET (a CU-masked queue, a shared GPU; read at every call)
+int sweep_cu_budget() {
+    int dev = 0, n = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    if (const char* e = getenv("EMAGLS_CU_BUDGET")) { const int b = atoi(e); if (b > 0 && b < n) n = b; }
+    return n;
+}
+// Can `ndesigns` designs' workgroups of the resident sweep all be on the device at once?  The runtime's occupancy figure for the
+// kernel variant (registers, LDS, waves per CU) times the CUs of one XCD against the workgroups a design pair places there --
+// decided BEFORE the launch: a sweep whose workgroups cannot all become resident would wait for its peers until the time-out.
+bool persist_sweep_fits(int D, int C, int ndesigns) {
+    if (!persist_sweep_supported(D, C) || ndesigns < 1 || ndesigns > SWEEP_MULTI_MAX) return false;
+    persist_set_attributes();
+    const bool twin = ndesigns > 8 && sweep_twin_enabled();
+    const int nh = twin ? 2 : 1, dpw = persist_sweep_dpw(D), ni = persist_ni(C);
+    const int nWG = (int)ceil_div(persist_sweep_nwg(D), nh);
+    int occ = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, persist_kernel_ptr(dpw, ni, nh), PS_NT * nh, persist_dyn_bytes(dpw, ni, nh)));
+    const int per_xcd = (ndesigns > 8 ? 2 : 1) * nWG;
+    return per_xcd <= occ * (sweep_cu_budget() / 8);
+}
 
 void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const HalfSweepArgs& a = m.a[0];
@@ -467,18 +512,9 @@ void launch_sweep_persist(const HalfSweepMulti& m, hipStream_t st) {
     const int nWG = (int)ceil_div(nSlab, nh);
     const unsigned nblocks = 8u * (unsigned)nWG * (m.n > 8 ? 2u : 1u);
     const int dpw = persist_sweep_dpw(a.D);
-    const int ni = a.C <= 8 ? 2 : (a.C <= 16 ? 4 : (a.C <= 28 ? 7 : 8));
-    const size_t rows = 4 * (size_t)ni;   // (only the swept channel quarters take LDS: 28 rows for the 25 channels of order 4)
-    const size_t dyn = sizeof(cplx) * ((size_t)nh * rows * (dpw + 4) + rows * PS_MLD + (size_t)nh * 2 * dpw);
-    static PerDeviceOnce attr_once;   // (function attributes are per device)
-    if (attr_once.first()) {
-#define EMAGLS_PS_ATTR(D, N) do { \
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<D, N, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_persist_kernel<D, N, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); } while (0)
-        EMAGLS_PS_ATTR(64, 2); EMAGLS_PS_ATTR(64, 4); EMAGLS_PS_ATTR(64, 7); EMAGLS_PS_ATTR(64, 8);
-        EMAGLS_PS_ATTR(96, 2); EMAGLS_PS_ATTR(96, 4); EMAGLS_PS_ATTR(96, 7); EMAGLS_PS_ATTR(96, 8);
-#undef EMAGLS_PS_ATTR
-    }
+    const int ni = persist_ni(a.C);
+    const size_t dyn = persist_dyn_bytes(dpw, ni, nh);
+    persist_set_attributes();
 #define EMAGLS_PS_GO(D, N) do { if (twin) sweep_persist_kernel<D, N, 2><<<dim3(nblocks), 2 * PS_NT, dyn, st>>>(m, nWG); \
                                 else sweep_persist_kernel<D, N, 1><<<dim3(nblocks), PS_NT, dyn, st>>>(m, nWG); } while (0)
     if (dpw == 64) { if (ni == 2) EMAGLS_PS_GO(64, 2); else if (ni == 4) EMAGLS_PS_GO(64, 4); else if (ni == 7) EMAGLS_PS_GO(64, 7); else EMAGLS_PS_GO(64, 8); }

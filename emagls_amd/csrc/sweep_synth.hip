@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(SY_NT) sweep_synth_kernel(HalfSweepMulti m, in
             if (lane >= nWG) return true;
             w = ll_load(xcc_ll + lane);
             return ll_ok(w, tag0);
-        }, a.abort_flag);
+        }, a.abort_flag, a.wait_ticks);
         const bool same = lane >= nWG || (unsigned)w == xcc;
         if (lane == 0) {
             s_local = alive && __builtin_amdgcn_ballot_w64(!same) == 0 && a.force_global == 0;
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(SY_NT) sweep_synth_kernel(HalfSweepMulti m, in
                             ok = ok && ll_ok(t0, tag) && ll_ok(t1, tag) && ll_ok(t2, tag) && ll_ok(t3, tag);
                         }
                         return ok && ll_ok(w0, tag) && ll_ok(w1, tag) && ll_ok(w2, tag) && ll_ok(w3, tag);
-                    }, a.abort_flag, &spins1, (a.timing && member == 1 && lane == 0 && q == member) ? &a.timing[(int64_t)kb * 16 + 6] : nullptr);
+                    }, a.abort_flag, a.wait_ticks, &spins1, (a.timing && member == 1 && lane == 0 && q == member) ? &a.timing[(int64_t)kb * 16 + 6] : nullptr);
                     const double re = wave_sum(lane < nWG ? ll_value(w0, w1) : 0.0);
                     const double im = wave_sum(lane < nWG ? ll_value(w2, w3) : 0.0);
                     double re2 = 0.0, im2 = 0.0, re3 = 0.0, im3 = 0.0;
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(SY_NT) sweep_synth_kernel(HalfSweepMulti m, in
                         if (x0 < nd2) { w0 = ll_load(src + x0); w1 = ll_load(src + nd2 + x0); ok = ll_ok(w0, tag) && ll_ok(w1, tag); }
                         if (x1 < nd2) { w2 = ll_load(src + x1); w3 = ll_load(src + nd2 + x1); ok = ok && ll_ok(w2, tag) && ll_ok(w3, tag); }
                         return ok;
-                    }, a.abort_flag);
+                    }, a.abort_flag, a.wait_ticks);
                     double* vd = reinterpret_cast<double*>(vt);
                     // double x = 2 (e C + c) + re/im  ->  padded slot 2 (32 e + c) + re/im
                     if (x0 < nd2) vd[x0 + ((x0 >> 1) >= C ? 2 * (PS_CMAX - C) : 0)] = ll_value(w0, w1);
@@ -648,15 +648,7 @@ void launch_synth_rows(const void* U, int nchunks, const void* Pm, const void* M
     KERNEL_CHECK();
 }
 
-void launch_sweep_synth(const HalfSweepMulti& m, hipStream_t st) {
-    const HalfSweepArgs& a = m.a[0];
-    const int nWG = persist_sweep_nwg(a.D);
-    if (!synth_sweep_supported(a.D, a.C, a.nord_pad) || m.n > SWEEP_MULTI_MAX) throw Error(2, "synthesising sweep: shape not supported");
-    const unsigned nblocks = 8u * (unsigned)nWG * (m.n > 8 ? 2u : 1u);
-    const int dpw = persist_sweep_dpw(a.D);
-    const int ni = a.C <= 8 ? 2 : (a.C <= 16 ? 4 : 8);
-    const size_t rows = 4 * (size_t)ni;
-    const size_t dyn = sizeof(cplx) * (rows * (dpw + 4) + rows * SY_MLD + (size_t)2 * dpw);
+static void synth_set_attributes() {
     static PerDeviceOnce attr_once;   // (function attributes are per device)
     if (attr_once.first()) {
 #define EMAGLS_SY_ATTR(D, N) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_synth_kernel<D, N>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
@@ -664,6 +656,38 @@ void launch_sweep_synth(const HalfSweepMulti& m, hipStream_t st) {
         EMAGLS_SY_ATTR(96, 2); EMAGLS_SY_ATTR(96, 4); EMAGLS_SY_ATTR(96, 8);
 #undef EMAGLS_SY_ATTR
     }
+}
+static int synth_ni(int M) { return M <= 8 ? 2 : (M <= 16 ? 4 : 8); }
+static size_t synth_dyn_bytes(int dpw, int ni) {
+    const size_t rows = 4 * (size_t)ni;
+    return sizeof(cplx) * (rows * (dpw + 4) + rows * SY_MLD + (size_t)2 * dpw);
+}
+static const void* synth_kernel_ptr(int dpw, int ni) {
+#define EMAGLS_SY_PTR(D, N) reinterpret_cast<const void*>(sweep_synth_kernel<D, N>)
+    if (dpw == 64) return ni == 2 ? EMAGLS_SY_PTR(64, 2) : ni == 4 ? EMAGLS_SY_PTR(64, 4) : EMAGLS_SY_PTR(64, 8);
+    return ni == 2 ? EMAGLS_SY_PTR(96, 2) : ni == 4 ? EMAGLS_SY_PTR(96, 4) : EMAGLS_SY_PTR(96, 8);
+#undef EMAGLS_SY_PTR
+}
+// residency of the synthesising sweep, decided before the launch like persist_sweep_fits
+bool synth_sweep_fits(int D, int nmics, int nOrd, int ndesigns) {
+    if (!synth_sweep_supported(D, nmics, nOrd) || ndesigns < 1 || ndesigns > SWEEP_MULTI_MAX) return false;
+    synth_set_attributes();
+    const int dpw = persist_sweep_dpw(D), ni = synth_ni(nmics);
+    int occ = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, synth_kernel_ptr(dpw, ni), SY_NT, synth_dyn_bytes(dpw, ni)));
+    const int per_xcd = (ndesigns > 8 ? 2 : 1) * persist_sweep_nwg(D);
+    return per_xcd <= occ * (sweep_cu_budget() / 8);
+}
+
+void launch_sweep_synth(const HalfSweepMulti& m, hipStream_t st) {
+    const HalfSweepArgs& a = m.a[0];
+    const int nWG = persist_sweep_nwg(a.D);
+    if (!synth_sweep_supported(a.D, a.C, a.nord_pad) || m.n > SWEEP_MULTI_MAX) throw Error(2, "synthesising sweep: shape not supported");
+    const unsigned nblocks = 8u * (unsigned)nWG * (m.n > 8 ? 2u : 1u);
+    const int dpw = persist_sweep_dpw(a.D);
+    const int ni = synth_ni(a.C);
+    const size_t dyn = synth_dyn_bytes(dpw, ni);
+    synth_set_attributes();
 #define EMAGLS_SY_GO(D, N) sweep_synth_kernel<D, N><<<dim3(nblocks), SY_NT, dyn, st>>>(m, nWG)
     if (dpw == 64) { if (ni == 2) EMAGLS_SY_GO(64, 2); else if (ni == 4) EMAGLS_SY_GO(64, 4); else EMAGLS_SY_GO(64, 8); }
     else { if (ni == 2) EMAGLS_SY_GO(96, 2); else if (ni == 4) EMAGLS_SY_GO(96, 4); else EMAGLS_SY_GO(96, 8); }

@@ -269,6 +269,11 @@ typedef struct emagls_plan_info {
      * g_first: first bin whose direction-space operand G_k is formed */
     int gram_from, hh_end, hh_orders, g_first;
     int sim_order_own;               /* the design's own simulation order (sim_order is the padded one with sim_order_pad) */
+    /* form of the phase sweep the next execute takes: 0 one launch per bin, 1 one resident launch on operands G_k materialised
+     * in HBM, 2 one resident launch that evaluates its operands itself from the angles between HRIR directions and microphones
+     * (array designs on the built-in SH basis; EMAGLS_SWEEP_SYNTH=0 selects form 1).  sweep_units: form 2, the polynomial
+     * evaluations per direction and bin -- antipodal microphone pairs count once (15 pairs + 2 single capsules on the em32). */
+    int sweep_form, sweep_units;
 } emagls_plan_info;
 
 int emagls_plan_create(const emagls_design_desc* desc, emagls_plan** plan);

@@ -795,6 +795,119 @@ def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
         assert rel(vL, dL) > 0   # (it did take the other kernel)
 
 
+@pytest.mark.parametrize("nmics,paired", [(32, "em32"), (32, "none"), (20, "some"), (12, "none"), (7, "none")])
+def test_synthesising_sweep_on_other_arrays(grids, thin, monkeypatch, nmics, paired):
+    """sweep_synth.hip evaluates pwGrid from the angles between HRIR directions and microphones; antipodal microphone pairs share
+    one polynomial evaluation (g(-x) from the even and odd parts of g(x)).  Arrays with every, some and no antipodal pair, 7 to 32
+    microphones (8-, 16- and 32-row slabs): against the oracle, against the materialised operands (EMAGLS_SWEEP_SYNTH=0) and
+    with the pairing switched off (EMAGLS_SYNTH_PAIRS=0 is read once per process, so that comparison runs in the default
+    process only through the plan's unit count)."""
+    import emagls_amd as E
+    from emagls_amd import Plan, _lib as L
+    rng = np.random.default_rng(1000 + nmics)
+    if paired == "em32":
+        maz, mzn = grids["mic_azi"], grids["mic_zen"]
+    else:
+        # a spread-out array (a jittered spherical Fibonacci lattice: a random placement is so ill-conditioned that the oracle
+        # itself moves by more than the tolerance with the rounding of its SVD, DESIGN.md section 3)
+        from emagls_amd import synth
+        nbase = nmics - 6 if paired == "some" else nmics
+        maz, mzn = synth.fibonacci_grid(nbase)
+        maz = maz + 0.05 * rng.standard_normal(nbase)
+        mzn = np.clip(mzn + 0.05 * rng.standard_normal(nbase), 0.05, np.pi - 0.05)
+        if paired == "some":   # six microphones of the upper half get exact antipodes at the end of the list
+            up = np.argsort(mzn)[:6]
+            maz = np.concatenate([maz, maz[up] + np.pi])
+            mzn = np.concatenate([mzn, np.pi - mzn[up]])
+    N = 2 if nmics < 16 else (3 if nmics < 25 else 4)   # (orders whose Gram route starts below k_cut: every swept bin qualifies)
+    hL, hR, azi, zen = thin["hL"], thin["hR"], thin["azi"], thin["zen"]
+    p = Plan(L.KIND_EMAGLS2, "real", N, 48000.0, 128, hL.shape[0], hL.shape[1], 0.042, nmics)
+    p.set_hrir_grid(azi, zen)
+    p.set_mic_grid(maz, mzn)
+    i = p.info()
+    want_units = {"em32": 17, "none": nmics, "some": nmics - 6}[paired]
+    assert i.sweep_form == 2 and i.sweep_units == want_units, (i.sweep_form, i.sweep_units)
+    p.close()
+    for fn, extra in (("getEMagLs2Filters", ()), ("getEMagLsFilters", ())):
+        if fn == "getEMagLsFilters" and nmics < (N + 1) ** 2:
+            continue
+        args = (hL, hR, azi, zen, 0.042, maz, mzn, N, 48000.0, 128, "real")
+        w = getattr(E, fn)(*args)
+        o = getattr(O, fn)(*args)
+        e_o = max(rel(w[0], o[0]), rel(w[1], o[1]))
+        monkeypatch.setenv("EMAGLS_SWEEP_SYNTH", "0")
+        L.check(L.load().emagls_cache_clear())   # (the one-shot plan cache holds the synthesising plan of this shape)
+        m = getattr(E, fn)(*args)
+        monkeypatch.delenv("EMAGLS_SWEEP_SYNTH")
+        L.check(L.load().emagls_cache_clear())
+        e_m = max(rel(w[0], m[0]), rel(w[1], m[1]))
+        print(f"synthesising sweep, {fn}, {nmics} microphones ({paired} pairs, {want_units} units): rel vs oracle = {e_o:.3e}, vs materialised operands = {e_m:.3e}")
+        assert e_o < TOL and e_m < TOL and e_m > 0
+
+
+def test_residency_is_decided_before_the_launch(grids, thin, monkeypatch):
+    """A resident sweep needs all its workgroups on the device at once.  Whether they fit is decided BEFORE the launch from the
+    runtime's occupancy figure of the kernel variant and the CUs of an XCD (EMAGLS_CU_BUDGET stands in for a CU-masked queue or
+    a shared GPU): a design or a batch that cannot be resident takes the launch-per-bin sweep at once -- no wait for peers until
+    a time-out (the 0.2 s stall of earlier rounds), same filters."""
+    import ctypes
+    import time
+    from emagls_amd import Batch, Plan, _lib as L
+
+    def plan(j=0):
+        p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], 0.042, 32)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(grids["mic_azi"] + 0.05 * j, grids["mic_zen"])
+        p.set_hrirs(thin["hL"] * (1.0 + 0.1 * j), thin["hR"])
+        return p
+
+    p = plan()
+    p.execute()
+    ref = p.get_filters()
+    assert p.info().sweep_form == 2 and p.info().num_sweep_launches == 1   # resident, operands evaluated in the launch
+    p.close()
+    # 901 directions = 15 workgroups per design on one XCD: 4 CUs per XCD cannot hold them
+    monkeypatch.setenv("EMAGLS_CU_BUDGET", "32")
+    p = plan()
+    assert p.info().sweep_form == 0
+    t0 = time.perf_counter()
+    p.execute()
+    out = p.get_filters()
+    dt = time.perf_counter() - t0
+    assert p.info().num_sweep_launches > 1
+    p.close()
+    print(f"one design without room for a resident sweep: launch per bin from the start, first execute {dt * 1e3:.1f} ms, "
+          f"rel vs the resident form = {max(rel(out[0], ref[0]), rel(out[1], ref[1])):.3e}")
+    assert dt < 0.15 and rel(out[0], ref[0]) < 1e-6 and rel(out[1], ref[1]) < 1e-6
+    # 8 CUs per XCD: one design fits (two workgroups per CU), the 12 designs of a batch (two designs per XCD) do not
+    monkeypatch.setenv("EMAGLS_CU_BUDGET", "64")
+    plans = [plan(j) for j in range(12)]
+    singles = []
+    for q in plans:
+        assert q.info().sweep_form == 2
+        q.execute()
+        singles.append(q.get_filters())
+    lib = L.load()
+    prev = ctypes.c_int(0)
+    L.check(lib.emagls_set_batch_max(16, ctypes.byref(prev)))
+    try:
+        b = Batch(plans)
+    finally:
+        L.check(lib.emagls_set_batch_max(prev.value, None))
+    assert plans[0].info().sweep_form == 0
+    t0 = time.perf_counter()
+    b.execute()
+    outs = b.get_filters()
+    dt = time.perf_counter() - t0
+    worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(outs, singles))
+    print(f"12-design batch without room for its resident sweep: launch per bin from the start, first execute {dt * 1e3:.1f} ms, "
+          f"worst rel vs the single designs = {worst:.3e}")
+    assert dt < 0.5 and worst < 1e-6
+    b.close()
+    for q in plans:
+        q.close()
+
+
 def test_emagls2_filters_config4_shape(grids, hrirs):
     """BASELINE config 4, one job of the radius batch: raw 32-mic em32, 2702 directions, 1024 taps (nfft 2048,
     1024 solved bins, k_cut 86), default real basis."""

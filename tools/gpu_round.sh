@@ -27,8 +27,9 @@ timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${tag}_prof_slots4 -o benc
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_hrirsets -o hs -- python3 $R/tools/experiments/hrir_sets_prof.py 4 > $R/gpurun_out/${tag}_prof_hrirsets.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_default20 -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_default20.log 2>&1
 if [ "$pmc" = "pmc" ]; then
-  # counters in passes of their own (kernel-trace only next to --pmc); one batch of 8 designs, 4 batches executed
-  PMCCMD="python3 $R/bench.py --steps 32 --warmup 0 --slots 1 --batch 8 --no-cpu-baseline --no-sh-roofline --no-secondary"
+  # counters in passes of their own (kernel-trace only next to --pmc); one batch of 16 designs (the bench's default: two lane
+  # groups of 8 before one 16-design sweep launch), 4 batches executed
+  PMCCMD="python3 $R/bench.py --steps 64 --warmup 0 --slots 1 --batch 16 --no-cpu-baseline --no-sh-roofline --no-secondary"
   for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do
     timeout 400 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/${tag}_pmc_$c -o pmc -- $PMCCMD > $R/gpurun_out/${tag}_pmc_$c.log 2>&1
   done

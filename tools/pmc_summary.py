@@ -27,7 +27,9 @@ def demangle(n):
     return d or n
 
 
-LANES = 8   # designs per batch in the profiled command
+LANES = 8   # grid.z of the stages before the sweep in the profiled command (a 16-design batch runs them as two lane groups of 8)
+SWEEP_DESIGNS = int(os.environ.get("EMAGLS_PMC_SWEEP_DESIGNS", "16"))   # designs one sweep launch of the profiled command covers
+ONCE_PER_GROUP = "hrir_fft"   # a kernel every lane group launches exactly once per execute (counts the executes of the run)
 
 
 def read(d):
@@ -65,9 +67,10 @@ def read(d):
             continue          # (the single-design plan bench.py also runs: not part of the per-batch figures)
         out[kname][cname].append(val)
         dur[kname].append(ns)
-    n_exec = max([len(v) for k, cs in out.items() if "dspace_g" in k for v in cs.values()] or [1])
+    n_exec = max([len(v) for k, cs in out.items() if ONCE_PER_GROUP in k for v in cs.values()] or [1])
+    n_sweeps = max(1, n_exec * LANES // SWEEP_DESIGNS)   # (batch executes of the run: the last launches are the batch's)
     for (kname, cname), lst in sweeps.items():
-        lst = lst[-n_exec:]
+        lst = lst[-n_sweeps:]
         out[kname][cname] = [v for v, _ in lst]
         dur[kname] = [ns for _, ns in lst]
     res = {k: {c: (sum(v) / len(v), len(v)) for c, v in cs.items()} for k, cs in out.items()}
@@ -84,8 +87,9 @@ def main():
             merged[k].update(cs)
     res = {"note": "means per dispatch from separate rocprofv3 --pmc passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE "
                    "doubled per the gfx950 correction of MI355X_MICROARCH.md; WRITE_SIZE matched the algorithmic bytes on sh_basis_kernel)",
-           "designs_per_launch": LANES, "build": os.environ.get("EMAGLS_BUILD_TAG", "?")}
+           "designs_per_launch": LANES, "designs_per_sweep_launch": SWEEP_DESIGNS, "build": os.environ.get("EMAGLS_BUILD_TAG", "?")}
     per_set = 0.0
+    sweep_set = 0.0
     rows = []
     launches_per_batch = {}
     for k, cs in merged.items():
@@ -102,16 +106,20 @@ def main():
             e["write_kb"] = e.get("WRITE_SIZE", 0.0)
             e["bytes"] = int((2 * e["fetch_kb"] + e["write_kb"]) * 1024)
             launches_per_batch[name] = nd
-            per_set += e["bytes"] * nd
+            if "sweep_persist" in name or "sweep_synth" in name:
+                sweep_set += e["bytes"] / float(SWEEP_DESIGNS)   # (one launch per batch execute, SWEEP_DESIGNS designs each)
+            else:
+                per_set += e["bytes"] * nd
         base = name.split("<")[0]
-        key = base if base in ("sweep_persist_kernel", "sweep_half_kernel", "dspace_g_kernel") else name
+        key = base if base in ("sweep_persist_kernel", "sweep_synth_kernel", "sweep_half_kernel", "dspace_g_kernel") else name
         res[key] = e
         rows.append((name, e))
     # batch executions in the run = dispatches of a kernel that runs once per batch
-    n_exec = max([n for k, n in launches_per_batch.items() if k.startswith("dspace_g")] or [1])
-    per_set = per_set / (n_exec * LANES)
-    res["per_set"] = {"bytes": int(per_set), "batch_executions": n_exec,
-                      "note": "sum over the 8-lane dispatches of the run / (batch executions x 8 designs)"}
+    n_exec = max([n for k, n in launches_per_batch.items() if k.startswith(ONCE_PER_GROUP)] or [1])
+    per_set = per_set / (n_exec * LANES) + sweep_set
+    res["per_set"] = {"bytes": int(per_set), "lane_group_executions": n_exec, "sweep_bytes_per_set": int(sweep_set),
+                      "note": "sum over the 8-lane dispatches of the run / (lane-group executions x 8 designs) + the sweep launch's bytes / "
+                              "the designs it covers"}
     with open(out_json, "w") as f:
         json.dump(res, f, indent=1)
     counters = sorted({c for _, e in rows for c in e if c not in ("dispatches", "fetch_kb", "write_kb", "bytes")})
