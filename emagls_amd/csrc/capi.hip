@@ -1233,7 +1233,7 @@ void emagls_pre_sweep(emagls_plan& p) {
         launch_zsolve_flagged(p.get("Z"), ldSh, p.get(cb ? "R" : "Rc"), p.get(cb ? "Rinv" : "Rinvc"), p.get<double>("cond_ok"), Sh, p.C,
                               hh_end, k0, s0);
         launch_yri_accurate(p.get("Yc"), p.ldS, cb, p.get("Z"), ldSh, p.get<double>("cond_ok"), (int)p.D, Sh, p.C, hh_end, k0,
-                            p.get("Yri"), p.ldD, s0);
+                            p.get("Yri"), p.ldD, s0, p.custom_basis ? nullptr : p.get("Ycm"), p.ldD);
     }
     // synthesising sweep: the chain runs in the microphone domain on Mt_k = Pm^T M_k Pm, from the start value W(k0-1,:) Pm
     if (p.synth) launch_synth_mt(p.get("Mw"), p.get<double>("Pm"), p.C, M, k0, p.P, p.get("W"), p.get("Mt"), p.get("Winit"), s0);

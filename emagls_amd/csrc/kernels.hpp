@@ -158,8 +158,9 @@ void launch_qt(const void* Yc, int64_t ldY, const void* E, int ldE, int D, int S
 void launch_dspace_g(const void* QT, int64_t ldD, bool is_cplx, const void* bn, int nOrders, int D, int C, int P, int k0, void* G,
                      hipStream_t st, int real_mode = 0, int sh_order = -1, int k_end = -1);
 void launch_cond_flags(const double* sv, int C, int P, int hh_end, double* cond_ok, hipStream_t st);
+// (Ycm: the column-major SH matrix [S][ldYcm] of a real basis -- the coalesced form; null: the row-major walk)
 void launch_yri_accurate(const void* Q, int64_t ldQ, bool is_cplx, const void* Z, int ldS, const double* cond_ok, int D, int S,
-                         int C, int P, int k0, void* Yri, int64_t ldD, hipStream_t st);
+                         int C, int P, int k0, void* Yri, int64_t ldD, hipStream_t st, const void* Ycm = nullptr, int64_t ldYcm = 0);
 
 // ---- atf.hip
 void launch_grid_match(const double* aziA, const double* zenA, int64_t nA, const double* aziB, const double* zenB,
