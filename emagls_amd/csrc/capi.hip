@@ -1861,6 +1861,37 @@ void from_atf_subject_pre_stage(emagls_plan& p) {   // a subject of a sharing ba
     launch_zero(p.get("W"), p.bufs["W"].bytes, p.stream);
     from_atf_subject_stage(p);
 }
+// Subjects of ONE ATF set on ONE HRIR grid (checked on the device): the whole batch as two single-stream graphs around the
+// resident sweep -- plan 0's full stage (grid match, ATF spectra, per-bin factors), then per subject only the HRIR prologue
+// (plan 0's grid match serves every subject) and the least-squares rows; afterwards every subject's epilogue.  Eight graphs
+// on eight streams with an event pair each (the earlier form) cost more host time than the stages take on the GPU: 10.2 ms
+// per batch of BASELINE config 5, of which 3.3 ms are the sweep and ~4 ms kernels that could overlap.
+void batch_atf_shared_stage(emagls_batch& b, int part) {
+    emagls_plan& p0 = *b.plans[0];
+    std::vector<hipStream_t> keep;
+    for (auto* p : b.plans) { keep.push_back(p->stream); p->stream = b.stream; }
+    auto restore = [&] { for (size_t j = 0; j < b.plans.size(); ++j) b.plans[j]->stream = keep[j]; };
+    try {
+        if (part == 0) {
+            plan_pre_stage(p0);
+            for (size_t j = 1; j < b.plans.size(); ++j) {
+                emagls_plan& p = *b.plans[j];
+                p.stage_names.clear();
+                launch_zero(p.get("flag"), sizeof(int) * NFLAG, b.stream);
+                launch_zero(p.get("W"), p.bufs["W"].bytes, b.stream);
+                // (the subject keeps its own copy of the match: emagls_plan_get_info and the debug buffers read it per plan)
+                launch_conj_copy(p0.get("match_idx"), p.get("match_idx"), p.Dm, false, b.stream);
+                launch_conj_copy(p0.get("match_dev"), p.get("match_dev"), p.Dm, false, b.stream);
+                launch_conj_copy(p0.get("mean_dev"), p.get("mean_dev"), 1, false, b.stream);
+                stage_prologue(p, 1, p.hrir_smaller ? nullptr : p.get<int64_t>("match_idx"), p.Dm);
+                from_atf_ls_rows(p, p0, b.stream);
+            }
+        } else {
+            for (auto* p : b.plans) from_atf_post_sweep(*p);
+        }
+    } catch (...) { restore(); throw; }
+    restore();
+}
 void batch_execute_atf(emagls_batch& b) {
     for (auto* p : b.plans)
         if (!p->have_hrirs || !p->have_hrir_grid || !p->have_atfs)
@@ -1868,6 +1899,20 @@ void batch_execute_atf(emagls_batch& b) {
     batch_atf_decide_sharing(b);
     const bool replay = b.use_graph && b.eager_runs >= 1;
     emagls_plan& p0 = *b.plans[0];
+    static const bool one_stream = [] { const char* e = getenv("EMAGLS_ATF_ONE_STREAM"); return !(e && e[0] == '0'); }();
+    if (b.atf_share && p0.sweep_persist && one_stream) {
+        if (replay && !b.graph_exec) {
+            capture_into(b.stream, &b.graph, &b.graph_exec, [&] { batch_atf_shared_stage(b, 0); });
+            capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_atf_shared_stage(b, 2); });
+        }
+        b.used = 0;
+        if (replay) HIP_CHECK(hipGraphLaunch(b.graph_exec, b.stream)); else batch_atf_shared_stage(b, 0);
+        batch_sweep_stage(b);   // (never captured: see SweepChain)
+        if (replay) HIP_CHECK(hipGraphLaunch(b.post_exec, b.stream)); else batch_atf_shared_stage(b, 2);
+        for (auto* p : b.plans) { p->executed = true; p->sweep_launches = 1; }
+        if (!replay) ++b.eager_runs;
+        return;
+    }
     auto pre = [&](emagls_plan& p) { if (b.atf_share && &p != &p0) from_atf_subject_pre_stage(p); else plan_pre_stage(p); };
     if (replay && !p0.pre_exec) {
         for (auto* p : b.plans) capture_into(p->stream, &p->pre_graph, &p->pre_exec, [&] { pre(*p); });
