@@ -1298,7 +1298,7 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
         a.bsc = p.get<cplx>("bsc"); a.nord_pad = synth_nord_pad(p.simOrder + 1);
         static const int split = [] { const char* e = getenv("EMAGLS_SYNTH_SPLIT"); return e ? atoi(e) : 67; }();
         a.synth_split = split;
-        static const int prio = [] { const char* e = getenv("EMAGLS_SYNTH_PRIO"); return e ? std::max(0, std::min(2, atoi(e))) : 0; }();
+        static const int prio = [] { const char* e = getenv("EMAGLS_SYNTH_PRIO"); return e ? std::max(0, std::min(5, atoi(e))) : 5; }();
         a.synth_prio = prio;
         a.Winit = p.get<cplx>("Winit"); a.U = p.get<cplx>("Usw");
     }

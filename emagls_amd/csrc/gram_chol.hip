@@ -328,11 +328,9 @@ __global__ void __launch_bounds__(256) chol_update_kernel(T* __restrict__ G, int
     }
 }
 
-// The whole factorisation in ONE launch: a workgroup of 256 threads per design walks the block columns (diagonal block, row
-// panel, trailing update) with the panel's rows R(J, :) in LDS; the matrix itself stays in global memory (L2 resident: 512 KB at
-// S = 256).  The three-kernel form above costs 22 launches at S = 256 (8 x diag + 7 x panel + 7 x update: 290 us for 8
-// designs, every launch a dependent step of ~13 us) -- the chain of a design is latency, not work; one resident workgroup
-// per design removes the launch boundaries (dependent steps become workgroup barriers).
+// The whole factorisation in ONE launch (opt-in, see chol_fused_enabled: measured slower than the 22 launches at S = 256): a
+// workgroup of 256 threads per design walks the block columns (diagonal block, row panel, trailing update) with the panel's rows
+// R(J, :) in LDS; the matrix itself stays in global memory (L2 resident: 512 KB at S = 256).
 //   panel: thread = one trailing column, forward substitution in registers against the factored diagonal block (LDS broadcast)
 //   update: 4 x 4 register tiles of the upper triangle of the trailing block, panel rows from LDS
 template <typename T>
@@ -656,8 +654,12 @@ void launch_gram(const void* Yc, int64_t D, int S, int64_t ld, bool is_cplx, voi
     if (is_cplx) gram_impl<cplx>(Yc, D, S, ld, Gp, G, R, Sh, st); else gram_impl<double>(Yc, D, S, ld, Gp, G, R, Sh, st);
 }
 
-// EMAGLS_CHOL_FUSED=0: the three-kernel form for every size
-static bool chol_fused_enabled() { static const bool on = [] { const char* e = getenv("EMAGLS_CHOL_FUSED"); return !(e && e[0] == '0'); }(); return on; }
+// EMAGLS_CHOL_FUSED=1 selects the single-launch form below.  Measured (round 4, config 3, S_h = 256, 8 designs per launch): 448 us
+// against 290 us for the 22 launches of the three-kernel form alone, 1.1 ms against ~0.4 ms next to other batches (one resident
+// workgroup per design waits for a CU with 57 KB of LDS to spare), no difference in filter sets/s -- the diagonal block's 32
+// dependent elimination steps dominate either way and the single workgroup adds the panel and the update to the same chain.
+// Faster only for small factors (S_h = 121: 152 us).  Off by default.
+static bool chol_fused_enabled() { static const bool on = [] { const char* e = getenv("EMAGLS_CHOL_FUSED"); return e && e[0] == '1'; }(); return on; }
 template <typename T> static void chol_impl(void* G, int S, int* flag, hipStream_t st) {
     {   // one resident workgroup per design while the panel's rows fit the LDS (S <= 544 real, 288 complex)
         const int W = std::max(S - NB, 0), ldp = (W + 4 + 3) / 4 * 4 + 4;

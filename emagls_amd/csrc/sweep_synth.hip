@@ -133,7 +133,22 @@ __global__ void __launch_bounds__(SY_NT) sweep_synth_kernel(HalfSweepMulti m, in
     }
     // the chain's waves issue no more than M~ (16 KB) and |H| (1.5 KB) per bin: their polls never wait behind a slab
     // (the producers above the waves of other batches' kernels that share the CU: the chain waits for them at B1 / B2)
-    if (!producer) __builtin_amdgcn_s_setprio(3); else if (a.synth_prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.synth_prio == 2) __builtin_amdgcn_s_setprio(2);
+    // Two designs share an XCD's CUs in launches of 9-16 designs, and the SIMDs serve the OLDER waves first: the design whose
+    // workgroups were placed first ran at its solo speed (5.7 us per bin) and the other on what was left (8.0 us, hop 1 4.3 us:
+    // profiles/r04_sweep_timing.md) -- the launch lasts as long as the slower one (2.63 / 3.42 ms).  synth_prio 5 (default) tilts the
+    // chains' issue priorities the other way (second design 3, first design 2; producers 0): 2.97 / 3.20 ms.  Tilting the producers
+    // too (3: 3.22 / 2.88 ms) overshoots, tilting only the producers (4) does nothing.
+    const bool second = two && rest >= nWG;
+    if (a.synth_prio == 3) {
+        if (!producer) { if (second || !two) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+        else if (second) __builtin_amdgcn_s_setprio(1);
+    } else if (a.synth_prio == 4) {   // (experiment: only the producers tilted)
+        if (!producer) __builtin_amdgcn_s_setprio(3); else if (second) __builtin_amdgcn_s_setprio(1);
+    } else if (a.synth_prio == 5) {   // (experiment: only the chains tilted)
+        if (!producer) { if (second || !two) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+    } else {
+        if (!producer) __builtin_amdgcn_s_setprio(3); else if (a.synth_prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.synth_prio == 2) __builtin_amdgcn_s_setprio(2);
+    }
 
     if (producer) {
         // ================================ producers ================================
