@@ -574,6 +574,44 @@ def test_design_hrir_sets_in_one_call(grids, thin, kind):
     assert rel(wL[:, :, 0], wL[:, :, 9]) > 1e-3
 
 
+@pytest.mark.parametrize("kind,order,nmics", [("ls", 6, 0), ("magls", 5, 0), ("emagls2", 4, 40)])
+def test_design_hrir_sets_above_32_channels(thin, kind, order, nmics):
+    """Designs with more than 32 channels (LS / MagLS orders 5-7, arrays of 33-64 microphones) do not enter batches; the HRIR-set
+    job list runs their chunks plan by plan -- the same filters as the single calls (the header's promise; round 3 returned
+    EMAGLS_ERR_UNSUPPORTED as soon as nsets > 1).  5 sets = a chunk of four and a tail of one; also through the multi-GPU job
+    runner (one process)."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    rng = np.random.default_rng(77)
+    nsets = 5
+    azi, zen = thin["azi"], thin["zen"]
+    hL = np.stack([thin["hL"] * (1 + 0.03 * j) + 1e-3 * rng.standard_normal(thin["hL"].shape) for j in range(nsets)], axis=2)
+    hR = np.stack([thin["hR"] * (1 - 0.02 * j) + 1e-3 * rng.standard_normal(thin["hR"].shape) for j in range(nsets)], axis=2)
+    kw = dict(order=order, fs=48000.0, len=128, shDefinition="real")
+    if kind == "emagls2":
+        maz, mzn = synth.fibonacci_grid(nmics)
+        kw.update(micRadius=0.042, micGridAziRad=maz, micGridZenRad=mzn)
+        single = lambda a, b: E.getEMagLs2Filters(a, b, azi, zen, 0.042, maz, mzn, order, 48000.0, 128, "real")
+    elif kind == "magls":
+        single = lambda a, b: E.getMagLsFilters(a, b, azi, zen, order, 48000.0, 128, "real")
+    else:
+        single = lambda a, b: E.getLsFilters(a, b, azi, zen, order, "real")
+    wL, wR = E.designHrirSets(kind, hL, hR, azi, zen, **kw)
+    worst = 0.0
+    for j in range(nsets):
+        sL, sR = single(hL[:, :, j], hR[:, :, j])
+        assert wL[:, :, j].shape == sL.shape
+        worst = max(worst, rel(wL[:, :, j], sL), rel(wR[:, :, j], sR))
+    print(f"{kind} order {order} ({wL.shape[1]} channels): {nsets} HRIR sets in one call, chunks run plan by plan: worst rel vs single calls = {worst:.3e}")
+    assert worst < 1e-12
+    if kind == "magls":
+        from emagls_amd.batch import magls_hrir_sets
+        res = magls_hrir_sets([(hL[:, :, j], hR[:, :, j]) for j in range(nsets)], azi, zen, order, 48000.0, 128, "real", max_batch=3)
+        worst = max(max(rel(res[j][0], wL[:, :, j]), rel(res[j][1], wR[:, :, j])) for j in range(nsets))
+        print(f"magls order {order} through emagls_amd.batch.magls_hrir_sets (chunks of 3, plan by plan): worst rel = {worst:.3e}")
+        assert worst < 1e-12
+
+
 def test_design_hrir_sets_alternating_plan_sets(thin):
     """40 sets = two full chunks (which alternate between two sets of plans, the second chunk's upload overlapping the first
     chunk's compute) and a tail of 8: every chunk lands in its place."""
