@@ -495,8 +495,8 @@ void plan_setup(emagls_plan& p) {
     p.alloc("hrir_azi", sizeof(double) * p.D, false);
     p.alloc("hrir_zen", sizeof(double) * p.D, false);
     p.alloc("flag", sizeof(int) * NFLAG);
-    p.alloc("grpd", sizeof(double) * 2);
 
+    if (d.kind == EMAGLS_KIND_LS) p.alloc("grpd", sizeof(double) * 2);
     if (d.kind != EMAGLS_KIND_LS) {
         if (d.len < d.nsamp)
             throw Error(EMAGLS_ERR_ARG, magls_kind(d.kind) ? "HRIR len too short" : "len too short");
@@ -516,6 +516,7 @@ void plan_setup(emagls_plan& p) {
         p.kcut0 = std::min(p.k_cut - 1, p.P);  // 0-based index of the first magnitude-least-squares bin
         if (magls_kind(d.kind) && p.kcut0 < 1) throw Error(EMAGLS_ERR_ARG, "k_cut must be at least 2");
         p.alloc("tw", sizeof(cplx) * p.nfft);
+        p.alloc("grpd", sizeof(double) * (2 + 4 * (size_t)p.P));   // the two delays, then the delay phases [2][P] (grpdelay_median_kernel)
         if (p.diffuse) p.alloc("Hfull", sizeof(cplx) * (size_t)2 * p.P * p.ldD);   // time-aligned complex HRTFs of every bin
         p.alloc("dirsum", sizeof(double) * 2 * d.nsamp * hrir_dirsum_chunks(d.ndirs));
     }

@@ -10,6 +10,7 @@
 // applySubsampleDelay(ifft(W)) to ifft(W .* E): one transform instead of three.
 #include "kernels.hpp"
 #include "lds_fft.hpp"
+#include "wave_fft.hpp"
 
 namespace emagls {
 
@@ -48,6 +49,9 @@ __global__ void __launch_bounds__(256) hrir_dirsum_kernel(const double* __restri
 
 // one workgroup per ear: b = sum of partials; gd(k) = Re{ sum n b[n] z^-n / sum b[n] z^-n };
 // grpd[e] = median_k gd(k)   (MATLAB grpdelay FIR branch: |den| < 10 eps -> 0)
+// and behind the two delays the phases applySubsampleDelay multiplies the spectra with (applySubsampleDelay.m:8-13),
+// phs[e][kb] = exp(-1j*2*pi*omega(kb)*(-grpd[e])), omega = linspace(0, 0.5, nfft/2+1), Nyquist bin forced real: one table per design
+// instead of one per workgroup of hrir_fft_wave_kernel.  grpd: 2 + 4 P doubles.
 __global__ void __launch_bounds__(1024) grpdelay_median_kernel(const double* __restrict__ partial, int nchunks, int64_t L,
                                                                int nfft, const cplx* __restrict__ tw,
                                                                double* __restrict__ grpd, size_t bstride) {
@@ -93,7 +97,15 @@ __global__ void __launch_bounds__(1024) grpdelay_median_kernel(const double* __r
             __syncthreads();
         }
     }
-    if (threadIdx.x == 0) grpd[e] = (P & 1) ? v[(P - 1) / 2] : 0.5 * (v[P / 2 - 1] + v[P / 2]);
+    const double med = (P & 1) ? v[(P - 1) / 2] : 0.5 * (v[P / 2 - 1] + v[P / 2]);
+    if (threadIdx.x == 0) grpd[e] = med;
+    cplx* phs = reinterpret_cast<cplx*>(grpd + 2) + (size_t)e * P;
+    for (int kb = threadIdx.x; kb < P; kb += blockDim.x) {
+        double sn, cs;
+        sincos((6.283185307179586 * ((double)kb / (double)nfft)) * med, &sn, &cs);
+        if (kb == P - 1) sn = 0.0;
+        phs[kb] = mk(cs, sn);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -234,6 +246,101 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
                     for (int t = 0; t < HF_TD; ++t) if (t < nt) row[t] = habs[s][e][t];
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same spectra at nfft = 1024 on wave-private transforms (wave_fft.hpp): one wave = one direction (both ears packed), eight
+// directions per workgroup, no barrier until the |H| runs of 8 directions are put together.  The delay phases come from the
+// table grpdelay_median_kernel leaves behind grpd (mode 0).
+// ---------------------------------------------------------------------------------------------
+constexpr int HW_TD = 8;
+__global__ void __launch_bounds__(64 * HW_TD) hrir_fft_wave_kernel(const double* __restrict__ hL, const double* __restrict__ hR,
+                                                                   int64_t L, int64_t D, const int64_t* __restrict__ didx,
+                                                                   const cplx* __restrict__ tw, const double* __restrict__ grpd,
+                                                                   int mode, int n_c, int kabs0, cplx* __restrict__ Hc,
+                                                                   double* __restrict__ Habs, int64_t ldD, double* __restrict__ HcT, int ldT,
+                                                                   size_t bstride) {
+    hL = boff(hL, bstride); hR = boff(hR, bstride); didx = boff(didx, bstride); tw = boff(tw, bstride); grpd = boff(grpd, bstride); Hc = boff(Hc, bstride); Habs = boff(Habs, bstride);
+    HcT = boff(HcT, bstride);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int P = WF_N / 2 + 1;
+    cplx* tables = reinterpret_cast<cplx*>(smem);
+    cplx* bufs = tables + WF_TABLES;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    wave_fft_tables(tables, tw, tid, 64 * HW_TD);
+    __syncthreads();
+    const int64_t d0 = (int64_t)blockIdx.x * HW_TD;
+    const int nt = (int)min((int64_t)HW_TD, D - d0);
+    cplx* tb = bufs + (size_t)w * WF_BUF;
+    if (w < nt) {
+        const int64_t d = d0 + w;
+        const int64_t dsrc = didx ? didx[d] : d;
+        const double* pl = hL + dsrc * L;
+        const double* pr = hR + dsrc * L;
+        cplx v[16];
+        const bool upper_zero = mode == 0 && L <= WF_N / 2;
+        if (mode == 0) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int n = 64 * n1 + l;
+                v[n1] = (n < L && (n1 < 8 || !upper_zero)) ? mk(pl[n], pr[n]) : mk(0.0, 0.0);
+            }
+        } else {   // circshift(h, -s): out[n] = h[(n + s) mod nfft], zero beyond the L recorded taps
+            const int sL = (int)round(grpd[0]), sR = (int)round(grpd[1]);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int n = 64 * n1 + l;
+                int nl = (n + sL) % WF_N; if (nl < 0) nl += WF_N;
+                int nr = (n + sR) % WF_N; if (nr < 0) nr += WF_N;
+                v[n1] = mk(nl < L ? pl[nl] : 0.0, nr < L ? pr[nr] : 0.0);
+            }
+        }
+        if (upper_zero) wave_fft1024<true>(v, tb, tables, l); else wave_fft1024<false>(v, tb, tables, l);
+        wave_fft_store_natural(v, tb, l);
+        wave_lds_fence();
+        const cplx* phs = reinterpret_cast<const cplx*>(grpd + 2);
+        // lane = bin: unpack the ears, apply the delay phase, complex rows out, |H_L|, |H_R| into the slot of the bin
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int kb = l + 64 * s;
+            if (kb < P) {
+                const cplx z = tb[wf_slot(kb)], zc = conj(tb[wf_slot((WF_N - kb) & (WF_N - 1))]);
+                cplx HLv = mk(0.5 * (z.x + zc.x), 0.5 * (z.y + zc.y));
+                cplx HRv = mk(0.5 * (z.y - zc.y), -0.5 * (z.x - zc.x));  // (z - zc) / (2i)
+                if (mode == 0) {
+                    HLv = HLv * phs[kb];
+                    HRv = HRv * phs[P + kb];
+                }
+                if (kb < n_c) {
+                    Hc[((int64_t)0 * n_c + kb) * ldD + d] = HLv;
+                    Hc[((int64_t)1 * n_c + kb) * ldD + d] = HRv;
+                    if (HcT) {   // direction-major copy, HcT[d][2 (e n_c + kb) + re/im] (launch_hy_conj_mfma)
+                        double* rowT = HcT + d * ldT;
+                        *reinterpret_cast<cplx*>(rowT + 2 * kb) = HLv;
+                        *reinterpret_cast<cplx*>(rowT + 2 * (n_c + kb)) = HRv;
+                    }
+                }
+                const double nl2 = norm2(HLv), nr2 = norm2(HRv);
+                tb[wf_slot(kb)] = mk(nl2 > 0.0 ? nl2 * fast_rsqrt(nl2) : 0.0, nr2 > 0.0 ? nr2 * fast_rsqrt(nr2) : 0.0);
+            }
+        }
+    }
+    __syncthreads();
+    // |H| rows: 8 consecutive directions per (bin, ear) and thread
+    const int64_t na = P - kabs0;
+    for (int idx = tid; idx < 2 * P; idx += 64 * HW_TD) {
+        const int e = idx >= P, kb = idx - e * P;
+        if (kb < kabs0) continue;
+        const double* src = reinterpret_cast<const double*>(bufs + wf_slot(kb)) + e;
+        double* row = Habs + ((int64_t)e * na + (kb - kabs0)) * ldD + d0;   // (ldD and d0 are multiples of 8: 64-byte aligned)
+        if (nt == HW_TD) {
+#pragma unroll
+            for (int t = 0; t < HW_TD; t += 2)
+                *reinterpret_cast<double2*>(row + t) = make_double2(src[(size_t)t * WF_BUF * 2], src[(size_t)(t + 1) * WF_BUF * 2]);
+        } else {
+            for (int t = 0; t < nt; ++t) row[t] = src[(size_t)t * WF_BUF * 2];
         }
     }
 }
@@ -544,6 +651,9 @@ void launch_hrir_grpdelay(const double* hL, const double* hR, int64_t L, int64_t
     KERNEL_CHECK();
 }
 
+// EMAGLS_HRIR_FFT_WAVE=0: the LDS radix-2^2 form at every length (read per call: a test compares the two in one process)
+static bool hrir_fft_wave_enabled() { const char* e = getenv("EMAGLS_HRIR_FFT_WAVE"); return !(e && e[0] == '0'); }
+
 void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, const int64_t* didx, int nfft,
                      const void* tw, const double* grpd, int mode, int n_c, int kabs0, void* Hc, double* Habs,
                      int64_t ldD, hipStream_t st, double* HcT, int ldT) {
@@ -559,6 +669,16 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
     const int log2n = ilog2(nfft);
     const int P = nfft / 2 + 1;
     if (P > HF_MAXS * 512) throw Error(2, "HRIR FFT: nfft above 2048 is not supported");
+    if (nfft == WF_N && L <= WF_N && hrir_fft_wave_enabled()) {   // wave-private transforms
+        const size_t smw = sizeof(cplx) * (WF_TABLES + (size_t)HW_TD * WF_BUF);
+        static PerDeviceOnce wave_once;
+        if (wave_once.first())
+            HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hrir_fft_wave_kernel<<<bgrid((unsigned)ceil_div(D, HW_TD)), 64 * HW_TD, smw, st>>>(hL, hR, L, D, didx, (const cplx*)tw, grpd, mode, n_c, kabs0,
+                                                                                      (cplx*)Hc, Habs, ldD, HcT, ldT, batch_ctx().stride);
+        KERNEL_CHECK();
+        return;
+    }
     // directions per sub-tile: the largest power of two whose buffers stay below the LDS a CU has left next to a resident
     // sweep workgroup (160 KB - 77 KB)
     // (tried: 2 or 1 directions per sub-tile, 49 / 33 KB, so that three or four workgroups share a CU and the kernel fits next to a

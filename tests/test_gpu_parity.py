@@ -1058,6 +1058,22 @@ def test_from_atf_small(thin):
     assert report("FromAtf L", wL, oL) < TOL and report("FromAtf R", wR, oR) < TOL
 
 
+def test_from_atf_512_taps_wave_prologue(thin, monkeypatch):
+    """512-tap FromAtf filters: nfft = 1024, so the HRIR prologue with the integer circshift (lib/getEMagLsFiltersFromAtf.m:43-53)
+    runs on the wave-private transforms; same design with EMAGLS_HRIR_FFT_WAVE=0 on the LDS form."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    atf, aazi, azen = synth.glasses_atfs(natf=1024, nmics=8, taps=128)
+    hg = np.column_stack([thin["azi"], thin["zen"]])
+    ag = np.column_stack([aazi, azen])
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 512, 2000.0)
+    wL, wR = E.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 512, 2000.0, verbose=False)
+    assert report("FromAtf 512 taps (wave prologue) L", wL, oL) < TOL and report("R", wR, oR) < TOL
+    monkeypatch.setenv("EMAGLS_HRIR_FFT_WAVE", "0")
+    vL, vR = E.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 512, 2000.0, verbose=False)
+    assert report("FromAtf 512 taps (LDS prologue) L", vL, oL) < TOL and rel(vL, wL) < 1e-9 and rel(vR, wR) < 1e-9
+
+
 def test_from_atf_atf_grid_smaller(thin):
     """ATF grid smaller than the HRIR grid: the HRTFs are gathered instead (FromAtf.m:71-79,91-93)."""
     import emagls_amd as E

@@ -146,6 +146,46 @@ def test_stage_prologue(emagls_plan):
     assert rel(Ha[0], np.abs(HL[kcut0:P])) < 1e-12 and rel(Ha[1], np.abs(HR[kcut0:P])) < 1e-12
 
 
+@pytest.mark.parametrize("nsamp,ndirs", [(512, 157), (300, 64), (37, 9)])
+def test_stage_prologue_1024_wave_form(grids, hrirs, monkeypatch, nsamp, ndirs):
+    """nfft = 1024 (512-tap filters, the headline configuration) takes the wave-private transforms of wave_fft.hpp
+    (hrir_fft_wave_kernel); EMAGLS_HRIR_FFT_WAVE=0 keeps the LDS radix-2^2 form.  Both against the oracle's prologue
+    (lib/getEMagLsFilters.m:72-81), direction counts that are not a multiple of the 8 directions per workgroup included."""
+    from emagls_amd import Plan, _lib as L
+    rng = np.random.default_rng(5)
+    sel = np.sort(rng.choice(2702, ndirs, replace=False))
+    hL, hR = hrirs[0][:nsamp, sel], hrirs[1][:nsamp, sel]
+    if nsamp > hrirs[0].shape[0]:
+        extra = rng.standard_normal((nsamp - hrirs[0].shape[0], ndirs)) * 1e-3
+        hL, hR = np.vstack([hL, extra]), np.vstack([hR, -extra])
+    hL, hR = np.ascontiguousarray(hL), np.ascontiguousarray(hR)
+    azi, zen = grids["azi"][sel], grids["zen"][sel]
+    got = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("EMAGLS_HRIR_FFT_WAVE", form)
+        p = Plan(L.KIND_MAGLS, "real", 2, 48000.0, 512, hL.shape[0], ndirs)
+        p.set_hrir_grid(azi, zen)
+        p.set_hrirs(hL, hR)
+        p.set_profiling(1)
+        p.execute()
+        p.synchronize()
+        i = p.info()
+        nfft, P, kcut0 = i.nfft, i.num_pos_freqs, i.k_cut - 1
+        assert (nfft, P) == (1024, 513)
+        ldD = -(-ndirs // 64) * 64
+        Hc = p.debug("Hc", np.complex128).reshape(2, kcut0, ldD)[:, :, :ndirs].copy()
+        Ha = p.debug("Habs", np.float64).reshape(2, P - kcut0, ldD)[:, :, :ndirs].copy()
+        got[form] = (Hc, Ha, i.grp_delay_l, i.grp_delay_r)
+        p.close()
+    HL, HR, gL, gR = O._hrir_prologue(hL, hR, 1024, 513)
+    for form, (Hc, Ha, dl, dr) in got.items():
+        assert abs(dl - gL) < 1e-9 and abs(dr - gR) < 1e-9
+        e = max(rel(Hc[0], HL[:kcut0]), rel(Hc[1], HR[:kcut0]), rel(Ha[0], np.abs(HL[kcut0:513])), rel(Ha[1], np.abs(HR[kcut0:513])))
+        print(f"HRIR prologue {nsamp} taps x {ndirs} directions, nfft 1024, wave form {form}: rel vs oracle = {e:.3e}")
+        assert e < 1e-10    # (the complex rows carry the delay phase: pi x the difference of the two medians, itself held to 1e-9 above)
+    assert rel(got["1"][1], got["0"][1]) < 1e-13 and rel(got["1"][0], got["0"][0]) < 1e-13
+
+
 def test_stage_factor_and_sweep(emagls_plan, grids):
     """Per-bin factors against LAPACK on the SAME B_k: singular values, Jacobi sweep counts, the
     S-space inverse Z_k of the least-squares bins, the direction-space operands G_k / Yri_k of the swept
