@@ -4,10 +4,12 @@
 #include <hipfft/hipfft.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "kernels.hpp"
 #include "lds_fft.hpp"
 #include "reg_fft.hpp"
+#include "wave_fft.hpp"
 
 namespace emagls {
 
@@ -330,6 +332,182 @@ __global__ void __launch_bounds__(OLSR_NT) ols_fused_rr_kernel(const double* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The block at Nf = 1024 (257..512 taps) on wave-private transforms (wave_fft.hpp).  One wave carries a 1024-point transform in
+// 16 registers per lane and keeps its part of the output spectrum in registers as well, so nothing but the final sum leaves it:
+// with z_p = FFT(x_2p + i x_2p+1) and zc_p[k] = conj(z_p[N - k]),
+//     Y_L[k] + i Y_R[k] = sum_p z_p[k] A_p[k] + zc_p[k] B_p[k],   A_p = U_L + i U_R,  B_p = V_L + i V_R,
+//     U_e = (W_e,2p - i W_e,2p+1) / 2,  V_e = (W_e,2p + i W_e,2p+1) / 2,
+// and the mirrored term is conj(Q[N - k]) with Q[m] = sum_p z_p[m] conj(B_p[N - m]): both R = sum z A and Q accumulate at the bins a
+// lane already holds (no unpacking of the channel pair, no pass through LDS per pair); one mirrored exchange per block, then the
+// packed inverse transform of both ears as conj(FFT(conj(.))).
+//   tab [npairs][16][2][64]  A_p and conj(B_p[N - .]) at bin wf_bin(lane, i)   (ols_wave_tables_kernel)
+// G waves share a block (pairs g, g + G, ...; their partial sums meet in LDS): G = 1 for long signals -- every wave its own
+// block, no workgroup barrier at all -- G = 8 when there are fewer blocks than compute units.
+// ---------------------------------------------------------------------------------------------
+constexpr int OLSW_WAVES = 8;
+// pair_mode 0: pair p = channels (2 p, 2 p + 1); 1: (p, p + C / 2) -- the real and the imaginary plane of complex channel p
+__global__ void ols_wave_tables_kernel(const cplx* __restrict__ Wf, int C, int pair_mode, cplx* __restrict__ tab) {
+    constexpr int N = WF_N, Pf = N / 2 + 1;
+    const int npairs = (C + 1) / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npairs * 16 * 2 * 64) return;
+    const int l = idx & 63, t = (idx >> 6) & 1, i = (idx >> 7) & 15, p = idx >> 11;
+    const int m = wf_bin(l, i);
+    const int k = t ? ((N - m) & (N - 1)) : m;
+    auto W = [&](int e, int c) {
+        if (c >= C) return mk(0.0, 0.0);
+        const cplx* w = Wf + ((int64_t)e * C + c) * Pf;
+        return k <= N / 2 ? w[k] : conj(w[N - k]);
+    };
+    const int ca = pair_mode ? p : 2 * p, cb = pair_mode ? p + C / 2 : 2 * p + 1;
+    const cplx aL = W(0, ca), bL = W(0, cb), aR = W(1, ca), bR = W(1, cb);
+    cplx r;
+    if (t == 0) {   // A = U_L + i U_R,  U = (a - i b) / 2
+        const cplx uL = mk(0.5 * (aL.x + bL.y), 0.5 * (aL.y - bL.x)), uR = mk(0.5 * (aR.x + bR.y), 0.5 * (aR.y - bR.x));
+        r = mk(uL.x - uR.y, uL.y + uR.x);
+    } else {        // conj(B),  B = V_L + i V_R,  V = (a + i b) / 2
+        const cplx vL = mk(0.5 * (aL.x - bL.y), 0.5 * (aL.y + bL.x)), vR = mk(0.5 * (aR.x - bR.y), 0.5 * (aR.y + bR.x));
+        r = mk(vL.x - vR.y, -(vL.y + vR.x));
+    }
+    tab[idx] = r;
+}
+
+template <int G>
+__global__ void __launch_bounds__(64 * OLSW_WAVES) ols_wave_kernel(const double* __restrict__ sig, const cplx* __restrict__ sigc, int64_t n, int C, const cplx* __restrict__ tab,
+                                                                   const cplx* __restrict__ circle, int64_t len, int64_t B, int64_t nblocks,
+                                                                   double* __restrict__ out) {
+    constexpr int N = WF_N;
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* tables = reinterpret_cast<cplx*>(dyn);
+    cplx* bufs = tables + WF_TABLES;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int g = w % G;                                   // this wave's place among the waves of its block
+    const int64_t blk = (int64_t)blockIdx.x * (OLSW_WAVES / G) + w / G;
+    wave_fft_tables(tables, circle, tid, 64 * OLSW_WAVES);
+    __syncthreads();
+    cplx* tb = bufs + (size_t)w * WF_BUF;
+    const bool live = blk < nblocks;
+    const int npairs = (C + 1) / 2;
+    const int64_t s0 = blk * B - (len - 1);
+    const bool interior = s0 >= 0 && s0 + N <= n;
+    cplx R[16], Q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { R[i] = mk(0, 0); Q[i] = mk(0, 0); }
+    // the samples of channel pair p: x_2p + i x_2p+1 at n = 64 n1 + l
+    auto fetch = [&](cplx (&v)[16], int p) __attribute__((always_inline)) {
+        if (sigc) {   // complex channel p as it lies in memory: its planes are the pair
+            const cplx* xc = sigc + (int64_t)p * n;
+            if (interior) {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) v[n1] = xc[s0 + 64 * n1 + l];
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const int64_t src = s0 + 64 * n1 + l;
+                    const int64_t at = min(max(src, (int64_t)0), n - 1);
+                    const cplx x = xc[at];
+                    v[n1] = (src == at) ? x : mk(0.0, 0.0);
+                }
+            }
+            return;
+        }
+        const double* xa = sig + (int64_t)(2 * p) * n;
+        const double* xb = sig + (int64_t)min(2 * p + 1, C - 1) * n;
+        if (interior) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = mk(xa[s0 + 64 * n1 + l], xb[s0 + 64 * n1 + l]);
+        } else {   // the first and the last blocks: zero outside the signal (loads from a clamped address, then a select)
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int64_t src = s0 + 64 * n1 + l;
+                const int64_t at = min(max(src, (int64_t)0), n - 1);
+                const double a = xa[at], b = xb[at];
+                v[n1] = (src == at) ? mk(a, b) : mk(0.0, 0.0);
+            }
+        }
+    };
+    // (requesting the next pair's samples while this one is transformed would hide the 2 us the loads take -- a third of the
+    // kernel's time -- but a wave has no registers for them: 128 hold the sums, 64 the transform, and the compiler spills 500+ bytes
+    // per lane with 64 more in flight; pass 3 is consumed one half at a time for the same reason)
+    if (live) {
+        for (int p = g; p < npairs; p += G) {
+            cplx v[16];
+            fetch(v, p);
+            if (!sigc && 2 * p + 1 >= C) {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) v[n1].y = 0.0;
+            }
+            wf_pass1<false>(v, tb, tables, l);
+            wf_pass2_half<0>(tb, tables, l);
+            wf_pass2_half<1>(tb, tables, l);
+            wave_lds_fence();
+            const cplx* f = tab + (size_t)p * (16 * 2 * 64) + l;
+            auto half = [&](auto e_tag) __attribute__((always_inline)) {
+                constexpr int E = decltype(e_tag)::value;
+                cplx z[8];
+                wf_pass3_half<E>(z, tb, l);
+#pragma unroll
+                for (int j0 = 0; j0 < 8; j0 += 4) {   // (eight filter values in flight)
+                    cplx fa[4], fb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { fa[j] = f[(2 * (8 * E + j0 + j)) * 64]; fb[j] = f[(2 * (8 * E + j0 + j) + 1) * 64]; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { cfma(R[8 * E + j0 + j], z[j0 + j], fa[j]); cfma(Q[8 * E + j0 + j], z[j0 + j], fb[j]); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            half(std::integral_constant<int, 0>{});
+            half(std::integral_constant<int, 1>{});
+            wave_lds_fence();
+        }
+    }
+    if (G > 1) {   // the partial sums of the block's waves: everyone parks R, the first wave adds; then Q the same way
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            cplx (&acc)[16] = pass ? Q : R;
+            __syncthreads();
+            if (g != 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tb[i * 64 + l] = acc[i];
+            }
+            __syncthreads();
+            if (g == 0) {
+                for (int o = 1; o < G; ++o) {
+                    const cplx* ob = tb + (size_t)o * WF_BUF;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const cplx x = ob[i * 64 + l]; acc[i].x += x.x; acc[i].y += x.y; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!live || g != 0) return;
+    // conj(P[k]) = conj(R[k]) + Q[N - k] at k = 64 n1 + l: Q through the buffer in natural order, read mirrored; then R
+    cplx v[16];
+    wave_fft_store_natural(Q, tb, l);
+    wave_lds_fence();
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = tb[wf_slot((N - (64 * n1 + l)) & (N - 1))];
+    wave_lds_fence();
+    wave_fft_store_natural(R, tb, l);
+    wave_lds_fence();
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) { const cplx r = tb[wf_slot(64 * n1 + l)]; v[n1] = mk(v[n1].x + r.x, v[n1].y - r.y); }
+    wave_lds_fence();
+    wave_fft1024<false>(v, tb, tables, l);     // y_L + i y_R = conj(FFT(conj(P))) / N
+    const double scale = 1.0 / (double)N;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t j = wf_bin(l, i) - (len - 1);
+        const int64_t t = blk * B + j;
+        if (j >= 0 && t < n) {
+            stream_store(out + t, v[i].x * scale);
+            stream_store(out + n + t, -v[i].y * scale);
+        }
+    }
+}
+
 // [re(x_0..x_C-1), im(x_0..x_C-1)] planes (2C real channels of n samples) from interleaved complex columns; `swap` exchanges
 // the two halves and `neg_im` negates the imaginary planes
 __global__ void split_complex_kernel(const cplx* __restrict__ x, int64_t n, int C, int swap, int neg_im, double* __restrict__ out) {
@@ -369,14 +547,15 @@ struct DecodeWork {
     int64_t nblocks = 0;
     double *seg = nullptr, *wpad = nullptr, *y = nullptr;
     cplx *Xf = nullptr, *Wf = nullptr, *Yf = nullptr;
+    cplx *wtab = nullptr, *circle = nullptr;   // ols_wave_kernel: pair filters at the lanes' bins, exp(-2 pi i m / 1024)
     hipfftHandle pf = 0, pw = 0, pi = 0;
     void release() {
         if (pf) hipfftDestroy(pf);
         if (pw) hipfftDestroy(pw);
         if (pi) hipfftDestroy(pi);
         pf = pw = pi = 0;
-        hipFree(seg); hipFree(wpad); hipFree(y); hipFree(Xf); hipFree(Wf); hipFree(Yf);
-        seg = wpad = y = nullptr; Xf = Wf = Yf = nullptr;
+        hipFree(seg); hipFree(wpad); hipFree(y); hipFree(Xf); hipFree(Wf); hipFree(Yf); hipFree(wtab); hipFree(circle);
+        seg = wpad = y = nullptr; Xf = Wf = Yf = nullptr; wtab = circle = nullptr;
         C = Nf = 0; nblocks = 0; device = -1;
     }
     void ensure(int C_, int64_t nblocks_, int Nf_) {
@@ -390,6 +569,12 @@ struct DecodeWork {
             HIP_CHECK(hipMalloc(&wpad, sizeof(double) * 2 * C_ * Nf_));
             HIP_CHECK(hipMalloc(&Wf, sizeof(cplx) * 2 * C_ * Pf));
             fft_check(hipfftPlanMany(&pw, 1, nn, nullptr, 1, Nf_, nullptr, 1, Pf, HIPFFT_D2Z, 2 * C_), "plan D2Z filters");
+            if (Nf_ == WF_N && nblocks_ == 0) {
+                HIP_CHECK(hipMalloc(&wtab, sizeof(cplx) * (size_t)((C_ + 1) / 2) * 16 * 2 * 64));
+                HIP_CHECK(hipMalloc(&circle, sizeof(cplx) * WF_N));
+                launch_twiddles(WF_N, circle, nullptr);
+                HIP_CHECK(hipStreamSynchronize(nullptr));
+            }
             if (nblocks_ > 0) {   // (0: the fused kernel keeps the signal side in LDS; only the filter spectra pass through hipFFT)
                 HIP_CHECK(hipMalloc(&seg, sizeof(double) * C_ * nblocks_ * Nf_));
                 HIP_CHECK(hipMalloc(&y, sizeof(double) * 2 * nblocks_ * Nf_));
@@ -414,9 +599,18 @@ void decode_cache_clear() {
 // EMAGLS_DECODE_FUSED=0: always the hipFFT passes
 static bool decode_fused_enabled() { const char* e = getenv("EMAGLS_DECODE_FUSED"); return !(e && e[0] == '0'); }
 
+// true when binaural_decode_real takes the wave-private transforms for filters of `len` taps (ols_wave_kernel): the complex render
+// then hands over its interleaved signal as it is (sigc) instead of splitting it into planes first
+bool decode_wave_form(int64_t len) {
+    const char* e_rr = getenv("EMAGLS_DECODE_REGFFT");
+    const char* e_wave = getenv("EMAGLS_DECODE_WAVE");
+    return len <= 2048 && decode_fused_enabled() && 2 * len > WF_N / 2 && 2 * len <= WF_N && !(e_rr && e_rr[0] == '0') && !(e_wave && e_wave[0] == '0');
+}
+
 void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL, const double* wR, int64_t len,
-                          double* out, hipStream_t st) {
+                          double* out, hipStream_t st, const cplx* sigc) {
     if (n <= 0) return;
+    if (sigc && !decode_wave_form(len)) throw Error(3, "binaural_decode_real: an interleaved complex signal needs the wave form");
     if (len <= 2048 && decode_fused_enabled()) {
         // block length ~ filter length: twice the transforms of the 4x blocks below, but every one of them stays in LDS
         int Nf = 256, log2n = 8;
@@ -432,6 +626,28 @@ void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL,
         fft_check(hipfftExecD2Z(w.pw, w.wpad, (hipfftDoubleComplex*)w.Wf), "exec D2Z filters");
         const char* e_rr = getenv("EMAGLS_DECODE_REGFFT");   // (read at every call: a test switches forms inside one process)
         const bool use_rr = !(e_rr && e_rr[0] == '0');
+        const char* e_wave = getenv("EMAGLS_DECODE_WAVE");
+        if (use_rr && Nf == WF_N && !(e_wave && e_wave[0] == '0')) {   // wave-private transforms
+            int dev_w = 0, ncu_w = 256;
+            HIP_CHECK(hipGetDevice(&dev_w));
+            HIP_CHECK(hipDeviceGetAttribute(&ncu_w, hipDeviceAttributeMultiprocessorCount, dev_w));
+            const int npairs = (C + 1) / 2;
+            ols_wave_tables_kernel<<<(unsigned)ceil_div((int64_t)npairs * 2048, 256), 256, 0, st>>>(w.Wf, C, sigc ? 1 : 0, w.wtab);
+            KERNEL_CHECK();
+            const size_t dyn_w = sizeof(cplx) * (WF_TABLES + (size_t)OLSW_WAVES * WF_BUF);
+            static PerDeviceOnce wave_once;
+            if (wave_once.first()) {
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_wave_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_wave_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            if (nblocks >= 4 * (int64_t)ncu_w)
+                ols_wave_kernel<1><<<(unsigned)ceil_div(nblocks, OLSW_WAVES), 64 * OLSW_WAVES, dyn_w, st>>>(sig, sigc, n, C, w.wtab, w.circle, len, B, nblocks, out);
+            else
+                ols_wave_kernel<8><<<(unsigned)nblocks, 64 * OLSW_WAVES, dyn_w, st>>>(sig, sigc, n, C, w.wtab, w.circle, len, B, nblocks, out);
+            KERNEL_CHECK();
+            HIP_CHECK(hipStreamSynchronize(st));
+            return;
+        }
         if (use_rr && Nf <= 1024) {   // register-resident transforms (two-factor form)
             const int n1 = Nf == 1024 ? 32 : 16, n2 = Nf == 256 ? 16 : 32;
             int dev_rr = 0, ncu = 256;
@@ -513,15 +729,22 @@ void binaural_decode_complex(const void* sig, bool sig_cplx, int64_t n, int C, c
         else widen_real_kernel<<<grid, 256, 0, st>>>((const double*)x, total, swap, dst);
         KERNEL_CHECK();
     };
-    planes(sig, sig_cplx, n, 0, 0, sig2);
+    // (the wave form reads a complex signal as it lies in memory: sample = the pair (re, im) of one transform)
+    const cplx* sigc = (sig_cplx && decode_wave_form(len)) ? (const cplx*)sig : nullptr;
+    if (!sigc) planes(sig, sig_cplx, n, 0, 0, sig2);
     planes(wL, w_cplx, len, 0, 1, w2L);
     planes(wR, w_cplx, len, 0, 1, w2R);
-    binaural_decode_real(sig2, n, 2 * C, w2L, w2R, len, out, st);
+    binaural_decode_real(sig2, n, 2 * C, w2L, w2R, len, out, st, sigc);
     if (imag_abs) {
-        planes(sig, sig_cplx, n, 1, 0, sig2);      // [im x; re x]
-        planes(wL, w_cplx, len, 0, 0, w2L);        // [re w; im w]
-        planes(wR, w_cplx, len, 0, 0, w2R);
-        binaural_decode_real(sig2, n, 2 * C, w2L, w2R, len, d_tmp, st);
+        if (sigc) {                                    // [re x; im x] stays, the filter planes change places: [im w; re w]
+            planes(wL, w_cplx, len, 1, 0, w2L);
+            planes(wR, w_cplx, len, 1, 0, w2R);
+        } else {
+            planes(sig, sig_cplx, n, 1, 0, sig2);      // [im x; re x]
+            planes(wL, w_cplx, len, 0, 0, w2L);        // [re w; im w]
+            planes(wR, w_cplx, len, 0, 0, w2R);
+        }
+        binaural_decode_real(sig2, n, 2 * C, w2L, w2R, len, d_tmp, st, sigc);
         abs_sum_kernel<<<2, 1024, 0, st>>>(d_tmp, n, imag_skip, d_tmp + 2 * n);   // (binauralDecode.m:53-62: summed after the delay cut)
         KERNEL_CHECK();
         HIP_CHECK(hipMemcpyAsync(imag_abs, d_tmp + 2 * n, 2 * sizeof(double), hipMemcpyDeviceToHost, st));

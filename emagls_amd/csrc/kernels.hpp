@@ -172,7 +172,9 @@ double measure_fp64_peak(int which, int reps, bool burst = false, double* mhz = 
 
 // ---- decode.hip
 void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL, const double* wR, int64_t len,
-                          double* out /* [n x 2] column-major */, hipStream_t st);
+                          double* out /* [n x 2] column-major */, hipStream_t st,
+                          const cplx* sigc = nullptr /* the C / 2 complex channels whose planes are `sig`'s channels, interleaved (wave form only) */);
+bool decode_wave_form(int64_t len);
 void binaural_decode_complex(const void* sig, bool sig_cplx, int64_t n, int C, const void* wL, const void* wR, bool w_cplx, int64_t len,
                              double* sig2, double* w2L, double* w2R, double* out, double* imag_abs, double* d_tmp, hipStream_t st,
                              int64_t imag_skip = 0 /* samples left out of the imaginary-part sums (the compensateDelay cut) */);

@@ -11,8 +11,8 @@
 //
 // LDS layouts in 16-byte slots (lane groups of ds_write_b128 = 8 contiguous lanes on 8 slots, of ds_read_b128 = 16 lanes on 16
 // slots; every access below is conflict-free, checked by tools/experiments/lds_layout_check.py):
-//   transposition 1   slot = k1 * 68 + l
-//   transposition 2   slot = k1 * 68 + 8 ka + ((b + ka) & 7)
+//   transposition 1   slot = k1 * 68 + 8 a + ((b + a) & 7),  l = 8 a + b
+//   transposition 2   slot = k1 * 68 + 8 ka + ((b + ka) & 7)      (in place: a lane overwrites the diagonal it read)
 //   natural order     slot = wf_slot(k) = (k & ~7) | ((k + 2 ((k >> 4) & 3)) & 7)      (wave_fft_store_natural)
 #pragma once
 #include "reg_fft.hpp"
@@ -67,34 +67,62 @@ __device__ __forceinline__ void reg_fft16_upper_zero(cplx (&v)[16]) {
     for (int i = 0; i < 8; ++i) { v[i] = lo[i]; v[8 + i] = hi[i]; }
 }
 
-// v[n1] = z[64 n1 + l] in, v[i] = Z[wf_bin(l, i)] out; tb = this wave's WF_BUF slots, tables = wave_fft_tables
+// The three passes, separately for callers that put other work between them (decode.hip requests the next channel pair after
+// pass 1, when the 16 input registers are free, and consumes pass 3 one half at a time).
+//   wf_pass1        v[n1] = z[64 n1 + l] in; rows A'[k1][.] in the buffer afterwards
+//   wf_pass2_half   b = s + 4 H: the diagonal {8 a + ((b + a) & 7)} of row k1 is replaced IN PLACE by B'[k1][b][ka] (a -> ka)
+//   wf_pass3_half   ka = s + 4 E: out[j] = Z[k1 + 16 ka + 128 bitrev3(j)]
 template <bool UPPER_ZERO>
-__device__ __forceinline__ void wave_fft1024(cplx (&v)[16], cplx* tb, const cplx* tables, int l) {
+__device__ __forceinline__ void wf_pass1(cplx (&v)[16], cplx* tb, const cplx* tables, int l) {
     if (UPPER_ZERO) reg_fft16_upper_zero(v); else reg_fft<16>(v);
+    const int lsw = (l & ~7) | ((l + (l >> 3)) & 7);
+    // (four twiddles at a time: sixteen table reads in flight cost 64 registers the callers' accumulators need)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tb[rf_bitrev<4>(i) * WF_ROW + l] = v[i] * tables[i * 64 + l];
+    for (int i0 = 0; i0 < 16; i0 += 4) {
+        cplx t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = tables[(i0 + i) * 64 + l];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tb[rf_bitrev<4>(i0 + i) * WF_ROW + lsw] = v[i0 + i] * t[i];
+        __builtin_amdgcn_sched_barrier(0);
+    }
     wave_lds_fence();
-    const int s = l & 3;
+}
+template <int H>
+__device__ __forceinline__ void wf_pass2_half(cplx* tb, const cplx* tables, int l) {
+    const int b = (l & 3) + 4 * H;
     cplx* row = tb + (l >> 2) * WF_ROW;
-    const cplx* tw2 = tables + WF_TW1 + s;
-    cplx u0[8], u1[8];
+    const cplx* tw2 = tables + WF_TW1 + 32 * H + (l & 3);
+    cplx u[8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) { u0[a] = row[8 * a + s]; u1[a] = row[8 * a + s + 4]; }
-    reg_fft<8>(u0);
-    reg_fft<8>(u1);
-    wave_lds_fence();
+    for (int a = 0; a < 8; ++a) u[a] = row[8 * a + ((b + a) & 7)];
+    reg_fft<8>(u);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ka = rf_bitrev<3>(j);
-        row[8 * ka + ((s + ka) & 7)] = (j == 0) ? u0[j] : u0[j] * tw2[4 * j];
-        row[8 * ka + ((s + 4 + ka) & 7)] = (j == 0) ? u1[j] : u1[j] * tw2[4 * (8 + j)];
+        row[8 * ka + ((b + ka) & 7)] = (j == 0) ? u[j] : u[j] * tw2[4 * j];
     }
-    wave_lds_fence();
+}
+template <int E>
+__device__ __forceinline__ void wf_pass3_half(cplx (&out)[8], const cplx* tb, int l) {
+    const int ka = (l & 3) + 4 * E;
+    const cplx* rowk = tb + (l >> 2) * WF_ROW + 8 * ka;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) { u0[b] = row[8 * s + ((b + s) & 7)]; u1[b] = row[8 * (s + 4) + ((b + s + 4) & 7)]; }
+    for (int b = 0; b < 8; ++b) out[b] = rowk[(b + ka) & 7];
+    reg_fft<8>(out);
+}
+
+// v[n1] = z[64 n1 + l] in, v[i] = Z[wf_bin(l, i)] out; tb = this wave's WF_BUF slots, tables = wave_fft_tables
+template <bool UPPER_ZERO>
+__device__ __forceinline__ void wave_fft1024(cplx (&v)[16], cplx* tb, const cplx* tables, int l) {
+    wf_pass1<UPPER_ZERO>(v, tb, tables, l);
+    wf_pass2_half<0>(tb, tables, l);
+    wf_pass2_half<1>(tb, tables, l);
     wave_lds_fence();
-    reg_fft<8>(u0);
-    reg_fft<8>(u1);
+    cplx u0[8], u1[8];
+    wf_pass3_half<0>(u0, tb, l);
+    wf_pass3_half<1>(u1, tb, l);
+    wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < 8; ++j) { v[j] = u0[j]; v[8 + j] = u1[j]; }
 }

@@ -1214,10 +1214,11 @@ def test_binaural_decode(golden):
 
 
 @pytest.mark.parametrize("nsamp,nch,length", [(5000, 25, 512), (777, 4, 64), (100, 9, 256), (3000, 1, 2), (4097, 7, 1000),
-                                              (9000, 36, 2048), (2600, 16, 3000)])
+                                              (9000, 36, 2048), (2600, 16, 3000), (2000, 3, 257), (600000, 5, 400)])
 def test_binaural_decode_shapes(nsamp, nch, length, monkeypatch):
-    """The fused overlap-save kernels (up to 512 taps: register-resident two-factor transforms; up to 2048 taps: LDS transform
-    passes; segments, spectra and products never leave the CU) on ragged shapes --
+    """The fused overlap-save kernels (257..512 taps: wave-private 1024-point transforms, one wave per block on long signals
+    and eight waves per block on short ones; up to 256 taps, or with EMAGLS_DECODE_WAVE=0: half-wave two-factor transforms;
+    up to 2048 taps: LDS transform passes; segments, spectra and products never leave the CU) on ragged shapes --
     odd channel counts (the last transform carries one channel), signals shorter than a block, one channel, two taps, a length
     that is not a power of two -- against the oracle's time-domain sum, and against the hipFFT passes (EMAGLS_DECODE_FUSED=0),
     which also serve the filters above 2048 taps."""
@@ -1229,13 +1230,15 @@ def test_binaural_decode_shapes(nsamp, nch, length, monkeypatch):
     out = E.binauralDecode(sig, 48000, wL, wR, 48000)
     ref = O.binauralDecode(sig, wL, wR)
     assert out.shape == ref.shape == (nsamp, 2)
+    monkeypatch.setenv("EMAGLS_DECODE_WAVE", "0")        # the half-wave two-factor form (what up to 256 taps take anyway)
+    half = E.binauralDecode(sig, 48000, wL, wR, 48000)
     monkeypatch.setenv("EMAGLS_DECODE_REGFFT", "0")      # the fused kernel on LDS transform passes (what 513..2048 taps take anyway)
     lds = E.binauralDecode(sig, 48000, wL, wR, 48000)
     monkeypatch.setenv("EMAGLS_DECODE_FUSED", "0")
     plain = E.binauralDecode(sig, 48000, wL, wR, 48000)
-    print(f"decode {nsamp} x {nch}, {length} taps: fused vs oracle rel = {rel(out, ref):.3e}, LDS-pass form {rel(lds, ref):.3e}, "
-          f"hipFFT passes {rel(plain, ref):.3e}")
-    assert rel(out, ref) < 1e-12 and rel(lds, ref) < 1e-12 and rel(plain, ref) < 1e-12
+    print(f"decode {nsamp} x {nch}, {length} taps: fused vs oracle rel = {rel(out, ref):.3e}, half-wave form {rel(half, ref):.3e}, "
+          f"LDS-pass form {rel(lds, ref):.3e}, hipFFT passes {rel(plain, ref):.3e}")
+    assert rel(out, ref) < 1e-12 and rel(half, ref) < 1e-12 and rel(lds, ref) < 1e-12 and rel(plain, ref) < 1e-12
 
 
 def _sn3d_sh(N, dirs, basisType="real"):

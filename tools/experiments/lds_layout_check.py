@@ -24,8 +24,8 @@ def slot(k):
 
 if __name__ == "__main__":
     assert sorted(slot(k) for k in range(1024)) == list(range(1024))
-    print("transposition 1 write", max(worst(lambda l: k1 * ROW + l, WG, 8) for k1 in range(16)))
-    print("transposition 1 read ", max(worst(lambda l: (l >> 2) * ROW + 8 * a + (l & 3) + 4 * d, RG, 16) for a in range(8) for d in range(2)))
+    print("transposition 1 write", max(worst(lambda l: k1 * ROW + ((l & ~7) | ((l + (l >> 3)) & 7)), WG, 8) for k1 in range(16)))
+    print("transposition 1 read ", max(worst(lambda l: (l >> 2) * ROW + 8 * a + (((l & 3) + 4 * d + a) & 7), RG, 16) for a in range(8) for d in range(2)))
     print("transposition 2 write", max(worst(lambda l: (l >> 2) * ROW + ka * 8 + (((l & 3) + 4 * d + ka) & 7), WG, 8) for ka in range(8) for d in range(2)))
     print("transposition 2 read ", max(worst(lambda l: (l >> 2) * ROW + ((l & 3) + 4 * e) * 8 + ((b + (l & 3) + 4 * e) & 7), RG, 16)
                                        for b in range(8) for e in range(2)))
