@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(512) hrir_fft_kernel(const double* __restrict_
 // table grpdelay_median_kernel leaves behind grpd (mode 0).
 // ---------------------------------------------------------------------------------------------
 constexpr int HW_TD = 8;
+constexpr int HW_STRIDE = WF_BUF + 1;   // slots between the waves' buffers (+1: the |H| gather reads 8 buffers at one slot index)
 __global__ void __launch_bounds__(64 * HW_TD) hrir_fft_wave_kernel(const double* __restrict__ hL, const double* __restrict__ hR,
                                                                    int64_t L, int64_t D, const int64_t* __restrict__ didx,
                                                                    const cplx* __restrict__ tw, const double* __restrict__ grpd,
@@ -273,7 +274,7 @@ __global__ void __launch_bounds__(64 * HW_TD) hrir_fft_wave_kernel(const double*
     __syncthreads();
     const int64_t d0 = (int64_t)blockIdx.x * HW_TD;
     const int nt = (int)min((int64_t)HW_TD, D - d0);
-    cplx* tb = bufs + (size_t)w * WF_BUF;
+    cplx* tb = bufs + (size_t)w * HW_STRIDE;
     if (w < nt) {
         const int64_t d = d0 + w;
         const int64_t dsrc = didx ? didx[d] : d;
@@ -328,19 +329,15 @@ __global__ void __launch_bounds__(64 * HW_TD) hrir_fft_wave_kernel(const double*
         }
     }
     __syncthreads();
-    // |H| rows: 8 consecutive directions per (bin, ear) and thread
+    // |H| rows: lane = (row, direction), so that a wave's store covers 8 rows x 64 contiguous bytes (one thread per row with its
+    // eight directions costs 64 separate 16-byte pieces per store instruction: a third of the kernel's time)
     const int64_t na = P - kabs0;
-    for (int idx = tid; idx < 2 * P; idx += 64 * HW_TD) {
-        const int e = idx >= P, kb = idx - e * P;
-        if (kb < kabs0) continue;
-        const double* src = reinterpret_cast<const double*>(bufs + wf_slot(kb)) + e;
-        double* row = Habs + ((int64_t)e * na + (kb - kabs0)) * ldD + d0;   // (ldD and d0 are multiples of 8: 64-byte aligned)
-        if (nt == HW_TD) {
-#pragma unroll
-            for (int t = 0; t < HW_TD; t += 2)
-                *reinterpret_cast<double2*>(row + t) = make_double2(src[(size_t)t * WF_BUF * 2], src[(size_t)(t + 1) * WF_BUF * 2]);
-        } else {
-            for (int t = 0; t < nt; ++t) row[t] = src[(size_t)t * WF_BUF * 2];
+    const int t = tid & (HW_TD - 1);
+    if (t < nt) {
+        const double* src = reinterpret_cast<const double*>(bufs + (size_t)t * HW_STRIDE);
+        for (int idx = tid >> 3; idx < 2 * (P - kabs0); idx += 64) {
+            const int e = idx >= P - kabs0, kr = idx - e * (P - kabs0);
+            Habs[((int64_t)e * na + kr) * ldD + d0 + t] = src[2 * wf_slot(kr + kabs0) + e];
         }
     }
 }
@@ -670,7 +667,7 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
     const int P = nfft / 2 + 1;
     if (P > HF_MAXS * 512) throw Error(2, "HRIR FFT: nfft above 2048 is not supported");
     if (nfft == WF_N && L <= WF_N && hrir_fft_wave_enabled()) {   // wave-private transforms
-        const size_t smw = sizeof(cplx) * (WF_TABLES + (size_t)HW_TD * WF_BUF);
+        const size_t smw = sizeof(cplx) * (WF_TABLES + (size_t)HW_TD * HW_STRIDE);
         static PerDeviceOnce wave_once;
         if (wave_once.first())
             HIP_CHECK(hipFuncSetAttribute((const void*)hrir_fft_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
