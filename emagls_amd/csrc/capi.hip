@@ -581,7 +581,9 @@ void plan_setup(emagls_plan& p) {
         if (p.C > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 ATF microphones is not supported in this build");
         p.hrir_smaller = d.ndirs <= d.natf;  // min([a b]) returns the first index on ties (FromAtf.m:62)
         p.Dm = p.hrir_smaller ? d.ndirs : d.natf;
-        if (p.Dm > 4096) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 4096 matched directions is not supported in this build");
+        // (up to 3072 matched directions: resident sweep; above: the Gram route with one launch per bin, sweep_half_kernel walking
+        // several slabs per workgroup; the dense route -- QR of the Dm x M matrix itself -- holds 4096 rows)
+        if (p.Dm > 65536) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 65536 matched directions is not supported in this build");
         if (p.Dm < p.C) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer directions than microphones");
     }
     p.ldS = round_up(std::max(p.S, 1), 64);
@@ -740,8 +742,8 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Hc", sizeof(cplx) * (size_t)2 * n_c * p.ldD);
         p.alloc("Habs", sizeof(double) * (size_t)2 * std::max(p.P - p.kcut0, 1) * p.ldD);
         p.alloc("W", sizeof(cplx) * (size_t)2 * p.P * p.C);
-        if (magls_kind(d.kind) || d.kind == EMAGLS_KIND_FROM_ATF || p.wide) p.nWG = dense_sweep_nwg((int)Dh);
-        p.nWG_dense = dense_sweep_nwg((int)Dh);
+        if (magls_kind(d.kind) || d.kind == EMAGLS_KIND_FROM_ATF || p.wide) p.nWG = dense_sweep_nwg((int)Dh, p.C);
+        p.nWG_dense = dense_sweep_nwg((int)Dh, p.C);
         // the persistent sweep keeps one workgroup per CU resident (142 KB of LDS each): it needs the shape to fit one XCD's
         // 32 CUs per design AND that many CUs on this device (a partitioned or CU-masked GPU takes the launch-per-bin form)
         p.sweep_persist = plan_persist_possible(p);
@@ -1552,7 +1554,9 @@ void from_atf_post_sweep(emagls_plan& p) {
 }
 
 void execute_from_atf(emagls_plan& p) {
-    if (p.sweep_persist) {   // (eager / profiled executes; plan_execute captures the stages around the sweep otherwise)
+    // (eager / profiled executes; plan_execute captures the stages around the sweep otherwise.  More matched directions than the
+    // dense route's QR holds: the Gram route as well, emagls_run_sweep then launches bin by bin)
+    if (p.sweep_persist || p.Dm > 4096) {
         from_atf_pre_sweep(p);
         emagls_run_sweep(p);
         from_atf_post_sweep(p);

@@ -84,7 +84,7 @@ struct DenseSweepArgs;
 struct HalfSweepArgs;
 struct HalfSweepMulti;
 void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st);
-int dense_sweep_nwg(int D);
+int dense_sweep_nwg(int D, int C);
 void launch_sweep_half(const HalfSweepMulti& m, int kb, hipStream_t st);
 void launch_sweep_half_finalize(const HalfSweepMulti& m, int kb_last, hipStream_t st);
 // ---- sweep_persist.hip

@@ -75,7 +75,10 @@ __device__ __forceinline__ void sweep_dense_body(const DenseSweepArgs& a, int kb
     cplx* Wout = a.Wpart + (int64_t)(kb & 1) * nWG * 2 * C;
     const TX* X = reinterpret_cast<const TX*>(a.X) + (int64_t)kb * a.x_stride;
     const TX* Zd = reinterpret_cast<const TX*>(a.Zd) + (int64_t)kb * a.z_stride;
-    const int64_t d0 = (int64_t)blockIdx.x * DS_DPW;
+    // grids of more than 64 x 4096 / (2 C) directions: a workgroup walks `spw` slabs of 64 directions, so that the partial sums
+    // the next launch stages stay within 16 per thread (dense_sweep_nwg)
+    const int nslab = (a.D + DS_DPW - 1) / DS_DPW, spw = (nslab + nWG - 1) / nWG;
+    int64_t d0 = (int64_t)blockIdx.x * spw * DS_DPW;
     const int64_t na = a.P - a.kabs0;
     // ---- 0. every load of the launch goes out up front; the previous launch's partial sums first
     //         (they gate the chain and memory returns in order), then this slab's operands
@@ -88,20 +91,25 @@ __device__ __forceinline__ void sweep_dense_body(const DenseSweepArgs& a, int kb
         gv[i] = (!first && f < npart) ? Wprev[f] : mk(0, 0);
     }
     const int e_ = tid / DS_DPW, dd_ = tid % DS_DPW;       // phase-1 role: (ear, direction)
-    const int64_t d_ = d0 + dd_;
-    const bool p1 = tid < 2 * DS_DPW && d_ < a.D;
-    TX xr[SW_CMAX];
-#pragma unroll
-    for (int c = 0; c < SW_CMAX; ++c) xr[c] = (p1 && c < C) ? X[(int64_t)c * a.ldD + d_] : zero_of<TX>();
-    const double habs = p1 ? a.Habs[((int64_t)e_ * na + (kb - a.kabs0)) * a.ldH + d_] : 0.0;
     const int pair2 = tid >> 2, part2 = tid & 3;             // phase-2 role: (ear, channel) x 4 lanes
     constexpr int NZ = DS_DPW / 4;
+    TX xr[SW_CMAX];
     TX zr[NZ];
+    double habs;
+    bool p1;
+    auto load_slab = [&]() __attribute__((always_inline)) {
+        const int64_t d_ = d0 + dd_;
+        p1 = tid < 2 * DS_DPW && d_ < a.D;
 #pragma unroll
-    for (int j = 0; j < NZ; ++j) {
-        const int64_t d = d0 + part2 + 4 * j;
-        zr[j] = (pair2 < 2 * C && d < a.D) ? Zd[(int64_t)(pair2 % C) * a.ldD + d] : zero_of<TX>();
-    }
+        for (int c = 0; c < SW_CMAX; ++c) xr[c] = (p1 && c < C) ? X[(int64_t)c * a.ldD + d_] : zero_of<TX>();
+        habs = p1 ? a.Habs[((int64_t)e_ * na + (kb - a.kabs0)) * a.ldH + d_] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+            const int64_t d = d0 + part2 + 4 * j;
+            zr[j] = (pair2 < 2 * C && d < a.D) ? Zd[(int64_t)(pair2 % C) * a.ldD + d] : zero_of<TX>();
+        }
+    };
+    load_slab();
     // ---- 1. W(k-1) = sum of the staged partials
 #pragma unroll
     for (int i = 0; i < NGV; ++i) {
@@ -131,29 +139,39 @@ __device__ __forceinline__ void sweep_dense_body(const DenseSweepArgs& a, int kb
         }
     }
     __syncthreads();
-    // ---- 2. p = W(k-1) pwGrid ;  t = |H| p/|p|
-    if (tid < 2 * DS_DPW) {
-        cplx t = mk(0, 0);
-        if (p1) {
-            cplx pa = mk(0, 0), pb = mk(0, 0);
-#pragma unroll
-            for (int c = 0; c < SW_CMAX; c += 2) {
-                if (c < C) cfma(pa, Wp[e_ * C + c], xr[c]);
-                if (c + 1 < C) cfma(pb, Wp[e_ * C + c + 1], xr[c + 1]);
-            }
-            t = unit_phase_times(habs, pa + pb, nyq);
+    cplx acc3 = mk(0, 0);
+    for (int sl = 0; sl < spw; ++sl) {
+        if (sl > 0) {
+            __syncthreads();   // (the previous slab's t has been consumed)
+            d0 += DS_DPW;
+            load_slab();
         }
-        ts[e_][dd_] = t;
+        // ---- 2. p = W(k-1) pwGrid ;  t = |H| p/|p|
+        if (tid < 2 * DS_DPW) {
+            cplx t = mk(0, 0);
+            if (p1) {
+                cplx pa = mk(0, 0), pb = mk(0, 0);
+#pragma unroll
+                for (int c = 0; c < SW_CMAX; c += 2) {
+                    if (c < C) cfma(pa, Wp[e_ * C + c], xr[c]);
+                    if (c + 1 < C) cfma(pb, Wp[e_ * C + c + 1], xr[c + 1]);
+                }
+                t = unit_phase_times(habs, pa + pb, nyq);
+            }
+            ts[e_][dd_] = t;
+        }
+        __syncthreads();
+        // ---- 3. partial W(k,:)[e][c] = sum_{d in slab} t[e][d] Y_reg_inv[d][c] ; 4 lanes per (e,c)
+        if (pair2 < 2 * C) {
+            const int e = pair2 / C;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) cfma(acc3, ts[e][part2 + 4 * j], zr[j]);
+        }
     }
-    __syncthreads();
-    // ---- 3. partial W(k,:)[e][c] = sum_{d in slab} t[e][d] Y_reg_inv[d][c] ; 4 lanes per (e,c)
     if (pair2 < 2 * C) {
         const int e = pair2 / C, c = pair2 % C;
-        cplx acc = mk(0, 0);
-#pragma unroll
-        for (int j = 0; j < NZ; ++j) cfma(acc, ts[e][part2 + 4 * j], zr[j]);
-        acc = group_sum<4>(acc);
-        if (part2 == 0) Wout[((int64_t)e * C + c) * nWG + blockIdx.x] = acc;
+        acc3 = group_sum<4>(acc3);
+        if (part2 == 0) Wout[((int64_t)e * C + c) * nWG + blockIdx.x] = acc3;
     }
 }
 
@@ -187,7 +205,8 @@ __device__ __forceinline__ void sweep_half_body(const HalfSweepArgs& a, int kb, 
     const cplx* Wprev = a.Wpart + (int64_t)((kb - 1) & 1) * nWG * 2 * C;
     cplx* Wout = a.Wpart + (int64_t)(kb & 1) * nWG * 2 * C;
     const cplx* X = a.G + (int64_t)kb * a.g_stride;
-    const int64_t d0 = (int64_t)blockIdx.x * DS_DPW;
+    const int nslab = (a.D + DS_DPW - 1) / DS_DPW, spw = (nslab + nWG - 1) / nWG;   // (slabs per workgroup: sweep_dense_body)
+    int64_t d0 = (int64_t)blockIdx.x * spw * DS_DPW;
     const int64_t na = a.P - a.kabs0;
     // ---- 0. all loads up front; the previous launch's partial sums first (they gate the chain)
     constexpr int NGV = 16;
@@ -200,11 +219,27 @@ __device__ __forceinline__ void sweep_half_body(const HalfSweepArgs& a, int kb, 
     }
     constexpr int NXV = (SW_CMAX * DS_DPW) / DS_NT;  // 8 slab elements per thread
     cplx xv[NXV];
+    const int e_ = tid / DS_DPW, dd_ = tid % DS_DPW;
+    double habs;
+    bool p1;
+    auto load_slab = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NXV; ++i) {
-        const int f = tid + DS_NT * i, c = f / DS_DPW, dd = f % DS_DPW;
-        xv[i] = (c < C && d0 + dd < a.D) ? X[(int64_t)c * a.ldD + d0 + dd] : mk(0, 0);
-    }
+        for (int i = 0; i < NXV; ++i) {
+            const int f = tid + DS_NT * i, c = f / DS_DPW, dd = f % DS_DPW;
+            xv[i] = (c < C && d0 + dd < a.D) ? X[(int64_t)c * a.ldD + d0 + dd] : mk(0, 0);
+        }
+        const int64_t d_ = d0 + dd_;
+        p1 = tid < 2 * DS_DPW && d_ < a.D;
+        habs = p1 ? a.Habs[((int64_t)e_ * na + (kb - a.kabs0)) * a.ldH + d_] : 0.0;
+    };
+    auto stage_slab = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) {
+            const int f = tid + DS_NT * i, c = f / DS_DPW, dd = f % DS_DPW;
+            if (c < C) xs[(size_t)c * (DS_DPW + 1) + dd] = xv[i];
+        }
+    };
+    load_slab();
     constexpr int NMV = (SW_CMAX * SW_CMAX) / DS_NT;  // 4 elements of M per thread
     const cplx* M = a.Mw + (int64_t)(kb - 1) * C * C;
     cplx mv[NMV];
@@ -213,10 +248,6 @@ __device__ __forceinline__ void sweep_half_body(const HalfSweepArgs& a, int kb, 
         const int f = tid + DS_NT * i;
         mv[i] = (!first && f < C * C) ? M[f] : mk(0, 0);
     }
-    const int e_ = tid / DS_DPW, dd_ = tid % DS_DPW;
-    const int64_t d_ = d0 + dd_;
-    const bool p1 = tid < 2 * DS_DPW && d_ < a.D;
-    const double habs = p1 ? a.Habs[((int64_t)e_ * na + (kb - a.kabs0)) * a.ldH + d_] : 0.0;
     const bool prev_ok = first ? true : (a.cond_ok[kb - 1] != 0.0);
     const bool cur_ok = a.cond_ok[kb] != 0.0;
     // ---- 1. stage everything in LDS
@@ -225,11 +256,7 @@ __device__ __forceinline__ void sweep_half_body(const HalfSweepArgs& a, int kb, 
         const int f = tid + DS_NT * i;
         if (f < npart) stage[f + f / nWG] = gv[i];
     }
-#pragma unroll
-    for (int i = 0; i < NXV; ++i) {
-        const int f = tid + DS_NT * i, c = f / DS_DPW, dd = f % DS_DPW;
-        if (c < C) xs[(size_t)c * (DS_DPW + 1) + dd] = xv[i];
-    }
+    stage_slab();
 #pragma unroll
     for (int i = 0; i < NMV; ++i) {
         const int f = tid + DS_NT * i;
@@ -272,28 +299,35 @@ __device__ __forceinline__ void sweep_half_body(const HalfSweepArgs& a, int kb, 
         }
     }
     __syncthreads();
-    // ---- 4. p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
-    if (tid < 2 * DS_DPW) {
-        cplx t = mk(0, 0);
-        if (p1) {
-            cplx pa = mk(0, 0), pb = mk(0, 0);
-            int c = 0;
-            for (; c + 1 < C; c += 2) {
-                cfma(pa, Wp[e_ * C + c], xs[(size_t)c * (DS_DPW + 1) + dd_]);
-                cfma(pb, Wp[e_ * C + c + 1], xs[(size_t)(c + 1) * (DS_DPW + 1) + dd_]);
-            }
-            if (c < C) cfma(pa, Wp[e_ * C + c], xs[(size_t)c * (DS_DPW + 1) + dd_]);
-            t = unit_phase_times(habs, pa + pb, nyq);
+    cplx a0 = mk(0, 0), a1 = mk(0, 0);
+    for (int sl = 0; sl < spw; ++sl) {
+        if (sl > 0) {
+            __syncthreads();   // (the previous slab and its t have been consumed)
+            d0 += DS_DPW;
+            load_slab();
+            stage_slab();
+            __syncthreads();
         }
-        ts[e_][dd_] = t;
-    }
-    __syncthreads();
-    // ---- 5. partial of this slab: v = t conj(G)  (or t Y_reg_inv for an ill-conditioned bin); 4 lanes per (e,c)
-    {
+        // ---- 4. p = W(kb-1,:) pwGrid ;  t = |H| p/|p|
+        if (tid < 2 * DS_DPW) {
+            cplx t = mk(0, 0);
+            if (p1) {
+                cplx pa = mk(0, 0), pb = mk(0, 0);
+                int c = 0;
+                for (; c + 1 < C; c += 2) {
+                    cfma(pa, Wp[e_ * C + c], xs[(size_t)c * (DS_DPW + 1) + dd_]);
+                    cfma(pb, Wp[e_ * C + c + 1], xs[(size_t)(c + 1) * (DS_DPW + 1) + dd_]);
+                }
+                if (c < C) cfma(pa, Wp[e_ * C + c], xs[(size_t)c * (DS_DPW + 1) + dd_]);
+                t = unit_phase_times(habs, pa + pb, nyq);
+            }
+            ts[e_][dd_] = t;
+        }
+        __syncthreads();
+        // ---- 5. partial of this slab: v = t conj(G)  (or t Y_reg_inv for an ill-conditioned bin); 4 lanes per (e,c)
         const int pair = tid >> 2, part = tid & 3;
         if (pair < 2 * C) {
             const int e = pair / C, c = pair % C;
-            cplx a0 = mk(0, 0), a1 = mk(0, 0);
             if (cur_ok) {
                 const cplx* xrow = xs + (size_t)c * (DS_DPW + 1);
 #pragma unroll
@@ -306,6 +340,12 @@ __device__ __forceinline__ void sweep_half_body(const HalfSweepArgs& a, int kb, 
                 for (int dd = part; dd < DS_DPW; dd += 4)
                     if (d0 + dd < a.D) cfma(a0, ts[e][dd], Y[d0 + dd]);
             }
+        }
+    }
+    {
+        const int pair = tid >> 2, part = tid & 3;
+        if (pair < 2 * C) {
+            const int e = pair / C, c = pair % C;
             cplx acc = group_sum<4>(a0 + a1);
             if (part == 0) Wout[((int64_t)e * C + c) * nWG + blockIdx.x] = acc;
         }
@@ -528,7 +568,14 @@ void launch_sweep_dense(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_
     else sweep_dense_kernel<double><<<a.nWG, DS_NT, dyn, st>>>(a, kb);
     KERNEL_CHECK();
 }
-int dense_sweep_nwg(int D) { return (D + DS_DPW - 1) / DS_DPW; }
+// workgroups of the launch-per-bin sweeps: one per slab of 64 directions while the next launch can stage all their partial sums
+// (2 C nWG <= 16 per thread), several slabs per workgroup on larger grids
+int dense_sweep_nwg(int D, int C) {
+    const int nslab = (D + DS_DPW - 1) / DS_DPW, cap = std::max(1, 16 * DS_NT / (2 * std::max(C, 1)));
+    if (C > SW_CMAX) return nslab;   // (sweep_wide_kernel: one slab per workgroup, the partial sums are read in a loop)
+    const int spw = (nslab + cap - 1) / cap;
+    return (nslab + spw - 1) / spw;
+}
 
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st) {
     sweep_finalize_kernel<<<1, SW_NT, 0, st>>>((const cplx*)Wpart, (cplx*)W, nWG, C, P, kb_last);

@@ -1058,6 +1058,31 @@ def test_from_atf_small(thin):
     assert report("FromAtf L", wL, oL) < TOL and report("FromAtf R", wR, oR) < TOL
 
 
+def test_designs_on_large_hrir_grids():
+    """lib/*.m take any number of HRIR directions.  Above 3072 the resident sweep does not hold a design on one XCD and the
+    launch-per-bin sweeps take over, their workgroups walking several 64-direction slabs (dense_sweep_nwg) so that the next
+    launch can still stage every partial sum; FromAtf above 4096 matched directions stays on the Gram route.  MagLS, eMagLS and
+    FromAtf on a 5000-point grid against the oracle."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    D = 5000
+    azi, zen = synth.fibonacci_grid(D)
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen, taps=64)
+    maz, mzn = synth.em32_grid()
+    wL, wR = E.getMagLsFilters(hL, hR, azi, zen, 4, 48000.0, 128)
+    oL, oR = O.getMagLsFilters(hL, hR, azi, zen, 4, 48000.0, 128)
+    assert report("MagLS, 5000 directions L", wL, oL) < TOL and report("R", wR, oR) < TOL
+    args = (hL, hR, azi, zen, 0.042, maz, mzn, 4, 48000.0, 128)
+    wL, wR = E.getEMagLsFilters(*args)
+    oL, oR = O.getEMagLsFilters(*args)
+    assert report("eMagLS, 5000 directions L", wL, oL) < TOL and report("R", wR, oR) < TOL
+    atf, aazi, azen = synth.glasses_atfs(natf=5300, nmics=8, taps=64)
+    hg, ag = np.column_stack([azi, zen]), np.column_stack([aazi, azen])
+    wL, wR = E.getEMagLsFiltersFromAtf(hL, hR, hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)
+    oL, oR, _ = O.getEMagLsFiltersFromAtf(hL, hR, hg, atf, ag, 48000.0, 128, 2000.0)
+    assert report("FromAtf, 5000 matched directions L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
 def test_from_atf_512_taps_wave_prologue(thin, monkeypatch):
     """512-tap FromAtf filters: nfft = 1024, so the HRIR prologue with the integer circshift (lib/getEMagLsFiltersFromAtf.m:43-53)
     runs on the wave-private transforms; same design with EMAGLS_HRIR_FFT_WAVE=0 on the LDS form."""
