@@ -5,6 +5,7 @@ config 4: getEMagLs2Filters, raw 32-microphone em32, 2702 directions, 1024 taps 
           middle (r = 5 cm, order 22) and at the far end (r = 10 cm, order 44) of the radius range;
 config 5: getEMagLsFiltersFromAtf, 16 384 ATF directions x 8 microphones, 2702 HRIR directions, 2048 taps -- one HRTF subject.
 Inputs resident in HBM, hipGraph replay where the pipeline captures; wall-clock over `reps` executes after three warm ones."""
+import json
 import os
 import sys
 import time
@@ -27,7 +28,28 @@ def _grids():
     return azi, zen, maz, mzn
 
 
-def config4(radii, reps=4):
+def _roofline(workload, ms_per_execute, compulsory_bytes, note):
+    """`roofline` block of a secondary workload: its time per execute (measured here) against the HBM bytes one execute moves
+    (PMC passes of the same workload, profiles/secondary_traffic.json -- written by tools/secondary_traffic.py from
+    tools/experiments/secondary_prof.sh) and against the bytes it has to move at least (inputs once in, filters once out)."""
+    path = os.path.join(ROOT, "profiles", "secondary_traffic.json")
+    t = {}
+    try:
+        t = json.load(open(path)).get(workload, {})
+    except Exception:
+        pass
+    sec = ms_per_execute * 1e-3
+    traffic = t.get("bytes_per_execute")
+    out = {"bound": "latency", "ms_per_execute": round(ms_per_execute, 4), "compulsory_bytes": int(compulsory_bytes),
+           "compulsory_GBps": round(compulsory_bytes / sec / 1e9, 1), "traffic": traffic,
+           "achieved": round(traffic / sec / 1e9, 1) if traffic else None, "peak": 8000.0, "unit": "GB/s",
+           "frac": round(traffic / sec / 1e9 / 8000.0, 4) if traffic else None,
+           "traffic_over_compulsory": round(traffic / compulsory_bytes, 2) if traffic else None,
+           "kernel_time_us_per_execute": t.get("kernel_time_us_per_execute"), "dominant_kernel": t.get("dominant_kernel"), "note": note}
+    return out
+
+
+def config4(radii, reps=4, roofline_key=None):
     from emagls_amd import Batch, Plan, synth, _lib as L
     azi, zen, maz, mzn = _grids()
     hL, hR = synth.rigid_sphere_hrirs(azi, zen)
@@ -53,9 +75,14 @@ def config4(radii, reps=4):
     b.close()
     for p in plans:
         p.close()
-    return {"radii_cm": [round(100 * float(radii[0]), 3), round(100 * float(radii[-1]), 3)], "designs_per_batch": len(radii), "lane_mode": lanes,
-            "sim_order": info.sim_order, "orthonormal_route_orders": info.hh_orders, "gram_route_from_bin": info.gram_from,
-            "ms_per_batch": round(dt * 1e3, 3), "filter_sets_per_s": round(len(radii) / dt, 1)}
+    res = {"radii_cm": [round(100 * float(radii[0]), 3), round(100 * float(radii[-1]), 3)], "designs_per_batch": len(radii), "lane_mode": lanes,
+           "sim_order": info.sim_order, "orthonormal_route_orders": info.hh_orders, "gram_route_from_bin": info.gram_from,
+           "ms_per_batch": round(dt * 1e3, 3), "filter_sets_per_s": round(len(radii) / dt, 1)}
+    if roofline_key:
+        comp = len(radii) * (2 * hL.size * 8 + 2 * 1024 * 32 * 8)
+        res["roofline"] = _roofline(roofline_key, dt * 1e3, comp, "one lane batch of 8 radii alone on the GPU; the resident sweep (1024 taps: 983 dependent "
+                                    "bins) is the dominant kernel and is bound by its per-bin exchange, not by bytes")
+    return res
 
 
 def config4_rank_share(world=8, rank=5, reps=2):
@@ -180,6 +207,11 @@ def config5(reps=4, subjects=8):
     b.get_filters()
     out["batch"] = {"subjects": subjects, "atf_side_shared": b.shares_atf_side(), "ms_per_batch": round(dtb * 1e3, 3),
                     "ms_per_subject": round(dtb * 1e3 / subjects, 3), "filter_sets_per_s": round(subjects / dtb, 1)}
+    hbytes = 2 * 2702 * 512 * 8     # (the synthetic HRIRs of one subject; the ATF set counts once per execute)
+    out["roofline"] = _roofline("config5_single", dt * 1e3, atf.size * 8 + hbytes + 2 * 2048 * 8 * 8,
+                                "one subject: 1024 dependent bins x 8 channels, bound by the per-bin exchange of the resident sweep")
+    out["batch"]["roofline"] = _roofline("config5_batch", dtb * 1e3, atf.size * 8 + subjects * (hbytes + 2 * 2048 * 8 * 8),
+                                         "8 subjects of one ATF set in one resident sweep launch")
     b.close()
     for q in plans:
         q.close()
@@ -304,7 +336,7 @@ def config2_hrir_sets(n_batches=3, per_batch=16, rounds=6, share=True, diffuse=F
             "filter_sets_per_s": round(n / dt, 1)}
 
 
-def binaural_decode(nsamp=120000, nch=25, length=512, reps=10):
+def binaural_decode(nsamp=120000, nch=25, length=512, reps=10, kinds=("real", "complex")):
     """north_star item (iii) / SURVEY a13: dependencies/binauralDecode.m:33-42 at the harness's size -- a 120 000-sample SH
     recording x 25 channels through 512-tap filters, both ears -- real and complex SH, buffers resident in HBM
     (emagls_binaural_decode_device: overlap-save on hipFFT).  Algorithmic bytes = signal in + filters in + two ears out;
@@ -316,6 +348,8 @@ def binaural_decode(nsamp=120000, nch=25, length=512, reps=10):
     rng = np.random.default_rng(5)
     out = {}
     for name, cplx in (("real", False), ("complex", True)):
+        if name not in kinds:
+            continue
         dt = np.complex128 if cplx else np.float64
         sig = rng.standard_normal((nch, nsamp)) + (1j * rng.standard_normal((nch, nsamp)) if cplx else 0)
         wl = rng.standard_normal((nch, length)) + (1j * rng.standard_normal((nch, length)) if cplx else 0)
@@ -338,14 +372,18 @@ def binaural_decode(nsamp=120000, nch=25, length=512, reps=10):
         nbytes = es * nsamp * nch + 2 * es * length * nch + 8.0 * nsamp * 2
         out[name] = {"ms": round(t * 1e3, 4), "samples_per_s": round(nsamp / t, 1), "realtime_factor_48k": round(nsamp / 48000.0 / t, 1),
                      "algorithmic_bytes": nbytes, "achieved_GBps": round(nbytes / t / 1e9, 2), "frac_of_hbm_peak": round(nbytes / t / 1e9 / 8000.0, 5)}
+        if nsamp >= 1000000:
+            out[name]["roofline"] = _roofline("decode_" + name, t * 1e3, nbytes, "overlap-save blocks on wave-private transforms; every sample is part of two "
+                                              "segments -- the eight blocks of a workgroup are consecutive, so seven of eight second reads stay in the CU's caches")
+            out[name]["roofline"]["bound"] = "hbm"
     out["shape"] = {"samples": nsamp, "channels": nch, "taps": length}
     return out
 
 
-def binaural_decode_long(nsamp=4800000, nch=25, length=512, reps=3):
+def binaural_decode_long(nsamp=4800000, nch=25, length=512, reps=3, kinds=("real", "complex")):
     """The same render loop on 100 s of audio (4.8 M samples): launch overheads no longer count, what remains is the traffic of
     the overlap-save passes."""
-    out = binaural_decode(nsamp, nch, length, reps)
+    out = binaural_decode(nsamp, nch, length, reps, kinds)
     return out
 
 
@@ -353,7 +391,7 @@ def run():
     out = {}
     for name, radii in (("config4_r5cm", np.linspace(0.0480, 0.0500, 8)), ("config4_r10cm", np.linspace(0.0980, 0.1000, 8))):
         try:
-            out[name] = config4(radii)
+            out[name] = config4(radii, roofline_key=name)
         except Exception as e:
             out[name] = {"error": repr(e)}
     try:

@@ -1,5 +1,7 @@
-"""rocprofv3 target: a few binauralDecode calls on device buffers (fused overlap-save kernel against the hipFFT passes)."""
+"""rocprofv3 target: six binauralDecode calls on device buffers (100 s x 25 channels, 512 taps).
+    python tools/experiments/decode_prof.py [real|complex]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tools import bench_secondary as S
-print(json.dumps(S.binaural_decode_long(reps=3)))
+kind = sys.argv[1] if len(sys.argv) > 1 else "real"
+print(json.dumps(S.binaural_decode_long(reps=3, kinds=(kind,))))

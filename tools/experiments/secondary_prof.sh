@@ -14,9 +14,13 @@ run() {   # name, python script and arguments
   (cd $R; python tools/pmc_simple.py gpurun_out/${tag}_${name}.md gpurun_out/${tag}_${name}.json gpurun_out/${tag}_${name}_kt gpurun_out/${tag}_${name}_FETCH_SIZE gpurun_out/${tag}_${name}_WRITE_SIZE;
    rm -rf gpurun_out/${tag}_${name}_kt gpurun_out/${tag}_${name}_FETCH_SIZE gpurun_out/${tag}_${name}_WRITE_SIZE; head -8 gpurun_out/${tag}_${name}.md | cut -c1-170)
 }
-run decode $R/tools/experiments/decode_prof.py
+run decode_real $R/tools/experiments/decode_prof.py real
+run decode_complex $R/tools/experiments/decode_prof.py complex
 run shbasis $R/tools/experiments/shbasis_prof.py
 run config4_r5cm $R/tools/experiments/config4_prof.py 4.8 5.0
 run config4_r10cm $R/tools/experiments/config4_prof.py 9.8 10.0
 run config4_r2cm $R/tools/experiments/config4_prof.py 2.0 2.2 10
 run config5_batch $R/tools/experiments/config5_prof.py batch
+run config5_single $R/tools/experiments/config5_prof.py single
+run config3_batch $R/tools/experiments/config3_prof.py batch
+(cd $R; python tools/secondary_traffic.py $tag)
