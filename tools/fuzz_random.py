@@ -36,6 +36,12 @@ def draw(rng):
     D = int(rng.integers(60, 1600))
     taps = int(rng.choice([16, 33, 64, 100, 128, 200]))
     ln = int(2 * rng.integers(max(4, taps // 2), 200))          # even, >= taps (the reference asserts len >= HRIR length)
+    if os.environ.get("EMAGLS_FUZZ_ROUND4"):   # round 4's kernels: nfft = 1024 (wave-private HRIR prologue) and grids above 3072 directions
+        u = rng.random()
+        if u < 0.35:
+            ln, taps = 512, int(rng.choice([64, 200, 256, 400, 512]))
+        if 0.25 < u < 0.45 and kind in ("emagls", "emagls2", "magls", "ls", "emainch", "atf"):
+            D = int(rng.integers(3100, 7000))
     basis = str(rng.choice(["real", "complex"]))
     if kind in ("emagls", "emagls2"):
         N = int(rng.integers(0, 8))
