@@ -63,7 +63,9 @@ __global__ void __launch_bounds__(256) ypinv_gram_kernel(const T* __restrict__ Y
     if constexpr (sizeof(T) == sizeof(double)) Ypinv[(int64_t)c * ldD + d] = acc.x; else Ypinv[(int64_t)c * ldD + d] = acc;
 }
 
-// one bin of the sweep: X = Y_conj [c][ldD], Z = pinv(Y_conj) [c][ldD] (both fixed over the bins), 64 directions per workgroup
+// one bin of the sweep: X = Y_conj [c][ldD], Z = pinv(Y_conj) [c][ldD] (both fixed over the bins), 64 directions per workgroup.
+// Every operand of the launch is requested before the first use (the three loops of the first form loaded one element per
+// iteration: 22 + 32 + 32 dependent round trips to L2 per bin, 30 us per launch).
 template <typename TX>
 __global__ void __launch_bounds__(256) sweep_wide_kernel(DenseSweepArgs a, int kb) {
     __shared__ __attribute__((aligned(16))) cplx Wp[2][WD_SMAX];
@@ -75,14 +77,45 @@ __global__ void __launch_bounds__(256) sweep_wide_kernel(DenseSweepArgs a, int k
     const TX* Z = reinterpret_cast<const TX*>(a.Zd) + (int64_t)kb * a.z_stride;
     const int64_t d0 = (int64_t)blockIdx.x * 64, na = a.P - a.kabs0;
     const bool first = kb == a.kfirst;
+    constexpr int HC = WD_SMAX / 2;
+    // ---- requests: the previous launch's partial sums first (they gate the chain), then this slab's operands
+    const int pair1 = tid >> 1, half1 = tid & 1;             // phases 1 and 3: (ear, channel) x 2 lanes
+    constexpr int NG = sizeof(TX) == sizeof(double) ? 24 : 12;   // staged partial sums per thread; more workgroups: a loop behind them
+    cplx gw[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int w = half1 + 2 * i;
+        gw[i] = (!first && pair1 < 2 * C && w < nWG) ? Wprev[(int64_t)pair1 * nWG + w] : mk(0.0, 0.0);
+    }
+    const int dd2 = tid & 63, e2 = (tid >> 6) & 1, half2 = tid >> 7;   // phase 2: (direction, ear) x 2 lanes over the channels
+    const int64_t d2 = d0 + dd2;
+    TX xr[HC];
+#pragma unroll
+    for (int i = 0; i < HC; ++i) {
+        const int c = half2 + 2 * i;
+        xr[i] = (d2 < a.D && c < C) ? X[(int64_t)c * a.ldD + d2] : zero_of<TX>();
+    }
+    const double habs = (d2 < a.D && half2 == 0) ? a.Habs[((int64_t)e2 * na + (kb - a.kabs0)) * a.ldH + d2] : 0.0;
+    TX zr[32];                                               // phase 3: this thread pair's (ear, channel) row of the slab (2 C <= 128 pairs)
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int64_t d = d0 + half1 + 2 * j;
+        zr[j] = (pair1 < 2 * C && d < a.D) ? Z[(int64_t)(pair1 % C) * a.ldD + d] : zero_of<TX>();
+    }
     // ---- W(kb-1,:): the least-squares row for the first swept bin, the sum of the workgroups' partial sums afterwards
-    for (int pair = tid >> 1; pair < 2 * C; pair += 128) {
-        const int e = pair / C, c = pair % C, half = tid & 1;
+    if (pair1 < 2 * C) {
+        const int e = pair1 / C, c = pair1 % C;
         cplx acc = mk(0.0, 0.0);
-        if (first) { if (half == 0) acc = a.W[((int64_t)e * a.P + (kb - 1)) * C + c]; }
-        else for (int w = half; w < nWG; w += 2) acc += Wprev[(int64_t)pair * nWG + w];
+        if (first) { if (half1 == 0) acc = a.W[((int64_t)e * a.P + (kb - 1)) * C + c]; }
+        else {
+            cplx a0 = mk(0.0, 0.0), a1 = mk(0.0, 0.0);
+#pragma unroll
+            for (int i = 0; i < NG; i += 2) { a0 += gw[i]; a1 += gw[i + 1]; }
+            acc = a0 + a1;
+            for (int w = half1 + 2 * NG; w < nWG; w += 2) acc += Wprev[(int64_t)pair1 * nWG + w];
+        }
         acc = group_sum<2>(acc);
-        if (half == 0) {
+        if (half1 == 0) {
             Wp[e][c] = acc;
             if (blockIdx.x == 0 && !first) a.W[((int64_t)e * a.P + (kb - 1)) * C + c] = acc;
         }
@@ -90,35 +123,40 @@ __global__ void __launch_bounds__(256) sweep_wide_kernel(DenseSweepArgs a, int k
     __syncthreads();
     // ---- p = W(kb-1,:) Y_conj, t = |H| exp(i angle(p)) (Nyquist: real part)
     {
-        const int dd = tid & 63, e = (tid >> 6) & 1, half = tid >> 7;
-        const int64_t d = d0 + dd;
-        cplx p = mk(0.0, 0.0);
-        if (d < a.D) for (int c = half; c < C; c += 2) cfma(p, Wp[e][c], to_cplx(X[(int64_t)c * a.ldD + d]));
-        if (half == 1) ts[e][dd] = p;
+        cplx p = mk(0.0, 0.0), q = mk(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < HC; i += 2) {
+            if (half2 + 2 * i < C) cfma(p, Wp[e2][half2 + 2 * i], to_cplx(xr[i]));
+            if (half2 + 2 * i + 2 < C) cfma(q, Wp[e2][half2 + 2 * i + 2], to_cplx(xr[i + 1]));
+        }
+        p += q;
+        if (half2 == 1) ts[e2][dd2] = p;
         __syncthreads();
         cplx t = mk(0.0, 0.0);
-        if (half == 0) {
-            p += ts[e][dd];
-            if (d < a.D) {
-                const double h = a.Habs[((int64_t)e * na + (kb - a.kabs0)) * a.ldH + d];
+        if (half2 == 0) {
+            p += ts[e2][dd2];
+            if (d2 < a.D) {
                 const double a2 = norm2(p);
-                t = mk(h, 0.0);                                   // angle(0) = 0
-                if (a2 > 0.0) { const double ia = h / sqrt(a2); t = mk(p.x * ia, p.y * ia); }
+                t = mk(habs, 0.0);                                // angle(0) = 0
+                if (a2 > 0.0) { const double ia = habs / sqrt(a2); t = mk(p.x * ia, p.y * ia); }
                 if (kb == a.P - 1) t.y = 0.0;
             }
         }
         __syncthreads();   // (every wave has read the half sums)
-        if (half == 0) ts[e][dd] = t;
+        if (half2 == 0) ts[e2][dd2] = t;
     }
     __syncthreads();
     // ---- this workgroup's partial sums of t pinv(Y_conj)
-    for (int pair = tid >> 1; pair < 2 * C; pair += 128) {
-        const int e = pair / C, c = pair % C, half = tid & 1;
-        cplx acc = mk(0.0, 0.0);
-        for (int dd = half; dd < 64; dd += 2)
-            if (d0 + dd < a.D) cfma(acc, ts[e][dd], to_cplx(Z[(int64_t)c * a.ldD + d0 + dd]));
-        acc = group_sum<2>(acc);
-        if (half == 0) Wout[(int64_t)pair * nWG + blockIdx.x] = acc;
+    if (pair1 < 2 * C) {
+        const int e = pair1 / C;
+        cplx a0 = mk(0.0, 0.0), a1 = mk(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < 32; j += 2) {
+            cfma(a0, ts[e][half1 + 2 * j], to_cplx(zr[j]));
+            cfma(a1, ts[e][half1 + 2 * j + 2], to_cplx(zr[j + 1]));
+        }
+        cplx acc = group_sum<2>(a0 + a1);
+        if (half1 == 0) Wout[(int64_t)pair1 * nWG + blockIdx.x] = acc;
     }
 }
 

@@ -278,6 +278,68 @@ __global__ void __launch_bounds__(256) wa_yri_kernel(const double* __restrict__ 
         }
 }
 
+// The same product on the FP64 matrix cores (v_mfma_f64_16x16x4): the complex rows of Z_k as 2 C real rows against the real Q.
+// Workgroup = 4 waves = 128 real rows (all channels) x 64 directions of one bin, S walked in chunks of 32 through LDS (both
+// operands K-major there: As[k][row], Bs[k][direction]); a wave holds 32 rows x 64 directions = 2 x 4 tiles.  A 16-row tile
+// carries 8 channels with the rows ordered so that a lane's four result registers are (re, im) of channel kk and (re, im) of
+// channel 4 + kk: row 4 reg + kk  <->  channel 4 (reg >> 1) + kk, part reg & 1 -- the results leave as whole complex numbers.
+// (the scalar form above reads one LDS operand per FMA pair: 7.8 TFLOP/s, 18 ms for the 64-capsule design)
+constexpr int WY_KC = 32, WY_LDA = 132, WY_LDB = 68;
+typedef double wa_double4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) wa_yri_mfma_kernel(const double* __restrict__ Q, int64_t ldQ, const cplx* __restrict__ Z, int S, int C, int ldS,
+                                                          int D, int64_t ldD, cplx* __restrict__ Yri) {
+    __shared__ __attribute__((aligned(16))) double As[WY_KC][WY_LDA];
+    __shared__ __attribute__((aligned(16))) double Bs[WY_KC][WY_LDB];
+    const int kbi = blockIdx.y, d0 = blockIdx.x * 64;
+    const cplx* Zk = Z + (int64_t)kbi * C * ldS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ii = lane & 15, kk = lane >> 4;
+    wa_double4 acc[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = wa_double4{0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < S; s0 += WY_KC) {
+        __syncthreads();
+        for (int idx = tid; idx < WA_CMAX * WY_KC; idx += 256) {
+            const int c = idx >> 5, ss = idx & 31;
+            const cplx z = (c < C && s0 + ss < S) ? Zk[(int64_t)c * ldS + s0 + ss] : mk(0.0, 0.0);
+            const int row = 16 * (c >> 3) + 8 * ((c & 7) >> 2) + (c & 3);   // the (re) row of channel c; its (im) row is 4 further
+            As[ss][row] = z.x;
+            As[ss][row + 4] = z.y;
+        }
+        for (int idx = tid; idx < 64 * WY_KC; idx += 256) {
+            const int j = idx >> 5, ss = idx & 31;
+            Bs[ss][j] = (d0 + j < D && s0 + ss < S) ? Q[(int64_t)(d0 + j) * ldQ + s0 + ss] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < WY_KC; k0 += 4) {
+            const double a0 = As[k0 + kk][32 * wave + ii], a1 = As[k0 + kk][32 * wave + 16 + ii];
+            double b[4];
+#pragma unroll
+            for (int y = 0; y < 4; ++y) b[y] = Bs[k0 + kk][16 * y + ii];
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                acc[0][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[y], acc[0][y], 0, 0, 0);
+                acc[1][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[y], acc[1][y], 0, 0, 0);
+            }
+        }
+    }
+    // C / D layout: column = lane & 15, row = (lane >> 4) + 4 reg
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int c0 = 8 * (2 * wave + x) + kk;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int d = d0 + 16 * y + ii;
+            if (d < D) {
+                if (c0 < C) Yri[((int64_t)kbi * C + c0) * ldD + d] = mk(acc[x][y][0], acc[x][y][1]);
+                if (c0 + 4 < C) Yri[((int64_t)kbi * C + c0 + 4) * ldD + d] = mk(acc[x][y][2], acc[x][y][3]);
+            }
+        }
+    }
+}
+
 // least-squares rows: W[e][kb][c] = sum_d Hc[e][kb][d] Yri[kb][c][d]   (kb < n_c)
 __global__ void __launch_bounds__(256) wa_ls_kernel(const cplx* __restrict__ Hc, int64_t ldH, int n_c, const cplx* __restrict__ Yri, int64_t ldD, int D, int C,
                                                     int P, int kb_first, cplx* __restrict__ W) {
@@ -341,7 +403,9 @@ void launch_wa_factor(void* B, void* Vw, int S, int C, int ldS, int nbins, doubl
 }
 void launch_wa_yri(const void* Q, int64_t ldQ, const void* Z, int S, int C, int ldS, int D, int64_t ldD, int nbins, void* Yri, hipStream_t st) {
     if (nbins <= 0) return;
-    wa_yri_kernel<<<dim3((unsigned)ceil_div(D, 64), nbins), 256, 0, st>>>((const double*)Q, ldQ, (const cplx*)Z, S, C, ldS, D, ldD, (cplx*)Yri);
+    const char* e = getenv("EMAGLS_WA_YRI_MFMA");   // =0: the scalar form
+    if (e && e[0] == '0') wa_yri_kernel<<<dim3((unsigned)ceil_div(D, 64), nbins), 256, 0, st>>>((const double*)Q, ldQ, (const cplx*)Z, S, C, ldS, D, ldD, (cplx*)Yri);
+    else wa_yri_mfma_kernel<<<dim3((unsigned)ceil_div(D, 64), nbins), 256, 0, st>>>((const double*)Q, ldQ, (const cplx*)Z, S, C, ldS, D, ldD, (cplx*)Yri);
     KERNEL_CHECK();
 }
 void launch_wa_ls(const void* Hc, int64_t ldH, int n_c, const void* Yri, int64_t ldD, int D, int C, int P, int kb_first, int kb_end, void* W, hipStream_t st) {
