@@ -237,6 +237,149 @@ __global__ void __launch_bounds__(512) wa_back_kernel(const cplx* __restrict__ V
     for (int idx = tid; idx < C * ldS; idx += 512) Zk[idx] = conj(Zk[idx]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-resident forms of the two Householder kernels for S <= 64 NR rows (NR = 7: simulation order <= 20).  The forms above
+// walk every column through L2 for every reflector (two dependent passes per column and reflector: 5.7 and 11.8 ms for the 513
+// bins of the 64-capsule design); here a wave keeps its four columns in registers, lane l holding the rows l, l + 64, ...
+//   wa_back_reg_kernel   columns are independent: no barrier at all; two workgroups of 8 waves per bin (32 columns each)
+//   wa_qr_reg_kernel     16 waves = 64 columns; the owner of column j forms v_j and hands it to the others through LDS
+//                        (two buffers: one barrier per reflector)
+// ---------------------------------------------------------------------------------------------
+template <int NR>
+__global__ void __launch_bounds__(512) wa_back_reg_kernel(const cplx* __restrict__ Vw, const double* __restrict__ tauw, const cplx* __restrict__ Nw, int S,
+                                                          int C, int ldS, cplx* __restrict__ Z) {
+    const cplx* Vk = Vw + (int64_t)blockIdx.x * C * ldS;
+    const cplx* N = Nw + (int64_t)blockIdx.x * C * C;
+    cplx* Zk = Z + (int64_t)blockIdx.x * C * ldS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kbase = 32 * blockIdx.y + wave;      // this wave's columns: kbase + 8 q
+    cplx x[4][NR];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = kbase + 8 * q;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int s = lane + 64 * r;
+            x[q][r] = (k < C && s < C && s < S) ? conj(N[s * C + k]) : mk(0.0, 0.0);   // X[s][k] = conj(N[s][k])
+        }
+    }
+    for (int j = C - 1; j >= 0; --j) {
+        const cplx* vj = Vk + (int64_t)j * ldS;
+        const double tau = tauw[(int64_t)blockIdx.x * C + j];
+        cplx v[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int s = lane + 64 * r;
+            v[r] = (s >= j && s < S) ? vj[s] : mk(0.0, 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cplx w = mk(0.0, 0.0);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) cfma_conj(w, v[r], x[q][r]);
+            w = wave_sum(w);
+            w = mk(-w.x * tau, -w.y * tau);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) cfma(x[q][r], v[r], w);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = kbase + 8 * q;
+        if (k < C) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int s = lane + 64 * r;
+                if (s < ldS) Zk[(int64_t)k * ldS + s] = conj(x[q][r]);
+            }
+        }
+    }
+}
+
+template <int NR>
+__global__ void __launch_bounds__(1024) wa_qr_reg_kernel(const cplx* __restrict__ B, cplx* __restrict__ Vw, int S, int C, int ldS,
+                                                         double* __restrict__ tauw, cplx* __restrict__ R2w) {
+    __shared__ __attribute__((aligned(16))) cplx vbuf[2][64 * NR];
+    __shared__ double s_tau[2];
+    const cplx* Bk = B + (int64_t)blockIdx.x * C * ldS;
+    cplx* Vk = Vw + (int64_t)blockIdx.x * C * ldS;
+    cplx* R2 = R2w + (int64_t)blockIdx.x * C * C;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    cplx x[4][NR];                                  // columns wave + 16 q
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = wave + 16 * q;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int s = lane + 64 * r;
+            x[q][r] = (k < C && s < S) ? Bk[(int64_t)k * ldS + s] : mk(0.0, 0.0);
+        }
+    }
+    for (int j = 0; j < C; ++j) {
+        const int buf = j & 1;
+        if (wave == (j & 15)) {   // the owner: |a_j(j:)|, alpha, v_j = a_j(j:) - alpha e_1, tau_j = 2 / |v_j|^2
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q == (j >> 4)) {
+                    double n2 = 0.0;
+                    cplx x0 = mk(0.0, 0.0);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int s = lane + 64 * r;
+                        if (s >= j) n2 += norm2(x[q][r]);
+                        if (s == j) x0 = x[q][r];
+                    }
+                    n2 = wave_sum(n2);
+                    x0 = wave_sum(x0);               // (one lane holds it, the others zero)
+                    const double nx = sqrt(n2), ax = cabs(x0);
+                    cplx alpha = mk(-nx, 0.0);
+                    if (ax > 0.0) alpha = mk(-x0.x / ax * nx, -x0.y / ax * nx);
+                    const double nv2 = 2.0 * nx * (nx + ax);          // |x - alpha e_1|^2
+                    const double tau = nv2 > 0.0 ? 2.0 / nv2 : 0.0;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int s = lane + 64 * r;
+                        cplx v = s >= j ? x[q][r] : mk(0.0, 0.0);
+                        if (s == j) v = v - alpha;
+                        vbuf[buf][s] = v;
+                        if (s >= j && s < S) Vk[(int64_t)j * ldS + s] = v;
+                        if (s == j) x[q][r] = alpha; else if (s > j) x[q][r] = mk(0.0, 0.0);
+                    }
+                    if (lane == 0) { s_tau[buf] = tau; tauw[(int64_t)blockIdx.x * C + j] = tau; }
+                }
+            }
+        }
+        __syncthreads();
+        const double tau = s_tau[buf];
+        // columns k > j: a_k -= tau v (v^H a_k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = wave + 16 * q;
+            if (k > j && k < C) {
+                cplx w = mk(0.0, 0.0);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) cfma_conj(w, vbuf[buf][lane + 64 * r], x[q][r]);
+                w = wave_sum(w);
+                w = mk(-w.x * tau, -w.y * tau);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) cfma(x[q][r], vbuf[buf][lane + 64 * r], w);
+            }
+        }
+    }
+    // R2 (upper, row major [i][k]); the rest of the square zero
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = wave + 16 * q;
+        if (k < C) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int i = lane + 64 * r;
+                if (i < C) R2[i * C + k] = (i <= k && i < S) ? x[q][r] : mk(0.0, 0.0);
+            }
+        }
+    }
+}
+
 // Yri[kb][c][d] = sum_s conj(Q[d][s]) Z[kb][c][s]   (Q real: the real-arithmetic pipeline).  A workgroup: 64 directions x all
 // channels of one bin, S walked in chunks of 32 through LDS.
 __global__ void __launch_bounds__(256) wa_yri_kernel(const double* __restrict__ Q, int64_t ldQ, const cplx* __restrict__ Z, int S, int C, int ldS, int D,
@@ -390,7 +533,10 @@ void launch_wa_factor(void* B, void* Vw, int S, int C, int ldS, int nbins, doubl
                       void* Z, hipStream_t st) {
     if (nbins <= 0) return;
     if (C > WA_CMAX || S < C) throw Error(2, "wide array path: at most 64 channels and at least as many SH rows");
-    wa_qr_kernel<<<nbins, 512, 0, st>>>((cplx*)B, (cplx*)Vw, S, C, ldS, tauw, (cplx*)R2w);
+    const char* e_reg = getenv("EMAGLS_WA_REG");   // =0: the forms that walk the columns through L2
+    const bool reg7 = ldS <= 64 * 7 && !(e_reg && e_reg[0] == '0');
+    if (reg7) wa_qr_reg_kernel<7><<<nbins, 1024, 0, st>>>((const cplx*)B, (cplx*)Vw, S, C, ldS, tauw, (cplx*)R2w);
+    else wa_qr_kernel<<<nbins, 512, 0, st>>>((cplx*)B, (cplx*)Vw, S, C, ldS, tauw, (cplx*)R2w);
     KERNEL_CHECK();
     const int Cp = (C + 1) & ~1;
     const size_t dyn = sizeof(cplx) * (size_t)2 * Cp * (Cp + 1);
@@ -398,7 +544,8 @@ void launch_wa_factor(void* B, void* Vw, int S, int C, int ldS, int nbins, doubl
     if (attr_once.first()) HIP_CHECK(hipFuncSetAttribute((const void*)wa_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     wa_jacobi_kernel<<<nbins, 1024, dyn, st>>>((const cplx*)R2w, C, reg_c, (cplx*)Nw, sv, sweeps);
     KERNEL_CHECK();
-    wa_back_kernel<<<nbins, 512, 0, st>>>((const cplx*)Vw, tauw, (const cplx*)Nw, S, C, ldS, (cplx*)Z);
+    if (reg7) wa_back_reg_kernel<7><<<dim3(nbins, (unsigned)ceil_div(C, 32)), 512, 0, st>>>((const cplx*)Vw, tauw, (const cplx*)Nw, S, C, ldS, (cplx*)Z);
+    else wa_back_kernel<<<nbins, 512, 0, st>>>((const cplx*)Vw, tauw, (const cplx*)Nw, S, C, ldS, (cplx*)Z);
     KERNEL_CHECK();
 }
 void launch_wa_yri(const void* Q, int64_t ldQ, const void* Z, int S, int C, int ldS, int D, int64_t ldD, int nbins, void* Yri, hipStream_t st) {

@@ -1521,6 +1521,22 @@ def test_arrays_with_more_than_32_channels(thin, fn, order, nmics, basis):
     assert report(f"{fn} N={order} {nmics} mics {basis} L", wL, oL) < TOL and report("R", wR, oR) < TOL
 
 
+def test_wide_array_kernel_forms_agree(thin, monkeypatch):
+    """The 33..64-channel path's round-4 kernels (Householder QR and back-transform with the columns in registers, Y_reg_inv_k on
+    the FP64 matrix cores) against the forms they replace (EMAGLS_WA_REG=0, EMAGLS_WA_YRI_MFMA=0: columns walked through L2, scalar
+    product) on a 64-microphone design."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    maz, mzn = synth.fibonacci_grid(64)
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128, "real")
+    wL, wR = E.getEMagLs2Filters(*args)
+    monkeypatch.setenv("EMAGLS_WA_REG", "0")
+    monkeypatch.setenv("EMAGLS_WA_YRI_MFMA", "0")
+    vL, vR = E.getEMagLs2Filters(*args)
+    print(f"64 microphones, register / MFMA forms vs the plain ones: rel = {max(rel(wL, vL), rel(wR, vR)):.3e}")
+    assert rel(wL, vL) < 1e-8 and rel(wR, vR) < 1e-8
+
+
 def test_wide_arrays_refuse_what_they_cannot_do(thin):
     import emagls_amd as E
     from emagls_amd import synth
