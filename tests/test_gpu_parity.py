@@ -1521,6 +1521,19 @@ def test_arrays_with_more_than_32_channels(thin, fn, order, nmics, basis):
     assert report(f"{fn} N={order} {nmics} mics {basis} L", wL, oL) < TOL and report("R", wR, oR) < TOL
 
 
+def test_wide_array_at_8_cm(grids):
+    """The 64-capsule array at r = 8 cm (simulation order 35, 1296 simulated SH channels; round 3 stopped at 5.9 cm) on the full
+    2702-point grid against the oracle."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    hL, hR = synth.rigid_sphere_hrirs(grids["azi"], grids["zen"], taps=64)
+    maz, mzn = synth.fibonacci_grid(64)
+    args = (hL, hR, grids["azi"], grids["zen"], 0.08, maz, mzn, 4, 48000.0, 128, "real")
+    wL, wR = E.getEMagLs2Filters(*args)
+    oL, oR = O.getEMagLs2Filters(*args)
+    assert report("getEMagLs2Filters 64 mics r = 8 cm L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
 def test_wide_array_kernel_forms_agree(thin, monkeypatch):
     """The 33..64-channel path's round-4 kernels (Householder QR and back-transform with the columns in registers, Y_reg_inv_k on
     the FP64 matrix cores) against the forms they replace (EMAGLS_WA_REG=0, EMAGLS_WA_YRI_MFMA=0: columns walked through L2, scalar
@@ -1545,7 +1558,9 @@ def test_wide_arrays_refuse_what_they_cannot_do(thin):
     with pytest.raises(EmaglsError, match="more than 64"):
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128)
     maz, mzn = synth.fibonacci_grid(64)
-    with pytest.raises(EmaglsError, match="simulation order above 26"):
+    with pytest.raises(EmaglsError, match="simulation order above 47"):
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.12, maz, mzn, 4, 48000.0, 128)
+    with pytest.raises(EmaglsError, match="fewer HRIR directions than simulated SH channels"):   # (8 cm: 36^2 = 1296 channels, 901 directions)
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.08, maz, mzn, 4, 48000.0, 128)
     with pytest.raises(EmaglsError, match="covariance constraint"):
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128, applyDiffusenessConst=True)
