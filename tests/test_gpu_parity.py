@@ -1083,12 +1083,14 @@ def test_designs_on_large_hrir_grids():
     assert report("FromAtf, 5000 matched directions L", wL, oL) < TOL and report("R", wR, oR) < TOL
 
 
-def test_from_atf_512_taps_wave_prologue(thin, monkeypatch):
+@pytest.mark.parametrize("natf", [1024, 500])
+def test_from_atf_512_taps_wave_prologue(thin, monkeypatch, natf):
     """512-tap FromAtf filters: nfft = 1024, so the HRIR prologue with the integer circshift (lib/getEMagLsFiltersFromAtf.m:43-53)
-    runs on the wave-private transforms; same design with EMAGLS_HRIR_FFT_WAVE=0 on the LDS form."""
+    runs on the wave-private transforms -- on all HRIR directions (ATF grid the larger one) and on the gathered ones (ATF grid the
+    smaller one, FromAtf.m:71-79); same design with EMAGLS_HRIR_FFT_WAVE=0 on the LDS form."""
     import emagls_amd as E
     from emagls_amd import synth
-    atf, aazi, azen = synth.glasses_atfs(natf=1024, nmics=8, taps=128)
+    atf, aazi, azen = synth.glasses_atfs(natf=natf, nmics=8, taps=128)
     hg = np.column_stack([thin["azi"], thin["zen"]])
     ag = np.column_stack([aazi, azen])
     oL, oR, dev = O.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 512, 2000.0)
