@@ -1172,6 +1172,12 @@ void emagls_pre_sweep(emagls_plan& p) {
     fa.cond_limit = 10.0 * GRAM_COND_EST;   // (not the env override: the forced-estimate test must trip this check)
     fa.W = p.get<cplx>("W"); fa.sweeps_out = p.get<int>("jsweeps");
     fa.tauw = p.get<double>("tauw"); fa.R2w = p.get<cplx>("R2w"); fa.Nw = p.get<cplx>("Nw");
+    // single-stream sequences, EMAGLS_JACOBI_PAIR=1: the two Jacobi steps (Gram-route bins, Householder-route bins) as ONE launch --
+    // each lasts as long as its slowest bin (216 us) and on one stream they add up.  Off by default: with four batches in flight the
+    // shorter chain changes nothing (three runs each, 20 / 128 steps: 1831-1904 / 2260-2394 merged, 1789-1952 / 2334-2498 not)
+    const char* e_jp = getenv("EMAGLS_JACOBI_PAIR");
+    const bool merge_jacobi = s3 == s0 && p.nb_gram > 0 && hh_end > 1 && e_jp && e_jp[0] == '1';
+    FactorArgs fg_deferred{};
     auto blk_gram_route = [&] {
     if (s1 != s0) HIP_CHECK(hipStreamWaitEvent(s0, e_E, 0));
     if (s3 != s0) { HIP_CHECK(hipStreamWaitEvent(s3, e_Gy, 0)); HIP_CHECK(hipStreamWaitEvent(s3, e_E, 0)); }
@@ -1190,7 +1196,8 @@ void emagls_pre_sweep(emagls_plan& p) {
         // batches have workgroups to spare: a Jacobi workgroup walks a run of neighbouring bins, each warm-started from the
         // previous one (a third of the sweeps); a single design keeps one bin per workgroup (shortest critical path)
         fg.jrun = jacobi_run_length();
-        launch_factor_jacobi_gram(fg, p.nb_gram, s3);
+        if (merge_jacobi) { fg_deferred = fg; }   // (one launch with the Householder-route bins: blk_hh_route)
+        else launch_factor_jacobi_gram(fg, p.nb_gram, s3);
         p.mark("gram_route");
     }
     };
@@ -1199,7 +1206,8 @@ void emagls_pre_sweep(emagls_plan& p) {
     if (hh_end > 1) {
         launch_tn(p.get("R"), p.get("E"), Sh, p.C, p.ldS, nOrdH, cb, p.get("Tn"), ldSh, s0);
         p.mark("array_model+tn");
-        launch_factor(fa, hh_end - 1, cb, s0, 1);
+        launch_factor(fa, hh_end - 1, cb, s0, merge_jacobi ? (1 | 8) : 1);
+        if (merge_jacobi) launch_factor_jacobi_pair(fg_deferred, p.nb_gram, fa, hh_end - 1, s0);
     }
     };
     auto blk_flags = [&] {

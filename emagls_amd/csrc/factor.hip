@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(MAXT) factor_qr_kernel(FactorArgs a, size_t bs
 // kernel 2: one-sided Jacobi SVD of X = R2^H (C x C) in LDS, 256 threads = 16 column pairs x 16 lanes.
 //   R2 = Vx Sigma Ux^H;  N = Vx diag(g) Xrot^H with g = s_reg / s   (U2 diag(s_reg) V^H)
 // =============================================================================================
-__global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t bstride) {
+__device__ __forceinline__ void factor_jacobi_body(FactorArgs a, const int blk, size_t bstride) {
     batch_offset(a, bstride);
     __shared__ __attribute__((aligned(16))) cplx Xs[CPMAX][CPMAX + 1];  // Xs[col][row]
     __shared__ __attribute__((aligned(16))) cplx Vs[CPMAX][CPMAX + 1];
@@ -182,9 +182,9 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     // a workgroup walks `jrun` consecutive bins: neighbouring bins have nearly the same singular vectors, so the
     // rotations accumulated for one bin are the starting point of the next (X = R2^H V_prev is already almost
     // orthogonal by columns) and the sweeps drop from ~9 to ~3.  jrun = 1 keeps the bins independent.
-    const bool solo = (int)blockIdx.x < a.jsplit;   // (workgroup-uniform)
+    const bool solo = blk < a.jsplit;   // (workgroup-uniform)
     const int jrun = solo ? 1 : (a.jrun > 0 ? a.jrun : 1);
-    const int bi0 = solo ? (int)blockIdx.x : a.jsplit + ((int)blockIdx.x - a.jsplit) * jrun;
+    const int bi0 = solo ? blk : a.jsplit + (blk - a.jsplit) * jrun;
     for (int t = 0; t < jrun; ++t) {
     const int bi = bi0 + t;   // bin slot (workspaces are indexed by it)
     if (bi >= a.nbins) break;
@@ -360,6 +360,13 @@ __global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t
     __syncthreads();  // the next bin of the run rewrites Xs
     }
 }
+__global__ void __launch_bounds__(256) factor_jacobi_kernel(FactorArgs a, size_t bstride) { factor_jacobi_body(a, (int)blockIdx.x, bstride); }
+// two independent sets of bins in one launch (the Gram-route bins whose 1 % clipping is active and the Householder-route bins of
+// one design: each set is as long as its slowest bin's sweeps, so two launches on one stream cost twice that)
+__global__ void __launch_bounds__(256) factor_jacobi_pair_kernel(FactorArgs a, FactorArgs b, int na, size_t bstride) {
+    if ((int)blockIdx.x < na) factor_jacobi_body(a, (int)blockIdx.x, bstride);
+    else factor_jacobi_body(b, (int)blockIdx.x - na, bstride);
+}
 
 // =============================================================================================
 // kernel 3: Z_k = conj(Q2 [N; 0]) by applying the stored reflectors backwards; least-squares bins.
@@ -449,12 +456,14 @@ static void launch_one(const FactorArgs& a, int nbins, hipStream_t st, int phase
     if (phases & 1) {
         factor_qr_kernel<TT, NCH, RPT, MAXT><<<bgrid(nbins), threads, dyn, st>>>(a, batch_ctx().stride);
         KERNEL_CHECK();
-        FactorArgs aj = a;
-        aj.nbins = nbins;
-        aj.jsplit = nbins;   // one workgroup per bin: the full SVDs of the ill-conditioned bins are the long pole
-        aj.jrun = 1;
-        factor_jacobi_kernel<<<bgrid(nbins), 256, 0, st>>>(aj, batch_ctx().stride);
-        KERNEL_CHECK();
+        if (!(phases & 8)) {   // (8: the caller launches the Jacobi step itself, launch_factor_jacobi_pair)
+            FactorArgs aj = a;
+            aj.nbins = nbins;
+            aj.jsplit = nbins;   // one workgroup per bin: the full SVDs of the ill-conditioned bins are the long pole
+            aj.jrun = 1;
+            factor_jacobi_kernel<<<bgrid(nbins), 256, 0, st>>>(aj, batch_ctx().stride);
+            KERNEL_CHECK();
+        }
     }
     if (phases & 2) {
         factor_back_kernel<NCH, RPT, MAXT><<<bgrid(nbins), threads, 0, st>>>(a, batch_ctx().stride);
@@ -495,7 +504,21 @@ void launch_factor_jacobi_gram(const FactorArgs& a, int nbins, hipStream_t st) {
     KERNEL_CHECK();
 }
 
-// phases: 1 = QR + Jacobi, 2 = back-transform (+ least-squares bins), 3 = both
+// The Jacobi steps of the Gram-route bins (launch_factor_jacobi_gram's arguments) and of the Householder-route bins (launch_factor's,
+// after its QR with phases = 1 | 8) as one launch.
+void launch_factor_jacobi_pair(const FactorArgs& gram, int nb_gram, const FactorArgs& hh, int nb_hh, hipStream_t st) {
+    if (gram.C > CPMAX || hh.C > CPMAX) throw Error(2, "factor: more than 32 output channels is not supported in this build");
+    FactorArgs ag = gram, ah = hh;
+    ag.nbins = nb_gram;
+    const int jr = ag.jrun > 0 ? ag.jrun : 1;
+    ag.jsplit = 0;
+    const int na = (nb_gram + jr - 1) / jr;
+    ah.nbins = nb_hh; ah.jsplit = nb_hh; ah.jrun = 1;
+    factor_jacobi_pair_kernel<<<bgrid(na + nb_hh), 256, 0, st>>>(ag, ah, na, batch_ctx().stride);
+    KERNEL_CHECK();
+}
+
+// phases: 1 = QR + Jacobi (| 8: QR only), 2 = back-transform (+ least-squares bins), 3 = both
 void launch_factor(const FactorArgs& a0, int nbins, bool tn_cplx, hipStream_t st, int phases) {
     if (nbins <= 0) return;
     const FactorArgs& a = a0;

@@ -62,6 +62,7 @@ struct FactorArgs;
 void launch_factor(const FactorArgs& a, int nbins, bool tn_cplx, hipStream_t st, int phases = 3);
 // Jacobi SVD only, on Gram matrices that gram_solve_kernel handed over (route[kb] == 1); bins with route[kb] == 2 are skipped
 void launch_factor_jacobi_gram(const FactorArgs& a, int nbins, hipStream_t st);
+void launch_factor_jacobi_pair(const FactorArgs& gram, int nb_gram, const FactorArgs& hh, int nb_hh, hipStream_t st);
 
 // ---- gramroute.hip
 void launch_gram_kmat(const void* Gy, const void* E, int S, int ldE, int C, int nOrd, bool is_cplx, void* F, int64_t ldF, double* Kmat, int ldK,
