@@ -681,7 +681,11 @@ void launch_hrir_fft(const double* hL, const double* hR, int64_t L, int64_t D, c
     // (tried: 2 or 1 directions per sub-tile, 49 / 33 KB, so that three or four workgroups share a CU and the kernel fits next to a
     // twin sweep workgroup: 2062 / 2047 against 2174 sets/s in long runs, 1393 / 1633 against 1697 at 20 steps; all 8 directions in
     // one sub-tile, 148 KB: 2149-2152 against 2176-2186)
-    const size_t budget = 83 * 1024, shared = (size_t)2 * P * 16;
+    // (nfft = 2048 -- configs 4 and 5 -- gets two directions per sub-tile, 98 KB: nothing fits next to the round-4 sweep's twin
+    // workgroups anyway, and four sub-tiles instead of eight are 2-3 % of a config 4 / 5 batch)
+    size_t budget = (nfft >= 2048 ? 110 : 83) * 1024;
+    if (const char* e = getenv("EMAGLS_HRIR_FFT_LDS_KB")) budget = (size_t)std::max(40, std::min(158, atoi(e))) * 1024;
+    const size_t shared = (size_t)2 * P * 16;
     int TS = HF_TD;
     while (TS > 1 && (size_t)TS * nfft * 16 + shared > budget) TS >>= 1;
     const size_t sm = (size_t)TS * nfft * 16 + shared;
