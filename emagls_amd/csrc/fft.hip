@@ -69,19 +69,48 @@ __global__ void __launch_bounds__(1024) grpdelay_median_kernel(const double* __r
         b[n] = acc;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < npow2; k += blockDim.x) {
-        double g = INFINITY;
-        if (k < P) {
-            cplx num = mk(0, 0), den = mk(0, 0);
-            for (int64_t n = 0; n < L; ++n) {
-                const cplx w = tw[(int)(((int64_t)k * n) % nfft)];
-                cfma(den, b[n], w);
-                cfma(num, (double)n * b[n], w);
-            }
-            if (cabs(den) < 10.0 * 2.220446049250313e-16) { num = mk(0, 0); den = mk(1, 0); }
-            g = cdiv(num, den).x;
+    // the twiddle circle in LDS, walked by an index recurrence ((k n) mod nfft: one modulo and one dependent L2 round trip per
+    // tap cost 25 of the kernel's 75 us at nfft = 2048)
+    cplx* tws = reinterpret_cast<cplx*>(v + npow2);   // nfft
+    for (int j = threadIdx.x; j < nfft; j += blockDim.x) tws[j] = tw[j];
+    __syncthreads();
+    auto finish = [](cplx num, cplx den) {
+        if (cabs(den) < 10.0 * 2.220446049250313e-16) { num = mk(0, 0); den = mk(1, 0); }
+        return cdiv(num, den).x;
+    };
+    const int kmain = min(P, (int)blockDim.x);          // one thread per bin; the bins beyond the workgroup's size: all threads per bin
+    for (int k = threadIdx.x; k < npow2; k += blockDim.x) v[k] = INFINITY;
+    if ((int)threadIdx.x < kmain) {
+        const int k = threadIdx.x;
+        cplx num = mk(0, 0), den = mk(0, 0);
+        int j = 0;
+        for (int64_t n = 0; n < L; ++n) {
+            const cplx w = tws[j];
+            j += k; if (j >= nfft) j -= nfft;
+            cfma(den, b[n], w);
+            cfma(num, (double)n * b[n], w);
         }
-        v[k] = g;
+        v[k] = finish(num, den);
+    }
+    for (int k = kmain; k < P; ++k) {   // (nfft = 2048: the Nyquist bin; a second pass of one thread per bin would leave 1023 of 1024 idle)
+        __shared__ double red[16];
+        cplx num = mk(0, 0), den = mk(0, 0);
+        for (int64_t n = threadIdx.x; n < L; n += blockDim.x) {
+            const cplx w = tws[(int)(((int64_t)k * n) % nfft)];
+            cfma(den, b[n], w);
+            cfma(num, (double)n * b[n], w);
+        }
+        double parts[4] = {num.x, num.y, den.x, den.y};
+        for (int q = 0; q < 4; ++q) {
+            double x = wave_sum(parts[q]);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+            __syncthreads();
+            double t = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+            parts[q] = t;
+        }
+        if (threadIdx.x == 0) v[k] = finish(mk(parts[0], parts[1]), mk(parts[2], parts[3]));
     }
     __syncthreads();
     // bitonic sort ascending
@@ -643,7 +672,9 @@ void launch_hrir_grpdelay(const double* hL, const double* hR, int64_t L, int64_t
     const int P = nfft / 2 + 1;
     int npow2 = 1;
     while (npow2 < P) npow2 <<= 1;
-    size_t sm = (((size_t)L + 1) & ~(size_t)1) * 8 + (size_t)npow2 * 8;
+    size_t sm = (((size_t)L + 1) & ~(size_t)1) * 8 + (size_t)npow2 * 8 + (size_t)nfft * 16;
+    static PerDeviceOnce median_once;
+    if (median_once.first()) HIP_CHECK(hipFuncSetAttribute((const void*)grpdelay_median_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     grpdelay_median_kernel<<<bgrid(2), 1024, sm, st>>>(partial, nchunks, L, nfft, (const cplx*)tw, grpd, batch_ctx().stride);
     KERNEL_CHECK();
 }
