@@ -63,10 +63,31 @@ __global__ void __launch_bounds__(1024) grpdelay_median_kernel(const double* __r
     const int P = nfft / 2 + 1;
     int npow2 = 1;
     while (npow2 < P) npow2 <<= 1;
-    for (int64_t n = threadIdx.x; n < L; n += blockDim.x) {
-        double acc = 0.0;
-        for (int c = 0; c < nchunks; ++c) acc += partial[((int64_t)c * 2 + e) * L + n];
-        b[n] = acc;
+    // b = sum of the chunks' partial sums: nq threads per tap, four loads in flight each (one thread per tap with one accumulator
+    // walks nchunks dependent L2 round trips)
+    {
+        double* part = reinterpret_cast<double*>(reinterpret_cast<cplx*>(v + npow2) + nfft);   // [nq][L] behind the twiddle circle
+        const int nq = (int)max((int64_t)1, min((int64_t)8, (int64_t)blockDim.x / max(L, (int64_t)1)));
+        for (int64_t idx = threadIdx.x; idx < (int64_t)nq * L; idx += blockDim.x) {
+            const int64_t n = idx % L;
+            const int q = (int)(idx / L);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int c = q;
+            for (; c + 3 * nq < nchunks; c += 4 * nq) {
+                a0 += partial[((int64_t)c * 2 + e) * L + n];
+                a1 += partial[((int64_t)(c + nq) * 2 + e) * L + n];
+                a2 += partial[((int64_t)(c + 2 * nq) * 2 + e) * L + n];
+                a3 += partial[((int64_t)(c + 3 * nq) * 2 + e) * L + n];
+            }
+            for (; c < nchunks; c += nq) a0 += partial[((int64_t)c * 2 + e) * L + n];
+            part[idx] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        for (int64_t n = threadIdx.x; n < L; n += blockDim.x) {
+            double acc = 0.0;
+            for (int q = 0; q < nq; ++q) acc += part[(int64_t)q * L + n];
+            b[n] = acc;
+        }
     }
     __syncthreads();
     // the twiddle circle in LDS, walked by an index recurrence ((k n) mod nfft: one modulo and one dependent L2 round trip per
@@ -672,7 +693,7 @@ void launch_hrir_grpdelay(const double* hL, const double* hR, int64_t L, int64_t
     const int P = nfft / 2 + 1;
     int npow2 = 1;
     while (npow2 < P) npow2 <<= 1;
-    size_t sm = (((size_t)L + 1) & ~(size_t)1) * 8 + (size_t)npow2 * 8 + (size_t)nfft * 16;
+    size_t sm = (((size_t)L + 1) & ~(size_t)1) * 8 + (size_t)npow2 * 8 + (size_t)nfft * 16 + (size_t)std::max<int64_t>(1024, L) * 8;
     static PerDeviceOnce median_once;
     if (median_once.first()) HIP_CHECK(hipFuncSetAttribute((const void*)grpdelay_median_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     grpdelay_median_kernel<<<bgrid(2), 1024, sm, st>>>(partial, nchunks, L, nfft, (const cplx*)tw, grpd, batch_ctx().stride);
