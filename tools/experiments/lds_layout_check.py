@@ -22,8 +22,25 @@ def slot(k):
     return (k & ~7) | ((k + 2 * ((k >> 4) & 3)) & 7)
 
 
+def report():
+    """{access: worst number of distinct addresses on one 16-byte slot within a lane group}"""
+    return {
+        "transposition 1 write": max(worst(lambda l: k1 * ROW + ((l & ~7) | ((l + (l >> 3)) & 7)), WG, 8) for k1 in range(16)),
+        "transposition 1 read": max(worst(lambda l: (l >> 2) * ROW + 8 * a + (((l & 3) + 4 * d + a) & 7), RG, 16) for a in range(8) for d in range(2)),
+        "transposition 2 write": max(worst(lambda l: (l >> 2) * ROW + ka * 8 + (((l & 3) + 4 * d + ka) & 7), WG, 8) for ka in range(8) for d in range(2)),
+        "transposition 2 read": max(worst(lambda l: (l >> 2) * ROW + ((l & 3) + 4 * e) * 8 + ((b + (l & 3) + 4 * e) & 7), RG, 16)
+                                    for b in range(8) for e in range(2)),
+        "natural-order write": max(worst(lambda l: slot((l >> 2) + 16 * ((l & 3) + 4 * e) + 128 * kb), WG, 8) for e in range(2) for kb in range(8)),
+        "natural-order read k": max(worst(lambda l: slot(l + 64 * s), RG, 16) for s in range(8)),
+        "natural-order read N-k": max(worst(lambda l: slot((1024 - l - 64 * s) & 1023), RG, 16) for s in range(8)),
+    }
+
+
 if __name__ == "__main__":
     assert sorted(slot(k) for k in range(1024)) == list(range(1024))
+    for name, w in report().items():
+        print(f"{name:24s} {w}")
+    raise SystemExit(0)
     print("transposition 1 write", max(worst(lambda l: k1 * ROW + ((l & ~7) | ((l + (l >> 3)) & 7)), WG, 8) for k1 in range(16)))
     print("transposition 1 read ", max(worst(lambda l: (l >> 2) * ROW + 8 * a + (((l & 3) + 4 * d + a) & 7), RG, 16) for a in range(8) for d in range(2)))
     print("transposition 2 write", max(worst(lambda l: (l >> 2) * ROW + ka * 8 + (((l & 3) + 4 * d + ka) & 7), WG, 8) for ka in range(8) for d in range(2)))
