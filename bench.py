@@ -396,6 +396,9 @@ def main():
 
     out = torch.zeros((K, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")  # complex as (re,im)
     scratch = torch.zeros((Bsz, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")
+    # destination addresses of every design's two filter sets, once (64 tensor views per batch otherwise, inside the timed region)
+    out_ptrs = [[out[j, e].data_ptr() for j in range(K)] for e in range(2)]
+    scratch_ptrs = [[scratch[j, e].data_ptr() for j in range(Bsz)] for e in range(2)]
     coll_dev = "cpu" if shared_gpu else "cuda"     # (gloo gathers host tensors)
     gathered = [torch.zeros(out.shape, dtype=out.dtype, device=coll_dev) for _ in range(world)] if (use_pg and rank == 0) else None
 
@@ -441,8 +444,8 @@ def main():
             elif launch:
                 launch[0].execute()
             u, f0 = inflight.pop(0)
-            dst, base = (out, f0) if store else (scratch, 0)
-            u.collect([dst[base + j, 0].data_ptr() for j in range(u.size)], [dst[base + j, 1].data_ptr() for j in range(u.size)])
+            pl, pr, base = (out_ptrs[0], out_ptrs[1], f0) if store else (scratch_ptrs[0], scratch_ptrs[1], 0)
+            u.collect(pl[base:base + u.size], pr[base:base + u.size])
             done += u.size
             (free if u.size == Bsz else tails[u.size]).append(u)
         assert done == n_designs
