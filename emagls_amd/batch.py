@@ -52,21 +52,29 @@ def simulation_order(order, fs, radius, c=343.0, raw=False):
 
 
 def batch_cost(n, sim_order):
-    """Relative run time of one lane batch of `n` designs laid out for `sim_order` (measured on MI355X, eMagLS2 with 32
-    microphones and 1024 taps: 13.6 ms for 8 radii at simulation order 23, 24 ms at order 44): a part that does not depend
-    on the number of designs (the resident sweep costs the same for 1..8 designs, the latency chains of the per-bin
-    factorisation) and a part that does (G_k of every bin, HBM bound)."""
+    """Run time in ms of one lane batch of `n` designs laid out for `sim_order`, as measured on MI355X at the end of round 4
+    (eMagLS2, 32 microphones, order 4, 48 kHz, 1024 taps: every lane batch of BASELINE config 4's 256 radii alone on the GPU,
+    tools/experiments/config4_costs.py): a part per launch sequence and a part per design, both growing with the simulated SH
+    channels -- 10.1 ... 16.1 ms for 8 designs and 13.7 ... 22.4 ms for 16 between simulation orders 18 and 44 (the resident sweep
+    costs 16 designs 1.3 times what it costs 8: lane batches of 16 do the job list in 0.72 of the time of batches of 8).  Below
+    simulation order ~19 the designs of this shape keep materialised sweep operands (their ill-conditioned low bins reach beyond
+    k_cut: `sweep_form` 1) and cost 12 - 13 ms per 8, 18 - 21 ms per 16, whatever the order.  Only the ratios matter
+    (shard_lane_batches)."""
     S = (int(sim_order) + 1) ** 2
-    return (0.45 + 0.55 * n / 8.0) * (1.0 + 7.6e-4 * S)
+    g = n / 8.0
+    if int(sim_order) < 19:
+        return 5.6 + 7.2 * g
+    return (6.4 + 2.4 * g) + (1.67 + 1.93 * g) * 1e-3 * S
 
 
-def padded_lane_batches(sim_orders, max_batch=8):
+def padded_lane_batches(sim_orders, max_batch=16):
     """Lane batches across neighbouring simulation-order classes: the jobs sorted by simulation order (stable) and cut into
     ceil(n / max_batch) consecutive chunks of equal size (+-1).  Every design of a chunk is laid out for the chunk's highest
     simulation order (`sim_order_pad` of the plan: b_n = 0 above the design's own order, the same filters), so a chunk has ONE
     shape and runs in lane mode.  Returns [(job indices, pad order), ...], lowest orders first.
-    BASELINE config 4 (256 radii on 2..10 cm, 36 classes of 7-8 radii): 32 batches of 8 instead of 36 of 7-8 (or, sharded per
-    job, 200 of 1-2)."""
+    BASELINE config 4 (256 radii on 2..10 cm, 36 classes of 7-8 radii): 16 batches of 16 (32 of 8 with max_batch = 8) instead of
+    36 of 7-8 (or, sharded per job, 200 of 1-2).  A batch of more than 8 designs needs emagls_set_batch_max (the job lists of this
+    module raise it for the call)."""
     if not 1 <= max_batch <= 16:
         raise ValueError("a batch holds 1..16 designs")
     n = len(sim_orders)
@@ -265,11 +273,17 @@ def _execute_plans(plans, res, first, share_geometry=False):
     pl, pr = res.ptrs(first, len(plans))
     b = None
     if len(plans) > 1:
+        prev = C.c_int(0)
+        if len(plans) > 8:   # (the library's default limit is 8 designs per batch; up to 16 on request)
+            L.check(L.load().emagls_set_batch_max(len(plans), C.byref(prev)))
         try:
             b = Batch(plans)
         except L.EmaglsError as e:
             if e.code != L.ERR_UNSUPPORTED:
                 raise
+        finally:
+            if prev.value:
+                L.check(L.load().emagls_set_batch_max(prev.value, None))
     if b is not None:
         try:
             if share_geometry:
@@ -347,9 +361,9 @@ def _even_chunks(n, world, max_batch):
 
 
 def emagls2_radius_sweep(hL, hR, hrirGridAziRad, hrirGridZenRad, radii, micGridAziRad, micGridZenRad, order, fs, length,
-                         shDefinition="real", group=None, max_batch=8):
-    """getEMagLs2Filters (lib/getEMagLs2Filters.m:1-2) for every array radius of `radii` (BASELINE config 4): padded lane batches,
-    whole batches per rank, one gather.  Returns [(wMlsL, wMlsR), ...] in the order of `radii` on rank 0, None elsewhere."""
+                         shDefinition="real", group=None, max_batch=16):
+    """getEMagLs2Filters (lib/getEMagLs2Filters.m:1-2) for every array radius of `radii` (BASELINE config 4): padded lane batches
+    (of 16 designs: one resident sweep launch per batch, batch_cost), whole batches per rank, one gather.  Returns [(wMlsL, wMlsR), ...] in the order of `radii` on rank 0, None elsewhere."""
     from . import Plan, _lib as L
     hL = np.asfortranarray(hL, dtype=np.float64)
     hR = np.asfortranarray(hR, dtype=np.float64)

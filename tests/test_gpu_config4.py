@@ -147,20 +147,25 @@ def test_run_batch_composes_with_the_real_designs(grids, hrirs64):
         assert wL.shape == (64, 32) and np.array_equal(wL, dL) and np.array_equal(wR, dR)
 
 
-def test_one_ranks_share_of_config4_in_lane_mode(grids, hrirs64):
-    """BASELINE config 4 as named: 256 radii over 8 ranks.  One rank's full share -- 32 radii = 4 padded lane batches of 8
-    designs of neighbouring simulation-order classes (emagls_amd.batch.padded_lane_batches / shard_lane_batches) -- through
-    Batch: every batch runs in LANE mode, every job equals its own one-shot design (which is laid out for its own simulation
-    order, no padding), and one job of every batch is compared with the oracle."""
+@pytest.mark.parametrize("max_batch", [16, 8])
+def test_one_ranks_share_of_config4_in_lane_mode(grids, hrirs64, max_batch):
+    """BASELINE config 4 as named: 256 radii over 8 ranks.  One rank's full share -- 32 radii = 2 padded lane batches of 16 (the
+    default since round 4: one resident sweep launch per 16 designs) or 4 of 8 designs of neighbouring simulation-order classes
+    (emagls_amd.batch.padded_lane_batches / shard_lane_batches) -- through Batch: every batch runs in LANE mode, every job equals
+    its own one-shot design (which is laid out for its own simulation order, no padding), and one job of every batch is compared
+    with the oracle."""
+    import ctypes
     import emagls_amd as E
     from emagls_amd import Batch, Plan, _lib as L
     from emagls_amd.batch import padded_lane_batches, shard_lane_batches, simulation_order
     hrirs, length = hrirs64, 64
     radii = np.linspace(0.02, 0.10, 256)
     so = [simulation_order(4, 48000.0, r, raw=True) for r in radii]
-    per_rank, load = shard_lane_batches(padded_lane_batches(so), 8)
+    per_rank, load = shard_lane_batches(padded_lane_batches(so, max_batch), 8)
     mine = per_rank[5]
-    assert len(mine) == 4 and all(len(idx) == 8 for idx, _ in mine)
+    assert len(mine) == 32 // max_batch and all(len(idx) == max_batch for idx, _ in mine)
+    prev = ctypes.c_int(0)
+    L.check(L.load().emagls_set_batch_max(max_batch, ctypes.byref(prev)))
     results, padded = {}, 0
     for idx, pad in mine:
         plans = []
@@ -183,6 +188,7 @@ def test_one_ranks_share_of_config4_in_lane_mode(grids, hrirs64):
         b.close()
         for p in plans:
             p.close()
+    L.check(L.load().emagls_set_batch_max(prev.value, None))
     assert len(results) == 32 and padded >= 4      # the share really mixes simulation-order classes
     worst = 0.0
     for idx, _ in mine:                             # first and last job of every batch against its one-shot design
@@ -190,7 +196,7 @@ def test_one_ranks_share_of_config4_in_lane_mode(grids, hrirs64):
             wL, wR = E.getEMagLs2Filters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], float(radii[j]), grids["mic_azi"],
                                          grids["mic_zen"], 4, 48000.0, length, "real")
             worst = max(worst, rel(results[j][0], wL), rel(results[j][1], wR))
-    print(f"config 4, one rank's share (32 radii, 4 lane batches): padded lane batches vs one-shot designs, worst rel = {worst:.3e}")
+    print(f"config 4, one rank's share (32 radii, {len(mine)} lane batches): padded lane batches vs one-shot designs, worst rel = {worst:.3e}")
     assert worst < 1e-8
     worst_o = 0.0
     for idx, pad in mine:                           # one padded job per batch against the oracle
@@ -198,7 +204,7 @@ def test_one_ranks_share_of_config4_in_lane_mode(grids, hrirs64):
         oL, oR = O.getEMagLs2Filters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], float(radii[j]), grids["mic_azi"], grids["mic_zen"],
                                      4, 48000.0, length, "real")
         worst_o = max(worst_o, rel(results[j][0], oL), rel(results[j][1], oR))
-    print(f"config 4, one rank's share: 4 jobs vs oracle, worst rel = {worst_o:.3e}")
+    print(f"config 4, one rank's share: {len(mine)} jobs vs oracle, worst rel = {worst_o:.3e}")
     assert worst_o < TOL
 
 
@@ -219,13 +225,16 @@ def test_job_lists_of_config4_and_config5(grids, hrirs64):
     import emagls_amd as E
     from emagls_amd import synth
     from emagls_amd.batch import emagls2_radius_sweep, emagls_from_atf_subjects
-    radii = [0.031, 0.0312, 0.0335, 0.047, 0.0471, 0.0472, 0.0473, 0.0474, 0.0475, 0.0476]     # 10 radii -> batches of 5 + 5
+    # 10 radii -> one lane batch of 10 laid out for the largest radius' simulation order (batches of 5 + 5 with max_batch = 8): a design
+    # padded by seven orders may take the other sweep form than its one-shot twin -- the filters then agree to the 5e-9 ... 6e-8 the
+    # two forms differ by, not to the 1e-12 of identical routes
+    radii = [0.031, 0.0312, 0.0335, 0.047, 0.0471, 0.0472, 0.0473, 0.0474, 0.0475, 0.0476]
     out = emagls2_radius_sweep(hrirs64[0], hrirs64[1], grids["azi"], grids["zen"], radii, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 64)
     assert len(out) == len(radii)
     for j in (0, 2, 9):
         wL, wR = E.getEMagLs2Filters(hrirs64[0], hrirs64[1], grids["azi"], grids["zen"], radii[j], grids["mic_azi"], grids["mic_zen"], 4,
                                      48000.0, 64, "real")
-        assert rel(out[j][0], wL) < 1e-9 and rel(out[j][1], wR) < 1e-9
+        assert rel(out[j][0], wL) < 1e-7 and rel(out[j][1], wR) < 1e-7
     sub = slice(0, 2702, 3)
     azi, zen = grids["azi"][sub], grids["zen"][sub]
     subjects = [synth.rigid_sphere_hrirs(azi, zen, seed=5 + j, head_radius=0.08 + 0.004 * j) for j in range(3)]

@@ -85,19 +85,25 @@ def config4(radii, reps=4, roofline_key=None):
     return res
 
 
-def config4_rank_share(world=8, rank=5, reps=2):
-    """BASELINE config 4 as named: 256 radii on 2..10 cm over 8 GPUs.  One rank's full share -- 32 radii as 4 padded lane
-    batches of 8 (emagls_amd.batch.padded_lane_batches / shard_lane_batches) -- all four batches resident and in flight
-    together, full size (1024 taps).  filter_sets_per_s is what ONE GPU of the 8 delivers on the job list."""
+def config4_rank_share(world=8, rank=None, reps=2, max_batch=16):
+    """BASELINE config 4 as named: 256 radii on 2..10 cm over 8 GPUs.  One rank's full share -- 32 radii as 2 padded lane
+    batches of 16 (round 4; 4 of 8 with max_batch = 8: emagls_amd.batch.padded_lane_batches / shard_lane_batches) -- all its
+    batches resident and in flight together, full size (1024 taps); the rank is the one the cost model loads most.
+    filter_sets_per_s is what ONE GPU of the 8 delivers on the job list."""
     from emagls_amd import Batch, Plan, synth, _lib as L
     from emagls_amd.batch import padded_lane_batches, shard_lane_batches, simulation_order
     azi, zen, maz, mzn = _grids()
     hL, hR = synth.rigid_sphere_hrirs(azi, zen)
     radii = np.linspace(0.02, 0.10, 256)
     so = [simulation_order(4, 48000.0, r, raw=True) for r in radii]
-    per_rank, load = shard_lane_batches(padded_lane_batches(so), world)
+    per_rank, load = shard_lane_batches(padded_lane_batches(so, max_batch), world)
+    if rank is None:
+        rank = int(np.argmax(load))      # the rank the cost model loads most: its share bounds the job list
     mine = per_rank[rank]
+    import ctypes
     import torch
+    prev = ctypes.c_int(0)
+    L.check(L.load().emagls_set_batch_max(max(max_batch, 8), ctypes.byref(prev)))
     streams = [torch.cuda.Stream() for _ in mine]
     units = []
     for (idx, pad), st in zip(mine, streams):
@@ -135,6 +141,7 @@ def config4_rank_share(world=8, rank=5, reps=2):
         b.close()
         for p in plans:
             p.close()
+    L.check(L.load().emagls_set_batch_max(prev.value, None))
     return {"ranks": world, "rank": rank, "designs": n, "lane_batches": [len(idx) for idx, _ in mine], "pad_orders": [pad for _, pad in mine],
             "lane_mode": lanes, "rank_load_spread": round(max(load) / min(load), 4), "ms_per_batch_alone": each,
             "ms_per_share": round(dt * 1e3, 3), "filter_sets_per_s": round(n / dt, 1)}
