@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(OLSR_NT) ols_fused_rr_kernel(const double* __r
 // packed inverse transform of both ears as conj(FFT(conj(.))).
 //   tab [npairs][16][2][64]  A_p and conj(B_p[N - .]) at bin wf_bin(lane, i)   (ols_wave_tables_kernel)
 // G waves share a block (pairs g, g + G, ...; their partial sums meet in LDS): G = 1 for long signals -- every wave its own
-// block, no workgroup barrier at all -- G = 8 when there are fewer blocks than compute units.
+// block, no workgroup barrier at all -- G = 2, 4, 8 as the blocks get fewer, so that every CU still has a workgroup.
 // ---------------------------------------------------------------------------------------------
 constexpr int OLSW_WAVES = 8;
 // pair_mode 0: pair p = channels (2 p, 2 p + 1); 1: (p, p + C / 2) -- the real and the imaginary plane of complex channel p
@@ -638,12 +638,18 @@ void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL,
             static PerDeviceOnce wave_once;
             if (wave_once.first()) {
                 HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_wave_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_wave_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_wave_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ols_wave_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             }
-            if (nblocks >= 4 * (int64_t)ncu_w)
-                ols_wave_kernel<1><<<(unsigned)ceil_div(nblocks, OLSW_WAVES), 64 * OLSW_WAVES, dyn_w, st>>>(sig, sigc, n, C, w.wtab, w.circle, len, B, nblocks, out);
-            else
-                ols_wave_kernel<8><<<(unsigned)nblocks, 64 * OLSW_WAVES, dyn_w, st>>>(sig, sigc, n, C, w.wtab, w.circle, len, B, nblocks, out);
+            // waves per block: as few as still give every CU a workgroup (8 / G blocks per workgroup)
+            const int64_t cu = ncu_w;
+#define EMAGLS_OLSW_GO(G_) ols_wave_kernel<G_><<<(unsigned)ceil_div(nblocks, OLSW_WAVES / G_), 64 * OLSW_WAVES, dyn_w, st>>>(sig, sigc, n, C, w.wtab, w.circle, len, B, nblocks, out)
+            if (nblocks >= 8 * cu) EMAGLS_OLSW_GO(1);
+            else if (nblocks >= 4 * cu) EMAGLS_OLSW_GO(2);
+            else if (nblocks >= 2 * cu) EMAGLS_OLSW_GO(4);
+            else EMAGLS_OLSW_GO(8);
+#undef EMAGLS_OLSW_GO
             KERNEL_CHECK();
             HIP_CHECK(hipStreamSynchronize(st));
             return;

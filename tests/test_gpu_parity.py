@@ -1241,7 +1241,8 @@ def test_binaural_decode(golden):
 
 
 @pytest.mark.parametrize("nsamp,nch,length", [(5000, 25, 512), (777, 4, 64), (100, 9, 256), (3000, 1, 2), (4097, 7, 1000),
-                                              (9000, 36, 2048), (2600, 16, 3000), (2000, 3, 257), (600000, 5, 400)])
+                                              (9000, 36, 2048), (2600, 16, 3000), (2000, 3, 257), (600000, 5, 400), (700000, 2, 512),
+                                              (1100000, 3, 512)])
 def test_binaural_decode_shapes(nsamp, nch, length, monkeypatch):
     """The fused overlap-save kernels (257..512 taps: wave-private 1024-point transforms, one wave per block on long signals
     and eight waves per block on short ones; up to 256 taps, or with EMAGLS_DECODE_WAVE=0: half-wave two-factor transforms;
