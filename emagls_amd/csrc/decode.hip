@@ -373,6 +373,43 @@ __global__ void ols_wave_tables_kernel(const cplx* __restrict__ Wf, int C, int p
     tab[idx] = r;
 }
 
+// The same tables straight from the filter taps (no zero-padding pass, no hipFFT, no spectra in HBM): workgroup = channel pair, wave =
+// ear, one packed transform Z_e = FFT(w_e,a + i w_e,b) of the zero-padded taps each.  With it U_e[k] = conj(Z_e[N - k]) / 2 and
+// V_e[k] = Z_e[k] / 2, so both table entries of bin m come from c_e = conj(Z_e[N - m]):  A_p[m] = (c_L + i c_R) / 2,
+// conj(B_p[N - m]) = (c_L - i c_R) / 2.
+//   wL, wR [C][len] taps (len <= 512)
+__global__ void __launch_bounds__(128) ols_wave_filter_kernel(const double* __restrict__ wL, const double* __restrict__ wR, int C, int64_t len,
+                                                              int pair_mode, const cplx* __restrict__ circle, cplx* __restrict__ tab) {
+    constexpr int N = WF_N;
+    __shared__ __attribute__((aligned(16))) cplx lds[WF_TABLES + 2 * WF_BUF];
+    cplx* tables = lds;
+    const int tid = threadIdx.x, e = tid >> 6, l = tid & 63, p = blockIdx.x;
+    cplx* tb = lds + WF_TABLES + (size_t)e * WF_BUF;
+    wave_fft_tables(tables, circle, tid, 128);
+    __syncthreads();
+    const int ca = pair_mode ? p : 2 * p, cb = pair_mode ? p + C / 2 : 2 * p + 1;
+    const double* w = e ? wR : wL;
+    cplx v[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const int64_t t = 64 * n1 + l;
+        v[n1] = (n1 < 8 && t < len) ? mk(w[(int64_t)ca * len + t], cb < C ? w[(int64_t)cb * len + t] : 0.0) : mk(0.0, 0.0);
+    }
+    wave_fft1024<true>(v, tb, tables, l);
+    wave_fft_store_natural(v, tb, l);
+    __syncthreads();
+    const cplx* zL = lds + WF_TABLES;
+    const cplx* zR = zL + WF_BUF;
+    cplx* out = tab + (size_t)p * (16 * 2 * 64);
+    for (int idx = tid; idx < 16 * 64; idx += 128) {
+        const int i = idx >> 6, ll = idx & 63;
+        const int m = wf_bin(ll, i), km = wf_slot((N - m) & (N - 1));
+        const cplx cl = conj(zL[km]), cr = conj(zR[km]);
+        out[(2 * i) * 64 + ll] = mk(0.5 * (cl.x - cr.y), 0.5 * (cl.y + cr.x));       // (c_L + i c_R) / 2
+        out[(2 * i + 1) * 64 + ll] = mk(0.5 * (cl.x + cr.y), 0.5 * (cl.y - cr.x));   // (c_L - i c_R) / 2
+    }
+}
+
 template <int G>
 __global__ void __launch_bounds__(64 * OLSW_WAVES) ols_wave_kernel(const double* __restrict__ sig, const cplx* __restrict__ sigc, int64_t n, int C, const cplx* __restrict__ tab,
                                                                    const cplx* __restrict__ circle, int64_t len, int64_t B, int64_t nblocks,
@@ -620,19 +657,28 @@ void binaural_decode_real(const double* sig, int64_t n, int C, const double* wL,
         std::lock_guard<std::mutex> lk(g_decode_mu);
         DecodeWork& w = g_decode;
         w.ensure(C, 0, Nf);
-        fft_check(hipfftSetStream(w.pw, st), "set stream");
-        ols_padfilt_kernel<<<256, 256, 0, st>>>(wL, wR, C, len, Nf, w.wpad);
-        KERNEL_CHECK();
-        fft_check(hipfftExecD2Z(w.pw, w.wpad, (hipfftDoubleComplex*)w.Wf), "exec D2Z filters");
         const char* e_rr = getenv("EMAGLS_DECODE_REGFFT");   // (read at every call: a test switches forms inside one process)
         const bool use_rr = !(e_rr && e_rr[0] == '0');
         const char* e_wave = getenv("EMAGLS_DECODE_WAVE");
-        if (use_rr && Nf == WF_N && !(e_wave && e_wave[0] == '0')) {   // wave-private transforms
-            int dev_w = 0, ncu_w = 256;
-            HIP_CHECK(hipGetDevice(&dev_w));
-            HIP_CHECK(hipDeviceGetAttribute(&ncu_w, hipDeviceAttributeMultiprocessorCount, dev_w));
+        const bool wave_form = use_rr && Nf == WF_N && !(e_wave && e_wave[0] == '0');
+        const char* e_ft = getenv("EMAGLS_DECODE_FILTER_FFT");   // =hipfft: the filter side of the wave form through hipFFT + ols_wave_tables_kernel
+        const bool own_filter_side = wave_form && !(e_ft && e_ft[0] == 'h');
+        if (!own_filter_side) {
+            fft_check(hipfftSetStream(w.pw, st), "set stream");
+            ols_padfilt_kernel<<<256, 256, 0, st>>>(wL, wR, C, len, Nf, w.wpad);
+            KERNEL_CHECK();
+            fft_check(hipfftExecD2Z(w.pw, w.wpad, (hipfftDoubleComplex*)w.Wf), "exec D2Z filters");
+        }
+        if (wave_form) {   // wave-private transforms
+            static thread_local int ncu_w = 0;   // (per calling thread: one device query instead of one per call)
+            if (!ncu_w) {
+                int dev_w = 0;
+                HIP_CHECK(hipGetDevice(&dev_w));
+                HIP_CHECK(hipDeviceGetAttribute(&ncu_w, hipDeviceAttributeMultiprocessorCount, dev_w));
+            }
             const int npairs = (C + 1) / 2;
-            ols_wave_tables_kernel<<<(unsigned)ceil_div((int64_t)npairs * 2048, 256), 256, 0, st>>>(w.Wf, C, sigc ? 1 : 0, w.wtab);
+            if (own_filter_side) ols_wave_filter_kernel<<<npairs, 128, 0, st>>>(wL, wR, C, len, sigc ? 1 : 0, w.circle, w.wtab);
+            else ols_wave_tables_kernel<<<(unsigned)ceil_div((int64_t)npairs * 2048, 256), 256, 0, st>>>(w.Wf, C, sigc ? 1 : 0, w.wtab);
             KERNEL_CHECK();
             const size_t dyn_w = sizeof(cplx) * (WF_TABLES + (size_t)OLSW_WAVES * WF_BUF);
             static PerDeviceOnce wave_once;

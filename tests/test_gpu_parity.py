@@ -1258,6 +1258,9 @@ def test_binaural_decode_shapes(nsamp, nch, length, monkeypatch):
     out = E.binauralDecode(sig, 48000, wL, wR, 48000)
     ref = O.binauralDecode(sig, wL, wR)
     assert out.shape == ref.shape == (nsamp, 2)
+    monkeypatch.setenv("EMAGLS_DECODE_FILTER_FFT", "hipfft")   # the wave form's filter tables from hipFFT spectra instead of its own transform
+    assert rel(E.binauralDecode(sig, 48000, wL, wR, 48000), ref) < 1e-12
+    monkeypatch.delenv("EMAGLS_DECODE_FILTER_FFT")
     monkeypatch.setenv("EMAGLS_DECODE_WAVE", "0")        # the half-wave two-factor form (what up to 256 taps take anyway)
     half = E.binauralDecode(sig, 48000, wL, wR, 48000)
     monkeypatch.setenv("EMAGLS_DECODE_REGFFT", "0")      # the fused kernel on LDS transform passes (what 513..2048 taps take anyway)
