@@ -533,7 +533,6 @@ void plan_setup(emagls_plan& p) {
         p.wide = p.S > 32;
         if (p.S > 64) throw Error(EMAGLS_ERR_UNSUPPORTED, d.kind == EMAGLS_KIND_MAGLS_2D ? "CH order above 31 is not supported in this build"
                                                                                            : "SH order above 7 is not supported for LS/MagLS in this build");
-        if (p.wide && p.diffuse) throw Error(EMAGLS_ERR_UNSUPPORTED, "the covariance constraint is available up to 32 channels");
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than SH channels");
     } else if (array_kind(d.kind)) {
         if (!(d.mic_radius > 0) || d.nmics < 1) throw Error(EMAGLS_ERR_ARG, "invalid array geometry");
@@ -559,8 +558,8 @@ void plan_setup(emagls_plan& p) {
             if (p.C > 64) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 64 output channels is not supported in this build");
             if (d.kind != EMAGLS_KIND_EMAGLS && d.kind != EMAGLS_KIND_EMAGLS2)
                 throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: eMagLS / eMagLS2 only");
-            if (p.custom_basis || p.diffuse || d.sim_order_pad > 0)
-                throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: built-in SH basis, no covariance constraint, no padding");
+            if (p.custom_basis || d.sim_order_pad > 0)
+                throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: built-in SH basis, no padding");
             if (p.req_cplx && !p.real_internal) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: the real-arithmetic pipeline only");
             p.wide = true;
         }
@@ -1438,6 +1437,11 @@ void execute_emagls_wide(emagls_plan& p) {
     launch_hrir_grpdelay(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, d.ndirs, p.nfft, p.get("tw"), p.get<double>("dirsum"), p.get<double>("grpd"), st);
     launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"), p.get<double>("grpd"), 0, ls_end, p.kcut0,
                     p.get("Hc"), p.get<double>("Habs"), p.ldD, st);
+    if (p.diffuse) {   // the covariance constraint's target: the time-aligned complex HRTFs of every bin; G starts at bin 1 here
+        launch_hrir_fft(p.get<double>("hL"), p.get<double>("hR"), d.nsamp, p.D, nullptr, p.nfft, p.get("tw"), p.get<double>("grpd"), 0, p.P, p.P,
+                        p.get("Hfull"), p.get<double>("Habs"), p.ldD, st);
+        p.g0 = 1;
+    }
     p.mark("hrir_prologue");
     // ---- conj(Y) = Q R, order terms T_n = R(:,blk_n) E(:,blk_n)^T and QT_n, G_k of every solved bin
     launch_gram(p.get("Yc"), p.D, p.S, p.ldS, false, p.get("Gp"), nullptr, p.get("R"), p.S, st);

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) diffuse_constraint_kernel(cplx* __restric
                                                                  const cplx* __restrict__ H, int D, int C, int64_t ldD, int P,
                                                                  size_t bstride) {
     W = boff(W, bstride); G = boff(G, bstride); H = boff(H, bstride);
-    __shared__ cplx w_s[2][32];
+    __shared__ cplx w_s[2][64];
     __shared__ double red[4][8];
     __shared__ cplx m_s[4];
     const int kb = blockIdx.x + 1;
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256) diffuse_constraint_kernel(cplx* __restric
 void launch_diffuse_constraint(void* W, const void* G, bool g_cplx, int64_t g_stride, int g0, const void* H, int D, int C, int64_t ldD,
                                int P, hipStream_t st) {
     if (P < 2) return;
-    if (C > 32) throw Error(2, "diffuseness constraint: more than 32 channels is not supported");
+    if (C > 64) throw Error(2, "diffuseness constraint: more than 64 channels is not supported");
     if (g_cplx)
         diffuse_constraint_kernel<cplx><<<bgrid(P - 1), 256, 0, st>>>((cplx*)W, (const cplx*)G, g_stride, g0, (const cplx*)H, D, C, ldD, P,
                                                                        batch_ctx().stride);
