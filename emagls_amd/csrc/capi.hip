@@ -575,7 +575,9 @@ void plan_setup(emagls_plan& p) {
         p.C = (int)d.nmics;
         // up to 32 microphones on the Gram route (the M x M factors of the persistent sweep's form); the dense route behind its
         // conditioning flag -- QR + Jacobi of the Dm x M matrix itself -- holds up to 8 columns at this row count (factor.hip)
-        if (p.C > 32) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 ATF microphones is not supported in this build");
+        // (33..64 microphones: the plain per-bin path of wide_array.hip on the matched ATF matrices themselves, one subject at a time)
+        if (p.C > 64) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 64 ATF microphones is not supported in this build");
+        p.wide = p.C > 32;
         p.hrir_smaller = d.ndirs <= d.natf;  // min([a b]) returns the first index on ties (FromAtf.m:62)
         p.Dm = p.hrir_smaller ? d.ndirs : d.natf;
         // (up to 3072 matched directions: resident sweep; above: the Gram route with one launch per bin, sweep_half_kernel walking
@@ -727,6 +729,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("route", sizeof(int) * (size_t)p.P);
         p.gram_from = 1;   // every bin starts on the Gram route; a device-side conditioning flag moves the start up (plan_recover)
         p.alloc("Vws", sizeof(cplx) * (size_t)p.P * M * p.ldD);
+        if (p.wide) p.alloc("Bw", sizeof(cplx) * (size_t)p.P * M * p.ldD);   // the matched ATF matrices again: the QR works in place
         p.alloc("sv", sizeof(double) * (size_t)p.P * M);
         p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
         p.alloc("tauw", sizeof(double) * (size_t)p.P * M);
@@ -1563,7 +1566,53 @@ void from_atf_post_sweep(emagls_plan& p) {
     p.mark("epilogue");
 }
 
+// FromAtf with 33..64 microphones: pwGrid_k.' = X_k.' (Dm x M) is its own "S-space" (Q = I), so wide_array.hip's per-bin kernels --
+// Householder QR, one-sided Jacobi, back-transform -- give Y_reg_inv_k directly; one sweep launch per bin (lib/getEMagLsFiltersFromAtf.m:97-120).
+void execute_from_atf_wide(emagls_plan& p) {
+    hipStream_t st = p.stream;
+    const emagls_design_desc& d = p.d;
+    const int M = p.C, nb = p.P - 1;
+    const int64_t g_stride = (int64_t)M * p.ldD;
+    if (p.hrir_smaller)
+        launch_grid_match(p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), d.ndirs, p.get<double>("atf_azi"),
+                          p.get<double>("atf_zen"), d.natf, p.get<double>("cartB"), p.get<int64_t>("match_idx"),
+                          p.get<double>("match_dev"), p.get<double>("mean_dev"), st);
+    else
+        launch_grid_match(p.get<double>("atf_azi"), p.get<double>("atf_zen"), d.natf, p.get<double>("hrir_azi"),
+                          p.get<double>("hrir_zen"), d.ndirs, p.get<double>("cartB"), p.get<int64_t>("match_idx"),
+                          p.get<double>("match_dev"), p.get<double>("mean_dev"), st);
+    launch_atf_colidx(p.hrir_smaller ? p.get<int64_t>("match_idx") : nullptr, p.Dm, M, p.get<int64_t>("colidx"), st);
+    p.mark("grid_match");
+    stage_prologue(p, 1, p.hrir_smaller ? nullptr : p.get<int64_t>("match_idx"), p.Dm);
+    launch_real_fft_gather(p.get<double>("atf"), d.atf_taps, (int64_t)M * p.Dm, p.get<int64_t>("colidx"), p.nfft, p.get("tw"),
+                           p.get("X"), g_stride, p.Dm, p.ldD, st);
+    p.mark("atf_fft");
+    cplx* X = p.get<cplx>("X");
+    cplx* Z = p.get<cplx>("Z");
+    HIP_CHECK(hipMemcpyAsync(p.get("Bw"), X + g_stride, sizeof(cplx) * (size_t)nb * g_stride, hipMemcpyDeviceToDevice, st));
+    launch_wa_factor(p.get("Bw"), p.get("Vws"), (int)p.Dm, M, (int)p.ldD, nb, SVD_REGUL_CONST, p.get<double>("tauw"), p.get("R2w"), p.get("Nw"),
+                     p.get<double>("sv") + M, p.get<int>("jsweeps") + 1, Z + g_stride, st);
+    p.mark("factor_bins");
+    const int ls_end = std::min(p.kcut0, p.P);
+    launch_wa_ls(p.get("Hc"), p.ldD, ls_end, Z + g_stride, p.ldD, (int)p.Dm, M, p.P, 1, ls_end, p.get("W"), st);
+    p.mark("ls_bins");
+    DenseSweepArgs a{};
+    a.D = (int)p.Dm; a.C = M; a.ldD = (int)p.ldD; a.P = p.P;
+    a.X = X; a.x_stride = g_stride; a.Zd = Z; a.z_stride = g_stride;
+    a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
+    a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG; a.dpw = 0;
+    const int k0 = std::max(p.kcut0, 1);
+    a.kfirst = k0;
+    p.sweep_launches = 0;
+    for (int kb = k0; kb < p.P; ++kb) { launch_sweep_wide(a, kb, true, st); ++p.sweep_launches; }
+    if (k0 < p.P) launch_sweep_wide_finalize(p.get("Wpart"), p.get("W"), p.nWG, M, p.P, p.P - 1, st);
+    p.mark("magls_sweep");
+    launch_filter_epilogue(p.get("W"), M, p.nfft, (int)d.len, p.get("tw"), p.get<double>("grpd"), 0, 1, 1, 0, p.get("wL"), p.get("wR"), st);
+    p.mark("epilogue");
+}
+
 void execute_from_atf(emagls_plan& p) {
+    if (p.wide) { execute_from_atf_wide(p); return; }
     // (eager / profiled executes; plan_execute captures the stages around the sweep otherwise.  More matched directions than the
     // dense route's QR holds: the Gram route as well, emagls_run_sweep then launches bin by bin)
     if (p.sweep_persist || p.Dm > 4096) {

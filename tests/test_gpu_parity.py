@@ -1081,6 +1081,22 @@ def test_designs_on_large_hrir_grids():
     assert report("FromAtf, 5000 matched directions L", wL, oL) < TOL and report("R", wR, oR) < TOL
 
 
+@pytest.mark.parametrize("nmics", [40, 64])
+def test_from_atf_above_32_microphones(thin, nmics):
+    """lib/getEMagLsFiltersFromAtf.m:40 takes any microphone count.  33..64 microphones: the matched ATF matrix of every bin is
+    factored by the plain per-bin kernels of wide_array.hip (Householder QR + one-sided Jacobi, Y_reg_inv_k written out), one sweep
+    launch per bin (round 3 refused more than 32)."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    atf, aazi, azen = synth.glasses_atfs(natf=1500, nmics=nmics, taps=64)
+    hg = np.column_stack([thin["azi"], thin["zen"]])
+    ag = np.column_stack([aazi, azen])
+    wL, wR = E.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)
+    oL, oR, dev = O.getEMagLsFiltersFromAtf(thin["hL"], thin["hR"], hg, atf, ag, 48000.0, 128, 2000.0)
+    assert wL.shape == (128, nmics)
+    assert report(f"FromAtf {nmics} microphones L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
 @pytest.mark.parametrize("natf", [1024, 500])
 def test_from_atf_512_taps_wave_prologue(thin, monkeypatch, natf):
     """512-tap FromAtf filters: nfft = 1024, so the HRIR prologue with the integer circshift (lib/getEMagLsFiltersFromAtf.m:43-53)
