@@ -85,7 +85,7 @@ def config4(radii, reps=4, roofline_key=None):
     return res
 
 
-def config4_rank_share(world=8, rank=None, reps=2, max_batch=16):
+def config4_rank_share(world=8, rank=None, reps=4, max_batch=16):
     """BASELINE config 4 as named: 256 radii on 2..10 cm over 8 GPUs.  One rank's full share -- 32 radii as 2 padded lane
     batches of 16 (round 4; 4 of 8 with max_batch = 8: emagls_amd.batch.padded_lane_batches / shard_lane_batches) -- all its
     batches resident and in flight together, full size (1024 taps); the rank is the one the cost model loads most.
