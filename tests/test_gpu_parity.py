@@ -1097,6 +1097,22 @@ def test_from_atf_above_32_microphones(thin, nmics):
     assert report(f"FromAtf {nmics} microphones L", wL, oL) < TOL and report("R", wR, oR) < TOL
 
 
+def test_from_atf_subject_list_above_32_microphones(thin):
+    """emagls_amd.batch.emagls_from_atf_subjects with a 40-microphone ATF set: the library does not batch such designs, the job list
+    runs them plan by plan and returns what single calls return."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    from emagls_amd.batch import emagls_from_atf_subjects
+    atf, aazi, azen = synth.glasses_atfs(natf=1200, nmics=40, taps=64)
+    hg = np.column_stack([thin["azi"], thin["zen"]])
+    ag = np.column_stack([aazi, azen])
+    subjects = [(thin["hL"], thin["hR"]), (thin["hR"], thin["hL"])]
+    res = emagls_from_atf_subjects(subjects, hg, atf, ag, 48000.0, 128, 2000.0)
+    for (hL, hR), (wL, wR) in zip(subjects, res):
+        sL, sR = E.getEMagLsFiltersFromAtf(hL, hR, hg, atf, ag, 48000.0, 128, 2000.0, verbose=False)
+        assert rel(wL, sL) < 1e-12 and rel(wR, sR) < 1e-12
+
+
 @pytest.mark.parametrize("natf", [1024, 500])
 def test_from_atf_512_taps_wave_prologue(thin, monkeypatch, natf):
     """512-tap FromAtf filters: nfft = 1024, so the HRIR prologue with the integer circshift (lib/getEMagLsFiltersFromAtf.m:43-53)
