@@ -15,11 +15,11 @@ def _bench():
 
 
 def test_schedule_processes_exactly_the_requested_designs():
-    """The resident configuration (4 x 16) does not depend on --steps: a region of K designs is K // 16 full batches and one
+    """The resident configuration (8 x 16: eight batches per wave) does not depend on --steps: a region of K designs is K // 16 full batches and one
     partial batch (issued first: the batch with the least work reaches its sweep first), never a design more."""
     b = _bench()
     sch = b.schedule
-    assert (b.SLOTS, b.BSZ) == (4, 16)
+    assert (b.SLOTS, b.BSZ) == (8, 16)
     for k in range(1, 300):
         s = sch(k)
         assert sum(s) == k and all(x == 16 for x in s[1:]) and 1 <= s[0] <= 16
