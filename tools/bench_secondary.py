@@ -260,11 +260,15 @@ def config3_hrir_sets(n_batches=3, per_batch=16, rounds=6):
         b.synchronize()
     shared = all(b.shares_geometry() for _, b in units)
     t0 = time.perf_counter()
+    waves = os.environ.get("EMAGLS_BENCH_WAVES", "1") != "0"   # all batches started together and collected together (bench.py, run_designs)
     for r in range(rounds):
         for plans, b in units:
-            if r:
+            if r and not waves:
                 b.synchronize()
             b.execute()
+        if waves:
+            for plans, b in units:
+                b.synchronize()
     for plans, b in units:
         b.synchronize()
     dt = time.perf_counter() - t0
@@ -324,11 +328,15 @@ def config2_hrir_sets(n_batches=3, per_batch=16, rounds=6, share=True, diffuse=F
         b.synchronize()
     shared = all(b.shares_geometry() for _, b in units)
     t0 = time.perf_counter()
+    waves = os.environ.get("EMAGLS_BENCH_WAVES", "1") != "0"   # all batches started together and collected together (bench.py, run_designs)
     for r in range(rounds):
         for plans, b in units:
-            if r:
+            if r and not waves:
                 b.synchronize()
             b.execute()
+        if waves:
+            for plans, b in units:
+                b.synchronize()
     for plans, b in units:
         b.synchronize()
     dt = time.perf_counter() - t0
