@@ -609,7 +609,7 @@ def main():
                                    "48 kHz; one filter set per step, inputs resident in HBM",
                        "dirs": int(D), "taps": 512, "sim_order": info.sim_order, "bins": info.num_pos_freqs - 1,
                        "k_cut": info.k_cut, "designs_resident_per_gpu": nslots * Bsz, "designs_per_batch": Bsz,
-                       "batches_in_flight": nslots, "streams_per_batch": args.fork, "timed_schedule": "batches of %s designs" % schedule(K, Bsz),
+                       "batches_in_flight": nslots, "issue_order": ("waves: up to %d batches start together and are collected together" % nslots) if os.environ.get("EMAGLS_BENCH_WAVES", "1") != "0" else "sliding window", "streams_per_batch": args.fork, "timed_schedule": "batches of %s designs" % schedule(K, Bsz),
                        "setup": "each resident batch executed 3x (eager, hipGraph capture, replay) before the warm-up",
                        "parallelism": "independent jobs per GPU, one RCCL gather"},
             "roofline": roof,
