@@ -495,7 +495,7 @@ def main():
         D, Cc = inputs[4].shape[1], info.num_channels
         nbins_swept = info.num_pos_freqs - max(info.k_cut - 1, 1)
         nOrd = info.sim_order + 1
-        synth = info.sweep_form == 2
+        synth = info.sweep_form in (2, 3)
         Mm = 32   # microphones of the em32: the channels of the synthesising sweep's chain
         # algorithmic bytes of one swept bin (both ears).  Materialised operands: the bin's pwGrid (D x C complex), its C x C
         # matrix M_k, |H| of both ears, W(k-1) in and W(k) out.  Synthesising sweep: no pwGrid -- Mt_k (32 x 32), |H|, u(k) out.

@@ -42,6 +42,7 @@ SYMBOLS = {
     "emagls_cache_clear": (C.c_int, []),
     "emagls_fp64_peak_tflops": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "emagls_fp64_peak_tflops_ex": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "emagls_self_test": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "emagls_sh_basis": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "emagls_sh_basis_device": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "emagls_modal_bn": (C.c_int, [C.c_int, c_i64, C.c_void_p, C.c_void_p]),

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libemagls.so")
-SOURCES = ["sh_basis.hip", "modal.hip", "fft.hip", "gram_chol.hip", "factor.hip", "gramroute.hip", "sweep.hip", "sweep_persist.hip", "sweep_synth.hip", "dspace.hip", "atf.hip", "decode.hip", "render.hip", "render_api.hip", "emash.hip", "wide.hip", "wide_array.hip", "microbench.hip",
+SOURCES = ["sh_basis.hip", "modal.hip", "fft.hip", "gram_chol.hip", "factor.hip", "gramroute.hip", "sweep.hip", "sweep_persist.hip", "sweep_synth.hip", "sweep_reg.hip", "dspace.hip", "atf.hip", "decode.hip", "render.hip", "render_api.hip", "emash.hip", "wide.hip", "wide_array.hip", "microbench.hip",
            "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",

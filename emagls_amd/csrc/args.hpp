@@ -108,6 +108,8 @@ struct HalfSweepMulti {
     int n;
     HalfSweepArgs a[SWEEP_MULTI_MAX];
 };
+// designs per launch of the register-resident sweep (sweep_reg.hip): its argument blocks lie in device memory
+constexpr int REG_SWEEP_MAX = 40;
 
 
 }  // namespace emagls

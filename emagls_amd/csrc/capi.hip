@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -115,6 +116,10 @@ struct emagls_plan {
     // (persistent sweep, no swept bin on the Householder route) -- plan_update_synth
     bool synth_want = false, synth = false;
     int synth_units = 0;          // antipodal microphone pairs + single microphones (set with the microphone grid)
+    // the register-resident form of the synthesising sweep (sweep_reg.hip) took the last sweep of this plan (decided per launch:
+    // reg_sweep_wanted); its argument block lies in device memory ("sweep_args"; the host copy tells when it has to be stored again)
+    bool reg_sweep = false;
+    std::vector<char> sweep_args_last;
     bool synth_block = false;     // a batch whose designs do not all qualify keeps every one of them on the materialised operands
     const emagls_plan* geo_from = nullptr;   // set while a geometry-sharing batch runs this plan's stages on plan 0's geometry
     emagls_batch* owner = nullptr;  // the batch this plan currently belongs to (cleared by either destructor)
@@ -253,6 +258,8 @@ struct emagls_batch {
     hipGraphExec_t graph2_exec = nullptr;
     int eager_runs = 0;
     bool use_graph = true;
+    void* sweep_args_dev = nullptr;            // argument blocks of the register-resident sweep, one per plan (sweep_reg.hip)
+    std::vector<char> sweep_args_last;
     std::vector<hipEvent_t> events;
     size_t used = 0;
     hipEvent_t next_event() {
@@ -283,6 +290,7 @@ struct emagls_batch {
         if (stream && own_stream) emagls::pool_stream_give(stream);
         for (int i = 0; i < 3; ++i) if (side[i] && !(i == 0 && side0_external)) { hipStreamSynchronize(side[i]); emagls::pool_stream_give(side[i]); }
         if (cmp_flag) hipFree(cmp_flag);
+        if (sweep_args_dev) hipFree(sweep_args_dev);
         for (auto* p : plans) if (p) { p->sync_stream = nullptr; p->owner = nullptr; }
     }
 };
@@ -752,7 +760,9 @@ void plan_setup(emagls_plan& p) {
             p.alloc("Mw", sizeof(cplx) * ((size_t)p.P * p.C * p.C + 1024));
             p.alloc("cond_ok", sizeof(double) * (size_t)p.P);
         }
-        p.alloc("ll", persist_sweep_ll_bytes((int)Dh, p.synth_want ? std::max(p.C, (int)d.nmics) : p.C));
+        p.alloc("ll", std::max(persist_sweep_ll_bytes((int)Dh, p.synth_want ? std::max(p.C, (int)d.nmics) : p.C),
+                               p.synth_want && reg_sweep_nwg((int)Dh) <= 64 ? reg_sweep_ll_bytes((int)Dh, (int)d.nmics) : (size_t)0));
+        if (p.synth_want) p.alloc("sweep_args", sizeof(HalfSweepArgs));
         p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(p.nWG, p.nWG_dense) * 2 * p.C);
         p.out_rows = d.len;
     }
@@ -1317,41 +1327,85 @@ HalfSweepArgs emagls_half_args(emagls_plan& p) {
 }
 
 // A persistent sweep needs all of its workgroups resident.  Two sweeps launched from different streams could each get a
-// part of the CUs and wait for the rest forever (the kernels would give up after their spin limit and report an
-// error), so all persistent sweeps on a device are chained through one event: a sweep is only launched behind the
-// previous one.  The sweep is therefore never part of a captured graph (plans and batches capture the stages before it).
-// The chain state is per device and guarded by a mutex: plans of different host threads may sweep on the same GPU.
-struct SweepChain {
-    struct State { hipEvent_t ev = nullptr; bool recorded = false; };
+// part of the CUs and wait for the rest forever (the kernels would give up after their time-out and report an error), so the
+// sweeps of a device pass through one gate that counts workgroup slots per XCD: a sweep is launched behind as many of the
+// earlier ones (oldest first, by their completion events) as it takes for everything that may still be running next to it to
+// fit.  The register-resident form (sweep_reg.hip) takes ceil(n / 8) x nWG of the 96 slots of its kind an XCD has (3 workgroups
+// per CU), so several of its launches run side by side; the slab forms (sweep_persist.hip, sweep_synth.hip) fill every CU's LDS
+// and take the whole gate.  The sweep is therefore never part of a captured graph (plans and batches capture the stages before
+// it).  The gate's state is per device and guarded by a mutex: plans of different host threads may sweep on the same GPU.
+struct SweepGate {
+    struct Entry { hipEvent_t ev; int slots; };
+    struct State { std::deque<Entry> inflight; std::vector<hipEvent_t> pool; int capacity = 0; };
     static std::mutex& mutex() { static std::mutex m; return m; }
     static State& state() {   // (call with the mutex held)
         static std::map<int, State> per_device;
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
         State& st = per_device[dev];
-        if (!st.ev) HIP_CHECK(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+        if (st.capacity == 0) st.capacity = std::max(1, reg_sweep_slots_per_xcd());
         return st;
     }
     std::unique_lock<std::mutex> lock;
     hipStream_t st;
-    explicit SweepChain(hipStream_t s) : lock(mutex()), st(s) {
-        State& c = state();
-        if (c.recorded) HIP_CHECK(hipStreamWaitEvent(st, c.ev, 0));
+    int slots;
+    // slots_per_xcd <= 0: the whole device
+    SweepGate(hipStream_t s, int slots_per_xcd) : lock(mutex()), st(s), slots(0) {
+        State& g = state();
+        slots = slots_per_xcd <= 0 ? g.capacity : std::min(slots_per_xcd, g.capacity);
+        static const bool serial = [] { const char* e = getenv("EMAGLS_SWEEP_SERIAL"); return e && e[0] == '1'; }();
+        if (serial) slots = g.capacity;
+        while (!g.inflight.empty() && hipEventQuery(g.inflight.front().ev) == hipSuccess) {   // finished: no longer holds slots
+            g.pool.push_back(g.inflight.front().ev);
+            g.inflight.pop_front();
+        }
+        (void)hipGetLastError();   // (hipErrorNotReady of the query is not an error)
+        int held = 0;
+        for (const Entry& e : g.inflight) held += e.slots;
+        while (!g.inflight.empty() && held + slots > g.capacity) {
+            HIP_CHECK(hipStreamWaitEvent(st, g.inflight.front().ev, 0));
+            held -= g.inflight.front().slots;
+            g.pool.push_back(g.inflight.front().ev);   // (a wait already enqueued keeps the state the event had when it was enqueued)
+            g.inflight.pop_front();
+        }
     }
-    ~SweepChain() {   // (the lock is held from the wait to the record: no other sweep can slip in between)
+    ~SweepGate() {   // (the lock is held from the waits to the record: no other sweep can slip in between)
         try {
-            State& c = state();
-            const hipError_t e = hipEventRecord(c.ev, st);
-            if (e == hipSuccess) c.recorded = true;
+            State& g = state();
+            hipEvent_t ev = nullptr;
+            if (!g.pool.empty()) { ev = g.pool.back(); g.pool.pop_back(); }
+            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+            const hipError_t e = ev ? hipEventRecord(ev, st) : hipErrorUnknown;
+            if (e == hipSuccess) g.inflight.push_back(Entry{ev, slots});
             else {   // (e.g. the stream belongs to another device than the calling thread's current one: the next sweep would not
                      // be ordered behind this one -- never silently)
                 (void)hipGetLastError();
-                fprintf(stderr, "emagls: the sweep chain event could not be recorded (%s): persistent sweeps are no longer serialised\n",
+                fprintf(stderr, "emagls: the sweep gate's event could not be recorded (%s): persistent sweeps are no longer ordered\n",
                         hipGetErrorString(e));
             }
         } catch (...) {}
     }
 };
+
+// EMAGLS_SWEEP_REG=0: the synthesising sweep keeps its slab form (sweep_synth.hip) for every design (read at every launch)
+static bool reg_sweep_enabled() { const char* e = getenv("EMAGLS_SWEEP_REG"); return !(e && e[0] == '0'); }
+// does the register-resident form serve these `n` designs (all synthesising, of one shape) in one launch?
+static bool reg_sweep_wanted(emagls_plan* const* plans, int n) {
+    if (!reg_sweep_enabled() || n < 1) return false;
+    const emagls_plan& q = *plans[0];
+    for (int j = 0; j < n; ++j) {
+        const emagls_plan& p = *plans[j];
+        if (!p.synth || p.synth_units < 1 || p.synth_units > reg_sweep_max_units() || p.D != q.D || !p.has("sweep_args")) return false;
+    }
+    return reg_sweep_fits((int)q.D, (int)q.d.nmics, q.synth_units, q.simOrder + 1, n);
+}
+// the argument blocks of a launch in device memory (stored again only when one of them changed)
+static void reg_args_upload(const HalfSweepArgs* host, int n, void* dev, std::vector<char>& last, hipStream_t st) {
+    const size_t bytes = sizeof(HalfSweepArgs) * (size_t)n;
+    if (last.size() == bytes && memcmp(last.data(), host, bytes) == 0) return;
+    store_sweep_args(host, n, static_cast<HalfSweepArgs*>(dev), st);
+    last.assign(reinterpret_cast<const char*>(host), reinterpret_cast<const char*>(host) + bytes);
+}
 
 void emagls_run_sweep(emagls_plan& p) {
     hipStream_t s0 = p.stream;
@@ -1361,10 +1415,14 @@ void emagls_run_sweep(emagls_plan& p) {
     m.a[0] = emagls_half_args(p);
     p.sweep_launches = 0;
     if (k0 < p.P && p.sweep_persist) {
-        SweepChain chain(s0);
+        emagls_plan* self = &p;
+        p.reg_sweep = reg_sweep_wanted(&self, 1);
+        SweepGate gate(s0, p.reg_sweep ? reg_sweep_nwg((int)p.D) : 0);
         launch_zero(p.get("ll"), p.bufs["ll"].bytes, s0);
+        if (p.reg_sweep) reg_args_upload(&m.a[0], 1, p.get("sweep_args"), p.sweep_args_last, s0);
         if (p.prof_level >= 2) record_sweep_event(p, 0);
-        if (p.synth) launch_sweep_synth(m, s0); else launch_sweep_persist(m, s0);
+        if (p.reg_sweep) launch_sweep_reg(p.get<HalfSweepArgs>("sweep_args"), m.a[0], 1, s0);
+        else if (p.synth) launch_sweep_synth(m, s0); else launch_sweep_persist(m, s0);
         if (p.prof_level >= 2) record_sweep_event(p, 1);
         p.sweep_launches = 1;
     } else if (k0 < p.P) {
@@ -1776,15 +1834,21 @@ void plan_pre_stage(emagls_plan& p) {
     else emagls_pre_sweep(p);
 }
 void batch_sweep_stage(emagls_batch& b) {
-    HalfSweepMulti h{};
-    h.n = (int)b.plans.size();
-    for (int j = 0; j < h.n; ++j) h.a[j] = emagls_half_args(*b.plans[j]);
+    const int nb = (int)b.plans.size();
+    std::vector<HalfSweepArgs> ha((size_t)nb);
+    for (int j = 0; j < nb; ++j) ha[j] = emagls_half_args(*b.plans[j]);
     if (b.atf_share || b.geo_share)   // one ATF side / one geometry for every subject
-        for (int j = 1; j < h.n; ++j) {
-            h.a[j].G = h.a[0].G; h.a[j].Yri = h.a[0].Yri; h.a[j].Mw = h.a[0].Mw; h.a[j].cond_ok = h.a[0].cond_ok;
-            h.a[j].bsc = h.a[0].bsc; h.a[j].smap = h.a[0].smap;   // (synthesising sweep: plan 0's scaled modal terms and Mt; the grids are the same by the sharing check)
-            h.a[j].skip_flag = h.a[0].skip_flag;   // (MagLS: plan 0 judged the basis for everybody)
+        for (int j = 1; j < nb; ++j) {
+            ha[j].G = ha[0].G; ha[j].Yri = ha[0].Yri; ha[j].Mw = ha[0].Mw; ha[j].cond_ok = ha[0].cond_ok;
+            ha[j].bsc = ha[0].bsc; ha[j].smap = ha[0].smap;   // (synthesising sweep: plan 0's scaled modal terms and Mt; the grids are the same by the sharing check)
+            ha[j].skip_flag = ha[0].skip_flag;   // (MagLS: plan 0 judged the basis for everybody)
         }
+    const bool reg = b.plans[0]->sweep_persist && reg_sweep_wanted(b.plans.data(), nb);
+    for (auto* q : b.plans) q->reg_sweep = reg;
+    if (!reg && nb > SWEEP_MULTI_MAX) throw Error(EMAGLS_ERR_UNSUPPORTED, "internal: more than 16 designs in a batch need the register-resident sweep");
+    HalfSweepMulti h{};
+    h.n = std::min(nb, SWEEP_MULTI_MAX);
+    for (int j = 0; j < h.n; ++j) h.a[j] = ha[j];
     emagls_plan& q0 = *b.plans[0];
     const int kk0 = std::max(q0.kcut0, 1);
     if (kk0 >= q0.P) return;
@@ -1795,10 +1859,16 @@ void batch_sweep_stage(emagls_batch& b) {
         // queues that held each other's waits, stalled runs for seconds (28-880 sets/s): rejected)
         hipStream_t ss = b.stream;
         {
-            SweepChain chain(ss);
-            for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, ss);
+            SweepGate gate(ss, reg ? reg_sweep_nwg((int)q0.D) * (int)ceil_div(nb, 8) : 0);
+            if (b.lanes) { BatchScope sc(nb, b.stride); launch_zero(q0.get("ll"), q0.bufs["ll"].bytes, ss); }   // (one launch for every lane)
+            else for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, ss);
+            if (reg) {
+                if (!b.sweep_args_dev) HIP_CHECK(hipMalloc(&b.sweep_args_dev, sizeof(HalfSweepArgs) * (size_t)REG_SWEEP_MAX));
+                reg_args_upload(ha.data(), nb, b.sweep_args_dev, b.sweep_args_last, ss);
+            }
             if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[0], ss));
-            if (q0.synth) launch_sweep_synth(h, ss); else launch_sweep_persist(h, ss);
+            if (reg) launch_sweep_reg(static_cast<const HalfSweepArgs*>(b.sweep_args_dev), ha[0], nb, ss);
+            else if (q0.synth) launch_sweep_synth(h, ss); else launch_sweep_persist(h, ss);
             if (b.prof_level >= 1) HIP_CHECK(hipEventRecord(b.sweep_ev[1], ss));
         }
         if (ss != b.stream) b.depend(b.stream, ss);
@@ -2814,6 +2884,13 @@ int emagls_fp64_peak_tflops(int which, double* tflops) {
     });
 }
 
+int emagls_self_test(int which, double* max_err) {
+    return guarded([&] {
+        if (!max_err || which != 0) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        *max_err = reg_reduce_selftest();
+    });
+}
+
 int emagls_fp64_peak_tflops_ex(int which, int burst, double* tflops, double* shader_mhz) {
     return guarded([&] {
         if (!tflops || which < 0 || which > 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
@@ -3025,7 +3102,13 @@ int emagls_plan_get_info(emagls_plan* p, emagls_plan_info* info) {
         info->device_bytes = p->total_bytes;
         info->gram_from = p->gram_from; info->hh_end = p->hh_end; info->hh_orders = p->n_h + 1; info->g_first = p->g0;
         info->sim_order_own = array_kind(p->d.kind) ? p->simOrderOwn : p->simOrder;
-        info->sweep_form = p->d.kind == EMAGLS_KIND_LS ? 0 : (p->synth ? 2 : (p->sweep_persist ? 1 : 0));
+        bool reg = false;   // the form the next sweep takes (decided per launch: a batch's for its members)
+        if (p->synth) {
+            bool whole = p->owner != nullptr;
+            if (whole) for (auto* q : p->owner->plans) whole = whole && q != nullptr;
+            reg = whole ? reg_sweep_wanted(p->owner->plans.data(), (int)p->owner->plans.size()) : reg_sweep_wanted(&p, 1);
+        }
+        info->sweep_form = p->d.kind == EMAGLS_KIND_LS ? 0 : (p->synth ? (reg ? 3 : 2) : (p->sweep_persist ? 1 : 0));
         info->sweep_units = p->synth ? p->synth_units : 0;
         if (p->executed) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
@@ -3161,7 +3244,8 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         // (decided here, before any launch, from the runtime's occupancy of the kernel variant: persist_sweep_fits)
         const emagls_plan& f0 = *b->plans[0];
         const int64_t Dh0 = f0.d.kind == EMAGLS_KIND_FROM_ATF ? f0.Dm : f0.D;
-        const bool fits = f0.synth ? synth_sweep_fits((int)Dh0, (int)f0.d.nmics, f0.simOrder + 1, nplans) : persist_sweep_fits((int)Dh0, f0.C, nplans);
+        const bool fits = f0.synth ? (reg_sweep_wanted(b->plans.data(), nplans) || synth_sweep_fits((int)Dh0, (int)f0.d.nmics, f0.simOrder + 1, nplans))
+                                   : persist_sweep_fits((int)Dh0, f0.C, nplans);
         for (auto* p : b->plans) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
             if (!fits && p->sweep_persist) { p->sweep_persist = false; if (p->synth_want) { plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); } }

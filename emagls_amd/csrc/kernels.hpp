@@ -118,6 +118,18 @@ int synth_ls_chunks(int D);
 void launch_synth_ls(const void* Hc, int64_t ldH, int n_c, const void* bsc, int nord_pad, const double* dir_azi, const double* dir_zen, const double* mic_azi,
                      const double* mic_zen, const int* smap, int D, int M, int P, int kb_lo, int kb_hi, void* Upart, hipStream_t st, bool shared_geometry = false);
 void launch_sweep_synth(const HalfSweepMulti& m, hipStream_t st);
+// ---- sweep_reg.hip: the synthesising sweep with the operand in registers (a lane = a direction; no slab in LDS).  Units = antipodal
+// microphone pairs + single microphones (smap[32] + smap[33]); argument blocks in device memory (store_sweep_args)
+int reg_sweep_nwg(int D);
+int reg_sweep_max_units();
+bool reg_sweep_supported(int D, int nmics, int nunits, int nOrd);
+size_t reg_sweep_ll_bytes(int D, int nmics);
+int reg_sweep_capacity(int D);                 // designs one launch can keep resident on this device
+int reg_sweep_slots_per_xcd();                 // workgroups of the kernel one XCD holds
+bool reg_sweep_fits(int D, int nmics, int nunits, int nOrd, int ndesigns);
+void launch_sweep_reg(const HalfSweepArgs* args_dev, const HalfSweepArgs& a0, int n, hipStream_t st);
+double reg_reduce_selftest();
+void store_sweep_args(const HalfSweepArgs* host, int n, HalfSweepArgs* dev, hipStream_t st);
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
 void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, bool y_cplx, int D, int S, void* Pw, void* out,
                     int ldS, hipStream_t st);

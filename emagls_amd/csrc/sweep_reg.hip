@@ -1,0 +1,525 @@
+// Resident MagLS phase sweep, REGISTER-RESIDENT form: the waves that run the chain also evaluate the operand, and nothing of a
+// bin's slab of pwGrid_k.' ever lies in LDS.
+//
+// Reference (lib/getEMagLsFilters.m:87-103): per bin  p = W(k-1,:) pwGrid_k,  t = |H| p/|p|,  W(k,:) = t Y_reg_inv_k -- a
+// recurrence over the bins of one design.  sweep_synth.hip (round 4) evaluates pwGrid_k.' inside the launch from
+//     g_k[d][j] = sum_m bsc[k][m] T_m(x_dj),    x_dj = cos(angle between HRIR direction d and microphone j)
+// (Legendre addition theorem, Chebyshev basis, antipodal microphones as ONE unit: g(x) = E + O, g(-x) = E - O), but keeps the
+// slab of 96 directions x 32 microphones in LDS between producer waves and chain waves: 80 KB and 127 registers x 512 threads
+// per workgroup, two workgroups per CU, 29 CUs per design, four barriers and a two-hop exchange per bin; its vector ALUs
+// were busy 24 % of the time while the launch held 232 CUs (profiles/r04_pmc.md).
+//
+// Here a LANE owns ONE direction and all NU units of it: x_du (17 values for the em32) and the bin's E_u, O_u (68 values) live in
+// registers.  Per bin a wave
+//   * p phase:   p_e[d] = sum_u (wE_e[u] E_u + wO_e[u] O_u)  with  wE = w'[row A] + w'[row B], wO = w'[row A] - w'[row B]  read as
+//                LDS broadcasts -- no cross-lane step at all;
+//   * t = |H| p/|p| in the lane;
+//   * partial:   t_e conj(E_u), t_e conj(O_u) (136 values per lane) summed over the wave's 64 directions by a halving
+//                reduction: v_permlane32_swap / v_permlane16_swap exchange half of the values with the lane 32 / 16 away (one
+//                instruction per word, no select), two DPP steps inside the rows, an all-reduce inside the quads -- 9 values
+//                per lane are left, each total owned by one quad;
+//   * the four waves' partials are summed through 4.6 KB of LDS, turned into microphone rows (u = uE +- uO) and published as tagged
+//     granules; every workgroup of the design reads ALL partials of the bin (one hop: 11 workgroups x 2 KB at 2702 directions) and
+//     sums them in workgroup order;
+//   * the SAME waves then evaluate E, O of the next bin (1020 fused operations per lane at 20 orders) while the partials of the
+//     other workgroups arrive: the exchange latency hides behind arithmetic of the same wave instead of idling a CU.
+// 256 threads and 36 KB of LDS per workgroup, three barriers per bin, ceil(D / 256) workgroups per design (11 instead of 29), two
+// workgroups per CU: up to 40 designs of 2702 directions per launch (5 per XCD) instead of 16.
+//
+// Everything around the chain is sweep_synth.hip's: synth_coeff_kernel (bsc), synth_mt_kernel (Mt = Pm^T M Pm, the chain's
+// start value), synth_rows_kernel (the filters' rows from the stored totals), the row order of the microphones (smap).
+#include "kernels.hpp"
+#include "persist_common.hpp"
+#include "synth_common.hpp"
+
+#include <algorithm>
+
+namespace emagls {
+
+namespace {
+
+constexpr int RG_NT = 256;      // threads per workgroup
+constexpr int RG_DPW = 128;     // directions per workgroup: two lanes per direction
+constexpr int RG_MLD = 36;      // row stride of M~ in LDS (16 dwords mod 64)
+
+// ---- halving steps of the wave reduction.  Each takes two values per lane and returns ONE: half of the lanes get the sum of `a`
+// over the lane pair, the other half the sum of `b`.
+// lanes 0-31: a[l] + a[l + 32]; lanes 32-63: b[l - 32] + b[l]
+__device__ __forceinline__ double halve32(double a, double b) {
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);   // lanes 32-63 of the first <-> lanes 0-31 of the second
+    const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// even rows (of 16 lanes): a[l] + a[l + 16]; odd rows: b[l - 16] + b[l]
+__device__ __forceinline__ double halve16(double a, double b) {
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);   // odd rows of the first <-> even rows of the second
+    const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+constexpr int DPP_ROW_ROR8 = 0x128;   // lane l of a row reads lane (l + 8) % 16
+constexpr int DPP_ROW_SHL4 = 0x104;   // lane l reads lane l + 4
+constexpr int DPP_ROW_SHR4 = 0x114;   // lane l reads lane l - 4
+// lanes with bit 3 clear: a[l] + a[l ^ 8]; the others: b[l] + b[l ^ 8]
+__device__ __forceinline__ double halve8(double a, double b, bool keep_a) {
+    const double x = keep_a ? a : b, y = keep_a ? b : a;
+    return x + dpp_d<DPP_ROW_ROR8>(y);
+}
+// v[l] + v[l ^ 4]: the banks of four lanes with bit 2 clear read four lanes up, the others four lanes down
+__device__ __forceinline__ double add_xor4(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int plo = __builtin_amdgcn_update_dpp(0, lo, DPP_ROW_SHL4, 0xf, 0x5, false);
+    int phi = __builtin_amdgcn_update_dpp(0, hi, DPP_ROW_SHL4, 0xf, 0x5, false);
+    plo = __builtin_amdgcn_update_dpp(plo, lo, DPP_ROW_SHR4, 0xf, 0xA, false);
+    phi = __builtin_amdgcn_update_dpp(phi, hi, DPP_ROW_SHR4, 0xf, 0xA, false);
+    return v + __hiloint2double(phi, plo);
+}
+
+// E_u, O_u of GS unit slots accumulated in place (synth_group's schedule: two terms per pass, the coefficients of the next pass
+// requested before this pass's arithmetic); xcol: the lane's column of 2 cos values, one row of 256 per slot
+template <int U0, int GS, int NUL>
+__device__ __forceinline__ void synth_units(const double* xcol, cplx (&E)[NUL], cplx (&O)[NUL], const cplx* bs, int nord_pad) {
+    double x2[GS], pa[GS], pb[GS];
+#pragma unroll
+    for (int i = 0; i < GS; ++i) x2[i] = xcol[(U0 + i) * 256];
+#pragma unroll
+    for (int i = 0; i < GS; ++i) { pa[i] = 1.0; pb[i] = 0.5 * x2[i]; E[U0 + i] = mk(0.0, 0.0); O[U0 + i] = mk(0.0, 0.0); }
+    const unsigned bs0 = lds_addr(bs);
+    d2_t b0, b1, c0, c1;
+    auto request = [&](int n, d2_t& q0, d2_t& q1) __attribute__((always_inline)) {
+        const int nn = n < nord_pad ? n : nord_pad - 2;   // (the last pass re-reads its own coefficients)
+        lds_read16_async(q0, bs0 + 16 * nn, pa[0]); lds_read16_async(q1, bs0 + 16 * nn + 16, pa[0]);
+    };
+    auto pass = [&](const d2_t& q0, const d2_t& q1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+            E[U0 + i].x = fma(q0.x, pa[i], E[U0 + i].x); E[U0 + i].y = fma(q0.y, pa[i], E[U0 + i].y);
+            O[U0 + i].x = fma(q1.x, pb[i], O[U0 + i].x); O[U0 + i].y = fma(q1.y, pb[i], O[U0 + i].y);
+            pa[i] = fma(x2[i], pb[i], -pa[i]);          // T_{m+2}
+            pb[i] = fma(x2[i], pa[i], -pb[i]);          // T_{m+3}
+        }
+    };
+    request(0, b0, b1);
+    lds_wait2(b0, b1, pa[0]);
+    for (int n = 0; n < nord_pad; n += 4) {
+        request(n + 2, c0, c1);
+        pass(b0, b1);
+        lds_wait2(c0, c1, pb[GS - 1]);
+        if (n + 2 >= nord_pad) break;
+        request(n + 4, b0, b1);
+        pass(c0, c1);
+        lds_wait2(b0, b1, pb[GS - 1]);
+    }
+}
+
+// Index of a wave's partial value: [unit][E / O][ear][re / im]
+__host__ __device__ constexpr int rg_vidx(int u, int eo, int e, int ri) { return ((u * 2 + eo) * 2 + e) * 2 + ri; }
+
+// (a value the compiler must recompute from here on in every iteration: thread-derived indices and addresses of the loop's sections
+// otherwise stay in registers for the whole loop next to the operand)
+__device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// pointers that arrive through the argument block in memory: the compiler cannot see that they are global and would emit flat_*
+// accesses (which count on the LDS counter as well)
+#define RG_GLOBAL(T, p) ((T __attribute__((address_space(1)))*)(p))
+typedef const double __attribute__((address_space(1)))* gcd_t;
+typedef const cplx __attribute__((address_space(1)))* gcc_t;
+__device__ __forceinline__ cplx ldg(gcc_t p) { return mk(p->x, p->y); }
+
+constexpr int RG_NEX = 4 * PS_CMAX;   // doubles a workgroup publishes per bin: [ear][row (32, zero beyond the microphones)][re / im]
+
+// NUL: unit slots per lane (a direction's units are split between the two lanes of a pair: 2 NUL >= units)
+template <int NUL>
+__global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs* __restrict__ args, int n, int nWG) {
+    constexpr int NU2 = 2 * NUL;            // unit slots of a direction
+    constexpr int NVP = 8 * NU2;            // values of a wave's partial
+    constexpr int GA = (NUL + 1) / 2, GB = NUL - GA;   // slot groups of the synthesis (9: 5, 4)
+    static_assert(GB >= 1, "slot groups");
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* ring = reinterpret_cast<cplx*>(dyn);                       // [2][SY_NORD]  Chebyshev coefficients of two bins
+    cplx* ms = ring + 2 * SY_NORD;                                   // [32][MLD]     M~_{kb-1}
+    cplx* WE = ms + PS_CMAX * RG_MLD;                                // [2][NU2]      w'[row A] + w'[row B]
+    cplx* WO = WE + 2 * NU2;                                         // [2][NU2]      w'[row A] - w'[row B]
+    double* vt = reinterpret_cast<double*>(WO + 2 * NU2);            // [2][32][2]    totals of the previous bin, microphone rows
+    double* wpart = vt + RG_NEX;                                     // [4][NVP]      the waves' partials
+    double* xs = wpart + 4 * NVP;                                    // [NUL][256]    2 cos(direction, unit): a lane reads its own column
+    __shared__ int s_abort, s_local;
+
+    // block -> (XCD, slot) -> (design, member): design j lives on XCD j % 8, the (j / 8)-th design there
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int sub = rest / nWG, member = rest - sub * nWG;
+    const int design = xcd + 8 * sub;
+    if (design >= n) return;
+    const HalfSweepArgs& a = args[design];
+    const int tid = threadIdx.x;
+    const int C = a.C, P = a.P, D = a.D, kfirst = a.kfirst, kabs0 = a.kabs0;   // C: microphones (the chain's channels)
+    const int64_t ldH = a.ldH;
+    const int nord_pad = a.nord_pad;
+    const gcd_t Habs = RG_GLOBAL(const double, a.Habs);
+    const gcc_t Mw = RG_GLOBAL(const cplx, a.Mw);
+    const gcc_t bsc = RG_GLOBAL(const cplx, a.bsc);
+    const gcd_t Winit = RG_GLOBAL(const double, a.Winit);
+    cplx __attribute__((address_space(1)))* const Uout = RG_GLOBAL(cplx, a.U);
+    long long* const timing = a.timing;
+    int* const abort_flag = a.abort_flag;
+    const long long wait_ticks = a.wait_ticks;
+    const int* smap = a.smap;
+    const int npr = smap[32], nsg = smap[33], nun = npr + nsg;
+    u64* const part_ll = a.ll;                                       // [2][nWG][RG_NEX][2]
+    u64* const xcc_ll = a.ll + (size_t)2 * nWG * RG_NEX * 2;         // [nWG]
+    if (tid == 0) { s_abort = 0; s_local = 0; }
+    const int d0 = member * RG_DPW;
+
+    // ---- twice the cosine of the angle between the lane's direction and the (first) microphone of each of its units, kept in LDS (a
+    // lane reads back only its own column, a few values at a time)
+    {
+        const size_t ncplx = (size_t)2 * SY_NORD + PS_CMAX * RG_MLD + 4 * NU2;
+        for (size_t i = tid; i < ncplx; i += RG_NT) ring[i] = mk(0, 0);
+        for (int i = tid; i < RG_NEX + 4 * NVP; i += RG_NT) vt[i] = 0.0;
+        const int dgi = d0 + (tid >> 1) < D ? d0 + (tid >> 1) : D - 1;
+        double sd, cd;
+        sincos(a.dir_zen[dgi], &sd, &cd);
+        const double daz = a.dir_azi[dgi];
+#pragma unroll 1
+        for (int i = 0; i < NUL; ++i) {
+            const int u = (tid & 1) * NUL + i;
+            double v = 0.0;
+            if (u < nun) {
+                const int jm = smap[u < npr ? 2 * u : 2 * npr + (u - npr)];
+                double sm, cm;
+                sincos(a.mic_zen ? a.mic_zen[jm] : 1.5707963267948966, &sm, &cm);
+                v = fma(sd * sm, cos(daz - a.mic_azi[jm]), cd * cm);
+                v = 2.0 * fmin(1.0, fmax(-1.0, v));   // (2x: the factor of the Chebyshev recurrence)
+            }
+            xs[i * RG_NT + tid] = v;
+        }
+    }
+    __syncthreads();   // LDS is initialised
+
+    // ---- per-bin operands from memory
+    if (tid < nord_pad) {   // (lanes of wave 0)
+        ring[(kfirst & 1) * SY_NORD + tid] = ldg(bsc + (int64_t)kfirst * nord_pad + tid);
+        const int k1 = kfirst + 1 < P ? kfirst + 1 : P - 1;
+        ring[((kfirst + 1) & 1) * SY_NORD + tid] = ldg(bsc + (int64_t)k1 * nord_pad + tid);
+    }
+    // M~ (C x C in memory, bin kbm at a.Mw + kbm C C: the factor stage stores bin kb at slot kb - 1 and the pointer is shifted):
+    // thread = (row, four columns).  (Reads beyond a row's C columns stay inside the buffer -- it is padded by 1024 elements -- and
+    // are dropped when the row is staged.)
+    constexpr int NLM = 4;
+    cplx mReg[NLM];
+    auto fetch_m = [&](int kbm, int t) __attribute__((always_inline)) {
+        const int r = t >> 3, c0 = (t & 7) * 4;
+        const gcc_t M = Mw + (int64_t)kbm * C * C + r * C + c0;
+#pragma unroll
+        for (int i = 0; i < NLM; ++i) mReg[i] = ldg(M + i);
+    };
+    auto stage_m = [&](int t) __attribute__((always_inline)) {
+        const int r = t >> 3, c0 = (t & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < NLM; ++i) ms[r * RG_MLD + c0 + i] = (r < C && c0 + i < C) ? mReg[i] : mk(0, 0);
+    };
+    double hCur[2], hNext[2] = {0.0, 0.0};
+    auto fetch_h = [&](int kb, double (&h)[2], int t) __attribute__((always_inline)) {
+        const int kbg = (kb < P ? kb : P - 1) - kabs0;
+        const int dgi = d0 + (t >> 1) < D ? d0 + (t >> 1) : D - 1;
+        h[0] = (Habs + (int64_t)kbg * ldH)[dgi];
+        h[1] = (Habs + ((int64_t)(P - kabs0) + kbg) * ldH)[dgi];
+    };
+    fetch_h(kfirst, hCur, tid);
+    fetch_m(kfirst, tid);
+    stage_m(tid);
+
+    // ---- do all workgroups of this design share an XCD?  (then the granules stay in its L2)
+    if (tid < 64) {
+        const int lane = tid;
+        const unsigned xcc = read_xcc_id();
+        const unsigned tag0 = 0x58434300u;  // 'XCC'
+        if (lane == 0) ll_put(xcc_ll + member, ((u64)tag0 << 32) | xcc, false);
+        bool alive = true, same = true;
+        for (int base = 0; base < nWG && alive; base += 64) {
+            u64 w = 0;
+            alive = ll_wait([&] {
+                if (base + lane >= nWG) return true;
+                w = ll_load(xcc_ll + base + lane);
+                return ll_ok(w, tag0);
+            }, abort_flag, wait_ticks);
+            same = same && __builtin_amdgcn_ballot_w64(base + lane < nWG && (unsigned)w != xcc) == 0;
+        }
+        if (lane == 0) {
+            s_local = alive && same && a.force_global == 0;
+            if (!alive) s_abort = 1;
+            if (timing && member == 1) timing[15] = s_local;
+        }
+    }
+    __syncthreads();   // ring rows, M~, s_local
+    const bool local = s_local != 0;
+    if (s_abort) return;
+
+    // ---- operand of one bin: E_u, O_u of the lane's half of its direction's units
+    cplx E[NUL], O[NUL];
+#pragma unroll
+    for (int u = 0; u < NUL; ++u) { E[u] = mk(0, 0); O[u] = mk(0, 0); }
+
+#define RSTAMP(i) do { if (timing && member == 1 && tid == 0 && kb < P) timing[(int64_t)kb * 16 + (i)] = (long long)wall_clock64(); } while (0)
+    for (int kb = kfirst; kb <= P; ++kb) {
+        const bool first = (kb == kfirst);
+        const bool last = (kb == P);   // only the totals of bin P-1 are left to store
+        const bool nyq = (kb == P - 1);
+        // ---- the operand of this bin, while the other workgroups' partials of the previous bin arrive (the only place the
+        // synthesis is inlined: the loop is rotated so that it leads the iteration)
+        RSTAMP(7);
+        if (!last) {
+            const cplx* bs = ring + (kb & 1) * SY_NORD;
+            const double* xcol = xs + launder(tid);
+            synth_units<0, GA, NUL>(xcol, E, O, bs, nord_pad);
+            __builtin_amdgcn_sched_barrier(0);
+            synth_units<GA, GB, NUL>(xcol, E, O, bs, nord_pad);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ================= totals of bin kb-1: every workgroup's partial, summed in workgroup order =================
+        RSTAMP(0);
+        {
+            const int t = launder(tid);
+            if (t < RG_NEX) {   // (waves 0 and 1) thread = (ear, row, re / im)
+                if (first) {   // W(kfirst-1,:) Pm from the least-squares bins (synth_mt_kernel / synth_winit_kernel)
+                    vt[t] = Winit[t];
+                } else {
+                    const unsigned tag = (unsigned)(kb - 1);
+                    const u64* src = part_ll + ((size_t)((kb - 1) & 1) * nWG * RG_NEX + t) * 2;
+                    double sum = 0.0;
+                    const bool alive = ll_wait([&] {
+                        bool ok = true;
+                        double s = 0.0;
+                        for (int w = 0; w < nWG; ++w) {
+                            const u64 g0 = ll_load(src + (size_t)w * RG_NEX * 2), g1 = ll_load(src + (size_t)w * RG_NEX * 2 + 1);
+                            ok = ok && ll_ok(g0, tag) && ll_ok(g1, tag);
+                            s += ll_value(g0, g1);
+                        }
+                        sum = s;
+                        return ok;
+                    }, abort_flag, wait_ticks);
+                    vt[t] = sum;
+                    if (!alive && (t & 63) == 0) s_abort = 1;
+                }
+            }
+        }
+        RSTAMP(2);
+        __syncthreads();  // B1: vt is complete
+        if (s_abort) break;
+        // ---- w'(kb-1,:) = u_total conj(M~_{kb-1})  (the start value as it stands), as the p phase's unit weights; the totals themselves
+        // go to memory: the filters' rows are formed from them after the launch
+        {
+            const int t = launder(tid);
+            const int part = t & 3, pair = t >> 2, e = pair >> 5, c = pair & 31;
+            const cplx* vc = reinterpret_cast<const cplx*>(vt) + e * PS_CMAX;
+            cplx acc = mk(0, 0);
+            if (first) {
+                if (part == 0) acc = vc[c];
+            } else {
+#pragma unroll
+                for (int i = 0; i < PS_CMAX / 4; ++i)  // vt and ms are 0 beyond C
+                    cfma(acc, vc[part + 4 * i], conj(ms[(part + 4 * i) * RG_MLD + c]));
+            }
+            acc = group_sum<4>(acc);
+            const cplx other = shfl_xor_c(acc, 4);   // the row c ^ 1
+            if (part == 0 && c < C) {
+                if (c < 2 * npr) {
+                    if ((c & 1) == 0) { WE[e * NU2 + (c >> 1)] = acc + other; WO[e * NU2 + (c >> 1)] = acc - other; }
+                } else {
+                    WE[e * NU2 + npr + (c - 2 * npr)] = acc; WO[e * NU2 + npr + (c - 2 * npr)] = acc;
+                }
+                if (member == 0 && !first) {
+                    cplx __attribute__((address_space(1)))* dst = Uout + ((int64_t)e * P + (kb - 1)) * PS_CMAX + c;
+                    const cplx v = vc[c];
+                    dst->x = v.x; dst->y = v.y;
+                }
+            }
+        }
+        if (last) break;
+        __syncthreads();  // B2: the weights are complete; M~ may be replaced
+        RSTAMP(3);
+        fetch_m(kb, launder(tid));      // M~ of the next iteration: requested here, staged behind the p phase (which covers the round trip)
+        // ---- p = w'(kb-1,:) g^T (this lane's units, then the sum of the lane pair);  t = |H| p/|p|
+        cplx t0, t1;
+        {
+            const int t = launder(tid);
+            const cplx* we = WE + (t & 1) * NUL, *wo = WO + (t & 1) * NUL;
+            cplx p0 = mk(0, 0), p1 = mk(0, 0);
+#pragma unroll
+            for (int u = 0; u < NUL; ++u) {
+                const cplx we0 = we[u], wo0 = wo[u], we1 = we[NU2 + u], wo1 = wo[NU2 + u];
+                cfma(p0, we0, E[u]); cfma(p0, wo0, O[u]);
+                cfma(p1, we1, E[u]); cfma(p1, wo1, O[u]);
+            }
+            p0.x += dpp_d<DPP_XOR1>(p0.x); p0.y += dpp_d<DPP_XOR1>(p0.y);
+            p1.x += dpp_d<DPP_XOR1>(p1.x); p1.y += dpp_d<DPP_XOR1>(p1.y);
+            const bool dvalid = d0 + (t >> 1) < D;
+            t0 = dvalid ? unit_phase(hCur[0], p0, nyq) : mk(0, 0);
+            t1 = dvalid ? unit_phase(hCur[1], p1, nyq) : mk(0, 0);
+        }
+        stage_m(launder(tid));
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- this wave's partial  t conj(E_u), t conj(O_u)  summed over its 32 directions (the lanes of one parity)
+        {
+            const int lane = launder(tid) & 63;
+            const bool keep8 = (lane & 8) == 0;
+            // one unit slot (eight values: E / O, ear, re / im) at a time: three halving steps leave ONE register whose lane l holds
+            // the sum over eight lanes of value (l >> 3), the all-reduce over the lane bits 1 and 2 completes it
+            double r[NUL];
+#pragma unroll
+            for (int c = 0; c < NUL; ++c) {
+                // value j = 4 eo + 2 e + ri
+                const double v0 = fma(t0.x, E[c].x, t0.y * E[c].y), v1 = fma(t0.y, E[c].x, -(t0.x * E[c].y));
+                const double v2 = fma(t1.x, E[c].x, t1.y * E[c].y), v3 = fma(t1.y, E[c].x, -(t1.x * E[c].y));
+                const double v4 = fma(t0.x, O[c].x, t0.y * O[c].y), v5 = fma(t0.y, O[c].x, -(t0.x * O[c].y));
+                const double v6 = fma(t1.x, O[c].x, t1.y * O[c].y), v7 = fma(t1.y, O[c].x, -(t1.x * O[c].y));
+                const double a0 = halve32(v0, v4), a1 = halve32(v1, v5), a2 = halve32(v2, v6), a3 = halve32(v3, v7);   // lanes >= 32: O
+                const double b0 = halve16(a0, a2), b1 = halve16(a1, a3);                                                 // odd rows: ear 1
+                double v = halve8(b0, b1, keep8);                                                                       // bit 3: imaginary part
+                v += dpp_d<DPP_XOR2>(v);
+                v = add_xor4(v);
+                r[c] = v;
+                __builtin_amdgcn_sched_barrier(0);   // (one slot at a time: the scheduler otherwise starts them all)
+            }
+            if ((lane & 6) == 0) {
+                double* wp = wpart + (launder(tid) >> 6) * NVP + (lane & 1) * NUL * 8 + (lane >> 3);
+#pragma unroll
+                for (int c = 0; c < NUL; ++c) wp[8 * c] = r[c];
+            }
+        }
+        // (the operand registers are free now: what the next iterations need from memory is requested here)
+        {
+            const int t = launder(tid);
+            fetch_h(kb + 1, hNext, t);
+            if (t < nord_pad) ring[(kb & 1) * SY_NORD + t] = ldg(bsc + (int64_t)(kb + 2 < P ? kb + 2 : P - 1) * nord_pad + t);   // row kb + 2 (row kb was read at the top of this iteration, before B1)
+        }
+        __syncthreads();  // B3: the waves' partials, M~ and the ring row are in place
+        RSTAMP(4);
+        // ---- the workgroup's partial in microphone rows, published as granules
+        {
+            const int t = launder(tid);
+            if (t < RG_NEX) {
+                const int xe = t >> 6, xr = (t >> 1) & 31, xri = t & 1;
+                double v = 0.0;
+                if (xr < C) {
+                    const int xu = xr < 2 * npr ? (xr >> 1) : npr + (xr - 2 * npr);
+                    const bool xneg = xr < 2 * npr && (xr & 1);
+                    const double* wE = wpart + rg_vidx(xu, 0, xe, xri);
+                    const double sE = (wE[0] + wE[NVP]) + (wE[2 * NVP] + wE[3 * NVP]);
+                    const double sO = (wE[4] + wE[NVP + 4]) + (wE[2 * NVP + 4] + wE[3 * NVP + 4]);
+                    v = xneg ? sE - sO : sE + sO;
+                }
+                u64* dst = part_ll + (((size_t)(kb & 1) * nWG + member) * RG_NEX + t) * 2;
+                ll_store(dst, dst + 1, v, (unsigned)kb, local);
+            }
+        }
+        RSTAMP(5);
+        hCur[0] = hNext[0]; hCur[1] = hNext[1];
+    }
+#undef RSTAMP
+}
+
+// the wave reduction of the kernel above on its own: in [64 lanes][8 values] -> out [2 lane parities][8] (the sums over the 32 lanes of a parity)
+__global__ void __launch_bounds__(64) reg_reduce_selftest_kernel(const double* __restrict__ in, double* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const double* v = in + lane * 8;
+    const bool keep8 = (lane & 8) == 0;
+    const double a0 = halve32(v[0], v[4]), a1 = halve32(v[1], v[5]), a2 = halve32(v[2], v[6]), a3 = halve32(v[3], v[7]);
+    const double b0 = halve16(a0, a2), b1 = halve16(a1, a3);
+    double r = halve8(b0, b1, keep8);
+    r += dpp_d<DPP_XOR2>(r);
+    r = add_xor4(r);
+    if ((lane & 6) == 0) out[(lane & 1) * 8 + (lane >> 3)] = r;
+}
+
+// argument blocks into device memory, stream-ordered (no host buffer has to outlive the call)
+__global__ void __launch_bounds__(64) store_args_kernel(HalfSweepMulti m, HalfSweepArgs* dst) {
+    const int nw = (int)(sizeof(HalfSweepArgs) / 8);
+    for (int j = 0; j < m.n; ++j) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&m.a[j]);
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + j);
+        for (int i = threadIdx.x; i < nw; i += 64) d[i] = src[i];
+    }
+}
+static_assert(sizeof(HalfSweepArgs) % 8 == 0, "argument block in whole words");
+
+constexpr int RG_NUL = 9;   // unit slots per lane: designs of up to 18 units (the em32: 15 antipodal pairs + 2 single capsules)
+size_t reg_dyn_bytes(int nul) {
+    const size_t nu2 = 2 * (size_t)nul, nvp = 8 * nu2;
+    return sizeof(cplx) * ((size_t)2 * SY_NORD + PS_CMAX * RG_MLD + 4 * nu2) + sizeof(double) * (RG_NEX + 4 * nvp + (size_t)nul * RG_NT);
+}
+
+}  // namespace
+
+int reg_sweep_nwg(int D) { return (int)ceil_div(D, RG_DPW); }
+int reg_sweep_max_units() { return 2 * RG_NUL; }
+bool reg_sweep_supported(int D, int nmics, int nunits, int nOrd) {
+    return nmics >= 2 && nmics <= PS_CMAX && nunits >= 1 && nunits <= 2 * RG_NUL && reg_sweep_nwg(D) <= 64 && nOrd <= SY_NORD && D >= 1;
+}
+size_t reg_sweep_ll_bytes(int D, int nmics) {
+    const size_t nwg = (size_t)reg_sweep_nwg(D);
+    (void)nmics;
+    return sizeof(u64) * ((size_t)2 * nwg * RG_NEX * 2 + nwg + 64);
+}
+// workgroups of the register-resident sweep one CU holds (registers, LDS: the runtime's figure)
+static int reg_sweep_occupancy() {
+    int occ = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL>), RG_NT,
+                                                           reg_dyn_bytes(RG_NUL)));
+    return occ;
+}
+int reg_sweep_slots_per_xcd() { return reg_sweep_occupancy() * (sweep_cu_budget() / 8); }
+// designs ONE launch can hold resident: per XCD ceil(n / 8) designs of nWG workgroups each
+int reg_sweep_capacity(int D) {
+    const int k = reg_sweep_slots_per_xcd() / reg_sweep_nwg(D);
+    return std::min(REG_SWEEP_MAX, 8 * k);
+}
+bool reg_sweep_fits(int D, int nmics, int nunits, int nOrd, int ndesigns) {
+    if (!reg_sweep_supported(D, nmics, nunits, nOrd) || ndesigns < 1) return false;
+    return ndesigns <= reg_sweep_capacity(D);
+}
+
+// args: `n` argument blocks in device memory
+void launch_sweep_reg(const HalfSweepArgs* args_dev, const HalfSweepArgs& a0, int n, hipStream_t st) {
+    const int nWG = reg_sweep_nwg(a0.D);
+    if (n < 1 || n > REG_SWEEP_MAX) throw Error(2, "register-resident sweep: too many designs in one launch");
+    const unsigned nblocks = 8u * (unsigned)nWG * (unsigned)ceil_div(n, 8);
+    sweep_reg_kernel<RG_NUL><<<dim3(nblocks), RG_NT, reg_dyn_bytes(RG_NUL), st>>>(args_dev, n, nWG);
+    KERNEL_CHECK();
+}
+
+// max |device - host| of the wave reduction on pseudo-random values (debug entry emagls_self_test)
+double reg_reduce_selftest() {
+    double h_in[64 * 8], h_out[16], want[16] = {0};
+    unsigned long long x = 88172645463325252ull;
+    for (int i = 0; i < 64 * 8; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h_in[i] = (double)(x % 2000001ull) / 1000000.0 - 1.0; }
+    for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) want[(l & 1) * 8 + j] += h_in[l * 8 + j];
+    double *d_in = nullptr, *d_out = nullptr;
+    HIP_CHECK(hipMalloc(&d_in, sizeof h_in));
+    HIP_CHECK(hipMalloc(&d_out, sizeof h_out));
+    HIP_CHECK(hipMemcpy(d_in, h_in, sizeof h_in, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(d_out, 0, sizeof h_out));
+    reg_reduce_selftest_kernel<<<1, 64>>>(d_in, d_out);
+    KERNEL_CHECK();
+    HIP_CHECK(hipMemcpy(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipFree(d_in));
+    HIP_CHECK(hipFree(d_out));
+    double err = 0.0;
+    for (int i = 0; i < 16; ++i) err = std::max(err, std::fabs(h_out[i] - want[i]));
+    return err;
+}
+
+void store_sweep_args(const HalfSweepArgs* host, int n, HalfSweepArgs* dev, hipStream_t st) {
+    for (int first = 0; first < n; first += SWEEP_MULTI_MAX) {
+        HalfSweepMulti m{};
+        m.n = std::min(SWEEP_MULTI_MAX, n - first);
+        for (int j = 0; j < m.n; ++j) m.a[j] = host[first + j];
+        store_args_kernel<<<1, 64, 0, st>>>(m, dev + first);
+        KERNEL_CHECK();
+    }
+}
+
+}  // namespace emagls

@@ -71,6 +71,9 @@ int emagls_fp64_peak_tflops(int which, double* tflops);
  * state), burst == 0 the ~10 ms launches of the call above; shader_mhz (optional) receives the shader clock the timed loop ran
  * at (in-kernel cycle counter over the 100 MHz wall counter). */
 int emagls_fp64_peak_tflops_ex(int which, int burst, double* tflops, double* shader_mhz);
+/* Device-side self tests of building blocks that have no entry point of their own.  which = 0: the wave reduction of the
+ * register-resident sweep (permlane swaps and DPP steps against a plain sum; max_err: largest absolute difference). */
+int emagls_self_test(int which, double* max_err);
 
 /* ---- kernel-level entry points ------------------------------------------------------------- */
 
@@ -271,8 +274,10 @@ typedef struct emagls_plan_info {
     int sim_order_own;               /* the design's own simulation order (sim_order is the padded one with sim_order_pad) */
     /* form of the phase sweep the next execute takes: 0 one launch per bin, 1 one resident launch on operands G_k materialised
      * in HBM, 2 one resident launch that evaluates its operands itself from the angles between HRIR directions and microphones
-     * (array designs on the built-in SH basis; EMAGLS_SWEEP_SYNTH=0 selects form 1).  sweep_units: form 2, the polynomial
-     * evaluations per direction and bin -- antipodal microphone pairs count once (15 pairs + 2 single capsules on the em32). */
+     * (array designs on the built-in SH basis; EMAGLS_SWEEP_SYNTH=0 selects form 1), 3 the same with the operand of a bin held
+     * in registers by the waves that run the recurrence (up to 18 units; EMAGLS_SWEEP_REG=0 selects form 2; several such sweeps
+     * share the device).  sweep_units: forms 2 and 3, the polynomial evaluations per direction and bin -- antipodal microphone
+     * pairs count once (15 pairs + 2 single capsules on the em32). */
     int sweep_form, sweep_units;
 } emagls_plan_info;
 

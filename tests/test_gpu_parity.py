@@ -788,7 +788,7 @@ def test_batch_of_ema_in_ch_designs(thin):
         p.close()
 
 
-@pytest.mark.parametrize("mode", ["launch_per_bin", "persistent_write_through", "synthesising"])
+@pytest.mark.parametrize("mode", ["launch_per_bin", "persistent_write_through", "synthesising", "synthesising_slab"])
 def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
     """The phase sweep on materialised operands has three forms: the persistent launch with XCD-local granule stores (default
     when all workgroups of a design share an XCD), the same with write-through stores (any placement), and one launch per
@@ -820,14 +820,19 @@ def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
         monkeypatch.setenv("EMAGLS_SWEEP_PERSIST", "0")
     elif mode == "synthesising":
         monkeypatch.setenv("EMAGLS_SWEEP_SYNTH", "1")
+    elif mode == "synthesising_slab":   # sweep_synth.hip instead of sweep_reg.hip
+        monkeypatch.setenv("EMAGLS_SWEEP_SYNTH", "1")
+        monkeypatch.setenv("EMAGLS_SWEEP_REG", "0")
     else:
         monkeypatch.setenv("EMAGLS_PERSIST_GLOBAL", "1")
     (vL, vR), n_variant = run()
     assert (n_variant > 1) == (mode == "launch_per_bin")
     print(f"sweep variant {mode} vs default: rel = {max(rel(vL, dL), rel(vR, dR)):.3e}")
-    tol = 1e-6 if mode == "synthesising" else 1e-12
+    # (the synthesising forms are bounded at about 10x their measured distance from the materialised operands -- 5e-9
+    # ... 6e-8 over the suite, DESIGN.md section 3 -- not at the oracle tolerance)
+    tol = 5e-7 if mode.startswith("synthesising") else 1e-12
     assert rel(vL, dL) < tol and rel(vR, dR) < tol
-    if mode == "synthesising":
+    if mode.startswith("synthesising"):
         assert rel(vL, dL) > 0   # (it did take the other kernel)
 
 
@@ -862,7 +867,7 @@ def test_synthesising_sweep_on_other_arrays(grids, thin, monkeypatch, nmics, pai
     p.set_mic_grid(maz, mzn)
     i = p.info()
     want_units = {"em32": 17, "none": nmics, "some": nmics - 6}[paired]
-    assert i.sweep_form == 2 and i.sweep_units == want_units, (i.sweep_form, i.sweep_units)
+    assert i.sweep_form == (3 if want_units <= 18 else 2) and i.sweep_units == want_units, (i.sweep_form, i.sweep_units)
     p.close()
     for fn, extra in (("getEMagLs2Filters", ()), ("getEMagLsFilters", ())):
         if fn == "getEMagLsFilters" and nmics < (N + 1) ** 2:
@@ -900,7 +905,7 @@ def test_residency_is_decided_before_the_launch(grids, thin, monkeypatch):
     p = plan()
     p.execute()
     ref = p.get_filters()
-    assert p.info().sweep_form == 2 and p.info().num_sweep_launches == 1   # resident, operands evaluated in the launch
+    assert p.info().sweep_form == 3 and p.info().num_sweep_launches == 1   # resident, operands evaluated in the launch (in registers)
     p.close()
     # 901 directions = 15 workgroups per design on one XCD: 4 CUs per XCD cannot hold them
     monkeypatch.setenv("EMAGLS_CU_BUDGET", "32")
@@ -914,34 +919,39 @@ def test_residency_is_decided_before_the_launch(grids, thin, monkeypatch):
     p.close()
     print(f"one design without room for a resident sweep: launch per bin from the start, first execute {dt * 1e3:.1f} ms, "
           f"rel vs the resident form = {max(rel(out[0], ref[0]), rel(out[1], ref[1])):.3e}")
-    assert dt < 0.15 and rel(out[0], ref[0]) < 1e-6 and rel(out[1], ref[1]) < 1e-6
-    # 8 CUs per XCD: one design fits (two workgroups per CU), the 12 designs of a batch (two designs per XCD) do not
+    # (no wall-clock bound: the sweep form and the launch count already show that no time-out path was taken)
+    assert rel(out[0], ref[0]) < 1e-6 and rel(out[1], ref[1]) < 1e-6
+    # 8 CUs per XCD: one design fits; the 12 designs of a batch (two designs per XCD) fit in the register-resident form (8 workgroups
+    # per design, three per CU) and do not in the slab form (15 workgroups per design, two per CU)
     monkeypatch.setenv("EMAGLS_CU_BUDGET", "64")
-    plans = [plan(j) for j in range(12)]
-    singles = []
-    for q in plans:
-        assert q.info().sweep_form == 2
-        q.execute()
-        singles.append(q.get_filters())
     lib = L.load()
-    prev = ctypes.c_int(0)
-    L.check(lib.emagls_set_batch_max(16, ctypes.byref(prev)))
-    try:
-        b = Batch(plans)
-    finally:
-        L.check(lib.emagls_set_batch_max(prev.value, None))
-    assert plans[0].info().sweep_form == 0
-    t0 = time.perf_counter()
-    b.execute()
-    outs = b.get_filters()
-    dt = time.perf_counter() - t0
-    worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(outs, singles))
-    print(f"12-design batch without room for its resident sweep: launch per bin from the start, first execute {dt * 1e3:.1f} ms, "
-          f"worst rel vs the single designs = {worst:.3e}")
-    assert dt < 0.5 and worst < 1e-6
-    b.close()
-    for q in plans:
-        q.close()
+    for reg in ("0", "1"):
+        monkeypatch.setenv("EMAGLS_SWEEP_REG", reg)
+        plans = [plan(j) for j in range(12)]
+        singles = []
+        for q in plans:
+            assert q.info().sweep_form == (3 if reg == "1" else 2)
+            q.execute()
+            singles.append(q.get_filters())
+        prev = ctypes.c_int(0)
+        L.check(lib.emagls_set_batch_max(16, ctypes.byref(prev)))
+        try:
+            b = Batch(plans)
+        finally:
+            L.check(lib.emagls_set_batch_max(prev.value, None))
+        assert plans[0].info().sweep_form == (3 if reg == "1" else 0)
+        t0 = time.perf_counter()
+        b.execute()
+        outs = b.get_filters()
+        dt = time.perf_counter() - t0
+        assert (plans[0].info().num_sweep_launches > 1) == (reg == "0")
+        worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(outs, singles))
+        print(f"12-design batch on 64 CUs, EMAGLS_SWEEP_REG={reg}: sweep form {plans[0].info().sweep_form}, first execute {dt * 1e3:.1f} ms, "
+              f"worst rel vs the single designs = {worst:.3e}")
+        assert worst < 1e-6
+        b.close()
+        for q in plans:
+            q.close()
 
 
 def test_emagls2_filters_config4_shape(grids, hrirs):

@@ -259,3 +259,14 @@ def test_stage_factor_and_sweep(emagls_plan, grids):
                                 grids["mic_radius"], grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 128, "complex")
     assert rel(wL, oL) < 1e-6 and rel(wR, oR) < 1e-6, (rel(wL, oL), rel(wR, oR))
     print("stage times (ms):", p.stage_times())
+
+
+def test_wave_reduction_of_the_register_resident_sweep():
+    """sweep_reg.hip sums a wave's 32 directions per lane parity with v_permlane32_swap / v_permlane16_swap halving steps, a DPP
+    row rotation and two all-reduce steps inside the eight-lane groups: against a plain sum on the host."""
+    import ctypes
+    from emagls_amd import _lib as L
+    err = ctypes.c_double(-1.0)
+    L.check(L.load().emagls_self_test(0, ctypes.byref(err)))
+    print(f"wave reduction self test: max abs error = {err.value:.3e}")
+    assert 0.0 <= err.value < 1e-13

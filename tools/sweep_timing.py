@@ -38,6 +38,19 @@ def main():
     for j, p in [(0, plans[0]), (n - 1, plans[-1])][:min(n, 2)]:
         t = p.debug("sweep_timing", np.int64).reshape(P, 16).astype(np.float64) * 0.01   # microseconds
         kb = np.arange(k0 + 2, P - 2)
+        if info.sweep_form == 3:   # sweep_reg.hip: 7 iteration starts (operand synthesis), 0 poll starts, 2 totals in LDS, 3 B2 passed, 4 B3 passed, 5 published
+            rows = {
+                "bin period (stamp 7 -> next bin's stamp 7)": t[kb + 1, 7] - t[kb, 7],
+                "operand synthesis (7->0)": t[kb, 0] - t[kb, 7],
+                "wait for the other workgroups' partials + sum (0->2)": t[kb, 2] - t[kb, 0],
+                "B1 + M phase + B2 (2->3)": t[kb, 3] - t[kb, 2],
+                "p phase + partial + wave reduction + B3 (3->4)": t[kb, 4] - t[kb, 3],
+                "workgroup sum + publish (4->5)": t[kb, 5] - t[kb, 4],
+            }
+            print("design %d of %d (register-resident form): %d swept bins, sweep span %.1f us, one XCD: %s" % (j, n, P - k0, t[P - 1, 5] - t[k0, 7], bool(p.debug("sweep_timing", np.int64)[15])))
+            for name, v in rows.items():
+                print("  %-56s median %6.2f  mean %6.2f  p90 %6.2f us" % (name, np.median(v), v.mean(), np.percentile(v, 90)))
+            continue
         rows = {
             "bin period (stamp 0 -> next bin's stamp 0)": t[kb + 1, 0] - t[kb, 0],
             "comm start -> first poll answered (0->6)": t[kb, 6] - t[kb, 0],
