@@ -143,8 +143,8 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
     cplx* ms = ring + 2 * SY_NORD;                                   // [32][MLD]     M~_{kb-1}
     cplx* WE = ms + PS_CMAX * RG_MLD;                                // [2][NU2]      w'[row A] + w'[row B]
     cplx* WO = WE + 2 * NU2;                                         // [2][NU2]      w'[row A] - w'[row B]
-    double* vt = reinterpret_cast<double*>(WO + 2 * NU2);            // [2][32][2]    totals of the previous bin, microphone rows
-    double* wpart = vt + RG_NEX;                                     // [4][NVP]      the waves' partials
+    double* vt = reinterpret_cast<double*>(WO + 2 * NU2);            // [2][2][32][2] totals of the previous bin in microphone rows: the sums over the even and over the odd workgroups
+    double* wpart = vt + 2 * RG_NEX;                                 // [4][NVP]      the waves' partials
     double* xs = wpart + 4 * NVP;                                    // [NUL][256]    2 cos(direction, unit): a lane reads its own column
     __shared__ int s_abort, s_local;
 
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
     {
         const size_t ncplx = (size_t)2 * SY_NORD + PS_CMAX * RG_MLD + 4 * NU2;
         for (size_t i = tid; i < ncplx; i += RG_NT) ring[i] = mk(0, 0);
-        for (int i = tid; i < RG_NEX + 4 * NVP; i += RG_NT) vt[i] = 0.0;
+        for (int i = tid; i < 2 * RG_NEX + 4 * NVP; i += RG_NT) vt[i] = 0.0;
         const int dgi = d0 + (tid >> 1) < D ? d0 + (tid >> 1) : D - 1;
         double sd, cd;
         sincos(a.dir_zen[dgi], &sd, &cd);
@@ -282,28 +282,38 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
         // ================= totals of bin kb-1: every workgroup's partial, summed in workgroup order =================
         RSTAMP(0);
         {
+            // thread = (half of the workgroups, ear, row, re / im): the partials of the workgroups half, half + 2, ... of one double,
+            // requested six at a time (a loop over 22 sources with one request in flight took 3 us per bin)
             const int t = launder(tid);
-            if (t < RG_NEX) {   // (waves 0 and 1) thread = (ear, row, re / im)
-                if (first) {   // W(kfirst-1,:) Pm from the least-squares bins (synth_mt_kernel / synth_winit_kernel)
-                    vt[t] = Winit[t];
-                } else {
-                    const unsigned tag = (unsigned)(kb - 1);
-                    const u64* src = part_ll + ((size_t)((kb - 1) & 1) * nWG * RG_NEX + t) * 2;
-                    double sum = 0.0;
-                    const bool alive = ll_wait([&] {
-                        bool ok = true;
-                        double s = 0.0;
-                        for (int w = 0; w < nWG; ++w) {
-                            const u64 g0 = ll_load(src + (size_t)w * RG_NEX * 2), g1 = ll_load(src + (size_t)w * RG_NEX * 2 + 1);
-                            ok = ok && ll_ok(g0, tag) && ll_ok(g1, tag);
-                            s += ll_value(g0, g1);
+            const int j = t & (RG_NEX - 1), half = t >> 7;
+            if (first) {   // W(kfirst-1,:) Pm from the least-squares bins (synth_mt_kernel / synth_winit_kernel)
+                vt[t] = half == 0 ? Winit[j] : 0.0;
+            } else {
+                const unsigned tag = (unsigned)(kb - 1);
+                const u64* src = part_ll + ((size_t)((kb - 1) & 1) * nWG * RG_NEX + j) * 2;
+                double sum = 0.0;
+                const bool alive = ll_wait([&] {
+                    bool ok = true;
+                    double s = 0.0;
+                    for (int base = half; base < nWG; base += 12) {
+                        u64 g0[6], g1[6];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            const int w = base + 2 * i < nWG ? base + 2 * i : half;   // (beyond the last source: the first one again, not added)
+                            g0[i] = ll_load(src + (size_t)w * RG_NEX * 2);
+                            g1[i] = ll_load(src + (size_t)w * RG_NEX * 2 + 1);
                         }
-                        sum = s;
-                        return ok;
-                    }, abort_flag, wait_ticks);
-                    vt[t] = sum;
-                    if (!alive && (t & 63) == 0) s_abort = 1;
-                }
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            ok = ok && ll_ok(g0[i], tag) && ll_ok(g1[i], tag);
+                            if (base + 2 * i < nWG) s += ll_value(g0[i], g1[i]);
+                        }
+                    }
+                    sum = s;
+                    return ok;
+                }, abort_flag, wait_ticks);
+                vt[t] = sum;
+                if (!alive && (t & 63) == 0) s_abort = 1;
             }
         }
         RSTAMP(2);
@@ -314,14 +324,14 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
         {
             const int t = launder(tid);
             const int part = t & 3, pair = t >> 2, e = pair >> 5, c = pair & 31;
-            const cplx* vc = reinterpret_cast<const cplx*>(vt) + e * PS_CMAX;
+            const cplx* vc = reinterpret_cast<const cplx*>(vt) + e * PS_CMAX;   // (+ RG_NEX / 2: the odd workgroups' sum)
             cplx acc = mk(0, 0);
             if (first) {
                 if (part == 0) acc = vc[c];
             } else {
 #pragma unroll
                 for (int i = 0; i < PS_CMAX / 4; ++i)  // vt and ms are 0 beyond C
-                    cfma(acc, vc[part + 4 * i], conj(ms[(part + 4 * i) * RG_MLD + c]));
+                    cfma(acc, vc[part + 4 * i] + vc[RG_NEX / 2 + part + 4 * i], conj(ms[(part + 4 * i) * RG_MLD + c]));
             }
             acc = group_sum<4>(acc);
             const cplx other = shfl_xor_c(acc, 4);   // the row c ^ 1
@@ -333,7 +343,7 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
                 }
                 if (member == 0 && !first) {
                     cplx __attribute__((address_space(1)))* dst = Uout + ((int64_t)e * P + (kb - 1)) * PS_CMAX + c;
-                    const cplx v = vc[c];
+                    const cplx v = vc[c] + vc[RG_NEX / 2 + c];
                     dst->x = v.x; dst->y = v.y;
                 }
             }
@@ -449,7 +459,7 @@ static_assert(sizeof(HalfSweepArgs) % 8 == 0, "argument block in whole words");
 constexpr int RG_NUL = 9;   // unit slots per lane: designs of up to 18 units (the em32: 15 antipodal pairs + 2 single capsules)
 size_t reg_dyn_bytes(int nul) {
     const size_t nu2 = 2 * (size_t)nul, nvp = 8 * nu2;
-    return sizeof(cplx) * ((size_t)2 * SY_NORD + PS_CMAX * RG_MLD + 4 * nu2) + sizeof(double) * (RG_NEX + 4 * nvp + (size_t)nul * RG_NT);
+    return sizeof(cplx) * ((size_t)2 * SY_NORD + PS_CMAX * RG_MLD + 4 * nu2) + sizeof(double) * (2 * RG_NEX + 4 * nvp + (size_t)nul * RG_NT);
 }
 
 }  // namespace

@@ -29,7 +29,7 @@ def main():
     sel = f"select s.kernel_name, d.start, d.end, d.{qcol} from {kd} d join {ks} s on d.kernel_id=s.id order by d.start" if qcol else \
         f"select s.kernel_name, d.start, d.end, 0 from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"
     rows = list(cur.execute(sel))
-    sw = [r for r in rows if ("sweep_persist" in r[0] or "sweep_synth" in r[0])]
+    sw = [r for r in rows if ("sweep_persist" in r[0] or "sweep_synth" in r[0] or "sweep_reg" in r[0])]
     last = sw[-nsw:]
     # the timed region starts after the idle gap that precedes the first kernel of the unit owning the first of these sweeps
     t_end = max(r[2] for r in last)

@@ -25,7 +25,7 @@ def main():
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = [(s, e, gx) for n, s, e, gx in cur.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x / d.workgroup_size_x from {kd} d "
-                                                        f"join {ks} s on d.kernel_id=s.id order by d.start") if ("sweep_persist" in n or "sweep_synth" in n)]
+                                                        f"join {ks} s on d.kernel_id=s.id order by d.start") if ("sweep_persist" in n or "sweep_synth" in n or "sweep_reg" in n)]
     dur = [(e - s) / 1e3 for s, e, _ in rows]
     gmax = max(g for _, _, g in rows)
     full = [(e - s) / 1e3 for s, e, g in rows if g == gmax]

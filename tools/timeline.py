@@ -37,15 +37,15 @@ def main():
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = list(cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-    sw_all = [r for r in rows if ("sweep_persist" in r[0] or "sweep_synth" in r[0])]
+    sw_all = [r for r in rows if ("sweep_persist" in r[0] or "sweep_synth" in r[0] or "sweep_reg" in r[0])]
     if len(sw_all) > nsw + 1:   # leave the very last sweep out (drain of the pipeline)
         t0, t1 = sw_all[-nsw - 1][1], sw_all[-2][2]
         rows = [r for r in rows if r[1] >= t0 and r[2] <= t1]
     t0, t1 = rows[0][1], max(r[2] for r in rows)
     wall = t1 - t0
     allv = [(s, e) for _, s, e in rows]
-    sweep = [(s, e) for n, s, e in rows if ("sweep_persist" in n or "sweep_synth" in n)]
-    others = [(s, e) for n, s, e in rows if ("sweep_persist" not in n and "sweep_synth" not in n)]
+    sweep = [(s, e) for n, s, e in rows if ("sweep_persist" in n or "sweep_synth" in n or "sweep_reg" in n)]
+    others = [(s, e) for n, s, e in rows if ("sweep_persist" not in n and "sweep_synth" not in n and "sweep_reg" not in n)]
     busy, sw, ot = union(allv), union(sweep), union(others)
     both = sw + ot - busy
     print(f"steady-state window {wall / 1e6:.2f} ms, {len(rows)} dispatches")
