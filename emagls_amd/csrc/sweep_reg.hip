@@ -126,9 +126,25 @@ __device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); retu
 // accesses (which count on the LDS counter as well)
 #define RG_GLOBAL(T, p) ((T __attribute__((address_space(1)))*)(p))
 typedef const double __attribute__((address_space(1)))* gcd_t;
+typedef u64 __attribute__((address_space(1)))* gu64_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// granules in global memory (the helpers of persist_common.hpp take generic pointers)
+__device__ __forceinline__ u64 gll_load(gu64_t p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gll_put(gu64_t dst, u64 word, bool local) {
+    if (local) __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// both granules of a double in ONE request that misses the CU's own cache (each 8-byte granule carries its own tag, so the two
+// halves need not be read atomically together); the value is defined by rg_wait_loads
+__device__ __forceinline__ void gll_load16_async(u32x4_t& out, gu64_t p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(out) : "v"(p) : "memory"); }
 typedef const cplx __attribute__((address_space(1)))* gcc_t;
 __device__ __forceinline__ cplx ldg(gcc_t p) { return mk(p->x, p->y); }
 
+constexpr int RG_POLL = 12;   // partials a thread requests at once (22 workgroups at 2702 directions: 11 per thread, one round trip)
+__device__ __forceinline__ void rg_wait_loads(u32x4_t (&g)[RG_POLL]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]), "+v"(g[8]), "+v"(g[9]),
+                 "+v"(g[10]), "+v"(g[11]) :: "memory");
+}
 constexpr int RG_NEX = 4 * PS_CMAX;   // doubles a workgroup publishes per bin: [ear][row (32, zero beyond the microphones)][re / im]
 
 // NUL: unit slots per lane (a direction's units are split between the two lanes of a pair: 2 NUL >= units)
@@ -148,9 +164,12 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
     double* xs = wpart + 4 * NVP;                                    // [NUL][256]    2 cos(direction, unit): a lane reads its own column
     __shared__ int s_abort, s_local;
 
-    // block -> (XCD, slot) -> (design, member): design j lives on XCD j % 8, the (j / 8)-th design there
+    // block -> (XCD, slot) -> (design, member): design j lives on XCD j % 8, the (j / 8)-th of the nsub designs there.  The designs of
+    // an XCD take the slots in turn: the SIMDs serve the older waves first, and with one design's workgroups all dispatched before
+    // the next one's the first design ran at 7.2 us per bin and the second at 10.4 (the launch lasts as long as the slowest)
+    const int nsub = (n + 7) >> 3;
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int sub = rest / nWG, member = rest - sub * nWG;
+    const int member = rest / nsub, sub = rest - member * nsub;
     const int design = xcd + 8 * sub;
     if (design >= n) return;
     const HalfSweepArgs& a = args[design];
@@ -168,8 +187,8 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
     const long long wait_ticks = a.wait_ticks;
     const int* smap = a.smap;
     const int npr = smap[32], nsg = smap[33], nun = npr + nsg;
-    u64* const part_ll = a.ll;                                       // [2][nWG][RG_NEX][2]
-    u64* const xcc_ll = a.ll + (size_t)2 * nWG * RG_NEX * 2;         // [nWG]
+    const gu64_t part_ll = RG_GLOBAL(u64, a.ll);                     // [2][nWG][RG_NEX][2]
+    const gu64_t xcc_ll = part_ll + (size_t)2 * nWG * RG_NEX * 2;    // [nWG]
     if (tid == 0) { s_abort = 0; s_local = 0; }
     const int d0 = member * RG_DPW;
 
@@ -237,13 +256,13 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
         const int lane = tid;
         const unsigned xcc = read_xcc_id();
         const unsigned tag0 = 0x58434300u;  // 'XCC'
-        if (lane == 0) ll_put(xcc_ll + member, ((u64)tag0 << 32) | xcc, false);
+        if (lane == 0) gll_put(xcc_ll + member, ((u64)tag0 << 32) | xcc, false);
         bool alive = true, same = true;
         for (int base = 0; base < nWG && alive; base += 64) {
             u64 w = 0;
             alive = ll_wait([&] {
                 if (base + lane >= nWG) return true;
-                w = ll_load(xcc_ll + base + lane);
+                w = gll_load(xcc_ll + base + lane);
                 return ll_ok(w, tag0);
             }, abort_flag, wait_ticks);
             same = same && __builtin_amdgcn_ballot_w64(base + lane < nWG && (unsigned)w != xcc) == 0;
@@ -290,23 +309,23 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
                 vt[t] = half == 0 ? Winit[j] : 0.0;
             } else {
                 const unsigned tag = (unsigned)(kb - 1);
-                const u64* src = part_ll + ((size_t)((kb - 1) & 1) * nWG * RG_NEX + j) * 2;
+                const gu64_t src = part_ll + ((size_t)((kb - 1) & 1) * nWG * RG_NEX + j) * 2;
                 double sum = 0.0;
                 const bool alive = ll_wait([&] {
                     bool ok = true;
                     double s = 0.0;
-                    for (int base = half; base < nWG; base += 12) {
-                        u64 g0[6], g1[6];
+                    for (int base = half; base < nWG; base += 2 * RG_POLL) {
+                        u32x4_t g[RG_POLL];
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) {
+                        for (int i = 0; i < RG_POLL; ++i) {
                             const int w = base + 2 * i < nWG ? base + 2 * i : half;   // (beyond the last source: the first one again, not added)
-                            g0[i] = ll_load(src + (size_t)w * RG_NEX * 2);
-                            g1[i] = ll_load(src + (size_t)w * RG_NEX * 2 + 1);
+                            gll_load16_async(g[i], src + (size_t)w * RG_NEX * 2);
                         }
+                        rg_wait_loads(g);
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) {
-                            ok = ok && ll_ok(g0[i], tag) && ll_ok(g1[i], tag);
-                            if (base + 2 * i < nWG) s += ll_value(g0[i], g1[i]);
+                        for (int i = 0; i < RG_POLL; ++i) {
+                            ok = ok && g[i].y == tag && g[i].w == tag;
+                            if (base + 2 * i < nWG) s += __hiloint2double((int)g[i].z, (int)g[i].x);
                         }
                     }
                     sum = s;
@@ -422,8 +441,10 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
                     const double sO = (wE[4] + wE[NVP + 4]) + (wE[2 * NVP + 4] + wE[3 * NVP + 4]);
                     v = xneg ? sE - sO : sE + sO;
                 }
-                u64* dst = part_ll + (((size_t)(kb & 1) * nWG + member) * RG_NEX + t) * 2;
-                ll_store(dst, dst + 1, v, (unsigned)kb, local);
+                const gu64_t dst = part_ll + (((size_t)(kb & 1) * nWG + member) * RG_NEX + t) * 2;
+                const u64 bits = (u64)__double_as_longlong(v), tg = (u64)(unsigned)kb << 32;
+                gll_put(dst, tg | (bits & 0xffffffffull), local);
+                gll_put(dst + 1, tg | (bits >> 32), local);
             }
         }
         RSTAMP(5);
