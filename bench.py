@@ -250,7 +250,7 @@ def main():
     ap.add_argument("--no-sh-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 4 / config 5 / one-shot secondary figures")
     args = ap.parse_args()
-    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or not 1 <= args.batch <= 16 or args.slots < 1:
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or not 1 <= args.batch <= 32 or args.slots < 1:
         raise SystemExit("bench.py: invalid arguments")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -109,7 +109,7 @@ struct HalfSweepMulti {
     HalfSweepArgs a[SWEEP_MULTI_MAX];
 };
 // designs per launch of the register-resident sweep (sweep_reg.hip): its argument blocks lie in device memory
-constexpr int REG_SWEEP_MAX = 40;
+constexpr int REG_SWEEP_MAX = 32;
 
 
 }  // namespace emagls

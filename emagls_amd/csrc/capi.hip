@@ -761,7 +761,7 @@ void plan_setup(emagls_plan& p) {
             p.alloc("cond_ok", sizeof(double) * (size_t)p.P);
         }
         p.alloc("ll", std::max(persist_sweep_ll_bytes((int)Dh, p.synth_want ? std::max(p.C, (int)d.nmics) : p.C),
-                               p.synth_want && reg_sweep_nwg((int)Dh) <= 64 ? reg_sweep_ll_bytes((int)Dh, (int)d.nmics) : (size_t)0));
+                               p.synth_want ? reg_sweep_ll_bytes((int)Dh, (int)d.nmics) : (size_t)0));
         if (p.synth_want) p.alloc("sweep_args", sizeof(HalfSweepArgs));
         p.alloc("Wpart", sizeof(cplx) * (size_t)2 * std::max(p.nWG, p.nWG_dense) * 2 * p.C);
         p.out_rows = d.len;
@@ -1417,7 +1417,7 @@ void emagls_run_sweep(emagls_plan& p) {
     if (k0 < p.P && p.sweep_persist) {
         emagls_plan* self = &p;
         p.reg_sweep = reg_sweep_wanted(&self, 1);
-        SweepGate gate(s0, p.reg_sweep ? reg_sweep_nwg((int)p.D) : 0);
+        SweepGate gate(s0, p.reg_sweep ? reg_sweep_gate_cost((int)p.D, 1) : 0);
         launch_zero(p.get("ll"), p.bufs["ll"].bytes, s0);
         if (p.reg_sweep) reg_args_upload(&m.a[0], 1, p.get("sweep_args"), p.sweep_args_last, s0);
         if (p.prof_level >= 2) record_sweep_event(p, 0);
@@ -1859,7 +1859,7 @@ void batch_sweep_stage(emagls_batch& b) {
         // queues that held each other's waits, stalled runs for seconds (28-880 sets/s): rejected)
         hipStream_t ss = b.stream;
         {
-            SweepGate gate(ss, reg ? reg_sweep_nwg((int)q0.D) * (int)ceil_div(nb, 8) : 0);
+            SweepGate gate(ss, reg ? reg_sweep_gate_cost((int)q0.D, nb) : 0);
             if (b.lanes) { BatchScope sc(nb, b.stride); launch_zero(q0.get("ll"), q0.bufs["ll"].bytes, ss); }   // (one launch for every lane)
             else for (auto* q : b.plans) launch_zero(q->get("ll"), q->bufs["ll"].bytes, ss);
             if (reg) {
@@ -2813,7 +2813,7 @@ int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR,
 
 // designs per batch: 8 by default (one per XCD in the resident sweep), up to 16 (two per XCD) after emagls_set_batch_max / EMAGLS_BATCH_MAX
 namespace {
-std::atomic<int> g_batch_max{[] { const char* e = getenv("EMAGLS_BATCH_MAX"); return e ? std::max(1, std::min(SWEEP_MULTI_MAX, atoi(e))) : 8; }()};
+std::atomic<int> g_batch_max{[] { const char* e = getenv("EMAGLS_BATCH_MAX"); return e ? std::max(1, std::min(REG_SWEEP_MAX, atoi(e))) : 8; }()};
 thread_local int g_batch_max_override = 0;   // emagls_design_hrir_sets builds batches of 16 of its own whatever the caller's limit is
 }
 // work planes of the complex device-resident decode, grown on demand and kept (released by emagls_cache_clear)
@@ -3205,7 +3205,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         // launch-per-bin form.  Hence opt-in: EMAGLS_BATCH_MAX=16.
         const int batch_max = std::max(g_batch_max.load(), g_batch_max_override);
         if (nplans > batch_max)
-            throw Error(EMAGLS_ERR_UNSUPPORTED, batch_max >= SWEEP_MULTI_MAX ? "at most 16 designs per batch"
+            throw Error(EMAGLS_ERR_UNSUPPORTED, batch_max >= REG_SWEEP_MAX ? "at most 32 designs per batch"
                                                                              : "at most 8 designs per batch (emagls_set_batch_max(16) / EMAGLS_BATCH_MAX=16 allows 16)");
         std::unique_ptr<emagls_batch> b(new emagls_batch);
         for (int j = 0; j < nplans; ++j) {
@@ -3246,6 +3246,9 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         const int64_t Dh0 = f0.d.kind == EMAGLS_KIND_FROM_ATF ? f0.Dm : f0.D;
         const bool fits = f0.synth ? (reg_sweep_wanted(b->plans.data(), nplans) || synth_sweep_fits((int)Dh0, (int)f0.d.nmics, f0.simOrder + 1, nplans))
                                    : persist_sweep_fits((int)Dh0, f0.C, nplans);
+        if (nplans > SWEEP_MULTI_MAX && !(f0.synth && reg_sweep_wanted(b->plans.data(), nplans)))
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 16 designs per batch: only array designs that take the register-resident sweep (built-in SH basis, "
+                                                "microphone grids set, at most 18 antipodal pairs + single microphones, a launch the device can hold)");
         for (auto* p : b->plans) {
             HIP_CHECK(hipStreamSynchronize(p->stream));
             if (!fits && p->sweep_persist) { p->sweep_persist = false; if (p->synth_want) { plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); } }
@@ -3298,7 +3301,7 @@ int emagls_batch_get_filters(emagls_batch* b, void* const* wL, void* const* wR) 
             // lane batch into device buffers of this GPU: one scatter launch instead of 2 n copies (0.25 ms on the stream for 16
             // designs -- the tail of a short run's timed region)
             bool scattered = false;
-            if (b->lanes && n <= 16 && bytes % 16 == 0) {
+            if (b->lanes && n <= 32 && bytes % 16 == 0) {
                 bool dev_dst = true;
                 for (size_t j = 0; j < n && dev_dst; ++j)
                     for (void* q : {wL[j], wR[j]}) {
@@ -3339,7 +3342,7 @@ int emagls_batch_lane_mode(emagls_batch* b, int* lanes) {
 }
 int emagls_set_batch_max(int max_designs, int* previous) {
     return guarded([&] {
-        if (max_designs < 1 || max_designs > SWEEP_MULTI_MAX) throw Error(EMAGLS_ERR_ARG, "a batch holds 1..16 designs");
+        if (max_designs < 1 || max_designs > REG_SWEEP_MAX) throw Error(EMAGLS_ERR_ARG, "a batch holds 1..32 designs (more than 16: array designs on the register-resident sweep)");
         const int prev = g_batch_max.exchange(max_designs);
         if (previous) *previous = prev;
     });

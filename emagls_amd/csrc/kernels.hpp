@@ -11,7 +11,7 @@ namespace emagls {
 void launch_zero(void* p, size_t bytes, hipStream_t st);
 void launch_compare_words(const void* a, const void* b, size_t bytes, int* differ, hipStream_t st);
 void launch_broadcast_lanes(const void* src, size_t bytes, size_t stride, int nlanes, hipStream_t st);
-struct LanePtrs { void* p[32]; };   // [2 j + ear] for up to 16 designs
+struct LanePtrs { void* p[64]; };   // [2 j + ear] for up to 32 designs
 void launch_scatter_lanes(const void* srcL, const void* srcR, size_t stride, size_t bytes, int n, const LanePtrs& dst, hipStream_t st);
 void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out, int ld, hipStream_t st, bool out_real = false);
 void launch_sh_coeff(int N, double* tab, hipStream_t st);
@@ -120,12 +120,13 @@ void launch_synth_ls(const void* Hc, int64_t ldH, int n_c, const void* bsc, int 
 void launch_sweep_synth(const HalfSweepMulti& m, hipStream_t st);
 // ---- sweep_reg.hip: the synthesising sweep with the operand in registers (a lane = a direction; no slab in LDS).  Units = antipodal
 // microphone pairs + single microphones (smap[32] + smap[33]); argument blocks in device memory (store_sweep_args)
-int reg_sweep_nwg(int D);
 int reg_sweep_max_units();
 bool reg_sweep_supported(int D, int nmics, int nunits, int nOrd);
 size_t reg_sweep_ll_bytes(int D, int nmics);
-int reg_sweep_capacity(int D);                 // designs one launch can keep resident on this device
-int reg_sweep_slots_per_xcd();                 // workgroups of the kernel one XCD holds
+int reg_sweep_capacity(int D);                  // designs one launch can keep resident on this device
+int reg_sweep_slots_per_xcd();                  // the sweep gate's capacity: thirds of a CU per XCD
+int reg_sweep_pick_waves(int D, int ndesigns);  // waves per workgroup of a launch of `ndesigns` designs (4, 8 or 12; 0: cannot be resident)
+int reg_sweep_gate_cost(int D, int ndesigns);   // what such a launch takes of the gate's capacity
 bool reg_sweep_fits(int D, int nmics, int nunits, int nOrd, int ndesigns);
 void launch_sweep_reg(const HalfSweepArgs* args_dev, const HalfSweepArgs& a0, int n, hipStream_t st);
 double reg_reduce_selftest();

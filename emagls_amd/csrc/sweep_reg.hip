@@ -38,8 +38,6 @@ namespace emagls {
 
 namespace {
 
-constexpr int RG_NT = 256;      // threads per workgroup
-constexpr int RG_DPW = 128;     // directions per workgroup: two lanes per direction
 constexpr int RG_MLD = 36;      // row stride of M~ in LDS (16 dwords mod 64)
 
 // ---- halving steps of the wave reduction.  Each takes two values per lane and returns ONE: half of the lanes get the sum of `a`
@@ -60,31 +58,20 @@ __device__ __forceinline__ double halve16(double a, double b) {
     const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
     return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
-constexpr int DPP_ROW_ROR8 = 0x128;   // lane l of a row reads lane (l + 8) % 16
-constexpr int DPP_ROW_SHL4 = 0x104;   // lane l reads lane l + 4
-constexpr int DPP_ROW_SHR4 = 0x114;   // lane l reads lane l - 4
-// lanes with bit 3 clear: a[l] + a[l ^ 8]; the others: b[l] + b[l ^ 8]
-__device__ __forceinline__ double halve8(double a, double b, bool keep_a) {
+// inside a row: lanes with keep_a get a[l] + a[perm(l)], the others b[l] + b[perm(l)]; perm (a DPP control, its own inverse) maps the
+// keep_a lanes onto the others
+template <int CTRL> __device__ __forceinline__ double halve_row(double a, double b, bool keep_a) {
     const double x = keep_a ? a : b, y = keep_a ? b : a;
-    return x + dpp_d<DPP_ROW_ROR8>(y);
-}
-// v[l] + v[l ^ 4]: the banks of four lanes with bit 2 clear read four lanes up, the others four lanes down
-__device__ __forceinline__ double add_xor4(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    int plo = __builtin_amdgcn_update_dpp(0, lo, DPP_ROW_SHL4, 0xf, 0x5, false);
-    int phi = __builtin_amdgcn_update_dpp(0, hi, DPP_ROW_SHL4, 0xf, 0x5, false);
-    plo = __builtin_amdgcn_update_dpp(plo, lo, DPP_ROW_SHR4, 0xf, 0xA, false);
-    phi = __builtin_amdgcn_update_dpp(phi, hi, DPP_ROW_SHR4, 0xf, 0xA, false);
-    return v + __hiloint2double(phi, plo);
+    return x + dpp_d<CTRL>(y);
 }
 
 // E_u, O_u of GS unit slots accumulated in place (synth_group's schedule: two terms per pass, the coefficients of the next pass
-// requested before this pass's arithmetic); xcol: the lane's column of 2 cos values, one row of 256 per slot
-template <int U0, int GS, int NUL>
+// requested before this pass's arithmetic); xcol: the lane's column of 2 cos values, one row of NT per slot
+template <int U0, int GS, int NUL, int NT>
 __device__ __forceinline__ void synth_units(const double* xcol, cplx (&E)[NUL], cplx (&O)[NUL], const cplx* bs, int nord_pad) {
     double x2[GS], pa[GS], pb[GS];
 #pragma unroll
-    for (int i = 0; i < GS; ++i) x2[i] = xcol[(U0 + i) * 256];
+    for (int i = 0; i < GS; ++i) x2[i] = xcol[(U0 + i) * NT];
 #pragma unroll
     for (int i = 0; i < GS; ++i) { pa[i] = 1.0; pb[i] = 0.5 * x2[i]; E[U0 + i] = mk(0.0, 0.0); O[U0 + i] = mk(0.0, 0.0); }
     const unsigned bs0 = lds_addr(bs);
@@ -115,9 +102,6 @@ __device__ __forceinline__ void synth_units(const double* xcol, cplx (&E)[NUL], 
     }
 }
 
-// Index of a wave's partial value: [unit][E / O][ear][re / im]
-__host__ __device__ constexpr int rg_vidx(int u, int eo, int e, int ri) { return ((u * 2 + eo) * 2 + e) * 2 + ri; }
-
 // (a value the compiler must recompute from here on in every iteration: thread-derived indices and addresses of the loop's sections
 // otherwise stay in registers for the whole loop next to the operand)
 __device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -126,8 +110,10 @@ __device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); retu
 // accesses (which count on the LDS counter as well)
 #define RG_GLOBAL(T, p) ((T __attribute__((address_space(1)))*)(p))
 typedef const double __attribute__((address_space(1)))* gcd_t;
+typedef const cplx __attribute__((address_space(1)))* gcc_t;
 typedef u64 __attribute__((address_space(1)))* gu64_t;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cplx ldg(gcc_t p) { return mk(p->x, p->y); }
 // granules in global memory (the helpers of persist_common.hpp take generic pointers)
 __device__ __forceinline__ u64 gll_load(gu64_t p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gll_put(gu64_t dst, u64 word, bool local) {
@@ -137,39 +123,40 @@ __device__ __forceinline__ void gll_put(gu64_t dst, u64 word, bool local) {
 // both granules of a double in ONE request that misses the CU's own cache (each 8-byte granule carries its own tag, so the two
 // halves need not be read atomically together); the value is defined by rg_wait_loads
 __device__ __forceinline__ void gll_load16_async(u32x4_t& out, gu64_t p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(out) : "v"(p) : "memory"); }
-typedef const cplx __attribute__((address_space(1)))* gcc_t;
-__device__ __forceinline__ cplx ldg(gcc_t p) { return mk(p->x, p->y); }
 
-constexpr int RG_POLL = 12;   // partials a thread requests at once (22 workgroups at 2702 directions: 11 per thread, one round trip)
+constexpr int RG_POLL = 12;   // partials a thread requests at once (22 workgroups at 2702 directions and 4 waves: 11 per thread, one round trip)
 __device__ __forceinline__ void rg_wait_loads(u32x4_t (&g)[RG_POLL]) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]), "+v"(g[8]), "+v"(g[9]),
                  "+v"(g[10]), "+v"(g[11]) :: "memory");
 }
 constexpr int RG_NEX = 4 * PS_CMAX;   // doubles a workgroup publishes per bin: [ear][row (32, zero beyond the microphones)][re / im]
+constexpr int RG_SVC = 256;           // threads that serve the workgroup: exchange, M phase, M~ staging (waves 0-3)
 
-// NUL: unit slots per lane (a direction's units are split between the two lanes of a pair: 2 NUL >= units)
-template <int NUL>
-__global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs* __restrict__ args, int n, int nWG) {
+// NUL: unit slots per lane (a direction's units are split between the two waves of a pair: 2 NUL >= units); NW: waves per workgroup
+template <int NUL, int NW>
+__global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs* __restrict__ args, int n, int nWG) {
+    constexpr int NT = 64 * NW, DPW = 32 * NW, NB = NW / 2;   // threads, directions and 64-direction blocks of a workgroup
     constexpr int NU2 = 2 * NUL;            // unit slots of a direction
-    constexpr int NVP = 8 * NU2;            // values of a wave's partial
+    constexpr int NCH = (NUL + 1) / 2;      // chunks of two slots in the wave reduction
+    constexpr int NVW = 16 * NCH;           // values of a wave's partial: [slot][E / O][ear][re / im], padded to whole chunks
     constexpr int GA = (NUL + 1) / 2, GB = NUL - GA;   // slot groups of the synthesis (9: 5, 4)
-    static_assert(GB >= 1, "slot groups");
+    static_assert(GB >= 1 && NW % 2 == 0 && NT >= RG_SVC, "layout");
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     cplx* ring = reinterpret_cast<cplx*>(dyn);                       // [2][SY_NORD]  Chebyshev coefficients of two bins
     cplx* ms = ring + 2 * SY_NORD;                                   // [32][MLD]     M~_{kb-1}
     cplx* WE = ms + PS_CMAX * RG_MLD;                                // [2][NU2]      w'[row A] + w'[row B]
     cplx* WO = WE + 2 * NU2;                                         // [2][NU2]      w'[row A] - w'[row B]
     double* vt = reinterpret_cast<double*>(WO + 2 * NU2);            // [2][2][32][2] totals of the previous bin in microphone rows: the sums over the even and over the odd workgroups
-    double* wpart = vt + 2 * RG_NEX;                                 // [4][NVP]      the waves' partials
-    double* xs = wpart + 4 * NVP;                                    // [NUL][256]    2 cos(direction, unit): a lane reads its own column
+    double* wpart = vt + 2 * RG_NEX;                                 // [NW][NVW]     the waves' partials
+    double* pp = wpart + NW * NVW;                                   // [NW][4][64]   a wave's share of p (its half of the units): [ear][re / im][lane]
+    double* xs = pp + NW * 256;                                      // [NUL][NT]     2 cos(direction, unit): a lane reads its own column
     __shared__ int s_abort, s_local;
 
-    // block -> (XCD, slot) -> (design, member): design j lives on XCD j % 8, the (j / 8)-th of the nsub designs there.  The designs of
-    // an XCD take the slots in turn: the SIMDs serve the older waves first, and with one design's workgroups all dispatched before
-    // the next one's the first design ran at 7.2 us per bin and the second at 10.4 (the launch lasts as long as the slowest)
-    const int nsub = (n + 7) >> 3;
+    // block -> (XCD, slot) -> (design, member): design j lives on XCD j % 8, the (j / 8)-th design there.  (One design's workgroups
+    // after the other's: taking the slots in turn was tried -- with workgroups that share CUs unevenly BOTH designs then run at the
+    // pace of their slowest workgroups, 9.9 us per bin each instead of 7.2 / 10.4.)
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int member = rest / nsub, sub = rest - member * nsub;
+    const int sub = rest / nWG, member = rest - sub * nWG;
     const int design = xcd + 8 * sub;
     if (design >= n) return;
     const HalfSweepArgs& a = args[design];
@@ -190,21 +177,24 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
     const gu64_t part_ll = RG_GLOBAL(u64, a.ll);                     // [2][nWG][RG_NEX][2]
     const gu64_t xcc_ll = part_ll + (size_t)2 * nWG * RG_NEX * 2;    // [nWG]
     if (tid == 0) { s_abort = 0; s_local = 0; }
-    const int d0 = member * RG_DPW;
+    const int d0 = member * DPW;
+    // thread -> direction of the workgroup: wave pair q = wave / 2 takes the directions 64 q .. 64 q + 63 (lane = direction), wave
+    // parity h the unit slots h NUL .. h NUL + NUL - 1
+    auto dir_of = [&](int t) __attribute__((always_inline)) { return d0 + 64 * (t >> 7) + (t & 63); };
 
     // ---- twice the cosine of the angle between the lane's direction and the (first) microphone of each of its units, kept in LDS (a
     // lane reads back only its own column, a few values at a time)
     {
         const size_t ncplx = (size_t)2 * SY_NORD + PS_CMAX * RG_MLD + 4 * NU2;
-        for (size_t i = tid; i < ncplx; i += RG_NT) ring[i] = mk(0, 0);
-        for (int i = tid; i < 2 * RG_NEX + 4 * NVP; i += RG_NT) vt[i] = 0.0;
-        const int dgi = d0 + (tid >> 1) < D ? d0 + (tid >> 1) : D - 1;
+        for (size_t i = tid; i < ncplx; i += NT) ring[i] = mk(0, 0);
+        for (int i = tid; i < 2 * RG_NEX + NW * NVW + NW * 256; i += NT) vt[i] = 0.0;
+        const int dgi = dir_of(tid) < D ? dir_of(tid) : D - 1;
         double sd, cd;
         sincos(a.dir_zen[dgi], &sd, &cd);
         const double daz = a.dir_azi[dgi];
 #pragma unroll 1
         for (int i = 0; i < NUL; ++i) {
-            const int u = (tid & 1) * NUL + i;
+            const int u = ((tid >> 6) & 1) * NUL + i;
             double v = 0.0;
             if (u < nun) {
                 const int jm = smap[u < npr ? 2 * u : 2 * npr + (u - npr)];
@@ -213,7 +203,7 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
                 v = fma(sd * sm, cos(daz - a.mic_azi[jm]), cd * cm);
                 v = 2.0 * fmin(1.0, fmax(-1.0, v));   // (2x: the factor of the Chebyshev recurrence)
             }
-            xs[i * RG_NT + tid] = v;
+            xs[i * NT + tid] = v;
         }
     }
     __syncthreads();   // LDS is initialised
@@ -225,8 +215,8 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
         ring[((kfirst + 1) & 1) * SY_NORD + tid] = ldg(bsc + (int64_t)k1 * nord_pad + tid);
     }
     // M~ (C x C in memory, bin kbm at a.Mw + kbm C C: the factor stage stores bin kb at slot kb - 1 and the pointer is shifted):
-    // thread = (row, four columns).  (Reads beyond a row's C columns stay inside the buffer -- it is padded by 1024 elements -- and
-    // are dropped when the row is staged.)
+    // service thread = (row, four columns).  (Reads beyond a row's C columns stay inside the buffer -- it is padded by 1024 elements --
+    // and are dropped when the row is staged.)
     constexpr int NLM = 4;
     cplx mReg[NLM];
     auto fetch_m = [&](int kbm, int t) __attribute__((always_inline)) {
@@ -243,13 +233,12 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
     double hCur[2], hNext[2] = {0.0, 0.0};
     auto fetch_h = [&](int kb, double (&h)[2], int t) __attribute__((always_inline)) {
         const int kbg = (kb < P ? kb : P - 1) - kabs0;
-        const int dgi = d0 + (t >> 1) < D ? d0 + (t >> 1) : D - 1;
+        const int dgi = dir_of(t) < D ? dir_of(t) : D - 1;
         h[0] = (Habs + (int64_t)kbg * ldH)[dgi];
         h[1] = (Habs + ((int64_t)(P - kabs0) + kbg) * ldH)[dgi];
     };
     fetch_h(kfirst, hCur, tid);
-    fetch_m(kfirst, tid);
-    stage_m(tid);
+    if (tid < RG_SVC) { fetch_m(kfirst, tid); stage_m(tid); }
 
     // ---- do all workgroups of this design share an XCD?  (then the granules stay in its L2)
     if (tid < 64) {
@@ -277,7 +266,7 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
     const bool local = s_local != 0;
     if (s_abort) return;
 
-    // ---- operand of one bin: E_u, O_u of the lane's half of its direction's units
+    // ---- operand of one bin: E_u, O_u of the lane's direction, the wave's half of the units
     cplx E[NUL], O[NUL];
 #pragma unroll
     for (int u = 0; u < NUL; ++u) { E[u] = mk(0, 0); O[u] = mk(0, 0); }
@@ -293,16 +282,16 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
         if (!last) {
             const cplx* bs = ring + (kb & 1) * SY_NORD;
             const double* xcol = xs + launder(tid);
-            synth_units<0, GA, NUL>(xcol, E, O, bs, nord_pad);
+            synth_units<0, GA, NUL, NT>(xcol, E, O, bs, nord_pad);
             __builtin_amdgcn_sched_barrier(0);
-            synth_units<GA, GB, NUL>(xcol, E, O, bs, nord_pad);
+            synth_units<GA, GB, NUL, NT>(xcol, E, O, bs, nord_pad);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ================= totals of bin kb-1: every workgroup's partial, summed in workgroup order =================
         RSTAMP(0);
-        {
-            // thread = (half of the workgroups, ear, row, re / im): the partials of the workgroups half, half + 2, ... of one double,
-            // requested six at a time (a loop over 22 sources with one request in flight took 3 us per bin)
+        if (launder(tid) < RG_SVC) {
+            // service thread = (half of the workgroups, ear, row, re / im): the partials of the workgroups half, half + 2, ... of one
+            // double, requested together (a loop over 22 sources with one request in flight took 3 us per bin)
             const int t = launder(tid);
             const int j = t & (RG_NEX - 1), half = t >> 7;
             if (first) {   // W(kfirst-1,:) Pm from the least-squares bins (synth_mt_kernel / synth_winit_kernel)
@@ -340,7 +329,7 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
         if (s_abort) break;
         // ---- w'(kb-1,:) = u_total conj(M~_{kb-1})  (the start value as it stands), as the p phase's unit weights; the totals themselves
         // go to memory: the filters' rows are formed from them after the launch
-        {
+        if (launder(tid) < RG_SVC) {
             const int t = launder(tid);
             const int part = t & 3, pair = t >> 2, e = pair >> 5, c = pair & 31;
             const cplx* vc = reinterpret_cast<const cplx*>(vt) + e * PS_CMAX;   // (+ RG_NEX / 2: the odd workgroups' sum)
@@ -370,12 +359,14 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
         if (last) break;
         __syncthreads();  // B2: the weights are complete; M~ may be replaced
         RSTAMP(3);
-        fetch_m(kb, launder(tid));      // M~ of the next iteration: requested here, staged behind the p phase (which covers the round trip)
-        // ---- p = w'(kb-1,:) g^T (this lane's units, then the sum of the lane pair);  t = |H| p/|p|
+        const bool svc = launder(tid) < RG_SVC;
+        if (svc) fetch_m(kb, launder(tid));      // M~ of the next iteration: requested here, staged behind the p phase (which covers the round trip)
+        // ---- p = w'(kb-1,:) g^T: this wave's units, then the sum with the partner wave's;  t = |H| p/|p|
         cplx t0, t1;
         {
             const int t = launder(tid);
-            const cplx* we = WE + (t & 1) * NUL, *wo = WO + (t & 1) * NUL;
+            const int wave = t >> 6, lane = t & 63;
+            const cplx* we = WE + (wave & 1) * NUL, *wo = WO + (wave & 1) * NUL;
             cplx p0 = mk(0, 0), p1 = mk(0, 0);
 #pragma unroll
             for (int u = 0; u < NUL; ++u) {
@@ -383,40 +374,59 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
                 cfma(p0, we0, E[u]); cfma(p0, wo0, O[u]);
                 cfma(p1, we1, E[u]); cfma(p1, wo1, O[u]);
             }
-            p0.x += dpp_d<DPP_XOR1>(p0.x); p0.y += dpp_d<DPP_XOR1>(p0.y);
-            p1.x += dpp_d<DPP_XOR1>(p1.x); p1.y += dpp_d<DPP_XOR1>(p1.y);
-            const bool dvalid = d0 + (t >> 1) < D;
+            double* mine = pp + wave * 256 + lane;
+            mine[0] = p0.x; mine[64] = p0.y; mine[128] = p1.x; mine[192] = p1.y;
+            if (svc) stage_m(t);
+            __syncthreads();  // Bp: the partner wave's share of p
+            RSTAMP(8);
+            const double* theirs = pp + (wave ^ 1) * 256 + lane;
+            p0.x += theirs[0]; p0.y += theirs[64]; p1.x += theirs[128]; p1.y += theirs[192];
+            const bool dvalid = dir_of(t) < D;
             t0 = dvalid ? unit_phase(hCur[0], p0, nyq) : mk(0, 0);
             t1 = dvalid ? unit_phase(hCur[1], p1, nyq) : mk(0, 0);
         }
-        stage_m(launder(tid));
         __builtin_amdgcn_sched_barrier(0);
-        // ---- this wave's partial  t conj(E_u), t conj(O_u)  summed over its 32 directions (the lanes of one parity)
+        // ---- this wave's partial  t conj(E_u), t conj(O_u)  summed over its 64 directions
         {
-            const int lane = launder(tid) & 63;
-            const bool keep8 = (lane & 8) == 0;
-            // one unit slot (eight values: E / O, ear, re / im) at a time: three halving steps leave ONE register whose lane l holds
-            // the sum over eight lanes of value (l >> 3), the all-reduce over the lane bits 1 and 2 completes it
-            double r[NUL];
+            const int t = launder(tid);
+            const int lane = t & 63;
+            const bool keep8 = (lane & 8) == 0, keep4 = (lane & 4) == 0;
+            // two unit slots (sixteen values: slot, E / O, ear, re / im) at a time: four halving steps leave ONE register whose lane l
+            // holds the sum over sixteen lanes of value 16 c + (l >> 2), the all-reduce inside the quad completes it
+            double r[NCH];
 #pragma unroll
-            for (int c = 0; c < NUL; ++c) {
-                // value j = 4 eo + 2 e + ri
-                const double v0 = fma(t0.x, E[c].x, t0.y * E[c].y), v1 = fma(t0.y, E[c].x, -(t0.x * E[c].y));
-                const double v2 = fma(t1.x, E[c].x, t1.y * E[c].y), v3 = fma(t1.y, E[c].x, -(t1.x * E[c].y));
-                const double v4 = fma(t0.x, O[c].x, t0.y * O[c].y), v5 = fma(t0.y, O[c].x, -(t0.x * O[c].y));
-                const double v6 = fma(t1.x, O[c].x, t1.y * O[c].y), v7 = fma(t1.y, O[c].x, -(t1.x * O[c].y));
-                const double a0 = halve32(v0, v4), a1 = halve32(v1, v5), a2 = halve32(v2, v6), a3 = halve32(v3, v7);   // lanes >= 32: O
-                const double b0 = halve16(a0, a2), b1 = halve16(a1, a3);                                                 // odd rows: ear 1
-                double v = halve8(b0, b1, keep8);                                                                       // bit 3: imaginary part
-                v += dpp_d<DPP_XOR2>(v);
-                v = add_xor4(v);
-                r[c] = v;
-                __builtin_amdgcn_sched_barrier(0);   // (one slot at a time: the scheduler otherwise starts them all)
+            for (int c = 0; c < NCH; ++c) {
+                double v[16];   // value j = 8 (slot & 1) + 4 eo + 2 e + ri
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (2 * c + s < NUL) {
+                        const cplx gE = E[2 * c + s < NUL ? 2 * c + s : 0], gO = O[2 * c + s < NUL ? 2 * c + s : 0];
+                        v[8 * s + 0] = fma(t0.x, gE.x, t0.y * gE.y); v[8 * s + 1] = fma(t0.y, gE.x, -(t0.x * gE.y));
+                        v[8 * s + 2] = fma(t1.x, gE.x, t1.y * gE.y); v[8 * s + 3] = fma(t1.y, gE.x, -(t1.x * gE.y));
+                        v[8 * s + 4] = fma(t0.x, gO.x, t0.y * gO.y); v[8 * s + 5] = fma(t0.y, gO.x, -(t0.x * gO.y));
+                        v[8 * s + 6] = fma(t1.x, gO.x, t1.y * gO.y); v[8 * s + 7] = fma(t1.y, gO.x, -(t1.x * gO.y));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[8 * s + j] = 0.0;
+                    }
+                }
+                double h1[8], h2[4], h3[2];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h1[j] = halve32(v[j], v[j + 8]);                         // lanes >= 32: the odd slot
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h2[j] = halve16(h1[j], h1[j + 4]);                       // odd rows: O
+#pragma unroll
+                for (int j = 0; j < 2; ++j) h3[j] = halve_row<DPP_ROW_MIRROR>(h2[j], h2[j + 2], keep8);   // bit 3: ear 1
+                double x = halve_row<DPP_HALF_MIRROR>(h3[0], h3[1], keep4);                          // bit 2: imaginary part
+                x += dpp_d<DPP_XOR1>(x);
+                x += dpp_d<DPP_XOR2>(x);
+                r[c] = x;
+                __builtin_amdgcn_sched_barrier(0);   // (one chunk at a time: the scheduler otherwise starts them all)
             }
-            if ((lane & 6) == 0) {
-                double* wp = wpart + (launder(tid) >> 6) * NVP + (lane & 1) * NUL * 8 + (lane >> 3);
+            if ((lane & 3) == 0) {
+                double* wp = wpart + (t >> 6) * NVW + (lane >> 2);
 #pragma unroll
-                for (int c = 0; c < NUL; ++c) wp[8 * c] = r[c];
+                for (int c = 0; c < NCH; ++c) wp[16 * c] = r[c];
             }
         }
         // (the operand registers are free now: what the next iterations need from memory is requested here)
@@ -428,24 +438,24 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
         __syncthreads();  // B3: the waves' partials, M~ and the ring row are in place
         RSTAMP(4);
         // ---- the workgroup's partial in microphone rows, published as granules
-        {
+        if (launder(tid) < RG_NEX) {
             const int t = launder(tid);
-            if (t < RG_NEX) {
-                const int xe = t >> 6, xr = (t >> 1) & 31, xri = t & 1;
-                double v = 0.0;
-                if (xr < C) {
-                    const int xu = xr < 2 * npr ? (xr >> 1) : npr + (xr - 2 * npr);
-                    const bool xneg = xr < 2 * npr && (xr & 1);
-                    const double* wE = wpart + rg_vidx(xu, 0, xe, xri);
-                    const double sE = (wE[0] + wE[NVP]) + (wE[2 * NVP] + wE[3 * NVP]);
-                    const double sO = (wE[4] + wE[NVP + 4]) + (wE[2 * NVP + 4] + wE[3 * NVP + 4]);
-                    v = xneg ? sE - sO : sE + sO;
-                }
-                const gu64_t dst = part_ll + (((size_t)(kb & 1) * nWG + member) * RG_NEX + t) * 2;
-                const u64 bits = (u64)__double_as_longlong(v), tg = (u64)(unsigned)kb << 32;
-                gll_put(dst, tg | (bits & 0xffffffffull), local);
-                gll_put(dst + 1, tg | (bits >> 32), local);
+            const int xe = t >> 6, xr = (t >> 1) & 31, xri = t & 1;
+            double v = 0.0;
+            if (xr < C) {
+                const int xu = xr < 2 * npr ? (xr >> 1) : npr + (xr - 2 * npr);
+                const bool xneg = xr < 2 * npr && (xr & 1);
+                const int h = xu >= NUL ? 1 : 0;
+                const double* wE = wpart + h * NVW + 8 * (xu - h * NUL) + 2 * xe + xri;   // wave h of block 0; + 4: the O value
+                double sE = 0.0, sO = 0.0;
+#pragma unroll
+                for (int q = 0; q < NB; ++q) { sE += wE[2 * q * NVW]; sO += wE[2 * q * NVW + 4]; }
+                v = xneg ? sE - sO : sE + sO;
             }
+            const gu64_t dst = part_ll + (((size_t)(kb & 1) * nWG + member) * RG_NEX + t) * 2;
+            const u64 bits = (u64)__double_as_longlong(v), tg = (u64)(unsigned)kb << 32;
+            gll_put(dst, tg | (bits & 0xffffffffull), local);
+            gll_put(dst + 1, tg | (bits >> 32), local);
         }
         RSTAMP(5);
         hCur[0] = hNext[0]; hCur[1] = hNext[1];
@@ -453,17 +463,23 @@ __global__ void __launch_bounds__(RG_NT, 2) sweep_reg_kernel(const HalfSweepArgs
 #undef RSTAMP
 }
 
-// the wave reduction of the kernel above on its own: in [64 lanes][8 values] -> out [2 lane parities][8] (the sums over the 32 lanes of a parity)
+// the wave reduction of the kernel above on its own: in [64 lanes][16 values] -> out [16] (lane l ends up with the sum over all lanes of
+// value l >> 2)
 __global__ void __launch_bounds__(64) reg_reduce_selftest_kernel(const double* __restrict__ in, double* __restrict__ out) {
     const int lane = threadIdx.x;
-    const double* v = in + lane * 8;
-    const bool keep8 = (lane & 8) == 0;
-    const double a0 = halve32(v[0], v[4]), a1 = halve32(v[1], v[5]), a2 = halve32(v[2], v[6]), a3 = halve32(v[3], v[7]);
-    const double b0 = halve16(a0, a2), b1 = halve16(a1, a3);
-    double r = halve8(b0, b1, keep8);
-    r += dpp_d<DPP_XOR2>(r);
-    r = add_xor4(r);
-    if ((lane & 6) == 0) out[(lane & 1) * 8 + (lane >> 3)] = r;
+    const double* v = in + lane * 16;
+    const bool keep8 = (lane & 8) == 0, keep4 = (lane & 4) == 0;
+    double h1[8], h2[4], h3[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h1[j] = halve32(v[j], v[j + 8]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h2[j] = halve16(h1[j], h1[j + 4]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) h3[j] = halve_row<DPP_ROW_MIRROR>(h2[j], h2[j + 2], keep8);
+    double x = halve_row<DPP_HALF_MIRROR>(h3[0], h3[1], keep4);
+    x += dpp_d<DPP_XOR1>(x);
+    x += dpp_d<DPP_XOR2>(x);
+    if ((lane & 3) == 0) out[lane >> 2] = x;
 }
 
 // argument blocks into device memory, stream-ordered (no host buffer has to outlive the call)
@@ -477,57 +493,84 @@ __global__ void __launch_bounds__(64) store_args_kernel(HalfSweepMulti m, HalfSw
 }
 static_assert(sizeof(HalfSweepArgs) % 8 == 0, "argument block in whole words");
 
-constexpr int RG_NUL = 9;   // unit slots per lane: designs of up to 18 units (the em32: 15 antipodal pairs + 2 single capsules)
-size_t reg_dyn_bytes(int nul) {
-    const size_t nu2 = 2 * (size_t)nul, nvp = 8 * nu2;
-    return sizeof(cplx) * ((size_t)2 * SY_NORD + PS_CMAX * RG_MLD + 4 * nu2) + sizeof(double) * (2 * RG_NEX + 4 * nvp + (size_t)nul * RG_NT);
+constexpr int RG_NUL = 9;   // unit slots per wave: designs of up to 18 units (the em32: 15 antipodal pairs + 2 single capsules)
+size_t reg_dyn_bytes(int nul, int nw) {
+    const size_t nu2 = 2 * (size_t)nul, nvw = 16 * (((size_t)nul + 1) / 2);
+    return sizeof(cplx) * ((size_t)2 * SY_NORD + PS_CMAX * RG_MLD + 4 * nu2) +
+           sizeof(double) * (2 * RG_NEX + (size_t)nw * nvw + (size_t)nw * 256 + (size_t)nul * 64 * nw);
 }
+const void* reg_kernel_ptr(int nw) {
+    return nw == 4 ? reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 4>)
+                   : nw == 8 ? reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 8>) : reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 12>);
+}
+void reg_set_attributes() {
+    static PerDeviceOnce attr_once;   // (function attributes are per device)
+    if (attr_once.first())
+        for (int nw : {4, 8, 12}) HIP_CHECK(hipFuncSetAttribute(reg_kernel_ptr(nw), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+}
+int reg_nwg(int D, int nw) { return (int)ceil_div(D, 32 * nw); }
+// thirds of a CU a workgroup of nw waves is counted as: four waves share a CU with two more of their kind, larger workgroups take it
+int reg_wg_cost(int nw) { return nw == 4 ? 1 : 3; }
 
 }  // namespace
 
-int reg_sweep_nwg(int D) { return (int)ceil_div(D, RG_DPW); }
 int reg_sweep_max_units() { return 2 * RG_NUL; }
 bool reg_sweep_supported(int D, int nmics, int nunits, int nOrd) {
-    return nmics >= 2 && nmics <= PS_CMAX && nunits >= 1 && nunits <= 2 * RG_NUL && reg_sweep_nwg(D) <= 64 && nOrd <= SY_NORD && D >= 1;
+    return nmics >= 2 && nmics <= PS_CMAX && nunits >= 1 && nunits <= 2 * RG_NUL && D >= 1 && reg_nwg(D, 12) <= 32 && nOrd <= SY_NORD;
 }
 size_t reg_sweep_ll_bytes(int D, int nmics) {
-    const size_t nwg = (size_t)reg_sweep_nwg(D);
+    const size_t nwg = (size_t)reg_nwg(D, 4);   // (the form with the most workgroups)
     (void)nmics;
     return sizeof(u64) * ((size_t)2 * nwg * RG_NEX * 2 + nwg + 64);
 }
-// workgroups of the register-resident sweep one CU holds (registers, LDS: the runtime's figure)
-static int reg_sweep_occupancy() {
-    int occ = 0;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL>), RG_NT,
-                                                           reg_dyn_bytes(RG_NUL)));
-    return occ;
+// the gate's unit: thirds of a CU per XCD (sweep_reg.hip workgroups of four waves are a third, larger ones a whole CU)
+int reg_sweep_slots_per_xcd() { return 3 * (sweep_cu_budget() / 8); }
+// Waves per workgroup for a launch of n designs: the smallest workgroups (the most CUs per design, the shortest bins) with which
+// every workgroup has a CU of its own -- workgroups that share CUs unevenly run at the pace of the slowest -- and, when even
+// twelve waves do not get there, four waves with up to three workgroups per CU.  0: the launch cannot be resident.
+int reg_sweep_pick_waves(int D, int ndesigns) {
+    if (ndesigns < 1 || ndesigns > REG_SWEEP_MAX) return 0;
+    const int nsub = (int)ceil_div(ndesigns, 8), cus = sweep_cu_budget() / 8;
+    if (const char* e = getenv("EMAGLS_REG_WAVES")) {   // (experiments: 4, 8 or 12 whenever it fits)
+        const int nw = atoi(e);
+        if ((nw == 4 || nw == 8 || nw == 12) && nsub * reg_nwg(D, nw) * reg_wg_cost(nw) <= 3 * cus) return nw;
+    }
+    for (int nw : {4, 8, 12}) if (nsub * reg_nwg(D, nw) <= cus) return nw;
+    return nsub * reg_nwg(D, 4) <= 3 * cus ? 4 : 0;
 }
-int reg_sweep_slots_per_xcd() { return reg_sweep_occupancy() * (sweep_cu_budget() / 8); }
-// designs ONE launch can hold resident: per XCD ceil(n / 8) designs of nWG workgroups each
+int reg_sweep_gate_cost(int D, int ndesigns) {
+    const int nw = reg_sweep_pick_waves(D, ndesigns);
+    return nw ? (int)ceil_div(ndesigns, 8) * reg_nwg(D, nw) * reg_wg_cost(nw) : 0;
+}
 int reg_sweep_capacity(int D) {
-    const int k = reg_sweep_slots_per_xcd() / reg_sweep_nwg(D);
-    return std::min(REG_SWEEP_MAX, 8 * k);
+    int n = 0;
+    for (int k = 8; k <= REG_SWEEP_MAX; k += 8) if (reg_sweep_pick_waves(D, k)) n = k;
+    return n;
 }
 bool reg_sweep_fits(int D, int nmics, int nunits, int nOrd, int ndesigns) {
-    if (!reg_sweep_supported(D, nmics, nunits, nOrd) || ndesigns < 1) return false;
-    return ndesigns <= reg_sweep_capacity(D);
+    return reg_sweep_supported(D, nmics, nunits, nOrd) && reg_sweep_pick_waves(D, ndesigns) != 0;
 }
 
 // args: `n` argument blocks in device memory
 void launch_sweep_reg(const HalfSweepArgs* args_dev, const HalfSweepArgs& a0, int n, hipStream_t st) {
-    const int nWG = reg_sweep_nwg(a0.D);
-    if (n < 1 || n > REG_SWEEP_MAX) throw Error(2, "register-resident sweep: too many designs in one launch");
+    const int nw = reg_sweep_pick_waves(a0.D, n);
+    if (!nw) throw Error(2, "register-resident sweep: the launch cannot be resident");
+    const int nWG = reg_nwg(a0.D, nw);
     const unsigned nblocks = 8u * (unsigned)nWG * (unsigned)ceil_div(n, 8);
-    sweep_reg_kernel<RG_NUL><<<dim3(nblocks), RG_NT, reg_dyn_bytes(RG_NUL), st>>>(args_dev, n, nWG);
+    const size_t dyn = reg_dyn_bytes(RG_NUL, nw);
+    reg_set_attributes();
+    if (nw == 4) sweep_reg_kernel<RG_NUL, 4><<<dim3(nblocks), 256, dyn, st>>>(args_dev, n, nWG);
+    else if (nw == 8) sweep_reg_kernel<RG_NUL, 8><<<dim3(nblocks), 512, dyn, st>>>(args_dev, n, nWG);
+    else sweep_reg_kernel<RG_NUL, 12><<<dim3(nblocks), 768, dyn, st>>>(args_dev, n, nWG);
     KERNEL_CHECK();
 }
 
 // max |device - host| of the wave reduction on pseudo-random values (debug entry emagls_self_test)
 double reg_reduce_selftest() {
-    double h_in[64 * 8], h_out[16], want[16] = {0};
+    double h_in[64 * 16], h_out[16], want[16] = {0};
     unsigned long long x = 88172645463325252ull;
-    for (int i = 0; i < 64 * 8; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h_in[i] = (double)(x % 2000001ull) / 1000000.0 - 1.0; }
-    for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) want[(l & 1) * 8 + j] += h_in[l * 8 + j];
+    for (int i = 0; i < 64 * 16; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h_in[i] = (double)(x % 2000001ull) / 1000000.0 - 1.0; }
+    for (int l = 0; l < 64; ++l) for (int j = 0; j < 16; ++j) want[j] += h_in[l * 16 + j];
     double *d_in = nullptr, *d_out = nullptr;
     HIP_CHECK(hipMalloc(&d_in, sizeof h_in));
     HIP_CHECK(hipMalloc(&d_out, sizeof h_out));

@@ -44,7 +44,8 @@ def main():
                 "operand synthesis (7->0)": t[kb, 0] - t[kb, 7],
                 "wait for the other workgroups' partials + sum (0->2)": t[kb, 2] - t[kb, 0],
                 "B1 + M phase + B2 (2->3)": t[kb, 3] - t[kb, 2],
-                "p phase + partial + wave reduction + B3 (3->4)": t[kb, 4] - t[kb, 3],
+                "p phase (own units) + Bp (3->8)": t[kb, 8] - t[kb, 3],
+                "t + partial + wave reduction + B3 (8->4)": t[kb, 4] - t[kb, 8],
                 "workgroup sum + publish (4->5)": t[kb, 5] - t[kb, 4],
             }
             print("design %d of %d (register-resident form): %d swept bins, sweep span %.1f us, one XCD: %s" % (j, n, P - k0, t[P - 1, 5] - t[k0, 7], bool(p.debug("sweep_timing", np.int64)[15])))
