@@ -253,9 +253,11 @@ struct emagls_batch {
     hipGraphExec_t post_exec = nullptr;
     bool side0_external = false;               // side[0] belongs to the caller (emagls_batch_set_side_stream)
     int order_hint = 0;                        // single-group batches: 1 / 2 = stage order of emagls_pre_sweep the caller asks for (emagls_batch_set_stage_order)
-    int groups = 1;                            // lane groups before the sweep (2 for more than 8 designs: batch_execute_lanes)
+    int groups = 1;                            // lane groups before the sweep (ceil(designs / 8), up to 4: batch_execute_lanes)
     hipGraph_t graph2 = nullptr;               // the second lane group's stages before the sweep (on side[0])
     hipGraphExec_t graph2_exec = nullptr;
+    hipGraph_t graphx[2] = {nullptr, nullptr};             // the third and fourth groups' (on side[1], side[2])
+    hipGraphExec_t graphx_exec[2] = {nullptr, nullptr};
     int eager_runs = 0;
     bool use_graph = true;
     void* sweep_args_dev = nullptr;            // argument blocks of the register-resident sweep, one per plan (sweep_reg.hip)
@@ -286,6 +288,7 @@ struct emagls_batch {
         if (post_graph) hipGraphDestroy(post_graph);
         if (graph2_exec) hipGraphExecDestroy(graph2_exec);
         if (graph2) hipGraphDestroy(graph2);
+        for (int i = 0; i < 2; ++i) { if (graphx_exec[i]) hipGraphExecDestroy(graphx_exec[i]); if (graphx[i]) hipGraphDestroy(graphx[i]); }
         for (auto e : sweep_ev) if (e) hipEventDestroy(e);
         if (stream && own_stream) emagls::pool_stream_give(stream);
         for (int i = 0; i < 3; ++i) if (side[i] && !(i == 0 && side0_external)) { hipStreamSynchronize(side[i]); emagls::pool_stream_give(side[i]); }
@@ -1895,7 +1898,7 @@ void batch_lanes_part(emagls_batch& b, int part, int first, int count, hipStream
     p0.stage_order = 0;
     if (part == 0 && p0.nstreams == 1) {
         const int sm = stagger_mode();
-        if (sm == 1) p0.stage_order = b.groups > 1 ? 1 + group : (b.order_hint ? 1 + (b.order_hint - 1) % 2 : 0);
+        if (sm == 1) p0.stage_order = b.groups > 1 ? 1 + group % 2 : (b.order_hint ? 1 + (b.order_hint - 1) % 2 : 0);
         else if (sm >= 10) p0.stage_order = group == 0 ? sm / 10 % 10 : sm % 10;   // (experiments: "12", "21", "11", "22")
     }
     if (p0.nstreams > 1) for (int i = 0; i < 3; ++i) p0.side[i] = b.side[i];
@@ -1918,35 +1921,40 @@ int batch_group_first(const emagls_batch& b, int g) { const int n = (int)b.plans
 void batch_execute_lanes(emagls_batch& b) {
     const bool replay = b.use_graph && b.eager_runs >= 1;
     const int n = (int)b.plans.size();
-    if (b.groups > 1 && !b.side[0]) b.side[0] = emagls::pool_stream_take();
-    hipStream_t gs[2] = {b.stream, b.groups > 1 ? b.side[0] : b.stream};
+    const int ng = b.groups;
+    for (int g = 1; g < ng; ++g) if (!b.side[g - 1]) b.side[g - 1] = emagls::pool_stream_take();
+    hipStream_t gs[4] = {b.stream, b.stream, b.stream, b.stream};
+    for (int g = 1; g < ng; ++g) gs[g] = b.side[g - 1];
+    hipGraph_t* gr[4] = {&b.graph, &b.graph2, &b.graphx[0], &b.graphx[1]};
+    hipGraphExec_t* ge[4] = {&b.graph_exec, &b.graph2_exec, &b.graphx_exec[0], &b.graphx_exec[1]};
     if (replay && !b.graph_exec) {
-        for (int g = 0; g < b.groups; ++g) {
+        for (int g = 0; g < ng; ++g) {
             const int f = batch_group_first(b, g), c = batch_group_first(b, g + 1) - f;
-            capture_into(gs[g], g == 0 ? &b.graph : &b.graph2, g == 0 ? &b.graph_exec : &b.graph2_exec, [&] { batch_lanes_part(b, 0, f, c, gs[g], g); });
+            capture_into(gs[g], gr[g], ge[g], [&] { batch_lanes_part(b, 0, f, c, gs[g], g); });
         }
         capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_lanes_part(b, 2, 0, n, b.stream); });
     }
     b.used = 0;
-    if (b.groups > 1) b.depend(gs[1], b.stream);   // (the previous execute of this batch is done with the buffers)
-    if (replay && b.groups > 1) {
-        // a graph launch of ~60 kernel nodes costs ~1 ms of host time: the second group's launch goes out from a thread of its
-        // own, or its stages would start a millisecond (three under a profiler) behind the first group's
-        hipError_t e2 = hipSuccess;
+    for (int g = 1; g < ng; ++g) b.depend(gs[g], b.stream);   // (the previous execute of this batch is done with the buffers)
+    if (replay && ng > 1) {
+        // a graph launch of ~60 kernel nodes costs ~1 ms of host time: the other groups' launches go out from threads of their
+        // own, or their stages would start a millisecond (three under a profiler) behind the first group's
+        hipError_t err[4] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess};
         const int dev = b.device;
-        std::thread t2([&] { e2 = hipSetDevice(dev); if (e2 == hipSuccess) e2 = hipGraphLaunch(b.graph2_exec, gs[1]); });
-        const hipError_t e1 = hipGraphLaunch(b.graph_exec, gs[0]);
-        t2.join();
-        HIP_CHECK(e1);
-        HIP_CHECK(e2);
+        std::vector<std::thread> th;
+        for (int g = 1; g < ng; ++g)
+            th.emplace_back([&, g] { err[g] = hipSetDevice(dev); if (err[g] == hipSuccess) err[g] = hipGraphLaunch(*ge[g], gs[g]); });
+        err[0] = hipGraphLaunch(*ge[0], gs[0]);
+        for (auto& t : th) t.join();
+        for (int g = 0; g < ng; ++g) HIP_CHECK(err[g]);
     } else {
-        for (int g = 0; g < b.groups; ++g) {
+        for (int g = 0; g < ng; ++g) {
             const int f = batch_group_first(b, g), c = batch_group_first(b, g + 1) - f;
-            if (replay) HIP_CHECK(hipGraphLaunch(g == 0 ? b.graph_exec : b.graph2_exec, gs[g])); else batch_lanes_part(b, 0, f, c, gs[g], g);
+            if (replay) HIP_CHECK(hipGraphLaunch(*ge[g], gs[g])); else batch_lanes_part(b, 0, f, c, gs[g], g);
         }
     }
-    if (b.groups > 1) b.depend(b.stream, gs[1]);
-    batch_sweep_stage(b);   // (never captured: see SweepChain)
+    for (int g = 1; g < ng; ++g) b.depend(b.stream, gs[g]);
+    batch_sweep_stage(b);   // (never captured: see SweepGate)
     if (replay) HIP_CHECK(hipGraphLaunch(b.post_exec, b.stream)); else batch_lanes_part(b, 2, 0, n, b.stream);
     emagls_plan& p0 = *b.plans[0];
     for (auto* p : b.plans) {
@@ -2440,6 +2448,10 @@ void drop_batch_graphs(emagls_batch& b) {
     if (b.post_graph) { HIP_CHECK(hipGraphDestroy(b.post_graph)); b.post_graph = nullptr; }
     if (b.graph2_exec) { HIP_CHECK(hipGraphExecDestroy(b.graph2_exec)); b.graph2_exec = nullptr; }
     if (b.graph2) { HIP_CHECK(hipGraphDestroy(b.graph2)); b.graph2 = nullptr; }
+    for (int i = 0; i < 2; ++i) {
+        if (b.graphx_exec[i]) { HIP_CHECK(hipGraphExecDestroy(b.graphx_exec[i])); b.graphx_exec[i] = nullptr; }
+        if (b.graphx[i]) { HIP_CHECK(hipGraphDestroy(b.graphx[i])); b.graphx[i] = nullptr; }
+    }
     b.eager_runs = 0;
 }
 // Device-side status words of a design: [0] Cholesky pivot, [1] persistent sweep gave up waiting, [2] a Gram-route bin was
@@ -2609,10 +2621,11 @@ void batch_try_lanes(emagls_batch& b) {
     HIP_CHECK(hipDeviceSynchronize());
     b.lanes = true;
     b.stride = stride;
-    {   // more than 8 designs: two lane groups before the sweep (EMAGLS_BATCH_GROUPS=1 keeps one launch sequence for all lanes)
+    {   // more than 8 designs: lane groups of up to 8 before the sweep, at most four (EMAGLS_BATCH_GROUPS=1 keeps one launch sequence
+        // for all lanes, 2 / 3 / 4 cap the number of groups)
         const char* e = getenv("EMAGLS_BATCH_GROUPS");
-        const int want = e ? atoi(e) : 2;
-        b.groups = (b.plans.size() > 8 && want >= 2) ? 2 : 1;
+        const int cap = e ? std::max(1, std::min(4, atoi(e))) : 4;
+        b.groups = std::max(1, std::min(cap, (int)ceil_div((int64_t)b.plans.size(), 8)));
     }
 }
 
