@@ -536,7 +536,7 @@ def main():
         ch = Mm if synth else Cc
         reg = info.sweep_form == 3
         if reg:   # sweep_reg.hip: 4 / 8 / 12 waves of 32 directions per workgroup for up to 8 / 16 / 32 designs per launch
-            nw = 4 if big <= 8 else (8 if big <= 16 else 12)
+            nw = next(w for w in (4, 6, 8, 10, 12) if -(-big // 8) * -(-D // (32 * w)) <= 32 or w == 12)
             nwg = -(-D // (32 * nw))
         else:
             nwg = -(-D // (64 if D <= 2048 else 96))

@@ -499,14 +499,20 @@ size_t reg_dyn_bytes(int nul, int nw) {
     return sizeof(cplx) * ((size_t)2 * SY_NORD + PS_CMAX * RG_MLD + 4 * nu2) +
            sizeof(double) * (2 * RG_NEX + (size_t)nw * nvw + (size_t)nw * 256 + (size_t)nul * 64 * nw);
 }
+constexpr int RG_WAVES[] = {4, 6, 8, 10, 12};   // waves per workgroup of the instantiations
 const void* reg_kernel_ptr(int nw) {
-    return nw == 4 ? reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 4>)
-                   : nw == 8 ? reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 8>) : reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 12>);
+    switch (nw) {
+        case 4: return reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 4>);
+        case 6: return reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 6>);
+        case 8: return reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 8>);
+        case 10: return reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 10>);
+        default: return reinterpret_cast<const void*>(sweep_reg_kernel<RG_NUL, 12>);
+    }
 }
 void reg_set_attributes() {
     static PerDeviceOnce attr_once;   // (function attributes are per device)
     if (attr_once.first())
-        for (int nw : {4, 8, 12}) HIP_CHECK(hipFuncSetAttribute(reg_kernel_ptr(nw), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        for (int nw : RG_WAVES) HIP_CHECK(hipFuncSetAttribute(reg_kernel_ptr(nw), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 }
 int reg_nwg(int D, int nw) { return (int)ceil_div(D, 32 * nw); }
 // thirds of a CU a workgroup of nw waves is counted as: four waves share a CU with two more of their kind, larger workgroups take it
@@ -531,11 +537,11 @@ int reg_sweep_slots_per_xcd() { return 3 * (sweep_cu_budget() / 8); }
 int reg_sweep_pick_waves(int D, int ndesigns) {
     if (ndesigns < 1 || ndesigns > REG_SWEEP_MAX) return 0;
     const int nsub = (int)ceil_div(ndesigns, 8), cus = sweep_cu_budget() / 8;
-    if (const char* e = getenv("EMAGLS_REG_WAVES")) {   // (experiments: 4, 8 or 12 whenever it fits)
+    if (const char* e = getenv("EMAGLS_REG_WAVES")) {   // (experiments: 4 ... 12 whenever it fits)
         const int nw = atoi(e);
-        if ((nw == 4 || nw == 8 || nw == 12) && nsub * reg_nwg(D, nw) * reg_wg_cost(nw) <= 3 * cus) return nw;
+        if ((nw == 4 || nw == 6 || nw == 8 || nw == 10 || nw == 12) && nsub * reg_nwg(D, nw) * reg_wg_cost(nw) <= 3 * cus) return nw;
     }
-    for (int nw : {4, 8, 12}) if (nsub * reg_nwg(D, nw) <= cus) return nw;
+    for (int nw : RG_WAVES) if (nsub * reg_nwg(D, nw) <= cus) return nw;
     return nsub * reg_nwg(D, 4) <= 3 * cus ? 4 : 0;
 }
 int reg_sweep_gate_cost(int D, int ndesigns) {
@@ -559,9 +565,13 @@ void launch_sweep_reg(const HalfSweepArgs* args_dev, const HalfSweepArgs& a0, in
     const unsigned nblocks = 8u * (unsigned)nWG * (unsigned)ceil_div(n, 8);
     const size_t dyn = reg_dyn_bytes(RG_NUL, nw);
     reg_set_attributes();
-    if (nw == 4) sweep_reg_kernel<RG_NUL, 4><<<dim3(nblocks), 256, dyn, st>>>(args_dev, n, nWG);
-    else if (nw == 8) sweep_reg_kernel<RG_NUL, 8><<<dim3(nblocks), 512, dyn, st>>>(args_dev, n, nWG);
-    else sweep_reg_kernel<RG_NUL, 12><<<dim3(nblocks), 768, dyn, st>>>(args_dev, n, nWG);
+    switch (nw) {
+        case 4: sweep_reg_kernel<RG_NUL, 4><<<dim3(nblocks), 256, dyn, st>>>(args_dev, n, nWG); break;
+        case 6: sweep_reg_kernel<RG_NUL, 6><<<dim3(nblocks), 384, dyn, st>>>(args_dev, n, nWG); break;
+        case 8: sweep_reg_kernel<RG_NUL, 8><<<dim3(nblocks), 512, dyn, st>>>(args_dev, n, nWG); break;
+        case 10: sweep_reg_kernel<RG_NUL, 10><<<dim3(nblocks), 640, dyn, st>>>(args_dev, n, nWG); break;
+        default: sweep_reg_kernel<RG_NUL, 12><<<dim3(nblocks), 768, dyn, st>>>(args_dev, n, nWG); break;
+    }
     KERNEL_CHECK();
 }
 
