@@ -96,17 +96,10 @@ def spawn_ranks(n, argv, script=None, timeout=None):
 
 
 def schedule(n_designs, bsz=BSZ):
-    """Batch sizes that process exactly n_designs: full batches and one partial batch.  The partial batch goes FIRST: when
-    the pipeline fills from empty, the batch with the least work reaches its sweep first and the serial chain of sweeps starts
-    earlier (1390 -> 1466 filter sets/s at 20 steps)."""
+    """Chunk sizes in which the library's scheduler (emagls_jobs_run) processes a list of n_designs equal-shape jobs: consecutive
+    chunks of bsz, the rest last -- exactly n_designs, never a design more."""
     full, tail = divmod(int(n_designs), bsz)
-    if os.environ.get("EMAGLS_BENCH_TAIL_LAST"):
-        return [bsz] * full + ([tail] if tail else [])
-    split = int(os.environ.get("EMAGLS_BENCH_SPLIT", "0"))
-    if split and tail and full and 0 < split <= bsz and 0 < bsz + tail - split <= bsz:
-        # (experiment) the partial batch and one full batch re-divided: `split` designs first, the rest last
-        return [split] + [bsz] * (full - 1) + [bsz + tail - split]
-    return ([tail] if tail else []) + [bsz] * full
+    return [bsz] * full + ([tail] if tail else [])
 
 
 # --------------------------------------------------------------------------------------------
@@ -257,11 +250,9 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--slots", type=int, default=int(os.environ.get("EMAGLS_BENCH_SLOTS", str(SLOTS))),
-                    help="resident batches per GPU (profiling runs use 1)")
+                    help="chunks of the job list in flight per GPU (emagls_jobs_run; profiling runs use 1)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("EMAGLS_BENCH_BATCH", str(BSZ))),
-                    help="designs per batch (<= 16; profiling runs use 1 for the single-design kernel times)")
-    ap.add_argument("--fork", type=int, default=int(os.environ.get("EMAGLS_BENCH_FORK", "1")),
-                    help="streams the stages before a batch's sweep fork onto (1..4, emagls_batch_set_streams)")
+                    help="designs per chunk (<= 32; profiling runs use 1 for the single-design kernel times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sh-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 4 / config 5 / one-shot secondary figures")
@@ -305,23 +296,8 @@ def main():
     from emagls_amd import Batch, Plan, _lib as L
     lib = L.load()
     L.check(lib.emagls_set_device(local_rank))
-    if args.batch > 8:   # 9..16 designs per batch: two designs per XCD in the resident sweep (the library's default limit is 8)
-        L.check(lib.emagls_set_batch_max(args.batch, None))
     K, W = args.steps, args.warmup
     nslots, Bsz = args.slots, args.batch
-    # The HIP runtime multiplexes every stream of the process onto 4 hardware queues, and two batches whose streams share a
-    # queue run strictly one after the other (measured: the third batch of a 20-design run waited 8 ms behind the first one's
-    # sweep).  The streams of the batches that can be in flight together are therefore created here, before the library
-    # creates any stream of its own, and handed to the batches (emagls_batch_set_stream): consecutive streams land on
-    # different queues.  The tail batches come first so that [full, full, tail] never shares a queue.
-    # (tried: a high-priority stream for the first batch, so that ONE batch reaches its sweep early in a short run: slower, 1357
-    # vs 1400 sets/s at 20 steps and 1750 vs 1910 at 128)
-    lane_streams = [torch.cuda.Stream(device=local_rank) for _ in range(nslots + 2)]
-    next_stream = iter(lane_streams)
-    # (batches of more than 8 designs run the stages before their sweep as two lane groups: the second group's streams)
-    side_streams = [torch.cuda.Stream(device=local_rank) for _ in range(nslots + 2)] if Bsz > 8 else []
-    next_side = iter(side_streams)
-
     def make_plan(seed_offset, streams=1):
         azi, zen, maz, mzn, hL, hR = load_inputs(seed_offset=seed_offset)
         p = Plan(L.KIND_EMAGLS, os.environ.get("EMAGLS_BENCH_BASIS", "complex"), 4, 48000.0, 512, hL.shape[0], hL.shape[1], 0.042, 32)
@@ -354,68 +330,45 @@ def main():
     info = p0.info()
     p0.close()
 
-    # ---- SETUP: the resident configuration (independent of --steps): nslots batches of Bsz designs, plus one smaller batch
-    # object per distinct tail size of the warm-up and the timed schedule
-    class Unit:
-        count = 0
-
-        def __init__(self, size, seed0):
-            self.seeds = [seed0 + j for j in range(size)]
-            self.plans = [make_plan(seed0 + j)[0] for j in range(size)]
-            self.batch = Batch(self.plans) if size > 1 else None
-            self.size = size
-            if self.batch is not None:
-                st = next(next_stream, None)
-                if st is not None:
-                    self.batch.set_stream(st.cuda_stream)
-                if args.fork > 1 and self.batch.lane_mode():
-                    self.batch.set_streams(args.fork)
-                # batches of up to 8 designs that run side by side issue the stages before their sweeps in complementary
-                # orders (emagls_batch_set_stage_order; the two lane groups of a larger batch do so by themselves)
-                so = os.environ.get("EMAGLS_BENCH_STAGE_ORDER", "alt")
-                if size <= 8 and self.batch.lane_mode() and args.fork == 1 and so != "0":
-                    self.batch.set_stage_order(1 + Unit.count % 2 if so == "alt" else int(so))
-                Unit.count += 1
-                if size > 8:
-                    st2 = next(next_side, None)
-                    if st2 is not None:
-                        self.batch.set_side_stream(st2.cuda_stream)
-
-        def execute(self):
-            self.batch.execute() if self.batch is not None else self.plans[0].execute()
-
-        def collect(self, dst_l, dst_r):
-            if self.batch is not None:   # one synchronisation and one status check for the whole batch; device-to-device copies
-                self.batch.get_filters_into(dst_l, dst_r)
-            else:
-                L.check(lib.emagls_plan_get_filters(self.plans[0]._h, C.c_void_p(dst_l[0]), C.c_void_p(dst_r[0])))
-
-        def wait(self):
-            self.batch.synchronize() if self.batch is not None else self.plans[0].synchronize()
-
-        def close(self):
-            if self.batch is not None:
-                self.batch.close()
-            for p in self.plans:
-                p.close()
-
-    tails = {}      # size -> the batch objects of that size (as many as one schedule holds)
-    for n_designs in (K, W):
-        sizes = [t for t in schedule(n_designs, Bsz) if t != Bsz]
-        for t in set(sizes):
-            while len(tails.setdefault(t, [])) < sizes.count(t):
-                tails[t].append(Unit(t, rank * 1000 + 500 + t + 40 * len(tails[t])))
-    units = [Unit(Bsz, rank * 1000 + b * Bsz) for b in range(nslots)]
-    for u in units + [v for vs in tails.values() for v in vs]:   # eager run, hipGraph capture, first replay
-        for _ in range(3):
-            u.execute()
-        u.wait()
-
+    # ---- SETUP: the job list of the timed region.  One job = one design (descriptor, its own HRIR set resident in HBM, room for its
+    # filters in `out`); the library's scheduler (emagls_jobs_run, include/emagls.h) cuts the list into chunks of Bsz designs, runs
+    # every chunk as a lane batch and keeps nslots chunks in flight from its own threads.  The HRIR sets of min(K, NIN) distinct
+    # designs are resident (a longer list goes through them again).
+    NIN = 4 * 32
+    n_in = min(max(K, W, 1), NIN)
+    gen = [load_inputs(seed_offset=rank * 1000 + j) for j in range(n_in)]
+    azi, zen, maz, mzn = gen[0][:4]
+    d_hrirs = torch.empty((n_in, 2, gen[0][4].shape[1], gen[0][4].shape[0]), dtype=torch.float64, device="cuda")   # [design][ear][direction][tap]
+    for j, g in enumerate(gen):
+        d_hrirs[j, 0] = torch.from_numpy(np.ascontiguousarray(g[4].T))
+        d_hrirs[j, 1] = torch.from_numpy(np.ascontiguousarray(g[5].T))
+    torch.cuda.synchronize()
     out = torch.zeros((K, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")  # complex as (re,im)
-    scratch = torch.zeros((Bsz, 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")
-    # destination addresses of every design's two filter sets, once (64 tensor views per batch otherwise, inside the timed region)
-    out_ptrs = [[out[j, e].data_ptr() for j in range(K)] for e in range(2)]
-    scratch_ptrs = [[scratch[j, e].data_ptr() for j in range(Bsz)] for e in range(2)]
+    scratch = torch.zeros((max(W, 1), 2, info.out_cols, info.out_rows, 2), dtype=torch.float64, device="cuda")
+    grids = [np.ascontiguousarray(v, dtype=np.float64) for v in (azi, zen, maz, mzn)]
+    desc = L.DesignDesc(L.KIND_EMAGLS, L.BASIS[os.environ.get("EMAGLS_BENCH_BASIS", "complex")], 4, 48000.0, 512, gen[0][4].shape[0], gen[0][4].shape[1],
+                        0.042, 32, 0.0, 0, 0, 0, 0, 0)
+
+    def job_list(n, dst):
+        arr = (L.Job * n)()
+        for k in range(n):
+            j = arr[k]
+            j.desc = desc
+            j.hL, j.hR = d_hrirs[k % n_in, 0].data_ptr(), d_hrirs[k % n_in, 1].data_ptr()
+            j.hrir_azi, j.hrir_zen, j.mic_azi, j.mic_zen = (g.ctypes.data for g in grids)
+            j.wL, j.wR = dst[k, 0].data_ptr(), dst[k, 1].data_ptr()
+        return arr
+    jobs_timed, jobs_warm = job_list(K, out), (job_list(W, scratch) if W else None)
+    seed_of = [rank * 1000 + k % n_in for k in range(K)]   # HRIR seed offset of every design of the timed region
+
+    def run_jobs(arr, n):
+        L.check(lib.emagls_jobs_run(arr, n, Bsz, nslots, 0))
+    # every chunk shape of the two lists three times: eager run, hipGraph capture, first replay
+    for _ in range(3):
+        run_jobs(jobs_timed, K)
+        if W:
+            run_jobs(jobs_warm, W)
+    out.zero_()
     coll_dev = "cpu" if shared_gpu else "cuda"     # (gloo gathers host tensors)
     gathered = [torch.zeros(out.shape, dtype=out.dtype, device=coll_dev) for _ in range(world)] if (use_pg and rank == 0) else None
 
@@ -424,87 +377,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from concurrent.futures import ThreadPoolExecutor
-    # (plans and batches run on the device they were created on whatever the calling thread's current device is; the
-    # initializer only keeps the workers' own HIP calls -- none today -- on this rank's GPU)
-    launcher = ThreadPoolExecutor(max_workers=max(nslots, 2), initializer=lambda: L.check(lib.emagls_set_device(local_rank)))
-    # (the pool starts its threads on first use and each runs the initializer -- a HIP call in a new thread: done here, in the
-    # setup, so that the first parallel launch of the timed region does not pay for it: one 20-step run in ten was 30 % low)
-    import threading
-    _gate = threading.Barrier(max(nslots, 2))
-    list(launcher.map(lambda _: _gate.wait(timeout=30), range(max(nslots, 2))))
-
-    seed_of = [None] * K      # HRIR seed offset of every design of the timed region
-    timed_units = []          # the batches the timed region executed
-
-    def run_designs(n_designs, store):
-        """Exactly n_designs designs through the resident batches, at most nslots batches in flight (sliding window: a slot is
-        re-issued as soon as its results have been collected)."""
-        sched = schedule(n_designs, Bsz)
-        free, inflight = list(units), []
-        idx = first = done = 0
-        if store:
-            timed_units.clear()
-        # Batches are issued in WAVES: up to nslots batches at once, all of them collected before the next wave goes out.  The stages
-        # before the sweeps of a wave then run together, and its resident sweeps follow each other undisturbed -- a sweep launch next
-        # to other batches' stages waits for CUs they keep refilling and is stretched from 3.2 to 4.6 - 5.3 ms (DESIGN.md section 5).
-        # 512 steps: 2735 - 2750 sets/s in waves of six against 2390 - 2404 with a sliding window of four (EMAGLS_BENCH_WAVES=0).
-        waves = os.environ.get("EMAGLS_BENCH_WAVES", "0") != "0"
-        nwaves = -(-len(sched) // nslots)
-        per_wave = -(-len(sched) // nwaves) if waves else nslots
-        wave_overlap = int(os.environ.get("EMAGLS_BENCH_WAVE_OVERLAP", "0")) if waves else 0   # (experiment: the next wave goes out while this many batches of the last one are still in flight -- 2570-2700 sets/s at 512 steps with 1 or 2 against 2724-2738 with none)
-        while idx < len(sched) or inflight:
-            launch = []
-            while idx < len(sched) and len(inflight) < per_wave + wave_overlap and not (waves and len(inflight) > wave_overlap and not launch):
-                size = sched[idx]
-                if size == Bsz:
-                    if not free:
-                        break
-                    u = free.pop(0)
-                else:
-                    u = tails[size].pop(0)   # (a partial batch of the schedule)
-                launch.append(u)
-                inflight.append((u, first))
-                if store:
-                    seed_of[first:first + size] = u.seeds
-                    if u not in timed_units:
-                        timed_units.append(u)
-                first += size
-                idx += 1
-            # a batch's execute is ~1 ms of host time (two hipGraphLaunch calls): when several batches start at once (the
-            # fill of the pipeline) their launches are issued from parallel host threads (the C calls release the GIL)
-            if len(launch) > 1:
-                list(launcher.map(lambda x: x.execute(), launch))
-            elif launch:
-                launch[0].execute()
-            u, f0 = inflight.pop(0)
-            pl, pr, base = (out_ptrs[0], out_ptrs[1], f0) if store else (scratch_ptrs[0], scratch_ptrs[1], 0)
-            u.collect(pl[base:base + u.size], pr[base:base + u.size])
-            done += u.size
-            (free if u.size == Bsz else tails[u.size]).append(u)
-        assert done == n_designs
-
     # ---- W warm-up designs, untimed (also warms the collective)
     if W:
-        run_designs(W, False)
+        run_jobs(jobs_warm, W)
     if use_pg:
         dist.gather(out.cpu() if shared_gpu else out, gathered, dst=0)
-    # ---- timed region: exactly K designs + one gather (hipGraph replays; two HIP events bracket each batch's sweep launch)
-    for u in units + [v for vs in tails.values() for v in vs]:
-        if u.batch is not None:
-            u.batch.set_profiling(1)
+    # ---- timed region: exactly K designs + one gather (two HIP events bracket each chunk's sweep launch)
+    L.check(lib.emagls_jobs_set_profiling(1))
     import gc
     gc.collect()
     gc.disable()   # (a generation-2 collection of this process takes milliseconds: not inside a 10 ms timed region)
     barrier()
     t0 = time.perf_counter()
-    run_designs(K, True)
+    run_jobs(jobs_timed, K)
     gather_ms = None
     if use_pg:   # (inside the timed region, as the contract asks; its share is reported next to the figure)
         torch.cuda.synchronize()
         tg0 = time.perf_counter()
         dist.gather(out.cpu() if shared_gpu else out, gathered, dst=0)
-        torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg0) * 1e3
     barrier()
     dt = time.perf_counter() - t0
@@ -514,9 +404,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     # duration of the dominant kernel's launches inside the timed region (the last execute of every full batch)
-    # (the batches of the largest size the timed region ran: the full ones, or the single partial batch of a short run)
-    big = max((u.size for u in timed_units if u.batch is not None), default=0)
-    batch_sweep_ms = [u.batch.sweep_time_ms() for u in timed_units if u.batch is not None and u.size == big]
+    # (the chunks of the largest size the timed region ran: the full ones, or the single partial chunk of a short run; the library
+    # reports the last sweep launch of every resident chunk)
+    cap = 64
+    ms_arr, nd_arr, cnt = (C.c_double * cap)(), (C.c_int * cap)(), C.c_int(0)
+    L.check(lib.emagls_jobs_sweep_times(ms_arr, nd_arr, cap, C.byref(cnt)))
+    L.check(lib.emagls_jobs_set_profiling(0))
+    sizes_timed = set(schedule(K, Bsz))
+    chunk_times = [(nd_arr[i], ms_arr[i]) for i in range(min(cnt.value, cap)) if nd_arr[i] in sizes_timed]
+    big = max((n for n, _ in chunk_times), default=0)
+    batch_sweep_ms = [t for n, t in chunk_times if n == big]
 
     if rank == 0:
         D, Cc = inputs[4].shape[1], info.num_channels
@@ -645,8 +542,9 @@ def main():
                                    "48 kHz; one filter set per step, inputs resident in HBM",
                        "dirs": int(D), "taps": 512, "sim_order": info.sim_order, "bins": info.num_pos_freqs - 1,
                        "k_cut": info.k_cut, "designs_resident_per_gpu": nslots * Bsz, "designs_per_batch": Bsz,
-                       "batches_in_flight": nslots, "issue_order": ("waves: up to %d batches start together and are collected together" % nslots) if os.environ.get("EMAGLS_BENCH_WAVES", "0") != "0" else "sliding window", "streams_per_batch": args.fork, "timed_schedule": "batches of %s designs" % schedule(K, Bsz),
-                       "setup": "each resident batch executed 3x (eager, hipGraph capture, replay) before the warm-up",
+                       "batches_in_flight": nslots, "issue_order": "emagls_jobs_run: the library's scheduler, one job list per timed region (chunks of designs_per_batch, batches_in_flight of them between upload and collection, a library thread each)",
+                       "timed_schedule": "chunks of %s designs" % schedule(K, Bsz), "distinct_hrir_sets_resident": n_in,
+                       "setup": "the timed and the warm-up job lists run 3x (eager, hipGraph capture, replay) before the warm-up",
                        "parallelism": "independent jobs per GPU, one RCCL gather"},
             "roofline": roof,
             "flops": flops,
@@ -666,9 +564,7 @@ def main():
             except Exception as e:  # the large launch needs ~3.5 GB; never fail the bench on it
                 res["sh_basis_roofline"] = {"error": str(e)}
         if not args.no_secondary and world == 1:
-            for u in units + [v for vs in tails.values() for v in vs]:
-                u.close()
-            units, tails = [], {}
+            L.check(lib.emagls_cache_clear())   # (the resident chunks of the job list: the secondary figures bring their own)
             try:
                 res["one_shot_ms"] = time_one_shot(lib, inputs)
             except Exception as e:
@@ -691,8 +587,7 @@ def main():
             res["parity_small_case"] = parity_check()
         print(json.dumps(res))
         sys.stdout.flush()
-    for u in units + [v for vs in tails.values() for v in vs]:
-        u.close()
+    L.check(lib.emagls_cache_clear())
     if use_pg:
         dist.destroy_process_group()
 

@@ -33,6 +33,15 @@ class PlanInfo(C.Structure):
                 ("sim_order_own", C.c_int), ("sweep_form", C.c_int), ("sweep_units", C.c_int)]
 
 
+class Job(C.Structure):
+    """emagls_job: one design of a job list (emagls_jobs_run)."""
+    _fields_ = [("desc", DesignDesc), ("hL", C.c_void_p), ("hR", C.c_void_p), ("hrir_azi", C.c_void_p), ("hrir_zen", C.c_void_p),
+                ("mic_azi", C.c_void_p), ("mic_zen", C.c_void_p), ("atf", C.c_void_p), ("atf_azi", C.c_void_p), ("atf_zen", C.c_void_p),
+                ("wL", C.c_void_p), ("wR", C.c_void_p)]
+
+
+JOBS_SHARE_GEOMETRY = 1
+
 # name -> (restype, argtypes); every symbol include/emagls.h declares
 SYMBOLS = {
     "emagls_last_error": (C.c_char_p, []),
@@ -132,6 +141,9 @@ SYMBOLS = {
     "emagls_from_atf_hrir_sets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_double, C.c_void_p, C.c_void_p,
                                             C.POINTER(C.c_double)]),
+    "emagls_jobs_run": (C.c_int, [C.POINTER(Job), C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "emagls_jobs_set_profiling": (C.c_int, [C.c_int]),
+    "emagls_jobs_sweep_times": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "emagls_batch_set_geometry_sharing": (C.c_int, [C.c_void_p, C.c_int]),
     "emagls_batch_shares_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "emagls_batch_set_side_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

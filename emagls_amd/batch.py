@@ -27,9 +27,9 @@ def lane_groups(shape_keys, max_batch=8):
     """Group a rank's jobs into lane batches: a `Batch` runs in lane mode (one launch of every kernel for all its designs,
     one XCD per design in the sweep) only when its plans have identical shapes.  `shape_keys[i]` is any hashable that
     determines the shape of job i -- for a radius sweep `simulation_order(order, fs, radius)` -- and the result is a list of
-    index lists of at most `max_batch` (<= 16) jobs each, largest classes first, job order kept inside a class."""
-    if not 1 <= max_batch <= 16:
-        raise ValueError("a batch holds 1..16 designs")
+    index lists of at most `max_batch` (<= 32) jobs each, largest classes first, job order kept inside a class."""
+    if not 1 <= max_batch <= 32:
+        raise ValueError("a batch holds 1..32 designs")
     classes = {}
     for i, k in enumerate(shape_keys):
         classes.setdefault(k, []).append(i)
@@ -75,8 +75,8 @@ def padded_lane_batches(sim_orders, max_batch=16):
     BASELINE config 4 (256 radii on 2..10 cm, 36 classes of 7-8 radii): 16 batches of 16 (32 of 8 with max_batch = 8) instead of
     36 of 7-8 (or, sharded per job, 200 of 1-2).  A batch of more than 8 designs needs emagls_set_batch_max (the job lists of this
     module raise it for the call)."""
-    if not 1 <= max_batch <= 16:
-        raise ValueError("a batch holds 1..16 designs")
+    if not 1 <= max_batch <= 32:
+        raise ValueError("a batch holds 1..32 designs")
     n = len(sim_orders)
     if n == 0:
         return []
@@ -242,7 +242,9 @@ class _Results:
         dims = (max(self.nslots, 1), 2, int(cols), int(rows)) + ((2,) if cplx else ())
         if self.on_device:
             import torch
+            # (the library fills the buffer device to device on its own streams: nothing of torch's may still be writing it)
             self.buf = torch.zeros(dims, dtype=torch.float64, device="cuda")
+            torch.cuda.current_stream().synchronize()
         else:
             self.buf = np.zeros(dims, dtype=np.float64)
 
@@ -262,65 +264,52 @@ class _Results:
         return np.asfortranarray(block[0].T), np.asfortranarray(block[1].T)
 
 
-def _execute_plans(plans, res, first, share_geometry=False):
-    """One chunk of a rank's share: a Batch when the library takes the plans as one (lane mode, shared sweep launch), plan by plan
-    when it refuses them as a batch (EMAGLS_ERR_UNSUPPORTED: designs with more than 32 channels run one at a time -- same
-    filters).  The filters go straight into `res` (slots first .. first + len(plans) - 1)."""
-    import ctypes as C
-    from . import Batch, _lib as L
-    info = plans[0].info()
-    res.ensure(info.out_rows, info.out_cols, info.out_is_complex)
-    pl, pr = res.ptrs(first, len(plans))
-    b = None
-    if len(plans) > 1:
-        prev = C.c_int(0)
-        if len(plans) > 8:   # (the library's default limit is 8 designs per batch; up to 16 on request)
-            L.check(L.load().emagls_set_batch_max(len(plans), C.byref(prev)))
-        try:
-            b = Batch(plans)
-        except L.EmaglsError as e:
-            if e.code != L.ERR_UNSUPPORTED:
-                raise
-        finally:
-            if prev.value:
-                L.check(L.load().emagls_set_batch_max(prev.value, None))
-    if b is not None:
-        try:
-            if share_geometry:
-                b.share_geometry(True)
-            b.execute()
-            b.get_filters_into(pl, pr)
-        finally:
-            b.close()
+def _out_shape(job):
+    """(rows, columns, complex?) of a job's filters: read off a plan of its descriptor."""
+    from . import Plan
+    kw = dict(job)
+    p = Plan(kw["kind"], kw["basis"], kw["order"], kw["fs"], kw["length"], np.asarray(kw["hL"]).shape[0], np.asarray(kw["hL"]).shape[1],
+             kw.get("mic_radius", 0.0), 0 if kw.get("mic_azi") is None else int(np.asarray(kw["mic_azi"]).size),
+             f_trans=kw.get("f_trans", 0.0), atf_taps=0 if kw.get("atf") is None else np.asarray(kw["atf"]).shape[0],
+             natf=0 if kw.get("atf") is None else np.asarray(kw["atf"]).shape[2], sim_order_pad=kw.get("sim_order_pad", 0),
+             **({"nmics": np.asarray(kw["atf"]).shape[1]} if kw.get("atf") is not None else {}))
+    try:
+        i = p.info()
+        return int(i.out_rows), int(i.out_cols), bool(i.out_is_complex)
+    finally:
+        p.close()
+
+
+def _run_share(jobs, res, max_batch, share_geometry=False):
+    """This rank's share of a job list on the library's scheduler (emagls_jobs_run: chunks of one shape as lane batches, several
+    chunks in flight from the library's own threads).  `jobs` = keyword dictionaries of jobs.JobList.add; the filters go straight
+    into `res` (slot i = job i of the share), device to device when `res` lives on the GPU."""
+    from .jobs import JobList
+    if not jobs:
         return
-    lib = L.load()
-    for p in plans:
-        p.execute()
-    for j, p in enumerate(plans):
-        L.check(lib.emagls_plan_get_filters(p._h, C.c_void_p(pl[j]), C.c_void_p(pr[j])))
+    res.ensure(*_out_shape(jobs[0]))
+    jl = JobList()
+    for i, kw in enumerate(jobs):
+        pl, pr = res.ptrs(i, 1)
+        jl.add(out=(pl[0], pr[0]), **kw)
+    jl.run(batch_size=max_batch, in_flight=4, share_geometry=share_geometry)
 
 
-def _run_plan_jobs(n, chunks_per_rank, make_plans, group=None, share_geometry=False):
-    """The shared loop of the job lists below.  `chunks_per_rank[r]` = [(job indices, extra), ...] for rank r;
-    `make_plans(indices, extra)` returns the plans of one chunk with their inputs set.  Every rank runs its chunks, the ranks
-    agree that nobody failed, ONE gather of the device buffers brings the filters to rank 0.  Returns [(wL, wR), ...] in job
-    order on rank 0 (and in a single process), None elsewhere."""
+def _run_job_list(n, shards, make_job, group=None, max_batch=16, share_geometry=False):
+    """The shared loop of the job lists below.  `shards[r]` = the job indices of rank r in the order it runs them (jobs of one shape
+    next to each other: the library cuts chunks where the shape changes); `make_job(j)` = the keyword dictionary of job j.  Every
+    rank runs its share through the library's scheduler, the ranks agree that nobody failed, ONE gather of the device buffers
+    brings the filters to rank 0.  Returns [(wL, wR), ...] in job order on rank 0 (and in a single process), None elsewhere."""
     import torch
     import torch.distributed as dist
     have_pg, rank, world = _pg(group)
     on_device = have_pg and world > 1 and dist.get_backend(group) == "nccl"
-    shards = [[j for idx, _ in ch for j in idx] for ch in chunks_per_rank]
     res = _Results(len(shards[rank]), on_device)
-    err, first = None, 0
+    err = None
     try:
-        for idx, extra in chunks_per_rank[rank]:
-            plans = make_plans(idx, extra)
-            try:
-                _execute_plans(plans, res, first, share_geometry)
-            finally:
-                for p in plans:
-                    p.close()
-            first += len(idx)
+        _run_share([make_job(j) for j in shards[rank]], res, max_batch, share_geometry)
+        if on_device:
+            torch.cuda.synchronize()   # (the library wrote the buffer on its own streams)
     except Exception as e:
         err = e
     _agree_or_raise(err, group)
@@ -355,40 +344,38 @@ def _run_plan_jobs(n, chunks_per_rank, make_plans, group=None, share_geometry=Fa
     return out
 
 
-def _even_chunks(n, world, max_batch):
-    """Equal-shape jobs: longest-processing-time shares, each cut into chunks of at most max_batch."""
-    return [[(s[i:i + max_batch], None) for i in range(0, len(s), max_batch)] for s in shard_jobs(np.ones(n), world)]
+def _even_shards(n, world):
+    """Equal-shape jobs: longest-processing-time shares (the library cuts a share into chunks of at most max_batch)."""
+    return shard_jobs(np.ones(n), world)
 
 
 def emagls2_radius_sweep(hL, hR, hrirGridAziRad, hrirGridZenRad, radii, micGridAziRad, micGridZenRad, order, fs, length,
-                         shDefinition="real", group=None, max_batch=16):
+                         shDefinition="real", group=None, max_batch=16, _one_share_of=None):
     """getEMagLs2Filters (lib/getEMagLs2Filters.m:1-2) for every array radius of `radii` (BASELINE config 4): padded lane batches
     (of 16 designs: one resident sweep launch per batch, batch_cost), whole batches per rank, one gather.  Returns [(wMlsL, wMlsR), ...] in the order of `radii` on rank 0, None elsewhere."""
-    from . import Plan, _lib as L
+    from . import _lib as L
     hL = np.asfortranarray(hL, dtype=np.float64)
     hR = np.asfortranarray(hR, dtype=np.float64)
     radii = [float(r) for r in radii]
     so = [simulation_order(order, fs, r, raw=True) for r in radii]
-    nmics = int(np.asarray(micGridAziRad).size)
+    maz, mzn = np.asarray(micGridAziRad, dtype=np.float64), np.asarray(micGridZenRad, dtype=np.float64)
+    azi, zen = np.asarray(hrirGridAziRad, dtype=np.float64), np.asarray(hrirGridZenRad, dtype=np.float64)
+    nmics = int(maz.size)
     _, _, world = _pg(group)
-    per_rank, _ = shard_lane_batches(padded_lane_batches(so, max_batch), world)
+    per_rank, load = shard_lane_batches(padded_lane_batches(so, max_batch), world if _one_share_of is None else int(_one_share_of))
+    pad_of = {j: pad for bl in per_rank for idx, pad in bl for j in idx}
+    shards = [[j for idx, _ in bl for j in idx] for bl in per_rank]
+    if _one_share_of is not None:   # (measurement: the share of the most loaded of `_one_share_of` ranks, run in this single process)
+        r = int(np.argmax(load))
+        shards = [shards[r]]
 
-    def make_plans(idx, pad):
-        plans = []
-        try:
-            for j in idx:
-                p = Plan(L.KIND_EMAGLS2, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], radii[j], nmics,
-                         sim_order_pad=int(pad) if nmics <= 32 else 0)   # (no padding on the path of more than 32 microphones)
-                plans.append(p)
-                p.set_hrir_grid(hrirGridAziRad, hrirGridZenRad)
-                p.set_mic_grid(micGridAziRad, micGridZenRad)
-                p.set_hrirs(hL, hR)
-        except Exception:
-            for p in plans:
-                p.close()
-            raise
-        return plans
-    return _run_plan_jobs(len(radii), per_rank, make_plans, group)
+    def make_job(j):
+        return dict(kind=L.KIND_EMAGLS2, basis=shDefinition, order=int(order), fs=float(fs), length=int(length), hL=hL, hR=hR, hrir_azi=azi, hrir_zen=zen,
+                    mic_radius=radii[j], mic_azi=maz, mic_zen=mzn, sim_order_pad=int(pad_of[j]) if nmics <= 32 else 0)   # (no padding on the path of more than 32 microphones)
+    out = _run_job_list(len(radii), shards, make_job, group, max_batch)
+    if _one_share_of is not None:
+        return [out[j] for j in shards[0]]
+    return out
 
 
 def emagls_from_atf_subjects(subjects, hrirGridAziZenRad, atfIrs, atfGridAziZenRad, fs, filterLen, fTrans, group=None,
@@ -397,31 +384,18 @@ def emagls_from_atf_subjects(subjects, hrirGridAziZenRad, atfIrs, atfGridAziZenR
     ATF set and HRIR grid (BASELINE config 5): the subjects are spread over the ranks, each rank runs its share in batches
     that compute the ATF side once (Batch.shares_atf_side) and sweep all their subjects in one resident launch; one gather.
     Returns [(wMlsL, wMlsR), ...] in the order of `subjects` on rank 0, None elsewhere."""
-    from . import Plan, _lib as L
+    from . import _lib as L
     hg = np.asarray(hrirGridAziZenRad, dtype=np.float64)
     ag = np.asarray(atfGridAziZenRad, dtype=np.float64)
     atf = np.asfortranarray(atfIrs, dtype=np.float64)
-    taps, M, Da = atf.shape
+    hazi, hzen, aazi, azen = (np.ascontiguousarray(v) for v in (hg[:, 0], hg[:, 1], ag[:, 0], ag[:, 1]))
     _, _, world = _pg(group)
 
-    def make_plans(idx, _):
-        plans = []
-        try:
-            for j in idx:
-                hL = np.asfortranarray(subjects[j][0], dtype=np.float64)
-                hR = np.asfortranarray(subjects[j][1], dtype=np.float64)
-                p = Plan(L.KIND_FROM_ATF, "real", 0, float(fs), int(filterLen), hL.shape[0], hL.shape[1], nmics=M, f_trans=float(fTrans),
-                         atf_taps=taps, natf=Da)
-                plans.append(p)
-                p.set_hrir_grid(hg[:, 0], hg[:, 1])
-                p.set_hrirs(hL, hR)
-                p.set_atfs(atf, ag[:, 0], ag[:, 1])
-        except Exception:
-            for p in plans:
-                p.close()
-            raise
-        return plans
-    return _run_plan_jobs(len(subjects), _even_chunks(len(subjects), world, max_batch), make_plans, group)
+    def make_job(j):
+        return dict(kind=L.KIND_FROM_ATF, basis="real", order=0, fs=float(fs), length=int(filterLen), hL=np.asfortranarray(subjects[j][0], dtype=np.float64),
+                    hR=np.asfortranarray(subjects[j][1], dtype=np.float64), hrir_azi=hazi, hrir_zen=hzen, atf=atf, atf_azi=aazi, atf_zen=azen,
+                    f_trans=float(fTrans))
+    return _run_job_list(len(subjects), _even_shards(len(subjects), world), make_job, group, max_batch)
 
 
 def emagls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, micRadius, micGridAziRad, micGridZenRad, order, fs, length,
@@ -432,7 +406,7 @@ def emagls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, micRadius, micGri
     batches that compute the geometry stages once (Batch.share_geometry: SH matrices, array model, every bin's regularised
     inverse) and sweep all their sets in one resident launch (designs with more than 32 channels: one at a time); one gather.
     Same filters as the single calls.  Returns [(wL, wR), ...] in the order of `subjects` on rank 0, None elsewhere."""
-    from . import Plan, _lib as L
+    from . import _lib as L
     K = {"emagls": L.KIND_EMAGLS, "emagls2": L.KIND_EMAGLS2, "emainch": L.KIND_EMA_CH}[kind]
     azi = np.asarray(hrirGridAziRad, dtype=np.float64)
     zen = np.asarray(hrirGridZenRad, dtype=np.float64)
@@ -440,23 +414,10 @@ def emagls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, micRadius, micGri
     mzn = None if micGridZenRad is None else np.asarray(micGridZenRad, dtype=np.float64)
     _, _, world = _pg(group)
 
-    def make_plans(idx, _):
-        plans = []
-        try:
-            for j in idx:
-                hL = np.asfortranarray(subjects[j][0], dtype=np.float64)
-                hR = np.asfortranarray(subjects[j][1], dtype=np.float64)
-                p = Plan(K, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], float(micRadius), maz.size)
-                plans.append(p)
-                p.set_hrir_grid(azi, zen)
-                p.set_mic_grid(maz, mzn)
-                p.set_hrirs(hL, hR)
-        except Exception:
-            for p in plans:
-                p.close()
-            raise
-        return plans
-    return _run_plan_jobs(len(subjects), _even_chunks(len(subjects), world, max_batch), make_plans, group, share_geometry=True)
+    def make_job(j):
+        return dict(kind=K, basis=shDefinition, order=int(order), fs=float(fs), length=int(length), hL=np.asfortranarray(subjects[j][0], dtype=np.float64),
+                    hR=np.asfortranarray(subjects[j][1], dtype=np.float64), hrir_azi=azi, hrir_zen=zen, mic_radius=float(micRadius), mic_azi=maz, mic_zen=mzn)
+    return _run_job_list(len(subjects), _even_shards(len(subjects), world), make_job, group, max_batch, share_geometry=True)
 
 
 def magls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, order, fs, length, shDefinition="real", group=None, max_batch=8):
@@ -465,25 +426,13 @@ def magls_hrir_sets(subjects, hrirGridAziRad, hrirGridZenRad, order, fs, length,
     side once (Batch.share_geometry) and sweep all their sets in one resident launch (orders 5..7, more than 32 channels: one
     design at a time); one gather.  Same filters as the single calls.  Returns [(wL, wR), ...] in the order of `subjects` on
     rank 0, None elsewhere."""
-    from . import Plan, _lib as L
+    from . import _lib as L
     azi = np.asarray(hrirGridAziRad, dtype=np.float64)
     zen = None if hrirGridZenRad is None else np.asarray(hrirGridZenRad, dtype=np.float64)
     K = L.KIND_MAGLS if zen is not None else L.KIND_MAGLS_2D
     _, _, world = _pg(group)
 
-    def make_plans(idx, _):
-        plans = []
-        try:
-            for j in idx:
-                hL = np.asfortranarray(subjects[j][0], dtype=np.float64)
-                hR = np.asfortranarray(subjects[j][1], dtype=np.float64)
-                p = Plan(K, shDefinition, int(order), float(fs), int(length), hL.shape[0], hL.shape[1], 0.0, 0)
-                plans.append(p)
-                p.set_hrir_grid(azi, zen)
-                p.set_hrirs(hL, hR)
-        except Exception:
-            for p in plans:
-                p.close()
-            raise
-        return plans
-    return _run_plan_jobs(len(subjects), _even_chunks(len(subjects), world, max_batch), make_plans, group, share_geometry=True)
+    def make_job(j):
+        return dict(kind=K, basis=shDefinition, order=int(order), fs=float(fs), length=int(length), hL=np.asfortranarray(subjects[j][0], dtype=np.float64),
+                    hR=np.asfortranarray(subjects[j][1], dtype=np.float64), hrir_azi=azi, hrir_zen=zen)
+    return _run_job_list(len(subjects), _even_shards(len(subjects), world), make_job, group, max_batch, share_geometry=True)

@@ -2874,6 +2874,7 @@ int emagls_set_device(int device) {
 
 void emagls_sets_cache_clear_internal();
 void emagls_atfsets_cache_clear_internal();
+void emagls_jobs_cache_clear_internal();
 int emagls_cache_clear(void) {
     return guarded([&] {
         {
@@ -2888,6 +2889,7 @@ int emagls_cache_clear(void) {
         }
         emagls_sets_cache_clear_internal();
         emagls_atfsets_cache_clear_internal();
+        emagls_jobs_cache_clear_internal();
     });
 }
 
@@ -3794,6 +3796,209 @@ SetsCache g_atfsets[2];
 void emagls_atfsets_cache_clear_internal() {
     std::lock_guard<std::mutex> lk(g_atfsets_mu);
     for (auto& c : g_atfsets) c.release();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Job lists (independent designs are the unit of parallelism -- the loop over array radii / HRIR sets / subjects that
+// a user of the reference writes around one of its functions, testEMagLs.m:75-95).  emagls_jobs_run takes the list, cuts it into
+// chunks of consecutive jobs of one shape, and keeps up to `in_flight` chunks between input upload and result collection: every
+// chunk in flight has a worker thread of the library (uploads, the batch's graph launches, the wait for its filters), so that one
+// chunk's inputs travel and another's results are collected while the GPU works on the others.  The plans and lane batches of a
+// chunk shape stay resident between calls (released by emagls_cache_clear) whenever the chunk's designs can be re-used as they are
+// (same descriptors); array radii that change from chunk to chunk get plans of their own and release them.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct JobSlot {
+    std::string key;                  // the descriptors of the slot's designs, byte for byte
+    int device = -1;
+    std::vector<emagls_plan*> plans;
+    emagls_batch* batch = nullptr;
+    std::vector<std::vector<double>> grids;   // per plan: hrir azi | zen | mic azi | zen as last uploaded (unchanged grids are not uploaded again)
+    uint64_t last_use = 0;
+    ~JobSlot() {
+        if (batch) emagls_batch_destroy(batch);
+        for (auto* p : plans) emagls_plan_destroy(p);
+    }
+};
+std::mutex g_jobs_mu;
+std::vector<std::unique_ptr<JobSlot>> g_jobs_free;   // resident slots nobody uses at the moment
+std::atomic<int> g_jobs_prof{0};                     // emagls_jobs_set_profiling: the chunks' batches time their sweep launches
+uint64_t g_jobs_tick = 0;
+constexpr size_t JOBS_RESIDENT_DESIGNS = 4 * REG_SWEEP_MAX;   // designs kept resident between calls (0.19 GB each at config 3)
+
+void check_rc(int rc) { if (rc != EMAGLS_OK) throw Error(rc, g_last_error); }
+// what makes two designs share a lane batch: everything but the array radius inside one (padded) simulation-order class
+std::string job_shape(const emagls_design_desc& d) {
+    emagls_design_desc k = d;
+    if (array_kind(d.kind) && d.sim_order_pad > 0) {
+        const int own = std::max(d.kind == EMAGLS_KIND_EMAGLS2 ? SMAIR_DEFAULT_ORDER : d.order, (int)std::ceil(d.fs * kPi * d.mic_radius / C_SOUND));
+        if (own <= d.sim_order_pad) k.mic_radius = 0.0;   // (laid out for sim_order_pad whatever the radius)
+    }
+    return std::string(reinterpret_cast<const char*>(&k), sizeof k);
+}
+void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
+    DeviceGuard dg(device);
+    std::string key;
+    for (int j = 0; j < n; ++j) key.append(reinterpret_cast<const char*>(&jobs[j].desc), sizeof(emagls_design_desc));
+    std::unique_ptr<JobSlot> slot;
+    {
+        std::lock_guard<std::mutex> lk(g_jobs_mu);
+        for (size_t i = 0; i < g_jobs_free.size(); ++i)
+            if (g_jobs_free[i]->device == device && g_jobs_free[i]->key == key) { slot = std::move(g_jobs_free[i]); g_jobs_free.erase(g_jobs_free.begin() + i); break; }
+    }
+    if (!slot) {
+        slot.reset(new JobSlot);
+        slot->key = key; slot->device = device;
+        slot->grids.resize((size_t)n);
+        for (int j = 0; j < n; ++j) {
+            emagls_plan* p = nullptr;
+            check_rc(emagls_plan_create(&jobs[j].desc, &p));
+            slot->plans.push_back(p);
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        const emagls_job& jb = jobs[j];
+        emagls_plan* p = slot->plans[(size_t)j];
+        const emagls_design_desc& d = jb.desc;
+        // grids (host arrays): uploaded when they differ from what the plan holds
+        std::vector<double> g;
+        auto app = [&](const double* a, int64_t m) { if (a) g.insert(g.end(), a, a + m); else g.push_back(-1e300); };
+        const bool has_mics = array_kind(d.kind);
+        app(jb.hrir_azi, d.ndirs); app(jb.hrir_zen, d.ndirs);
+        if (has_mics) { app(jb.mic_azi, d.nmics); app(jb.mic_zen, d.nmics); }
+        if (g != slot->grids[(size_t)j]) {
+            if (!jb.hrir_azi) throw Error(EMAGLS_ERR_ARG, "job without an HRIR grid");
+            check_rc(emagls_plan_set_hrir_grid(p, jb.hrir_azi, jb.hrir_zen));
+            if (has_mics) {
+                if (!jb.mic_azi) throw Error(EMAGLS_ERR_ARG, "array design without a microphone grid");
+                check_rc(emagls_plan_set_mic_grid(p, jb.mic_azi, jb.mic_zen));
+            }
+            slot->grids[(size_t)j] = std::move(g);
+        }
+        if (d.kind == EMAGLS_KIND_FROM_ATF) {
+            if (!jb.atf || !jb.atf_azi || !jb.atf_zen) throw Error(EMAGLS_ERR_ARG, "FromAtf job without its ATF set");
+            check_rc(emagls_plan_set_atfs(p, jb.atf, jb.atf_azi, jb.atf_zen));
+        }
+        if (!jb.hL || !jb.hR || !jb.wL || !jb.wR) throw Error(EMAGLS_ERR_ARG, "job without HRIRs or without room for its filters");
+        check_rc(emagls_plan_set_hrirs(p, jb.hL, jb.hR));
+    }
+    if (n > 1 && !slot->batch) {
+        g_batch_max_override = REG_SWEEP_MAX;
+        const int rc = emagls_batch_create(slot->plans.data(), n, &slot->batch);
+        g_batch_max_override = 0;
+        if (rc != EMAGLS_OK && rc != EMAGLS_ERR_UNSUPPORTED) check_rc(rc);   // (unsupported as a batch -- e.g. more than 32 channels: plan by plan)
+        if (rc != EMAGLS_OK) slot->batch = nullptr;
+    }
+    if (slot->batch && (flags & EMAGLS_JOBS_SHARE_GEOMETRY)) {
+        // HRIR sets on one geometry: the geometry stages once per chunk (the library compares the grids on the device, and a chunk whose
+        // designs do not agree runs them as independent designs -- emagls_batch_set_geometry_sharing)
+        const int kind = jobs[0].desc.kind;
+        if (kind != EMAGLS_KIND_FROM_ATF && kind != EMAGLS_KIND_EMA_SH) check_rc(emagls_batch_set_geometry_sharing(slot->batch, 1));
+    }
+    if (slot->batch) {
+        std::vector<void*> wl((size_t)n), wr((size_t)n);
+        for (int j = 0; j < n; ++j) { wl[(size_t)j] = jobs[j].wL; wr[(size_t)j] = jobs[j].wR; }
+        if (slot->batch->prof_level != g_jobs_prof.load()) check_rc(emagls_batch_set_profiling(slot->batch, g_jobs_prof.load()));
+        check_rc(emagls_batch_execute(slot->batch));
+        check_rc(emagls_batch_get_filters(slot->batch, wl.data(), wr.data()));
+    } else {
+        for (int j = 0; j < n; ++j) check_rc(emagls_plan_execute(slot->plans[(size_t)j]));
+        for (int j = 0; j < n; ++j) check_rc(emagls_plan_get_filters(slot->plans[(size_t)j], jobs[j].wL, jobs[j].wR));
+    }
+    // keep the slot when its designs can serve another chunk as they are
+    std::lock_guard<std::mutex> lk(g_jobs_mu);
+    slot->last_use = ++g_jobs_tick;
+    g_jobs_free.push_back(std::move(slot));
+    size_t resident = 0;
+    for (auto& f : g_jobs_free) resident += f->plans.size();
+    while (resident > JOBS_RESIDENT_DESIGNS && g_jobs_free.size() > 1) {   // least recently used first
+        size_t old = 0;
+        for (size_t i = 1; i < g_jobs_free.size(); ++i) if (g_jobs_free[i]->last_use < g_jobs_free[old]->last_use) old = i;
+        resident -= g_jobs_free[old]->plans.size();
+        g_jobs_free.erase(g_jobs_free.begin() + old);
+    }
+}
+}  // namespace
+void emagls_jobs_cache_clear_internal() {
+    std::lock_guard<std::mutex> lk(g_jobs_mu);
+    g_jobs_free.clear();
+}
+
+int emagls_jobs_set_profiling(int level) {
+    return guarded([&] { g_jobs_prof.store(level > 0 ? 1 : 0); });
+}
+int emagls_jobs_sweep_times(double* ms, int* designs, int capacity, int* count) {
+    return guarded([&] {
+        if (!count || capacity < 0 || (capacity > 0 && (!ms || !designs))) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        std::lock_guard<std::mutex> lk(g_jobs_mu);
+        int n = 0;
+        for (auto& f : g_jobs_free) {
+            if (!f->batch || f->batch->prof_level < 1 || !f->batch->sweep_ev[0] || f->batch->eager_runs < 1) continue;
+            if (n < capacity) {
+                DeviceGuard dg(f->device);
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, f->batch->sweep_ev[0], f->batch->sweep_ev[1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+                ms[n] = t; designs[n] = (int)f->plans.size();
+            }
+            ++n;
+        }
+        *count = n;
+    });
+}
+
+int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int in_flight, int flags) {
+    return guarded([&] {
+        if (!jobs || njobs < 0) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        if (njobs == 0) return;
+        if (batch_size <= 0) batch_size = REG_SWEEP_MAX;
+        if (in_flight <= 0) in_flight = 4;
+        batch_size = std::min(batch_size, REG_SWEEP_MAX);
+        int device = 0;
+        HIP_CHECK(hipGetDevice(&device));
+        // chunks: consecutive jobs of one shape; more than 16 designs per chunk only where the register-resident sweep takes them
+        // (array designs on the built-in basis; decided when the batch is created: a refused batch of 17 ... 32 is an error the caller
+        // avoids by asking for batches of 16)
+        std::vector<std::pair<int64_t, int>> chunks;
+        for (int64_t first = 0; first < njobs;) {
+            const std::string shape = job_shape(jobs[first].desc);
+            const int cap = array_kind(jobs[first].desc.kind) && !jobs[first].desc.custom_basis && !jobs[first].desc.diffuseness ? batch_size
+                                                                                                                              : std::min(batch_size, SWEEP_MULTI_MAX);
+            int n = 1;
+            while (first + n < njobs && n < cap && job_shape(jobs[first + n].desc) == shape) ++n;
+            chunks.emplace_back(first, n);
+            first += n;
+        }
+        // workers: each takes the next chunk until none is left; the first error stops the hand-out and is reported
+        std::atomic<size_t> next{0};
+        std::mutex err_mu;
+        int err_code = EMAGLS_OK;
+        std::string err_msg;
+        auto work = [&] {
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= chunks.size()) return;
+                {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (err_code != EMAGLS_OK) return;
+                }
+                try {
+                    jobs_run_chunk(jobs + chunks[c].first, chunks[c].second, device, flags);
+                } catch (const Error& e) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (err_code == EMAGLS_OK) { err_code = e.code; err_msg = e.what(); }
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (err_code == EMAGLS_OK) { err_code = EMAGLS_ERR_HIP; err_msg = e.what(); }
+                }
+            }
+        };
+        const int nthreads = (int)std::min<size_t>((size_t)in_flight, chunks.size());
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+        if (err_code != EMAGLS_OK) throw Error(err_code, err_msg);
+    });
 }
 int emagls_from_atf_hrir_sets(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, int64_t nsets, const double* hrir_azi,
                               const double* hrir_zen, const double* atf_irs, int64_t atf_taps, int64_t nmics, int64_t natf, const double* atf_azi,

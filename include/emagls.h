@@ -341,6 +341,41 @@ int emagls_set_batch_max(int max_designs, int* previous);
  * emagls_batch_shares_geometry reports what the last execute did. */
 int emagls_batch_set_geometry_sharing(emagls_batch* batch, int enable);
 int emagls_batch_shares_geometry(emagls_batch* batch, int* shared);
+/* ---- job lists ---------------------------------------------------------------------------------------------------
+ * Independent designs are the unit of parallelism of the reference's users: the loop over array radii, HRIR sets or subjects
+ * around one of its functions (testEMagLs.m:75-95, testEMagLsFromAtfs.m:72-73).  One job = one design: its descriptor, its inputs
+ * and room for its filters.  hL / hR / atf and wL / wR may be host or device buffers of the current device (device buffers are
+ * read and written stream-ordered: nothing crosses PCIe); the grids are host arrays. */
+typedef struct emagls_job {
+    emagls_design_desc desc;
+    const double* hL;           /* [nsamp x ndirs] */
+    const double* hR;
+    const double* hrir_azi;     /* [ndirs] */
+    const double* hrir_zen;     /* [ndirs]; NULL: horizontal grid (MAGLS_2D) */
+    const double* mic_azi;      /* [nmics], array designs */
+    const double* mic_zen;      /* [nmics]; NULL: equatorial array (EMA_CH / EMA_SH) */
+    const double* atf;          /* FROM_ATF: [atf_taps x nmics x natf] */
+    const double* atf_azi;      /* FROM_ATF: [natf] */
+    const double* atf_zen;
+    void* wL;                   /* [len x channels] real, or interleaved complex for a complex basis (emagls_plan_info.out_is_complex) */
+    void* wR;
+} emagls_job;
+/* Runs the whole list and returns when every job's filters are in place.  Consecutive jobs of one shape form chunks of up to
+ * batch_size designs (<= 0: 32; more than 16 only for array designs that take the register-resident sweep) that run as lane
+ * batches -- one launch of every kernel for the chunk, one resident sweep launch --; up to in_flight chunks (<= 0: 4) are between
+ * upload and collection at any time, each driven by a thread of the library, so that uploads, launches and the collection of
+ * results overlap with the GPU's work on the other chunks.  Plans and batches of chunks whose descriptors repeat stay resident
+ * between calls (emagls_cache_clear releases them).  Same filters as the single calls.
+ * flags: EMAGLS_JOBS_SHARE_GEOMETRY -- the designs of a chunk that agree in everything but their HRIRs (checked on the device) compute
+ * the geometry stages once (emagls_batch_set_geometry_sharing; the filters are bit-identical to the independent designs'). */
+#define EMAGLS_JOBS_SHARE_GEOMETRY 1
+int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int in_flight, int flags);
+/* Measurement hooks of the job lists (bench.py's roofline figure): level > 0 makes the chunks' batches bracket their sweep launch
+ * with HIP events on the stream it is launched on; emagls_jobs_sweep_times then reports, for every resident chunk that ran since,
+ * the duration of its LAST sweep launch (ms) and the designs it covered (count: chunks available, capacity: room in the arrays). */
+int emagls_jobs_set_profiling(int level);
+int emagls_jobs_sweep_times(double* ms, int* designs, int capacity, int* count);
+
 /* HRIR sets on ONE grid (and, for the array kinds, ONE array) in one call -- the loop
  *     for i = 1:nsets, [wL(:,:,i), wR(:,:,i)] = getEMagLsFilters(hL(:,:,i), hR(:,:,i), grid..., array..., order, fs, len, shDefinition); end
  * around lib/getLsFilters.m:30 / getMagLsFilters.m:30 / getMagLsFilters2D.m:1 (hrir_zen NULL) / getEMagLsFilters.m:32 /

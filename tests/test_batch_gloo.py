@@ -96,44 +96,37 @@ def test_single_process_lane_batches():
     assert len(out) == 3 and all(np.array_equal(out[j][0], _design(jobs[j])[0]) for j in range(3))
 
 
-class _FakePlan:
-    """Stands in for emagls_amd.Plan in the CPU tests of the plan-based job runner (the library needs a GPU)."""
-    def __init__(self, job):
-        self.job = job
-
-    def close(self):
-        pass
-
-
-def _fake_execute(plans, res, first, share_geometry=False):
-    """What batch._execute_plans does, without the library: the filters of every plan written through the addresses `res` hands
-    out (column-major len x channels, complex interleaved), exactly as emagls_batch_get_filters would."""
+def _fake_share(jobs, res, max_batch, share_geometry=False):
+    """What batch._run_share does, without the library: the filters of every job written through the addresses `res` hands out
+    (column-major len x channels, complex interleaved), exactly as emagls_jobs_run would."""
     import ctypes as C
-    cplx = plans[0].job[1]
+    if not jobs:
+        return
+    cplx = jobs[0]["job"][1]
     res.ensure(16, 5, cplx)
-    pl, pr = res.ptrs(first, len(plans))
-    for j, p in enumerate(plans):
-        if p.job[0] < 0:
+    for i, kw in enumerate(jobs):
+        if kw["job"][0] < 0:
             raise ValueError("unsupported shape (test)")
-        wL, wR = _design(p.job)
-        for w, addr in ((wL, pl[j]), (wR, pr[j])):
+        pl, pr = res.ptrs(i, 1)
+        wL, wR = _design(kw["job"])
+        for w, addr in ((wL, pl[0]), (wR, pr[0])):
             flat = np.asfortranarray(w).ravel(order="F")
             flat = flat.view(np.float64) if cplx else flat
             C.memmove(addr, flat.ctypes.data, flat.nbytes)
 
 
-def _plan_jobs_worker(rank, world, port, cplx, fail, q):
+def _job_list_worker(rank, world, port, cplx, fail, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from emagls_amd import batch as B
-    B._execute_plans = _fake_execute
+    B._run_share = _fake_share
     jobs = [(0.02 + 0.004 * j, cplx) for j in range(7)]
     if fail:
         jobs[5] = (-1.0, cplx)   # (lands on one rank only)
-    chunks = B._even_chunks(len(jobs), world, 3)
+    shards = B._even_shards(len(jobs), world)
     try:
-        out = B._run_plan_jobs(len(jobs), chunks, lambda idx, _: [_FakePlan(jobs[j]) for j in idx], None)
+        out = B._run_job_list(len(jobs), shards, lambda j: {"job": jobs[j]}, None, 3)
     except Exception as e:
         q.put((rank, type(e).__name__))
         dist.destroy_process_group()
@@ -148,13 +141,14 @@ def _plan_jobs_worker(rank, world, port, cplx, fail, q):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-def test_plan_job_runner_gathers_device_layout_buffers(cplx):
-    """batch._run_plan_jobs (the loop behind the four job lists): chunks per rank, the filters written in place into the gather's
-    own buffer, one gather, job order restored on rank 0 -- two gloo ranks, the library replaced by a stand-in."""
+def test_job_list_runner_gathers_device_layout_buffers(cplx):
+    """batch._run_job_list (the loop behind the four job lists): a share per rank through the library's scheduler, the filters
+    written in place into the gather's own buffer, one gather, job order restored on rank 0 -- two gloo ranks, the library replaced
+    by a stand-in."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_plan_jobs_worker, args=(r, 2, port, cplx, False, q)) for r in range(2)]
+    procs = [ctx.Process(target=_job_list_worker, args=(r, 2, port, cplx, False, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -169,7 +163,7 @@ def test_a_failing_rank_does_not_leave_the_others_in_the_gather():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_plan_jobs_worker, args=(r, 2, port, False, True, q)) for r in range(2)]
+    procs = [ctx.Process(target=_job_list_worker, args=(r, 2, port, False, True, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -179,18 +173,18 @@ def test_a_failing_rank_does_not_leave_the_others_in_the_gather():
     assert sorted(got.values()) == ["RuntimeError", "ValueError"]
 
 
-def test_plan_job_runner_single_process():
+def test_job_list_runner_single_process():
     from emagls_amd import batch as B
-    keep = B._execute_plans
-    B._execute_plans = _fake_execute
+    keep = B._run_share
+    B._run_share = _fake_share
     try:
         jobs = [(0.02 + 0.004 * j, True) for j in range(5)]
-        out = B._run_plan_jobs(5, B._even_chunks(5, 1, 2), lambda idx, _: [_FakePlan(jobs[j]) for j in idx], None)
+        out = B._run_job_list(5, B._even_shards(5, 1), lambda j: {"job": jobs[j]}, None, 2)
         assert all(np.array_equal(out[j][0], _design(jobs[j])[0]) and np.isfortran(out[j][0]) for j in range(5))
         with pytest.raises(ValueError):
-            B._run_plan_jobs(1, [[([0], None)]], lambda idx, _: [_FakePlan((-1.0, False))], None)
+            B._run_job_list(1, [[0]], lambda j: {"job": (-1.0, False)}, None, 2)
     finally:
-        B._execute_plans = keep
+        B._run_share = keep
 
 
 def _gpu_worker(rank, world, port, q):

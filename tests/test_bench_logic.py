@@ -15,30 +15,15 @@ def _bench():
 
 
 def test_schedule_processes_exactly_the_requested_designs():
-    """The resident configuration (4 x 32: four batches in flight) does not depend on --steps: a region of K designs is K // 32 full batches and one
-    partial batch (issued first: the batch with the least work reaches its sweep first), never a design more."""
+    """The resident configuration (4 x 32: four chunks in flight) does not depend on --steps: a region of K designs is K // 32 full chunks and one
+    partial chunk (the order in which emagls_jobs_run cuts a list of equal-shape jobs), never a design more."""
     b = _bench()
     sch = b.schedule
     assert (b.SLOTS, b.BSZ) == (4, 32)
     for k in range(1, 300):
         s = sch(k)
-        assert sum(s) == k and all(x == 32 for x in s[1:]) and 1 <= s[0] <= 32
-    assert sch(20) == [20] and sch(128) == [32] * 4 and sch(5, 8) == [5] and sch(20, 8) == [4, 8, 8] and sch(20, 16) == [4, 16]
-
-
-def test_schedule_split_experiment_keeps_the_design_count(monkeypatch):
-    """EMAGLS_BENCH_SPLIT (an experiment knob: the partial batch and one full batch re-divided) never changes how many designs
-    a timed region holds, and values that do not fit fall back to the default division."""
-    b = _bench()
-    for split in (1, 8, 10, 12, 16, 19, 40):
-        monkeypatch.setenv("EMAGLS_BENCH_SPLIT", str(split))
-        for k in (5, 16, 20, 36, 37, 128):
-            s = b.schedule(k, 16)
-            assert sum(s) == k and all(1 <= x <= 16 for x in s)
-    monkeypatch.setenv("EMAGLS_BENCH_SPLIT", "12")
-    assert b.schedule(20, 16) == [12, 8] and b.schedule(36, 16) == [12, 16, 8] and b.schedule(128, 16) == [16] * 8
-    monkeypatch.setenv("EMAGLS_BENCH_SPLIT", "2")     # (the rest would be 18 > 16 designs: default division)
-    assert b.schedule(20, 16) == [4, 16]
+        assert sum(s) == k and all(x == 32 for x in s[:-1]) and 1 <= s[-1] <= 32
+    assert sch(20) == [20] and sch(128) == [32] * 4 and sch(5, 8) == [5] and sch(20, 8) == [8, 8, 4] and sch(20, 16) == [16, 4]
 
 
 def test_gpus_flag_spawns_fresh_ranks(tmp_path):

@@ -1,0 +1,72 @@
+"""The library's job scheduler (emagls_jobs_run, include/emagls.h) against the single calls: the loop over HRIR sets / array radii /
+subjects that a user of the reference writes around one of its functions (testEMagLs.m:75-95), handed over in one call."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def thin(grids, hrirs):
+    sub = slice(0, 2702, 3)
+    return dict(hL=hrirs[0][:, sub], hR=hrirs[1][:, sub], azi=grids["azi"][sub], zen=grids["zen"][sub])
+
+
+def test_job_list_equals_the_single_calls(grids, thin):
+    """A mixed list -- 37 eMagLS designs on their own HRIR sets (chunks of 32 + 5: the first on the register-resident sweep with
+    twelve waves per workgroup), 3 eMagLS2 designs on different radii of one simulation-order class, 2 MagLS designs -- through
+    emagls_jobs_run with host arrays in and out; every job's filters equal the single call's (the lane batches are bit-identical
+    to single plans; the one-shot entry points take the same kernels)."""
+    import emagls_amd as E
+    from emagls_amd import _lib as L
+    from emagls_amd.jobs import JobList
+    azi, zen, maz, mzn = thin["azi"], thin["zen"], grids["mic_azi"], grids["mic_zen"]
+    rng = np.random.default_rng(7)
+    sets = [(thin["hL"] * (1.0 + 0.05 * rng.standard_normal()), thin["hR"] * (1.0 + 0.05 * rng.standard_normal())) for _ in range(37)]
+    jl = JobList()
+    for hL, hR in sets:
+        jl.add(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, hL, hR, azi, zen, mic_radius=0.042, mic_azi=maz, mic_zen=mzn, out_shape=(128, 25, True))
+    radii = [0.0470, 0.0471, 0.0473]
+    for r in radii:
+        jl.add(L.KIND_EMAGLS2, "real", 4, 48000.0, 128, thin["hL"], thin["hR"], azi, zen, mic_radius=r, mic_azi=maz, mic_zen=mzn, sim_order_pad=21,
+               out_shape=(128, 32, False))
+    for hL, hR in sets[:2]:
+        jl.add(L.KIND_MAGLS, "real", 4, 48000.0, 128, hL, hR, azi, zen, out_shape=(128, 25, False))
+    jl.run()
+    res = jl.results()
+    worst = 0.0
+    for j in (0, 5, 31, 32, 36):
+        w = E.getEMagLsFilters(sets[j][0], sets[j][1], azi, zen, 0.042, maz, mzn, 4, 48000.0, 128, "complex")
+        worst = max(worst, rel(res[j][0], w[0]), rel(res[j][1], w[1]))
+    for i, r in enumerate(radii):
+        w = E.getEMagLs2Filters(thin["hL"], thin["hR"], azi, zen, r, maz, mzn, 4, 48000.0, 128, "real")
+        worst = max(worst, rel(res[37 + i][0], w[0]), rel(res[37 + i][1], w[1]))
+    for i in range(2):
+        w = E.getMagLsFilters(sets[i][0], sets[i][1], azi, zen, 4, 48000.0, 128, "real")
+        worst = max(worst, rel(res[40 + i][0], w[0]), rel(res[40 + i][1], w[1]))
+    print(f"job list of 42 designs (3 kinds, 5 chunks) vs the single calls: worst rel = {worst:.3e}")
+    assert worst < 1e-9
+    # the same list again (resident chunks, replayed graphs), with the designs of a chunk sharing their geometry: bit-identical
+    jl.run(share_geometry=True)
+    res2 = jl.results()
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(res, res2))
+    L.check(L.load().emagls_cache_clear())
+
+
+def test_job_list_reports_a_failing_job(thin, grids):
+    """A job the library cannot run (an array design without its microphone grid) fails the call with its message; the jobs before
+    it may have run, nothing hangs."""
+    from emagls_amd import _lib as L
+    from emagls_amd.jobs import JobList
+    jl = JobList()
+    jl.add(L.KIND_EMAGLS, "real", 4, 48000.0, 128, thin["hL"], thin["hR"], thin["azi"], thin["zen"], mic_radius=0.042, mic_azi=grids["mic_azi"],
+           mic_zen=grids["mic_zen"], out_shape=(128, 25, False))
+    jl.add(L.KIND_EMAGLS, "real", 4, 48000.0, 128, thin["hL"], thin["hR"], thin["azi"], thin["zen"], mic_radius=0.05, nmics=32, out_shape=(128, 25, False))
+    with pytest.raises(L.EmaglsError) as e:
+        jl.run()
+    assert "microphone grid" in str(e.value)
+    L.check(L.load().emagls_cache_clear())

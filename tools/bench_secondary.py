@@ -147,6 +147,29 @@ def config4_rank_share(world=8, rank=None, reps=4, max_batch=16):
             "ms_per_share": round(dt * 1e3, 3), "filter_sets_per_s": round(n / dt, 1)}
 
 
+def config4_rank_share_runner(world=8, reps=3, max_batch=16):
+    """The same share through the PRODUCT's runner: emagls_amd.batch.emagls2_radius_sweep with host arrays (the HRIRs travel over
+    PCIe once per design, the plans of every chunk are created inside the call -- the radii differ from chunk to chunk -- and the
+    filters come back to the host), the library's scheduler keeping the rank's chunks in flight."""
+    from emagls_amd import synth, _lib as L
+    from emagls_amd.batch import emagls2_radius_sweep
+    azi, zen, maz, mzn = _grids()
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen)
+    radii = np.linspace(0.02, 0.10, 256)
+    ts = []
+    n = 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = emagls2_radius_sweep(hL, hR, azi, zen, radii, maz, mzn, 4, 48000.0, 1024, "real", max_batch=max_batch, _one_share_of=world)
+        ts.append(time.perf_counter() - t0)
+        n = len(out)
+        L.check(L.load().emagls_cache_clear())
+    dt = float(np.median(ts))
+    return {"ranks": world, "designs": n, "max_batch": max_batch, "s_per_share_runs": [round(t, 4) for t in ts], "ms_per_share": round(dt * 1e3, 3),
+            "filter_sets_per_s": round(n / dt, 1),
+            "note": "emagls_amd.batch.emagls2_radius_sweep (emagls_jobs_run underneath), host arrays in and out, plan creation inside the call"}
+
+
 def em64(reps=2):
     """A 64-capsule array (33..64 channels: the plain S-space path of wide_array.hip): getEMagLs2Filters, 64 microphones,
     r = 4.2 cm, 2702 directions, 1024 taps -- one design at a time."""
@@ -413,6 +436,10 @@ def run():
         out["config4_rank_share"] = config4_rank_share()
     except Exception as e:
         out["config4_rank_share"] = {"error": repr(e)}
+    try:
+        out["config4_rank_share_through_the_runner"] = config4_rank_share_runner()
+    except Exception as e:
+        out["config4_rank_share_through_the_runner"] = {"error": repr(e)}
     try:
         out["config3_hrir_sets_on_one_geometry"] = config3_hrir_sets()
     except Exception as e:
