@@ -268,11 +268,12 @@ def _out_shape(job):
     """(rows, columns, complex?) of a job's filters: read off a plan of its descriptor."""
     from . import Plan
     kw = dict(job)
-    p = Plan(kw["kind"], kw["basis"], kw["order"], kw["fs"], kw["length"], np.asarray(kw["hL"]).shape[0], np.asarray(kw["hL"]).shape[1],
-             kw.get("mic_radius", 0.0), 0 if kw.get("mic_azi") is None else int(np.asarray(kw["mic_azi"]).size),
-             f_trans=kw.get("f_trans", 0.0), atf_taps=0 if kw.get("atf") is None else np.asarray(kw["atf"]).shape[0],
-             natf=0 if kw.get("atf") is None else np.asarray(kw["atf"]).shape[2], sim_order_pad=kw.get("sim_order_pad", 0),
-             **({"nmics": np.asarray(kw["atf"]).shape[1]} if kw.get("atf") is not None else {}))
+    nsamp, ndirs = np.asarray(kw["hL"]).shape
+    atf = kw.get("atf")
+    nmics = np.asarray(atf).shape[1] if atf is not None else (0 if kw.get("mic_azi") is None else int(np.asarray(kw["mic_azi"]).size))
+    p = Plan(kw["kind"], kw["basis"], kw["order"], kw["fs"], kw["length"], nsamp, ndirs, kw.get("mic_radius", 0.0), nmics,
+             f_trans=kw.get("f_trans", 0.0), atf_taps=0 if atf is None else np.asarray(atf).shape[0],
+             natf=0 if atf is None else np.asarray(atf).shape[2], sim_order_pad=kw.get("sim_order_pad", 0))
     try:
         i = p.info()
         return int(i.out_rows), int(i.out_cols), bool(i.out_is_complex)

@@ -3,12 +3,14 @@
 // order: lib/getEMagLsFilters.m:44-48, dependencies/getSMAIRMatrix.m:95); all array arithmetic runs
 // in the HIP kernels.  There is no CPU fallback: without a GPU every entry point returns an error.
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -3815,6 +3817,7 @@ struct JobSlot {
     emagls_batch* batch = nullptr;
     std::vector<std::vector<double>> grids;   // per plan: hrir azi | zen | mic azi | zen as last uploaded (unchanged grids are not uploaded again)
     uint64_t last_use = 0;
+    int runs = 0;                             // executes so far (the first two are the eager run and the graph capture)
     ~JobSlot() {
         if (batch) emagls_batch_destroy(batch);
         for (auto* p : plans) emagls_plan_destroy(p);
@@ -3823,21 +3826,31 @@ struct JobSlot {
 std::mutex g_jobs_mu;
 std::vector<std::unique_ptr<JobSlot>> g_jobs_free;   // resident slots nobody uses at the moment
 std::atomic<int> g_jobs_prof{0};                     // emagls_jobs_set_profiling: the chunks' batches time their sweep launches
+// A chunk's first two executes (the eager run with its one-time function attributes and lazy module loads, then the hipGraph capture)
+// run with no other chunk of the job lists between upload and collection: captures from several threads at once ended in
+// hipErrorStreamCaptureInvalidated ("operation failed due to a previous error during capture").  Replays share the lock.
+std::shared_timed_mutex g_jobs_warm_mu;
 uint64_t g_jobs_tick = 0;
 constexpr size_t JOBS_RESIDENT_DESIGNS = 4 * REG_SWEEP_MAX;   // designs kept resident between calls (0.19 GB each at config 3)
 
 void check_rc(int rc) { if (rc != EMAGLS_OK) throw Error(rc, g_last_error); }
 // what makes two designs share a lane batch: everything but the array radius inside one (padded) simulation-order class
-std::string job_shape(const emagls_design_desc& d) {
+void job_shape(const emagls_design_desc& d, std::string& out) {
     emagls_design_desc k = d;
     if (array_kind(d.kind) && d.sim_order_pad > 0) {
         const int own = std::max(d.kind == EMAGLS_KIND_EMAGLS2 ? SMAIR_DEFAULT_ORDER : d.order, (int)std::ceil(d.fs * kPi * d.mic_radius / C_SOUND));
         if (own <= d.sim_order_pad) k.mic_radius = 0.0;   // (laid out for sim_order_pad whatever the radius)
     }
-    return std::string(reinterpret_cast<const char*>(&k), sizeof k);
+    out.assign(reinterpret_cast<const char*>(&k), sizeof k);
 }
 void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
     DeviceGuard dg(device);
+    static const bool trace = getenv("EMAGLS_JOBS_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (trace) fprintf(stderr, "emagls jobs: chunk of %d, %s at %.3f ms\n", n, what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     std::string key;
     for (int j = 0; j < n; ++j) key.append(reinterpret_cast<const char*>(&jobs[j].desc), sizeof(emagls_design_desc));
     std::unique_ptr<JobSlot> slot;
@@ -3855,6 +3868,7 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
             check_rc(emagls_plan_create(&jobs[j].desc, &p));
             slot->plans.push_back(p);
         }
+        lap("plans created");
     }
     for (int j = 0; j < n; ++j) {
         const emagls_job& jb = jobs[j];
@@ -3880,14 +3894,26 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
             check_rc(emagls_plan_set_atfs(p, jb.atf, jb.atf_azi, jb.atf_zen));
         }
         if (!jb.hL || !jb.hR || !jb.wL || !jb.wR) throw Error(EMAGLS_ERR_ARG, "job without HRIRs or without room for its filters");
-        check_rc(emagls_plan_set_hrirs(p, jb.hL, jb.hR));
+        if (!slot->batch && n > 1 && !slot->runs) check_rc(emagls_plan_set_hrirs(p, jb.hL, jb.hR));   // (before the batch exists: plan by plan)
     }
-    if (n > 1 && !slot->batch) {
+    if (n > 1 && !slot->batch && !slot->runs) {
         g_batch_max_override = REG_SWEEP_MAX;
         const int rc = emagls_batch_create(slot->plans.data(), n, &slot->batch);
         g_batch_max_override = 0;
         if (rc != EMAGLS_OK && rc != EMAGLS_ERR_UNSUPPORTED) check_rc(rc);   // (unsupported as a batch -- e.g. more than 32 channels: plan by plan)
         if (rc != EMAGLS_OK) slot->batch = nullptr;
+        lap("inputs set, batch created");
+    } else if (slot->batch) {
+        // the HRIRs of every design on the batch's stream, ordered before its execute: no host synchronisation per plan
+        for (int j = 0; j < n; ++j) {
+            emagls_plan& q = *slot->plans[(size_t)j];
+            const size_t bytes = sizeof(double) * (size_t)q.d.nsamp * (size_t)q.d.ndirs;
+            HIP_CHECK(hipMemcpyAsync(q.get("hL"), jobs[j].hL, bytes, hipMemcpyDefault, slot->batch->stream));
+            HIP_CHECK(hipMemcpyAsync(q.get("hR"), jobs[j].hR, bytes, hipMemcpyDefault, slot->batch->stream));
+            q.have_hrirs = true;
+        }
+    } else {
+        for (int j = 0; j < n; ++j) check_rc(emagls_plan_set_hrirs(slot->plans[(size_t)j], jobs[j].hL, jobs[j].hR));
     }
     if (slot->batch && (flags & EMAGLS_JOBS_SHARE_GEOMETRY)) {
         // HRIR sets on one geometry: the geometry stages once per chunk (the library compares the grids on the device, and a chunk whose
@@ -3895,16 +3921,24 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
         const int kind = jobs[0].desc.kind;
         if (kind != EMAGLS_KIND_FROM_ATF && kind != EMAGLS_KIND_EMA_SH) check_rc(emagls_batch_set_geometry_sharing(slot->batch, 1));
     }
-    if (slot->batch) {
-        std::vector<void*> wl((size_t)n), wr((size_t)n);
-        for (int j = 0; j < n; ++j) { wl[(size_t)j] = jobs[j].wL; wr[(size_t)j] = jobs[j].wR; }
-        if (slot->batch->prof_level != g_jobs_prof.load()) check_rc(emagls_batch_set_profiling(slot->batch, g_jobs_prof.load()));
-        check_rc(emagls_batch_execute(slot->batch));
-        check_rc(emagls_batch_get_filters(slot->batch, wl.data(), wr.data()));
-    } else {
-        for (int j = 0; j < n; ++j) check_rc(emagls_plan_execute(slot->plans[(size_t)j]));
-        for (int j = 0; j < n; ++j) check_rc(emagls_plan_get_filters(slot->plans[(size_t)j], jobs[j].wL, jobs[j].wR));
+    {
+        const bool warm = slot->runs >= 2;
+        std::shared_lock<std::shared_timed_mutex> shared(g_jobs_warm_mu, std::defer_lock);
+        std::unique_lock<std::shared_timed_mutex> alone(g_jobs_warm_mu, std::defer_lock);
+        if (warm) shared.lock(); else alone.lock();
+        if (slot->batch) {
+            std::vector<void*> wl((size_t)n), wr((size_t)n);
+            for (int j = 0; j < n; ++j) { wl[(size_t)j] = jobs[j].wL; wr[(size_t)j] = jobs[j].wR; }
+            if (slot->batch->prof_level != g_jobs_prof.load()) check_rc(emagls_batch_set_profiling(slot->batch, g_jobs_prof.load()));
+            check_rc(emagls_batch_execute(slot->batch));
+            check_rc(emagls_batch_get_filters(slot->batch, wl.data(), wr.data()));
+        } else {
+            for (int j = 0; j < n; ++j) check_rc(emagls_plan_execute(slot->plans[(size_t)j]));
+            for (int j = 0; j < n; ++j) check_rc(emagls_plan_get_filters(slot->plans[(size_t)j], jobs[j].wL, jobs[j].wR));
+        }
+        ++slot->runs;
     }
+    lap("executed and collected");
     // keep the slot when its designs can serve another chunk as they are
     std::lock_guard<std::mutex> lk(g_jobs_mu);
     slot->last_use = ++g_jobs_tick;
@@ -3960,11 +3994,12 @@ int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int i
         // avoids by asking for batches of 16)
         std::vector<std::pair<int64_t, int>> chunks;
         for (int64_t first = 0; first < njobs;) {
-            const std::string shape = job_shape(jobs[first].desc);
+            std::string shape, other;
+            job_shape(jobs[first].desc, shape);
             const int cap = array_kind(jobs[first].desc.kind) && !jobs[first].desc.custom_basis && !jobs[first].desc.diffuseness ? batch_size
                                                                                                                               : std::min(batch_size, SWEEP_MULTI_MAX);
             int n = 1;
-            while (first + n < njobs && n < cap && job_shape(jobs[first + n].desc) == shape) ++n;
+            while (first + n < njobs && n < cap && (job_shape(jobs[first + n].desc, other), other == shape)) ++n;
             chunks.emplace_back(first, n);
             first += n;
         }
