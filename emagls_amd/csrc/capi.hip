@@ -3826,9 +3826,9 @@ struct JobSlot {
 std::mutex g_jobs_mu;
 std::vector<std::unique_ptr<JobSlot>> g_jobs_free;   // resident slots nobody uses at the moment
 std::atomic<int> g_jobs_prof{0};                     // emagls_jobs_set_profiling: the chunks' batches time their sweep launches
-// A chunk's first two executes (the eager run with its one-time function attributes and lazy module loads, then the hipGraph capture)
-// run with no other chunk of the job lists between upload and collection: captures from several threads at once ended in
-// hipErrorStreamCaptureInvalidated ("operation failed due to a previous error during capture").  Replays share the lock.
+// A resident chunk's second run (the hipGraph capture of the stages around the sweep) has the job lists' share of the device to itself:
+// captures next to other threads' uploads or launches ended in hipErrorStreamCaptureInvalidated ("operation failed due to a previous
+// error during capture").  Every other run shares the lock.
 std::shared_timed_mutex g_jobs_warm_mu;
 uint64_t g_jobs_tick = 0;
 constexpr size_t JOBS_RESIDENT_DESIGNS = 4 * REG_SWEEP_MAX;   // designs kept resident between calls (0.19 GB each at config 3)
@@ -3859,6 +3859,12 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
         for (size_t i = 0; i < g_jobs_free.size(); ++i)
             if (g_jobs_free[i]->device == device && g_jobs_free[i]->key == key) { slot = std::move(g_jobs_free[i]); g_jobs_free.erase(g_jobs_free.begin() + i); break; }
     }
+    // a chunk shares the device with the other chunks in flight, except on its slot's SECOND run: that one captures the hipGraphs of the
+    // stages around the sweep, and a capture next to another thread's uploads or launches is invalidated (hipErrorStreamCaptureInvalidated)
+    const bool capturing = slot && slot->runs == 1;
+    std::shared_lock<std::shared_timed_mutex> shared(g_jobs_warm_mu, std::defer_lock);
+    std::unique_lock<std::shared_timed_mutex> alone(g_jobs_warm_mu, std::defer_lock);
+    if (capturing) alone.lock(); else shared.lock();
     if (!slot) {
         slot.reset(new JobSlot);
         slot->key = key; slot->device = device;
@@ -3896,13 +3902,14 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
         if (!jb.hL || !jb.hR || !jb.wL || !jb.wR) throw Error(EMAGLS_ERR_ARG, "job without HRIRs or without room for its filters");
         if (!slot->batch && n > 1 && !slot->runs) check_rc(emagls_plan_set_hrirs(p, jb.hL, jb.hR));   // (before the batch exists: plan by plan)
     }
+    lap("inputs set");
     if (n > 1 && !slot->batch && !slot->runs) {
         g_batch_max_override = REG_SWEEP_MAX;
         const int rc = emagls_batch_create(slot->plans.data(), n, &slot->batch);
         g_batch_max_override = 0;
         if (rc != EMAGLS_OK && rc != EMAGLS_ERR_UNSUPPORTED) check_rc(rc);   // (unsupported as a batch -- e.g. more than 32 channels: plan by plan)
         if (rc != EMAGLS_OK) slot->batch = nullptr;
-        lap("inputs set, batch created");
+        lap("batch created");
     } else if (slot->batch) {
         // the HRIRs of every design on the batch's stream, ordered before its execute: no host synchronisation per plan
         for (int j = 0; j < n; ++j) {
@@ -3922,10 +3929,6 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
         if (kind != EMAGLS_KIND_FROM_ATF && kind != EMAGLS_KIND_EMA_SH) check_rc(emagls_batch_set_geometry_sharing(slot->batch, 1));
     }
     {
-        const bool warm = slot->runs >= 2;
-        std::shared_lock<std::shared_timed_mutex> shared(g_jobs_warm_mu, std::defer_lock);
-        std::unique_lock<std::shared_timed_mutex> alone(g_jobs_warm_mu, std::defer_lock);
-        if (warm) shared.lock(); else alone.lock();
         if (slot->batch) {
             std::vector<void*> wl((size_t)n), wr((size_t)n);
             for (int j = 0; j < n; ++j) { wl[(size_t)j] = jobs[j].wL; wr[(size_t)j] = jobs[j].wR; }
