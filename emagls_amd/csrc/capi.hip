@@ -88,6 +88,28 @@ struct emagls_plan {
     hipStream_t stream = nullptr;
     std::map<std::string, DevBuf> bufs;
     std::shared_ptr<Arena> arena;  // set when a batch moved the buffers into its arena (they are not freed one by one then)
+    // The plan's ~75 buffers are carved out of a few slabs (one hipMalloc / hipFree per 32 MB instead of one per buffer: a job list
+    // whose array radii change from chunk to chunk creates and releases its plans inside the call, and 1200 hipFree calls per chunk
+    // of 16 plans were 0.28 s of its 0.39 s).  A buffer that grows takes a new region; the slabs go when the plan goes, or when a
+    // batch has moved every buffer into its arena.
+    struct Slab { char* base; size_t size, used; };
+    std::vector<Slab> slabs;
+    static constexpr size_t SLAB_BYTES = (size_t)32 << 20;
+    void* slab_take(size_t bytes) {
+        bytes = (bytes + 255) / 256 * 256;
+        if (slabs.empty() || slabs.back().used + bytes > slabs.back().size) {
+            Slab sl{nullptr, std::max(bytes, SLAB_BYTES), 0};
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sl.base), sl.size));
+            slabs.push_back(sl);
+        }
+        void* p = slabs.back().base + slabs.back().used;
+        slabs.back().used += bytes;
+        return p;
+    }
+    void release_slabs() {
+        for (auto& sl : slabs) if (sl.base) hipFree(sl.base);
+        slabs.clear();
+    }
     int64_t total_bytes = 0;
     // derived constants
     bool cplx_basis = false;      // element type of the internal SH machinery
@@ -171,6 +193,7 @@ struct emagls_plan {
     ~emagls_plan() {
         if (owner) emagls_batch_forget(owner, this);
         for (auto& kv : bufs) if (kv.second.p && kv.second.owned) hipFree(kv.second.p);
+        release_slabs();
         for (auto e : stage_events) hipEventDestroy(e);
         for (auto e : sweep_events) hipEventDestroy(e);
         for (auto e : sync_events) hipEventDestroy(e);
@@ -194,9 +217,9 @@ struct emagls_plan {
             total_bytes -= (int64_t)it->second.bytes;
         }
         DevBuf b;
-        HIP_CHECK(hipMalloc(&b.p, (bytes + 15) / 16 * 16));  // (launch_zero works on whole 8-byte words)
+        b.p = slab_take((bytes + 15) / 16 * 16);  // (launch_zero works on whole 8-byte words)
         b.bytes = bytes;
-        b.owned = true;
+        b.owned = false;   // (part of a slab)
         if (zero) HIP_CHECK(hipMemsetAsync(b.p, 0, bytes, stream));
         bufs[name] = b;
         total_bytes += (int64_t)bytes;
@@ -2607,11 +2630,19 @@ void batch_try_lanes(emagls_batch& b) {
         size_t i = 0;
         for (auto& kv : p.bufs) {
             char* dst = static_cast<char*>(arena->base) + j * stride + off[i++];
-            HIP_CHECK(hipMemcpy(dst, kv.second.p, kv.second.bytes, hipMemcpyDeviceToDevice));
+            HIP_CHECK(hipMemcpyAsync(dst, kv.second.p, kv.second.bytes, hipMemcpyDeviceToDevice, b.stream));
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(b.stream));   // (every plan's streams were synchronised by the caller: the buffers are final)
+    for (size_t j = 0; j < b.plans.size(); ++j) {
+        emagls_plan& p = *b.plans[j];
+        size_t i = 0;
+        for (auto& kv : p.bufs) {
             if (kv.second.owned) HIP_CHECK(hipFree(kv.second.p));
-            kv.second.p = dst;
+            kv.second.p = static_cast<char*>(arena->base) + j * stride + off[i++];
             kv.second.owned = false;
         }
+        p.release_slabs();
         p.arena = arena;  // (a previous arena is released when its last plan has moved out)
         // the captured graphs hold the old addresses
         if (p.graph_exec) { HIP_CHECK(hipGraphExecDestroy(p.graph_exec)); p.graph_exec = nullptr; }
@@ -3831,7 +3862,7 @@ std::atomic<int> g_jobs_prof{0};                     // emagls_jobs_set_profilin
 // error during capture").  Every other run shares the lock.
 std::shared_timed_mutex g_jobs_warm_mu;
 uint64_t g_jobs_tick = 0;
-constexpr size_t JOBS_RESIDENT_DESIGNS = 4 * REG_SWEEP_MAX;   // designs kept resident between calls (0.19 GB each at config 3)
+std::atomic<size_t> g_jobs_resident_max{4 * REG_SWEEP_MAX};   // designs kept resident between calls (0.19 GB each at config 3); at least one call's chunks in flight
 
 void check_rc(int rc) { if (rc != EMAGLS_OK) throw Error(rc, g_last_error); }
 // what makes two designs share a lane batch: everything but the array radius inside one (padded) simulation-order class
@@ -3948,7 +3979,7 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
     g_jobs_free.push_back(std::move(slot));
     size_t resident = 0;
     for (auto& f : g_jobs_free) resident += f->plans.size();
-    while (resident > JOBS_RESIDENT_DESIGNS && g_jobs_free.size() > 1) {   // least recently used first
+    while (resident > g_jobs_resident_max.load() && g_jobs_free.size() > 1) {   // least recently used first
         size_t old = 0;
         for (size_t i = 1; i < g_jobs_free.size(); ++i) if (g_jobs_free[i]->last_use < g_jobs_free[old]->last_use) old = i;
         resident -= g_jobs_free[old]->plans.size();
@@ -3990,6 +4021,7 @@ int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int i
         if (batch_size <= 0) batch_size = REG_SWEEP_MAX;
         if (in_flight <= 0) in_flight = 4;
         batch_size = std::min(batch_size, REG_SWEEP_MAX);
+        g_jobs_resident_max.store(std::max((size_t)4 * REG_SWEEP_MAX, (size_t)batch_size * (size_t)in_flight));
         int device = 0;
         HIP_CHECK(hipGetDevice(&device));
         // chunks: consecutive jobs of one shape; more than 16 designs per chunk only where the register-resident sweep takes them
