@@ -595,3 +595,53 @@ def test_sh_rotation_closed_forms():
         y_hor = O.getSH(3, np.array([[azi, math.pi / 2]]), "real")[0]     # (3) plane-wave coefficient rows (real SH: Y itself)
         y_el = O.getSH(3, np.array([[azi, zen]]), "real")[0]
         assert np.abs(y_hor @ D - y_el).max() < 1e-12
+
+
+# ---------------------------------------------------------------- the clipped pseudo-inverse, pinned by a fixture PAIR
+def test_cross_fixture_ls_bins_pin_the_clipping_rule(golden, grids):
+    """Below k_cut both array methods are least-squares fits of the SAME HRTFs (lib/getEMagLsFilters.m:92-94,
+    lib/getEMagLs2Filters.m:92-94): W_e(k,:) = H(k,:) Yri_e and W_2(k,:) = H(k,:) Yri_2 with Yri = conj(U) (s_reg .* V.') of
+    pwGrid.' (:88-90).  The rows of pwGrid_e = pinv(Y_lo) pwGrid_2 (getSMAIRMatrix.m:119-121) lie in the span of pwGrid_2's, so
+    U_e = U_2 (U_2^H U_e) and the unknown HRTFs drop out:
+        W_e(k,:) = W_2(k,:) A_k,    A_k = V_2.'^-1 diag(1 / s_reg2) conj(U_2^H U_e) diag(s_reg_e) V_e.',
+    with A_k computed from the oracle's array model and its clipped SVDs alone.  Predicting the eMagLS fixture's spectrum from the
+    eMagLS2 fixture's (both re-padded to nfft; the window and delay bookkeeping are the same for both and cancel to leakage
+    level) pins the 1 % clipping rule (:89: every other threshold is an order of magnitude worse), the Y_lo projection, the modal
+    terms and the simulation order to 6e-4 -- two orders tighter than the physics test above, and on the regularised inverse
+    itself, which no other fixture relation reaches."""
+    fs, nfft = 48000.0, 1024
+    azi, zen = grids["azi"], grids["zen"]
+    micd = np.column_stack([grids["mic_azi"], grids["mic_zen"]])
+
+    def spec(w):
+        wp = np.zeros((nfft, w.shape[1]))
+        wp[256:768] = w
+        return np.fft.fft(wp, axis=0)
+    sm_e, so = O.getSMAIRMatrix(4, fs, nfft, grids["mic_radius"], micd, "real", returnRawMicSigs=False)
+    sm_2, _ = O.getSMAIRMatrix(4, fs, nfft, grids["mic_radius"], micd, "real", returnRawMicSigs=True)
+    Yh = O.getSH(so, np.column_stack([azi, zen]), "real").T
+    bins = np.arange(3, 40)      # 0-based; all below k_cut - 1 = 42
+
+    def parts(pw, c):
+        U, s, Vh = np.linalg.svd(pw.T, full_matrices=False)
+        return U, (1.0 / np.maximum(s, c * s.max()) if c > 0 else 1.0 / s), Vh
+
+    def errors(We, W2, c):
+        out = []
+        for k in bins:
+            Ue, sre, Vhe = parts(sm_e[:, :, k] @ Yh, c)
+            U2, sr2, Vh2 = parts(sm_2[:, :, k] @ Yh, c)
+            A = (Vh2.T / sr2[None, :]) @ np.conj(U2.conj().T @ Ue) @ (sre[:, None] * np.conj(Vhe))
+            out.append(np.linalg.norm(W2[k] @ A - We[k]) / np.linalg.norm(We[k]))
+        return np.array(out)
+    res = {}
+    for ear, (ke, k2) in {"L": ("real_eMagLS_woDC/wEMlsL", "real_eMagLS2_woDC/wEMls2L"), "R": ("real_eMagLS_woDC/wEMlsR", "real_eMagLS2_woDC/wEMls2R")}.items():
+        We, W2 = spec(golden[ke]), spec(golden[k2])
+        res[ear] = {c: errors(We, W2, c) for c in ((0.01, 0.0, 0.1, 0.001) if ear == "L" else (0.01,))}
+        e = res[ear][0.01]
+        print(f"eMagLS fixture predicted from the eMagLS2 fixture, ear {ear}, bins 4..40: median rel. error {np.median(e):.2e}, max {e.max():.2e}")
+        assert np.median(e) < 1.5e-3 and e.max() < 1e-2
+    for c, name in ((0.0, "no clipping"), (0.1, "10 %"), (0.001, "0.1 %")):
+        e = res["L"][c]
+        print(f"  with the threshold at {name}: median {np.median(e):.2e}")
+        assert np.median(e) > 5 * np.median(res["L"][0.01])
