@@ -69,10 +69,62 @@ struct DevBuf {
     size_t bytes = 0;
     bool owned = false;   // allocated on its own (hipFree when dropped); false once a batch moved it into its arena
 };
+// Device memory of plans (slabs) and batches (arenas) comes from a process-wide pool of blocks that are handed back instead of freed:
+// a job list whose plans live for one chunk each otherwise pays hipMalloc / hipFree of ~0.35 GB per design again and again (and
+// the calls were erratic next to running kernels: 30 ms ... 1.6 s for the plans of one chunk).  emagls_cache_clear() frees the pool;
+// EMAGLS_POOL_GB (default 64) bounds what it keeps.
+struct BlockPool {
+    std::mutex mu;
+    std::map<int, std::multimap<size_t, void*>> free_;   // device -> size -> block
+    size_t held = 0;
+    static BlockPool& get() { static BlockPool p; return p; }
+    static size_t cap() {
+        static const size_t c = [] { const char* e = getenv("EMAGLS_POOL_GB"); return (size_t)(e ? std::max(0, atoi(e)) : 64) << 30; }();
+        return c;
+    }
+    // a block of at least `bytes` (exactly `bytes` when it has to be allocated); *got = its size
+    void* take(size_t bytes, size_t* got) {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& fl = free_[dev];
+            auto it = fl.lower_bound(bytes);
+            if (it != fl.end() && it->first <= bytes + bytes / 4) {
+                void* p = it->second;
+                *got = it->first;
+                held -= it->first;
+                fl.erase(it);
+                return p;
+            }
+        }
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, bytes));
+        *got = bytes;
+        return p;
+    }
+    void give(void* p, size_t bytes) {
+        if (!p) return;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); hipFree(p); return; }
+        std::lock_guard<std::mutex> lk(mu);
+        if (held + bytes > cap()) { hipFree(p); return; }
+        free_[dev].emplace(bytes, p);
+        held += bytes;
+    }
+    void clear() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& d : free_) for (auto& kv : d.second) hipFree(kv.second);
+        free_.clear();
+        held = 0;
+    }
+};
+
 // one allocation that holds the buffers of all plans of a batch at a constant stride (see emagls_batch)
 struct Arena {
     void* base = nullptr;
-    ~Arena() { if (base) hipFree(base); }
+    size_t bytes = 0;
+    ~Arena() { if (base) BlockPool::get().give(base, bytes); }
 };
 
 int round_up(int64_t v, int64_t m) { return (int)(ceil_div(v, m) * m); }
@@ -98,8 +150,8 @@ struct emagls_plan {
     void* slab_take(size_t bytes) {
         bytes = (bytes + 255) / 256 * 256;
         if (slabs.empty() || slabs.back().used + bytes > slabs.back().size) {
-            Slab sl{nullptr, std::max(bytes, SLAB_BYTES), 0};
-            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sl.base), sl.size));
+            Slab sl{nullptr, (std::max(bytes, SLAB_BYTES) + SLAB_BYTES - 1) / SLAB_BYTES * SLAB_BYTES, 0};
+            sl.base = static_cast<char*>(BlockPool::get().take(sl.size, &sl.size));
             slabs.push_back(sl);
         }
         void* p = slabs.back().base + slabs.back().used;
@@ -107,7 +159,7 @@ struct emagls_plan {
         return p;
     }
     void release_slabs() {
-        for (auto& sl : slabs) if (sl.base) hipFree(sl.base);
+        for (auto& sl : slabs) BlockPool::get().give(sl.base, sl.size);
         slabs.clear();
     }
     int64_t total_bytes = 0;
@@ -2624,7 +2676,7 @@ void batch_try_lanes(emagls_batch& b) {
     }
     stride = (stride + 4095) / 4096 * 4096;
     auto arena = std::make_shared<Arena>();
-    HIP_CHECK(hipMalloc(&arena->base, stride * b.plans.size()));
+    arena->base = BlockPool::get().take((stride * b.plans.size() + ((size_t)64 << 20) - 1) / ((size_t)64 << 20) * ((size_t)64 << 20), &arena->bytes);
     for (size_t j = 0; j < b.plans.size(); ++j) {
         emagls_plan& p = *b.plans[j];
         size_t i = 0;
@@ -2923,6 +2975,7 @@ int emagls_cache_clear(void) {
         emagls_sets_cache_clear_internal();
         emagls_atfsets_cache_clear_internal();
         emagls_jobs_cache_clear_internal();
+        BlockPool::get().clear();
     });
 }
 

@@ -8,7 +8,7 @@ EMAGLS_JOBS_TRACE=1 timeout 900 python - > gpurun_out/${tag}_config4_runner.json
 import json, sys, os
 sys.path.insert(0, os.getcwd())
 from tools import bench_secondary as S
-print(json.dumps({"runner16": S.config4_rank_share_runner(reps=3)}))
+print(json.dumps({"runner16": S.config4_rank_share_runner(reps=5)}))
 PY
 cut -c1-500 gpurun_out/${tag}_config4_runner.json; grep "emagls jobs" gpurun_out/${tag}_config4_runner.err | tail -10
 run() { name=$1; shift; timeout 900 "$@" > gpurun_out/${tag}_$name.json 2> gpurun_out/${tag}_$name.err; python - <<PY
