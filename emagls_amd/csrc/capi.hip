@@ -77,7 +77,7 @@ struct BlockPool {
     std::mutex mu;
     std::map<int, std::multimap<size_t, void*>> free_;   // device -> size -> block
     size_t held = 0;
-    static BlockPool& get() { static BlockPool p; return p; }
+    static BlockPool& get() { static BlockPool* p = new BlockPool; return *p; }   // (never destroyed: plans of static caches hand their blocks back at exit)
     static size_t cap() {
         static const size_t c = [] { const char* e = getenv("EMAGLS_POOL_GB"); return (size_t)(e ? std::max(0, atoi(e)) : 64) << 30; }();
         return c;
@@ -3957,6 +3957,7 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
             emagls_plan* p = nullptr;
             check_rc(emagls_plan_create(&jobs[j].desc, &p));
             slot->plans.push_back(p);
+            if (j == 0) lap("first plan created");
         }
         lap("plans created");
     }

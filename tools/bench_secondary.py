@@ -163,7 +163,7 @@ def config4_rank_share_runner(world=8, reps=3, max_batch=16):
         out = emagls2_radius_sweep(hL, hR, azi, zen, radii, maz, mzn, 4, 48000.0, 1024, "real", max_batch=max_batch, _one_share_of=world)
         ts.append(time.perf_counter() - t0)
         n = len(out)
-        L.check(L.load().emagls_cache_clear())
+    L.check(L.load().emagls_cache_clear())
     dt = float(np.median(ts))
     return {"ranks": world, "designs": n, "max_batch": max_batch, "s_per_share_runs": [round(t, 4) for t in ts], "ms_per_share": round(dt * 1e3, 3),
             "filter_sets_per_s": round(n / dt, 1),
