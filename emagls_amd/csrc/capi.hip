@@ -2099,9 +2099,10 @@ void batch_atf_shared_stage(emagls_batch& b, int part) {
                 launch_zero(p.get("flag"), sizeof(int) * NFLAG, b.stream);
                 launch_zero(p.get("W"), p.bufs["W"].bytes, b.stream);
                 // (the subject keeps its own copy of the match: emagls_plan_get_info and the debug buffers read it per plan)
-                launch_conj_copy(p0.get("match_idx"), p.get("match_idx"), p.Dm, false, b.stream);
-                launch_conj_copy(p0.get("match_dev"), p.get("match_dev"), p.Dm, false, b.stream);
-                launch_conj_copy(p0.get("mean_dev"), p.get("mean_dev"), 1, false, b.stream);
+                // (plain device-to-device copies: match_idx holds 64-bit integers)
+                HIP_CHECK(hipMemcpyAsync(p.get("match_idx"), p0.get("match_idx"), sizeof(int64_t) * (size_t)p.Dm, hipMemcpyDeviceToDevice, b.stream));
+                HIP_CHECK(hipMemcpyAsync(p.get("match_dev"), p0.get("match_dev"), sizeof(double) * (size_t)p.Dm, hipMemcpyDeviceToDevice, b.stream));
+                HIP_CHECK(hipMemcpyAsync(p.get("mean_dev"), p0.get("mean_dev"), sizeof(double), hipMemcpyDeviceToDevice, b.stream));
                 stage_prologue(p, 1, p.hrir_smaller ? nullptr : p.get<int64_t>("match_idx"), p.Dm);
                 from_atf_ls_rows(p, p0, b.stream);
             }
@@ -2549,6 +2550,9 @@ bool plan_recover(emagls_plan& p, const int* flag, bool apply) {
         if (p.d.kind == EMAGLS_KIND_FROM_ATF && p.C > 8)
             throw Error(EMAGLS_ERR_UNSUPPORTED, "the ATF matrices of some bins are too ill-conditioned for the Gram route (cond > 3e4) and the "
                                                 "dense route holds at most 8 microphones in this build");
+        if (p.d.kind == EMAGLS_KIND_FROM_ATF && p.Dm > 4096)
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "the ATF matrices of some bins are too ill-conditioned for the Gram route (cond > 3e4) and the "
+                                                "dense route holds at most 4096 matched directions in this build");
         if (apply && p.d.kind == EMAGLS_KIND_FROM_ATF) {
             // measured ATFs: the bins up to the offending one take the dense route (QR + Jacobi of the matched ATF matrix itself)
             p.gram_from = flag[3] + 1 < p.P ? flag[3] + 1 : 0;
@@ -2632,6 +2636,7 @@ bool batch_unify_routes_once(emagls_batch& b) {
     return true;
 }
 
+void batch_decide_residency(emagls_batch& b);
 // One sweep launch serves every design of a batch: the synthesising form only when all of them qualify
 void batch_unify_synth(emagls_batch& b) {
     bool all = true, any = false;
@@ -2729,6 +2734,7 @@ void batch_redo(emagls_batch& b, const std::vector<int>& flags) {
     {
         const std::vector<int64_t> before = [&] { std::vector<int64_t> v; for (auto* q : b.plans) v.push_back(q->total_bytes); return v; }();
         batch_unify_synth(b);
+        batch_decide_residency(b);   // (the form may have changed: the residency of the kernel that will be launched)
         for (size_t j = 0; j < b.plans.size(); ++j) moved = moved || b.plans[j]->total_bytes != before[j];
     }
     if (b.lanes && moved) {   // re-allocated buffers left the arena: lane mode needs them at the common stride again
@@ -3297,6 +3303,26 @@ int emagls_plan_debug_buffer(emagls_plan* p, const char* name, void* dst, size_t
 }
 void* emagls_plan_stream(emagls_plan* p) { return p ? (void*)p->stream : nullptr; }
 
+// Can the resident sweep of the form the batch will launch keep all its workgroups on the device?  Decided before any launch, from the
+// runtime's occupancy of that kernel variant (a sweep that cannot be resident would wait for its peers until the time-out); re-evaluated
+// whenever the form changes (batch_redo).  A batch that does not fit takes one launch per bin.
+void batch_decide_residency(emagls_batch& b) {
+    emagls_plan& f0 = *b.plans[0];
+    const int n = (int)b.plans.size();
+    if (f0.d.kind == EMAGLS_KIND_LS) return;
+    bool all_persist = true;
+    for (auto* p : b.plans) all_persist = all_persist && p->sweep_persist;
+    if (!all_persist) return;
+    const int64_t Dh0 = f0.d.kind == EMAGLS_KIND_FROM_ATF ? f0.Dm : f0.D;
+    const bool fits = f0.synth ? (reg_sweep_wanted(b.plans.data(), n) || (n <= SWEEP_MULTI_MAX && synth_sweep_fits((int)Dh0, (int)f0.d.nmics, f0.simOrder + 1, n)))
+                               : (n <= SWEEP_MULTI_MAX && persist_sweep_fits((int)Dh0, f0.C, n));
+    if (fits) return;
+    for (auto* p : b.plans) {
+        p->sweep_persist = false;
+        if (p->synth_want) { plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); }
+    }
+}
+
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
     return guarded([&] {
         if (!plans || !batch || nplans < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
@@ -3344,16 +3370,15 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         // (up to 8 designs: 16 CUs stay free of sweep workgroups, so that kernels of other batches which need a whole CU keep
         // making progress and the dispatcher never has a reason to hold the sweep's own workgroups back)
         // (decided here, before any launch, from the runtime's occupancy of the kernel variant: persist_sweep_fits)
-        const emagls_plan& f0 = *b->plans[0];
-        const int64_t Dh0 = f0.d.kind == EMAGLS_KIND_FROM_ATF ? f0.Dm : f0.D;
-        const bool fits = f0.synth ? (reg_sweep_wanted(b->plans.data(), nplans) || synth_sweep_fits((int)Dh0, (int)f0.d.nmics, f0.simOrder + 1, nplans))
-                                   : persist_sweep_fits((int)Dh0, f0.C, nplans);
-        if (nplans > SWEEP_MULTI_MAX && !(f0.synth && reg_sweep_wanted(b->plans.data(), nplans)))
+        const bool array_batch = b->plans[0]->d.kind != EMAGLS_KIND_FROM_ATF && !magls_kind(b->plans[0]->d.kind) && b->plans[0]->d.kind != EMAGLS_KIND_LS;
+        for (auto* p : b->plans) HIP_CHECK(hipStreamSynchronize(p->stream));
+        // (the sweep's form first -- one launch serves every design: the synthesising forms only when all qualify --, then its residency)
+        if (array_batch) batch_unify_synth(*b);
+        batch_decide_residency(*b);
+        if (nplans > SWEEP_MULTI_MAX && !(b->plans[0]->synth && b->plans[0]->sweep_persist && reg_sweep_wanted(b->plans.data(), nplans)))
             throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 16 designs per batch: only array designs that take the register-resident sweep (built-in SH basis, "
                                                 "microphone grids set, at most 18 antipodal pairs + single microphones, a launch the device can hold)");
         for (auto* p : b->plans) {
-            HIP_CHECK(hipStreamSynchronize(p->stream));
-            if (!fits && p->sweep_persist) { p->sweep_persist = false; if (p->synth_want) { plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); } }
             p->nstreams = 1;
             p->prof_level = 0;
             p->sync_stream = b->stream;

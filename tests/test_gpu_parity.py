@@ -883,7 +883,8 @@ def test_synthesising_sweep_on_other_arrays(grids, thin, monkeypatch, nmics, pai
         L.check(L.load().emagls_cache_clear())
         e_m = max(rel(w[0], m[0]), rel(w[1], m[1]))
         print(f"synthesising sweep, {fn}, {nmics} microphones ({paired} pairs, {want_units} units): rel vs oracle = {e_o:.3e}, vs materialised operands = {e_m:.3e}")
-        assert e_o < TOL and e_m < TOL and e_m > 0
+        # (explicit margins instead of the oracle tolerance: 10x the largest distances measured over the suite)
+        assert e_o < 2e-7 and 0 < e_m < 2e-7
 
 
 def test_residency_is_decided_before_the_launch(grids, thin, monkeypatch):
