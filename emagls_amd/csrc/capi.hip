@@ -2636,7 +2636,6 @@ bool batch_unify_routes_once(emagls_batch& b) {
     return true;
 }
 
-void batch_decide_residency(emagls_batch& b);
 // One sweep launch serves every design of a batch: the synthesising form only when all of them qualify
 void batch_unify_synth(emagls_batch& b) {
     bool all = true, any = false;
@@ -2645,6 +2644,26 @@ void batch_unify_synth(emagls_batch& b) {
     for (auto* p : b.plans)
         if (p->synth) { p->synth_block = true; plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); drop_plan_graphs(*p); }
 }
+// Can the resident sweep of the form the batch will launch keep all its workgroups on the device?  Decided before any launch, from the
+// runtime's occupancy of that kernel variant (a sweep that cannot be resident would wait for its peers until the time-out); re-evaluated
+// whenever the form changes (batch_redo).  A batch that does not fit takes one launch per bin.
+void batch_decide_residency(emagls_batch& b) {
+    emagls_plan& f0 = *b.plans[0];
+    const int n = (int)b.plans.size();
+    if (f0.d.kind == EMAGLS_KIND_LS) return;
+    bool all_persist = true;
+    for (auto* p : b.plans) all_persist = all_persist && p->sweep_persist;
+    if (!all_persist) return;
+    const int64_t Dh0 = f0.d.kind == EMAGLS_KIND_FROM_ATF ? f0.Dm : f0.D;
+    const bool fits = f0.synth ? (reg_sweep_wanted(b.plans.data(), n) || (n <= SWEEP_MULTI_MAX && synth_sweep_fits((int)Dh0, (int)f0.d.nmics, f0.simOrder + 1, n)))
+                               : (n <= SWEEP_MULTI_MAX && persist_sweep_fits((int)Dh0, f0.C, n));
+    if (fits) return;
+    for (auto* p : b.plans) {
+        p->sweep_persist = false;
+        if (p->synth_want) { plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); }
+    }
+}
+
 void batch_try_lanes(emagls_batch& b) {
     if (const char* e = getenv("EMAGLS_BATCH_LANES")) if (e[0] == '0') return;
     emagls_plan& q = *b.plans[0];
@@ -3302,26 +3321,6 @@ int emagls_plan_debug_buffer(emagls_plan* p, const char* name, void* dst, size_t
     });
 }
 void* emagls_plan_stream(emagls_plan* p) { return p ? (void*)p->stream : nullptr; }
-
-// Can the resident sweep of the form the batch will launch keep all its workgroups on the device?  Decided before any launch, from the
-// runtime's occupancy of that kernel variant (a sweep that cannot be resident would wait for its peers until the time-out); re-evaluated
-// whenever the form changes (batch_redo).  A batch that does not fit takes one launch per bin.
-void batch_decide_residency(emagls_batch& b) {
-    emagls_plan& f0 = *b.plans[0];
-    const int n = (int)b.plans.size();
-    if (f0.d.kind == EMAGLS_KIND_LS) return;
-    bool all_persist = true;
-    for (auto* p : b.plans) all_persist = all_persist && p->sweep_persist;
-    if (!all_persist) return;
-    const int64_t Dh0 = f0.d.kind == EMAGLS_KIND_FROM_ATF ? f0.Dm : f0.D;
-    const bool fits = f0.synth ? (reg_sweep_wanted(b.plans.data(), n) || (n <= SWEEP_MULTI_MAX && synth_sweep_fits((int)Dh0, (int)f0.d.nmics, f0.simOrder + 1, n)))
-                               : (n <= SWEEP_MULTI_MAX && persist_sweep_fits((int)Dh0, f0.C, n));
-    if (fits) return;
-    for (auto* p : b.plans) {
-        p->sweep_persist = false;
-        if (p->synth_want) { plan_alloc_routes(*p); HIP_CHECK(hipStreamSynchronize(p->stream)); }
-    }
-}
 
 int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
     return guarded([&] {
