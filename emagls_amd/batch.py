@@ -67,14 +67,19 @@ def batch_cost(n, sim_order):
     return (6.4 + 2.4 * g) + (1.67 + 1.93 * g) * 1e-3 * S
 
 
-def padded_lane_batches(sim_orders, max_batch=16):
+def padded_lane_batches(sim_orders, max_batch=16, balance=True):
     """Lane batches across neighbouring simulation-order classes: the jobs sorted by simulation order (stable) and cut into
-    ceil(n / max_batch) consecutive chunks of equal size (+-1).  Every design of a chunk is laid out for the chunk's highest
-    simulation order (`sim_order_pad` of the plan: b_n = 0 above the design's own order, the same filters), so a chunk has ONE
-    shape and runs in lane mode.  Returns [(job indices, pad order), ...], lowest orders first.
-    BASELINE config 4 (256 radii on 2..10 cm, 36 classes of 7-8 radii): 16 batches of 16 (32 of 8 with max_batch = 8) instead of
-    36 of 7-8 (or, sharded per job, 200 of 1-2).  A batch of more than 8 designs needs emagls_set_batch_max (the job lists of this
-    module raise it for the call)."""
+    ceil(n / max_batch) consecutive chunks.  Every design of a chunk is laid out for the chunk's highest simulation order
+    (`sim_order_pad` of the plan: b_n = 0 above the design's own order, the same filters), so a chunk has ONE shape and runs in
+    lane mode.  Returns [(job indices, pad order), ...], lowest orders first.
+    balance=True (default): the chunks are cut at equal COST, not equal size -- the smallest bound on `batch_cost(size, highest
+    order)` that needs no more than ceil(n / max_batch) chunks, so chunks of high orders hold fewer designs (never more than 32, the
+    library's limit; `max_batch` is then the AVERAGE chunk size).  Whole chunks go to ranks (shard_lane_batches): with chunks of
+    equal size the most loaded of 8 ranks carried 8 % more than the least loaded one on BASELINE config 4; with chunks of equal
+    cost 2 %.  balance=False: chunks of equal size (+-1).
+    BASELINE config 4 (256 radii on 2..10 cm, 36 classes of 7-8 radii): 16 batches (32 with max_batch = 8) instead of 36 of 7-8
+    (or, sharded per job, 200 of 1-2).  A batch of more than 8 designs needs emagls_set_batch_max (the job lists of this module
+    go through emagls_jobs_run, which raises it for the call)."""
     if not 1 <= max_batch <= 32:
         raise ValueError("a batch holds 1..32 designs")
     n = len(sim_orders)
@@ -82,8 +87,35 @@ def padded_lane_batches(sim_orders, max_batch=16):
         return []
     order = sorted(range(n), key=lambda i: (sim_orders[i], i))
     nb = -(-n // max_batch)
-    base, extra = divmod(n, nb)
     out, pos = [], 0
+    if balance and nb > 1:
+        so = [sim_orders[i] for i in order]
+
+        def cut(T):
+            """greedy chunks of cost <= T each (a chunk's cost: batch_cost at its size and its highest order); None if a single design exceeds T"""
+            chunks, pos = [], 0
+            while pos < n:
+                size = 1
+                if batch_cost(1, so[pos]) > T:
+                    return None
+                while pos + size < n and size < 32 and batch_cost(size + 1, so[pos + size]) <= T:
+                    size += 1
+                chunks.append((pos, size))
+                pos += size
+            return chunks
+        lo, hi = 0.0, batch_cost(32, max(so)) + 1.0
+        for _ in range(40):   # the smallest cost bound that needs no more than nb chunks
+            mid = 0.5 * (lo + hi)
+            c = cut(mid)
+            if c is not None and len(c) <= nb:
+                hi = mid
+            else:
+                lo = mid
+        for pos, size in cut(hi):
+            idx = order[pos:pos + size]
+            out.append((idx, max(sim_orders[i] for i in idx)))
+        return out
+    base, extra = divmod(n, nb)
     for b in range(nb):
         size = base + (1 if b < extra else 0)
         idx = order[pos:pos + size]
@@ -119,14 +151,14 @@ def _collective_device(group, device=None):
     return "cuda" if dist.get_backend(group) == "nccl" else "cpu"
 
 
-def _agree_or_raise(err, group, device=None):
+def _agree_or_raise(err, group, device=None, force=False):
     """Every rank enters the gather or none does: the ranks agree on an error flag first (one 8-byte all-reduce).  A rank whose
     share failed (an unsupported shape, out of memory) raises its own exception, the others a RuntimeError that names the
     failing rank -- nobody is left waiting inside a collective."""
     import torch
     import torch.distributed as dist
     have, rank, world = _pg(group)
-    if not have or world == 1:
+    if not have or (world == 1 and not force):
         if err is not None:
             raise err
         return
@@ -303,8 +335,12 @@ def _run_job_list(n, shards, make_job, group=None, max_batch=16, share_geometry=
     brings the filters to rank 0.  Returns [(wL, wR), ...] in job order on rank 0 (and in a single process), None elsewhere."""
     import torch
     import torch.distributed as dist
+    import os
     have_pg, rank, world = _pg(group)
-    on_device = have_pg and world > 1 and dist.get_backend(group) == "nccl"
+    # (EMAGLS_FORCE_COLLECTIVE=1: a single rank goes through the agreement, the device buffers and the gather as well -- how the
+    # RCCL path of this loop is exercised on a box with one GPU)
+    force = have_pg and os.environ.get("EMAGLS_FORCE_COLLECTIVE", "0") == "1"
+    on_device = have_pg and (world > 1 or force) and dist.get_backend(group) == "nccl"
     res = _Results(len(shards[rank]), on_device)
     err = None
     try:
@@ -313,8 +349,8 @@ def _run_job_list(n, shards, make_job, group=None, max_batch=16, share_geometry=
             torch.cuda.synchronize()   # (the library wrote the buffer on its own streams)
     except Exception as e:
         err = e
-    _agree_or_raise(err, group)
-    if world == 1:
+    _agree_or_raise(err, group, force=force)
+    if world == 1 and not force:
         out = [None] * n
         for i, j in enumerate(shards[0]):
             out[j] = _Results.unpack(res.buf[i], res.shape[2])

@@ -240,3 +240,51 @@ def test_two_ranks_with_real_designs_on_one_gpu():
     tag, worst = q.get(timeout=5)
     print(f"two ranks, three job lists, gathered on rank 0: worst rel vs single calls = {worst:.3e}")
     assert tag == "ok" and worst < 1e-9
+
+
+def _nccl_worker(port, q):
+    """ONE rank on RCCL with EMAGLS_FORCE_COLLECTIVE=1: the job list's filters written device to device into the gather's buffer
+    (a torch tensor), the agreement all-reduce, the shape all-reduce and the gather itself all run on `nccl` -- the device branch of
+    batch._run_job_list that a box with one GPU can execute."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["EMAGLS_FORCE_COLLECTIVE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import emagls_amd as E
+        from emagls_amd import synth
+        from emagls_amd.batch import emagls2_radius_sweep, emagls_hrir_sets
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        azi, zen = synth.fibonacci_grid(700)
+        maz, mzn = synth.em32_grid()
+        hL, hR = synth.rigid_sphere_hrirs(azi, zen, taps=64)
+        subjects = [synth.rigid_sphere_hrirs(azi, zen, taps=64, seed=40 + j, head_radius=0.08 + 0.002 * j) for j in range(4)]
+        out_s = emagls_hrir_sets(subjects, azi, zen, 0.042, maz, mzn, 4, 48000.0, 128, "complex", max_batch=3)
+        radii = [0.047, 0.0471, 0.0473]
+        out_r = emagls2_radius_sweep(hL, hR, azi, zen, radii, maz, mzn, 4, 48000.0, 64)
+        worst = 0.0
+        for j in range(4):
+            w = E.getEMagLsFilters(subjects[j][0], subjects[j][1], azi, zen, 0.042, maz, mzn, 4, 48000.0, 128, "complex")
+            worst = max(worst, rel(out_s[j][0], w[0]), rel(out_s[j][1], w[1]))
+        for j in range(3):
+            w = E.getEMagLs2Filters(hL, hR, azi, zen, radii[j], maz, mzn, 4, 48000.0, 64, "real")
+            worst = max(worst, rel(out_r[j][0], w[0]), rel(out_r[j][1], w[1]))
+        q.put(("ok", worst))
+    except Exception as e:   # pragma: no cover
+        q.put(("error: %r" % (e,), 1.0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_job_lists_through_rccl_on_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    tag, worst = q.get(timeout=5)
+    print(f"one rank, RCCL collectives, device-resident results: worst rel vs single calls = {worst:.3e}")
+    assert tag == "ok" and worst < 1e-9

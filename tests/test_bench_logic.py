@@ -89,25 +89,32 @@ def test_lane_groups_for_a_radius_sweep():
 
 def test_config4_split_is_class_aware():
     """BASELINE config 4 as named: 256 radii on 2..10 cm over 8 ranks.  Sharding single jobs (round 2) left every rank with
-    23-29 lane batches of 1-2 designs; whole padded lane batches go to ranks now: every batch holds 16 designs (round 4: one
-    resident sweep launch per 16 designs; 8 in round 3) of neighbouring simulation-order classes (laid out for the highest of
-    them), every rank gets 2 batches (4 of 8), loads within 10 % (5 %) by the measured cost model."""
+    23-29 lane batches of 1-2 designs; whole padded lane batches go to ranks now.  Round 5: the batches are cut at equal COST
+    (batch_cost at the batch's size and highest order; high orders: fewer designs per batch, never more than 32), so that the two
+    batches a rank gets weigh the same whichever they are: the most loaded rank carries 1 % more than the least loaded one
+    (batches of equal size: 8 %); every batch holds designs of neighbouring simulation-order classes laid out for the highest."""
     import numpy as np
     from emagls_amd.batch import batch_cost, lane_groups, padded_lane_batches, shard_jobs, shard_lane_batches, simulation_order
     radii = np.linspace(0.02, 0.10, 256)
     so = [simulation_order(4, 48000.0, r, raw=True) for r in radii]
-    for max_batch, per, spread, padding, classes in ((16, 2, 1.10, 1.07, 3), (8, 4, 1.05, 1.04, 2)):
+    for max_batch, per, spread, padding, classes in ((16, 2, 1.03, 1.08, 5), (8, 4, 1.03, 1.04, 3)):
         batches = padded_lane_batches(so, max_batch) if max_batch != 16 else padded_lane_batches(so)
-        assert sorted(j for idx, _ in batches for j in idx) == list(range(256))
+        assert sorted(j for idx, _ in batches for j in idx) == list(range(256)) and len(batches) == 256 // max_batch
+        costs = [batch_cost(len(idx), pad) for idx, pad in batches]
+        assert max(costs) / min(costs) < 1.12                              # equal-cost batches (to one design)
         for idx, pad in batches:
             own = [so[j] for j in idx]
-            assert pad == max(own) and max(own) - min(own) <= classes      # neighbouring classes only
+            assert pad == max(own) and max(own) - min(own) <= classes and 1 <= len(idx) <= 32   # neighbouring classes only
         per_rank, load = shard_lane_batches(batches, 8)
         assert sorted(j for bl in per_rank for idx, _ in bl for j in idx) == list(range(256))
-        assert all(len(bl) == per and sum(len(idx) for idx, _ in bl) == 32 for bl in per_rank)
-        assert all(len(idx) == max_batch for bl in per_rank for idx, _ in bl)
+        assert all(len(bl) == per for bl in per_rank)
         assert max(load) / min(load) < spread
-        # the cost of padding: the batches are laid out for 3 % (6 %) more SH channels than the designs own
+        # equal-size batches for comparison: the round-4 split
+        _, load_eq = shard_lane_batches(padded_lane_batches(so, max_batch, balance=False), 8)
+        assert max(load_eq) / min(load_eq) >= max(load) / min(load)
+        if max_batch == 16:
+            assert max(load_eq) > max(load)      # (the job list ends earlier)
+        # the cost of padding: the batches are laid out for 3 % (7 %) more SH channels than the designs own
         assert sum((pad + 1) ** 2 * len(idx) for idx, pad in batches) / sum((s + 1) ** 2 for s in so) < padding
         if max_batch == 16:
             load16 = max(load)
@@ -116,9 +123,10 @@ def test_config4_split_is_class_aware():
     old = shard_jobs([(s + 1) ** 2 for s in so], 8)
     sizes = [len(g) for s in old for g in lane_groups([so[j] for j in s])]
     assert max(sizes) <= 2
-    # ragged job counts: equal-sized chunks, never a batch of one next to full ones
-    assert [len(idx) for idx, _ in padded_lane_batches([5] * 9 + [7] * 8, 8)] == [6, 6, 5]
-    assert [len(idx) for idx, _ in padded_lane_batches([5] * 9 + [7] * 8)] == [9, 8]
+    # ragged job counts of few classes: never a batch of one next to full ones
+    assert [len(idx) for idx, _ in padded_lane_batches([5] * 9 + [7] * 8, 8, balance=False)] == [6, 6, 5]
+    assert [len(idx) for idx, _ in padded_lane_batches([5] * 9 + [7] * 8, balance=False)] == [9, 8]
+    assert sum(len(idx) for idx, _ in padded_lane_batches([5] * 9 + [7] * 8, 8)) == 17 and min(len(idx) for idx, _ in padded_lane_batches([5] * 9 + [7] * 8, 8)) >= 4
     assert [len(idx) for idx, _ in padded_lane_batches([4] * 3)] == [3] and padded_lane_batches([]) == []
     assert batch_cost(8, 44) > batch_cost(8, 9) > batch_cost(1, 9)
 
