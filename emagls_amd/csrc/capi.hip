@@ -23,6 +23,13 @@ using namespace emagls;
 namespace {
 
 thread_local std::string g_last_error;
+// EMAGLS_JOBS_TRACE=1: wall-clock marks of the job lists' host-side phases on stderr
+static bool trace_on() { static const bool t = getenv("EMAGLS_JOBS_TRACE") != nullptr; return t; }
+static void trace_mark(const char* what) {
+    if (!trace_on()) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "emagls trace: %-44s %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
 
 constexpr double C_SOUND = 343.0;       // dependencies/getSMAIRMatrix.m:86
 constexpr int NFFT_MAX_LEN = 2048;      // lib/getEMagLsFilters.m:35
@@ -1467,11 +1474,16 @@ struct SweepGate {
     }
 };
 
-// EMAGLS_SWEEP_REG=0: the synthesising sweep keeps its slab form (sweep_synth.hip) for every design (read at every launch)
-static bool reg_sweep_enabled() { const char* e = getenv("EMAGLS_SWEEP_REG"); return !(e && e[0] == '0'); }
-// does the register-resident form serve these `n` designs (all synthesising, of one shape) in one launch?
+// EMAGLS_SWEEP_REG=0: the synthesising sweep keeps its slab form (sweep_synth.hip) for every design; 2: the register-resident form for
+// launches of any size (read at every launch)
+static int reg_sweep_mode() { const char* e = getenv("EMAGLS_SWEEP_REG"); return e ? atoi(e) : 1; }
+// does the register-resident form serve these `n` designs (all synthesising, of one shape) in one launch?  Up to 8 designs (one per
+// XCD) the slab form is the faster one -- 5.4 us per bin on 29 CUs per design against 7.0 us on 22 -- and a launch of its own has the
+// device to itself anyway; from 9 designs on the register-resident form wins (16 designs: 3.8 against 3.4 ms next to each other, but
+// 32 designs in 5.2 ms and room for other kernels).
 static bool reg_sweep_wanted(emagls_plan* const* plans, int n) {
-    if (!reg_sweep_enabled() || n < 1) return false;
+    const int mode = reg_sweep_mode();
+    if (mode == 0 || n < 1 || (mode == 1 && n <= 8)) return false;
     const emagls_plan& q = *plans[0];
     for (int j = 0; j < n; ++j) {
         const emagls_plan& p = *plans[j];
@@ -2670,7 +2682,9 @@ void batch_try_lanes(emagls_batch& b) {
     if (!q.sweep_persist) return;
     for (auto* p : b.plans)
         if (p->S != q.S || p->simOrder != q.simOrder || p->d.kind != q.d.kind || p->C != q.C || p->P != q.P) return;
+    trace_mark("lanes: start");
     batch_unify_routes(b);
+    trace_mark("lanes: routes unified");
     batch_unify_synth(b);
     const bool dbg = getenv("EMAGLS_DEBUG_LANES") != nullptr;
     for (auto* p : b.plans) {
@@ -2699,6 +2713,7 @@ void batch_try_lanes(emagls_batch& b) {
         stride += (kv.second.bytes + 255) / 256 * 256;
     }
     stride = (stride + 4095) / 4096 * 4096;
+    trace_mark("lanes: shapes compared");
     auto arena = std::make_shared<Arena>();
     arena->base = BlockPool::get().take((stride * b.plans.size() + ((size_t)64 << 20) - 1) / ((size_t)64 << 20) * ((size_t)64 << 20), &arena->bytes);
     for (size_t j = 0; j < b.plans.size(); ++j) {
@@ -2709,7 +2724,9 @@ void batch_try_lanes(emagls_batch& b) {
             HIP_CHECK(hipMemcpyAsync(dst, kv.second.p, kv.second.bytes, hipMemcpyDeviceToDevice, b.stream));
         }
     }
+    trace_mark("lanes: arena taken, copies enqueued");
     HIP_CHECK(hipStreamSynchronize(b.stream));   // (every plan's streams were synchronised by the caller: the buffers are final)
+    trace_mark("lanes: copies done");
     for (size_t j = 0; j < b.plans.size(); ++j) {
         emagls_plan& p = *b.plans[j];
         size_t i = 0;
@@ -3372,8 +3389,11 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         const bool array_batch = b->plans[0]->d.kind != EMAGLS_KIND_FROM_ATF && !magls_kind(b->plans[0]->d.kind) && b->plans[0]->d.kind != EMAGLS_KIND_LS;
         for (auto* p : b->plans) HIP_CHECK(hipStreamSynchronize(p->stream));
         // (the sweep's form first -- one launch serves every design: the synthesising forms only when all qualify --, then its residency)
+        trace_mark("batch create: plans synchronised");
         if (array_batch) batch_unify_synth(*b);
+        trace_mark("batch create: sweep form unified");
         batch_decide_residency(*b);
+        trace_mark("batch create: residency decided");
         if (nplans > SWEEP_MULTI_MAX && !(b->plans[0]->synth && b->plans[0]->sweep_persist && reg_sweep_wanted(b->plans.data(), nplans)))
             throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 16 designs per batch: only array designs that take the register-resident sweep (built-in SH basis, "
                                                 "microphone grids set, at most 18 antipodal pairs + single microphones, a launch the device can hold)");
@@ -3386,6 +3406,7 @@ int emagls_batch_create(emagls_plan** plans, int nplans, emagls_batch** batch) {
         b->atf = b->plans[0]->d.kind == EMAGLS_KIND_FROM_ATF;
         b->magls = magls_kind(b->plans[0]->d.kind) || b->plans[0]->d.kind == EMAGLS_KIND_LS;
         if (!b->atf && !b->magls) { batch_unify_synth(*b); batch_try_lanes(*b); }
+        trace_mark("batch create: lanes tried");
         *batch = b.release();
     });
 }

@@ -788,7 +788,7 @@ def test_batch_of_ema_in_ch_designs(thin):
         p.close()
 
 
-@pytest.mark.parametrize("mode", ["launch_per_bin", "persistent_write_through", "synthesising", "synthesising_slab"])
+@pytest.mark.parametrize("mode", ["launch_per_bin", "persistent_write_through", "synthesising", "synthesising_registers"])
 def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
     """The phase sweep on materialised operands has three forms: the persistent launch with XCD-local granule stores (default
     when all workgroups of a design share an XCD), the same with write-through stores (any placement), and one launch per
@@ -818,11 +818,11 @@ def test_sweep_variants_agree(grids, thin, monkeypatch, mode):
     assert n_default == 1  # the persistent kernel is the default
     if mode == "launch_per_bin":
         monkeypatch.setenv("EMAGLS_SWEEP_PERSIST", "0")
-    elif mode == "synthesising":
+    elif mode == "synthesising":         # sweep_synth.hip: the form of launches of up to 8 designs
         monkeypatch.setenv("EMAGLS_SWEEP_SYNTH", "1")
-    elif mode == "synthesising_slab":   # sweep_synth.hip instead of sweep_reg.hip
+    elif mode == "synthesising_registers":   # sweep_reg.hip (the form of larger launches) for this single design
         monkeypatch.setenv("EMAGLS_SWEEP_SYNTH", "1")
-        monkeypatch.setenv("EMAGLS_SWEEP_REG", "0")
+        monkeypatch.setenv("EMAGLS_SWEEP_REG", "2")
     else:
         monkeypatch.setenv("EMAGLS_PERSIST_GLOBAL", "1")
     (vL, vR), n_variant = run()
@@ -867,7 +867,7 @@ def test_synthesising_sweep_on_other_arrays(grids, thin, monkeypatch, nmics, pai
     p.set_mic_grid(maz, mzn)
     i = p.info()
     want_units = {"em32": 17, "none": nmics, "some": nmics - 6}[paired]
-    assert i.sweep_form == (3 if want_units <= 18 else 2) and i.sweep_units == want_units, (i.sweep_form, i.sweep_units)
+    assert i.sweep_form == 2 and i.sweep_units == want_units, (i.sweep_form, i.sweep_units)
     p.close()
     for fn, extra in (("getEMagLs2Filters", ()), ("getEMagLsFilters", ())):
         if fn == "getEMagLsFilters" and nmics < (N + 1) ** 2:
@@ -885,6 +885,15 @@ def test_synthesising_sweep_on_other_arrays(grids, thin, monkeypatch, nmics, pai
         print(f"synthesising sweep, {fn}, {nmics} microphones ({paired} pairs, {want_units} units): rel vs oracle = {e_o:.3e}, vs materialised operands = {e_m:.3e}")
         # (explicit margins instead of the oracle tolerance: 10x the largest distances measured over the suite)
         assert e_o < 2e-7 and 0 < e_m < 2e-7
+        if want_units <= 18:   # the register-resident form (sweep_reg.hip: the form of launches of more than 8 designs) on the same design
+            monkeypatch.setenv("EMAGLS_SWEEP_REG", "2")
+            L.check(L.load().emagls_cache_clear())
+            r = getattr(E, fn)(*args)
+            monkeypatch.delenv("EMAGLS_SWEEP_REG")
+            L.check(L.load().emagls_cache_clear())
+            e_r, e_rs = max(rel(r[0], o[0]), rel(r[1], o[1])), max(rel(r[0], w[0]), rel(r[1], w[1]))
+            print(f"    register-resident form: rel vs oracle = {e_r:.3e}, vs the slab form = {e_rs:.3e}")
+            assert e_r < 2e-7 and e_rs < 1e-9
 
 
 def test_residency_is_decided_before_the_launch(grids, thin, monkeypatch):
@@ -906,7 +915,7 @@ def test_residency_is_decided_before_the_launch(grids, thin, monkeypatch):
     p = plan()
     p.execute()
     ref = p.get_filters()
-    assert p.info().sweep_form == 3 and p.info().num_sweep_launches == 1   # resident, operands evaluated in the launch (in registers)
+    assert p.info().sweep_form == 2 and p.info().num_sweep_launches == 1   # resident, operands evaluated in the launch
     p.close()
     # 901 directions = 15 workgroups per design on one XCD: 4 CUs per XCD cannot hold them
     monkeypatch.setenv("EMAGLS_CU_BUDGET", "32")
@@ -931,7 +940,7 @@ def test_residency_is_decided_before_the_launch(grids, thin, monkeypatch):
         plans = [plan(j) for j in range(12)]
         singles = []
         for q in plans:
-            assert q.info().sweep_form == (3 if reg == "1" else 2)
+            assert q.info().sweep_form == 2
             q.execute()
             singles.append(q.get_filters())
         prev = ctypes.c_int(0)
