@@ -4039,6 +4039,10 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags) {
         g_batch_max_override = 0;
         if (rc != EMAGLS_OK && rc != EMAGLS_ERR_UNSUPPORTED) check_rc(rc);   // (unsupported as a batch -- e.g. more than 32 channels: plan by plan)
         if (rc != EMAGLS_OK) slot->batch = nullptr;
+        if (slot->batch) {   // (experiment: EMAGLS_JOBS_FORK=2..4 forks the stages before the sweep of single-group batches onto that many streams)
+            static const int fork = [] { const char* e = getenv("EMAGLS_JOBS_FORK"); return e ? atoi(e) : 0; }();
+            if (fork >= 2 && fork <= 4 && slot->batch->lanes && slot->batch->groups == 1) check_rc(emagls_batch_set_streams(slot->batch, fork));
+        }
         lap("batch created");
     } else if (slot->batch) {
         // the HRIRs of every design on the batch's stream, ordered before its execute: no host synchronisation per plan

@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs*
     if (s_abort) return;
 
     // ---- operand of one bin: E_u, O_u of the lane's direction, the wave's half of the units
+    const bool last_slot_used = ((tid >> 6) & 1) * NUL + NUL - 1 < nun || GB < 2;   // (wave-uniform)
     cplx E[NUL], O[NUL];
 #pragma unroll
     for (int u = 0; u < NUL; ++u) { E[u] = mk(0, 0); O[u] = mk(0, 0); }
@@ -284,7 +285,10 @@ __global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs*
             const double* xcol = xs + launder(tid);
             synth_units<0, GA, NUL, NT>(xcol, E, O, bs, nord_pad);
             __builtin_amdgcn_sched_barrier(0);
-            synth_units<GA, GB, NUL, NT>(xcol, E, O, bs, nord_pad);
+            // (the em32's 17 units: the second wave of a pair holds 8 -- its last slot stays zero and is skipped here, in the p phase's
+            // weights (zero) and in the wave reduction)
+            if (last_slot_used) synth_units<GA, GB, NUL, NT>(xcol, E, O, bs, nord_pad);
+            else synth_units<GA, GB - 1, NUL, NT>(xcol, E, O, bs, nord_pad);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ================= totals of bin kb-1: every workgroup's partial, summed in workgroup order =================
@@ -370,6 +374,7 @@ __global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs*
             cplx p0 = mk(0, 0), p1 = mk(0, 0);
 #pragma unroll
             for (int u = 0; u < NUL; ++u) {
+                if (u == NUL - 1 && !last_slot_used) continue;
                 const cplx we0 = we[u], wo0 = wo[u], we1 = we[NU2 + u], wo1 = wo[NU2 + u];
                 cfma(p0, we0, E[u]); cfma(p0, wo0, O[u]);
                 cfma(p1, we1, E[u]); cfma(p1, wo1, O[u]);
@@ -396,6 +401,7 @@ __global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs*
             double r[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
+                if (NUL % 2 == 1 && c == NCH - 1 && !last_slot_used) { r[c] = 0.0; continue; }   // (a chunk of the unused slot alone)
                 double v[16];   // value j = 8 (slot & 1) + 4 eo + 2 e + ri
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
