@@ -22,15 +22,15 @@ timeout 600 python bench.py --steps 128 --warmup 32 --no-cpu-baseline --no-sh-ro
 export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_single -o bench -- python3 $R/bench.py --steps 8 --warmup 0 --slots 1 --batch 1 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_single.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_batch -o bench -- python3 $R/bench.py --steps 32 --warmup 0 --slots 1 --batch 8 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_batch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_batch16 -o bench -- python3 $R/bench.py --steps 64 --warmup 0 --slots 1 --batch 16 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_batch16.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_batch16 -o bench -- python3 $R/bench.py --steps 128 --warmup 0 --slots 1 --batch 32 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_batch16.log 2>&1
 timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${tag}_prof_slots4 -o bench -- python3 $R/bench.py --steps 128 --warmup 0 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_slots4.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_hrirsets -o hs -- python3 $R/tools/experiments/hrir_sets_prof.py 4 > $R/gpurun_out/${tag}_prof_hrirsets.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_default20 -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sh-roofline --no-secondary > $R/gpurun_out/${tag}_prof_default20.log 2>&1
 if [ "$pmc" = "pmc" ]; then
-  # counters in passes of their own (kernel-trace only next to --pmc); one batch of 16 designs (the bench's default: two lane
-  # groups of 8 before one 16-design sweep launch), 4 batches executed
-  PMCCMD="python3 $R/bench.py --steps 64 --warmup 0 --slots 1 --batch 16 --no-cpu-baseline --no-sh-roofline --no-secondary"
-  for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES; do
+  # counters in passes of their own (kernel-trace only next to --pmc); one chunk of 32 designs in flight (the bench's default shape:
+  # two lane groups of 16 before one 32-design sweep launch), 4 chunks executed after the three set-up runs
+  PMCCMD="python3 $R/bench.py --steps 128 --warmup 0 --slots 1 --batch 32 --no-cpu-baseline --no-sh-roofline --no-secondary"
+  for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU; do
     timeout 400 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/${tag}_pmc_$c -o pmc -- $PMCCMD > $R/gpurun_out/${tag}_pmc_$c.log 2>&1
   done
   cd $R
@@ -41,7 +41,7 @@ cd $R
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_single 1 > gpurun_out/${tag}_kernels_single.md 2>&1
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch 8 > gpurun_out/${tag}_kernels_batch.md 2>&1
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch > gpurun_out/${tag}_kernels_batch_all.md 2>&1
-python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch16 8 > gpurun_out/${tag}_kernels_batch16_groups.md 2>&1
+python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch16 16 > gpurun_out/${tag}_kernels_batch16_groups.md 2>&1
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_batch16 > gpurun_out/${tag}_kernels_batch16_all.md 2>&1
 python tools/sweep_launches.py gpurun_out/${tag}_prof_default20 gpurun_out/${tag}_prof_default20.log > gpurun_out/${tag}_default20_sweep_launches.md 2>&1
 python tools/kernel_avgs.py gpurun_out/${tag}_prof_default20 > gpurun_out/${tag}_default20_kernels.md 2>&1

@@ -27,8 +27,8 @@ def demangle(n):
     return d or n
 
 
-LANES = 8   # grid.z of the stages before the sweep in the profiled command (a 16-design batch runs them as two lane groups of 8)
-SWEEP_DESIGNS = int(os.environ.get("EMAGLS_PMC_SWEEP_DESIGNS", "16"))   # designs one sweep launch of the profiled command covers
+LANES = int(os.environ.get("EMAGLS_PMC_LANES", "16"))   # grid.z of the stages before the sweep in the profiled command (a 32-design chunk runs them as two lane groups of 16)
+SWEEP_DESIGNS = int(os.environ.get("EMAGLS_PMC_SWEEP_DESIGNS", "32"))   # designs one sweep launch of the profiled command covers
 ONCE_PER_GROUP = "hrir_fft"   # a kernel every lane group launches exactly once per execute (counts the executes of the run)
 
 
@@ -60,7 +60,7 @@ def read(d):
     dur = defaultdict(list)
     sweeps = defaultdict(list)
     for kname, cname, _, val, gz, ns in cur.execute(q2):
-        if "sweep_persist" in kname or "sweep_synth" in kname:      # (design = blockIdx.x there, not grid.z: the batch launches are the LAST ones of the run)
+        if "sweep_persist" in kname or "sweep_synth" in kname or "sweep_reg" in kname:      # (design = blockIdx.x there, not grid.z: the batch launches are the LAST ones of the run)
             sweeps[(kname, cname)].append((val, ns))
             continue
         if gz != LANES:
@@ -106,20 +106,20 @@ def main():
             e["write_kb"] = e.get("WRITE_SIZE", 0.0)
             e["bytes"] = int((2 * e["fetch_kb"] + e["write_kb"]) * 1024)
             launches_per_batch[name] = nd
-            if "sweep_persist" in name or "sweep_synth" in name:
+            if "sweep_persist" in name or "sweep_synth" in name or "sweep_reg" in name:
                 sweep_set += e["bytes"] / float(SWEEP_DESIGNS)   # (one launch per batch execute, SWEEP_DESIGNS designs each)
             else:
                 per_set += e["bytes"] * nd
         base = name.split("<")[0]
-        key = base if base in ("sweep_persist_kernel", "sweep_synth_kernel", "sweep_half_kernel", "dspace_g_kernel") else name
+        key = base if base in ("sweep_persist_kernel", "sweep_synth_kernel", "sweep_reg_kernel", "sweep_half_kernel", "dspace_g_kernel") else name
         res[key] = e
         rows.append((name, e))
     # batch executions in the run = dispatches of a kernel that runs once per batch
     n_exec = max([n for k, n in launches_per_batch.items() if k.startswith(ONCE_PER_GROUP)] or [1])
     per_set = per_set / (n_exec * LANES) + sweep_set
     res["per_set"] = {"bytes": int(per_set), "lane_group_executions": n_exec, "sweep_bytes_per_set": int(sweep_set),
-                      "note": "sum over the 8-lane dispatches of the run / (lane-group executions x 8 designs) + the sweep launch's bytes / "
-                              "the designs it covers"}
+                      "note": "sum over the lane-group dispatches of the run / (lane-group executions x %d designs) + the sweep launch's bytes / "
+                              "the designs it covers" % LANES}
     with open(out_json, "w") as f:
         json.dump(res, f, indent=1)
     counters = sorted({c for _, e in rows for c in e if c not in ("dispatches", "fetch_kb", "write_kb", "bytes")})
