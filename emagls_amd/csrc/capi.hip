@@ -3960,7 +3960,7 @@ std::atomic<int> g_jobs_prof{0};                     // emagls_jobs_set_profilin
 // error during capture").  Every other run shares the lock.
 std::shared_timed_mutex g_jobs_warm_mu;
 uint64_t g_jobs_tick = 0;
-std::atomic<size_t> g_jobs_resident_max{4 * REG_SWEEP_MAX};   // designs kept resident between calls (0.19 GB each at config 3); at least one call's chunks in flight
+std::atomic<size_t> g_jobs_resident_max{8 * REG_SWEEP_MAX};   // designs kept resident between calls (0.19 GB each at config 3); at least one call's chunks in flight
 
 void check_rc(int rc) { if (rc != EMAGLS_OK) throw Error(rc, g_last_error); }
 // what makes two designs share a lane batch: everything but the array radius inside one (padded) simulation-order class
@@ -4130,7 +4130,8 @@ int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int i
         if (batch_size <= 0) batch_size = REG_SWEEP_MAX;
         if (in_flight <= 0) in_flight = 4;
         batch_size = std::min(batch_size, REG_SWEEP_MAX);
-        g_jobs_resident_max.store(std::max((size_t)4 * REG_SWEEP_MAX, (size_t)batch_size * (size_t)in_flight));
+        g_jobs_resident_max.store(std::max((size_t)8 * REG_SWEEP_MAX, (size_t)2 * batch_size * (size_t)in_flight));   // (EMAGLS_JOBS_RESIDENT overrides)
+        if (const char* e = getenv("EMAGLS_JOBS_RESIDENT")) { const long v = atol(e); if (v > 0) g_jobs_resident_max.store((size_t)v); }
         int device = 0;
         HIP_CHECK(hipGetDevice(&device));
         // chunks: consecutive jobs of one shape; more than 16 designs per chunk only where the register-resident sweep takes them

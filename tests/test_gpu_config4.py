@@ -149,8 +149,8 @@ def test_run_batch_composes_with_the_real_designs(grids, hrirs64):
 
 @pytest.mark.parametrize("max_batch", [16, 8])
 def test_one_ranks_share_of_config4_in_lane_mode(grids, hrirs64, max_batch):
-    """BASELINE config 4 as named: 256 radii over 8 ranks.  One rank's full share -- 32 radii = 2 padded lane batches of 16 (the
-    default since round 4: one resident sweep launch per 16 designs) or 4 of 8 designs of neighbouring simulation-order classes
+    """BASELINE config 4 as named: 256 radii over 8 ranks.  One rank's full share -- 2 padded lane batches of about 16 designs (cut at
+    equal cost since round 5: more designs per batch at low simulation orders, never more than 32) or 4 of about 8 designs of neighbouring simulation-order classes
     (emagls_amd.batch.padded_lane_batches / shard_lane_batches) -- through Batch: every batch runs in LANE mode, every job equals
     its own one-shot design (which is laid out for its own simulation order, no padding), and one job of every batch is compared
     with the oracle."""
@@ -163,9 +163,10 @@ def test_one_ranks_share_of_config4_in_lane_mode(grids, hrirs64, max_batch):
     so = [simulation_order(4, 48000.0, r, raw=True) for r in radii]
     per_rank, load = shard_lane_batches(padded_lane_batches(so, max_batch), 8)
     mine = per_rank[5]
-    assert len(mine) == 32 // max_batch and all(len(idx) == max_batch for idx, _ in mine)
+    assert len(mine) == 32 // max_batch and all(1 <= len(idx) <= 32 for idx, _ in mine)
+    nmine = sum(len(idx) for idx, _ in mine)
     prev = ctypes.c_int(0)
-    L.check(L.load().emagls_set_batch_max(max_batch, ctypes.byref(prev)))
+    L.check(L.load().emagls_set_batch_max(max(len(idx) for idx, _ in mine), ctypes.byref(prev)))
     results, padded = {}, 0
     for idx, pad in mine:
         plans = []
@@ -189,14 +190,14 @@ def test_one_ranks_share_of_config4_in_lane_mode(grids, hrirs64, max_batch):
         for p in plans:
             p.close()
     L.check(L.load().emagls_set_batch_max(prev.value, None))
-    assert len(results) == 32 and padded >= 4      # the share really mixes simulation-order classes
+    assert len(results) == nmine and padded >= 4      # the share really mixes simulation-order classes
     worst = 0.0
     for idx, _ in mine:                             # first and last job of every batch against its one-shot design
         for j in (idx[0], idx[-1]):
             wL, wR = E.getEMagLs2Filters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], float(radii[j]), grids["mic_azi"],
                                          grids["mic_zen"], 4, 48000.0, length, "real")
             worst = max(worst, rel(results[j][0], wL), rel(results[j][1], wR))
-    print(f"config 4, one rank's share (32 radii, {len(mine)} lane batches): padded lane batches vs one-shot designs, worst rel = {worst:.3e}")
+    print(f"config 4, one rank's share ({nmine} radii, {len(mine)} lane batches): padded lane batches vs one-shot designs, worst rel = {worst:.3e}")
     assert worst < 1e-8
     worst_o = 0.0
     for idx, pad in mine:                           # one padded job per batch against the oracle

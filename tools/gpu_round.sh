@@ -6,13 +6,13 @@ tag=${1:-r}; what=${2:-tests}; pmc=${3:-}
 export EMAGLS_BUILD_TAG=$tag
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 if [ "$what" = "tests" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q -rP -x ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/${tag}_tests_full.log 2>&1
+  timeout 1500 python -m pytest tests -m gpu -q -rP -x --durations=40 ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/${tag}_tests_full.log 2>&1
   tail -5 gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_tests.log
   grep -h "norm_diff=\|rel = \|^case (\|rel L\|worst rel" gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_parity.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
 fi
 if [ "$what" = "testsonly" ]; then
-  timeout 2400 python -m pytest tests -m gpu -q -rP ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/${tag}_tests_full.log 2>&1
+  timeout 2400 python -m pytest tests -m gpu -q -rP --durations=40 ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/${tag}_tests_full.log 2>&1
   tail -15 gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_tests.log
   grep -h "norm_diff=\|rel = \|^case (\|rel L\|worst rel" gpurun_out/${tag}_tests_full.log > gpurun_out/${tag}_parity.log
   cat gpurun_out/${tag}_tests.log; exit 0
