@@ -328,6 +328,12 @@ def main():
     p0.synchronize()
     sweep_ms, sweep_n = p0.sweep_kernel_time()
     info = p0.info()
+    # the sweep form of a chunk of n such designs (decided per launch): a lone design takes the slab form 2, larger chunks form 3
+    form_of_chunk = {}
+    for n_ in range(1, 33):
+        f_ = C.c_int(0)
+        if lib.emagls_plan_sweep_form_in_batch(p0._h, n_, C.byref(f_)) == 0:
+            form_of_chunk[n_] = f_.value
     p0.close()
 
     # ---- SETUP: the job list of the timed region.  One job = one design (descriptor, its own HRIR set resident in HBM, room for its
@@ -431,7 +437,8 @@ def main():
         #   operand synthesis: units x D x (orders padded to even) x 3 fused operations (Chebyshev term + complex sum)
         #   p phase and partial phase: D x channels x 2 ears x 4 each;  M phase: 2 ears x channels^2 x 4 in each of the nWG workgroups
         ch = Mm if synth else Cc
-        reg = info.sweep_form == 3
+        # (the form is decided per launch: a lone design takes the slab form 2, the chunks of the timed region the register-resident form 3)
+        reg = form_of_chunk.get(int(big), info.sweep_form) == 3 if big > 1 else info.sweep_form == 3
         if reg:   # sweep_reg.hip: 4 / 8 / 12 waves of 32 directions per workgroup for up to 8 / 16 / 32 designs per launch
             nw = next(w for w in (4, 6, 8, 10, 12) if -(-big // 8) * -(-D // (32 * w)) <= 32 or w == 12)
             nwg = -(-D // (32 * nw))

@@ -119,6 +119,7 @@ SYMBOLS = {
     "emagls_plan_synchronize": (C.c_int, [C.c_void_p]),
     "emagls_plan_get_filters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "emagls_plan_get_info": (C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
+    "emagls_plan_sweep_form_in_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "emagls_plan_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "emagls_plan_set_streams": (C.c_int, [C.c_void_p, C.c_int]),
     "emagls_plan_num_stages": (C.c_int, [C.c_void_p]),

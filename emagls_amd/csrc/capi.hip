@@ -3235,6 +3235,15 @@ int emagls_plan_get_filters(emagls_plan* p, void* wL, void* wR) {
         HIP_CHECK(hipMemcpy(wR, p->get("wR"), bytes, hipMemcpyDefault));
     });
 }
+int emagls_plan_sweep_form_in_batch(emagls_plan* p, int designs, int* form) {
+    return guarded([&] {
+        DeviceGuard dg(p ? p->device : -1);
+        if (!p || !form || designs < 1 || designs > REG_SWEEP_MAX) throw Error(EMAGLS_ERR_ARG, "emagls_plan_sweep_form_in_batch: null pointer or designs outside 1..32");
+        std::vector<emagls_plan*> same((size_t)designs, p);
+        const bool reg = p->synth && reg_sweep_wanted(same.data(), designs);
+        *form = p->d.kind == EMAGLS_KIND_LS ? 0 : (p->synth ? (reg ? 3 : 2) : (p->sweep_persist ? 1 : 0));
+    });
+}
 int emagls_plan_get_info(emagls_plan* p, emagls_plan_info* info) {
     return guarded([&] {
         DeviceGuard dg(p ? p->device : -1);

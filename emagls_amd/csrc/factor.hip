@@ -371,10 +371,120 @@ __global__ void __launch_bounds__(256) factor_jacobi_pair_kernel(FactorArgs a, F
 // =============================================================================================
 // kernel 3: Z_k = conj(Q2 [N; 0]) by applying the stored reflectors backwards; least-squares bins.
 // =============================================================================================
+// Round 5: the reflector of a step comes from LDS.  Every thread of the workgroup needs all of v_j (the C columns of Z_k are updated
+// with the same vector), and the form of rounds 1-4 -- each thread loads its rows of v_j from global memory, holds them in registers
+// next to its rows of B and was capped at 72 registers so that two workgroups share a CU -- spilled 25 registers inside the loop:
+// 430 MB of scratch writes per 16-design launch, 14 us per step, 354 us per launch (profiles/r05_pmc.md).  Now v_j is staged once per
+// step (zero outside rows j..S-1, so the passes need no row test), v_(j-1) is requested before step j's arithmetic and stored after
+// it, and both passes read the vector from LDS: registers hold B only.
+template <int NCH, int RPT, int MAXT>
+__global__ void __launch_bounds__(MAXT) factor_back_kernel(FactorArgs a, size_t bstride) {
+    batch_offset(a, bstride);
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* vbuf = reinterpret_cast<cplx*>(dyn);   // [2][ldv]
+    __shared__ double tau_s[CPMAX];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int c = tid / NCH, ch = tid % NCH;
+    const int S = a.S, C = a.C, ldS = a.ldS;
+    const int ldv = max(ldS, NCH * RPT);         // (the passes read NCH * RPT rows: zeros beyond S)
+    const int kb = a.kb0 + blockIdx.x;
+    // Z_k feeds the least-squares bins and the ill-conditioned swept bins only (the sweep uses G_k and M_k)
+    if (a.cond_ok && kb >= a.ls_end && a.cond_ok[kb] != 0.0) return;   // (uniform over the workgroup)
+    const bool active = c < C;
+    const cplx* Vw = a.Vws + (int64_t)blockIdx.x * C * ldS;
+    const cplx* N = a.Nw + (int64_t)blockIdx.x * C * C;
+    if (tid < C) tau_s[tid] = a.tauw[(int64_t)blockIdx.x * C + tid];
+    cplx B[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int s = ch + NCH * i;
+        B[i] = (active && s < C) ? N[(int64_t)s * C + c] : mk(0, 0);
+    }
+    // staged elements per thread and step through registers (requested a step ahead); rows beyond NST * threads -- few channels on
+    // many rows -- are staged by a plain loop after the step's arithmetic
+    constexpr int NST = (NCH * RPT + MAXT - 1) / MAXT < 4 ? (NCH * RPT + MAXT - 1) / MAXT : 4;
+    auto stage_load = [&](int j, cplx (&r)[NST]) __attribute__((always_inline)) {
+        const cplx* vj = Vw + (int64_t)j * ldS;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int s = tid + nthr * q;
+            r[q] = (s >= j && s < S) ? vj[s] : mk(0, 0);
+        }
+    };
+    auto stage_store = [&](int j, const cplx (&r)[NST]) __attribute__((always_inline)) {
+        cplx* dst = vbuf + (size_t)(j & 1) * ldv;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int s = tid + nthr * q;
+            if (s < ldv) dst[s] = r[q];
+        }
+    };
+    // rows beyond NST * threads (tall problems on few threads): staged by a plain loop
+    auto stage_rest = [&](int j) __attribute__((always_inline)) {
+        const cplx* vj = Vw + (int64_t)j * ldS;
+        cplx* dst = vbuf + (size_t)(j & 1) * ldv;
+        for (int s = tid + nthr * NST; s < ldv; s += nthr) dst[s] = (s >= j && s < S) ? vj[s] : mk(0, 0);
+    };
+    {
+        cplx r[NST];
+        stage_load(C - 1, r);
+        stage_store(C - 1, r);
+        stage_rest(C - 1);
+    }
+    for (int j = C - 1; j >= 0; --j) {
+        __syncthreads();   // v_j is in its buffer; the other buffer's readers (step j + 1) are done
+        cplx r[NST];
+        if (j > 0) stage_load(j - 1, r);
+        const cplx* v = vbuf + (size_t)(j & 1) * ldv + ch;
+        cplx w = mk(0, 0);
+        // (a few rows at a time: the scheduler would otherwise request all RPT values of the vector at once, next to the RPT rows of B)
+        constexpr int CH = RPT > 8 ? 4 : 8;
+#pragma unroll
+        for (int i0 = 0; i0 < RPT; i0 += CH) {
+#pragma unroll
+            for (int i = i0; i < (i0 + CH < RPT ? i0 + CH : RPT); ++i) cfma_conj(w, v[NCH * i], B[i]);
+            if constexpr (RPT > 8) __builtin_amdgcn_sched_barrier(0);
+        }
+        w = group_sum<NCH>(w);
+        w = w * tau_s[j];
+        // (tall problems: the update pass reads the vector from LDS again instead of holding RPT more values next to B)
+        if constexpr (RPT > 8) asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i0 = 0; i0 < RPT; i0 += CH) {
+#pragma unroll
+            for (int i = i0; i < (i0 + CH < RPT ? i0 + CH : RPT); ++i) { cplx p = w * v[NCH * i]; B[i] -= p; }
+            if constexpr (RPT > 8) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j > 0) { stage_store(j - 1, r); stage_rest(j - 1); }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int s = ch + NCH * i;
+        if (s < S) a.Z[((int64_t)kb * C + c) * ldS + s] = conj(B[i]);
+    }
+    if (a.Hq && kb < a.ls_end) {
+        for (int e = 0; e < 2; ++e) {
+            const cplx* hq = a.Hq + e * a.hq_estride + (int64_t)kb * a.ldHq;
+            cplx w = mk(0, 0);
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int s = ch + NCH * i;
+                if (s < S) { if (a.hq_conj) cfma(w, hq[s], B[i]); else cfma(w, hq[s], conj(B[i])); }
+            }
+            if (a.hq_conj) w = conj(w);
+            w = group_sum<NCH>(w);
+            if (ch == 0) a.W[((int64_t)e * a.P + kb) * C + c] = w;
+        }
+    }
+}
+
+// The form of rounds 1-4 (every thread reads its rows of v_j from global memory): kept for the tall problems (more than 256 rows:
+// config 4's large radii), where the rows of B alone fill the registers a 1024-thread workgroup may have and the compiler spills
+// less around global loads than around the staged form's LDS reads (EMAGLS_BACK_LDS=1 takes the staged form there too).
 template <int NCH, int RPT, int MAXT>
 __global__ void __launch_bounds__(MAXT)
-// (up to 256 rows: at most 72 VGPRs, so that a 16-wave workgroup fits on a CU next to a resident sweep workgroup, 4 x 72 + 224)
-__attribute__((amdgpu_waves_per_eu(RPT <= 8 ? 7 : 4, 8))) factor_back_kernel(FactorArgs a, size_t bstride) {
+__attribute__((amdgpu_waves_per_eu(4, 8))) factor_back_global_kernel(FactorArgs a, size_t bstride) {
     batch_offset(a, bstride);
     const int tid = threadIdx.x;
     const int c = tid / NCH, ch = tid % NCH;
@@ -466,7 +576,16 @@ static void launch_one(const FactorArgs& a, int nbins, hipStream_t st, int phase
         }
     }
     if (phases & 2) {
-        factor_back_kernel<NCH, RPT, MAXT><<<bgrid(nbins), threads, 0, st>>>(a, batch_ctx().stride);
+        static const bool lds_tall = [] { const char* e = getenv("EMAGLS_BACK_LDS"); return e && e[0] == '1'; }();
+        if (RPT <= 8 || lds_tall) {
+            static PerDeviceOnce back_once;
+            if (back_once.first())
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(factor_back_kernel<NCH, RPT, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            const size_t dyn_b = (size_t)2 * std::max(a.ldS, NCH * RPT) * sizeof(cplx);
+            factor_back_kernel<NCH, RPT, MAXT><<<bgrid(nbins), threads, dyn_b, st>>>(a, batch_ctx().stride);
+        } else {
+            factor_back_global_kernel<NCH, RPT, MAXT><<<bgrid(nbins), threads, 0, st>>>(a, batch_ctx().stride);
+        }
         KERNEL_CHECK();
     }
 }

@@ -297,6 +297,9 @@ int emagls_plan_synchronize(emagls_plan* plan);
 /* synchronise, check device-side status flags, copy the filters out */
 int emagls_plan_get_filters(emagls_plan* plan, void* wL, void* wR);
 int emagls_plan_get_info(emagls_plan* plan, emagls_plan_info* info);
+/* the sweep form (emagls_plan_info.sweep_form) a batch of `designs` plans shaped like `plan` takes: what bench.py names its
+ * dominant kernel by (the form is decided per launch, by the number of designs in it) */
+int emagls_plan_sweep_form_in_batch(emagls_plan* plan, int designs, int* form);
 /* 1..4: number of HIP streams one design may use (independent branches fork onto side streams; default 3,
  * best for the latency of ONE design; use 1 when several plans are in flight). Drops the captured graph. */
 int emagls_plan_set_streams(emagls_plan* plan, int nstreams);

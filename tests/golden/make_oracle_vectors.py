@@ -22,11 +22,18 @@ def main():
     azi, zen = g["grid/hrirGridAziRad"], g["grid/hrirGridZenRad"]
     maz, mzn = g["grid/micGridAziRad"], g["grid/micGridZenRad"]
     hL, hR = synth.rigid_sphere_hrirs(azi, zen)
+    path = os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz")
     out = {}
-    # BASELINE config 4, far end of the radius batch: r = 10 cm, 1024 taps, simulation order 44
-    wL, wR = O.getEMagLs2Filters(hL, hR, azi, zen, 0.10, maz, mzn, 4, 48000.0, 1024, "real")
-    out["config4_r100mm_len1024/wL"], out["config4_r100mm_len1024/wR"] = wL, wR
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz"), **out)
+    if os.path.exists(path) and "--all" not in sys.argv:   # (only the cases the file does not hold yet; --all recomputes everything)
+        with np.load(path) as old:
+            out = {k: old[k] for k in old}
+    # BASELINE config 4 at full size (1024 taps): the far end of the radius batch, r = 10 cm, simulation order 44; r = 5 cm, order 22
+    for name, radius in (("config4_r100mm_len1024", 0.10), ("config4_r50mm_len1024", 0.05)):
+        if name + "/wL" in out:
+            continue
+        wL, wR = O.getEMagLs2Filters(hL, hR, azi, zen, radius, maz, mzn, 4, 48000.0, 1024, "real")
+        out[name + "/wL"], out[name + "/wR"] = wL, wR
+    np.savez_compressed(path, **out)
     print({k: v.shape for k, v in out.items()})
 
 
