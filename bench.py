@@ -517,7 +517,7 @@ def main():
         # each loop ran at: the sustained MFMA figure is below AMD's 78.6 TFLOP/s (= 100 % SQ_VALU_MFMA_BUSY_CYCLES, which is
         # how profiles/ prices gram_mfma_kernel's 41 % utilisation)
         peaks_detail = {}
-        for nm, which in (("mfma", 0), ("vector", 1)):
+        for nm, which in (("mfma", 0), ("vector", 1), ("mfma_4x4x4_4b", 2)):
             for mode, burst in (("sustained", 0), ("burst", 1)):
                 tf, mhz = C.c_double(0.0), C.c_double(0.0)
                 if lib.emagls_fp64_peak_tflops_ex(which, burst, C.byref(tf), C.byref(mhz)) == 0:
@@ -536,8 +536,10 @@ def main():
                  "fp64_mfma_peak_tflops_measured": round(peak_mfma.value, 2), "fp64_vector_peak_tflops_measured": round(peak_vec.value, 2),
                  "fp64_peaks_by_launch_length": peaks_detail, "fp64_mfma_peak_tflops_spec": 78.6,
                  "exec_frac_of_vector_peak": (f_exec * K / dt / 1e3) / peak_vec.value if peak_vec.value > 0 else None,
-                 "fp64_mfma_loop_note": "the measured MFMA figure is LOOP limited (the microbenchmark's issue pattern tops out at 63 % of the "
-                                        "pipe at every clock it was run at); kernels' MFMA utilisation is quoted against the 78.6 TFLOP/s spec",
+                 "fp64_mfma_shape_note": "fp64_mfma_peak_tflops_measured is the v_mfma_f64_16x16x4 loop (the shape the pipeline's GEMM kernels issue): "
+                                         "it sustains 62 % of the pipe's nominal rate at any number of waves, accumulators or operand registers; the "
+                                         "v_mfma_f64_4x4x4_4b loop (mfma_4x4x4_4b_* above) reaches 95 % (tools/experiments/mfma_peak.hip); kernels' MFMA "
+                                         "utilisation is quoted against the 78.6 TFLOP/s spec",
                  "note": "F_ref: reference formulation (SURVEY 8d: 126 GFLOP at config 3, 111 of them the pwGrid GEMM the "
                          "factorised pipeline never executes); F_exec: flops the pipeline executes per set; peaks measured on "
                          "this device by emagls_fp64_peak_tflops (v_mfma_f64_16x16x4_f64 / v_fma_f64 on every CU)"}

@@ -1032,11 +1032,15 @@ int emagls_gram_from(const emagls_plan& p) {
     return from < p.P ? from : 0;
 }
 
-// bins per Jacobi workgroup on the Gram route (warm start from the neighbouring bin): 4 in batches of 4+ designs, else 2 / 1
-int jacobi_run_length() {
+// bins per Jacobi workgroup on the Gram route (warm start from the neighbouring bin: fewer rotations per bin, but the launch lasts as
+// long as its longest run).  Round 5, config 3 through the job scheduler: a lone chunk of 20 designs on forked streams -- nothing else
+// on the GPU, the launch on the critical path -- 2219 / 2231 sets/s with runs of 4, 2263 / 2301 with 2, 2277 / 2311 with single bins;
+// chunks in flight next to each other (128 / 512 steps): 3474-3494 / 3537-3639 with 4, 3471-3497 / 3550-3597 with 2, 3375-3465 /
+// 3544-3572 with 1.  So: single bins where the stages before the sweep are forked (latency mode), runs of 2 in lane groups.
+int jacobi_run_length(const emagls_plan& p) {
     static const int forced = [] { const char* e = getenv("EMAGLS_JACOBI_RUN"); return e ? std::max(1, atoi(e)) : 0; }();
     if (forced) return forced;
-    return batch_ctx().n >= 4 ? 4 : (batch_ctx().n >= 2 ? 2 : 1);
+    return (batch_ctx().n >= 2 && p.nstreams <= 1) ? 2 : 1;
 }
 
 // getEMagLsFiltersEMAinSH: everything before the sweep (kernels and derivation: emash.hip).  One stream.
@@ -1116,7 +1120,7 @@ void ema_sh_pre_sweep(emagls_plan& p) {
         fg.cond_limit = 10.0 * GRAM_COND_EST;
         fg.sweeps_out = p.get<int>("jsweeps");
         fg.tauw = p.get<double>("tauw"); fg.R2w = p.get<cplx>("R2w"); fg.Nw = p.get<cplx>("Nw"); fg.Mw = p.get<cplx>("Mw");
-        fg.jrun = jacobi_run_length();
+        fg.jrun = jacobi_run_length(p);
         launch_factor_jacobi_gram(fg, nb, st);
     }
     launch_cond_flags(p.get<double>("sv"), p.C, p.P, 1, p.get<double>("cond_ok"), st);
@@ -1294,7 +1298,7 @@ void emagls_pre_sweep(emagls_plan& p) {
         fg.R2w = fa.R2w + off * p.C * p.C; fg.Mw = fa.Mw + off * p.C * p.C; fg.Nw = fa.Nw + off * p.C * p.C; fg.tauw = fa.tauw + off * p.C;
         // batches have workgroups to spare: a Jacobi workgroup walks a run of neighbouring bins, each warm-started from the
         // previous one (a third of the sweeps); a single design keeps one bin per workgroup (shortest critical path)
-        fg.jrun = jacobi_run_length();
+        fg.jrun = jacobi_run_length(p);
         if (merge_jacobi) { fg_deferred = fg; }   // (one launch with the Householder-route bins: blk_hh_route)
         else launch_factor_jacobi_gram(fg, p.nb_gram, s3);
         p.mark("gram_route");
@@ -3023,7 +3027,7 @@ int emagls_cache_clear(void) {
 
 int emagls_fp64_peak_tflops(int which, double* tflops) {
     return guarded([&] {
-        if (!tflops || which < 0 || which > 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        if (!tflops || which < 0 || which > 2) throw Error(EMAGLS_ERR_ARG, "invalid argument");
         *tflops = measure_fp64_peak(which, 3);
     });
 }
@@ -3037,7 +3041,7 @@ int emagls_self_test(int which, double* max_err) {
 
 int emagls_fp64_peak_tflops_ex(int which, int burst, double* tflops, double* shader_mhz) {
     return guarded([&] {
-        if (!tflops || which < 0 || which > 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        if (!tflops || which < 0 || which > 2) throw Error(EMAGLS_ERR_ARG, "invalid argument");
         *tflops = measure_fp64_peak(which, 3, burst != 0, shader_mhz);
     });
 }

@@ -15,6 +15,7 @@
 namespace emagls {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
 // Gram.  Workgroup = 4 waves = 64x64 tile of G, each wave a 32x32 sub-tile (2x2 MFMA tiles).
@@ -162,6 +163,87 @@ __global__ void __launch_bounds__(256) gram_lds_kernel(const double* __restrict_
                     if (R && gi < Sh && gj < Sh) { R[(int64_t)gi * Sh + gj] = v; if (!diag) R[(int64_t)gj * Sh + gi] = 0.0; }
                 }
             }
+}
+
+// Round 5: the same tile on v_mfma_f64_4x4x4_4b.  On gfx950 the 16 x 16 x 4 FP64 shape sustains 49 TFLOP/s whatever is done around it
+// (62 % of the pipe's nominal rate), the four-block 4 x 4 x 4 shape 75 (tools/experiments/mfma_peak.hip); operand layout found by
+// experiment (tools/experiments/mfma_4x4_layout.hip): lane l = x + 4 b + 16 y supplies A_b[i = x][k = y] and B_b[k = y][j = x] and
+// receives D_b[i = y][j = x].  A wave's 32 x 32 sub-tile is 8 row tiles (ra) x 2 column groups (rb) of four blocks: element
+// (4 ra + i, 16 rb + 4 b + j) accumulates in register [ra][rb] of lane j + 4 b + 16 i -- sixteen independent instructions per four
+// rows of Y.  The stages hold the panels permuted so that a lane's eight A values and two B values of a row are contiguous
+// (four + one ds_read_b128 per sixteen instructions; lanes that differ in b only read the same A address: a broadcast).
+//   A stage  [k][half][i][ra]      column 32 half + 4 ra + i of the row panel
+//   B stage  [k][half][4 b + j][rb]  column 32 half + 16 rb + 4 b + j of the column panel
+constexpr int G4_LD = 64 + 8;
+__global__ void __launch_bounds__(256) gram_lds4_kernel(const double* __restrict__ Yc, int64_t ld, int S, int64_t rows, int nbt,
+                                                        double* __restrict__ G, double* __restrict__ R, int Sh, size_t bstride) {
+    Yc = boff(Yc, bstride); G = boff(G, bstride); R = boff(R, bstride);
+    __shared__ __attribute__((aligned(16))) double As[2][GL_KC][G4_LD];
+    __shared__ __attribute__((aligned(16))) double Bs[2][GL_KC][G4_LD];
+    int t = blockIdx.x, ti = 0;
+    while (t >= nbt - ti) { t -= nbt - ti; ++ti; }
+    const int tj = ti + t;
+    const bool diag = ti == tj;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int hi = wave >> 1, hj = wave & 1;                    // the wave's 32 x 32 sub-tile: row half, column half
+    const int lx = lane & 3, lb = (lane >> 2) & 3, ly = lane >> 4;
+    // loader role: row lr of the stage, columns lc .. lc + 3 of the panel (16 threads cover one 512-byte row segment)
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    const double* pa = Yc + (int64_t)lr * ld + ti * 64 + lc;
+    const double* pb = Yc + (int64_t)lr * ld + tj * 64 + lc;
+    // where the loader's four columns go: A layout (i = q, ra = (lc & 31) / 4), B layout (j = q, b = (lc / 4) & 3, rb = (lc & 31) / 16)
+    const int sa = (lc >> 5) * 32 + ((lc & 31) >> 2);                               // + 8 q
+    const int sb = (lc >> 5) * 32 + (((lc >> 2) & 3) * 4) * 2 + ((lc & 31) >> 4);    // + 2 q
+    double4_t ra4, rb4;
+    auto fetch = [&](int64_t d0) __attribute__((always_inline)) {
+        const bool ok = d0 + lr < rows;
+        ra4 = ok ? *reinterpret_cast<const double4_t*>(pa + d0 * ld) : double4_t{0, 0, 0, 0};
+        rb4 = diag ? ra4 : (ok ? *reinterpret_cast<const double4_t*>(pb + d0 * ld) : double4_t{0, 0, 0, 0});
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { As[buf][lr][sa + 8 * q] = ra4[q]; Bs[buf][lr][sb + 2 * q] = rb4[q]; }
+    };
+    double acc[8][2];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) { acc[x][0] = 0.0; acc[x][1] = 0.0; }
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int64_t nst = (rows + GL_KC - 1) / GL_KC;
+    const int oa = hi * 32 + lx * 8, ob = hj * 32 + (lb * 4 + lx) * 2;
+    for (int64_t c = 0; c < nst; ++c) {
+        const int buf = (int)(c & 1);
+        if (c + 1 < nst) fetch((c + 1) * GL_KC);
+#pragma unroll
+        for (int k4 = 0; k4 < GL_KC; k4 += 4) {
+            const double* arow = &As[buf][k4 + ly][oa];
+            const double* brow = &Bs[buf][k4 + ly][ob];
+            double a[8], b[2];
+#pragma unroll
+            for (int x = 0; x < 8; x += 2) { const double2_t v = *reinterpret_cast<const double2_t*>(arow + x); a[x] = v[0]; a[x + 1] = v[1]; }
+            { const double2_t v = *reinterpret_cast<const double2_t*>(brow); b[0] = v[0]; b[1] = v[1]; }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                acc[x][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[x], b[0], acc[x][0], 0, 0, 0);
+                acc[x][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[x], b[1], acc[x][1], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nst) stage(buf ^ 1);
+        __syncthreads();
+    }
+    const int i0 = ti * 64 + hi * 32, j0 = tj * 64 + hj * 32;
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int gi = i0 + 4 * x + ly, gj = j0 + 16 * y + 4 * lb + lx;
+            if (gi < S && gj < S) {
+                const double v = acc[x][y];
+                if (G) { G[(int64_t)gi * S + gj] = v; if (!diag) G[(int64_t)gj * S + gi] = 0.0; }   // (block lower triangle: zeros, like the reduce kernel)
+                if (R && gi < Sh && gj < Sh) { R[(int64_t)gi * Sh + gj] = v; if (!diag) R[(int64_t)gj * Sh + gi] = 0.0; }
+            }
+        }
 }
 
 // sums the K-split partials into the Gram matrix Gy (S x S, upper block triangle) and copies its leading Sh x Sh block to R
@@ -639,7 +721,14 @@ static void gram_impl(const void* Yc, int64_t D, int S, int64_t ld, void* Gp, vo
         // enough tiles to fill the chip without a K split (lane batches of array designs): the LDS-staged kernel, no partials
         static const bool lds_ok = [] { const char* e = getenv("EMAGLS_GRAM_LDS"); return !(e && e[0] == '0'); }();
         if (lds_ok && (int64_t)ntiles * batch_ctx().n >= 128 && ld >= 64 * nbt) {
-            gram_lds_kernel<<<bgrid(ntiles), 256, 0, st>>>((const double*)Yc, ld, S, gram_dpad(D, S), nbt, (double*)G, (double*)R, Sh, batch_ctx().stride);
+            // EMAGLS_GRAM_MFMA4=1: the tile on the 4 x 4 x 4 shape.  Measured (16 designs per launch, 448 workgroups, nothing else on the
+            // GPU): 304 us against 236 us for the 16 x 16 x 4 kernel -- that one runs AT its shape's limit (42 of 49 TFLOP/s), this one
+            // at 47 % of the pipe: with two waves per SIMD (the tile count allows no more) the LDS reads and the stage barrier are not
+            // hidden behind sixteen-cycle instructions.  Off by default.
+            const char* e4 = getenv("EMAGLS_GRAM_MFMA4");   // (read at every launch: a test switches forms inside one process)
+            const bool four = e4 && e4[0] == '1';
+            if (four) gram_lds4_kernel<<<bgrid(ntiles), 256, 0, st>>>((const double*)Yc, ld, S, gram_dpad(D, S), nbt, (double*)G, (double*)R, Sh, batch_ctx().stride);
+            else gram_lds_kernel<<<bgrid(ntiles), 256, 0, st>>>((const double*)Yc, ld, S, gram_dpad(D, S), nbt, (double*)G, (double*)R, Sh, batch_ctx().stride);
             KERNEL_CHECK();
             return;
         }

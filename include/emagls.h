@@ -65,7 +65,9 @@ int emagls_set_device(int device);
 int emagls_cache_clear(void);
 
 /* Measured FP64 peak of the current device in TFLOP/s (best of a few launches that keep every CU busy): which = 0 the matrix
- * pipe (v_mfma_f64_16x16x4_f64), which = 1 the vector pipe (v_fma_f64).  bench.py prices its executed flops against it. */
+ * pipe on v_mfma_f64_16x16x4_f64 (the shape the pipeline's GEMM kernels issue), which = 1 the vector pipe (v_fma_f64), which = 2
+ * the matrix pipe on v_mfma_f64_4x4x4_4b_f64 -- on gfx950 the shape that reaches the pipe's nominal rate (75 of 78.6 TFLOP/s; the
+ * 16 x 16 x 4 shape sustains 49).  bench.py prices its executed flops against the vector figure. */
 int emagls_fp64_peak_tflops(int which, double* tflops);
 /* The same with the launch length chosen: burst != 0 times launches of <= 1 ms (before the chip settles at its sustained power
  * state), burst == 0 the ~10 ms launches of the call above; shader_mhz (optional) receives the shader clock the timed loop ran

@@ -764,6 +764,33 @@ def test_sixteen_design_lane_batch(grids, thin, monkeypatch):
         p.close()
 
 
+def test_gram_tile_on_the_four_block_mfma_shape(grids, thin, monkeypatch):
+    """The Gram product of a lane batch on v_mfma_f64_4x4x4_4b (EMAGLS_GRAM_MFMA4=1; gram_chol.hip: measured slower than the
+    16 x 16 x 4 kernel in this pipeline, so off by default) against the default kernel: the same filters to rounding."""
+    from emagls_amd import Batch, Plan, _lib as L, synth
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EMAGLS_GRAM_MFMA4", mode)
+        plans = []
+        for j in range(5):   # (28 tiles x 5 designs: the LDS-staged tile kernels take over from 128 workgroups on)
+            azi = np.mod(thin["azi"] + 0.21 * j, 2 * np.pi)
+            hL, hR = synth.rigid_sphere_hrirs(azi, thin["zen"], seed=11 + j)
+            p = Plan(L.KIND_EMAGLS, "real", 4, 48000.0, 128, hL.shape[0], hL.shape[1], 0.042, 32)
+            p.set_hrir_grid(azi, thin["zen"])
+            p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+            p.set_hrirs(hL, hR)
+            plans.append(p)
+        b = Batch(plans)
+        b.execute()
+        res[mode] = b.get_filters()
+        b.close()
+        for p in plans:
+            p.close()
+    worst = max(max(rel(a[0], c[0]), rel(a[1], c[1])) for a, c in zip(res["0"], res["1"]))
+    print(f"Gram tile on the 4 x 4 x 4 shape vs the 16 x 16 x 4 kernel: worst rel = {worst:.3e}")
+    assert 0.0 < worst < 1e-9      # (not bit-identical: another summation order; if it were, the switch did nothing)
+
+
 def test_batch_of_ema_in_ch_designs(thin):
     """Equatorial-array designs in a lane batch (odd channel count, 9): equal to the one-shot entry point."""
     import emagls_amd as E

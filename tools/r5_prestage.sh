@@ -17,12 +17,12 @@ run b20c python bench.py --steps 20 --warmup 5 $B
 run b128 python bench.py --steps 128 --warmup 32 $B
 run b512 python bench.py --steps 512 --warmup 64 $B
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof -o p -- python3 $R/bench.py --steps 20 --warmup 5 $B > $R/gpurun_out/${tag}_prof.log 2>&1
-cd $R; f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python - "$f" <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:24]:
-    print("%-70s %6s calls  avg %9.1f us  total %9.1f ms" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
-PY
-rm -rf gpurun_out/${tag}_prof
+# kernel times: one 32-design chunk at a time (two lane groups of 16), and the driver's 20-step command
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof16 -o p -- python3 $R/bench.py --steps 128 --warmup 0 --slots 1 --batch 32 $B > $R/gpurun_out/${tag}_prof16.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof20 -o p -- python3 $R/bench.py --steps 20 --warmup 5 $B > $R/gpurun_out/${tag}_prof20.log 2>&1
+cd $R
+python tools/kernel_avgs.py gpurun_out/${tag}_prof16 16 > gpurun_out/${tag}_kernels16.md 2>&1
+python tools/kernel_avgs.py gpurun_out/${tag}_prof20 20 > gpurun_out/${tag}_kernels20.md 2>&1
+python tools/fill_timeline.py gpurun_out/${tag}_prof20 2 > gpurun_out/${tag}_timeline20.md 2>&1
+rm -rf gpurun_out/${tag}_prof16 gpurun_out/${tag}_prof20
+head -22 gpurun_out/${tag}_kernels16.md | cut -c1-150
