@@ -323,13 +323,22 @@ def test_lane_batch_matches_single_designs(grids, thin):
         else:
             for (wL, wR), (fL, fR) in zip(res, first):
                 assert np.array_equal(wL, fL) and np.array_equal(wR, fR), it
-    # the stages before the sweep forked onto four streams (emagls_batch_set_streams; what bench.py runs): eager, captured with
-    # the forks, replayed -- bitwise the same filters as on one stream
+    # the stages before the sweep forked onto four streams (emagls_batch_set_streams; what a job list of one chunk runs): eager,
+    # captured with the forks, replayed -- the same filters as on one stream to rounding (since round 5 the forked form takes its
+    # Gram-route Jacobi bins one by one and the lane groups in warm-started runs of two: not bitwise the same), and bitwise the same
+    # from execute to execute
     b.set_streams(4)
+    forked = None
     for it in range(3):
         b.execute()
-        for (wL, wR), (fL, fR) in zip(b.get_filters(), first):
-            assert np.array_equal(wL, fL) and np.array_equal(wR, fR), it
+        got = b.get_filters()
+        for (wL, wR), (fL, fR) in zip(got, first):
+            assert rel(wL, fL) < 1e-12 and rel(wR, fR) < 1e-12, it
+        if forked is None:
+            forked = got
+        else:
+            for (wL, wR), (fL, fR) in zip(got, forked):
+                assert np.array_equal(wL, fL) and np.array_equal(wR, fR), it
     b.set_streams(1)
     b.execute()
     for (wL, wR), (fL, fR) in zip(b.get_filters(), first):
