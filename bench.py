@@ -441,6 +441,10 @@ def main():
         reg = form_of_chunk.get(int(big), info.sweep_form) == 3 if big > 1 else info.sweep_form == 3
         if reg:   # sweep_reg.hip: 4 / 8 / 12 waves of 32 directions per workgroup for up to 8 / 16 / 32 designs per launch
             nw = next(w for w in (4, 6, 8, 10, 12) if -(-big // 8) * -(-D // (32 * w)) <= 32 or w == 12)
+            # (a launch whose designs are spread over all XCDs because that needs fewer waves per workgroup: reg_sweep_spread_waves)
+            nw_spread = next((w for w in (4, 6, 8, 10, 12) if big * -(-D // (32 * w)) <= 256), nw)
+            if os.environ.get("EMAGLS_REG_SPREAD", "2") != "0" and nw_spread < nw:
+                nw = nw_spread
             nwg = -(-D // (32 * nw))
         else:
             nwg = -(-D // (64 if D <= 2048 else 96))

@@ -1487,7 +1487,8 @@ static int reg_sweep_mode() { const char* e = getenv("EMAGLS_SWEEP_REG"); return
 // 32 designs in 5.2 ms and room for other kernels).
 static bool reg_sweep_wanted(emagls_plan* const* plans, int n) {
     const int mode = reg_sweep_mode();
-    if (mode == 0 || n < 1 || (mode == 1 && n <= 8)) return false;
+    static const int reg_min = [] { const char* e = getenv("EMAGLS_SWEEP_REG_MIN"); return e ? std::max(1, atoi(e)) : 9; }();   // (experiments)
+    if (mode == 0 || n < 1 || (mode == 1 && n < reg_min)) return false;
     const emagls_plan& q = *plans[0];
     for (int j = 0; j < n; ++j) {
         const emagls_plan& p = *plans[j];
@@ -3034,8 +3035,8 @@ int emagls_fp64_peak_tflops(int which, double* tflops) {
 
 int emagls_self_test(int which, double* max_err) {
     return guarded([&] {
-        if (!max_err || which != 0) throw Error(EMAGLS_ERR_ARG, "invalid argument");
-        *max_err = reg_reduce_selftest();
+        if (!max_err || which < 0 || which > 2) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        *max_err = which == 0 ? reg_reduce_selftest() : gram_tile_selftest(which == 2);
     });
 }
 

@@ -10,6 +10,8 @@
 // The HRIR grid's SH matrix is well conditioned (cond 1.5 at N=19 on the 2702-point grid), so
 // Cholesky-QR loses nothing; a non-positive pivot raises a device flag and the host reports it.
 #include <cstdlib>
+#include <vector>
+
 #include "kernels.hpp"
 
 namespace emagls {
@@ -244,6 +246,45 @@ __global__ void __launch_bounds__(256) gram_lds4_kernel(const double* __restrict
                 if (R && gi < Sh && gj < Sh) { R[(int64_t)gi * Sh + gj] = v; if (!diag) R[(int64_t)gj * Sh + gi] = 0.0; }
             }
         }
+}
+
+// both tile kernels on a pseudo-random matrix against a plain host sum (debug entry emagls_self_test(1)): largest error relative to
+// the largest element of the Gram matrix; `four` selects the kernel
+double gram_tile_selftest(bool four) {
+    const int S = 100, D = 333, ld = 128, nbt = 2, ntiles = 3;
+    const int64_t rows = 336;   // (a multiple of four, like gram_dpad)
+    std::vector<double> Y((size_t)rows * ld, 0.0), G((size_t)S * S, 0.0), want((size_t)S * S, 0.0);
+    unsigned long long x = 88172645463325252ull;
+    for (int d = 0; d < D; ++d)
+        for (int c = 0; c < S; ++c) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; Y[(size_t)d * ld + c] = (double)(x % 2000001ull) / 1000000.0 - 1.0; }
+    double gmax = 0.0;
+    for (int i = 0; i < S; ++i)
+        for (int j = i; j < S; ++j) {
+            double acc = 0.0;
+            for (int d = 0; d < D; ++d) acc += Y[(size_t)d * ld + i] * Y[(size_t)d * ld + j];
+            want[(size_t)i * S + j] = acc;
+            gmax = std::max(gmax, std::fabs(acc));
+        }
+    double *dY = nullptr, *dG = nullptr;
+    HIP_CHECK(hipMalloc(&dY, sizeof(double) * Y.size()));
+    HIP_CHECK(hipMalloc(&dG, sizeof(double) * G.size()));
+    HIP_CHECK(hipMemcpy(dY, Y.data(), sizeof(double) * Y.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(dG, 0, sizeof(double) * G.size()));
+    if (four) gram_lds4_kernel<<<dim3(ntiles), 256>>>(dY, ld, S, rows, nbt, dG, nullptr, 0, 0);
+    else gram_lds_kernel<<<dim3(ntiles), 256>>>(dY, ld, S, rows, nbt, dG, nullptr, 0, 0);
+    KERNEL_CHECK();
+    HIP_CHECK(hipMemcpy(G.data(), dG, sizeof(double) * G.size(), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipFree(dY));
+    HIP_CHECK(hipFree(dG));
+    double err = 0.0;
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) {
+            // (upper block triangle: the tiles (0,0), (0,1), (1,1); inside a diagonal tile both triangles are written)
+            const bool upper_block = (i >> 6) <= (j >> 6);
+            const double w = upper_block ? want[(size_t)std::min(i, j) * S + std::max(i, j)] : 0.0;
+            err = std::max(err, std::fabs(G[(size_t)i * S + j] - w));
+        }
+    return err / gmax;
 }
 
 // sums the K-split partials into the Gram matrix Gy (S x S, upper block triangle) and copies its leading Sh x Sh block to R

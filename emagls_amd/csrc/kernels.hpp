@@ -130,6 +130,7 @@ int reg_sweep_gate_cost(int D, int ndesigns);   // what such a launch takes of t
 bool reg_sweep_fits(int D, int nmics, int nunits, int nOrd, int ndesigns);
 void launch_sweep_reg(const HalfSweepArgs* args_dev, const HalfSweepArgs& a0, int n, hipStream_t st);
 double reg_reduce_selftest();
+double gram_tile_selftest(bool four);   // gram_chol.hip: the LDS-staged Gram tile kernels against a host sum
 void store_sweep_args(const HalfSweepArgs* host, int n, HalfSweepArgs* dev, hipStream_t st);
 void launch_sweep_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);
 void launch_hy_conj(const void* Hc, int64_t ldD, int nrows, const void* Yc, int64_t ldY, bool y_cplx, int D, int S, void* Pw, void* out,

@@ -134,7 +134,7 @@ constexpr int RG_SVC = 256;           // threads that serve the workgroup: excha
 
 // NUL: unit slots per lane (a direction's units are split between the two waves of a pair: 2 NUL >= units); NW: waves per workgroup
 template <int NUL, int NW>
-__global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs* __restrict__ args, int n, int nWG) {
+__global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs* __restrict__ args, int n, int nWG, int spread) {
     constexpr int NT = 64 * NW, DPW = 32 * NW, NB = NW / 2;   // threads, directions and 64-direction blocks of a workgroup
     constexpr int NU2 = 2 * NUL;            // unit slots of a direction
     constexpr int NCH = (NUL + 1) / 2;      // chunks of two slots in the wave reduction
@@ -155,9 +155,19 @@ __global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs*
     // block -> (XCD, slot) -> (design, member): design j lives on XCD j % 8, the (j / 8)-th design there.  (One design's workgroups
     // after the other's: taking the slots in turn was tried -- with workgroups that share CUs unevenly BOTH designs then run at the
     // pace of their slowest workgroups, 9.9 us per bin each instead of 7.2 / 10.4.)
-    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int sub = rest / nWG, member = rest - sub * nWG;
-    const int design = xcd + 8 * sub;
+    // spread != 0: a design's workgroups are consecutive blocks, i.e. dealt round over ALL XCDs -- for design counts that leave
+    // CUs idle when every design must stay inside one XCD (20 designs: three per XCD on four of them, ten waves per CU on 27 of 32
+    // CUs, against eight waves on 220 of 256); the granules then travel through memory (the check below finds the XCDs differ)
+    int design, member;
+    if (spread) {
+        design = (int)blockIdx.x / nWG;
+        member = (int)blockIdx.x - design * nWG;
+    } else {
+        const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+        const int sub = rest / nWG;
+        member = rest - sub * nWG;
+        design = xcd + 8 * sub;
+    }
     if (design >= n) return;
     const HalfSweepArgs& a = args[design];
     const int tid = threadIdx.x;
@@ -550,7 +560,19 @@ int reg_sweep_pick_waves(int D, int ndesigns) {
     for (int nw : RG_WAVES) if (nsub * reg_nwg(D, nw) <= cus) return nw;
     return nsub * reg_nwg(D, 4) <= 3 * cus ? 4 : 0;
 }
+// Waves per workgroup when the designs of a launch are spread over all XCDs (0: not spread): taken when it gives every workgroup a
+// CU of its own with FEWER waves than the XCD-local layout needs (EMAGLS_REG_SPREAD=0: never, =1: whenever it fits).
+int reg_sweep_spread_waves(int D, int ndesigns) {
+    const char* es = getenv("EMAGLS_REG_SPREAD");   // (read at every launch: a test switches layouts inside one process)
+    const int mode = es ? atoi(es) : 2;
+    if (mode == 0 || ndesigns < 1 || ndesigns > REG_SWEEP_MAX || getenv("EMAGLS_REG_WAVES")) return 0;
+    const int cus = sweep_cu_budget(), local = reg_sweep_pick_waves(D, ndesigns);
+    for (int nw : RG_WAVES)
+        if (ndesigns * reg_nwg(D, nw) <= cus) return (mode == 1 || local == 0 || nw < local) ? nw : 0;
+    return 0;
+}
 int reg_sweep_gate_cost(int D, int ndesigns) {
+    if (const int ns = reg_sweep_spread_waves(D, ndesigns)) return (int)ceil_div((int64_t)ndesigns * reg_nwg(D, ns), 8) * reg_wg_cost(ns);
     const int nw = reg_sweep_pick_waves(D, ndesigns);
     return nw ? (int)ceil_div(ndesigns, 8) * reg_nwg(D, nw) * reg_wg_cost(nw) : 0;
 }
@@ -565,18 +587,19 @@ bool reg_sweep_fits(int D, int nmics, int nunits, int nOrd, int ndesigns) {
 
 // args: `n` argument blocks in device memory
 void launch_sweep_reg(const HalfSweepArgs* args_dev, const HalfSweepArgs& a0, int n, hipStream_t st) {
-    const int nw = reg_sweep_pick_waves(a0.D, n);
+    const int ns = reg_sweep_spread_waves(a0.D, n);
+    const int nw = ns ? ns : reg_sweep_pick_waves(a0.D, n);
     if (!nw) throw Error(2, "register-resident sweep: the launch cannot be resident");
-    const int nWG = reg_nwg(a0.D, nw);
-    const unsigned nblocks = 8u * (unsigned)nWG * (unsigned)ceil_div(n, 8);
+    const int nWG = reg_nwg(a0.D, nw), spread = ns ? 1 : 0;
+    const unsigned nblocks = spread ? (unsigned)(n * nWG) : 8u * (unsigned)nWG * (unsigned)ceil_div(n, 8);
     const size_t dyn = reg_dyn_bytes(RG_NUL, nw);
     reg_set_attributes();
     switch (nw) {
-        case 4: sweep_reg_kernel<RG_NUL, 4><<<dim3(nblocks), 256, dyn, st>>>(args_dev, n, nWG); break;
-        case 6: sweep_reg_kernel<RG_NUL, 6><<<dim3(nblocks), 384, dyn, st>>>(args_dev, n, nWG); break;
-        case 8: sweep_reg_kernel<RG_NUL, 8><<<dim3(nblocks), 512, dyn, st>>>(args_dev, n, nWG); break;
-        case 10: sweep_reg_kernel<RG_NUL, 10><<<dim3(nblocks), 640, dyn, st>>>(args_dev, n, nWG); break;
-        default: sweep_reg_kernel<RG_NUL, 12><<<dim3(nblocks), 768, dyn, st>>>(args_dev, n, nWG); break;
+        case 4: sweep_reg_kernel<RG_NUL, 4><<<dim3(nblocks), 256, dyn, st>>>(args_dev, n, nWG, spread); break;
+        case 6: sweep_reg_kernel<RG_NUL, 6><<<dim3(nblocks), 384, dyn, st>>>(args_dev, n, nWG, spread); break;
+        case 8: sweep_reg_kernel<RG_NUL, 8><<<dim3(nblocks), 512, dyn, st>>>(args_dev, n, nWG, spread); break;
+        case 10: sweep_reg_kernel<RG_NUL, 10><<<dim3(nblocks), 640, dyn, st>>>(args_dev, n, nWG, spread); break;
+        default: sweep_reg_kernel<RG_NUL, 12><<<dim3(nblocks), 768, dyn, st>>>(args_dev, n, nWG, spread); break;
     }
     KERNEL_CHECK();
 }

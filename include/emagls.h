@@ -74,7 +74,8 @@ int emagls_fp64_peak_tflops(int which, double* tflops);
  * at (in-kernel cycle counter over the 100 MHz wall counter). */
 int emagls_fp64_peak_tflops_ex(int which, int burst, double* tflops, double* shader_mhz);
 /* Device-side self tests of building blocks that have no entry point of their own.  which = 0: the wave reduction of the
- * register-resident sweep (permlane swaps and DPP steps against a plain sum; max_err: largest absolute difference). */
+ * register-resident sweep (permlane swaps and DPP steps against a plain sum; max_err: largest absolute difference); which = 1 / 2:
+ * the LDS-staged Gram tile on v_mfma_f64_16x16x4 / on v_mfma_f64_4x4x4_4b against a host sum (max_err relative to the largest element). */
 int emagls_self_test(int which, double* max_err);
 
 /* ---- kernel-level entry points ------------------------------------------------------------- */

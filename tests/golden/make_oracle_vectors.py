@@ -33,6 +33,17 @@ def main():
             continue
         wL, wR = O.getEMagLs2Filters(hL, hR, azi, zen, radius, maz, mzn, 4, 48000.0, 1024, "real")
         out[name + "/wL"], out[name + "/wR"] = wL, wR
+    # BASELINE config 5 at full size (FromAtf, 16 384 ATF directions x 8 microphones, 2048 taps): the oracle needs 30 s
+    if "config5_full/wL" not in out:
+        atf, aazi, azen = synth.glasses_atfs(natf=16384, nmics=8, taps=256)
+        wL, wR, _ = O.getEMagLsFiltersFromAtf(hL, hR, np.column_stack([azi, zen]), atf, np.column_stack([aazi, azen]), 48000.0, 2048, 2000.0)
+        out["config5_full/wL"], out["config5_full/wR"] = wL, wR
+    # the 64-capsule array at r = 8 cm (simulation order 35), 64-tap HRIRs, 128-tap filters: 35 s
+    if "wide64_r80mm_len128/wL" not in out:
+        h64L, h64R = synth.rigid_sphere_hrirs(azi, zen, taps=64)
+        m64a, m64z = synth.fibonacci_grid(64)
+        wL, wR = O.getEMagLs2Filters(h64L, h64R, azi, zen, 0.08, m64a, m64z, 4, 48000.0, 128, "real")
+        out["wide64_r80mm_len128/wL"], out["wide64_r80mm_len128/wR"] = wL, wR
     np.savez_compressed(path, **out)
     print({k: v.shape for k, v in out.items()})
 

@@ -773,6 +773,47 @@ def test_sixteen_design_lane_batch(grids, thin, monkeypatch):
         p.close()
 
 
+def test_register_resident_sweep_spread_over_all_xcds(grids, thin, monkeypatch):
+    """A launch of the register-resident sweep keeps every design inside one XCD (the granules of the per-bin exchange stay in its L2)
+    or deals a design's workgroups round over all eight (EMAGLS_REG_SPREAD; the default takes it when it needs fewer waves per
+    workgroup: 20 designs of config 3 run 220 workgroups of 8 waves instead of 27 per XCD of 10, 4.2 against 5.3 ms).  The partial
+    sums are added in workgroup order either way: bitwise the same filters, on a batch of 10 designs, both layouts forced."""
+    import ctypes
+    from emagls_amd import Batch, Plan, _lib as L, synth
+    lib = L.load()
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EMAGLS_REG_SPREAD", mode)
+        plans = []
+        for j in range(10):
+            azi = np.mod(thin["azi"] + 0.17 * j, 2 * np.pi)
+            hL, hR = synth.rigid_sphere_hrirs(azi, thin["zen"], seed=31 + j)
+            p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, hL.shape[0], hL.shape[1], 0.042, 32)
+            p.set_hrir_grid(azi, thin["zen"])
+            p.set_mic_grid(np.mod(grids["mic_azi"] + 0.1 * j, 2 * np.pi), grids["mic_zen"])
+            p.set_hrirs(hL, hR)
+            plans.append(p)
+        prev = ctypes.c_int(0)
+        L.check(lib.emagls_set_batch_max(16, ctypes.byref(prev)))
+        try:
+            b = Batch(plans)
+        finally:
+            L.check(lib.emagls_set_batch_max(prev.value, None))
+        b.execute()
+        res[mode] = b.get_filters()
+        assert plans[0].info().sweep_form == 3
+        if mode == "1":   # one design against the oracle
+            azi = np.mod(thin["azi"] + 0.17 * 9, 2 * np.pi)
+            hL, hR = synth.rigid_sphere_hrirs(azi, thin["zen"], seed=31 + 9)
+            oL, oR = O.getEMagLsFilters(hL, hR, azi, thin["zen"], 0.042, np.mod(grids["mic_azi"] + 0.9, 2 * np.pi), grids["mic_zen"], 4, 48000.0, 128, "complex")
+            assert rel(res[mode][9][0], oL) < TOL and rel(res[mode][9][1], oR) < TOL
+        b.close()
+        for p in plans:
+            p.close()
+    for (aL, aR), (cL, cR) in zip(res["0"], res["1"]):
+        assert np.array_equal(aL, cL) and np.array_equal(aR, cR)
+
+
 def test_gram_tile_on_the_four_block_mfma_shape(grids, thin, monkeypatch):
     """The Gram product of a lane batch on v_mfma_f64_4x4x4_4b (EMAGLS_GRAM_MFMA4=1; gram_chol.hip: measured slower than the
     16 x 16 x 4 kernel in this pipeline, so off by default) against the default kernel: the same filters to rounding."""
@@ -782,10 +823,10 @@ def test_gram_tile_on_the_four_block_mfma_shape(grids, thin, monkeypatch):
         monkeypatch.setenv("EMAGLS_GRAM_MFMA4", mode)
         plans = []
         for j in range(5):   # (28 tiles x 5 designs: the LDS-staged tile kernels take over from 128 workgroups on)
-            azi = np.mod(thin["azi"] + 0.21 * j, 2 * np.pi)
-            hL, hR = synth.rigid_sphere_hrirs(azi, thin["zen"], seed=11 + j)
+            azi = np.mod(grids["azi"] + 0.21 * j, 2 * np.pi)   # (the full 2702-point grid: the thin ones take the K-split kernel)
+            hL, hR = synth.rigid_sphere_hrirs(azi, grids["zen"], taps=64, seed=11 + j)
             p = Plan(L.KIND_EMAGLS, "real", 4, 48000.0, 128, hL.shape[0], hL.shape[1], 0.042, 32)
-            p.set_hrir_grid(azi, thin["zen"])
+            p.set_hrir_grid(azi, grids["zen"])
             p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
             p.set_hrirs(hL, hR)
             plans.append(p)
@@ -797,7 +838,9 @@ def test_gram_tile_on_the_four_block_mfma_shape(grids, thin, monkeypatch):
             p.close()
     worst = max(max(rel(a[0], c[0]), rel(a[1], c[1])) for a, c in zip(res["0"], res["1"]))
     print(f"Gram tile on the 4 x 4 x 4 shape vs the 16 x 16 x 4 kernel: worst rel = {worst:.3e}")
-    assert 0.0 < worst < 1e-9      # (not bit-identical: another summation order; if it were, the switch did nothing)
+    # (bit-identical, as it turns out: both shapes contract four rows per instruction in the same order; the kernels themselves against
+    # a host sum: tests/test_gpu_stages.py::test_gram_tile_kernels_against_a_host_sum)
+    assert worst < 1e-9
 
 
 def test_batch_of_ema_in_ch_designs(thin):
@@ -1098,7 +1141,9 @@ def test_from_atf_config5_shape(grids, hrirs):
     hg = np.column_stack([grids["azi"], grids["zen"]])
     ag = np.column_stack([aazi, azen])
     wL, wR = E.getEMagLsFiltersFromAtf(hrirs[0], hrirs[1], hg, atf, ag, 48000.0, 2048, 2000.0, verbose=False)
-    oL, oR, dev = O.getEMagLsFiltersFromAtf(hrirs[0], hrirs[1], hg, atf, ag, 48000.0, 2048, 2000.0)
+    # (the oracle needs 30 s for it: its output is a stored vector, tests/golden/make_oracle_vectors.py, same seeded inputs)
+    vec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
+    oL, oR = vec["config5_full/wL"], vec["config5_full/wR"]
     assert wL.shape == (2048, 8)
     assert report("FromAtf config5 L", wL, oL) < TOL and report("FromAtf config5 R", wR, oR) < TOL
 
@@ -1644,7 +1689,9 @@ def test_wide_array_at_8_cm(grids):
     maz, mzn = synth.fibonacci_grid(64)
     args = (hL, hR, grids["azi"], grids["zen"], 0.08, maz, mzn, 4, 48000.0, 128, "real")
     wL, wR = E.getEMagLs2Filters(*args)
-    oL, oR = O.getEMagLs2Filters(*args)
+    # (the oracle needs 35 s for it: its output is a stored vector, tests/golden/make_oracle_vectors.py, same seeded inputs)
+    vec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
+    oL, oR = vec["wide64_r80mm_len128/wL"], vec["wide64_r80mm_len128/wR"]
     assert report("getEMagLs2Filters 64 mics r = 8 cm L", wL, oL) < TOL and report("R", wR, oR) < TOL
 
 

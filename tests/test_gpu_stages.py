@@ -270,3 +270,16 @@ def test_wave_reduction_of_the_register_resident_sweep():
     L.check(L.load().emagls_self_test(0, ctypes.byref(err)))
     print(f"wave reduction self test: max abs error = {err.value:.3e}")
     assert 0.0 <= err.value < 1e-13
+
+
+def test_gram_tile_kernels_against_a_host_sum():
+    """gram_chol.hip's LDS-staged Gram tiles -- on v_mfma_f64_16x16x4 (what lane batches run) and on the four-block
+    v_mfma_f64_4x4x4_4b shape (EMAGLS_GRAM_MFMA4=1; operand layout found by experiment) -- on a 333 x 100 pseudo-random matrix
+    (ragged: partial tiles, rows that are not a multiple of the stage) against a plain host sum."""
+    import ctypes
+    from emagls_amd import _lib as L
+    for which, name in ((1, "16 x 16 x 4"), (2, "4 x 4 x 4, four blocks")):
+        err = ctypes.c_double(-1.0)
+        L.check(L.load().emagls_self_test(which, ctypes.byref(err)))
+        print(f"Gram tile on the {name} shape: max error relative to the largest element = {err.value:.3e}")
+        assert 0.0 <= err.value < 1e-13

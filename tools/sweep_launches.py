@@ -24,16 +24,32 @@ def main():
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-    rows = [(s, e, gx) for n, s, e, gx in cur.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x / d.workgroup_size_x from {kd} d "
-                                                        f"join {ks} s on d.kernel_id=s.id order by d.start") if ("sweep_persist" in n or "sweep_synth" in n or "sweep_reg" in n)]
-    dur = [(e - s) / 1e3 for s, e, _ in rows]
-    gmax = max(g for _, _, g in rows)
-    full = [(e - s) / 1e3 for s, e, g in rows if g == gmax]
+    kname = js.get("roofline", {}).get("kernel", "sweep_persist_kernel")
+    allrows = [(n, s, e, gx) for n, s, e, gx in cur.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x / d.workgroup_size_x from {kd} d "
+                                                            f"join {ks} s on d.kernel_id=s.id order by d.start") if ("sweep_persist" in n or "sweep_synth" in n or "sweep_reg" in n)]
     print(f"command: python3 bench.py --steps {js['steps']} --warmup {js['warmup']} --no-secondary   ->  {js['value']:.1f} {js['unit']}")
-    print(f"sweep_persist_kernel launches in the trace: {len(dur)}; all: avg {sum(dur) / len(dur):.1f} us, min {min(dur):.1f}, max {max(dur):.1f}")
-    print(f"launches with the full grid of {gmax} workgroups ({bsz} designs): {len(full)}; avg {sum(full) / len(full):.1f} us")
-    last = full[-n_timed:]
-    print(f"the {n_timed} full-batch launches of the timed region (the last ones): " + ", ".join(f"{x:.1f}" for x in last) + f" us; avg {sum(last) / len(last):.1f} us")
+    if "sweep_reg" in kname:
+        # round 5: the timed region is ONE job list (chunks of `bsz` designs, the partial chunk last); its chunks' sweeps are the last
+        # launches of the register-resident kernel in the trace (set-up runs and warm-up come before; launches of up to 8 designs take
+        # the slab kernel)
+        rows = [(s, e, g) for n, s, e, g in allrows if "sweep_reg" in n]
+        n_chunks = -(-js["steps"] // bsz)
+        last_rows = rows[-n_chunks:]
+        big = max(g for _, _, g in last_rows)
+        last = [(e - s) / 1e3 for s, e, g in last_rows if g == big]
+        dur = [(e - s) / 1e3 for s, e, _ in rows]
+        print(f"{kname} launches in the trace: {len(dur)}; all: avg {sum(dur) / len(dur):.1f} us, min {min(dur):.1f}, max {max(dur):.1f}")
+        print(f"the {len(last)} launches of the timed region's largest chunks ({big} workgroups each; the last launches of the trace): "
+              + ", ".join(f"{x:.1f}" for x in last) + f" us; avg {sum(last) / len(last):.1f} us")
+    else:
+        rows = [(s, e, gx) for n, s, e, gx in allrows]
+        dur = [(e - s) / 1e3 for s, e, _ in rows]
+        gmax = max(g for _, _, g in rows)
+        full = [(e - s) / 1e3 for s, e, g in rows if g == gmax]
+        print(f"sweep launches in the trace: {len(dur)}; all: avg {sum(dur) / len(dur):.1f} us, min {min(dur):.1f}, max {max(dur):.1f}")
+        print(f"launches with the full grid of {gmax} workgroups ({bsz} designs): {len(full)}; avg {sum(full) / len(full):.1f} us")
+        last = full[-n_timed:]
+        print(f"the {n_timed} full-batch launches of the timed region (the last ones): " + ", ".join(f"{x:.1f}" for x in last) + f" us; avg {sum(last) / len(last):.1f} us")
     r = js["roofline"]
     print(f"bench.py, HIP events on the batch streams, same run: roofline.avg_launch_us = {r['avg_launch_us']:.1f} us "
           f"(achieved {r['achieved']:.0f} {r['unit']}, frac {r['frac']:.3f})")
