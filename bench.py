@@ -492,8 +492,8 @@ def main():
                     "avg_launch_us_single_design": single_s * 1e6,
                     "algorithmic_bytes_per_launch": bytes_launch, "bins_per_launch": nbins_swept / sweep_n,
                     "us_per_bin": avg_s * 1e6 * sweep_n / nbins_swept,
-                    "note": ("sequential recurrence over the frequency bins (W(k) needs W(k-1)): one launch sweeps the designs of a batch, up to four per "
-                             "XCD; " + (("the operand of every bin is evaluated inside the launch from the angles between HRIR directions and microphones by the "
+                    "note": ("sequential recurrence over the frequency bins (W(k) needs W(k-1)): one launch sweeps the designs of a chunk, up to four per "
+                             "XCD (a chunk that would leave CUs idle that way -- the 20 designs of the driver's run -- has its designs spread over all XCDs); " + (("the operand of every bin is evaluated inside the launch from the angles between HRIR directions and microphones by the "
                                          "waves that run the recurrence and stays in their registers (sweep_reg.hip: no operand in HBM or LDS); with twelve waves per "
                                          "CU the launch is limited by the issue rate of FP64 vector operations (2.2 instructions per useful fused operation: "
                                          "cross-lane reduction, exchange, barriers) and by the per-bin exchange of partial sums (DESIGN.md section 5)" if reg else
