@@ -483,8 +483,8 @@ def main():
                     "frac": tflops / 78.6 if synth else hbm_gbs / HBM_PEAK_GBS,
                     "busiest_resource": "FP64 vector pipe (peak: AMD's 78.6 TFLOP/s)" if synth else "HBM (8 TB/s)",
                     "traffic": traffic,
-                    "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of build %s with %d designs per sweep launch; not measured "
-                                       "in this run)" % (pmc.get("build", "?"), int(pmc_designs))) if traffic is not None else None,
+                    "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of build %s, commit %s, with %d designs per sweep launch; not "
+                                       "measured in this run)" % (pmc.get("build", "?"), pmc.get("commit", "?"), int(pmc_designs))) if traffic is not None else None,
                     "hbm": {"algorithmic_bytes_per_launch": bytes_launch, "achieved_GBs": hbm_gbs, "frac_of_8TBs": hbm_gbs / HBM_PEAK_GBS},
                     "fp64": {"flop_per_launch": flop_launch, "achieved_TFLOPs": tflops, "frac_of_78.6": tflops / 78.6},
                     "launches_per_step": sweep_n / designs_per_launch,
