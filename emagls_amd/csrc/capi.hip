@@ -4066,11 +4066,18 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
         lap("batch created");
     } else if (slot->batch) {
         // the HRIRs of every design on the batch's stream, ordered before its execute: no host synchronisation per plan
+        // (jobs that name the SAME HRIR arrays -- one HRIR set for every radius of an array sweep -- are served device to device from
+        // the first plan that received them: 5.5 MB over PCIe instead of 5.5 MB per design from pageable memory)
         for (int j = 0; j < n; ++j) {
             emagls_plan& q = *slot->plans[(size_t)j];
             const size_t bytes = sizeof(double) * (size_t)q.d.nsamp * (size_t)q.d.ndirs;
-            HIP_CHECK(hipMemcpyAsync(q.get("hL"), jobs[j].hL, bytes, hipMemcpyDefault, slot->batch->stream));
-            HIP_CHECK(hipMemcpyAsync(q.get("hR"), jobs[j].hR, bytes, hipMemcpyDefault, slot->batch->stream));
+            int src = -1;
+            for (int i = 0; i < j && src < 0; ++i)
+                if (jobs[i].hL == jobs[j].hL && jobs[i].hR == jobs[j].hR && slot->plans[(size_t)i]->d.nsamp == q.d.nsamp && slot->plans[(size_t)i]->d.ndirs == q.d.ndirs) src = i;
+            const void* sl = src >= 0 ? slot->plans[(size_t)src]->get("hL") : jobs[j].hL;
+            const void* sr = src >= 0 ? slot->plans[(size_t)src]->get("hR") : jobs[j].hR;
+            HIP_CHECK(hipMemcpyAsync(q.get("hL"), sl, bytes, hipMemcpyDefault, slot->batch->stream));
+            HIP_CHECK(hipMemcpyAsync(q.get("hR"), sr, bytes, hipMemcpyDefault, slot->batch->stream));
             q.have_hrirs = true;
         }
     } else {

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) gram_lds_kernel(const double* __restrict_
 // (four + one ds_read_b128 per sixteen instructions; lanes that differ in b only read the same A address: a broadcast).
 //   A stage  [k][half][i][ra]      column 32 half + 4 ra + i of the row panel
 //   B stage  [k][half][4 b + j][rb]  column 32 half + 16 rb + 4 b + j of the column panel
-constexpr int G4_LD = 64 + 8;
+constexpr int G4_LD = 64 + 2;   // (row stride 132 banks = 4 mod 64: the four k rows x four 64-byte A segments of a read tile the banks)
 __global__ void __launch_bounds__(256) gram_lds4_kernel(const double* __restrict__ Yc, int64_t ld, int S, int64_t rows, int nbt,
                                                         double* __restrict__ G, double* __restrict__ R, int Sh, size_t bstride) {
     Yc = boff(Yc, bstride); G = boff(G, bstride); R = boff(R, bstride);
