@@ -7,7 +7,9 @@ result against the oracle (dev tooling; the fixed cases of tests/shape_cases.py 
 A case the library refuses with EMAGLS_ERR_UNSUPPORTED / _ARG counts as 'refused' (its message is printed), not as a failure.
 A case above 1e-6 is re-examined: the oracle is run twice more with the two LAPACK SVD drivers (gesdd / gesvd); where those two
 disagree at the same level (a bin's smallest singular values at eps * s_max: the clipped subspace's singular vectors are
-rounding noise, so is the reference's own result) the case counts as 'ill_posed', otherwise as a MISMATCH."""
+rounding noise, so is the reference's own result) the case counts as 'ill_posed'; so does an array design whose oracle result moves
+by more than 1e-7 when the array model is perturbed by half an ulp (round 5: the drivers decompose the same rounded matrix and
+cannot see what the result owes to that rounding); otherwise it is a MISMATCH."""
 import os
 import sys
 import time
@@ -183,9 +185,28 @@ def main():
                 a, b = oracle_filters(c, "gesdd"), oracle_filters(c, "gesvd")
                 self_dev = max(SC.rel(a[0], b[0]), SC.rel(a[1], b[1]))
                 ill = self_dev > 1e-7 and e < 100.0 * self_dev
+                form_dev = None
+                if not ill and c[0] in ("emagls", "emagls2", "emainch", "emainsh"):
+                    # (round 5) the two drivers decompose the SAME rounded matrix; what the reference's result owes to the rounding of
+                    # the matrix itself shows when the array model is moved by half an ulp: the oracle against itself on that
+                    from oracle import emagls_oracle as O
+                    orig = O.getSMAIRMatrix
+                    prng = np.random.default_rng(12345)
+
+                    def perturbed(*args, **kw):
+                        out = orig(*args, **kw)
+                        return (out[0] * (1.0 + 1.1e-16 * prng.uniform(-1.0, 1.0, out[0].shape)),) + tuple(out[1:])
+                    O.getSMAIRMatrix = perturbed
+                    try:
+                        p2 = oracle_filters(c, "gesdd")
+                    finally:
+                        O.getSMAIRMatrix = orig
+                    form_dev = max(SC.rel(a[0], p2[0]), SC.rel(a[1], p2[1]))
+                    ill = form_dev > 1e-7 and e < 100.0 * form_dev
                 tally["ill_posed" if ill else "mismatch"] += 1
-                print(f"case {i} {c} -> {'ill-posed' if ill else 'MISMATCH'} rel={e:.2e}, oracle gesdd vs gesvd {self_dev:.2e} "
-                      f"({time.time() - t:.1f} s)", flush=True)
+                print(f"case {i} {c} -> {'ill-posed' if ill else 'MISMATCH'} rel={e:.2e}, oracle gesdd vs gesvd {self_dev:.2e}"
+                      + (f", oracle vs oracle with the array model moved by half an ulp {form_dev:.2e}" if form_dev is not None else "")
+                      + f" ({time.time() - t:.1f} s)", flush=True)
         except EmaglsError as ex:
             tally["refused"] += 1
             print(f"case {i} {c} -> refused: {str(ex)[:140]}", flush=True)
