@@ -1711,6 +1711,21 @@ def test_wide_array_kernel_forms_agree(thin, monkeypatch):
     assert rel(wL, vL) < 1e-8 and rel(wR, vR) < 1e-8
 
 
+@pytest.mark.parametrize("fn,radius", [("getEMagLsFilters", 0.12), ("getEMagLs2Filters", 0.142)])
+def test_simulation_orders_above_47(grids, fn, radius):
+    """dependencies/getSMAIRMatrix.m:95 takes any array radius; until round 5 the build stopped at simulation order 47 (10.9 cm at
+    48 kHz).  Orders 53 and 63 (12 cm, 14.2 cm: the em32's layout on a larger sphere) on a 1500-point grid against the oracle;
+    above 63 the call is refused (order 71 was measured wrong: tools/experiments/order_cap.py)."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    azi, zen = synth.fibonacci_grid(1500)
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen, taps=64)
+    args = (hL, hR, azi, zen, radius, grids["mic_azi"], grids["mic_zen"], 4, 48000.0, 96, "real")
+    wL, wR = getattr(E, fn)(*args)
+    oL, oR = getattr(O, fn)(*args)
+    assert report(f"{fn} r = {100 * radius:.1f} cm L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
 def test_wide_arrays_refuse_what_they_cannot_do(thin):
     import emagls_amd as E
     from emagls_amd import synth
@@ -1719,8 +1734,8 @@ def test_wide_arrays_refuse_what_they_cannot_do(thin):
     with pytest.raises(EmaglsError, match="more than 64"):
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128)
     maz, mzn = synth.fibonacci_grid(64)
-    with pytest.raises(EmaglsError, match="simulation order above 47"):
-        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.12, maz, mzn, 4, 48000.0, 128)
+    with pytest.raises(EmaglsError, match="simulation order above 63"):
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.15, maz, mzn, 4, 48000.0, 128)
     with pytest.raises(EmaglsError, match="fewer HRIR directions than simulated SH channels"):   # (8 cm: 36^2 = 1296 channels, 901 directions)
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.08, maz, mzn, 4, 48000.0, 128)
 
