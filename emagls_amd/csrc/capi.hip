@@ -658,7 +658,7 @@ void plan_setup(emagls_plan& p) {
             if (p.req_cplx && !p.real_internal) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: the real-arithmetic pipeline only");
             p.wide = true;
         }
-        if (p.simOrder > 63) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 63 (array radius > ~14.3 cm at 48 kHz) is not supported in this build: validated against the oracle up to 63, wrong at 71");
+        if (p.simOrder > 85) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 85 (array radius > ~19.3 cm at 48 kHz) is not supported: the reference's own getSH overflows there (factorials beyond 170!)");
         // (fewer directions than simulated SH channels are fine as long as the orders of the orthonormal route are covered:
         // plan_routes checks D >= S_h.  The wide path orthogonalises all S columns.)
         if (p.D < p.S && (p.wide || d.kind == EMAGLS_KIND_EMA_SH)) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than simulated SH channels");

@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(SY_NT) sweep_synth_kernel(HalfSweepMulti m, in
 //   bsc[m] = sum_{n >= m, n - m even} c_mn beta_n,   c_mn = (2 - delta_m0) lambda((n - m) / 2) lambda((n + m) / 2),
 //   lambda(j) = prod_{i < j} (i + 1/2) / (i + 1)     (all c_mn in (0, 1]: the conversion amplifies nothing).
 // Nyquist row real (getSMAIRMatrix.m:116); zero beyond the design's orders up to the even row length.
-__global__ void __launch_bounds__(64) synth_coeff_kernel(const cplx* __restrict__ bn, int nOrd, int nord_pad, int P, cplx* __restrict__ bsc, size_t bstride) {
+__global__ void __launch_bounds__(128) synth_coeff_kernel(const cplx* __restrict__ bn, int nOrd, int nord_pad, int P, cplx* __restrict__ bsc, size_t bstride) {
     bn = boff(bn, bstride); bsc = boff(bsc, bstride);
     __shared__ double lam[2 * SY_NORD];
     __shared__ cplx beta[SY_NORD];
@@ -574,7 +574,7 @@ int synth_nord_pad(int nOrd) { return (nOrd + 1) & ~1; }
 
 void launch_synth_prepare(const void* bn, int nOrd, int P, void* bsc, const void* Zlo, int ldZ, int nOut, int M, const int* smap, double* Pm, hipStream_t st) {
     const int np = synth_nord_pad(nOrd);
-    synth_coeff_kernel<<<bgrid((unsigned)P), 64, 0, st>>>((const cplx*)bn, nOrd, np, P, (cplx*)bsc, batch_ctx().stride);
+    synth_coeff_kernel<<<bgrid((unsigned)P), np <= 64 ? 64 : 128, 0, st>>>((const cplx*)bn, nOrd, np, P, (cplx*)bsc, batch_ctx().stride);   // (thread = order)
     KERNEL_CHECK();
     synth_pm_kernel<<<bgrid(1), 256, 0, st>>>((const cplx*)Zlo, ldZ, nOut, M, smap, Pm, batch_ctx().stride);
     KERNEL_CHECK();

@@ -6,7 +6,7 @@
 namespace emagls {
 namespace {
 
-constexpr int SY_NORD = 64;     // orders a ring slot holds (simulation order <= 63)
+constexpr int SY_NORD = 96;     // orders a ring slot holds (simulation order <= 95)
 
 // LDS reads whose latency the compiler must not "optimise": it sinks an ordinary read of the NEXT pass's coefficients to the top of
 // that pass (no side effects, used only there), where every pass then waits an LDS round trip.  Issued through inline assembly

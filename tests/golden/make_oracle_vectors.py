@@ -44,10 +44,11 @@ def main():
         m64a, m64z = synth.fibonacci_grid(64)
         wL, wR = O.getEMagLs2Filters(h64L, h64R, azi, zen, 0.08, m64a, m64z, 4, 48000.0, 128, "real")
         out["wide64_r80mm_len128/wL"], out["wide64_r80mm_len128/wR"] = wL, wR
-    # simulation orders above 47 (round 5): the em32's layout at r = 12 cm (order 53) and 14.2 cm (order 63) on a 1500-point grid, 20-30 s each
+    # simulation orders above 47 (round 5): the em32's layout at r = 12 cm (order 53), 14.2 cm (order 63) and 19.3 cm (order 85, the last one the
+    # reference's factorial-based getSH can form) on a 1500-point grid, 20-40 s each
     fa, fz = synth.fibonacci_grid(1500)
     fL, fR = synth.rigid_sphere_hrirs(fa, fz, taps=64)
-    for name, fn, radius in (("order53_emagls", O.getEMagLsFilters, 0.12), ("order63_emagls2", O.getEMagLs2Filters, 0.142)):
+    for name, fn, radius in (("order53_emagls", O.getEMagLsFilters, 0.12), ("order63_emagls2", O.getEMagLs2Filters, 0.142), ("order85_emagls2", O.getEMagLs2Filters, 0.193)):
         if name + "/wL" in out:
             continue
         wL, wR = fn(fL, fR, fa, fz, radius, maz, mzn, 4, 48000.0, 96, "real")

@@ -1711,11 +1711,12 @@ def test_wide_array_kernel_forms_agree(thin, monkeypatch):
     assert rel(wL, vL) < 1e-8 and rel(wR, vR) < 1e-8
 
 
-@pytest.mark.parametrize("fn,radius", [("getEMagLsFilters", 0.12), ("getEMagLs2Filters", 0.142)])
+@pytest.mark.parametrize("fn,radius", [("getEMagLsFilters", 0.12), ("getEMagLs2Filters", 0.142), ("getEMagLs2Filters", 0.193)])
 def test_simulation_orders_above_47(grids, fn, radius):
     """dependencies/getSMAIRMatrix.m:95 takes any array radius; until round 5 the build stopped at simulation order 47 (10.9 cm at
-    48 kHz).  Orders 53 and 63 (12 cm, 14.2 cm: the em32's layout on a larger sphere) on a 1500-point grid against the oracle;
-    above 63 the call is refused (order 71 was measured wrong: tools/experiments/order_cap.py)."""
+    48 kHz) -- a table size, and one kernel (the Chebyshev conversion of the series, one thread per order in a single wave) that
+    was silently wrong from 65 orders on.  Orders 53, 63 and 85 (12 cm, 14.2 cm, 19.3 cm: the em32's layout on a larger sphere) on a
+    1500-point grid against the oracle; above 85 the call is refused: the reference's own getSH overflows there (170!)."""
     import emagls_amd as E
     from emagls_amd import synth
     azi, zen = synth.fibonacci_grid(1500)
@@ -1724,7 +1725,7 @@ def test_simulation_orders_above_47(grids, fn, radius):
     wL, wR = getattr(E, fn)(*args)
     # (the oracle needs 20-30 s for each: stored vectors, tests/golden/make_oracle_vectors.py, same seeded inputs)
     vec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
-    key = "order53_emagls" if fn == "getEMagLsFilters" else "order63_emagls2"
+    key = "order53_emagls" if fn == "getEMagLsFilters" else ("order63_emagls2" if radius < 0.15 else "order85_emagls2")
     oL, oR = vec[key + "/wL"], vec[key + "/wR"]
     assert report(f"{fn} r = {100 * radius:.1f} cm L", wL, oL) < TOL and report("R", wR, oR) < TOL
 
@@ -1737,8 +1738,8 @@ def test_wide_arrays_refuse_what_they_cannot_do(thin):
     with pytest.raises(EmaglsError, match="more than 64"):
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128)
     maz, mzn = synth.fibonacci_grid(64)
-    with pytest.raises(EmaglsError, match="simulation order above 63"):
-        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.15, maz, mzn, 4, 48000.0, 128)
+    with pytest.raises(EmaglsError, match="simulation order above 85"):
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.20, maz, mzn, 4, 48000.0, 128)
     with pytest.raises(EmaglsError, match="fewer HRIR directions than simulated SH channels"):   # (8 cm: 36^2 = 1296 channels, 901 directions)
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.08, maz, mzn, 4, 48000.0, 128)
 

@@ -13,7 +13,7 @@ maz, mzn = g["grid/micGridAziRad"].ravel(), g["grid/micGridZenRad"].ravel()
 azi, zen = synth.fibonacci_grid(1500)
 hL, hR = synth.rigid_sphere_hrirs(azi, zen, taps=64)
 for fn, oracle, name in ((E.getEMagLsFilters, O.getEMagLsFilters, "eMagLS"), (E.getEMagLs2Filters, O.getEMagLs2Filters, "eMagLS2")):
-    for r in (0.135, 0.16, 0.20, 0.216, 0.22):
+    for r in (0.146, 0.16, 0.18, 0.193):
         t = time.time()
         try:
             w = fn(hL, hR, azi, zen, r, maz, mzn, 4, 48000.0, 96, "real")
