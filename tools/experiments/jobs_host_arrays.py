@@ -1,0 +1,44 @@
+"""One job list of config-3 designs with HOST arrays in and out (the PCIe-inclusive figure of the scheduler):
+pageable NumPy arrays against page-locked ones (torch pin_memory), 256 designs per call, chunks of 32, four in flight.
+    python tools/experiments/jobs_host_arrays.py"""
+import os, sys, time, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+from emagls_amd import _lib as L
+
+lib = L.load()
+NJ, NIN = 256, 32
+azi, zen, maz, mzn, hL0, hR0 = bench.load_inputs(seed_offset=0)
+nsamp, D = hL0.shape
+sets = [bench.load_inputs(seed_offset=j)[4:6] for j in range(NIN)]
+for pinned in (False, True):
+    def host(shape):
+        t = torch.empty(shape, dtype=torch.float64, pin_memory=pinned)
+        return t
+    ins = []
+    for hL, hR in sets:
+        a, b = host((D, nsamp)), host((D, nsamp))          # column-major [nsamp x D] = row-major [D x nsamp]
+        a.copy_(torch.from_numpy(np.ascontiguousarray(hL.T))); b.copy_(torch.from_numpy(np.ascontiguousarray(hR.T)))
+        ins.append((a, b))
+    outs = [(host((25, 512, 2)), host((25, 512, 2))) for _ in range(NJ)]   # complex [512 x 25] column-major
+    desc = L.DesignDesc(L.KIND_EMAGLS, L.BASIS["complex"], 4, 48000.0, 512, nsamp, D, 0.042, 32, 0.0, 0, 0, 0, 0, 0)
+    jobs = (L.Job * NJ)()
+    keep = [np.ascontiguousarray(x, dtype=np.float64) for x in (azi, zen, maz, mzn)]
+    for j in range(NJ):
+        jb = jobs[j]
+        jb.desc = desc
+        a, b = ins[j % NIN]
+        jb.hL, jb.hR = C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr())
+        jb.hrir_azi, jb.hrir_zen = C.c_void_p(keep[0].ctypes.data), C.c_void_p(keep[1].ctypes.data)
+        jb.mic_azi, jb.mic_zen = C.c_void_p(keep[2].ctypes.data), C.c_void_p(keep[3].ctypes.data)
+        jb.wL, jb.wR = C.c_void_p(outs[j][0].data_ptr()), C.c_void_p(outs[j][1].data_ptr())
+    for rep in range(4):
+        t0 = time.perf_counter()
+        L.check(lib.emagls_jobs_run(jobs, NJ, 32, 4, 0))
+        dt = time.perf_counter() - t0
+        print(f"host arrays {'page-locked' if pinned else 'pageable   '}, call {rep}: {NJ / dt:7.1f} filter sets/s ({dt * 1e3:.1f} ms for {NJ} designs; 5.5 MB in, 0.4 MB out per design)", flush=True)
+    w = np.frombuffer(outs[3][0].numpy().tobytes(), dtype=np.complex128).reshape(25, 512).T
+    print("  checksum of design 3:", float(np.abs(w).sum()))

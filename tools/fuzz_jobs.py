@@ -24,8 +24,12 @@ def mic_grid(rng, M, paired):
         azi, zen = synth.fibonacci_grid(M)
         return np.mod(azi + 0.05 * rng.standard_normal(M), 2 * np.pi), np.clip(zen + 0.03 * rng.standard_normal(M), 0.05, np.pi - 0.05)
     npair = M // 2
-    azi, zen = synth.fibonacci_grid(2 * npair + 2)
-    azi, zen = azi[:npair] + 0.1 * rng.standard_normal(npair), np.clip(zen[:npair] * 0.5 + 0.03 * rng.standard_normal(npair), 0.05, np.pi / 2 - 0.02)
+    # (the upper half of a Fibonacci grid of 2 npair points and its mirror image: spread over the sphere like the em32's pairs; a first
+    # version squeezed the capsules towards the poles and drew designs whose pinv(Y_lo) is ill-conditioned -- two lists of seed 11
+    # came out above the tolerance against the oracle AND against the single calls, profiles/r05_fuzz_jobs.md)
+    fa, fz = synth.fibonacci_grid(2 * npair)
+    up = np.argsort(fz)[:npair]
+    azi, zen = fa[up] + 0.05 * rng.standard_normal(npair), np.clip(fz[up] + 0.02 * rng.standard_normal(npair), 0.05, np.pi / 2 - 0.02)
     a = np.concatenate([azi, azi + np.pi]); z = np.concatenate([zen, np.pi - zen])
     if M % 2:
         a = np.append(a, 0.3); z = np.append(z, np.pi / 2)
@@ -43,9 +47,16 @@ def draw(rng):
         M = int(rng.integers(4, 33))
     taps = int(rng.choice([16, 33, 64, 100, 128]))
     ln = int(2 * rng.integers(max(16, taps // 2), 257))
+    paired = bool(rng.random() < 0.6)
+    if kind == "emagls" and paired:
+        # an array of antipodal pairs sees the even orders through the pairs' sums and the odd ones through their differences: pinv(Y_lo)
+        # exists only with at least as many pairs as the larger of the two families has functions (order 4: 15 -- the em32 has exactly that)
+        even, odd = sum(2 * n + 1 for n in range(0, N + 1, 2)), sum(2 * n + 1 for n in range(1, N + 1, 2))
+        if M // 2 < max(even, odd):
+            paired = False
     return dict(kind=kind, n=int(rng.integers(9, 29)), D=int(rng.integers(100, 3000)), taps=taps, ln=ln,
                 fs=float(rng.choice([16000.0, 32000.0, 44100.0, 48000.0, 96000.0])), r=float(rng.uniform(0.01, 0.08)), M=M, N=N,
-                basis=str(rng.choice(["real", "complex"])), paired=bool(rng.random() < 0.6), spread=str(rng.choice(["0", "1", "2"])), seed=int(rng.integers(1 << 30)))
+                basis=str(rng.choice(["real", "complex"])), paired=paired, spread=str(rng.choice(["0", "1", "2"])), seed=int(rng.integers(1 << 30)))
 
 
 def run(c):
