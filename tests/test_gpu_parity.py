@@ -395,6 +395,48 @@ def test_gram_matrix_of_a_lane_batch(grids, thin):
         p.close()
 
 
+def test_twenty_hrir_sets_on_one_geometry_take_the_register_resident_sweep(grids, thin):
+    """Geometry sharing in batches of more than 16 sets (round 5: bench.py's secondary figure runs batches of 32, 4.5 k sets/s against
+    3.1 k with 16): the geometry stages once, ONE register-resident sweep launch for all sets -- the same filters as the single designs
+    (which take the slab form of the sweep: to rounding) and as the same batch without sharing."""
+    import ctypes
+    from emagls_amd import Batch, Plan, _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(77)
+    plans, singles = [], []
+    for j in range(20):
+        hL = thin["hL"] * (1.0 + 0.03 * j) + 1e-3 * rng.standard_normal(thin["hL"].shape)
+        hR = thin["hR"] * (1.0 - 0.02 * j) + 1e-3 * rng.standard_normal(thin["hR"].shape)
+        p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, hL.shape[0], hL.shape[1], grids["mic_radius"], 32)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])
+        p.set_hrirs(hL, hR)
+        if j in (0, 7, 19):
+            p.execute()
+            singles.append((j, p.get_filters()))
+        plans.append(p)
+    prev = ctypes.c_int(0)
+    L.check(lib.emagls_set_batch_max(32, ctypes.byref(prev)))
+    try:
+        b = Batch(plans)
+    finally:
+        L.check(lib.emagls_set_batch_max(prev.value, None))
+    b.execute()
+    indep = b.get_filters()
+    assert plans[0].info().sweep_form == 3
+    b.share_geometry(True)
+    b.execute()
+    assert b.shares_geometry() and plans[1].info().num_sweep_launches == 1
+    shared = b.get_filters()
+    worst_s = max(max(rel(shared[j][0], w[0]), rel(shared[j][1], w[1])) for j, w in singles)
+    worst_i = max(max(rel(a[0], c[0]), rel(a[1], c[1])) for a, c in zip(shared, indep))
+    print(f"20 HRIR sets on one geometry, register-resident sweep: vs single plans {worst_s:.3e}, vs the same batch unshared {worst_i:.3e}")
+    assert worst_s < 2e-7 and worst_i < 1e-9
+    b.close()
+    for p in plans:
+        p.close()
+
+
 @pytest.mark.parametrize("kind", ["emagls", "emagls2", "emainch"])
 def test_hrir_sets_on_one_geometry_share_it(grids, thin, kind):
     """Batches of HRIR sets on one geometry (the loop over subjects around getEMagLsFilters with the same grids and array):
