@@ -571,6 +571,26 @@ def main():
         if shared_gpu and world > ndev:
             res["INVALID_as_a_measurement"] = ("EMAGLS_BENCH_SHARED_GPU=1: %d ranks shared %d GPU(s) and the collectives ran on gloo -- a test of "
                                                "the N > 1 control flow, not an N-GPU figure" % (world, ndev))
+        parity_failed = None
+        if not args.no_cpu_baseline and world == 1:
+            # the CPU baseline runs on the inputs of design 0 of the timed region, and its filters are the checker of that design's GPU
+            # filters: the accuracy half of the metric on the metric's own configuration.  (Before the secondary figures in the line;
+            # a run whose filters are off by 1e-6 or more fails: exit code 3 after the line is printed.)
+            cb = cpu_baseline(*load_inputs(seed_offset=seed_of[0]))
+            oracle_lr = cb.pop("oracle_filters")
+            g = out[0].cpu().numpy()   # [ear][channel][tap][re, im]
+            gl, gr = (np.ascontiguousarray((g[e, ..., 0] + 1j * g[e, ..., 1]).T) for e in range(2))
+            res["parity"] = parity_on_metric_config(gl, gr, oracle_lr, seed_of[0])
+            # (also inside cpu_baseline -- the oracle run IS the checker -- so that a record which keeps only the contract's keys shows it)
+            cb["gpu_vs_this_oracle_run_rel_complex_error"] = res["parity"]["rel_complex_error"]
+            cb["gpu_vs_this_oracle_run_max_abs_db"] = res["parity"]["max_abs_db_diff"]
+            res["cpu_baseline"] = cb
+            res["speedup_vs_cpu_baseline"] = res["value"] / cb["value"]
+            L.check(lib.emagls_cache_clear())
+            res["parity_small_case"] = parity_check()
+            for key in ("parity", "parity_small_case"):
+                if not res[key]["rel_complex_error"] < res[key]["tolerance"]:
+                    parity_failed = "%s: rel_complex_error %.3e >= %.0e" % (key, res[key]["rel_complex_error"], res[key]["tolerance"])
         if not args.no_sh_roofline and world == 1:
             try:
                 res["sh_basis_roofline"] = sh_basis_roofline(lib)
@@ -587,19 +607,15 @@ def main():
                 res["secondary"] = bench_secondary.run()
             except Exception as e:
                 res["secondary"] = {"error": repr(e)}
-        if not args.no_cpu_baseline and world == 1:
-            # the CPU baseline runs on the inputs of design 0 of the timed region, and its filters are the checker of that design's GPU
-            # filters: the accuracy half of the metric on the metric's own configuration
-            cb = cpu_baseline(*load_inputs(seed_offset=seed_of[0]))
-            oracle_lr = cb.pop("oracle_filters")
-            res["cpu_baseline"] = cb
-            res["speedup_vs_cpu_baseline"] = res["value"] / cb["value"]
-            g = out[0].cpu().numpy()   # [ear][channel][tap][re, im]
-            gl, gr = (np.ascontiguousarray((g[e, ..., 0] + 1j * g[e, ..., 1]).T) for e in range(2))
-            res["parity"] = parity_on_metric_config(gl, gr, oracle_lr, seed_of[0])
-            res["parity_small_case"] = parity_check()
         print(json.dumps(res))
         sys.stdout.flush()
+        if "parity" in res:
+            sys.stderr.write("bench.py parity (design 0 of the timed region vs the oracle): rel_complex_error %.3e, max |dB| %.2e, tolerance %.0e\n"
+                             % (res["parity"]["rel_complex_error"], res["parity"]["max_abs_db_diff"], res["parity"]["tolerance"]))
+        if parity_failed:
+            sys.stderr.write("bench.py: PARITY FAILED -- %s; the throughput figure above is not a valid result\n" % parity_failed)
+            L.check(lib.emagls_cache_clear())
+            sys.exit(3)
     L.check(lib.emagls_cache_clear())
     if use_pg:
         dist.destroy_process_group()

@@ -297,20 +297,24 @@ class _Results:
 
 
 def _out_shape(job):
-    """(rows, columns, complex?) of a job's filters: read off a plan of its descriptor."""
-    from . import Plan
+    """(rows, columns, complex?) of a job's filters, from its descriptor alone (no plan, no device memory): what
+    emagls_plan_info reports -- len x channels; LS keeps the HRIR length (lib/getLsFilters.m:33); channels = (N+1)^2 in the SH
+    domain, 2N+1 circular harmonics (getMagLsFilters2D, EMAinCH), the microphones for eMagLS2 / FromAtf; complex for a complex
+    basis except FromAtf (tests/test_gpu_jobs.py checks it against the plans of every kind)."""
+    from . import _lib as L
     kw = dict(job)
-    nsamp, ndirs = np.asarray(kw["hL"]).shape
+    kind, order = kw["kind"], int(kw["order"])
+    nsamp = np.asarray(kw["hL"]).shape[0]
     atf = kw.get("atf")
     nmics = np.asarray(atf).shape[1] if atf is not None else (0 if kw.get("mic_azi") is None else int(np.asarray(kw["mic_azi"]).size))
-    p = Plan(kw["kind"], kw["basis"], kw["order"], kw["fs"], kw["length"], nsamp, ndirs, kw.get("mic_radius", 0.0), nmics,
-             f_trans=kw.get("f_trans", 0.0), atf_taps=0 if atf is None else np.asarray(atf).shape[0],
-             natf=0 if atf is None else np.asarray(atf).shape[2], sim_order_pad=kw.get("sim_order_pad", 0))
-    try:
-        i = p.info()
-        return int(i.out_rows), int(i.out_cols), bool(i.out_is_complex)
-    finally:
-        p.close()
+    if kind in (L.KIND_EMAGLS2, L.KIND_FROM_ATF):
+        cols = nmics
+    elif kind in (L.KIND_MAGLS_2D, L.KIND_EMA_CH):
+        cols = 2 * order + 1
+    else:
+        cols = (order + 1) ** 2
+    rows = nsamp if kind == L.KIND_LS else int(kw["length"])
+    return int(rows), int(cols), bool(kw["basis"] == "complex" and kind != L.KIND_FROM_ATF)
 
 
 def _run_share(jobs, res, max_batch, share_geometry=False):
@@ -409,7 +413,10 @@ def emagls2_radius_sweep(hL, hR, hrirGridAziRad, hrirGridZenRad, radii, micGridA
     def make_job(j):
         return dict(kind=L.KIND_EMAGLS2, basis=shDefinition, order=int(order), fs=float(fs), length=int(length), hL=hL, hR=hR, hrir_azi=azi, hrir_zen=zen,
                     mic_radius=radii[j], mic_azi=maz, mic_zen=mzn, sim_order_pad=int(pad_of[j]) if nmics <= 32 else 0)   # (no padding on the path of more than 32 microphones)
-    out = _run_job_list(len(radii), shards, make_job, group, max_batch)
+    # (the balanced cut makes chunks of up to 32 designs, `max_batch` on average: the library must not cut them again at `max_batch`
+    # -- a chunk of 20 would run as 16 + 4, the tail on the slower slab form, and the cost model behind the shards would no longer
+    # describe what runs; chunks end where the padded shape changes anyway.  More than 32 microphones: plan by plan.)
+    out = _run_job_list(len(radii), shards, make_job, group, 32 if nmics <= 32 else max_batch)
     if _one_share_of is not None:
         return [out[j] for j in shards[0]]
     return out

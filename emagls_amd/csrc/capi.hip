@@ -106,7 +106,13 @@ struct BlockPool {
             }
         }
         void* p = nullptr;
-        HIP_CHECK(hipMalloc(&p, bytes));
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipErrorOutOfMemory) {   // the pool may hold gigabytes of blocks of other sizes: return them to the runtime and try once more
+            (void)hipGetLastError();
+            clear();
+            e = hipMalloc(&p, bytes);
+        }
+        HIP_CHECK(e);
         *got = bytes;
         return p;
     }
@@ -251,6 +257,11 @@ struct emagls_plan {
 
     ~emagls_plan() {
         if (owner) emagls_batch_forget(owner, this);
+        // the slabs go back to a pool that other threads take from at once (no hipFree that would wait for pending work): nothing
+        // enqueued by this plan may still be running on them
+        if (stream) hipStreamSynchronize(stream);
+        for (auto st : side) if (st) hipStreamSynchronize(st);
+        (void)hipGetLastError();
         for (auto& kv : bufs) if (kv.second.p && kv.second.owned) hipFree(kv.second.p);
         release_slabs();
         for (auto e : stage_events) hipEventDestroy(e);
@@ -1446,18 +1457,22 @@ struct SweepGate {
         slots = slots_per_xcd <= 0 ? g.capacity : std::min(slots_per_xcd, g.capacity);
         static const bool serial = [] { const char* e = getenv("EMAGLS_SWEEP_SERIAL"); return e && e[0] == '1'; }();
         if (serial) slots = g.capacity;
-        while (!g.inflight.empty() && hipEventQuery(g.inflight.front().ev) == hipSuccess) {   // finished: no longer holds slots
-            g.pool.push_back(g.inflight.front().ev);
-            g.inflight.pop_front();
+        // finished launches no longer hold slots (anywhere in the queue: launches of different sizes finish out of order)
+        for (auto it = g.inflight.begin(); it != g.inflight.end();) {
+            if (hipEventQuery(it->ev) == hipSuccess) { g.pool.push_back(it->ev); it = g.inflight.erase(it); }
+            else ++it;
         }
         (void)hipGetLastError();   // (hipErrorNotReady of the query is not an error)
+        // Everything that has not FINISHED may still run next to this launch unless this launch waits for it -- also a launch that
+        // an earlier one already waits for (it may not even have started: sweeps are enqueued behind the stages before them).  So
+        // an entry stays in the queue, and counts for every later launch, until its event reports completion; this launch waits
+        // for the oldest entries, as many as it takes for the rest to fit next to it.
         int held = 0;
         for (const Entry& e : g.inflight) held += e.slots;
-        while (!g.inflight.empty() && held + slots > g.capacity) {
-            HIP_CHECK(hipStreamWaitEvent(st, g.inflight.front().ev, 0));
-            held -= g.inflight.front().slots;
-            g.pool.push_back(g.inflight.front().ev);   // (a wait already enqueued keeps the state the event had when it was enqueued)
-            g.inflight.pop_front();
+        for (const Entry& e : g.inflight) {
+            if (held + slots <= g.capacity) break;
+            HIP_CHECK(hipStreamWaitEvent(st, e.ev, 0));
+            held -= e.slots;
         }
     }
     ~SweepGate() {   // (the lock is held from the waits to the record: no other sweep can slip in between)
@@ -3986,6 +4001,16 @@ void job_shape(const emagls_design_desc& d, std::string& out) {
     }
     out.assign(reinterpret_cast<const char*>(&k), sizeof k);
 }
+// will the slot's next execute capture hipGraphs?  (the batch forms and plan_execute capture on the run after an eager one)
+bool slot_will_capture(const JobSlot& s) {
+    if (s.batch) {
+        const emagls_batch& b = *s.batch;
+        return b.use_graph && b.eager_runs >= 1 && !b.graph_exec && !(b.plans.size() && b.plans[0]->pre_exec);
+    }
+    for (const emagls_plan* p : s.plans)
+        if (p->use_graph && p->prof_level == 0 && p->eager_runs >= 1 && !p->pre_exec && !p->graph_exec) return true;
+    return false;
+}
 void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool solo) {
     DeviceGuard dg(device);
     static const bool trace = getenv("EMAGLS_JOBS_TRACE") != nullptr;
@@ -4007,7 +4032,9 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
     }
     // a chunk shares the device with the other chunks in flight, except on its slot's SECOND run: that one captures the hipGraphs of the
     // stages around the sweep, and a capture next to another thread's uploads or launches is invalidated (hipErrorStreamCaptureInvalidated)
-    const bool capturing = slot && slot->runs == 1;
+    // (decided from the objects' own state, not from the slot's run count: a batch whose graphs were dropped by a recovery --
+    // drop_batch_graphs after a flagged bin or a lanes rebuild -- captures again on a later run)
+    const bool capturing = slot && slot_will_capture(*slot);
     std::shared_lock<std::shared_timed_mutex> shared(g_jobs_warm_mu, std::defer_lock);
     std::unique_lock<std::shared_timed_mutex> alone(g_jobs_warm_mu, std::defer_lock);
     if (capturing) alone.lock(); else shared.lock();
@@ -4183,7 +4210,16 @@ int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int i
                     if (err_code != EMAGLS_OK) return;
                 }
                 try {
-                    jobs_run_chunk(jobs + chunks[c].first, chunks[c].second, device, flags, chunks.size() == 1);
+                    try {
+                        jobs_run_chunk(jobs + chunks[c].first, chunks[c].second, device, flags, chunks.size() == 1);
+                    } catch (const Error& e) {
+                        // a chunk of 17 ... 32 designs whose sweep stopped being the register-resident form (a recovery moved it to
+                        // the slab or launch-per-bin forms, which hold 16 designs): the same designs as two chunks of at most 16
+                        if (chunks[c].second <= SWEEP_MULTI_MAX || e.code != EMAGLS_ERR_UNSUPPORTED || !strstr(e.what(), "more than 16 designs")) throw;
+                        const int h = (chunks[c].second + 1) / 2;
+                        jobs_run_chunk(jobs + chunks[c].first, h, device, flags, false);
+                        jobs_run_chunk(jobs + chunks[c].first + h, chunks[c].second - h, device, flags, false);
+                    }
                 } catch (const Error& e) {
                     std::lock_guard<std::mutex> lk(err_mu);
                     if (err_code == EMAGLS_OK) { err_code = e.code; err_msg = e.what(); }
