@@ -297,24 +297,19 @@ class _Results:
 
 
 def _out_shape(job):
-    """(rows, columns, complex?) of a job's filters, from its descriptor alone (no plan, no device memory): what
-    emagls_plan_info reports -- len x channels; LS keeps the HRIR length (lib/getLsFilters.m:33); channels = (N+1)^2 in the SH
-    domain, 2N+1 circular harmonics (getMagLsFilters2D, EMAinCH), the microphones for eMagLS2 / FromAtf; complex for a complex
-    basis except FromAtf (tests/test_gpu_jobs.py checks it against the plans of every kind)."""
+    """(rows, columns, complex?) of a job's filters, from its descriptor alone (emagls_design_out_shape: no plan, no device
+    memory)."""
+    import ctypes as C
     from . import _lib as L
     kw = dict(job)
-    kind, order = kw["kind"], int(kw["order"])
-    nsamp = np.asarray(kw["hL"]).shape[0]
+    nsamp, ndirs = np.asarray(kw["hL"]).shape
     atf = kw.get("atf")
     nmics = np.asarray(atf).shape[1] if atf is not None else (0 if kw.get("mic_azi") is None else int(np.asarray(kw["mic_azi"]).size))
-    if kind in (L.KIND_EMAGLS2, L.KIND_FROM_ATF):
-        cols = nmics
-    elif kind in (L.KIND_MAGLS_2D, L.KIND_EMA_CH):
-        cols = 2 * order + 1
-    else:
-        cols = (order + 1) ** 2
-    rows = nsamp if kind == L.KIND_LS else int(kw["length"])
-    return int(rows), int(cols), bool(kw["basis"] == "complex" and kind != L.KIND_FROM_ATF)
+    desc = L.DesignDesc(int(kw["kind"]), L.BASIS[kw["basis"]], int(kw["order"]), float(kw["fs"]), int(kw["length"]), int(nsamp), int(ndirs),
+                        float(kw.get("mic_radius", 0.0)), int(nmics), float(kw.get("f_trans", 0.0)), 0, 0, 0, 0, int(kw.get("sim_order_pad", 0)))
+    rows, cols, cplx = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    L.check(L.load().emagls_design_out_shape(C.byref(desc), C.byref(rows), C.byref(cols), C.byref(cplx)))
+    return int(rows.value), int(cols.value), bool(cplx.value)
 
 
 def _run_share(jobs, res, max_batch, share_geometry=False):

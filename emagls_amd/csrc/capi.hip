@@ -3793,6 +3793,20 @@ int emagls_simulation_order(int kind, int order, double fs, double mic_radius) {
         default: return order;
     }
 }
+int emagls_design_out_shape(const emagls_design_desc* desc, int64_t* rows, int64_t* cols, int* is_complex) {
+    return guarded([&] {
+        if (!desc || !rows || !cols || !is_complex) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        const emagls_design_desc& d = *desc;
+        if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_EMA_SH || d.order < 0) throw Error(EMAGLS_ERR_ARG, "invalid design kind or order");
+        switch (d.kind) {
+            case EMAGLS_KIND_EMAGLS2: case EMAGLS_KIND_FROM_ATF: *cols = d.nmics; break;                       // one filter per microphone
+            case EMAGLS_KIND_MAGLS_2D: case EMAGLS_KIND_EMA_CH: *cols = 2 * (int64_t)d.order + 1; break;       // circular harmonics
+            default: *cols = ((int64_t)d.order + 1) * (d.order + 1);
+        }
+        *rows = d.kind == EMAGLS_KIND_LS ? d.nsamp : d.len;                                                    // lib/getLsFilters.m:33: h * Y_pinv
+        *is_complex = d.basis == EMAGLS_BASIS_COMPLEX && d.kind != EMAGLS_KIND_FROM_ATF;
+    });
+}
 int emagls_get_ls_filters_with_basis(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, const void* Y_hrir, int order,
                                      int basis, void* wL, void* wR) {
     emagls_design_desc d{};
@@ -3992,6 +4006,11 @@ uint64_t g_jobs_tick = 0;
 std::atomic<size_t> g_jobs_resident_max{8 * REG_SWEEP_MAX};   // designs kept resident between calls (0.19 GB each at config 3); at least one call's chunks in flight
 
 void check_rc(int rc) { if (rc != EMAGLS_OK) throw Error(rc, g_last_error); }
+bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t at{};
+    if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // (plain host memory: not registered)
+    return at.type == hipMemoryTypeDevice;
+}
 // what makes two designs share a lane batch: everything but the array radius inside one (padded) simulation-order class
 void job_shape(const emagls_design_desc& d, std::string& out) {
     emagls_design_desc k = d;
@@ -4095,7 +4114,26 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
         // the HRIRs of every design on the batch's stream, ordered before its execute: no host synchronisation per plan
         // (jobs that name the SAME HRIR arrays -- one HRIR set for every radius of an array sweep -- are served device to device from
         // the first plan that received them: 5.5 MB over PCIe instead of 5.5 MB per design from pageable memory)
-        for (int j = 0; j < n; ++j) {
+        // inputs that already lie in device memory: ONE gather launch for the whole chunk (hipMemcpyAsync per buffer otherwise)
+        bool gathered = false;
+        if (2 * n <= 64) {
+            bool all_dev = true;
+            for (int j = 0; j < n && all_dev; ++j) all_dev = is_device_pointer(jobs[j].hL) && is_device_pointer(jobs[j].hR);
+            if (all_dev) {
+                LanePtrs src{}, dst{};
+                const emagls_plan& q0 = *slot->plans[0];
+                const size_t bytes = sizeof(double) * (size_t)q0.d.nsamp * (size_t)q0.d.ndirs;
+                for (int j = 0; j < n; ++j) {
+                    emagls_plan& q = *slot->plans[(size_t)j];
+                    src.p[2 * j] = const_cast<double*>(jobs[j].hL); src.p[2 * j + 1] = const_cast<double*>(jobs[j].hR);
+                    dst.p[2 * j] = q.get("hL"); dst.p[2 * j + 1] = q.get("hR");
+                    q.have_hrirs = true;
+                }
+                launch_gather_buffers(src, dst, 2 * n, bytes, slot->batch->stream);
+                gathered = true;
+            }
+        }
+        for (int j = 0; j < n && !gathered; ++j) {
             emagls_plan& q = *slot->plans[(size_t)j];
             const size_t bytes = sizeof(double) * (size_t)q.d.nsamp * (size_t)q.d.ndirs;
             int src = -1;

@@ -13,6 +13,7 @@ void launch_compare_words(const void* a, const void* b, size_t bytes, int* diffe
 void launch_broadcast_lanes(const void* src, size_t bytes, size_t stride, int nlanes, hipStream_t st);
 struct LanePtrs { void* p[64]; };   // [2 j + ear] for up to 32 designs
 void launch_scatter_lanes(const void* srcL, const void* srcR, size_t stride, size_t bytes, int n, const LanePtrs& dst, hipStream_t st);
+void launch_gather_buffers(const LanePtrs& src, const LanePtrs& dst, int nbuf, size_t bytes, hipStream_t st);   // nbuf <= 64 device buffers of `bytes` each
 void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out, int ld, hipStream_t st, bool out_real = false);
 void launch_sh_coeff(int N, double* tab, hipStream_t st);
 inline size_t esz(bool c) { return c ? sizeof(cplx) : sizeof(double); }   // element size of a real / complex basis

@@ -168,6 +168,32 @@ void launch_scatter_lanes(const void* srcL, const void* srcR, size_t stride, siz
     KERNEL_CHECK();
 }
 
+// the inputs of a lane batch (hL / hR of every design) from the caller's device buffers into the plans' own: ONE launch instead of two
+// copies per design (40 copies of 2.8 MB each took 0.37 ms of a 7.6 ms job list at config 3 -- 0.3 TB/s, the copies' own launch
+// gaps -- and everything else waited behind them); blockIdx.y = buffer
+__global__ void __launch_bounds__(256) gather_buffers_kernel(LanePtrs src, LanePtrs dst, int64_t n8) {
+    const int j = blockIdx.y;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(src.p[j]) | reinterpret_cast<uintptr_t>(dst.p[j])) & 15) == 0) {
+        const uint4* s = reinterpret_cast<const uint4*>(src.p[j]);
+        uint4* d = reinterpret_cast<uint4*>(dst.p[j]);
+        const int64_t n16 = n8 >> 1;
+        for (int64_t i = i0; i < n16; i += stride) d[i] = s[i];
+        if ((n8 & 1) && i0 == 0) reinterpret_cast<unsigned long long*>(dst.p[j])[n8 - 1] = reinterpret_cast<const unsigned long long*>(src.p[j])[n8 - 1];
+    } else {
+        const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src.p[j]);
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst.p[j]);
+        for (int64_t i = i0; i < n8; i += stride) d[i] = s[i];
+    }
+}
+void launch_gather_buffers(const LanePtrs& src, const LanePtrs& dst, int nbuf, size_t bytes, hipStream_t st) {
+    const int64_t n8 = (int64_t)(bytes / 8);
+    if (n8 == 0 || nbuf <= 0) return;
+    const unsigned gx = (unsigned)std::min<int64_t>(96, ceil_div(n8 / 2 + 1, 256));
+    gather_buffers_kernel<<<dim3(gx, (unsigned)nbuf), 256, 0, st>>>(src, dst, n8);
+    KERNEL_CHECK();
+}
+
 // *differ = 1 when two device buffers differ in any 8-byte word (a batch of FromAtf subjects checks that its plans really hold
 // the same ATF set and grids before it computes the ATF side once for all of them)
 __global__ void compare_words_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, int64_t n8, int* differ) {

@@ -376,6 +376,12 @@ typedef struct emagls_job {
  * the geometry stages once (emagls_batch_set_geometry_sharing; the filters are bit-identical to the independent designs'). */
 #define EMAGLS_JOBS_SHARE_GEOMETRY 1
 int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int in_flight, int flags);
+/* Shape of a design's filters from its descriptor alone (no plan, no device memory: what a caller needs to allocate wL / wR of a
+ * job): rows x cols, real or interleaved complex -- len x channels like the reference's outputs (lib/getEMagLsFilters.m:139-142);
+ * LS keeps the HRIR length (lib/getLsFilters.m:33); channels = (N+1)^2 in the SH domain, 2N+1 circular harmonics (MAGLS_2D,
+ * EMA_CH), the microphones for EMAGLS2 / FROM_ATF; complex for a complex basis except FROM_ATF.  The same numbers as
+ * emagls_plan_info.out_rows / out_cols / out_is_complex of a plan of that descriptor. */
+int emagls_design_out_shape(const emagls_design_desc* desc, int64_t* rows, int64_t* cols, int* is_complex);
 /* Measurement hooks of the job lists (bench.py's roofline figure): level > 0 makes the chunks' batches bracket their sweep launch
  * with HIP events on the stream it is launched on; emagls_jobs_sweep_times then reports, for every resident chunk that ran since,
  * the duration of its LAST sweep launch (ms) and the designs it covered (count: chunks available, capacity: room in the arrays). */

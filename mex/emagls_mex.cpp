@@ -13,6 +13,7 @@
 #include <cctype>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "emagls.h"
 #include "mex.h"
@@ -71,6 +72,7 @@ void at_exit() { emagls_cache_clear(); }
 // emagls_mex('decode',  in, wL, wR, compensateDelay)            real or complex in / filters; [out, imagAbsSum] = ...
 // emagls_mex('sets', kind, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition)   3-D hL / hR: a loop over HRIR sets in one call
 // emagls_mex('fromatfsets', hL, hR, hrirGridAziZen, atfIrs, atfGridAziZen, fs, filterLen, fTrans)      3-D hL / hR: the subjects of one ATF set
+// emagls_mex('jobs', jobs[, batchSize, inFlight, shareGeometry])   struct array of independent designs (any kinds, radii, HRIR sets): W = {wL, wR} per job
 // caller-evaluated shFunction handles (the wrappers evaluate them at emagls_mex('simorder', kind, order, fs, micRadius)):
 // emagls_mex('ls_y', hL, hR, Yhrir, order, shDefinition)        emagls_mex('magls_y', hL, hR, Yhrir, order, fs, len, shDefinition)
 // emagls_mex('emagls_y' | 'emagls2_y', hL, hR, Yhrir, micRadius, Ymic, order, fs, len, shDefinition)
@@ -152,6 +154,94 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const int rc = emagls_design_hrir_sets(kind, hL, hR, nsamp, ndirs, nsets, azi, zen, r, mazi, mzen, nmics, order, fs, len, basis,
                                                out_ptr(plhs[0]), out_ptr(wR));
         if (nlhs > 1) plhs[1] = wR; else mxDestroyArray(wR);
+        if (rc) fail(rc);
+        return;
+    }
+    if (c == "jobs") {
+        // W = emagls_mex('jobs', jobs, batchSize, inFlight, shareGeometry)
+        // The loop a user of the reference writes around one of its design functions (testEMagLs.m:75-95: array radii; HRIR sets;
+        // testEMagLsFromAtfs.m:72-73: subjects) handed over in ONE call: the library's scheduler (emagls_jobs_run) cuts the list into
+        // chunks of one shape, runs each as a lane batch and keeps several chunks in flight.  `jobs` is a struct array, one element per
+        // design, with the reference's argument names as fields:
+        //   kind ('ls' | 'magls' | 'magls2d' | 'emagls' | 'emagls2' | 'emainch' | 'emainsh' | 'fromatf'), hL, hR, hrirGridAziRad,
+        //   hrirGridZenRad, order, fs, len, shDefinition, micRadius, micGridAziRad, micGridZenRad (array designs),
+        //   atfIrs, atfGridAziRad, atfGridZenRad, fTrans (fromatf), applyDiffusenessConst, simOrderPad (optional)
+        // Returns an n x 2 cell array {wL, wR} with the filters each single call would return.
+        if (nrhs < 2 || !mxIsStruct(prhs[1])) mexErrMsgIdAndTxt("eMagLS:arg", "jobs needs a struct array of designs");
+        const mxArray* J = prhs[1];
+        const mwSize n = mxGetNumberOfElements(J);
+        auto num = [&](int i, double dflt) { return nrhs > i && !mxIsEmpty(prhs[i]) ? mxGetScalar(prhs[i]) : dflt; };
+        const int batch_size = (int)num(2, 0), in_flight = (int)num(3, 0);
+        const int share = nrhs > 4 && (mxIsLogicalScalarTrue(prhs[4]) || (!mxIsEmpty(prhs[4]) && mxGetScalar(prhs[4]) != 0));
+        plhs[0] = mxCreateCellMatrix(n, 2);
+        std::vector<emagls_job> jobs(n);
+        for (mwSize i = 0; i < n; ++i) {
+            auto fld = [&](const char* name) -> const mxArray* { const mxArray* a = mxGetField(J, i, name); return (a && !mxIsEmpty(a)) ? a : nullptr; };
+            auto req = [&](const char* name) -> const mxArray* {
+                const mxArray* a = fld(name);
+                if (!a) mexErrMsgIdAndTxt("eMagLS:arg", "jobs(%d).%s is missing", (int)i + 1, name);
+                return a;
+            };
+            auto vec = [&](const char* name, mwSize want) -> const double* {
+                const mxArray* a = fld(name);
+                if (!a) return nullptr;
+                if (mxGetNumberOfElements(a) != want) mexErrMsgIdAndTxt("eMagLS:arg", "jobs(%d).%s must have %d elements", (int)i + 1, name, (int)want);
+                return dbl(a, name);
+            };
+            char kb[16] = {0};
+            mxGetString(req("kind"), kb, sizeof kb);
+            const std::string ks(kb);
+            emagls_job& jb = jobs[i];
+            std::memset(&jb, 0, sizeof jb);
+            emagls_design_desc& d = jb.desc;
+            if (ks == "ls") d.kind = EMAGLS_KIND_LS; else if (ks == "magls") d.kind = EMAGLS_KIND_MAGLS; else if (ks == "magls2d") d.kind = EMAGLS_KIND_MAGLS_2D;
+            else if (ks == "emagls") d.kind = EMAGLS_KIND_EMAGLS; else if (ks == "emagls2") d.kind = EMAGLS_KIND_EMAGLS2;
+            else if (ks == "emainch") d.kind = EMAGLS_KIND_EMA_CH; else if (ks == "emainsh") d.kind = EMAGLS_KIND_EMA_SH;
+            else if (ks == "fromatf") d.kind = EMAGLS_KIND_FROM_ATF;
+            else mexErrMsgIdAndTxt("eMagLS:arg", "jobs(%d).kind: unknown design kind '%s'", (int)i + 1, kb);
+            const mxArray* hL = req("hL");
+            const mxArray* hR = req("hR");
+            if (mxGetM(hL) != mxGetM(hR) || mxGetN(hL) != mxGetN(hR)) mexErrMsgIdAndTxt("eMagLS:arg", "jobs(%d): hL and hR must have the same size", (int)i + 1);
+            d.nsamp = (int64_t)mxGetM(hL); d.ndirs = (int64_t)mxGetN(hL);
+            jb.hL = dbl(hL, "hL"); jb.hR = dbl(hR, "hR");
+            d.basis = basis_of(fld("shDefinition"));
+            const bool atf = d.kind == EMAGLS_KIND_FROM_ATF;
+            d.order = atf ? 0 : (int)mxGetScalar(req("order"));
+            d.fs = fld("fs") ? mxGetScalar(fld("fs")) : 48000.0;
+            d.len = d.kind == EMAGLS_KIND_LS ? d.nsamp : (int64_t)mxGetScalar(req("len"));
+            jb.hrir_azi = vec("hrirGridAziRad", (mwSize)d.ndirs);
+            jb.hrir_zen = vec("hrirGridZenRad", (mwSize)d.ndirs);
+            if (!jb.hrir_azi) mexErrMsgIdAndTxt("eMagLS:arg", "jobs(%d).hrirGridAziRad is missing", (int)i + 1);
+            const bool arr = d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2 || d.kind == EMAGLS_KIND_EMA_CH || d.kind == EMAGLS_KIND_EMA_SH;
+            if (arr) {
+                d.mic_radius = mxGetScalar(req("micRadius"));
+                d.nmics = (int64_t)mxGetNumberOfElements(req("micGridAziRad"));
+                jb.mic_azi = vec("micGridAziRad", (mwSize)d.nmics);
+                jb.mic_zen = vec("micGridZenRad", (mwSize)d.nmics);
+            }
+            if (atf) {
+                const mxArray* a = req("atfIrs");                      // [taps x mics x dirs] (lib/getEMagLsFiltersFromAtf.m:11)
+                const mwSize* ad = mxGetDimensions(a);
+                d.atf_taps = (int64_t)ad[0]; d.nmics = (int64_t)ad[1]; d.natf = mxGetNumberOfDimensions(a) > 2 ? (int64_t)ad[2] : 1;
+                jb.atf = dbl(a, "atfIrs");
+                jb.atf_azi = vec("atfGridAziRad", (mwSize)d.natf);
+                jb.atf_zen = vec("atfGridZenRad", (mwSize)d.natf);
+                d.f_trans = mxGetScalar(req("fTrans"));
+                d.basis = EMAGLS_BASIS_REAL;
+            }
+            if (const mxArray* a = fld("applyDiffusenessConst")) d.diffuseness = mxIsLogicalScalarTrue(a) || mxGetScalar(a) != 0;
+            if (const mxArray* a = fld("simOrderPad")) d.sim_order_pad = (int)mxGetScalar(a);
+            int64_t rows = 0, cols = 0;
+            int cplx = 0;
+            const int rc = emagls_design_out_shape(&d, &rows, &cols, &cplx);
+            if (rc) fail(rc);
+            mxArray* wl = mxCreateDoubleMatrix((mwSize)rows, (mwSize)cols, cplx ? mxCOMPLEX : mxREAL);
+            mxArray* wr = mxCreateDoubleMatrix((mwSize)rows, (mwSize)cols, cplx ? mxCOMPLEX : mxREAL);
+            mxSetCell(plhs[0], i, wl);           // column-major n x 2: wL in column 1, wR in column 2
+            mxSetCell(plhs[0], n + i, wr);
+            jb.wL = out_ptr(wl); jb.wR = out_ptr(wr);
+        }
+        const int rc = n ? emagls_jobs_run(jobs.data(), (int64_t)n, batch_size, in_flight, share ? EMAGLS_JOBS_SHARE_GEOMETRY : 0) : 0;
         if (rc) fail(rc);
         return;
     }

@@ -13,7 +13,7 @@ typedef struct mxArray_tag mxArray;
 typedef double mxDouble;
 typedef struct { double real, imag; } mxComplexDouble;
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
-typedef enum { mxUNKNOWN_CLASS = 0, mxLOGICAL_CLASS = 3, mxCHAR_CLASS = 4, mxDOUBLE_CLASS = 6 } mxClassID;
+typedef enum { mxUNKNOWN_CLASS = 0, mxLOGICAL_CLASS = 3, mxCELL_CLASS = 1, mxSTRUCT_CLASS = 2, mxCHAR_CLASS = 4, mxDOUBLE_CLASS = 6 } mxClassID;
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]);
 void mexErrMsgIdAndTxt(const char* id, const char* fmt, ...);
@@ -38,6 +38,12 @@ bool mxIsDouble(const mxArray* a);
 bool mxIsChar(const mxArray* a);
 bool mxIsEmpty(const mxArray* a);
 bool mxIsLogicalScalarTrue(const mxArray* a);
+bool mxIsStruct(const mxArray* a);
+bool mxIsCell(const mxArray* a);
+mxArray* mxGetField(const mxArray* a, mwSize index, const char* name);   /* NULL when the struct has no such field */
+mxArray* mxCreateCellMatrix(mwSize m, mwSize n);
+void mxSetCell(mxArray* a, mwSize index, mxArray* value);
+mxArray* mxGetCell(const mxArray* a, mwSize index);
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,9 @@ struct mxArray_tag {
     std::vector<mwSize> dims;
     std::vector<double> data;   // interleaved (re, im) when cplx
     std::string text;
+    std::vector<std::string> fields;     // struct arrays: element i, field f at cells[i * fields.size() + f]
+    std::vector<mxArray_tag*> cells;     // cell arrays and struct arrays own their elements
+    ~mxArray_tag() { for (auto* c : cells) delete c; }
     mwSize numel() const { mwSize n = 1; for (mwSize d : dims) n *= d; return n; }
 };
 namespace {
@@ -59,6 +62,20 @@ bool mxIsDouble(const mxArray* a) { return a->cls == mxDOUBLE_CLASS; }
 bool mxIsChar(const mxArray* a) { return a->cls == mxCHAR_CLASS; }
 bool mxIsEmpty(const mxArray* a) { return a->numel() == 0; }
 bool mxIsLogicalScalarTrue(const mxArray* a) { return a->cls == mxLOGICAL_CLASS && a->numel() == 1 && a->logical_value; }
+bool mxIsStruct(const mxArray* a) { return a->cls == mxSTRUCT_CLASS; }
+bool mxIsCell(const mxArray* a) { return a->cls == mxCELL_CLASS; }
+mxArray* mxGetField(const mxArray* a, mwSize index, const char* name) {
+    if (a->cls != mxSTRUCT_CLASS || index >= a->numel()) return nullptr;
+    for (size_t f = 0; f < a->fields.size(); ++f) if (a->fields[f] == name) return a->cells[index * a->fields.size() + f];
+    return nullptr;
+}
+mxArray* mxCreateCellMatrix(mwSize m, mwSize n) {
+    mxArray* a = new mxArray_tag;
+    a->cls = mxCELL_CLASS; a->dims = {m, n}; a->cells.assign(m * n, nullptr);
+    return a;
+}
+void mxSetCell(mxArray* a, mwSize index, mxArray* value) { if (a->cls == mxCELL_CLASS && index < a->cells.size()) { delete a->cells[index]; a->cells[index] = value; } }
+mxArray* mxGetCell(const mxArray* a, mwSize index) { return (a->cls == mxCELL_CLASS && index < a->cells.size()) ? a->cells[index] : nullptr; }
 
 // ---- the test's side ----
 void* stub_array(int ndim, const size_t* dims, const double* data, int is_complex) {
@@ -77,6 +94,22 @@ void* stub_logical(int v) {
     a->cls = mxLOGICAL_CLASS; a->logical_value = v != 0; a->dims = {1, 1};
     return a;
 }
+// a 1 x n struct array with the given field names; stub_struct_set hands a value over (the struct owns it; NULL = [])
+void* stub_struct(size_t n, int nfields, const char** names) {
+    mxArray* a = new mxArray_tag;
+    a->cls = mxSTRUCT_CLASS; a->dims = {1, (mwSize)n};
+    for (int f = 0; f < nfields; ++f) a->fields.push_back(names[f]);
+    a->cells.assign(n * (size_t)nfields, nullptr);
+    return a;
+}
+void stub_struct_set(void* s, size_t index, int field, void* value) {
+    mxArray* a = static_cast<mxArray*>(s);
+    mxArray*& slot = a->cells[index * a->fields.size() + (size_t)field];
+    delete slot;
+    slot = static_cast<mxArray*>(value);
+}
+int stub_is_cell(const void* a) { return static_cast<const mxArray*>(a)->cls == mxCELL_CLASS; }
+void* stub_cell_get(const void* a, size_t index) { return mxGetCell(static_cast<const mxArray*>(a), index); }
 void stub_free(void* a) { delete static_cast<mxArray*>(a); }
 int stub_ndim(const void* a) { return (int)static_cast<const mxArray*>(a)->dims.size(); }
 void stub_dims(const void* a, size_t* out) { const mxArray* x = static_cast<const mxArray*>(a); for (size_t i = 0; i < x->dims.size(); ++i) out[i] = x->dims[i]; }

@@ -66,3 +66,25 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert "emagls_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_design_out_shape_needs_no_gpu(lib):
+    """emagls_design_out_shape (include/emagls.h): the filter shape of every design kind from the descriptor alone -- what a C or MEX
+    caller allocates for a job of emagls_jobs_run (lib/getLsFilters.m:33 keeps the HRIR length; lib/getEMagLs2Filters.m:132-135 one
+    filter per microphone; getMagLsFilters2D / EMAinCH 2N+1 circular harmonics; FromAtf real whatever the basis)."""
+    import ctypes as C
+    from emagls_amd import _lib as L
+    cases = [  # kind, basis, order, len, nsamp, nmics -> rows, cols, complex
+        (L.KIND_LS, "complex", 3, 512, 128, 0, (128, 16, True)), (L.KIND_MAGLS, "real", 4, 512, 128, 0, (512, 25, False)),
+        (L.KIND_MAGLS_2D, "complex", 7, 256, 64, 0, (256, 15, True)), (L.KIND_EMAGLS, "complex", 4, 512, 128, 32, (512, 25, True)),
+        (L.KIND_EMAGLS2, "complex", 4, 1024, 128, 32, (1024, 32, True)), (L.KIND_EMAGLS2, "real", 1, 1024, 128, 64, (1024, 64, False)),
+        (L.KIND_EMA_CH, "real", 5, 512, 128, 16, (512, 11, False)), (L.KIND_EMA_SH, "real", 3, 512, 128, 16, (512, 16, False)),
+        (L.KIND_FROM_ATF, "complex", 0, 2048, 256, 8, (2048, 8, False))]
+    for kind, basis, order, ln, nsamp, nmics, want in cases:
+        d = L.DesignDesc(kind, L.BASIS[basis], order, 48000.0, ln, nsamp, 2702, 0.042, nmics, 0.0, 0, 0, 0, 0, 0)
+        r, c, z = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        assert lib.emagls_design_out_shape(C.byref(d), C.byref(r), C.byref(c), C.byref(z)) == 0
+        assert (r.value, c.value, bool(z.value)) == want, (kind, basis)
+    bad = L.DesignDesc(99, 0, 1, 48000.0, 16, 16, 10, 0.0, 0, 0.0, 0, 0, 0, 0, 0)
+    r, c, z = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    assert lib.emagls_design_out_shape(C.byref(bad), C.byref(r), C.byref(c), C.byref(z)) != 0

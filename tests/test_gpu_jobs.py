@@ -70,3 +70,23 @@ def test_job_list_reports_a_failing_job(thin, grids):
         jl.run()
     assert "microphone grid" in str(e.value)
     L.check(L.load().emagls_cache_clear())
+
+
+def test_design_out_shape_equals_the_plans(thin, grids):
+    """emagls_design_out_shape against emagls_plan_info of a plan of the same descriptor, every kind (the runners of
+    emagls_amd/batch.py and the MEX 'jobs' command size their outputs by it)."""
+    import ctypes as C
+    from emagls_amd import Plan, _lib as L
+    lib = L.load()
+    for kind, basis, order, nmics, extra in [(L.KIND_LS, "complex", 2, 0, {}), (L.KIND_MAGLS, "real", 3, 0, {}), (L.KIND_MAGLS_2D, "complex", 5, 0, {}),
+                                             (L.KIND_EMAGLS, "complex", 4, 32, {}), (L.KIND_EMAGLS2, "complex", 2, 12, {}), (L.KIND_EMAGLS2, "real", 4, 40, {}),
+                                             (L.KIND_EMA_CH, "real", 3, 9, {}), (L.KIND_EMA_SH, "complex", 2, 9, {}),
+                                             (L.KIND_FROM_ATF, "real", 0, 5, dict(f_trans=2000.0, atf_taps=48, natf=300))]:
+        p = Plan(kind, basis, order, 48000.0, 128, 64, 901, 0.042 if nmics and kind != L.KIND_FROM_ATF else 0.0, nmics, **extra)
+        i = p.info()
+        d = L.DesignDesc(kind, L.BASIS[basis], order, 48000.0, 128, 64, 901, 0.042 if nmics and kind != L.KIND_FROM_ATF else 0.0, nmics,
+                         extra.get("f_trans", 0.0), extra.get("atf_taps", 0), extra.get("natf", 0), 0, 0, 0)
+        r, c, z = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        L.check(lib.emagls_design_out_shape(C.byref(d), C.byref(r), C.byref(c), C.byref(z)))
+        assert (r.value, c.value, bool(z.value)) == (i.out_rows, i.out_cols, bool(i.out_is_complex)), (kind, basis)
+        p.close()

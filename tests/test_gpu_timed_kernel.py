@@ -57,6 +57,8 @@ def test_timed_kernel_at_full_size(grids, sets, oracle_filters, monkeypatch, n):
     lib = L.load()
     # the form such a chunk takes (decided per launch): 3 = the register-resident sweep
     p = Plan(L.KIND_EMAGLS, "complex", 4, 48000.0, 512, 128, 2702, 0.042, 32)
+    p.set_hrir_grid(grids["azi"], grids["zen"])
+    p.set_mic_grid(grids["mic_azi"], grids["mic_zen"])    # (the antipodal pairs of the array decide the form: 17 units on the em32)
     form = ctypes.c_int(0)
     L.check(lib.emagls_plan_sweep_form_in_batch(p._h, n, ctypes.byref(form)))
     p.close()

@@ -41,11 +41,26 @@ def mex():
     h.stub_data.restype = C.c_void_p
     h.stub_data.argtypes = [C.c_void_p]
     h.stub_call.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    h.stub_struct.restype = C.c_void_p
+    h.stub_struct.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_char_p)]
+    h.stub_struct_set.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    h.stub_is_cell.argtypes = [C.c_void_p]
+    h.stub_cell_get.restype = C.c_void_p
+    h.stub_cell_get.argtypes = [C.c_void_p, C.c_size_t]
 
     class MexCallError(RuntimeError):
         pass
 
     def to_mx(v):
+        if isinstance(v, list) and v and isinstance(v[0], dict):     # a 1 x n struct array (fields: the union of the keys; missing = [])
+            names = sorted({k for d in v for k in d})
+            arr = (C.c_char_p * len(names))(*[k.encode() for k in names])
+            st = h.stub_struct(len(v), len(names), arr)
+            for i, d in enumerate(v):
+                for f, k in enumerate(names):
+                    if k in d and d[k] is not None:
+                        h.stub_struct_set(st, i, f, to_mx(d[k]))
+            return st
         if isinstance(v, str):
             return h.stub_string(v.encode())
         if isinstance(v, (bool, np.bool_)):
@@ -58,6 +73,12 @@ def mex():
         return h.stub_array(a.ndim, dims, a.ctypes.data_as(C.c_void_p), int(np.iscomplexobj(a)))
 
     def from_mx(p):
+        if h.stub_is_cell(p):
+            nd = h.stub_ndim(p)
+            dims = (C.c_size_t * nd)()
+            h.stub_dims(p, dims)
+            m, n = int(dims[0]), int(dims[1])
+            return [[from_mx(h.stub_cell_get(p, c * m + r)) for c in range(n)] for r in range(m)]    # column-major cells -> rows of a list
         nd = h.stub_ndim(p)
         dims = (C.c_size_t * nd)()
         h.stub_dims(p, dims)
@@ -101,6 +122,19 @@ def test_gateway_compiles_and_dispatches(mex):
         mex(2, "nothing", *([np.zeros((4, 4))] * 12))
     with pytest.raises(mex.Error, match="decode needs"):
         mex(1, "decode", np.zeros((4, 4)))
+    # 'jobs': the struct array is checked field by field before anything reaches the GPU
+    with pytest.raises(mex.Error, match="jobs needs a struct array"):
+        mex(1, "jobs", np.zeros((4, 4)))
+    h = np.zeros((8, 30))
+    ok = dict(kind="magls", hL=h, hR=h, hrirGridAziRad=np.zeros(30), hrirGridZenRad=np.zeros(30), order=1, fs=48000.0, len=16, shDefinition="real")
+    with pytest.raises(mex.Error, match=r"jobs\(2\).kind: unknown design kind 'nothing'"):
+        mex(1, "jobs", [ok, dict(ok, kind="nothing")])
+    with pytest.raises(mex.Error, match=r"jobs\(1\).order is missing"):
+        mex(1, "jobs", [{k: v for k, v in ok.items() if k != "order"}])
+    with pytest.raises(mex.Error, match=r"jobs\(1\).hrirGridZenRad must have 30 elements"):
+        mex(1, "jobs", [dict(ok, hrirGridZenRad=np.zeros(7))])
+    with pytest.raises(mex.Error, match=r"jobs\(1\).micRadius is missing"):
+        mex(1, "jobs", [dict(ok, kind="emagls2")])
 
 
 @pytest.fixture(scope="module")
@@ -167,3 +201,45 @@ def test_gateway_design_calls_match_the_python_binding(mex, grids, thin):
         warnings.simplefilter("ignore")
         ref = E.binauralDecode(sc, 48000, cL, cR, 48000)
     assert np.array_equal(out, ref) and imag.shape == (1, 2) and np.all(imag > 0)
+
+
+@pytest.mark.gpu
+def test_job_list_through_the_gateway(mex, grids, thin):
+    """emagls_mex('jobs', struct array) -- mex/designJobs.m -- against emagls_amd.jobs.JobList on the same list: 11 eMagLS designs on
+    their own HRIR sets (one chunk on the register-resident sweep), 3 eMagLS2 designs on different array radii, 2 MagLS designs, one
+    FromAtf design; the gateway marshals the struct fields into emagls_job records and allocates the cell array of outputs, the
+    scheduler behind both is the same: bit for bit."""
+    from emagls_amd import _lib as L, synth
+    from emagls_amd.jobs import JobList
+    hL, hR, azi, zen = thin["hL"], thin["hR"], thin["azi"], thin["zen"]
+    maz, mzn, r = grids["mic_azi"], grids["mic_zen"], grids["mic_radius"]
+    rng = np.random.default_rng(11)
+    sets = [(hL * (1.0 + 0.05 * rng.standard_normal()), hR * (1.0 + 0.05 * rng.standard_normal())) for _ in range(11)]
+    atf, aazi, azen = synth.glasses_atfs(natf=300, nmics=5, taps=48, fs=48000.0)
+    common = dict(hrirGridAziRad=azi, hrirGridZenRad=zen, fs=48000.0, len=128)
+    jobs = [dict(common, kind="emagls", hL=a, hR=b, micRadius=r, micGridAziRad=maz, micGridZenRad=mzn, order=4, shDefinition="complex") for a, b in sets]
+    radii = [0.0470, 0.0471, 0.0473]
+    jobs += [dict(common, kind="emagls2", hL=hL, hR=hR, micRadius=x, micGridAziRad=maz, micGridZenRad=mzn, order=4, shDefinition="real", simOrderPad=21) for x in radii]
+    jobs += [dict(common, kind="magls", hL=a, hR=b, order=3, shDefinition="real") for a, b in sets[:2]]
+    jobs += [dict(common, kind="fromatf", hL=hL, hR=hR, atfIrs=atf, atfGridAziRad=aazi + 0.01, atfGridZenRad=azen, fTrans=2000.0)]
+    W = mex(1, "jobs", jobs, 32, 4, False)[0]
+    assert len(W) == len(jobs) and all(len(row) == 2 for row in W)
+    jl = JobList()
+    for a, b in sets:
+        jl.add(L.KIND_EMAGLS, "complex", 4, 48000.0, 128, a, b, azi, zen, mic_radius=r, mic_azi=maz, mic_zen=mzn, out_shape=(128, 25, True))
+    for x in radii:
+        jl.add(L.KIND_EMAGLS2, "real", 4, 48000.0, 128, hL, hR, azi, zen, mic_radius=x, mic_azi=maz, mic_zen=mzn, sim_order_pad=21, out_shape=(128, 32, False))
+    for a, b in sets[:2]:
+        jl.add(L.KIND_MAGLS, "real", 3, 48000.0, 128, a, b, azi, zen, out_shape=(128, 16, False))
+    jl.add(L.KIND_FROM_ATF, "real", 0, 48000.0, 128, hL, hR, azi, zen, atf=atf, atf_azi=aazi + 0.01, atf_zen=azen, f_trans=2000.0, out_shape=(128, 5, False))
+    jl.run(batch_size=32, in_flight=4)
+    for j, ((gl, gr), (el, er)) in enumerate(zip(W, jl.results())):
+        assert gl.shape == el.shape and gl.dtype == el.dtype, j
+        assert np.array_equal(gl, el) and np.array_equal(gr, er), j
+    assert np.abs(W[0][0]).max() > 0 and np.abs(W[-1][1]).max() > 0
+    # HRIR sets on one geometry: the flag reaches the scheduler (bit-identical filters either way)
+    W2 = mex(1, "jobs", jobs[:11], 32, 4, True)[0]
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(W[:11], W2))
+    with pytest.raises(mex.Error, match="eMagLS:native.*len too short"):     # the library's message, forwarded
+        mex(1, "jobs", [dict(jobs[0], len=16)])
+    L.check(L.load().emagls_cache_clear())
