@@ -229,6 +229,15 @@ def pmc_traffic():
         return {}
 
 
+def _traffic_stale(pmc):
+    """True when the committed PMC passes were taken on other kernel sources than this run's (tools/csrc_hash.py)."""
+    try:
+        from tools.csrc_hash import stale
+        return bool(stale(pmc.get("csrc_sha16")))
+    except Exception:
+        return None
+
+
 def time_one_shot(lib, inputs, n=3):
     """The entry point the reference-side caller binds (the MEX shim calls emagls_get_emagls_filters with host arrays):
     cold = first call of the process for this shape, warm = later calls (plan cache inside the library)."""
@@ -483,6 +492,7 @@ def main():
                     "frac": tflops / 78.6 if synth else hbm_gbs / HBM_PEAK_GBS,
                     "busiest_resource": "FP64 vector pipe (peak: AMD's 78.6 TFLOP/s)" if synth else "HBM (8 TB/s)",
                     "traffic": traffic,
+                    "traffic_stale": (None if traffic is None else _traffic_stale(pmc)),
                     "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of build %s, commit %s, with %d designs per sweep launch; not "
                                        "measured in this run)" % (pmc.get("build", "?"), pmc.get("commit", "?"), int(pmc_designs))) if traffic is not None else None,
                     "hbm": {"algorithmic_bytes_per_launch": bytes_launch, "achieved_GBs": hbm_gbs, "frac_of_8TBs": hbm_gbs / HBM_PEAK_GBS},

@@ -572,9 +572,11 @@ void plan_setup(emagls_plan& p) {
     if (d.ndirs < 1 || d.nsamp < 1) throw Error(EMAGLS_ERR_ARG, "empty HRIR set");
     if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
     HIP_CHECK(hipGetDevice(&p.device));
+    const auto t_setup0 = std::chrono::steady_clock::now();
     p.stream = StreamPool::get().take();
     if (const char* ng = getenv("EMAGLS_NO_GRAPH")) p.use_graph = !(ng[0] == '1');
     for (auto& st : p.side) st = StreamPool::get().take();
+    const auto t_setup1 = std::chrono::steady_clock::now();
     if (const char* ns = getenv("EMAGLS_STREAMS")) p.nstreams = std::max(1, std::min(4, atoi(ns)));
     p.req_cplx = d.basis == EMAGLS_BASIS_COMPLEX;
     // Complex-basis eMagLS / eMagLS2 designs run in real arithmetic.  With Y_c = Y_r T (T unitary, block diagonal per order)
@@ -868,7 +870,14 @@ void plan_setup(emagls_plan& p) {
     p.out_cplx = p.req_cplx && d.kind != EMAGLS_KIND_FROM_ATF;
     p.alloc("wL", (p.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p.out_rows * p.out_cols);
     p.alloc("wR", (p.out_cplx ? sizeof(cplx) : sizeof(double)) * (size_t)p.out_rows * p.out_cols);
+    const auto t_setup2 = std::chrono::steady_clock::now();
     HIP_CHECK(hipStreamSynchronize(p.stream));
+    if (trace_on()) {
+        const auto t_setup3 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "emagls trace: plan setup: streams %.3f ms, %zu buffers in %zu slabs %.3f ms, final sync %.3f ms\n", ms(t_setup0, t_setup1), p.bufs.size(),
+                p.slabs.size(), ms(t_setup1, t_setup2), ms(t_setup2, t_setup3));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,127 @@
+"""GPU parity through the C ABI against the CPU oracle, tolerance 1e-6 relative complex error (BASELINE.json north_star), with the
+reference's own assertAllClose metrics (verifyEMagLs.m:370-395): getEMagLsFiltersEMAinCH / EMAinSH (lib/getEMagLsFiltersEMAinCH.m:52-113, lib/getEMagLsFiltersEMAinSH.m:66-143).
+(Split out of tests/test_gpu_parity.py in round 6 so that `-x` loses less.)"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import emagls_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def report(name, w, o):
+    nd, db, adb = O.assert_all_close_metrics(w, o)
+    print(f"{name}: norm_diff={nd:.3e} max_dB={db:.3e} max|dB|={adb:.3e}")
+    return nd
+
+
+@pytest.fixture(scope="module")
+def thin(grids, hrirs):
+    sub = slice(0, 2702, 3)
+    return dict(hL=hrirs[0][:, sub], hR=hrirs[1][:, sub], azi=grids["azi"][sub], zen=grids["zen"][sub])
+
+
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_emagls_ema_in_ch(thin, basis):
+    """getEMagLsFiltersEMAinCH: equatorial array of 16 microphones on a 4.2 cm sphere, order 4,
+    filters in the 9 circular harmonics.  Same per-bin kernel as eMagLS with pinv(CH(micAzi)) in front; the complex basis
+    exercises the CH conjugate rule of the epilogue."""
+    import emagls_amd as E
+    mic_azi = np.linspace(0.0, 2 * np.pi, 16, endpoint=False) + 0.1
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, mic_azi, 4, 48000.0, 128, basis)
+    wL, wR = E.getEMagLsFiltersEMAinCH(*args)
+    oL, oR = O.getEMagLsFiltersEMAinCH(*args)
+    assert wL.dtype == oL.dtype and wL.shape == (128, 9)
+    assert report("EMAinCH L " + basis, wL, oL) < TOL and report("EMAinCH R " + basis, wR, oR) < TOL
+    from emagls_amd._lib import EmaglsError
+    with pytest.raises(EmaglsError, match="fewer microphones"):
+        E.getEMagLsFiltersEMAinCH(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, mic_azi[:8], 4, 48000.0, 128, basis)
+
+
+def test_batch_of_ema_in_ch_designs(thin):
+    """Equatorial-array designs in a lane batch (odd channel count, 9): equal to the one-shot entry point."""
+    import emagls_amd as E
+    from emagls_amd import Batch, Plan, _lib as L
+    mazs = [np.linspace(0.0, 2 * np.pi, 12, endpoint=False) + 0.1 * (j + 1) for j in range(3)]
+    plans = []
+    for maz in mazs:
+        p = Plan(L.KIND_EMA_CH, "complex", 4, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], 0.042, 12)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(maz)
+        p.set_hrirs(thin["hL"], thin["hR"])
+        plans.append(p)
+    b = Batch(plans)
+    for it in range(2):
+        b.execute()
+        res = b.get_filters()
+    for (wL, wR), maz in zip(res, mazs):
+        sL, sR = E.getEMagLsFiltersEMAinCH(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, 4, 48000.0, 128, "complex")
+        assert wL.shape == (128, 9) and rel(wL, sL) < 1e-12 and rel(wR, sR) < 1e-12
+    b.close()
+    for p in plans:
+        p.close()
+
+
+@pytest.mark.parametrize("basis,nmics", [("real", 16), ("complex", 16), ("real", 9)])
+def test_emagls_ema_in_sh(thin, basis, nmics):
+    """getEMagLsFiltersEMAinSH (second half): equatorial array on a 4.2 cm sphere, order 4, filters in the
+    25 spherical harmonics.  Horizontal-projection order terms rotated per direction, Gram route for every bin (the model has
+    no radial terms: cond(pwGrid) < 1e3 at every bin)."""
+    import emagls_amd as E
+    mic_azi = np.linspace(0.0, 2 * np.pi, nmics, endpoint=False) + 0.1
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, mic_azi, 4, 48000.0, 128, basis)
+    wL, wR = E.getEMagLsFiltersEMAinSH(*args)
+    oL, oR = O.getEMagLsFiltersEMAinSH(*args)
+    assert wL.dtype == oL.dtype and wL.shape == (128, 25)
+    assert report("EMAinSH L " + basis, wL, oL) < TOL and report("EMAinSH R " + basis, wR, oR) < TOL
+    from emagls_amd._lib import EmaglsError
+    with pytest.raises(EmaglsError, match="fewer microphones"):
+        E.getEMagLsFiltersEMAinSH(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, mic_azi[:8], 4, 48000.0, 128, basis)
+
+
+def test_emagls_ema_in_sh_low_order_and_horizontal_directions(thin):
+    """Order 2 on a grid that contains directions exactly on the horizon (the reference leaves those unrotated, EMAinSH.m:92)."""
+    import emagls_amd as E
+    azi, zen = thin["azi"].copy(), thin["zen"].copy()
+    zen[::7] = np.pi / 2
+    mic_azi = np.linspace(0.0, 2 * np.pi, 12, endpoint=False)
+    args = (thin["hL"], thin["hR"], azi, zen, 0.05, mic_azi, 2, 48000.0, 256, "real")
+    wL, wR = E.getEMagLsFiltersEMAinSH(*args)
+    oL, oR = O.getEMagLsFiltersEMAinSH(*args)
+    assert wL.shape == (256, 9)
+    assert report("EMAinSH N=2 L", wL, oL) < TOL and report("EMAinSH N=2 R", wR, oR) < TOL
+
+
+def test_batch_of_ema_in_sh_designs_on_a_caller_stream(thin):
+    """EMAinSH designs in a lane batch that runs on a stream the caller created (emagls_batch_set_stream): equal to the
+    one-shot entry point; three executes (eager, capture, replay)."""
+    import torch
+    import emagls_amd as E
+    from emagls_amd import Batch, Plan, _lib as L
+    st = torch.cuda.Stream()
+    mazs = [np.linspace(0.0, 2 * np.pi, 12, endpoint=False) + 0.1 * (j + 1) for j in range(3)]
+    plans = []
+    for maz in mazs:
+        p = Plan(L.KIND_EMA_SH, "real", 3, 48000.0, 128, thin["hL"].shape[0], thin["hL"].shape[1], 0.042, 12)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_mic_grid(maz)
+        p.set_hrirs(thin["hL"], thin["hR"])
+        plans.append(p)
+    b = Batch(plans)
+    b.set_stream(st.cuda_stream)
+    for it in range(3):
+        b.execute()
+        res = b.get_filters()
+    for (wL, wR), maz in zip(res, mazs):
+        sL, sR = E.getEMagLsFiltersEMAinSH(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, 3, 48000.0, 128, "real")
+        assert wL.shape == (128, 16) and rel(wL, sL) < 1e-12 and rel(wR, sR) < 1e-12
+    b.close()
+    for p in plans:
+        p.close()

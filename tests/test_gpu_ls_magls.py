@@ -1,0 +1,238 @@
+"""GPU parity through the C ABI against the CPU oracle, tolerance 1e-6 relative complex error (BASELINE.json north_star), with the
+reference's own assertAllClose metrics (verifyEMagLs.m:370-395): getLsFilters / getMagLsFilters (lib/getLsFilters.m:30-34, lib/getMagLsFilters.m:30-98): BASELINE configs 1 and 2, SH orders 5-7, the covariance constraint, batches of HRIR sets.
+(Split out of tests/test_gpu_parity.py in round 6 so that `-x` loses less.)"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import emagls_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def report(name, w, o):
+    nd, db, adb = O.assert_all_close_metrics(w, o)
+    print(f"{name}: norm_diff={nd:.3e} max_dB={db:.3e} max|dB|={adb:.3e}")
+    return nd
+
+
+@pytest.fixture(scope="module")
+def thin(grids, hrirs):
+    sub = slice(0, 2702, 3)
+    return dict(hL=hrirs[0][:, sub], hR=hrirs[1][:, sub], azi=grids["azi"][sub], zen=grids["zen"][sub])
+
+
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_ls_filters_config1(grids, hrirs, basis):
+    import emagls_amd as E
+    wL, wR = E.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, basis)
+    oL, oR = O.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, basis)
+    assert wL.shape == (128, 25) and wL.dtype == oL.dtype
+    assert report("LS L " + basis, wL, oL) < 1e-12 and report("LS R " + basis, wR, oR) < 1e-12
+
+
+def test_ls_golden_surrogate(golden, grids):
+    """The reference's golden LS filters are reproduced from the surrogate input h = wLs Y^H."""
+    import emagls_amd as E
+    d = np.column_stack([grids["azi"], grids["zen"]])
+    for basis in ("real", "complex"):
+        Yc = O.getSH(4, d, basis).conj().T
+        gL, gR = golden[f"{basis}_LS/wLsL"], golden[f"{basis}_LS/wLsR"]
+        hL, hR = gL @ Yc, gR @ Yc
+        if basis == "complex":
+            continue  # complex surrogate HRIRs are outside the real-input ABI
+        wL, wR = E.getLsFilters(hL, hR, grids["azi"], grids["zen"], 4, basis)
+        assert rel(wL, gL) < 1e-11 and rel(wR, gR) < 1e-11
+
+
+@pytest.mark.parametrize("basis", ["real", "complex"])
+def test_magls_filters_config2(grids, hrirs, basis):
+    import emagls_amd as E
+    wL, wR = E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 512, basis)
+    oL, oR = O.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 512, basis)
+    assert wL.shape == (512, 25) and wL.dtype == oL.dtype
+    assert report("MagLS L " + basis, wL, oL) < TOL and report("MagLS R " + basis, wR, oR) < TOL
+
+
+@pytest.mark.parametrize("order,basis", [(5, "real"), (7, "real"), (6, "complex"), (7, "complex")])
+def test_ls_and_magls_orders_5_to_7(grids, hrirs, order, basis):
+    """SH orders above 4 (lib/getMagLsFilters.m:45-48 takes any order; 36..64 channels): the plain path for more than 32
+    channels -- pinv(Y_conj) from the inverse of the SH Gram matrix (the 2702-point grid is well conditioned up to order 7 and
+    far beyond: certified on the device), one sweep launch per bin -- against the oracle at full size."""
+    import emagls_amd as E
+    C = (order + 1) ** 2
+    wL, wR = E.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, basis)
+    oL, oR = O.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, basis)
+    assert wL.shape == (128, C) and wL.dtype == oL.dtype
+    assert report(f"LS order {order} {basis} L", wL, oL) < 1e-11 and report("R", wR, oR) < 1e-11
+    wL, wR = E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, 48000.0, 256, basis)
+    oL, oR = O.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, 48000.0, 256, basis)
+    assert wL.shape == (256, C) and wL.dtype == oL.dtype
+    assert report(f"MagLS order {order} {basis} L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
+def test_wide_orders_refuse_what_they_cannot_do(grids, hrirs, thin):
+    import emagls_amd as E
+    from emagls_amd._lib import EmaglsError
+    with pytest.raises(EmaglsError, match="order above 7"):
+        E.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 8, "real")
+    # an order the grid cannot resolve well: 49 SH channels on 60 directions of a polar cap -> the certificate (or the Cholesky
+    # pivot) refuses instead of returning garbage
+    from emagls_amd import synth
+    azi, zen = synth.fibonacci_grid(60)
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen * 0.3, taps=32)
+    with pytest.raises(EmaglsError):
+        E.getLsFilters(hL, hR, azi, zen * 0.3, 6, "real")
+
+
+def test_magls_filters_config2_with_the_covariance_constraint(grids, hrirs):
+    """BASELINE config 2 as named -- getMagLsFilters N=4, full L2702 grid, 512 taps, covariance constraint ON -- at full size
+    against the oracle's specification of the constraint (the Hermitian positive definite 2x2 ear mixing with M Rhat M = R;
+    own specification: the reference's implementation was removed from the snapshot and its *_wDC fixture pins this form for
+    eMagLS / eMagLS2 only)."""
+    import emagls_amd as E
+    args = (hrirs[0], hrirs[1], grids["azi"], grids["zen"], 4, 48000.0, 512, "real")
+    wL, wR = E.getMagLsFilters(*args, applyDiffusenessConst=True)
+    oL, oR = O.getMagLsFilters(*args, applyDiffusenessConst=True)
+    uL, uR = E.getMagLsFilters(*args)
+    assert wL.shape == (512, 25)
+    assert report("MagLS + covariance constraint, config 2 full size L", wL, oL) < TOL and report("R", wR, oR) < TOL
+    assert 1e-3 < rel(wL, uL) < 0.5      # the constraint does something
+
+
+@pytest.mark.parametrize("two_d", [False, True])
+def test_magls_batches(grids, thin, two_d):
+    """MagLS / MagLS-2D plans in a batch (getMagLsFilters in a loop over HRIR sets): one resident sweep launch for all designs
+    instead of one per design; with Batch.share_geometry() the SH side (basis, Cholesky factor, pinv, the sweep's operands) is
+    computed once for sets on one grid.  Same filters as the single designs in both forms; sets on different grids run
+    unshared; orders above 4 (the plain path) stay out of batches."""
+    from emagls_amd import Batch, Plan, _lib as L
+    from emagls_amd._lib import EmaglsError
+    rng = np.random.default_rng(41)
+    if two_d:
+        azi = np.sort(np.mod(np.linspace(0, 2 * np.pi, 360, endpoint=False) + 0.002 * rng.standard_normal(360), 2 * np.pi))
+        from emagls_amd import synth
+        base = synth.rigid_sphere_hrirs(azi, np.full(360, np.pi / 2))
+        zen, K, order = None, L.KIND_MAGLS_2D, 6
+    else:
+        azi, zen, base, K, order = thin["azi"], thin["zen"], (thin["hL"], thin["hR"]), L.KIND_MAGLS, 4
+    plans, singles = [], []
+    for j in range(7):
+        hL = base[0] * (1.0 + 0.06 * j) + 1e-3 * rng.standard_normal(base[0].shape)
+        hR = base[1] * (1.0 - 0.04 * j) + 1e-3 * rng.standard_normal(base[1].shape)
+        p = Plan(K, "complex", order, 48000.0, 128, hL.shape[0], hL.shape[1], 0.0, 0)
+        p.set_hrir_grid(azi, zen)
+        p.set_hrirs(hL, hR)
+        p.execute()
+        singles.append(p.get_filters())
+        plans.append(p)
+    b = Batch(plans)
+    outs = {}
+    for share in (False, True):
+        b.share_geometry(share)
+        for it in range(3):
+            b.execute()
+            got = b.get_filters()
+            assert b.shares_geometry() == share and plans[3].info().num_sweep_launches == 1
+            if it:
+                assert all(np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) for a, c in zip(got, outs[share]))
+            outs[share] = got
+        worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(outs[share], singles))
+        print(f"{'MagLS-2D' if two_d else 'MagLS'} batch of 7, geometry shared = {share}: worst rel vs single designs = {worst:.3e}")
+        assert worst < 1e-12
+    assert rel(singles[0][0], singles[4][0]) > 1e-3
+    # one set moves to another grid: the batch still runs (unshared) and follows
+    plans[5].set_hrir_grid(np.mod(azi + 0.01, 2 * np.pi), zen)
+    b.execute()
+    assert not b.shares_geometry()
+    moved = b.get_filters()
+    plans[5].execute()
+    ref5 = plans[5].get_filters()
+    assert max(rel(moved[5][0], ref5[0]), rel(moved[5][1], ref5[1])) < 1e-12 and rel(moved[0][0], singles[0][0]) < 1e-12
+    assert rel(moved[5][0], singles[5][0]) > 1e-6
+    b.close()
+    if not two_d:
+        wide = Plan(L.KIND_MAGLS, "real", 5, 48000.0, 128, base[0].shape[0], base[0].shape[1], 0.0, 0)
+        with pytest.raises(EmaglsError, match="more than 32 channels"):
+            Batch([wide, wide])
+        wide.close()
+    for p in plans:
+        p.close()
+
+
+def test_ls_batches(thin):
+    """getLsFilters in a loop over HRIR sets: LS plans in a batch, pinv(Y) once for sets on one grid (Batch.share_geometry)."""
+    from emagls_amd import Batch, Plan, _lib as L
+    rng = np.random.default_rng(43)
+    plans, singles = [], []
+    for j in range(5):
+        hL = thin["hL"] * (1.0 + 0.1 * j) + 1e-3 * rng.standard_normal(thin["hL"].shape)
+        p = Plan(L.KIND_LS, "real", 4, 48000.0, thin["hL"].shape[0], hL.shape[0], hL.shape[1], 0.0, 0)
+        p.set_hrir_grid(thin["azi"], thin["zen"])
+        p.set_hrirs(hL, thin["hR"])
+        p.execute()
+        singles.append(p.get_filters())
+        plans.append(p)
+    b = Batch(plans)
+    for share in (False, True):
+        b.share_geometry(share)
+        b.execute()
+        out = b.get_filters()
+        assert b.shares_geometry() == share
+        worst = max(max(rel(o[0], s_[0]), rel(o[1], s_[1])) for o, s_ in zip(out, singles))
+        print(f"LS batch of 5, geometry shared = {share}: worst rel vs single designs = {worst:.3e}")
+        assert worst < 1e-13
+    assert rel(singles[0][0], singles[3][0]) > 1e-3
+    b.close()
+    for p in plans:
+        p.close()
+
+
+def test_magls_ill_conditioned_basis_falls_back_for_one_call_only(thin):
+    """MagLS on the persistent sweep uses M = R^-1 R^-H.  A grid on which the order-4 basis is nearly rank deficient (all
+    directions in a thin band about the equator: diagonal of R spans 1e6, Gram matrix still positive definite) raises status word 4 -- a word of its own, not the sweep's
+    residency time-out -- the call is served by the launch-per-bin sweep, and the SAME plan (what a cached one-shot plan is)
+    goes back to the persistent sweep on the next, well-conditioned grid."""
+    from emagls_amd import Plan, _lib as L
+    from emagls_amd import synth
+    n = thin["hL"].shape[1]
+    azi, zen = synth.fibonacci_grid(n)
+    p = Plan(L.KIND_MAGLS, "real", 4, 48000.0, 128, thin["hL"].shape[0], n)
+    p.set_hrirs(thin["hL"], thin["hR"])
+    p.set_hrir_grid(azi, np.pi / 2 + (zen - np.pi / 2) * 0.023)   # an equatorial band: cos-odd harmonics nearly coincide
+    p.execute()
+    wL, wR = p.get_filters()
+    assert p.info().num_sweep_launches > 1 and np.isfinite(wL).all() and np.isfinite(wR).all()
+    p.set_hrir_grid(thin["azi"], thin["zen"])
+    for _ in range(3):
+        p.execute()
+        wL, wR = p.get_filters()
+        assert p.info().num_sweep_launches == 1
+    p.close()
+    oL, oR = O.getMagLsFilters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 4, 48000.0, 128, "real")
+    assert report("MagLS after a fallback call L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
+@pytest.mark.parametrize("fn,order,nmics,basis", [("getMagLsFilters", 6, 0, "real"), ("getMagLsFilters", 5, 0, "complex"),
+                                                  ("getEMagLs2Filters", 4, 48, "real"), ("getEMagLsFilters", 6, 64, "real")])
+def test_covariance_constraint_above_32_channels(thin, fn, order, nmics, basis):
+    """The covariance constraint (own specification) on the 33..64-channel paths (round 3 refused it there):
+    the 2 x 2 correction per bin only needs the rendered HRTFs W G_k of the design, whatever its width."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    if fn == "getMagLsFilters":
+        args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], order, 48000.0, 128, basis)
+    else:
+        maz, mzn = synth.fibonacci_grid(nmics)
+        args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, order, 48000.0, 128, basis)
+    wL, wR = getattr(E, fn)(*args, applyDiffusenessConst=True)
+    oL, oR = getattr(O, fn)(*args, applyDiffusenessConst=True)
+    uL, _ = getattr(E, fn)(*args)
+    assert report(f"{fn} N={order} {nmics} mics {basis} with the covariance constraint L", wL, oL) < TOL and report("R", wR, oR) < TOL
+    assert rel(wL, uL) > 1e-4      # (the constraint did something)

@@ -74,16 +74,21 @@ def test_timed_kernel_at_full_size(grids, sets, oracle_filters, monkeypatch, n):
             assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(runs[0], later))
         got[spread] = runs[0]
     L.check(lib.emagls_cache_clear())
+    # every placement against the oracle (a placement changes the waves per workgroup, hence the workgroups of a design and the
+    # grouping of the partial sums: 20 designs run 11 workgroups of 8 waves spread over all XCDs, 9 of 10 waves inside one XCD)
     worst = 0.0
-    for j in CHECKED:
-        if j >= n:
-            continue
-        oL, oR = oracle_filters[j]
-        e = max(rel(got["2"][j][0], oL), rel(got["2"][j][1], oR))
-        nd, db, adb = O.assert_all_close_metrics(np.hstack(got["2"][j]), np.hstack([oL, oR]))
-        print(f"emagls_jobs_run, {n} config-3 designs at full size, design {j}: rel = {e:.3e}, normalised max abs diff = {nd:.3e}, max |dB| = {adb:.2e}")
-        worst = max(worst, e)
+    for spread in got:
+        for j in CHECKED:
+            if j >= n:
+                continue
+            oL, oR = oracle_filters[j]
+            e = max(rel(got[spread][j][0], oL), rel(got[spread][j][1], oR))
+            nd, db, adb = O.assert_all_close_metrics(np.hstack(got[spread][j]), np.hstack([oL, oR]))
+            if spread == "2":
+                print(f"emagls_jobs_run, {n} config-3 designs at full size, design {j}: rel = {e:.3e}, normalised max abs diff = {nd:.3e}, max |dB| = {adb:.2e}")
+            worst = max(worst, e)
     assert worst < TOL
-    # the partial sums are added in workgroup order whatever the placement: the same filters bit for bit
-    for other in ("0", "1"):
-        assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got["2"], got[other])), other
+    # between the placements: the same operand values, another order of the partial sums
+    between = max(max(rel(a[0], b[0]), rel(a[1], b[1])) for other in ("0", "1") for a, b in zip(got["2"], got[other]))
+    print(f"emagls_jobs_run, {n} designs: placements of the sweep launch against each other: worst rel = {between:.2e}")
+    assert between < 1e-10

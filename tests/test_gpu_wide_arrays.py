@@ -57,3 +57,86 @@ def test_low_bins_against_40_digit_rows(nmics):
     assert worst_oracle > 1e3 * worst_gpu          # ... and the oracle's own arithmetic is what the filter-level distance measures
     # the filters differ from the oracle's by the oracle's own error in those two rows, weighted by their share of the spectrum
     assert e_filters < (1e-6 if nmics <= 36 else 3e-5)
+
+
+TOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def report(name, w, o):
+    nd, db, adb = O.assert_all_close_metrics(w, o)
+    print(f"{name}: norm_diff={nd:.3e} max_dB={db:.3e} max|dB|={adb:.3e}")
+    return nd
+
+
+@pytest.fixture(scope="module")
+def thin(grids, hrirs):
+    sub = slice(0, 2702, 3)
+    return dict(hL=hrirs[0][:, sub], hR=hrirs[1][:, sub], azi=grids["azi"][sub], zen=grids["zen"][sub])
+
+
+# ---- eMagLS / eMagLS2 with 33..64 channels against the FP64 oracle (from tests/test_gpu_parity.py, round 4)
+@pytest.mark.parametrize("fn,order,nmics,basis", [("getEMagLs2Filters", 4, 64, "real"), ("getEMagLs2Filters", 4, 48, "complex"),
+                                                  ("getEMagLsFilters", 6, 64, "real"), ("getEMagLsFilters", 5, 64, "complex"),
+                                                  ("getEMagLsFilters", 7, 64, "real")])
+def test_arrays_with_more_than_32_channels(thin, fn, order, nmics, basis):
+    """A 64-capsule array (lib/getEMagLs2Filters.m:66 takes any microphone count; SH-domain designs of order 5..7 need 36..64
+    microphones): 33..64 channels run on the plain S-space path of wide_array.hip -- Householder QR + one-sided Jacobi of every
+    bin's S x C matrix in global memory / LDS, Y_reg_inv of every bin materialised, one sweep launch per bin."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    maz, mzn = synth.fibonacci_grid(nmics)
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, order, 48000.0, 128, basis)
+    wL, wR = getattr(E, fn)(*args)
+    oL, oR = getattr(O, fn)(*args)
+    C = nmics if fn == "getEMagLs2Filters" else (order + 1) ** 2
+    assert wL.shape == (128, C) and wL.dtype == oL.dtype
+    assert report(f"{fn} N={order} {nmics} mics {basis} L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
+def test_wide_array_at_8_cm(grids):
+    """The 64-capsule array at r = 8 cm (simulation order 35, 1296 simulated SH channels; round 3 stopped at 5.9 cm) on the full
+    2702-point grid against the oracle."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    hL, hR = synth.rigid_sphere_hrirs(grids["azi"], grids["zen"], taps=64)
+    maz, mzn = synth.fibonacci_grid(64)
+    args = (hL, hR, grids["azi"], grids["zen"], 0.08, maz, mzn, 4, 48000.0, 128, "real")
+    wL, wR = E.getEMagLs2Filters(*args)
+    # (the oracle needs 35 s for it: its output is a stored vector, tests/golden/make_oracle_vectors.py, same seeded inputs)
+    vec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
+    oL, oR = vec["wide64_r80mm_len128/wL"], vec["wide64_r80mm_len128/wR"]
+    assert report("getEMagLs2Filters 64 mics r = 8 cm L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
+def test_wide_array_kernel_forms_agree(thin, monkeypatch):
+    """The 33..64-channel path's round-4 kernels (Householder QR and back-transform with the columns in registers, Y_reg_inv_k on
+    the FP64 matrix cores) against the forms they replace (EMAGLS_WA_REG=0, EMAGLS_WA_YRI_MFMA=0: columns walked through L2, scalar
+    product) on a 64-microphone design."""
+    import emagls_amd as E
+    from emagls_amd import synth
+    maz, mzn = synth.fibonacci_grid(64)
+    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128, "real")
+    wL, wR = E.getEMagLs2Filters(*args)
+    monkeypatch.setenv("EMAGLS_WA_REG", "0")
+    monkeypatch.setenv("EMAGLS_WA_YRI_MFMA", "0")
+    vL, vR = E.getEMagLs2Filters(*args)
+    print(f"64 microphones, register / MFMA forms vs the plain ones: rel = {max(rel(wL, vL), rel(wR, vR)):.3e}")
+    assert rel(wL, vL) < 1e-8 and rel(wR, vR) < 1e-8
+
+
+def test_wide_arrays_refuse_what_they_cannot_do(thin):
+    import emagls_amd as E
+    from emagls_amd import synth
+    from emagls_amd._lib import EmaglsError
+    maz, mzn = synth.fibonacci_grid(80)
+    with pytest.raises(EmaglsError, match="more than 64"):
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, maz, mzn, 4, 48000.0, 128)
+    maz, mzn = synth.fibonacci_grid(64)
+    with pytest.raises(EmaglsError, match="simulation order above 85"):
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.20, maz, mzn, 4, 48000.0, 128)
+    with pytest.raises(EmaglsError, match="fewer HRIR directions than simulated SH channels"):   # (8 cm: 36^2 = 1296 channels, 901 directions)
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.08, maz, mzn, 4, 48000.0, 128)

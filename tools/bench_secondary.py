@@ -28,14 +28,22 @@ def _grids():
     return azi, zen, maz, mzn
 
 
+def _csrc_now():
+    from tools.csrc_hash import csrc_sha16
+    return csrc_sha16()
+
+
 def _roofline(workload, ms_per_execute, compulsory_bytes, note):
     """`roofline` block of a secondary workload: its time per execute (measured here) against the HBM bytes one execute moves
     (PMC passes of the same workload, profiles/secondary_traffic.json -- written by tools/secondary_traffic.py from
     tools/experiments/secondary_prof.sh) and against the bytes it has to move at least (inputs once in, filters once out)."""
     path = os.path.join(ROOT, "profiles", "secondary_traffic.json")
-    t = {}
+    t, stale = {}, None
     try:
-        t = json.load(open(path)).get(workload, {})
+        allw = json.load(open(path))
+        t = allw.get(workload, {})
+        from tools.csrc_hash import stale as _stale
+        stale = _stale(allw.get("csrc_sha16"))     # the PMC passes were taken on other kernel sources than this run's
     except Exception:
         pass
     sec = ms_per_execute * 1e-3
@@ -46,6 +54,9 @@ def _roofline(workload, ms_per_execute, compulsory_bytes, note):
            "frac": round(traffic / sec / 1e9 / 8000.0, 4) if traffic else None,
            "traffic_over_compulsory": round(traffic / compulsory_bytes, 2) if traffic else None,
            "kernel_time_us_per_execute": t.get("kernel_time_us_per_execute"), "dominant_kernel": t.get("dominant_kernel"), "note": note}
+    if traffic is not None:
+        out["stale"] = bool(stale)
+        out["traffic_source"] = "profiles/secondary_traffic.json (PMC passes on kernel sources %s; this run's: %s)" % (allw.get("csrc_sha16", "unstamped"), _csrc_now())
     return out
 
 

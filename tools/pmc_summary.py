@@ -16,6 +16,9 @@ import subprocess
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.csrc_hash import csrc_sha16 as _csrc_sha16  # noqa: E402
+
 
 def demangle(n):
     try:
@@ -87,7 +90,7 @@ def main():
             merged[k].update(cs)
     res = {"note": "means per dispatch from separate rocprofv3 --pmc passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE "
                    "doubled per the gfx950 correction of MI355X_MICROARCH.md; WRITE_SIZE matched the algorithmic bytes on sh_basis_kernel)",
-           "designs_per_launch": LANES, "designs_per_sweep_launch": SWEEP_DESIGNS, "build": os.environ.get("EMAGLS_BUILD_TAG", "?")}
+           "designs_per_launch": LANES, "designs_per_sweep_launch": SWEEP_DESIGNS, "build": os.environ.get("EMAGLS_BUILD_TAG", "?"), "csrc_sha16": _csrc_sha16()}
     per_set = 0.0
     sweep_set = 0.0
     rows = []

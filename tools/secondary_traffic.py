@@ -7,6 +7,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools.csrc_hash import csrc_sha16  # noqa: E402
 # workload -> (executes of the profiled command, designs per execute)
 WORKLOADS = {"decode_real": (6, 1), "decode_complex": (6, 1), "shbasis": (6, 1), "config4_r5cm": (6, 8), "config4_r10cm": (6, 8),
              "config4_r2cm": (6, 8), "config5_batch": (6, 8), "config5_single": (6, 1), "config3_batch": (6, 8)}
@@ -16,7 +18,9 @@ def main():
     tag = sys.argv[1]
     out = {"note": "HBM bytes per execute = sum over kernels of (2 x FETCH_SIZE + WRITE_SIZE) x 1024 x dispatches / executes of the profiled "
                    "command (tools/experiments/secondary_prof.sh; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)",
-           "source": tag}
+           "source": tag, "csrc_sha16": csrc_sha16(),
+           "stamp_note": "csrc_sha16: sha256 over emagls_amd/csrc at the time of the profile (tools/csrc_hash.py); tools/bench_secondary.py marks the "
+                         "blocks stale when the tree's differs"}
     for w, (nexec, designs) in WORKLOADS.items():
         path = os.path.join(ROOT, "gpurun_out", f"{tag}_{w}.json")
         if not os.path.exists(path):
