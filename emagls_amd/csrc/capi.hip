@@ -159,12 +159,15 @@ struct emagls_plan {
     // batch has moved every buffer into its arena.
     struct Slab { char* base; size_t size, used; };
     std::vector<Slab> slabs;
+    bool slab_zeroed = false;      // the newest slab was zero-filled when it was taken
     static constexpr size_t SLAB_BYTES = (size_t)32 << 20;
     void* slab_take(size_t bytes) {
         bytes = (bytes + 255) / 256 * 256;
         if (slabs.empty() || slabs.back().used + bytes > slabs.back().size) {
             Slab sl{nullptr, (std::max(bytes, SLAB_BYTES) + SLAB_BYTES - 1) / SLAB_BYTES * SLAB_BYTES, 0};
             sl.base = static_cast<char*>(BlockPool::get().take(sl.size, &sl.size));
+            // (one fill per slab instead of one per buffer: 66 hipMemsetAsync calls were 1.9 ms of a plan's set-up)
+            if (hipMemsetAsync(sl.base, 0, sl.size, stream) != hipSuccess) { (void)hipGetLastError(); slab_zeroed = false; } else slab_zeroed = true;
             slabs.push_back(sl);
         }
         void* p = slabs.back().base + slabs.back().used;
@@ -236,7 +239,9 @@ struct emagls_plan {
     int stage_order = 0;          // order of the stages before the sweep (emagls_pre_sweep): 0 branches, 1 / 2 the complementary single-stream orders of lane groups
     hipStream_t sync_stream = nullptr;  // stream whose completion means this plan's results are ready
     // fork/join inside one design: independent branches run on side streams (captured into the same graph)
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // taken from the pool when a multi-stream execute first needs them (need_sides)
+    bool owns_stream = true;      // false: `stream` belongs to the job slot that created the plan (one stream for all plans of a chunk)
+    void need_sides(int n) { for (int i = 0; i < n - 1 && i < 3; ++i) if (!side[i]) side[i] = StreamPool::get().take(); }
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
     hipEvent_t next_sync_event() {
@@ -272,7 +277,7 @@ struct emagls_plan {
         if (graph) hipGraphDestroy(graph);
         if (pre_exec) hipGraphExecDestroy(pre_exec);
         if (pre_graph) hipGraphDestroy(pre_graph);
-        StreamPool::get().give(stream);
+        if (owns_stream) StreamPool::get().give(stream);
     }
     void* alloc(const std::string& name, size_t bytes, bool zero = true) {
         if (bytes == 0) bytes = 16;
@@ -289,8 +294,8 @@ struct emagls_plan {
         DevBuf b;
         b.p = slab_take((bytes + 15) / 16 * 16);  // (launch_zero works on whole 8-byte words)
         b.bytes = bytes;
-        b.owned = false;   // (part of a slab)
-        if (zero) HIP_CHECK(hipMemsetAsync(b.p, 0, bytes, stream));
+        b.owned = false;   // (part of a slab, zero-filled when the slab was taken)
+        if (zero && !slab_zeroed) HIP_CHECK(hipMemsetAsync(b.p, 0, bytes, stream));
         bufs[name] = b;
         total_bytes += (int64_t)bytes;
         return b.p;
@@ -565,6 +570,7 @@ void plan_alloc_routes(emagls_plan& p) {
     }
 }
 
+thread_local hipStream_t g_plan_stream_shared = nullptr;   // set by the job scheduler around the creation of a chunk's plans
 void plan_setup(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     if (d.kind < EMAGLS_KIND_LS || d.kind > EMAGLS_KIND_EMA_SH) throw Error(EMAGLS_ERR_ARG, "unknown design kind");
@@ -573,9 +579,11 @@ void plan_setup(emagls_plan& p) {
     if (d.kind != EMAGLS_KIND_FROM_ATF && d.order < 0) throw Error(EMAGLS_ERR_ARG, "negative SH order");
     HIP_CHECK(hipGetDevice(&p.device));
     const auto t_setup0 = std::chrono::steady_clock::now();
-    p.stream = StreamPool::get().take();
+    // (the plans of a job chunk share the slot's stream -- hipStreamCreate was 3 ms of a plan's set-up, four streams each --; the side
+    // streams of a multi-stream execute are taken when one first asks for them)
+    if (g_plan_stream_shared) { p.stream = g_plan_stream_shared; p.owns_stream = false; }
+    else p.stream = StreamPool::get().take();
     if (const char* ng = getenv("EMAGLS_NO_GRAPH")) p.use_graph = !(ng[0] == '1');
-    for (auto& st : p.side) st = StreamPool::get().take();
     const auto t_setup1 = std::chrono::steady_clock::now();
     if (const char* ns = getenv("EMAGLS_STREAMS")) p.nstreams = std::max(1, std::min(4, atoi(ns)));
     p.req_cplx = d.basis == EMAGLS_BASIS_COMPLEX;
@@ -1161,6 +1169,7 @@ void emagls_pre_sweep(emagls_plan& p) {
     const int ldM = round_up(M, 64);
     // side streams shorten one design's critical path; with several designs in flight they only add queue
     // contention, so a plan can be restricted to its main stream (emagls_plan_set_streams / EMAGLS_STREAMS=1)
+    if (p.nstreams >= 2) p.need_sides(p.nstreams);   // (no-op for a lane group: batch_lanes_part lends the batch's streams)
     hipStream_t s0 = p.stream, s1 = p.nstreams >= 2 ? p.side[0] : s0, s2 = p.nstreams >= 3 ? p.side[1] : s0;
     hipStream_t s3 = p.nstreams >= 4 ? p.side[2] : s0;   // the Gram route of the per-bin factors (needs Gy, E, b_n; not the Cholesky factor)
     const int nOrd = p.simOrder + 1;
@@ -1899,6 +1908,7 @@ void plan_execute(emagls_plan& p) {
             throw Error(EMAGLS_ERR_ARG, "microphone grid must be set before execute");
     }
     if (d.kind == EMAGLS_KIND_FROM_ATF && !p.have_atfs) throw Error(EMAGLS_ERR_ARG, "ATFs must be set before execute");
+    if (p.nstreams >= 2) p.need_sides(p.nstreams);   // (before any capture begins)
     const bool persist = d.kind != EMAGLS_KIND_LS && p.sweep_persist;
     if (p.prof_level == 0 && p.use_graph && persist) {
         // the persistent sweep is launched directly (SweepChain); the stages before it are captured from the second
@@ -3999,9 +4009,11 @@ struct JobSlot {
     std::vector<std::vector<double>> grids;   // per plan: hrir azi | zen | mic azi | zen as last uploaded (unchanged grids are not uploaded again)
     uint64_t last_use = 0;
     int runs = 0;                             // executes so far (the first two are the eager run and the graph capture)
+    hipStream_t stream = nullptr;             // the plans' common stream (uploads, and the executes of designs that run plan by plan)
     ~JobSlot() {
         if (batch) emagls_batch_destroy(batch);
         for (auto* p : plans) emagls_plan_destroy(p);
+        if (stream) emagls::pool_stream_give(stream);   // (synchronised there)
     }
 };
 std::mutex g_jobs_mu;
@@ -4070,6 +4082,8 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
         slot.reset(new JobSlot);
         slot->key = key; slot->device = device;
         slot->grids.resize((size_t)n);
+        slot->stream = emagls::pool_stream_take();
+        struct SharedStream { SharedStream(hipStream_t st) { g_plan_stream_shared = st; } ~SharedStream() { g_plan_stream_shared = nullptr; } } shared_stream(slot->stream);
         for (int j = 0; j < n; ++j) {
             emagls_plan* p = nullptr;
             check_rc(emagls_plan_create(&jobs[j].desc, &p));

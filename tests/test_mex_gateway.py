@@ -237,9 +237,10 @@ def test_job_list_through_the_gateway(mex, grids, thin):
         assert gl.shape == el.shape and gl.dtype == el.dtype, j
         assert np.array_equal(gl, el) and np.array_equal(gr, er), j
     assert np.abs(W[0][0]).max() > 0 and np.abs(W[-1][1]).max() > 0
-    # HRIR sets on one geometry: the flag reaches the scheduler (bit-identical filters either way)
+    # HRIR sets on one geometry: the flag reaches the scheduler (the same filters: the geometry stages run once, on plan 0's grids)
     W2 = mex(1, "jobs", jobs[:11], 32, 4, True)[0]
-    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(W[:11], W2))
+    dev = max(np.abs(a[e] - b[e]).max() / np.abs(a[e]).max() for a, b in zip(W[:11], W2) for e in range(2))
+    assert dev < 1e-11, dev
     with pytest.raises(mex.Error, match="eMagLS:native.*len too short"):     # the library's message, forwarded
         mex(1, "jobs", [dict(jobs[0], len=16)])
     L.check(L.load().emagls_cache_clear())
