@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libemagls.so")
+LIB_PATH = os.environ.get("EMAGLS_LIB_PATH") or os.path.join(_HERE, "lib", "libemagls.so")   # (the override: A/B runs of two builds in one GPU session)
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NUMERIC = 0, 1, 2, 3, 4
 BASIS = {"real": 0, "complex": 1}

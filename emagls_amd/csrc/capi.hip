@@ -51,6 +51,18 @@ struct StreamPool {
     hipStream_t take() {
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
+        {   // The first streams a process creates each open a hardware queue of their own (GPU_MAX_HW_QUEUES = 4), later ones share
+            // those queues.  Since round 6 a job chunk's plans no longer take four streams each (hipStreamCreate was 3 ms of a plan's
+            // set-up), so a lone chunk's batch would fork its stages onto exactly those first streams -- and ran 8 % slower that way
+            // (2400-2470 against 2590-2670 sets/s at 20 steps, A/B on one box, profiles/r06_stream_warm.md; any number of parked streams
+            // from 4 to 80 restores it).  So the pool parks 8 streams before it hands the first one out (EMAGLS_STREAM_WARM=n; 0: none).
+            static const int warm = [] { const char* e = getenv("EMAGLS_STREAM_WARM"); return e ? atoi(e) : 8; }();
+            static std::once_flag once;
+            if (warm > 0) std::call_once(once, [&] {
+                std::lock_guard<std::mutex> lk(mu);
+                for (int i = 0; i < warm; ++i) { hipStream_t st = nullptr; if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) idle[dev].push_back(st); }
+            });
+        }
         if (enabled()) {
             std::lock_guard<std::mutex> lk(mu);
             auto& v = idle[dev];
@@ -167,7 +179,8 @@ struct emagls_plan {
             Slab sl{nullptr, (std::max(bytes, SLAB_BYTES) + SLAB_BYTES - 1) / SLAB_BYTES * SLAB_BYTES, 0};
             sl.base = static_cast<char*>(BlockPool::get().take(sl.size, &sl.size));
             // (one fill per slab instead of one per buffer: 66 hipMemsetAsync calls were 1.9 ms of a plan's set-up)
-            if (hipMemsetAsync(sl.base, 0, sl.size, stream) != hipSuccess) { (void)hipGetLastError(); slab_zeroed = false; } else slab_zeroed = true;
+            static const bool fill = [] { const char* e = getenv("EMAGLS_SLAB_FILL"); return !(e && e[0] == '0'); }();
+            if (!fill || hipMemsetAsync(sl.base, 0, sl.size, stream) != hipSuccess) { (void)hipGetLastError(); slab_zeroed = false; } else slab_zeroed = true;
             slabs.push_back(sl);
         }
         void* p = slabs.back().base + slabs.back().used;
@@ -584,6 +597,7 @@ void plan_setup(emagls_plan& p) {
     if (g_plan_stream_shared) { p.stream = g_plan_stream_shared; p.owns_stream = false; }
     else p.stream = StreamPool::get().take();
     if (const char* ng = getenv("EMAGLS_NO_GRAPH")) p.use_graph = !(ng[0] == '1');
+    if (const char* es = getenv("EMAGLS_EAGER_SIDES")) if (es[0] == '1') p.need_sides(4);   // (experiments: round 5's four streams per plan)
     const auto t_setup1 = std::chrono::steady_clock::now();
     if (const char* ns = getenv("EMAGLS_STREAMS")) p.nstreams = std::max(1, std::min(4, atoi(ns)));
     p.req_cplx = d.basis == EMAGLS_BASIS_COMPLEX;
@@ -4082,7 +4096,8 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
         slot.reset(new JobSlot);
         slot->key = key; slot->device = device;
         slot->grids.resize((size_t)n);
-        slot->stream = emagls::pool_stream_take();
+        static const bool share_stream = [] { const char* e = getenv("EMAGLS_JOBS_SHARED_STREAM"); return !(e && e[0] == '0'); }();
+        if (share_stream) slot->stream = emagls::pool_stream_take();
         struct SharedStream { SharedStream(hipStream_t st) { g_plan_stream_shared = st; } ~SharedStream() { g_plan_stream_shared = nullptr; } } shared_stream(slot->stream);
         for (int j = 0; j < n; ++j) {
             emagls_plan* p = nullptr;
