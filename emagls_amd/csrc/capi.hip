@@ -4017,11 +4017,12 @@ void emagls_atfsets_cache_clear_internal() {
 namespace {
 struct JobSlot {
     std::string key;                  // the descriptors of the slot's designs, byte for byte
+    std::string shape;                // what makes designs share a lane batch (job_shape), job by job: a slot of another key but this shape hands its memory on
     int device = -1;
     std::vector<emagls_plan*> plans;
     emagls_batch* batch = nullptr;
     std::vector<std::vector<double>> grids;   // per plan: hrir azi | zen | mic azi | zen as last uploaded (unchanged grids are not uploaded again)
-    uint64_t last_use = 0;
+    uint64_t last_use = 0, last_call = 0;     // (last_call: the emagls_jobs_run call that used the slot last)
     int runs = 0;                             // executes so far (the first two are the eager run and the graph capture)
     hipStream_t stream = nullptr;             // the plans' common stream (uploads, and the executes of designs that run plan by plan)
     ~JobSlot() {
@@ -4065,7 +4066,7 @@ bool slot_will_capture(const JobSlot& s) {
         if (p->use_graph && p->prof_level == 0 && p->eager_runs >= 1 && !p->pre_exec && !p->graph_exec) return true;
     return false;
 }
-void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool solo) {
+void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool solo, uint64_t call) {
     DeviceGuard dg(device);
     static const bool trace = getenv("EMAGLS_JOBS_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -4076,14 +4077,28 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
     // (a list of ONE chunk has the device to itself: its batch runs the stages before the sweep as one lane group forked onto three
     // streams -- the independent branches of the pipeline side by side: 2160 against 2070 sets/s for a list of 20 config-3 designs --,
     // chunks that share the device with others as two single-stream lane groups: 3300 against 3140 sets/s at 512 designs)
-    std::string key(solo ? "S" : "P");
-    for (int j = 0; j < n; ++j) key.append(reinterpret_cast<const char*>(&jobs[j].desc), sizeof(emagls_design_desc));
-    std::unique_ptr<JobSlot> slot;
+    std::string key(solo ? "S" : "P"), shape(solo ? "S" : "P"), one;
+    for (int j = 0; j < n; ++j) {
+        key.append(reinterpret_cast<const char*>(&jobs[j].desc), sizeof(emagls_design_desc));
+        job_shape(jobs[j].desc, one);
+        shape.append(one);
+    }
+    std::unique_ptr<JobSlot> slot, recycled;
     {
         std::lock_guard<std::mutex> lk(g_jobs_mu);
         for (size_t i = 0; i < g_jobs_free.size(); ++i)
             if (g_jobs_free[i]->device == device && g_jobs_free[i]->key == key) { slot = std::move(g_jobs_free[i]); g_jobs_free.erase(g_jobs_free.begin() + i); break; }
+        // no resident slot of these designs, but an idle one of the same SHAPE (other array radii of the same padded classes: the next
+        // list of a radius study): its memory serves the new slot -- slabs and arena go back to the block pool and come out again at
+        // exactly the sizes asked for.  Fresh device memory is what a new slot must not need: hipMalloc of a 4 GB arena took 0.3 ms on
+        // some boxes and 0.5 s on others (the driver clears VRAM it hands out for the first time), 1 s per call of 28 new radii.
+        if (!slot)
+            for (size_t i = 0; i < g_jobs_free.size(); ++i)
+                if (g_jobs_free[i]->device == device && g_jobs_free[i]->shape == shape && g_jobs_free[i]->last_call != call) {   // (not a chunk of THIS list: a repeat of the list finds all its chunks resident)
+                    recycled = std::move(g_jobs_free[i]); g_jobs_free.erase(g_jobs_free.begin() + i); break;
+                }
     }
+    recycled.reset();   // (outside the lock: the destructor waits for the slot's streams)
     // a chunk shares the device with the other chunks in flight, except on its slot's SECOND run: that one captures the hipGraphs of the
     // stages around the sweep, and a capture next to another thread's uploads or launches is invalidated (hipErrorStreamCaptureInvalidated)
     // (decided from the objects' own state, not from the slot's run count: a batch whose graphs were dropped by a recovery --
@@ -4091,10 +4106,12 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
     const bool capturing = slot && slot_will_capture(*slot);
     std::shared_lock<std::shared_timed_mutex> shared(g_jobs_warm_mu, std::defer_lock);
     std::unique_lock<std::shared_timed_mutex> alone(g_jobs_warm_mu, std::defer_lock);
-    if (capturing) alone.lock(); else shared.lock();
+    // (the exclusive lock only around the execute that captures: the uploads before it and the wait for the filters after it run next to
+    // the other chunks -- a first call with host arrays spent 40 ... 140 ms per chunk uploading under the exclusive lock)
+    shared.lock();
     if (!slot) {
         slot.reset(new JobSlot);
-        slot->key = key; slot->device = device;
+        slot->key = key; slot->shape = shape; slot->device = device;
         slot->grids.resize((size_t)n);
         static const bool share_stream = [] { const char* e = getenv("EMAGLS_JOBS_SHARED_STREAM"); return !(e && e[0] == '0'); }();
         if (share_stream) slot->stream = emagls::pool_stream_take();
@@ -4197,10 +4214,14 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
             std::vector<void*> wl((size_t)n), wr((size_t)n);
             for (int j = 0; j < n; ++j) { wl[(size_t)j] = jobs[j].wL; wr[(size_t)j] = jobs[j].wR; }
             if (slot->batch->prof_level != g_jobs_prof.load()) check_rc(emagls_batch_set_profiling(slot->batch, g_jobs_prof.load()));
+            if (capturing) { shared.unlock(); alone.lock(); }
             check_rc(emagls_batch_execute(slot->batch));
+            if (capturing) { alone.unlock(); shared.lock(); }
             check_rc(emagls_batch_get_filters(slot->batch, wl.data(), wr.data()));
         } else {
+            if (capturing) { shared.unlock(); alone.lock(); }
             for (int j = 0; j < n; ++j) check_rc(emagls_plan_execute(slot->plans[(size_t)j]));
+            if (capturing) { alone.unlock(); shared.lock(); }
             for (int j = 0; j < n; ++j) check_rc(emagls_plan_get_filters(slot->plans[(size_t)j], jobs[j].wL, jobs[j].wR));
         }
         ++slot->runs;
@@ -4209,6 +4230,7 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
     // keep the slot when its designs can serve another chunk as they are
     std::lock_guard<std::mutex> lk(g_jobs_mu);
     slot->last_use = ++g_jobs_tick;
+    slot->last_call = call;
     g_jobs_free.push_back(std::move(slot));
     size_t resident = 0;
     for (auto& f : g_jobs_free) resident += f->plans.size();
@@ -4272,6 +4294,8 @@ int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int i
             chunks.emplace_back(first, n);
             first += n;
         }
+        static std::atomic<uint64_t> g_jobs_call{0};
+        const uint64_t call = ++g_jobs_call;
         // workers: each takes the next chunk until none is left; the first error stops the hand-out and is reported
         std::atomic<size_t> next{0};
         std::mutex err_mu;
@@ -4287,14 +4311,14 @@ int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int i
                 }
                 try {
                     try {
-                        jobs_run_chunk(jobs + chunks[c].first, chunks[c].second, device, flags, chunks.size() == 1);
+                        jobs_run_chunk(jobs + chunks[c].first, chunks[c].second, device, flags, chunks.size() == 1, call);
                     } catch (const Error& e) {
                         // a chunk of 17 ... 32 designs whose sweep stopped being the register-resident form (a recovery moved it to
                         // the slab or launch-per-bin forms, which hold 16 designs): the same designs as two chunks of at most 16
                         if (chunks[c].second <= SWEEP_MULTI_MAX || e.code != EMAGLS_ERR_UNSUPPORTED || !strstr(e.what(), "more than 16 designs")) throw;
                         const int h = (chunks[c].second + 1) / 2;
-                        jobs_run_chunk(jobs + chunks[c].first, h, device, flags, false);
-                        jobs_run_chunk(jobs + chunks[c].first + h, chunks[c].second - h, device, flags, false);
+                        jobs_run_chunk(jobs + chunks[c].first, h, device, flags, false, call);
+                        jobs_run_chunk(jobs + chunks[c].first + h, chunks[c].second - h, device, flags, false, call);
                     }
                 } catch (const Error& e) {
                     std::lock_guard<std::mutex> lk(err_mu);
