@@ -101,6 +101,15 @@ struct BlockPool {
         static const size_t c = [] { const char* e = getenv("EMAGLS_POOL_GB"); return (size_t)(e ? std::max(0, atoi(e)) : 64) << 30; }();
         return c;
     }
+    // Sizes of large blocks (batch arenas: gigabytes) come in classes -- multiples of an eighth of the power of two below them -- so that
+    // the arenas of similar chunks (other array radii: routes, hence buffer sizes, a few per cent apart) are the SAME size and one
+    // chunk's released arena serves the next exactly.  Fresh device memory is what a new chunk must not need: hipMalloc of a 4 GB arena
+    // took 0.3 ms on one box and 0.5 ... 2.9 s next to running kernels on others (profiles/r06_cold_path.md).
+    static size_t size_class(size_t bytes) {
+        size_t step = (size_t)64 << 20;
+        while (step * 16 <= bytes) step *= 2;
+        return (bytes + step - 1) / step * step;
+    }
     // a block of at least `bytes` (exactly `bytes` when it has to be allocated); *got = its size
     void* take(size_t bytes, size_t* got) {
         int dev = 0;
@@ -2768,14 +2777,18 @@ void batch_try_lanes(emagls_batch& b) {
     stride = (stride + 4095) / 4096 * 4096;
     trace_mark("lanes: shapes compared");
     auto arena = std::make_shared<Arena>();
-    arena->base = BlockPool::get().take((stride * b.plans.size() + ((size_t)64 << 20) - 1) / ((size_t)64 << 20) * ((size_t)64 << 20), &arena->bytes);
-    for (size_t j = 0; j < b.plans.size(); ++j) {
+    arena->base = BlockPool::get().take(BlockPool::size_class(stride * b.plans.size()), &arena->bytes);
+    for (size_t j = 0; j < b.plans.size(); ++j) {   // (one launch per 96 buffers: move_buffers_kernel)
         emagls_plan& p = *b.plans[j];
         size_t i = 0;
+        BufferMoves mv{};
         for (auto& kv : p.bufs) {
             char* dst = static_cast<char*>(arena->base) + j * stride + off[i++];
-            HIP_CHECK(hipMemcpyAsync(dst, kv.second.p, kv.second.bytes, hipMemcpyDeviceToDevice, b.stream));
+            if ((reinterpret_cast<uintptr_t>(kv.second.p) & 15) != 0) { HIP_CHECK(hipMemcpyAsync(dst, kv.second.p, kv.second.bytes, hipMemcpyDeviceToDevice, b.stream)); continue; }
+            mv.src[mv.n] = kv.second.p; mv.dst[mv.n] = dst; mv.bytes[mv.n] = kv.second.bytes;
+            if (++mv.n == 96) { launch_move_buffers(mv, b.stream); mv.n = 0; }
         }
+        launch_move_buffers(mv, b.stream);
     }
     trace_mark("lanes: arena taken, copies enqueued");
     HIP_CHECK(hipStreamSynchronize(b.stream));   // (every plan's streams were synchronised by the caller: the buffers are final)

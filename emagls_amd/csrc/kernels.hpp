@@ -14,6 +14,8 @@ void launch_broadcast_lanes(const void* src, size_t bytes, size_t stride, int nl
 struct LanePtrs { void* p[64]; };   // [2 j + ear] for up to 32 designs
 void launch_scatter_lanes(const void* srcL, const void* srcR, size_t stride, size_t bytes, int n, const LanePtrs& dst, hipStream_t st);
 void launch_gather_buffers(const LanePtrs& src, const LanePtrs& dst, int nbuf, size_t bytes, hipStream_t st);   // nbuf <= 64 device buffers of `bytes` each
+struct BufferMoves { const void* src[96]; void* dst[96]; size_t bytes[96]; int n; };   // device-to-device copies of one launch
+void launch_move_buffers(const BufferMoves& m, hipStream_t st);
 void launch_ch_basis(int N, int M, const double* azi, bool cplx_basis, void* out, int ld, hipStream_t st, bool out_real = false);
 void launch_sh_coeff(int N, double* tab, hipStream_t st);
 inline size_t esz(bool c) { return c ? sizeof(cplx) : sizeof(double); }   // element size of a real / complex basis

@@ -194,6 +194,27 @@ void launch_gather_buffers(const LanePtrs& src, const LanePtrs& dst, int nbuf, s
     KERNEL_CHECK();
 }
 
+// the same for buffers of different sizes (a plan's ~70 buffers on their way into a batch's arena: one launch per plan instead of one
+// hipMemcpyAsync per buffer -- 924 calls per chunk of 14 plans were 9 ms of host time); every buffer starts 16-byte aligned and is
+// allocated in multiples of 16 bytes
+__global__ void __launch_bounds__(256) move_buffers_kernel(BufferMoves m) {
+    const int j = blockIdx.y;
+    const int64_t n16 = (int64_t)((m.bytes[j] + 15) / 16);
+    const uint4* s = reinterpret_cast<const uint4*>(m.src[j]);
+    uint4* d = reinterpret_cast<uint4*>(m.dst[j]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+void launch_move_buffers(const BufferMoves& m, hipStream_t st) {
+    if (m.n <= 0) return;
+    size_t big = 0;
+    for (int j = 0; j < m.n; ++j) big = std::max(big, m.bytes[j]);
+    // (four 16-byte words per thread on the largest buffer, up to 2048 workgroups per buffer: with 64 the ~0.3 GB of a plan moved at
+    // 0.4 TB/s; the blocks of a small buffer beyond its end return at once)
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ceil_div((int64_t)(big / 16 + 1), 1024)));
+    move_buffers_kernel<<<dim3(gx, (unsigned)m.n), 256, 0, st>>>(m);
+    KERNEL_CHECK();
+}
+
 // *differ = 1 when two device buffers differ in any 8-byte word (a batch of FromAtf subjects checks that its plans really hold
 // the same ATF set and grids before it computes the ATF side once for all of them)
 __global__ void compare_words_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, int64_t n8, int* differ) {

@@ -324,6 +324,40 @@ def config3_hrir_sets(n_batches=3, per_batch=32, rounds=6):
                     "figure of this line treats its designs as independent and does NOT use this"}
 
 
+def config3_host_arrays(njobs=256, nsets=32):
+    """BASELINE config 3 as ONE job list of 256 designs with HOST arrays in and out (pageable NumPy memory: 5.5 MB of HRIRs in, 0.4 MB
+    of filters out per design, the PCIe-inclusive figure of the scheduler): the first call of the shape in an initialised process --
+    after emagls_cache_clear: no plans, no arenas, no graphs, an empty block pool --, and the same list again (chunks resident)."""
+    import ctypes as C
+    from emagls_amd import synth, _lib as L
+    lib = L.load()
+    azi, zen, maz, mzn = _grids()
+    sets = [tuple(np.asfortranarray(h) for h in synth.rigid_sphere_hrirs(azi, zen, seed=4242 + j)) for j in range(nsets)]
+    nsamp, D = sets[0][0].shape
+    outs = [(np.zeros((512, 25), dtype=np.complex128, order="F"), np.zeros((512, 25), dtype=np.complex128, order="F")) for _ in range(njobs)]
+    desc = L.DesignDesc(L.KIND_EMAGLS, L.BASIS["complex"], 4, 48000.0, 512, nsamp, D, 0.042, 32, 0.0, 0, 0, 0, 0, 0)
+    keep = [np.ascontiguousarray(x, dtype=np.float64) for x in (azi, zen, maz, mzn)]
+    jobs = (L.Job * njobs)()
+    for j in range(njobs):
+        jb = jobs[j]
+        jb.desc = desc
+        jb.hL, jb.hR = C.c_void_p(sets[j % nsets][0].ctypes.data), C.c_void_p(sets[j % nsets][1].ctypes.data)
+        jb.hrir_azi, jb.hrir_zen, jb.mic_azi, jb.mic_zen = (C.c_void_p(k.ctypes.data) for k in keep)
+        jb.wL, jb.wR = C.c_void_p(outs[j][0].ctypes.data), C.c_void_p(outs[j][1].ctypes.data)
+    L.check(lib.emagls_cache_clear())
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        L.check(lib.emagls_jobs_run(jobs, njobs, 32, 4, 0))
+        ts.append(time.perf_counter() - t0)
+    L.check(lib.emagls_cache_clear())
+    res = float(np.median(ts[2:]))
+    return {"designs": njobs, "first_call_s": round(ts[0], 4), "first_call_filter_sets_per_s": round(njobs / ts[0], 1), "second_call_s": round(ts[1], 4),
+            "resident_s": [round(t, 4) for t in ts[2:]], "filter_sets_per_s": round(njobs / res, 1),
+            "note": "emagls_jobs_run, chunks of 32, four in flight, pageable host arrays; first_call: after emagls_cache_clear in an initialised "
+                    "process (plans, arenas, eager runs; the second call captures the graphs); filter_sets_per_s: chunks resident"}
+
+
 def config2_hrir_sets(n_batches=3, per_batch=16, rounds=6, share=True, diffuse=False):
     """BASELINE config 2's design (getMagLsFilters N = 4, 2702 directions, 512 taps) as a job list of HRIR sets: MagLS plans in
     batches -- one resident sweep launch per batch instead of one per design; share=True: sets on one grid, SH side once per
@@ -457,6 +491,10 @@ def run():
         out["config4_rank_share_through_the_runner"] = config4_rank_share_runner()
     except Exception as e:
         out["config4_rank_share_through_the_runner"] = {"error": repr(e)}
+    try:
+        out["config3_job_list_with_host_arrays"] = config3_host_arrays()
+    except Exception as e:
+        out["config3_job_list_with_host_arrays"] = {"error": repr(e)}
     try:
         out["config3_hrir_sets_on_one_geometry"] = config3_hrir_sets()
     except Exception as e:
