@@ -33,6 +33,8 @@
 #include "synth_common.hpp"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 namespace emagls {
 
@@ -116,6 +118,8 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ cplx ldg(gcc_t p) { return mk(p->x, p->y); }
 // granules in global memory (the helpers of persist_common.hpp take generic pointers)
 __device__ __forceinline__ u64 gll_load(gu64_t p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (`local`: workgroup-scope stores for traffic BETWEEN workgroups of one XCD -- formally a data race; it relies on the per-CU vector cache
+// of gfx942 / gfx950 being write-through, so that the store reaches the XCD's L2 at once.  Any other architecture: EMAGLS_PERSIST_GLOBAL=1.)
 __device__ __forceinline__ void gll_put(gu64_t dst, u64 word, bool local) {
     if (local) __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -531,6 +535,22 @@ void reg_set_attributes() {
         for (int nw : RG_WAVES) HIP_CHECK(hipFuncSetAttribute(reg_kernel_ptr(nw), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 }
 int reg_nwg(int D, int nw) { return (int)ceil_div(D, 32 * nw); }
+// workgroups of `nw` waves the runtime can keep on one CU (registers, LDS, wave slots of THIS build of the kernel), once per device:
+// the residency decisions below count on three 4-wave workgroups per CU and on one of every larger form
+int reg_occupancy(int nw) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, int> cache;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({dev, nw});
+    if (it != cache.end()) return it->second;
+    reg_set_attributes();
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reg_kernel_ptr(nw), 64 * nw, reg_dyn_bytes(RG_NUL, nw)) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    cache[{dev, nw}] = nb;
+    return nb;
+}
 // thirds of a CU a workgroup of nw waves is counted as: four waves share a CU with two more of their kind, larger workgroups take it
 int reg_wg_cost(int nw) { return nw == 4 ? 1 : 3; }
 
@@ -555,10 +575,10 @@ int reg_sweep_pick_waves(int D, int ndesigns) {
     const int nsub = (int)ceil_div(ndesigns, 8), cus = sweep_cu_budget() / 8;
     if (const char* e = getenv("EMAGLS_REG_WAVES")) {   // (experiments: 4 ... 12 whenever it fits)
         const int nw = atoi(e);
-        if ((nw == 4 || nw == 6 || nw == 8 || nw == 10 || nw == 12) && nsub * reg_nwg(D, nw) * reg_wg_cost(nw) <= 3 * cus) return nw;
+        if ((nw == 4 || nw == 6 || nw == 8 || nw == 10 || nw == 12) && nsub * reg_nwg(D, nw) * reg_wg_cost(nw) <= 3 * cus && reg_occupancy(nw) >= (nw == 4 ? 3 : 1)) return nw;
     }
-    for (int nw : RG_WAVES) if (nsub * reg_nwg(D, nw) <= cus) return nw;
-    return nsub * reg_nwg(D, 4) <= 3 * cus ? 4 : 0;
+    for (int nw : RG_WAVES) if (nsub * reg_nwg(D, nw) <= cus && reg_occupancy(nw) >= 1) return nw;
+    return (nsub * reg_nwg(D, 4) <= 3 * cus && reg_occupancy(4) >= 3) ? 4 : 0;
 }
 // Waves per workgroup when the designs of a launch are spread over all XCDs (0: not spread): taken when it gives every workgroup a
 // CU of its own with FEWER waves than the XCD-local layout needs (EMAGLS_REG_SPREAD=0: never, =1: whenever it fits).
@@ -568,7 +588,7 @@ int reg_sweep_spread_waves(int D, int ndesigns) {
     if (mode == 0 || ndesigns < 1 || ndesigns > REG_SWEEP_MAX || getenv("EMAGLS_REG_WAVES")) return 0;
     const int cus = sweep_cu_budget(), local = reg_sweep_pick_waves(D, ndesigns);
     for (int nw : RG_WAVES)
-        if (ndesigns * reg_nwg(D, nw) <= cus) return (mode == 1 || local == 0 || nw < local) ? nw : 0;
+        if (ndesigns * reg_nwg(D, nw) <= cus && reg_occupancy(nw) >= 1) return (mode == 1 || local == 0 || nw < local) ? nw : 0;
     return 0;
 }
 int reg_sweep_gate_cost(int D, int ndesigns) {
