@@ -695,11 +695,14 @@ void plan_setup(emagls_plan& p) {
         // narrow path takes: 64 microphones at 7 / 8 / 10 cm agree with the oracle to 1e-10, tools/experiments/wide_radius.py)
         if (p.C > 32) {
             if (p.C > 64) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 64 output channels is not supported in this build");
-            if (d.kind != EMAGLS_KIND_EMAGLS && d.kind != EMAGLS_KIND_EMAGLS2)
-                throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: eMagLS / eMagLS2 only");
+            if (d.kind != EMAGLS_KIND_EMAGLS && d.kind != EMAGLS_KIND_EMAGLS2 && d.kind != EMAGLS_KIND_EMA_SH)
+                throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: eMagLS / eMagLS2 / EMAinSH only");
             if (p.custom_basis || d.sim_order_pad > 0)
                 throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: built-in SH basis, no padding");
-            if (p.req_cplx && !p.real_internal) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: the real-arithmetic pipeline only");
+            // (EMAinSH orders 5..7 factor the direction-space operands themselves -- execute_ema_sh_wide -- in either basis)
+            if (d.kind != EMAGLS_KIND_EMA_SH && p.req_cplx && !p.real_internal)
+                throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 32 output channels: the real-arithmetic pipeline only");
+            if (d.kind == EMAGLS_KIND_EMA_SH && p.diffuse) throw Error(EMAGLS_ERR_UNSUPPORTED, "EMAinSH above order 4: no covariance constraint in this build");
             p.wide = true;
         }
         if (p.simOrder > 85) throw Error(EMAGLS_ERR_UNSUPPORTED, "simulation order above 85 (array radius > ~19.3 cm at 48 kHz) is not supported: the reference's own getSH overflows there (factorials beyond 170!)");
@@ -772,8 +775,7 @@ void plan_setup(emagls_plan& p) {
             p.alloc("N_lo", sizeof(cplx) * (size_t)p.nOut * p.nOut);
         }
         if (d.kind == EMAGLS_KIND_EMA_SH) {
-            if (N > 4) throw Error(EMAGLS_ERR_UNSUPPORTED, "EMAinSH: SH order above 4 is not supported in this build");
-            const int npts = ema_sh_npts(p.C), ldP = round_up(npts, 64);
+            const int npts = ema_sh_npts(p.C), ldP = round_up(npts, 64);   // (C <= 64: orders up to 7, checked above)
             const int64_t ldA = round_up((int64_t)(p.D + 1) * npts, 64);
             p.alloc("Ech", esz(cb) * (size_t)(2 * N + 1) * p.ldS);          // pinv(CH(micAzi)) Y_mic
             p.alloc("sh_tab_lo", sizeof(double) * sh_coeff_count(N));      // recurrence table of the output order (its layout depends on the order)
@@ -807,7 +809,22 @@ void plan_setup(emagls_plan& p) {
         p.alloc("nvalid", sizeof(int) * 4);
         p.upload("nvalid", &p.simOrderOwn, sizeof(int));
         p.alloc("bn", sizeof(cplx) * (size_t)p.P * (p.simOrder + 1));
-        if (p.wide) {   // wide_array.hip: every bin on the S-space route in global memory, Y_reg_inv of every bin materialised
+        if (p.wide && d.kind == EMAGLS_KIND_EMA_SH) {
+            // EMAinSH orders 5..7 (36..64 channels): G_k of every bin materialised, factored in place of a common S-space
+            // (wide_array.hip on the D x C operand itself, like FromAtf above 32 microphones), one sweep launch per bin
+            const size_t nb = (size_t)p.P - 1, nOrdW = (size_t)p.simOrder + 1;
+            p.alloc("QT", esz(cb) * nOrdW * p.C * p.ldD);
+            p.alloc("G", sizeof(cplx) * (nb * p.C + 32) * p.ldD, false);
+            p.alloc("Yri", sizeof(cplx) * (nb * p.C + 32) * p.ldD, false);
+            p.alloc("Bw", sizeof(cplx) * nb * p.C * p.ldD, false);
+            p.alloc("Vw", sizeof(cplx) * nb * p.C * p.ldD, false);
+            p.alloc("tauw", sizeof(double) * nb * p.C);
+            p.alloc("R2w", sizeof(cplx) * nb * p.C * p.C);
+            p.alloc("Nw", sizeof(cplx) * nb * p.C * p.C);
+            p.alloc("sv", sizeof(double) * (size_t)p.P * p.C);
+            p.alloc("jsweeps", sizeof(int) * (size_t)p.P);
+            p.g0 = 1;
+        } else if (p.wide) {   // wide_array.hip: every bin on the S-space route in global memory, Y_reg_inv of every bin materialised
             const size_t nb = (size_t)p.P - 1, nOrdW = (size_t)p.simOrder + 1;
             p.alloc("R", sizeof(double) * (size_t)p.S * p.S);
             p.alloc("Rinv", sizeof(double) * (size_t)ceil_div(p.S, 32) * 32 * 32);
@@ -1094,8 +1111,9 @@ int jacobi_run_length(const emagls_plan& p) {
     return (batch_ctx().n >= 2 && p.nstreams <= 1) ? 2 : 1;
 }
 
-// getEMagLsFiltersEMAinSH: everything before the sweep (kernels and derivation: emash.hip).  One stream.
-void ema_sh_pre_sweep(emagls_plan& p) {
+// getEMagLsFiltersEMAinSH: the HRIR prologue, the array model, the per-direction rotations and G_k of every bin (kernels and derivation:
+// emash.hip).  One stream.
+void ema_sh_operands(emagls_plan& p) {
     const emagls_design_desc& d = p.d;
     const bool cb = p.cplx_basis;
     hipStream_t st = p.stream;
@@ -1141,6 +1159,12 @@ void ema_sh_pre_sweep(emagls_plan& p) {
     {
         const char* B = (const char*)p.get("Arot") + esz(cb) * (size_t)p.D * npts;   // the unrotated point set: columns D*npts..
         launch_widen(B, ldA, cb, p.get("Bc"), ldP, p.C, npts, false, false, st);
+        if (p.C > 32) {
+            // orders 5..7: pinv of the npts x C point matrix by wide_array.hip's QR + one-sided Jacobi (no clipping: the point set
+            // resolves the order, nothing is dropped) -- Z comes out as pinv(B) [C][ldP] like the narrow factorisation's
+            launch_wa_factor(p.get("Bc"), p.get("Vb"), npts, p.C, ldP, 1, 0.0, p.get<double>("tau_b"), p.get("R2_b"), p.get("N_b"), p.get<double>("sv"),
+                             p.get<int>("jsweeps"), p.get("Zb"), st);
+        } else {
         FactorArgs a{};
         a.S = npts; a.C = p.C; a.ldS = ldP; a.kb0 = 0; a.P = 2;
         a.Xd = p.get<cplx>("Bc"); a.xd_stride = 0;
@@ -1148,6 +1172,7 @@ void ema_sh_pre_sweep(emagls_plan& p) {
         a.Z = p.get<cplx>("Zb"); a.Vws = p.get<cplx>("Vb");
         a.tauw = p.get<double>("tau_b"); a.R2w = p.get<cplx>("R2_b"); a.Nw = p.get<cplx>("N_b");
         launch_factor(a, 1, true, st);
+        }
     }
     launch_rot_from_points(p.get("Arot"), ldA, p.get("Zb"), ldP, p.C, npts, p.get<double>("hrir_zen"), (int)p.D, cb, p.get("Rot"), st);
     p.mark("sh_rotations");
@@ -1158,6 +1183,15 @@ void ema_sh_pre_sweep(emagls_plan& p) {
     launch_qt_rotate(p.get("QT"), p.ldD, nOrd, p.C, N, (int)p.D, p.get("Rot"), cb, st);
     launch_dspace_g(p.get("QT"), p.ldD, cb, p.get("bn"), nOrd, (int)p.D, p.C, p.P, p.g0, p.get("G"), st, 0, -1);
     p.mark("order_terms+G");
+}
+// everything before the sweep, up to order 4 (32 channels: the tuned Gram-route kernels and the resident sweep)
+void ema_sh_pre_sweep(emagls_plan& p) {
+    ema_sh_operands(p);
+    const bool cb = p.cplx_basis;
+    hipStream_t st = p.stream;
+    const int ls_end = std::min(p.kcut0, p.P);
+    const int64_t g_stride = (int64_t)p.C * p.ldD;
+    (void)cb;
     // ---- per-bin C x C matrices: Gram route for every bin
     const int ldK = round_up(p.C * p.C, 64), gf = 1, nb = p.P - 1;
     launch_gram_from_g(p.get("G"), g_stride, p.ldD, (int)p.D, p.C, gf, nb, p.g0, p.get<double>("Apk"), ldK, st);
@@ -1609,8 +1643,41 @@ void emagls_post_sweep(emagls_plan& p) {
     p.mark("epilogue");
 }
 
+// getEMagLsFiltersEMAinSH at orders 5..7 (36 / 49 / 64 channels; lib/getEMagLsFiltersEMAinSH.m:66-143): the per-direction rotations leave
+// no common S-space, so pwGrid_k.' = G_k (D x C) is factored itself -- Householder QR, one-sided Jacobi on the triangular factor, 1 %
+// clipping, back-transform: Y_reg_inv_k directly (wide_array.hip with Q = I, the form FromAtf takes above 32 microphones) --, then
+// the least-squares bins and one sweep launch per bin.
+void execute_ema_sh_wide(emagls_plan& p) {
+    hipStream_t st = p.stream;
+    const int nb = p.P - 1, ls_end = std::min(p.kcut0, p.P), k0 = std::max(p.kcut0, 1);
+    const int64_t g_stride = (int64_t)p.C * p.ldD;
+    ema_sh_operands(p);                                   // G_k of the bins 1 .. P-1 (g0 = 1)
+    cplx* G = p.get<cplx>("G");
+    cplx* Yri = p.get<cplx>("Yri");
+    HIP_CHECK(hipMemcpyAsync(p.get("Bw"), G, sizeof(cplx) * (size_t)nb * g_stride, hipMemcpyDeviceToDevice, st));   // (the QR works in place)
+    launch_wa_factor(p.get("Bw"), p.get("Vw"), (int)p.D, p.C, (int)p.ldD, nb, SVD_REGUL_CONST, p.get<double>("tauw"), p.get("R2w"), p.get("Nw"),
+                     p.get<double>("sv") + p.C, p.get<int>("jsweeps") + 1, Yri, st);
+    p.mark("factor_bins");
+    launch_wa_ls(p.get("Hc"), p.ldD, ls_end, Yri, p.ldD, (int)p.D, p.C, p.P, 1, ls_end, p.get("W"), st);
+    p.mark("ls_bins");
+    DenseSweepArgs a{};
+    a.D = (int)p.D; a.C = p.C; a.ldD = (int)p.ldD; a.P = p.P;
+    a.X = G - g_stride; a.x_stride = g_stride;            // (indexed by kb: bin 1 at the buffer's start)
+    a.Zd = Yri - g_stride; a.z_stride = g_stride;
+    a.Habs = p.get<double>("Habs"); a.ldH = p.ldD; a.kabs0 = p.kcut0;
+    a.Wpart = p.get<cplx>("Wpart"); a.W = p.get<cplx>("W"); a.nWG = p.nWG; a.dpw = 0; a.kfirst = k0;
+    p.sweep_launches = 0;
+    for (int kb = k0; kb < p.P; ++kb) { launch_sweep_wide(a, kb, true, st); ++p.sweep_launches; }
+    if (k0 < p.P) launch_sweep_wide_finalize(p.get("Wpart"), p.get("W"), p.nWG, p.C, p.P, p.P - 1, st);
+    p.mark("magls_sweep");
+    launch_filter_epilogue(p.get("W"), p.C, p.nfft, (int)p.d.len, p.get("tw"), p.get<double>("grpd"), p.req_cplx ? 1 : 0, 1, 0,
+                           p.out_cplx ? 1 : 0, p.get("wL"), p.get("wR"), st);
+    p.mark("epilogue");
+}
+
 // eMagLS / eMagLS2 with 33..64 channels: wide_array.hip.  One stream, every bin on the S-space route.
 void execute_emagls_wide(emagls_plan& p) {
+    if (p.d.kind == EMAGLS_KIND_EMA_SH) { execute_ema_sh_wide(p); return; }
     const emagls_design_desc& d = p.d;
     hipStream_t st = p.stream;
     const bool raw = d.kind == EMAGLS_KIND_EMAGLS2;

@@ -108,8 +108,52 @@ __global__ void __launch_bounds__(256) rot_from_points_kernel(const T* __restric
         out[idx] = acc;
     }
 }
+// The same for more than 32 channels (orders 5..7: the full C x npts operands of a direction no longer fit the LDS): one workgroup per
+// (direction, order l), only the (2l+1) x (2l+1) diagonal block of Rot_d -- all that qt_rotate_kernel reads; the rest of Rot stays zero.
+template <typename T>
+__global__ void __launch_bounds__(256) rot_blocks_from_points_kernel(const T* __restrict__ A, int64_t ldA, const cplx* __restrict__ Z, int ldP, int C,
+                                                                     int npts, const double* __restrict__ zen, T* __restrict__ Rot, size_t bstride) {
+    A = boff(A, bstride); Z = boff(Z, bstride); zen = boff(zen, bstride); Rot = boff(Rot, bstride);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int d = blockIdx.x, l = blockIdx.y, B = 2 * l + 1, c0 = l * l;
+    T* a_s = reinterpret_cast<T*>(smem);   // [B][npts]
+    T* z_s = a_s + (size_t)B * npts;       // [B][npts]
+    T* out = Rot + (size_t)d * C * C;
+    if (zen[d] == 1.5707963267948966) {
+        for (int idx = threadIdx.x; idx < B * B; idx += blockDim.x) out[(size_t)(c0 + idx / B) * C + c0 + idx % B] = from_c<T>(mk((idx / B) == (idx % B) ? 1.0 : 0.0, 0.0));
+        return;
+    }
+    for (int idx = threadIdx.x; idx < B * npts; idx += blockDim.x) {
+        const int c = c0 + idx / npts, p = idx % npts;
+        a_s[idx] = A[(int64_t)c * ldA + (int64_t)d * npts + p];
+        z_s[idx] = from_c<T>(Z[(size_t)c * ldP + p]);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < B * B; idx += blockDim.x) {
+        const int i = idx / B, j = idx - i * B;
+        T acc = from_c<T>(mk(0.0, 0.0));
+        for (int p = 0; p < npts; ++p) cfma(acc, z_s[j * npts + p], a_s[i * npts + p]);
+        out[(size_t)(c0 + i) * C + c0 + j] = acc;
+    }
+}
 void launch_rot_from_points(const void* A, int64_t ldA, const void* Z, int ldP, int C, int npts, const double* zen, int D, bool cb, void* Rot,
                             hipStream_t st) {
+    if (C > 32) {
+        int N = 0;
+        while ((N + 1) * (N + 1) < C) ++N;
+        const size_t smb = (size_t)2 * (2 * N + 1) * npts * (cb ? sizeof(cplx) : sizeof(double));
+        static PerDeviceOnce attr_blocks;
+        if (attr_blocks.first()) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)rot_blocks_from_points_kernel<cplx>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_CHECK(hipFuncSetAttribute((const void*)rot_blocks_from_points_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        launch_zero(Rot, (cb ? sizeof(cplx) : sizeof(double)) * (size_t)D * C * C, st);
+        const dim3 grid((unsigned)D, (unsigned)(N + 1));
+        if (cb) rot_blocks_from_points_kernel<cplx><<<bgrid(grid), 256, smb, st>>>((const cplx*)A, ldA, (const cplx*)Z, ldP, C, npts, zen, (cplx*)Rot, batch_ctx().stride);
+        else rot_blocks_from_points_kernel<double><<<bgrid(grid), 256, smb, st>>>((const double*)A, ldA, (const cplx*)Z, ldP, C, npts, zen, (double*)Rot, batch_ctx().stride);
+        KERNEL_CHECK();
+        return;
+    }
     const size_t sm = (size_t)2 * C * npts * (cb ? sizeof(cplx) : sizeof(double));
     static PerDeviceOnce attr_once;   // (function attributes are per device)
     if (attr_once.first()) {
@@ -147,6 +191,26 @@ __device__ __forceinline__ void rotate_block(T* __restrict__ QT, int64_t ldD, in
         for (int j = 0; j < B; ++j) q[(int64_t)j * ldD] = o[j];
     }
 }
+// orders 5..7: the block (up to 15 x 15) stays in memory (a thread's own block, read through L2), the output row in registers
+template <typename T, int L>
+__device__ __forceinline__ void rotate_block_mem(T* __restrict__ QT, int64_t ldD, int nOrd, int C, int d, const T* __restrict__ rot) {
+    constexpr int B = 2 * L + 1, c0 = L * L;
+    for (int n = 0; n < nOrd; ++n) {
+        T* q = QT + ((int64_t)n * C + c0) * ldD + d;
+        T o[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) o[j] = from_c<T>(mk(0.0, 0.0));
+#pragma unroll 1
+        for (int i = 0; i < B; ++i) {
+            const T vi = q[(int64_t)i * ldD];
+            const T* r = rot + (size_t)(c0 + i) * C + c0;
+#pragma unroll
+            for (int j = 0; j < B; ++j) cfma(o[j], vi, r[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) q[(int64_t)j * ldD] = o[j];
+    }
+}
 template <typename T>
 __global__ void __launch_bounds__(128) qt_rotate_kernel(T* __restrict__ QT, int64_t ldD, int nOrd, int C, int N, int D, const T* __restrict__ Rot,
                                                         size_t bstride) {
@@ -159,9 +223,12 @@ __global__ void __launch_bounds__(128) qt_rotate_kernel(T* __restrict__ QT, int6
     if (N >= 2) rotate_block<T, 2>(QT, ldD, nOrd, C, d, rot);
     if (N >= 3) rotate_block<T, 3>(QT, ldD, nOrd, C, d, rot);
     if (N >= 4) rotate_block<T, 4>(QT, ldD, nOrd, C, d, rot);
+    if (N >= 5) rotate_block_mem<T, 5>(QT, ldD, nOrd, C, d, rot);
+    if (N >= 6) rotate_block_mem<T, 6>(QT, ldD, nOrd, C, d, rot);
+    if (N >= 7) rotate_block_mem<T, 7>(QT, ldD, nOrd, C, d, rot);
 }
 void launch_qt_rotate(void* QT, int64_t ldD, int nOrd, int C, int N, int D, const void* Rot, bool cb, hipStream_t st) {
-    if (N > 4) throw Error(2, "EMAinSH: SH order above 4 is not supported in this build");
+    if (N > 7) throw Error(2, "EMAinSH: SH order above 7 is not supported in this build");
     const unsigned g = (unsigned)ceil_div(D, 128);
     if (cb) qt_rotate_kernel<cplx><<<bgrid(g), 128, 0, st>>>((cplx*)QT, ldD, nOrd, C, N, D, (const cplx*)Rot, batch_ctx().stride);
     else qt_rotate_kernel<double><<<bgrid(g), 128, 0, st>>>((double*)QT, ldD, nOrd, C, N, D, (const double*)Rot, batch_ctx().stride);
