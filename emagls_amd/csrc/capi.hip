@@ -766,7 +766,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Ymic_cm", esz(cb) * (size_t)p.S * M);                 // [S][M]
         p.alloc("Ymic_rm", esz(cb) * (size_t)ldM * p.ldS);             // [M][ldS]
         p.alloc("E", esz(cb) * (size_t)p.C * p.ldS);                   // [C][ldS]
-        if (d.kind != EMAGLS_KIND_EMAGLS2 && p.nOut <= 32) {
+        if (d.kind == EMAGLS_KIND_EMA_SH || (d.kind != EMAGLS_KIND_EMAGLS2 && p.nOut <= 32)) {   // (EMAinSH: pinv of the 2N+1 circular harmonics, any order)
             p.alloc("Ylo_c", sizeof(cplx) * (size_t)p.nOut * ldM);     // [nOut][ldM] complex copy of Y_Lo^T
             p.alloc("Zlo", sizeof(cplx) * (size_t)p.nOut * ldM);
             p.alloc("Vlo", sizeof(cplx) * (size_t)p.nOut * ldM);
