@@ -259,6 +259,7 @@ struct emagls_plan {
     hipGraphExec_t pre_exec = nullptr;
     int nstreams = 1;
     int stage_order = 0;          // order of the stages before the sweep (emagls_pre_sweep): 0 branches, 1 / 2 the complementary single-stream orders of lane groups
+    int pre_phase = 0;            // emagls_pre_sweep: 0 everything, 1 only what the sweep needs, 2 the rest (plan_defers_hh_route)
     hipStream_t sync_stream = nullptr;  // stream whose completion means this plan's results are ready
     // fork/join inside one design: independent branches run on side streams (captured into the same graph)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // taken from the pool when a multi-stream execute first needs them (need_sides)
@@ -380,6 +381,11 @@ struct emagls_batch {
     hipGraphExec_t graph2_exec = nullptr;
     hipGraph_t graphx[2] = {nullptr, nullptr};             // the third and fourth groups' (on side[1], side[2])
     hipGraphExec_t graphx_exec[2] = {nullptr, nullptr};
+    hipGraph_t graph_hh[4] = {nullptr, nullptr, nullptr, nullptr};   // per lane group: the stages the sweep does not need (plan_defers_hh_route), next to the sweep
+    hipGraphExec_t graph_hh_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t hh_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool defer_hh = false;                     // what the captured graphs were captured with (batch_execute_lanes)
+    bool alone = false;                        // the batch has the device to itself (the job scheduler's single-chunk lists; EMAGLS_DEFER_HH=2: every lane batch)
     int eager_runs = 0;
     bool use_graph = true;
     void* sweep_args_dev = nullptr;            // argument blocks of the register-resident sweep, one per plan (sweep_reg.hip)
@@ -411,6 +417,11 @@ struct emagls_batch {
         if (graph2_exec) hipGraphExecDestroy(graph2_exec);
         if (graph2) hipGraphDestroy(graph2);
         for (int i = 0; i < 2; ++i) { if (graphx_exec[i]) hipGraphExecDestroy(graphx_exec[i]); if (graphx[i]) hipGraphDestroy(graphx[i]); }
+        for (int i = 0; i < 4; ++i) {
+            if (hh_stream[i]) { hipStreamSynchronize(hh_stream[i]); emagls::pool_stream_give(hh_stream[i]); }
+            if (graph_hh_exec[i]) hipGraphExecDestroy(graph_hh_exec[i]);
+            if (graph_hh[i]) hipGraphDestroy(graph_hh[i]);
+        }
         for (auto e : sweep_ev) if (e) hipEventDestroy(e);
         if (stream && own_stream) emagls::pool_stream_give(stream);
         for (int i = 0; i < 3; ++i) if (side[i] && !(i == 0 && side0_external)) { hipStreamSynchronize(side[i]); emagls::pool_stream_give(side[i]); }
@@ -1217,6 +1228,16 @@ void ema_sh_pre_sweep(emagls_plan& p) {
     p.mark("ls_bins");
 }
 
+// The synthesising sweep needs the Gram-route bins only: M~_k of the swept bins, the start value W(k_cut-1,:) (a least-squares bin of the
+// Gram route), |H|, the Chebyshev coefficients.  The Cholesky factor of the grid's SH Gram matrix and the whole orthonormal route of
+// the ill-conditioned low bins (T_n, Householder QR, Jacobi, back-transform, their least-squares rows: bins 1 .. hh_end-1) feed the
+// filters' rows, i.e. the epilogue AFTER the sweep -- 0.9 ms of the 3 ms a lone 20-design chunk spent before its sweep.  A batch
+// therefore runs them next to the sweep on a stream of their own (batch_execute_lanes).  EMAGLS_DEFER_HH=0: everything before the sweep.
+bool plan_defers_hh_route(const emagls_plan& p) {
+    static const bool on = [] { const char* e = getenv("EMAGLS_DEFER_HH"); return !(e && e[0] == '0'); }();
+    const int k0 = std::max(p.kcut0, 1);
+    return on && p.synth && !p.diffuse && p.prof_level == 0 && p.d.kind != EMAGLS_KIND_EMA_SH && p.gram_from > 0 && p.hh_end > 1 && p.hh_end <= k0 - 1;
+}
 void emagls_pre_sweep(emagls_plan& p) {
     if (p.d.kind == EMAGLS_KIND_EMA_SH) { ema_sh_pre_sweep(p); return; }
     const emagls_design_desc& d = p.d;
@@ -1237,7 +1258,8 @@ void emagls_pre_sweep(emagls_plan& p) {
     const int ls_h = std::min(ls_end, hh_end);     // least-squares bins [1, ls_h) on the Householder route, [ls_h, ls_end) on the Gram route
     const int64_t g_stride = (int64_t)p.C * p.ldD;
     cplx* Gk = p.get<cplx>("G") - (int64_t)p.g0 * g_stride;   // indexed by kb
-    p.sync_used = 0;
+    const int phase = plan_defers_hh_route(p) ? p.pre_phase : 0;
+    if (phase != 2) p.sync_used = 0;
 
     // The stages before the sweep as blocks.  Their data dependencies: array (mic SH matrix, E, b_n) <- nothing; prologue (HRIR
     // spectra) <- nothing; basis (Yc) <- nothing; gram (Gy, R) <- basis; chol <- gram; gterms (QT_n, G_k) <- basis, array;
@@ -1437,7 +1459,23 @@ void emagls_pre_sweep(emagls_plan& p) {
     if (p.synth) launch_synth_mt(p.get("Mw"), p.get<double>("Pm"), p.C, M, k0, p.P, p.get("W"), p.get("Mt"), p.get("Winit"), s0);
     };
 
+    if (phase == 2) {   // what the sweep did not need, on one stream: Cholesky factor, orthonormal route of the low bins, their rows
+        blk_chol(); blk_rows(); blk_hh_route(); blk_flags(); blk_back();
+        return;
+    }
     launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), s0);
+    if (phase == 1) {   // only what the sweep needs (forked like order 0 when the plan has side streams)
+        if (s1 != s0) p.depend(s1, s0);
+        if (s2 != s0) p.depend(s2, s0);
+        // (tried: the least-squares bins' partial sums u(k) = H(k,:) conj(g_k) on the prologue's stream, off this path -- 2755-2813 against
+        // 2802-2855 sets/s at 20 steps: the Gram route then queued behind the HRIR transform in one hardware queue)
+        blk_array(); blk_prologue(); blk_basis(); blk_gram(); blk_gterms(); blk_gram_route();
+        p.depend(s0, s2);   // (spectra of the least-squares bins, |H|)
+        p.depend(s0, s3);   // (M_k of the Gram-route bins when that route has a stream of its own)
+        blk_tail();
+        p.mark("yri_operands");
+        return;
+    }
     if (order == 1) {          // bandwidth-bound kernels first
         blk_array(); blk_prologue(); blk_basis(); blk_gram(); blk_gterms();
         blk_chol(); blk_rows(); blk_gram_route(); blk_hh_route(); blk_flags(); blk_back(); blk_tail();
@@ -2107,6 +2145,15 @@ static int stagger_mode() {
     static const int m = [] { const char* e = getenv("EMAGLS_STAGGER"); return e ? atoi(e) : 1; }();
     return m;
 }
+// a lane batch whose designs all keep the orthonormal route of their low bins off the path to the sweep (plan_defers_hh_route)
+bool batch_defers_hh(const emagls_batch& b) {
+    // Only a batch that has the device to itself (a job list of ONE chunk: b.alone, set with its forked streams): there the stages are
+    // the path to the sweep -- 2570-2620 -> 2810-2880 sets/s at 20 steps although the sweep itself runs 10 % longer next to them.  With
+    // four chunks in flight the same work only moves, and the slower sweeps cost 6 % (3470 -> 3270 at 128 steps).
+    if (!b.lanes || !b.alone || b.geo_share || b.atf_share) return false;
+    for (const emagls_plan* p : b.plans) if (!p || !plan_defers_hh_route(*p)) return false;
+    return true;
+}
 void batch_lanes_part(emagls_batch& b, int part, int first, int count, hipStream_t st, int group = 0) {
     emagls_plan& p0 = *b.plans[first];
     hipStream_t keep = p0.stream, keep_side[3] = {p0.side[0], p0.side[1], p0.side[2]};
@@ -2120,10 +2167,13 @@ void batch_lanes_part(emagls_batch& b, int part, int first, int count, hipStream
         else if (sm >= 10) p0.stage_order = group == 0 ? sm / 10 % 10 : sm % 10;   // (experiments: "12", "21", "11", "22")
     }
     if (p0.nstreams > 1) for (int i = 0; i < 3; ++i) p0.side[i] = b.side[i];
-    auto restore = [&] { p0.stream = keep; p0.nstreams = keep_streams; p0.stage_order = keep_order; for (int i = 0; i < 3; ++i) p0.side[i] = keep_side[i]; };
+    const int keep_phase = p0.pre_phase;
+    // part 0 of a batch that runs the orthonormal route next to its sweep: only what the sweep needs; part 3: the rest
+    p0.pre_phase = part == 3 ? 2 : (part == 0 && b.defer_hh) ? 1 : 0;
+    auto restore = [&] { p0.stream = keep; p0.nstreams = keep_streams; p0.stage_order = keep_order; p0.pre_phase = keep_phase; for (int i = 0; i < 3; ++i) p0.side[i] = keep_side[i]; };
     try {
         BatchScope sc(count, b.stride);
-        if (part == 0) plan_pre_stage(p0); else emagls_post_sweep(p0);
+        if (part == 0) plan_pre_stage(p0); else if (part == 3) emagls_pre_sweep(p0); else emagls_post_sweep(p0);
     } catch (...) {
         restore();
         throw;
@@ -2145,10 +2195,16 @@ void batch_execute_lanes(emagls_batch& b) {
     for (int g = 1; g < ng; ++g) gs[g] = b.side[g - 1];
     hipGraph_t* gr[4] = {&b.graph, &b.graph2, &b.graphx[0], &b.graphx[1]};
     hipGraphExec_t* ge[4] = {&b.graph_exec, &b.graph2_exec, &b.graphx_exec[0], &b.graphx_exec[1]};
+    // the stages the sweep does not need (Cholesky factor, orthonormal route of the low bins) run NEXT to it, one stream per lane group
+    // (decided on the eager run and when the graphs are captured; a replay keeps what its graphs were captured with)
+    if (!replay || !b.graph_exec) b.defer_hh = batch_defers_hh(b);
+    const bool defer = b.defer_hh;
+    if (defer) for (int g = 0; g < ng; ++g) if (!b.hh_stream[g]) b.hh_stream[g] = emagls::pool_stream_take();
     if (replay && !b.graph_exec) {
         for (int g = 0; g < ng; ++g) {
             const int f = batch_group_first(b, g), c = batch_group_first(b, g + 1) - f;
             capture_into(gs[g], gr[g], ge[g], [&] { batch_lanes_part(b, 0, f, c, gs[g], g); });
+            if (defer) capture_into(b.hh_stream[g], &b.graph_hh[g], &b.graph_hh_exec[g], [&] { batch_lanes_part(b, 3, f, c, b.hh_stream[g], g); });
         }
         capture_into(b.stream, &b.post_graph, &b.post_exec, [&] { batch_lanes_part(b, 2, 0, n, b.stream); });
     }
@@ -2171,8 +2227,16 @@ void batch_execute_lanes(emagls_batch& b) {
             if (replay) HIP_CHECK(hipGraphLaunch(*ge[g], gs[g])); else batch_lanes_part(b, 0, f, c, gs[g], g);
         }
     }
+    if (defer) for (int g = 0; g < ng; ++g) b.depend(b.hh_stream[g], gs[g]);   // (behind the group's stages, before the sweep is enqueued)
     for (int g = 1; g < ng; ++g) b.depend(b.stream, gs[g]);
     batch_sweep_stage(b);   // (never captured: see SweepGate)
+    if (defer) {
+        for (int g = 0; g < ng; ++g) {
+            const int f = batch_group_first(b, g), c = batch_group_first(b, g + 1) - f;
+            if (replay) HIP_CHECK(hipGraphLaunch(b.graph_hh_exec[g], b.hh_stream[g])); else batch_lanes_part(b, 3, f, c, b.hh_stream[g], g);
+            b.depend(b.stream, b.hh_stream[g]);   // (the epilogue reads the rows of every bin)
+        }
+    }
     if (replay) HIP_CHECK(hipGraphLaunch(b.post_exec, b.stream)); else batch_lanes_part(b, 2, 0, n, b.stream);
     emagls_plan& p0 = *b.plans[0];
     for (auto* p : b.plans) {
@@ -2670,6 +2734,10 @@ void drop_batch_graphs(emagls_batch& b) {
     for (int i = 0; i < 2; ++i) {
         if (b.graphx_exec[i]) { HIP_CHECK(hipGraphExecDestroy(b.graphx_exec[i])); b.graphx_exec[i] = nullptr; }
         if (b.graphx[i]) { HIP_CHECK(hipGraphDestroy(b.graphx[i])); b.graphx[i] = nullptr; }
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (b.graph_hh_exec[i]) { HIP_CHECK(hipGraphExecDestroy(b.graph_hh_exec[i])); b.graph_hh_exec[i] = nullptr; }
+        if (b.graph_hh[i]) { HIP_CHECK(hipGraphDestroy(b.graph_hh[i])); b.graph_hh[i] = nullptr; }
     }
     b.eager_runs = 0;
 }
@@ -3677,6 +3745,9 @@ int emagls_batch_set_streams(emagls_batch* b, int nstreams) {
         for (int i = 0; i < nstreams - 1; ++i) if (!b->side[i]) b->side[i] = emagls::pool_stream_take();
         if (nstreams != b->nstreams) drop_batch_graphs(*b);   // (the next execute runs eagerly, the one after it captures the forks)
         b->nstreams = nstreams;
+        // (forked stages are for a batch that has the device to itself: it also runs what the sweep does not need next to the sweep)
+        static const int defer_mode = [] { const char* e = getenv("EMAGLS_DEFER_HH"); return e ? atoi(e) : 1; }();
+        b->alone = nstreams >= 2 || defer_mode == 2;
     });
 }
 int emagls_batch_set_stage_order(emagls_batch* b, int order) {
@@ -4243,6 +4314,7 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
                 if (slot->batch->groups != 1) { HIP_CHECK(hipStreamSynchronize(slot->batch->stream)); drop_batch_graphs(*slot->batch); slot->batch->groups = 1; }
                 check_rc(emagls_batch_set_streams(slot->batch, fork));
             }
+            slot->batch->alone = true;   // (also with EMAGLS_JOBS_FORK=1)
         }
         lap("batch created");
     } else if (slot->batch) {

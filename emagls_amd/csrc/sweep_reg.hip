@@ -138,7 +138,7 @@ constexpr int RG_SVC = 256;           // threads that serve the workgroup: excha
 
 // NUL: unit slots per lane (a direction's units are split between the two waves of a pair: 2 NUL >= units); NW: waves per workgroup
 template <int NUL, int NW>
-__global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs* __restrict__ args, int n, int nWG, int spread) {
+__global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs* __restrict__ args, int n, int nWG, int spread, int prio) {
     constexpr int NT = 64 * NW, DPW = 32 * NW, NB = NW / 2;   // threads, directions and 64-direction blocks of a workgroup
     constexpr int NU2 = 2 * NUL;            // unit slots of a direction
     constexpr int NCH = (NUL + 1) / 2;      // chunks of two slots in the wave reduction
@@ -173,6 +173,9 @@ __global__ void __launch_bounds__(64 * NW) sweep_reg_kernel(const HalfSweepArgs*
         design = xcd + 8 * sub;
     }
     if (design >= n) return;
+    // the chain's waves ahead of whatever shares their SIMDs (the stages of other chunks; a lone chunk's own orthonormal route, which runs
+    // next to its sweep since round 6): priority 3 of 0..3.  EMAGLS_REG_PRIO=0 (argument `prio`): the default priority.
+    if (prio) __builtin_amdgcn_s_setprio(3);
     const HalfSweepArgs& a = args[design];
     const int tid = threadIdx.x;
     const int C = a.C, P = a.P, D = a.D, kfirst = a.kfirst, kabs0 = a.kabs0;   // C: microphones (the chain's channels)
@@ -614,12 +617,13 @@ void launch_sweep_reg(const HalfSweepArgs* args_dev, const HalfSweepArgs& a0, in
     const unsigned nblocks = spread ? (unsigned)(n * nWG) : 8u * (unsigned)nWG * (unsigned)ceil_div(n, 8);
     const size_t dyn = reg_dyn_bytes(RG_NUL, nw);
     reg_set_attributes();
+    static const int prio = [] { const char* e = getenv("EMAGLS_REG_PRIO"); return e ? atoi(e) : 1; }();
     switch (nw) {
-        case 4: sweep_reg_kernel<RG_NUL, 4><<<dim3(nblocks), 256, dyn, st>>>(args_dev, n, nWG, spread); break;
-        case 6: sweep_reg_kernel<RG_NUL, 6><<<dim3(nblocks), 384, dyn, st>>>(args_dev, n, nWG, spread); break;
-        case 8: sweep_reg_kernel<RG_NUL, 8><<<dim3(nblocks), 512, dyn, st>>>(args_dev, n, nWG, spread); break;
-        case 10: sweep_reg_kernel<RG_NUL, 10><<<dim3(nblocks), 640, dyn, st>>>(args_dev, n, nWG, spread); break;
-        default: sweep_reg_kernel<RG_NUL, 12><<<dim3(nblocks), 768, dyn, st>>>(args_dev, n, nWG, spread); break;
+        case 4: sweep_reg_kernel<RG_NUL, 4><<<dim3(nblocks), 256, dyn, st>>>(args_dev, n, nWG, spread, prio); break;
+        case 6: sweep_reg_kernel<RG_NUL, 6><<<dim3(nblocks), 384, dyn, st>>>(args_dev, n, nWG, spread, prio); break;
+        case 8: sweep_reg_kernel<RG_NUL, 8><<<dim3(nblocks), 512, dyn, st>>>(args_dev, n, nWG, spread, prio); break;
+        case 10: sweep_reg_kernel<RG_NUL, 10><<<dim3(nblocks), 640, dyn, st>>>(args_dev, n, nWG, spread, prio); break;
+        default: sweep_reg_kernel<RG_NUL, 12><<<dim3(nblocks), 768, dyn, st>>>(args_dev, n, nWG, spread, prio); break;
     }
     KERNEL_CHECK();
 }

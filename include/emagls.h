@@ -437,7 +437,10 @@ int emagls_batch_sweep_time(emagls_batch* batch, double* ms);
  * design fork onto side streams and the captured graph carries the forks: [HRIR-grid SH matrix, Gram matrix, Cholesky factor,
  * Householder-route factors] | [array model, order terms, G_k of every bin] | [HRIR prologue, least-squares right-hand sides]
  * | [Gram-route factors].  Shortens the path to the batch's sweep from the sum of the kernels to its longest branch (what a
- * short run, a pipeline filling from empty, is bound by); with many batches in flight it only adds queue contention. */
+ * short run, a pipeline filling from empty, is bound by); with many batches in flight it only adds queue contention.  A batch with
+ * forked stages is taken to have the device to itself: what its sweep does not need -- the Cholesky factor and the orthonormal
+ * route of the ill-conditioned low bins, which only feed the filters' rows (lib/getEMagLsFilters.m:94) -- then runs NEXT to the sweep
+ * on a stream of its own (designs on the synthesising sweep; EMAGLS_DEFER_HH=0 keeps everything before the sweep). */
 int emagls_batch_set_streams(emagls_batch* batch, int nstreams);
 /* Lane mode, one stream: the order in which a batch of up to 8 designs issues the stages before its sweep.  0 (default): the
  * order of a single design.  1: the kernels that fill the chip first (HRIR transform, SH Gram matrix, G_k of every bin), the
