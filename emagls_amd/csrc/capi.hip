@@ -260,6 +260,9 @@ struct emagls_plan {
     int nstreams = 1;
     int stage_order = 0;          // order of the stages before the sweep (emagls_pre_sweep): 0 branches, 1 / 2 the complementary single-stream orders of lane groups
     int pre_phase = 0;            // emagls_pre_sweep: 0 everything, 1 only what the sweep needs, 2 the rest (plan_defers_hh_route)
+    bool defer_hh = false;        // plan_execute: what the captured stages before the sweep were captured with
+    bool alone = false;           // the plan of a one-shot call (the device to itself, like a plan with forked stages)
+    hipStream_t hh_stream = nullptr;   // the stream of the stages that run next to the sweep
     hipStream_t sync_stream = nullptr;  // stream whose completion means this plan's results are ready
     // fork/join inside one design: independent branches run on side streams (captured into the same graph)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // taken from the pool when a multi-stream execute first needs them (need_sides)
@@ -289,6 +292,7 @@ struct emagls_plan {
         // enqueued by this plan may still be running on them
         if (stream) hipStreamSynchronize(stream);
         for (auto st : side) if (st) hipStreamSynchronize(st);
+        if (hh_stream) hipStreamSynchronize(hh_stream);
         (void)hipGetLastError();
         for (auto& kv : bufs) if (kv.second.p && kv.second.owned) hipFree(kv.second.p);
         release_slabs();
@@ -296,6 +300,7 @@ struct emagls_plan {
         for (auto e : sweep_events) hipEventDestroy(e);
         for (auto e : sync_events) hipEventDestroy(e);
         for (auto st : side) StreamPool::get().give(st);
+        StreamPool::get().give(hh_stream);
         if (graph_exec) hipGraphExecDestroy(graph_exec);
         if (graph) hipGraphDestroy(graph);
         if (pre_exec) hipGraphExecDestroy(pre_exec);
@@ -2041,9 +2046,28 @@ void plan_execute(emagls_plan& p) {
     if (p.prof_level == 0 && p.use_graph && persist) {
         // the persistent sweep is launched directly (SweepChain); the stages before it are captured from the second
         // execute on (the first runs eagerly: one-time function attributes, lazy module load)
-        if (!p.pre_exec && p.eager_runs >= 1) capture_into(p.stream, &p.pre_graph, &p.pre_exec, [&] { plan_pre_stage(p); });
-        if (p.pre_exec) HIP_CHECK(hipGraphLaunch(p.pre_exec, p.stream)); else plan_pre_stage(p);
+        // a design with forked stages (it has the device to itself) runs what its sweep does not need -- Cholesky factor, orthonormal
+        // route of the low bins: plan_defers_hh_route -- NEXT to the sweep, eagerly on a stream of its own (a dozen launches)
+        if (!p.pre_exec) p.defer_hh = (p.nstreams >= 2 || p.alone) && array_kind(d.kind) && plan_defers_hh_route(p);
+        p.pre_phase = p.defer_hh ? 1 : 0;
+        try {
+            if (!p.pre_exec && p.eager_runs >= 1) capture_into(p.stream, &p.pre_graph, &p.pre_exec, [&] { plan_pre_stage(p); });
+            if (p.pre_exec) HIP_CHECK(hipGraphLaunch(p.pre_exec, p.stream)); else plan_pre_stage(p);
+        } catch (...) { p.pre_phase = 0; throw; }
+        p.pre_phase = 0;
+        if (p.defer_hh) {
+            if (!p.hh_stream) p.hh_stream = StreamPool::get().take();
+            p.depend(p.hh_stream, p.stream);   // (behind the stages the sweep needs, before the sweep is enqueued)
+        }
         emagls_run_sweep(p);
+        if (p.defer_hh) {
+            hipStream_t keep = p.stream;
+            const int keep_n = p.nstreams;
+            p.stream = p.hh_stream; p.nstreams = 1; p.pre_phase = 2;
+            try { emagls_pre_sweep(p); } catch (...) { p.stream = keep; p.nstreams = keep_n; p.pre_phase = 0; throw; }
+            p.stream = keep; p.nstreams = keep_n; p.pre_phase = 0;
+            p.depend(p.stream, p.hh_stream);   // (the epilogue reads the rows of every bin)
+        }
         if (d.kind == EMAGLS_KIND_FROM_ATF) from_atf_post_sweep(p);
         else if (magls_kind(d.kind)) magls_post_sweep(p);
         else emagls_post_sweep(p);
@@ -3099,6 +3123,7 @@ int one_shot(const emagls_design_desc& desc, const double* hL, const double* hR,
                 // is captured and replayed inside whatever session the caller runs.  EMAGLS_ONESHOT_STREAMS=3 restores the forks.
                 const char* e = getenv("EMAGLS_ONESHOT_STREAMS");
                 fresh->nstreams = e ? std::max(1, std::min(3, atoi(e))) : 1;
+                fresh->alone = true;   // (a one-shot call has the device to itself: the orthonormal route of the low bins runs next to the sweep)
             }
             p = fresh.get();
         }
