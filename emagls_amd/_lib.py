@@ -49,6 +49,7 @@ SYMBOLS = {
     "emagls_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "emagls_set_device": (C.c_int, [C.c_int]),
     "emagls_cache_clear": (C.c_int, []),
+    "emagls_cache_release_designs": (C.c_int, []),
     "emagls_fp64_peak_tflops": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "emagls_fp64_peak_tflops_ex": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "emagls_self_test": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),

@@ -91,14 +91,17 @@ struct DevBuf {
 // Device memory of plans (slabs) and batches (arenas) comes from a process-wide pool of blocks that are handed back instead of freed:
 // a job list whose plans live for one chunk each otherwise pays hipMalloc / hipFree of ~0.35 GB per design again and again (and
 // the calls were erratic next to running kernels: 30 ms ... 1.6 s for the plans of one chunk).  emagls_cache_clear() frees the pool;
-// EMAGLS_POOL_GB (default 64) bounds what it keeps.
+// EMAGLS_POOL_GB (default 128) bounds what it keeps.
 struct BlockPool {
     std::mutex mu;
     std::map<int, std::multimap<size_t, void*>> free_;   // device -> size -> block
     size_t held = 0;
     static BlockPool& get() { static BlockPool* p = new BlockPool; return *p; }   // (never destroyed: plans of static caches hand their blocks back at exit)
     static size_t cap() {
-        static const size_t c = [] { const char* e = getenv("EMAGLS_POOL_GB"); return (size_t)(e ? std::max(0, atoi(e)) : 64) << 30; }();
+        // (128 GB of the 288: a rank's share of BASELINE config 4 holds two arenas of 21 GB -- the small radii keep materialised
+        // operands, 1.5 GB per design -- plus as much again in released plan slabs while the next chunks are being built; with 64 GB the
+        // arenas were freed and every list of new radii allocated them afresh, 0.3 ms ... 5 s per hipMalloc)
+        static const size_t c = [] { const char* e = getenv("EMAGLS_POOL_GB"); return (size_t)(e ? std::max(0, atoi(e)) : 128) << 30; }();
         return c;
     }
     // Sizes of large blocks (batch arenas: gigabytes) come in classes -- multiples of an eighth of the power of two below them -- so that
@@ -111,14 +114,19 @@ struct BlockPool {
         return (bytes + step - 1) / step * step;
     }
     // a block of at least `bytes` (exactly `bytes` when it has to be allocated); *got = its size
-    void* take(size_t bytes, size_t* got) {
+    // (alloc_bytes: what a miss allocates -- an arena asks for a block that holds its need and, when there is none, allocates the size
+    // class of an eighth more: the next list's need, a few per cent larger, then fits the block this one hands back)
+    void* take(size_t bytes, size_t* got, size_t alloc_bytes = 0) {
+        if (alloc_bytes < bytes) alloc_bytes = bytes;
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
         {
             std::lock_guard<std::mutex> lk(mu);
             auto& fl = free_[dev];
             auto it = fl.lower_bound(bytes);
-            if (it != fl.end() && it->first <= bytes + bytes / 4) {
+            // (the smallest block that is large enough, up to a quarter larger -- half larger for the gigabyte-sized arenas, whose need
+            // moves by a few per cent from one list of array radii to the next: fresh device memory for 2 x 4.5 GB took 3.6 s there)
+            if (it != fl.end() && it->first <= bytes + (bytes >= ((size_t)1 << 30) ? bytes / 2 : bytes / 4)) {
                 void* p = it->second;
                 *got = it->first;
                 held -= it->first;
@@ -127,14 +135,22 @@ struct BlockPool {
             }
         }
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, bytes);
+        const auto t_alloc0 = std::chrono::steady_clock::now();
+        hipError_t e = hipMalloc(&p, alloc_bytes);
+        if (trace_on() && alloc_bytes >= ((size_t)256 << 20)) {
+            std::lock_guard<std::mutex> lk(mu);
+            std::string have;
+            for (auto& kv : free_[dev]) if (kv.first >= ((size_t)256 << 20)) have += " " + std::to_string(kv.first >> 20);
+            fprintf(stderr, "emagls trace: block pool miss: need %zu MB, hipMalloc of %zu MB took %.1f ms; large blocks in the pool (MB):%s\n", bytes >> 20, alloc_bytes >> 20,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc0).count(), have.c_str());
+        }
         if (e == hipErrorOutOfMemory) {   // the pool may hold gigabytes of blocks of other sizes: return them to the runtime and try once more
             (void)hipGetLastError();
             clear();
-            e = hipMalloc(&p, bytes);
+            e = hipMalloc(&p, alloc_bytes);
         }
         HIP_CHECK(e);
-        *got = bytes;
+        *got = alloc_bytes;
         return p;
     }
     void give(void* p, size_t bytes) {
@@ -941,6 +957,15 @@ void plan_setup(emagls_plan& p) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "emagls trace: plan setup: streams %.3f ms, %zu buffers in %zu slabs %.3f ms, final sync %.3f ms\n", ms(t_setup0, t_setup1), p.bufs.size(),
                 p.slabs.size(), ms(t_setup1, t_setup2), ms(t_setup2, t_setup3));
+        static std::atomic<int> shown{0};
+        if (shown.fetch_add(1) % 64 == 0) {   // (every 64th plan: its largest buffers)
+            std::vector<std::pair<size_t, std::string>> big;
+            for (auto& kv : p.bufs) big.emplace_back(kv.second.bytes, kv.first);
+            std::sort(big.rbegin(), big.rend());
+            std::string line;
+            for (size_t i = 0; i < big.size() && i < 12; ++i) line += " " + big[i].second + "=" + std::to_string(big[i].first >> 20);
+            fprintf(stderr, "emagls trace: plan of %lld MB (sim order %d, S_h %d, hh_end %d); largest buffers (MB):%s\n", (long long)(p.total_bytes >> 20), p.simOrder, p.S_h, p.hh_end, line.c_str());
+        }
     }
 }
 
@@ -2936,7 +2961,10 @@ void batch_try_lanes(emagls_batch& b) {
     stride = (stride + 4095) / 4096 * 4096;
     trace_mark("lanes: shapes compared");
     auto arena = std::make_shared<Arena>();
-    arena->base = BlockPool::get().take(BlockPool::size_class(stride * b.plans.size()), &arena->bytes);
+    {
+        const size_t need = stride * b.plans.size();
+        arena->base = BlockPool::get().take(need, &arena->bytes, BlockPool::size_class(need + need / 8));
+    }
     for (size_t j = 0; j < b.plans.size(); ++j) {   // (one launch per 96 buffers: move_buffers_kernel)
         emagls_plan& p = *b.plans[j];
         size_t i = 0;
@@ -3228,6 +3256,18 @@ int emagls_set_device(int device) {
 void emagls_sets_cache_clear_internal();
 void emagls_atfsets_cache_clear_internal();
 void emagls_jobs_cache_clear_internal();
+int emagls_cache_release_designs(void) {
+    return guarded([&] {
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (size_t i = g_cache.size(); i-- > 0;)
+                if (!g_cache[i].busy) g_cache.erase(g_cache.begin() + i);
+        }
+        emagls_sets_cache_clear_internal();
+        emagls_atfsets_cache_clear_internal();
+        emagls_jobs_cache_clear_internal();
+    });
+}
 int emagls_cache_clear(void) {
     return guarded([&] {
         {

@@ -61,8 +61,13 @@ int emagls_set_device(int device);
 
 /* The one-shot entry points below keep the plans of their most recent shapes alive (device buffers, captured hipGraphs; at most
  * EMAGLS_PLAN_CACHE plans, default 4, 0 disables), and emagls_binaural_decode its hipFFT plans and work buffers.  This call
- * releases all of it (a MEX gateway registers it with mexAtExit). */
+ * releases all of it (a MEX gateway registers it with mexAtExit), together with the resident chunks of the job lists and the pool of
+ * device-memory blocks that plans and batches hand back. */
 int emagls_cache_clear(void);
+/* The same without the block pool: every resident plan, batch and job chunk goes, their device memory stays with the library for the
+ * next designs (a long-running process that moves on to another study: fresh device memory is what costs -- hipMalloc of a few GB took
+ * 0.3 ms on some boxes and seconds on others, profiles/r06_cold_path.md). */
+int emagls_cache_release_designs(void);
 
 /* Measured FP64 peak of the current device in TFLOP/s (best of a few launches that keep every CU busy): which = 0 the matrix
  * pipe on v_mfma_f64_16x16x4_f64 (the shape the pipeline's GEMM kernels issue), which = 1 the vector pipe (v_fma_f64), which = 2
