@@ -406,7 +406,7 @@ struct emagls_batch {
     hipGraphExec_t graph_hh_exec[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t hh_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     bool defer_hh = false;                     // what the captured graphs were captured with (batch_execute_lanes)
-    bool alone = false;                        // the batch has the device to itself (the job scheduler's single-chunk lists; EMAGLS_DEFER_HH=2: every lane batch)
+    bool alone = true;                         // the batch has the device to itself: the default of emagls_batch_create; the job scheduler clears it for the chunks of a list that keeps several in flight
     int eager_runs = 0;
     bool use_graph = true;
     void* sweep_args_dev = nullptr;            // argument blocks of the register-resident sweep, one per plan (sweep_reg.hip)
@@ -2199,7 +2199,8 @@ bool batch_defers_hh(const emagls_batch& b) {
     // Only a batch that has the device to itself (a job list of ONE chunk: b.alone, set with its forked streams): there the stages are
     // the path to the sweep -- 2570-2620 -> 2810-2880 sets/s at 20 steps although the sweep itself runs 10 % longer next to them.  With
     // four chunks in flight the same work only moves, and the slower sweeps cost 6 % (3470 -> 3270 at 128 steps).
-    if (!b.lanes || !b.alone || b.geo_share || b.atf_share) return false;
+    static const int defer_mode = [] { const char* e = getenv("EMAGLS_DEFER_HH"); return e ? atoi(e) : 1; }();   // (2: every lane batch -- experiments)
+    if (!b.lanes || !(b.alone || defer_mode == 2) || b.geo_share || b.atf_share) return false;
     for (const emagls_plan* p : b.plans) if (!p || !plan_defers_hh_route(*p)) return false;
     return true;
 }
@@ -3810,9 +3811,6 @@ int emagls_batch_set_streams(emagls_batch* b, int nstreams) {
         for (int i = 0; i < nstreams - 1; ++i) if (!b->side[i]) b->side[i] = emagls::pool_stream_take();
         if (nstreams != b->nstreams) drop_batch_graphs(*b);   // (the next execute runs eagerly, the one after it captures the forks)
         b->nstreams = nstreams;
-        // (forked stages are for a batch that has the device to itself: it also runs what the sweep does not need next to the sweep)
-        static const int defer_mode = [] { const char* e = getenv("EMAGLS_DEFER_HH"); return e ? atoi(e) : 1; }();
-        b->alone = nstreams >= 2 || defer_mode == 2;
     });
 }
 int emagls_batch_set_stage_order(emagls_batch* b, int order) {
@@ -4379,7 +4377,10 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
                 if (slot->batch->groups != 1) { HIP_CHECK(hipStreamSynchronize(slot->batch->stream)); drop_batch_graphs(*slot->batch); slot->batch->groups = 1; }
                 check_rc(emagls_batch_set_streams(slot->batch, fork));
             }
-            slot->batch->alone = true;   // (also with EMAGLS_JOBS_FORK=1)
+        }
+        if (slot->batch) {
+            slot->batch->alone = solo;   // (chunks in flight next to each other keep the orthonormal route before their sweeps: batch_defers_hh)
+            if (!solo && slot->batch->graph_exec) { HIP_CHECK(hipStreamSynchronize(slot->batch->stream)); drop_batch_graphs(*slot->batch); }
         }
         lap("batch created");
     } else if (slot->batch) {

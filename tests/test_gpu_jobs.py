@@ -90,3 +90,41 @@ def test_design_out_shape_equals_the_plans(thin, grids):
         L.check(lib.emagls_design_out_shape(C.byref(d), C.byref(r), C.byref(c), C.byref(z)))
         assert (r.value, c.value, bool(z.value)) == (i.out_rows, i.out_cols, bool(i.out_is_complex)), (kind, basis)
         p.close()
+
+
+def test_sweep_gate_counts_launches_until_they_finish(grids, thin, monkeypatch):
+    """Register-resident sweeps of different sizes in flight at once (the gate dropped a launch from its count as soon as
+    ONE later launch waited for it, so a third launch could start next to a 32-design sweep that had not finished -- both only partly
+    resident, spinning until the time-out).  A list of 32 + 12 + 12 + 32 + 12 designs on a small grid, four chunks in flight, the
+    in-kernel wait for peers raised to 2 s: a launch that is not resident shows as a failure (status word 1 -> EMAGLS_ERR_HIP after
+    the launch-per-bin re-run is refused for chunks above 16) or as seconds of run time, not as a silent fallback."""
+    import time
+    from emagls_amd import _lib as L
+    from emagls_amd.jobs import JobList
+    monkeypatch.setenv("EMAGLS_SWEEP_WAIT_MS", "2000")
+    azi, zen, maz, mzn = thin["azi"], thin["zen"], grids["mic_azi"], grids["mic_zen"]
+    rng = np.random.default_rng(5)
+    sizes = [32, 12, 12, 32, 12]
+    jl = JobList()
+    order = []
+    for ci, n in enumerate(sizes):     # chunks end where the shape changes: alternate two filter lengths
+        length = 128 if ci % 2 == 0 else 160
+        for _ in range(n):
+            hL, hR = thin["hL"] * (1.0 + 0.05 * rng.standard_normal()), thin["hR"] * (1.0 + 0.05 * rng.standard_normal())
+            jl.add(L.KIND_EMAGLS, "complex", 4, 48000.0, length, hL, hR, azi, zen, mic_radius=0.042, mic_azi=maz, mic_zen=mzn, out_shape=(length, 25, True))
+            order.append((hL, hR, length))
+    for rep in range(3):     # eager, capture, replay -- every chunk again
+        t0 = time.perf_counter()
+        jl.run(batch_size=32, in_flight=4)
+        dt = time.perf_counter() - t0
+        assert dt < 1.5, f"run {rep} took {dt:.2f} s: a sweep launch waited for workgroups that were not resident"
+    res = jl.results()
+    import emagls_amd as E
+    worst = 0.0
+    for j in (0, 31, 32, 43, 56, 87, 99):
+        hL, hR, length = order[j]
+        w = E.getEMagLsFilters(hL, hR, azi, zen, 0.042, maz, mzn, 4, 48000.0, length, "complex")
+        worst = max(worst, rel(res[j][0], w[0]), rel(res[j][1], w[1]))
+    print(f"sweeps of 32 + 12 + 12 + 32 + 12 designs in flight: worst rel vs the single calls = {worst:.3e}")
+    assert worst < 1e-9
+    L.check(L.load().emagls_cache_clear())
