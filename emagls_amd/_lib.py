@@ -145,6 +145,8 @@ SYMBOLS = {
                                             C.POINTER(C.c_double)]),
     "emagls_jobs_run": (C.c_int, [C.POINTER(Job), C.c_int64, C.c_int, C.c_int, C.c_int]),
     "emagls_design_out_shape": (C.c_int, [C.POINTER(DesignDesc), C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(C.c_int)]),
+    "emagls_jobs_shard": (C.c_int, [C.POINTER(Job), C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "emagls_jobs_run_devices": (C.c_int, [C.POINTER(Job), C.c_int64, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]),
     "emagls_jobs_set_profiling": (C.c_int, [C.c_int]),
     "emagls_jobs_sweep_times": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "emagls_batch_set_geometry_sharing": (C.c_int, [C.c_void_p, C.c_int]),

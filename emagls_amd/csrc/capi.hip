@@ -4555,6 +4555,162 @@ int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int i
         if (err_code != EMAGLS_OK) throw Error(err_code, err_msg);
     });
 }
+// ---------------------------------------------------------------------------------------------
+// Job lists over several GPUs at the C boundary: the split of emagls_amd/batch.py restated in C, and a runner that
+// drives the devices of ONE process from a thread each -- what a MEX caller (one MATLAB process) or any C host has without
+// torch.distributed.  One process per GPU with an RCCL gather is the other form (emagls_amd/batch.py; INTEGRATION.md shows both).
+// ---------------------------------------------------------------------------------------------
+namespace {
+// run time model of one lane batch of n designs laid out for sim_order (emagls_amd/batch.py: batch_cost, measured in round 4)
+double shard_batch_cost(int n, int sim_order) {
+    const double S = (double)(sim_order + 1) * (sim_order + 1), g = n / 8.0;
+    if (sim_order < 19) return 5.6 + 7.2 * g;
+    return (6.4 + 2.4 * g) + (1.67 + 1.93 * g) * 1e-3 * S;
+}
+// emagls_amd/batch.py: padded_lane_batches(sim_orders, max_batch, balance=True) -- consecutive chunks of the jobs sorted by simulation
+// order, cut at equal COST; returns (first, size) into `order`
+std::vector<std::pair<int, int>> shard_padded_batches(const std::vector<int>& so_sorted, int max_batch) {
+    const int n = (int)so_sorted.size();
+    const int nb = (n + max_batch - 1) / max_batch;
+    std::vector<std::pair<int, int>> out;
+    if (nb <= 1) { out.emplace_back(0, n); return out; }
+    auto cut = [&](double T, std::vector<std::pair<int, int>>& chunks) {
+        chunks.clear();
+        int pos = 0;
+        while (pos < n) {
+            if (shard_batch_cost(1, so_sorted[pos]) > T) return false;
+            int size = 1;
+            while (pos + size < n && size < 32 && shard_batch_cost(size + 1, so_sorted[pos + size]) <= T) ++size;
+            chunks.emplace_back(pos, size);
+            pos += size;
+        }
+        return true;
+    };
+    double lo = 0.0, hi = shard_batch_cost(32, so_sorted.back()) + 1.0;
+    std::vector<std::pair<int, int>> c;
+    for (int it = 0; it < 40; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (cut(mid, c) && (int)c.size() <= nb) hi = mid; else lo = mid;
+    }
+    cut(hi, out);
+    return out;
+}
+struct ShardUnit { std::vector<int> jobs; int pad = 0; double cost = 1.0; };
+// the units of a list (lane batches of array-radius families, single jobs otherwise) in list order of their first job
+void shard_units(const emagls_job* jobs, int64_t njobs, int max_batch, std::vector<ShardUnit>& units) {
+    // families: everything but the array radius (and the padding) equal
+    std::map<std::string, std::vector<int>> fam;
+    std::vector<std::string> fam_order;
+    for (int64_t j = 0; j < njobs; ++j) {
+        emagls_design_desc k = jobs[j].desc;
+        const bool radius_family = (k.kind == EMAGLS_KIND_EMAGLS || k.kind == EMAGLS_KIND_EMAGLS2 || k.kind == EMAGLS_KIND_EMA_CH) && !k.custom_basis && k.nmics <= 32;
+        if (radius_family) { k.mic_radius = 0.0; k.sim_order_pad = 0; }
+        std::string key(reinterpret_cast<const char*>(&k), sizeof k);
+        key.push_back(radius_family ? 'R' : 'E');
+        if (!fam.count(key)) fam_order.push_back(key);
+        fam[key].push_back((int)j);
+    }
+    for (const std::string& key : fam_order) {
+        const std::vector<int>& idx = fam[key];
+        if (key.back() == 'R' && idx.size() > 1) {
+            std::vector<int> order(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) order[i] = (int)i;
+            auto so_of = [&](int i) { const emagls_design_desc& d = jobs[idx[(size_t)i]].desc; return emagls_simulation_order(d.kind, d.order, d.fs, d.mic_radius); };
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return so_of(a) < so_of(b); });
+            std::vector<int> so_sorted(order.size());
+            for (size_t i = 0; i < order.size(); ++i) so_sorted[i] = so_of(order[i]);
+            if (so_sorted.front() == so_sorted.back()) {   // one simulation-order class: equal jobs, a unit each (the library cuts a rank's share into chunks)
+                for (int j : idx) { ShardUnit u; u.jobs.push_back(j); u.cost = 1.0; units.push_back(std::move(u)); }
+                continue;
+            }
+            for (auto& fs : shard_padded_batches(so_sorted, max_batch)) {
+                ShardUnit u;
+                for (int i = fs.first; i < fs.first + fs.second; ++i) { u.jobs.push_back(idx[(size_t)order[(size_t)i]]); u.pad = std::max(u.pad, so_sorted[(size_t)i]); }
+                u.cost = shard_batch_cost((int)u.jobs.size(), u.pad);
+                units.push_back(std::move(u));
+            }
+        } else {
+            for (int j : idx) { ShardUnit u; u.jobs.push_back(j); u.cost = 1.0; units.push_back(std::move(u)); }
+        }
+    }
+}
+}  // namespace
+
+int emagls_jobs_shard(const emagls_job* jobs, int64_t njobs, int world, int max_batch, int* rank_of_job, int* order_in_rank, int* sim_order_pad) {
+    return guarded([&] {
+        if (!jobs || njobs < 0 || world < 1 || !rank_of_job) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        if (max_batch <= 0) max_batch = 16;
+        if (max_batch > 32) throw Error(EMAGLS_ERR_ARG, "a batch holds 1..32 designs");
+        std::vector<ShardUnit> units;
+        shard_units(jobs, njobs, max_batch, units);
+        // whole units to ranks by longest processing time (ties: the earlier unit, the lower rank), cheapest first inside a rank
+        std::vector<int> by_cost(units.size());
+        for (size_t i = 0; i < units.size(); ++i) by_cost[i] = (int)i;
+        std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return units[(size_t)a].cost > units[(size_t)b].cost; });
+        std::vector<double> load((size_t)world, 0.0);
+        std::vector<std::vector<int>> mine((size_t)world);
+        for (int u : by_cost) {
+            int r = 0;
+            for (int q = 1; q < world; ++q) if (load[(size_t)q] < load[(size_t)r]) r = q;
+            mine[(size_t)r].push_back(u);
+            load[(size_t)r] += units[(size_t)u].cost;
+        }
+        for (int r = 0; r < world; ++r) {
+            std::stable_sort(mine[(size_t)r].begin(), mine[(size_t)r].end(), [&](int a, int b) {
+                return units[(size_t)a].cost < units[(size_t)b].cost || (units[(size_t)a].cost == units[(size_t)b].cost && a < b); });
+            int pos = 0;
+            for (int u : mine[(size_t)r])
+                for (int j : units[(size_t)u].jobs) {
+                    rank_of_job[j] = r;
+                    if (order_in_rank) order_in_rank[j] = pos;
+                    if (sim_order_pad) sim_order_pad[j] = units[(size_t)u].pad;
+                    ++pos;
+                }
+        }
+    });
+}
+
+int emagls_jobs_run_devices(const emagls_job* jobs, int64_t njobs, const int* devices, int ndevices, int batch_size, int in_flight, int flags) {
+    return guarded([&] {
+        if (!jobs || njobs < 0 || !devices || ndevices < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
+        int avail = 0;
+        HIP_CHECK(hipGetDeviceCount(&avail));
+        for (int i = 0; i < ndevices; ++i) if (devices[i] < 0 || devices[i] >= avail) throw Error(EMAGLS_ERR_ARG, "no such device");
+        if (njobs == 0) return;
+        std::vector<int> rank((size_t)njobs), pos((size_t)njobs), pad((size_t)njobs);
+        check_rc(emagls_jobs_shard(jobs, njobs, ndevices, std::min(batch_size > 0 ? batch_size : 16, 16), rank.data(), pos.data(), pad.data()));
+        // every device's share as a list of its own (jobs of one lane batch adjacent, laid out for the batch's simulation order)
+        std::vector<std::vector<emagls_job>> share((size_t)ndevices);
+        for (int r = 0; r < ndevices; ++r) {
+            int64_t cnt = 0;
+            for (int64_t j = 0; j < njobs; ++j) cnt += rank[(size_t)j] == r;
+            share[(size_t)r].resize((size_t)cnt);
+        }
+        for (int64_t j = 0; j < njobs; ++j) {
+            emagls_job jb = jobs[j];
+            if (pad[(size_t)j] > 0 && jb.desc.sim_order_pad == 0) jb.desc.sim_order_pad = pad[(size_t)j];
+            share[(size_t)rank[(size_t)j]][(size_t)pos[(size_t)j]] = jb;
+        }
+        std::vector<int> rc((size_t)ndevices, EMAGLS_OK);
+        std::vector<std::string> msg((size_t)ndevices);
+        auto work = [&](int r) {
+            if (share[(size_t)r].empty()) return;
+            if (hipSetDevice(devices[r]) != hipSuccess) { rc[(size_t)r] = EMAGLS_ERR_HIP; msg[(size_t)r] = "hipSetDevice failed"; return; }
+            rc[(size_t)r] = emagls_jobs_run(share[(size_t)r].data(), (int64_t)share[(size_t)r].size(), batch_size > 0 ? batch_size : 32, in_flight, flags);
+            if (rc[(size_t)r] != EMAGLS_OK) msg[(size_t)r] = g_last_error;   // (thread-local: this thread's)
+        };
+        std::vector<std::thread> th;
+        for (int r = 1; r < ndevices; ++r) th.emplace_back(work, r);
+        int keep = 0;
+        HIP_CHECK(hipGetDevice(&keep));
+        work(0);
+        for (auto& t : th) t.join();
+        HIP_CHECK(hipSetDevice(keep));
+        for (int r = 0; r < ndevices; ++r)
+            if (rc[(size_t)r] != EMAGLS_OK) throw Error(rc[(size_t)r], "device " + std::to_string(devices[r]) + ": " + msg[(size_t)r]);
+    });
+}
+
 int emagls_from_atf_hrir_sets(const double* hL, const double* hR, int64_t nsamp, int64_t ndirs, int64_t nsets, const double* hrir_azi,
                               const double* hrir_zen, const double* atf_irs, int64_t atf_taps, int64_t nmics, int64_t natf, const double* atf_azi,
                               const double* atf_zen, double fs, int64_t filter_len, double f_trans, double* wL, double* wR, double* mean_dev) {

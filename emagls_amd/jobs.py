@@ -62,13 +62,29 @@ class JobList:
     def __len__(self):
         return len(self._jobs)
 
-    def run(self, batch_size=0, in_flight=0, share_geometry=False):
-        """Runs every job added so far; returns when all filters are in place."""
+    def run(self, batch_size=0, in_flight=0, share_geometry=False, devices=None):
+        """Runs every job added so far; returns when all filters are in place.  `devices`: HIP ordinals of the GPUs of this process to
+        split the list over (emagls_jobs_run_devices: one host thread per device, host arrays in and out, no gather); None: the
+        current device."""
         n = len(self._jobs)
         if n == 0:
             return
         arr = (L.Job * n)(*self._jobs)
-        L.check(L.load().emagls_jobs_run(arr, n, int(batch_size), int(in_flight), L.JOBS_SHARE_GEOMETRY if share_geometry else 0))
+        flags = L.JOBS_SHARE_GEOMETRY if share_geometry else 0
+        if devices is None:
+            L.check(L.load().emagls_jobs_run(arr, n, int(batch_size), int(in_flight), flags))
+        else:
+            dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+            L.check(L.load().emagls_jobs_run_devices(arr, n, dev, len(devices), int(batch_size), int(in_flight), flags))
+
+    def shard(self, world, max_batch=16):
+        """(rank of every job, its position in the rank's share, the simulation order its lane batch is laid out for) -- the split of
+        emagls_jobs_shard (needs no GPU)."""
+        n = len(self._jobs)
+        arr = (L.Job * max(n, 1))(*self._jobs)
+        rank, pos, pad = (C.c_int * max(n, 1))(), (C.c_int * max(n, 1))(), (C.c_int * max(n, 1))()
+        L.check(L.load().emagls_jobs_shard(arr, n, int(world), int(max_batch), rank, pos, pad))
+        return list(rank[:n]), list(pos[:n]), list(pad[:n])
 
     def results(self):
         """[(wL, wR), ...] of the jobs whose filters were allocated here (None for jobs with their own `out`)."""

@@ -381,6 +381,22 @@ typedef struct emagls_job {
  * the geometry stages once (emagls_batch_set_geometry_sharing; the filters are bit-identical to the independent designs'). */
 #define EMAGLS_JOBS_SHARE_GEOMETRY 1
 int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int in_flight, int flags);
+/* ---- job lists over several GPUs ------------------------------------------------------------------------------------------
+ * Independent jobs shard without any collective on the data path.  emagls_jobs_shard is the split every runner of this
+ * library uses (emagls_amd/batch.py restated in C): array-radius studies -- jobs that differ only in mic_radius, up to 32 microphones
+ * -- are sorted by simulation order (dependencies/getSMAIRMatrix.m:95), cut into lane batches of equal COST (on average max_batch
+ * designs, <= 32; every design of a batch laid out for the batch's highest order: sim_order_pad[j], to be written into
+ * desc.sim_order_pad) and whole batches go to ranks by longest processing time; any other job is a unit of its own.  rank_of_job[j]:
+ * the rank of job j; order_in_rank[j] (optional): its position in that rank's share (the jobs of a batch adjacent, cheap batches
+ * first); sim_order_pad (optional).  Needs no GPU. */
+int emagls_jobs_shard(const emagls_job* jobs, int64_t njobs, int world, int max_batch, int* rank_of_job, int* order_in_rank, int* sim_order_pad);
+/* The GPUs of ONE process: the list is split with emagls_jobs_shard over `ndevices` devices (their HIP ordinals in `devices`; the
+ * same ordinal may appear twice) and every device's share runs through emagls_jobs_run from a host thread of its own.  Inputs and
+ * outputs are host arrays (or memory every listed device can reach); there is no gather: each device writes its jobs' filters where
+ * the jobs point.  What a MEX caller -- one MATLAB process -- uses for BASELINE config 4's 256 radii or config 5's subjects
+ * (emagls_mex('jobs', jobs, batchSize, inFlight, shareGeometry, devices)); one process per GPU with an RCCL gather of device buffers
+ * is emagls_amd/batch.py. */
+int emagls_jobs_run_devices(const emagls_job* jobs, int64_t njobs, const int* devices, int ndevices, int batch_size, int in_flight, int flags);
 /* Shape of a design's filters from its descriptor alone (no plan, no device memory: what a caller needs to allocate wL / wR of a
  * job): rows x cols, real or interleaved complex -- len x channels like the reference's outputs (lib/getEMagLsFilters.m:139-142);
  * LS keeps the HRIR length (lib/getLsFilters.m:33); channels = (N+1)^2 in the SH domain, 2N+1 circular harmonics (MAGLS_2D,

@@ -1,5 +1,5 @@
-function W = designJobs(jobs, batchSize, inFlight, shareGeometry)
-% W = designJobs(jobs, batchSize, inFlight, shareGeometry)
+function W = designJobs(jobs, batchSize, inFlight, shareGeometry, devices)
+% W = designJobs(jobs, batchSize, inFlight, shareGeometry, devices)
 %
 % A list of independent filter designs in ONE call on the MI355X library: the loop a script writes around
 % getEMagLsFilters / getEMagLs2Filters / getMagLsFilters / getEMagLsFiltersFromAtf ... (testEMagLs.m:75-95 over array radii,
@@ -12,6 +12,9 @@ function W = designJobs(jobs, batchSize, inFlight, shareGeometry)
 %                  atfIrs, atfGridAziRad, atfGridZenRad, fTrans, applyDiffusenessConst, simOrderPad
 % batchSize     .. designs per chunk (default 32), inFlight .. chunks in flight (default 4)
 % shareGeometry .. true: designs of a chunk that differ only in their HRIRs compute the geometry stages once
+% devices       .. GPUs of this MATLAB process to split the list over, e.g. 0:7 (default: the current device).  Array-radius
+%                  studies are cut into lane batches of equal cost and whole batches go to devices (emagls_jobs_shard); every
+%                  device runs its share from a host thread of its own and writes its filters straight into W: no gather
 % W             .. numel(jobs) x 2 cell array {wL, wR}: the filters each single call returns
 %
 % Example (256 array radii, BASELINE config 4):
@@ -23,5 +26,6 @@ function W = designJobs(jobs, batchSize, inFlight, shareGeometry)
 if nargin < 2, batchSize = []; end
 if nargin < 3, inFlight = []; end
 if nargin < 4, shareGeometry = false; end
-W = emagls_mex('jobs', jobs, batchSize, inFlight, logical(shareGeometry));
+if nargin < 5, devices = []; end
+W = emagls_mex('jobs', jobs, batchSize, inFlight, logical(shareGeometry), double(devices));
 end

@@ -72,7 +72,7 @@ void at_exit() { emagls_cache_clear(); }
 // emagls_mex('decode',  in, wL, wR, compensateDelay)            real or complex in / filters; [out, imagAbsSum] = ...
 // emagls_mex('sets', kind, hL, hR, azi, zen, micRadius, micAzi, micZen, order, fs, len, shDefinition)   3-D hL / hR: a loop over HRIR sets in one call
 // emagls_mex('fromatfsets', hL, hR, hrirGridAziZen, atfIrs, atfGridAziZen, fs, filterLen, fTrans)      3-D hL / hR: the subjects of one ATF set
-// emagls_mex('jobs', jobs[, batchSize, inFlight, shareGeometry])   struct array of independent designs (any kinds, radii, HRIR sets): W = {wL, wR} per job
+// emagls_mex('jobs', jobs[, batchSize, inFlight, shareGeometry, devices])   struct array of independent designs (any kinds, radii, HRIR sets): W = {wL, wR} per job
 // caller-evaluated shFunction handles (the wrappers evaluate them at emagls_mex('simorder', kind, order, fs, micRadius)):
 // emagls_mex('ls_y', hL, hR, Yhrir, order, shDefinition)        emagls_mex('magls_y', hL, hR, Yhrir, order, fs, len, shDefinition)
 // emagls_mex('emagls_y' | 'emagls2_y', hL, hR, Yhrir, micRadius, Ymic, order, fs, len, shDefinition)
@@ -158,7 +158,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         return;
     }
     if (c == "jobs") {
-        // W = emagls_mex('jobs', jobs, batchSize, inFlight, shareGeometry)
+        // W = emagls_mex('jobs', jobs, batchSize, inFlight, shareGeometry, devices)
         // The loop a user of the reference writes around one of its design functions (testEMagLs.m:75-95: array radii; HRIR sets;
         // testEMagLsFromAtfs.m:72-73: subjects) handed over in ONE call: the library's scheduler (emagls_jobs_run) cuts the list into
         // chunks of one shape, runs each as a lane batch and keeps several chunks in flight.  `jobs` is a struct array, one element per
@@ -241,7 +241,16 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             mxSetCell(plhs[0], n + i, wr);
             jb.wL = out_ptr(wl); jb.wR = out_ptr(wr);
         }
-        const int rc = n ? emagls_jobs_run(jobs.data(), (int64_t)n, batch_size, in_flight, share ? EMAGLS_JOBS_SHARE_GEOMETRY : 0) : 0;
+        // devices (optional, 6th argument): HIP ordinals of the GPUs of this MATLAB process to split the list over -- one host thread per
+        // device, every device writes its jobs' filters straight into the output arrays (emagls_jobs_run_devices; no gather)
+        std::vector<int> devices;
+        if (nrhs > 5 && !mxIsEmpty(prhs[5])) {
+            const double* dv = dbl(prhs[5], "devices");
+            for (mwSize i = 0; i < mxGetNumberOfElements(prhs[5]); ++i) devices.push_back((int)dv[i]);
+        }
+        const int fl = share ? EMAGLS_JOBS_SHARE_GEOMETRY : 0;
+        const int rc = !n ? 0 : devices.empty() ? emagls_jobs_run(jobs.data(), (int64_t)n, batch_size, in_flight, fl)
+                                                 : emagls_jobs_run_devices(jobs.data(), (int64_t)n, devices.data(), (int)devices.size(), batch_size, in_flight, fl);
         if (rc) fail(rc);
         return;
     }

@@ -16,3 +16,38 @@ def test_wave_fft_lds_layouts_are_conflict_free():
     assert sorted(m.slot(k) for k in range(1024)) == list(range(1024))
     assert all(r[k] == 1 for k in ("transposition 1 write", "transposition 1 read", "transposition 2 write", "transposition 2 read", "natural-order write")), r
     assert r["natural-order read k"] <= 2 and r["natural-order read N-k"] <= 2, r
+
+
+def test_c_shard_plan_equals_the_python_split():
+    import numpy as np
+    """emagls_jobs_shard (the split behind emagls_jobs_run_devices and the MEX 'jobs' command) against emagls_amd/batch.py on BASELINE
+    config 4 -- 256 array radii over 8 ranks, padded lane batches of equal cost, whole batches by longest processing time -- and on a
+    list of equal-shape jobs (round robin).  No GPU: the planner reads descriptors only."""
+    from emagls_amd import _lib as L
+    from emagls_amd.jobs import JobList
+    from emagls_amd.batch import padded_lane_batches, shard_lane_batches, simulation_order, shard_jobs
+    h = np.zeros((8, 40))
+    azi = np.zeros(40)
+    radii = np.linspace(0.02, 0.10, 256)
+    jl = JobList()
+    for r in radii:
+        jl.add(L.KIND_EMAGLS2, "real", 4, 48000.0, 1024, h, h, azi, azi, mic_radius=float(r), mic_azi=np.zeros(32), mic_zen=np.zeros(32), out_shape=(1024, 32, False))
+    rank, pos, pad = jl.shard(8, 16)
+    so = [simulation_order(4, 48000.0, float(r), raw=True) for r in radii]
+    per_rank, load = shard_lane_batches(padded_lane_batches(so, 16), 8)
+    for r, bl in enumerate(per_rank):
+        share = [j for idx, _ in bl for j in idx]
+        assert [j for j in range(256) if rank[j] == r and True] == sorted(share)
+        assert [pos[j] for j in share] == list(range(len(share)))
+        for idx, p in bl:
+            assert all(pad[j] == p for j in idx)
+    assert max(load) / min(load) < 1.02
+    # equal shapes: one job per unit, longest processing time on unit costs = round robin
+    jl2 = JobList()
+    for _ in range(37):
+        jl2.add(L.KIND_EMAGLS, "complex", 4, 48000.0, 512, h, h, azi, azi, mic_radius=0.042, mic_azi=np.zeros(32), mic_zen=np.zeros(32), out_shape=(512, 25, True))
+    rank2, pos2, pad2 = jl2.shard(4)
+    shards = shard_jobs(np.ones(37), 4)
+    for r, sjobs in enumerate(shards):
+        assert [j for j in range(37) if rank2[j] == r] == sjobs
+    assert all(p == 0 for p in pad2)

@@ -243,4 +243,10 @@ def test_job_list_through_the_gateway(mex, grids, thin):
     assert dev < 1e-11, dev
     with pytest.raises(mex.Error, match="eMagLS:native.*len too short"):     # the library's message, forwarded
         mex(1, "jobs", [dict(jobs[0], len=16)])
+    # the same list over "two" devices of this process (the one GPU listed twice): emagls_jobs_run_devices behind the sixth argument
+    W3 = mex(1, "jobs", jobs, 32, 4, False, np.array([0.0, 0.0]))[0]
+    dev3 = max(np.abs(a[e] - b[e]).max() / np.abs(a[e]).max() for a, b in zip(W, W3) for e in range(2))
+    assert dev3 < 5e-7, dev3   # (the radius jobs run in padded lane batches there)
+    with pytest.raises(mex.Error, match="eMagLS:native.*no such device"):
+        mex(1, "jobs", jobs[:2], 32, 4, False, np.array([0.0, 99.0]))
     L.check(L.load().emagls_cache_clear())
