@@ -35,8 +35,9 @@ def main():
                   "kernel_time_us_per_execute": round(busy / nexec, 1),
                   "dominant_kernel": {"name": dom[0][:90], "launches_per_execute": round(dom[1]["dispatches"] / nexec, 2), "avg_us": round(dom[1]["avg_us"], 1),
                                       "bytes_per_launch": int(dom[1].get("bytes", 0))}}
-    with open(os.path.join(ROOT, "profiles", "secondary_traffic.json"), "w") as f:
-        json.dump(out, f, indent=1)
+    for path in (os.path.join(ROOT, "profiles", "secondary_traffic.json"), os.path.join(ROOT, "gpurun_out", f"{tag}_secondary_traffic.json")):
+        with open(path, "w") as f:     # (gpurun merges only gpurun_out/ back: copy that file over profiles/secondary_traffic.json)
+            json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1)[:1500])
 
 
