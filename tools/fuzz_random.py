@@ -62,7 +62,7 @@ def draw(rng):
         N = int(rng.integers(0, 13))
         return (kind, D, taps, ln, fs, float(rng.uniform(0.01, 0.08)), int(rng.integers(2 * N + 1, 33)), N, basis)
     if kind == "emainsh":
-        N = int(rng.integers(1, 5))
+        N = int(rng.integers(1, 8)) if os.environ.get("EMAGLS_FUZZ_ROUND6") else int(rng.integers(1, 5))   # (orders 5..7 since round 6)
         return (kind, D, taps, ln, fs, float(rng.uniform(0.02, 0.08)), int(rng.integers(2 * N + 1, 33)), N, basis)
     if kind == "magls2d":
         return (kind, int(rng.integers(40, 720)), taps, ln, fs, 0, 0, int(rng.integers(0, 20)), basis)
