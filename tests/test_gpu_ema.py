@@ -127,17 +127,18 @@ def test_batch_of_ema_in_sh_designs_on_a_caller_stream(thin):
         p.close()
 
 
-@pytest.mark.parametrize("order,basis,nmics", [(5, "real", 16), (6, "complex", 20), (7, "real", 24), (5, "complex", 11)])
-def test_emagls_ema_in_sh_orders_5_to_7(thin, order, basis, nmics):
+@pytest.mark.parametrize("order,basis,nmics,length", [(5, "real", 16, 128), (6, "complex", 20, 96), (7, "real", 24, 64), (5, "complex", 11, 128)])
+def test_emagls_ema_in_sh_orders_5_to_7(thin, order, basis, nmics, length):
     """getEMagLsFiltersEMAinSH at orders 5..7 (lib/getEMagLsFiltersEMAinSH.m:66-143; 36 / 49 / 64 spherical-harmonic channels: round 6).
     The tuned kernels hold 32 channels; above that the per-direction rotations are fitted blockwise (one SH order at a time), the
     point-set pseudo-inverse and every bin's D x C operand are factored by wide_array.hip's QR + one-sided Jacobi, and the sweep is
     one launch per bin.  The smallest array the reference accepts (2 N + 1 microphones) included."""
     import emagls_amd as E
     mic_azi = np.linspace(0.0, 2 * np.pi, nmics, endpoint=False) + 0.1
-    args = (thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.042, mic_azi, order, 48000.0, 128, basis)
+    hL, hR = thin["hL"][:length], thin["hR"][:length]     # (the oracle's SVDs of 901 x 64 matrices are what this test takes: fewer bins at order 7)
+    args = (hL, hR, thin["azi"], thin["zen"], 0.042, mic_azi, order, 48000.0, length, basis)
     wL, wR = E.getEMagLsFiltersEMAinSH(*args)
     oL, oR = O.getEMagLsFiltersEMAinSH(*args)
-    assert wL.dtype == oL.dtype and wL.shape == (128, (order + 1) ** 2)
+    assert wL.dtype == oL.dtype and wL.shape == (length, (order + 1) ** 2)
     assert report(f"EMAinSH N={order} L {basis}", wL, oL) < TOL and report(f"EMAinSH N={order} R {basis}", wR, oR) < TOL
     print(f"EMAinSH order {order} ({basis}, {nmics} microphones): rel = {max(rel(wL, oL), rel(wR, oR)):.3e}")
