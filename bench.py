@@ -506,7 +506,9 @@ def main():
                              "XCD (a chunk that would leave CUs idle that way -- the 20 designs of the driver's run -- has its designs spread over all XCDs); " + (("the operand of every bin is evaluated inside the launch from the angles between HRIR directions and microphones by the "
                                          "waves that run the recurrence and stays in their registers (sweep_reg.hip: no operand in HBM or LDS); with twelve waves per "
                                          "CU the launch is limited by the issue rate of FP64 vector operations (2.2 instructions per useful fused operation: "
-                                         "cross-lane reduction, exchange, barriers) and by the per-bin exchange of partial sums (DESIGN.md section 5)" if reg else
+                                         "cross-lane reduction, exchange, barriers) and by the per-bin exchange of partial sums (DESIGN.md section 5); since "
+                                         "round 6 a lone chunk's launch shares its CUs with the orthonormal route of the low bins for about half of its "
+                                         "run time (DESIGN.md section 2.17): avg_launch_us is the launch as it ran -- 4.2 ms alone, 4.6-4.75 ms that way" if reg else
                                          "the slab of pwGrid of every bin is evaluated inside the launch from the angles between HRIR directions and "
                                          "microphones (sweep_synth.hip: no operand in HBM); the chain is bound by the per-bin exchange of partial sums between "
                                          "workgroups and its barriers, not by a throughput resource (DESIGN.md section 5)") if synth else
