@@ -30,6 +30,8 @@ def main():
         p.set_hrirs(hL, hR)
         plans.append(p)
     b = Batch(plans) if n > 1 else None
+    if b and os.environ.get("SWEEP_TIMING_FORK"):   # the lone chunk of a job list: one lane group (EMAGLS_BATCH_GROUPS=1), stages forked
+        b.set_streams(int(os.environ["SWEEP_TIMING_FORK"]))
     for _ in range(4):
         (b.execute() if b else plans[0].execute())
     (b.synchronize() if b else plans[0].synchronize())
@@ -51,6 +53,11 @@ def main():
             print("design %d of %d (register-resident form): %d swept bins, sweep span %.1f us, one XCD: %s" % (j, n, P - k0, t[P - 1, 5] - t[k0, 7], bool(p.debug("sweep_timing", np.int64)[15])))
             for name, v in rows.items():
                 print("  %-56s median %6.2f  mean %6.2f  p90 %6.2f us" % (name, np.median(v), v.mean(), np.percentile(v, 90)))
+            if os.environ.get("SWEEP_TIMING_WINDOWS"):   # the phases over the run of the launch (what runs NEXT to it ends somewhere inside)
+                nwin = int(os.environ["SWEEP_TIMING_WINDOWS"])
+                print("  windows of the swept bins (us from the first bin: mean of period / synthesis / wait / M / p / products / publish):")
+                for w in np.array_split(np.arange(len(kb)), nwin):
+                    print("    %7.0f .. %7.0f us: " % (t[kb[w[0]], 7] - t[k0, 7], t[kb[w[-1]], 7] - t[k0, 7]) + "  ".join("%5.2f" % v[w].mean() for v in rows.values()))
             continue
         rows = {
             "bin period (stamp 0 -> next bin's stamp 0)": t[kb + 1, 0] - t[kb, 0],
