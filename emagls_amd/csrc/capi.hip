@@ -699,11 +699,13 @@ void plan_setup(emagls_plan& p) {
         p.S = d.kind == EMAGLS_KIND_MAGLS_2D ? 2 * N + 1 : (N + 1) * (N + 1);
         p.C = p.S;
         p.nOut = p.S;
-        // up to 32 channels: the tuned kernels (register tiles, the persistent sweep); 33..64 (SH orders 5..7): the plain path of
-        // wide.hip -- pinv(Y_conj) from the inverse of the Gram matrix, one sweep launch per bin
+        // up to 32 channels: the tuned kernels (register tiles, the persistent sweep); 33..256 (SH orders 5..15, CH orders 16..127): the
+        // plain path of wide.hip -- pinv(Y_conj) from the inverse of the Gram matrix, one sweep launch per bin (above 64 channels its
+        // loop forms)
         p.wide = p.S > 32;
-        if (p.S > 64) throw Error(EMAGLS_ERR_UNSUPPORTED, d.kind == EMAGLS_KIND_MAGLS_2D ? "CH order above 31 is not supported in this build"
-                                                                                           : "SH order above 7 is not supported for LS/MagLS in this build");
+        if (p.S > 256) throw Error(EMAGLS_ERR_UNSUPPORTED, d.kind == EMAGLS_KIND_MAGLS_2D ? "CH order above 127 is not supported in this build"
+                                                                                            : "SH order above 15 is not supported for LS/MagLS in this build");
+        if (p.S > 64 && p.diffuse) throw Error(EMAGLS_ERR_UNSUPPORTED, "more than 64 channels: no covariance constraint in this build");
         if (p.D < p.S) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than SH channels");
     } else if (array_kind(d.kind)) {
         if (!(d.mic_radius > 0) || d.nmics < 1) throw Error(EMAGLS_ERR_ARG, "invalid array geometry");
@@ -784,6 +786,7 @@ void plan_setup(emagls_plan& p) {
         p.alloc("Nw", sizeof(cplx) * (size_t)p.C * p.C);
         p.alloc("Ypinv", esz(cb) * (size_t)p.C * p.ldD);
         if (p.wide) p.alloc("Mg", sizeof(cplx) * (size_t)p.S * p.S);   // (Y^T conj(Y))^-1
+        if (p.S > 64) p.alloc("Mgw", sizeof(cplx) * (size_t)p.S * p.S + 2 * sizeof(double));   // R^-1 and the certificate's norms (wide.hip: 65..256 channels)
         if (d.kind == EMAGLS_KIND_LS) {
             p.out_rows = d.nsamp;
         } else {
@@ -1025,7 +1028,7 @@ void run_pinv_of_R(emagls_plan& p) {
     hipStream_t st = p.stream;
     const bool cb = p.cplx_basis;
     if (p.wide) {   // 33..64 channels: the inverse of the Gram matrix, certified well conditioned on the device (wide.hip)
-        launch_gram_inverse(p.get("R"), p.S, cb, p.get("Mg"), p.get<int>("flag"), st);
+        launch_gram_inverse(p.get("R"), p.S, cb, p.get("Mg"), p.get<int>("flag"), st, p.has("Mgw") ? p.get("Mgw") : nullptr);
         launch_ypinv_gram(p.get("Ycm"), p.ldD, cb, p.get("Mg"), p.S, (int)p.D, p.get("Ypinv"), st);
         p.mark("pinv");
         return;

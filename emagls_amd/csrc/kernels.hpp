@@ -152,7 +152,7 @@ void launch_widen(const void* in, int64_t ldi, bool in_cplx, void* out, int64_t 
                   bool upper_only, hipStream_t st);
 
 // ---- wide.hip: LS / MagLS above 32 channels (SH orders 5..7)
-void launch_gram_inverse(const void* R, int S, bool is_cplx, void* M, int* status, hipStream_t st);
+void launch_gram_inverse(const void* R, int S, bool is_cplx, void* M, int* status, hipStream_t st, void* work = nullptr);   // work (S > 64): S x S complex + 2 doubles
 void launch_ypinv_gram(const void* Ycm, int64_t ldD, bool is_cplx, const void* M, int S, int D, void* Ypinv, hipStream_t st);
 void launch_sweep_wide(const DenseSweepArgs& a, int kb, bool x_cplx, hipStream_t st);
 void launch_sweep_wide_finalize(const void* Wpart, void* W, int nWG, int C, int P, int kb_last, hipStream_t st);

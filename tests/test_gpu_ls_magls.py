@@ -77,11 +77,28 @@ def test_ls_and_magls_orders_5_to_7(grids, hrirs, order, basis):
     assert report(f"MagLS order {order} {basis} L", wL, oL) < TOL and report("R", wR, oR) < TOL
 
 
+@pytest.mark.parametrize("order,basis,taps", [(8, "real", 256), (10, "complex", 128), (15, "real", 128), (12, "complex", 128)])
+def test_ls_and_magls_orders_8_to_15(grids, hrirs, order, basis, taps):
+    """SH orders 8..15 (81..256 channels; round 6): the loop forms of wide.hip -- R^-1 by back substitution in global memory, the
+    certificate's norms by atomics, the per-bin sweep launch with loops over the channels -- against the oracle on the 2702-point
+    grid."""
+    import emagls_amd as E
+    C = (order + 1) ** 2
+    wL, wR = E.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, basis)
+    oL, oR = O.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, basis)
+    assert wL.shape == (128, C) and wL.dtype == oL.dtype
+    assert report(f"LS order {order} {basis} L", wL, oL) < 1e-10 and report("R", wR, oR) < 1e-10
+    wL, wR = E.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, 48000.0, taps, basis)
+    oL, oR = O.getMagLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], order, 48000.0, taps, basis)
+    assert wL.shape == (taps, C) and wL.dtype == oL.dtype
+    assert report(f"MagLS order {order} {basis} L", wL, oL) < TOL and report("R", wR, oR) < TOL
+
+
 def test_wide_orders_refuse_what_they_cannot_do(grids, hrirs, thin):
     import emagls_amd as E
     from emagls_amd._lib import EmaglsError
-    with pytest.raises(EmaglsError, match="order above 7"):
-        E.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 8, "real")
+    with pytest.raises(EmaglsError, match="order above 15"):
+        E.getLsFilters(hrirs[0], hrirs[1], grids["azi"], grids["zen"], 16, "real")
     # an order the grid cannot resolve well: 49 SH channels on 60 directions of a polar cap -> the certificate (or the Cholesky
     # pivot) refuses instead of returning garbage
     from emagls_amd import synth

@@ -113,7 +113,8 @@ def horizontal_hrirs():
 
 
 @pytest.mark.parametrize("basis,order,length", [("real", 4, 256), ("complex", 4, 256), ("real", 7, 512), ("complex", 15, 128),
-                                                ("real", 20, 128), ("complex", 24, 128)])   # (orders above 15: more than 32 channels, wide.hip)
+                                                ("real", 20, 128), ("complex", 24, 128),   # (orders above 15: more than 32 channels, wide.hip)
+                                                ("real", 40, 128), ("complex", 60, 128)])  # (above 31: more than 64 channels, its loop forms)
 def test_magls_filters_2d(horizontal_hrirs, basis, order, length):
     import emagls_amd as E
     hL, hR, azi = horizontal_hrirs
@@ -132,8 +133,8 @@ def test_magls_filters_2d_errors(horizontal_hrirs):
     hL, hR, azi = horizontal_hrirs
     with pytest.raises(EmaglsError, match="HRIR len too short"):       # getMagLsFilters2D.m:38
         E.getMagLsFilters2D(hL, hR, azi, 4, 48000.0, 64)
-    with pytest.raises(EmaglsError, match="order above 31"):
-        E.getMagLsFilters2D(hL, hR, azi, 32, 48000.0, 256)
+    with pytest.raises(EmaglsError, match="order above 127"):
+        E.getMagLsFilters2D(hL, hR, azi, 128, 48000.0, 256)
 
 
 @pytest.mark.parametrize("radius,order,fs,length", [(0.042, 4, 48000.0, 512), (0.0875, 3, 44100.0, 256), (0.042, 1, 48000.0, 2048)])
