@@ -56,16 +56,17 @@ def draw(rng):
         M = int(rng.integers(max(2, (N + 1) ** 2 // 2), 65)) if kind == "emagls" else int(rng.integers(2, 65))
         r = float(rng.uniform(0.005, 0.058))
         return (kind, D, taps, ln, fs, r, M, N, basis)
+    wide6 = bool(os.environ.get("EMAGLS_FUZZ_ROUND6B"))   # (second half of round 6: LS / MagLS orders up to 15, MagLS-2D up to 110)
     if kind in ("magls", "ls"):
-        return (kind, D, taps, ln, fs, 0, 0, int(rng.integers(0, 8)), basis)
+        return (kind, D, taps, ln, fs, 0, 0, int(rng.integers(0, 16 if wide6 else 8)), basis)
     if kind == "emainch":
         N = int(rng.integers(0, 13))
         return (kind, D, taps, ln, fs, float(rng.uniform(0.01, 0.08)), int(rng.integers(2 * N + 1, 33)), N, basis)
     if kind == "emainsh":
-        N = int(rng.integers(1, 8)) if os.environ.get("EMAGLS_FUZZ_ROUND6") else int(rng.integers(1, 5))   # (orders 5..7 since round 6)
+        N = int(rng.integers(1, 8)) if (os.environ.get("EMAGLS_FUZZ_ROUND6") or wide6) else int(rng.integers(1, 5))   # (orders 5..7 since round 6)
         return (kind, D, taps, ln, fs, float(rng.uniform(0.02, 0.08)), int(rng.integers(2 * N + 1, 33)), N, basis)
     if kind == "magls2d":
-        return (kind, int(rng.integers(40, 720)), taps, ln, fs, 0, 0, int(rng.integers(0, 20)), basis)
+        return (kind, int(rng.integers(40, 720)), taps, ln, fs, 0, 0, int(rng.integers(0, 110 if wide6 else 20)), basis)
     return ("atf", D, taps, ln, 48000.0, int(rng.integers(30, 3000)), int(rng.integers(1, 17)), int(rng.choice([16, 50, 64, 128])),
             float(rng.choice([500.0, 1500.0, 2000.0, 3000.0])))
 
