@@ -114,8 +114,9 @@ __global__ void __launch_bounds__(512) wa_qr_kernel(cplx* __restrict__ B, cplx* 
 // One-sided Jacobi on M = R2^H (C x C, columns of M = conjugated rows of R2): M J = A with orthogonal columns a_j = s_j u_j.
 // 32 disjoint column pairs per round (round-robin tournament, C - 1 rounds per sweep), 32 lanes per pair.
 // Output N = conj(J) diag(s_reg / s) A^T (C x C, row major) and the singular values.
+// flag2: another sweep follows one in which some rotation had |gamma|^2 > flag2 alpha beta (1e-28: the rule of rounds 3-5)
 __global__ void __launch_bounds__(1024) wa_jacobi_kernel(const cplx* __restrict__ R2w, int C, double reg_c, cplx* __restrict__ Nw, double* __restrict__ sv,
-                                                         int* __restrict__ sweeps_out) {
+                                                         int* __restrict__ sweeps_out, double flag2) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     const int Cp = (C + 1) & ~1, ld = Cp + 1;            // even column count (a zero column pads an odd C)
     cplx* A = reinterpret_cast<cplx*>(dyn);               // [Cp][ld]  A[col][row]
@@ -145,30 +146,45 @@ __global__ void __launch_bounds__(1024) wa_jacobi_kernel(const cplx* __restrict_
                 int p = player(pr), q = player(Cp - 1 - pr);
                 if (p > q) { const int t = p; p = q; q = t; }
                 cplx* ap = A + p * ld; cplx* aq = A + q * ld;
-                double al = 0.0, be = 0.0; cplx ga = mk(0.0, 0.0);
-                for (int r = l32; r < Cp; r += 32) { const cplx x = ap[r], y = aq[r]; al += norm2(x); be += norm2(y); cfma_conj(ga, x, y); }
+                cplx* jp = J + p * ld; cplx* jq = J + q * ld;
+                // (Cp <= 64: at most two rows per lane; J's rows are requested with A's, so the rotation has no LDS round trip left)
+                const int r0 = l32, r1 = l32 + 32;
+                const bool one = r0 < Cp, two = r1 < Cp;
+                const cplx x0 = one ? ap[r0] : mk(0.0, 0.0), y0 = one ? aq[r0] : mk(0.0, 0.0);
+                const cplx u0 = one ? jp[r0] : mk(0.0, 0.0), v0 = one ? jq[r0] : mk(0.0, 0.0);
+                const cplx x1 = two ? ap[r1] : mk(0.0, 0.0), y1 = two ? aq[r1] : mk(0.0, 0.0);
+                const cplx u1 = two ? jp[r1] : mk(0.0, 0.0), v1 = two ? jq[r1] : mk(0.0, 0.0);
+                double al = norm2(x0) + norm2(x1), be = norm2(y0) + norm2(y1);
+                cplx ga = mk(0.0, 0.0);
+                cfma_conj(ga, x0, y0); cfma_conj(ga, x1, y1);
                 al = group_sum<32>(al); be = group_sum<32>(be); ga = group_sum<32>(ga);
-                const double g = sqrt(norm2(ga));
-                if (g > 0.0 && g > 1e-15 * sqrt(al * be)) {
-                    const cplx ph = mk(ga.x / g, ga.y / g);
-                    const double zeta = (be - al) / (2.0 * g);
-                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                const double ag2 = norm2(ga), ab = al * be;
+                // rotate when |gamma| > 1e-15 sqrt(alpha beta)  (reciprocals and roots from the hardware seeds + Newton steps, as in
+                // factor_jacobi_body: the IEEE expansions of the seven divisions and roots were the longest part of a round)
+                if (ag2 > 0.0 && ag2 > 1e-30 * ab) {
+                    const double iag = fast_rsqrt(ag2);           // 1 / |gamma|
+                    const cplx ph = mk(ga.x * iag, ga.y * iag);
+                    const double zeta = 0.5 * (be - al) * iag;
+                    const double z2 = fma(zeta, zeta, 1.0);
+                    const double sq = z2 * fast_rsqrt(z2);        // sqrt(1 + zeta^2)
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + sq);
+                    const double c = fast_rsqrt(fma(t, t, 1.0)), s = c * t;
                     const cplx sph = mk(s * ph.x, s * ph.y), sphc = mk(s * ph.x, -s * ph.y);   // s e^{i phi}, s e^{-i phi}
-                    cplx* jp = J + p * ld; cplx* jq = J + q * ld;
-                    for (int r = l32; r < Cp; r += 32) {
-                        const cplx x = ap[r], y = aq[r];
-                        cplx nx = mk(c * x.x, c * x.y), ny = mk(c * y.x, c * y.y);
+                    auto rot = [&](const cplx& x, const cplx& y, cplx& nx, cplx& ny) __attribute__((always_inline)) {
                         cplx t1 = mk(0.0, 0.0), t2 = mk(0.0, 0.0);
                         cfma(t1, sphc, y); cfma(t2, sph, x);
-                        ap[r] = nx - t1; aq[r] = t2 + ny;
-                        const cplx u = jp[r], v = jq[r];
-                        cplx nu = mk(c * u.x, c * u.y), nv = mk(c * v.x, c * v.y);
-                        cplx t3 = mk(0.0, 0.0), t4 = mk(0.0, 0.0);
-                        cfma(t3, sphc, v); cfma(t4, sph, u);
-                        jp[r] = nu - t3; jq[r] = t4 + nv;
+                        nx = mk(c * x.x, c * x.y) - t1; ny = t2 + mk(c * y.x, c * y.y);
+                    };
+                    cplx nx, ny;
+                    if (one) {
+                        rot(x0, y0, nx, ny); ap[r0] = nx; aq[r0] = ny;
+                        rot(u0, v0, nx, ny); jp[r0] = nx; jq[r0] = ny;
                     }
-                    if (l32 == 0 && g > 1e-14 * sqrt(al * be)) s_rot = 1;
+                    if (two) {
+                        rot(x1, y1, nx, ny); ap[r1] = nx; aq[r1] = ny;
+                        rot(u1, v1, nx, ny); jp[r1] = nx; jq[r1] = ny;
+                    }
+                    if (l32 == 0 && ag2 > flag2 * ab) s_rot = 1;
                 }
             }
             __syncthreads();
@@ -542,7 +558,8 @@ void launch_wa_factor(void* B, void* Vw, int S, int C, int ldS, int nbins, doubl
     const size_t dyn = sizeof(cplx) * (size_t)2 * Cp * (Cp + 1);
     static PerDeviceOnce attr_once;
     if (attr_once.first()) HIP_CHECK(hipFuncSetAttribute((const void*)wa_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    wa_jacobi_kernel<<<nbins, 1024, dyn, st>>>((const cplx*)R2w, C, reg_c, (cplx*)Nw, sv, sweeps);
+    static const double flag2 = [] { const char* e = getenv("EMAGLS_WA_JACOBI_FLAG"); const double f = e ? atof(e) : 1e-14; return f * f; }();
+    wa_jacobi_kernel<<<nbins, 1024, dyn, st>>>((const cplx*)R2w, C, reg_c, (cplx*)Nw, sv, sweeps, flag2);
     KERNEL_CHECK();
     if (reg7) wa_back_reg_kernel<7><<<dim3(nbins, (unsigned)ceil_div(C, 32)), 512, 0, st>>>((const cplx*)Vw, tauw, (const cplx*)Nw, S, C, ldS, (cplx*)Z);
     else wa_back_kernel<<<nbins, 512, 0, st>>>((const cplx*)Vw, tauw, (const cplx*)Nw, S, C, ldS, (cplx*)Z);
