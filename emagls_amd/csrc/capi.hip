@@ -743,6 +743,10 @@ void plan_setup(emagls_plan& p) {
         // (fewer directions than simulated SH channels are fine as long as the orders of the orthonormal route are covered:
         // plan_routes checks D >= S_h.  The wide path orthogonalises all S columns.)
         if (p.D < p.S && (p.wide || d.kind == EMAGLS_KIND_EMA_SH)) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than simulated SH channels");
+        // (rank-deficient array model on the 33..64-channel path, e.g. 49 microphones on a 2 cm sphere at 16 kHz -- 25 simulated SH channels: the
+        // reference's clipped inverse is then 100 / s_max times singular vectors of rounding noise; launch_wa_factor)
+        if (p.wide && d.kind != EMAGLS_KIND_EMA_SH && p.S < p.C)
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "33..64 channels with fewer simulated SH channels than channels (rank-deficient array model: the reference's clipped inverse is rounding noise there) is not supported");
         if (p.D < p.C) throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer HRIR directions than channels");
         if (d.kind != EMAGLS_KIND_EMAGLS2 && d.kind != EMAGLS_KIND_EMA_SH && d.nmics < p.nOut)
             throw Error(EMAGLS_ERR_UNSUPPORTED, "fewer microphones than output channels");

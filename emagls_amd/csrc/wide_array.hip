@@ -548,7 +548,11 @@ void launch_wa_assemble(const void* Tn, const void* bn, int nOrd, int S, int C, 
 void launch_wa_factor(void* B, void* Vw, int S, int C, int ldS, int nbins, double reg_c, double* tauw, void* R2w, void* Nw, double* sv, int* sweeps,
                       void* Z, hipStream_t st) {
     if (nbins <= 0) return;
-    if (C > WA_CMAX || S < C) throw Error(2, "wide array path: at most 64 channels and at least as many SH rows");
+    if (C > WA_CMAX) throw Error(2, "wide array path: at most 64 channels");
+    // (fewer simulated SH channels than microphones: pwGrid has rank S < C, and the reference's clipped inverse then carries 100 / s_max
+    // times left singular vectors that LAPACK's rounding alone determines -- its own result changes with the SVD driver.  The path
+    // for up to 32 channels returns the part that is determined; this one refuses.)
+    if (S < C) throw Error(2, "33..64 channels with fewer simulated SH channels than channels (rank-deficient array model: the reference's clipped inverse is rounding noise there) is not supported");
     const char* e_reg = getenv("EMAGLS_WA_REG");   // =0: the forms that walk the columns through L2
     const bool reg7 = ldS <= 64 * 7 && !(e_reg && e_reg[0] == '0');
     if (reg7) wa_qr_reg_kernel<7><<<nbins, 1024, 0, st>>>((const cplx*)B, (cplx*)Vw, S, C, ldS, tauw, (cplx*)R2w);

@@ -140,3 +140,8 @@ def test_wide_arrays_refuse_what_they_cannot_do(thin):
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.20, maz, mzn, 4, 48000.0, 128)
     with pytest.raises(EmaglsError, match="fewer HRIR directions than simulated SH channels"):   # (8 cm: 36^2 = 1296 channels, 901 directions)
         E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.08, maz, mzn, 4, 48000.0, 128)
+    # 49 microphones on a 2 cm sphere at 16 kHz: 25 simulated SH channels, pwGrid has rank 25 < 49 -- the reference's clipped inverse
+    # (lib/getEMagLs2Filters.m:84-88) then scales singular vectors of rounding noise by 100 / s_max; this path refuses
+    maz, mzn = synth.fibonacci_grid(49)
+    with pytest.raises(EmaglsError, match="rank-deficient"):
+        E.getEMagLs2Filters(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.02, maz, mzn, 4, 16000.0, 128)
