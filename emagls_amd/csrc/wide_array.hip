@@ -457,20 +457,40 @@ __global__ void __launch_bounds__(256) wa_yri_mfma_kernel(const double* __restri
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = wa_double4{0.0, 0.0, 0.0, 0.0};
+    // the next chunk of both operands is requested before the matrix instructions of the current one and stored behind them (round 6:
+    // load -> barrier -> 64 MFMAs -> barrier per chunk left the pipe idle for a global round trip in every chunk)
+    constexpr int NA = WA_CMAX * WY_KC / 256, NB = 64 * WY_KC / 256;
+    cplx za[NA];
+    double qb[NB];
+    auto fetch = [&](int s0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + 256 * u, c = idx >> 5, ss = idx & 31;
+            za[u] = (c < C && s0 + ss < S) ? Zk[(int64_t)c * ldS + s0 + ss] : mk(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + 256 * u, j = idx >> 5, ss = idx & 31;
+            qb[u] = (d0 + j < D && s0 + ss < S) ? Q[(int64_t)(d0 + j) * ldQ + s0 + ss] : 0.0;
+        }
+    };
+    fetch(0);
     for (int s0 = 0; s0 < S; s0 += WY_KC) {
         __syncthreads();
-        for (int idx = tid; idx < WA_CMAX * WY_KC; idx += 256) {
-            const int c = idx >> 5, ss = idx & 31;
-            const cplx z = (c < C && s0 + ss < S) ? Zk[(int64_t)c * ldS + s0 + ss] : mk(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + 256 * u, c = idx >> 5, ss = idx & 31;
             const int row = 16 * (c >> 3) + 8 * ((c & 7) >> 2) + (c & 3);   // the (re) row of channel c; its (im) row is 4 further
-            As[ss][row] = z.x;
-            As[ss][row + 4] = z.y;
+            As[ss][row] = za[u].x;
+            As[ss][row + 4] = za[u].y;
         }
-        for (int idx = tid; idx < 64 * WY_KC; idx += 256) {
-            const int j = idx >> 5, ss = idx & 31;
-            Bs[ss][j] = (d0 + j < D && s0 + ss < S) ? Q[(int64_t)(d0 + j) * ldQ + s0 + ss] : 0.0;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + 256 * u, j = idx >> 5, ss = idx & 31;
+            Bs[ss][j] = qb[u];
         }
         __syncthreads();
+        if (s0 + WY_KC < S) fetch(s0 + WY_KC);
 #pragma unroll
         for (int k0 = 0; k0 < WY_KC; k0 += 4) {
             const double a0 = As[k0 + kk][32 * wave + ii], a1 = As[k0 + kk][32 * wave + 16 + ii];
