@@ -276,6 +276,12 @@ struct emagls_plan {
     int nstreams = 1;
     int stage_order = 0;          // order of the stages before the sweep (emagls_pre_sweep): 0 branches, 1 / 2 the complementary single-stream orders of lane groups
     int pre_phase = 0;            // emagls_pre_sweep: 0 everything, 1 only what the sweep needs, 2 the rest (plan_defers_hh_route)
+    // HRIR sets on ONE geometry through a plan of the 33..64-channel path (emagls_design_hrir_sets): what depends on the grids and the array only
+    // -- G_k, the per-bin factors, Y_reg_inv_k: 19 of the 31 ms of a 64-capsule design -- is kept from the last clean run on the same grids
+    bool geo_keep = false;                   // the caller runs sets of one geometry through this plan
+    bool geo_skip = false;                   // (this execute: the geometry stages are skipped)
+    uint64_t geo_done_version = ~0ull;       // atf_side_version of the last run whose flags came back clean
+    uint64_t geo_run_version = ~0ull;        // ... of the last full run (promoted by plan_check_flags)
     bool defer_hh = false;        // plan_execute: what the captured stages before the sweep were captured with
     bool alone = false;           // the plan of a one-shot call (the device to itself, like a plan with forked stages)
     hipStream_t hh_stream = nullptr;   // the stream of the stages that run next to the sweep
@@ -1759,7 +1765,9 @@ void execute_emagls_wide(emagls_plan& p) {
     const int M = (int)d.nmics, nOrd = p.simOrder + 1, nb = p.P - 1;
     const int ls_end = std::min(p.kcut0, p.P), k0 = std::max(p.kcut0, 1);
     const int64_t g_stride = (int64_t)p.C * p.ldD;
-    // ---- SH matrices, array model, modal terms
+    // ---- SH matrices, array model, modal terms  (geo: skipped when the plan keeps them from its last run on these grids)
+    const bool geo = !p.geo_skip;
+    if (geo) {
     launch_sh_coeff(p.simOrder, p.get<double>("sh_tab"), st);
     launch_sh_basis(p.simOrder, p.D, p.get<double>("hrir_azi"), p.get<double>("hrir_zen"), p.get<double>("sh_tab"), false, p.get("Ycm"), p.ldD, st);
     launch_transpose_conj(p.get("Ycm"), p.D, p.S, p.ldD, p.get("Yc"), p.Dpad, p.ldS, false, true, st);
@@ -1787,6 +1795,7 @@ void execute_emagls_wide(emagls_plan& p) {
         launch_wa_e(p.get("Ymic_cm"), M, p.nOut, p.S, p.get("Minv"), p.get("E"), (int)p.ldS, st);
     }
     launch_modal_bn(p.simOrder, p.P, p.get<double>("kr"), 1.0, -1.0, p.get("bn"), nOrd, 1, st, p.get<int>("nvalid"));
+    }
     p.mark("array_model");
     // ---- HRIR prologue
     launch_twiddles(p.nfft, p.get("tw"), st);
@@ -1800,6 +1809,7 @@ void execute_emagls_wide(emagls_plan& p) {
     }
     p.mark("hrir_prologue");
     // ---- conj(Y) = Q R, order terms T_n = R(:,blk_n) E(:,blk_n)^T and QT_n, G_k of every solved bin
+    if (geo) {
     launch_gram(p.get("Yc"), p.D, p.S, p.ldS, false, p.get("Gp"), nullptr, p.get("R"), p.S, st);
     launch_cholesky(p.get("R"), p.S, false, p.get<int>("flag"), st);
     launch_qform(p.get("Yc"), p.get("R"), p.get("Rinv"), p.S, p.D, p.ldS, false, p.get("Q"), st);
@@ -1812,6 +1822,7 @@ void execute_emagls_wide(emagls_plan& p) {
     launch_wa_factor(p.get("Bw"), p.get("Vw"), p.S, p.C, (int)p.ldS, nb, SVD_REGUL_CONST, p.get<double>("tauw"), p.get("R2w"), p.get("Nw"),
                      p.get<double>("sv") + p.C, p.get<int>("jsweeps") + 1, p.get("Zw"), st);
     launch_wa_yri(p.get("Q"), p.ldS, p.get("Zw"), p.S, p.C, (int)p.ldS, (int)p.D, p.ldD, nb, p.get("Yri"), st);
+    }
     p.mark("factor_bins");
     // ---- least-squares bins, sweep (G and Yri start at bin 1)
     launch_wa_ls(p.get("Hc"), p.ldD, ls_end, p.get("Yri"), p.ldD, (int)p.D, p.C, p.P, 1, ls_end, p.get("W"), st);
@@ -2107,6 +2118,17 @@ void plan_execute(emagls_plan& p) {
         p.executed = true;
         return;
     }
+    // sets of one geometry through a plan of the 33..64-channel path: the stages that depend on the grids alone are kept from the last clean run
+    // on these grids; such an execute runs eagerly (a thousand launches of 12 us each: the host stays ahead)
+    if (p.geo_keep && p.wide && p.prof_level == 0 && (d.kind == EMAGLS_KIND_EMAGLS || d.kind == EMAGLS_KIND_EMAGLS2) &&
+        p.geo_done_version == p.atf_side_version) {
+        p.geo_skip = true;
+        try { run_pipeline(p); } catch (...) { p.geo_skip = false; throw; }
+        p.geo_skip = false;
+        p.executed = true;
+        return;
+    }
+    p.geo_run_version = p.atf_side_version;
     if (p.prof_level == 0 && p.use_graph) {
         // first execute runs eagerly (one-time function attributes, lazy module load), the second is captured
         if (!p.graph_exec && p.eager_runs >= 1) {
@@ -3075,6 +3097,7 @@ void plan_check_flags(emagls_plan& p) {
         p.sweep_persist = true;
     }
     throw_fatal_flags(flag);
+    p.geo_done_version = p.geo_run_version;   // (clean: a later set on the same grids may keep this run's geometry stages)
 }
 
 }  // namespace
@@ -4158,7 +4181,8 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
             for (int64_t first = 0; first < nsets; ++k) {
                 // (chunks of designs with more than 32 channels run plan by plan and hold gigabytes per plan: four at a time)
                 const bool wide_kind = ((kind == EMAGLS_KIND_MAGLS_2D || kind == EMAGLS_KIND_EMA_CH) ? 2 * order + 1 : kind == EMAGLS_KIND_EMAGLS2 ? (int)nmics : (order + 1) * (order + 1)) > 32;
-                const int chunk_max = wide_kind ? 4 : SWEEP_MULTI_MAX;
+                // (eMagLS / eMagLS2 there: one plan per chunk -- two plans alternate and keep their geometry stages, plan_execute -- instead of four)
+                const int chunk_max = wide_kind ? ((kind == EMAGLS_KIND_EMAGLS || kind == EMAGLS_KIND_EMAGLS2) ? 1 : 4) : SWEEP_MULTI_MAX;
                 const int n = (int)std::min<int64_t>(chunk_max, nsets - first);
                 const int slot = n == chunk_max ? (int)(k % 2) : 2;
                 SetsCache* c = &g_sets[slot];
@@ -4169,6 +4193,7 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
                         for (int j = 0; j < n; ++j) {
                             emagls_plan* p = nullptr;
                             req(emagls_plan_create(&d, &p));
+                            p->geo_keep = true;   // (one geometry for every set by this entry point's contract: plans of the 33..64-channel path keep their geometry stages)
                             c->plans.push_back(p);
                         }
                         // designs with more than 32 channels (LS / MagLS orders 5..7, arrays of 33..64 channels) do not enter
@@ -4434,6 +4459,9 @@ void jobs_run_chunk(const emagls_job* jobs, int n, int device, int flags, bool s
         const int kind = jobs[0].desc.kind;
         if (kind != EMAGLS_KIND_FROM_ATF && kind != EMAGLS_KIND_EMA_SH) check_rc(emagls_batch_set_geometry_sharing(slot->batch, 1));
     }
+    // (designs of the 33..64-channel path run plan by plan: with the flag a plan keeps its geometry stages from its last clean run while
+    // its own grids stay the same -- plan_execute)
+    if (!slot->batch) for (auto* q : slot->plans) q->geo_keep = (flags & EMAGLS_JOBS_SHARE_GEOMETRY) != 0;
     {
         if (slot->batch) {
             std::vector<void*> wl((size_t)n), wr((size_t)n);
@@ -4512,8 +4540,15 @@ int emagls_jobs_run(const emagls_job* jobs, int64_t njobs, int batch_size, int i
         for (int64_t first = 0; first < njobs;) {
             std::string shape, other;
             job_shape(jobs[first].desc, shape);
-            const int cap = array_kind(jobs[first].desc.kind) && !jobs[first].desc.custom_basis && !jobs[first].desc.diffuseness ? batch_size
-                                                                                                                              : std::min(batch_size, SWEEP_MULTI_MAX);
+            int cap = array_kind(jobs[first].desc.kind) && !jobs[first].desc.custom_basis && !jobs[first].desc.diffuseness ? batch_size
+                                                                                                                            : std::min(batch_size, SWEEP_MULTI_MAX);
+            // HRIR sets on one geometry on the 33..64-channel path (plan by plan, gigabytes per plan): one design per chunk, so that the sets
+            // pass through `in_flight` plans which keep their geometry stages (plan_execute) instead of one plan per set
+            {
+                const emagls_design_desc& d0 = jobs[first].desc;
+                const int64_t ch = d0.kind == EMAGLS_KIND_EMAGLS2 ? d0.nmics : (int64_t)(d0.order + 1) * (d0.order + 1);
+                if ((flags & EMAGLS_JOBS_SHARE_GEOMETRY) && (d0.kind == EMAGLS_KIND_EMAGLS || d0.kind == EMAGLS_KIND_EMAGLS2) && ch > 32) cap = 1;
+            }
             int n = 1;
             while (first + n < njobs && n < cap && (job_shape(jobs[first + n].desc, other), other == shape)) ++n;
             chunks.emplace_back(first, n);

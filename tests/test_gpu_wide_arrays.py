@@ -128,6 +128,34 @@ def test_wide_array_kernel_forms_agree(thin, monkeypatch):
     assert rel(wL, vL) < 1e-8 and rel(wR, vR) < 1e-8
 
 
+def test_hrir_sets_on_a_64_capsule_array_keep_the_geometry_stages(thin):
+    """HRIR sets on ONE geometry through the 33..64-channel path (the loop over subjects around lib/getEMagLs2Filters.m:32): the C call
+    (emagls_design_hrir_sets) and the job list with the share-geometry flag pass the sets through plans that keep G_k, the per-bin
+    factors and Y_reg_inv_k from their last clean run on the same grids (19 of a design's 31 ms).  Same filters as the single calls --
+    on the first call (plans run their geometry stages once), on a repeat (no plan does), and after the array has changed (all do)."""
+    import emagls_amd as E
+    from emagls_amd import synth, _lib as L
+    from emagls_amd.batch import emagls_hrir_sets
+    lib = L.load()
+    L.check(lib.emagls_cache_clear())
+    azi, zen = thin["azi"], thin["zen"]
+    subjects = [synth.rigid_sphere_hrirs(azi, zen, seed=31 + j, head_radius=0.08 + 0.002 * j) for j in range(5)]
+    hL = np.stack([s_[0] for s_ in subjects], axis=2)
+    hR = np.stack([s_[1] for s_ in subjects], axis=2)
+    worst = 0.0
+    for rot in (0.0, 0.0, 0.3):     # (the third pass: another array -- the plans' grids change, their geometry stages run again)
+        maz, mzn = synth.fibonacci_grid(64)
+        maz = maz + rot
+        single = [E.getEMagLs2Filters(s_[0], s_[1], azi, zen, 0.042, maz, mzn, 4, 48000.0, 128, "real") for s_ in subjects]
+        wL, wR = E.designHrirSets("emagls2", hL, hR, azi, zen, 0.042, maz, mzn, 4, 48000.0, 128, "real")
+        res = emagls_hrir_sets(subjects, azi, zen, 0.042, maz, mzn, 4, 48000.0, 128, "real", kind="emagls2")
+        for j in range(5):
+            worst = max(worst, rel(wL[:, :, j], single[j][0]), rel(wR[:, :, j], single[j][1]), rel(res[j][0], single[j][0]), rel(res[j][1], single[j][1]))
+    L.check(lib.emagls_cache_clear())
+    print(f"5 HRIR sets on a 64-capsule array, C call and job list, three passes, against the single designs: worst rel = {worst:.2e}")
+    assert worst < 1e-12
+
+
 def test_wide_arrays_refuse_what_they_cannot_do(thin):
     import emagls_amd as E
     from emagls_amd import synth

@@ -208,8 +208,23 @@ def em64(reps=2):
     p.get_filters()
     i = p.info()
     p.close()
-    return {"mics": 64, "radius_cm": 4.2, "taps": 1024, "sim_order": i.sim_order, "ms_per_design": round(dt * 1e3, 2), "filter_sets_per_s": round(1.0 / dt, 1),
-            "device_GB": round(i.device_bytes / 1e9, 2)}
+    out = {"mics": 64, "radius_cm": 4.2, "taps": 1024, "sim_order": i.sim_order, "ms_per_design": round(dt * 1e3, 2), "filter_sets_per_s": round(1.0 / dt, 1),
+           "device_GB": round(i.device_bytes / 1e9, 2)}
+    # HRIR sets on this one geometry (emagls_design_hrir_sets): two plans alternate and keep G_k, the per-bin factors and Y_reg_inv_k
+    # between sets (round 6) -- first call (plans created, geometry stages once per plan) and a repeat
+    import emagls_amd as E
+    nset = 8
+    sets = [synth.rigid_sphere_hrirs(azi, zen, seed=5 + j) for j in range(nset)]
+    sL, sR = np.stack([q[0] for q in sets], axis=2), np.stack([q[1] for q in sets], axis=2)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        E.designHrirSets("emagls2", sL, sR, azi, zen, 0.042, maz, mzn, 4, 48000.0, 1024, "real")
+        times.append(time.perf_counter() - t0)
+    out["hrir_sets_on_one_geometry"] = {"sets": nset, "first_call_ms_per_set": round(times[0] * 1e3 / nset, 2), "ms_per_set": round(min(times[1:]) * 1e3 / nset, 2),
+                                        "filter_sets_per_s": round(nset / min(times[1:]), 1),
+                                        "note": "emagls_design_hrir_sets: the sets pass through two plans that keep their geometry stages (same filters as the single designs, bit for bit)"}
+    return out
 
 
 def config5(reps=4, subjects=8):
