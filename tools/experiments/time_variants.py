@@ -1,11 +1,11 @@
 """Warm one-shot latency of the design variants at the config-3 size (2702 directions, 512 taps, em32 / 16-microphone equatorial array)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import emagls_amd as E
 from emagls_amd import synth
 
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_fixtures.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "ref_fixtures.npz"))
 azi, zen, maz, mzn = g["grid/hrirGridAziRad"], g["grid/hrirGridZenRad"], g["grid/micGridAziRad"], g["grid/micGridZenRad"]
 hL, hR = synth.rigid_sphere_hrirs(azi, zen)
 eq = np.linspace(0, 2 * np.pi, 16, endpoint=False)
