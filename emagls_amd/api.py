@@ -242,10 +242,10 @@ def designHrirSets(kind, hL, hR, hrirGridAziRad, hrirGridZenRad=None, micRadius=
                    fs=48000.0, len=512, shDefinition="real"):
     """The loop over HRIR sets around one of the reference's design functions, as ONE call (emagls_design_hrir_sets): hL, hR
     [numSamples x numDirections x numSets] on one grid (and one array); kind in 'ls', 'magls', 'magls2d', 'emagls', 'emagls2',
-    'emainch'.  Returns wL, wR [len x channels x numSets] -- the filters nsets single calls return (lib/getLsFilters.m:30,
+    'emainch', 'emainsh'.  Returns wL, wR [len x channels x numSets] -- the filters nsets single calls return (lib/getLsFilters.m:30,
     getMagLsFilters.m:30, getMagLsFilters2D.m:1, getEMagLsFilters.m:32, getEMagLs2Filters.m:32, getEMagLsFiltersEMAinCH.m:32)."""
     kinds = {"ls": L.KIND_LS, "magls": L.KIND_MAGLS, "magls2d": L.KIND_MAGLS_2D, "emagls": L.KIND_EMAGLS, "emagls2": L.KIND_EMAGLS2,
-             "emainch": L.KIND_EMA_CH}
+             "emainch": L.KIND_EMA_CH, "emainsh": L.KIND_EMA_SH}
     if kind not in kinds:
         raise ValueError("kind must be one of %s" % sorted(kinds))
     b, cplx = _basis(shDefinition)
@@ -256,11 +256,11 @@ def designHrirSets(kind, hL, hR, hrirGridAziRad, hrirGridZenRad=None, micRadius=
     n, D, nsets = hL.shape
     azi, pa = _vec(hrirGridAziRad, D, "hrirGridAziRad")
     zen, pz = (None, None) if hrirGridZenRad is None else _vec(hrirGridZenRad, D, "hrirGridZenRad")
-    arr = kind in ("emagls", "emagls2", "emainch")
+    arr = kind in ("emagls", "emagls2", "emainch", "emainsh")
     micAzi, pma = _vec(micGridAziRad) if arr else (None, None)
     micZen, pmz = (None, None) if (not arr or micGridZenRad is None) else _vec(micGridZenRad, micAzi.size, "micGridZenRad")
     N = int(order)
-    C_ = {"ls": (N + 1) ** 2, "magls": (N + 1) ** 2, "magls2d": 2 * N + 1, "emagls": (N + 1) ** 2, "emainch": 2 * N + 1}.get(kind)
+    C_ = {"ls": (N + 1) ** 2, "magls": (N + 1) ** 2, "magls2d": 2 * N + 1, "emagls": (N + 1) ** 2, "emainch": 2 * N + 1, "emainsh": (N + 1) ** 2}.get(kind)
     if kind == "emagls2":
         C_ = micAzi.size
     rows = n if kind == "ls" else int(len)

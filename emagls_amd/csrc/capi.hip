@@ -4147,9 +4147,9 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
                             int64_t nmics, int order, double fs, int64_t len, int basis, void* wL, void* wR) {
     return guarded([&] {
         if (!hL || !hR || !hrir_azi || !wL || !wR || nsets < 1) throw Error(EMAGLS_ERR_ARG, "invalid argument");
-        const bool arr = kind == EMAGLS_KIND_EMAGLS || kind == EMAGLS_KIND_EMAGLS2 || kind == EMAGLS_KIND_EMA_CH;
+        const bool arr = kind == EMAGLS_KIND_EMAGLS || kind == EMAGLS_KIND_EMAGLS2 || kind == EMAGLS_KIND_EMA_CH || kind == EMAGLS_KIND_EMA_SH;
         if (!arr && kind != EMAGLS_KIND_LS && kind != EMAGLS_KIND_MAGLS && kind != EMAGLS_KIND_MAGLS_2D)
-            throw Error(EMAGLS_ERR_UNSUPPORTED, "HRIR-set job lists: LS, MagLS, MagLS-2D, eMagLS, eMagLS2, EMAinCH");
+            throw Error(EMAGLS_ERR_UNSUPPORTED, "HRIR-set job lists: LS, MagLS, MagLS-2D, eMagLS, eMagLS2, EMAinCH, EMAinSH");
         emagls_design_desc d{};
         d.kind = kind; d.basis = basis; d.order = order; d.fs = fs; d.len = kind == EMAGLS_KIND_LS ? nsamp : len; d.nsamp = nsamp; d.ndirs = ndirs;
         d.mic_radius = arr ? mic_radius : 0.0; d.nmics = arr ? nmics : 0;
@@ -4182,7 +4182,7 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
                 // (chunks of designs with more than 32 channels run plan by plan and hold gigabytes per plan: four at a time)
                 const bool wide_kind = ((kind == EMAGLS_KIND_MAGLS_2D || kind == EMAGLS_KIND_EMA_CH) ? 2 * order + 1 : kind == EMAGLS_KIND_EMAGLS2 ? (int)nmics : (order + 1) * (order + 1)) > 32;
                 // (eMagLS / eMagLS2 there: one plan per chunk -- two plans alternate and keep their geometry stages, plan_execute -- instead of four)
-                const int chunk_max = wide_kind ? ((kind == EMAGLS_KIND_EMAGLS || kind == EMAGLS_KIND_EMAGLS2) ? 1 : 4) : SWEEP_MULTI_MAX;
+                const int chunk_max = wide_kind ? ((kind == EMAGLS_KIND_EMAGLS || kind == EMAGLS_KIND_EMAGLS2) ? 1 : 4) : kind == EMAGLS_KIND_EMA_SH ? 4 : SWEEP_MULTI_MAX;
                 const int n = (int)std::min<int64_t>(chunk_max, nsets - first);
                 const int slot = n == chunk_max ? (int)(k % 2) : 2;
                 SetsCache* c = &g_sets[slot];
@@ -4198,7 +4198,8 @@ int emagls_design_hrir_sets(int kind, const double* hL, const double* hR, int64_
                         }
                         // designs with more than 32 channels (LS / MagLS orders 5..7, arrays of 33..64 channels) do not enter
                         // batches (emagls_batch_create): their chunk runs plan by plan, same filters as nsets single calls
-                        if (n > 1 && !c->plans[0]->wide) {
+                        // (EMAinSH -- lib/getEMagLsFiltersEMAinSH.m:32 -- has no lane batches either: plan by plan)
+                        if (n > 1 && !c->plans[0]->wide && kind != EMAGLS_KIND_EMA_SH) {
                             g_batch_max_override = SWEEP_MULTI_MAX;
                             const int r = emagls_batch_create(c->plans.data(), n, &c->batch);
                             g_batch_max_override = 0;

@@ -414,8 +414,8 @@ int emagls_jobs_sweep_times(double* ms, int* designs, int capacity, int* count);
 /* HRIR sets on ONE grid (and, for the array kinds, ONE array) in one call -- the loop
  *     for i = 1:nsets, [wL(:,:,i), wR(:,:,i)] = getEMagLsFilters(hL(:,:,i), hR(:,:,i), grid..., array..., order, fs, len, shDefinition); end
  * around lib/getLsFilters.m:30 / getMagLsFilters.m:30 / getMagLsFilters2D.m:1 (hrir_zen NULL) / getEMagLsFilters.m:32 /
- * getEMagLs2Filters.m:32 / getEMagLsFiltersEMAinCH.m:32 (mic_zen NULL), kind = EMAGLS_KIND_LS / _MAGLS / _MAGLS_2D / _EMAGLS /
- * _EMAGLS2 / _EMA_CH.  hL, hR [nsamp x ndirs x nsets] (MATLAB 3-D arrays), wL, wR [len x channels x nsets] (LS: nsamp rows; `fs`
+ * getEMagLs2Filters.m:32 / getEMagLsFiltersEMAinCH.m:32 / getEMagLsFiltersEMAinSH.m:32 (mic_zen NULL; EMAinSH plan by plan), kind =
+ * EMAGLS_KIND_LS / _MAGLS / _MAGLS_2D / _EMAGLS / _EMAGLS2 / _EMA_CH / _EMA_SH.  hL, hR [nsamp x ndirs x nsets] (MATLAB 3-D arrays), wL, wR [len x channels x nsets] (LS: nsamp rows; `fs`
  * and `len` are ignored for LS).  Internally: plans and geometry-sharing batches of up to 16 sets (kept for the next call of the
  * same shape; emagls_cache_clear releases them), one resident sweep launch per batch; the same filters as nsets single calls.
  * eMagLS / eMagLS2 with 33..64 channels: the sets pass through two plans that keep their geometry stages between sets. */

@@ -8,11 +8,11 @@ function [wL, wR] = designHrirSets(kind, hL, hR, hrirGridAziRad, hrirGridZenRad,
 %                                                   micRadius, micGridAziRad, micGridZenRad, order, fs, len, shDefinition);
 %     end
 %
-% kind           .. 'ls' | 'magls' | 'magls2d' | 'emagls' | 'emagls2' | 'emainch'  (getLsFilters, getMagLsFilters,
-%                   getMagLsFilters2D, getEMagLsFilters, getEMagLs2Filters, getEMagLsFiltersEMAinCH)
+% kind           .. 'ls' | 'magls' | 'magls2d' | 'emagls' | 'emagls2' | 'emainch' | 'emainsh'  (getLsFilters, getMagLsFilters,
+%                   getMagLsFilters2D, getEMagLsFilters, getEMagLs2Filters, getEMagLsFiltersEMAinCH, getEMagLsFiltersEMAinSH)
 % hL, hR         .. [numSamples x numDirections x numSets], all sets on the same HRIR grid (and the same array)
 % hrirGridZenRad .. [] for 'magls2d'; micRadius, micGridAziRad, micGridZenRad .. [] where the single call has no such argument
-%                   (micGridZenRad also for 'emainch'); fs, len .. ignored for 'ls'
+%                   (micGridZenRad also for 'emainch' / 'emainsh'); fs, len .. ignored for 'ls'
 % wL, wR         .. [len x numChannels x numSets]: the filters the single calls return
 %
 % The geometry-only stages (SH matrices, array model, every bin's regularised inverse) run once per batch of up to 16 sets and

@@ -123,7 +123,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         int kind;
         if (ks == "ls") kind = EMAGLS_KIND_LS; else if (ks == "magls") kind = EMAGLS_KIND_MAGLS; else if (ks == "magls2d") kind = EMAGLS_KIND_MAGLS_2D;
         else if (ks == "emagls") kind = EMAGLS_KIND_EMAGLS; else if (ks == "emagls2") kind = EMAGLS_KIND_EMAGLS2;
-        else if (ks == "emainch") kind = EMAGLS_KIND_EMA_CH;
+        else if (ks == "emainch") kind = EMAGLS_KIND_EMA_CH; else if (ks == "emainsh") kind = EMAGLS_KIND_EMA_SH;
         else { mexErrMsgIdAndTxt("eMagLS:arg", "unknown design kind '%s'", kb); return; }
         const double* hL = dbl(prhs[2], "hL");
         const double* hR = dbl(prhs[3], "hR");

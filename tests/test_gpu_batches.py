@@ -281,7 +281,7 @@ def test_hrir_sets_on_one_geometry_share_it(grids, thin, kind):
         p.close()
 
 
-@pytest.mark.parametrize("kind", ["ls", "magls", "magls2d", "emagls", "emagls2", "emainch"])
+@pytest.mark.parametrize("kind", ["ls", "magls", "magls2d", "emagls", "emagls2", "emainch", "emainsh"])
 def test_design_hrir_sets_in_one_call(grids, thin, kind):
     """emagls_design_hrir_sets: the loop over HRIR sets around a design function as ONE C call (3-D arrays in and out; plans and
     geometry-sharing batches of up to 16 sets inside, kept for the next call).  19 sets = a batch of 16 and a tail batch of 3;
@@ -297,28 +297,31 @@ def test_design_hrir_sets_in_one_call(grids, thin, kind):
         azi, zen, base = thin["azi"], thin["zen"], (thin["hL"], thin["hR"])
     hL = np.stack([base[0] * (1 + 0.03 * j) + 1e-3 * rng.standard_normal(base[0].shape) for j in range(nsets)], axis=2)
     hR = np.stack([base[1] * (1 - 0.02 * j) + 1e-3 * rng.standard_normal(base[1].shape) for j in range(nsets)], axis=2)
-    order = {"magls2d": 5, "emainch": 3}.get(kind, 4)
-    ma = np.linspace(0, 2 * np.pi, 9, endpoint=False) + 0.2 if kind == "emainch" else grids["mic_azi"]
-    mz = None if kind == "emainch" else grids["mic_zen"]
+    order = {"magls2d": 5, "emainch": 3, "emainsh": 2}.get(kind, 4)
+    ma = np.linspace(0, 2 * np.pi, 9, endpoint=False) + 0.2 if kind in ("emainch", "emainsh") else grids["mic_azi"]
+    mz = None if kind in ("emainch", "emainsh") else grids["mic_zen"]
+    if kind == "emainsh":   # (plan by plan, no batches: fewer sets)
+        nsets, hL, hR = 6, hL[:, :, :6], hR[:, :, :6]
     kw = dict(order=order, fs=48000.0, len=128, shDefinition="complex")
-    if kind in ("emagls", "emagls2", "emainch"):
+    if kind in ("emagls", "emagls2", "emainch", "emainsh"):
         kw.update(micRadius=grids["mic_radius"], micGridAziRad=ma, micGridZenRad=mz)
     single = {"ls": lambda a, b: E.getLsFilters(a, b, azi, zen, order, "complex"),
               "magls": lambda a, b: E.getMagLsFilters(a, b, azi, zen, order, 48000.0, 128, "complex"),
               "magls2d": lambda a, b: E.getMagLsFilters2D(a, b, azi, order, 48000.0, 128, "complex"),
               "emagls": lambda a, b: E.getEMagLsFilters(a, b, azi, zen, grids["mic_radius"], ma, mz, order, 48000.0, 128, "complex"),
               "emagls2": lambda a, b: E.getEMagLs2Filters(a, b, azi, zen, grids["mic_radius"], ma, mz, order, 48000.0, 128, "complex"),
-              "emainch": lambda a, b: E.getEMagLsFiltersEMAinCH(a, b, azi, zen, grids["mic_radius"], ma, order, 48000.0, 128, "complex")}[kind]
+              "emainch": lambda a, b: E.getEMagLsFiltersEMAinCH(a, b, azi, zen, grids["mic_radius"], ma, order, 48000.0, 128, "complex"),
+              "emainsh": lambda a, b: E.getEMagLsFiltersEMAinSH(a, b, azi, zen, grids["mic_radius"], ma, order, 48000.0, 128, "complex")}[kind]
     for rep in range(2):
         wL, wR = E.designHrirSets(kind, hL, hR, azi, zen, **kw)
         worst = 0.0
-        for j in (0, 7, 15, 16, 18):
+        for j in ((0, 7, 15, 16, 18) if nsets == 19 else (0, 3, 4, 5)):
             sL, sR = single(hL[:, :, j], hR[:, :, j])
             assert wL[:, :, j].shape == sL.shape and wL.dtype == sL.dtype
             worst = max(worst, rel(wL[:, :, j], sL), rel(wR[:, :, j], sR))
-        print(f"{kind}: 19 HRIR sets in one call (pass {rep}): worst rel vs single calls = {worst:.3e}")
+        print(f"{kind}: {nsets} HRIR sets in one call (pass {rep}): worst rel vs single calls = {worst:.3e}")
         assert worst < 1e-9
-    assert rel(wL[:, :, 0], wL[:, :, 9]) > 1e-3
+    assert rel(wL[:, :, 0], wL[:, :, nsets // 2]) > 1e-3
 
 
 @pytest.mark.parametrize("kind,order,nmics", [("ls", 6, 0), ("magls", 5, 0), ("emagls2", 4, 40)])
