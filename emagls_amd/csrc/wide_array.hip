@@ -519,6 +519,164 @@ __global__ void __launch_bounds__(256) wa_yri_mfma_kernel(const double* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Tall problems (more rows than the register forms above hold: EMAinSH orders 5..7 and matched ATF matrices factor D-long columns --
+// 2702 rows --, arrays at large radii S > 448; round 6).  The plain forms walk every column twice per reflector with one load in flight
+// per lane: 14.5 ms (QR) and 30.3 ms (back-transform) for the 256 bins of an order-6 EMAinSH design.  Here the reflector of a step
+// lies in LDS (zero outside its rows, so no row tests), and a column is loaded ONCE per step with all its loads in flight:
+//   wa_back_tall_kernel  the columns of X are independent: a wave keeps ONE column in registers through all reflectors (NRT rows per
+//                        lane), a workgroup = 8 columns of a bin; v_{j-1} is requested before step j's arithmetic
+//   wa_qr_tall_kernel    a wave takes the trailing columns of a step in turn: whole column -> registers, dot, update, store
+// ---------------------------------------------------------------------------------------------
+constexpr int WA_TALL = 48;     // rows per lane: up to 3072 rows
+template <int NRT>
+__global__ void __launch_bounds__(512) wa_back_tall_kernel(const cplx* __restrict__ Vw, const double* __restrict__ tauw, const cplx* __restrict__ Nw, int S,
+                                                           int C, int ldS, cplx* __restrict__ Z) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* vs = reinterpret_cast<cplx*>(dyn);              // [64 NRT]
+    __shared__ double tau_s[WA_CMAX];
+    const cplx* Vk = Vw + (int64_t)blockIdx.x * C * ldS;
+    const cplx* N = Nw + (int64_t)blockIdx.x * C * C;
+    cplx* Zk = Z + (int64_t)blockIdx.x * C * ldS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = 8 * blockIdx.y + wave;
+    const bool active = c < C;
+    if (tid < C) tau_s[tid] = tauw[(int64_t)blockIdx.x * C + tid];
+    cplx x[NRT];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+        const int s = lane + 64 * i;
+        x[i] = (active && s < C && s < S) ? conj(N[s * C + c]) : mk(0.0, 0.0);   // X[s][c] = conj(N[s][c])
+    }
+    constexpr int NST = 64 * NRT / 512;   // staged values per thread and step
+    cplx r[NST];
+    auto fetch = [&](int j) __attribute__((always_inline)) {
+        const cplx* vj = Vk + (int64_t)j * ldS;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int s = tid + 512 * q;
+            r[q] = (s >= j && s < S) ? vj[s] : mk(0.0, 0.0);
+        }
+    };
+    fetch(C - 1);
+    for (int j = C - 1; j >= 0; --j) {
+        __syncthreads();   // (the readers of step j + 1 are done)
+#pragma unroll
+        for (int q = 0; q < NST; ++q) vs[tid + 512 * q] = r[q];
+        __syncthreads();
+        if (j > 0) fetch(j - 1);
+        // (four rows of the reflector at a time: the scheduler would otherwise request all NRT values next to the NRT rows of x and spill)
+        cplx w0 = mk(0.0, 0.0), w1 = mk(0.0, 0.0);
+#pragma unroll
+        for (int i0 = 0; i0 < NRT; i0 += 4) {
+#pragma unroll
+            for (int i = i0; i < i0 + 4; i += 2) { cfma_conj(w0, vs[lane + 64 * i], x[i]); cfma_conj(w1, vs[lane + 64 * (i + 1)], x[i + 1]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cplx w = wave_sum(w0 + w1);
+        const double tau = tau_s[j];
+        w = mk(w.x * tau, w.y * tau);
+#pragma unroll
+        for (int i0 = 0; i0 < NRT; i0 += 4) {
+#pragma unroll
+            for (int i = i0; i < i0 + 4; ++i) { cplx t = mk(0.0, 0.0); cfma(t, vs[lane + 64 * i], w); x[i] = x[i] - t; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+        const int s = lane + 64 * i;
+        if (s < ldS) Zk[(int64_t)c * ldS + s] = s < S ? conj(x[i]) : mk(0.0, 0.0);
+    }
+}
+
+template <int NRT>
+__global__ void __launch_bounds__(512) wa_qr_tall_kernel(cplx* __restrict__ B, cplx* __restrict__ Vw, int S, int C, int ldS, double* __restrict__ tauw,
+                                                         cplx* __restrict__ R2w) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    cplx* vs = reinterpret_cast<cplx*>(dyn);              // [64 NRT]  v_j, zero outside rows j .. S-1
+    __shared__ double red[8];
+    __shared__ cplx s_alpha;
+    __shared__ double s_tau;
+    cplx* Bk = B + (int64_t)blockIdx.x * C * ldS;
+    cplx* Vk = Vw + (int64_t)blockIdx.x * C * ldS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NST = 64 * NRT / 512;
+    for (int j = 0; j < C; ++j) {
+        cplx* aj = Bk + (int64_t)j * ldS;
+        // column j (as the earlier steps left it) into LDS, its norm on the way
+        cplx r[NST];
+        double n2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int s = tid + 512 * q;
+            r[q] = (s >= j && s < S) ? aj[s] : mk(0.0, 0.0);
+            n2 += norm2(r[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NST; ++q) vs[tid + 512 * q] = r[q];
+        n2 = block_sum(n2, red);   // (contains the barriers that complete vs)
+        if (tid == 0) {
+            const cplx x0 = vs[j];
+            const double nx = sqrt(n2), ax = cabs(x0);
+            cplx alpha = mk(-nx, 0.0);
+            if (ax > 0.0) alpha = mk(-x0.x / ax * nx, -x0.y / ax * nx);
+            const double nv2 = 2.0 * nx * (nx + ax);          // |x - alpha e_1|^2
+            s_alpha = alpha;
+            s_tau = nv2 > 0.0 ? 2.0 / nv2 : 0.0;
+            vs[j] = x0 - alpha;
+            tauw[(int64_t)blockIdx.x * C + j] = s_tau;
+        }
+        __syncthreads();
+        const cplx alpha = s_alpha;
+        const double tau = s_tau;
+        // v_j to memory (the back-transform reads it), column j itself: alpha on the diagonal, zeros below
+        cplx* vj = Vk + (int64_t)j * ldS;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int s = tid + 512 * q;
+            if (s >= j && s < S) { vj[s] = vs[s]; aj[s] = s == j ? alpha : mk(0.0, 0.0); }
+        }
+        // columns k > j: a_k -= tau v (v^H a_k); a wave per column, the column once through registers
+        for (int k = j + 1 + wave; k < C; k += 8) {
+            cplx* ak = Bk + (int64_t)k * ldS;
+            cplx a[NRT];
+#pragma unroll
+            for (int i = 0; i < NRT; ++i) {
+                const int s = lane + 64 * i;
+                a[i] = (s >= j && s < S) ? ak[s] : mk(0.0, 0.0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cplx w0 = mk(0.0, 0.0), w1 = mk(0.0, 0.0);
+#pragma unroll
+            for (int i0 = 0; i0 < NRT; i0 += 8) {
+#pragma unroll
+                for (int i = i0; i < i0 + 8; i += 2) { cfma_conj(w0, vs[lane + 64 * i], a[i]); cfma_conj(w1, vs[lane + 64 * (i + 1)], a[i + 1]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cplx w = wave_sum(w0 + w1);
+            w = mk(w.x * tau, w.y * tau);
+#pragma unroll
+            for (int i0 = 0; i0 < NRT; i0 += 8) {
+#pragma unroll
+                for (int i = i0; i < i0 + 8; ++i) {
+                    const int s = lane + 64 * i;
+                    if (s >= j && s < S) { cplx t = mk(0.0, 0.0); cfma(t, vs[s], w); ak[s] = a[i] - t; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();   // (vs is rewritten by the next step; the trailing columns are complete in memory for this workgroup)
+    }
+    cplx* R2 = R2w + (int64_t)blockIdx.x * C * C;
+    for (int idx = tid; idx < C * C; idx += 512) {
+        const int i = idx / C, k = idx % C;
+        R2[idx] = (i <= k && i < S) ? Bk[(int64_t)k * ldS + i] : mk(0.0, 0.0);
+    }
+}
+
 // least-squares rows: W[e][kb][c] = sum_d Hc[e][kb][d] Yri[kb][c][d]   (kb < n_c)
 __global__ void __launch_bounds__(256) wa_ls_kernel(const cplx* __restrict__ Hc, int64_t ldH, int n_c, const cplx* __restrict__ Yri, int64_t ldD, int D, int C,
                                                     int P, int kb_first, cplx* __restrict__ W) {
@@ -575,7 +733,18 @@ void launch_wa_factor(void* B, void* Vw, int S, int C, int ldS, int nbins, doubl
     if (S < C) throw Error(2, "33..64 channels with fewer simulated SH channels than channels (rank-deficient array model: the reference's clipped inverse is rounding noise there) is not supported");
     const char* e_reg = getenv("EMAGLS_WA_REG");   // =0: the forms that walk the columns through L2
     const bool reg7 = ldS <= 64 * 7 && !(e_reg && e_reg[0] == '0');
+    const char* e_tall = getenv("EMAGLS_WA_TALL");   // =0: the plain forms for the tall problems
+    const bool tall = !reg7 && S <= 64 * WA_TALL && !(e_tall && e_tall[0] == '0');
+    const size_t dyn_tall = sizeof(cplx) * 64 * WA_TALL;
+    if (tall) {
+        static PerDeviceOnce tall_once;
+        if (tall_once.first()) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)wa_qr_tall_kernel<WA_TALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            HIP_CHECK(hipFuncSetAttribute((const void*)wa_back_tall_kernel<WA_TALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        }
+    }
     if (reg7) wa_qr_reg_kernel<7><<<nbins, 1024, 0, st>>>((const cplx*)B, (cplx*)Vw, S, C, ldS, tauw, (cplx*)R2w);
+    else if (tall) wa_qr_tall_kernel<WA_TALL><<<nbins, 512, dyn_tall, st>>>((cplx*)B, (cplx*)Vw, S, C, ldS, tauw, (cplx*)R2w);
     else wa_qr_kernel<<<nbins, 512, 0, st>>>((cplx*)B, (cplx*)Vw, S, C, ldS, tauw, (cplx*)R2w);
     KERNEL_CHECK();
     const int Cp = (C + 1) & ~1;
@@ -586,6 +755,7 @@ void launch_wa_factor(void* B, void* Vw, int S, int C, int ldS, int nbins, doubl
     wa_jacobi_kernel<<<nbins, 1024, dyn, st>>>((const cplx*)R2w, C, reg_c, (cplx*)Nw, sv, sweeps, flag2);
     KERNEL_CHECK();
     if (reg7) wa_back_reg_kernel<7><<<dim3(nbins, (unsigned)ceil_div(C, 32)), 512, 0, st>>>((const cplx*)Vw, tauw, (const cplx*)Nw, S, C, ldS, (cplx*)Z);
+    else if (tall) wa_back_tall_kernel<WA_TALL><<<dim3(nbins, (unsigned)ceil_div(C, 8)), 512, dyn_tall, st>>>((const cplx*)Vw, tauw, (const cplx*)Nw, S, C, ldS, (cplx*)Z);
     else wa_back_kernel<<<nbins, 512, 0, st>>>((const cplx*)Vw, tauw, (const cplx*)Nw, S, C, ldS, (cplx*)Z);
     KERNEL_CHECK();
 }

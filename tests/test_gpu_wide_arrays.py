@@ -156,6 +156,33 @@ def test_hrir_sets_on_a_64_capsule_array_keep_the_geometry_stages(thin):
     assert worst < 1e-12
 
 
+def test_tall_householder_forms_agree(thin, monkeypatch):
+    """The Householder kernels for problems with more rows than the register forms hold (round 6: the reflector in LDS, a column once
+    through registers per step -- wa_qr_tall_kernel, wa_back_tall_kernel) against the plain forms (EMAGLS_WA_TALL=0): an order-6
+    EMAinSH design (its per-bin factorisation works on D-long columns, 901 rows here) and a 64-microphone array at 8 cm (S = 1296)."""
+    import emagls_amd as E
+    from emagls_amd import synth, _lib as L
+    lib = L.load()
+    maz20 = np.linspace(0, 2 * np.pi, 20, endpoint=False) + 0.1
+    maz, mzn = synth.fibonacci_grid(64)
+    sub = slice(0, 901, 1)
+    azi, zen = synth.fibonacci_grid(1400)
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen, taps=64)
+    runs = {"EMAinSH order 6": lambda: E.getEMagLsFiltersEMAinSH(thin["hL"], thin["hR"], thin["azi"], thin["zen"], 0.05, maz20, 6, 48000.0, 128, "real"),
+            "64 microphones at 8 cm": lambda: E.getEMagLs2Filters(hL, hR, azi, zen, 0.08, maz, mzn, 4, 48000.0, 64, "real")}
+    for name, run in runs.items():
+        monkeypatch.delenv("EMAGLS_WA_TALL", raising=False)
+        L.check(lib.emagls_cache_clear())
+        wL, wR = run()
+        monkeypatch.setenv("EMAGLS_WA_TALL", "0")
+        L.check(lib.emagls_cache_clear())
+        vL, vR = run()
+        e = max(rel(wL, vL), rel(wR, vR))
+        print(f"{name}: tall Householder forms vs the plain ones: rel = {e:.3e}")
+        assert e < 1e-9
+    L.check(lib.emagls_cache_clear())
+
+
 def test_wide_arrays_refuse_what_they_cannot_do(thin):
     import emagls_amd as E
     from emagls_amd import synth
