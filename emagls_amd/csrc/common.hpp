@@ -103,6 +103,8 @@ struct BatchScope {
 
 #ifdef __HIPCC__
 inline dim3 bgrid(dim3 g) { g.z = (unsigned)batch_ctx().n; return g; }
+// EMAGLS_XCD_RUNS=0: the kernels that take an XCD-aware tile order (xcd_run_index) keep the dispatch order
+inline int xcd_runs_enabled() { static const int on = [] { const char* e = getenv("EMAGLS_XCD_RUNS"); return (e && e[0] == '0') ? 0 : 1; }(); return on; }
 // (byte arithmetic on the pointer itself: a round trip through an integer hides the address space from the compiler and
 // every access through the result becomes a flat_* instruction, which also counts on lgkmcnt and so couples with LDS waits)
 template <typename T> __device__ __forceinline__ T* boffz(T* p, size_t stride, unsigned z) {
@@ -110,6 +112,18 @@ template <typename T> __device__ __forceinline__ T* boffz(T* p, size_t stride, u
     return p ? reinterpret_cast<T*>(reinterpret_cast<byte_t*>(p) + (size_t)z * stride) : p;
 }
 template <typename T> __device__ __forceinline__ T* boff(T* p, size_t stride) { return boffz(p, stride, blockIdx.z); }
+// XCD-aware workgroup -> (lane, tile) for kernels whose tiles of ONE lane share operands (round 6).  Workgroups go to the eight XCDs in
+// turn in dispatch order (x fastest, then y, then z), so the plain mapping deals the tiles of a lane over all eight L2s and every tile
+// fetches the shared operands itself.  Here XCD x takes a contiguous run of the lane-major (lane, tile) list: the tiles of a lane start
+// together on ONE XCD, walk their operands at the same pace, and what one tile fetched is an L2 hit for the others.  tile = x + gridDim.x * y
+// of the remapped workgroup.  (A bijection of the grid for any lane count: XCD x owns ceil((W - x) / 8) list items.)
+__device__ __forceinline__ void xcd_run_index(unsigned& tile, unsigned& lane) {
+    const unsigned nt = gridDim.x * gridDim.y, W = nt * gridDim.z, L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned x = L & 7u, slot = L >> 3, q = W >> 3, r = W & 7u;
+    const unsigned g = x * q + (x < r ? x : r) + slot;
+    lane = g / nt;
+    tile = g - lane * nt;
+}
 // the integer round trip (flat_* accesses): kept for the factor kernels, whose QR kernel the compiler schedules worse
 // with global_* accesses under its 128-VGPR cap (805 -> 901 us per 8-design launch)
 template <typename T> __device__ __forceinline__ T* boff_flat(T* p, size_t stride, unsigned z) {

@@ -104,11 +104,16 @@ __global__ void __launch_bounds__(256) gram_mfma_kernel(const T* __restrict__ Yc
 constexpr int GL_KC = 16;          // rows per stage
 constexpr int GL_LD = 64 + 16;     // row stride of a stage in doubles (32 banks mod 64: the four k rows of a fragment read tile the banks)
 __global__ void __launch_bounds__(256) gram_lds_kernel(const double* __restrict__ Yc, int64_t ld, int S, int64_t rows, int nbt,
-                                                       double* __restrict__ G, double* __restrict__ R, int Sh, size_t bstride) {
-    Yc = boff(Yc, bstride); G = boff(G, bstride); R = boff(R, bstride);
+                                                       double* __restrict__ G, double* __restrict__ R, int Sh, size_t bstride, int xcd_runs) {
+    // workgroup -> (lane, tile), XCD aware (xcd_run_index, common.hpp): the plain mapping dealt the 28 tiles of a design over all eight L2s and
+    // every tile fetched its two panels itself -- 68 MB per design for a 9.9 MB operand, 15 MB this way (profiles/r06_xcd_runs.md)
+    unsigned zl = blockIdx.z, tl = blockIdx.x;
+    if (xcd_runs) xcd_run_index(tl, zl);
+    int t = (int)tl;
+    Yc = boffz(Yc, bstride, zl); G = boffz(G, bstride, zl); R = boffz(R, bstride, zl);
     __shared__ __attribute__((aligned(16))) double As[2][GL_KC][GL_LD];
     __shared__ __attribute__((aligned(16))) double Bs[2][GL_KC][GL_LD];
-    int t = blockIdx.x, ti = 0;
+    int ti = 0;
     while (t >= nbt - ti) { t -= nbt - ti; ++ti; }
     const int tj = ti + t;
     const bool diag = ti == tj;
@@ -271,7 +276,7 @@ double gram_tile_selftest(bool four) {
     HIP_CHECK(hipMemcpy(dY, Y.data(), sizeof(double) * Y.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(dG, 0, sizeof(double) * G.size()));
     if (four) gram_lds4_kernel<<<dim3(ntiles), 256>>>(dY, ld, S, rows, nbt, dG, nullptr, 0, 0);
-    else gram_lds_kernel<<<dim3(ntiles), 256>>>(dY, ld, S, rows, nbt, dG, nullptr, 0, 0);
+    else gram_lds_kernel<<<dim3(ntiles), 256>>>(dY, ld, S, rows, nbt, dG, nullptr, 0, 0, 1);
     KERNEL_CHECK();
     HIP_CHECK(hipMemcpy(G.data(), dG, sizeof(double) * G.size(), hipMemcpyDeviceToHost));
     HIP_CHECK(hipFree(dY));
@@ -769,7 +774,9 @@ static void gram_impl(const void* Yc, int64_t D, int S, int64_t ld, void* Gp, vo
             const char* e4 = getenv("EMAGLS_GRAM_MFMA4");   // (read at every launch: a test switches forms inside one process)
             const bool four = e4 && e4[0] == '1';
             if (four) gram_lds4_kernel<<<bgrid(ntiles), 256, 0, st>>>((const double*)Yc, ld, S, gram_dpad(D, S), nbt, (double*)G, (double*)R, Sh, batch_ctx().stride);
-            else gram_lds_kernel<<<bgrid(ntiles), 256, 0, st>>>((const double*)Yc, ld, S, gram_dpad(D, S), nbt, (double*)G, (double*)R, Sh, batch_ctx().stride);
+            else {
+                gram_lds_kernel<<<bgrid(ntiles), 256, 0, st>>>((const double*)Yc, ld, S, gram_dpad(D, S), nbt, (double*)G, (double*)R, Sh, batch_ctx().stride, xcd_runs_enabled());
+            }
             KERNEL_CHECK();
             return;
         }

@@ -141,12 +141,15 @@ __global__ void __launch_bounds__(128) gram_coef_kernel(const cplx* __restrict__
 // Cm + s * cstride (the caller sums the partials in a fixed order).
 __global__ void __launch_bounds__(256) gemm_tn_f64_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, int K,
                                                           double* __restrict__ Cm, int ldc, int M, int N, int mtiles, int64_t cstride,
-                                                          size_t bstride) {
-    A = boff(A, bstride); B = boff(B, bstride); Cm = boff(Cm, bstride);
+                                                          size_t bstride, int xcd_runs) {
+    // (the tiles of a lane share both operands: XCD-aware order, xcd_run_index)
+    unsigned zl = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+    if (xcd_runs) { unsigned tl; xcd_run_index(tl, zl); by = tl / gridDim.x; bx = tl - by * gridDim.x; }
+    A = boffz(A, bstride, zl); B = boffz(B, bstride, zl); Cm = boffz(Cm, bstride, zl);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int split = blockIdx.x / mtiles, mt = blockIdx.x - split * mtiles;
+    const int split = (int)bx / mtiles, mt = (int)bx - split * mtiles;
     A += (int64_t)split * K * lda; B += (int64_t)split * K * ldb; Cm += (int64_t)split * cstride;
-    const int m0 = mt * 64 + (wave >> 1) * 32, n0 = blockIdx.y * 64 + (wave & 1) * 32;
+    const int m0 = mt * 64 + (wave >> 1) * 32, n0 = (int)by * 64 + (wave & 1) * 32;
     const int ii = lane & 15, kk = lane >> 4;
     double4_t acc[2][2];
 #pragma unroll
@@ -344,7 +347,7 @@ void launch_gram_gemm(const void* bn, int nOrd, int P, int kb0, int nbins, doubl
     const int K = (nOrd * nOrd + 3) / 4 * 4;
     const int mtiles = (nbins + 63) / 64;
     gemm_tn_f64_kernel<<<bgrid(dim3(mtiles, (C * C + 63) / 64)), 256, 0, st>>>(Cf, ldC, Kmat, ldK, K, Apk, ldA, nbins, C * C, mtiles, 0,
-                                                                               batch_ctx().stride);
+                                                                               batch_ctx().stride, xcd_runs_enabled());
     KERNEL_CHECK();
 }
 
@@ -384,7 +387,7 @@ void launch_hy_conj_mfma(const double* HcT, int ldT, int n_c, const void* Yc, in
     const int64_t pstride = (int64_t)(ceil_div(M, 64) * 64) * ldP;
     const int kc = hym_kslice(D);                            // rows D .. HYM_KS kc of both operands are zero (padded buffers)
     gemm_tn_f64_kernel<<<bgrid(dim3(mtiles * HYM_KS, (N + 63) / 64)), 256, 0, st>>>(HcT, ldT, (const double*)Yc, ldb, kc, Pw, ldP, M, N, mtiles,
-                                                                                    pstride, batch_ctx().stride);
+                                                                                    pstride, batch_ctx().stride, xcd_runs_enabled());
     KERNEL_CHECK();
     hy_combine_kernel<<<bgrid(dim3((unsigned)ceil_div(S, 256), 2 * n_c)), 256, 0, st>>>(Pw, ldP, pstride, 2 * n_c, S, y_cplx ? 1 : 0, (cplx*)out, ldS,
                                                                                       batch_ctx().stride);

@@ -487,13 +487,16 @@ constexpr int SL_DIRS = 4;   // directions per thread
 __global__ void __launch_bounds__(256) synth_ls_kernel(const cplx* __restrict__ Hc, int64_t ldH, int n_c, const cplx* __restrict__ bsc, int nord_pad,
                                                        const double* __restrict__ dir_azi, const double* __restrict__ dir_zen,
                                                        const double* __restrict__ mic_azi, const double* __restrict__ mic_zen, const int* __restrict__ smap,
-                                                       int D, int P, int kb_lo, int kb_hi, cplx* __restrict__ Upart, size_t bstride, size_t gstride) {
-    Hc = boff(Hc, bstride); Upart = boff(Upart, bstride); dir_azi = boff(dir_azi, bstride); dir_zen = boff(dir_zen, bstride);
-    mic_azi = boff(mic_azi, bstride); mic_zen = boff(mic_zen, bstride); smap = boff(smap, bstride); bsc = boff(bsc, gstride);
+                                                       int D, int P, int kb_lo, int kb_hi, cplx* __restrict__ Upart, size_t bstride, size_t gstride, int xcd_runs) {
+    // (every (unit, chunk) workgroup of a lane reads the lane's spectra of the least-squares bins: XCD-aware order, xcd_run_index)
+    unsigned zl = blockIdx.z, bxu = blockIdx.x, byu = blockIdx.y;
+    if (xcd_runs) { unsigned tl; xcd_run_index(tl, zl); byu = tl / gridDim.x; bxu = tl - byu * gridDim.x; }
+    Hc = boffz(Hc, bstride, zl); Upart = boffz(Upart, bstride, zl); dir_azi = boffz(dir_azi, bstride, zl); dir_zen = boffz(dir_zen, bstride, zl);
+    mic_azi = boffz(mic_azi, bstride, zl); mic_zen = boffz(mic_zen, bstride, zl); smap = boffz(smap, bstride, zl); bsc = boffz(bsc, gstride, zl);
     __shared__ __attribute__((aligned(16))) cplx bs[SY_NORD];
     __shared__ cplx red[4][4];
     const int npr = smap[32], nsg = smap[33];
-    const int u = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = (int)bxu, chunk = (int)byu, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (u >= npr + nsg) return;
     const int row = u < npr ? 2 * u : 2 * npr + (u - npr);
     const bool paired = u < npr;
@@ -596,7 +599,7 @@ void launch_synth_ls(const void* Hc, int64_t ldH, int n_c, const void* bsc, int 
     if (kb_hi <= kb_lo) return;
     synth_ls_kernel<<<bgrid(dim3((unsigned)M, (unsigned)synth_ls_chunks(D))), 256, 0, st>>>((const cplx*)Hc, ldH, n_c, (const cplx*)bsc, nord_pad, dir_azi, dir_zen,
                                                                                           mic_azi, mic_zen, smap, D, P, kb_lo, kb_hi, (cplx*)Upart, batch_ctx().stride,
-                                                                                          shared_geometry ? 0 : batch_ctx().stride);
+                                                                                          shared_geometry ? 0 : batch_ctx().stride, xcd_runs_enabled());
     KERNEL_CHECK();
 }
 void launch_synth_rows(const void* U, int nchunks, const void* Pm, const void* Mw, int nOut, int M, int k_lo, int k_hi, int P, void* W, hipStream_t st,
