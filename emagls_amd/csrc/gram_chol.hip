@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(256) gram_mfma_kernel(const T* __restrict__ Yc
 // Gy and into the leading block of R -- no K-split partials (20 MB per design written and read back) and no reduce kernel.
 // The MFMA fragments come from LDS (16 consecutive doubles per k row: conflict free), not from global memory.
 constexpr int GL_KC = 16;          // rows per stage
+constexpr int GL_SB = 8;           // tiles per side of a super-block (the order in which a lane's tiles are taken)
 constexpr int GL_LD = 64 + 16;     // row stride of a stage in doubles (32 banks mod 64: the four k rows of a fragment read tile the banks)
 __global__ void __launch_bounds__(256) gram_lds_kernel(const double* __restrict__ Yc, int64_t ld, int S, int64_t rows, int nbt,
                                                        double* __restrict__ G, double* __restrict__ R, int Sh, size_t bstride, int xcd_runs) {
@@ -113,9 +114,30 @@ __global__ void __launch_bounds__(256) gram_lds_kernel(const double* __restrict_
     Yc = boffz(Yc, bstride, zl); G = boffz(G, bstride, zl); R = boffz(R, bstride, zl);
     __shared__ __attribute__((aligned(16))) double As[2][GL_KC][GL_LD];
     __shared__ __attribute__((aligned(16))) double Bs[2][GL_KC][GL_LD];
-    int ti = 0;
-    while (t >= nbt - ti) { t -= nbt - ti; ++ti; }
-    const int tj = ti + t;
+    // tile order inside a lane: super-blocks of GL_SB x GL_SB tiles over the upper block triangle, row-major inside a super-block.  The
+    // ~100 tiles an XCD runs at a time then share 2 GL_SB panels instead of the 1 + 32 of a tile row (S = 2025: 528 tiles per design, 4.9 GB
+    // per 8-lane launch in row order); up to GL_SB tile rows (config 3: 7) it IS the row order.
+    int ti = 0, tj = 0;
+    {
+        const int nsb = (nbt + GL_SB - 1) / GL_SB;
+        bool found = false;
+        for (int I = 0; I < nsb && !found; ++I) {
+            const int ri = min(GL_SB, nbt - I * GL_SB);
+            for (int J = I; J < nsb && !found; ++J) {
+                const int rj = min(GL_SB, nbt - J * GL_SB);
+                const int cnt = I == J ? ri * (ri + 1) / 2 : ri * rj;
+                if (t >= cnt) { t -= cnt; continue; }
+                if (I == J) {
+                    int a = 0;
+                    while (t >= ri - a) { t -= ri - a; ++a; }
+                    ti = I * GL_SB + a; tj = ti + t;
+                } else {
+                    ti = I * GL_SB + t / rj; tj = J * GL_SB + t % rj;
+                }
+                found = true;
+            }
+        }
+    }
     const bool diag = ti == tj;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;      // the wave's 32 x 32 sub-tile
