@@ -51,3 +51,22 @@ def test_c_shard_plan_equals_the_python_split():
     for r, sjobs in enumerate(shards):
         assert [j for j in range(37) if rank2[j] == r] == sjobs
     assert all(p == 0 for p in pad2)
+
+
+def test_xcd_run_index_is_a_bijection():
+    """The XCD-aware workgroup -> (lane, tile) map of emagls_amd/csrc/common.hpp (xcd_run_index), restated: workgroup L of the dispatch
+    order runs on XCD L % 8 and takes item x q + min(x, r) + L // 8 of the lane-major (lane, tile) list (W = 8 q + r items).  For any
+    tile and lane count it must hit every item exactly once, and the items of one XCD must be a contiguous run."""
+    for nt, lanes in ((28, 1), (28, 16), (28, 20), (28, 32), (528, 8), (21, 5), (96, 3), (1, 1), (7, 9)):
+        W = nt * lanes
+        q, r = divmod(W, 8)
+        seen = {}
+        for L in range(W):
+            x, slot = L % 8, L // 8
+            g = x * q + min(x, r) + slot
+            assert 0 <= g < W
+            seen.setdefault(x, []).append(g)
+        items = sorted(g for v in seen.values() for g in v)
+        assert items == list(range(W))
+        for x, v in seen.items():
+            assert v == list(range(v[0], v[0] + len(v)))   # (in slot order: a contiguous, ascending run)
