@@ -15,6 +15,10 @@ A case above 1e-6 is re-examined, and never counted as ok:
     oracle's are not, the distance is the REFERENCE ARITHMETIC's own rounding error (LAPACK's SVD of the rounded pwGrid) and the case
     counts as 'reference_noise', with both distances printed (round 6; round 5 excused such cases by a factor-100 rule on a
     perturbation probe -- removed);
+  * otherwise, for array designs, the singular values of the reference's FP64 pwGrid in its lowest bins are counted: where some lie below
+    1e-14 of the largest (the noise floor of the FP64 product is 3e-17), the reference weights singular vectors that its own rounding errors
+    decide with 100 / s_max -- such a case counts as 'ill_posed' as well, with the count printed (round 6, after seed 81's case 83: 127 x the
+    drivers' disagreement, 12 of 25 singular values at the noise floor; profiles/r06_fuzz_random.md);
   * anything else is a MISMATCH."""
 import os
 import sys
@@ -204,6 +208,41 @@ def exact_row_probe(case):
     return g, o
 
 
+def noise_rank_probe(case):
+    """For an array design: how many singular values of the reference's FP64 pwGrid lie below 1e-14 of the largest (the FP64 noise floor is
+    3e-17) in its lowest solved bins -- (worst count, channels, bin).  The reference weights the singular vectors of ALL of them with
+    100 / s_max (1 % clipping, lib/getEMagLsFilters.m:96-99): vectors of singular values at the noise floor are decided by the rounding
+    errors of the reference's own matrix product, and no other arithmetic reproduces them."""
+    from emagls_amd import synth
+    from oracle import emagls_oracle as O
+    import shape_cases as SC
+    kind, D, taps, ln, fs, r, M, N, basis = case
+    if kind not in ("emagls", "emagls2", "emainch"):
+        return None
+    azi, zen = synth.fibonacci_grid(D)
+    nfft, f, P, k_cut = O._design_consts(fs, ln, max(O.F_CUT_MIN_FREQ, 500 * N))
+    if kind == "emainch":
+        ma = np.linspace(0, 2 * np.pi, M, endpoint=False) + 0.2
+        smair, simOrder = O.getSMAIRMatrix(N, fs, nfft, r, np.column_stack([ma, np.full(M, np.pi / 2)]), basis, returnRawMicSigs=True)
+        Lp = O.pinv(O.getCH(N, ma, basis))
+    else:
+        ma, mz = SC.mics(M, D + M)
+        raw = kind == "emagls2"
+        smair, simOrder = O.getSMAIRMatrix(O.SMAIR_DEFAULT_ORDER if raw else N, fs, nfft, r, np.column_stack([ma, mz]), basis, returnRawMicSigs=raw)
+        Lp = None
+    Yc = O.getSH(simOrder, np.column_stack([azi, zen]), basis).conj().T
+    worst = (0, 0, 0)
+    for kb in range(1, min(P - 1, 8)):
+        pw = smair[:, :, kb] @ Yc
+        if Lp is not None:
+            pw = Lp @ pw
+        sv = np.linalg.svd(pw, compute_uv=False)
+        n = int((sv < 1e-14 * sv.max()).sum())
+        if n > worst[0]:
+            worst = (n, sv.size, kb + 1)
+    return worst
+
+
 def main():
     from emagls_amd._lib import EmaglsError
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
@@ -237,6 +276,11 @@ def main():
                         extra = f", rows of bins 2-3 against 40-digit arithmetic: GPU {g:.2e}, FP64 oracle {o:.2e}"
                         if g < 1e-9 and o > 10.0 * g:
                             verdict = "reference-noise"
+                if verdict == "MISMATCH":
+                    nr = noise_rank_probe(c)
+                    if nr is not None and nr[0] > 0:
+                        verdict = "ill-posed"
+                        extra += f", {nr[0]} of {nr[1]} singular values of the reference's FP64 pwGrid below 1e-14 s_max in bin {nr[2]} (weighted by 100 / s_max: noise vectors)"
                 tally[{"ill-posed": "ill_posed", "MISMATCH": "mismatch", "reference-noise": "reference_noise"}[verdict]] += 1
                 print(f"case {i} {c} -> {verdict} rel={e:.2e}, oracle gesdd vs gesvd {self_dev:.2e}{extra} ({time.time() - t:.1f} s)", flush=True)
         except EmaglsError as ex:
