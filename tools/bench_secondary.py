@@ -227,6 +227,37 @@ def em64(reps=2):
     return out
 
 
+def plain_paths(reps=2):
+    """The designs of round 6's widened shapes on the plain (launch-per-bin) paths, one at a time, 2702 directions: getEMagLsFiltersEMAinSH of
+    order 6 (49 channels, 20 equatorial microphones, 512 taps: tall Householder kernels), getMagLsFilters of order 15 (256 channels, 512 taps:
+    the loop forms of wide.hip), getLsFilters of order 15."""
+    from emagls_amd import Plan, synth, _lib as L
+    azi, zen, _, _ = _grids()
+    hL, hR = synth.rigid_sphere_hrirs(azi, zen)
+
+    def timed(p):
+        p.set_hrir_grid(azi, zen)
+        p.set_hrirs(hL, hR)
+        for _ in range(2):
+            p.execute()
+        p.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            p.execute()
+            p.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        p.get_filters()
+        p.close()
+        return round(dt * 1e3, 2)
+    out = {}
+    p = Plan(L.KIND_EMA_SH, "real", 6, 48000.0, 512, hL.shape[0], hL.shape[1], 0.05, 20)
+    p.set_mic_grid(np.linspace(0, 2 * np.pi, 20, endpoint=False) + 0.1, None)
+    out["emainsh_order6_ms_per_design"] = timed(p)
+    out["magls_order15_ms_per_design"] = timed(Plan(L.KIND_MAGLS, "real", 15, 48000.0, 512, hL.shape[0], hL.shape[1]))
+    out["ls_order15_ms_per_design"] = timed(Plan(L.KIND_LS, "real", 15, 48000.0, 128, hL.shape[0], hL.shape[1]))
+    return out
+
+
 def config5(reps=4, subjects=8):
     """BASELINE config 5: one HRTF subject alone, and the batch of 8 subjects of one ATF set (ATF side computed once, one
     resident sweep launch for all subjects)."""
@@ -531,6 +562,10 @@ def run():
         out["em64_emagls2"] = em64()
     except Exception as e:
         out["em64_emagls2"] = {"error": repr(e)}
+    try:
+        out["plain_paths"] = plain_paths()
+    except Exception as e:
+        out["plain_paths"] = {"error": repr(e)}
     try:
         out["binaural_decode"] = binaural_decode()
     except Exception as e:
