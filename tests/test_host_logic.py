@@ -70,3 +70,34 @@ def test_xcd_run_index_is_a_bijection():
         assert items == list(range(W))
         for x, v in seen.items():
             assert v == list(range(v[0], v[0] + len(v)))   # (in slot order: a contiguous, ascending run)
+
+
+def test_c_shard_plan_on_a_mixed_list():
+    """emagls_jobs_shard on a list that mixes what a study mixes: an array-radius family (lane batches, laid out for their batch's order), LS and
+    MagLS designs, a 64-capsule design and FromAtf subjects (units of their own).  Every job lands on exactly one rank at a position of its
+    own, only the radius family is padded, and no rank stays empty."""
+    import numpy as np
+    from emagls_amd import _lib as L
+    from emagls_amd.jobs import JobList
+    h = np.zeros((8, 40))
+    azi = np.zeros(40)
+    jl = JobList()
+    fam = []
+    for r in np.linspace(0.03, 0.06, 40):
+        fam.append(jl.add(L.KIND_EMAGLS2, "real", 4, 48000.0, 512, h, h, azi, azi, mic_radius=float(r), mic_azi=np.zeros(32), mic_zen=np.zeros(32), out_shape=(512, 32, False)))
+    other = []
+    for _ in range(6):
+        other.append(jl.add(L.KIND_LS, "real", 4, 48000.0, 8, h, h, azi, azi, out_shape=(8, 25, False)))
+        other.append(jl.add(L.KIND_MAGLS, "complex", 3, 48000.0, 64, h, h, azi, azi, out_shape=(64, 16, True)))
+    other.append(jl.add(L.KIND_EMAGLS2, "real", 4, 48000.0, 512, h, h, azi, azi, mic_radius=0.042, mic_azi=np.zeros(64), mic_zen=np.zeros(64), out_shape=(512, 64, False)))
+    for _ in range(3):
+        other.append(jl.add(L.KIND_FROM_ATF, "real", 0, 48000.0, 256, h, h, azi, azi, atf=1, atf_azi=azi, atf_zen=azi, nmics=8, f_trans=2000.0, out_shape=(256, 8, False)))
+    world = 4
+    rank, pos, pad = jl.shard(world, 16)
+    n = len(jl)
+    assert sorted(set(rank)) == list(range(world))
+    for r in range(world):
+        mine = [j for j in range(n) if rank[j] == r]
+        assert sorted(pos[j] for j in mine) == list(range(len(mine)))
+    assert all(pad[j] == 0 for j in other)
+    assert any(pad[j] > 0 for j in fam)
